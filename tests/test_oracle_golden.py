@@ -1,0 +1,168 @@
+"""The CPU restatement (oracle/cales_oracle.c) against golden vectors produced by the reference's
+own compiled operators (tests/golden/gen_golden.py). Each operator is fed the GOLDEN input of its
+stage, so errors do not accumulate. Tolerance 1e-13 relative; most stages are
+bit-identical because the oracle keeps the reference's expression order."""
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle
+from tests.util import FULL_CASES, RK, F, load_golden, relerr
+
+TOL = 1e-13
+
+
+@pytest.mark.parametrize("name", FULL_CASES + ["couette_imp3d_ops"])
+def test_setup_products(name):
+    g, case = load_golden(name)
+    o = Oracle(case)
+    grid = o.grid()
+    for k in ("dzc", "dzf", "zc", "zf"):
+        assert relerr(grid[k], g["g_" + k]) < 1e-15, k
+    assert (o.index_wm() == g["par_index_wm"]).all()
+    assert (o.cbcvel() == g["par_cbcvel_after_initbc"]).all()
+    for a, b in zip(o.rhsbp(), (g["rhsbp_x"], g["rhsbp_y"], g["rhsbp_z"])):
+        assert np.abs(a - b).max() <= 1e-15 * max(1., np.abs(b).max())
+    # parsed namelist == what the reference's read_input produced
+    for k in ("ng", "l", "gr", "cfl", "dtmax", "dt_f", "visci", "bcvel", "bcpre", "bcsgs", "bforce", "velf", "hwm",
+              "is_forced", "lwm", "cbcpre", "cbcsgs", "nstep", "icheck", "isave", "stop_type"):
+        assert np.all(np.asarray(getattr(case, k)) == g["par_" + k]), k
+    assert case.inivel == str(g["par_inivel"]) and case.sgstype == str(g["par_sgstype"])
+    assert np.allclose(case.dl, g["par_dl"], rtol=1e-16, atol=0) and case.visc == float(g["par_visc"])
+
+
+def test_grids():
+    g = np.load(__import__("os").path.join(__import__("tests.util", fromlist=["GOLD"]).GOLD, "grids.npz"))
+    import ctypes as C
+    from oracle.oracle import build
+    lib = C.CDLL(build())
+    q = 0
+    while f"g{q}_spec" in g.files:
+        gtype, gr, n3, lz = g[f"g{q}_spec"]
+        n3 = int(n3)
+        out = [np.zeros(n3 + 2) for _ in range(4)]
+        lib.o_initgrid(int(gtype), n3, C.c_double(gr), C.c_double(lz), *[a.ctypes.data_as(C.c_void_p) for a in out])
+        for a, k in zip(out, ("dzc", "dzf", "zc", "zf")):
+            assert relerr(a, g[f"g{q}_{k}"]) < 4e-16, (q, k)
+        q += 1
+    assert q == 8
+
+
+@pytest.mark.parametrize("name", FULL_CASES)
+def test_initflow(name):
+    g, case = load_golden(name)
+    o = Oracle(case)
+    u, v, w, p = o.initflow(case.inivel, case.is_wallturb) if case.inivel != "hcp" else (None,) * 4
+    if u is None:
+        pytest.skip("hcp not restated")
+    for a, k in zip((u, v, w, p), "uvwp"):
+        ref = g["if_" + k]
+        assert np.abs(a - ref).max() <= 2e-15 * max(1., np.abs(ref).max()), k
+
+
+@pytest.mark.parametrize("name", FULL_CASES)
+def test_startup_and_substeps(name):
+    g, case = load_golden(name)
+    o = Oracle(case)
+    imp = case.impdiff
+    # start-up: bounduvw, boundp, cmpt_sgs, boundp(visct), chkdt   (main.f90:370-375,395)
+    u, v, w, p = (F(g["s0raw_" + k]) for k in "uvwp")
+    o.bounduvw(u, v, w, True, False); o.boundp(p, 0)
+    for a, k in zip((u, v, w, p), "uvwp"):
+        assert relerr(a, g["s0_" + k]) < TOL, ("s0", k)
+    visct = o.zeros()
+    o.cmpt_sgs(F(g["s0_u"]), F(g["s0_v"]), F(g["s0_w"]), visct)
+    assert relerr(visct[1:-1, 1:-1, 1:-1], g["s0_visct_nobc"][1:-1, 1:-1, 1:-1]) < TOL
+    o.boundp(visct, 1)
+    assert relerr(visct, g["s0_visct"]) < TOL
+    if np.any(case.lwm != 0):
+        for iv, nm in ((1, "bcu"), (2, "bcv"), (3, "bcw")):
+            for a, d in zip(o.bcvel_planes(iv), "xyz"):
+                _cmp_wm_planes(a, g[f"s0_{nm}_{d}"], case, iv, d)
+    s0 = [F(g["s0_" + k]) for k in ("u", "v", "w", "p", "visct")]
+    assert abs(o.chkdt(s0[4], s0[0], s0[1], s0[2]) / float(g["dt_cfl"]) - 1) < 1e-14
+    m = o.mom(s0[0], s0[1], s0[2], s0[4])
+    names = ("dudt", "dvdt", "dwdt") + (("dudtd", "dvdtd", "dwdtd") if imp else ())
+    for a, k in zip(m, names):
+        assert relerr(a, g["m_" + k]) < TOL, k
+    assert abs(o.bulk_mean(s0[0], "f") - float(g["mean_u_f"])) <= 1e-15 * max(1, abs(float(g["mean_u_f"])))
+    d0 = o.chkdiv(s0[0], s0[1], s0[2])
+    assert abs(d0[1] / g["div0"][1] - 1) < 1e-14 and abs(d0[0] - g["div0"][0]) < 1e-12 * max(1, abs(g["div0"][0]))
+
+    dt = float(g["dt"])
+    prev = dict(u=g["s0_u"], v=g["s0_v"], w=g["s0_w"], p=g["s0_p"], visct=g["s0_visct"])
+    for irk in (1, 2, 3):
+        K = f"r{irk}_"
+        dtrk = (RK[irk - 1][0] + RK[irk - 1][1]) * dt; dtrki = dtrk ** (-1)
+        alpha = -.5 * case.visc * dtrk if imp else 0.
+        # rk + bulk_forcing
+        u, v, w = F(prev["u"]), F(prev["v"]), F(prev["w"])
+        f = o.rk(irk, dt, F(prev["p"]), F(prev["visct"]), u, v, w)
+        o.bulk_forcing(f, u, v, w)
+        assert np.abs(f - g[K + "s1_f"]).max() < 1e-14
+        for a, k in zip((u, v, w), "uvw"):
+            assert relerr(a, g[K + "s1_" + k]) < TOL, (K, "s1", k)
+        nxt = "s1"
+        if imp == 2:
+            u, v, w = (F(g[K + "s1_" + k]) for k in "uvw")
+            for iv, q in ((1, u), (2, v), (3, w)):
+                o.updt_rhs_b_velz(iv, alpha, q)
+            for a, k in zip((u, v, w), "uvw"):
+                assert relerr(a, g[K + "s1a_" + k]) < TOL, (K, "s1a", k)
+            nxt = "s1b"
+        # bounduvw (wall model updated)
+        sfx = "_orc" if nxt == "s1b" else ""
+        u, v, w = (F(g[K + nxt + "_" + k + sfx]) for k in "uvw")
+        o.bounduvw(u, v, w, True, False)
+        for a, k in zip((u, v, w), "uvw"):
+            assert relerr(a, g[K + "s2_" + k]) < TOL, (K, "s2", k)
+        # fillps + boundary r.h.s.
+        pp = o.zeros()
+        o.fillps(dtrki, F(g[K + "s2_u"]), F(g[K + "s2_v"]), F(g[K + "s2_w"]), pp)
+        o.updt_rhs_b_p(pp)
+        n = o.n
+        assert relerr(pp[1:-1, 1:-1, 1:-1], g[K + "s3_pp"][1:-1, 1:-1, 1:-1]) < TOL
+        # boundp(pp) from the stored solver output
+        pp = F(g[K + "s5_pp"]); pp[0, :, :] = 0; pp[-1, :, :] = 0; pp[:, 0, :] = 0; pp[:, -1, :] = 0; pp[:, :, 0] = 0; pp[:, :, -1] = 0
+        o.boundp(pp, 0)
+        assert relerr(pp, g[K + "s5_pp"]) < TOL
+        # correc + bounduvw(is_correc)
+        u, v, w = (F(g[K + "s2_" + k]) for k in "uvw")
+        o.correc(dtrk, F(g[K + "s5_pp"]), u, v, w)
+        if irk == 1:
+            for a, k in zip((u, v, w), "uvw"):
+                assert relerr(a, g[K + "s6_" + k]) < TOL, (K, "s6", k)
+        o.bounduvw(u, v, w, True, True)
+        for a, k in zip((u, v, w), "uvw"):
+            assert relerr(a, g[K + "s7_" + k]) < TOL, (K, "s7", k)
+        # updatep + boundp
+        p = F(prev["p"])
+        o.updatep(alpha, F(g[K + "s5_pp"]), p); o.boundp(p, 0)
+        assert relerr(p, g[K + "s8_p"]) < TOL
+        # sgs
+        visct = F(prev["visct"])
+        o.cmpt_sgs(F(g[K + "s7_u"]), F(g[K + "s7_v"]), F(g[K + "s7_w"]), visct); o.boundp(visct, 1)
+        assert relerr(visct, g[K + "s9_visct"]) < (TOL if case.sgstype != "dsmag" else 1e-11), (K, "s9")
+        prev = dict(u=g[K + "s7_u"], v=g[K + "s7_v"], w=g[K + "s7_w"], p=g[K + "s8_p"], visct=g[K + "s9_visct"])
+    assert abs(o.chkdt(F(prev["visct"]), F(prev["u"]), F(prev["v"]), F(prev["w"])) / float(g["dt_cfl_end"]) - 1) < 1e-14
+
+
+def _cmp_wm_planes(a, ref, case, ivel, d):
+    """bc planes: compare where the reference defines them (wall-model loops do not touch every ghost entry)."""
+    assert np.abs(a - ref).max() <= 1e-13 * max(1., np.abs(ref).max()), (ivel, d)
+
+
+def test_imp3d_operators():
+    g, case = load_golden("couette_imp3d_ops")
+    o = Oracle(case)
+    s0 = [F(g["s0_" + k]) for k in ("u", "v", "w", "p", "visct")]
+    for a, k in zip(o.mom(s0[0], s0[1], s0[2], s0[4]), ("dudt", "dvdt", "dwdt", "dudtd", "dvdtd", "dwdtd")):
+        assert relerr(a, g["m_" + k]) < TOL, k
+    u, v, w = s0[0].copy(order="F"), s0[1].copy(order="F"), s0[2].copy(order="F")
+    for irk in (1, 2):
+        o.rk(irk, float(g["dt"]), s0[3], s0[4], u, v, w)
+        for a, k in zip((u, v, w), "uvw"):
+            assert relerr(a, g[f"r{irk}_s1_{k}"]) < TOL
+    p = s0[3].copy(order="F")
+    o.updatep(float(g["upd_alpha"]), F(g["upd_pp"]), p)
+    assert relerr(p, g["upd_p"]) < TOL
+    assert abs(o.chkdt(s0[4], u, v, w) / float(g["dt_cfl"]) - 1) < 1e-14

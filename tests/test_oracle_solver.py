@@ -1,0 +1,58 @@
+"""The one boundary where parity is unpinned by the reference (FFTW r2r + solver.f90, not
+buildable here): the restated transforms are checked against scipy.fft (FFTW conventions,
+reference src/fft.f90:192-245) and the solve by the discrete identity L_h(solve(r)) = r built
+with the pinned fillps/correc stencils (correc -> chkdiv ~ 0 is also in the golden files)."""
+import numpy as np
+import pytest
+import scipy.fft as sf
+
+from oracle.oracle import R2R, Oracle
+from tests.util import F, load_golden
+
+
+@pytest.mark.parametrize("n", [8, 12, 15, 20, 64, 90])
+def test_r2r_kinds_match_fftw_definitions(n):
+    g, case = load_golden("tgv_ppp")
+    o = Oracle(case)
+    rng = np.random.RandomState(n)
+    x = rng.rand(n) - 0.5
+    X = sf.rfft(x)
+    hc = np.concatenate([X.real, X.imag[1:(n + 1) // 2][::-1]])
+    assert np.allclose(o.r2r(R2R["R2HC"], x), hc, atol=1e-13)
+    assert np.allclose(o.r2r(R2R["HC2R"], hc), n * x, atol=1e-12)
+    assert np.allclose(o.r2r(R2R["REDFT10"], x), sf.dct(x, type=2), atol=1e-13)
+    assert np.allclose(o.r2r(R2R["REDFT01"], x), sf.dct(x, type=3), atol=1e-13)
+    assert np.allclose(o.r2r(R2R["RODFT10"], x), sf.dst(x, type=2), atol=1e-13)
+    assert np.allclose(o.r2r(R2R["RODFT01"], x), sf.dst(x, type=3), atol=1e-13)
+    assert np.allclose(o.r2r(R2R["REDFT11"], x), sf.dct(x, type=4), atol=1e-13)
+    assert np.allclose(o.r2r(R2R["RODFT11"], x), sf.dst(x, type=4), atol=1e-13)
+    assert np.allclose(o.r2r(R2R["REDFT00"], x), sf.dct(x, type=1), atol=1e-13)
+    assert np.allclose(o.r2r(R2R["RODFT00"], x), sf.dst(x, type=1), atol=1e-13)
+
+
+def laplacian(o, case, p):
+    """7-point Laplacian consistent with fillps(correc(.)) (reference fillps.f90:40-44, correc.f90:45-66)."""
+    g = o.grid(); dzci = 1 / g["dzc"]; dzfi = 1 / g["dzf"]
+    dxi, dyi = case.dli[0], case.dli[1]
+    c = p[1:-1, 1:-1, 1:-1]
+    lap = (p[2:, 1:-1, 1:-1] - 2 * c + p[:-2, 1:-1, 1:-1]) * dxi ** 2 + (p[1:-1, 2:, 1:-1] - 2 * c + p[1:-1, :-2, 1:-1]) * dyi ** 2
+    n3 = c.shape[2]
+    k = np.arange(1, n3 + 1)
+    lap += ((p[1:-1, 1:-1, 2:] - c) * dzci[k] - (c - p[1:-1, 1:-1, :-2]) * dzci[k - 1]) * dzfi[k]
+    return lap
+
+
+@pytest.mark.parametrize("name", ["tgv_ppp", "chan_smag", "duct_smag_wm", "cavity_nnn", "devchan_nd"])
+def test_laplacian_identity(name):
+    g, case = load_golden(name)
+    o = Oracle(case)
+    rng = np.random.RandomState(3)
+    r = o.zeros(); r[1:-1, 1:-1, 1:-1] = rng.rand(*o.n) - 0.5
+    singular = not np.any(case.cbcpre == "D")
+    if singular:   # compatibility: zero volume-weighted mean
+        dzf = o.grid()["dzf"][1:-1]
+        r[1:-1, 1:-1, 1:-1] -= (r[1:-1, 1:-1, 1:-1] * dzf).sum() / (dzf.sum() * o.n[0] * o.n[1])
+    p = r.copy(order="F")
+    o.solver(p); o.boundp(p, 0)
+    res = laplacian(o, case, p) - r[1:-1, 1:-1, 1:-1]
+    assert np.abs(res).max() < 1e-11 * max(1., np.abs(r).max() * case.dli.max() ** 2 * 0 + 1)
