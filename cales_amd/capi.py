@@ -1,0 +1,103 @@
+"""ctypes binding of libcales_hip.so (C-ABI declared in include/cales.h).
+
+There is no CPU fallback: if the HIP library has not been built, importing the symbols raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcales_hip.so")
+
+SGS = {"none": 0, "smag": 1, "dsmag": 2}
+FIELDS = dict(u=0, v=1, w=2, p=3, pp=4, visct=5, dudt=6, dvdt=7, dwdt=8, dudto=9, dvdto=10, dwdto=11,
+              dudtd=12, dvdtd=13, dwdtd=14)
+
+# every symbol include/cales.h declares (tests/test_capi_symbols.py checks the list against the header)
+SYMBOLS = ["cales_initgrid", "cales_initflow", "cales_check_case", "cales_create", "cales_destroy", "cales_last_error",
+           "cales_sync", "cales_local_size", "cales_upload_state", "cales_download_state", "cales_set_field",
+           "cales_get_field", "cales_get_bcvel", "cales_bounduvw", "cales_boundp", "cales_mom", "cales_rk",
+           "cales_bulk_forcing", "cales_get_forcing", "cales_bulk_mean", "cales_fillps", "cales_updt_rhs_b",
+           "cales_solver", "cales_helmholtz_z", "cales_correc", "cales_updatep", "cales_cmpt_sgs", "cales_chkdt",
+           "cales_chkdiv", "cales_step", "cales_get_dpdl", "cales_profile_enable", "cales_profile_reset",
+           "cales_profile_count", "cales_profile_get", "cales_device_info"]
+
+
+class CalesCase(C.Structure):
+    """struct cales_case of include/cales.h."""
+    _fields_ = [("ng", C.c_int32 * 3), ("l", C.c_double * 3), ("gtype", C.c_int32), ("gr", C.c_double),
+                ("visci", C.c_double), ("cbcvel", C.c_char * 18), ("cbcpre", C.c_char * 6), ("cbcsgs", C.c_char * 6),
+                ("bcvel", C.c_double * 18), ("bcpre", C.c_double * 6), ("bcsgs", C.c_double * 6),
+                ("bforce", C.c_double * 3), ("is_forced", C.c_int32 * 3), ("velf", C.c_double * 3),
+                ("sgstype", C.c_int32), ("lwm", C.c_int32 * 6), ("hwm", C.c_double), ("impdiff", C.c_int32),
+                ("nranks", C.c_int32), ("rank", C.c_int32)]
+
+
+def _chars(a) -> bytes:
+    return "".join(np.asarray(a).ravel(order="F").tolist()).encode()
+
+
+def make_case(case, nranks: int = 1, rank: int = 0) -> CalesCase:
+    """cales_amd.nml.Case -> struct cales_case (Fortran storage order kept)."""
+    p = CalesCase()
+    p.ng[:] = [int(x) for x in case.ng]
+    p.l[:] = [float(x) for x in case.l]
+    p.gtype, p.gr, p.visci = int(case.gtype), float(case.gr), float(case.visci)
+    p.cbcvel, p.cbcpre, p.cbcsgs = _chars(case.cbcvel), _chars(case.cbcpre), _chars(case.cbcsgs)
+    p.bcvel[:] = case.bcvel.ravel(order="F").tolist()
+    p.bcpre[:] = case.bcpre.ravel(order="F").tolist()
+    p.bcsgs[:] = case.bcsgs.ravel(order="F").tolist()
+    p.bforce[:] = case.bforce.tolist()
+    p.is_forced[:] = [int(x) for x in case.is_forced]
+    p.velf[:] = case.velf.tolist()
+    if case.sgstype not in SGS:
+        raise ValueError("ERROR: unknown SGS model" if case.sgstype != "amd" else "ERROR: AMD model not yet implemented")
+    p.sgstype = SGS[case.sgstype]
+    p.lwm[:] = [int(x) for x in case.lwm.ravel(order="F")]
+    p.hwm = float(case.hwm)
+    p.impdiff = int(case.impdiff)
+    p.nranks, p.rank = int(nranks), int(rank)
+    return p
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(make -C cales_amd/csrc). The CaLES hot path has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.cales_last_error.restype = C.c_char_p
+        L.cales_last_error.argtypes = [C.c_void_p]
+        L.cales_create.argtypes = [C.POINTER(CalesCase), C.c_void_p, C.POINTER(C.c_void_p)]
+        dp = C.c_void_p
+        for name, args in {
+            "cales_destroy": [C.c_void_p], "cales_sync": [C.c_void_p], "cales_local_size": [C.c_void_p, dp, dp],
+            "cales_upload_state": [C.c_void_p, dp, dp, dp, dp], "cales_download_state": [C.c_void_p, dp, dp, dp, dp, dp],
+            "cales_set_field": [C.c_void_p, C.c_int, dp], "cales_get_field": [C.c_void_p, C.c_int, dp],
+            "cales_get_bcvel": [C.c_void_p, C.c_int, dp, dp, dp],
+            "cales_bounduvw": [C.c_void_p, C.c_int, C.c_int], "cales_boundp": [C.c_void_p, C.c_int, C.c_int],
+            "cales_mom": [C.c_void_p], "cales_rk": [C.c_void_p, C.c_int, C.c_double], "cales_bulk_forcing": [C.c_void_p],
+            "cales_get_forcing": [C.c_void_p, dp], "cales_bulk_mean": [C.c_void_p, C.c_int, C.c_int, dp],
+            "cales_fillps": [C.c_void_p, C.c_double], "cales_updt_rhs_b": [C.c_void_p], "cales_solver": [C.c_void_p],
+            "cales_helmholtz_z": [C.c_void_p, C.c_int, C.c_double], "cales_correc": [C.c_void_p, C.c_double],
+            "cales_updatep": [C.c_void_p, C.c_double], "cales_cmpt_sgs": [C.c_void_p], "cales_chkdt": [C.c_void_p, dp],
+            "cales_chkdiv": [C.c_void_p, dp, dp], "cales_step": [C.c_void_p, C.c_double], "cales_get_dpdl": [C.c_void_p, dp],
+            "cales_profile_enable": [C.c_void_p, C.c_int], "cales_profile_reset": [C.c_void_p],
+            "cales_profile_count": [C.c_void_p], "cales_profile_get": [C.c_void_p, C.c_int, C.c_char_p, C.c_int, dp, dp],
+            "cales_device_info": [C.c_void_p, C.c_char_p, C.c_int, dp],
+            "cales_initgrid": [C.c_int, C.c_int, C.c_double, C.c_double, dp, dp, dp, dp],
+            "cales_initflow": [C.POINTER(CalesCase), C.c_char_p, C.c_int, dp, dp, dp, dp],
+            "cales_check_case": [C.POINTER(CalesCase), C.c_char_p, C.c_int],
+        }.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = None if name == "cales_destroy" else C.c_int
+        _lib = L
+    return _lib

@@ -1,0 +1,310 @@
+// extern "C" entry points of libcales_hip.so (include/cales.h): context life cycle, host<->device copies,
+// one entry per reference operator, the fused time step (reference src/main.f90:417-508) and the
+// HIP-event kernel timers used by bench.py's roofline line.
+#include "common.hpp"
+
+static thread_local std::string g_create_err;
+
+// ------------------------------------------------------------------------------------------ profiling
+int prof_begin(cales_ctx *c, const char *name) {
+  int slot = -1;
+  for (size_t q = 0; q < c->stats.size(); ++q) if (c->stats[q].name == name) { slot = (int)q; break; }
+  if (slot < 0) { KernelStat s; s.name = name; c->stats.push_back(s); slot = (int)c->stats.size() - 1; }
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  if (!c->evpool.empty()) { ev = c->evpool.back(); c->evpool.pop_back(); }
+  else { hipEventCreate(&ev.first); hipEventCreate(&ev.second); }
+  hipEventRecord(ev.first, c->stream);
+  c->pending.push_back({slot, ev});
+  return (int)c->pending.size() - 1;
+}
+void prof_end(cales_ctx *c, int idx) { hipEventRecord(c->pending[idx].second.second, c->stream); }
+void prof_flush(cales_ctx *c) {
+  if (c->pending.empty()) return;
+  hipStreamSynchronize(c->stream);
+  for (auto &pe : c->pending) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, pe.second.first, pe.second.second);
+    c->stats[pe.first].calls += 1; c->stats[pe.first].ms += ms;
+    c->evpool.push_back(pe.second);
+  }
+  c->pending.clear();
+}
+
+// ------------------------------------------------------------------------------------------ helpers
+static int dev_alloc(cales_ctx *c, double **p, size_t n, bool zero = true) {
+  HIPCHK(c, hipMalloc(p, (n ? n : 1) * sizeof(double)));
+  if (zero) HIPCHK(c, hipMemset(*p, 0, (n ? n : 1) * sizeof(double)));
+  return 0;
+}
+static int upload_vec(cales_ctx *c, double **p, const std::vector<double> &v) {
+  if (dev_alloc(c, p, v.size(), false)) return 1;
+  HIPCHK(c, hipMemcpy(*p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+static int upload_bound(cales_ctx *c, DBound &b, std::vector<double> h[3]) {
+  return upload_vec(c, &b.x, h[0]) || upload_vec(c, &b.y, h[1]) || upload_vec(c, &b.z, h[2]);
+}
+static void free_bound(DBound &b) { hipFree(b.x); hipFree(b.y); hipFree(b.z); }
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------------ host-only helpers
+int cales_initgrid(int gtype, int n, double gr, double lz, double *dzc, double *dzf, double *zc, double *zf) {
+  if (n < 1 || !dzc || !dzf || !zc || !zf) return 1;
+  hs_initgrid(gtype, n, gr, lz, dzc, dzf, zc, zf);
+  return 0;
+}
+int cales_initflow(const cales_case *cs, const char *inivel, int is_wallturb, double *u, double *v, double *w, double *p) {
+  if (!cs || !inivel || !u || !v || !w || !p) return 1;
+  return hs_initflow(cs, inivel, is_wallturb, u, v, w, p);
+}
+int cales_check_case(const cales_case *cs, char *msg, int msglen) {
+  std::string m;
+  const int rc = hs_check_case(cs, m);
+  if (msg && msglen > 0) { std::snprintf(msg, msglen, "%s", m.c_str()); }
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------ context
+const char *cales_last_error(const cales_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+void cales_destroy(cales_ctx *c) {
+  if (!c) return;
+  hipStreamSynchronize(c->stream);
+  prof_flush(c);
+  for (auto &ev : c->evpool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+  solver_teardown(c);
+  for (int q = 0; q < CALES_NFIELDS; ++q) hipFree(c->f[q]);
+  hipFree(c->d_dzc); hipFree(c->d_dzf); hipFree(c->d_zc); hipFree(c->d_zf); hipFree(c->d_dzci); hipFree(c->d_dzfi); hipFree(c->d_gvr_c); hipFree(c->d_gvr_f);
+  DBound *bs[11] = {&c->bcu, &c->bcv, &c->bcw, &c->bcp, &c->bcs, &c->bcuf, &c->bcvf, &c->bcwf, &c->bcu_mag, &c->bcv_mag, &c->bcw_mag};
+  for (auto *b : bs) free_bound(*b);
+  for (int d = 0; d < 3; ++d) hipFree(c->rhsbp[d]);
+  hipFree(c->scr1); hipFree(c->scr2); hipFree(c->d_red); hipFree(c->d_force); hipHostFree(c->h_red);
+  hipFree(c->s0); hipFree(c->uc); hipFree(c->vc); hipFree(c->wc); hipFree(c->uf); hipFree(c->vf); hipFree(c->wf); hipFree(c->alph2); hipFree(c->d_p1d);
+  for (int m = 0; m < 6; ++m) { hipFree(c->wk[m]); hipFree(c->sij[m]); hipFree(c->mij[m]); }
+  if (c->own_stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int cales_create(const cales_case *cs, void *stream, cales_ctx **out) {
+  if (!cs || !out) { g_create_err = "null argument"; return 1; }
+  *out = nullptr;
+  std::string msg;
+  if (hs_check_case(cs, msg)) { g_create_err = msg; return 2; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_err = "no HIP device: the CaLES hot path has no CPU fallback"; return 3; }
+  cales_ctx *c = new cales_ctx();
+  c->C = *cs;
+  // zero all device pointers
+  for (auto &p : c->f) p = nullptr;
+  c->d_dzc = c->d_dzf = c->d_zc = c->d_zf = c->d_dzci = c->d_dzfi = c->d_gvr_c = c->d_gvr_f = nullptr;
+  DBound *bs[11] = {&c->bcu, &c->bcv, &c->bcw, &c->bcp, &c->bcs, &c->bcuf, &c->bcvf, &c->bcwf, &c->bcu_mag, &c->bcv_mag, &c->bcw_mag};
+  for (auto *b : bs) b->x = b->y = b->z = nullptr;
+  for (int d = 0; d < 3; ++d) { c->rhsbp[d] = nullptr; c->d_av[d] = c->d_bv[d] = c->d_cv[d] = nullptr; }
+  c->rhsbz_vel = c->d_lamx = c->d_lamy = c->d_a = c->d_b = c->d_c = c->d_twx = c->d_twy = c->d_twx_post = c->d_twy_post = nullptr;
+  c->scr1 = c->scr2 = c->d_red = c->h_red = c->d_force = nullptr;
+  c->s0 = c->uc = c->vc = c->wc = c->uf = c->vf = c->wf = c->alph2 = c->d_p1d = nullptr;
+  for (int m = 0; m < 6; ++m) c->wk[m] = c->sij[m] = c->mij[m] = nullptr;
+  c->sgs_first = true;
+  auto fail = [&](int rc) { g_create_err = c->err; cales_destroy(c); return rc; };
+  if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+  else { c->own_stream = true; if (hipStreamCreate(&c->stream) != hipSuccess) { c->own_stream = false; c->stream = 0; c->err = "hipStreamCreate failed"; return fail(4); } }
+  // geometry: y-slab of rank `rank`
+  const int P = cs->nranks, r = cs->rank;
+  c->n[0] = cs->ng[0]; c->n[1] = cs->ng[1] / P; c->n[2] = cs->ng[2];
+  c->lo[0] = 1; c->lo[1] = r * c->n[1] + 1; c->lo[2] = 1;
+  for (int d = 0; d < 3; ++d) { c->dl[d] = cs->l[d] / (double)(1.f * (float)cs->ng[d]); c->dli[d] = 1. / c->dl[d]; }   // param.f90:153-154
+  c->visc = 1. / cs->visci;
+  Geom &g = c->g;
+  g.n1 = c->n[0]; g.n2 = c->n[1]; g.n3 = c->n[2]; g.s1 = g.n1 + 2; g.s12 = (long)(g.n1 + 2) * (g.n2 + 2); g.jlo = c->lo[1] - 1; g.ng2 = cs->ng[1];
+  c->ntot = (size_t)g.s12 * (g.n3 + 2);
+  const int n3 = c->n[2];
+  // z grid and metrics (main.f90:246-285)
+  c->dzc.resize(n3 + 2); c->dzf.resize(n3 + 2); c->zc.resize(n3 + 2); c->zf.resize(n3 + 2);
+  c->dzci.resize(n3 + 2); c->dzfi.resize(n3 + 2); c->gvr_c.resize(n3 + 2); c->gvr_f.resize(n3 + 2);
+  hs_initgrid(cs->gtype, n3, cs->gr, cs->l[2], c->dzc.data(), c->dzf.data(), c->zc.data(), c->zf.data());
+  for (int k = 0; k <= n3 + 1; ++k) {
+    c->dzci[k] = 1. / c->dzc[k]; c->dzfi[k] = 1. / c->dzf[k];
+    c->gvr_c[k] = c->dl[0] * c->dl[1] * c->dzc[k] / (cs->l[0] * cs->l[1] * cs->l[2]);
+    c->gvr_f[k] = c->dl[0] * c->dl[1] * c->dzf[k] / (cs->l[0] * cs->l[1] * cs->l[2]);
+  }
+  if (upload_vec(c, &c->d_dzc, c->dzc) || upload_vec(c, &c->d_dzf, c->dzf) || upload_vec(c, &c->d_zc, c->zc) || upload_vec(c, &c->d_zf, c->zf) ||
+      upload_vec(c, &c->d_dzci, c->dzci) || upload_vec(c, &c->d_dzfi, c->dzfi) || upload_vec(c, &c->d_gvr_c, c->gvr_c) || upload_vec(c, &c->d_gvr_f, c->gvr_f))
+    return fail(5);
+  // which faces are physical boundaries of this slab (initmpi.f90:201-204 for x-pencils; y is the decomposed direction)
+  c->is_bound[0] = c->is_bound[1] = 1;
+  { const bool per_y = cs->cbcpre[2] == 'P' && cs->cbcpre[3] == 'P';
+    c->is_bound[2] = (!per_y && r == 0) ? 1 : 0; c->is_bound[3] = (!per_y && r == P - 1) ? 1 : 0;
+    const bool per_z = cs->cbcpre[4] == 'P' && cs->cbcpre[5] == 'P';
+    c->is_bound[4] = c->is_bound[5] = per_z ? 0 : 1; }
+  // boundary-condition tables (bound.f90:726-867)
+  std::vector<double> hb[11][3];
+  hs_initbc(c, hb);
+  for (int q = 0; q < 11; ++q) if (upload_bound(c, *bs[q], hb[q])) return fail(6);
+  // pressure boundary r.h.s. (main.f90:317, bound.f90:447-499)
+  { const int *n = c->n;
+    const double dx01[2] = {c->dl[0], c->dl[0]}, dy01[2] = {c->dl[1], c->dl[1]};
+    const double dzc01[2] = {c->dzc[0], c->dzc[n3]}, dzf01[2] = {c->dzf[1], c->dzf[n3]};
+    std::vector<double> rx((size_t)n[1] * n[2] * 2), ry((size_t)n[0] * n[2] * 2), rz((size_t)n[0] * n[1] * 2);
+    hs_bc_rhs(&cs->cbcpre[0], hb[3][0].data(), n[1], n[2], dx01, dx01, 'c', rx.data());
+    hs_bc_rhs(&cs->cbcpre[2], hb[3][1].data(), n[0], n[2], dy01, dy01, 'c', ry.data());
+    hs_bc_rhs(&cs->cbcpre[4], hb[3][2].data(), n[0], n[1], dzc01, dzf01, 'c', rz.data());
+    if (upload_vec(c, &c->rhsbp[0], rx) || upload_vec(c, &c->rhsbp[1], ry) || upload_vec(c, &c->rhsbp[2], rz)) return fail(7); }
+  // fields (haloed); r.h.s. buffers use the same layout so every kernel shares one index
+  const int nfields = cs->impdiff ? CALES_NFIELDS : CALES_DUDTD;
+  for (int q = 0; q < nfields; ++q) if (dev_alloc(c, &c->f[q], c->ntot)) return fail(8);
+  if (dev_alloc(c, &c->scr1, c->ntot) || dev_alloc(c, &c->scr2, c->ntot)) return fail(9);
+  c->red_blocks = 8;
+  if (dev_alloc(c, &c->d_red, 64 + 16 * (size_t)(n3 + 2) + 4 * (size_t)(n3 + 2)) || dev_alloc(c, &c->d_force, 8)) return fail(10);
+  if (hipHostMalloc((void **)&c->h_red, 64 * sizeof(double)) != hipSuccess) { c->err = "hipHostMalloc failed"; return fail(11); }
+  // sgs scratch (sgs.f90:70-83,154-171)
+  for (int d = 1; d <= 3; ++d) for (int s = 0; s <= 1; ++s) c->is_wall[s + 2 * (d - 1)] = (ISB(c, s, d) && CBV(c, s, d, d) == 'D') ? 1. : 0.;
+  // wall flags are global properties of the case, not of the slab (distances use global indices)
+  for (int s = 0; s <= 1; ++s) c->is_wall[s + 2] = (!(cs->cbcpre[2] == 'P' && cs->cbcpre[3] == 'P') && CBV(c, s, 2, 2) == 'D') ? 1. : 0.;
+  if (cs->sgstype >= 1) {
+    if (dev_alloc(c, &c->s0, c->ntot)) return fail(12);
+    const int nw = cs->sgstype == 1 ? 3 : 6;
+    for (int m = 0; m < nw; ++m) if (dev_alloc(c, &c->wk[m], c->ntot)) return fail(12);
+  }
+  if (cs->sgstype == 2) {
+    if (dev_alloc(c, &c->uc, c->ntot) || dev_alloc(c, &c->vc, c->ntot) || dev_alloc(c, &c->wc, c->ntot) || dev_alloc(c, &c->uf, c->ntot) ||
+        dev_alloc(c, &c->vf, c->ntot) || dev_alloc(c, &c->wf, c->ntot) || dev_alloc(c, &c->alph2, c->ntot) || dev_alloc(c, &c->d_p1d, 2 * (size_t)n3 + 2))
+      return fail(13);
+    for (int m = 0; m < 6; ++m) if (dev_alloc(c, &c->sij[m], c->ntot) || dev_alloc(c, &c->mij[m], c->ntot)) return fail(13);
+  }
+  if (solver_setup(c)) return fail(14);
+  if (hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "sync failed"; return fail(15); }
+  *out = c;
+  return 0;
+}
+
+int cales_sync(cales_ctx *c) { HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
+int cales_local_size(const cales_ctx *c, int32_t n[3], int32_t lo[3]) { for (int d = 0; d < 3; ++d) { n[d] = c->n[d]; lo[d] = c->lo[d]; } return 0; }
+
+// ------------------------------------------------------------------------------------------ copies
+int cales_set_field(cales_ctx *c, int field, const double *host) {
+  if (field < 0 || field >= CALES_NFIELDS || !c->f[field]) { c->err = "bad field id"; return 1; }
+  HIPCHK(c, hipMemcpyAsync(c->f[field], host, c->ntot * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+int cales_get_field(cales_ctx *c, int field, double *host) {
+  if (field < 0 || field >= CALES_NFIELDS || !c->f[field]) { c->err = "bad field id"; return 1; }
+  HIPCHK(c, hipMemcpyAsync(host, c->f[field], c->ntot * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+int cales_upload_state(cales_ctx *c, const double *u, const double *v, const double *w, const double *p) {
+  return cales_set_field(c, CALES_U, u) || cales_set_field(c, CALES_V, v) || cales_set_field(c, CALES_W, w) || cales_set_field(c, CALES_P, p);
+}
+int cales_download_state(cales_ctx *c, double *u, double *v, double *w, double *p, double *visct) {
+  if (u && cales_get_field(c, CALES_U, u)) return 1;
+  if (v && cales_get_field(c, CALES_V, v)) return 1;
+  if (w && cales_get_field(c, CALES_W, w)) return 1;
+  if (p && cales_get_field(c, CALES_P, p)) return 1;
+  if (visct && cales_get_field(c, CALES_VISCT, visct)) return 1;
+  return 0;
+}
+int cales_get_bcvel(cales_ctx *c, int ivel, double *x, double *y, double *z) {
+  const DBound &b = ivel == 1 ? c->bcu : ivel == 2 ? c->bcv : c->bcw; const int *n = c->n;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(x, b.x, sizeof(double) * (size_t)(n[1] + 2) * (n[2] + 2) * 2, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(y, b.y, sizeof(double) * (size_t)(n[0] + 2) * (n[2] + 2) * 2, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(z, b.z, sizeof(double) * (size_t)(n[0] + 2) * (n[1] + 2) * 2, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ operators
+int cales_bounduvw(cales_ctx *c, int is_updt_wm, int is_correc) {
+  return op_bounduvw(c, c->bcu, c->bcv, c->bcw, is_updt_wm, is_correc, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W]);
+}
+int cales_boundp(cales_ctx *c, int field, int which) {
+  if (field < 0 || field >= CALES_NFIELDS || !c->f[field]) { c->err = "bad field id"; return 1; }
+  return op_boundp(c, c->f[field], which);
+}
+int cales_mom(cales_ctx *c) { return op_mom(c); }
+int cales_rk(cales_ctx *c, int irk, double dt) { if (irk < 1 || irk > 3) { c->err = "irk must be 1..3"; return 1; } return op_rk(c, irk, dt); }
+int cales_bulk_forcing(cales_ctx *c) { return op_bulk_forcing(c); }
+int cales_get_forcing(cales_ctx *c, double f[3]) {
+  HIPCHK(c, hipMemcpyAsync(c->h_red + 32, c->d_force, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int q = 0; q < 3; ++q) f[q] = c->h_red[32 + q];
+  return 0;
+}
+int cales_bulk_mean(cales_ctx *c, int field, int c_or_f, double *mean) {
+  if (field < 0 || field >= CALES_NFIELDS || !c->f[field]) { c->err = "bad field id"; return 1; }
+  if (int e = op_bulk_mean_dev(c, c->f[field], c_or_f, c->d_red + 16)) return e;
+  HIPCHK(c, hipMemcpyAsync(c->h_red + 16, c->d_red + 16, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *mean = c->h_red[16];
+  return 0;
+}
+int cales_fillps(cales_ctx *c, double dtrki) { return op_fillps(c, dtrki); }
+int cales_updt_rhs_b(cales_ctx *c) { return op_updt_rhs_b(c); }
+int cales_solver(cales_ctx *c) { return op_solver(c); }
+int cales_helmholtz_z(cales_ctx *c, int ivel, double alpha) { if (ivel < 1 || ivel > 3) { c->err = "ivel must be 1..3"; return 1; } return op_helmholtz_z(c, ivel, alpha); }
+int cales_correc(cales_ctx *c, double dtrk) { return op_correc(c, dtrk); }
+int cales_updatep(cales_ctx *c, double alpha) { return op_updatep(c, alpha); }
+int cales_cmpt_sgs(cales_ctx *c) { return op_cmpt_sgs(c); }
+int cales_chkdt(cales_ctx *c, double *dtmax) { return op_chkdt(c, dtmax); }
+int cales_chkdiv(cales_ctx *c, double *divtot, double *divmax) { return op_chkdiv(c, divtot, divmax); }
+
+// ------------------------------------------------------------------------------------------ time step (main.f90:412-508)
+__global__ void k_zero6(double *f) { if (threadIdx.x < 6) f[threadIdx.x] = 0.; }
+
+int cales_step(cales_ctx *c, double dt) {
+  static const double rk[3][2] = {{32. / 60., 0.}, {25. / 60., -17. / 60.}, {45. / 60., -25. / 60.}};
+  hipLaunchKernelGGL(k_zero6, dim3(1), dim3(64), 0, c->stream, c->d_force);     // dpdl(:) = 0
+  for (int irk = 1; irk <= 3; ++irk) {
+    const double dtrk = (rk[irk - 1][0] + rk[irk - 1][1]) * dt, dtrki = 1. / dtrk;
+    double alpha = 0.;
+    if (int e = op_rk(c, irk, dt)) return e;
+    if (int e = op_bulk_forcing(c)) return e;
+    if (c->C.impdiff == 2) {
+      alpha = -.5 * c->visc * dtrk;
+      for (int iv = 1; iv <= 3; ++iv) if (int e = op_helmholtz_z(c, iv, alpha)) return e;
+    }
+    if (int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 0, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W])) return e;
+    if (int e = op_fillps(c, dtrki)) return e;
+    if (int e = op_updt_rhs_b(c)) return e;
+    if (int e = op_solver(c)) return e;
+    if (int e = op_boundp(c, c->f[CALES_PP], 0)) return e;
+    if (int e = op_correc(c, dtrk)) return e;
+    if (int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 1, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W])) return e;
+    if (int e = op_updatep(c, alpha)) return e;
+    if (int e = op_boundp(c, c->f[CALES_P], 0)) return e;
+    if (int e = op_cmpt_sgs(c)) return e;
+    if (int e = op_boundp(c, c->f[CALES_VISCT], 1)) return e;
+  }
+  c->h_red[40] = dt;
+  return 0;
+}
+int cales_get_dpdl(cales_ctx *c, double dpdl[3]) {
+  HIPCHK(c, hipMemcpyAsync(c->h_red + 32, c->d_force, 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const double dti = 1. / c->h_red[40];
+  for (int q = 0; q < 3; ++q) dpdl[q] = -c->h_red[35 + q] * dti;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ measurement
+int cales_profile_enable(cales_ctx *c, int on) { prof_flush(c); c->prof = on != 0; return 0; }
+int cales_profile_reset(cales_ctx *c) { prof_flush(c); c->stats.clear(); return 0; }
+int cales_profile_count(cales_ctx *c) { prof_flush(c); return (int)c->stats.size(); }
+int cales_profile_get(cales_ctx *c, int idx, char *name, int namelen, int64_t *calls, double *total_ms) {
+  prof_flush(c);
+  if (idx < 0 || idx >= (int)c->stats.size()) return 1;
+  if (name && namelen > 0) std::snprintf(name, namelen, "%s", c->stats[idx].name.c_str());
+  if (calls) *calls = c->stats[idx].calls;
+  if (total_ms) *total_ms = c->stats[idx].ms;
+  return 0;
+}
+int cales_device_info(cales_ctx *c, char *name, int namelen, int64_t *hbm_bytes) {
+  hipDeviceProp_t p; int dev = 0;
+  HIPCHK(c, hipGetDevice(&dev)); HIPCHK(c, hipGetDeviceProperties(&p, dev));
+  if (name && namelen > 0) std::snprintf(name, namelen, "%s (%s)", p.name, p.gcnArchName);
+  if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+  return 0;
+}
+
+}  // extern "C"

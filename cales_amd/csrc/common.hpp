@@ -1,0 +1,127 @@
+// Internal definitions shared by the HIP translation units of libcales_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <string>
+#include <vector>
+#include "../../include/cales.h"
+
+#define CALES_EPS 2.220446049250313e-16     /* epsilon(1._rp), reference src/param.f90:20 */
+#define CALES_BIG 1.7976931348623157e308    /* huge(1._rp), src/param.f90:25 */
+
+struct Geom {              // passed by value to kernels
+  int n1, n2, n3;          // local interior sizes
+  int s1;                  // n1+2
+  long s12;                // (n1+2)*(n2+2)
+  int jlo;                 // global index offset of local row j=1 is jlo+1 (y-slab)
+  int ng2;                 // global n2
+  __host__ __device__ inline size_t ix(int i, int j, int k) const { return (size_t)i + (size_t)s1 * (size_t)j + (size_t)s12 * (size_t)k; }
+};
+
+struct DBound { double *x, *y, *z; };   // device BC planes (0:na+1,0:nb+1,0:1), reference src/typedef.f90:10-14
+
+struct KernelStat { std::string name; int64_t calls = 0; double ms = 0.; };
+
+struct cales_ctx {
+  cales_case C;
+  Geom g;
+  int n[3], lo[3];
+  double dl[3], dli[3], visc;
+  hipStream_t stream; bool own_stream;
+  std::string err;
+  // host copies of the grid
+  std::vector<double> dzc, dzf, zc, zf, dzci, dzfi, gvr_c, gvr_f;
+  char cbcvel[18];
+  int is_bound[6], index_wm[6];
+  // device grid (0:n3+1)
+  double *d_dzc, *d_dzf, *d_zc, *d_zf, *d_dzci, *d_dzfi, *d_gvr_c, *d_gvr_f;
+  // fields
+  double *f[CALES_NFIELDS];
+  size_t ntot;
+  // BC planes
+  DBound bcu, bcv, bcw, bcp, bcs, bcuf, bcvf, bcwf, bcu_mag, bcv_mag, bcw_mag;
+  double *rhsbp[3];        // (na,nb,0:1)
+  double *rhsbz_vel;       // scratch (n1,n2,0:1) for z-implicit Helmholtz r.h.s.
+  // solver
+  double *d_lamx, *d_lamy;     // eigenvalues per stored spectral index
+  double *d_a, *d_b, *d_c;     // tridiagonal (n3)
+  double *d_av[3], *d_bv[3], *d_cv[3];
+  double normfft;
+  int xkind, ykind;            // 0: periodic (r2c / c2c), 1: Neumann-Neumann cell-centred (DCT-II/III)
+  double *d_twx, *d_twy;       // twiddle tables
+  double *d_twx_post, *d_twy_post;
+  double *scr1, *scr2;         // solver scratch (haloed size)
+  // reductions
+  double *d_red; double *h_red;       // partial sums / results (pinned host)
+  double *d_force;                    // f(3) + dpdl(3) accumulators on device
+  int red_blocks;
+  // sgs scratch
+  double *s0, *wk[6], *sij[6], *mij[6], *uc, *vc, *wc, *uf, *vf, *wf, *alph2, *d_p1d;
+  double is_wall[6];
+  bool sgs_first;
+  // profiling
+  bool prof = false;
+  std::vector<KernelStat> stats;
+  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> evpool;
+};
+
+#define CBV(c, side, dir, vel) ((c)->cbcvel[(side) + 2 * ((dir) - 1) + 6 * ((vel) - 1)])
+#define CBP(c, side, dir) ((c)->C.cbcpre[(side) + 2 * ((dir) - 1)])
+#define CBS(c, side, dir) ((c)->C.cbcsgs[(side) + 2 * ((dir) - 1)])
+#define LWM(c, side, dir) ((c)->C.lwm[(side) + 2 * ((dir) - 1)])
+#define ISB(c, side, dir) ((c)->is_bound[(side) + 2 * ((dir) - 1)])
+#define IWM(c, side, dir) ((c)->index_wm[(side) + 2 * ((dir) - 1)])
+
+#define HIPCHK(ctx, call)                                                                          \
+  do {                                                                                             \
+    hipError_t e_ = (call);                                                                        \
+    if (e_ != hipSuccess) {                                                                        \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                              \
+      return 1;                                                                                    \
+    }                                                                                              \
+  } while (0)
+
+// profiling bracket: PROF_BEGIN(ctx,"name"); launch...; PROF_END(ctx)
+int  prof_begin(cales_ctx *c, const char *name);
+void prof_end(cales_ctx *c, int slot);
+void prof_flush(cales_ctx *c);
+struct ProfScope {
+  cales_ctx *c; int slot;
+  ProfScope(cales_ctx *c_, const char *name) : c(c_), slot(c_->prof ? prof_begin(c_, name) : -1) {}
+  ~ProfScope() { if (slot >= 0) prof_end(c, slot); }
+};
+
+// ---- host-side set-up (host_setup.cpp)
+void   hs_initgrid(int gtype, int n, double gr, double lz, double *dzc, double *dzf, double *zc, double *zf);
+void   hs_initbc(cales_ctx *c, std::vector<double> hb[11][3]);
+void   hs_eigenvalues(int n, const char *cbc2, char c_or_f, double *lambda);
+void   hs_tridmatrix(const char *cbc2, int n, const double *dzci, const double *dzfi, char c_or_f, double *a, double *b, double *c);
+int    hs_initflow(const cales_case *cs, const char *inivel, int is_wallturb, double *u, double *v, double *w, double *p);
+int    hs_check_case(const cales_case *cs, std::string &msg);
+void   hs_bc_rhs(const char *cbc2, const double *bc, int na, int nb, const double *dlc, const double *dlf, char c_or_f, double *rhs);
+
+// ---- device operators (k_*.hip); all asynchronous on c->stream
+int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm, int is_correc, double *u, double *v, double *w);
+int op_boundp(cales_ctx *c, double *p, int which);
+int op_mom(cales_ctx *c);
+int op_rk(cales_ctx *c, int irk, double dt);
+int op_bulk_forcing(cales_ctx *c);
+int op_bulk_mean_dev(cales_ctx *c, const double *p, int c_or_f, double *d_out);   // result to device scalar
+int op_fillps(cales_ctx *c, double dtrki);
+int op_updt_rhs_b(cales_ctx *c);
+int op_solver(cales_ctx *c);
+int op_helmholtz_z(cales_ctx *c, int ivel, double alpha);
+int op_correc(cales_ctx *c, double dtrk);
+int op_updatep(cales_ctx *c, double alpha);
+int op_cmpt_sgs(cales_ctx *c);
+int op_chkdt(cales_ctx *c, double *dtmax);
+int op_chkdiv(cales_ctx *c, double *divtot, double *divmax);
+int solver_setup(cales_ctx *c);
+void solver_teardown(cales_ctx *c);
+
+static inline dim3 grid3(int nx, int ny, int nz, dim3 b) { return dim3((nx + b.x - 1) / b.x, (ny + b.y - 1) / b.y, (nz + b.z - 1) / b.z); }

@@ -1,0 +1,230 @@
+// Host-side set-up of the CaLES hot path: z grid, boundary-condition tables, solver operands,
+// deterministic initial fields, input checks. Pure C++ (no device code); exported through the
+// C-ABI (api.hip) so that a Fortran or Python host gets the same numbers.
+//
+// Fortran default-real (single precision) literals of the reference are reproduced where they
+// change the value: the golden vectors in tests/golden come from the reference itself.
+#include "common.hpp"
+
+static const double kPi = std::acos(-1.0);
+
+// ---------------------------------------------------------------- src/initgrid.f90:83-196
+static double stretch(int gtype, int kg, int nzg, double alpha, double z0) {
+  switch (gtype) {
+  case 2: return alpha != 0. ? 1.0 * (1. + std::tanh((z0 - 1.0) * alpha) / std::tanh(alpha / 1.)) : z0;
+  case 3: return alpha != 0. ? 1. - 1.0 * (1. + std::tanh((1. - z0 - 1.0) * alpha) / std::tanh(alpha / 1.)) : z0;
+  case 4:
+    if (alpha == 0.) return z0;
+    return z0 <= 0.5 ? 0.5 * (1. - 1. + std::tanh(2. * alpha * (z0 - 0.)) / std::tanh(alpha))
+                     : 0.5 * (1. + 1. + std::tanh(2. * alpha * (z0 - 1.)) / std::tanh(alpha));
+  case 5: {   // Pirozzoli & Orlandi 'natural' stretching
+    const double kb = 32., al = kPi / 1.5, c_eta = 0.8, dyp = 0.05;
+    const double nh = nzg / 2., rn = nh / kb;
+    const double retau = 1. / (1. + rn * rn) * (dyp * nh + std::pow(3. / 4. * al * c_eta * nh, 4. / 3.) * (rn * rn));
+    const double k = 1. * std::min(kg, nzg - kg), rk = k / kb;
+    double z = 1. / (1. + rk * rk) * (dyp * k + std::pow(3. / 4. * al * c_eta * k, 4. / 3.) * (rk * rk)) / (2. * retau);
+    return kg > nzg - kg ? 1. - z : z; }
+  case 6: {   // Larsson's wall-model grid; `dzc = 0.1*32./nzg` is a default-real expression
+    const double dzc = (double)(0.1f * 32.f / (float)nzg);
+    return z0 - (dzc * nzg / 2. - 1.) / (2. * kPi) * std::sin(2. * kPi * z0); }
+  default:    // 1: clustered at both ends
+    return alpha != 0. ? 0.5 * (1. + std::tanh((z0 - 0.5) * alpha) / std::tanh(alpha / 2.)) : z0;
+  }
+}
+
+void hs_initgrid(int gtype, int n, double gr, double lz, double *dzc, double *dzf, double *zc, double *zf) {
+  // src/initgrid.f90:15-81
+  zf[0] = 0.;
+  for (int k = 1; k <= n; ++k) {
+    const double z0 = (double)(((float)k - 0.f) / (1.f * (float)n));   // `(k-0.)/(1.*n)`: default real
+    zf[k] = stretch(gtype, k, n, gr, z0) * lz;
+  }
+  for (int k = 1; k <= n; ++k) dzf[k] = zf[k] - zf[k - 1];
+  dzf[0] = dzf[1]; dzf[n + 1] = dzf[n];
+  for (int k = 0; k <= n; ++k) dzc[k] = .5 * (dzf[k] + dzf[k + 1]);
+  dzc[n + 1] = dzc[n];
+  zc[0] = -dzc[0] / 2.; zf[0] = 0.;
+  for (int k = 1; k <= n + 1; ++k) { zc[k] = zc[k - 1] + dzc[k - 1]; zf[k] = zf[k - 1] + dzf[k]; }
+}
+
+// ---------------------------------------------------------------- src/bound.f90:726-867
+// hb[b][d]: host images of the 11 `bound` objects (order: bcu bcv bcw bcp bcs bcuf bcvf bcwf bcu_mag bcv_mag bcw_mag)
+void hs_initbc(cales_ctx *c, std::vector<double> hb[11][3]) {
+  const int *n = c->n;
+  std::memcpy(c->cbcvel, c->C.cbcvel, 18);
+  for (int idir = 1; idir <= 3; ++idir)
+    for (int s = 0; s <= 1; ++s)
+      if (LWM(c, s, idir) != 0)
+        for (int ivel = 1; ivel <= 3; ++ivel) CBV(c, s, idir, ivel) = (ivel == idir) ? 'D' : 'N';
+  const size_t pl[3] = {(size_t)(n[1] + 2) * (n[2] + 2), (size_t)(n[0] + 2) * (n[2] + 2), (size_t)(n[0] + 2) * (n[1] + 2)};
+  auto fill = [&](int b, const double *v6) {
+    for (int d = 0; d < 3; ++d) {
+      hb[b][d].assign(2 * pl[d], 0.);
+      for (int s = 0; s < 2; ++s) std::fill(hb[b][d].begin() + s * pl[d], hb[b][d].begin() + (s + 1) * pl[d], v6[s + 2 * d]);
+    }
+  };
+  fill(0, &c->C.bcvel[0]); fill(1, &c->C.bcvel[6]); fill(2, &c->C.bcvel[12]);
+  fill(3, c->C.bcpre); fill(4, c->C.bcsgs);
+  for (int b = 0; b < 3; ++b) for (int d = 0; d < 3; ++d) { hb[5 + b][d] = hb[b][d]; hb[8 + b][d] = hb[b][d]; }
+  // wall-model interpolation index = first cell centre at or beyond height h, counted from the wall
+  const double h = c->C.hwm; const double *dl = c->dl; const double *zc = c->zc.data(); const double l3 = c->C.l[2];
+  for (int q = 0; q < 6; ++q) c->index_wm[q] = 0;
+  // x and y planes are rank-local in x; in y the slab owning the wall evaluates with LOCAL row numbers (as the reference)
+  if (ISB(c, 0, 1) && LWM(c, 0, 1) != 0) { int i = 1; while ((i - 0.5) * dl[0] < h) ++i; IWM(c, 0, 1) = i; }
+  if (ISB(c, 1, 1) && LWM(c, 1, 1) != 0) { int i = n[0]; while ((n[0] - i + 0.5) * dl[0] < h) --i; IWM(c, 1, 1) = i; }
+  if (ISB(c, 0, 2) && LWM(c, 0, 2) != 0) { int j = 1; while ((j - 0.5) * dl[1] < h) ++j; IWM(c, 0, 2) = j; }
+  if (ISB(c, 1, 2) && LWM(c, 1, 2) != 0) { int j = n[1]; while ((n[1] - j + 0.5) * dl[1] < h) --j; IWM(c, 1, 2) = j; }
+  if (ISB(c, 0, 3) && LWM(c, 0, 3) != 0) { int k = 1; while (zc[k] < h) ++k; IWM(c, 0, 3) = k; }
+  if (ISB(c, 1, 3) && LWM(c, 1, 3) != 0) { int k = n[2]; while (l3 - zc[k] < h) --k; IWM(c, 1, 3) = k; }
+}
+
+// src/bound.f90:501-560
+void hs_bc_rhs(const char *cbc2, const double *bc, int na, int nb, const double *dlc, const double *dlf, char c_or_f, double *rhs) {
+  const size_t pl = (size_t)(na + 2) * (nb + 2), rl = (size_t)na * nb;
+  for (int s = 0; s <= 1; ++s) {
+    const double sgn = s == 0 ? 1. : -1.;
+    for (int b = 1; b <= nb; ++b) for (int a = 1; a <= na; ++a) {
+      const double v = bc[a + (size_t)(na + 2) * b + s * pl]; double r = 0.;
+      if (c_or_f == 'c') { if (cbc2[s] == 'D') r = -2. * v / dlc[s] / dlf[s]; else if (cbc2[s] == 'N') r = sgn * v / dlf[s]; }
+      else               { if (cbc2[s] == 'D') r = -v / dlc[s] / dlf[s];      else if (cbc2[s] == 'N') r = sgn * v / dlc[s]; }
+      rhs[(a - 1) + (size_t)na * (b - 1) + s * rl] = r;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- src/initsolver.f90:66-169
+void hs_eigenvalues(int n, const char *cbc2, char c_or_f, double *lambda) {
+  const bool pp = cbc2[0] == 'P' && cbc2[1] == 'P', nn = cbc2[0] == 'N' && cbc2[1] == 'N', dd = cbc2[0] == 'D' && cbc2[1] == 'D';
+  for (int l = 1; l <= n; ++l) {
+    double v;
+    if (pp) v = -2. * (1. - std::cos((2 * (l - 1)) * kPi / (1. * n)));
+    else if (nn) v = -2. * (1. - std::cos((l - 1) * kPi / (1. * n)));
+    else if (dd) v = (c_or_f == 'c') ? -2. * (1. - std::cos(l * kPi / (1. * n))) : (l < n ? -2. * (1. - std::cos(l * kPi / (1. * n))) : 0.);
+    else v = -2. * (1. - std::cos((2 * l - 1) * kPi / (2. * n)));
+    lambda[l - 1] = v;
+  }
+}
+void hs_tridmatrix(const char *cbc2, int n, const double *dzci, const double *dzfi, char c_or_f, double *a, double *b, double *c) {
+  for (int k = 1; k <= n; ++k) {
+    if (c_or_f == 'c') { a[k - 1] = dzfi[k] * dzci[k - 1]; c[k - 1] = dzfi[k] * dzci[k]; }
+    else               { a[k - 1] = dzfi[k] * dzci[k];     c[k - 1] = dzfi[k + 1] * dzci[k]; }
+    b[k - 1] = -(a[k - 1] + c[k - 1]);
+  }
+  double factor[2];
+  for (int s = 0; s < 2; ++s) factor[s] = cbc2[s] == 'P' ? 0. : cbc2[s] == 'D' ? -1. : 1.;
+  if (c_or_f == 'c') { b[0] += factor[0] * a[0]; b[n - 1] += factor[1] * c[n - 1]; }
+  else { if (cbc2[0] == 'N') b[0] += factor[0] * a[0]; if (cbc2[1] == 'N') b[n - 1] += factor[1] * c[n - 1]; }
+}
+
+// ---------------------------------------------------------------- src/initflow.f90:17-283
+int hs_initflow(const cales_case *cs, const char *inivel_, int is_wallturb, double *u, double *v, double *w, double *p) {
+  const int n1 = cs->ng[0], n2 = cs->ng[1], n3 = cs->ng[2];
+  const size_t s1 = n1 + 2, s2 = n2 + 2;
+  auto IX = [&](int i, int j, int k) { return (size_t)i + s1 * ((size_t)j + s2 * (size_t)k); };
+  const std::string inivel(inivel_);
+  double dl[3]; for (int d = 0; d < 3; ++d) dl[d] = cs->l[d] / (double)(1.f * (float)cs->ng[d]);
+  const double *l = cs->l; const double visc = 1. / cs->visci, pi = kPi;
+  std::vector<double> dzc(n3 + 2), dzf(n3 + 2), zc(n3 + 2), zf(n3 + 2);
+  hs_initgrid(cs->gtype, n3, cs->gr, l[2], dzc.data(), dzf.data(), zc.data(), zf.data());
+  auto bcvel = [&](int side, int dir, int vel) { return cs->bcvel[side + 2 * (dir - 1) + 6 * (vel - 1)]; };
+  double uref = 1., ubulk = uref; bool is_mean = false, is3d = false;
+  if (cs->is_forced[0]) ubulk = cs->velf[0];
+  std::vector<double> u1d(n3 + 2, 0.);
+  auto poiseuille = [&](double norm) { for (int k = 1; k <= n3; ++k) { const double z = zc[k] / l[2]; u1d[k] = 6. * z * (1. - z) * norm; } };
+  if (inivel == "cou") {
+    uref = bcvel(0, 3, 1) - bcvel(1, 3, 1);
+    for (int k = 1; k <= n3; ++k) { const double z = zc[k] / l[2]; u1d[k] = .5 * (1. - 2. * z) * uref; }
+    uref = std::fabs(uref);
+  } else if (inivel == "poi") { poiseuille(ubulk); is_mean = true;
+  } else if (inivel == "iop") {
+    ubulk = .5 * std::fabs(bcvel(0, 3, 1) + bcvel(1, 3, 1)); poiseuille(ubulk);
+    for (int k = 1; k <= n3; ++k) u1d[k] = u1d[k] - ubulk;
+    is_mean = true;
+  } else if (inivel == "zer") {
+  } else if (inivel == "uni") { for (int k = 1; k <= n3; ++k) u1d[k] = uref;
+  } else if (inivel == "pdc") {
+    const double lref = l[2] / 2.;
+    if (is_wallturb) { uref = std::pow(cs->bforce[0] * lref, 0.5); const double retau = uref * lref / visc, reb = std::pow(retau / .09, 1. / .88); ubulk = reb * visc / (2 * lref); }
+    else ubulk = cs->bforce[0] * (lref * lref) / (3. * visc);
+    poiseuille(ubulk); is_mean = true;
+  } else if (inivel == "tgv") { is3d = true;
+    for (int k = 1; k <= n3; ++k) { const double zcc = zc[k] / l[2] * 2. * pi;
+      for (int j = 1; j <= n2; ++j) { const double yc = (j - .5) * dl[1] / l[1] * 2. * pi, yf = (j - .0) * dl[1] / l[1] * 2. * pi;
+        for (int i = 1; i <= n1; ++i) { const double xc = (i - .5) * dl[0] / l[0] * 2. * pi, xf = (i - .0) * dl[0] / l[0] * 2. * pi; const size_t q = IX(i, j, k);
+          u[q] = std::sin(xf) * std::cos(yc) * std::cos(zcc) * uref; v[q] = -std::cos(xc) * std::sin(yf) * std::cos(zcc) * uref; w[q] = 0.; p[q] = 0.; } } }
+  } else if (inivel == "tgw") { is3d = true;
+    for (int k = 1; k <= n3; ++k) for (int j = 1; j <= n2; ++j) { const double yc = (j - .5) * dl[1], yf = (j - .0) * dl[1];
+      for (int i = 1; i <= n1; ++i) { const double xc = (i - .5) * dl[0], xf = (i - .0) * dl[0]; const size_t q = IX(i, j, k);
+        u[q] = std::cos(xf) * std::sin(yc) * uref; v[q] = -std::sin(xc) * std::cos(yf) * uref; w[q] = 0.;
+        p[q] = -(std::cos(2. * xc) + std::cos(2. * yc)) / 4. * (uref * uref); } }
+  } else if (inivel == "ant") { is3d = true;
+    const double cf = (double)(4.f * std::sqrt(2.f) / 3.f / std::sqrt(3.f));    // default-real constant (initflow.f90:146)
+    for (int k = 1; k <= n3; ++k) { const double zcc = zc[k] / l[2] * 2. * pi + 0.5 * pi, zff = zf[k] / l[2] * 2. * pi + 0.5 * pi;
+      for (int j = 1; j <= n2; ++j) { const double yc = (j - .5) * dl[1] / l[1] * 2. * pi + 0.5 * pi, yf = (j - .0) * dl[1] / l[1] * 2. * pi + 0.5 * pi;
+        for (int i = 1; i <= n1; ++i) { const double xc = (i - .5) * dl[0] / l[0] * 2. * pi + 0.5 * pi, xf = (i - .0) * dl[0] / l[0] * 2. * pi + 0.5 * pi; const size_t q = IX(i, j, k);
+          u[q] = cf * (std::sin(xf - 5. * pi / 6.) * std::cos(yc - 1. * pi / 6.) * std::sin(zcc) - std::sin(xf - 1. * pi / 6.) * std::sin(yc) * std::cos(zcc - 5. * pi / 6.)) * uref;
+          v[q] = cf * (std::sin(xc) * std::sin(yf - 5. * pi / 6.) * std::sin(zcc - 1. * pi / 6.) - std::cos(xc - 5. * pi / 6.) * std::sin(yf - 1. * pi / 6.) * std::sin(zcc)) * uref;
+          w[q] = cf * (std::cos(xc - 1. * pi / 6.) * std::sin(yc) * std::sin(zff - 5. * pi / 6.) - std::sin(xc) * std::cos(yc - 5. * pi / 6.) * std::sin(zff - 1. * pi / 6.)) * uref;
+          p[q] = -(u[q] * u[q] + v[q] * v[q] + w[q] * w[q]) / 2.; } } }
+  } else if (inivel == "duc") { is3d = true; is_mean = true;
+    for (int k = 1; k <= n3; ++k) for (int j = 1; j <= n2; ++j) {
+      double sum_term = 0.; const double ly = .5 * l[1], lz = .5 * l[2], xi = -1. + (j + 1 - 1.5) * dl[1] / ly, eta = -1. + zc[k] / lz;
+      for (int m = 0; m <= 100; ++m) {
+        const double cosh_term = std::cosh((2 * m + 1) * pi * ly / (2 * lz) * xi) / std::cosh((2 * m + 1) * pi * ly / (2 * lz));
+        const double cos_term = std::cos((2 * m + 1) * pi / 2 * eta);
+        const double term = ((m & 1) ? -1. : 1.) / (double)((2 * m + 1) * (2 * m + 1) * (2 * m + 1)) * cosh_term * cos_term;
+        sum_term = sum_term + term;
+      }
+      const double tp = 2. / pi, val = .5 * (lz * lz) * (1. - eta * eta - 4. * (tp * tp * tp) * sum_term);
+      for (int i = 0; i <= n1 + 1; ++i) { const size_t q = IX(i, j, k); u[q] = val; v[q] = 0.; w[q] = 0.; p[q] = 0.; } }
+  } else {
+    return (inivel == "log" || inivel == "hcl" || inivel == "tbl") ? 2 : 1;   // RNG-based kinds are not offered
+  }
+  if (!is3d) for (int k = 1; k <= n3; ++k) for (int j = 1; j <= n2; ++j) for (int i = 1; i <= n1; ++i) {
+    const size_t q = IX(i, j, k); u[q] = u1d[k]; v[q] = 0.; w[q] = 0.; p[q] = 0.; }
+  if (is_mean && inivel != "iop") {   // set_mean, initflow.f90:317-338 (serial sum, one rank)
+    double meanold = 0.;
+    for (int k = 1; k <= n3; ++k) { const double gvr = dzf[k] / l[2] * (dl[0] / l[0]) * (dl[1] / l[1]);
+      for (int j = 1; j <= n2; ++j) for (int i = 1; i <= n1; ++i) meanold = meanold + u[IX(i, j, k)] * gvr; }
+    if (meanold != 0.) for (int k = 1; k <= n3; ++k) for (int j = 1; j <= n2; ++j) for (int i = 1; i <= n1; ++i)
+      u[IX(i, j, k)] = u[IX(i, j, k)] / meanold * ubulk;
+  }
+  if (is_wallturb) {                  // streamwise vortex pair, initflow.f90:218-246
+    for (int k = 1; k <= n3; ++k) { const double zcc = 2. * zc[k] / l[2] - 1., zff = 2. * (zc[k] / l[2] + .5 * dzf[k] / l[2]) - 1.;
+      for (int j = 1; j <= n2; ++j) { const double yc = ((j - 0.5) * dl[1] - .5 * l[1]) * 2. / l[2], yf = ((j - 0.0) * dl[1] - .5 * l[1]) * 2. / l[2];
+        for (int i = 1; i <= n1; ++i) { const double xc = ((i - 0.5) * dl[0] - .5 * l[0]) * 2. / l[2]; const size_t q = IX(i, j, k);
+          const double gxy = xc * std::exp(-4. * (4. * (yf * yf) + xc * xc)), dfz = -4. * zcc * (1. - zcc * zcc);
+          const double fz = (1. - zff * zff) * (1. - zff * zff), dgxy = std::exp(-4. * (4. * (yc * yc) + xc * xc)) * (1. - 8. * (xc * xc));
+          v[q] = -1. * gxy * dfz * ubulk * 1.5; w[q] = 1. * fz * dgxy * ubulk * 1.5; p[q] = 0.; } } }
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- src/sanity.f90:33-274 (rules)
+int hs_check_case(const cales_case *cs, std::string &msg) {
+  auto pr = [&](const char *a, int dir) { return std::string(1, a[0 + 2 * dir]) + std::string(1, a[1 + 2 * dir]); };
+  for (int d = 0; d < 3; ++d) if (cs->ng[d] < 2 || cs->ng[d] % 2) { msg = "ng(:) must be even and >= 2"; return 1; }
+  if (cs->nranks < 1 || cs->ng[1] % cs->nranks || (cs->ng[0] / 2) % 1) { msg = "ng(2) must be divisible by the number of ranks"; return 1; }
+  for (int d = 0; d < 3; ++d) {
+    const std::string bp = pr(cs->cbcpre, d);
+    auto valid = [](const std::string &b) { return b == "PP" || b == "ND" || b == "DN" || b == "NN" || b == "DD"; };
+    for (int ivel = 0; ivel < 3; ++ivel)
+      if (!valid(pr(cs->cbcvel + 6 * ivel, d))) { msg = "velocity BCs not valid (sanity.f90:136-147)"; return 1; }
+    if (!valid(bp)) { msg = "pressure BCs not valid (sanity.f90:150-160)"; return 1; }
+    const std::string bv = pr(cs->cbcvel + 6 * d, d), bs = pr(cs->cbcsgs, d);
+    if (!((bv == "PP" && bp == "PP") || (bv == "ND" && bp == "DN") || (bv == "DN" && bp == "ND") || (bv == "DD" && bp == "NN") || (bv == "NN" && bp == "DD"))) {
+      msg = "velocity and pressure BCs not compatible (sanity.f90:163-175)"; return 1; }
+    if (!valid(bs)) { msg = "sgs BCs not valid (sanity.f90:178-188)"; return 1; }
+    if (!((bv == "PP" && bs == "PP") || (bv != "PP" && bs == "DD"))) { msg = "velocity and sgs BCs not compatible (sanity.f90:191-203)"; return 1; }
+    if (d < 2 && (cs->bcpre[0 + 2 * d] != 0. || cs->bcpre[1 + 2 * d] != 0.)) { msg = "pressure BCs in x and y must be homogeneous"; return 1; }
+    if (cs->is_forced[d] && bp != "PP") { msg = "flow cannot be forced in a non-periodic direction"; return 1; }
+    for (int s = 0; s < 2; ++s) if (cs->lwm[s + 2 * d] != 0)
+      for (int ivel = 0; ivel < 3; ++ivel) if (cs->cbcvel[s + 2 * d + 6 * ivel] != 'D') { msg = "wall-model faces must have Dirichlet velocity BCs (sanity.f90:209-221)"; return 1; }
+  }
+  if (cs->sgstype < 0 || cs->sgstype > 2) { msg = "unknown SGS model"; return 1; }
+  if (cs->impdiff == 1) { msg = "3-D implicit diffusion (_IMPDIFF without _IMPDIFF_1D) is not provided by this build"; return 1; }
+  if (cs->impdiff != 0 && cs->impdiff != 2) { msg = "impdiff must be 0 or 2"; return 1; }
+  // transforms offered in x,y: periodic and cell-centred Neumann-Neumann (what the reference's GPU path offers, sanity.f90:265-273)
+  for (int d = 0; d < 2; ++d) { const std::string bp = pr(cs->cbcpre, d); if (bp != "PP" && bp != "NN") { msg = "pressure BC pair in x/y must be PP or NN on the device path"; return 1; } }
+  return 0;
+}

@@ -1,0 +1,338 @@
+// Ghost-cell kernels: bounduvw / boundp / set_bc (reference src/bound.f90:18-399), the single-rank
+// image of updthalo (src/bound.f90:619-696), updt_rhs_b (src/bound.f90:562-617) and the log-law /
+// laminar wall model (src/wmodel.f90:19-335).
+//
+// The reference issues one tiny `!$acc kernels` region per face and field (39 regions). Here all faces
+// of one direction (up to 3 fields x 2 sides) go into ONE launch; the x -> y -> z order of the
+// reference is kept because corner ghosts depend on it.
+#include "common.hpp"
+
+struct BcJob {
+  double *p;          // field
+  const double *bc;   // plane of side `ibound` (already offset), (0:na+1,0:nb+1)
+  double dr;
+  char ctype;         // 'P','D','N'
+  char centered;
+  char ibound;
+};
+struct BcJobs { int njobs, idir; BcJob job[6]; };
+
+__global__ __launch_bounds__(256) void k_set_bc(Geom g, BcJobs J) {
+  const BcJob jb = J.job[blockIdx.z];
+  const int idir = J.idir;
+  const int na = idir == 1 ? g.n2 : g.n1, nb = idir == 3 ? g.n2 : g.n3, n = idir == 1 ? g.n1 : idir == 2 ? g.n2 : g.n3;
+  const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y;
+  if (a > na + 1 || b > nb + 1) return;
+  const long st = idir == 1 ? 1 : idir == 2 ? (long)g.s1 : g.s12;
+  const size_t base = idir == 1 ? g.ix(0, a, b) : idir == 2 ? g.ix(a, 0, b) : g.ix(a, b, 0);
+  double *p = jb.p + base;
+#define P(m) p[(long)(m)*st]
+  const double bcv = jb.bc ? jb.bc[a + (size_t)(na + 2) * b] : 0.;
+  const double sgn = (jb.ctype == 'D' && jb.centered) ? -1. : 1.;
+  switch (jb.ctype) {
+  case 'P':   // bound.f90:220-248 (one job handles both ends)
+    { const double lo = P(n), hi = P(1); P(0) = lo; P(n + 1) = hi; } break;
+  case 'D':   // bound.f90:249-319
+    if (jb.centered) { if (jb.ibound == 0) P(0) = 2. * bcv + sgn * P(1); else P(n + 1) = 2. * bcv + sgn * P(n); }
+    else { if (jb.ibound == 0) P(0) = bcv; else { P(n + 1) = P(n - 1); P(n) = bcv; } }
+    break;
+  case 'N':   // bound.f90:320-396
+    if (jb.centered) { if (jb.ibound == 0) P(0) = -jb.dr * bcv + sgn * P(1); else P(n + 1) = jb.dr * bcv + sgn * P(n); }
+    else { if (jb.ibound == 0) P(0) = -jb.dr * bcv + P(1); else { P(n + 1) = P(n); P(n) = jb.dr * bcv + P(n - 1); } }
+    break;
+  }
+#undef P
+}
+
+static int launch_jobs(cales_ctx *c, BcJobs &J) {
+  if (J.njobs == 0) return 0;
+  const int na = J.idir == 1 ? c->n[1] : c->n[0], nb = J.idir == 3 ? c->n[1] : c->n[2];
+  dim3 b(64, 4, 1), gr((na + 2 + 63) / 64, (nb + 2 + 3) / 4, J.njobs);
+  hipLaunchKernelGGL(k_set_bc, gr, b, 0, c->stream, c->g, J);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+static inline const double *plane(const DBound &b, int idir, int ibound, const int *n) {
+  const size_t pl = idir == 1 ? (size_t)(n[1] + 2) * (n[2] + 2) : idir == 2 ? (size_t)(n[0] + 2) * (n[2] + 2) : (size_t)(n[0] + 2) * (n[1] + 2);
+  const double *base = idir == 1 ? b.x : idir == 2 ? b.y : b.z;
+  return base + (size_t)ibound * pl;
+}
+static inline void add_job(BcJobs &J, double *p, char ctype, int ibound, int centered, const double *bc, double dr) {
+  BcJob &j = J.job[J.njobs++];
+  j.p = p; j.bc = bc; j.dr = dr; j.ctype = ctype; j.centered = (char)centered; j.ibound = (char)ibound;
+}
+
+// single-rank halo exchange == periodic copy in the non-pencil directions (bound.f90:619-696, nb = self)
+static int halo_self(cales_ctx *c, int nf, double **flds) {
+  for (int idir = 2; idir <= 3; ++idir) {
+    if (ISB(c, 0, idir)) continue;       // not periodic: neighbours are MPI_PROC_NULL
+    BcJobs J; J.njobs = 0; J.idir = idir;
+    for (int q = 0; q < nf; ++q) add_job(J, flds[q], 'P', 0, 1, nullptr, 0.);
+    if (int e = launch_jobs(c, J)) return e;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ boundp (bound.f90:156-200)
+int op_boundp(cales_ctx *c, double *p, int which) {
+  ProfScope ps(c, "boundp");
+  const char *cbc = which == 0 ? c->C.cbcpre : c->C.cbcsgs; const DBound &bc = which == 0 ? c->bcp : c->bcs;
+  double *fl[1] = {p};
+  if (int e = halo_self(c, 1, fl)) return e;
+  for (int idir = 1; idir <= 3; ++idir) {
+    if (!ISB(c, 0, idir)) continue;
+    BcJobs J; J.njobs = 0; J.idir = idir;
+    const double dr0 = idir < 3 ? c->dl[idir - 1] : c->dzc[0], dr1 = idir < 3 ? c->dl[idir - 1] : c->dzc[c->n[2]];
+    const char c0 = cbc[0 + 2 * (idir - 1)], c1 = cbc[1 + 2 * (idir - 1)];
+    if (c0 == 'P') add_job(J, p, 'P', 0, 1, nullptr, 0.);      // both ends in one job (identical result to the two calls)
+    else { add_job(J, p, c0, 0, 1, plane(bc, idir, 0, c->n), dr0); add_job(J, p, c1, 1, 1, plane(bc, idir, 1, c->n), dr1); }
+    if (int e = launch_jobs(c, J)) return e;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ wall model (wmodel.f90:65-335)
+__device__ inline double vel_relative(double v1, double v2, double coef, double mag) {
+  double r = (1. - coef) * v1 + coef * v2;
+  return r - mag;
+}
+__device__ inline void wallmodel(int mtype, double uh, double vh, double h, double l1d, double visc, double &t1, double &t2) {
+  const double kap = 0.41, blog = 5.20;
+  double upar = sqrt(uh * uh + vh * vh), tauw_tot;
+  if (mtype == 1) {
+    double conv = 1., utau = fmax(sqrt(upar / h * visc), visc / h * exp(-kap * blog));
+    while (conv > 0.5e-4) {
+      const double utau_old = utau;
+      const double f = upar / utau - 1. / kap * log(h * utau / visc) - blog;
+      const double fp = -1. / utau * (upar / utau + 1. / kap);
+      utau = fabs(utau - f / fp);
+      conv = fabs(utau / utau_old - 1.);
+    }
+    tauw_tot = utau * utau;
+  } else {
+    const double del = 0.5 * l1d, umax = upar / (h / del * (2. - h / del));
+    tauw_tot = 2. / del * umax * visc;
+  }
+  t1 = tauw_tot * uh / (upar + CALES_EPS); t2 = tauw_tot * vh / (upar + CALES_EPS);
+}
+
+struct WmArgs {
+  int idir, ibound, mtype, i1, i2;   // i1/i2: near / far interpolation index along idir
+  double coef, sgn, h, l1d, visc;
+  const double *u, *v, *w;           // velocity fields
+  double *bc_a, *bc_b;               // planes (side ibound) receiving the first / second tangential component
+  const double *mag_a, *mag_b;       // *_mag planes (side ibound)
+  const double *zc, *zf, *dzc;
+};
+// blockIdx.z = 0: first tangential component loop, 1: second (wmodel.f90:138-153/154-170, 189-204/205-221, 240-255/256-271)
+__global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmArgs A) {
+  const int na = A.idir == 1 ? g.n2 : g.n1, nb = A.idir == 3 ? g.n2 : g.n3;
+  const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y, comp = blockIdx.z;
+  const size_t ld = na + 2;
+  const double visci = 1. / A.visc;
+  double t1, t2;
+#define M(pl, a_, b_) pl[(a_) + ld * (b_)]
+  if (A.idir == 1) {          // wall normal x; a = j, b = k; tangential: v (first), w (second)
+    const int i1 = A.i1, i2 = A.i2;
+    if (comp == 0) {
+      if (a > na || b < 1 || b > nb) return;           // j = 0..n2, k = 1..n3
+      const int j = a, k = b;
+      const double v1 = A.v[g.ix(i1, j, k)], v2 = A.v[g.ix(i2, j, k)];
+      const double w1 = 0.25 * (A.w[g.ix(i1, j, k)] + A.w[g.ix(i1, j + 1, k)] + A.w[g.ix(i1, j, k - 1)] + A.w[g.ix(i1, j + 1, k - 1)]);
+      const double w2 = 0.25 * (A.w[g.ix(i2, j, k)] + A.w[g.ix(i2, j + 1, k)] + A.w[g.ix(i2, j, k - 1)] + A.w[g.ix(i2, j + 1, k - 1)]);
+      const double v_mag = M(A.mag_a, j, k), w_mag = 0.25 * (M(A.mag_b, j, k) + M(A.mag_b, j + 1, k) + M(A.mag_b, j, k - 1) + M(A.mag_b, j + 1, k - 1));
+      wallmodel(A.mtype, vel_relative(v1, v2, A.coef, v_mag), vel_relative(w1, w2, A.coef, w_mag), A.h, A.l1d, A.visc, t1, t2);
+      M(A.bc_a, j, k) = A.sgn * visci * t1;
+    } else {
+      if (a < 1 || a > na || b > nb) return;           // j = 1..n2, k = 0..n3
+      const int j = a, k = b;
+      const double wei = (A.zf[k] - A.zc[k]) / A.dzc[k];
+      const double v1 = 0.5 * ((1. - wei) * (A.v[g.ix(i1, j - 1, k)] + A.v[g.ix(i1, j, k)]) + wei * (A.v[g.ix(i1, j - 1, k + 1)] + A.v[g.ix(i1, j, k + 1)]));
+      const double v2 = 0.5 * ((1. - wei) * (A.v[g.ix(i2, j - 1, k)] + A.v[g.ix(i2, j, k)]) + wei * (A.v[g.ix(i2, j - 1, k + 1)] + A.v[g.ix(i2, j, k + 1)]));
+      const double w1 = A.w[g.ix(i1, j, k)], w2 = A.w[g.ix(i2, j, k)];
+      const double v_mag = 0.5 * ((1. - wei) * (M(A.mag_a, j - 1, k) + M(A.mag_a, j, k)) + wei * (M(A.mag_a, j - 1, k + 1) + M(A.mag_a, j, k + 1)));
+      const double w_mag = M(A.mag_b, j, k);
+      wallmodel(A.mtype, vel_relative(v1, v2, A.coef, v_mag), vel_relative(w1, w2, A.coef, w_mag), A.h, A.l1d, A.visc, t1, t2);
+      M(A.bc_b, j, k) = A.sgn * visci * t2;
+    }
+  } else if (A.idir == 2) {   // wall normal y; a = i, b = k; tangential: u (first), w (second)
+    const int j1 = A.i1, j2 = A.i2;
+    if (comp == 0) {
+      if (a > na || b < 1 || b > nb) return;           // i = 0..n1, k = 1..n3
+      const int i = a, k = b;
+      const double u1 = A.u[g.ix(i, j1, k)], u2 = A.u[g.ix(i, j2, k)];
+      const double w1 = 0.25 * (A.w[g.ix(i, j1, k)] + A.w[g.ix(i + 1, j1, k)] + A.w[g.ix(i, j1, k - 1)] + A.w[g.ix(i + 1, j1, k - 1)]);
+      const double w2 = 0.25 * (A.w[g.ix(i, j2, k)] + A.w[g.ix(i + 1, j2, k)] + A.w[g.ix(i, j2, k - 1)] + A.w[g.ix(i + 1, j2, k - 1)]);
+      const double u_mag = M(A.mag_a, i, k), w_mag = 0.25 * (M(A.mag_b, i, k) + M(A.mag_b, i + 1, k) + M(A.mag_b, i, k - 1) + M(A.mag_b, i + 1, k - 1));
+      wallmodel(A.mtype, vel_relative(u1, u2, A.coef, u_mag), vel_relative(w1, w2, A.coef, w_mag), A.h, A.l1d, A.visc, t1, t2);
+      M(A.bc_a, i, k) = A.sgn * visci * t1;
+    } else {
+      if (a < 1 || a > na || b > nb) return;           // i = 1..n1, k = 0..n3
+      const int i = a, k = b;
+      const double wei = (A.zf[k] - A.zc[k]) / A.dzc[k];
+      const double u1 = 0.5 * ((1. - wei) * (A.u[g.ix(i - 1, j1, k)] + A.u[g.ix(i, j1, k)]) + wei * (A.u[g.ix(i - 1, j1, k + 1)] + A.u[g.ix(i, j1, k + 1)]));
+      const double u2 = 0.5 * ((1. - wei) * (A.u[g.ix(i - 1, j2, k)] + A.u[g.ix(i, j2, k)]) + wei * (A.u[g.ix(i - 1, j2, k + 1)] + A.u[g.ix(i, j2, k + 1)]));
+      const double w1 = A.w[g.ix(i, j1, k)], w2 = A.w[g.ix(i, j2, k)];
+      const double u_mag = 0.5 * ((1. - wei) * (M(A.mag_a, i - 1, k) + M(A.mag_a, i, k)) + wei * (M(A.mag_a, i - 1, k + 1) + M(A.mag_a, i, k + 1)));
+      const double w_mag = M(A.mag_b, i, k);
+      wallmodel(A.mtype, vel_relative(u1, u2, A.coef, u_mag), vel_relative(w1, w2, A.coef, w_mag), A.h, A.l1d, A.visc, t1, t2);
+      M(A.bc_b, i, k) = A.sgn * visci * t2;
+    }
+  } else {                    // wall normal z; a = i, b = j; tangential: u (first), v (second)
+    const int k1 = A.i1, k2 = A.i2;
+    if (comp == 0) {
+      if (a > na || b < 1 || b > nb) return;           // i = 0..n1, j = 1..n2
+      const int i = a, j = b;
+      const double u1 = A.u[g.ix(i, j, k1)], u2 = A.u[g.ix(i, j, k2)];
+      const double v1 = 0.25 * (A.v[g.ix(i, j, k1)] + A.v[g.ix(i + 1, j, k1)] + A.v[g.ix(i, j - 1, k1)] + A.v[g.ix(i + 1, j - 1, k1)]);
+      const double v2 = 0.25 * (A.v[g.ix(i, j, k2)] + A.v[g.ix(i + 1, j, k2)] + A.v[g.ix(i, j - 1, k2)] + A.v[g.ix(i + 1, j - 1, k2)]);
+      const double u_mag = M(A.mag_a, i, j), v_mag = 0.25 * (M(A.mag_b, i, j) + M(A.mag_b, i + 1, j) + M(A.mag_b, i, j - 1) + M(A.mag_b, i + 1, j - 1));
+      wallmodel(A.mtype, vel_relative(u1, u2, A.coef, u_mag), vel_relative(v1, v2, A.coef, v_mag), A.h, A.l1d, A.visc, t1, t2);
+      M(A.bc_a, i, j) = A.sgn * visci * t1;
+    } else {
+      if (a < 1 || a > na || b > nb) return;           // i = 1..n1, j = 0..n2
+      const int i = a, j = b;
+      const double u1 = 0.25 * (A.u[g.ix(i - 1, j, k1)] + A.u[g.ix(i, j, k1)] + A.u[g.ix(i - 1, j + 1, k1)] + A.u[g.ix(i, j + 1, k1)]);
+      const double u2 = 0.25 * (A.u[g.ix(i - 1, j, k2)] + A.u[g.ix(i, j, k2)] + A.u[g.ix(i - 1, j + 1, k2)] + A.u[g.ix(i, j + 1, k2)]);
+      const double v1 = A.v[g.ix(i, j, k1)], v2 = A.v[g.ix(i, j, k2)];
+      const double u_mag = 0.25 * (M(A.mag_a, i - 1, j) + M(A.mag_a, i, j) + M(A.mag_a, i - 1, j + 1) + M(A.mag_a, i, j + 1));
+      const double v_mag = M(A.mag_b, i, j);
+      wallmodel(A.mtype, vel_relative(u1, u2, A.coef, u_mag), vel_relative(v1, v2, A.coef, v_mag), A.h, A.l1d, A.visc, t1, t2);
+      M(A.bc_b, i, j) = A.sgn * visci * t2;
+    }
+  }
+#undef M
+}
+
+static int updt_wallmodelbc(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, const double *u, const double *v, const double *w) {
+  const int *n = c->n; const double h = c->C.hwm; const double *dl = c->dl;
+  for (int idir = 1; idir <= 3; ++idir) for (int ib = 0; ib <= 1; ++ib) {
+    if (!(ISB(c, ib, idir) && LWM(c, ib, idir) != 0)) continue;
+    WmArgs A; A.idir = idir; A.ibound = ib; A.mtype = LWM(c, ib, idir); A.h = h; A.visc = c->visc; A.l1d = c->C.l[idir - 1];
+    A.u = u; A.v = v; A.w = w; A.zc = c->d_zc; A.zf = c->d_zf; A.dzc = c->d_dzc;
+    const int index = IWM(c, ib, idir);
+    A.i2 = index; A.i1 = ib == 0 ? index - 1 : index + 1; A.sgn = ib == 0 ? 1. : -1.;
+    if (idir == 1) { A.coef = ib == 0 ? (h - (A.i1 - 0.5) * dl[0]) / dl[0] : (h - (n[0] - A.i1 + 0.5) * dl[0]) / dl[0]; }
+    else if (idir == 2) { A.coef = ib == 0 ? (h - (A.i1 - 0.5) * dl[1]) / dl[1] : (h - (n[1] - A.i1 + 0.5) * dl[1]) / dl[1]; }
+    else { A.coef = ib == 0 ? (h - c->zc[A.i1]) / c->dzc[A.i1] : (h - (c->C.l[2] - c->zc[A.i1])) / (c->dzc[A.i2]); }
+    DBound *ba = idir == 1 ? &bv : &bu, *bb = idir == 3 ? &bv : &bw;
+    const DBound *ma = idir == 1 ? &c->bcv_mag : &c->bcu_mag, *mb = idir == 3 ? &c->bcv_mag : &c->bcw_mag;
+    A.bc_a = const_cast<double *>(plane(*ba, idir, ib, n)); A.bc_b = const_cast<double *>(plane(*bb, idir, ib, n));
+    A.mag_a = plane(*ma, idir, ib, n); A.mag_b = plane(*mb, idir, ib, n);
+    const int na = idir == 1 ? n[1] : n[0], nb = idir == 3 ? n[1] : n[2];
+    dim3 b(64, 4, 1), gr((na + 2 + 63) / 64, (nb + 2 + 3) / 4, 2);
+    hipLaunchKernelGGL(k_wallmodel, gr, b, 0, c->stream, c->g, A);
+  }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ bounduvw (bound.f90:18-154)
+int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm, int is_correc, double *u, double *v, double *w) {
+  ProfScope ps(c, "bounduvw");
+  const int *n = c->n;
+  double *fl[3] = {u, v, w};
+  if (int e = halo_self(c, 3, fl)) return e;
+  DBound *bnd[3] = {&bu, &bv, &bw};
+  for (int idir = 1; idir <= 3; ++idir) {
+    if (!ISB(c, 0, idir)) continue;
+    BcJobs J; J.njobs = 0; J.idir = idir;
+    const bool periodic = CBV(c, 0, idir, idir) == 'P' && CBV(c, 1, idir, idir) == 'P';
+    const bool impose_norm = (!is_correc) || periodic;
+    const double drn0 = idir < 3 ? c->dl[idir - 1] : c->dzf[0], drn1 = idir < 3 ? c->dl[idir - 1] : c->dzf[n[2]];
+    const double drt0 = idir < 3 ? c->dl[idir - 1] : c->dzc[0], drt1 = idir < 3 ? c->dl[idir - 1] : c->dzc[n[2]];
+    for (int ivel = 1; ivel <= 3; ++ivel) {
+      double *p = fl[ivel - 1];
+      const bool normal = ivel == idir;
+      const char c0 = CBV(c, 0, idir, ivel), c1 = CBV(c, 1, idir, ivel);
+      if (normal) {
+        if (!impose_norm) continue;
+        if (c0 == 'P') add_job(J, p, 'P', 0, 0, nullptr, 0.);
+        else { add_job(J, p, c0, 0, 0, plane(*bnd[ivel - 1], idir, 0, n), drn0); add_job(J, p, c1, 1, 0, plane(*bnd[ivel - 1], idir, 1, n), drn1); }
+      } else {
+        if (c0 == 'P' && LWM(c, 0, idir) == 0) { add_job(J, p, 'P', 0, 1, nullptr, 0.); continue; }
+        if (LWM(c, 0, idir) == 0) add_job(J, p, c0, 0, 1, plane(*bnd[ivel - 1], idir, 0, n), drt0);
+        if (LWM(c, 1, idir) == 0) add_job(J, p, c1, 1, 1, plane(*bnd[ivel - 1], idir, 1, n), drt1);
+      }
+    }
+    if (int e = launch_jobs(c, J)) return e;
+  }
+  if (is_updt_wm) if (int e = updt_wallmodelbc(c, bu, bv, bw, u, v, w)) return e;
+  for (int idir = 1; idir <= 3; ++idir) {   // tangential Neumann BCs carrying the wall-model stress (bound.f90:125-148)
+    BcJobs J; J.njobs = 0; J.idir = idir;
+    const double drt0 = idir < 3 ? c->dl[idir - 1] : c->dzc[0], drt1 = idir < 3 ? c->dl[idir - 1] : c->dzc[n[2]];
+    for (int ib = 0; ib <= 1; ++ib) {
+      if (!(ISB(c, ib, idir) && LWM(c, ib, idir) != 0)) continue;
+      for (int ivel = 1; ivel <= 3; ++ivel) if (ivel != idir)
+        add_job(J, fl[ivel - 1], CBV(c, ib, idir, ivel), ib, 1, plane(*bnd[ivel - 1], idir, ib, n), ib ? drt1 : drt0);
+    }
+    if (int e = launch_jobs(c, J)) return e;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ updt_rhs_b (bound.f90:562-617)
+struct RhsJob { double *p; const double *rhs; int idir, pos, na, nb; };
+__global__ __launch_bounds__(256) void k_updt_rhs_b(Geom g, RhsJob J) {
+  const int a = blockIdx.x * 64 + threadIdx.x + 1, b = blockIdx.y * 4 + threadIdx.y + 1;
+  if (a > J.na || b > J.nb) return;
+  const size_t q = J.idir == 1 ? g.ix(J.pos, a, b) : J.idir == 2 ? g.ix(a, J.pos, b) : g.ix(a, b, J.pos);
+  J.p[q] += J.rhs[(a - 1) + (size_t)J.na * (b - 1)];
+}
+static int rhs_b_dir(cales_ctx *c, double *p, int idir, const char *cbc6, const char *cf, const double *rhs, double scale_unused) {
+  const int *n = c->n;
+  const int na = idir == 1 ? n[1] : n[0], nb = idir == 3 ? n[1] : n[2];
+  const int q = (cf[idir - 1] == 'f' && cbc6[1 + 2 * (idir - 1)] == 'D') ? 1 : 0;
+  for (int ib = 0; ib <= 1; ++ib) {
+    if (!ISB(c, ib, idir)) continue;
+    RhsJob J; J.p = p; J.rhs = rhs + (size_t)ib * na * nb; J.idir = idir; J.pos = ib ? n[idir - 1] - q : 1; J.na = na; J.nb = nb;
+    hipLaunchKernelGGL(k_updt_rhs_b, dim3((na + 63) / 64, (nb + 3) / 4), dim3(64, 4), 0, c->stream, c->g, J);
+  }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+static bool plane_all_zero(const cales_ctx *c, int idir) { (void)c; (void)idir; return false; }
+
+int op_updt_rhs_b(cales_ctx *c) {
+  ProfScope ps(c, "updt_rhs_b");
+  // the planes are zero for periodic and homogeneous BCs; skip those launches (adding 0. is the identity)
+  for (int idir = 1; idir <= 3; ++idir) {
+    const bool zero = (c->C.bcpre[0 + 2 * (idir - 1)] == 0. && c->C.bcpre[1 + 2 * (idir - 1)] == 0.) ||
+                      (CBP(c, 0, idir) == 'P');
+    if (zero || plane_all_zero(c, idir)) continue;
+    if (int e = rhs_b_dir(c, c->f[CALES_PP], idir, c->C.cbcpre, "ccc", c->rhsbp[idir - 1], 1.)) return e;
+  }
+  return 0;
+}
+
+// z part of the Helmholtz boundary r.h.s. for one velocity component (main.f90:425-433): rhsbz computed on the
+// host from the CURRENT bc planes would need a download; the planes of wall-model faces change every substep,
+// so the term is evaluated on the device from the plane directly.
+__global__ __launch_bounds__(256) void k_rhs_b_velz(Geom g, double *p, const double *bcplane, int ib, char ctype, char c_or_f, double dlc,
+                                                    double dlf, double alpha, int pos) {
+  const int i = blockIdx.x * 64 + threadIdx.x + 1, j = blockIdx.y * 4 + threadIdx.y + 1;
+  if (i > g.n1 || j > g.n2) return;
+  const double bcv = bcplane[i + (size_t)(g.n1 + 2) * j];
+  const double sgn = ib == 0 ? 1. : -1.;
+  double r = 0.;
+  if (c_or_f == 'c') { if (ctype == 'D') r = -2. * bcv / dlc / dlf; else if (ctype == 'N') r = sgn * bcv / dlf; }
+  else               { if (ctype == 'D') r = -bcv / dlc / dlf;      else if (ctype == 'N') r = sgn * bcv / dlc; }
+  p[g.ix(i, j, pos)] += r * alpha;
+}
+int op_rhs_b_velz(cales_ctx *c, int ivel, double alpha) {
+  const int *n = c->n; const int n3 = n[2];
+  const char cf = ivel == 3 ? 'f' : 'c';
+  const DBound &bc = ivel == 1 ? c->bcu : ivel == 2 ? c->bcv : c->bcw;
+  const char *cbc = &c->cbcvel[6 * (ivel - 1) + 4];
+  const int q = (cf == 'f' && cbc[1] == 'D') ? 1 : 0;
+  // bound.f90:479-482: dzc01_c=[dzc(0),dzc(n)], dzf01_c=[dzf(1),dzf(n)]; dzc01_f=[dzc(1),dzc(n-1)], dzf01_f=[dzf(1),dzf(n)]
+  for (int ib = 0; ib <= 1; ++ib) {
+    if (!ISB(c, ib, 3) || cbc[ib] == 'P') continue;
+    const double dlc = cf == 'c' ? (ib ? c->dzc[n3] : c->dzc[0]) : (ib ? c->dzc[n3 - 1] : c->dzc[1]);
+    const double dlf = ib ? c->dzf[n3] : c->dzf[1];
+    hipLaunchKernelGGL(k_rhs_b_velz, dim3((n[0] + 63) / 64, (n[1] + 3) / 4), dim3(64, 4), 0, c->stream, c->g, c->f[CALES_U + ivel - 1],
+                       plane(bc, 3, ib, n), ib, cbc[ib], cf, dlc, dlf, alpha, ib ? n3 - q : 1);
+  }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,306 @@
+// Eddy-viscosity kernels: cmpt_sgs (reference src/sgs.f90:21-386) for 'smag' (van Driest damped) and
+// 'dsmag' (dynamic, plane-averaged: the reference hard-wires _CHANNEL, sgs.f90:8,362-364), with
+// strain_rate (sgs.f90:1019-1110), extrapolate (682-767), filter3d (616-680), interpolate (850-870),
+// ave1d_channel (433-482) and cmpt_alph2 (769-822).
+#include "common.hpp"
+
+#define BX 64
+#define BY 4
+
+// ------------------------------------------------------------------------------------------ extrapolate
+struct ExJob { double *p; int idir, ibound; double factor; };
+struct ExJobs { int njobs; ExJob job[18]; };
+__global__ __launch_bounds__(256) void k_extrapolate(Geom g, ExJobs J) {
+  const ExJob jb = J.job[blockIdx.z];
+  const int idir = jb.idir;
+  const int na = idir == 1 ? g.n2 : g.n1, nb = idir == 3 ? g.n2 : g.n3, n = idir == 1 ? g.n1 : idir == 2 ? g.n2 : g.n3;
+  const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y;
+  if (a > na + 1 || b > nb + 1) return;
+  const long st = idir == 1 ? 1 : idir == 2 ? (long)g.s1 : g.s12;
+  double *p = jb.p + (idir == 1 ? g.ix(0, a, b) : idir == 2 ? g.ix(a, 0, b) : g.ix(a, b, 0));
+#define P(m) p[(long)(m)*st]
+  const double f = jb.factor;
+  if (idir < 3) { if (jb.ibound == 0) P(0) = 2. * P(1) - P(2); else P(n + 1) = 2. * P(n) - P(n - 1); }
+  else { if (jb.ibound == 0) P(0) = (1. + f) * P(1) - f * P(2); else P(n + 1) = (1. + f) * P(n) - f * P(n - 1); }
+#undef P
+}
+// mode 0: `lwm` form (wall-model faces, z factors from the grid), 1: `cbc` form (all no-slip walls, factor 1)
+static int extrapolate(cales_ctx *c, int nf, double **p, const int *iface, int mode) {
+  const int *n = c->n;
+  for (int idir = 1; idir <= 3; ++idir) {      // one launch per direction, order x,y,z as the reference
+    ExJobs J; J.njobs = 0;
+    for (int q = 0; q < nf; ++q) for (int ib = 0; ib <= 1; ++ib) {
+      bool done;
+      double factor = 1.;
+      if (mode == 1) done = ISB(c, ib, idir) && CBV(c, ib, idir, idir) == 'D' && iface[q] != idir;
+      else {
+        done = ISB(c, ib, idir) && LWM(c, ib, idir) != 0 && iface[q] != idir;
+        factor = ib == 0 ? (1. / c->dzci[0]) * c->dzci[1] : (1. / c->dzci[n[2]]) * c->dzci[n[2] - 1];
+      }
+      if (!done) continue;
+      ExJob &j = J.job[J.njobs++]; j.p = p[q]; j.idir = idir; j.ibound = ib; j.factor = factor;
+    }
+    if (!J.njobs) continue;
+    const int na = idir == 1 ? n[1] : n[0], nb = idir == 3 ? n[1] : n[2];
+    hipLaunchKernelGGL(k_extrapolate, dim3((na + 2 + 63) / 64, (nb + 2 + 3) / 4, J.njobs), dim3(64, 4), 0, c->stream, c->g, J);
+  }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ strain_rate
+template <int WITH_SIJ>
+__global__ __launch_bounds__(BX *BY) void k_strain(Geom g, double dxi, double dyi, const double *__restrict__ dzci,
+                                                    const double *__restrict__ dzfi, const double *__restrict__ u,
+                                                    const double *__restrict__ v, const double *__restrict__ w, double *__restrict__ s0,
+                                                    double *__restrict__ s11o, double *__restrict__ s22o, double *__restrict__ s33o,
+                                                    double *__restrict__ s12o, double *__restrict__ s13o, double *__restrict__ s23o) {
+  const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;
+  if (i > g.n1 || j > g.n2) return;
+  const size_t c = g.ix(i, j, k);
+  const long sj = g.s1, sk = g.s12;
+#define LD(a, di, dj, dk) a[c + (di) + (dj)*sj + (dk)*sk]
+  const double u_mcm = LD(u, -1, 0, -1), u_ccm = LD(u, 0, 0, -1), u_mmc = LD(u, -1, -1, 0), u_cmc = LD(u, 0, -1, 0), u_mcc = LD(u, -1, 0, 0),
+               u_ccc = LD(u, 0, 0, 0), u_mpc = LD(u, -1, 1, 0), u_cpc = LD(u, 0, 1, 0), u_mcp = LD(u, -1, 0, 1), u_ccp = LD(u, 0, 0, 1);
+  const double v_cmm = LD(v, 0, -1, -1), v_ccm = LD(v, 0, 0, -1), v_mmc = LD(v, -1, -1, 0), v_cmc = LD(v, 0, -1, 0), v_pmc = LD(v, 1, -1, 0),
+               v_mcc = LD(v, -1, 0, 0), v_ccc = LD(v, 0, 0, 0), v_pcc = LD(v, 1, 0, 0), v_cmp = LD(v, 0, -1, 1), v_ccp = LD(v, 0, 0, 1);
+  const double w_cmm = LD(w, 0, -1, -1), w_mcm = LD(w, -1, 0, -1), w_ccm = LD(w, 0, 0, -1), w_pcm = LD(w, 1, 0, -1), w_cpm = LD(w, 0, 1, -1),
+               w_cmc = LD(w, 0, -1, 0), w_mcc = LD(w, -1, 0, 0), w_ccc = LD(w, 0, 0, 0), w_pcc = LD(w, 1, 0, 0), w_cpc = LD(w, 0, 1, 0);
+#undef LD
+  const double zc = dzci[k], zm = dzci[k - 1];
+  const double s11 = (u_ccc - u_mcc) * dxi, s22 = (v_ccc - v_cmc) * dyi, s33 = (w_ccc - w_ccm) * dzfi[k];
+  const double s12 = .125 * ((u_cpc - u_ccc) * dyi + (v_pcc - v_ccc) * dxi + (u_ccc - u_cmc) * dyi + (v_pmc - v_cmc) * dxi +
+                             (u_mpc - u_mcc) * dyi + (v_ccc - v_mcc) * dxi + (u_mcc - u_mmc) * dyi + (v_cmc - v_mmc) * dxi);
+  const double s13 = .125 * ((u_ccp - u_ccc) * zc + (w_pcc - w_ccc) * dxi + (u_ccc - u_ccm) * zm + (w_pcm - w_ccm) * dxi +
+                             (u_mcp - u_mcc) * zc + (w_ccc - w_mcc) * dxi + (u_mcc - u_mcm) * zm + (w_ccm - w_mcm) * dxi);
+  const double s23 = .125 * ((v_ccp - v_ccc) * zc + (w_cpc - w_ccc) * dyi + (v_ccc - v_ccm) * zm + (w_cpm - w_ccm) * dyi +
+                             (v_cmp - v_cmc) * zc + (w_ccc - w_cmc) * dyi + (v_cmc - v_cmm) * zm + (w_ccm - w_cmm) * dyi);
+  s0[c] = sqrt(2. * (s11 * s11 + s22 * s22 + s33 * s33 + 2. * (s12 * s12 + s13 * s13 + s23 * s23)));
+  if (WITH_SIJ) { s11o[c] = s11; s22o[c] = s22; s33o[c] = s33; s12o[c] = s12; s13o[c] = s13; s23o[c] = s23; }
+}
+static int strain_rate(cales_ctx *c, const double *u, const double *v, const double *w, double *s0, double **sij) {
+  ProfScope ps(c, "strain_rate");
+  dim3 b(BX, BY, 1), gr = grid3(c->n[0], c->n[1], c->n[2], b);
+  if (sij) hipLaunchKernelGGL(k_strain<1>, gr, b, 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, u, v, w, s0, sij[0], sij[1], sij[2], sij[3], sij[4], sij[5]);
+  else hipLaunchKernelGGL(k_strain<0>, gr, b, 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, u, v, w, s0, (double *)nullptr,
+                          (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ static Smagorinsky (sgs.f90:98-152)
+struct SmagArgs { double w0, w1, w2, w3, w4, w5, dl1, dl2, l3, dxi, dyi, visc, sumw; };
+__global__ __launch_bounds__(BX *BY) void k_smag(Geom g, SmagArgs A, const double *__restrict__ zc, const double *__restrict__ dzci,
+                                                  const double *__restrict__ dzf, const double *__restrict__ u, const double *__restrict__ v,
+                                                  const double *__restrict__ w, const double *__restrict__ s0, double *__restrict__ visct) {
+  const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;
+  if (i > g.n1 || j > g.n2) return;
+  double fd;
+  if (A.sumw == 0.) fd = 1.;
+  else {
+    const int jg = j + g.jlo;                    // global row: distances to the y walls use global indices
+    double dw[6];
+    dw[0] = A.dl1 * (i - 0.5); dw[1] = A.dl1 * (g.n1 - i + 0.5);
+    dw[2] = A.dl2 * (jg - 0.5); dw[3] = A.dl2 * (g.ng2 - jg + 0.5);
+    dw[4] = zc[k]; dw[5] = A.l3 - zc[k];
+    const double isw[6] = {A.w0, A.w1, A.w2, A.w3, A.w4, A.w5};
+    int loc = 0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) dw[q] = dw[q] * isw[q] + CALES_BIG * (1. - isw[q]);
+#pragma unroll
+    for (int q = 1; q < 6; ++q) if (dw[q] < dw[loc]) loc = q;
+    const double dw_min = dw[loc];
+    double t1, t2, sc;
+    const int n1 = g.n1, n2 = g.n2, n3 = g.n3;
+    switch (loc) {
+    case 0: t1 = v[g.ix(1, j, k)] - v[g.ix(0, j, k)] + v[g.ix(1, j - 1, k)] - v[g.ix(0, j - 1, k)];
+            t2 = w[g.ix(1, j, k)] - w[g.ix(0, j, k)] + w[g.ix(1, j, k - 1)] - w[g.ix(0, j, k - 1)]; sc = A.dxi; break;
+    case 1: t1 = v[g.ix(n1, j, k)] - v[g.ix(n1 + 1, j, k)] + v[g.ix(n1, j - 1, k)] - v[g.ix(n1 + 1, j - 1, k)];
+            t2 = w[g.ix(n1, j, k)] - w[g.ix(n1 + 1, j, k)] + w[g.ix(n1, j, k - 1)] - w[g.ix(n1 + 1, j, k - 1)]; sc = A.dxi; break;
+    case 2: t1 = u[g.ix(i, 1, k)] - u[g.ix(i, 0, k)] + u[g.ix(i - 1, 1, k)] - u[g.ix(i - 1, 0, k)];
+            t2 = w[g.ix(i, 1, k)] - w[g.ix(i, 0, k)] + w[g.ix(i, 1, k - 1)] - w[g.ix(i, 0, k - 1)]; sc = A.dyi; break;
+    case 3: t1 = u[g.ix(i, n2, k)] - u[g.ix(i, n2 + 1, k)] + u[g.ix(i - 1, n2, k)] - u[g.ix(i - 1, n2 + 1, k)];
+            t2 = w[g.ix(i, n2, k)] - w[g.ix(i, n2 + 1, k)] + w[g.ix(i, n2, k - 1)] - w[g.ix(i, n2 + 1, k - 1)]; sc = A.dyi; break;
+    case 4: t1 = u[g.ix(i, j, 1)] - u[g.ix(i, j, 0)] + u[g.ix(i - 1, j, 1)] - u[g.ix(i - 1, j, 0)];
+            t2 = v[g.ix(i, j, 1)] - v[g.ix(i, j, 0)] + v[g.ix(i, j - 1, 1)] - v[g.ix(i, j - 1, 0)]; sc = dzci[0]; break;
+    default: t1 = u[g.ix(i, j, n3)] - u[g.ix(i, j, n3 + 1)] + u[g.ix(i - 1, j, n3)] - u[g.ix(i - 1, j, n3 + 1)];
+             t2 = v[g.ix(i, j, n3)] - v[g.ix(i, j, n3 + 1)] + v[g.ix(i, j - 1, n3)] - v[g.ix(i, j - 1, n3 + 1)]; sc = dzci[n3]; break;
+    }
+    double tauw_s = sqrt(t1 * t1 + t2 * t2) * sc;
+    tauw_s = 0.5 * A.visc * tauw_s;
+    const double dw_plus = dw_min * sqrt(tauw_s) * (1. / A.visc);
+    fd = 1. - exp(-dw_plus / 25.);
+  }
+  const double del = pow(A.dl1 * A.dl2 * dzf[k], 1. / 3.);
+  const double t = 0.11 * del * fd;           // c_smag, src/param.f90:33
+  const size_t c = g.ix(i, j, k);
+  visct[c] = (t * t) * s0[c];
+}
+
+// ------------------------------------------------------------------------------------------ small dsmag kernels
+__global__ __launch_bounds__(256) void k_copy3(size_t n, const double *__restrict__ a, const double *__restrict__ b, const double *__restrict__ c_,
+                                               double *__restrict__ x, double *__restrict__ y, double *__restrict__ z) {
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) { x[q] = a[q]; y[q] = b[q]; z[q] = c_[q]; }
+}
+__global__ __launch_bounds__(256) void k_copy1(size_t n, const double *__restrict__ a, double *__restrict__ x) {
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) x[q] = a[q];
+}
+struct P6 { double *p[6]; };
+struct CP6 { const double *p[6]; };
+__global__ __launch_bounds__(256) void k_s0sij(size_t n, const double *__restrict__ s0, CP6 sij, P6 wk) {   // sgs.f90:198-210 (all cells)
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) {
+    const double s = s0[q];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) wk.p[m][q] = s * sij.p[m][q];
+  }
+}
+__global__ __launch_bounds__(256) void k_uiuj(size_t n, const double *__restrict__ uc, const double *__restrict__ vc, const double *__restrict__ wc, P6 wk) {
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) {   // sgs.f90:283-295
+    const double a = uc[q], b = vc[q], c_ = wc[q];
+    wk.p[0][q] = a * a; wk.p[1][q] = b * b; wk.p[2][q] = c_ * c_; wk.p[3][q] = a * b; wk.p[4][q] = a * c_; wk.p[5][q] = b * c_;
+  }
+}
+// filter3d (sgs.f90:632-679): 27-point top-hat, weights 8/4/2/1 over 64
+__global__ __launch_bounds__(BX *BY) void k_filter3d(Geom g, const double *__restrict__ p, double *__restrict__ pf) {
+  const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;
+  if (i > g.n1 || j > g.n2) return;
+  const size_t c = g.ix(i, j, k);
+  const long sj = g.s1, sk = g.s12;
+#define Q(di, dj, dk) p[c + (di) + (dj)*sj + (dk)*sk]
+  pf[c] = (8. * (Q(0, 0, 0)) + 4. * (Q(-1, 0, 0) + Q(0, -1, 0) + Q(0, 0, -1) + Q(1, 0, 0) + Q(0, 1, 0) + Q(0, 0, 1)) +
+           2. * (Q(0, -1, -1) + Q(-1, 0, -1) + Q(-1, -1, 0) + Q(0, 1, -1) + Q(1, 0, -1) + Q(1, -1, 0) + Q(0, -1, 1) + Q(-1, 0, 1) +
+                 Q(-1, 1, 0) + Q(0, 1, 1) + Q(1, 0, 1) + Q(1, 1, 0)) +
+           1. * (Q(-1, -1, -1) + Q(1, -1, -1) + Q(-1, 1, -1) + Q(1, 1, -1) + Q(-1, -1, 1) + Q(1, -1, 1) + Q(-1, 1, 1) + Q(1, 1, 1))) / 64.;
+#undef Q
+}
+__global__ __launch_bounds__(BX *BY) void k_mij(Geom g, P6 mij, const double *__restrict__ alph2, const double *__restrict__ s0, CP6 sij) {
+  const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;   // sgs.f90:262-272
+  if (i > g.n1 || j > g.n2) return;
+  const size_t c = g.ix(i, j, k);
+  const double a = alph2[c], s = s0[c];
+#pragma unroll
+  for (int m = 0; m < 6; ++m) mij.p[m][c] = 2. * (mij.p[m][c] - a * s * sij.p[m][c]);
+}
+__global__ __launch_bounds__(BX *BY) void k_interp(Geom g, const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ w,
+                                                    double *__restrict__ uc, double *__restrict__ vc, double *__restrict__ wc) {
+  const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;   // sgs.f90:860-869
+  if (i > g.n1 || j > g.n2) return;
+  const size_t c = g.ix(i, j, k);
+  uc[c] = 0.5 * (u[c] + u[c - 1]); vc[c] = 0.5 * (v[c] + v[c - g.s1]); wc[c] = 0.5 * (w[c] + w[c - g.s12]);
+}
+__global__ __launch_bounds__(BX *BY) void k_contract(Geom g, CP6 mij, CP6 lij, const double *__restrict__ uf, const double *__restrict__ vf,
+                                                      const double *__restrict__ wf, double *__restrict__ lm, double *__restrict__ mm) {
+  const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;   // sgs.f90:328-358
+  if (i > g.n1 || j > g.n2) return;
+  const size_t c = g.ix(i, j, k);
+  double m_[6], l_[6];
+#pragma unroll
+  for (int m = 0; m < 6; ++m) { m_[m] = mij.p[m][c]; l_[m] = lij.p[m][c]; }
+  const double a = uf[c], b = vf[c], d = wf[c];
+  l_[0] -= a * a; l_[1] -= b * b; l_[2] -= d * d; l_[3] -= a * b; l_[4] -= a * d; l_[5] -= b * d;
+  lm[c] = m_[0] * l_[0] + m_[1] * l_[1] + m_[2] * l_[2] + (m_[3] * l_[3] + m_[4] * l_[4] + m_[5] * l_[5]) * 2.;
+  mm[c] = m_[0] * m_[0] + m_[1] * m_[1] + m_[2] * m_[2] + (m_[3] * m_[3] + m_[4] * m_[4] + m_[5] * m_[5]) * 2.;
+}
+// ave1d_channel (sgs.f90:462-480): plane sums of two fields -> p1d(2, n3); one block per (k, field)
+__global__ __launch_bounds__(256) void k_plane_sum(Geom g, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ p1d) {
+  __shared__ double sh[4];
+  const int k = blockIdx.x + 1; const double *p = blockIdx.y ? b : a;
+  double acc = 0.;
+  const long np = (long)g.n1 * g.n2;
+  for (long q = threadIdx.x; q < np; q += 256) acc += p[g.ix((int)(q % g.n1) + 1, (int)(q / g.n1) + 1, k)];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) p1d[blockIdx.y * g.n3 + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+// visct = max(visct*<LM>/<MM>,0) (sgs.f90:372-380); the plane averages replace the broadcast arrays
+__global__ __launch_bounds__(BX *BY) void k_dsmag_final(Geom g, double gar, const double *__restrict__ p1d, double *__restrict__ visct) {
+  const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;
+  if (i > g.n1 || j > g.n2) return;
+  const size_t c = g.ix(i, j, k);
+  const double lm = p1d[k - 1] * gar, mm = p1d[g.n3 + k - 1] * gar;
+  double vt = visct[c] * lm / mm;
+  visct[c] = fmax(vt, 0.);
+}
+__global__ __launch_bounds__(256) void k_alph2(Geom g, double w0, double w1, double w2, double w3, double w4, double w5, double *__restrict__ alph2) {
+  const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;    // sgs.f90:783-816
+  if (i > g.n1 + 1 || j > g.n2 + 1) return;
+  const int jg = j + g.jlo;
+  const bool near = (w0 != 0. && i == 1) || (w1 != 0. && i == g.n1) || (w2 != 0. && jg == 1) || (w3 != 0. && jg == g.ng2) ||
+                    (w4 != 0. && k == 1) || (w5 != 0. && k == g.n3);
+  alph2[g.ix(i, j, k)] = near ? 2.52 : 4.00;
+}
+
+static inline dim3 lin_grid(size_t n) { size_t b = (n + 255) / 256; if (b > 4096) b = 4096; return dim3((unsigned)b); }
+
+int op_cmpt_sgs(cales_ctx *c) {
+  const int *n = c->n; const size_t nt = c->ntot;
+  double **f = c->f; double *visct = f[CALES_VISCT];
+  if (c->C.sgstype == 0) {           // 'none': visct = 0 once (sgs.f90:62-68)
+    if (c->sgs_first) { c->sgs_first = false; HIPCHK(c, hipMemsetAsync(visct, 0, nt * sizeof(double), c->stream)); }
+    return 0;
+  }
+  ProfScope ps(c, c->C.sgstype == 1 ? "cmpt_sgs_smag" : "cmpt_sgs_dsmag");
+  dim3 b(BX, BY, 1), gr = grid3(n[0], n[1], n[2], b);
+  if (c->sgs_first) {
+    c->sgs_first = false;
+    if (c->C.sgstype == 2)
+      hipLaunchKernelGGL(k_alph2, grid3(n[0] + 2, n[1] + 2, n[2] + 2, dim3(64, 4, 1)), dim3(64, 4, 1), 0, c->stream, c->g, c->is_wall[0], c->is_wall[1],
+                         c->is_wall[2], c->is_wall[3], c->is_wall[4], c->is_wall[5], c->alph2);
+  }
+  double **wk = c->wk;
+  // wk(1:3) = u,v,w ; extrapolate at wall-model faces ; strain rate (sgs.f90:84-92 / 173-181)
+  hipLaunchKernelGGL(k_copy3, lin_grid(nt), dim3(256), 0, c->stream, nt, f[CALES_U], f[CALES_V], f[CALES_W], wk[0], wk[1], wk[2]);
+  const int if123[3] = {1, 2, 3};
+  if (int e = extrapolate(c, 3, wk, if123, 0)) return e;
+  if (c->C.sgstype == 1) {
+    if (int e = strain_rate(c, wk[0], wk[1], wk[2], c->s0, nullptr)) return e;
+    SmagArgs A; A.w0 = c->is_wall[0]; A.w1 = c->is_wall[1]; A.w2 = c->is_wall[2]; A.w3 = c->is_wall[3]; A.w4 = c->is_wall[4]; A.w5 = c->is_wall[5];
+    A.dl1 = c->dl[0]; A.dl2 = c->dl[1]; A.l3 = c->C.l[2]; A.dxi = c->dli[0]; A.dyi = c->dli[1]; A.visc = c->visc;
+    A.sumw = 0.; for (int q = 0; q < 6; ++q) A.sumw += c->is_wall[q];
+    hipLaunchKernelGGL(k_smag, gr, b, 0, c->stream, c->g, A, c->d_zc, c->d_dzci, c->d_dzf, f[CALES_U], f[CALES_V], f[CALES_W], c->s0, visct);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  // ---- dynamic model (sgs.f90:153-380)
+  double **sij = c->sij, **mij = c->mij, **lij = c->sij;
+  if (int e = strain_rate(c, wk[0], wk[1], wk[2], c->s0, sij)) return e;
+  hipLaunchKernelGGL(k_copy1, lin_grid(nt), dim3(256), 0, c->stream, nt, c->s0, visct);
+  if (int e = op_boundp(c, c->s0, 1)) return e;
+  for (int m = 0; m < 6; ++m) if (int e = op_boundp(c, sij[m], 1)) return e;
+  CP6 csij; P6 pwk, pmij; CP6 cmij;
+  for (int m = 0; m < 6; ++m) { csij.p[m] = sij[m]; pwk.p[m] = wk[m]; pmij.p[m] = mij[m]; cmij.p[m] = mij[m]; }
+  hipLaunchKernelGGL(k_s0sij, lin_grid(nt), dim3(256), 0, c->stream, nt, c->s0, csij, pwk);
+  const int if0[6] = {0, 0, 0, 0, 0, 0};
+  if (int e = extrapolate(c, 6, wk, if0, 1)) return e;
+  for (int m = 0; m < 6; ++m) hipLaunchKernelGGL(k_filter3d, gr, b, 0, c->stream, c->g, wk[m], mij[m]);
+  hipLaunchKernelGGL(k_copy3, lin_grid(nt), dim3(256), 0, c->stream, nt, f[CALES_U], f[CALES_V], f[CALES_W], wk[0], wk[1], wk[2]);
+  if (int e = extrapolate(c, 3, wk, if123, 1)) return e;
+  hipLaunchKernelGGL(k_filter3d, gr, b, 0, c->stream, c->g, wk[0], c->uf);
+  hipLaunchKernelGGL(k_filter3d, gr, b, 0, c->stream, c->g, wk[1], c->vf);
+  hipLaunchKernelGGL(k_filter3d, gr, b, 0, c->stream, c->g, wk[2], c->wf);
+  if (int e = op_bounduvw(c, c->bcuf, c->bcvf, c->bcwf, 0, 0, c->uf, c->vf, c->wf)) return e;
+  double *ff[3] = {c->uf, c->vf, c->wf};
+  if (int e = extrapolate(c, 3, ff, if123, 0)) return e;
+  if (int e = strain_rate(c, c->uf, c->vf, c->wf, c->s0, sij)) return e;
+  hipLaunchKernelGGL(k_mij, gr, b, 0, c->stream, c->g, pmij, c->alph2, c->s0, csij);
+  hipLaunchKernelGGL(k_interp, gr, b, 0, c->stream, c->g, f[CALES_U], f[CALES_V], f[CALES_W], c->uc, c->vc, c->wc);
+  if (int e = op_boundp(c, c->uc, 1)) return e;
+  if (int e = op_boundp(c, c->vc, 1)) return e;
+  if (int e = op_boundp(c, c->wc, 1)) return e;
+  hipLaunchKernelGGL(k_uiuj, lin_grid(nt), dim3(256), 0, c->stream, nt, c->uc, c->vc, c->wc, pwk);
+  if (int e = extrapolate(c, 6, wk, if0, 1)) return e;
+  for (int m = 0; m < 6; ++m) hipLaunchKernelGGL(k_filter3d, gr, b, 0, c->stream, c->g, wk[m], lij[m]);
+  double *cc[3] = {c->uc, c->vc, c->wc};
+  if (int e = extrapolate(c, 3, cc, if0, 1)) return e;
+  hipLaunchKernelGGL(k_filter3d, gr, b, 0, c->stream, c->g, c->uc, c->uf);
+  hipLaunchKernelGGL(k_filter3d, gr, b, 0, c->stream, c->g, c->vc, c->vf);
+  hipLaunchKernelGGL(k_filter3d, gr, b, 0, c->stream, c->g, c->wc, c->wf);
+  CP6 clij; for (int m = 0; m < 6; ++m) clij.p[m] = lij[m];
+  hipLaunchKernelGGL(k_contract, gr, b, 0, c->stream, c->g, cmij, clij, c->uf, c->vf, c->wf, wk[0], wk[1]);
+  hipLaunchKernelGGL(k_plane_sum, dim3(n[2], 2), dim3(256), 0, c->stream, c->g, wk[0], wk[1], c->d_p1d);
+  const double gar = c->dl[0] * c->dl[1] / (c->C.l[0] * c->C.l[1]);
+  hipLaunchKernelGGL(k_dsmag_final, gr, b, 0, c->stream, c->g, gar, c->d_p1d, visct);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}

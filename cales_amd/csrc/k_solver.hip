@@ -1,0 +1,332 @@
+// FFT-based direct Poisson solver and the z tridiagonal sweeps (reference src/solver.f90:20-233,
+// src/solver_gpu.f90:32-477, src/fft.f90, src/initsolver.f90).
+//
+// MI355X design (no hipFFT/rocFFT, no transposes on one GPU, no MFMA -- the pass is HBM-bound):
+//   x pass : batched real-to-complex FFT of the contiguous rows. The n1 reals of a row become n1/2+1
+//            complex modes that are written IN PLACE over the haloed row (n1+2 doubles = n1/2+1 double2).
+//   y pass : batched complex FFT of the strided columns; a workgroup stages CB adjacent complex columns
+//            (CB*16 B contiguous per row) of one z-plane in LDS, transforms them there and writes back.
+//   z pass : Thomas algorithm, one thread per complex mode (re,im share the pivots), coalesced over x.
+//   then y and x inverse passes, scaled by normfft.
+// Transforms are radix-4/2/3/5 Stockham stages in LDS (ping-pong buffers), twiddles from a table.
+// Spectral layout differs from FFTW's half-complex order; eigenvalues are laid out to match, so the
+// solution p = solver(rhs) is the same discrete function (checked against the oracle).
+#include "common.hpp"
+
+struct cpx { double x, y; };
+__device__ inline cpx cadd(cpx a, cpx b) { return {a.x + b.x, a.y + b.y}; }
+__device__ inline cpx csub(cpx a, cpx b) { return {a.x - b.x, a.y - b.y}; }
+__device__ inline cpx cmul(cpx a, cpx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ inline cpx cconj(cpx a) { return {a.x, -a.y}; }
+template <int INV> __device__ inline cpx mul_mi(cpx a) { return INV ? cpx{-a.y, a.x} : cpx{a.y, -a.x}; }   // fwd: *(-i), inv: *(+i)
+
+// one Stockham autosort stage of radix R on a length-N line: in -> out, t = lane within the line's T threads
+template <int R, int INV>
+__device__ inline void fft_stage(const cpx *__restrict__ in, cpx *__restrict__ out, int N, int Ns, int t, int T, const cpx *__restrict__ tw) {
+  const int M = N / R, tstep = N / (Ns * R);
+  for (int j = t; j < M; j += T) {
+    const int k = j % Ns;
+    cpx v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = in[j + r * M];
+    if (Ns > 1) {
+#pragma unroll
+      for (int r = 1; r < R; ++r) { cpx w = tw[k * r * tstep]; if (INV) w.y = -w.y; v[r] = cmul(v[r], w); }
+    }
+    const int j0 = (j - k) * R + k;
+    if (R == 2) {
+      out[j0] = cadd(v[0], v[1]); out[j0 + Ns] = csub(v[0], v[1]);
+    } else if (R == 4) {
+      const cpx a0 = cadd(v[0], v[2]), a1 = csub(v[0], v[2]), a2 = cadd(v[1], v[3]), a3 = mul_mi<INV>(csub(v[1], v[3]));
+      out[j0] = cadd(a0, a2); out[j0 + Ns] = cadd(a1, a3); out[j0 + 2 * Ns] = csub(a0, a2); out[j0 + 3 * Ns] = csub(a1, a3);
+    } else if (R == 3) {
+      const double s3 = INV ? 0.86602540378443864676 : -0.86602540378443864676;
+      const cpx s = cadd(v[1], v[2]), d = csub(v[1], v[2]);
+      const cpx m = {v[0].x - 0.5 * s.x, v[0].y - 0.5 * s.y}, rot = {-s3 * d.y, s3 * d.x};   // i*s3*d
+      out[j0] = cadd(v[0], s); out[j0 + Ns] = cadd(m, rot); out[j0 + 2 * Ns] = csub(m, rot);
+    } else if (R == 5) {
+      const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
+      const double s1 = INV ? 0.95105651629515357212 : -0.95105651629515357212, s2 = INV ? 0.58778525229247312917 : -0.58778525229247312917;
+      const cpx a = cadd(v[1], v[4]), b = csub(v[1], v[4]), c = cadd(v[2], v[3]), d = csub(v[2], v[3]);
+      const cpx m1 = {v[0].x + c1 * a.x + c2 * c.x, v[0].y + c1 * a.y + c2 * c.y}, m2 = {v[0].x + c2 * a.x + c1 * c.x, v[0].y + c2 * a.y + c1 * c.y};
+      const cpx r1 = {-(s1 * b.y + s2 * d.y), s1 * b.x + s2 * d.x}, r2 = {-(s2 * b.y - s1 * d.y), s2 * b.x - s1 * d.x};
+      out[j0] = cadd(v[0], cadd(a, c)); out[j0 + Ns] = cadd(m1, r1); out[j0 + 4 * Ns] = csub(m1, r1);
+      out[j0 + 2 * Ns] = cadd(m2, r2); out[j0 + 3 * Ns] = csub(m2, r2);
+    }
+  }
+}
+
+struct FftPlan { int N, nst, radix[16]; };
+static bool make_plan(int N, FftPlan &P) {
+  P.N = N; P.nst = 0; int m = N;
+  while (m % 4 == 0) { P.radix[P.nst++] = 4; m /= 4; }
+  while (m % 2 == 0) { P.radix[P.nst++] = 2; m /= 2; }
+  while (m % 3 == 0) { P.radix[P.nst++] = 3; m /= 3; }
+  while (m % 5 == 0) { P.radix[P.nst++] = 5; m /= 5; }
+  return m == 1;
+}
+// runs all stages; returns the buffer holding the result (a or b). All threads of the block must call it.
+template <int INV>
+__device__ inline cpx *fft_line(const FftPlan &P, cpx *a, cpx *b, int t, int T, const cpx *tw) {
+  int Ns = 1;
+  for (int s = 0; s < P.nst; ++s) {
+    const int R = P.radix[s];
+    if (R == 4) fft_stage<4, INV>(a, b, P.N, Ns, t, T, tw);
+    else if (R == 2) fft_stage<2, INV>(a, b, P.N, Ns, t, T, tw);
+    else if (R == 3) fft_stage<3, INV>(a, b, P.N, Ns, t, T, tw);
+    else fft_stage<5, INV>(a, b, P.N, Ns, t, T, tw);
+    Ns *= R;
+    __syncthreads();
+    cpx *tmp = a; a = b; b = tmp;
+  }
+  return a;
+}
+
+// ------------------------------------------------------------------------------------------ x pass
+// rows are (j,k), j=1..n2, k=1..n3. R rows per block, T = blockDim.x / R threads per row.
+template <int INV>
+__global__ __launch_bounds__(256) void k_fft_x(Geom g, FftPlan P, int R, const cpx *__restrict__ tw, const cpx *__restrict__ twp,
+                                                double *__restrict__ p, double scale) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int nh = P.N, n = 2 * nh, T = blockDim.x / R, row = threadIdx.x / T, t = threadIdx.x % T;
+  const int ld = nh + 1;
+  cpx *A = reinterpret_cast<cpx *>(smem) + (size_t)row * 2 * ld, *B = A + ld;
+  const long r = (long)blockIdx.x * R + row, nrows = (long)g.n2 * g.n3;
+  const bool live = r < nrows;
+  const int j = live ? (int)(r % g.n2) + 1 : 1, k = live ? (int)(r / g.n2) + 1 : 1;
+  double *rowp = p + g.ix(0, j, k);
+  if (!INV) {
+    if (live) for (int q = t; q < nh; q += T) A[q] = cpx{rowp[1 + 2 * q], rowp[2 + 2 * q]};
+    __syncthreads();
+    cpx *Z = fft_line<0>(P, A, B, t, T, tw);
+    if (live) {
+      double2 *out = reinterpret_cast<double2 *>(rowp);
+      for (int kk = t; kk <= nh / 2; kk += T) {
+        const cpx zk = Z[kk], zm = cconj(Z[(nh - kk) % nh]);
+        const cpx E = {0.5 * (zk.x + zm.x), 0.5 * (zk.y + zm.y)};
+        const cpx D = csub(zk, zm), O = {0.5 * D.y, -0.5 * D.x};     // -i/2 * (zk - conj(zm))
+        const cpx wO = cmul(twp[kk], O);
+        const cpx xk = cadd(E, wO), xm = cconj(csub(E, wO));
+        out[kk] = make_double2(xk.x, xk.y);
+        out[nh - kk] = make_double2(xm.x, xm.y);
+      }
+    }
+  } else {
+    if (live) {
+      const double2 *in = reinterpret_cast<const double2 *>(rowp);
+      for (int kk = t; kk <= nh; kk += T) { const double2 v = in[kk]; B[kk] = cpx{v.x, v.y}; }
+    }
+    __syncthreads();
+    for (int kk = t; kk < nh; kk += T) {
+      const cpx xk = B[kk], xm = cconj(B[nh - kk]);
+      const cpx S = cadd(xk, xm), D = csub(xk, xm);
+      const cpx wD = cmul(cconj(twp[kk]), D);
+      A[kk] = cpx{S.x - wD.y, S.y + wD.x};                           // S + i*conj(w^k)*D
+    }
+    __syncthreads();
+    cpx *z = fft_line<1>(P, A, B, t, T, tw);
+    if (live) for (int q = t; q < nh; q += T) { rowp[1 + 2 * q] = z[q].x * scale; rowp[2 + 2 * q] = z[q].y * scale; }
+  }
+  (void)n;
+}
+
+// ------------------------------------------------------------------------------------------ y pass
+// block = CB adjacent complex columns (m0..m0+CB-1) of plane k; T = blockDim.x / CB threads per column.
+template <int INV>
+__global__ __launch_bounds__(256) void k_fft_y(Geom g, FftPlan P, int CB, int ncols, const cpx *__restrict__ tw, double *__restrict__ p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int N = P.N, ld = N + 1, T = blockDim.x / CB;
+  const int m0 = blockIdx.x * CB, k = blockIdx.y + 1;
+  cpx *base = reinterpret_cast<cpx *>(smem);
+  double2 *pc = reinterpret_cast<double2 *>(p);
+  const size_t rowc = (size_t)g.s1 / 2;                                    // complex per row
+  for (int q = threadIdx.x; q < CB * N; q += blockDim.x) {
+    const int col = q % CB, j = q / CB;
+    if (m0 + col < ncols) { const double2 v = pc[(g.ix(0, j + 1, k) >> 1) + m0 + col]; base[(size_t)col * 2 * ld + j] = cpx{v.x, v.y}; }
+  }
+  __syncthreads();
+  const int col = threadIdx.x / T, t = threadIdx.x % T;
+  cpx *A = base + (size_t)col * 2 * ld, *B = A + ld;
+  cpx *Z = fft_line<INV>(P, A, B, t, T, tw);
+  const bool swapped = (Z != A);   // same for every column
+  for (int q = threadIdx.x; q < CB * N; q += blockDim.x) {
+    const int c2 = q % CB, j = q / CB;
+    if (m0 + c2 < ncols) { const cpx v = base[(size_t)c2 * 2 * ld + (swapped ? ld : 0) + j]; pc[(g.ix(0, j + 1, k) >> 1) + m0 + c2] = make_double2(v.x, v.y); }
+  }
+  (void)rowc;
+}
+
+// ------------------------------------------------------------------------------------------ z pass (solver.f90:82-179)
+// VT = double2: spectral pairs (re,im) of mode m in row j; VT = double: real field columns i=1..n1.
+template <typename VT> __device__ inline VT vmul(VT a, double s);
+template <> __device__ inline double2 vmul<double2>(double2 a, double s) { return make_double2(a.x * s, a.y * s); }
+template <> __device__ inline double vmul<double>(double a, double s) { return a * s; }
+template <typename VT> __device__ inline VT vfms(VT a, double s, VT b);   // a - s*b
+template <> __device__ inline double2 vfms<double2>(double2 a, double s, double2 b) { return make_double2(a.x - s * b.x, a.y - s * b.y); }
+template <> __device__ inline double vfms<double>(double a, double s, double b) { return a - s * b; }
+template <typename VT> __device__ inline VT vfma(VT a, double s, VT b);   // a + s*b
+template <> __device__ inline double2 vfma<double2>(double2 a, double s, double2 b) { return make_double2(a.x + s * b.x, a.y + s * b.y); }
+template <> __device__ inline double vfma<double>(double a, double s, double b) { return a + s * b; }
+
+template <typename VT, int PERIODIC>
+__global__ __launch_bounds__(256) void k_gaussel(Geom g, int nz, int ncol, int i0, const double *__restrict__ a, const double *__restrict__ b,
+                                                 const double *__restrict__ c, const double *__restrict__ lamx,
+                                                 const double *__restrict__ lamy, double *__restrict__ pd, double *__restrict__ dscr,
+                                                 double *__restrict__ p2scr) {
+  const int m = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y + 1;
+  if (m >= ncol || j > g.n2) return;
+  constexpr int W = sizeof(VT) / sizeof(double);
+  VT *p = reinterpret_cast<VT *>(pd);
+  const size_t e0 = (g.ix(0, j, 1)) / W + m + i0;            // element index of k=1 in units of VT
+  const size_t st = (size_t)g.s12 / W;
+  const size_t s0 = (size_t)m + (size_t)ncol * (size_t)(j - 1), sst = (size_t)ncol * g.n2;   // scratch [k][j][m]
+  const double lam = (lamx ? lamx[m] : 0.) + (lamy ? lamy[j - 1 + g.jlo] : 0.);
+  const int n = PERIODIC ? nz - 1 : nz;
+  // forward elimination
+  double z = 1. / (b[0] + lam + CALES_EPS), d = c[0] * z;
+  VT v = vmul(p[e0], z);
+  p[e0] = v; dscr[s0] = d;
+  double v2 = 0.;
+  if (PERIODIC) { v2 = (n == 1 ? -c[0] : -a[0]) * z; p2scr[s0] = v2; }
+  for (int l = 1; l < n; ++l) {
+    const double bb = b[l] + lam;
+    z = 1. / (bb - a[l] * d + CALES_EPS);
+    d = c[l] * z;
+    v = vmul(vfms(p[e0 + l * st], a[l], v), z);
+    p[e0 + l * st] = v; dscr[s0 + l * sst] = d;
+    if (PERIODIC) { const double r2 = (l == n - 1) ? -c[n - 1] : 0.; v2 = (r2 - a[l] * v2) * z; p2scr[s0 + l * sst] = v2; }
+  }
+  // back substitution
+  for (int l = n - 2; l >= 0; --l) {
+    v = vfms(p[e0 + l * st], dscr[s0 + l * sst], v);
+    p[e0 + l * st] = v;
+    if (PERIODIC) { v2 = p2scr[s0 + l * sst] - dscr[s0 + l * sst] * v2; p2scr[s0 + l * sst] = v2; }
+  }
+  if (PERIODIC) {   // solver.f90:124-133
+    const VT p11 = p[e0], p1n = p[e0 + (size_t)(n - 1) * st];
+    const double p21 = p2scr[s0], p2n = p2scr[s0 + (size_t)(n - 1) * sst];
+    const double den = (b[nz - 1] + lam) + c[nz - 1] * p21 + a[nz - 1] * p2n + CALES_EPS;
+    VT pn = vfms(vfms(p[e0 + (size_t)(nz - 1) * st], c[nz - 1], p11), a[nz - 1], p1n);
+    pn = vmul(pn, 1. / den);
+    p[e0 + (size_t)(nz - 1) * st] = pn;
+    for (int l = 0; l < n; ++l) p[e0 + l * st] = vfma(p[e0 + l * st], p2scr[s0 + l * sst], pn);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+struct SolverPlans { FftPlan px, py; int Rx, CBy; size_t shx, shy; };
+struct PlanSlot { cales_ctx *ctx; SolverPlans sp; };
+static std::vector<PlanSlot> g_slots;
+static SolverPlans *find_plans(cales_ctx *c) { for (auto &s : g_slots) if (s.ctx == c) return &s.sp; return nullptr; }
+
+int solver_setup(cales_ctx *c) {
+  const int *n = c->n; const int n1 = c->C.ng[0], n2g = c->C.ng[1], n3 = n[2];
+  const std::string bx = std::string(1, c->C.cbcpre[0]) + c->C.cbcpre[1], by = std::string(1, c->C.cbcpre[2]) + c->C.cbcpre[3];
+  if (bx != "PP" || by != "PP") { c->err = "solver: only periodic x and y pressure BCs are provided by the device path in this build"; return 1; }
+  if (c->C.nranks != 1) { c->err = "solver: multi-rank transposes not built yet"; return 1; }
+  SolverPlans sp;
+  if (!make_plan(n1 / 2, sp.px) || !make_plan(n2g, sp.py)) { c->err = "solver: ng(1)/2 and ng(2) must factor into 2,3,5"; return 1; }
+  // rows per block in x: aim at ~nh/4 threads per row, 256 threads per block
+  { int T = std::max(1, std::min(256, (n1 / 2) / 4)); int p2 = 1; while (p2 * 2 <= T) p2 *= 2; T = p2; sp.Rx = 256 / T; }
+  sp.shx = (size_t)sp.Rx * 2 * (n1 / 2 + 1) * sizeof(cpx);
+  while (sp.shx > 60 * 1024 && sp.Rx > 1) { sp.Rx /= 2; sp.shx = (size_t)sp.Rx * 2 * (n1 / 2 + 1) * sizeof(cpx); }
+  sp.CBy = 8;
+  sp.shy = (size_t)sp.CBy * 2 * (n2g + 1) * sizeof(cpx);
+  while (sp.shy > 60 * 1024 && sp.CBy > 1) { sp.CBy /= 2; sp.shy = (size_t)sp.CBy * 2 * (n2g + 1) * sizeof(cpx); }
+  if (sp.shx > 64 * 1024 || sp.shy > 64 * 1024) { c->err = "solver: line too long for the LDS-resident transform"; return 1; }
+  // eigenvalues (initsolver.f90:66-98); x: modes 0..n1/2 (half-complex symmetry), y: modes 0..n2-1
+  std::vector<double> lx(n1), ly(n2g);
+  hs_eigenvalues(n1, "PP", 'c', lx.data()); hs_eigenvalues(n2g, "PP", 'c', ly.data());
+  for (auto &v : lx) v = v * (c->dli[0] * c->dli[0]);
+  for (auto &v : ly) v = v * (c->dli[1] * c->dli[1]);
+  const int mh = n1 / 2 + 1;
+  HIPCHK(c, hipMalloc(&c->d_lamx, mh * sizeof(double))); HIPCHK(c, hipMalloc(&c->d_lamy, n2g * sizeof(double)));
+  HIPCHK(c, hipMemcpy(c->d_lamx, lx.data(), mh * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_lamy, ly.data(), n2g * sizeof(double), hipMemcpyHostToDevice));
+  // tridiagonal (initsolver.f90:127-169), pressure: cell-centred
+  std::vector<double> a(n3), b(n3), cc(n3);
+  hs_tridmatrix(&c->C.cbcpre[4], n3, c->dzci.data(), c->dzfi.data(), 'c', a.data(), b.data(), cc.data());
+  HIPCHK(c, hipMalloc(&c->d_a, n3 * sizeof(double))); HIPCHK(c, hipMalloc(&c->d_b, n3 * sizeof(double))); HIPCHK(c, hipMalloc(&c->d_c, n3 * sizeof(double)));
+  HIPCHK(c, hipMemcpy(c->d_a, a.data(), n3 * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_b, b.data(), n3 * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_c, cc.data(), n3 * sizeof(double), hipMemcpyHostToDevice));
+  c->normfft = 1. / ((double)n1 * (double)n2g);             // fft.f90:99,136,142 with norm = [1,0] twice
+  // twiddles: exp(-2 pi i q/N)
+  auto mk = [&](int N, int cnt, double **dev) -> int {
+    std::vector<double> t(2 * (size_t)cnt);
+    const double pi = std::acos(-1.0);
+    for (int q = 0; q < cnt; ++q) { const double ang = -2. * pi * q / N; t[2 * q] = std::cos(ang); t[2 * q + 1] = std::sin(ang); }
+    HIPCHK(c, hipMalloc(dev, t.size() * sizeof(double)));
+    HIPCHK(c, hipMemcpy(*dev, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+  };
+  if (mk(n1 / 2, n1 / 2, &c->d_twx)) return 1;
+  if (mk(n1, n1 / 2 + 1, &c->d_twx_post)) return 1;
+  if (mk(n2g, n2g, &c->d_twy)) return 1;
+  if (c->C.impdiff == 2)
+    for (int iv = 0; iv < 3; ++iv) {
+      hs_tridmatrix(&c->cbcvel[6 * iv + 4], n3, c->dzci.data(), c->dzfi.data(), iv == 2 ? 'f' : 'c', a.data(), b.data(), cc.data());
+      HIPCHK(c, hipMalloc(&c->d_av[iv], 3 * n3 * sizeof(double)));   // a | b | c (unscaled); scaled copies follow
+      c->d_bv[iv] = c->d_av[iv] + n3; c->d_cv[iv] = c->d_av[iv] + 2 * n3;
+      HIPCHK(c, hipMemcpy(c->d_av[iv], a.data(), n3 * sizeof(double), hipMemcpyHostToDevice));
+      HIPCHK(c, hipMemcpy(c->d_bv[iv], b.data(), n3 * sizeof(double), hipMemcpyHostToDevice));
+      HIPCHK(c, hipMemcpy(c->d_cv[iv], cc.data(), n3 * sizeof(double), hipMemcpyHostToDevice));
+    }
+  g_slots.push_back({c, sp});
+  return 0;
+}
+void solver_teardown(cales_ctx *c) {
+  for (size_t q = 0; q < g_slots.size(); ++q) if (g_slots[q].ctx == c) { g_slots.erase(g_slots.begin() + q); break; }
+  hipFree(c->d_lamx); hipFree(c->d_lamy); hipFree(c->d_a); hipFree(c->d_b); hipFree(c->d_c);
+  hipFree(c->d_twx); hipFree(c->d_twx_post); hipFree(c->d_twy);
+  for (int iv = 0; iv < 3; ++iv) hipFree(c->d_av[iv]);
+}
+
+int op_solver(cales_ctx *c) {
+  SolverPlans *sp = find_plans(c);
+  if (!sp) { c->err = "solver not initialised"; return 1; }
+  const int *n = c->n; double *pp = c->f[CALES_PP];
+  const int mh = c->g.s1 / 2;
+  const long nrows = (long)n[1] * n[2];
+  const bool periodic_z = CBP(c, 0, 3) == 'P' && CBP(c, 1, 3) == 'P';
+  { ProfScope ps(c, "fft_x_fwd");
+    hipLaunchKernelGGL(k_fft_x<0>, dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
+                       (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, pp, 1.); }
+  { ProfScope ps(c, "fft_y_fwd");
+    hipLaunchKernelGGL(k_fft_y<0>, dim3((mh + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, mh, (const cpx *)c->d_twy, pp); }
+  { ProfScope ps(c, "gaussel_z");
+    dim3 b(64, 4), gr((mh + 63) / 64, (n[1] + 3) / 4);
+    if (periodic_z) hipLaunchKernelGGL((k_gaussel<double2, 1>), gr, b, 0, c->stream, c->g, n[2], mh, 0, c->d_a, c->d_b, c->d_c, c->d_lamx, c->d_lamy, pp, c->scr1, c->scr2);
+    else hipLaunchKernelGGL((k_gaussel<double2, 0>), gr, b, 0, c->stream, c->g, n[2], mh, 0, c->d_a, c->d_b, c->d_c, c->d_lamx, c->d_lamy, pp, c->scr1, c->scr2); }
+  { ProfScope ps(c, "fft_y_bwd");
+    hipLaunchKernelGGL(k_fft_y<1>, dim3((mh + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, mh, (const cpx *)c->d_twy, pp); }
+  { ProfScope ps(c, "fft_x_bwd");
+    hipLaunchKernelGGL(k_fft_x<1>, dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
+                       (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, pp, c->normfft); }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// z-implicit Helmholtz solve of one velocity component (solver.f90:182-233 with aa,bb,cc of main.f90:435-437)
+__global__ void k_scale_abc(int n, double alpha, const double *a, const double *b, const double *c, double *aa, double *bb, double *cc) {
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k < n) { aa[k] = a[k] * alpha; bb[k] = b[k] * alpha + 1.; cc[k] = c[k] * alpha; }
+}
+int op_rhs_b_velz(cales_ctx *c, int ivel, double alpha);
+int op_helmholtz_z(cales_ctx *c, int ivel, double alpha) {
+  if (c->C.impdiff != 2) { c->err = "helmholtz_z needs impdiff = 2"; return 1; }
+  ProfScope ps(c, "helmholtz_z");
+  const int *n = c->n; const int n3 = n[2];
+  if (int e = op_rhs_b_velz(c, ivel, alpha)) return e;
+  double *abc = c->d_red + 64 + 16 * (n3 + 2);     // scaled coefficients live behind the reduction partials
+  hipLaunchKernelGGL(k_scale_abc, dim3((n3 + 63) / 64), dim3(64), 0, c->stream, n3, alpha, c->d_av[ivel - 1], c->d_bv[ivel - 1], c->d_cv[ivel - 1], abc, abc + n3, abc + 2 * n3);
+  const char *bcz = &c->cbcvel[6 * (ivel - 1) + 4];
+  const int q = (ivel == 3 && bcz[1] == 'D') ? 1 : 0;
+  const bool periodic = bcz[0] == 'P' && bcz[1] == 'P';
+  dim3 b(64, 4), gr((n[0] + 63) / 64, (n[1] + 3) / 4);
+  double *fld = c->f[CALES_U + ivel - 1];
+  if (periodic) hipLaunchKernelGGL((k_gaussel<double, 1>), gr, b, 0, c->stream, c->g, n3 - q, n[0], 1, abc, abc + n3, abc + 2 * n3, (const double *)nullptr, (const double *)nullptr, fld, c->scr1, c->scr2);
+  else hipLaunchKernelGGL((k_gaussel<double, 0>), gr, b, 0, c->stream, c->g, n3 - q, n[0], 1, abc, abc + n3, abc + 2 * n3, (const double *)nullptr, (const double *)nullptr, fld, c->scr1, c->scr2);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,404 @@
+// Stencil / streaming kernels of the RK substep and of the projection:
+//   mom_xyz_ad (src/mom.f90:17-309), RK update (src/rk.f90:77-119), bulk forcing (src/mom.f90:311-335,
+//   src/utils.f90:16-47), fillps (src/fillps.f90), correc (src/correc.f90), updatep (src/updatep.f90),
+//   chkdt (src/chkdt.f90), chkdiv (src/chkdiv.f90).
+// Layout: x contiguous, one thread per cell, 64 lanes along x (coalesced 512-B wavefront rows).
+// All are HBM-bound; no MFMA on this path.
+#include "common.hpp"
+
+#define BX 64
+#define BY 4
+
+__constant__ double c_rk[3][2] = {{32. / 60., 0.}, {25. / 60., -17. / 60.}, {45. / 60., -25. / 60.}};
+
+// ------------------------------------------------------------------------------------------ mom_xyz_ad
+template <int IMP>
+__global__ __launch_bounds__(BX *BY) void k_mom(Geom g, const double *__restrict__ u, const double *__restrict__ v,
+                                                 const double *__restrict__ w, const double *__restrict__ s,
+                                                 const double *__restrict__ dzci, const double *__restrict__ dzfi, double dxi,
+                                                 double dyi, double visc, double *__restrict__ dudt, double *__restrict__ dvdt,
+                                                 double *__restrict__ dwdt, double *__restrict__ dudtd,
+                                                 double *__restrict__ dvdtd, double *__restrict__ dwdtd) {
+  const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;
+  if (i > g.n1 || j > g.n2) return;
+  const size_t c = g.ix(i, j, k);
+  const long sj = g.s1, sk = g.s12;
+#define LD(a, di, dj, dk) a[c + (di) + (dj)*sj + (dk)*sk]
+  const double u_ccm = LD(u, 0, 0, -1), u_pcm = LD(u, 1, 0, -1), u_cpm = LD(u, 0, 1, -1), u_cmc = LD(u, 0, -1, 0),
+               u_mcc = LD(u, -1, 0, 0), u_ccc = LD(u, 0, 0, 0), u_pcc = LD(u, 1, 0, 0), u_mpc = LD(u, -1, 1, 0),
+               u_cpc = LD(u, 0, 1, 0), u_mcp = LD(u, -1, 0, 1), u_ccp = LD(u, 0, 0, 1);
+  const double v_ccm = LD(v, 0, 0, -1), v_cpm = LD(v, 0, 1, -1), v_cmc = LD(v, 0, -1, 0), v_pmc = LD(v, 1, -1, 0),
+               v_mcc = LD(v, -1, 0, 0), v_ccc = LD(v, 0, 0, 0), v_pcc = LD(v, 1, 0, 0), v_cpc = LD(v, 0, 1, 0),
+               v_cmp = LD(v, 0, -1, 1), v_ccp = LD(v, 0, 0, 1);
+  const double w_ccm = LD(w, 0, 0, -1), w_pcm = LD(w, 1, 0, -1), w_cpm = LD(w, 0, 1, -1), w_cmc = LD(w, 0, -1, 0),
+               w_mcc = LD(w, -1, 0, 0), w_ccc = LD(w, 0, 0, 0), w_pcc = LD(w, 1, 0, 0), w_cpc = LD(w, 0, 1, 0),
+               w_ccp = LD(w, 0, 0, 1);
+  const double s_ccm = LD(s, 0, 0, -1), s_pcm = LD(s, 1, 0, -1), s_cpm = LD(s, 0, 1, -1), s_cmc = LD(s, 0, -1, 0),
+               s_pmc = LD(s, 1, -1, 0), s_mcc = LD(s, -1, 0, 0), s_ccc = LD(s, 0, 0, 0), s_pcc = LD(s, 1, 0, 0),
+               s_mpc = LD(s, -1, 1, 0), s_cpc = LD(s, 0, 1, 0), s_cmp = LD(s, 0, -1, 1), s_mcp = LD(s, -1, 0, 1),
+               s_ccp = LD(s, 0, 0, 1), s_ppc = LD(s, 1, 1, 0), s_pcp = LD(s, 1, 0, 1), s_cpp = LD(s, 0, 1, 1);
+#undef LD
+  const double dzci_k = dzci[k], dzci_m = dzci[k - 1], dzfi_k = dzfi[k], dzfi_p = dzfi[k + 1];
+  double visc_ip, visc_im, visc_jp, visc_jm, visc_kp, visc_km;
+  // ---- x momentum (mom.f90:143-186)
+  visc_ip = s_pcc; visc_im = s_ccc;
+  visc_jp = 0.25 * (s_ccc + s_pcc + s_cpc + s_ppc); visc_jm = 0.25 * (s_ccc + s_pcc + s_cmc + s_pmc);
+  visc_kp = 0.25 * (s_ccc + s_pcc + s_ccp + s_pcp); visc_km = 0.25 * (s_ccc + s_pcc + s_ccm + s_pcm);
+  const double dudx_ip = (u_pcc - u_ccc) * dxi, dudx_im = (u_ccc - u_mcc) * dxi, dudy_jp = (u_cpc - u_ccc) * dyi,
+               dudy_jm = (u_ccc - u_cmc) * dyi, dudz_kp = (u_ccp - u_ccc) * dzci_k, dudz_km = (u_ccc - u_ccm) * dzci_m;
+  const double dvdx_jp = (v_pcc - v_ccc) * dxi, dvdx_jm = (v_pmc - v_cmc) * dxi, dwdx_kp = (w_pcc - w_ccc) * dxi,
+               dwdx_km = (w_pcm - w_ccm) * dxi;
+  const double uu_ip = 0.25 * (u_pcc + u_ccc) * (u_ccc + u_pcc), uu_im = 0.25 * (u_mcc + u_ccc) * (u_ccc + u_mcc),
+               vu_jp = 0.25 * (v_pcc + v_ccc) * (u_ccc + u_cpc), vu_jm = 0.25 * (v_pmc + v_cmc) * (u_ccc + u_cmc),
+               wu_kp = 0.25 * (w_pcc + w_ccc) * (u_ccc + u_ccp), wu_km = 0.25 * (w_pcm + w_ccm) * (u_ccc + u_ccm);
+  const double dudtd_xy = visc * (dudx_ip - dudx_im) * dxi + visc * (dudy_jp - dudy_jm) * dyi;
+  const double dudtd_z = visc * (dudz_kp - dudz_km) * dzfi_k;
+  double dudt_s = -(uu_ip - uu_im) * dxi - (vu_jp - vu_jm) * dyi - (wu_kp - wu_km) * dzfi_k +
+                  (visc_ip * (dudx_ip + dudx_ip) - visc_im * (dudx_im + dudx_im)) * dxi +
+                  (visc_jp * (dudy_jp + dvdx_jp) - visc_jm * (dudy_jm + dvdx_jm)) * dyi +
+                  (visc_kp * (dudz_kp + dwdx_kp) - visc_km * (dudz_km + dwdx_km)) * dzfi_k;
+  // ---- y momentum (mom.f90:188-231)
+  visc_ip = 0.25 * (s_ccc + s_cpc + s_pcc + s_ppc); visc_im = 0.25 * (s_ccc + s_cpc + s_mcc + s_mpc);
+  visc_jp = s_cpc; visc_jm = s_ccc;
+  visc_kp = 0.25 * (s_ccc + s_cpc + s_ccp + s_cpp); visc_km = 0.25 * (s_ccc + s_cpc + s_ccm + s_cpm);
+  const double dvdx_ip = (v_pcc - v_ccc) * dxi, dvdx_im = (v_ccc - v_mcc) * dxi, dvdy_jp = (v_cpc - v_ccc) * dyi,
+               dvdy_jm = (v_ccc - v_cmc) * dyi, dvdz_kp = (v_ccp - v_ccc) * dzci_k, dvdz_km = (v_ccc - v_ccm) * dzci_m;
+  const double dudy_ip = (u_cpc - u_ccc) * dyi, dudy_im = (u_mpc - u_mcc) * dyi, dwdy_kp = (w_cpc - w_ccc) * dyi,
+               dwdy_km = (w_cpm - w_ccm) * dyi;
+  const double uv_ip = 0.25 * (u_ccc + u_cpc) * (v_ccc + v_pcc), uv_im = 0.25 * (u_mcc + u_mpc) * (v_ccc + v_mcc),
+               vv_jp = 0.25 * (v_ccc + v_cpc) * (v_ccc + v_cpc), vv_jm = 0.25 * (v_ccc + v_cmc) * (v_ccc + v_cmc),
+               wv_kp = 0.25 * (w_ccc + w_cpc) * (v_ccc + v_ccp), wv_km = 0.25 * (w_ccm + w_cpm) * (v_ccc + v_ccm);
+  const double dvdtd_xy = visc * (dvdx_ip - dvdx_im) * dxi + visc * (dvdy_jp - dvdy_jm) * dyi;
+  const double dvdtd_z = visc * (dvdz_kp - dvdz_km) * dzfi_k;
+  double dvdt_s = -(uv_ip - uv_im) * dxi - (vv_jp - vv_jm) * dyi - (wv_kp - wv_km) * dzfi_k +
+                  (visc_ip * (dvdx_ip + dudy_ip) - visc_im * (dvdx_im + dudy_im)) * dxi +
+                  (visc_jp * (dvdy_jp + dvdy_jp) - visc_jm * (dvdy_jm + dvdy_jm)) * dyi +
+                  (visc_kp * (dvdz_kp + dwdy_kp) - visc_km * (dvdz_km + dwdy_km)) * dzfi_k;
+  // ---- z momentum (mom.f90:233-276)
+  visc_ip = 0.25 * (s_ccc + s_ccp + s_pcc + s_pcp); visc_im = 0.25 * (s_ccc + s_ccp + s_mcc + s_mcp);
+  visc_jp = 0.25 * (s_ccc + s_ccp + s_cpc + s_cpp); visc_jm = 0.25 * (s_ccc + s_ccp + s_cmc + s_cmp);
+  visc_kp = s_ccp; visc_km = s_ccc;
+  const double dwdx_ip = (w_pcc - w_ccc) * dxi, dwdx_im = (w_ccc - w_mcc) * dxi, dwdy_jp = (w_cpc - w_ccc) * dyi,
+               dwdy_jm = (w_ccc - w_cmc) * dyi, dwdz_kp = (w_ccp - w_ccc) * dzfi_p, dwdz_km = (w_ccc - w_ccm) * dzfi_k;
+  const double dudz_ip = (u_ccp - u_ccc) * dzci_k, dudz_im = (u_mcp - u_mcc) * dzci_k, dvdz_jp = (v_ccp - v_ccc) * dzci_k,
+               dvdz_jm = (v_cmp - v_cmc) * dzci_k;
+  const double uw_ip = 0.25 * (u_ccc + u_ccp) * (w_ccc + w_pcc), uw_im = 0.25 * (u_mcc + u_mcp) * (w_ccc + w_mcc),
+               vw_jp = 0.25 * (v_ccc + v_ccp) * (w_ccc + w_cpc), vw_jm = 0.25 * (v_cmc + v_cmp) * (w_ccc + w_cmc),
+               ww_kp = 0.25 * (w_ccc + w_ccp) * (w_ccc + w_ccp), ww_km = 0.25 * (w_ccc + w_ccm) * (w_ccc + w_ccm);
+  const double dwdtd_xy = visc * (dwdx_ip - dwdx_im) * dxi + visc * (dwdy_jp - dwdy_jm) * dyi;
+  const double dwdtd_z = visc * (dwdz_kp - dwdz_km) * dzci_k;
+  double dwdt_s = -(uw_ip - uw_im) * dxi - (vw_jp - vw_jm) * dyi - (ww_kp - ww_km) * dzci_k +
+                  (visc_ip * (dwdx_ip + dudz_ip) - visc_im * (dwdx_im + dudz_im)) * dxi +
+                  (visc_jp * (dwdy_jp + dvdz_jp) - visc_jm * (dwdy_jm + dvdz_jm)) * dyi +
+                  (visc_kp * (dwdz_kp + dwdz_kp) - visc_km * (dwdz_km + dwdz_km)) * dzci_k;
+  if (IMP == 2) {          // _IMPDIFF_1D: mom.f90:278-284
+    dudt[c] = dudt_s + dudtd_xy; dvdt[c] = dvdt_s + dvdtd_xy; dwdt[c] = dwdt_s + dwdtd_xy;
+    dudtd[c] = dudtd_z; dvdtd[c] = dvdtd_z; dwdtd[c] = dwdtd_z;
+  } else {                 // explicit: mom.f90:297-302
+    dudt[c] = dudt_s + dudtd_xy + dudtd_z; dvdt[c] = dvdt_s + dvdtd_xy + dvdtd_z; dwdt[c] = dwdt_s + dwdtd_xy + dwdtd_z;
+  }
+}
+
+int op_mom(cales_ctx *c) {
+  ProfScope ps(c, "mom_xyz_ad");
+  dim3 b(BX, BY, 1), gr = grid3(c->n[0], c->n[1], c->n[2], b);
+  double **f = c->f;
+  if (c->C.impdiff == 2)
+    hipLaunchKernelGGL(k_mom<2>, gr, b, 0, c->stream, c->g, f[CALES_U], f[CALES_V], f[CALES_W], f[CALES_VISCT], c->d_dzci, c->d_dzfi,
+                       c->dli[0], c->dli[1], c->visc, f[CALES_DUDT], f[CALES_DVDT], f[CALES_DWDT], f[CALES_DUDTD], f[CALES_DVDTD], f[CALES_DWDTD]);
+  else
+    hipLaunchKernelGGL(k_mom<0>, gr, b, 0, c->stream, c->g, f[CALES_U], f[CALES_V], f[CALES_W], f[CALES_VISCT], c->d_dzci, c->d_dzfi,
+                       c->dli[0], c->dli[1], c->visc, f[CALES_DUDT], f[CALES_DVDT], f[CALES_DWDT], (double *)nullptr, (double *)nullptr, (double *)nullptr);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ RK update (rk.f90:77-94)
+template <int IMP>
+__global__ __launch_bounds__(BX *BY) void k_rk_update(Geom g, double f1, double f2, double f12, double dxi, double dyi, double bfx,
+                                                       double bfy, double bfz, const double *__restrict__ dzci,
+                                                       const double *__restrict__ p, double *__restrict__ u, double *__restrict__ v,
+                                                       double *__restrict__ w, const double *__restrict__ du,
+                                                       const double *__restrict__ dv, const double *__restrict__ dw,
+                                                       const double *__restrict__ duo, const double *__restrict__ dvo,
+                                                       const double *__restrict__ dwo, const double *__restrict__ dud,
+                                                       const double *__restrict__ dvd, const double *__restrict__ dwd) {
+  const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;
+  if (i > g.n1 || j > g.n2) return;
+  const size_t c = g.ix(i, j, k);
+  const double pc = p[c];
+  double un = u[c] + f1 * du[c] + f2 * duo[c] + f12 * (bfx - dxi * (p[c + 1] - pc));
+  double vn = v[c] + f1 * dv[c] + f2 * dvo[c] + f12 * (bfy - dyi * (p[c + g.s1] - pc));
+  double wn = w[c] + f1 * dw[c] + f2 * dwo[c] + f12 * (bfz - dzci[k] * (p[c + g.s12] - pc));
+  if (IMP) { un = un + f12 * dud[c]; vn = vn + f12 * dvd[c]; wn = wn + f12 * dwd[c]; }
+  u[c] = un; v[c] = vn; w[c] = wn;
+}
+
+// Helmholtz r.h.s. (rk.f90:110-119)
+__global__ __launch_bounds__(BX *BY) void k_rk_imp_rhs(Geom g, double hf12, double *__restrict__ u, double *__restrict__ v,
+                                                        double *__restrict__ w, const double *__restrict__ dud,
+                                                        const double *__restrict__ dvd, const double *__restrict__ dwd) {
+  const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;
+  if (i > g.n1 || j > g.n2) return;
+  const size_t c = g.ix(i, j, k);
+  u[c] = u[c] - hf12 * dud[c]; v[c] = v[c] - hf12 * dvd[c]; w[c] = w[c] - hf12 * dwd[c];
+}
+
+// ------------------------------------------------------------------------------------------ deterministic reductions
+// stage 1: one partial per block over the interior; stage 2: one block folds the partials in index order.
+__device__ inline double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ inline double wave_max(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+  return v;
+}
+template <int OP>   // 0 sum, 1 max
+__device__ inline double block_reduce(double v, double *sh) {
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = (blockDim.x * blockDim.y + 63) >> 6;
+  v = OP ? wave_max(v) : wave_sum(v);
+  if (lane == 0) sh[wv] = v;
+  __syncthreads();
+  double r = 0.;
+  if (tid == 0) { r = sh[0]; for (int q = 1; q < nw; ++q) r = OP ? fmax(r, sh[q]) : r + sh[q]; }
+  __syncthreads();
+  return r;
+}
+
+// bulk_mean (utils.f90:35-44): sum p*grid_vol_ratio(k) over the interior
+__global__ __launch_bounds__(256) void k_bulk_mean_partial(Geom g, const double *__restrict__ p, const double *__restrict__ gvr,
+                                                           double *__restrict__ part) {
+  __shared__ double sh[4];
+  const int k = blockIdx.y + 1;
+  double acc = 0.;
+  const long nplane = (long)g.n1 * g.n2;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nplane; q += (long)gridDim.x * 256) {
+    const int i = (int)(q % g.n1) + 1, j = (int)(q / g.n1) + 1;
+    acc += p[g.ix(i, j, k)];
+  }
+  acc *= gvr[k];
+  const double r = block_reduce<0>(acc, sh);
+  if (threadIdx.x == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = r;
+}
+// out[slot] = op(partials); optional: f = velf - mean (rk.f90:209-221), dpdl += f (main.f90:492)
+__global__ __launch_bounds__(256) void k_fold(const double *__restrict__ part, int np, int op, double *__restrict__ out, int slot,
+                                              int mode, double velf, double *__restrict__ force, int comp) {
+  __shared__ double sh[4];
+  double acc = 0.;
+  for (int q = threadIdx.x; q < np; q += 256) acc = op ? fmax(acc, part[q]) : acc + part[q];
+  const double r = op ? block_reduce<1>(acc, sh) : block_reduce<0>(acc, sh);
+  if (threadIdx.x == 0) {
+    out[slot] = r;
+    if (mode == 1) { const double f = velf - r; force[comp] = f; force[3 + comp] += f; }
+  }
+}
+
+int op_bulk_mean_dev(cales_ctx *c, const double *p, int c_or_f, double *d_out) {
+  ProfScope ps(c, "bulk_mean");
+  const int nbx = 8;
+  dim3 gr(nbx, c->n[2]);
+  hipLaunchKernelGGL(k_bulk_mean_partial, gr, dim3(256), 0, c->stream, c->g, p, c_or_f ? c->d_gvr_f : c->d_gvr_c, c->d_red + 64);
+  hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, nbx * c->n[2], 0, d_out, 0, 0, 0., (double *)nullptr, 0);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+static int forcing_component(cales_ctx *c, int comp) {   // cmpt_bulk_forcing, rk.f90:197-222
+  const int nbx = 8;
+  dim3 gr(nbx, c->n[2]);
+  const double *p = c->f[CALES_U + comp];
+  hipLaunchKernelGGL(k_bulk_mean_partial, gr, dim3(256), 0, c->stream, c->g, p, comp == 2 ? c->d_gvr_c : c->d_gvr_f, c->d_red + 64);
+  hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, nbx * c->n[2], 0, c->d_red, 8 + comp, 1, c->C.velf[comp], c->d_force, comp);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+__global__ void k_zero_force(double *force) { if (threadIdx.x < 3) force[threadIdx.x] = 0.; }
+
+int op_rk(cales_ctx *c, int irk, double dt) {
+  static const double rk[3][2] = {{32. / 60., 0.}, {25. / 60., -17. / 60.}, {45. / 60., -25. / 60.}};   // param.f90:27-29
+  const double f1 = rk[irk - 1][0] * dt, f2 = rk[irk - 1][1] * dt, f12 = f1 + f2;
+  if (int e = op_mom(c)) return e;
+  double **f = c->f;
+  dim3 b(BX, BY, 1), gr = grid3(c->n[0], c->n[1], c->n[2], b);
+  {
+    ProfScope ps(c, "rk_update");
+    if (c->C.impdiff)
+      hipLaunchKernelGGL(k_rk_update<1>, gr, b, 0, c->stream, c->g, f1, f2, f12, c->dli[0], c->dli[1], c->C.bforce[0], c->C.bforce[1], c->C.bforce[2],
+                         c->d_dzci, f[CALES_P], f[CALES_U], f[CALES_V], f[CALES_W], f[CALES_DUDT], f[CALES_DVDT], f[CALES_DWDT],
+                         f[CALES_DUDTO], f[CALES_DVDTO], f[CALES_DWDTO], f[CALES_DUDTD], f[CALES_DVDTD], f[CALES_DWDTD]);
+    else
+      hipLaunchKernelGGL(k_rk_update<0>, gr, b, 0, c->stream, c->g, f1, f2, f12, c->dli[0], c->dli[1], c->C.bforce[0], c->C.bforce[1], c->C.bforce[2],
+                         c->d_dzci, f[CALES_P], f[CALES_U], f[CALES_V], f[CALES_W], f[CALES_DUDT], f[CALES_DVDT], f[CALES_DWDT],
+                         f[CALES_DUDTO], f[CALES_DVDTO], f[CALES_DWDTO], (double *)nullptr, (double *)nullptr, (double *)nullptr);
+  }
+  for (int q = 0; q < 3; ++q) std::swap(f[CALES_DUDT + q], f[CALES_DUDTO + q]);     // swap, rk.f90:98-100
+  hipLaunchKernelGGL(k_zero_force, dim3(1), dim3(64), 0, c->stream, c->d_force);
+  for (int q = 0; q < 3; ++q) if (c->C.is_forced[q]) if (int e = forcing_component(c, q)) return e;
+  if (c->C.impdiff) {
+    ProfScope ps(c, "rk_imp_rhs");
+    hipLaunchKernelGGL(k_rk_imp_rhs, gr, b, 0, c->stream, c->g, .5 * f12, f[CALES_U], f[CALES_V], f[CALES_W], f[CALES_DUDTD], f[CALES_DVDTD], f[CALES_DWDTD]);
+  }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// bulk_forcing (mom.f90:311-335): u += f, f read from device memory (no host round trip)
+__global__ __launch_bounds__(BX *BY) void k_bulk_forcing(Geom g, double *__restrict__ u, double *__restrict__ v, double *__restrict__ w,
+                                                          const double *__restrict__ force, int fx, int fy, int fz) {
+  const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;
+  if (i > g.n1 || j > g.n2) return;
+  const size_t c = g.ix(i, j, k);
+  if (fx) u[c] += force[0];
+  if (fy) v[c] += force[1];
+  if (fz) w[c] += force[2];
+}
+int op_bulk_forcing(cales_ctx *c) {
+  if (!(c->C.is_forced[0] || c->C.is_forced[1] || c->C.is_forced[2])) return 0;
+  ProfScope ps(c, "bulk_forcing");
+  dim3 b(BX, BY, 1), gr = grid3(c->n[0], c->n[1], c->n[2], b);
+  hipLaunchKernelGGL(k_bulk_forcing, gr, b, 0, c->stream, c->g, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W], c->d_force,
+                     c->C.is_forced[0], c->C.is_forced[1], c->C.is_forced[2]);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ fillps (fillps.f90:36-47)
+__global__ __launch_bounds__(BX *BY) void k_fillps(Geom g, double dti, double dtidxi, double dtidyi, const double *__restrict__ dzfi,
+                                                    const double *__restrict__ u, const double *__restrict__ v,
+                                                    const double *__restrict__ w, double *__restrict__ p) {
+  const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;
+  if (i > g.n1 || j > g.n2) return;
+  const size_t c = g.ix(i, j, k);
+  p[c] = ((w[c] - w[c - g.s12]) * dti * dzfi[k] + (v[c] - v[c - g.s1]) * dtidyi + (u[c] - u[c - 1]) * dtidxi);
+}
+int op_fillps(cales_ctx *c, double dti) {
+  ProfScope ps(c, "fillps");
+  dim3 b(BX, BY, 1), gr = grid3(c->n[0], c->n[1], c->n[2], b);
+  hipLaunchKernelGGL(k_fillps, gr, b, 0, c->stream, c->g, dti, dti * c->dli[0], dti * c->dli[1], c->d_dzfi, c->f[CALES_U], c->f[CALES_V],
+                     c->f[CALES_W], c->f[CALES_PP]);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ correc (correc.f90:44-67)
+// ranges include ghost planes: u: i=0..n1, j,k=0..n+1; v: j=0..n2; w: k=0..n3
+__global__ __launch_bounds__(BX *BY) void k_correc(Geom g, double fi, double fj, double dt, const double *__restrict__ dzci,
+                                                    const double *__restrict__ p, double *__restrict__ u, double *__restrict__ v,
+                                                    double *__restrict__ w) {
+  const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y, k = blockIdx.z;
+  if (i > g.n1 + 1 || j > g.n2 + 1) return;
+  const size_t c = g.ix(i, j, k);
+  const double pc = p[c];
+  if (i <= g.n1) u[c] = u[c] - fi * (p[c + 1] - pc);
+  if (j <= g.n2) v[c] = v[c] - fj * (p[c + g.s1] - pc);
+  if (k <= g.n3) w[c] = w[c] - dt * dzci[k] * (p[c + g.s12] - pc);
+}
+int op_correc(cales_ctx *c, double dt) {
+  ProfScope ps(c, "correc");
+  dim3 b(BX, BY, 1), gr = grid3(c->n[0] + 2, c->n[1] + 2, c->n[2] + 2, b);
+  hipLaunchKernelGGL(k_correc, gr, b, 0, c->stream, c->g, dt * c->dli[0], dt * c->dli[1], dt, c->d_dzci, c->f[CALES_PP], c->f[CALES_U],
+                     c->f[CALES_V], c->f[CALES_W]);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ updatep (updatep.f90:30-47)
+template <int IMP>
+__global__ __launch_bounds__(BX *BY) void k_updatep(Geom g, double alpha, const double *__restrict__ dzci, const double *__restrict__ dzfi,
+                                                     const double *__restrict__ pp, double *__restrict__ p) {
+  const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;
+  if (i > g.n1 || j > g.n2) return;
+  const size_t c = g.ix(i, j, k);
+  if (IMP == 0) p[c] = p[c] + pp[c];
+  else p[c] = p[c] + pp[c] + alpha * (((pp[c + g.s12] - pp[c]) * dzci[k] - (pp[c] - pp[c - g.s12]) * dzci[k - 1]) * dzfi[k]);
+}
+int op_updatep(cales_ctx *c, double alpha) {
+  ProfScope ps(c, "updatep");
+  dim3 b(BX, BY, 1), gr = grid3(c->n[0], c->n[1], c->n[2], b);
+  if (c->C.impdiff == 2) hipLaunchKernelGGL(k_updatep<2>, gr, b, 0, c->stream, c->g, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], c->f[CALES_P]);
+  else hipLaunchKernelGGL(k_updatep<0>, gr, b, 0, c->stream, c->g, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], c->f[CALES_P]);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ chkdiv (chkdiv.f90:35-47)
+__global__ __launch_bounds__(256) void k_chkdiv_partial(Geom g, double dxi, double dyi, const double *__restrict__ dzfi,
+                                                        const double *__restrict__ u, const double *__restrict__ v,
+                                                        const double *__restrict__ w, double *__restrict__ psum, double *__restrict__ pmax) {
+  __shared__ double sh[4];
+  const int k = blockIdx.y + 1;
+  double acc = 0., mx = 0.;
+  const long nplane = (long)g.n1 * g.n2;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nplane; q += (long)gridDim.x * 256) {
+    const int i = (int)(q % g.n1) + 1, j = (int)(q / g.n1) + 1;
+    const size_t c = g.ix(i, j, k);
+    const double div = (w[c] - w[c - g.s12]) * dzfi[k] + (v[c] - v[c - g.s1]) * dyi + (u[c] - u[c - 1]) * dxi;
+    mx = fmax(mx, fabs(div)); acc += div;
+  }
+  const double rs = block_reduce<0>(acc, sh), rm = block_reduce<1>(mx, sh);
+  if (threadIdx.x == 0) { const size_t o = (size_t)blockIdx.y * gridDim.x + blockIdx.x; psum[o] = rs; pmax[o] = rm; }
+}
+int op_chkdiv(cales_ctx *c, double *divtot, double *divmax) {
+  const int nbx = 8, np = nbx * c->n[2];
+  hipLaunchKernelGGL(k_chkdiv_partial, dim3(nbx, c->n[2]), dim3(256), 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzfi, c->f[CALES_U],
+                     c->f[CALES_V], c->f[CALES_W], c->d_red + 64, c->d_red + 64 + np);
+  hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, np, 0, c->d_red, 0, 0, 0., (double *)nullptr, 0);
+  hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64 + np, np, 1, c->d_red, 1, 0, 0., (double *)nullptr, 0);
+  HIPCHK(c, hipMemcpyAsync(c->h_red, c->d_red, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *divtot = c->h_red[0]; *divmax = c->h_red[1];
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ chkdt (chkdt.f90:50-98)
+template <int IMP>
+__global__ __launch_bounds__(256) void k_chkdt_partial(Geom g, double dxi, double dyi, double visc, const double *__restrict__ dzci,
+                                                       const double *__restrict__ dzfi, const double *__restrict__ s,
+                                                       const double *__restrict__ u, const double *__restrict__ v,
+                                                       const double *__restrict__ w, double *__restrict__ pa, double *__restrict__ pd) {
+  __shared__ double sh[4];
+  const int k = blockIdx.y + 1;
+  const double dl2i = dxi * dxi + dyi * dyi, zf2 = dzfi[k] * dzfi[k], zc2 = dzci[k] * dzci[k];
+  double dti = 0., dtid = 0.;
+  const long nplane = (long)g.n1 * g.n2, sj = g.s1, sk = g.s12;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nplane; q += (long)gridDim.x * 256) {
+    const int i = (int)(q % g.n1) + 1, j = (int)(q / g.n1) + 1;
+    const size_t c = g.ix(i, j, k);
+    const double ux = fabs(u[c]), vx = 0.25 * fabs(v[c] + v[c - sj] + v[c + 1] + v[c + 1 - sj]),
+                 wx = 0.25 * fabs(w[c] + w[c - sk] + w[c + 1] + w[c + 1 - sk]);
+    const double uy = 0.25 * fabs(u[c] + u[c + sj] + u[c - 1 + sj] + u[c - 1]), vy = fabs(v[c]),
+                 wy = 0.25 * fabs(w[c] + w[c + sj] + w[c + sj - sk] + w[c - sk]);
+    const double uz = 0.25 * fabs(u[c] + u[c - 1] + u[c - 1 + sk] + u[c + sk]), vz = 0.25 * fabs(v[c] + v[c - sj] + v[c - sj + sk] + v[c + sk]),
+                 wz = fabs(w[c]);
+    const double dtix = ux * dxi + vx * dyi + wx * dzfi[k], dtiy = uy * dxi + vy * dyi + wy * dzfi[k], dtiz = uz * dxi + vz * dyi + wz * dzci[k];
+    dti = fmax(fmax(fmax(dti, dtix), dtiy), dtiz);
+    const double viscx = 0.5 * (s[c] + s[c + 1]), viscy = 0.5 * (s[c] + s[c + sj]), viscz = 0.5 * (s[c] + s[c + sk]);
+    double dtidx = viscx * (dl2i + zf2), dtidy = viscy * (dl2i + zf2), dtidz = viscz * (dl2i + zc2);
+    dtidx += visc * dl2i; dtidy += visc * dl2i; dtidz += visc * dl2i;
+    if (IMP == 0) { dtidx += visc * zf2; dtidy += visc * zf2; dtidz += visc * zc2; }
+    dtid = fmax(fmax(fmax(dtid, dtidx), dtidy), dtidz);
+  }
+  const double ra = block_reduce<1>(dti, sh), rd = block_reduce<1>(dtid, sh);
+  if (threadIdx.x == 0) { const size_t o = (size_t)blockIdx.y * gridDim.x + blockIdx.x; pa[o] = ra; pd[o] = rd; }
+}
+int op_chkdt(cales_ctx *c, double *dtmax) {
+  const int nbx = 8, np = nbx * c->n[2];
+  double **f = c->f;
+  if (c->C.impdiff == 2)
+    hipLaunchKernelGGL(k_chkdt_partial<2>, dim3(nbx, c->n[2]), dim3(256), 0, c->stream, c->g, 1. / c->dl[0], 1. / c->dl[1], c->visc, c->d_dzci,
+                       c->d_dzfi, f[CALES_VISCT], f[CALES_U], f[CALES_V], f[CALES_W], c->d_red + 64, c->d_red + 64 + np);
+  else
+    hipLaunchKernelGGL(k_chkdt_partial<0>, dim3(nbx, c->n[2]), dim3(256), 0, c->stream, c->g, 1. / c->dl[0], 1. / c->dl[1], c->visc, c->d_dzci,
+                       c->d_dzfi, f[CALES_VISCT], f[CALES_U], f[CALES_V], f[CALES_W], c->d_red + 64, c->d_red + 64 + np);
+  hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, np, 1, c->d_red, 0, 0, 0., (double *)nullptr, 0);
+  hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64 + np, np, 1, c->d_red, 1, 0, 0., (double *)nullptr, 0);
+  HIPCHK(c, hipMemcpyAsync(c->h_red, c->d_red, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double dti = c->h_red[0], dtid = c->h_red[1];
+  if (dti == 0.) dti = 1.;
+  if (dtid == 0.) dtid = CALES_EPS;
+  *dtmax = std::fmin(0.4125 / dtid, 1.732 / dti);
+  return 0;
+}

@@ -1,0 +1,104 @@
+/* cales.h -- C-ABI of the MI355X-native CaLES hot path (libcales_hip.so).
+ *
+ * Drop-in boundary: one entry per routine the reference driver calls inside its time loop
+ * (reference src/main.f90:417-507). A Fortran host binds these with ISO_C_BINDING
+ * (cales_amd/fortran/cales_c.f90). Plain pointers and sizes only.
+ *
+ * Conventions
+ *  - every entry returns 0 on success, non-zero on error (cales_last_error() gives the text);
+ *  - host fields are Fortran-ordered doubles WITH one halo cell, a(0:n1+1,0:n2+1,0:n3+1),
+ *    n = local sizes of the rank's y-slab (n = ng for one rank);
+ *  - all device work is queued on ONE HIP stream (the reference's single `async(1)` queue,
+ *    src/main.f90:368); entries that return scalars synchronise, the others do not.
+ */
+#ifndef CALES_H
+#define CALES_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The run-time image of input.nml (reference src/param.f90:37-76,95-119). Character and
+ * multi-dimensional entries keep Fortran storage order, so a Fortran host can pass its
+ * namelist variables unchanged: cbcvel(0:1,3,3) -> [side + 2*dir + 6*vel]. */
+typedef struct cales_case {
+  int32_t ng[3];          /* global grid */
+  double  l[3];
+  int32_t gtype; double gr;
+  double  visci;
+  char    cbcvel[18], cbcpre[6], cbcsgs[6];
+  double  bcvel[18], bcpre[6], bcsgs[6];
+  double  bforce[3]; int32_t is_forced[3]; double velf[3];
+  int32_t sgstype;        /* 0 'none', 1 'smag', 2 'dsmag'  (src/sgs.f90:61-153) */
+  int32_t lwm[6]; double hwm;
+  int32_t impdiff;        /* 0 explicit; 2 = _IMPDIFF + _IMPDIFF_1D (z-implicit). 1 (3-D implicit) is rejected */
+  int32_t nranks, rank;   /* y-slab decomposition: rank owns rows rank*ng2/nranks+1 ... */
+} cales_case;
+
+typedef struct cales_ctx cales_ctx;
+
+enum cales_field { CALES_U = 0, CALES_V = 1, CALES_W = 2, CALES_P = 3, CALES_PP = 4, CALES_VISCT = 5,
+                   CALES_DUDT = 6, CALES_DVDT = 7, CALES_DWDT = 8,      /* current RK r.h.s. (rk.f90 dudtrk)  */
+                   CALES_DUDTO = 9, CALES_DVDTO = 10, CALES_DWDTO = 11, /* previous RK r.h.s. (dudtrko)       */
+                   CALES_DUDTD = 12, CALES_DVDTD = 13, CALES_DWDTD = 14,/* implicit part (dudtrkd)            */
+                   CALES_NFIELDS = 15 };
+
+/* ---- host-only helpers (no GPU needed) -------------------------------------------------- */
+/* src/initgrid.f90:15  initgrid(gtype,n,gr,lz,dzc,dzf,zc,zf); arrays (0:n+1) */
+int cales_initgrid(int gtype, int n, double gr, double lz, double *dzc, double *dzf, double *zc, double *zf);
+/* src/initflow.f90:17  initflow(inivel,...,u,v,w,p): deterministic kinds only
+ * (zer uni cou poi iop pdc tgv tgw ant duc); global haloed host arrays; returns 2 for RNG-based kinds */
+int cales_initflow(const cales_case *c, const char *inivel, int is_wallturb, double *u, double *v, double *w, double *p);
+/* src/sanity.f90:33-67 rules restated; returns 0 if the case is accepted */
+int cales_check_case(const cales_case *c, char *msg, int msglen);
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* stream: a hipStream_t to queue on, or NULL to let the context create its own */
+int  cales_create(const cales_case *c, void *stream, cales_ctx **out);
+void cales_destroy(cales_ctx *ctx);
+const char *cales_last_error(const cales_ctx *ctx);    /* ctx may be NULL for create-time errors */
+int  cales_sync(cales_ctx *ctx);
+int  cales_local_size(const cales_ctx *ctx, int32_t n[3], int32_t lo[3]);
+
+/* host <-> device (src/main.f90:368 `enter data copyin(u,v,w,p)`, :576-607 `update self`) */
+int cales_upload_state(cales_ctx *ctx, const double *u, const double *v, const double *w, const double *p);
+int cales_download_state(cales_ctx *ctx, double *u, double *v, double *w, double *p, double *visct);
+int cales_set_field(cales_ctx *ctx, int field, const double *host);
+int cales_get_field(cales_ctx *ctx, int field, double *host);
+int cales_get_bcvel(cales_ctx *ctx, int ivel, double *x, double *y, double *z);  /* bcu/bcv/bcw planes (typedef.f90:10) */
+
+/* ---- operators, named after the reference routines they replace ------------------------- */
+int cales_bounduvw(cales_ctx *ctx, int is_updt_wm, int is_correc);          /* src/bound.f90:18   */
+int cales_boundp(cales_ctx *ctx, int field, int which);                     /* src/bound.f90:156; which 0 cbcpre/bcp, 1 cbcsgs/bcs */
+int cales_mom(cales_ctx *ctx);                                              /* src/mom.f90:17 -> CALES_DUDT.. */
+int cales_rk(cales_ctx *ctx, int irk, double dt);                           /* src/rk.f90:17 (forcing f stays on the device) */
+int cales_bulk_forcing(cales_ctx *ctx);                                     /* src/mom.f90:311    */
+int cales_get_forcing(cales_ctx *ctx, double f[3]);                         /* f of the last cales_rk (sync)  */
+int cales_bulk_mean(cales_ctx *ctx, int field, int c_or_f, double *mean);   /* src/utils.f90:16 (sync) */
+int cales_fillps(cales_ctx *ctx, double dtrki);                             /* src/fillps.f90:14  */
+int cales_updt_rhs_b(cales_ctx *ctx);                                       /* src/bound.f90:562, pressure r.h.s. */
+int cales_solver(cales_ctx *ctx);                                           /* src/solver.f90:20 on CALES_PP */
+int cales_helmholtz_z(cales_ctx *ctx, int ivel, double alpha);              /* main.f90:425-445: updt_rhs_b + solver_gaussel_z */
+int cales_correc(cales_ctx *ctx, double dtrk);                              /* src/correc.f90:14  */
+int cales_updatep(cales_ctx *ctx, double alpha);                            /* src/updatep.f90:14 */
+int cales_cmpt_sgs(cales_ctx *ctx);                                         /* src/sgs.f90:21     */
+int cales_chkdt(cales_ctx *ctx, double *dtmax);                             /* src/chkdt.f90:17 (sync) */
+int cales_chkdiv(cales_ctx *ctx, double *divtot, double *divmax);           /* src/chkdiv.f90:16 (sync) */
+
+/* one time step = 3 RK substeps in the order of src/main.f90:417-508; no host synchronisation */
+int cales_step(cales_ctx *ctx, double dt);
+int cales_get_dpdl(cales_ctx *ctx, double dpdl[3]);                         /* main.f90:492,508 (sync) */
+
+/* ---- measurement -------------------------------------------------------------------------- */
+/* When enabled, every kernel launch is bracketed by HIP events on the context's stream. */
+int cales_profile_enable(cales_ctx *ctx, int on);
+int cales_profile_reset(cales_ctx *ctx);
+int cales_profile_count(cales_ctx *ctx);
+int cales_profile_get(cales_ctx *ctx, int idx, char *name, int namelen, int64_t *calls, double *total_ms);
+/* algorithmic words (8 B) per cell per call of the named kernel group, for the roofline line */
+int cales_device_info(cales_ctx *ctx, char *name, int namelen, int64_t *hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

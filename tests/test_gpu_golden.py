@@ -1,0 +1,121 @@
+"""HIP hot path (through the C-ABI) against the golden vectors produced by the reference's own
+compiled operators. Same stage-by-stage replay as tests/test_oracle_golden.py: every operator is fed
+the golden input of its stage. FP64 tolerance 1e-13 relative (L-inf, scaled by the field maximum);
+the kernels keep the reference's expression order but are compiled with FMA contraction."""
+import numpy as np
+import pytest
+
+from tests.util import RK, F, load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-13
+DEVICE_CASES = ["tgv_ppp", "chan_smag_wm", "chan_smag", "chan_dsmag", "halfchan_imp1d"]   # periodic x,y (device transforms)
+
+
+def _hot(case):
+    from cales_amd.hotpath import HotPath
+    return HotPath(case)
+
+
+@pytest.mark.parametrize("name", DEVICE_CASES)
+def test_startup_and_substeps(name):
+    g, case = load_golden(name)
+    h = _hot(case)
+    imp = case.impdiff
+    h.upload(*(F(g["s0raw_" + k]) for k in "uvwp"))
+    h.bounduvw(True, False); h.boundp("p", 0)
+    for k in "uvwp":
+        assert relerr(h.get(k), g["s0_" + k]) < TOL, ("s0", k)
+    h.upload(*(F(g["s0_" + k]) for k in "uvwp"))
+    h.cmpt_sgs()
+    assert relerr(h.get("visct")[1:-1, 1:-1, 1:-1], g["s0_visct_nobc"][1:-1, 1:-1, 1:-1]) < (TOL if case.sgstype != "dsmag" else 1e-11)
+    h.set("visct", F(g["s0_visct_nobc"])); h.boundp("visct", 1)
+    assert relerr(h.get("visct"), g["s0_visct"]) < TOL
+    if np.any(case.lwm != 0):
+        for iv, nm in ((1, "bcu"), (2, "bcv"), (3, "bcw")):
+            for a, d in zip(h.bcvel_planes(iv), "xyz"):
+                ref = g[f"s0_{nm}_{d}"]
+                assert np.abs(a - ref).max() <= 1e-12 * max(1., np.abs(ref).max()), (nm, d)
+    h.set("visct", F(g["s0_visct"]))
+    assert abs(h.chkdt() / float(g["dt_cfl"]) - 1) < 1e-13
+    h.mom()
+    for fld, k in (("dudt", "dudt"), ("dvdt", "dvdt"), ("dwdt", "dwdt")) + ((("dudtd", "dudtd"), ("dvdtd", "dvdtd"), ("dwdtd", "dwdtd")) if imp else ()):
+        assert relerr(h.get(fld)[1:-1, 1:-1, 1:-1], g["m_" + k]) < TOL, k
+    assert abs(h.bulk_mean("u", "f") - float(g["mean_u_f"])) <= 1e-13 * max(1, abs(float(g["mean_u_f"])))
+    d0 = h.chkdiv()
+    assert abs(d0[1] / g["div0"][1] - 1) < 1e-12 and abs(d0[0] - g["div0"][0]) < 1e-11 * max(1, abs(g["div0"][0]))
+
+    dt = float(g["dt"])
+    prev = dict(u=g["s0_u"], v=g["s0_v"], w=g["s0_w"], p=g["s0_p"], visct=g["s0_visct"])
+    for irk in (1, 2, 3):
+        K = f"r{irk}_"
+        dtrk = (RK[irk - 1][0] + RK[irk - 1][1]) * dt; dtrki = dtrk ** (-1)
+        alpha = -.5 * case.visc * dtrk if imp else 0.
+        h.upload(F(prev["u"]), F(prev["v"]), F(prev["w"]), F(prev["p"])); h.set("visct", F(prev["visct"]))
+        f = h.rk(irk, dt); h.bulk_forcing()
+        assert np.abs(f - g[K + "s1_f"]).max() < 1e-13
+        for k in "uvw":
+            assert relerr(h.get(k)[1:-1, 1:-1, 1:-1], g[K + "s1_" + k][1:-1, 1:-1, 1:-1]) < TOL, (K, "s1", k)
+        nxt, sfx = "s1", ""
+        if imp == 2:
+            for k in "uvw":
+                h.set(k, F(g[K + "s1_" + k]))
+            for iv in (1, 2, 3):
+                h.helmholtz_z(iv, alpha)
+            for k in "uvw":   # the oracle made these (solver_gaussel_z is not buildable from the reference here)
+                assert relerr(h.get(k)[1:-1, 1:-1, 1:-1], g[K + "s1b_" + k + "_orc"][1:-1, 1:-1, 1:-1]) < 1e-12, (K, "s1b", k)
+            nxt, sfx = "s1b", "_orc"
+        for k in "uvw":
+            h.set(k, F(g[K + nxt + "_" + k + sfx]))
+        h.bounduvw(True, False)
+        for k in "uvw":
+            assert relerr(h.get(k), g[K + "s2_" + k]) < TOL, (K, "s2", k)
+        h.fillps(dtrki); h.updt_rhs_b()
+        assert relerr(h.get("pp")[1:-1, 1:-1, 1:-1], g[K + "s3_pp"][1:-1, 1:-1, 1:-1]) < TOL
+        # Poisson solve: golden output came from the oracle; the reference's own chkdiv certified it (r?_div)
+        h.set("pp", F(g[K + "s3_pp"])); h.solver(); h.boundp("pp", 0)
+        a, b = h.get("pp"), g[K + "s5_pp"]
+        a = a - a[1:-1, 1:-1, 1:-1].mean(); b = b - b[1:-1, 1:-1, 1:-1].mean()
+        assert relerr(a, b) < 1e-11, (K, "s5")
+        h.set("pp", F(g[K + "s5_pp"]))
+        for k in "uvw":
+            h.set(k, F(g[K + "s2_" + k]))
+        h.correc(dtrk)
+        if irk == 1:
+            for k in "uvw":
+                assert relerr(h.get(k), g[K + "s6_" + k]) < TOL, (K, "s6", k)
+        h.bounduvw(True, True)
+        for k in "uvw":
+            assert relerr(h.get(k), g[K + "s7_" + k]) < TOL, (K, "s7", k)
+        dv = h.chkdiv()
+        assert dv[1] < 1e-12, "divergence after projection"
+        h.set("p", F(prev["p"])); h.updatep(alpha); h.boundp("p", 0)
+        assert relerr(h.get("p"), g[K + "s8_p"]) < TOL
+        h.set("visct", F(prev["visct"]))
+        for k in "uvw":
+            h.set(k, F(g[K + "s7_" + k]))
+        h.cmpt_sgs(); h.boundp("visct", 1)
+        assert relerr(h.get("visct"), g[K + "s9_visct"]) < (TOL if case.sgstype != "dsmag" else 1e-10), (K, "s9")
+        prev = dict(u=g[K + "s7_u"], v=g[K + "s7_v"], w=g[K + "s7_w"], p=g[K + "s8_p"], visct=g[K + "s9_visct"])
+    h.close()
+
+
+@pytest.mark.parametrize("name", DEVICE_CASES)
+def test_fused_step_matches_operator_sequence(name):
+    """cales_step (one call, no host sync) == the golden end-of-step state, up to the growth of round-off
+    through three substeps (1e-10) and with p compared after removing its mean (singular mode, solver.f90:165)."""
+    g, case = load_golden(name)
+    h = _hot(case)
+    h.upload(*(F(g["s0_" + k]) for k in "uvwp")); h.set("visct", F(g["s0_visct"]))
+    h.step(float(g["dt"]))
+    u, v, w, p, visct = h.download()
+    for a, k in zip((u, v, w), "uvw"):
+        assert relerr(a, g["r3_s7_" + k]) < 1e-10, k
+    pg = g["r3_s8_p"]
+    assert relerr(p - p[1:-1, 1:-1, 1:-1].mean(), pg - pg[1:-1, 1:-1, 1:-1].mean()) < 1e-9
+    assert relerr(visct, g["r3_s9_visct"]) < 1e-8
+    assert np.abs(h.dpdl() - g["dpdl"]).max() < 1e-9 * max(1., np.abs(g["dpdl"]).max())
+    dv = h.chkdiv()
+    assert dv[1] < 1e-12 and abs(dv[1]) < 10 * max(g["r3_div"][1], 1e-16) * 10
+    h.close()
