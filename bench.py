@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py -- time-steps/s of the CaLES hot path on MI355X, with roofline and CPU-baseline objects.
+
+Workload (BASELINE.json, configs[2], the one the metric is quoted on): turbulent channel, 512^3,
+dynamic Smagorinsky, from the reference's examples/les/_manuscript_turbulent_channel/input.nml
+(ng -> 512^3, sgstype -> 'dsmag', visci = 10000), Poiseuille + vortex-pair initial field (inivel='poi',
+is_wallturb=T; deterministic), bulk-velocity forcing in x. A step = 3 RK substeps (src/main.f90:417-508)
+with the fields resident in HBM. dt is fixed to 0.5*dt_cfl(initial field).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--ng n1 n2 n3] [--sgs none|smag|dsmag]
+
+N > 1: one process per GPU (torch.distributed.run), y-slab decomposition of the SAME 512^3 problem
+(strong scaling), see cales_amd/decomp.py.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
+
+# algorithmic FP64 words per cell per launch (DESIGN.md "Kernels")
+WORDS = {"mom_xyz_ad": 7, "rk_update": 13, "fillps": 4, "correc": 7, "updatep": 3, "bulk_forcing": 2,
+         "fft_x_fwd": 2, "fft_y_fwd": 2, "gaussel_z": 2, "fft_y_bwd": 2, "fft_x_bwd": 2,
+         "strain_rate": 10, "filter3d": 2}
+W_STEP = {"none": 44, "smag": 51, "dsmag": 178}   # per substep; x3 per step
+
+
+def channel_case(ng, sgs):
+    from cales_amd.nml import parse_text
+    text = open(os.path.join(ROOT, "cales_amd", "cases", "turbulent_channel.nml")).read()
+    case = parse_text(text)
+    case.ng[:] = ng
+    case.sgstype = sgs
+    return case
+
+
+def cpu_baseline(case_full, seconds_budget=25.0):
+    """Oracle (oracle/cales_oracle.c, OpenMP) timed on the host on a bounded sample: same physics, 128x128x64."""
+    from oracle.oracle import Oracle
+    case = case_full.copy()
+    case.ng[:] = (128, 128, 64)
+    cores = os.cpu_count() or 1
+    o = Oracle(case, nthreads=cores)
+    u, v, w, p = o.initflow(case.inivel, case.is_wallturb)
+    visct, pp = o.zeros(), o.zeros()
+    o.bounduvw(u, v, w, True, False); o.boundp(p, 0); o.cmpt_sgs(u, v, w, visct); o.boundp(visct, 1)
+    dt = 0.5 * o.chkdt(visct, u, v, w)
+    o.step(dt, u, v, w, p, pp, visct)            # warm-up (allocations, twiddles)
+    t0 = time.perf_counter(); k = 0
+    while k < 2 or (time.perf_counter() - t0 < seconds_budget / 3 and k < 20):
+        o.step(dt, u, v, w, p, pp, visct); k += 1
+    t = (time.perf_counter() - t0) / k
+    ncell_s = float(np.prod(case.ng)); ncell_f = float(np.prod(case_full.ng))
+    return {"value": (1.0 / t) * ncell_s / ncell_f, "unit": "time-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{k} steps of the same case at 128x128x64 ({t:.3f} s/step), scaled by cell count to "
+                      f"{'x'.join(str(int(x)) for x in case_full.ng)}; OpenMP over {cores} host threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--ng", type=int, nargs=3, default=[512, 512, 512])
+    ap.add_argument("--sgs", default="dsmag", choices=["none", "smag", "dsmag"])
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+
+    from cales_amd.hotpath import initflow
+    case = channel_case(a.ng, a.sgs)
+    if world == 1:
+        from cales_amd.hotpath import HotPath
+        h = HotPath(case)
+        u, v, w, p = initflow(case)
+        h.upload(u, v, w, p)
+        del u, v, w, p
+    else:
+        from cales_amd.decomp import SlabHotPath
+        h = SlabHotPath(case, dist, torch)
+        h.upload_initial()
+    h.startup()
+    dt = 0.5 * h.chkdt()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        h.step(dt)
+    barrier()
+    h.profile_reset(); h.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        h.step(dt)
+    barrier()
+    t = time.perf_counter() - t0
+    h.profile(False)
+    if world > 1:
+        tt = torch.tensor([t], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t = float(tt.item())
+    stats = h.profile_stats()
+    divtot, divmax = h.chkdiv()
+    if not np.isfinite(divtot) or divmax > 2.2e-9:       # the reference's abort rule, main.f90:538
+        raise SystemExit(f"bench invalid: divergence {divmax}")
+
+    if rank == 0:
+        ncell = float(np.prod(case.ng)); nloc = ncell / world
+        ms_step = 1e3 * t / a.steps
+        # dominant kernel (by measured time) among the per-kernel timers
+        leaf = {k: v for k, v in stats.items() if k in WORDS and v[0] > 0}
+        dom = max(leaf, key=lambda k: leaf[k][1])
+        calls, ms = leaf[dom]
+        ach = WORDS[dom] * 8.0 * nloc / (ms / calls * 1e-3)
+        solve = ["fft_x_fwd", "fft_y_fwd", "gaussel_z", "fft_y_bwd", "fft_x_bwd"]
+        solve_ms = sum(stats[k][1] / stats[k][0] for k in solve if k in stats and stats[k][0])
+        out = {
+            "metric": "time-steps/sec", "value": a.steps / t, "unit": "time-steps/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"turbulent channel {case.ng[0]}x{case.ng[1]}x{case.ng[2]}, sgstype={case.sgstype}, "
+                                   "PP/PP/NN pressure BCs, bulk forcing in x (BASELINE.json configs[2]); 3 RK substeps/step",
+                       "decomposition": f"y-slabs x{world}" if world > 1 else "single GPU", "dt": dt},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK, "traffic": None,
+                         "algorithmic_bytes_per_launch": WORDS[dom] * 8.0 * nloc, "avg_launch_ms": ms / calls, "launches": calls},
+            "poisson_solve": {"ms": solve_ms, "algorithmic_GBps": 10 * 8.0 * nloc / (solve_ms * 1e-3) / 1e9 if solve_ms else None,
+                              "frac_of_hbm_peak": 10 * 8.0 * nloc / (solve_ms * 1e-3) / HBM_PEAK if solve_ms else None},
+            "step_effective": {"algorithmic_GB_per_step": 3 * 8.0 * ncell * W_STEP[case.sgstype] / 1e9,
+                               "frac_of_hbm_peak": 3 * 8.0 * ncell * W_STEP[case.sgstype] / (t / a.steps) / (world * HBM_PEAK)},
+            "kernels_ms_per_step": {k: round(v[1] / a.steps, 4) for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])},
+            "divmax": divmax,
+        }
+        if world == 1 and not a.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(case)
+        print(json.dumps(out))
+    h.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
