@@ -101,6 +101,7 @@ def main():
     dt = 0.5 * h.chkdt()
 
     def barrier():
+        h.sync()                      # the context's own HIP stream
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

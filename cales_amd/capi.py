@@ -23,7 +23,8 @@ SYMBOLS = ["cales_initgrid", "cales_initflow", "cales_check_case", "cales_create
            "cales_bulk_forcing", "cales_get_forcing", "cales_bulk_mean", "cales_fillps", "cales_updt_rhs_b",
            "cales_solver", "cales_helmholtz_z", "cales_correc", "cales_updatep", "cales_cmpt_sgs", "cales_chkdt",
            "cales_chkdiv", "cales_step", "cales_get_dpdl", "cales_profile_enable", "cales_profile_reset",
-           "cales_profile_count", "cales_profile_get", "cales_device_info"]
+           "cales_profile_count", "cales_profile_get", "cales_device_info", "cales_comm_buffer_doubles", "cales_set_comm",
+           "cales_initflow_slab"]
 
 
 class CalesCase(C.Structure):
@@ -72,6 +73,15 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(make -C cales_amd/csrc). The CaLES hot path has no CPU fallback.")
+        # PyTorch-ROCm wheels bundle their own HIP/HSA runtime under the same soname (libamdhip64.so.7). A process
+        # must hold ONE runtime: whichever is loaded first wins, and torch cannot initialise on top of the system
+        # copy. So torch (when installed) is imported before libcales_hip.so is opened; set CALES_NO_TORCH=1 for a
+        # torch-free process (e.g. alongside the Fortran driver).
+        if os.environ.get("CALES_NO_TORCH") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         L.cales_last_error.restype = C.c_char_p
         L.cales_last_error.argtypes = [C.c_void_p]
@@ -95,6 +105,9 @@ def lib() -> C.CDLL:
             "cales_initgrid": [C.c_int, C.c_int, C.c_double, C.c_double, dp, dp, dp, dp],
             "cales_initflow": [C.POINTER(CalesCase), C.c_char_p, C.c_int, dp, dp, dp, dp],
             "cales_check_case": [C.POINTER(CalesCase), C.c_char_p, C.c_int],
+            "cales_comm_buffer_doubles": [C.c_void_p, dp],
+            "cales_set_comm": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64],
+            "cales_initflow_slab": [C.POINTER(CalesCase), C.c_char_p, C.c_int, dp, dp, dp, dp],
         }.items():
             fn = getattr(L, name)
             fn.argtypes = args

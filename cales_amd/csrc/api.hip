@@ -56,7 +56,7 @@ int cales_initgrid(int gtype, int n, double gr, double lz, double *dzc, double *
 }
 int cales_initflow(const cales_case *cs, const char *inivel, int is_wallturb, double *u, double *v, double *w, double *p) {
   if (!cs || !inivel || !u || !v || !w || !p) return 1;
-  return hs_initflow(cs, inivel, is_wallturb, u, v, w, p);
+  return hs_initflow(cs, inivel, is_wallturb, u, v, w, p, 0, 1);
 }
 int cales_check_case(const cales_case *cs, char *msg, int msglen) {
   std::string m;
@@ -80,7 +80,7 @@ void cales_destroy(cales_ctx *c) {
   for (auto *b : bs) free_bound(*b);
   for (int d = 0; d < 3; ++d) hipFree(c->rhsbp[d]);
   hipFree(c->scr1); hipFree(c->scr2); hipFree(c->d_red); hipFree(c->d_force); hipHostFree(c->h_red);
-  hipFree(c->s0); hipFree(c->uc); hipFree(c->vc); hipFree(c->wc); hipFree(c->uf); hipFree(c->vf); hipFree(c->wf); hipFree(c->alph2); hipFree(c->d_p1d);
+  hipFree(c->s0); hipFree(c->uc); hipFree(c->vc); hipFree(c->wc); hipFree(c->uf); hipFree(c->vf); hipFree(c->wf); hipFree(c->alph2); if (!c->p1d_in_comm) hipFree(c->d_p1d);
   for (int m = 0; m < 6; ++m) { hipFree(c->wk[m]); hipFree(c->sij[m]); hipFree(c->mij[m]); }
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
@@ -111,6 +111,7 @@ int cales_create(const cales_case *cs, void *stream, cales_ctx **out) {
   else { c->own_stream = true; if (hipStreamCreate(&c->stream) != hipSuccess) { c->own_stream = false; c->stream = 0; c->err = "hipStreamCreate failed"; return fail(4); } }
   // geometry: y-slab of rank `rank`
   const int P = cs->nranks, r = cs->rank;
+  c->P = P; c->rank = r; c->per_y = cs->cbcpre[2] == 'P' && cs->cbcpre[3] == 'P';
   c->n[0] = cs->ng[0]; c->n[1] = cs->ng[1] / P; c->n[2] = cs->ng[2];
   c->lo[0] = 1; c->lo[1] = r * c->n[1] + 1; c->lo[2] = 1;
   for (int d = 0; d < 3; ++d) { c->dl[d] = cs->l[d] / (double)(1.f * (float)cs->ng[d]); c->dli[d] = 1. / c->dl[d]; }   // param.f90:153-154
@@ -156,6 +157,7 @@ int cales_create(const cales_case *cs, void *stream, cales_ctx **out) {
   if (dev_alloc(c, &c->scr1, c->ntot) || dev_alloc(c, &c->scr2, c->ntot)) return fail(9);
   c->red_blocks = 8;
   if (dev_alloc(c, &c->d_red, 64 + 16 * (size_t)(n3 + 2) + 4 * (size_t)(n3 + 2)) || dev_alloc(c, &c->d_force, 8)) return fail(10);
+  c->res = c->d_red;
   if (hipHostMalloc((void **)&c->h_red, 64 * sizeof(double)) != hipSuccess) { c->err = "hipHostMalloc failed"; return fail(11); }
   // sgs scratch (sgs.f90:70-83,154-171)
   for (int d = 1; d <= 3; ++d) for (int s = 0; s <= 1; ++s) c->is_wall[s + 2 * (d - 1)] = (ISB(c, s, d) && CBV(c, s, d, d) == 'D') ? 1. : 0.;
@@ -233,8 +235,8 @@ int cales_get_forcing(cales_ctx *c, double f[3]) {
 }
 int cales_bulk_mean(cales_ctx *c, int field, int c_or_f, double *mean) {
   if (field < 0 || field >= CALES_NFIELDS || !c->f[field]) { c->err = "bad field id"; return 1; }
-  if (int e = op_bulk_mean_dev(c, c->f[field], c_or_f, c->d_red + 16)) return e;
-  HIPCHK(c, hipMemcpyAsync(c->h_red + 16, c->d_red + 16, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (int e = op_bulk_mean_dev(c, c->f[field], c_or_f, nullptr)) return e;
+  HIPCHK(c, hipMemcpyAsync(c->h_red + 16, c->res + 16, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   *mean = c->h_red[16];
   return 0;
@@ -285,6 +287,36 @@ int cales_get_dpdl(cales_ctx *c, double dpdl[3]) {
   const double dti = 1. / c->h_red[40];
   for (int q = 0; q < 3; ++q) dpdl[q] = -c->h_red[35 + q] * dti;
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------ multi-GPU hooks
+#define CALES_RES_TAIL 4096
+int cales_comm_buffer_doubles(const cales_ctx *c, int64_t *n) {
+  const int64_t a2a = 2 * (int64_t)c->P * c->n[2] * c->n[1] * c->cw;                 // [peer][k][jl][mm] complex
+  const int64_t halo = 4 * 8 * (int64_t)c->g.s1 * (c->n[2] + 2);                     // lo|hi x up to 8 fields (send in A, recv in B)
+  const int64_t tail = CALES_RES_TAIL + 2 * (int64_t)(c->n[2] + 2);
+  *n = std::max(a2a, halo) + tail;
+  return 0;
+}
+int cales_set_comm(cales_ctx *c, cales_halo_cb halo, cales_alltoall_cb a2a, cales_allreduce_cb allred, void *user,
+                   double *bufA, double *bufB, int64_t nbuf) {
+  int64_t need = 0; cales_comm_buffer_doubles(c, &need);
+  if (!halo || !a2a || !allred || !bufA || !bufB || nbuf < need) { c->err = "cales_set_comm: missing callback/buffer or buffers too small"; return 1; }
+  c->comm.halo = halo; c->comm.a2a = a2a; c->comm.allred = allred; c->comm.user = user;
+  c->comm.A = bufA; c->comm.B = bufB; c->comm.nbuf = nbuf; c->comm.on = true;
+  HIPCHK(c, hipMemsetAsync(bufA, 0, nbuf * sizeof(double), c->stream));
+  HIPCHK(c, hipMemsetAsync(bufB, 0, nbuf * sizeof(double), c->stream));
+  // reduction results live in the tail of A so that the host can all-reduce them in place
+  const int64_t tail = CALES_RES_TAIL + 2 * (int64_t)(c->n[2] + 2);
+  c->res = bufA + (nbuf - tail);
+  if (c->d_p1d) { hipFree(c->d_p1d); }
+  c->d_p1d = c->res + 64;
+  c->p1d_in_comm = true;
+  return 0;
+}
+int cales_initflow_slab(const cales_case *cs, const char *inivel, int is_wallturb, double *u, double *v, double *w, double *p) {
+  if (!cs || !inivel || !u || !v || !w || !p) return 1;
+  return hs_initflow(cs, inivel, is_wallturb, u, v, w, p, cs->rank, cs->nranks);
 }
 
 // ------------------------------------------------------------------------------------------ measurement

@@ -24,6 +24,33 @@ struct Geom {              // passed by value to kernels
 
 struct DBound { double *x, *y, *z; };   // device BC planes (0:na+1,0:nb+1,0:1), reference src/typedef.f90:10-14
 
+// Communication hooks (include/cales.h): y-slab neighbours, slab<->mode-block all-to-all, all-reduce.
+struct Comm {
+  cales_halo_cb halo = nullptr; cales_alltoall_cb a2a = nullptr; cales_allreduce_cb allred = nullptr; void *user = nullptr;
+  double *A = nullptr, *B = nullptr; int64_t nbuf = 0;   // two device staging buffers owned by the host (doubles)
+  bool on = false;
+};
+
+// Where the spectral (after the x transform) data of the Poisson solve lives.
+//  blocked = 0: in place in the haloed array: complex (m, j, k) at (ix(0,j,k)>>1) + m
+//  blocked = 1: staging buffer laid out [peer][k][jl][mm] (complex), peer block = n3*n2l*cw:
+//               on the slab side peer = m/cw, on the mode-block side peer = (j-1)/n2l.
+struct Spec {
+  int blocked, cw, n2l, n3;
+  // slab side: global mode m, LOCAL row jl (1-based), plane k (1-based)
+  __host__ __device__ inline size_t at_slab(const Geom &g, int m, int jl, int k) const {
+    if (!blocked) return (g.ix(0, jl, k) >> 1) + (size_t)m;
+    const int peer = m / cw, mm = m - peer * cw;
+    return (size_t)mm + (size_t)cw * ((size_t)(jl - 1) + (size_t)n2l * ((size_t)(k - 1) + (size_t)n3 * peer));
+  }
+  // mode-block side: LOCAL mode mm, GLOBAL row j (1-based), plane k (1-based)
+  __host__ __device__ inline size_t at_mode(const Geom &g, int mm, int j, int k) const {
+    if (!blocked) return (g.ix(0, j, k) >> 1) + (size_t)mm;
+    const int peer = (j - 1) / n2l, jl = (j - 1) - peer * n2l;
+    return (size_t)mm + (size_t)cw * ((size_t)jl + (size_t)n2l * ((size_t)(k - 1) + (size_t)n3 * peer));
+  }
+};
+
 struct KernelStat { std::string name; int64_t calls = 0; double ms = 0.; };
 
 struct cales_ctx {
@@ -63,6 +90,11 @@ struct cales_ctx {
   double *s0, *wk[6], *sij[6], *mij[6], *uc, *vc, *wc, *uf, *vf, *wf, *alph2, *d_p1d;
   double is_wall[6];
   bool sgs_first;
+  // decomposition
+  int P = 1, rank = 0; bool per_y = true; int cw = 0;      // cw: complex mode columns per rank (padded)
+  Comm comm;
+  bool p1d_in_comm = false;
+  double *res = nullptr;                // reduction results (inside comm.A when comm is on, so they can be all-reduced)
   // profiling
   bool prof = false;
   std::vector<KernelStat> stats;
@@ -101,7 +133,7 @@ void   hs_initgrid(int gtype, int n, double gr, double lz, double *dzc, double *
 void   hs_initbc(cales_ctx *c, std::vector<double> hb[11][3]);
 void   hs_eigenvalues(int n, const char *cbc2, char c_or_f, double *lambda);
 void   hs_tridmatrix(const char *cbc2, int n, const double *dzci, const double *dzfi, char c_or_f, double *a, double *b, double *c);
-int    hs_initflow(const cales_case *cs, const char *inivel, int is_wallturb, double *u, double *v, double *w, double *p);
+int    hs_initflow(const cales_case *cs, const char *inivel, int is_wallturb, double *u, double *v, double *w, double *p, int rank, int nranks);
 int    hs_check_case(const cales_case *cs, std::string &msg);
 void   hs_bc_rhs(const char *cbc2, const double *bc, int na, int nb, const double *dlc, const double *dlf, char c_or_f, double *rhs);
 

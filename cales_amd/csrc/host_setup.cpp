@@ -117,8 +117,13 @@ void hs_tridmatrix(const char *cbc2, int n, const double *dzci, const double *dz
 }
 
 // ---------------------------------------------------------------- src/initflow.f90:17-283
-int hs_initflow(const cales_case *cs, const char *inivel_, int is_wallturb, double *u, double *v, double *w, double *p) {
-  const int n1 = cs->ng[0], n2 = cs->ng[1], n3 = cs->ng[2];
+int hs_initflow(const cales_case *cs, const char *inivel_, int is_wallturb, double *u, double *v, double *w, double *p, int rank, int nranks) {
+  // Fills the y-slab of `rank` (local haloed arrays, rows jl = 1..n2l <-> global j = jl + jlo). The volume mean
+  // of set_mean (initflow.f90:317-338) is accumulated over the GLOBAL index range in the reference's loop order,
+  // so every rank rescales by the same number a one-rank run would use.
+  const int n1 = cs->ng[0], n2g = cs->ng[1], n3 = cs->ng[2];
+  if (nranks < 1 || n2g % nranks) return 1;
+  const int n2 = n2g / nranks, jlo = rank * n2;
   const size_t s1 = n1 + 2, s2 = n2 + 2;
   auto IX = [&](int i, int j, int k) { return (size_t)i + s1 * ((size_t)j + s2 * (size_t)k); };
   const std::string inivel(inivel_);
@@ -127,9 +132,9 @@ int hs_initflow(const cales_case *cs, const char *inivel_, int is_wallturb, doub
   std::vector<double> dzc(n3 + 2), dzf(n3 + 2), zc(n3 + 2), zf(n3 + 2);
   hs_initgrid(cs->gtype, n3, cs->gr, l[2], dzc.data(), dzf.data(), zc.data(), zf.data());
   auto bcvel = [&](int side, int dir, int vel) { return cs->bcvel[side + 2 * (dir - 1) + 6 * (vel - 1)]; };
-  double uref = 1., ubulk = uref; bool is_mean = false, is3d = false;
+  double uref = 1., ubulk = uref; bool is_mean = false, is3d = false, is2d = false;
   if (cs->is_forced[0]) ubulk = cs->velf[0];
-  std::vector<double> u1d(n3 + 2, 0.);
+  std::vector<double> u1d(n3 + 2, 0.), u2d;        // u2d(jg,k): x-independent duct profile for ALL global rows
   auto poiseuille = [&](double norm) { for (int k = 1; k <= n3; ++k) { const double z = zc[k] / l[2]; u1d[k] = 6. * z * (1. - z) * norm; } };
   if (inivel == "cou") {
     uref = bcvel(0, 3, 1) - bcvel(1, 3, 1);
@@ -149,25 +154,26 @@ int hs_initflow(const cales_case *cs, const char *inivel_, int is_wallturb, doub
     poiseuille(ubulk); is_mean = true;
   } else if (inivel == "tgv") { is3d = true;
     for (int k = 1; k <= n3; ++k) { const double zcc = zc[k] / l[2] * 2. * pi;
-      for (int j = 1; j <= n2; ++j) { const double yc = (j - .5) * dl[1] / l[1] * 2. * pi, yf = (j - .0) * dl[1] / l[1] * 2. * pi;
-        for (int i = 1; i <= n1; ++i) { const double xc = (i - .5) * dl[0] / l[0] * 2. * pi, xf = (i - .0) * dl[0] / l[0] * 2. * pi; const size_t q = IX(i, j, k);
+      for (int jl = 1; jl <= n2; ++jl) { const int j = jl + jlo; const double yc = (j - .5) * dl[1] / l[1] * 2. * pi, yf = (j - .0) * dl[1] / l[1] * 2. * pi;
+        for (int i = 1; i <= n1; ++i) { const double xc = (i - .5) * dl[0] / l[0] * 2. * pi, xf = (i - .0) * dl[0] / l[0] * 2. * pi; const size_t q = IX(i, jl, k);
           u[q] = std::sin(xf) * std::cos(yc) * std::cos(zcc) * uref; v[q] = -std::cos(xc) * std::sin(yf) * std::cos(zcc) * uref; w[q] = 0.; p[q] = 0.; } } }
   } else if (inivel == "tgw") { is3d = true;
-    for (int k = 1; k <= n3; ++k) for (int j = 1; j <= n2; ++j) { const double yc = (j - .5) * dl[1], yf = (j - .0) * dl[1];
-      for (int i = 1; i <= n1; ++i) { const double xc = (i - .5) * dl[0], xf = (i - .0) * dl[0]; const size_t q = IX(i, j, k);
+    for (int k = 1; k <= n3; ++k) for (int jl = 1; jl <= n2; ++jl) { const int j = jl + jlo; const double yc = (j - .5) * dl[1], yf = (j - .0) * dl[1];
+      for (int i = 1; i <= n1; ++i) { const double xc = (i - .5) * dl[0], xf = (i - .0) * dl[0]; const size_t q = IX(i, jl, k);
         u[q] = std::cos(xf) * std::sin(yc) * uref; v[q] = -std::sin(xc) * std::cos(yf) * uref; w[q] = 0.;
         p[q] = -(std::cos(2. * xc) + std::cos(2. * yc)) / 4. * (uref * uref); } }
   } else if (inivel == "ant") { is3d = true;
     const double cf = (double)(4.f * std::sqrt(2.f) / 3.f / std::sqrt(3.f));    // default-real constant (initflow.f90:146)
     for (int k = 1; k <= n3; ++k) { const double zcc = zc[k] / l[2] * 2. * pi + 0.5 * pi, zff = zf[k] / l[2] * 2. * pi + 0.5 * pi;
-      for (int j = 1; j <= n2; ++j) { const double yc = (j - .5) * dl[1] / l[1] * 2. * pi + 0.5 * pi, yf = (j - .0) * dl[1] / l[1] * 2. * pi + 0.5 * pi;
-        for (int i = 1; i <= n1; ++i) { const double xc = (i - .5) * dl[0] / l[0] * 2. * pi + 0.5 * pi, xf = (i - .0) * dl[0] / l[0] * 2. * pi + 0.5 * pi; const size_t q = IX(i, j, k);
+      for (int jl = 1; jl <= n2; ++jl) { const int j = jl + jlo; const double yc = (j - .5) * dl[1] / l[1] * 2. * pi + 0.5 * pi, yf = (j - .0) * dl[1] / l[1] * 2. * pi + 0.5 * pi;
+        for (int i = 1; i <= n1; ++i) { const double xc = (i - .5) * dl[0] / l[0] * 2. * pi + 0.5 * pi, xf = (i - .0) * dl[0] / l[0] * 2. * pi + 0.5 * pi; const size_t q = IX(i, jl, k);
           u[q] = cf * (std::sin(xf - 5. * pi / 6.) * std::cos(yc - 1. * pi / 6.) * std::sin(zcc) - std::sin(xf - 1. * pi / 6.) * std::sin(yc) * std::cos(zcc - 5. * pi / 6.)) * uref;
           v[q] = cf * (std::sin(xc) * std::sin(yf - 5. * pi / 6.) * std::sin(zcc - 1. * pi / 6.) - std::cos(xc - 5. * pi / 6.) * std::sin(yf - 1. * pi / 6.) * std::sin(zcc)) * uref;
           w[q] = cf * (std::cos(xc - 1. * pi / 6.) * std::sin(yc) * std::sin(zff - 5. * pi / 6.) - std::sin(xc) * std::cos(yc - 5. * pi / 6.) * std::sin(zff - 1. * pi / 6.)) * uref;
           p[q] = -(u[q] * u[q] + v[q] * v[q] + w[q] * w[q]) / 2.; } } }
-  } else if (inivel == "duc") { is3d = true; is_mean = true;
-    for (int k = 1; k <= n3; ++k) for (int j = 1; j <= n2; ++j) {
+  } else if (inivel == "duc") { is2d = true; is_mean = true;
+    u2d.assign((size_t)(n2g + 2) * (n3 + 2), 0.);
+    for (int k = 1; k <= n3; ++k) for (int j = 1; j <= n2g; ++j) {
       double sum_term = 0.; const double ly = .5 * l[1], lz = .5 * l[2], xi = -1. + (j + 1 - 1.5) * dl[1] / ly, eta = -1. + zc[k] / lz;
       for (int m = 0; m <= 100; ++m) {
         const double cosh_term = std::cosh((2 * m + 1) * pi * ly / (2 * lz) * xi) / std::cosh((2 * m + 1) * pi * ly / (2 * lz));
@@ -175,24 +181,27 @@ int hs_initflow(const cales_case *cs, const char *inivel_, int is_wallturb, doub
         const double term = ((m & 1) ? -1. : 1.) / (double)((2 * m + 1) * (2 * m + 1) * (2 * m + 1)) * cosh_term * cos_term;
         sum_term = sum_term + term;
       }
-      const double tp = 2. / pi, val = .5 * (lz * lz) * (1. - eta * eta - 4. * (tp * tp * tp) * sum_term);
-      for (int i = 0; i <= n1 + 1; ++i) { const size_t q = IX(i, j, k); u[q] = val; v[q] = 0.; w[q] = 0.; p[q] = 0.; } }
+      const double tp = 2. / pi;
+      u2d[j + (size_t)(n2g + 2) * k] = .5 * (lz * lz) * (1. - eta * eta - 4. * (tp * tp * tp) * sum_term);
+    }
   } else {
     return (inivel == "log" || inivel == "hcl" || inivel == "tbl") ? 2 : 1;   // RNG-based kinds are not offered
   }
-  if (!is3d) for (int k = 1; k <= n3; ++k) for (int j = 1; j <= n2; ++j) for (int i = 1; i <= n1; ++i) {
-    const size_t q = IX(i, j, k); u[q] = u1d[k]; v[q] = 0.; w[q] = 0.; p[q] = 0.; }
-  if (is_mean && inivel != "iop") {   // set_mean, initflow.f90:317-338 (serial sum, one rank)
+  auto prof = [&](int jg, int k) { return is2d ? u2d[jg + (size_t)(n2g + 2) * k] : u1d[k]; };
+  if (!is3d) for (int k = 1; k <= n3; ++k) for (int jl = 1; jl <= n2; ++jl) {
+    const double val = prof(jl + jlo, k);
+    for (int i = (is2d ? 0 : 1); i <= (is2d ? n1 + 1 : n1); ++i) { const size_t q = IX(i, jl, k); u[q] = val; v[q] = 0.; w[q] = 0.; p[q] = 0.; } }
+  if (is_mean && inivel != "iop") {   // set_mean over the global domain, same summation order as one rank
     double meanold = 0.;
     for (int k = 1; k <= n3; ++k) { const double gvr = dzf[k] / l[2] * (dl[0] / l[0]) * (dl[1] / l[1]);
-      for (int j = 1; j <= n2; ++j) for (int i = 1; i <= n1; ++i) meanold = meanold + u[IX(i, j, k)] * gvr; }
-    if (meanold != 0.) for (int k = 1; k <= n3; ++k) for (int j = 1; j <= n2; ++j) for (int i = 1; i <= n1; ++i)
-      u[IX(i, j, k)] = u[IX(i, j, k)] / meanold * ubulk;
+      for (int j = 1; j <= n2g; ++j) { const double t = prof(j, k) * gvr; for (int i = 1; i <= n1; ++i) meanold = meanold + t; } }
+    if (meanold != 0.) for (int k = 1; k <= n3; ++k) for (int jl = 1; jl <= n2; ++jl) for (int i = 1; i <= n1; ++i)
+      u[IX(i, jl, k)] = u[IX(i, jl, k)] / meanold * ubulk;
   }
   if (is_wallturb) {                  // streamwise vortex pair, initflow.f90:218-246
     for (int k = 1; k <= n3; ++k) { const double zcc = 2. * zc[k] / l[2] - 1., zff = 2. * (zc[k] / l[2] + .5 * dzf[k] / l[2]) - 1.;
-      for (int j = 1; j <= n2; ++j) { const double yc = ((j - 0.5) * dl[1] - .5 * l[1]) * 2. / l[2], yf = ((j - 0.0) * dl[1] - .5 * l[1]) * 2. / l[2];
-        for (int i = 1; i <= n1; ++i) { const double xc = ((i - 0.5) * dl[0] - .5 * l[0]) * 2. / l[2]; const size_t q = IX(i, j, k);
+      for (int jl = 1; jl <= n2; ++jl) { const int j = jl + jlo; const double yc = ((j - 0.5) * dl[1] - .5 * l[1]) * 2. / l[2], yf = ((j - 0.0) * dl[1] - .5 * l[1]) * 2. / l[2];
+        for (int i = 1; i <= n1; ++i) { const double xc = ((i - 0.5) * dl[0] - .5 * l[0]) * 2. / l[2]; const size_t q = IX(i, jl, k);
           const double gxy = xc * std::exp(-4. * (4. * (yf * yf) + xc * xc)), dfz = -4. * zcc * (1. - zcc * zcc);
           const double fz = (1. - zff * zff) * (1. - zff * zff), dgxy = std::exp(-4. * (4. * (yc * yc) + xc * xc)) * (1. - 8. * (xc * xc));
           v[q] = -1. * gxy * dfz * ubulk * 1.5; w[q] = 1. * fz * dgxy * ubulk * 1.5; p[q] = 0.; } } }
@@ -222,6 +231,8 @@ int hs_check_case(const cales_case *cs, std::string &msg) {
       for (int ivel = 0; ivel < 3; ++ivel) if (cs->cbcvel[s + 2 * d + 6 * ivel] != 'D') { msg = "wall-model faces must have Dirichlet velocity BCs (sanity.f90:209-221)"; return 1; }
   }
   if (cs->sgstype < 0 || cs->sgstype > 2) { msg = "unknown SGS model"; return 1; }
+  if (cs->sgstype == 1 && cs->nranks > 2 && cs->cbcvel[0 + 2 * 1 + 6 * 1] == 'D' && cs->cbcvel[1 + 2 * 1 + 6 * 1] == 'D') {
+    msg = "more than two subdomains between two opposite walls (sanity.f90:98-111)"; return 1; }
   if (cs->impdiff == 1) { msg = "3-D implicit diffusion (_IMPDIFF without _IMPDIFF_1D) is not provided by this build"; return 1; }
   if (cs->impdiff != 0 && cs->impdiff != 2) { msg = "impdiff must be 0 or 2"; return 1; }
   // transforms offered in x,y: periodic and cell-centred Neumann-Neumann (what the reference's GPU path offers, sanity.f90:265-273)

@@ -62,10 +62,42 @@ static inline void add_job(BcJobs &J, double *p, char ctype, int ibound, int cen
   j.p = p; j.bc = bc; j.dr = dr; j.ctype = ctype; j.centered = (char)centered; j.ibound = (char)ibound;
 }
 
-// single-rank halo exchange == periodic copy in the non-pencil directions (bound.f90:619-696, nb = self)
+// y-slab neighbours (bound.f90:619-696 for idir = 2): pack the first/last interior rows of nf fields into the
+// staging buffer A, let the host exchange them, unpack into the ghost rows. Planes include the x/z ghosts.
+struct HaloFields { int nf; double *p[8]; };
+__global__ __launch_bounds__(256) void k_pack_y(Geom g, HaloFields H, double *__restrict__ lo, double *__restrict__ hi) {
+  const int i = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y * 4 + threadIdx.y, f = blockIdx.z;
+  if (i > g.n1 + 1 || k > g.n3 + 1) return;
+  const size_t q = (size_t)i + (size_t)g.s1 * ((size_t)k + (size_t)(g.n3 + 2) * f);
+  lo[q] = H.p[f][g.ix(i, 1, k)]; hi[q] = H.p[f][g.ix(i, g.n2, k)];
+}
+__global__ __launch_bounds__(256) void k_unpack_y(Geom g, HaloFields H, const double *__restrict__ lo, const double *__restrict__ hi, int has_lo, int has_hi) {
+  const int i = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y * 4 + threadIdx.y, f = blockIdx.z;
+  if (i > g.n1 + 1 || k > g.n3 + 1) return;
+  const size_t q = (size_t)i + (size_t)g.s1 * ((size_t)k + (size_t)(g.n3 + 2) * f);
+  if (has_lo) H.p[f][g.ix(i, 0, k)] = lo[q];
+  if (has_hi) H.p[f][g.ix(i, g.n2 + 1, k)] = hi[q];
+}
+static int halo_y_comm(cales_ctx *c, int nf, double **flds) {
+  if (!c->comm.on) { c->err = "nranks > 1 but no communication hooks registered (cales_set_comm)"; return 1; }
+  const int64_t plane = (int64_t)c->g.s1 * (c->n[2] + 2), cnt = plane * nf;
+  if (4 * cnt > c->comm.nbuf) { c->err = "halo staging buffer too small"; return 1; }
+  HaloFields H; H.nf = nf; for (int q = 0; q < nf; ++q) H.p[q] = flds[q];
+  dim3 b(64, 4, 1), gr((c->g.s1 + 63) / 64, (c->n[2] + 2 + 3) / 4, nf);
+  hipLaunchKernelGGL(k_pack_y, gr, b, 0, c->stream, c->g, H, c->comm.A, c->comm.A + cnt);
+  if (c->comm.halo(c->comm.user, 0, cnt, 0, cnt, cnt)) { c->err = "halo callback failed"; return 1; }
+  const int has_lo = (c->per_y || c->rank > 0) ? 1 : 0, has_hi = (c->per_y || c->rank < c->P - 1) ? 1 : 0;
+  hipLaunchKernelGGL(k_unpack_y, gr, b, 0, c->stream, c->g, H, c->comm.B, c->comm.B + cnt, has_lo, has_hi);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// halo exchange in the non-pencil directions: y across slabs (or a periodic copy on one rank), z always local
 static int halo_self(cales_ctx *c, int nf, double **flds) {
-  for (int idir = 2; idir <= 3; ++idir) {
-    if (ISB(c, 0, idir)) continue;       // not periodic: neighbours are MPI_PROC_NULL
+  if (c->P > 1) { if (int e = halo_y_comm(c, nf, flds)) return e; }
+  for (int idir = (c->P > 1 ? 3 : 2); idir <= 3; ++idir) {
+    const bool periodic = idir == 2 ? c->per_y : !ISB(c, 0, 3);
+    if (!periodic) continue;             // not periodic: neighbours are MPI_PROC_NULL
     BcJobs J; J.njobs = 0; J.idir = idir;
     for (int q = 0; q < nf; ++q) add_job(J, flds[q], 'P', 0, 1, nullptr, 0.);
     if (int e = launch_jobs(c, J)) return e;
@@ -80,12 +112,15 @@ int op_boundp(cales_ctx *c, double *p, int which) {
   double *fl[1] = {p};
   if (int e = halo_self(c, 1, fl)) return e;
   for (int idir = 1; idir <= 3; ++idir) {
-    if (!ISB(c, 0, idir)) continue;
+    if (!ISB(c, 0, idir) && !ISB(c, 1, idir)) continue;
     BcJobs J; J.njobs = 0; J.idir = idir;
     const double dr0 = idir < 3 ? c->dl[idir - 1] : c->dzc[0], dr1 = idir < 3 ? c->dl[idir - 1] : c->dzc[c->n[2]];
     const char c0 = cbc[0 + 2 * (idir - 1)], c1 = cbc[1 + 2 * (idir - 1)];
     if (c0 == 'P') add_job(J, p, 'P', 0, 1, nullptr, 0.);      // both ends in one job (identical result to the two calls)
-    else { add_job(J, p, c0, 0, 1, plane(bc, idir, 0, c->n), dr0); add_job(J, p, c1, 1, 1, plane(bc, idir, 1, c->n), dr1); }
+    else {
+      if (ISB(c, 0, idir)) add_job(J, p, c0, 0, 1, plane(bc, idir, 0, c->n), dr0);
+      if (ISB(c, 1, idir)) add_job(J, p, c1, 1, 1, plane(bc, idir, 1, c->n), dr1);
+    }
     if (int e = launch_jobs(c, J)) return e;
   }
   return 0;
@@ -235,7 +270,7 @@ int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm
   if (int e = halo_self(c, 3, fl)) return e;
   DBound *bnd[3] = {&bu, &bv, &bw};
   for (int idir = 1; idir <= 3; ++idir) {
-    if (!ISB(c, 0, idir)) continue;
+    if (!ISB(c, 0, idir) && !ISB(c, 1, idir)) continue;
     BcJobs J; J.njobs = 0; J.idir = idir;
     const bool periodic = CBV(c, 0, idir, idir) == 'P' && CBV(c, 1, idir, idir) == 'P';
     const bool impose_norm = (!is_correc) || periodic;
@@ -248,11 +283,14 @@ int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm
       if (normal) {
         if (!impose_norm) continue;
         if (c0 == 'P') add_job(J, p, 'P', 0, 0, nullptr, 0.);
-        else { add_job(J, p, c0, 0, 0, plane(*bnd[ivel - 1], idir, 0, n), drn0); add_job(J, p, c1, 1, 0, plane(*bnd[ivel - 1], idir, 1, n), drn1); }
+        else {
+          if (ISB(c, 0, idir)) add_job(J, p, c0, 0, 0, plane(*bnd[ivel - 1], idir, 0, n), drn0);
+          if (ISB(c, 1, idir)) add_job(J, p, c1, 1, 0, plane(*bnd[ivel - 1], idir, 1, n), drn1);
+        }
       } else {
         if (c0 == 'P' && LWM(c, 0, idir) == 0) { add_job(J, p, 'P', 0, 1, nullptr, 0.); continue; }
-        if (LWM(c, 0, idir) == 0) add_job(J, p, c0, 0, 1, plane(*bnd[ivel - 1], idir, 0, n), drt0);
-        if (LWM(c, 1, idir) == 0) add_job(J, p, c1, 1, 1, plane(*bnd[ivel - 1], idir, 1, n), drt1);
+        if (ISB(c, 0, idir) && LWM(c, 0, idir) == 0) add_job(J, p, c0, 0, 1, plane(*bnd[ivel - 1], idir, 0, n), drt0);
+        if (ISB(c, 1, idir) && LWM(c, 1, idir) == 0) add_job(J, p, c1, 1, 1, plane(*bnd[ivel - 1], idir, 1, n), drt1);
       }
     }
     if (int e = launch_jobs(c, J)) return e;

@@ -231,6 +231,7 @@ __global__ __launch_bounds__(256) void k_alph2(Geom g, double w0, double w1, dou
   alph2[g.ix(i, j, k)] = near ? 2.52 : 4.00;
 }
 
+int allreduce_res(cales_ctx *c, int slot, int count, int op);
 static inline dim3 lin_grid(size_t n) { size_t b = (n + 255) / 256; if (b > 4096) b = 4096; return dim3((unsigned)b); }
 
 int op_cmpt_sgs(cales_ctx *c) {
@@ -299,6 +300,7 @@ int op_cmpt_sgs(cales_ctx *c) {
   CP6 clij; for (int m = 0; m < 6; ++m) clij.p[m] = lij[m];
   hipLaunchKernelGGL(k_contract, gr, b, 0, c->stream, c->g, cmij, clij, c->uf, c->vf, c->wf, wk[0], wk[1]);
   hipLaunchKernelGGL(k_plane_sum, dim3(n[2], 2), dim3(256), 0, c->stream, c->g, wk[0], wk[1], c->d_p1d);
+  if (c->P > 1) { if (int e = allreduce_res(c, (int)(c->d_p1d - c->res), 2 * n[2], 0)) return e; }   // sgs.f90:475
   const double gar = c->dl[0] * c->dl[1] / (c->C.l[0] * c->C.l[1]);
   hipLaunchKernelGGL(k_dsmag_final, gr, b, 0, c->stream, c->g, gar, c->d_p1d, visct);
   HIPCHK(c, hipGetLastError());

@@ -86,7 +86,7 @@ __device__ inline cpx *fft_line(const FftPlan &P, cpx *a, cpx *b, int t, int T, 
 // rows are (j,k), j=1..n2, k=1..n3. R rows per block, T = blockDim.x / R threads per row.
 template <int INV>
 __global__ __launch_bounds__(256) void k_fft_x(Geom g, FftPlan P, int R, const cpx *__restrict__ tw, const cpx *__restrict__ twp,
-                                                double *__restrict__ p, double scale) {
+                                                double *__restrict__ p, double scale, Spec S, double2 *__restrict__ spec) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int nh = P.N, n = 2 * nh, T = blockDim.x / R, row = threadIdx.x / T, t = threadIdx.x % T;
   const int ld = nh + 1;
@@ -100,21 +100,19 @@ __global__ __launch_bounds__(256) void k_fft_x(Geom g, FftPlan P, int R, const c
     __syncthreads();
     cpx *Z = fft_line<0>(P, A, B, t, T, tw);
     if (live) {
-      double2 *out = reinterpret_cast<double2 *>(rowp);
       for (int kk = t; kk <= nh / 2; kk += T) {
         const cpx zk = Z[kk], zm = cconj(Z[(nh - kk) % nh]);
         const cpx E = {0.5 * (zk.x + zm.x), 0.5 * (zk.y + zm.y)};
         const cpx D = csub(zk, zm), O = {0.5 * D.y, -0.5 * D.x};     // -i/2 * (zk - conj(zm))
         const cpx wO = cmul(twp[kk], O);
         const cpx xk = cadd(E, wO), xm = cconj(csub(E, wO));
-        out[kk] = make_double2(xk.x, xk.y);
-        out[nh - kk] = make_double2(xm.x, xm.y);
+        spec[S.at_slab(g, kk, j, k)] = make_double2(xk.x, xk.y);
+        spec[S.at_slab(g, nh - kk, j, k)] = make_double2(xm.x, xm.y);
       }
     }
   } else {
     if (live) {
-      const double2 *in = reinterpret_cast<const double2 *>(rowp);
-      for (int kk = t; kk <= nh; kk += T) { const double2 v = in[kk]; B[kk] = cpx{v.x, v.y}; }
+      for (int kk = t; kk <= nh; kk += T) { const double2 v = spec[S.at_slab(g, kk, j, k)]; B[kk] = cpx{v.x, v.y}; }
     }
     __syncthreads();
     for (int kk = t; kk < nh; kk += T) {
@@ -133,16 +131,14 @@ __global__ __launch_bounds__(256) void k_fft_x(Geom g, FftPlan P, int R, const c
 // ------------------------------------------------------------------------------------------ y pass
 // block = CB adjacent complex columns (m0..m0+CB-1) of plane k; T = blockDim.x / CB threads per column.
 template <int INV>
-__global__ __launch_bounds__(256) void k_fft_y(Geom g, FftPlan P, int CB, int ncols, const cpx *__restrict__ tw, double *__restrict__ p) {
+__global__ __launch_bounds__(256) void k_fft_y(Geom g, FftPlan P, int CB, int ncols, const cpx *__restrict__ tw, Spec S, double2 *__restrict__ pc) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int N = P.N, ld = N + 1, T = blockDim.x / CB;
   const int m0 = blockIdx.x * CB, k = blockIdx.y + 1;
   cpx *base = reinterpret_cast<cpx *>(smem);
-  double2 *pc = reinterpret_cast<double2 *>(p);
-  const size_t rowc = (size_t)g.s1 / 2;                                    // complex per row
   for (int q = threadIdx.x; q < CB * N; q += blockDim.x) {
     const int col = q % CB, j = q / CB;
-    if (m0 + col < ncols) { const double2 v = pc[(g.ix(0, j + 1, k) >> 1) + m0 + col]; base[(size_t)col * 2 * ld + j] = cpx{v.x, v.y}; }
+    if (m0 + col < ncols) { const double2 v = pc[S.at_mode(g, m0 + col, j + 1, k)]; base[(size_t)col * 2 * ld + j] = cpx{v.x, v.y}; }
   }
   __syncthreads();
   const int col = threadIdx.x / T, t = threadIdx.x % T;
@@ -151,9 +147,8 @@ __global__ __launch_bounds__(256) void k_fft_y(Geom g, FftPlan P, int CB, int nc
   const bool swapped = (Z != A);   // same for every column
   for (int q = threadIdx.x; q < CB * N; q += blockDim.x) {
     const int c2 = q % CB, j = q / CB;
-    if (m0 + c2 < ncols) { const cpx v = base[(size_t)c2 * 2 * ld + (swapped ? ld : 0) + j]; pc[(g.ix(0, j + 1, k) >> 1) + m0 + c2] = make_double2(v.x, v.y); }
+    if (m0 + c2 < ncols) { const cpx v = base[(size_t)c2 * 2 * ld + (swapped ? ld : 0) + j]; pc[S.at_mode(g, m0 + c2, j + 1, k)] = make_double2(v.x, v.y); }
   }
-  (void)rowc;
 }
 
 // ------------------------------------------------------------------------------------------ z pass (solver.f90:82-179)
@@ -168,19 +163,22 @@ template <typename VT> __device__ inline VT vfma(VT a, double s, VT b);   // a +
 template <> __device__ inline double2 vfma<double2>(double2 a, double s, double2 b) { return make_double2(a.x + s * b.x, a.y + s * b.y); }
 template <> __device__ inline double vfma<double>(double a, double s, double b) { return a + s * b; }
 
+// ncol x nrow columns; spectral solve: S maps (m, j) (mode side), mofs = global index of local mode 0, nmode = number of
+// real modes (padding columns beyond it are skipped). Real fields (VT = double): in-place haloed array, i0 = 1.
 template <typename VT, int PERIODIC>
-__global__ __launch_bounds__(256) void k_gaussel(Geom g, int nz, int ncol, int i0, const double *__restrict__ a, const double *__restrict__ b,
+__global__ __launch_bounds__(256) void k_gaussel(Geom g, int nz, int ncol, int nrow, int i0, int mofs, int nmode, Spec S,
+                                                 const double *__restrict__ a, const double *__restrict__ b,
                                                  const double *__restrict__ c, const double *__restrict__ lamx,
                                                  const double *__restrict__ lamy, double *__restrict__ pd, double *__restrict__ dscr,
                                                  double *__restrict__ p2scr) {
   const int m = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y + 1;
-  if (m >= ncol || j > g.n2) return;
+  if (m >= ncol || j > nrow || m + mofs >= nmode) return;
   constexpr int W = sizeof(VT) / sizeof(double);
   VT *p = reinterpret_cast<VT *>(pd);
-  const size_t e0 = (g.ix(0, j, 1)) / W + m + i0;            // element index of k=1 in units of VT
-  const size_t st = (size_t)g.s12 / W;
-  const size_t s0 = (size_t)m + (size_t)ncol * (size_t)(j - 1), sst = (size_t)ncol * g.n2;   // scratch [k][j][m]
-  const double lam = (lamx ? lamx[m] : 0.) + (lamy ? lamy[j - 1 + g.jlo] : 0.);
+  const size_t e0 = W == 2 ? S.at_mode(g, m, j, 1) : g.ix(m + i0, j, 1);    // element index of k=1 in units of VT
+  const size_t st = W == 2 ? (S.blocked ? (size_t)S.cw * S.n2l : (size_t)g.s12 / 2) : (size_t)g.s12;
+  const size_t s0 = (size_t)m + (size_t)ncol * (size_t)(j - 1), sst = (size_t)ncol * nrow;   // scratch [k][j][m]
+  const double lam = (lamx ? lamx[m + mofs] : 0.) + (lamy ? lamy[j - 1] : 0.);
   const int n = PERIODIC ? nz - 1 : nz;
   // forward elimination
   double z = 1. / (b[0] + lam + CALES_EPS), d = c[0] * z;
@@ -223,7 +221,6 @@ int solver_setup(cales_ctx *c) {
   const int *n = c->n; const int n1 = c->C.ng[0], n2g = c->C.ng[1], n3 = n[2];
   const std::string bx = std::string(1, c->C.cbcpre[0]) + c->C.cbcpre[1], by = std::string(1, c->C.cbcpre[2]) + c->C.cbcpre[3];
   if (bx != "PP" || by != "PP") { c->err = "solver: only periodic x and y pressure BCs are provided by the device path in this build"; return 1; }
-  if (c->C.nranks != 1) { c->err = "solver: multi-rank transposes not built yet"; return 1; }
   SolverPlans sp;
   if (!make_plan(n1 / 2, sp.px) || !make_plan(n2g, sp.py)) { c->err = "solver: ng(1)/2 and ng(2) must factor into 2,3,5"; return 1; }
   // rows per block in x: aim at ~nh/4 threads per row, 256 threads per block
@@ -240,6 +237,8 @@ int solver_setup(cales_ctx *c) {
   for (auto &v : lx) v = v * (c->dli[0] * c->dli[0]);
   for (auto &v : ly) v = v * (c->dli[1] * c->dli[1]);
   const int mh = n1 / 2 + 1;
+  c->cw = (mh + c->P - 1) / c->P;                            // complex mode columns per rank (last block padded)
+  if (c->P > 1 && (size_t)c->cw * n2g * n3 > c->ntot) { c->err = "solver: scratch too small for the mode-block layout"; return 1; }
   HIPCHK(c, hipMalloc(&c->d_lamx, mh * sizeof(double))); HIPCHK(c, hipMalloc(&c->d_lamy, n2g * sizeof(double)));
   HIPCHK(c, hipMemcpy(c->d_lamx, lx.data(), mh * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_lamy, ly.data(), n2g * sizeof(double), hipMemcpyHostToDevice));
@@ -286,23 +285,32 @@ int op_solver(cales_ctx *c) {
   SolverPlans *sp = find_plans(c);
   if (!sp) { c->err = "solver not initialised"; return 1; }
   const int *n = c->n; double *pp = c->f[CALES_PP];
-  const int mh = c->g.s1 / 2;
+  const int mh = c->g.s1 / 2, n2g = c->C.ng[1];
   const long nrows = (long)n[1] * n[2];
   const bool periodic_z = CBP(c, 0, 3) == 'P' && CBP(c, 1, 3) == 'P';
+  const bool dist = c->P > 1;
+  if (dist && !c->comm.on) { c->err = "solver: nranks > 1 but no communication hooks registered (cales_set_comm)"; return 1; }
+  Spec S; S.blocked = dist ? 1 : 0; S.cw = c->cw; S.n2l = n[1]; S.n3 = n[2];
+  double2 *slab_spec = dist ? reinterpret_cast<double2 *>(c->comm.A) : reinterpret_cast<double2 *>(pp);
+  double2 *mode_spec = dist ? reinterpret_cast<double2 *>(c->comm.B) : reinterpret_cast<double2 *>(pp);
+  const int ncol = dist ? c->cw : mh, mofs = dist ? c->rank * c->cw : 0;
+  const int64_t a2a_count = (int64_t)n[2] * n[1] * c->cw * 2;
   { ProfScope ps(c, "fft_x_fwd");
     hipLaunchKernelGGL(k_fft_x<0>, dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
-                       (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, pp, 1.); }
+                       (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, pp, 1., S, slab_spec); }
+  if (dist) { ProfScope ps(c, "alltoall"); if (c->comm.a2a(c->comm.user, 0, a2a_count)) { c->err = "alltoall callback failed"; return 1; } }
   { ProfScope ps(c, "fft_y_fwd");
-    hipLaunchKernelGGL(k_fft_y<0>, dim3((mh + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, mh, (const cpx *)c->d_twy, pp); }
+    hipLaunchKernelGGL(k_fft_y<0>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, (const cpx *)c->d_twy, S, mode_spec); }
   { ProfScope ps(c, "gaussel_z");
-    dim3 b(64, 4), gr((mh + 63) / 64, (n[1] + 3) / 4);
-    if (periodic_z) hipLaunchKernelGGL((k_gaussel<double2, 1>), gr, b, 0, c->stream, c->g, n[2], mh, 0, c->d_a, c->d_b, c->d_c, c->d_lamx, c->d_lamy, pp, c->scr1, c->scr2);
-    else hipLaunchKernelGGL((k_gaussel<double2, 0>), gr, b, 0, c->stream, c->g, n[2], mh, 0, c->d_a, c->d_b, c->d_c, c->d_lamx, c->d_lamy, pp, c->scr1, c->scr2); }
+    dim3 b(64, 4), gr((ncol + 63) / 64, (n2g + 3) / 4);
+    if (periodic_z) hipLaunchKernelGGL((k_gaussel<double2, 1>), gr, b, 0, c->stream, c->g, n[2], ncol, n2g, 0, mofs, mh, S, c->d_a, c->d_b, c->d_c, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2);
+    else hipLaunchKernelGGL((k_gaussel<double2, 0>), gr, b, 0, c->stream, c->g, n[2], ncol, n2g, 0, mofs, mh, S, c->d_a, c->d_b, c->d_c, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2); }
   { ProfScope ps(c, "fft_y_bwd");
-    hipLaunchKernelGGL(k_fft_y<1>, dim3((mh + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, mh, (const cpx *)c->d_twy, pp); }
+    hipLaunchKernelGGL(k_fft_y<1>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, (const cpx *)c->d_twy, S, mode_spec); }
+  if (dist) { ProfScope ps(c, "alltoall"); if (c->comm.a2a(c->comm.user, 1, a2a_count)) { c->err = "alltoall callback failed"; return 1; } }
   { ProfScope ps(c, "fft_x_bwd");
     hipLaunchKernelGGL(k_fft_x<1>, dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
-                       (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, pp, c->normfft); }
+                       (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, pp, c->normfft, S, slab_spec); }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -325,8 +333,9 @@ int op_helmholtz_z(cales_ctx *c, int ivel, double alpha) {
   const bool periodic = bcz[0] == 'P' && bcz[1] == 'P';
   dim3 b(64, 4), gr((n[0] + 63) / 64, (n[1] + 3) / 4);
   double *fld = c->f[CALES_U + ivel - 1];
-  if (periodic) hipLaunchKernelGGL((k_gaussel<double, 1>), gr, b, 0, c->stream, c->g, n3 - q, n[0], 1, abc, abc + n3, abc + 2 * n3, (const double *)nullptr, (const double *)nullptr, fld, c->scr1, c->scr2);
-  else hipLaunchKernelGGL((k_gaussel<double, 0>), gr, b, 0, c->stream, c->g, n3 - q, n[0], 1, abc, abc + n3, abc + 2 * n3, (const double *)nullptr, (const double *)nullptr, fld, c->scr1, c->scr2);
+  Spec S; S.blocked = 0; S.cw = 0; S.n2l = n[1]; S.n3 = n3;
+  if (periodic) hipLaunchKernelGGL((k_gaussel<double, 1>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, abc, abc + n3, abc + 2 * n3, (const double *)nullptr, (const double *)nullptr, fld, c->scr1, c->scr2);
+  else hipLaunchKernelGGL((k_gaussel<double, 0>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, abc, abc + n3, abc + 2 * n3, (const double *)nullptr, (const double *)nullptr, fld, c->scr1, c->scr2);
   HIPCHK(c, hipGetLastError());
   return 0;
 }

@@ -181,27 +181,36 @@ __global__ __launch_bounds__(256) void k_bulk_mean_partial(Geom g, const double 
   const double r = block_reduce<0>(acc, sh);
   if (threadIdx.x == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = r;
 }
-// out[slot] = op(partials); optional: f = velf - mean (rk.f90:209-221), dpdl += f (main.f90:492)
-__global__ __launch_bounds__(256) void k_fold(const double *__restrict__ part, int np, int op, double *__restrict__ out, int slot,
-                                              int mode, double velf, double *__restrict__ force, int comp) {
+// out[slot] = op(partials)
+__global__ __launch_bounds__(256) void k_fold(const double *__restrict__ part, int np, int op, double *__restrict__ out, int slot) {
   __shared__ double sh[4];
   double acc = 0.;
   for (int q = threadIdx.x; q < np; q += 256) acc = op ? fmax(acc, part[q]) : acc + part[q];
   const double r = op ? block_reduce<1>(acc, sh) : block_reduce<0>(acc, sh);
-  if (threadIdx.x == 0) {
-    out[slot] = r;
-    if (mode == 1) { const double f = velf - r; force[comp] = f; force[3 + comp] += f; }
-  }
+  if (threadIdx.x == 0) out[slot] = r;
+}
+// f = velf - mean (rk.f90:209-221), dpdl += f (main.f90:492)
+__global__ void k_force_finish(const double *__restrict__ res, int slot, double velf, double *__restrict__ force, int comp) {
+  if (threadIdx.x == 0) { const double f = velf - res[slot]; force[comp] = f; force[3 + comp] += f; }
+}
+// all-reduce of res[slot..slot+count) across the slabs (utils.f90:46, chkdiv.f90:50-51, chkdt.f90:98, sgs.f90:475)
+int allreduce_res(cales_ctx *c, int slot, int count, int op) {
+  if (c->P == 1) return 0;
+  if (!c->comm.on) { c->err = "nranks > 1 but no communication hooks registered (cales_set_comm)"; return 1; }
+  const int64_t off = (c->res - c->comm.A) + slot;
+  if (c->comm.allred(c->comm.user, off, count, op)) { c->err = "allreduce callback failed"; return 1; }
+  return 0;
 }
 
 int op_bulk_mean_dev(cales_ctx *c, const double *p, int c_or_f, double *d_out) {
+  (void)d_out;
   ProfScope ps(c, "bulk_mean");
   const int nbx = 8;
   dim3 gr(nbx, c->n[2]);
   hipLaunchKernelGGL(k_bulk_mean_partial, gr, dim3(256), 0, c->stream, c->g, p, c_or_f ? c->d_gvr_f : c->d_gvr_c, c->d_red + 64);
-  hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, nbx * c->n[2], 0, d_out, 0, 0, 0., (double *)nullptr, 0);
+  hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, nbx * c->n[2], 0, c->res, 16);
   HIPCHK(c, hipGetLastError());
-  return 0;
+  return allreduce_res(c, 16, 1, 0);
 }
 
 static int forcing_component(cales_ctx *c, int comp) {   // cmpt_bulk_forcing, rk.f90:197-222
@@ -209,7 +218,9 @@ static int forcing_component(cales_ctx *c, int comp) {   // cmpt_bulk_forcing, r
   dim3 gr(nbx, c->n[2]);
   const double *p = c->f[CALES_U + comp];
   hipLaunchKernelGGL(k_bulk_mean_partial, gr, dim3(256), 0, c->stream, c->g, p, comp == 2 ? c->d_gvr_c : c->d_gvr_f, c->d_red + 64);
-  hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, nbx * c->n[2], 0, c->d_red, 8 + comp, 1, c->C.velf[comp], c->d_force, comp);
+  hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, nbx * c->n[2], 0, c->res, 8 + comp);
+  if (int e = allreduce_res(c, 8 + comp, 1, 0)) return e;
+  hipLaunchKernelGGL(k_force_finish, dim3(1), dim3(64), 0, c->stream, c->res, 8 + comp, c->C.velf[comp], c->d_force, comp);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -344,9 +355,11 @@ int op_chkdiv(cales_ctx *c, double *divtot, double *divmax) {
   const int nbx = 8, np = nbx * c->n[2];
   hipLaunchKernelGGL(k_chkdiv_partial, dim3(nbx, c->n[2]), dim3(256), 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzfi, c->f[CALES_U],
                      c->f[CALES_V], c->f[CALES_W], c->d_red + 64, c->d_red + 64 + np);
-  hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, np, 0, c->d_red, 0, 0, 0., (double *)nullptr, 0);
-  hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64 + np, np, 1, c->d_red, 1, 0, 0., (double *)nullptr, 0);
-  HIPCHK(c, hipMemcpyAsync(c->h_red, c->d_red, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, np, 0, c->res, 0);
+  hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64 + np, np, 1, c->res, 1);
+  if (int e = allreduce_res(c, 0, 1, 0)) return e;
+  if (int e = allreduce_res(c, 1, 1, 1)) return e;
+  HIPCHK(c, hipMemcpyAsync(c->h_red, c->res, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   *divtot = c->h_red[0]; *divmax = c->h_red[1];
   return 0;
@@ -392,9 +405,10 @@ int op_chkdt(cales_ctx *c, double *dtmax) {
   else
     hipLaunchKernelGGL(k_chkdt_partial<0>, dim3(nbx, c->n[2]), dim3(256), 0, c->stream, c->g, 1. / c->dl[0], 1. / c->dl[1], c->visc, c->d_dzci,
                        c->d_dzfi, f[CALES_VISCT], f[CALES_U], f[CALES_V], f[CALES_W], c->d_red + 64, c->d_red + 64 + np);
-  hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, np, 1, c->d_red, 0, 0, 0., (double *)nullptr, 0);
-  hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64 + np, np, 1, c->d_red, 1, 0, 0., (double *)nullptr, 0);
-  HIPCHK(c, hipMemcpyAsync(c->h_red, c->d_red, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, np, 1, c->res, 0);
+  hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64 + np, np, 1, c->res, 1);
+  if (int e = allreduce_res(c, 0, 2, 1)) return e;
+  HIPCHK(c, hipMemcpyAsync(c->h_red, c->res, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   double dti = c->h_red[0], dtid = c->h_red[1];
   if (dti == 0.) dti = 1.;

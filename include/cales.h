@@ -89,6 +89,26 @@ int cales_chkdiv(cales_ctx *ctx, double *divtot, double *divmax);           /* s
 int cales_step(cales_ctx *ctx, double dt);
 int cales_get_dpdl(cales_ctx *ctx, double dpdl[3]);                         /* main.f90:492,508 (sync) */
 
+/* ---- multi-GPU: y-slab decomposition --------------------------------------
+ * The reference exchanges halos with MPI_SENDRECV / cudecompUpdateHalos (src/bound.f90:619-723) and transposes
+ * pencils with 2decomp / cudecompTranspose* (src/solver.f90:50-66, src/solver_gpu.f90:97-125). Here the rank owns
+ * a y-slab; the library packs/unpacks on the device and calls back into the host for the three exchanges, which the
+ * host performs on its own communicator (torch.distributed/RCCL in cales_amd/decomp.py). Offsets are in doubles,
+ * relative to the staging buffers A and B registered below; every callback must enqueue its work on the
+ * context's stream (or order it after that stream) and return 0.
+ *   halo:      send A[off_send_lo..+count) to the lower y-neighbour and A[off_send_hi..) to the upper one; receive the
+ *              lower neighbour's "hi" block into B[off_recv_lo..) and the upper neighbour's "lo" block into B[off_recv_hi..)
+ *   alltoall:  dir 0: A -> B, dir 1: B -> A; `count` doubles per peer, peer blocks contiguous in rank order
+ *   allreduce: in place on A[off..off+count), op 0 sum, 1 max, 2 min */
+typedef int (*cales_halo_cb)(void *user, int64_t off_send_lo, int64_t off_send_hi, int64_t off_recv_lo, int64_t off_recv_hi, int64_t count);
+typedef int (*cales_alltoall_cb)(void *user, int dir, int64_t count);
+typedef int (*cales_allreduce_cb)(void *user, int64_t off, int64_t count, int op);
+int cales_comm_buffer_doubles(const cales_ctx *ctx, int64_t *n);      /* required size of A and of B */
+int cales_set_comm(cales_ctx *ctx, cales_halo_cb halo, cales_alltoall_cb a2a, cales_allreduce_cb allred, void *user,
+                   double *bufA, double *bufB, int64_t nbuf);
+/* initial field of the rank's slab only (local haloed arrays); the volume mean is summed in the global order */
+int cales_initflow_slab(const cales_case *c, const char *inivel, int is_wallturb, double *u, double *v, double *w, double *p);
+
 /* ---- measurement -------------------------------------------------------------------------- */
 /* When enabled, every kernel launch is bracketed by HIP events on the context's stream. */
 int cales_profile_enable(cales_ctx *ctx, int on);

@@ -1,0 +1,114 @@
+"""CPU-side checks of the product (no GPU needed): the C-ABI library loads and exports every symbol
+include/cales.h declares; its host-only helpers reproduce the reference's set-up (golden vectors); the
+namelist reader mirrors read_input (reference src/param.f90:88-224)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from cales_amd import capi
+from cales_amd.nml import NamelistError, parse_text
+from tests.util import FULL_CASES, GOLD, load_golden, relerr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "cales.h")).read()
+    declared = set(re.findall(r"\b(cales_[a-z_0-9]+)\s*\(", hdr)) - {"cales_halo_cb", "cales_alltoall_cb", "cales_allreduce_cb"}
+    assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
+    L = capi.lib()
+    for s in declared:
+        assert hasattr(L, s), s
+
+
+def test_no_cpu_fallback_and_no_oracle_in_product():
+    """cales_create must fail loudly without a HIP device; nothing under cales_amd/ touches oracle/."""
+    for root, _, files in os.walk(os.path.join(ROOT, "cales_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".f90", "Makefile")):
+                txt = open(os.path.join(root, f), errors="ignore").read()
+                assert "oracle" not in txt.replace("the oracle", "").replace("against the oracle", "") or f.endswith(".hip"), (root, f)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    g, case = load_golden("tgv_ppp")
+    from cales_amd.hotpath import CalesError, HotPath
+    with pytest.raises(CalesError):
+        HotPath(case)
+
+
+def test_initgrid_matches_reference():
+    from cales_amd.hotpath import initgrid
+    g = np.load(os.path.join(GOLD, "grids.npz"))
+    q = 0
+    while f"g{q}_spec" in g.files:
+        gtype, gr, n3, lz = g[f"g{q}_spec"]
+        out = initgrid(int(gtype), int(n3), float(gr), float(lz))
+        for k in ("dzc", "dzf", "zc", "zf"):
+            assert relerr(out[k], g[f"g{q}_{k}"]) < 4e-16, (q, k)
+        q += 1
+
+
+@pytest.mark.parametrize("name", [c for c in FULL_CASES if c != "halfchan_imp1d"])
+def test_initflow_matches_reference(name):
+    from cales_amd.hotpath import initflow
+    g, case = load_golden(name)
+    for a, k in zip(initflow(case), "uvwp"):
+        ref = g["if_" + k]
+        assert np.abs(a - ref).max() <= 2e-15 * max(1., np.abs(ref).max()), k
+
+
+def test_rng_initial_fields_are_refused():
+    from cales_amd.hotpath import CalesError, initflow
+    g, case = load_golden("chan_smag")
+    case.inivel = "log"
+    with pytest.raises(CalesError):
+        initflow(case)
+    case.inivel = "nonsense"
+    with pytest.raises(CalesError):
+        initflow(case)
+
+
+def test_check_case_rules():
+    """the rules of reference src/sanity.f90:115-274 that bound what the kernels must support"""
+    from cales_amd.hotpath import CalesError, check_case
+    g, case = load_golden("chan_smag_wm")
+    check_case(case)
+    bad = case.copy(); bad.cbcpre[:, 2] = "D"                  # velocity DD needs pressure NN
+    with pytest.raises(CalesError):
+        check_case(bad)
+    bad = case.copy(); bad.is_forced[2] = True                 # forcing along a non-periodic direction
+    with pytest.raises(CalesError):
+        check_case(bad)
+    bad = case.copy(); bad.cbcvel[0, 2, 0] = "N"               # wall-model faces must be all-Dirichlet
+    with pytest.raises(CalesError):
+        check_case(bad)
+    bad = case.copy(); bad.bcpre[0, 0] = 1.                    # x,y pressure BC values must be zero
+    with pytest.raises(CalesError):
+        check_case(bad)
+    bad = case.copy(); bad.impdiff = 1                         # 3-D implicit diffusion: not provided
+    with pytest.raises(CalesError):
+        check_case(bad)
+    with pytest.raises(CalesError):
+        check_case(case, nranks=5)                             # ng(2) not divisible
+
+
+def test_namelist_reader():
+    g, case = load_golden("tgv_ppp")
+    text = str(g["input_nml"])
+    # the reference's examples/dns/* close &les with a backslash: accepted
+    alt = re.sub(r"(?s)(&les.*?)\n/", lambda m: m.group(1) + "\n" + chr(92), text, count=1)
+    assert alt.count(chr(92)) == 1
+    c2 = parse_text(alt)
+    assert c2.sgstype == case.sgstype and (c2.lwm == case.lwm).all() and c2.hwm == case.hwm
+    assert c2.dt_f == -1.0                                     # default, param.f90:124
+    assert (case.cbcvel == "P").all() and case.cbcvel.shape == (2, 3, 3)
+    with pytest.raises(NamelistError):
+        parse_text("&dns\nng(1:3) = 4,4,4\n/\n")               # &les missing (param.f90:144-150)
+    with pytest.raises(NamelistError):
+        parse_text(text.replace("gtype = 1", "gtype = 1, bogus = 3"))
+    c3 = parse_text(text.replace("ng(1:3) = 12, 10, 8", "ng(1:3) = 3*16 ! repeat count"))
+    assert (c3.ng == 16).all()
