@@ -1,0 +1,97 @@
+! ISO_C_BINDING view of include/cales.h -- what a Fortran host (the reference's own language) binds to.
+! `type(cales_case)` mirrors `struct cales_case`; character and multi-dimensional members keep the
+! storage order of the reference's namelist variables (src/param.f90:37-76), so they are copied unchanged.
+module cales_c
+  use, intrinsic :: iso_c_binding
+  implicit none
+  public
+  integer(c_int), parameter :: CALES_U = 0, CALES_V = 1, CALES_W = 2, CALES_P = 3, CALES_PP = 4, CALES_VISCT = 5
+  type, bind(C) :: cales_case
+    integer(c_int32_t) :: ng(3)
+    real(c_double)     :: l(3)
+    integer(c_int32_t) :: gtype
+    real(c_double)     :: gr
+    real(c_double)     :: visci
+    character(kind=c_char) :: cbcvel(18),cbcpre(6),cbcsgs(6)
+    real(c_double)     :: bcvel(18),bcpre(6),bcsgs(6)
+    real(c_double)     :: bforce(3)
+    integer(c_int32_t) :: is_forced(3)
+    real(c_double)     :: velf(3)
+    integer(c_int32_t) :: sgstype
+    integer(c_int32_t) :: lwm(6)
+    real(c_double)     :: hwm
+    integer(c_int32_t) :: impdiff
+    integer(c_int32_t) :: nranks,rank
+  end type cales_case
+  interface
+    integer(c_int) function cales_initgrid(gtype,n,gr,lz,dzc,dzf,zc,zf) bind(C,name='cales_initgrid')
+      import; integer(c_int), value :: gtype,n; real(c_double), value :: gr,lz; real(c_double) :: dzc(*),dzf(*),zc(*),zf(*)
+    end function
+    integer(c_int) function cales_initflow(c,inivel,is_wallturb,u,v,w,p) bind(C,name='cales_initflow')
+      import; type(cales_case), intent(in) :: c; character(kind=c_char) :: inivel(*); integer(c_int), value :: is_wallturb
+      real(c_double) :: u(*),v(*),w(*),p(*)
+    end function
+    integer(c_int) function cales_check_case(c,msg,msglen) bind(C,name='cales_check_case')
+      import; type(cales_case), intent(in) :: c; character(kind=c_char) :: msg(*); integer(c_int), value :: msglen
+    end function
+    integer(c_int) function cales_create(c,stream,ctx) bind(C,name='cales_create')
+      import; type(cales_case), intent(in) :: c; type(c_ptr), value :: stream; type(c_ptr) :: ctx
+    end function
+    subroutine cales_destroy(ctx) bind(C,name='cales_destroy')
+      import; type(c_ptr), value :: ctx
+    end subroutine
+    type(c_ptr) function cales_last_error(ctx) bind(C,name='cales_last_error')
+      import; type(c_ptr), value :: ctx
+    end function
+    integer(c_int) function cales_upload_state(ctx,u,v,w,p) bind(C,name='cales_upload_state')
+      import; type(c_ptr), value :: ctx; real(c_double) :: u(*),v(*),w(*),p(*)
+    end function
+    integer(c_int) function cales_download_state(ctx,u,v,w,p,visct) bind(C,name='cales_download_state')
+      import; type(c_ptr), value :: ctx; real(c_double) :: u(*),v(*),w(*),p(*),visct(*)
+    end function
+    integer(c_int) function cales_bounduvw(ctx,is_updt_wm,is_correc) bind(C,name='cales_bounduvw')
+      import; type(c_ptr), value :: ctx; integer(c_int), value :: is_updt_wm,is_correc
+    end function
+    integer(c_int) function cales_boundp(ctx,field,which) bind(C,name='cales_boundp')
+      import; type(c_ptr), value :: ctx; integer(c_int), value :: field,which
+    end function
+    integer(c_int) function cales_cmpt_sgs(ctx) bind(C,name='cales_cmpt_sgs')
+      import; type(c_ptr), value :: ctx
+    end function
+    integer(c_int) function cales_chkdt(ctx,dtmax) bind(C,name='cales_chkdt')
+      import; type(c_ptr), value :: ctx; real(c_double) :: dtmax
+    end function
+    integer(c_int) function cales_chkdiv(ctx,divtot,divmax) bind(C,name='cales_chkdiv')
+      import; type(c_ptr), value :: ctx; real(c_double) :: divtot,divmax
+    end function
+    integer(c_int) function cales_step(ctx,dt) bind(C,name='cales_step')
+      import; type(c_ptr), value :: ctx; real(c_double), value :: dt
+    end function
+    integer(c_int) function cales_get_dpdl(ctx,dpdl) bind(C,name='cales_get_dpdl')
+      import; type(c_ptr), value :: ctx; real(c_double) :: dpdl(3)
+    end function
+    integer(c_int) function cales_bulk_mean(ctx,field,c_or_f,mean) bind(C,name='cales_bulk_mean')
+      import; type(c_ptr), value :: ctx; integer(c_int), value :: field,c_or_f; real(c_double) :: mean
+    end function
+    integer(c_int) function cales_sync(ctx) bind(C,name='cales_sync')
+      import; type(c_ptr), value :: ctx
+    end function
+    ! the per-operator entries (cales_rk, cales_fillps, cales_solver, cales_correc, cales_updatep, ...) follow the
+    ! same pattern; the driver below uses the fused cales_step, which queues exactly their sequence.
+    integer(c_int) function cales_rk(ctx,irk,dt) bind(C,name='cales_rk')
+      import; type(c_ptr), value :: ctx; integer(c_int), value :: irk; real(c_double), value :: dt
+    end function
+    integer(c_int) function cales_fillps(ctx,dtrki) bind(C,name='cales_fillps')
+      import; type(c_ptr), value :: ctx; real(c_double), value :: dtrki
+    end function
+    integer(c_int) function cales_solver(ctx) bind(C,name='cales_solver')
+      import; type(c_ptr), value :: ctx
+    end function
+    integer(c_int) function cales_correc(ctx,dtrk) bind(C,name='cales_correc')
+      import; type(c_ptr), value :: ctx; real(c_double), value :: dtrk
+    end function
+    integer(c_int) function cales_updatep(ctx,alpha) bind(C,name='cales_updatep')
+      import; type(c_ptr), value :: ctx; real(c_double), value :: alpha
+    end function
+  end interface
+end module cales_c

@@ -1,0 +1,96 @@
+"""The Fortran host (cales_amd/fortran/cales, ISO_C_BINDING over the C-ABI) run as a user would run the
+reference: `input.nml` in the working directory, `fld.bin` / `time.out` / `forcing.out` / `grid.bin` out.
+Checks the checkpoint byte layout (reference src/load.f90:20-153, utils/read_binary_data/python/
+read_restart_file.py:43-56), equality with the Python host driving the same library, and restart equivalence."""
+import os
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.util import F, load_golden
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "cales_amd", "fortran", "cales")
+
+
+def _nml(name, **subs):
+    g, case = load_golden(name)
+    text = str(g["input_nml"])
+    for k, v in subs.items():
+        text, n = re.subn(rf"(?m)\b{k}\s*=\s*[^,\n]+", f"{k} = {v}", text, count=1)
+        assert n == 1, k
+    return text
+
+
+def _run(tmp, text, args=()):
+    os.makedirs(tmp, exist_ok=True)
+    open(os.path.join(tmp, "input.nml"), "w").write(text)
+    r = subprocess.run([EXE, *args], cwd=tmp, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+def _read_fld(path, ng):
+    data = np.fromfile(path, dtype=np.float64)
+    n = int(np.prod(ng))
+    assert data.size == 4 * n + 2                                   # (4*N+2)*sizeof(rp), load.f90:44-52
+    flds = [data[q * n:(q + 1) * n].reshape(ng, order="F") for q in range(4)]
+    return flds, data[-2], int(round(data[-1]))
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="Fortran host not built (amdflang absent)")
+@pytest.mark.parametrize("name", ["tgv_ppp", "chan_smag_wm"])
+def test_fortran_host_equals_python_host(tmp_path, name):
+    from cales_amd.hotpath import HotPath, initflow
+    from cales_amd.nml import parse_text
+    text = _nml(name, nstep=4, icheck=2, iout0d=2, isave=100000)
+    text = re.sub(r"stop_type\(1:3\) = .*", "stop_type(1:3) = T, F, F", text)
+    out = _run(str(tmp_path), text)
+    assert "*** Fim ***" in out
+    case = parse_text(text)
+    ng = tuple(int(x) for x in case.ng)
+    (u, v, w, p), time, istep = _read_fld(os.path.join(tmp_path, "fld.bin"), ng)
+    assert istep == 4
+    # same loop with the Python host (main.f90:395-396,523-527)
+    h = HotPath(case)
+    h.upload(*initflow(case)); h.startup()
+    dt = min(case.cfl * h.chkdt(), case.dtmax); t = 0.
+    for s in range(1, 5):
+        t += dt; h.step(dt)
+        if s % 2 == 0:
+            dt = min(case.cfl * h.chkdt(), case.dtmax)
+    gu, gv, gw, gp, _ = h.download()
+    for a, b in ((u, gu), (v, gv), (w, gw), (p, gp)):
+        assert np.array_equal(a, b[1:-1, 1:-1, 1:-1])               # same library, same sequence: bit-identical
+    assert abs(time - t) < 1e-15 * max(1., t)
+    tout = np.loadtxt(os.path.join(tmp_path, "time.out"))
+    assert tout.shape == (2, 3) and tout[-1, 0] == 4.
+    if case.is_forced.any():
+        fo = np.loadtxt(os.path.join(tmp_path, "forcing.out"))
+        assert fo.shape == (2, 7) and abs(fo[-1, 4] - 1.) < 1e-10      # bulk velocity held at velf = 1
+    grid = np.fromfile(os.path.join(tmp_path, "grid.bin"))
+    g, _ = load_golden(name)
+    assert np.allclose(grid[:ng[2]], g["g_dzc"][1:-1], rtol=1e-15)
+    h.close()
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="Fortran host not built (amdflang absent)")
+def test_restart_equivalence(tmp_path):
+    """4 steps in one go == 2 steps, checkpoint, restart, 2 more (the RK history is not saved; harmless because
+    rkcoeff(2,1) = 0, src/param.f90:27-29)."""
+    base = re.sub(r"stop_type\(1:3\) = .*", "stop_type(1:3) = T, F, F", _nml("chan_smag", nstep=4, icheck=2, iout0d=0, isave=100000))
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    _run(a, base)
+    _run(b, base.replace("nstep = 4", "nstep = 2"))
+    _run(b, base.replace("restart = F", "restart = T"))
+    ng = (10, 12, 8)
+    fa, ta, ia = _read_fld(os.path.join(a, "fld.bin"), ng)
+    fb, tb, ib = _read_fld(os.path.join(b, "fld.bin"), ng)
+    assert ia == ib == 4 and abs(ta - tb) < 1e-14
+    for x, y in zip(fa[:3], fb[:3]):
+        assert np.abs(x - y).max() < 1e-12 * max(1., np.abs(x).max())
+    assert np.abs((fa[3] - fa[3].mean()) - (fb[3] - fb[3].mean())).max() < 1e-10
