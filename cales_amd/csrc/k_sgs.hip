@@ -54,7 +54,8 @@ __global__ __launch_bounds__(BX *BY) void k_strain(Geom g, double dxi, double dy
                                                     const double *__restrict__ dzfi, const double *__restrict__ u,
                                                     const double *__restrict__ v, const double *__restrict__ w, double *__restrict__ s0,
                                                     double *__restrict__ s11o, double *__restrict__ s22o, double *__restrict__ s33o,
-                                                    double *__restrict__ s12o, double *__restrict__ s13o, double *__restrict__ s23o) {
+                                                    double *__restrict__ s12o, double *__restrict__ s13o, double *__restrict__ s23o,
+                                                    double *__restrict__ s0copy) {
   const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;
   if (i > g.n1 || j > g.n2) return;
   const size_t c = g.ix(i, j, k);
@@ -75,15 +76,17 @@ __global__ __launch_bounds__(BX *BY) void k_strain(Geom g, double dxi, double dy
                              (u_mcp - u_mcc) * zc + (w_ccc - w_mcc) * dxi + (u_mcc - u_mcm) * zm + (w_ccm - w_mcm) * dxi);
   const double s23 = .125 * ((v_ccp - v_ccc) * zc + (w_cpc - w_ccc) * dyi + (v_ccc - v_ccm) * zm + (w_cpm - w_ccm) * dyi +
                              (v_cmp - v_cmc) * zc + (w_ccc - w_cmc) * dyi + (v_cmc - v_cmm) * zm + (w_ccm - w_cmm) * dyi);
-  s0[c] = sqrt(2. * (s11 * s11 + s22 * s22 + s33 * s33 + 2. * (s12 * s12 + s13 * s13 + s23 * s23)));
+  const double s0v = sqrt(2. * (s11 * s11 + s22 * s22 + s33 * s33 + 2. * (s12 * s12 + s13 * s13 + s23 * s23)));
+  s0[c] = s0v;
   if (WITH_SIJ) { s11o[c] = s11; s22o[c] = s22; s33o[c] = s33; s12o[c] = s12; s13o[c] = s13; s23o[c] = s23; }
+  if (WITH_SIJ == 2) s0copy[c] = s0v;          // visct = s0 (sgs.f90:184) without a separate copy pass
 }
 static int strain_rate(cales_ctx *c, const double *u, const double *v, const double *w, double *s0, double **sij) {
   ProfScope ps(c, "strain_rate");
   dim3 b(BX, BY, 1), gr = grid3(c->n[0], c->n[1], c->n[2], b);
-  if (sij) hipLaunchKernelGGL(k_strain<1>, gr, b, 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, u, v, w, s0, sij[0], sij[1], sij[2], sij[3], sij[4], sij[5]);
+  if (sij) hipLaunchKernelGGL(k_strain<1>, gr, b, 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, u, v, w, s0, sij[0], sij[1], sij[2], sij[3], sij[4], sij[5], (double *)nullptr);
   else hipLaunchKernelGGL(k_strain<0>, gr, b, 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, u, v, w, s0, (double *)nullptr,
-                          (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr);
+                          (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -231,7 +234,240 @@ __global__ __launch_bounds__(256) void k_alph2(Geom g, double w0, double w1, dou
   alph2[g.ix(i, j, k)] = near ? 2.52 : 4.00;
 }
 
+// ================================================================================================
+// Fast path of the dynamic model for cases whose only walls are in z (channels) and without wall model.
+// Same arithmetic as the reference sequence (sgs.f90:153-380) re-associated for the hardware:
+//  * the 27-point top-hat (sgs.f90:632-679) is separable, (1,2,1)^3/64: each thread owns an (i,j) column and
+//    marches in k with three planes of 2-D filtered values in registers; per plane it loads 3 rows per field
+//    (coalesced along x) and gets its x neighbours by wave shuffles -> 3 loads/cell instead of 27;
+//  * products (|S|Sij, ui uj) are formed on the fly, the wall extrapolation of the filtered fields
+//    (extrapolate(...,cbc), sgs.f90:705-710,751-766, factor 1) becomes f2(0) = 2 f2(1) - f2(2) on the 2-D filtered planes
+//    (the 2-D filter and the extrapolation are both linear and commute);
+//  * strain rate of the filtered velocity and the Mij update are one kernel; the Lij/contraction/plane sums are
+//    one kernel whose only output are per-block partial sums (LM and MM are never stored).
+// Traffic: ~62 words/cell instead of ~166 measured for the kernel-per-loop sequence (profiles/r01a_*).
+// ================================================================================================
+#define MBY 4
+struct MarchArgs {
+  const double *in[7];
+  double *out[6];
+  const double *mij[6];
+  double *part;
+  int kchunk, nblk;
+  unsigned zlo_mask, zhi_mask;    // bit q: quantity q is linearly extrapolated through the lower / upper z wall
+};
+// Tile = 62 x TY outputs handled by 64 x (TY+2) threads that march in k. Every thread loads exactly its own cell of each
+// input (full-width coalesced rows, no divergent loads, one load phase per plane, next plane prefetched), keeps three
+// planes of its own cell in registers, combines them in z first, gets the x neighbours by wave shuffles and the y
+// neighbours through double-buffered LDS. With the wall rule Q(0) = 2Q(1)-Q(2) the z combination at the first plane is
+// simply 4 Q(1), so ghost planes of extrapolated quantities are never read.
+//  MODE 0: the 3 fields themselves; MODE 1: s0*sij (6 quantities); MODE 2: uc,vc,wc and their six products (9 quantities)
+template <int MODE> struct NQT_ { static constexpr int v = MODE == 0 ? 3 : (MODE == 1 ? 6 : 9); };
+template <int MODE> struct NST_ { static constexpr int v = MODE == 1 ? 6 : 3; };     // values kept per plane and thread
+template <int MODE> struct TY_ { static constexpr int v = MODE == 2 ? 6 : 8; };
+
+template <int MODE>
+__device__ inline void cell_load(const MarchArgs &A, size_t idx, bool ok, double *s) {
+  constexpr int NS = NST_<MODE>::v;
+  if (!ok) {
+#pragma unroll
+    for (int q = 0; q < NS; ++q) s[q] = 0.;
+    return;
+  }
+  if (MODE == 1) {
+    const double s0 = A.in[0][idx];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) s[m] = s0 * A.in[1 + m][idx];
+  } else { s[0] = A.in[0][idx]; s[1] = A.in[1][idx]; s[2] = A.in[2][idx]; }
+}
+// quantity values of one stored plane
+template <int MODE>
+__device__ inline void quantities(const double *s, double *q) {
+  if (MODE == 2) { q[0] = s[0]; q[1] = s[1]; q[2] = s[2]; q[3] = s[0] * s[0]; q[4] = s[1] * s[1]; q[5] = s[2] * s[2];
+                   q[6] = s[0] * s[1]; q[7] = s[0] * s[2]; q[8] = s[1] * s[2]; }
+  else {
+#pragma unroll
+    for (int m = 0; m < NST_<MODE>::v; ++m) q[m] = s[m];
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64 * (TY_<MODE>::v + 2)) void k_filter_tile(Geom g, MarchArgs A) {
+  constexpr int NQ = NQT_<MODE>::v, NS = NST_<MODE>::v, TY = TY_<MODE>::v;
+  __shared__ double sh[2][NQ][TY + 2][64];
+  __shared__ double shr[2][TY + 2];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int i = blockIdx.x * 62 + tx, j = blockIdx.y * TY + ty;            // tx = 0 / 63 and ty = 0 / TY+1 are halo threads
+  const int kbeg = blockIdx.z * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
+  const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1;
+  const bool outok = tx >= 1 && tx <= 62 && ty >= 1 && ty <= TY && i <= g.n1 && j <= g.n2;
+  const bool inner = ty >= 1 && ty <= TY;
+  double sm[NS], sc[NS], sp[NS], sn[NS];
+  const size_t c0 = g.ix(i, j, 0);
+  cell_load<MODE>(A, c0 + (size_t)(kbeg - 1) * g.s12, ldok, sm);
+  cell_load<MODE>(A, c0 + (size_t)kbeg * g.s12, ldok, sc);
+  cell_load<MODE>(A, c0 + (size_t)(kbeg + 1) * g.s12, ldok, sp);
+  int buf = 0;
+  for (int k = kbeg; k <= kend; ++k) {
+    if (k + 2 <= g.n3 + 1) cell_load<MODE>(A, c0 + (size_t)(k + 2) * g.s12, ldok, sn);     // prefetch
+    double qm[NQ], qc[NQ], qp[NQ], r[NQ];
+    quantities<MODE>(sm, qm); quantities<MODE>(sc, qc); quantities<MODE>(sp, qp);
+    const bool lo = k == 1, hi = k == g.n3;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      // ghost planes by the wall rule: Q(0) = 2Q(1)-Q(2), Q(n+1) = 2Q(n)-Q(n-1)
+      const double vm = (lo && (A.zlo_mask >> q & 1u)) ? 2. * qc[q] - qp[q] : qm[q];
+      const double vp = (hi && (A.zhi_mask >> q & 1u)) ? 2. * qc[q] - qm[q] : qp[q];
+      const double G = vm + 2. * qc[q] + vp;
+      r[q] = __shfl_up(G, 1, 64) + 2. * G + __shfl_down(G, 1, 64);
+      sh[buf][q][ty][tx] = r[q];
+    }
+    __syncthreads();
+    const size_t idx = c0 + (size_t)k * g.s12;
+    double F[NQ];
+    if (inner) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) F[q] = (sh[buf][q][ty - 1][tx] + 2. * r[q] + sh[buf][q][ty + 1][tx]) / 64.;
+    }
+    if (MODE != 2) {
+      if (outok) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) A.out[q][idx] = F[q];
+      }
+    } else {
+      double lm = 0., mm = 0.;
+      if (outok) {
+        const double l0 = F[3] - F[0] * F[0], l1 = F[4] - F[1] * F[1], l2 = F[5] - F[2] * F[2], l3 = F[6] - F[0] * F[1],
+                     l4 = F[7] - F[0] * F[2], l5 = F[8] - F[1] * F[2];
+        const double m0 = A.mij[0][idx], m1 = A.mij[1][idx], m2 = A.mij[2][idx], m3 = A.mij[3][idx], m4 = A.mij[4][idx], m5 = A.mij[5][idx];
+        lm = m0 * l0 + m1 * l1 + m2 * l2 + (m3 * l3 + m4 * l4 + m5 * l5) * 2.;       // sgs.f90:344-349
+        mm = m0 * m0 + m1 * m1 + m2 * m2 + (m3 * m3 + m4 * m4 + m5 * m5) * 2.;       // sgs.f90:350-355
+      }
+      for (int o = 32; o > 0; o >>= 1) { lm += __shfl_down(lm, o, 64); mm += __shfl_down(mm, o, 64); }
+      if (tx == 0) { shr[0][ty] = lm; shr[1][ty] = mm; }
+      __syncthreads();
+      if (tx == 0 && ty == 0) {
+        double a = 0., b = 0.;
+        for (int q = 1; q <= TY; ++q) { a += shr[0][q]; b += shr[1][q]; }
+        const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+        A.part[(size_t)(k - 1) * A.nblk + blk] = a; A.part[(size_t)(g.n3 + k - 1) * A.nblk + blk] = b;
+      }
+      // the next plane's barrier orders these reads of shr before it is rewritten
+    }
+#pragma unroll
+    for (int q = 0; q < NS; ++q) { sm[q] = sc[q]; sc[q] = sp[q]; sp[q] = sn[q]; }
+    buf ^= 1;
+  }
+}
+// p1d[which*n3 + k-1] = sum over the blocks' partials, fixed order (ave1d_channel, sgs.f90:462-472)
+__global__ __launch_bounds__(256) void k_plane_fold(int n3, int nblk, const double *__restrict__ part, double *__restrict__ p1d) {
+  __shared__ double sh[4];
+  const double *p = part + (size_t)blockIdx.x * nblk;
+  double acc = 0.;
+  for (int q = threadIdx.x; q < nblk; q += 256) acc += p[q];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) p1d[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+  (void)n3;
+}
+
+// strain rate of the test-filtered velocity fused with the Mij update (sgs.f90:261-272); alph2 from the indices (sgs.f90:783-816)
+__global__ __launch_bounds__(BX *BY) void k_strain_mij(Geom g, double dxi, double dyi, const double *__restrict__ dzci,
+                                                        const double *__restrict__ dzfi, const double *__restrict__ u,
+                                                        const double *__restrict__ v, const double *__restrict__ w, P6 mij, int zlo_wall, int zhi_wall) {
+  const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;
+  if (i > g.n1 || j > g.n2) return;
+  const size_t c = g.ix(i, j, k);
+  const long sj = g.s1, sk = g.s12;
+#define LD(a, di, dj, dk) a[c + (di) + (dj)*sj + (dk)*sk]
+  const double u_mcm = LD(u, -1, 0, -1), u_ccm = LD(u, 0, 0, -1), u_mmc = LD(u, -1, -1, 0), u_cmc = LD(u, 0, -1, 0), u_mcc = LD(u, -1, 0, 0),
+               u_ccc = LD(u, 0, 0, 0), u_mpc = LD(u, -1, 1, 0), u_cpc = LD(u, 0, 1, 0), u_mcp = LD(u, -1, 0, 1), u_ccp = LD(u, 0, 0, 1);
+  const double v_cmm = LD(v, 0, -1, -1), v_ccm = LD(v, 0, 0, -1), v_mmc = LD(v, -1, -1, 0), v_cmc = LD(v, 0, -1, 0), v_pmc = LD(v, 1, -1, 0),
+               v_mcc = LD(v, -1, 0, 0), v_ccc = LD(v, 0, 0, 0), v_pcc = LD(v, 1, 0, 0), v_cmp = LD(v, 0, -1, 1), v_ccp = LD(v, 0, 0, 1);
+  const double w_cmm = LD(w, 0, -1, -1), w_mcm = LD(w, -1, 0, -1), w_ccm = LD(w, 0, 0, -1), w_pcm = LD(w, 1, 0, -1), w_cpm = LD(w, 0, 1, -1),
+               w_cmc = LD(w, 0, -1, 0), w_mcc = LD(w, -1, 0, 0), w_ccc = LD(w, 0, 0, 0), w_pcc = LD(w, 1, 0, 0), w_cpc = LD(w, 0, 1, 0);
+#undef LD
+  const double zc = dzci[k], zm = dzci[k - 1];
+  double sij[6];
+  sij[0] = (u_ccc - u_mcc) * dxi; sij[1] = (v_ccc - v_cmc) * dyi; sij[2] = (w_ccc - w_ccm) * dzfi[k];
+  sij[3] = .125 * ((u_cpc - u_ccc) * dyi + (v_pcc - v_ccc) * dxi + (u_ccc - u_cmc) * dyi + (v_pmc - v_cmc) * dxi +
+                   (u_mpc - u_mcc) * dyi + (v_ccc - v_mcc) * dxi + (u_mcc - u_mmc) * dyi + (v_cmc - v_mmc) * dxi);
+  sij[4] = .125 * ((u_ccp - u_ccc) * zc + (w_pcc - w_ccc) * dxi + (u_ccc - u_ccm) * zm + (w_pcm - w_ccm) * dxi +
+                   (u_mcp - u_mcc) * zc + (w_ccc - w_mcc) * dxi + (u_mcc - u_mcm) * zm + (w_ccm - w_mcm) * dxi);
+  sij[5] = .125 * ((v_ccp - v_ccc) * zc + (w_cpc - w_ccc) * dyi + (v_ccc - v_ccm) * zm + (w_cpm - w_ccm) * dyi +
+                   (v_cmp - v_cmc) * zc + (w_ccc - w_cmc) * dyi + (v_cmc - v_cmm) * zm + (w_ccm - w_cmm) * dyi);
+  const double s0 = sqrt(2. * (sij[0] * sij[0] + sij[1] * sij[1] + sij[2] * sij[2] + 2. * (sij[3] * sij[3] + sij[4] * sij[4] + sij[5] * sij[5])));
+  const double alph2 = ((zlo_wall && k == 1) || (zhi_wall && k == g.n3)) ? 2.52 : 4.00;
+#pragma unroll
+  for (int m = 0; m < 6; ++m) mij.p[m][c] = 2. * (mij.p[m][c] - alph2 * s0 * sij[m]);
+}
+
 int allreduce_res(cales_ctx *c, int slot, int count, int op);
+int op_boundp(cales_ctx *c, double *p, int which);
+static bool dsmag_fast_ok(const cales_ctx *c) {
+  for (int q = 0; q < 4; ++q) if (c->is_wall[q] != 0.) return false;      // walls in x or y: general path
+  for (int q = 0; q < 6; ++q) if (c->C.lwm[q] != 0) return false;         // wall model: general path
+  return c->n[2] >= 3 && getenv("CALES_DSMAG_REFERENCE_SEQUENCE") == nullptr;
+}
+static int dsmag_fast(cales_ctx *c) {
+  const int *n = c->n; double **f = c->f; double *visct = f[CALES_VISCT];
+  dim3 b(BX, BY, 1), gr = grid3(n[0], n[1], n[2], b);
+  double **sij = c->sij, **mij = c->mij;
+  const int zlo = c->is_wall[4] != 0., zhi = c->is_wall[5] != 0.;
+  // K_A: strain rate straight from u,v,w (no wall-model faces -> extrapolate(...,lwm) is a no-op), s0 -> visct as well
+  { ProfScope ps(c, "strain_rate");
+    hipLaunchKernelGGL(k_strain<2>, gr, b, 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, f[CALES_U], f[CALES_V], f[CALES_W], c->s0,
+                       sij[0], sij[1], sij[2], sij[3], sij[4], sij[5], visct); }
+  if (int e = op_boundp(c, c->s0, 1)) return e;
+  for (int m = 0; m < 6; ++m) if (int e = op_boundp(c, sij[m], 1)) return e;
+  // tiles of 62 x TY columns marching in k; k is also split into chunks so that several rounds of blocks balance the chip
+  auto tiles = [&](int ty, dim3 &mb, dim3 &mg, int &kchunk) {
+    mb = dim3(64, ty + 2, 1); mg = dim3((n[0] + 61) / 62, (n[1] + ty - 1) / ty, 1);
+    kchunk = n[2];
+    while ((long)mg.x * mg.y * ((n[2] + kchunk - 1) / kchunk) < 2048 && kchunk > 32) kchunk = (kchunk + 1) / 2;
+    mg.z = (n[2] + kchunk - 1) / kchunk;
+  };
+  dim3 mb, mg, mb2, mg2; int kchunk, kchunk2;
+  tiles(8, mb, mg, kchunk); tiles(6, mb2, mg2, kchunk2);
+  MarchArgs A; A.kchunk = kchunk; A.nblk = mg.x * mg.y; A.part = nullptr;
+  // K_B: mij = filter(|S| Sij)
+  { ProfScope ps(c, "filter_s0sij");
+    A.in[0] = c->s0; for (int m = 0; m < 6; ++m) { A.in[1 + m] = sij[m]; A.out[m] = mij[m]; }
+    A.zlo_mask = zlo ? 0x3fu : 0u; A.zhi_mask = zhi ? 0x3fu : 0u;
+    hipLaunchKernelGGL(k_filter_tile<1>, mg, mb, 0, c->stream, c->g, A); }
+  // K_C: test-filtered velocity; u,v are extrapolated through the z walls, w (stored on the z faces) is not (sgs.f90:705-710)
+  { ProfScope ps(c, "filter_uvw");
+    A.in[0] = f[CALES_U]; A.in[1] = f[CALES_V]; A.in[2] = f[CALES_W]; A.out[0] = c->uf; A.out[1] = c->vf; A.out[2] = c->wf;
+    A.zlo_mask = zlo ? 0x3u : 0u; A.zhi_mask = zhi ? 0x3u : 0u;
+    hipLaunchKernelGGL(k_filter_tile<0>, mg, mb, 0, c->stream, c->g, A); }
+  if (int e = op_bounduvw(c, c->bcuf, c->bcvf, c->bcwf, 0, 0, c->uf, c->vf, c->wf)) return e;
+  // K_D: strain rate of the filtered velocity + Mij
+  { ProfScope ps(c, "strain_mij");
+    P6 pm; for (int m = 0; m < 6; ++m) pm.p[m] = mij[m];
+    hipLaunchKernelGGL(k_strain_mij, gr, b, 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, c->uf, c->vf, c->wf, pm, zlo, zhi); }
+  // K_E: cell-centred velocity, its sgs-type ghost cells (periodic exchange; wall ghosts are replaced by the extrapolation rule)
+  { ProfScope ps(c, "interp_uvw");
+    hipLaunchKernelGGL(k_interp, gr, b, 0, c->stream, c->g, f[CALES_U], f[CALES_V], f[CALES_W], c->uc, c->vc, c->wc); }
+  if (int e = op_boundp(c, c->uc, 1)) return e;
+  if (int e = op_boundp(c, c->vc, 1)) return e;
+  if (int e = op_boundp(c, c->wc, 1)) return e;
+  // K_F: Lij = filter(ui uj) - filter(ui) filter(uj), LM = Mij Lij, MM = Mij Mij, plane partial sums
+  { ProfScope ps(c, "lij_contract");
+    A.in[0] = c->uc; A.in[1] = c->vc; A.in[2] = c->wc; for (int m = 0; m < 6; ++m) A.mij[m] = mij[m];
+    A.part = c->wk[0];
+    if ((size_t)2 * n[2] * mg2.x * mg2.y > c->ntot) { c->err = "dsmag: partial-sum scratch too small"; return 1; }
+    A.zlo_mask = zlo ? 0x1ffu : 0u; A.zhi_mask = zhi ? 0x1ffu : 0u;
+    A.kchunk = kchunk2; A.nblk = mg2.x * mg2.y;
+    hipLaunchKernelGGL(k_filter_tile<2>, mg2, mb2, 0, c->stream, c->g, A);
+    hipLaunchKernelGGL(k_plane_fold, dim3(2 * n[2]), dim3(256), 0, c->stream, n[2], A.nblk, c->wk[0], c->d_p1d); }
+  if (c->P > 1) { if (int e = allreduce_res(c, (int)(c->d_p1d - c->res), 2 * n[2], 0)) return e; }   // sgs.f90:475
+  const double gar = c->dl[0] * c->dl[1] / (c->C.l[0] * c->C.l[1]);
+  hipLaunchKernelGGL(k_dsmag_final, gr, b, 0, c->stream, c->g, gar, c->d_p1d, visct);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 static inline dim3 lin_grid(size_t n) { size_t b = (n + 255) / 256; if (b > 4096) b = 4096; return dim3((unsigned)b); }
 
 int op_cmpt_sgs(cales_ctx *c) {
@@ -249,6 +485,7 @@ int op_cmpt_sgs(cales_ctx *c) {
       hipLaunchKernelGGL(k_alph2, grid3(n[0] + 2, n[1] + 2, n[2] + 2, dim3(64, 4, 1)), dim3(64, 4, 1), 0, c->stream, c->g, c->is_wall[0], c->is_wall[1],
                          c->is_wall[2], c->is_wall[3], c->is_wall[4], c->is_wall[5], c->alph2);
   }
+  if (c->C.sgstype == 2 && dsmag_fast_ok(c)) return dsmag_fast(c);
   double **wk = c->wk;
   // wk(1:3) = u,v,w ; extrapolate at wall-model faces ; strain rate (sgs.f90:84-92 / 173-181)
   hipLaunchKernelGGL(k_copy3, lin_grid(nt), dim3(256), 0, c->stream, nt, f[CALES_U], f[CALES_V], f[CALES_W], wk[0], wk[1], wk[2]);
