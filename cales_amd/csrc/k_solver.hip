@@ -82,6 +82,147 @@ __device__ inline cpx *fft_line(const FftPlan &P, cpx *a, cpx *b, int t, int T, 
   return a;
 }
 
+// ------------------------------------------------------------------------------------------ power-of-two lines: radix-8 in registers
+// N = 2^p >= 16, T = N/8 threads per line. Each stage: every thread reads 8 complex from LDS into registers, ALL threads
+// of the block pass a barrier, then write their 8 results back (Stockham positions) -- one LDS buffer, no ping-pong, and
+// log8(N) stages (512 = 8*8*8) instead of log4. A last radix-4 / radix-2 stage handles p mod 3 != 0.
+template <int INV> __device__ inline cpx tw_mul(cpx v, cpx w) { if (INV) w.y = -w.y; return cmul(v, w); }
+template <int INV>
+__device__ inline void fft8_regs(cpx *v) {   // natural order in -> natural order out
+  const double h = 0.70710678118654752440;
+  cpx a0 = cadd(v[0], v[4]), a1 = cadd(v[1], v[5]), a2 = cadd(v[2], v[6]), a3 = cadd(v[3], v[7]);
+  cpx b0 = csub(v[0], v[4]), b1 = csub(v[1], v[5]), b2 = csub(v[2], v[6]), b3 = csub(v[3], v[7]);
+  // b_n *= w8^n  (forward w8 = e^{-i pi/4})
+  b1 = INV ? cpx{(b1.x - b1.y) * h, (b1.x + b1.y) * h} : cpx{(b1.x + b1.y) * h, (b1.y - b1.x) * h};
+  b2 = mul_mi<INV>(b2);
+  b3 = INV ? cpx{(-b3.x - b3.y) * h, (b3.x - b3.y) * h} : cpx{(-b3.x + b3.y) * h, (-b3.x - b3.y) * h};
+  cpx c0 = cadd(a0, a2), c1 = cadd(a1, a3), d0 = csub(a0, a2), d1 = mul_mi<INV>(csub(a1, a3));
+  v[0] = cadd(c0, c1); v[4] = csub(c0, c1); v[2] = cadd(d0, d1); v[6] = csub(d0, d1);
+  c0 = cadd(b0, b2); c1 = cadd(b1, b3); d0 = csub(b0, b2); d1 = mul_mi<INV>(csub(b1, b3));
+  v[1] = cadd(c0, c1); v[5] = csub(c0, c1); v[3] = cadd(d0, d1); v[7] = csub(d0, d1);
+}
+// all threads of the block must call it (barriers); buf holds the line; result in buf
+// LDS index skew: one extra slot every 8 complex, so the stride-8 scatter of the first stage (and the transposed
+// loads/stores of the callers) spread over the banks
+__device__ inline int lpad(int i) { return i + (i >> 3); }
+template <int INV>
+__device__ inline void fft_line8(int N, cpx *buf, int t, const cpx *__restrict__ tw) {
+  const int T = N >> 3;
+  int Ns = 1;
+  while (Ns * 8 <= N) {                         // radix-8 stages, one butterfly per thread
+    const int M = N >> 3, tstep = N / (Ns * 8), k = t % Ns, j0 = (t - k) * 8 + k;
+    cpx v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = buf[lpad(t + r * M)];
+    if (Ns > 1) {
+#pragma unroll
+      for (int r = 1; r < 8; ++r) v[r] = tw_mul<INV>(v[r], tw[k * r * tstep]);
+    }
+    fft8_regs<INV>(v);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) buf[lpad(j0 + r * Ns)] = v[r];
+    __syncthreads();
+    Ns *= 8;
+  }
+  if (Ns * 4 == N) {                             // last radix-4 stage: two butterflies per thread
+    const int M = N >> 2, tstep = 1;
+    cpx v[2][4]; int j0[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int j = t + b * T, k = j % Ns; j0[b] = (j - k) * 4 + k;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[b][r] = buf[lpad(j + r * M)];
+#pragma unroll
+      for (int r = 1; r < 4; ++r) v[b][r] = tw_mul<INV>(v[b][r], tw[k * r * tstep]);
+      const cpx a0 = cadd(v[b][0], v[b][2]), a1 = csub(v[b][0], v[b][2]), a2 = cadd(v[b][1], v[b][3]), a3 = mul_mi<INV>(csub(v[b][1], v[b][3]));
+      v[b][0] = cadd(a0, a2); v[b][1] = cadd(a1, a3); v[b][2] = csub(a0, a2); v[b][3] = csub(a1, a3);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) buf[lpad(j0[b] + r * Ns)] = v[b][r];
+    __syncthreads();
+  } else if (Ns * 2 == N) {                      // last radix-2 stage: four butterflies per thread
+    const int M = N >> 1;
+    cpx v[4][2]; int j0[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int j = t + b * T, k = j % Ns; j0[b] = (j - k) * 2 + k;
+      const cpx x0 = buf[lpad(j)], x1 = tw_mul<INV>(buf[lpad(j + M)], tw[k]);
+      v[b][0] = cadd(x0, x1); v[b][1] = csub(x0, x1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { buf[lpad(j0[b])] = v[b][0]; buf[lpad(j0[b] + Ns)] = v[b][1]; }
+    __syncthreads();
+  }
+}
+
+// x pass for nh = n1/2 = 2^p: R = blockDim.x / (nh/8) rows per block, one LDS buffer of nh+1 complex per row
+template <int INV>
+__global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, const cpx *__restrict__ tw, const cpx *__restrict__ twp,
+                                                 double *__restrict__ p, double scale, Spec S, double2 *__restrict__ spec) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int T = nh >> 3, R = blockDim.x / T, row = threadIdx.x / T, t = threadIdx.x % T, ld = lpad(nh) + 2;
+  cpx *A = reinterpret_cast<cpx *>(smem) + (size_t)row * ld;
+  const long r = (long)blockIdx.x * R + row, nrows = (long)g.n2 * g.n3;
+  const bool live = r < nrows;
+  const int j = live ? (int)(r % g.n2) + 1 : 1, k = live ? (int)(r / g.n2) + 1 : 1;
+  double *rowp = p + g.ix(0, j, k);
+  if (!INV) {
+    if (live) for (int q = t; q < nh; q += T) A[lpad(q)] = cpx{rowp[1 + 2 * q], rowp[2 + 2 * q]};
+    __syncthreads();
+    fft_line8<0>(nh, A, t, tw);
+    if (live) {
+      for (int kk = t; kk <= nh / 2; kk += T) {
+        const cpx zk = A[lpad(kk)], zm = cconj(A[lpad((nh - kk) % nh)]);
+        const cpx E = {0.5 * (zk.x + zm.x), 0.5 * (zk.y + zm.y)};
+        const cpx D = csub(zk, zm), O = {0.5 * D.y, -0.5 * D.x};     // -i/2 * (zk - conj(zm))
+        const cpx wO = cmul(twp[kk], O);
+        const cpx xk = cadd(E, wO), xm = cconj(csub(E, wO));
+        spec[S.at_slab(g, kk, j, k)] = make_double2(xk.x, xk.y);
+        spec[S.at_slab(g, nh - kk, j, k)] = make_double2(xm.x, xm.y);
+      }
+    }
+  } else {
+    if (live) for (int kk = t; kk <= nh; kk += T) { const double2 v = spec[S.at_slab(g, kk, j, k)]; A[lpad(kk)] = cpx{v.x, v.y}; }
+    __syncthreads();
+    // Z'_k = (X_k + conj X_{nh-k}) + i conj(w^k) (X_k - conj X_{nh-k}), pairs (k, nh-k) in place
+    for (int kk = t; kk <= nh / 2; kk += T) {
+      const cpx xa = A[lpad(kk)], xb = A[lpad(nh - kk)];
+      const cpx Sa = cadd(xa, cconj(xb)), Da = csub(xa, cconj(xb)), wa = cmul(cconj(twp[kk]), Da);
+      const cpx Sb = cadd(xb, cconj(xa)), Db = csub(xb, cconj(xa)), wb = cmul(cconj(twp[nh - kk]), Db);
+      const cpx za = cpx{Sa.x - wa.y, Sa.y + wa.x}, zb = cpx{Sb.x - wb.y, Sb.y + wb.x};
+      A[lpad(kk)] = za;
+      if (kk != 0 && 2 * kk != nh) A[lpad(nh - kk)] = zb;
+    }
+    __syncthreads();
+    fft_line8<1>(nh, A, t, tw);
+    if (live) for (int q = t; q < nh; q += T) { rowp[1 + 2 * q] = A[lpad(q)].x * scale; rowp[2 + 2 * q] = A[lpad(q)].y * scale; }
+  }
+}
+
+// y pass for N = n2 = 2^p: CB = blockDim.x / (N/8) adjacent complex columns of plane k per block
+template <int INV>
+__global__ __launch_bounds__(512) void k_fft_y8(Geom g, int N, int ncols, const cpx *__restrict__ tw, Spec S, double2 *__restrict__ pc) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int T = N >> 3, CB = blockDim.x / T, ld = lpad(N) + 1;
+  const int m0 = blockIdx.x * CB, k = blockIdx.y + 1;
+  cpx *base = reinterpret_cast<cpx *>(smem);
+  for (int q = threadIdx.x; q < CB * N; q += blockDim.x) {
+    const int col = q % CB, j = q / CB;
+    if (m0 + col < ncols) { const double2 v = pc[S.at_mode(g, m0 + col, j + 1, k)]; base[(size_t)col * ld + lpad(j)] = cpx{v.x, v.y}; }
+  }
+  __syncthreads();
+  fft_line8<INV>(N, base + (size_t)(threadIdx.x / T) * ld, threadIdx.x % T, tw);
+  for (int q = threadIdx.x; q < CB * N; q += blockDim.x) {
+    const int c2 = q % CB, j = q / CB;
+    if (m0 + c2 < ncols) { const cpx v = base[(size_t)c2 * ld + lpad(j)]; pc[S.at_mode(g, m0 + c2, j + 1, k)] = make_double2(v.x, v.y); }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ x pass
 // rows are (j,k), j=1..n2, k=1..n3. R rows per block, T = blockDim.x / R threads per row.
 template <int INV>
@@ -212,7 +353,7 @@ __global__ __launch_bounds__(256) void k_gaussel(Geom g, int nz, int ncol, int n
 }
 
 // ------------------------------------------------------------------------------------------ host side
-struct SolverPlans { FftPlan px, py; int Rx, CBy; size_t shx, shy; };
+struct SolverPlans { FftPlan px, py; int Rx, CBy; size_t shx, shy; bool x8, y8; int x8_threads, y8_threads; size_t shx8, shy8; };
 struct PlanSlot { cales_ctx *ctx; SolverPlans sp; };
 static std::vector<PlanSlot> g_slots;
 static SolverPlans *find_plans(cales_ctx *c) { for (auto &s : g_slots) if (s.ctx == c) return &s.sp; return nullptr; }
@@ -231,6 +372,15 @@ int solver_setup(cales_ctx *c) {
   sp.shy = (size_t)sp.CBy * 2 * (n2g + 1) * sizeof(cpx);
   while (sp.shy > 60 * 1024 && sp.CBy > 1) { sp.CBy /= 2; sp.shy = (size_t)sp.CBy * 2 * (n2g + 1) * sizeof(cpx); }
   if (sp.shx > 64 * 1024 || sp.shy > 64 * 1024) { c->err = "solver: line too long for the LDS-resident transform"; return 1; }
+  // power-of-two lines take the radix-8 register kernels
+  auto pow2 = [](int v) { return v >= 16 && (v & (v - 1)) == 0; };
+  sp.x8 = pow2(n1 / 2) && n1 / 2 <= 1024; sp.y8 = pow2(n2g) && n2g <= 1024;
+  if (sp.x8) { const int T = (n1 / 2) / 8; sp.x8_threads = T >= 256 ? T : (256 / T) * T;
+               sp.shx8 = (size_t)(sp.x8_threads / T) * (n1 / 2 + n1 / 16 + 2) * sizeof(cpx); }
+  if (sp.y8) { const int T = n2g / 8; int CB = std::max(1, std::min(std::max(8, 256 / T), 512 / T));
+               while (CB > 1 && (size_t)CB * (n2g + n2g / 8 + 1) * sizeof(cpx) > 64 * 1024) CB /= 2;
+               sp.y8_threads = CB * T; sp.shy8 = (size_t)CB * (n2g + n2g / 8 + 1) * sizeof(cpx); }
+  if (getenv("CALES_FFT_GENERIC")) sp.x8 = sp.y8 = false;
   // eigenvalues (initsolver.f90:66-98); x: modes 0..n1/2 (half-complex symmetry), y: modes 0..n2-1
   std::vector<double> lx(n1), ly(n2g);
   hs_eigenvalues(n1, "PP", 'c', lx.data()); hs_eigenvalues(n2g, "PP", 'c', ly.data());
@@ -295,21 +445,29 @@ int op_solver(cales_ctx *c) {
   double2 *mode_spec = dist ? reinterpret_cast<double2 *>(c->comm.B) : reinterpret_cast<double2 *>(pp);
   const int ncol = dist ? c->cw : mh, mofs = dist ? c->rank * c->cw : 0;
   const int64_t a2a_count = (int64_t)n[2] * n[1] * c->cw * 2;
+  const int nh = c->C.ng[0] / 2;
+  const int Rx8 = sp->x8 ? sp->x8_threads / (nh / 8) : 1, CB8 = sp->y8 ? sp->y8_threads / (n2g / 8) : 1;
   { ProfScope ps(c, "fft_x_fwd");
-    hipLaunchKernelGGL(k_fft_x<0>, dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
+    if (sp->x8) hipLaunchKernelGGL(k_fft_x8<0>, dim3((unsigned)((nrows + Rx8 - 1) / Rx8)), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh,
+                                   (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, pp, 1., S, slab_spec);
+    else hipLaunchKernelGGL(k_fft_x<0>, dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
                        (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, pp, 1., S, slab_spec); }
   if (dist) { ProfScope ps(c, "alltoall"); if (c->comm.a2a(c->comm.user, 0, a2a_count)) { c->err = "alltoall callback failed"; return 1; } }
   { ProfScope ps(c, "fft_y_fwd");
-    hipLaunchKernelGGL(k_fft_y<0>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, (const cpx *)c->d_twy, S, mode_spec); }
+    if (sp->y8) hipLaunchKernelGGL(k_fft_y8<0>, dim3((ncol + CB8 - 1) / CB8, n[2]), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, (const cpx *)c->d_twy, S, mode_spec);
+    else hipLaunchKernelGGL(k_fft_y<0>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, (const cpx *)c->d_twy, S, mode_spec); }
   { ProfScope ps(c, "gaussel_z");
     dim3 b(64, 4), gr((ncol + 63) / 64, (n2g + 3) / 4);
     if (periodic_z) hipLaunchKernelGGL((k_gaussel<double2, 1>), gr, b, 0, c->stream, c->g, n[2], ncol, n2g, 0, mofs, mh, S, c->d_a, c->d_b, c->d_c, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2);
     else hipLaunchKernelGGL((k_gaussel<double2, 0>), gr, b, 0, c->stream, c->g, n[2], ncol, n2g, 0, mofs, mh, S, c->d_a, c->d_b, c->d_c, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2); }
   { ProfScope ps(c, "fft_y_bwd");
-    hipLaunchKernelGGL(k_fft_y<1>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, (const cpx *)c->d_twy, S, mode_spec); }
+    if (sp->y8) hipLaunchKernelGGL(k_fft_y8<1>, dim3((ncol + CB8 - 1) / CB8, n[2]), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, (const cpx *)c->d_twy, S, mode_spec);
+    else hipLaunchKernelGGL(k_fft_y<1>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, (const cpx *)c->d_twy, S, mode_spec); }
   if (dist) { ProfScope ps(c, "alltoall"); if (c->comm.a2a(c->comm.user, 1, a2a_count)) { c->err = "alltoall callback failed"; return 1; } }
   { ProfScope ps(c, "fft_x_bwd");
-    hipLaunchKernelGGL(k_fft_x<1>, dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
+    if (sp->x8) hipLaunchKernelGGL(k_fft_x8<1>, dim3((unsigned)((nrows + Rx8 - 1) / Rx8)), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh,
+                                   (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, pp, c->normfft, S, slab_spec);
+    else hipLaunchKernelGGL(k_fft_x<1>, dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
                        (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, pp, c->normfft, S, slab_spec); }
   HIPCHK(c, hipGetLastError());
   return 0;
