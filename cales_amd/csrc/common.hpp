@@ -156,4 +156,20 @@ int op_chkdiv(cales_ctx *c, double *divtot, double *divmax);
 int solver_setup(cales_ctx *c);
 void solver_teardown(cales_ctx *c);
 
+// XCD-aware block order for the one-plane-per-block stencil kernels (grid = x tiles, y tiles, z planes).
+// Workgroups are dealt round-robin to the 8 XCDs, each with its private 4 MiB L2 (MI355X_MICROARCH.md, "Workgroup
+// dispatch"). The remap lets every XCD walk a fixed (x tile, group of 8 y-adjacent tiles) column through k, so the k+-1
+// planes and j+-1 rows a block needs were fetched moments earlier by blocks of the SAME XCD and are L2 hits instead
+// of HBM re-reads. Only the order changes (a bijection on block ids); results are identical.
+#ifdef __HIPCC__
+__device__ inline void stencil_block(int &bx, int &by, int &bz) {
+  const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z, SUB = 8;
+  if (gy % SUB != 0 || (gx * (gy / SUB)) % 8 != 0) { bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z; return; }
+  const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  const unsigned xcd = L & 7u, s = L >> 3;
+  const unsigned sub = s % SUB, k = (s / SUB) % gz, T = (s / (SUB * gz)) * 8 + xcd;
+  bx = (int)(T % gx); by = (int)((T / gx) * SUB + sub); bz = (int)k;
+}
+#endif
+
 static inline dim3 grid3(int nx, int ny, int nz, dim3 b) { return dim3((nx + b.x - 1) / b.x, (ny + b.y - 1) / b.y, (nz + b.z - 1) / b.z); }

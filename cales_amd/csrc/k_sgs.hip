@@ -56,7 +56,8 @@ __global__ __launch_bounds__(BX *BY) void k_strain(Geom g, double dxi, double dy
                                                     double *__restrict__ s11o, double *__restrict__ s22o, double *__restrict__ s33o,
                                                     double *__restrict__ s12o, double *__restrict__ s13o, double *__restrict__ s23o,
                                                     double *__restrict__ s0copy) {
-  const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;
+  int bx_, by_, bz_; stencil_block(bx_, by_, bz_);
+  const int i = bx_ * BX + threadIdx.x + 1, j = by_ * BY + threadIdx.y + 1, k = bz_ + 1;
   if (i > g.n1 || j > g.n2) return;
   const size_t c = g.ix(i, j, k);
   const long sj = g.s1, sk = g.s12;
@@ -96,7 +97,8 @@ struct SmagArgs { double w0, w1, w2, w3, w4, w5, dl1, dl2, l3, dxi, dyi, visc, s
 __global__ __launch_bounds__(BX *BY) void k_smag(Geom g, SmagArgs A, const double *__restrict__ zc, const double *__restrict__ dzci,
                                                   const double *__restrict__ dzf, const double *__restrict__ u, const double *__restrict__ v,
                                                   const double *__restrict__ w, const double *__restrict__ s0, double *__restrict__ visct) {
-  const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;
+  int bx_, by_, bz_; stencil_block(bx_, by_, bz_);
+  const int i = bx_ * BX + threadIdx.x + 1, j = by_ * BY + threadIdx.y + 1, k = bz_ + 1;
   if (i > g.n1 || j > g.n2) return;
   double fd;
   if (A.sumw == 0.) fd = 1.;
@@ -165,7 +167,8 @@ __global__ __launch_bounds__(256) void k_uiuj(size_t n, const double *__restrict
 }
 // filter3d (sgs.f90:632-679): 27-point top-hat, weights 8/4/2/1 over 64
 __global__ __launch_bounds__(BX *BY) void k_filter3d(Geom g, const double *__restrict__ p, double *__restrict__ pf) {
-  const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;
+  int bx_, by_, bz_; stencil_block(bx_, by_, bz_);
+  const int i = bx_ * BX + threadIdx.x + 1, j = by_ * BY + threadIdx.y + 1, k = bz_ + 1;
   if (i > g.n1 || j > g.n2) return;
   const size_t c = g.ix(i, j, k);
   const long sj = g.s1, sk = g.s12;
@@ -376,7 +379,8 @@ __global__ __launch_bounds__(256) void k_plane_fold(int n3, int nblk, const doub
 __global__ __launch_bounds__(BX *BY) void k_strain_mij(Geom g, double dxi, double dyi, const double *__restrict__ dzci,
                                                         const double *__restrict__ dzfi, const double *__restrict__ u,
                                                         const double *__restrict__ v, const double *__restrict__ w, P6 mij, int zlo_wall, int zhi_wall) {
-  const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;
+  int bx_, by_, bz_; stencil_block(bx_, by_, bz_);
+  const int i = bx_ * BX + threadIdx.x + 1, j = by_ * BY + threadIdx.y + 1, k = bz_ + 1;
   if (i > g.n1 || j > g.n2) return;
   const size_t c = g.ix(i, j, k);
   const long sj = g.s1, sk = g.s12;

@@ -160,66 +160,110 @@ __device__ inline void fft_line8(int N, cpx *buf, int t, const cpx *__restrict__
   }
 }
 
-// x pass for nh = n1/2 = 2^p: R = blockDim.x / (nh/8) rows per block, one LDS buffer of nh+1 complex per row
+// x pass for nh = n1/2 = 2^p. Persistent: a block owns `iters` consecutive groups of R rows, R = blockDim.x / (nh/8);
+// the next group's rows are prefetched into registers while the current one is transformed; twiddles live in LDS.
 template <int INV>
-__global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, const cpx *__restrict__ tw, const cpx *__restrict__ twp,
+__global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const cpx *__restrict__ twg, const cpx *__restrict__ twpg,
                                                  double *__restrict__ p, double scale, Spec S, double2 *__restrict__ spec) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int T = nh >> 3, R = blockDim.x / T, row = threadIdx.x / T, t = threadIdx.x % T, ld = lpad(nh) + 2;
-  cpx *A = reinterpret_cast<cpx *>(smem) + (size_t)row * ld;
-  const long r = (long)blockIdx.x * R + row, nrows = (long)g.n2 * g.n3;
-  const bool live = r < nrows;
-  const int j = live ? (int)(r % g.n2) + 1 : 1, k = live ? (int)(r / g.n2) + 1 : 1;
-  double *rowp = p + g.ix(0, j, k);
-  if (!INV) {
-    if (live) for (int q = t; q < nh; q += T) A[lpad(q)] = cpx{rowp[1 + 2 * q], rowp[2 + 2 * q]};
+  cpx *tw = reinterpret_cast<cpx *>(smem), *twp = tw + nh;                   // nh + (nh+1) twiddles
+  cpx *A = twp + nh + 1 + (size_t)row * ld;
+  for (int q = threadIdx.x; q < nh; q += blockDim.x) tw[q] = twg[q];
+  for (int q = threadIdx.x; q <= nh; q += blockDim.x) twp[q] = twpg[q];
+  const long nrows = (long)g.n2 * g.n3;
+  const int NE = 8;                                                          // elements per thread and row: nh / T
+  cpx nxt[NE + 1];
+  auto rowptr = [&](long r, int &j, int &k) { j = (int)(r % g.n2) + 1; k = (int)(r / g.n2) + 1; };
+  auto fetch = [&](long r) {
+    if (r >= nrows) return;
+    int j, k; rowptr(r, j, k);
+    if (!INV) {
+      const double *rowp = p + g.ix(0, j, k);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) { const int q = t + e * T; nxt[e] = cpx{rowp[1 + 2 * q], rowp[2 + 2 * q]}; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) { const double2 v = spec[S.at_slab(g, t + e * T, j, k)]; nxt[e] = cpx{v.x, v.y}; }
+      if (t == 0) { const double2 v = spec[S.at_slab(g, nh, j, k)]; nxt[NE] = cpx{v.x, v.y}; }
+    }
+  };
+  long r = ((long)blockIdx.x * iters) * R + row;
+  fetch(r);
+  for (int it = 0; it < iters; ++it, r += R) {
+    const bool live = r < nrows;
+    int j = 1, k = 1; if (live) rowptr(r, j, k);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) A[lpad(t + e * T)] = nxt[e];
+    if (INV && t == 0) A[lpad(nh)] = nxt[NE];
     __syncthreads();
-    fft_line8<0>(nh, A, t, tw);
-    if (live) {
+    if (it + 1 < iters) fetch(r + R);                                        // in flight during the transform
+    double *rowp = p + g.ix(0, j, k);
+    if (!INV) {
+      fft_line8<0>(nh, A, t, tw);
+      if (live) {
+        for (int kk = t; kk <= nh / 2; kk += T) {
+          const cpx zk = A[lpad(kk)], zm = cconj(A[lpad((nh - kk) % nh)]);
+          const cpx E = {0.5 * (zk.x + zm.x), 0.5 * (zk.y + zm.y)};
+          const cpx D = csub(zk, zm), O = {0.5 * D.y, -0.5 * D.x};     // -i/2 * (zk - conj(zm))
+          const cpx wO = cmul(twp[kk], O);
+          const cpx xk = cadd(E, wO), xm = cconj(csub(E, wO));
+          spec[S.at_slab(g, kk, j, k)] = make_double2(xk.x, xk.y);
+          spec[S.at_slab(g, nh - kk, j, k)] = make_double2(xm.x, xm.y);
+        }
+      }
+    } else {
+      // Z'_k = (X_k + conj X_{nh-k}) + i conj(w^k) (X_k - conj X_{nh-k}), pairs (k, nh-k) in place
       for (int kk = t; kk <= nh / 2; kk += T) {
-        const cpx zk = A[lpad(kk)], zm = cconj(A[lpad((nh - kk) % nh)]);
-        const cpx E = {0.5 * (zk.x + zm.x), 0.5 * (zk.y + zm.y)};
-        const cpx D = csub(zk, zm), O = {0.5 * D.y, -0.5 * D.x};     // -i/2 * (zk - conj(zm))
-        const cpx wO = cmul(twp[kk], O);
-        const cpx xk = cadd(E, wO), xm = cconj(csub(E, wO));
-        spec[S.at_slab(g, kk, j, k)] = make_double2(xk.x, xk.y);
-        spec[S.at_slab(g, nh - kk, j, k)] = make_double2(xm.x, xm.y);
+        const cpx xa = A[lpad(kk)], xb = A[lpad(nh - kk)];
+        const cpx Sa = cadd(xa, cconj(xb)), Da = csub(xa, cconj(xb)), wa = cmul(cconj(twp[kk]), Da);
+        const cpx Sb = cadd(xb, cconj(xa)), Db = csub(xb, cconj(xa)), wb = cmul(cconj(twp[nh - kk]), Db);
+        const cpx za = cpx{Sa.x - wa.y, Sa.y + wa.x}, zb = cpx{Sb.x - wb.y, Sb.y + wb.x};
+        A[lpad(kk)] = za;
+        if (kk != 0 && 2 * kk != nh) A[lpad(nh - kk)] = zb;
+      }
+      __syncthreads();
+      fft_line8<1>(nh, A, t, tw);
+      if (live) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) { const int q = t + e * T; const cpx z = A[lpad(q)]; rowp[1 + 2 * q] = z.x * scale; rowp[2 + 2 * q] = z.y * scale; }
       }
     }
-  } else {
-    if (live) for (int kk = t; kk <= nh; kk += T) { const double2 v = spec[S.at_slab(g, kk, j, k)]; A[lpad(kk)] = cpx{v.x, v.y}; }
     __syncthreads();
-    // Z'_k = (X_k + conj X_{nh-k}) + i conj(w^k) (X_k - conj X_{nh-k}), pairs (k, nh-k) in place
-    for (int kk = t; kk <= nh / 2; kk += T) {
-      const cpx xa = A[lpad(kk)], xb = A[lpad(nh - kk)];
-      const cpx Sa = cadd(xa, cconj(xb)), Da = csub(xa, cconj(xb)), wa = cmul(cconj(twp[kk]), Da);
-      const cpx Sb = cadd(xb, cconj(xa)), Db = csub(xb, cconj(xa)), wb = cmul(cconj(twp[nh - kk]), Db);
-      const cpx za = cpx{Sa.x - wa.y, Sa.y + wa.x}, zb = cpx{Sb.x - wb.y, Sb.y + wb.x};
-      A[lpad(kk)] = za;
-      if (kk != 0 && 2 * kk != nh) A[lpad(nh - kk)] = zb;
-    }
-    __syncthreads();
-    fft_line8<1>(nh, A, t, tw);
-    if (live) for (int q = t; q < nh; q += T) { rowp[1 + 2 * q] = A[lpad(q)].x * scale; rowp[2 + 2 * q] = A[lpad(q)].y * scale; }
   }
 }
 
-// y pass for N = n2 = 2^p: CB = blockDim.x / (N/8) adjacent complex columns of plane k per block
+// y pass for N = n2 = 2^p: CB = blockDim.x / (N/8) adjacent complex columns; persistent over `kchunk` planes with
+// register prefetch of the next plane; twiddles in LDS.
 template <int INV>
-__global__ __launch_bounds__(512) void k_fft_y8(Geom g, int N, int ncols, const cpx *__restrict__ tw, Spec S, double2 *__restrict__ pc) {
+__global__ __launch_bounds__(512) void k_fft_y8(Geom g, int N, int ncols, int kchunk, const cpx *__restrict__ twg, Spec S, double2 *__restrict__ pc) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int T = N >> 3, CB = blockDim.x / T, ld = lpad(N) + 1;
-  const int m0 = blockIdx.x * CB, k = blockIdx.y + 1;
-  cpx *base = reinterpret_cast<cpx *>(smem);
-  for (int q = threadIdx.x; q < CB * N; q += blockDim.x) {
-    const int col = q % CB, j = q / CB;
-    if (m0 + col < ncols) { const double2 v = pc[S.at_mode(g, m0 + col, j + 1, k)]; base[(size_t)col * ld + lpad(j)] = cpx{v.x, v.y}; }
-  }
-  __syncthreads();
-  fft_line8<INV>(N, base + (size_t)(threadIdx.x / T) * ld, threadIdx.x % T, tw);
-  for (int q = threadIdx.x; q < CB * N; q += blockDim.x) {
-    const int c2 = q % CB, j = q / CB;
-    if (m0 + c2 < ncols) { const cpx v = base[(size_t)c2 * ld + lpad(j)]; pc[S.at_mode(g, m0 + c2, j + 1, k)] = make_double2(v.x, v.y); }
+  const int m0 = blockIdx.x * CB, kbeg = blockIdx.y * kchunk + 1, kend = min(kbeg + kchunk - 1, g.n3);
+  cpx *tw = reinterpret_cast<cpx *>(smem), *base = tw + N;
+  for (int q = threadIdx.x; q < N; q += blockDim.x) tw[q] = twg[q];
+  const int NE = 8;                                                          // CB*N / blockDim.x
+  cpx nxt[NE];
+  auto fetch = [&](int k) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int q = threadIdx.x + e * blockDim.x, col = q % CB, j = q / CB;
+      if (m0 + col < ncols) { const double2 v = pc[S.at_mode(g, m0 + col, j + 1, k)]; nxt[e] = cpx{v.x, v.y}; }
+    }
+  };
+  fetch(kbeg);
+  for (int k = kbeg; k <= kend; ++k) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { const int q = threadIdx.x + e * blockDim.x, col = q % CB, j = q / CB; base[(size_t)col * ld + lpad(j)] = nxt[e]; }
+    __syncthreads();
+    if (k < kend) fetch(k + 1);                                               // in flight during the transform
+    fft_line8<INV>(N, base + (size_t)(threadIdx.x / T) * ld, threadIdx.x % T, tw);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int q = threadIdx.x + e * blockDim.x, c2 = q % CB, j = q / CB;
+      if (m0 + c2 < ncols) { const cpx v = base[(size_t)c2 * ld + lpad(j)]; pc[S.at_mode(g, m0 + c2, j + 1, k)] = make_double2(v.x, v.y); }
+    }
+    __syncthreads();
   }
 }
 
@@ -376,10 +420,10 @@ int solver_setup(cales_ctx *c) {
   auto pow2 = [](int v) { return v >= 16 && (v & (v - 1)) == 0; };
   sp.x8 = pow2(n1 / 2) && n1 / 2 <= 1024; sp.y8 = pow2(n2g) && n2g <= 1024;
   if (sp.x8) { const int T = (n1 / 2) / 8; sp.x8_threads = T >= 256 ? T : (256 / T) * T;
-               sp.shx8 = (size_t)(sp.x8_threads / T) * (n1 / 2 + n1 / 16 + 2) * sizeof(cpx); }
+               sp.shx8 = ((size_t)(sp.x8_threads / T) * (n1 / 2 + n1 / 16 + 2) + (n1 + 1)) * sizeof(cpx); }
   if (sp.y8) { const int T = n2g / 8; int CB = std::max(1, std::min(std::max(8, 256 / T), 512 / T));
-               while (CB > 1 && (size_t)CB * (n2g + n2g / 8 + 1) * sizeof(cpx) > 64 * 1024) CB /= 2;
-               sp.y8_threads = CB * T; sp.shy8 = (size_t)CB * (n2g + n2g / 8 + 1) * sizeof(cpx); }
+               while (CB > 1 && ((size_t)CB * (n2g + n2g / 8 + 1) + n2g) * sizeof(cpx) > 64 * 1024) CB /= 2;
+               sp.y8_threads = CB * T; sp.shy8 = ((size_t)CB * (n2g + n2g / 8 + 1) + n2g) * sizeof(cpx); }
   if (getenv("CALES_FFT_GENERIC")) sp.x8 = sp.y8 = false;
   // eigenvalues (initsolver.f90:66-98); x: modes 0..n1/2 (half-complex symmetry), y: modes 0..n2-1
   std::vector<double> lx(n1), ly(n2g);
@@ -447,25 +491,31 @@ int op_solver(cales_ctx *c) {
   const int64_t a2a_count = (int64_t)n[2] * n[1] * c->cw * 2;
   const int nh = c->C.ng[0] / 2;
   const int Rx8 = sp->x8 ? sp->x8_threads / (nh / 8) : 1, CB8 = sp->y8 ? sp->y8_threads / (n2g / 8) : 1;
+  // persistent blocks: several row groups / planes per block so that the register prefetch overlaps the transforms
+  const long xgroups = (nrows + Rx8 - 1) / Rx8;
+  int xiters = 1; while (xiters < 8 && xgroups / (xiters * 2) >= 2048) xiters *= 2;
+  const unsigned xblocks = (unsigned)((xgroups + xiters - 1) / xiters);
+  int ykchunk = 1; { const long cg = (ncol + CB8 - 1) / CB8; while (ykchunk < 8 && cg * (n[2] / (ykchunk * 2)) >= 2048 && n[2] % (ykchunk * 2) == 0) ykchunk *= 2; }
+  const int ychunks = (n[2] + ykchunk - 1) / ykchunk;
   { ProfScope ps(c, "fft_x_fwd");
-    if (sp->x8) hipLaunchKernelGGL(k_fft_x8<0>, dim3((unsigned)((nrows + Rx8 - 1) / Rx8)), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh,
+    if (sp->x8) hipLaunchKernelGGL(k_fft_x8<0>, dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, pp, 1., S, slab_spec);
     else hipLaunchKernelGGL(k_fft_x<0>, dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
                        (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, pp, 1., S, slab_spec); }
   if (dist) { ProfScope ps(c, "alltoall"); if (c->comm.a2a(c->comm.user, 0, a2a_count)) { c->err = "alltoall callback failed"; return 1; } }
   { ProfScope ps(c, "fft_y_fwd");
-    if (sp->y8) hipLaunchKernelGGL(k_fft_y8<0>, dim3((ncol + CB8 - 1) / CB8, n[2]), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, (const cpx *)c->d_twy, S, mode_spec);
+    if (sp->y8) hipLaunchKernelGGL(k_fft_y8<0>, dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, S, mode_spec);
     else hipLaunchKernelGGL(k_fft_y<0>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, (const cpx *)c->d_twy, S, mode_spec); }
   { ProfScope ps(c, "gaussel_z");
     dim3 b(64, 4), gr((ncol + 63) / 64, (n2g + 3) / 4);
     if (periodic_z) hipLaunchKernelGGL((k_gaussel<double2, 1>), gr, b, 0, c->stream, c->g, n[2], ncol, n2g, 0, mofs, mh, S, c->d_a, c->d_b, c->d_c, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2);
     else hipLaunchKernelGGL((k_gaussel<double2, 0>), gr, b, 0, c->stream, c->g, n[2], ncol, n2g, 0, mofs, mh, S, c->d_a, c->d_b, c->d_c, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2); }
   { ProfScope ps(c, "fft_y_bwd");
-    if (sp->y8) hipLaunchKernelGGL(k_fft_y8<1>, dim3((ncol + CB8 - 1) / CB8, n[2]), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, (const cpx *)c->d_twy, S, mode_spec);
+    if (sp->y8) hipLaunchKernelGGL(k_fft_y8<1>, dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, S, mode_spec);
     else hipLaunchKernelGGL(k_fft_y<1>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, (const cpx *)c->d_twy, S, mode_spec); }
   if (dist) { ProfScope ps(c, "alltoall"); if (c->comm.a2a(c->comm.user, 1, a2a_count)) { c->err = "alltoall callback failed"; return 1; } }
   { ProfScope ps(c, "fft_x_bwd");
-    if (sp->x8) hipLaunchKernelGGL(k_fft_x8<1>, dim3((unsigned)((nrows + Rx8 - 1) / Rx8)), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh,
+    if (sp->x8) hipLaunchKernelGGL(k_fft_x8<1>, dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, pp, c->normfft, S, slab_spec);
     else hipLaunchKernelGGL(k_fft_x<1>, dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
                        (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, pp, c->normfft, S, slab_spec); }

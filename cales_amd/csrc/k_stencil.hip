@@ -19,7 +19,8 @@ __global__ __launch_bounds__(BX *BY) void k_mom(Geom g, const double *__restrict
                                                  double dyi, double visc, double *__restrict__ dudt, double *__restrict__ dvdt,
                                                  double *__restrict__ dwdt, double *__restrict__ dudtd,
                                                  double *__restrict__ dvdtd, double *__restrict__ dwdtd) {
-  const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;
+  int bx_, by_, bz_; stencil_block(bx_, by_, bz_);
+  const int i = bx_ * BX + threadIdx.x + 1, j = by_ * BY + threadIdx.y + 1, k = bz_ + 1;
   if (i > g.n1 || j > g.n2) return;
   const size_t c = g.ix(i, j, k);
   const long sj = g.s1, sk = g.s12;
