@@ -80,7 +80,8 @@ struct cales_ctx {
   double normfft;
   int xkind, ykind;            // 0: periodic (r2c / c2c), 1: Neumann-Neumann cell-centred (DCT-II/III)
   double *d_twx, *d_twy;       // twiddle tables
-  double *d_twx_post, *d_twy_post;
+  double *d_twx_post, *d_twy_post;    // d_twy_post: DCT weights of the x direction
+  double *scr_twyd = nullptr;           // DCT weights of the y direction
   double *scr1, *scr2;         // solver scratch (haloed size)
   // reductions
   double *d_red; double *h_red;       // partial sums / results (pinned host)

@@ -269,9 +269,13 @@ __global__ __launch_bounds__(512) void k_fft_y8(Geom g, int N, int ncols, int kc
 
 // ------------------------------------------------------------------------------------------ x pass
 // rows are (j,k), j=1..n2, k=1..n3. R rows per block, T = blockDim.x / R threads per row.
+// kind 0: periodic (FFTW R2HC/HC2R); kind 1: Neumann-Neumann cell-centred (REDFT10/REDFT01 = DCT-II/III) by Makhoul's
+// reordering v[i] = x[2i], v[n-1-i] = x[2i+1] around the same real FFT: Y_k = 2 Re(w_k V_k), Y_{n-k} = -2 Im(w_k V_k),
+// w_k = e^{-i pi k/(2n)} (table twd); the n real coefficients Y_0..Y_{n-1} are stored at the real slots 0..n-1 of the row.
+__device__ inline int dct_src(int e, int n) { return e < n / 2 ? 2 * e : 2 * (n - 1 - e) + 1; }   // v[e] = x[dct_src(e)]
 template <int INV>
-__global__ __launch_bounds__(256) void k_fft_x(Geom g, FftPlan P, int R, const cpx *__restrict__ tw, const cpx *__restrict__ twp,
-                                                double *__restrict__ p, double scale, Spec S, double2 *__restrict__ spec) {
+__global__ __launch_bounds__(256) void k_fft_x(Geom g, FftPlan P, int R, int kind, const cpx *__restrict__ tw, const cpx *__restrict__ twp,
+                                                const cpx *__restrict__ twd, double *__restrict__ p, double scale, Spec S, double2 *__restrict__ spec) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int nh = P.N, n = 2 * nh, T = blockDim.x / R, row = threadIdx.x / T, t = threadIdx.x % T;
   const int ld = nh + 1;
@@ -280,8 +284,10 @@ __global__ __launch_bounds__(256) void k_fft_x(Geom g, FftPlan P, int R, const c
   const bool live = r < nrows;
   const int j = live ? (int)(r % g.n2) + 1 : 1, k = live ? (int)(r / g.n2) + 1 : 1;
   double *rowp = p + g.ix(0, j, k);
+  double *specd = reinterpret_cast<double *>(spec);
   if (!INV) {
-    if (live) for (int q = t; q < nh; q += T) A[q] = cpx{rowp[1 + 2 * q], rowp[2 + 2 * q]};
+    if (live) for (int q = t; q < nh; q += T)
+      A[q] = kind ? cpx{rowp[1 + dct_src(2 * q, n)], rowp[1 + dct_src(2 * q + 1, n)]} : cpx{rowp[1 + 2 * q], rowp[2 + 2 * q]};
     __syncthreads();
     cpx *Z = fft_line<0>(P, A, B, t, T, tw);
     if (live) {
@@ -290,49 +296,90 @@ __global__ __launch_bounds__(256) void k_fft_x(Geom g, FftPlan P, int R, const c
         const cpx E = {0.5 * (zk.x + zm.x), 0.5 * (zk.y + zm.y)};
         const cpx D = csub(zk, zm), O = {0.5 * D.y, -0.5 * D.x};     // -i/2 * (zk - conj(zm))
         const cpx wO = cmul(twp[kk], O);
-        const cpx xk = cadd(E, wO), xm = cconj(csub(E, wO));
-        spec[S.at_slab(g, kk, j, k)] = make_double2(xk.x, xk.y);
-        spec[S.at_slab(g, nh - kk, j, k)] = make_double2(xm.x, xm.y);
+        const cpx xk = cadd(E, wO), xm = cconj(csub(E, wO));          // V_kk and V_{nh-kk}
+        if (!kind) {
+          spec[S.at_slab(g, kk, j, k)] = make_double2(xk.x, xk.y);
+          spec[S.at_slab(g, nh - kk, j, k)] = make_double2(xm.x, xm.y);
+        } else {
+          const int k2 = nh - kk;
+          const cpx a = cmul(twd[kk], xk), b2 = cmul(twd[k2], xm);
+          // real slot r lives in pair r/2, component r%2
+          auto put = [&](int rr, double val) { if (rr < n) specd[2 * S.at_slab(g, rr >> 1, j, k) + (rr & 1)] = val; };
+          put(kk, 2. * a.x); if (kk) put(n - kk, -2. * a.y);
+          put(k2, 2. * b2.x); if (k2 && k2 != n - k2) put(n - k2, -2. * b2.y);
+        }
       }
     }
   } else {
     if (live) {
-      for (int kk = t; kk <= nh; kk += T) { const double2 v = spec[S.at_slab(g, kk, j, k)]; B[kk] = cpx{v.x, v.y}; }
+      if (!kind) { for (int kk = t; kk <= nh; kk += T) { const double2 v = spec[S.at_slab(g, kk, j, k)]; B[kk] = cpx{v.x, v.y}; } }
+      else for (int kk = t; kk <= nh; kk += T) {                      // X_k = conj(w_k) (Y_k - i Y_{n-k}), Y_n := 0
+        const double yk = specd[2 * S.at_slab(g, kk >> 1, j, k) + (kk & 1)];
+        const int r2 = n - kk; const double ym = kk == 0 ? 0. : specd[2 * S.at_slab(g, r2 >> 1, j, k) + (r2 & 1)];
+        B[kk] = cmul(cconj(twd[kk]), cpx{yk, -ym});
+      }
     }
     __syncthreads();
     for (int kk = t; kk < nh; kk += T) {
       const cpx xk = B[kk], xm = cconj(B[nh - kk]);
-      const cpx S = cadd(xk, xm), D = csub(xk, xm);
+      const cpx S2 = cadd(xk, xm), D = csub(xk, xm);
       const cpx wD = cmul(cconj(twp[kk]), D);
-      A[kk] = cpx{S.x - wD.y, S.y + wD.x};                           // S + i*conj(w^k)*D
+      A[kk] = cpx{S2.x - wD.y, S2.y + wD.x};                         // S + i*conj(w^k)*D
     }
     __syncthreads();
     cpx *z = fft_line<1>(P, A, B, t, T, tw);
-    if (live) for (int q = t; q < nh; q += T) { rowp[1 + 2 * q] = z[q].x * scale; rowp[2 + 2 * q] = z[q].y * scale; }
+    if (live) for (int q = t; q < nh; q += T) {
+      if (!kind) { rowp[1 + 2 * q] = z[q].x * scale; rowp[2 + 2 * q] = z[q].y * scale; }
+      else { rowp[1 + dct_src(2 * q, n)] = z[q].x * scale; rowp[1 + dct_src(2 * q + 1, n)] = z[q].y * scale; }
+    }
   }
-  (void)n;
 }
 
 // ------------------------------------------------------------------------------------------ y pass
 // block = CB adjacent complex columns (m0..m0+CB-1) of plane k; T = blockDim.x / CB threads per column.
+// kind 1 (Neumann-Neumann): the DCT acts on the real and imaginary parts separately; with V = FFT(reordered column),
+// C_k = w_k V_k + conj(w_k) V_{N-k} (forward) and Z_k = conj(w_k) (C_k - i C_{N-k}), C_N := 0 (inverse).
 template <int INV>
-__global__ __launch_bounds__(256) void k_fft_y(Geom g, FftPlan P, int CB, int ncols, const cpx *__restrict__ tw, Spec S, double2 *__restrict__ pc) {
+__global__ __launch_bounds__(256) void k_fft_y(Geom g, FftPlan P, int CB, int ncols, int kind, const cpx *__restrict__ tw,
+                                                const cpx *__restrict__ twd, Spec S, double2 *__restrict__ pc) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int N = P.N, ld = N + 1, T = blockDim.x / CB;
   const int m0 = blockIdx.x * CB, k = blockIdx.y + 1;
   cpx *base = reinterpret_cast<cpx *>(smem);
+  // load: forward NN reorders rows into Makhoul order; inverse NN stages the raw coefficients in the second buffer
   for (int q = threadIdx.x; q < CB * N; q += blockDim.x) {
     const int col = q % CB, j = q / CB;
-    if (m0 + col < ncols) { const double2 v = pc[S.at_mode(g, m0 + col, j + 1, k)]; base[(size_t)col * 2 * ld + j] = cpx{v.x, v.y}; }
+    if (m0 + col < ncols) {
+      const double2 v = pc[S.at_mode(g, m0 + col, j + 1, k)];
+      int dst = j;
+      if (kind && !INV) dst = (j & 1) ? N - 1 - (j >> 1) : (j >> 1);
+      base[(size_t)col * 2 * ld + ((kind && INV) ? ld : 0) + dst] = cpx{v.x, v.y};
+    }
   }
   __syncthreads();
+  if (kind && INV) {
+    for (int q = threadIdx.x; q < CB * N; q += blockDim.x) {
+      const int col = q / N, kk = q % N;
+      const cpx *Bc = base + (size_t)col * 2 * ld + ld;
+      const cpx ck = Bc[kk], cm = kk == 0 ? cpx{0., 0.} : Bc[N - kk];
+      base[(size_t)col * 2 * ld + kk] = cmul(cconj(twd[kk]), cpx{ck.x + cm.y, ck.y - cm.x});     // C_k - i C_{N-k}
+    }
+    __syncthreads();
+  }
   const int col = threadIdx.x / T, t = threadIdx.x % T;
   cpx *A = base + (size_t)col * 2 * ld, *B = A + ld;
   cpx *Z = fft_line<INV>(P, A, B, t, T, tw);
   const bool swapped = (Z != A);   // same for every column
   for (int q = threadIdx.x; q < CB * N; q += blockDim.x) {
     const int c2 = q % CB, j = q / CB;
-    if (m0 + c2 < ncols) { const cpx v = base[(size_t)c2 * 2 * ld + (swapped ? ld : 0) + j]; pc[S.at_mode(g, m0 + c2, j + 1, k)] = make_double2(v.x, v.y); }
+    if (m0 + c2 < ncols) {
+      const cpx *Zc = base + (size_t)c2 * 2 * ld + (swapped ? ld : 0);
+      cpx v;
+      if (!kind) v = Zc[j];
+      else if (!INV) { const cpx w = twd[j]; v = cadd(cmul(w, Zc[j]), cmul(cconj(w), Zc[(N - j) % N])); }
+      else v = Zc[(j & 1) ? N - 1 - (j >> 1) : (j >> 1)];
+      pc[S.at_mode(g, m0 + c2, j + 1, k)] = make_double2(v.x, v.y);
+    }
   }
 }
 
@@ -350,6 +397,32 @@ template <> __device__ inline double vfma<double>(double a, double s, double b) 
 
 // ncol x nrow columns; spectral solve: S maps (m, j) (mode side), mofs = global index of local mode 0, nmode = number of
 // real modes (padding columns beyond it are skipped). Real fields (VT = double): in-place haloed array, i0 = 1.
+// NN in x: the two reals of a pair are different modes -> two scalar recurrences (pivots d1,d2 kept as a double2)
+__global__ __launch_bounds__(256) void k_gaussel_split(Geom g, int nz, int ncol, int nrow, int mofs, int nmode, Spec S,
+                                                       const double *__restrict__ a, const double *__restrict__ b, const double *__restrict__ c,
+                                                       const double *__restrict__ lamx, const double *__restrict__ lamy,
+                                                       double2 *__restrict__ p, double2 *__restrict__ dscr) {
+  const int m = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y + 1;
+  if (m >= ncol || j > nrow || m + mofs >= nmode) return;
+  const size_t e0 = S.at_mode(g, m, j, 1), st = S.blocked ? (size_t)S.cw * S.n2l : (size_t)g.s12 / 2;
+  const size_t s0 = (size_t)m + (size_t)ncol * (size_t)(j - 1), sst = (size_t)ncol * nrow;
+  const double l1 = lamx[2 * (m + mofs)] + lamy[j - 1], l2 = lamx[2 * (m + mofs) + 1] + lamy[j - 1];
+  double z1 = 1. / (b[0] + l1 + CALES_EPS), z2 = 1. / (b[0] + l2 + CALES_EPS), d1 = c[0] * z1, d2 = c[0] * z2;
+  double2 v = p[e0]; v.x *= z1; v.y *= z2; p[e0] = v; dscr[s0] = make_double2(d1, d2);
+  for (int l = 1; l < nz; ++l) {
+    z1 = 1. / ((b[l] + l1) - a[l] * d1 + CALES_EPS); z2 = 1. / ((b[l] + l2) - a[l] * d2 + CALES_EPS);
+    d1 = c[l] * z1; d2 = c[l] * z2;
+    const double2 q = p[e0 + l * st];
+    v = make_double2((q.x - a[l] * v.x) * z1, (q.y - a[l] * v.y) * z2);
+    p[e0 + l * st] = v; dscr[s0 + l * sst] = make_double2(d1, d2);
+  }
+  for (int l = nz - 2; l >= 0; --l) {
+    const double2 q = p[e0 + l * st], d = dscr[s0 + l * sst];
+    v = make_double2(q.x - d.x * v.x, q.y - d.y * v.y);
+    p[e0 + l * st] = v;
+  }
+}
+
 template <typename VT, int PERIODIC>
 __global__ __launch_bounds__(256) void k_gaussel(Geom g, int nz, int ncol, int nrow, int i0, int mofs, int nmode, Spec S,
                                                  const double *__restrict__ a, const double *__restrict__ b,
@@ -405,7 +478,10 @@ static SolverPlans *find_plans(cales_ctx *c) { for (auto &s : g_slots) if (s.ctx
 int solver_setup(cales_ctx *c) {
   const int *n = c->n; const int n1 = c->C.ng[0], n2g = c->C.ng[1], n3 = n[2];
   const std::string bx = std::string(1, c->C.cbcpre[0]) + c->C.cbcpre[1], by = std::string(1, c->C.cbcpre[2]) + c->C.cbcpre[3];
-  if (bx != "PP" || by != "PP") { c->err = "solver: only periodic x and y pressure BCs are provided by the device path in this build"; return 1; }
+  if ((bx != "PP" && bx != "NN") || (by != "PP" && by != "NN")) { c->err = "solver: pressure BC pairs in x/y must be PP or NN (cell-centred) on the device path"; return 1; }
+  c->xkind = bx == "NN" ? 1 : 0; c->ykind = by == "NN" ? 1 : 0;
+  if (c->xkind && !c->ykind) { c->err = "solver: NN in x with periodic y is not provided (x modes would pair into complex columns with different eigenvalues)"; return 1; }
+  if (c->xkind && c->C.cbcpre[4] == 'P') { c->err = "solver: NN in x with periodic z is not provided"; return 1; }
   SolverPlans sp;
   if (!make_plan(n1 / 2, sp.px) || !make_plan(n2g, sp.py)) { c->err = "solver: ng(1)/2 and ng(2) must factor into 2,3,5"; return 1; }
   // rows per block in x: aim at ~nh/4 threads per row, 256 threads per block
@@ -418,7 +494,7 @@ int solver_setup(cales_ctx *c) {
   if (sp.shx > 64 * 1024 || sp.shy > 64 * 1024) { c->err = "solver: line too long for the LDS-resident transform"; return 1; }
   // power-of-two lines take the radix-8 register kernels
   auto pow2 = [](int v) { return v >= 16 && (v & (v - 1)) == 0; };
-  sp.x8 = pow2(n1 / 2) && n1 / 2 <= 1024; sp.y8 = pow2(n2g) && n2g <= 1024;
+  sp.x8 = pow2(n1 / 2) && n1 / 2 <= 1024 && !c->xkind; sp.y8 = pow2(n2g) && n2g <= 1024 && !c->ykind;
   if (sp.x8) { const int T = (n1 / 2) / 8; sp.x8_threads = T >= 256 ? T : (256 / T) * T;
                sp.shx8 = ((size_t)(sp.x8_threads / T) * (n1 / 2 + n1 / 16 + 2) + (n1 + 1)) * sizeof(cpx); }
   if (sp.y8) { const int T = n2g / 8; int CB = std::max(1, std::min(std::max(8, 256 / T), 512 / T));
@@ -426,15 +502,15 @@ int solver_setup(cales_ctx *c) {
                sp.y8_threads = CB * T; sp.shy8 = ((size_t)CB * (n2g + n2g / 8 + 1) + n2g) * sizeof(cpx); }
   if (getenv("CALES_FFT_GENERIC")) sp.x8 = sp.y8 = false;
   // eigenvalues (initsolver.f90:66-98); x: modes 0..n1/2 (half-complex symmetry), y: modes 0..n2-1
-  std::vector<double> lx(n1), ly(n2g);
-  hs_eigenvalues(n1, "PP", 'c', lx.data()); hs_eigenvalues(n2g, "PP", 'c', ly.data());
+  std::vector<double> lx(n1 + 2, 0.), ly(n2g);
+  hs_eigenvalues(n1, c->xkind ? "NN" : "PP", 'c', lx.data()); hs_eigenvalues(n2g, c->ykind ? "NN" : "PP", 'c', ly.data());
   for (auto &v : lx) v = v * (c->dli[0] * c->dli[0]);
   for (auto &v : ly) v = v * (c->dli[1] * c->dli[1]);
   const int mh = n1 / 2 + 1;
   c->cw = (mh + c->P - 1) / c->P;                            // complex mode columns per rank (last block padded)
   if (c->P > 1 && (size_t)c->cw * n2g * n3 > c->ntot) { c->err = "solver: scratch too small for the mode-block layout"; return 1; }
-  HIPCHK(c, hipMalloc(&c->d_lamx, mh * sizeof(double))); HIPCHK(c, hipMalloc(&c->d_lamy, n2g * sizeof(double)));
-  HIPCHK(c, hipMemcpy(c->d_lamx, lx.data(), mh * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMalloc(&c->d_lamx, (n1 + 2) * sizeof(double))); HIPCHK(c, hipMalloc(&c->d_lamy, n2g * sizeof(double)));
+  HIPCHK(c, hipMemcpy(c->d_lamx, lx.data(), (n1 + 2) * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_lamy, ly.data(), n2g * sizeof(double), hipMemcpyHostToDevice));
   // tridiagonal (initsolver.f90:127-169), pressure: cell-centred
   std::vector<double> a(n3), b(n3), cc(n3);
@@ -443,7 +519,7 @@ int solver_setup(cales_ctx *c) {
   HIPCHK(c, hipMemcpy(c->d_a, a.data(), n3 * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_b, b.data(), n3 * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_c, cc.data(), n3 * sizeof(double), hipMemcpyHostToDevice));
-  c->normfft = 1. / ((double)n1 * (double)n2g);             // fft.f90:99,136,142 with norm = [1,0] twice
+  c->normfft = 1. / ((c->xkind ? 2. : 1.) * (double)n1 * (c->ykind ? 2. : 1.) * (double)n2g);   // fft.f90:99,136,142; find_fft norm = [1,0] (PP) / [2,0] (NN)
   // twiddles: exp(-2 pi i q/N)
   auto mk = [&](int N, int cnt, double **dev) -> int {
     std::vector<double> t(2 * (size_t)cnt);
@@ -456,6 +532,8 @@ int solver_setup(cales_ctx *c) {
   if (mk(n1 / 2, n1 / 2, &c->d_twx)) return 1;
   if (mk(n1, n1 / 2 + 1, &c->d_twx_post)) return 1;
   if (mk(n2g, n2g, &c->d_twy)) return 1;
+  if (mk(4 * n1, n1 / 2 + 1, &c->d_twy_post)) return 1;      // DCT weights e^{-i pi k/(2 n1)}, k = 0..n1/2 (x)
+  if (mk(4 * n2g, n2g, &c->scr_twyd)) return 1;              // e^{-i pi k/(2 n2)}, k = 0..n2-1 (y)
   if (c->C.impdiff == 2)
     for (int iv = 0; iv < 3; ++iv) {
       hs_tridmatrix(&c->cbcvel[6 * iv + 4], n3, c->dzci.data(), c->dzfi.data(), iv == 2 ? 'f' : 'c', a.data(), b.data(), cc.data());
@@ -471,7 +549,7 @@ int solver_setup(cales_ctx *c) {
 void solver_teardown(cales_ctx *c) {
   for (size_t q = 0; q < g_slots.size(); ++q) if (g_slots[q].ctx == c) { g_slots.erase(g_slots.begin() + q); break; }
   hipFree(c->d_lamx); hipFree(c->d_lamy); hipFree(c->d_a); hipFree(c->d_b); hipFree(c->d_c);
-  hipFree(c->d_twx); hipFree(c->d_twx_post); hipFree(c->d_twy);
+  hipFree(c->d_twx); hipFree(c->d_twx_post); hipFree(c->d_twy); hipFree(c->d_twy_post); hipFree(c->scr_twyd);
   for (int iv = 0; iv < 3; ++iv) hipFree(c->d_av[iv]);
 }
 
@@ -500,25 +578,27 @@ int op_solver(cales_ctx *c) {
   { ProfScope ps(c, "fft_x_fwd");
     if (sp->x8) hipLaunchKernelGGL(k_fft_x8<0>, dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, pp, 1., S, slab_spec);
-    else hipLaunchKernelGGL(k_fft_x<0>, dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
-                       (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, pp, 1., S, slab_spec); }
+    else hipLaunchKernelGGL(k_fft_x<0>, dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx, c->xkind,
+                       (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec); }
   if (dist) { ProfScope ps(c, "alltoall"); if (c->comm.a2a(c->comm.user, 0, a2a_count)) { c->err = "alltoall callback failed"; return 1; } }
   { ProfScope ps(c, "fft_y_fwd");
     if (sp->y8) hipLaunchKernelGGL(k_fft_y8<0>, dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, S, mode_spec);
-    else hipLaunchKernelGGL(k_fft_y<0>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, (const cpx *)c->d_twy, S, mode_spec); }
+    else hipLaunchKernelGGL(k_fft_y<0>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
   { ProfScope ps(c, "gaussel_z");
     dim3 b(64, 4), gr((ncol + 63) / 64, (n2g + 3) / 4);
-    if (periodic_z) hipLaunchKernelGGL((k_gaussel<double2, 1>), gr, b, 0, c->stream, c->g, n[2], ncol, n2g, 0, mofs, mh, S, c->d_a, c->d_b, c->d_c, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2);
+    if (c->xkind) hipLaunchKernelGGL(k_gaussel_split, gr, b, 0, c->stream, c->g, n[2], ncol, n2g, mofs, c->C.ng[0] / 2, S, c->d_a, c->d_b, c->d_c, c->d_lamx, c->d_lamy,
+                                     (double2 *)mode_spec, (double2 *)c->scr1);
+    else if (periodic_z) hipLaunchKernelGGL((k_gaussel<double2, 1>), gr, b, 0, c->stream, c->g, n[2], ncol, n2g, 0, mofs, mh, S, c->d_a, c->d_b, c->d_c, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2);
     else hipLaunchKernelGGL((k_gaussel<double2, 0>), gr, b, 0, c->stream, c->g, n[2], ncol, n2g, 0, mofs, mh, S, c->d_a, c->d_b, c->d_c, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2); }
   { ProfScope ps(c, "fft_y_bwd");
     if (sp->y8) hipLaunchKernelGGL(k_fft_y8<1>, dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, S, mode_spec);
-    else hipLaunchKernelGGL(k_fft_y<1>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, (const cpx *)c->d_twy, S, mode_spec); }
+    else hipLaunchKernelGGL(k_fft_y<1>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
   if (dist) { ProfScope ps(c, "alltoall"); if (c->comm.a2a(c->comm.user, 1, a2a_count)) { c->err = "alltoall callback failed"; return 1; } }
   { ProfScope ps(c, "fft_x_bwd");
     if (sp->x8) hipLaunchKernelGGL(k_fft_x8<1>, dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, pp, c->normfft, S, slab_spec);
-    else hipLaunchKernelGGL(k_fft_x<1>, dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
-                       (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, pp, c->normfft, S, slab_spec); }
+    else hipLaunchKernelGGL(k_fft_x<1>, dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx, c->xkind,
+                       (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec); }
   HIPCHK(c, hipGetLastError());
   return 0;
 }

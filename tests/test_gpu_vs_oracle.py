@@ -17,7 +17,9 @@ def _hot(case):
 
 @pytest.mark.parametrize("name,ng", [("chan_smag", (32, 16, 12)), ("chan_smag", (48, 40, 24)), ("chan_smag", (64, 128, 8)),
                                      ("chan_smag", (512, 64, 6)), ("chan_smag", (60, 90, 10)), ("chan_smag", (2048, 16, 4)),
-                                     ("tgv_ppp", (32, 32, 16)), ("tgv_ppp", (24, 20, 18)), ("halfchan_imp1d", (16, 1024, 4))])
+                                     ("tgv_ppp", (32, 32, 16)), ("tgv_ppp", (24, 20, 18)), ("halfchan_imp1d", (16, 1024, 4)),
+                                     ("duct_smag_wm", (32, 64, 16)), ("duct_smag_wm", (24, 30, 12)), ("duct_smag_wm", (128, 256, 8)),
+                                     ("cavity_nnn", (32, 16, 12)), ("cavity_nnn", (20, 36, 10)), ("cavity_nnn", (256, 128, 6))])
 def test_poisson_solve(name, ng):
     g, case = load_golden(name)
     case.ng[:] = ng
@@ -36,7 +38,8 @@ def test_poisson_solve(name, ng):
 
 
 @pytest.mark.parametrize("name,ng,nsteps", [("tgv_ppp", (32, 24, 16), 5), ("chan_smag_wm", (32, 16, 16), 5), ("chan_dsmag", (32, 16, 16), 5),
-                                            ("halfchan_imp1d", (16, 16, 16), 3), ("chan_smag", (24, 20, 12), 10)])
+                                            ("halfchan_imp1d", (16, 16, 16), 3), ("chan_smag", (24, 20, 12), 10),
+                                            ("duct_smag_wm", (16, 24, 24), 4), ("cavity_nnn", (16, 16, 16), 5)])
 def test_time_steps(name, ng, nsteps):
     """u,v,w <= 1e-9, p (mean removed) <= 1e-8 after the steps; divmax same order of magnitude"""
     from cales_amd.hotpath import initflow
