@@ -75,6 +75,7 @@ void cales_destroy(cales_ctx *c) {
   for (auto &ev : c->evpool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
   solver_teardown(c);
   for (int q = 0; q < CALES_NFIELDS; ++q) hipFree(c->f[q]);
+  for (int q = 0; q < 3; ++q) hipFree(c->f2[q]);
   hipFree(c->d_dzc); hipFree(c->d_dzf); hipFree(c->d_zc); hipFree(c->d_zf); hipFree(c->d_dzci); hipFree(c->d_dzfi); hipFree(c->d_gvr_c); hipFree(c->d_gvr_f);
   DBound *bs[11] = {&c->bcu, &c->bcv, &c->bcw, &c->bcp, &c->bcs, &c->bcuf, &c->bcvf, &c->bcwf, &c->bcu_mag, &c->bcv_mag, &c->bcw_mag};
   for (auto *b : bs) free_bound(*b);
@@ -155,6 +156,7 @@ int cales_create(const cales_case *cs, void *stream, cales_ctx **out) {
   const int nfields = cs->impdiff ? CALES_NFIELDS : CALES_DUDTD;
   for (int q = 0; q < nfields; ++q) if (dev_alloc(c, &c->f[q], c->ntot)) return fail(8);
   if (dev_alloc(c, &c->scr1, c->ntot) || dev_alloc(c, &c->scr2, c->ntot)) return fail(9);
+  for (int q = 0; q < 3; ++q) if (dev_alloc(c, &c->f2[q], c->ntot)) return fail(9);
   c->red_blocks = 8;
   if (dev_alloc(c, &c->d_red, 64 + 16 * (size_t)(n3 + 2) + 4 * (size_t)(n3 + 2)) || dev_alloc(c, &c->d_force, 8)) return fail(10);
   c->res = c->d_red;

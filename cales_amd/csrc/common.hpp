@@ -68,6 +68,7 @@ struct cales_ctx {
   double *d_dzc, *d_dzf, *d_zc, *d_zf, *d_dzci, *d_dzfi, *d_gvr_c, *d_gvr_f;
   // fields
   double *f[CALES_NFIELDS];
+  double *f2[3] = {nullptr, nullptr, nullptr};   // second velocity buffers of the fused mom+RK kernel (pointers are swapped with f[U..W])
   size_t ntot;
   // BC planes
   DBound bcu, bcv, bcw, bcp, bcs, bcuf, bcvf, bcwf, bcu_mag, bcv_mag, bcw_mag;
@@ -143,6 +144,7 @@ int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm
 int op_boundp(cales_ctx *c, double *p, int which);
 int op_mom(cales_ctx *c);
 int op_rk(cales_ctx *c, int irk, double dt);
+int op_momrk(cales_ctx *c, double f1, double f2, double f12);
 int op_bulk_forcing(cales_ctx *c);
 int op_bulk_mean_dev(cales_ctx *c, const double *p, int c_or_f, double *d_out);   // result to device scalar
 int op_fillps(cales_ctx *c, double dtrki);

@@ -1,0 +1,159 @@
+// Fused momentum r.h.s. + RK update (reference src/mom.f90:17-309 + src/rk.f90:77-94) as a plane-marching tile kernel.
+//
+// The kernel-per-loop version (k_mom + k_rk_update in k_stencil.hip) issues 55 + 13 vector loads per cell and is bound by the
+// L1/TA rate, and it writes the r.h.s. only to read it back. Here a block of 64 x (TYM+2) threads owns a tile of 62 x TYM
+// columns and marches in k: every thread loads ONLY its own cell of u,v,w,visct,p per plane (coalesced rows, next plane
+// prefetched), the planes k-1..k+1 live in a 4-slot LDS ring from which the 13/16-point stencils are read, and the RK update
+// is applied in the same pass. Velocities are written to a second set of buffers (the stencil still needs the old values of
+// the neighbours); the host swaps the pointers. Arithmetic and expression order are those of the reference.
+// Algorithmic traffic: 14 words/cell (5 in + 3 old r.h.s. in + 3 velocities + 3 r.h.s. out) instead of 7 + 13.
+#include "common.hpp"
+
+#define TYM 6
+
+struct MomRkArgs {
+  const double *u, *v, *w, *s, *p, *duo, *dvo, *dwo;
+  double *un, *vn, *wn, *du, *dv, *dw, *dud, *dvd, *dwd;
+  const double *dzci, *dzfi;
+  double dxi, dyi, visc, f1, f2, f12, bfx, bfy, bfz;
+  int kchunk;
+};
+
+template <int IMP>
+__global__ __launch_bounds__(64 * (TYM + 2), 4) void k_momrk(Geom g, MomRkArgs A) {
+  __shared__ double sh[4][4][TYM + 2][64];
+  __shared__ double shp[2][TYM + 2][64];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int i = blockIdx.x * 62 + tx, j = blockIdx.y * TYM + ty;
+  const int kbeg = blockIdx.z * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
+  const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1;
+  const bool outok = tx >= 1 && tx <= 62 && ty >= 1 && ty <= TYM && i <= g.n1 && j <= g.n2;
+  const size_t c0 = ldok ? g.ix(i, j, 0) : 0;
+  const size_t sk = (size_t)g.s12;
+  auto ld5 = [&](int k, double *q) {
+    if (ldok && k <= g.n3 + 1) { const size_t c = c0 + (size_t)k * sk; q[0] = A.u[c]; q[1] = A.v[c]; q[2] = A.w[c]; q[3] = A.s[c]; q[4] = A.p[c]; }
+    else { q[0] = q[1] = q[2] = q[3] = q[4] = 0.; }
+  };
+  double q0[5], q1[5], nx[5];
+  ld5(kbeg - 1, q0); ld5(kbeg, q1); ld5(kbeg + 1, nx);
+#pragma unroll
+  for (int f = 0; f < 4; ++f) { sh[f][(kbeg - 1) & 3][ty][tx] = q0[f]; sh[f][kbeg & 3][ty][tx] = q1[f]; }
+  double pcur = q1[4];
+  for (int k = kbeg; k <= kend; ++k) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) sh[f][(k + 1) & 3][ty][tx] = nx[f];
+    shp[k & 1][ty][tx] = pcur;
+    const double pnext = nx[4];
+    __syncthreads();
+    double pf[5];
+    ld5(k + 2, pf);                                         // prefetch, in flight during the stencil
+    if (outok) {
+      const size_t c = c0 + (size_t)k * sk;
+      const double duo = A.duo[c], dvo = A.dvo[c], dwo = A.dwo[c];
+      const int km = (k - 1) & 3, kc = k & 3, kp = (k + 1) & 3;
+#define LS(f, sl, di, dj) sh[f][sl][ty + (dj)][tx + (di)]
+      const double u_ccm = LS(0, km, 0, 0), u_pcm = LS(0, km, 1, 0), u_cpm = LS(0, km, 0, 1), u_cmc = LS(0, kc, 0, -1), u_mcc = LS(0, kc, -1, 0),
+                   u_ccc = LS(0, kc, 0, 0), u_pcc = LS(0, kc, 1, 0), u_mpc = LS(0, kc, -1, 1), u_cpc = LS(0, kc, 0, 1), u_mcp = LS(0, kp, -1, 0),
+                   u_ccp = LS(0, kp, 0, 0);
+      const double v_ccm = LS(1, km, 0, 0), v_cpm = LS(1, km, 0, 1), v_cmc = LS(1, kc, 0, -1), v_pmc = LS(1, kc, 1, -1), v_mcc = LS(1, kc, -1, 0),
+                   v_ccc = LS(1, kc, 0, 0), v_pcc = LS(1, kc, 1, 0), v_cpc = LS(1, kc, 0, 1), v_cmp = LS(1, kp, 0, -1), v_ccp = LS(1, kp, 0, 0);
+      const double w_ccm = LS(2, km, 0, 0), w_pcm = LS(2, km, 1, 0), w_cpm = LS(2, km, 0, 1), w_cmc = LS(2, kc, 0, -1), w_mcc = LS(2, kc, -1, 0),
+                   w_ccc = LS(2, kc, 0, 0), w_pcc = LS(2, kc, 1, 0), w_cpc = LS(2, kc, 0, 1), w_ccp = LS(2, kp, 0, 0);
+      const double s_ccm = LS(3, km, 0, 0), s_pcm = LS(3, km, 1, 0), s_cpm = LS(3, km, 0, 1), s_cmc = LS(3, kc, 0, -1), s_pmc = LS(3, kc, 1, -1),
+                   s_mcc = LS(3, kc, -1, 0), s_ccc = LS(3, kc, 0, 0), s_pcc = LS(3, kc, 1, 0), s_mpc = LS(3, kc, -1, 1), s_cpc = LS(3, kc, 0, 1),
+                   s_cmp = LS(3, kp, 0, -1), s_mcp = LS(3, kp, -1, 0), s_ccp = LS(3, kp, 0, 0), s_ppc = LS(3, kc, 1, 1), s_pcp = LS(3, kp, 1, 0),
+                   s_cpp = LS(3, kp, 0, 1);
+#undef LS
+      const double p_ccc = pcur, p_pcc = shp[k & 1][ty][tx + 1], p_cpc = shp[k & 1][ty + 1][tx], p_ccp = pnext;
+      const double dxi = A.dxi, dyi = A.dyi, visc = A.visc;
+      const double dzci_k = A.dzci[k], dzci_m = A.dzci[k - 1], dzfi_k = A.dzfi[k], dzfi_p = A.dzfi[k + 1];
+      double visc_ip, visc_im, visc_jp, visc_jm, visc_kp, visc_km;
+      // ---- x momentum (mom.f90:143-186)
+      visc_ip = s_pcc; visc_im = s_ccc;
+      visc_jp = 0.25 * (s_ccc + s_pcc + s_cpc + s_ppc); visc_jm = 0.25 * (s_ccc + s_pcc + s_cmc + s_pmc);
+      visc_kp = 0.25 * (s_ccc + s_pcc + s_ccp + s_pcp); visc_km = 0.25 * (s_ccc + s_pcc + s_ccm + s_pcm);
+      const double dudx_ip = (u_pcc - u_ccc) * dxi, dudx_im = (u_ccc - u_mcc) * dxi, dudy_jp = (u_cpc - u_ccc) * dyi,
+                   dudy_jm = (u_ccc - u_cmc) * dyi, dudz_kp = (u_ccp - u_ccc) * dzci_k, dudz_km = (u_ccc - u_ccm) * dzci_m;
+      const double dvdx_jp = (v_pcc - v_ccc) * dxi, dvdx_jm = (v_pmc - v_cmc) * dxi, dwdx_kp = (w_pcc - w_ccc) * dxi,
+                   dwdx_km = (w_pcm - w_ccm) * dxi;
+      const double uu_ip = 0.25 * (u_pcc + u_ccc) * (u_ccc + u_pcc), uu_im = 0.25 * (u_mcc + u_ccc) * (u_ccc + u_mcc),
+                   vu_jp = 0.25 * (v_pcc + v_ccc) * (u_ccc + u_cpc), vu_jm = 0.25 * (v_pmc + v_cmc) * (u_ccc + u_cmc),
+                   wu_kp = 0.25 * (w_pcc + w_ccc) * (u_ccc + u_ccp), wu_km = 0.25 * (w_pcm + w_ccm) * (u_ccc + u_ccm);
+      const double dudtd_xy = visc * (dudx_ip - dudx_im) * dxi + visc * (dudy_jp - dudy_jm) * dyi;
+      const double dudtd_z = visc * (dudz_kp - dudz_km) * dzfi_k;
+      const double dudt_s = -(uu_ip - uu_im) * dxi - (vu_jp - vu_jm) * dyi - (wu_kp - wu_km) * dzfi_k +
+                            (visc_ip * (dudx_ip + dudx_ip) - visc_im * (dudx_im + dudx_im)) * dxi +
+                            (visc_jp * (dudy_jp + dvdx_jp) - visc_jm * (dudy_jm + dvdx_jm)) * dyi +
+                            (visc_kp * (dudz_kp + dwdx_kp) - visc_km * (dudz_km + dwdx_km)) * dzfi_k;
+      // ---- y momentum (mom.f90:188-231)
+      visc_ip = 0.25 * (s_ccc + s_cpc + s_pcc + s_ppc); visc_im = 0.25 * (s_ccc + s_cpc + s_mcc + s_mpc);
+      visc_jp = s_cpc; visc_jm = s_ccc;
+      visc_kp = 0.25 * (s_ccc + s_cpc + s_ccp + s_cpp); visc_km = 0.25 * (s_ccc + s_cpc + s_ccm + s_cpm);
+      const double dvdx_ip = (v_pcc - v_ccc) * dxi, dvdx_im = (v_ccc - v_mcc) * dxi, dvdy_jp = (v_cpc - v_ccc) * dyi,
+                   dvdy_jm = (v_ccc - v_cmc) * dyi, dvdz_kp = (v_ccp - v_ccc) * dzci_k, dvdz_km = (v_ccc - v_ccm) * dzci_m;
+      const double dudy_ip = (u_cpc - u_ccc) * dyi, dudy_im = (u_mpc - u_mcc) * dyi, dwdy_kp = (w_cpc - w_ccc) * dyi,
+                   dwdy_km = (w_cpm - w_ccm) * dyi;
+      const double uv_ip = 0.25 * (u_ccc + u_cpc) * (v_ccc + v_pcc), uv_im = 0.25 * (u_mcc + u_mpc) * (v_ccc + v_mcc),
+                   vv_jp = 0.25 * (v_ccc + v_cpc) * (v_ccc + v_cpc), vv_jm = 0.25 * (v_ccc + v_cmc) * (v_ccc + v_cmc),
+                   wv_kp = 0.25 * (w_ccc + w_cpc) * (v_ccc + v_ccp), wv_km = 0.25 * (w_ccm + w_cpm) * (v_ccc + v_ccm);
+      const double dvdtd_xy = visc * (dvdx_ip - dvdx_im) * dxi + visc * (dvdy_jp - dvdy_jm) * dyi;
+      const double dvdtd_z = visc * (dvdz_kp - dvdz_km) * dzfi_k;
+      const double dvdt_s = -(uv_ip - uv_im) * dxi - (vv_jp - vv_jm) * dyi - (wv_kp - wv_km) * dzfi_k +
+                            (visc_ip * (dvdx_ip + dudy_ip) - visc_im * (dvdx_im + dudy_im)) * dxi +
+                            (visc_jp * (dvdy_jp + dvdy_jp) - visc_jm * (dvdy_jm + dvdy_jm)) * dyi +
+                            (visc_kp * (dvdz_kp + dwdy_kp) - visc_km * (dvdz_km + dwdy_km)) * dzfi_k;
+      // ---- z momentum (mom.f90:233-276)
+      visc_ip = 0.25 * (s_ccc + s_ccp + s_pcc + s_pcp); visc_im = 0.25 * (s_ccc + s_ccp + s_mcc + s_mcp);
+      visc_jp = 0.25 * (s_ccc + s_ccp + s_cpc + s_cpp); visc_jm = 0.25 * (s_ccc + s_ccp + s_cmc + s_cmp);
+      visc_kp = s_ccp; visc_km = s_ccc;
+      const double dwdx_ip = (w_pcc - w_ccc) * dxi, dwdx_im = (w_ccc - w_mcc) * dxi, dwdy_jp = (w_cpc - w_ccc) * dyi,
+                   dwdy_jm = (w_ccc - w_cmc) * dyi, dwdz_kp = (w_ccp - w_ccc) * dzfi_p, dwdz_km = (w_ccc - w_ccm) * dzfi_k;
+      const double dudz_ip = (u_ccp - u_ccc) * dzci_k, dudz_im = (u_mcp - u_mcc) * dzci_k, dvdz_jp = (v_ccp - v_ccc) * dzci_k,
+                   dvdz_jm = (v_cmp - v_cmc) * dzci_k;
+      const double uw_ip = 0.25 * (u_ccc + u_ccp) * (w_ccc + w_pcc), uw_im = 0.25 * (u_mcc + u_mcp) * (w_ccc + w_mcc),
+                   vw_jp = 0.25 * (v_ccc + v_ccp) * (w_ccc + w_cpc), vw_jm = 0.25 * (v_cmc + v_cmp) * (w_ccc + w_cmc),
+                   ww_kp = 0.25 * (w_ccc + w_ccp) * (w_ccc + w_ccp), ww_km = 0.25 * (w_ccc + w_ccm) * (w_ccc + w_ccm);
+      const double dwdtd_xy = visc * (dwdx_ip - dwdx_im) * dxi + visc * (dwdy_jp - dwdy_jm) * dyi;
+      const double dwdtd_z = visc * (dwdz_kp - dwdz_km) * dzci_k;
+      const double dwdt_s = -(uw_ip - uw_im) * dxi - (vw_jp - vw_jm) * dyi - (ww_kp - ww_km) * dzci_k +
+                            (visc_ip * (dwdx_ip + dudz_ip) - visc_im * (dwdx_im + dudz_im)) * dxi +
+                            (visc_jp * (dwdy_jp + dvdz_jp) - visc_jm * (dwdy_jm + dvdz_jm)) * dyi +
+                            (visc_kp * (dwdz_kp + dwdz_kp) - visc_km * (dwdz_km + dwdz_km)) * dzci_k;
+      double du, dv, dw, dud = 0., dvd = 0., dwd = 0.;
+      if (IMP == 2) { du = dudt_s + dudtd_xy; dv = dvdt_s + dvdtd_xy; dw = dwdt_s + dwdtd_xy; dud = dudtd_z; dvd = dvdtd_z; dwd = dwdtd_z; }   // mom.f90:278-284
+      else { du = dudt_s + dudtd_xy + dudtd_z; dv = dvdt_s + dvdtd_xy + dvdtd_z; dw = dwdt_s + dwdtd_xy + dwdtd_z; }                        // mom.f90:297-302
+      // ---- RK update (rk.f90:81-91)
+      double un = u_ccc + A.f1 * du + A.f2 * duo + A.f12 * (A.bfx - dxi * (p_pcc - p_ccc));
+      double vn = v_ccc + A.f1 * dv + A.f2 * dvo + A.f12 * (A.bfy - dyi * (p_cpc - p_ccc));
+      double wn = w_ccc + A.f1 * dw + A.f2 * dwo + A.f12 * (A.bfz - dzci_k * (p_ccp - p_ccc));
+      if (IMP) { un = un + A.f12 * dud; vn = vn + A.f12 * dvd; wn = wn + A.f12 * dwd; A.dud[c] = dud; A.dvd[c] = dvd; A.dwd[c] = dwd; }
+      A.un[c] = un; A.vn[c] = vn; A.wn[c] = wn;
+      A.du[c] = du; A.dv[c] = dv; A.dw[c] = dw;
+    }
+    pcur = pnext;
+#pragma unroll
+    for (int f = 0; f < 5; ++f) nx[f] = pf[f];
+  }
+}
+
+// mom_xyz_ad + update of rk (rk.f90:74-94); leaves the new velocities in c->f[CALES_U..W] (pointers swapped with c->f2)
+int op_momrk(cales_ctx *c, double f1, double f2, double f12) {
+  ProfScope ps(c, "mom_rk_fused");
+  const int *n = c->n; double **f = c->f;
+  MomRkArgs A;
+  A.u = f[CALES_U]; A.v = f[CALES_V]; A.w = f[CALES_W]; A.s = f[CALES_VISCT]; A.p = f[CALES_P];
+  A.duo = f[CALES_DUDTO]; A.dvo = f[CALES_DVDTO]; A.dwo = f[CALES_DWDTO];
+  A.un = c->f2[0]; A.vn = c->f2[1]; A.wn = c->f2[2];
+  A.du = f[CALES_DUDT]; A.dv = f[CALES_DVDT]; A.dw = f[CALES_DWDT]; A.dud = f[CALES_DUDTD]; A.dvd = f[CALES_DVDTD]; A.dwd = f[CALES_DWDTD];
+  A.dzci = c->d_dzci; A.dzfi = c->d_dzfi; A.dxi = c->dli[0]; A.dyi = c->dli[1]; A.visc = c->visc;
+  A.f1 = f1; A.f2 = f2; A.f12 = f12; A.bfx = c->C.bforce[0]; A.bfy = c->C.bforce[1]; A.bfz = c->C.bforce[2];
+  dim3 b(64, TYM + 2, 1), gr((n[0] + 61) / 62, (n[1] + TYM - 1) / TYM, 1);
+  int kchunk = n[2];
+  while ((long)gr.x * gr.y * ((n[2] + kchunk - 1) / kchunk) < 2048 && kchunk > 32) kchunk = (kchunk + 1) / 2;
+  gr.z = (n[2] + kchunk - 1) / kchunk; A.kchunk = kchunk;
+  if (c->C.impdiff == 2) hipLaunchKernelGGL(k_momrk<2>, gr, b, 0, c->stream, c->g, A);
+  else hipLaunchKernelGGL(k_momrk<0>, gr, b, 0, c->stream, c->g, A);
+  HIPCHK(c, hipGetLastError());
+  for (int q = 0; q < 3; ++q) std::swap(c->f[CALES_U + q], c->f2[q]);
+  return 0;
+}

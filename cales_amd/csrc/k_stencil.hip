@@ -231,10 +231,13 @@ __global__ void k_zero_force(double *force) { if (threadIdx.x < 3) force[threadI
 int op_rk(cales_ctx *c, int irk, double dt) {
   static const double rk[3][2] = {{32. / 60., 0.}, {25. / 60., -17. / 60.}, {45. / 60., -25. / 60.}};   // param.f90:27-29
   const double f1 = rk[irk - 1][0] * dt, f2 = rk[irk - 1][1] * dt, f12 = f1 + f2;
-  if (int e = op_mom(c)) return e;
   double **f = c->f;
   dim3 b(BX, BY, 1), gr = grid3(c->n[0], c->n[1], c->n[2], b);
-  {
+  static const bool unfused = getenv("CALES_UNFUSED_RK") != nullptr;
+  if (!unfused && c->n[2] >= 2) {
+    if (int e = op_momrk(c, f1, f2, f12)) return e;
+  } else {
+    if (int e = op_mom(c)) return e;
     ProfScope ps(c, "rk_update");
     if (c->C.impdiff)
       hipLaunchKernelGGL(k_rk_update<1>, gr, b, 0, c->stream, c->g, f1, f2, f12, c->dli[0], c->dli[1], c->C.bforce[0], c->C.bforce[1], c->C.bforce[2],
