@@ -25,10 +25,15 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
 
-# algorithmic FP64 words per cell per launch (DESIGN.md "Kernels")
-WORDS = {"mom_xyz_ad": 7, "rk_update": 13, "fillps": 4, "correc": 7, "updatep": 3, "bulk_forcing": 2,
+# ALGORITHMIC FP64 words per cell per launch = the words of the reference loop nests a kernel replaces (SURVEY.md 8a and
+# App. E). Fused kernels are credited with the sum of the loops they fuse, so `achieved` is an
+# effective bandwidth; the hardware traffic of the same kernel (rocprofv3 PMC) is reported in `traffic`.
+WORDS = {"mom_xyz_ad": 7, "rk_update": 13, "mom_rk_fused": 20, "fillps": 4, "correc": 7, "updatep": 3, "bulk_forcing": 2,
          "fft_x_fwd": 2, "fft_y_fwd": 2, "gaussel_z": 2, "fft_y_bwd": 2, "fft_x_bwd": 2,
-         "strain_rate": 10, "filter3d": 2}
+         # dynamic model, fast path (sums to App. E's 131): strain 10 + visct=s0 2 + interpolate 6 | products 13 + 6 filters 12 |
+         # 3 filters 6 | strain 10 + Mij 20 | products 9 + 9 filters 18 + contraction 17 + plane averages 4 | final 4
+         "strain_rate": 18, "filter_s0sij": 25, "filter_uvw": 6, "strain_mij": 30, "interp_uvw": 6, "lij_contract": 48,
+         "filter3d": 2}
 W_STEP = {"none": 44, "smag": 51, "dsmag": 178}   # per substep; x3 per step
 
 
@@ -133,6 +138,16 @@ def main():
         dom = max(leaf, key=lambda k: leaf[k][1])
         calls, ms = leaf[dom]
         ach = WORDS[dom] * 8.0 * nloc / (ms / calls * 1e-3)
+        # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (profiles/summarize.py), if present
+        traffic, traffic_src = None, None
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "latest_kernels.json")))
+            kmap = prof.get("bench_to_kernel", {})
+            for row in prof.get("kernels", []):
+                if row["kernel"] == kmap.get(dom) and "hbm_read_bytes" in row and prof.get("ncell") == ncell and world == 1:
+                    traffic = row["hbm_read_bytes"] + row["hbm_write_bytes"]; traffic_src = prof.get("source")
+        except (OSError, ValueError, KeyError):
+            pass
         solve = ["fft_x_fwd", "fft_y_fwd", "gaussel_z", "fft_y_bwd", "fft_x_bwd"]
         solve_ms = sum(stats[k][1] / stats[k][0] for k in solve if k in stats and stats[k][0])
         out = {
@@ -143,7 +158,7 @@ def main():
                                    "PP/PP/NN pressure BCs, bulk forcing in x (BASELINE.json configs[2]); 3 RK substeps/step",
                        "decomposition": f"y-slabs x{world}" if world > 1 else "single GPU", "dt": dt},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK, "traffic": None,
+                         "frac": ach / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": WORDS[dom] * 8.0 * nloc, "avg_launch_ms": ms / calls, "launches": calls},
             "poisson_solve": {"ms": solve_ms, "algorithmic_GBps": 10 * 8.0 * nloc / (solve_ms * 1e-3) / 1e9 if solve_ms else None,
                               "frac_of_hbm_peak": 10 * 8.0 * nloc / (solve_ms * 1e-3) / HBM_PEAK if solve_ms else None},

@@ -24,8 +24,9 @@ __global__ __launch_bounds__(64 * (TYM + 2), 4) void k_momrk(Geom g, MomRkArgs A
   __shared__ double sh[4][4][TYM + 2][64];
   __shared__ double shp[2][TYM + 2][64];
   const int tx = threadIdx.x, ty = threadIdx.y;
-  const int i = blockIdx.x * 62 + tx, j = blockIdx.y * TYM + ty;
-  const int kbeg = blockIdx.z * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
+  const int bx_ = blockIdx.x, by_ = blockIdx.y, bz_ = blockIdx.z;
+  const int i = bx_ * 62 + tx, j = by_ * TYM + ty;
+  const int kbeg = bz_ * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
   const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1;
   const bool outok = tx >= 1 && tx <= 62 && ty >= 1 && ty <= TYM && i <= g.n1 && j <= g.n2;
   const size_t c0 = ldok ? g.ix(i, j, 0) : 0;

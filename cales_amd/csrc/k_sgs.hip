@@ -55,7 +55,7 @@ __global__ __launch_bounds__(BX *BY) void k_strain(Geom g, double dxi, double dy
                                                     const double *__restrict__ v, const double *__restrict__ w, double *__restrict__ s0,
                                                     double *__restrict__ s11o, double *__restrict__ s22o, double *__restrict__ s33o,
                                                     double *__restrict__ s12o, double *__restrict__ s13o, double *__restrict__ s23o,
-                                                    double *__restrict__ s0copy) {
+                                                    double *__restrict__ s0copy, double *__restrict__ uc, double *__restrict__ vc, double *__restrict__ wc) {
   int bx_, by_, bz_; stencil_block(bx_, by_, bz_);
   const int i = bx_ * BX + threadIdx.x + 1, j = by_ * BY + threadIdx.y + 1, k = bz_ + 1;
   if (i > g.n1 || j > g.n2) return;
@@ -80,14 +80,17 @@ __global__ __launch_bounds__(BX *BY) void k_strain(Geom g, double dxi, double dy
   const double s0v = sqrt(2. * (s11 * s11 + s22 * s22 + s33 * s33 + 2. * (s12 * s12 + s13 * s13 + s23 * s23)));
   s0[c] = s0v;
   if (WITH_SIJ) { s11o[c] = s11; s22o[c] = s22; s33o[c] = s33; s12o[c] = s12; s13o[c] = s13; s23o[c] = s23; }
-  if (WITH_SIJ == 2) s0copy[c] = s0v;          // visct = s0 (sgs.f90:184) without a separate copy pass
+  if (WITH_SIJ == 2) {
+    s0copy[c] = s0v;                           // visct = s0 (sgs.f90:184) without a separate copy pass
+    uc[c] = 0.5 * (u_ccc + u_mcc); vc[c] = 0.5 * (v_ccc + v_cmc); wc[c] = 0.5 * (w_ccc + w_ccm);   // interpolate (sgs.f90:860-869), same loads
+  }
 }
 static int strain_rate(cales_ctx *c, const double *u, const double *v, const double *w, double *s0, double **sij) {
   ProfScope ps(c, "strain_rate");
   dim3 b(BX, BY, 1), gr = grid3(c->n[0], c->n[1], c->n[2], b);
-  if (sij) hipLaunchKernelGGL(k_strain<1>, gr, b, 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, u, v, w, s0, sij[0], sij[1], sij[2], sij[3], sij[4], sij[5], (double *)nullptr);
+  if (sij) hipLaunchKernelGGL(k_strain<1>, gr, b, 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, u, v, w, s0, sij[0], sij[1], sij[2], sij[3], sij[4], sij[5], (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr);
   else hipLaunchKernelGGL(k_strain<0>, gr, b, 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, u, v, w, s0, (double *)nullptr,
-                          (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr);
+                          (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -267,7 +270,7 @@ struct MarchArgs {
 //  MODE 0: the 3 fields themselves; MODE 1: s0*sij (6 quantities); MODE 2: uc,vc,wc and their six products (9 quantities)
 template <int MODE> struct NQT_ { static constexpr int v = MODE == 0 ? 3 : (MODE == 1 ? 6 : 9); };
 template <int MODE> struct NST_ { static constexpr int v = MODE == 1 ? 6 : 3; };     // values kept per plane and thread
-template <int MODE> struct TY_ { static constexpr int v = MODE == 2 ? 6 : 8; };
+template <int MODE> struct TY_ { static constexpr int v = 14; };
 
 template <int MODE>
 __device__ inline void cell_load(const MarchArgs &A, size_t idx, bool ok, double *s) {
@@ -300,8 +303,9 @@ __global__ __launch_bounds__(64 * (TY_<MODE>::v + 2)) void k_filter_tile(Geom g,
   __shared__ double sh[2][NQ][TY + 2][64];
   __shared__ double shr[2][TY + 2];
   const int tx = threadIdx.x, ty = threadIdx.y;
-  const int i = blockIdx.x * 62 + tx, j = blockIdx.y * TY + ty;            // tx = 0 / 63 and ty = 0 / TY+1 are halo threads
-  const int kbeg = blockIdx.z * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
+  const int bx_ = blockIdx.x, by_ = blockIdx.y, bz_ = blockIdx.z;   // (an XCD-contiguous tile order was measured 1.4x slower)
+  const int i = bx_ * 62 + tx, j = by_ * TY + ty;            // tx = 0 / 63 and ty = 0 / TY+1 are halo threads
+  const int kbeg = bz_ * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
   const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1;
   const bool outok = tx >= 1 && tx <= 62 && ty >= 1 && ty <= TY && i <= g.n1 && j <= g.n2;
   const bool inner = ty >= 1 && ty <= TY;
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(64 * (TY_<MODE>::v + 2)) void k_filter_tile(Geom g,
       if (tx == 0 && ty == 0) {
         double a = 0., b = 0.;
         for (int q = 1; q <= TY; ++q) { a += shr[0][q]; b += shr[1][q]; }
-        const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+        const int blk = by_ * gridDim.x + bx_;
         A.part[(size_t)(k - 1) * A.nblk + blk] = a; A.part[(size_t)(g.n3 + k - 1) * A.nblk + blk] = b;
       }
       // the next plane's barrier orders these reads of shr before it is rewritten
@@ -422,7 +426,7 @@ static int dsmag_fast(cales_ctx *c) {
   // K_A: strain rate straight from u,v,w (no wall-model faces -> extrapolate(...,lwm) is a no-op), s0 -> visct as well
   { ProfScope ps(c, "strain_rate");
     hipLaunchKernelGGL(k_strain<2>, gr, b, 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, f[CALES_U], f[CALES_V], f[CALES_W], c->s0,
-                       sij[0], sij[1], sij[2], sij[3], sij[4], sij[5], visct); }
+                       sij[0], sij[1], sij[2], sij[3], sij[4], sij[5], visct, c->uc, c->vc, c->wc); }
   if (int e = op_boundp(c, c->s0, 1)) return e;
   for (int m = 0; m < 6; ++m) if (int e = op_boundp(c, sij[m], 1)) return e;
   // tiles of 62 x TY columns marching in k; k is also split into chunks so that several rounds of blocks balance the chip
@@ -433,7 +437,7 @@ static int dsmag_fast(cales_ctx *c) {
     mg.z = (n[2] + kchunk - 1) / kchunk;
   };
   dim3 mb, mg, mb2, mg2; int kchunk, kchunk2;
-  tiles(8, mb, mg, kchunk); tiles(6, mb2, mg2, kchunk2);
+  tiles(TY_<0>::v, mb, mg, kchunk); tiles(TY_<2>::v, mb2, mg2, kchunk2);
   MarchArgs A; A.kchunk = kchunk; A.nblk = mg.x * mg.y; A.part = nullptr;
   // K_B: mij = filter(|S| Sij)
   { ProfScope ps(c, "filter_s0sij");
@@ -450,9 +454,8 @@ static int dsmag_fast(cales_ctx *c) {
   { ProfScope ps(c, "strain_mij");
     P6 pm; for (int m = 0; m < 6; ++m) pm.p[m] = mij[m];
     hipLaunchKernelGGL(k_strain_mij, gr, b, 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, c->uf, c->vf, c->wf, pm, zlo, zhi); }
-  // K_E: cell-centred velocity, its sgs-type ghost cells (periodic exchange; wall ghosts are replaced by the extrapolation rule)
-  { ProfScope ps(c, "interp_uvw");
-    hipLaunchKernelGGL(k_interp, gr, b, 0, c->stream, c->g, f[CALES_U], f[CALES_V], f[CALES_W], c->uc, c->vc, c->wc); }
+  // K_E: cell-centred velocity: written by K_A from the same loads; here only its sgs-type ghost cells
+  // (periodic exchange; wall ghosts are replaced by the extrapolation rule)
   if (int e = op_boundp(c, c->uc, 1)) return e;
   if (int e = op_boundp(c, c->vc, 1)) return e;
   if (int e = op_boundp(c, c->wc, 1)) return e;
