@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcales_hip.so")
+LIB_PATH = os.environ.get("CALES_LIB", os.path.join(_HERE, "libcales_hip.so"))   # CALES_LIB: tuning builds only
 
 SGS = {"none": 0, "smag": 1, "dsmag": 2}
 FIELDS = dict(u=0, v=1, w=2, p=3, pp=4, visct=5, dudt=6, dvdt=7, dwdt=8, dudto=9, dvdto=10, dwdto=11,

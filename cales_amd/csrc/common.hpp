@@ -19,6 +19,7 @@ struct Geom {              // passed by value to kernels
   long s12;                // (n1+2)*(n2+2)
   int jlo;                 // global index offset of local row j=1 is jlo+1 (y-slab)
   int ng2;                 // global n2
+
   __host__ __device__ inline size_t ix(int i, int j, int k) const { return (size_t)i + (size_t)s1 * (size_t)j + (size_t)s12 * (size_t)k; }
 };
 
@@ -165,6 +166,24 @@ void solver_teardown(cales_ctx *c);
 // planes and j+-1 rows a block needs were fetched moments earlier by blocks of the SAME XCD and are L2 hits instead
 // of HBM re-reads. Only the order changes (a bijection on block ids); results are identical.
 #ifdef __HIPCC__
+
+// ---- cross-lane moves on the vector ALU (DPP) instead of ds_bpermute: no LDS-pipe traffic, short latency ----
+template <int CTRL, int ROWMASK = 0xf>
+__device__ inline double dpp_f64(double v) {       // lanes without a source (or masked rows) receive 0
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline double lane_prev(double v) { return dpp_f64<0x138>(v); }   // wave_shr:1, lane i <- lane i-1 (lane 0 <- 0)
+__device__ inline double lane_next(double v) { return dpp_f64<0x130>(v); }   // wave_shl:1, lane i <- lane i+1 (lane 63 <- 0)
+// sum over the 64 lanes, valid in lane 63 only (row_shr 1,2,4,8 then row_bcast 15 and 31)
+__device__ inline double wave_sum_lane63(double s) {
+  s += dpp_f64<0x111>(s); s += dpp_f64<0x112>(s); s += dpp_f64<0x114>(s); s += dpp_f64<0x118>(s);
+  s += dpp_f64<0x142, 0xa>(s); s += dpp_f64<0x143, 0xc>(s);
+  return s;
+}
+
 __device__ inline void stencil_block(int &bx, int &by, int &bz) {
   const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z, SUB = 8;
   if (gy % SUB != 0 || (gx * (gy / SUB)) % 8 != 0) { bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z; return; }

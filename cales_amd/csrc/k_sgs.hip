@@ -54,8 +54,7 @@ __global__ __launch_bounds__(BX *BY) void k_strain(Geom g, double dxi, double dy
                                                     const double *__restrict__ dzfi, const double *__restrict__ u,
                                                     const double *__restrict__ v, const double *__restrict__ w, double *__restrict__ s0,
                                                     double *__restrict__ s11o, double *__restrict__ s22o, double *__restrict__ s33o,
-                                                    double *__restrict__ s12o, double *__restrict__ s13o, double *__restrict__ s23o,
-                                                    double *__restrict__ s0copy, double *__restrict__ uc, double *__restrict__ vc, double *__restrict__ wc) {
+                                                    double *__restrict__ s12o, double *__restrict__ s13o, double *__restrict__ s23o) {
   int bx_, by_, bz_; stencil_block(bx_, by_, bz_);
   const int i = bx_ * BX + threadIdx.x + 1, j = by_ * BY + threadIdx.y + 1, k = bz_ + 1;
   if (i > g.n1 || j > g.n2) return;
@@ -80,17 +79,13 @@ __global__ __launch_bounds__(BX *BY) void k_strain(Geom g, double dxi, double dy
   const double s0v = sqrt(2. * (s11 * s11 + s22 * s22 + s33 * s33 + 2. * (s12 * s12 + s13 * s13 + s23 * s23)));
   s0[c] = s0v;
   if (WITH_SIJ) { s11o[c] = s11; s22o[c] = s22; s33o[c] = s33; s12o[c] = s12; s13o[c] = s13; s23o[c] = s23; }
-  if (WITH_SIJ == 2) {
-    s0copy[c] = s0v;                           // visct = s0 (sgs.f90:184) without a separate copy pass
-    uc[c] = 0.5 * (u_ccc + u_mcc); vc[c] = 0.5 * (v_ccc + v_cmc); wc[c] = 0.5 * (w_ccc + w_ccm);   // interpolate (sgs.f90:860-869), same loads
-  }
 }
 static int strain_rate(cales_ctx *c, const double *u, const double *v, const double *w, double *s0, double **sij) {
   ProfScope ps(c, "strain_rate");
   dim3 b(BX, BY, 1), gr = grid3(c->n[0], c->n[1], c->n[2], b);
-  if (sij) hipLaunchKernelGGL(k_strain<1>, gr, b, 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, u, v, w, s0, sij[0], sij[1], sij[2], sij[3], sij[4], sij[5], (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr);
+  if (sij) hipLaunchKernelGGL(k_strain<1>, gr, b, 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, u, v, w, s0, sij[0], sij[1], sij[2], sij[3], sij[4], sij[5]);
   else hipLaunchKernelGGL(k_strain<0>, gr, b, 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, u, v, w, s0, (double *)nullptr,
-                          (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr);
+                          (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -223,12 +218,12 @@ __global__ __launch_bounds__(256) void k_plane_sum(Geom g, const double *__restr
   if (threadIdx.x == 0) p1d[blockIdx.y * g.n3 + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 // visct = max(visct*<LM>/<MM>,0) (sgs.f90:372-380); the plane averages replace the broadcast arrays
-__global__ __launch_bounds__(BX *BY) void k_dsmag_final(Geom g, double gar, const double *__restrict__ p1d, double *__restrict__ visct) {
+__global__ __launch_bounds__(BX *BY) void k_dsmag_final(Geom g, double gar, const double *__restrict__ p1d, const double *s0, double *visct) {
   const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;
   if (i > g.n1 || j > g.n2) return;
   const size_t c = g.ix(i, j, k);
   const double lm = p1d[k - 1] * gar, mm = p1d[g.n3 + k - 1] * gar;
-  double vt = visct[c] * lm / mm;
+  double vt = s0[c] * lm / mm;
   visct[c] = fmax(vt, 0.);
 }
 __global__ __launch_bounds__(256) void k_alph2(Geom g, double w0, double w1, double w2, double w3, double w4, double w5, double *__restrict__ alph2) {
@@ -242,128 +237,263 @@ __global__ __launch_bounds__(256) void k_alph2(Geom g, double w0, double w1, dou
 
 // ================================================================================================
 // Fast path of the dynamic model for cases whose only walls are in z (channels) and without wall model.
-// Same arithmetic as the reference sequence (sgs.f90:153-380) re-associated for the hardware:
-//  * the 27-point top-hat (sgs.f90:632-679) is separable, (1,2,1)^3/64: each thread owns an (i,j) column and
-//    marches in k with three planes of 2-D filtered values in registers; per plane it loads 3 rows per field
-//    (coalesced along x) and gets its x neighbours by wave shuffles -> 3 loads/cell instead of 27;
-//  * products (|S|Sij, ui uj) are formed on the fly, the wall extrapolation of the filtered fields
-//    (extrapolate(...,cbc), sgs.f90:705-710,751-766, factor 1) becomes f2(0) = 2 f2(1) - f2(2) on the 2-D filtered planes
-//    (the 2-D filter and the extrapolation are both linear and commute);
-//  * strain rate of the filtered velocity and the Mij update are one kernel; the Lij/contraction/plane sums are
-//    one kernel whose only output are per-block partial sums (LM and MM are never stored).
-// Traffic: ~62 words/cell instead of ~166 measured for the kernel-per-loop sequence (profiles/r01a_*).
+// Same arithmetic as the reference sequence (sgs.f90:153-380) re-associated for the hardware, three passes:
+//  K_AC  u,v,w -> |S|, |S|Sij, cell-centred velocity, test-filtered velocity        (k_strain_tile)
+//  K_B   |S|Sij -> filter(|S|Sij)                                                  (k_filter6_tile)
+//  K_DF  filtered velocity, cell-centred velocity, filter(|S|Sij) -> plane sums of Mij Lij and Mij Mij (k_lij_mij_tile)
+//  then <LM>/<MM> per plane and visct = max(|S| <LM>/<MM>, 0).
+//  * the 27-point top-hat (sgs.f90:632-679) is separable, (1,2,1)^3/64, combined z first, then x, then y;
+//  * the wall extrapolation of filtered fields (extrapolate(...,cbc), sgs.f90:705-710,751-766, factor 1) is the rule
+//    Q(0) = 2 Q(1) - Q(2) applied to the z combination (filter and extrapolation are linear and commute);
+//  * sij, Mij, Lij, LM, MM and the products ui uj are never stored.
+// Traffic: ~45 words/cell instead of ~166 measured for the kernel-per-loop sequence (profiles/r01a_*).
 // ================================================================================================
-#define MBY 4
-struct MarchArgs {
-  const double *in[7];
-  double *out[6];
-  const double *mij[6];
-  double *part;
-  int kchunk, nblk;
-  unsigned zlo_mask, zhi_mask;    // bit q: quantity q is linearly extrapolated through the lower / upper z wall
-};
 // Tile = 62 x TY outputs handled by 64 x (TY+2) threads that march in k. Every thread loads exactly its own cell of each
-// input (full-width coalesced rows, no divergent loads, one load phase per plane, next plane prefetched), keeps three
-// planes of its own cell in registers, combines them in z first, gets the x neighbours by wave shuffles and the y
-// neighbours through double-buffered LDS. With the wall rule Q(0) = 2Q(1)-Q(2) the z combination at the first plane is
-// simply 4 Q(1), so ghost planes of extrapolated quantities are never read.
-//  MODE 0: the 3 fields themselves; MODE 1: s0*sij (6 quantities); MODE 2: uc,vc,wc and their six products (9 quantities)
-template <int MODE> struct NQT_ { static constexpr int v = MODE == 0 ? 3 : (MODE == 1 ? 6 : 9); };
-template <int MODE> struct NST_ { static constexpr int v = MODE == 1 ? 6 : 3; };     // values kept per plane and thread
-template <int MODE> struct TY_ { static constexpr int v = 14; };
-
-template <int MODE>
-__device__ inline void cell_load(const MarchArgs &A, size_t idx, bool ok, double *s) {
-  constexpr int NS = NST_<MODE>::v;
-  if (!ok) {
-#pragma unroll
-    for (int q = 0; q < NS; ++q) s[q] = 0.;
-    return;
-  }
-  if (MODE == 1) {
-    const double s0 = A.in[0][idx];
-#pragma unroll
-    for (int m = 0; m < 6; ++m) s[m] = s0 * A.in[1 + m][idx];
-  } else { s[0] = A.in[0][idx]; s[1] = A.in[1][idx]; s[2] = A.in[2][idx]; }
-}
-// quantity values of one stored plane
-template <int MODE>
-__device__ inline void quantities(const double *s, double *q) {
-  if (MODE == 2) { q[0] = s[0]; q[1] = s[1]; q[2] = s[2]; q[3] = s[0] * s[0]; q[4] = s[1] * s[1]; q[5] = s[2] * s[2];
-                   q[6] = s[0] * s[1]; q[7] = s[0] * s[2]; q[8] = s[1] * s[2]; }
-  else {
-#pragma unroll
-    for (int m = 0; m < NST_<MODE>::v; ++m) q[m] = s[m];
-  }
-}
-
-template <int MODE>
-__global__ __launch_bounds__(64 * (TY_<MODE>::v + 2)) void k_filter_tile(Geom g, MarchArgs A) {
-  constexpr int NQ = NQT_<MODE>::v, NS = NST_<MODE>::v, TY = TY_<MODE>::v;
-  __shared__ double sh[2][NQ][TY + 2][64];
-  __shared__ double shr[2][TY + 2];
+// input (full-width coalesced rows, no divergent loads, one load phase per plane, next plane prefetched); x neighbours come
+// from wave shuffles, y neighbours through LDS. With the wall rule Q(0) = 2Q(1)-Q(2) ghost planes of extrapolated
+// quantities are never read.
+#ifndef TYB
+#define TYB 14
+#endif
+struct Filter6Args { const double *in[6]; double *out[6]; int kchunk, zlo, zhi; };
+// K_B: top-hat filter of six fields (the products |S|Sij), three planes of the own cell in registers, z combination first
+__global__ __launch_bounds__(64 * (TYB + 2)) void k_filter6_tile(Geom g, Filter6Args A) {
+  __shared__ double sh[2][6][TYB + 2][64];
   const int tx = threadIdx.x, ty = threadIdx.y;
-  const int bx_ = blockIdx.x, by_ = blockIdx.y, bz_ = blockIdx.z;   // (an XCD-contiguous tile order was measured 1.4x slower)
-  const int i = bx_ * 62 + tx, j = by_ * TY + ty;            // tx = 0 / 63 and ty = 0 / TY+1 are halo threads
-  const int kbeg = bz_ * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
+  const int i = blockIdx.x * 62 + tx, j = blockIdx.y * TYB + ty;            // tx = 0 / 63 and ty = 0 / TY+1 are halo threads
+  const int kbeg = blockIdx.z * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
   const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1;
-  const bool outok = tx >= 1 && tx <= 62 && ty >= 1 && ty <= TY && i <= g.n1 && j <= g.n2;
-  const bool inner = ty >= 1 && ty <= TY;
-  double sm[NS], sc[NS], sp[NS], sn[NS];
+  const bool outok = tx >= 1 && tx <= 62 && ty >= 1 && ty <= TYB && i <= g.n1 && j <= g.n2;
+  double sm[6], sc[6], sp[6], sn[6];
   const size_t c0 = g.ix(i, j, 0);
-  cell_load<MODE>(A, c0 + (size_t)(kbeg - 1) * g.s12, ldok, sm);
-  cell_load<MODE>(A, c0 + (size_t)kbeg * g.s12, ldok, sc);
-  cell_load<MODE>(A, c0 + (size_t)(kbeg + 1) * g.s12, ldok, sp);
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    sm[q] = ldok ? A.in[q][c0 + (size_t)(kbeg - 1) * g.s12] : 0.;
+    sc[q] = ldok ? A.in[q][c0 + (size_t)kbeg * g.s12] : 0.;
+    sp[q] = ldok ? A.in[q][c0 + (size_t)(kbeg + 1) * g.s12] : 0.;
+  }
   int buf = 0;
   for (int k = kbeg; k <= kend; ++k) {
-    if (k + 2 <= g.n3 + 1) cell_load<MODE>(A, c0 + (size_t)(k + 2) * g.s12, ldok, sn);     // prefetch
-    double qm[NQ], qc[NQ], qp[NQ], r[NQ];
-    quantities<MODE>(sm, qm); quantities<MODE>(sc, qc); quantities<MODE>(sp, qp);
-    const bool lo = k == 1, hi = k == g.n3;
+    const size_t idx = c0 + (size_t)k * g.s12;
+    if (k + 2 <= g.n3 + 1) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      // ghost planes by the wall rule: Q(0) = 2Q(1)-Q(2), Q(n+1) = 2Q(n)-Q(n-1)
-      const double vm = (lo && (A.zlo_mask >> q & 1u)) ? 2. * qc[q] - qp[q] : qm[q];
-      const double vp = (hi && (A.zhi_mask >> q & 1u)) ? 2. * qc[q] - qm[q] : qp[q];
-      const double G = vm + 2. * qc[q] + vp;
-      r[q] = __shfl_up(G, 1, 64) + 2. * G + __shfl_down(G, 1, 64);
+      for (int q = 0; q < 6; ++q) sn[q] = ldok ? A.in[q][idx + 2 * g.s12] : 0.;     // prefetch
+    }
+    const bool lo = A.zlo && k == 1, hi = A.zhi && k == g.n3;
+    double r[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const double vm = lo ? 2. * sc[q] - sp[q] : sm[q];
+      const double vp = hi ? 2. * sc[q] - sm[q] : sp[q];
+      const double G = vm + 2. * sc[q] + vp;
+      r[q] = lane_prev(G) + 2. * G + lane_next(G);
       sh[buf][q][ty][tx] = r[q];
     }
     __syncthreads();
-    const size_t idx = c0 + (size_t)k * g.s12;
-    double F[NQ];
-    if (inner) {
+    if (outok) {
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) F[q] = (sh[buf][q][ty - 1][tx] + 2. * r[q] + sh[buf][q][ty + 1][tx]) / 64.;
-    }
-    if (MODE != 2) {
-      if (outok) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) A.out[q][idx] = F[q];
-      }
-    } else {
-      double lm = 0., mm = 0.;
-      if (outok) {
-        const double l0 = F[3] - F[0] * F[0], l1 = F[4] - F[1] * F[1], l2 = F[5] - F[2] * F[2], l3 = F[6] - F[0] * F[1],
-                     l4 = F[7] - F[0] * F[2], l5 = F[8] - F[1] * F[2];
-        const double m0 = A.mij[0][idx], m1 = A.mij[1][idx], m2 = A.mij[2][idx], m3 = A.mij[3][idx], m4 = A.mij[4][idx], m5 = A.mij[5][idx];
-        lm = m0 * l0 + m1 * l1 + m2 * l2 + (m3 * l3 + m4 * l4 + m5 * l5) * 2.;       // sgs.f90:344-349
-        mm = m0 * m0 + m1 * m1 + m2 * m2 + (m3 * m3 + m4 * m4 + m5 * m5) * 2.;       // sgs.f90:350-355
-      }
-      for (int o = 32; o > 0; o >>= 1) { lm += __shfl_down(lm, o, 64); mm += __shfl_down(mm, o, 64); }
-      if (tx == 0) { shr[0][ty] = lm; shr[1][ty] = mm; }
-      __syncthreads();
-      if (tx == 0 && ty == 0) {
-        double a = 0., b = 0.;
-        for (int q = 1; q <= TY; ++q) { a += shr[0][q]; b += shr[1][q]; }
-        const int blk = by_ * gridDim.x + bx_;
-        A.part[(size_t)(k - 1) * A.nblk + blk] = a; A.part[(size_t)(g.n3 + k - 1) * A.nblk + blk] = b;
-      }
-      // the next plane's barrier orders these reads of shr before it is rewritten
+      for (int q = 0; q < 6; ++q) A.out[q][idx] = (sh[buf][q][ty - 1][tx] + 2. * r[q] + sh[buf][q][ty + 1][tx]) / 64.;
     }
 #pragma unroll
-    for (int q = 0; q < NS; ++q) { sm[q] = sc[q]; sc[q] = sp[q]; sp[q] = sn[q]; }
+    for (int q = 0; q < 6; ++q) { sm[q] = sc[q]; sc[q] = sp[q]; sp[q] = sn[q]; }
     buf ^= 1;
+  }
+}
+__device__ inline void uiuj(const double *s, double *q) {
+  q[0] = s[0]; q[1] = s[1]; q[2] = s[2]; q[3] = s[0] * s[0]; q[4] = s[1] * s[1]; q[5] = s[2] * s[2];
+  q[6] = s[0] * s[1]; q[7] = s[0] * s[2]; q[8] = s[1] * s[2];
+}
+// K_D + K_F in one pass: Lij from the on-the-fly filters of uc,vc,wc and their products (z-first separable top-hat), the strain
+// rate of the test-filtered velocity from an LDS ring of three raw planes of uf,vf,wf, Mij = 2 (filter(|S|Sij) - alph2 |Sf| Sfij)
+// (sgs.f90:261-272), the contractions (sgs.f90:344-355) and the per-plane partial sums. Mij is never stored.
+#ifndef TYF
+#define TYF 14
+#endif
+struct LijMijArgs {
+  const double *uc[3], *uf[3], *mf[6];
+  double *part;
+  const double *dzci, *dzfi;
+  double dxi, dyi;
+  int kchunk, nblk, zlo, zhi;
+};
+__global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijArgs A) {
+  __shared__ double sh[9][TYF + 2][64];
+  __shared__ double ring[3][3][TYF + 2][64];
+  __shared__ double shr[2][TYF + 2];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int i = blockIdx.x * 62 + tx, j = blockIdx.y * TYF + ty;
+  const int kbeg = blockIdx.z * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
+  const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1;
+  const bool outok = tx >= 1 && tx <= 62 && ty >= 1 && ty <= TYF && i <= g.n1 && j <= g.n2;
+  const bool inner = ty >= 1 && ty <= TYF;
+  const size_t c0 = g.ix(i, j, 0);
+  double sm[3], sc[3], sp[3], sn[3], fn[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    sm[q] = ldok ? A.uc[q][c0 + (size_t)(kbeg - 1) * g.s12] : 0.;
+    sc[q] = ldok ? A.uc[q][c0 + (size_t)kbeg * g.s12] : 0.;
+    sp[q] = ldok ? A.uc[q][c0 + (size_t)(kbeg + 1) * g.s12] : 0.;
+    ring[(kbeg - 1) % 3][q][ty][tx] = ldok ? A.uf[q][c0 + (size_t)(kbeg - 1) * g.s12] : 0.;
+    ring[kbeg % 3][q][ty][tx] = ldok ? A.uf[q][c0 + (size_t)kbeg * g.s12] : 0.;
+    fn[q] = ldok ? A.uf[q][c0 + (size_t)(kbeg + 1) * g.s12] : 0.;
+  }
+  int km = (kbeg - 1) % 3, kc = kbeg % 3, kp = (kbeg + 1) % 3;
+  for (int k = kbeg; k <= kend; ++k) {
+    const size_t idx = c0 + (size_t)k * g.s12;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) ring[kp][q][ty][tx] = fn[q];
+    if (k + 2 <= g.n3 + 1) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { sn[q] = ldok ? A.uc[q][idx + 2 * g.s12] : 0.; fn[q] = ldok ? A.uf[q][idx + 2 * g.s12] : 0.; }
+    }
+    double mf[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) mf[q] = outok ? A.mf[q][idx] : 0.;
+    double qm[9], qc[9], qp[9], r[9];
+    uiuj(sm, qm); uiuj(sc, qc); uiuj(sp, qp);
+    const bool lo = A.zlo && k == 1, hi = A.zhi && k == g.n3;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const double vm = lo ? 2. * qc[q] - qp[q] : qm[q];
+      const double vp = hi ? 2. * qc[q] - qm[q] : qp[q];
+      const double G = vm + 2. * qc[q] + vp;
+      r[q] = lane_prev(G) + 2. * G + lane_next(G);
+      sh[q][ty][tx] = r[q];
+    }
+    __syncthreads();
+    double lm = 0., mm = 0.;
+    if (outok) {
+      double F[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) F[q] = (sh[q][ty - 1][tx] + 2. * r[q] + sh[q][ty + 1][tx]) / 64.;
+      const double l0 = F[3] - F[0] * F[0], l1 = F[4] - F[1] * F[1], l2 = F[5] - F[2] * F[2], l3 = F[6] - F[0] * F[1],
+                   l4 = F[7] - F[0] * F[2], l5 = F[8] - F[1] * F[2];
+#define RU(dk, dj, di) ring[dk][0][ty + (dj)][tx + (di)]
+#define RV(dk, dj, di) ring[dk][1][ty + (dj)][tx + (di)]
+#define RW(dk, dj, di) ring[dk][2][ty + (dj)][tx + (di)]
+      const double u_mcm = RU(km, 0, -1), u_ccm = RU(km, 0, 0), u_mmc = RU(kc, -1, -1), u_cmc = RU(kc, -1, 0), u_mcc = RU(kc, 0, -1),
+                   u_ccc = RU(kc, 0, 0), u_mpc = RU(kc, 1, -1), u_cpc = RU(kc, 1, 0), u_mcp = RU(kp, 0, -1), u_ccp = RU(kp, 0, 0);
+      const double v_cmm = RV(km, -1, 0), v_ccm = RV(km, 0, 0), v_mmc = RV(kc, -1, -1), v_cmc = RV(kc, -1, 0), v_pmc = RV(kc, -1, 1),
+                   v_mcc = RV(kc, 0, -1), v_ccc = RV(kc, 0, 0), v_pcc = RV(kc, 0, 1), v_cmp = RV(kp, -1, 0), v_ccp = RV(kp, 0, 0);
+      const double w_cmm = RW(km, -1, 0), w_mcm = RW(km, 0, -1), w_ccm = RW(km, 0, 0), w_pcm = RW(km, 0, 1), w_cpm = RW(km, 1, 0),
+                   w_cmc = RW(kc, -1, 0), w_mcc = RW(kc, 0, -1), w_ccc = RW(kc, 0, 0), w_pcc = RW(kc, 0, 1), w_cpc = RW(kc, 1, 0);
+#undef RU
+#undef RV
+#undef RW
+      const double dxi = A.dxi, dyi = A.dyi, zc = A.dzci[k], zm = A.dzci[k - 1];
+      double sij[6];
+      sij[0] = (u_ccc - u_mcc) * dxi; sij[1] = (v_ccc - v_cmc) * dyi; sij[2] = (w_ccc - w_ccm) * A.dzfi[k];
+      sij[3] = .125 * ((u_cpc - u_ccc) * dyi + (v_pcc - v_ccc) * dxi + (u_ccc - u_cmc) * dyi + (v_pmc - v_cmc) * dxi +
+                       (u_mpc - u_mcc) * dyi + (v_ccc - v_mcc) * dxi + (u_mcc - u_mmc) * dyi + (v_cmc - v_mmc) * dxi);
+      sij[4] = .125 * ((u_ccp - u_ccc) * zc + (w_pcc - w_ccc) * dxi + (u_ccc - u_ccm) * zm + (w_pcm - w_ccm) * dxi +
+                       (u_mcp - u_mcc) * zc + (w_ccc - w_mcc) * dxi + (u_mcc - u_mcm) * zm + (w_ccm - w_mcm) * dxi);
+      sij[5] = .125 * ((v_ccp - v_ccc) * zc + (w_cpc - w_ccc) * dyi + (v_ccc - v_ccm) * zm + (w_cpm - w_ccm) * dyi +
+                       (v_cmp - v_cmc) * zc + (w_ccc - w_cmc) * dyi + (v_cmc - v_cmm) * zm + (w_ccm - w_cmm) * dyi);
+      const double s0 = sqrt(2. * (sij[0] * sij[0] + sij[1] * sij[1] + sij[2] * sij[2] + 2. * (sij[3] * sij[3] + sij[4] * sij[4] + sij[5] * sij[5])));
+      const double a2s0 = (lo || hi ? 2.52 : 4.00) * s0;      // alph2 (sgs.f90:783-816)
+      const double m0 = 2. * (mf[0] - a2s0 * sij[0]), m1 = 2. * (mf[1] - a2s0 * sij[1]), m2 = 2. * (mf[2] - a2s0 * sij[2]),
+                   m3 = 2. * (mf[3] - a2s0 * sij[3]), m4 = 2. * (mf[4] - a2s0 * sij[4]), m5 = 2. * (mf[5] - a2s0 * sij[5]);
+      lm = m0 * l0 + m1 * l1 + m2 * l2 + (m3 * l3 + m4 * l4 + m5 * l5) * 2.;       // sgs.f90:344-349
+      mm = m0 * m0 + m1 * m1 + m2 * m2 + (m3 * m3 + m4 * m4 + m5 * m5) * 2.;       // sgs.f90:350-355
+    }
+    lm = wave_sum_lane63(lm); mm = wave_sum_lane63(mm);
+    if (tx == 63) { shr[0][ty] = lm; shr[1][ty] = mm; }
+    __syncthreads();
+    if (tx == 0 && ty == 0) {
+      double a = 0., b = 0.;
+      for (int q = 1; q <= TYF; ++q) { a += shr[0][q]; b += shr[1][q]; }
+      const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+      A.part[(size_t)(k - 1) * A.nblk + blk] = a; A.part[(size_t)(g.n3 + k - 1) * A.nblk + blk] = b;
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { sm[q] = sc[q]; sc[q] = sp[q]; sp[q] = sn[q]; }
+    const int t = km; km = kc; kc = kp; kp = t;
+    (void)inner;
+  }
+}
+
+// K_A + K_C in one pass over u,v,w: strain rate (sgs.f90:571-630) stored as |S| and |S|Sij, cell-centred velocity (sgs.f90:860-869) and the
+// test-filtered velocity (sgs.f90:632-679 with the wall rule), all from an LDS ring of three raw planes.
+#ifndef TYS
+#define TYS 6
+#endif
+struct StrainTileArgs {
+  const double *u[3];
+  double *s0, *ssij[6], *uc[3], *uf[3];
+  const double *dzci, *dzfi;
+  double dxi, dyi;
+  int kchunk, zlo, zhi;
+};
+__global__ __launch_bounds__(64 * (TYS + 2)) void k_strain_tile(Geom g, StrainTileArgs A) {
+  __shared__ double ring[3][3][TYS + 2][64];
+  __shared__ double shs[3][TYS + 2][64];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int i = blockIdx.x * 62 + tx, j = blockIdx.y * TYS + ty;
+  const int kbeg = blockIdx.z * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
+  const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1;
+  const bool outok = tx >= 1 && tx <= 62 && ty >= 1 && ty <= TYS && i <= g.n1 && j <= g.n2;
+  const size_t c0 = g.ix(i, j, 0);
+  double fn[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    ring[(kbeg - 1) % 3][q][ty][tx] = ldok ? A.u[q][c0 + (size_t)(kbeg - 1) * g.s12] : 0.;
+    ring[kbeg % 3][q][ty][tx] = ldok ? A.u[q][c0 + (size_t)kbeg * g.s12] : 0.;
+    fn[q] = ldok ? A.u[q][c0 + (size_t)(kbeg + 1) * g.s12] : 0.;
+  }
+  int km = (kbeg - 1) % 3, kc = kbeg % 3, kp = (kbeg + 1) % 3;
+  for (int k = kbeg; k <= kend; ++k) {
+    const size_t idx = c0 + (size_t)k * g.s12;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) ring[kp][q][ty][tx] = fn[q];
+    if (k + 2 <= g.n3 + 1) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) fn[q] = ldok ? A.u[q][idx + 2 * g.s12] : 0.;
+    }
+    __syncthreads();
+    const bool lo = A.zlo && k == 1, hi = A.zhi && k == g.n3;
+    double r[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const double qm = ring[km][q][ty][tx], qc = ring[kc][q][ty][tx], qp = ring[kp][q][ty][tx];
+      const double vm = (lo && q < 2) ? 2. * qc - qp : qm;      // u,v extrapolated through the walls, w (on the faces) not
+      const double vp = (hi && q < 2) ? 2. * qc - qm : qp;
+      const double G = vm + 2. * qc + vp;
+      r[q] = lane_prev(G) + 2. * G + lane_next(G);
+      shs[q][ty][tx] = r[q];
+    }
+    if (outok) {
+#define RU(dk, dj, di) ring[dk][0][ty + (dj)][tx + (di)]
+#define RV(dk, dj, di) ring[dk][1][ty + (dj)][tx + (di)]
+#define RW(dk, dj, di) ring[dk][2][ty + (dj)][tx + (di)]
+      const double u_mcm = RU(km, 0, -1), u_ccm = RU(km, 0, 0), u_mmc = RU(kc, -1, -1), u_cmc = RU(kc, -1, 0), u_mcc = RU(kc, 0, -1),
+                   u_ccc = RU(kc, 0, 0), u_mpc = RU(kc, 1, -1), u_cpc = RU(kc, 1, 0), u_mcp = RU(kp, 0, -1), u_ccp = RU(kp, 0, 0);
+      const double v_cmm = RV(km, -1, 0), v_ccm = RV(km, 0, 0), v_mmc = RV(kc, -1, -1), v_cmc = RV(kc, -1, 0), v_pmc = RV(kc, -1, 1),
+                   v_mcc = RV(kc, 0, -1), v_ccc = RV(kc, 0, 0), v_pcc = RV(kc, 0, 1), v_cmp = RV(kp, -1, 0), v_ccp = RV(kp, 0, 0);
+      const double w_cmm = RW(km, -1, 0), w_mcm = RW(km, 0, -1), w_ccm = RW(km, 0, 0), w_pcm = RW(km, 0, 1), w_cpm = RW(km, 1, 0),
+                   w_cmc = RW(kc, -1, 0), w_mcc = RW(kc, 0, -1), w_ccc = RW(kc, 0, 0), w_pcc = RW(kc, 0, 1), w_cpc = RW(kc, 1, 0);
+#undef RU
+#undef RV
+#undef RW
+      const double dxi = A.dxi, dyi = A.dyi, zc = A.dzci[k], zm = A.dzci[k - 1];
+      const double s11 = (u_ccc - u_mcc) * dxi, s22 = (v_ccc - v_cmc) * dyi, s33 = (w_ccc - w_ccm) * A.dzfi[k];
+      const double s12 = .125 * ((u_cpc - u_ccc) * dyi + (v_pcc - v_ccc) * dxi + (u_ccc - u_cmc) * dyi + (v_pmc - v_cmc) * dxi +
+                                 (u_mpc - u_mcc) * dyi + (v_ccc - v_mcc) * dxi + (u_mcc - u_mmc) * dyi + (v_cmc - v_mmc) * dxi);
+      const double s13 = .125 * ((u_ccp - u_ccc) * zc + (w_pcc - w_ccc) * dxi + (u_ccc - u_ccm) * zm + (w_pcm - w_ccm) * dxi +
+                                 (u_mcp - u_mcc) * zc + (w_ccc - w_mcc) * dxi + (u_mcc - u_mcm) * zm + (w_ccm - w_mcm) * dxi);
+      const double s23 = .125 * ((v_ccp - v_ccc) * zc + (w_cpc - w_ccc) * dyi + (v_ccc - v_ccm) * zm + (w_cpm - w_ccm) * dyi +
+                                 (v_cmp - v_cmc) * zc + (w_ccc - w_cmc) * dyi + (v_cmc - v_cmm) * zm + (w_ccm - w_cmm) * dyi);
+      const double s0v = sqrt(2. * (s11 * s11 + s22 * s22 + s33 * s33 + 2. * (s12 * s12 + s13 * s13 + s23 * s23)));
+      A.s0[idx] = s0v;                                              // stands for visct = s0 (sgs.f90:184) until the final kernel
+      A.ssij[0][idx] = s0v * s11; A.ssij[1][idx] = s0v * s22; A.ssij[2][idx] = s0v * s33;      // |S|Sij (sgs.f90:198-210)
+      A.ssij[3][idx] = s0v * s12; A.ssij[4][idx] = s0v * s13; A.ssij[5][idx] = s0v * s23;
+      A.uc[0][idx] = 0.5 * (u_ccc + u_mcc); A.uc[1][idx] = 0.5 * (v_ccc + v_cmc); A.uc[2][idx] = 0.5 * (w_ccc + w_ccm);
+    }
+    __syncthreads();
+    if (outok) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) A.uf[q][idx] = (shs[q][ty - 1][tx] + 2. * r[q] + shs[q][ty + 1][tx]) / 64.;
+    }
+    const int t = km; km = kc; kc = kp; kp = t;
   }
 }
 // p1d[which*n3 + k-1] = sum over the blocks' partials, fixed order (ave1d_channel, sgs.f90:462-472)
@@ -379,38 +509,6 @@ __global__ __launch_bounds__(256) void k_plane_fold(int n3, int nblk, const doub
   (void)n3;
 }
 
-// strain rate of the test-filtered velocity fused with the Mij update (sgs.f90:261-272); alph2 from the indices (sgs.f90:783-816)
-__global__ __launch_bounds__(BX *BY) void k_strain_mij(Geom g, double dxi, double dyi, const double *__restrict__ dzci,
-                                                        const double *__restrict__ dzfi, const double *__restrict__ u,
-                                                        const double *__restrict__ v, const double *__restrict__ w, P6 mij, int zlo_wall, int zhi_wall) {
-  int bx_, by_, bz_; stencil_block(bx_, by_, bz_);
-  const int i = bx_ * BX + threadIdx.x + 1, j = by_ * BY + threadIdx.y + 1, k = bz_ + 1;
-  if (i > g.n1 || j > g.n2) return;
-  const size_t c = g.ix(i, j, k);
-  const long sj = g.s1, sk = g.s12;
-#define LD(a, di, dj, dk) a[c + (di) + (dj)*sj + (dk)*sk]
-  const double u_mcm = LD(u, -1, 0, -1), u_ccm = LD(u, 0, 0, -1), u_mmc = LD(u, -1, -1, 0), u_cmc = LD(u, 0, -1, 0), u_mcc = LD(u, -1, 0, 0),
-               u_ccc = LD(u, 0, 0, 0), u_mpc = LD(u, -1, 1, 0), u_cpc = LD(u, 0, 1, 0), u_mcp = LD(u, -1, 0, 1), u_ccp = LD(u, 0, 0, 1);
-  const double v_cmm = LD(v, 0, -1, -1), v_ccm = LD(v, 0, 0, -1), v_mmc = LD(v, -1, -1, 0), v_cmc = LD(v, 0, -1, 0), v_pmc = LD(v, 1, -1, 0),
-               v_mcc = LD(v, -1, 0, 0), v_ccc = LD(v, 0, 0, 0), v_pcc = LD(v, 1, 0, 0), v_cmp = LD(v, 0, -1, 1), v_ccp = LD(v, 0, 0, 1);
-  const double w_cmm = LD(w, 0, -1, -1), w_mcm = LD(w, -1, 0, -1), w_ccm = LD(w, 0, 0, -1), w_pcm = LD(w, 1, 0, -1), w_cpm = LD(w, 0, 1, -1),
-               w_cmc = LD(w, 0, -1, 0), w_mcc = LD(w, -1, 0, 0), w_ccc = LD(w, 0, 0, 0), w_pcc = LD(w, 1, 0, 0), w_cpc = LD(w, 0, 1, 0);
-#undef LD
-  const double zc = dzci[k], zm = dzci[k - 1];
-  double sij[6];
-  sij[0] = (u_ccc - u_mcc) * dxi; sij[1] = (v_ccc - v_cmc) * dyi; sij[2] = (w_ccc - w_ccm) * dzfi[k];
-  sij[3] = .125 * ((u_cpc - u_ccc) * dyi + (v_pcc - v_ccc) * dxi + (u_ccc - u_cmc) * dyi + (v_pmc - v_cmc) * dxi +
-                   (u_mpc - u_mcc) * dyi + (v_ccc - v_mcc) * dxi + (u_mcc - u_mmc) * dyi + (v_cmc - v_mmc) * dxi);
-  sij[4] = .125 * ((u_ccp - u_ccc) * zc + (w_pcc - w_ccc) * dxi + (u_ccc - u_ccm) * zm + (w_pcm - w_ccm) * dxi +
-                   (u_mcp - u_mcc) * zc + (w_ccc - w_mcc) * dxi + (u_mcc - u_mcm) * zm + (w_ccm - w_mcm) * dxi);
-  sij[5] = .125 * ((v_ccp - v_ccc) * zc + (w_cpc - w_ccc) * dyi + (v_ccc - v_ccm) * zm + (w_cpm - w_ccm) * dyi +
-                   (v_cmp - v_cmc) * zc + (w_ccc - w_cmc) * dyi + (v_cmc - v_cmm) * zm + (w_ccm - w_cmm) * dyi);
-  const double s0 = sqrt(2. * (sij[0] * sij[0] + sij[1] * sij[1] + sij[2] * sij[2] + 2. * (sij[3] * sij[3] + sij[4] * sij[4] + sij[5] * sij[5])));
-  const double alph2 = ((zlo_wall && k == 1) || (zhi_wall && k == g.n3)) ? 2.52 : 4.00;
-#pragma unroll
-  for (int m = 0; m < 6; ++m) mij.p[m][c] = 2. * (mij.p[m][c] - alph2 * s0 * sij[m]);
-}
-
 int allreduce_res(cales_ctx *c, int slot, int count, int op);
 int op_boundp(cales_ctx *c, double *p, int which);
 static bool dsmag_fast_ok(const cales_ctx *c) {
@@ -421,14 +519,8 @@ static bool dsmag_fast_ok(const cales_ctx *c) {
 static int dsmag_fast(cales_ctx *c) {
   const int *n = c->n; double **f = c->f; double *visct = f[CALES_VISCT];
   dim3 b(BX, BY, 1), gr = grid3(n[0], n[1], n[2], b);
-  double **sij = c->sij, **mij = c->mij;
+  double **ssij = c->sij, **mij = c->mij;
   const int zlo = c->is_wall[4] != 0., zhi = c->is_wall[5] != 0.;
-  // K_A: strain rate straight from u,v,w (no wall-model faces -> extrapolate(...,lwm) is a no-op), s0 -> visct as well
-  { ProfScope ps(c, "strain_rate");
-    hipLaunchKernelGGL(k_strain<2>, gr, b, 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, f[CALES_U], f[CALES_V], f[CALES_W], c->s0,
-                       sij[0], sij[1], sij[2], sij[3], sij[4], sij[5], visct, c->uc, c->vc, c->wc); }
-  if (int e = op_boundp(c, c->s0, 1)) return e;
-  for (int m = 0; m < 6; ++m) if (int e = op_boundp(c, sij[m], 1)) return e;
   // tiles of 62 x TY columns marching in k; k is also split into chunks so that several rounds of blocks balance the chip
   auto tiles = [&](int ty, dim3 &mb, dim3 &mg, int &kchunk) {
     mb = dim3(64, ty + 2, 1); mg = dim3((n[0] + 61) / 62, (n[1] + ty - 1) / ty, 1);
@@ -436,41 +528,44 @@ static int dsmag_fast(cales_ctx *c) {
     while ((long)mg.x * mg.y * ((n[2] + kchunk - 1) / kchunk) < 2048 && kchunk > 32) kchunk = (kchunk + 1) / 2;
     mg.z = (n[2] + kchunk - 1) / kchunk;
   };
-  dim3 mb, mg, mb2, mg2; int kchunk, kchunk2;
-  tiles(TY_<0>::v, mb, mg, kchunk); tiles(TY_<2>::v, mb2, mg2, kchunk2);
-  MarchArgs A; A.kchunk = kchunk; A.nblk = mg.x * mg.y; A.part = nullptr;
-  // K_B: mij = filter(|S| Sij)
-  { ProfScope ps(c, "filter_s0sij");
-    A.in[0] = c->s0; for (int m = 0; m < 6; ++m) { A.in[1 + m] = sij[m]; A.out[m] = mij[m]; }
-    A.zlo_mask = zlo ? 0x3fu : 0u; A.zhi_mask = zhi ? 0x3fu : 0u;
-    hipLaunchKernelGGL(k_filter_tile<1>, mg, mb, 0, c->stream, c->g, A); }
-  // K_C: test-filtered velocity; u,v are extrapolated through the z walls, w (stored on the z faces) is not (sgs.f90:705-710)
-  { ProfScope ps(c, "filter_uvw");
-    A.in[0] = f[CALES_U]; A.in[1] = f[CALES_V]; A.in[2] = f[CALES_W]; A.out[0] = c->uf; A.out[1] = c->vf; A.out[2] = c->wf;
-    A.zlo_mask = zlo ? 0x3u : 0u; A.zhi_mask = zhi ? 0x3u : 0u;
-    hipLaunchKernelGGL(k_filter_tile<0>, mg, mb, 0, c->stream, c->g, A); }
+  dim3 mb, mg; int kch;
+  // K_AC: |S|, |S|Sij, cell-centred and test-filtered velocity in one pass over u,v,w (no wall-model faces ->
+  // extrapolate(...,lwm) is a no-op; u,v are extrapolated through the z walls, w on the faces is not, sgs.f90:705-710)
+  { ProfScope ps(c, "strain_filter_uvw");
+    tiles(TYS, mb, mg, kch);
+    StrainTileArgs S;
+    S.u[0] = f[CALES_U]; S.u[1] = f[CALES_V]; S.u[2] = f[CALES_W]; S.s0 = c->s0;
+    for (int m = 0; m < 6; ++m) S.ssij[m] = ssij[m];
+    S.uc[0] = c->uc; S.uc[1] = c->vc; S.uc[2] = c->wc; S.uf[0] = c->uf; S.uf[1] = c->vf; S.uf[2] = c->wf;
+    S.dzci = c->d_dzci; S.dzfi = c->d_dzfi; S.dxi = c->dli[0]; S.dyi = c->dli[1]; S.kchunk = kch; S.zlo = zlo; S.zhi = zhi;
+    hipLaunchKernelGGL(k_strain_tile, mg, mb, 0, c->stream, c->g, S); }
+  // sgs-type ghost cells: only the periodic exchange matters (products of ghosts = ghosts of products; the wall ghosts are
+  // replaced by the extrapolation rule inside the filters)
+  for (int m = 0; m < 6; ++m) if (int e = op_boundp(c, ssij[m], 1)) return e;
   if (int e = op_bounduvw(c, c->bcuf, c->bcvf, c->bcwf, 0, 0, c->uf, c->vf, c->wf)) return e;
-  // K_D: strain rate of the filtered velocity + Mij
-  { ProfScope ps(c, "strain_mij");
-    P6 pm; for (int m = 0; m < 6; ++m) pm.p[m] = mij[m];
-    hipLaunchKernelGGL(k_strain_mij, gr, b, 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, c->uf, c->vf, c->wf, pm, zlo, zhi); }
-  // K_E: cell-centred velocity: written by K_A from the same loads; here only its sgs-type ghost cells
-  // (periodic exchange; wall ghosts are replaced by the extrapolation rule)
   if (int e = op_boundp(c, c->uc, 1)) return e;
   if (int e = op_boundp(c, c->vc, 1)) return e;
   if (int e = op_boundp(c, c->wc, 1)) return e;
-  // K_F: Lij = filter(ui uj) - filter(ui) filter(uj), LM = Mij Lij, MM = Mij Mij, plane partial sums
-  { ProfScope ps(c, "lij_contract");
-    A.in[0] = c->uc; A.in[1] = c->vc; A.in[2] = c->wc; for (int m = 0; m < 6; ++m) A.mij[m] = mij[m];
-    A.part = c->wk[0];
-    if ((size_t)2 * n[2] * mg2.x * mg2.y > c->ntot) { c->err = "dsmag: partial-sum scratch too small"; return 1; }
-    A.zlo_mask = zlo ? 0x1ffu : 0u; A.zhi_mask = zhi ? 0x1ffu : 0u;
-    A.kchunk = kchunk2; A.nblk = mg2.x * mg2.y;
-    hipLaunchKernelGGL(k_filter_tile<2>, mg2, mb2, 0, c->stream, c->g, A);
-    hipLaunchKernelGGL(k_plane_fold, dim3(2 * n[2]), dim3(256), 0, c->stream, n[2], A.nblk, c->wk[0], c->d_p1d); }
+  // K_B: filter(|S| Sij)
+  { ProfScope ps(c, "filter_s0sij");
+    tiles(TYB, mb, mg, kch);
+    Filter6Args A; A.kchunk = kch; A.zlo = zlo; A.zhi = zhi;
+    for (int m = 0; m < 6; ++m) { A.in[m] = ssij[m]; A.out[m] = mij[m]; }
+    hipLaunchKernelGGL(k_filter6_tile, mg, mb, 0, c->stream, c->g, A); }
+  // K_DF: strain rate of the filtered velocity, Mij, Lij, contractions and plane partial sums in one pass
+  { ProfScope ps(c, "lij_mij_contract");
+    tiles(TYF, mb, mg, kch);
+    LijMijArgs L;
+    L.uc[0] = c->uc; L.uc[1] = c->vc; L.uc[2] = c->wc; L.uf[0] = c->uf; L.uf[1] = c->vf; L.uf[2] = c->wf;
+    for (int m = 0; m < 6; ++m) L.mf[m] = mij[m];
+    L.part = c->wk[0]; L.dzci = c->d_dzci; L.dzfi = c->d_dzfi; L.dxi = c->dli[0]; L.dyi = c->dli[1];
+    L.kchunk = kch; L.nblk = mg.x * mg.y; L.zlo = zlo; L.zhi = zhi;
+    if ((size_t)2 * n[2] * L.nblk > c->ntot) { c->err = "dsmag: partial-sum scratch too small"; return 1; }
+    hipLaunchKernelGGL(k_lij_mij_tile, mg, mb, 0, c->stream, c->g, L);
+    hipLaunchKernelGGL(k_plane_fold, dim3(2 * n[2]), dim3(256), 0, c->stream, n[2], L.nblk, c->wk[0], c->d_p1d); }
   if (c->P > 1) { if (int e = allreduce_res(c, (int)(c->d_p1d - c->res), 2 * n[2], 0)) return e; }   // sgs.f90:475
   const double gar = c->dl[0] * c->dl[1] / (c->C.l[0] * c->C.l[1]);
-  hipLaunchKernelGGL(k_dsmag_final, gr, b, 0, c->stream, c->g, gar, c->d_p1d, visct);
+  hipLaunchKernelGGL(k_dsmag_final, gr, b, 0, c->stream, c->g, gar, c->d_p1d, c->s0, visct);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -546,7 +641,7 @@ int op_cmpt_sgs(cales_ctx *c) {
   hipLaunchKernelGGL(k_plane_sum, dim3(n[2], 2), dim3(256), 0, c->stream, c->g, wk[0], wk[1], c->d_p1d);
   if (c->P > 1) { if (int e = allreduce_res(c, (int)(c->d_p1d - c->res), 2 * n[2], 0)) return e; }   // sgs.f90:475
   const double gar = c->dl[0] * c->dl[1] / (c->C.l[0] * c->C.l[1]);
-  hipLaunchKernelGGL(k_dsmag_final, gr, b, 0, c->stream, c->g, gar, c->d_p1d, visct);
+  hipLaunchKernelGGL(k_dsmag_final, gr, b, 0, c->stream, c->g, gar, c->d_p1d, visct, visct);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
