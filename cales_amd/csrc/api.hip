@@ -36,6 +36,21 @@ static int dev_alloc(cales_ctx *c, double **p, size_t n, bool zero = true) {
   if (zero) HIPCHK(c, hipMemset(*p, 0, (n ? n : 1) * sizeof(double)));
   return 0;
 }
+// 3-D fields: pitch-padded rows, shifted so that element (1,j,k) sits on a 128-B boundary (see cales_create)
+static int field_alloc(cales_ctx *c, double **p) {
+  double *base = nullptr;
+  if (dev_alloc(c, &base, c->ntot + 16)) return 1;
+  *p = base + c->field_ofs;
+  return 0;
+}
+static void field_free(cales_ctx *c, double *p) { if (p) hipFree(p - c->field_ofs); }
+// host layout (0:n1+1,0:n2+1,0:n3+1), x contiguous  <->  device layout with row pitch s1
+__global__ __launch_bounds__(256) void k_repack(Geom g, int to_device, double *__restrict__ dev, double *__restrict__ packed) {
+  const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
+  if (i > g.n1 + 1 || j > g.n2 + 1) return;
+  const size_t h = (size_t)i + (size_t)(g.n1 + 2) * ((size_t)j + (size_t)(g.n2 + 2) * k);
+  if (to_device) dev[g.ix(i, j, k)] = packed[h]; else packed[h] = dev[g.ix(i, j, k)];
+}
 static int upload_vec(cales_ctx *c, double **p, const std::vector<double> &v) {
   if (dev_alloc(c, p, v.size(), false)) return 1;
   HIPCHK(c, hipMemcpy(*p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -74,15 +89,15 @@ void cales_destroy(cales_ctx *c) {
   prof_flush(c);
   for (auto &ev : c->evpool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
   solver_teardown(c);
-  for (int q = 0; q < CALES_NFIELDS; ++q) hipFree(c->f[q]);
-  for (int q = 0; q < 3; ++q) hipFree(c->f2[q]);
+  for (int q = 0; q < CALES_NFIELDS; ++q) field_free(c, c->f[q]);
+  for (int q = 0; q < 3; ++q) field_free(c, c->f2[q]);
   hipFree(c->d_dzc); hipFree(c->d_dzf); hipFree(c->d_zc); hipFree(c->d_zf); hipFree(c->d_dzci); hipFree(c->d_dzfi); hipFree(c->d_gvr_c); hipFree(c->d_gvr_f);
   DBound *bs[11] = {&c->bcu, &c->bcv, &c->bcw, &c->bcp, &c->bcs, &c->bcuf, &c->bcvf, &c->bcwf, &c->bcu_mag, &c->bcv_mag, &c->bcw_mag};
   for (auto *b : bs) free_bound(*b);
   for (int d = 0; d < 3; ++d) hipFree(c->rhsbp[d]);
-  hipFree(c->scr1); hipFree(c->scr2); hipFree(c->d_red); hipFree(c->d_force); hipHostFree(c->h_red);
-  hipFree(c->s0); hipFree(c->uc); hipFree(c->vc); hipFree(c->wc); hipFree(c->uf); hipFree(c->vf); hipFree(c->wf); hipFree(c->alph2); if (!c->p1d_in_comm) hipFree(c->d_p1d);
-  for (int m = 0; m < 6; ++m) { hipFree(c->wk[m]); hipFree(c->sij[m]); hipFree(c->mij[m]); }
+  field_free(c, c->scr1); field_free(c, c->scr2); hipFree(c->d_red); hipFree(c->d_force); hipHostFree(c->h_red);
+  field_free(c, c->s0); field_free(c, c->uc); field_free(c, c->vc); field_free(c, c->wc); field_free(c, c->uf); field_free(c, c->vf); field_free(c, c->wf); field_free(c, c->alph2); if (!c->p1d_in_comm) hipFree(c->d_p1d);
+  for (int m = 0; m < 6; ++m) { field_free(c, c->wk[m]); field_free(c, c->sij[m]); field_free(c, c->mij[m]); }
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -118,7 +133,13 @@ int cales_create(const cales_case *cs, void *stream, cales_ctx **out) {
   for (int d = 0; d < 3; ++d) { c->dl[d] = cs->l[d] / (double)(1.f * (float)cs->ng[d]); c->dli[d] = 1. / c->dl[d]; }   // param.f90:153-154
   c->visc = 1. / cs->visci;
   Geom &g = c->g;
-  g.n1 = c->n[0]; g.n2 = c->n[1]; g.n3 = c->n[2]; g.s1 = g.n1 + 2; g.s12 = (long)(g.n1 + 2) * (g.n2 + 2); g.jlo = c->lo[1] - 1; g.ng2 = cs->ng[1];
+  g.n1 = c->n[0]; g.n2 = c->n[1]; g.n3 = c->n[2];
+  // Row pitch: a multiple of 16 doubles (128 B) with room for the n1/2+1 complex modes of a row stored from i = 1; with the
+  // 15-double offset of dev_alloc, element i = 1 of every row is 128-B aligned, so kernels whose waves handle 64 consecutive
+  // cells from i = 1 read and write whole cache lines (partial-line writes cost ~1.5x, tools/micro/wrtile.hip).
+  g.s1 = getenv("CALES_UNALIGNED") ? g.n1 + 4 - (g.n1 & 1) : (g.n1 + 3 + 15) / 16 * 16;
+  c->field_ofs = getenv("CALES_UNALIGNED") ? 0 : 15;
+  g.s12 = (long)g.s1 * (g.n2 + 2); g.jlo = c->lo[1] - 1; g.ng2 = cs->ng[1];
   c->ntot = (size_t)g.s12 * (g.n3 + 2);
   const int n3 = c->n[2];
   // z grid and metrics (main.f90:246-285)
@@ -154,9 +175,9 @@ int cales_create(const cales_case *cs, void *stream, cales_ctx **out) {
     if (upload_vec(c, &c->rhsbp[0], rx) || upload_vec(c, &c->rhsbp[1], ry) || upload_vec(c, &c->rhsbp[2], rz)) return fail(7); }
   // fields (haloed); r.h.s. buffers use the same layout so every kernel shares one index
   const int nfields = cs->impdiff ? CALES_NFIELDS : CALES_DUDTD;
-  for (int q = 0; q < nfields; ++q) if (dev_alloc(c, &c->f[q], c->ntot)) return fail(8);
-  if (dev_alloc(c, &c->scr1, c->ntot) || dev_alloc(c, &c->scr2, c->ntot)) return fail(9);
-  for (int q = 0; q < 3; ++q) if (dev_alloc(c, &c->f2[q], c->ntot)) return fail(9);
+  for (int q = 0; q < nfields; ++q) if (field_alloc(c, &c->f[q])) return fail(8);
+  if (field_alloc(c, &c->scr1) || field_alloc(c, &c->scr2)) return fail(9);
+  for (int q = 0; q < 3; ++q) if (field_alloc(c, &c->f2[q])) return fail(9);
   c->red_blocks = 8;
   if (dev_alloc(c, &c->d_red, 64 + 16 * (size_t)(n3 + 2) + 4 * (size_t)(n3 + 2)) || dev_alloc(c, &c->d_force, 8)) return fail(10);
   c->res = c->d_red;
@@ -166,15 +187,15 @@ int cales_create(const cales_case *cs, void *stream, cales_ctx **out) {
   // wall flags are global properties of the case, not of the slab (distances use global indices)
   for (int s = 0; s <= 1; ++s) c->is_wall[s + 2] = (!(cs->cbcpre[2] == 'P' && cs->cbcpre[3] == 'P') && CBV(c, s, 2, 2) == 'D') ? 1. : 0.;
   if (cs->sgstype >= 1) {
-    if (dev_alloc(c, &c->s0, c->ntot)) return fail(12);
+    if (field_alloc(c, &c->s0)) return fail(12);
     const int nw = cs->sgstype == 1 ? 3 : 6;
-    for (int m = 0; m < nw; ++m) if (dev_alloc(c, &c->wk[m], c->ntot)) return fail(12);
+    for (int m = 0; m < nw; ++m) if (field_alloc(c, &c->wk[m])) return fail(12);
   }
   if (cs->sgstype == 2) {
-    if (dev_alloc(c, &c->uc, c->ntot) || dev_alloc(c, &c->vc, c->ntot) || dev_alloc(c, &c->wc, c->ntot) || dev_alloc(c, &c->uf, c->ntot) ||
-        dev_alloc(c, &c->vf, c->ntot) || dev_alloc(c, &c->wf, c->ntot) || dev_alloc(c, &c->alph2, c->ntot) || dev_alloc(c, &c->d_p1d, 2 * (size_t)n3 + 2))
+    if (field_alloc(c, &c->uc) || field_alloc(c, &c->vc) || field_alloc(c, &c->wc) || field_alloc(c, &c->uf) ||
+        field_alloc(c, &c->vf) || field_alloc(c, &c->wf) || field_alloc(c, &c->alph2) || dev_alloc(c, &c->d_p1d, 2 * (size_t)n3 + 2))
       return fail(13);
-    for (int m = 0; m < 6; ++m) if (dev_alloc(c, &c->sij[m], c->ntot) || dev_alloc(c, &c->mij[m], c->ntot)) return fail(13);
+    for (int m = 0; m < 6; ++m) if (field_alloc(c, &c->sij[m]) || field_alloc(c, &c->mij[m])) return fail(13);
   }
   if (solver_setup(c)) return fail(14);
   if (hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "sync failed"; return fail(15); }
@@ -188,13 +209,19 @@ int cales_local_size(const cales_ctx *c, int32_t n[3], int32_t lo[3]) { for (int
 // ------------------------------------------------------------------------------------------ copies
 int cales_set_field(cales_ctx *c, int field, const double *host) {
   if (field < 0 || field >= CALES_NFIELDS || !c->f[field]) { c->err = "bad field id"; return 1; }
-  HIPCHK(c, hipMemcpyAsync(c->f[field], host, c->ntot * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  const size_t nh = (size_t)(c->n[0] + 2) * (c->n[1] + 2) * (c->n[2] + 2);
+  const dim3 b(64, 4, 1), gr((c->n[0] + 2 + 63) / 64, (c->n[1] + 2 + 3) / 4, c->n[2] + 2);
+  HIPCHK(c, hipMemcpyAsync(c->scr1, host, nh * sizeof(double), hipMemcpyHostToDevice, c->stream));     // scr1: scratch between operators
+  hipLaunchKernelGGL(k_repack, gr, b, 0, c->stream, c->g, 1, c->f[field], c->scr1);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }
 int cales_get_field(cales_ctx *c, int field, double *host) {
   if (field < 0 || field >= CALES_NFIELDS || !c->f[field]) { c->err = "bad field id"; return 1; }
-  HIPCHK(c, hipMemcpyAsync(host, c->f[field], c->ntot * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  const size_t nh = (size_t)(c->n[0] + 2) * (c->n[1] + 2) * (c->n[2] + 2);
+  const dim3 b(64, 4, 1), gr((c->n[0] + 2 + 63) / 64, (c->n[1] + 2 + 3) / 4, c->n[2] + 2);
+  hipLaunchKernelGGL(k_repack, gr, b, 0, c->stream, c->g, 0, c->f[field], c->scr1);
+  HIPCHK(c, hipMemcpyAsync(host, c->scr1, nh * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }

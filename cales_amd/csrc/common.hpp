@@ -15,8 +15,8 @@
 
 struct Geom {              // passed by value to kernels
   int n1, n2, n3;          // local interior sizes
-  int s1;                  // n1+2
-  long s12;                // (n1+2)*(n2+2)
+  int s1;                  // row pitch >= n1+3, a multiple of 16 doubles
+  long s12;                // s1*(n2+2)
   int jlo;                 // global index offset of local row j=1 is jlo+1 (y-slab)
   int ng2;                 // global n2
 
@@ -103,6 +103,7 @@ struct cales_ctx {
   std::vector<KernelStat> stats;
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evpool;
+  int field_ofs = 0;       // doubles between a field's allocation and its element (0,0,0)
 };
 
 #define CBV(c, side, dir, vel) ((c)->cbcvel[(side) + 2 * ((dir) - 1) + 6 * ((vel) - 1)])

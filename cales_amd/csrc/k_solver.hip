@@ -557,14 +557,14 @@ int op_solver(cales_ctx *c) {
   SolverPlans *sp = find_plans(c);
   if (!sp) { c->err = "solver not initialised"; return 1; }
   const int *n = c->n; double *pp = c->f[CALES_PP];
-  const int mh = c->g.s1 / 2, n2g = c->C.ng[1];
+  const int mh = n[0] / 2 + 1, n2g = c->C.ng[1];
   const long nrows = (long)n[1] * n[2];
   const bool periodic_z = CBP(c, 0, 3) == 'P' && CBP(c, 1, 3) == 'P';
   const bool dist = c->P > 1;
   if (dist && !c->comm.on) { c->err = "solver: nranks > 1 but no communication hooks registered (cales_set_comm)"; return 1; }
   Spec S; S.blocked = dist ? 1 : 0; S.cw = c->cw; S.n2l = n[1]; S.n3 = n[2];
-  double2 *slab_spec = dist ? reinterpret_cast<double2 *>(c->comm.A) : reinterpret_cast<double2 *>(pp);
-  double2 *mode_spec = dist ? reinterpret_cast<double2 *>(c->comm.B) : reinterpret_cast<double2 *>(pp);
+  double2 *slab_spec = dist ? reinterpret_cast<double2 *>(c->comm.A) : reinterpret_cast<double2 *>(pp + 1);   // in place: modes of row (j,k) from i = 1
+  double2 *mode_spec = dist ? reinterpret_cast<double2 *>(c->comm.B) : reinterpret_cast<double2 *>(pp + 1);
   const int ncol = dist ? c->cw : mh, mofs = dist ? c->rank * c->cw : 0;
   const int64_t a2a_count = (int64_t)n[2] * n[1] * c->cw * 2;
   const int nh = c->C.ng[0] / 2;

@@ -31,7 +31,7 @@ def main():
         h.sync(); t = (time.perf_counter() - t0) / a.reps
         h.profile(False)
         st = h.profile_stats()
-        print(f"{op}: {1e3 * t:.3f} ms/call  " + "  ".join(f"{k}={v[1] / a.reps:.3f}" for k, v in sorted(st.items(), key=lambda kv: -kv[1][1])[:12]))
+        print(f"{op}: {1e3 * t:.3f} ms/call  " + "  ".join(f"{k}={v[1] / a.reps:.3f}" for k, v in sorted(st.items(), key=lambda kv: -kv[1][1])[:24]))
     h.close()
 
 
