@@ -168,6 +168,12 @@ void solver_teardown(cales_ctx *c);
 // of HBM re-reads. Only the order changes (a bijection on block ids); results are identical.
 #ifdef __HIPCC__
 
+// ---- global accesses as base pointer (kernel argument, scalar registers) + BYTE offset. With OFF = unsigned the compiler
+// emits the saddr + 32-bit voffset form: one VGPR per access stream instead of a 64-bit address per field (tile kernels
+// stream up to 17 fields). Hosts pick OFF = unsigned when a field is smaller than 4 GB, size_t otherwise.
+template <typename OFF> __device__ inline double ldb(const double *b, OFF o) { return *(const double *)((const char *)b + o); }
+template <typename OFF> __device__ inline void stb(double *b, OFF o, double v) { *(double *)((char *)b + o) = v; }
+
 // ---- cross-lane moves on the vector ALU (DPP) instead of ds_bpermute: no LDS-pipe traffic, short latency ----
 template <int CTRL, int ROWMASK = 0xf>
 __device__ inline double dpp_f64(double v) {       // lanes without a source (or masked rows) receive 0

@@ -1,9 +1,10 @@
 // Fused momentum r.h.s. + RK update (reference src/mom.f90:17-309 + src/rk.f90:77-94) as a plane-marching tile kernel.
 //
 // The kernel-per-loop version (k_mom + k_rk_update in k_stencil.hip) issues 55 + 13 vector loads per cell and is bound by the
-// L1/TA rate, and it writes the r.h.s. only to read it back. Here a block of 64 x (TYM+2) threads owns a tile of 62 x TYM
-// columns and marches in k: every thread loads ONLY its own cell of u,v,w,visct,p per plane (coalesced rows, next plane
-// prefetched), the planes k-1..k+1 live in a 4-slot LDS ring from which the 13/16-point stencils are read, and the RK update
+// L1/TA rate, and it writes the r.h.s. only to read it back. Here a block of 64 x (TYM+2) threads owns a tile of 64 x TYM
+// columns starting at i = 1 + 64 bx (whole 128-B lines in and out, see cales_create) and marches in k: every thread loads its
+// own cell of u,v,w,visct,p per plane (next plane prefetched), lanes 0 and 63 also the x-halo cell beside it; the planes
+// k-1..k+1 live in a 4-slot LDS ring (rows of 66) from which the 13/16-point stencils are read, and the RK update
 // is applied in the same pass. Velocities are written to a second set of buffers (the stencil still needs the old values of
 // the neighbours); the host swaps the pointers. Arithmetic and expression order are those of the reference.
 // Algorithmic traffic: 14 words/cell (5 in + 3 old r.h.s. in + 3 velocities + 3 r.h.s. out) instead of 7 + 13.
@@ -19,40 +20,49 @@ struct MomRkArgs {
   int kchunk;
 };
 
-template <int IMP>
+template <int IMP, typename OFF>
 __global__ __launch_bounds__(64 * (TYM + 2), 4) void k_momrk(Geom g, MomRkArgs A) {
-  __shared__ double sh[4][4][TYM + 2][64];
-  __shared__ double shp[2][TYM + 2][64];
+  __shared__ double sh[4][4][TYM + 2][66];
+  __shared__ double shp[3][TYM + 2][66];
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int bx_ = blockIdx.x, by_ = blockIdx.y, bz_ = blockIdx.z;
-  const int i = bx_ * 62 + tx, j = by_ * TYM + ty;
+  const int i = bx_ * 64 + tx + 1, j = by_ * TYM + ty;
   const int kbeg = bz_ * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
   const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1;
-  const bool outok = tx >= 1 && tx <= 62 && ty >= 1 && ty <= TYM && i <= g.n1 && j <= g.n2;
-  const size_t c0 = ldok ? g.ix(i, j, 0) : 0;
-  const size_t sk = (size_t)g.s12;
-  auto ld5 = [&](int k, double *q) {
-    if (ldok && k <= g.n3 + 1) { const size_t c = c0 + (size_t)k * sk; q[0] = A.u[c]; q[1] = A.v[c]; q[2] = A.w[c]; q[3] = A.s[c]; q[4] = A.p[c]; }
+  const bool outok = ty >= 1 && ty <= TYM && i <= g.n1 && j <= g.n2;
+  const OFF c0 = ldok ? (OFF)g.ix(i, j, 0) * 8 : 0;        // byte offsets (see ldb in common.hpp)
+  const OFF sk = (OFF)g.s12 * 8;
+  // x-halo columns (i = 64 bx and 64 bx + 65): the two y-halo waves, which have no outputs, fetch them for all rows of the
+  // tile -- wave 0 the left column, wave TYM+1 the right one; lane l -> row l/5, field l%5. One register instead of five.
+  const bool hwave = ty == 0 || ty == TYM + 1;
+  const int hr = tx / 5, hf_ = tx % 5, hxs = ty == 0 ? 0 : 65, hi_ = ty == 0 ? bx_ * 64 : bx_ * 64 + 65, hj = by_ * TYM + hr;
+  const bool hok = hwave && tx < 5 * (TYM + 2) && hi_ <= g.n1 + 1 && hj <= g.n2 + 1;
+  const double *hp = nullptr;
+  if (hok) { const double *fp = hf_ == 0 ? A.u : hf_ == 1 ? A.v : hf_ == 2 ? A.w : hf_ == 3 ? A.s : A.p; hp = fp + g.ix(hi_, hj, 0); }
+  const size_t sk64 = (size_t)g.s12;
+  auto ld5 = [&](int k, double *q, double &h) {
+    if (ldok && k <= g.n3 + 1) { const OFF c = c0 + (OFF)k * sk; q[0] = ldb(A.u, c); q[1] = ldb(A.v, c); q[2] = ldb(A.w, c); q[3] = ldb(A.s, c); q[4] = ldb(A.p, c); }
     else { q[0] = q[1] = q[2] = q[3] = q[4] = 0.; }
+    h = (hok && k <= g.n3 + 1) ? hp[(size_t)k * sk64] : 0.;
   };
-  double q0[5], q1[5], nx[5];
-  ld5(kbeg - 1, q0); ld5(kbeg, q1); ld5(kbeg + 1, nx);
+  // plane kk of the five fields -> ring slot kk&3 (u,v,w,visct) and kk%3 (p)
+  auto put = [&](int kk, const double *q, double h) {
 #pragma unroll
-  for (int f = 0; f < 4; ++f) { sh[f][(kbeg - 1) & 3][ty][tx] = q0[f]; sh[f][kbeg & 3][ty][tx] = q1[f]; }
-  double pcur = q1[4];
+    for (int f = 0; f < 4; ++f) sh[f][kk & 3][ty][tx + 1] = q[f];
+    shp[kk % 3][ty][tx + 1] = q[4];
+    if (hok) { if (hf_ < 4) sh[hf_][kk & 3][hr][hxs] = h; else shp[kk % 3][hr][hxs] = h; }
+  };
+  { double q[5], h;
+    ld5(kbeg - 1, q, h); put(kbeg - 1, q, h); ld5(kbeg, q, h); put(kbeg, q, h); ld5(kbeg + 1, q, h); put(kbeg + 1, q, h); }
   for (int k = kbeg; k <= kend; ++k) {
-#pragma unroll
-    for (int f = 0; f < 4; ++f) sh[f][(k + 1) & 3][ty][tx] = nx[f];
-    shp[k & 1][ty][tx] = pcur;
-    const double pnext = nx[4];
     __syncthreads();
-    double pf[5];
-    ld5(k + 2, pf);                                         // prefetch, in flight during the stencil
+    double pf[5], hf;
+    ld5(k + 2, pf, hf);                                     // prefetch, in flight during the stencil
     if (outok) {
-      const size_t c = c0 + (size_t)k * sk;
-      const double duo = A.duo[c], dvo = A.dvo[c], dwo = A.dwo[c];
+      const OFF c = c0 + (OFF)k * sk;
+      const double duo = ldb(A.duo, c), dvo = ldb(A.dvo, c), dwo = ldb(A.dwo, c);
       const int km = (k - 1) & 3, kc = k & 3, kp = (k + 1) & 3;
-#define LS(f, sl, di, dj) sh[f][sl][ty + (dj)][tx + (di)]
+#define LS(f, sl, di, dj) sh[f][sl][ty + (dj)][tx + 1 + (di)]
       const double u_ccm = LS(0, km, 0, 0), u_pcm = LS(0, km, 1, 0), u_cpm = LS(0, km, 0, 1), u_cmc = LS(0, kc, 0, -1), u_mcc = LS(0, kc, -1, 0),
                    u_ccc = LS(0, kc, 0, 0), u_pcc = LS(0, kc, 1, 0), u_mpc = LS(0, kc, -1, 1), u_cpc = LS(0, kc, 0, 1), u_mcp = LS(0, kp, -1, 0),
                    u_ccp = LS(0, kp, 0, 0);
@@ -65,7 +75,8 @@ __global__ __launch_bounds__(64 * (TYM + 2), 4) void k_momrk(Geom g, MomRkArgs A
                    s_cmp = LS(3, kp, 0, -1), s_mcp = LS(3, kp, -1, 0), s_ccp = LS(3, kp, 0, 0), s_ppc = LS(3, kc, 1, 1), s_pcp = LS(3, kp, 1, 0),
                    s_cpp = LS(3, kp, 0, 1);
 #undef LS
-      const double p_ccc = pcur, p_pcc = shp[k & 1][ty][tx + 1], p_cpc = shp[k & 1][ty + 1][tx], p_ccp = pnext;
+      const int pc = k % 3, pn = (k + 1) % 3;
+      const double p_ccc = shp[pc][ty][tx + 1], p_pcc = shp[pc][ty][tx + 2], p_cpc = shp[pc][ty + 1][tx + 1], p_ccp = shp[pn][ty][tx + 1];
       const double dxi = A.dxi, dyi = A.dyi, visc = A.visc;
       const double dzci_k = A.dzci[k], dzci_m = A.dzci[k - 1], dzfi_k = A.dzfi[k], dzfi_p = A.dzfi[k + 1];
       double visc_ip, visc_im, visc_jp, visc_jm, visc_kp, visc_km;
@@ -127,13 +138,11 @@ __global__ __launch_bounds__(64 * (TYM + 2), 4) void k_momrk(Geom g, MomRkArgs A
       double un = u_ccc + A.f1 * du + A.f2 * duo + A.f12 * (A.bfx - dxi * (p_pcc - p_ccc));
       double vn = v_ccc + A.f1 * dv + A.f2 * dvo + A.f12 * (A.bfy - dyi * (p_cpc - p_ccc));
       double wn = w_ccc + A.f1 * dw + A.f2 * dwo + A.f12 * (A.bfz - dzci_k * (p_ccp - p_ccc));
-      if (IMP) { un = un + A.f12 * dud; vn = vn + A.f12 * dvd; wn = wn + A.f12 * dwd; A.dud[c] = dud; A.dvd[c] = dvd; A.dwd[c] = dwd; }
-      A.un[c] = un; A.vn[c] = vn; A.wn[c] = wn;
-      A.du[c] = du; A.dv[c] = dv; A.dw[c] = dw;
+      if (IMP) { un = un + A.f12 * dud; vn = vn + A.f12 * dvd; wn = wn + A.f12 * dwd; stb(A.dud, c, dud); stb(A.dvd, c, dvd); stb(A.dwd, c, dwd); }
+      stb(A.un, c, un); stb(A.vn, c, vn); stb(A.wn, c, wn);
+      stb(A.du, c, du); stb(A.dv, c, dv); stb(A.dw, c, dw);
     }
-    pcur = pnext;
-#pragma unroll
-    for (int f = 0; f < 5; ++f) nx[f] = pf[f];
+    put(k + 2, pf, hf);        // slots (k+2)&3 and (k+2)%3 were last read in iteration k-1, i.e. before this iteration's barrier
   }
 }
 
@@ -148,12 +157,13 @@ int op_momrk(cales_ctx *c, double f1, double f2, double f12) {
   A.du = f[CALES_DUDT]; A.dv = f[CALES_DVDT]; A.dw = f[CALES_DWDT]; A.dud = f[CALES_DUDTD]; A.dvd = f[CALES_DVDTD]; A.dwd = f[CALES_DWDTD];
   A.dzci = c->d_dzci; A.dzfi = c->d_dzfi; A.dxi = c->dli[0]; A.dyi = c->dli[1]; A.visc = c->visc;
   A.f1 = f1; A.f2 = f2; A.f12 = f12; A.bfx = c->C.bforce[0]; A.bfy = c->C.bforce[1]; A.bfz = c->C.bforce[2];
-  dim3 b(64, TYM + 2, 1), gr((n[0] + 61) / 62, (n[1] + TYM - 1) / TYM, 1);
+  dim3 b(64, TYM + 2, 1), gr((n[0] + 63) / 64, (n[1] + TYM - 1) / TYM, 1);
   int kchunk = n[2];
   while ((long)gr.x * gr.y * ((n[2] + kchunk - 1) / kchunk) < 2048 && kchunk > 32) kchunk = (kchunk + 1) / 2;
   gr.z = (n[2] + kchunk - 1) / kchunk; A.kchunk = kchunk;
-  if (c->C.impdiff == 2) hipLaunchKernelGGL(k_momrk<2>, gr, b, 0, c->stream, c->g, A);
-  else hipLaunchKernelGGL(k_momrk<0>, gr, b, 0, c->stream, c->g, A);
+  const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32);      // 32-bit byte offsets
+  if (c->C.impdiff == 2) { if (small) hipLaunchKernelGGL((k_momrk<2, unsigned>), gr, b, 0, c->stream, c->g, A); else hipLaunchKernelGGL((k_momrk<2, size_t>), gr, b, 0, c->stream, c->g, A); }
+  else { if (small) hipLaunchKernelGGL((k_momrk<0, unsigned>), gr, b, 0, c->stream, c->g, A); else hipLaunchKernelGGL((k_momrk<0, size_t>), gr, b, 0, c->stream, c->g, A); }
   HIPCHK(c, hipGetLastError());
   for (int q = 0; q < 3; ++q) std::swap(c->f[CALES_U + q], c->f2[q]);
   return 0;

@@ -248,54 +248,67 @@ __global__ __launch_bounds__(256) void k_alph2(Geom g, double w0, double w1, dou
 //  * sij, Mij, Lij, LM, MM and the products ui uj are never stored.
 // Traffic: ~45 words/cell instead of ~166 measured for the kernel-per-loop sequence (profiles/r01a_*).
 // ================================================================================================
-// Tile = 62 x TY outputs handled by 64 x (TY+2) threads that march in k. Every thread loads exactly its own cell of each
-// input (full-width coalesced rows, no divergent loads, one load phase per plane, next plane prefetched); x neighbours come
-// from wave shuffles, y neighbours through LDS. With the wall rule Q(0) = 2Q(1)-Q(2) ghost planes of extrapolated
-// quantities are never read.
+// Tile kernels: blocks of 64 x (TY+2) threads march in k; every thread loads its own cell of each input per plane (full
+// coalesced rows, next plane prefetched), x neighbours come from DPP lane moves or LDS rows, y neighbours through LDS. The
+// kernels that write fields (K_AC, K_B) use tiles of 64 x TY outputs starting at i = 1 + 64 bx so that rows are read and
+// written as whole 128-B lines; the read-only K_DF uses 62 x TY outputs with the x halo inside the wave. With the wall rule
+// Q(0) = 2Q(1)-Q(2) ghost planes of extrapolated quantities are never read.
 #ifndef TYB
 #define TYB 14
 #endif
 struct Filter6Args { const double *in[6]; double *out[6]; int kchunk, zlo, zhi; };
-// K_B: top-hat filter of six fields (the products |S|Sij), three planes of the own cell in registers, z combination first
+// K_B: top-hat filter of six fields (the products |S|Sij). Tile = 64 x TYB outputs from i = 1 + 64 bx (whole 128-B lines in and
+// out); x combination first, on the plane just loaded (lanes 0 and 63 also load the x-halo cell beside them), then three
+// x-combined planes of the own cell roll in registers for the z combination, y neighbours through LDS.
+template <typename OFF>
 __global__ __launch_bounds__(64 * (TYB + 2)) void k_filter6_tile(Geom g, Filter6Args A) {
   __shared__ double sh[2][6][TYB + 2][64];
   const int tx = threadIdx.x, ty = threadIdx.y;
-  const int i = blockIdx.x * 62 + tx, j = blockIdx.y * TYB + ty;            // tx = 0 / 63 and ty = 0 / TY+1 are halo threads
+  const int i = blockIdx.x * 64 + tx + 1, j = blockIdx.y * TYB + ty;        // ty = 0 / TYB+1 are halo rows
   const int kbeg = blockIdx.z * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
-  const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1;
-  const bool outok = tx >= 1 && tx <= 62 && ty >= 1 && ty <= TYB && i <= g.n1 && j <= g.n2;
-  double sm[6], sc[6], sp[6], sn[6];
-  const size_t c0 = g.ix(i, j, 0);
+  const bool edge = tx == 0 || tx == 63;
+  const int ih = tx == 0 ? i - 1 : i + 1;
+  const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1, hok = edge && ih <= g.n1 + 1 && j <= g.n2 + 1;
+  const bool outok = ty >= 1 && ty <= TYB && i <= g.n1 && j <= g.n2;
+  const OFF c0 = ldok ? (OFF)g.ix(i, j, 0) * 8 : 0, ch = hok ? (OFF)g.ix(ih, j, 0) * 8 : 0, sk = (OFF)g.s12 * 8;   // byte offsets
+  auto load = [&](int kk, double *r, double *h) {
 #pragma unroll
-  for (int q = 0; q < 6; ++q) {
-    sm[q] = ldok ? A.in[q][c0 + (size_t)(kbeg - 1) * g.s12] : 0.;
-    sc[q] = ldok ? A.in[q][c0 + (size_t)kbeg * g.s12] : 0.;
-    sp[q] = ldok ? A.in[q][c0 + (size_t)(kbeg + 1) * g.s12] : 0.;
-  }
-  int buf = 0;
-  for (int k = kbeg; k <= kend; ++k) {
-    const size_t idx = c0 + (size_t)k * g.s12;
-    if (k + 2 <= g.n3 + 1) {
-#pragma unroll
-      for (int q = 0; q < 6; ++q) sn[q] = ldok ? A.in[q][idx + 2 * g.s12] : 0.;     // prefetch
-    }
-    const bool lo = A.zlo && k == 1, hi = A.zhi && k == g.n3;
-    double r[6];
+    for (int q = 0; q < 6; ++q) { r[q] = ldok ? ldb(A.in[q], c0 + (OFF)kk * sk) : 0.; h[q] = hok ? ldb(A.in[q], ch + (OFF)kk * sk) : 0.; }
+  };
+  auto xcomb = [&](const double *r, const double *h, double *X) {
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
-      const double vm = lo ? 2. * sc[q] - sp[q] : sm[q];
-      const double vp = hi ? 2. * sc[q] - sm[q] : sp[q];
-      const double G = vm + 2. * sc[q] + vp;
-      r[q] = lane_prev(G) + 2. * G + lane_next(G);
-      sh[buf][q][ty][tx] = r[q];
+      double pv = lane_prev(r[q]), nx = lane_next(r[q]);
+      if (tx == 0) pv = h[q];
+      if (tx == 63) nx = h[q];
+      X[q] = pv + 2. * r[q] + nx;
+    }
+  };
+  double xm[6], xc[6], xp[6], rn[6], hn[6];
+  load(kbeg - 1, rn, hn); xcomb(rn, hn, xm);
+  load(kbeg, rn, hn); xcomb(rn, hn, xc);
+  load(kbeg + 1, rn, hn);
+  int buf = 0;
+  for (int k = kbeg; k <= kend; ++k) {
+    const OFF idx = c0 + (OFF)k * sk;
+    xcomb(rn, hn, xp);
+    if (k + 2 <= g.n3 + 1) load(k + 2, rn, hn);                 // prefetch
+    const bool lo = A.zlo && k == 1, hi = A.zhi && k == g.n3;
+    double G[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const double vm = lo ? 2. * xc[q] - xp[q] : xm[q];          // wall rule Q(0) = 2Q(1) - Q(2)
+      const double vp = hi ? 2. * xc[q] - xm[q] : xp[q];
+      G[q] = vm + 2. * xc[q] + vp;
+      sh[buf][q][ty][tx] = G[q];
     }
     __syncthreads();
     if (outok) {
 #pragma unroll
-      for (int q = 0; q < 6; ++q) A.out[q][idx] = (sh[buf][q][ty - 1][tx] + 2. * r[q] + sh[buf][q][ty + 1][tx]) / 64.;
+      for (int q = 0; q < 6; ++q) stb(A.out[q], idx, (sh[buf][q][ty - 1][tx] + 2. * G[q] + sh[buf][q][ty + 1][tx]) / 64.);
     }
 #pragma unroll
-    for (int q = 0; q < 6; ++q) { sm[q] = sc[q]; sc[q] = sp[q]; sp[q] = sn[q]; }
+    for (int q = 0; q < 6; ++q) { xm[q] = xc[q]; xc[q] = xp[q]; }
     buf ^= 1;
   }
 }
@@ -316,6 +329,7 @@ struct LijMijArgs {
   double dxi, dyi;
   int kchunk, nblk, zlo, zhi;
 };
+template <typename OFF>
 __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijArgs A) {
   __shared__ double sh[9][TYF + 2][64];
   __shared__ double ring[3][3][TYF + 2][64];
@@ -326,29 +340,29 @@ __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijA
   const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1;
   const bool outok = tx >= 1 && tx <= 62 && ty >= 1 && ty <= TYF && i <= g.n1 && j <= g.n2;
   const bool inner = ty >= 1 && ty <= TYF;
-  const size_t c0 = g.ix(i, j, 0);
+  const OFF c0 = ldok ? (OFF)g.ix(i, j, 0) * 8 : 0, sk = (OFF)g.s12 * 8;      // byte offsets
   double sm[3], sc[3], sp[3], sn[3], fn[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
-    sm[q] = ldok ? A.uc[q][c0 + (size_t)(kbeg - 1) * g.s12] : 0.;
-    sc[q] = ldok ? A.uc[q][c0 + (size_t)kbeg * g.s12] : 0.;
-    sp[q] = ldok ? A.uc[q][c0 + (size_t)(kbeg + 1) * g.s12] : 0.;
-    ring[(kbeg - 1) % 3][q][ty][tx] = ldok ? A.uf[q][c0 + (size_t)(kbeg - 1) * g.s12] : 0.;
-    ring[kbeg % 3][q][ty][tx] = ldok ? A.uf[q][c0 + (size_t)kbeg * g.s12] : 0.;
-    fn[q] = ldok ? A.uf[q][c0 + (size_t)(kbeg + 1) * g.s12] : 0.;
+    sm[q] = ldok ? ldb(A.uc[q], c0 + (OFF)(kbeg - 1) * sk) : 0.;
+    sc[q] = ldok ? ldb(A.uc[q], c0 + (OFF)kbeg * sk) : 0.;
+    sp[q] = ldok ? ldb(A.uc[q], c0 + (OFF)(kbeg + 1) * sk) : 0.;
+    ring[(kbeg - 1) % 3][q][ty][tx] = ldok ? ldb(A.uf[q], c0 + (OFF)(kbeg - 1) * sk) : 0.;
+    ring[kbeg % 3][q][ty][tx] = ldok ? ldb(A.uf[q], c0 + (OFF)kbeg * sk) : 0.;
+    fn[q] = ldok ? ldb(A.uf[q], c0 + (OFF)(kbeg + 1) * sk) : 0.;
   }
   int km = (kbeg - 1) % 3, kc = kbeg % 3, kp = (kbeg + 1) % 3;
   for (int k = kbeg; k <= kend; ++k) {
-    const size_t idx = c0 + (size_t)k * g.s12;
+    const OFF idx = c0 + (OFF)k * sk;
 #pragma unroll
     for (int q = 0; q < 3; ++q) ring[kp][q][ty][tx] = fn[q];
     if (k + 2 <= g.n3 + 1) {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) { sn[q] = ldok ? A.uc[q][idx + 2 * g.s12] : 0.; fn[q] = ldok ? A.uf[q][idx + 2 * g.s12] : 0.; }
+      for (int q = 0; q < 3; ++q) { sn[q] = ldok ? ldb(A.uc[q], idx + 2 * sk) : 0.; fn[q] = ldok ? ldb(A.uf[q], idx + 2 * sk) : 0.; }
     }
     double mf[6];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) mf[q] = outok ? A.mf[q][idx] : 0.;
+    for (int q = 0; q < 6; ++q) mf[q] = outok ? ldb(A.mf[q], idx) : 0.;
     double qm[9], qc[9], qp[9], r[9];
     uiuj(sm, qm); uiuj(sc, qc); uiuj(sp, qp);
     const bool lo = A.zlo && k == 1, hi = A.zhi && k == g.n3;
@@ -424,47 +438,60 @@ struct StrainTileArgs {
   double dxi, dyi;
   int kchunk, zlo, zhi;
 };
+template <typename OFF>
 __global__ __launch_bounds__(64 * (TYS + 2)) void k_strain_tile(Geom g, StrainTileArgs A) {
-  __shared__ double ring[3][3][TYS + 2][64];
+  __shared__ double ring[3][3][TYS + 2][66];      // rows: x-halo cell, 64 own cells, x-halo cell
   __shared__ double shs[3][TYS + 2][64];
   const int tx = threadIdx.x, ty = threadIdx.y;
-  const int i = blockIdx.x * 62 + tx, j = blockIdx.y * TYS + ty;
+  const int i = blockIdx.x * 64 + tx + 1, j = blockIdx.y * TYS + ty;        // whole 128-B lines in and out (see cales_create)
   const int kbeg = blockIdx.z * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
-  const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1;
-  const bool outok = tx >= 1 && tx <= 62 && ty >= 1 && ty <= TYS && i <= g.n1 && j <= g.n2;
-  const size_t c0 = g.ix(i, j, 0);
-  double fn[3];
+  const bool edge = tx == 0 || tx == 63;
+  const int ih = tx == 0 ? i - 1 : i + 1, hx = tx == 0 ? 0 : 65;
+  const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1, hok = edge && ih <= g.n1 + 1 && j <= g.n2 + 1;
+  const bool outok = ty >= 1 && ty <= TYS && i <= g.n1 && j <= g.n2;
+  const OFF c0 = ldok ? (OFF)g.ix(i, j, 0) * 8 : 0, ch = hok ? (OFF)g.ix(ih, j, 0) * 8 : 0, sk = (OFF)g.s12 * 8;   // byte offsets
+  double fn[3], fh[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
-    ring[(kbeg - 1) % 3][q][ty][tx] = ldok ? A.u[q][c0 + (size_t)(kbeg - 1) * g.s12] : 0.;
-    ring[kbeg % 3][q][ty][tx] = ldok ? A.u[q][c0 + (size_t)kbeg * g.s12] : 0.;
-    fn[q] = ldok ? A.u[q][c0 + (size_t)(kbeg + 1) * g.s12] : 0.;
+    ring[(kbeg - 1) % 3][q][ty][tx + 1] = ldok ? ldb(A.u[q], c0 + (OFF)(kbeg - 1) * sk) : 0.;
+    ring[kbeg % 3][q][ty][tx + 1] = ldok ? ldb(A.u[q], c0 + (OFF)kbeg * sk) : 0.;
+    if (edge) {
+      ring[(kbeg - 1) % 3][q][ty][hx] = hok ? ldb(A.u[q], ch + (OFF)(kbeg - 1) * sk) : 0.;
+      ring[kbeg % 3][q][ty][hx] = hok ? ldb(A.u[q], ch + (OFF)kbeg * sk) : 0.;
+    }
+    fn[q] = ldok ? ldb(A.u[q], c0 + (OFF)(kbeg + 1) * sk) : 0.;
+    fh[q] = hok ? ldb(A.u[q], ch + (OFF)(kbeg + 1) * sk) : 0.;
   }
   int km = (kbeg - 1) % 3, kc = kbeg % 3, kp = (kbeg + 1) % 3;
   for (int k = kbeg; k <= kend; ++k) {
-    const size_t idx = c0 + (size_t)k * g.s12;
+    const OFF idx = c0 + (OFF)k * sk;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) ring[kp][q][ty][tx] = fn[q];
+    for (int q = 0; q < 3; ++q) { ring[kp][q][ty][tx + 1] = fn[q]; if (edge) ring[kp][q][ty][hx] = fh[q]; }
     if (k + 2 <= g.n3 + 1) {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) fn[q] = ldok ? A.u[q][idx + 2 * g.s12] : 0.;
+      for (int q = 0; q < 3; ++q) { fn[q] = ldok ? ldb(A.u[q], idx + 2 * sk) : 0.; fh[q] = hok ? ldb(A.u[q], ch + (OFF)(k + 2) * sk) : 0.; }
     }
     __syncthreads();
     const bool lo = A.zlo && k == 1, hi = A.zhi && k == g.n3;
     double r[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-      const double qm = ring[km][q][ty][tx], qc = ring[kc][q][ty][tx], qp = ring[kp][q][ty][tx];
-      const double vm = (lo && q < 2) ? 2. * qc - qp : qm;      // u,v extrapolated through the walls, w (on the faces) not
-      const double vp = (hi && q < 2) ? 2. * qc - qm : qp;
-      const double G = vm + 2. * qc + vp;
-      r[q] = lane_prev(G) + 2. * G + lane_next(G);
+      auto zcomb = [&](int x) {
+        const double qm = ring[km][q][ty][x], qc = ring[kc][q][ty][x], qp = ring[kp][q][ty][x];
+        const double vm = (lo && q < 2) ? 2. * qc - qp : qm;      // u,v extrapolated through the walls, w (on the faces) not
+        const double vp = (hi && q < 2) ? 2. * qc - qm : qp;
+        return vm + 2. * qc + vp;
+      };
+      const double G = zcomb(tx + 1);
+      double pv = lane_prev(G), nx = lane_next(G);
+      if (edge) { const double Gh = zcomb(hx); if (tx == 0) pv = Gh; else nx = Gh; }
+      r[q] = pv + 2. * G + nx;
       shs[q][ty][tx] = r[q];
     }
     if (outok) {
-#define RU(dk, dj, di) ring[dk][0][ty + (dj)][tx + (di)]
-#define RV(dk, dj, di) ring[dk][1][ty + (dj)][tx + (di)]
-#define RW(dk, dj, di) ring[dk][2][ty + (dj)][tx + (di)]
+#define RU(dk, dj, di) ring[dk][0][ty + (dj)][tx + 1 + (di)]
+#define RV(dk, dj, di) ring[dk][1][ty + (dj)][tx + 1 + (di)]
+#define RW(dk, dj, di) ring[dk][2][ty + (dj)][tx + 1 + (di)]
       const double u_mcm = RU(km, 0, -1), u_ccm = RU(km, 0, 0), u_mmc = RU(kc, -1, -1), u_cmc = RU(kc, -1, 0), u_mcc = RU(kc, 0, -1),
                    u_ccc = RU(kc, 0, 0), u_mpc = RU(kc, 1, -1), u_cpc = RU(kc, 1, 0), u_mcp = RU(kp, 0, -1), u_ccp = RU(kp, 0, 0);
       const double v_cmm = RV(km, -1, 0), v_ccm = RV(km, 0, 0), v_mmc = RV(kc, -1, -1), v_cmc = RV(kc, -1, 0), v_pmc = RV(kc, -1, 1),
@@ -483,15 +510,15 @@ __global__ __launch_bounds__(64 * (TYS + 2)) void k_strain_tile(Geom g, StrainTi
       const double s23 = .125 * ((v_ccp - v_ccc) * zc + (w_cpc - w_ccc) * dyi + (v_ccc - v_ccm) * zm + (w_cpm - w_ccm) * dyi +
                                  (v_cmp - v_cmc) * zc + (w_ccc - w_cmc) * dyi + (v_cmc - v_cmm) * zm + (w_ccm - w_cmm) * dyi);
       const double s0v = sqrt(2. * (s11 * s11 + s22 * s22 + s33 * s33 + 2. * (s12 * s12 + s13 * s13 + s23 * s23)));
-      A.s0[idx] = s0v;                                              // stands for visct = s0 (sgs.f90:184) until the final kernel
-      A.ssij[0][idx] = s0v * s11; A.ssij[1][idx] = s0v * s22; A.ssij[2][idx] = s0v * s33;      // |S|Sij (sgs.f90:198-210)
-      A.ssij[3][idx] = s0v * s12; A.ssij[4][idx] = s0v * s13; A.ssij[5][idx] = s0v * s23;
-      A.uc[0][idx] = 0.5 * (u_ccc + u_mcc); A.uc[1][idx] = 0.5 * (v_ccc + v_cmc); A.uc[2][idx] = 0.5 * (w_ccc + w_ccm);
+      stb(A.s0, idx, s0v);                                              // stands for visct = s0 (sgs.f90:184) until the final kernel
+      stb(A.ssij[0], idx, s0v * s11); stb(A.ssij[1], idx, s0v * s22); stb(A.ssij[2], idx, s0v * s33);      // |S|Sij (sgs.f90:198-210)
+      stb(A.ssij[3], idx, s0v * s12); stb(A.ssij[4], idx, s0v * s13); stb(A.ssij[5], idx, s0v * s23);
+      stb(A.uc[0], idx, 0.5 * (u_ccc + u_mcc)); stb(A.uc[1], idx, 0.5 * (v_ccc + v_cmc)); stb(A.uc[2], idx, 0.5 * (w_ccc + w_ccm));
     }
     __syncthreads();
     if (outok) {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) A.uf[q][idx] = (shs[q][ty - 1][tx] + 2. * r[q] + shs[q][ty + 1][tx]) / 64.;
+      for (int q = 0; q < 3; ++q) stb(A.uf[q], idx, (shs[q][ty - 1][tx] + 2. * r[q] + shs[q][ty + 1][tx]) / 64.);
     }
     const int t = km; km = kc; kc = kp; kp = t;
   }
@@ -522,23 +549,24 @@ static int dsmag_fast(cales_ctx *c) {
   double **ssij = c->sij, **mij = c->mij;
   const int zlo = c->is_wall[4] != 0., zhi = c->is_wall[5] != 0.;
   // tiles of 62 x TY columns marching in k; k is also split into chunks so that several rounds of blocks balance the chip
-  auto tiles = [&](int ty, dim3 &mb, dim3 &mg, int &kchunk) {
-    mb = dim3(64, ty + 2, 1); mg = dim3((n[0] + 61) / 62, (n[1] + ty - 1) / ty, 1);
+  auto tiles = [&](int ty, int wx, dim3 &mb, dim3 &mg, int &kchunk) {
+    mb = dim3(64, ty + 2, 1); mg = dim3((n[0] + wx - 1) / wx, (n[1] + ty - 1) / ty, 1);
     kchunk = n[2];
     while ((long)mg.x * mg.y * ((n[2] + kchunk - 1) / kchunk) < 2048 && kchunk > 32) kchunk = (kchunk + 1) / 2;
     mg.z = (n[2] + kchunk - 1) / kchunk;
   };
   dim3 mb, mg; int kch;
+  const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32);      // 32-bit byte offsets (ldb/stb)
   // K_AC: |S|, |S|Sij, cell-centred and test-filtered velocity in one pass over u,v,w (no wall-model faces ->
   // extrapolate(...,lwm) is a no-op; u,v are extrapolated through the z walls, w on the faces is not, sgs.f90:705-710)
   { ProfScope ps(c, "strain_filter_uvw");
-    tiles(TYS, mb, mg, kch);
+    tiles(TYS, 64, mb, mg, kch);
     StrainTileArgs S;
     S.u[0] = f[CALES_U]; S.u[1] = f[CALES_V]; S.u[2] = f[CALES_W]; S.s0 = c->s0;
     for (int m = 0; m < 6; ++m) S.ssij[m] = ssij[m];
     S.uc[0] = c->uc; S.uc[1] = c->vc; S.uc[2] = c->wc; S.uf[0] = c->uf; S.uf[1] = c->vf; S.uf[2] = c->wf;
     S.dzci = c->d_dzci; S.dzfi = c->d_dzfi; S.dxi = c->dli[0]; S.dyi = c->dli[1]; S.kchunk = kch; S.zlo = zlo; S.zhi = zhi;
-    hipLaunchKernelGGL(k_strain_tile, mg, mb, 0, c->stream, c->g, S); }
+    if (small) hipLaunchKernelGGL(k_strain_tile<unsigned>, mg, mb, 0, c->stream, c->g, S); else hipLaunchKernelGGL(k_strain_tile<size_t>, mg, mb, 0, c->stream, c->g, S); }
   // sgs-type ghost cells: only the periodic exchange matters (products of ghosts = ghosts of products; the wall ghosts are
   // replaced by the extrapolation rule inside the filters)
   for (int m = 0; m < 6; ++m) if (int e = op_boundp(c, ssij[m], 1)) return e;
@@ -548,20 +576,20 @@ static int dsmag_fast(cales_ctx *c) {
   if (int e = op_boundp(c, c->wc, 1)) return e;
   // K_B: filter(|S| Sij)
   { ProfScope ps(c, "filter_s0sij");
-    tiles(TYB, mb, mg, kch);
+    tiles(TYB, 64, mb, mg, kch);
     Filter6Args A; A.kchunk = kch; A.zlo = zlo; A.zhi = zhi;
     for (int m = 0; m < 6; ++m) { A.in[m] = ssij[m]; A.out[m] = mij[m]; }
-    hipLaunchKernelGGL(k_filter6_tile, mg, mb, 0, c->stream, c->g, A); }
+    if (small) hipLaunchKernelGGL(k_filter6_tile<unsigned>, mg, mb, 0, c->stream, c->g, A); else hipLaunchKernelGGL(k_filter6_tile<size_t>, mg, mb, 0, c->stream, c->g, A); }
   // K_DF: strain rate of the filtered velocity, Mij, Lij, contractions and plane partial sums in one pass
   { ProfScope ps(c, "lij_mij_contract");
-    tiles(TYF, mb, mg, kch);
+    tiles(TYF, 62, mb, mg, kch);
     LijMijArgs L;
     L.uc[0] = c->uc; L.uc[1] = c->vc; L.uc[2] = c->wc; L.uf[0] = c->uf; L.uf[1] = c->vf; L.uf[2] = c->wf;
     for (int m = 0; m < 6; ++m) L.mf[m] = mij[m];
     L.part = c->wk[0]; L.dzci = c->d_dzci; L.dzfi = c->d_dzfi; L.dxi = c->dli[0]; L.dyi = c->dli[1];
     L.kchunk = kch; L.nblk = mg.x * mg.y; L.zlo = zlo; L.zhi = zhi;
     if ((size_t)2 * n[2] * L.nblk > c->ntot) { c->err = "dsmag: partial-sum scratch too small"; return 1; }
-    hipLaunchKernelGGL(k_lij_mij_tile, mg, mb, 0, c->stream, c->g, L);
+    if (small) hipLaunchKernelGGL(k_lij_mij_tile<unsigned>, mg, mb, 0, c->stream, c->g, L); else hipLaunchKernelGGL(k_lij_mij_tile<size_t>, mg, mb, 0, c->stream, c->g, L);
     hipLaunchKernelGGL(k_plane_fold, dim3(2 * n[2]), dim3(256), 0, c->stream, n[2], L.nblk, c->wk[0], c->d_p1d); }
   if (c->P > 1) { if (int e = allreduce_res(c, (int)(c->d_p1d - c->res), 2 * n[2], 0)) return e; }   // sgs.f90:475
   const double gar = c->dl[0] * c->dl[1] / (c->C.l[0] * c->C.l[1]);
