@@ -300,9 +300,10 @@ int cales_step(cales_ctx *c, double dt) {
     if (int e = op_updt_rhs_b(c)) return e;
     if (int e = op_solver(c)) return e;
     if (int e = op_boundp(c, c->f[CALES_PP], 0)) return e;
-    if (int e = op_correc(c, dtrk)) return e;
+    const bool fuse_cu = getenv("CALES_UNFUSED_CORREC") == nullptr;     // updatep only needs pp: one pass with correc
+    if (int e = (fuse_cu ? op_correc_updatep(c, dtrk, alpha, 1) : op_correc(c, dtrk))) return e;
     if (int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 1, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W])) return e;
-    if (int e = op_updatep(c, alpha)) return e;
+    if (!fuse_cu) { if (int e = op_updatep(c, alpha)) return e; }
     if (int e = op_boundp(c, c->f[CALES_P], 0)) return e;
     if (int e = op_cmpt_sgs(c)) return e;
     if (int e = op_boundp(c, c->f[CALES_VISCT], 1)) return e;

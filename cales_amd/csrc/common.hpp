@@ -154,6 +154,7 @@ int op_updt_rhs_b(cales_ctx *c);
 int op_solver(cales_ctx *c);
 int op_helmholtz_z(cales_ctx *c, int ivel, double alpha);
 int op_correc(cales_ctx *c, double dtrk);
+int op_correc_updatep(cales_ctx *c, double dtrk, double alpha, int upd);
 int op_updatep(cales_ctx *c, double alpha);
 int op_cmpt_sgs(cales_ctx *c);
 int op_chkdt(cales_ctx *c, double *dtmax);

@@ -310,7 +310,61 @@ __global__ __launch_bounds__(BX *BY) void k_correc(Geom g, double fi, double fj,
   if (j <= g.n2) v[c] = v[c] - fj * (p[c + g.s1] - pc);
   if (k <= g.n3) w[c] = w[c] - dt * dzci[k] * (p[c + g.s12] - pc);
 }
+// Line-aligned form of the same loops, optionally fused with updatep (updatep.f90:30-47; UPD = 1 explicit, 2 z-implicit):
+// a wave covers the 64 cells i = 1 + 64 bx + lane of one row (whole 128-B lines), p(i+1) comes from the next lane, pp is
+// read once for both operators. The ghost columns i = 0 and i = n1+1 of the reference's ranges are left to k_correc_edge.
+// (A k-marching variant with the pressure planes in registers measured slower: the kernel is a pure stream.)
+template <int UPD>
+__global__ __launch_bounds__(BX *BY) void k_correc_cell(Geom g, double fi, double fj, double dt, double alpha, const double *__restrict__ dzci,
+                                                         const double *__restrict__ dzfi, const double *__restrict__ pp, double *__restrict__ u,
+                                                         double *__restrict__ v, double *__restrict__ w, double *__restrict__ p) {
+  const int tx = threadIdx.x, i = blockIdx.x * BX + tx + 1, j = blockIdx.y * BY + threadIdx.y, k = blockIdx.z;
+  if (j > g.n2 + 1) return;
+  const bool on = i <= g.n1, lastlane = tx == BX - 1 || i == g.n1;
+  const size_t c = g.ix(on ? i : g.n1, j, k);
+  const double pc = on ? pp[c] : 0.;
+  double px = lane_next(pc);
+  if (lastlane) px = pp[c + 1];
+  if (!on) return;
+  u[c] = u[c] - fi * (px - pc);
+  if (j <= g.n2) v[c] = v[c] - fj * (pp[c + g.s1] - pc);
+  const double pn = k <= g.n3 ? pp[c + g.s12] : 0.;
+  if (k <= g.n3) w[c] = w[c] - dt * dzci[k] * (pn - pc);
+  if (UPD && j >= 1 && j <= g.n2 && k >= 1 && k <= g.n3) {
+    if (UPD == 1) p[c] = p[c] + pc;
+    else p[c] = p[c] + pc + alpha * (((pn - pc) * dzci[k] - (pc - pp[c - g.s12]) * dzci[k - 1]) * dzfi[k]);
+  }
+}
+// ghost columns i = 0 (u,v,w) and i = n1+1 (v,w) of correc.f90:44-67
+__global__ __launch_bounds__(256) void k_correc_edge(Geom g, double fi, double fj, double dt, const double *__restrict__ dzci,
+                                                      const double *__restrict__ pp, double *__restrict__ u, double *__restrict__ v,
+                                                      double *__restrict__ w) {
+  const int j = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y * 4 + threadIdx.y, side = blockIdx.z;
+  if (j > g.n2 + 1 || k > g.n3 + 1) return;
+  const size_t c = g.ix(side ? g.n1 + 1 : 0, j, k);
+  const double pc = pp[c];
+  if (!side) u[c] = u[c] - fi * (pp[c + 1] - pc);
+  if (j <= g.n2) v[c] = v[c] - fj * (pp[c + g.s1] - pc);
+  if (k <= g.n3) w[c] = w[c] - dt * dzci[k] * (pp[c + g.s12] - pc);
+}
+// upd = 0: correc only; 1: correc + updatep in one pass (cales_step)
+int op_correc_updatep(cales_ctx *c, double dt, double alpha, int upd) {
+  ProfScope ps(c, upd ? "correc_updatep" : "correc");
+  const int *n = c->n;
+  dim3 b(BX, BY, 1), gr((n[0] + BX - 1) / BX, (n[1] + 2 + BY - 1) / BY, n[2] + 2);
+  double *f_[4] = {c->f[CALES_U], c->f[CALES_V], c->f[CALES_W], c->f[CALES_P]};
+  const double fi = dt * c->dli[0], fj = dt * c->dli[1];
+  const int mode = !upd ? 0 : (c->C.impdiff == 2 ? 2 : 1);
+  if (mode == 0) hipLaunchKernelGGL(k_correc_cell<0>, gr, b, 0, c->stream, c->g, fi, fj, dt, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], f_[0], f_[1], f_[2], f_[3]);
+  else if (mode == 1) hipLaunchKernelGGL(k_correc_cell<1>, gr, b, 0, c->stream, c->g, fi, fj, dt, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], f_[0], f_[1], f_[2], f_[3]);
+  else hipLaunchKernelGGL(k_correc_cell<2>, gr, b, 0, c->stream, c->g, fi, fj, dt, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], f_[0], f_[1], f_[2], f_[3]);
+  hipLaunchKernelGGL(k_correc_edge, dim3((n[1] + 2 + 63) / 64, (n[2] + 2 + 3) / 4, 2), dim3(64, 4, 1), 0, c->stream, c->g, fi, fj, dt, c->d_dzci, c->f[CALES_PP],
+                     f_[0], f_[1], f_[2]);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
 int op_correc(cales_ctx *c, double dt) {
+  if (getenv("CALES_UNFUSED_CORREC") == nullptr) return op_correc_updatep(c, dt, 0., 0);
   ProfScope ps(c, "correc");
   dim3 b(BX, BY, 1), gr = grid3(c->n[0] + 2, c->n[1] + 2, c->n[2] + 2, b);
   hipLaunchKernelGGL(k_correc, gr, b, 0, c->stream, c->g, dt * c->dli[0], dt * c->dli[1], dt, c->d_dzci, c->f[CALES_PP], c->f[CALES_U],
