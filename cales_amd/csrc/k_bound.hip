@@ -99,32 +99,39 @@ static int halo_self(cales_ctx *c, int nf, double **flds) {
     const bool periodic = idir == 2 ? c->per_y : !ISB(c, 0, 3);
     if (!periodic) continue;             // not periodic: neighbours are MPI_PROC_NULL
     BcJobs J; J.njobs = 0; J.idir = idir;
-    for (int q = 0; q < nf; ++q) add_job(J, flds[q], 'P', 0, 1, nullptr, 0.);
+    for (int q = 0; q < nf; ++q) {
+      if (J.njobs == 6) { if (int e = launch_jobs(c, J)) return e; J.njobs = 0; }
+      add_job(J, flds[q], 'P', 0, 1, nullptr, 0.);
+    }
     if (int e = launch_jobs(c, J)) return e;
   }
   return 0;
 }
 
 // ------------------------------------------------------------------------------------------ boundp (bound.f90:156-200)
-int op_boundp(cales_ctx *c, double *p, int which) {
+// nf <= 8 fields with the same BC set in one halo exchange and as few launches as the job table allows
+int op_boundp_multi(cales_ctx *c, int nf, double **p, int which) {
   ProfScope ps(c, "boundp");
   const char *cbc = which == 0 ? c->C.cbcpre : c->C.cbcsgs; const DBound &bc = which == 0 ? c->bcp : c->bcs;
-  double *fl[1] = {p};
-  if (int e = halo_self(c, 1, fl)) return e;
+  if (int e = halo_self(c, nf, p)) return e;
   for (int idir = 1; idir <= 3; ++idir) {
     if (!ISB(c, 0, idir) && !ISB(c, 1, idir)) continue;
     BcJobs J; J.njobs = 0; J.idir = idir;
     const double dr0 = idir < 3 ? c->dl[idir - 1] : c->dzc[0], dr1 = idir < 3 ? c->dl[idir - 1] : c->dzc[c->n[2]];
     const char c0 = cbc[0 + 2 * (idir - 1)], c1 = cbc[1 + 2 * (idir - 1)];
-    if (c0 == 'P') add_job(J, p, 'P', 0, 1, nullptr, 0.);      // both ends in one job (identical result to the two calls)
-    else {
-      if (ISB(c, 0, idir)) add_job(J, p, c0, 0, 1, plane(bc, idir, 0, c->n), dr0);
-      if (ISB(c, 1, idir)) add_job(J, p, c1, 1, 1, plane(bc, idir, 1, c->n), dr1);
+    for (int q = 0; q < nf; ++q) {
+      if (J.njobs + 2 > 6) { if (int e = launch_jobs(c, J)) return e; J.njobs = 0; }
+      if (c0 == 'P') add_job(J, p[q], 'P', 0, 1, nullptr, 0.);      // both ends in one job (identical result to the two calls)
+      else {
+        if (ISB(c, 0, idir)) add_job(J, p[q], c0, 0, 1, plane(bc, idir, 0, c->n), dr0);
+        if (ISB(c, 1, idir)) add_job(J, p[q], c1, 1, 1, plane(bc, idir, 1, c->n), dr1);
+      }
     }
-    if (int e = launch_jobs(c, J)) return e;
+    if (J.njobs) { if (int e = launch_jobs(c, J)) return e; }
   }
   return 0;
 }
+int op_boundp(cales_ctx *c, double *p, int which) { double *fl[1] = {p}; return op_boundp_multi(c, 1, fl, which); }
 
 // ------------------------------------------------------------------------------------------ wall model (wmodel.f90:65-335)
 __device__ inline double vel_relative(double v1, double v2, double coef, double mag) {

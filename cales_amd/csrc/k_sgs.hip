@@ -538,6 +538,7 @@ __global__ __launch_bounds__(256) void k_plane_fold(int n3, int nblk, const doub
 
 int allreduce_res(cales_ctx *c, int slot, int count, int op);
 int op_boundp(cales_ctx *c, double *p, int which);
+int op_boundp_multi(cales_ctx *c, int nf, double **p, int which);
 static bool dsmag_fast_ok(const cales_ctx *c) {
   for (int q = 0; q < 4; ++q) if (c->is_wall[q] != 0.) return false;      // walls in x or y: general path
   for (int q = 0; q < 6; ++q) if (c->C.lwm[q] != 0) return false;         // wall model: general path
@@ -569,11 +570,9 @@ static int dsmag_fast(cales_ctx *c) {
     if (small) hipLaunchKernelGGL(k_strain_tile<unsigned>, mg, mb, 0, c->stream, c->g, S); else hipLaunchKernelGGL(k_strain_tile<size_t>, mg, mb, 0, c->stream, c->g, S); }
   // sgs-type ghost cells: only the periodic exchange matters (products of ghosts = ghosts of products; the wall ghosts are
   // replaced by the extrapolation rule inside the filters)
-  for (int m = 0; m < 6; ++m) if (int e = op_boundp(c, ssij[m], 1)) return e;
+  if (int e = op_boundp_multi(c, 6, ssij, 1)) return e;
   if (int e = op_bounduvw(c, c->bcuf, c->bcvf, c->bcwf, 0, 0, c->uf, c->vf, c->wf)) return e;
-  if (int e = op_boundp(c, c->uc, 1)) return e;
-  if (int e = op_boundp(c, c->vc, 1)) return e;
-  if (int e = op_boundp(c, c->wc, 1)) return e;
+  { double *cc[3] = {c->uc, c->vc, c->wc}; if (int e = op_boundp_multi(c, 3, cc, 1)) return e; }
   // K_B: filter(|S| Sij)
   { ProfScope ps(c, "filter_s0sij");
     tiles(TYB, 64, mb, mg, kch);
