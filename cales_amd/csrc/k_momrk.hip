@@ -161,7 +161,7 @@ int op_momrk(cales_ctx *c, double f1, double f2, double f12) {
   int kchunk = n[2];
   while ((long)gr.x * gr.y * ((n[2] + kchunk - 1) / kchunk) < 2048 && kchunk > 32) kchunk = (kchunk + 1) / 2;
   gr.z = (n[2] + kchunk - 1) / kchunk; A.kchunk = kchunk;
-  const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32);      // 32-bit byte offsets
+  const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32) && getenv("CALES_WIDE_OFFSETS") == nullptr;      // 32-bit byte offsets
   if (c->C.impdiff == 2) { if (small) hipLaunchKernelGGL((k_momrk<2, unsigned>), gr, b, 0, c->stream, c->g, A); else hipLaunchKernelGGL((k_momrk<2, size_t>), gr, b, 0, c->stream, c->g, A); }
   else { if (small) hipLaunchKernelGGL((k_momrk<0, unsigned>), gr, b, 0, c->stream, c->g, A); else hipLaunchKernelGGL((k_momrk<0, size_t>), gr, b, 0, c->stream, c->g, A); }
   HIPCHK(c, hipGetLastError());

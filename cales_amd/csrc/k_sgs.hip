@@ -557,7 +557,7 @@ static int dsmag_fast(cales_ctx *c) {
     mg.z = (n[2] + kchunk - 1) / kchunk;
   };
   dim3 mb, mg; int kch;
-  const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32);      // 32-bit byte offsets (ldb/stb)
+  const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32) && getenv("CALES_WIDE_OFFSETS") == nullptr;      // 32-bit byte offsets (ldb/stb)
   // K_AC: |S|, |S|Sij, cell-centred and test-filtered velocity in one pass over u,v,w (no wall-model faces ->
   // extrapolate(...,lwm) is a no-op; u,v are extrapolated through the z walls, w on the faces is not, sgs.f90:705-710)
   { ProfScope ps(c, "strain_filter_uvw");

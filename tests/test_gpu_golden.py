@@ -122,3 +122,11 @@ def test_fused_step_matches_operator_sequence(name):
     dv = h.chkdiv()
     assert dv[1] < 1e-12 and abs(dv[1]) < 10 * max(g["r3_div"][1], 1e-16) * 10
     h.close()
+
+
+@pytest.mark.parametrize("name", ["chan_dsmag", "duct_smag_wm_imp1d"])
+def test_wide_offset_kernels(name, monkeypatch):
+    """Fields of 4 GB and more (e.g. the 1024^3 cavity) use the size_t instantiations of the tile kernels; force them
+    here on a small case and hold them to the same end-of-step tolerances."""
+    monkeypatch.setenv("CALES_WIDE_OFFSETS", "1")
+    test_fused_step_matches_operator_sequence(name)
