@@ -79,7 +79,17 @@ def cpu_baseline(case_full, seconds_budget=25.0):
         o.step(dt, *st); k += 1
     t = (time.perf_counter() - t0) / k
     ncell_s = float(np.prod(case.ng)); ncell_f = float(np.prod(case_full.ng))
+    o1, dt1, st1 = prepare(1)
+    t0 = time.perf_counter(); o1.step(dt1, *st1); o1.step(dt1, *st1); t_1 = (time.perf_counter() - t0) / 2
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
     return {"value": (1.0 / t) * ncell_s / ncell_f, "unit": "time-steps/s", "cores": cores, "kind": "port",
+            "value_1core": (1.0 / t_1) * ncell_s / ncell_f, "cpu_model": model, "host_threads_available": avail,
             "sample": f"{k} steps of the same case at 128x128x64 ({t:.3f} s/step), scaled by cell count to "
                       f"{'x'.join(str(int(x)) for x in case_full.ng)}; OpenMP over {cores} of {avail} host threads (best of 8/32/128)"}
 
@@ -87,8 +97,8 @@ def cpu_baseline(case_full, seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--ng", type=int, nargs=3, default=[512, 512, 512])
     ap.add_argument("--sgs", default="dsmag", choices=["none", "smag", "dsmag"])
     ap.add_argument("--no-cpu", action="store_true")
@@ -178,6 +188,11 @@ def main():
                          "algorithmic_bytes_per_launch": WORDS[dom] * 8.0 * nloc, "avg_launch_ms": ms / calls, "launches": calls},
             "poisson_solve": {"ms": solve_ms, "algorithmic_GBps": 10 * 8.0 * nloc / (solve_ms * 1e-3) / 1e9 if solve_ms else None,
                               "frac_of_hbm_peak": 10 * 8.0 * nloc / (solve_ms * 1e-3) / HBM_PEAK if solve_ms else None},
+            # north_star: ">= 50 % of the HBM roofline on the Poisson + RK sweep": one solve (10 words) + one fused
+            # momentum/RK pass (14 words) over the time of exactly those kernels
+            "poisson_plus_rk": (lambda ms: {"ms": ms, "algorithmic_GBps": 24 * 8.0 * nloc / (ms * 1e-3) / 1e9,
+                                            "frac_of_hbm_peak": 24 * 8.0 * nloc / (ms * 1e-3) / HBM_PEAK})(
+                solve_ms + stats["mom_rk_fused"][1] / stats["mom_rk_fused"][0]) if solve_ms and stats.get("mom_rk_fused", (0, 0))[0] else None,
             # traffic the reference's kernel-per-loop sequence would move for the same step, over the measured time: >1 is
             # possible and only says that fusion removed traffic; it is NOT a roofline fraction
             "step_vs_reference_traffic": {"reference_GB_per_step": 3 * 8.0 * ncell * W_STEP[case.sgstype] / 1e9,
