@@ -423,6 +423,37 @@ __global__ __launch_bounds__(256) void k_gaussel_split(Geom g, int nz, int ncol,
   }
 }
 
+// Non-periodic z, complex modes: the real and the imaginary part of a mode are two independent systems with the same
+// matrix, so they go to two neighbouring lanes (lane -> mode lane/2, part lane%2; a wave still covers 512 contiguous bytes
+// per row). Twice the waves of k_gaussel<double2,0> for the same traffic: the sweeps are latency-bound chains.
+__global__ __launch_bounds__(256) void k_gaussel_ri(Geom g, int nz, int ncol, int nrow, int mofs, int nmode, Spec S,
+                                                    const double *__restrict__ a, const double *__restrict__ b,
+                                                    const double *__restrict__ c, const double *__restrict__ lamx,
+                                                    const double *__restrict__ lamy, double *__restrict__ p, double *__restrict__ dscr) {
+  // threads run over (row, mode, part) linearly, so a block touches one contiguous piece of a plane per step
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  const int t = (int)(q % (2 * ncol)), m = t >> 1, part = t & 1, j = (int)(q / (2 * ncol)) + 1;
+  if (j > nrow || m + mofs >= nmode) return;
+  const size_t e0 = 2 * S.at_mode(g, m, j, 1) + part;
+  const size_t st = 2 * (S.blocked ? (size_t)S.cw * S.n2l : (size_t)g.s12 / 2);
+  const size_t s0 = (size_t)m + (size_t)ncol * (size_t)(j - 1), sst = (size_t)ncol * nrow;   // scratch [k][j][m]
+  const double lam = lamx[m + mofs] + lamy[j - 1];
+  double z = 1. / (b[0] + lam + CALES_EPS), d = c[0] * z;
+  double v = p[e0] * z;
+  p[e0] = v; dscr[s0] = d;      // both lanes of a pair store the same c' (one merged write); each reads back what it wrote
+  for (int l = 1; l < nz; ++l) {
+    const double bb = b[l] + lam;
+    z = 1. / (bb - a[l] * d + CALES_EPS);
+    d = c[l] * z;
+    v = (p[e0 + l * st] - a[l] * v) * z;
+    p[e0 + l * st] = v; dscr[s0 + l * sst] = d;
+  }
+  for (int l = nz - 2; l >= 0; --l) {
+    v = p[e0 + l * st] - dscr[s0 + l * sst] * v;
+    p[e0 + l * st] = v;
+  }
+}
+
 template <typename VT, int PERIODIC>
 __global__ __launch_bounds__(256) void k_gaussel(Geom g, int nz, int ncol, int nrow, int i0, int mofs, int nmode, Spec S,
                                                  const double *__restrict__ a, const double *__restrict__ b,
@@ -589,7 +620,8 @@ int op_solver(cales_ctx *c) {
     if (c->xkind) hipLaunchKernelGGL(k_gaussel_split, gr, b, 0, c->stream, c->g, n[2], ncol, n2g, mofs, c->C.ng[0] / 2, S, c->d_a, c->d_b, c->d_c, c->d_lamx, c->d_lamy,
                                      (double2 *)mode_spec, (double2 *)c->scr1);
     else if (periodic_z) hipLaunchKernelGGL((k_gaussel<double2, 1>), gr, b, 0, c->stream, c->g, n[2], ncol, n2g, 0, mofs, mh, S, c->d_a, c->d_b, c->d_c, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2);
-    else hipLaunchKernelGGL((k_gaussel<double2, 0>), gr, b, 0, c->stream, c->g, n[2], ncol, n2g, 0, mofs, mh, S, c->d_a, c->d_b, c->d_c, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2); }
+    else if (getenv("CALES_GAUSSEL_PAIR")) hipLaunchKernelGGL((k_gaussel<double2, 0>), gr, b, 0, c->stream, c->g, n[2], ncol, n2g, 0, mofs, mh, S, c->d_a, c->d_b, c->d_c, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2);
+    else hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, n[2], ncol, n2g, mofs, mh, S, c->d_a, c->d_b, c->d_c, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1); }
   { ProfScope ps(c, "fft_y_bwd");
     if (sp->y8) hipLaunchKernelGGL(k_fft_y8<1>, dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, S, mode_spec);
     else hipLaunchKernelGGL(k_fft_y<1>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
