@@ -233,7 +233,7 @@ int op_rk(cales_ctx *c, int irk, double dt) {
   const double f1 = rk[irk - 1][0] * dt, f2 = rk[irk - 1][1] * dt, f12 = f1 + f2;
   double **f = c->f;
   dim3 b(BX, BY, 1), gr = grid3(c->n[0], c->n[1], c->n[2], b);
-  static const bool unfused = getenv("CALES_UNFUSED_RK") != nullptr;
+  const bool unfused = getenv("CALES_UNFUSED_RK") != nullptr;
   if (!unfused && c->n[2] >= 2) {
     if (int e = op_momrk(c, f1, f2, f12)) return e;
   } else {

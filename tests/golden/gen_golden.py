@@ -45,6 +45,8 @@ CASES = {
                   {r"ng\(1:3\) = .*": "ng(1:3) = 10, 12, 8", r"gr = 5\.": "gr = 2."}, 0),
     "chan_dsmag": ("les/_manuscript_turbulent_channel/input.nml",
                    {r"ng\(1:3\) = .*": "ng(1:3) = 12, 8, 10", r"gr = 5\.": "gr = 2.", r"sgstype = 'smag'": "sgstype = 'dsmag'"}, 0),
+    "chan_dsmag_wm": ("les/_manuscript_turbulent_channel_wall_model/input.nml",
+                      {r"ng\(1:3\) = .*": "ng(1:3) = 12, 8, 10", r"visci = .*": "visci = 5640.", r"sgstype = 'smag'": "sgstype = 'dsmag'"}, 0),
     "duct_smag_wm": ("les/_manuscript_turbulent_duct_wall_model/input.nml",
                      {r"ng\(1:3\) = .*": "ng(1:3) = 8, 10, 10"}, 0),
     "duct_smag_wm_imp1d": ("les/_manuscript_turbulent_duct_wall_model/input.nml",
