@@ -328,6 +328,7 @@ struct LijMijArgs {
   const double *dzci, *dzfi;
   double dxi, dyi;
   int kchunk, nblk, zlo, zhi;
+  int wmlo, wmhi; double flo, fhi;      // wall-model z faces: ghost planes of uf,vf by extrapolate(...,lwm), sgs.f90:683-748
 };
 template <typename OFF>
 __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijArgs A) {
@@ -350,12 +351,14 @@ __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijA
     ring[(kbeg - 1) % 3][q][ty][tx] = ldok ? ldb(A.uf[q], c0 + (OFF)(kbeg - 1) * sk) : 0.;
     ring[kbeg % 3][q][ty][tx] = ldok ? ldb(A.uf[q], c0 + (OFF)kbeg * sk) : 0.;
     fn[q] = ldok ? ldb(A.uf[q], c0 + (OFF)(kbeg + 1) * sk) : 0.;
+    if (A.wmlo && kbeg == 1 && q < 2) ring[0][q][ty][tx] = (1. + A.flo) * ring[1][q][ty][tx] - A.flo * fn[q];
   }
   int km = (kbeg - 1) % 3, kc = kbeg % 3, kp = (kbeg + 1) % 3;
   for (int k = kbeg; k <= kend; ++k) {
     const OFF idx = c0 + (OFF)k * sk;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) ring[kp][q][ty][tx] = fn[q];
+    for (int q = 0; q < 3; ++q)
+      ring[kp][q][ty][tx] = (A.wmhi && k == g.n3 && q < 2) ? (1. + A.fhi) * ring[kc][q][ty][tx] - A.fhi * ring[km][q][ty][tx] : fn[q];
     if (k + 2 <= g.n3 + 1) {
 #pragma unroll
       for (int q = 0; q < 3; ++q) { sn[q] = ldok ? ldb(A.uc[q], idx + 2 * sk) : 0.; fn[q] = ldok ? ldb(A.uf[q], idx + 2 * sk) : 0.; }
@@ -437,6 +440,7 @@ struct StrainTileArgs {
   const double *dzci, *dzfi;
   double dxi, dyi;
   int kchunk, zlo, zhi;
+  int wmlo, wmhi; double flo, fhi;      // wall-model z faces: ghost planes of u,v by extrapolate(...,lwm), sgs.f90:683-748
 };
 template <typename OFF>
 __global__ __launch_bounds__(64 * (TYS + 2)) void k_strain_tile(Geom g, StrainTileArgs A) {
@@ -461,12 +465,20 @@ __global__ __launch_bounds__(64 * (TYS + 2)) void k_strain_tile(Geom g, StrainTi
     }
     fn[q] = ldok ? ldb(A.u[q], c0 + (OFF)(kbeg + 1) * sk) : 0.;
     fh[q] = hok ? ldb(A.u[q], ch + (OFF)(kbeg + 1) * sk) : 0.;
+    if (A.wmlo && kbeg == 1 && q < 2) {
+      ring[0][q][ty][tx + 1] = (1. + A.flo) * ring[1][q][ty][tx + 1] - A.flo * fn[q];
+      if (edge) ring[0][q][ty][hx] = (1. + A.flo) * ring[1][q][ty][hx] - A.flo * fh[q];
+    }
   }
   int km = (kbeg - 1) % 3, kc = kbeg % 3, kp = (kbeg + 1) % 3;
   for (int k = kbeg; k <= kend; ++k) {
     const OFF idx = c0 + (OFF)k * sk;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) { ring[kp][q][ty][tx + 1] = fn[q]; if (edge) ring[kp][q][ty][hx] = fh[q]; }
+    for (int q = 0; q < 3; ++q) {
+      const bool ex = A.wmhi && k == g.n3 && q < 2;
+      ring[kp][q][ty][tx + 1] = ex ? (1. + A.fhi) * ring[kc][q][ty][tx + 1] - A.fhi * ring[km][q][ty][tx + 1] : fn[q];
+      if (edge) ring[kp][q][ty][hx] = ex ? (1. + A.fhi) * ring[kc][q][ty][hx] - A.fhi * ring[km][q][ty][hx] : fh[q];
+    }
     if (k + 2 <= g.n3 + 1) {
 #pragma unroll
       for (int q = 0; q < 3; ++q) { fn[q] = ldok ? ldb(A.u[q], idx + 2 * sk) : 0.; fh[q] = hok ? ldb(A.u[q], ch + (OFF)(k + 2) * sk) : 0.; }
@@ -541,7 +553,7 @@ int op_boundp(cales_ctx *c, double *p, int which);
 int op_boundp_multi(cales_ctx *c, int nf, double **p, int which);
 static bool dsmag_fast_ok(const cales_ctx *c) {
   for (int q = 0; q < 4; ++q) if (c->is_wall[q] != 0.) return false;      // walls in x or y: general path
-  for (int q = 0; q < 6; ++q) if (c->C.lwm[q] != 0) return false;         // wall model: general path
+  for (int q = 0; q < 4; ++q) if (c->C.lwm[q] != 0) return false;         // wall model on x or y faces: general path
   return c->n[2] >= 3 && getenv("CALES_DSMAG_REFERENCE_SEQUENCE") == nullptr;
 }
 static int dsmag_fast(cales_ctx *c) {
@@ -549,6 +561,10 @@ static int dsmag_fast(cales_ctx *c) {
   dim3 b(BX, BY, 1), gr = grid3(n[0], n[1], n[2], b);
   double **ssij = c->sij, **mij = c->mij;
   const int zlo = c->is_wall[4] != 0., zhi = c->is_wall[5] != 0.;
+  // wall-model faces in z: the strain rates see ghost planes extrapolated from the interior (extrapolate(...,lwm) with the
+  // grid factor, sgs.f90:683-748) instead of the stress-carrying ghost cells
+  const int wmlo = ISB(c, 0, 3) && LWM(c, 0, 3) != 0, wmhi = ISB(c, 1, 3) && LWM(c, 1, 3) != 0;
+  const double flo = (1. / c->dzci[0]) * c->dzci[1], fhi = (1. / c->dzci[n[2]]) * c->dzci[n[2] - 1];
   // tiles of 62 x TY columns marching in k; k is also split into chunks so that several rounds of blocks balance the chip
   auto tiles = [&](int ty, int wx, dim3 &mb, dim3 &mg, int &kchunk) {
     mb = dim3(64, ty + 2, 1); mg = dim3((n[0] + wx - 1) / wx, (n[1] + ty - 1) / ty, 1);
@@ -566,7 +582,7 @@ static int dsmag_fast(cales_ctx *c) {
     S.u[0] = f[CALES_U]; S.u[1] = f[CALES_V]; S.u[2] = f[CALES_W]; S.s0 = c->s0;
     for (int m = 0; m < 6; ++m) S.ssij[m] = ssij[m];
     S.uc[0] = c->uc; S.uc[1] = c->vc; S.uc[2] = c->wc; S.uf[0] = c->uf; S.uf[1] = c->vf; S.uf[2] = c->wf;
-    S.dzci = c->d_dzci; S.dzfi = c->d_dzfi; S.dxi = c->dli[0]; S.dyi = c->dli[1]; S.kchunk = kch; S.zlo = zlo; S.zhi = zhi;
+    S.dzci = c->d_dzci; S.dzfi = c->d_dzfi; S.dxi = c->dli[0]; S.dyi = c->dli[1]; S.kchunk = kch; S.zlo = zlo; S.zhi = zhi; S.wmlo = wmlo; S.wmhi = wmhi; S.flo = flo; S.fhi = fhi;
     if (small) hipLaunchKernelGGL(k_strain_tile<unsigned>, mg, mb, 0, c->stream, c->g, S); else hipLaunchKernelGGL(k_strain_tile<size_t>, mg, mb, 0, c->stream, c->g, S); }
   // sgs-type ghost cells: only the periodic exchange matters (products of ghosts = ghosts of products; the wall ghosts are
   // replaced by the extrapolation rule inside the filters)
@@ -586,7 +602,7 @@ static int dsmag_fast(cales_ctx *c) {
     L.uc[0] = c->uc; L.uc[1] = c->vc; L.uc[2] = c->wc; L.uf[0] = c->uf; L.uf[1] = c->vf; L.uf[2] = c->wf;
     for (int m = 0; m < 6; ++m) L.mf[m] = mij[m];
     L.part = c->wk[0]; L.dzci = c->d_dzci; L.dzfi = c->d_dzfi; L.dxi = c->dli[0]; L.dyi = c->dli[1];
-    L.kchunk = kch; L.nblk = mg.x * mg.y; L.zlo = zlo; L.zhi = zhi;
+    L.kchunk = kch; L.nblk = mg.x * mg.y; L.zlo = zlo; L.zhi = zhi; L.wmlo = wmlo; L.wmhi = wmhi; L.flo = flo; L.fhi = fhi;
     if ((size_t)2 * n[2] * L.nblk > c->ntot) { c->err = "dsmag: partial-sum scratch too small"; return 1; }
     if (small) hipLaunchKernelGGL(k_lij_mij_tile<unsigned>, mg, mb, 0, c->stream, c->g, L); else hipLaunchKernelGGL(k_lij_mij_tile<size_t>, mg, mb, 0, c->stream, c->g, L);
     hipLaunchKernelGGL(k_plane_fold, dim3(2 * n[2]), dim3(256), 0, c->stream, n[2], L.nblk, c->wk[0], c->d_p1d); }

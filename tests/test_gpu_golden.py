@@ -133,7 +133,7 @@ def test_wide_offset_kernels(name, monkeypatch):
 
 
 @pytest.mark.parametrize("env", ["CALES_DSMAG_REFERENCE_SEQUENCE", "CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC"])
-@pytest.mark.parametrize("name", ["chan_dsmag", "duct_smag_wm_imp1d"])
+@pytest.mark.parametrize("name", ["chan_dsmag", "chan_dsmag_wm", "duct_smag_wm_imp1d"])
 def test_unfused_paths(name, env, monkeypatch):
     """The kernel-per-loop forms behind the operator-level entries (general dsmag sequence, mom + rk_update, correc +
     updatep) stay selectable and are held to the same end-of-step tolerances."""
