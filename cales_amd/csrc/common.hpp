@@ -103,6 +103,7 @@ struct cales_ctx {
   std::vector<KernelStat> stats;
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evpool;
+  double *d_del = nullptr;   // Smagorinsky filter width per plane (fast path)
   int field_ofs = 0;       // doubles between a field's allocation and its element (0,0,0)
 };
 

@@ -441,11 +441,13 @@ struct StrainTileArgs {
   double dxi, dyi;
   int kchunk, zlo, zhi;
   int wmlo, wmhi; double flo, fhi;      // wall-model z faces: ghost planes of u,v by extrapolate(...,lwm), sgs.f90:683-748
+  // SMAG = 1 (static Smagorinsky with van Driest damping for z walls, sgs.f90:98-152): the only output is visct
+  double *visct; const double *zc, *del; double l3, visc;      // del(k) = (dx dy dzf(k))^(1/3)
 };
-template <typename OFF>
+template <typename OFF, int SMAG>
 __global__ __launch_bounds__(64 * (TYS + 2)) void k_strain_tile(Geom g, StrainTileArgs A) {
   __shared__ double ring[3][3][TYS + 2][66];      // rows: x-halo cell, 64 own cells, x-halo cell
-  __shared__ double shs[3][TYS + 2][64];
+  __shared__ double shs[SMAG ? 1 : 3][TYS + 2][64];
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int i = blockIdx.x * 64 + tx + 1, j = blockIdx.y * TYS + ty;        // whole 128-B lines in and out (see cales_create)
   const int kbeg = blockIdx.z * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
@@ -470,6 +472,23 @@ __global__ __launch_bounds__(64 * (TYS + 2)) void k_strain_tile(Geom g, StrainTi
       if (edge) ring[0][q][ty][hx] = (1. + A.flo) * ring[1][q][ty][hx] - A.flo * fh[q];
     }
   }
+  // van Driest: wall units from the shear at the nearer z wall of this column (sgs.f90:117-143), read from the fields
+  // themselves (their ghost cells, not the extrapolated ones)
+  double tw_lo = 0., tw_hi = 0.;
+  if (SMAG && outok) {
+    const double *u = A.u[0], *v = A.u[1];
+    if (A.zlo) {
+      const double t1 = u[g.ix(i, j, 1)] - u[g.ix(i, j, 0)] + u[g.ix(i - 1, j, 1)] - u[g.ix(i - 1, j, 0)];
+      const double t2 = v[g.ix(i, j, 1)] - v[g.ix(i, j, 0)] + v[g.ix(i, j - 1, 1)] - v[g.ix(i, j - 1, 0)];
+      tw_lo = 0.5 * A.visc * (sqrt(t1 * t1 + t2 * t2) * A.dzci[0]);
+    }
+    if (A.zhi) {
+      const int n3 = g.n3;
+      const double t1 = u[g.ix(i, j, n3)] - u[g.ix(i, j, n3 + 1)] + u[g.ix(i - 1, j, n3)] - u[g.ix(i - 1, j, n3 + 1)];
+      const double t2 = v[g.ix(i, j, n3)] - v[g.ix(i, j, n3 + 1)] + v[g.ix(i, j - 1, n3)] - v[g.ix(i, j - 1, n3 + 1)];
+      tw_hi = 0.5 * A.visc * (sqrt(t1 * t1 + t2 * t2) * A.dzci[n3]);
+    }
+  }
   int km = (kbeg - 1) % 3, kc = kbeg % 3, kp = (kbeg + 1) % 3;
   for (int k = kbeg; k <= kend; ++k) {
     const OFF idx = c0 + (OFF)k * sk;
@@ -486,6 +505,7 @@ __global__ __launch_bounds__(64 * (TYS + 2)) void k_strain_tile(Geom g, StrainTi
     __syncthreads();
     const bool lo = A.zlo && k == 1, hi = A.zhi && k == g.n3;
     double r[3];
+    if (!SMAG) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       auto zcomb = [&](int x) {
@@ -499,6 +519,7 @@ __global__ __launch_bounds__(64 * (TYS + 2)) void k_strain_tile(Geom g, StrainTi
       if (edge) { const double Gh = zcomb(hx); if (tx == 0) pv = Gh; else nx = Gh; }
       r[q] = pv + 2. * G + nx;
       shs[q][ty][tx] = r[q];
+    }
     }
     if (outok) {
 #define RU(dk, dj, di) ring[dk][0][ty + (dj)][tx + 1 + (di)]
@@ -522,13 +543,25 @@ __global__ __launch_bounds__(64 * (TYS + 2)) void k_strain_tile(Geom g, StrainTi
       const double s23 = .125 * ((v_ccp - v_ccc) * zc + (w_cpc - w_ccc) * dyi + (v_ccc - v_ccm) * zm + (w_cpm - w_ccm) * dyi +
                                  (v_cmp - v_cmc) * zc + (w_ccc - w_cmc) * dyi + (v_cmc - v_cmm) * zm + (w_ccm - w_cmm) * dyi);
       const double s0v = sqrt(2. * (s11 * s11 + s22 * s22 + s33 * s33 + 2. * (s12 * s12 + s13 * s13 + s23 * s23)));
-      stb(A.s0, idx, s0v);                                              // stands for visct = s0 (sgs.f90:184) until the final kernel
-      stb(A.ssij[0], idx, s0v * s11); stb(A.ssij[1], idx, s0v * s22); stb(A.ssij[2], idx, s0v * s33);      // |S|Sij (sgs.f90:198-210)
-      stb(A.ssij[3], idx, s0v * s12); stb(A.ssij[4], idx, s0v * s13); stb(A.ssij[5], idx, s0v * s23);
-      stb(A.uc[0], idx, 0.5 * (u_ccc + u_mcc)); stb(A.uc[1], idx, 0.5 * (v_ccc + v_cmc)); stb(A.uc[2], idx, 0.5 * (w_ccc + w_ccm));
+      if (SMAG) {
+        double fd = 1.;
+        if (A.zlo || A.zhi) {     // nearest wall: the lower one wins a tie (minloc, sgs.f90:116)
+          const double dlo = A.zlo ? A.zc[k] : CALES_BIG, dhi = A.zhi ? A.l3 - A.zc[k] : CALES_BIG;
+          const bool up = dhi < dlo;
+          const double dw_plus = (up ? dhi : dlo) * sqrt(up ? tw_hi : tw_lo) * (1. / A.visc);
+          fd = 1. - exp(-dw_plus / 25.);
+        }
+        const double t = 0.11 * A.del[k] * fd;      // c_smag, src/param.f90:33
+        stb(A.visct, idx, (t * t) * s0v);
+      } else {
+        stb(A.s0, idx, s0v);                                              // stands for visct = s0 (sgs.f90:184) until the final kernel
+        stb(A.ssij[0], idx, s0v * s11); stb(A.ssij[1], idx, s0v * s22); stb(A.ssij[2], idx, s0v * s33);      // |S|Sij (sgs.f90:198-210)
+        stb(A.ssij[3], idx, s0v * s12); stb(A.ssij[4], idx, s0v * s13); stb(A.ssij[5], idx, s0v * s23);
+        stb(A.uc[0], idx, 0.5 * (u_ccc + u_mcc)); stb(A.uc[1], idx, 0.5 * (v_ccc + v_cmc)); stb(A.uc[2], idx, 0.5 * (w_ccc + w_ccm));
+      }
     }
     __syncthreads();
-    if (outok) {
+    if (!SMAG && outok) {
 #pragma unroll
       for (int q = 0; q < 3; ++q) stb(A.uf[q], idx, (shs[q][ty - 1][tx] + 2. * r[q] + shs[q][ty + 1][tx]) / 64.);
     }
@@ -583,7 +616,7 @@ static int dsmag_fast(cales_ctx *c) {
     for (int m = 0; m < 6; ++m) S.ssij[m] = ssij[m];
     S.uc[0] = c->uc; S.uc[1] = c->vc; S.uc[2] = c->wc; S.uf[0] = c->uf; S.uf[1] = c->vf; S.uf[2] = c->wf;
     S.dzci = c->d_dzci; S.dzfi = c->d_dzfi; S.dxi = c->dli[0]; S.dyi = c->dli[1]; S.kchunk = kch; S.zlo = zlo; S.zhi = zhi; S.wmlo = wmlo; S.wmhi = wmhi; S.flo = flo; S.fhi = fhi;
-    if (small) hipLaunchKernelGGL(k_strain_tile<unsigned>, mg, mb, 0, c->stream, c->g, S); else hipLaunchKernelGGL(k_strain_tile<size_t>, mg, mb, 0, c->stream, c->g, S); }
+    if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 0>), mg, mb, 0, c->stream, c->g, S); else hipLaunchKernelGGL((k_strain_tile<size_t, 0>), mg, mb, 0, c->stream, c->g, S); }
   // sgs-type ghost cells: only the periodic exchange matters (products of ghosts = ghosts of products; the wall ghosts are
   // replaced by the extrapolation rule inside the filters)
   if (int e = op_boundp_multi(c, 6, ssij, 1)) return e;
@@ -615,6 +648,40 @@ static int dsmag_fast(cales_ctx *c) {
 
 static inline dim3 lin_grid(size_t n) { size_t b = (n + 255) / 256; if (b > 4096) b = 4096; return dim3((unsigned)b); }
 
+// Static Smagorinsky for cases whose only walls are in z (channels, with or without wall model): strain rate and van Driest
+// damping in one pass of the tile kernel, u,v,w -> visct (4 words/cell instead of the 20 of copy + extrapolate + strain + smag)
+static bool smag_fast_ok(const cales_ctx *c) {
+  for (int q = 0; q < 4; ++q) if (c->is_wall[q] != 0. || c->C.lwm[q] != 0) return false;
+  return c->n[2] >= 3 && getenv("CALES_SMAG_REFERENCE_SEQUENCE") == nullptr;
+}
+__global__ void k_smag_del(int n, double dl1, double dl2, const double *__restrict__ dzf, double *__restrict__ del) {
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k < n) del[k] = pow(dl1 * dl2 * dzf[k], 1. / 3.);       // the filter width depends on k only (sgs.f90:145)
+}
+static int smag_fast(cales_ctx *c) {
+  const int *n = c->n; double **f = c->f;
+  if (!c->d_del) {
+    HIPCHK(c, hipMalloc(&c->d_del, (n[2] + 2) * sizeof(double)));
+    hipLaunchKernelGGL(k_smag_del, dim3((n[2] + 2 + 63) / 64), dim3(64), 0, c->stream, n[2] + 2, c->dl[0], c->dl[1], c->d_dzf, c->d_del);
+  }
+  dim3 mb(64, TYS + 2, 1), mg((n[0] + 63) / 64, (n[1] + TYS - 1) / TYS, 1);
+  int kch = n[2];
+  while ((long)mg.x * mg.y * ((n[2] + kch - 1) / kch) < 2048 && kch > 32) kch = (kch + 1) / 2;
+  mg.z = (n[2] + kch - 1) / kch;
+  StrainTileArgs S = {};
+  S.u[0] = f[CALES_U]; S.u[1] = f[CALES_V]; S.u[2] = f[CALES_W]; S.visct = f[CALES_VISCT];
+  S.dzci = c->d_dzci; S.dzfi = c->d_dzfi; S.dxi = c->dli[0]; S.dyi = c->dli[1]; S.kchunk = kch;
+  S.zlo = c->is_wall[4] != 0.; S.zhi = c->is_wall[5] != 0.;
+  S.wmlo = ISB(c, 0, 3) && LWM(c, 0, 3) != 0; S.wmhi = ISB(c, 1, 3) && LWM(c, 1, 3) != 0;
+  S.flo = (1. / c->dzci[0]) * c->dzci[1]; S.fhi = (1. / c->dzci[n[2]]) * c->dzci[n[2] - 1];
+  S.zc = c->d_zc; S.del = c->d_del; S.l3 = c->C.l[2]; S.visc = c->visc;
+  const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32) && getenv("CALES_WIDE_OFFSETS") == nullptr;
+  if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 1>), mg, mb, 0, c->stream, c->g, S);
+  else hipLaunchKernelGGL((k_strain_tile<size_t, 1>), mg, mb, 0, c->stream, c->g, S);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 int op_cmpt_sgs(cales_ctx *c) {
   const int *n = c->n; const size_t nt = c->ntot;
   double **f = c->f; double *visct = f[CALES_VISCT];
@@ -631,6 +698,7 @@ int op_cmpt_sgs(cales_ctx *c) {
                          c->is_wall[2], c->is_wall[3], c->is_wall[4], c->is_wall[5], c->alph2);
   }
   if (c->C.sgstype == 2 && dsmag_fast_ok(c)) return dsmag_fast(c);
+  if (c->C.sgstype == 1 && smag_fast_ok(c)) return smag_fast(c);
   double **wk = c->wk;
   // wk(1:3) = u,v,w ; extrapolate at wall-model faces ; strain rate (sgs.f90:84-92 / 173-181)
   hipLaunchKernelGGL(k_copy3, lin_grid(nt), dim3(256), 0, c->stream, nt, f[CALES_U], f[CALES_V], f[CALES_W], wk[0], wk[1], wk[2]);

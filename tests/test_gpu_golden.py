@@ -139,3 +139,10 @@ def test_unfused_paths(name, env, monkeypatch):
     updatep) stay selectable and are held to the same end-of-step tolerances."""
     monkeypatch.setenv(env, "1")
     test_fused_step_matches_operator_sequence(name)
+
+
+@pytest.mark.parametrize("name", ["chan_smag", "chan_smag_wm"])
+def test_smag_reference_sequence(name, monkeypatch):
+    """Static Smagorinsky through the kernel-per-loop sequence (the path ducts and cavities take)."""
+    monkeypatch.setenv("CALES_SMAG_REFERENCE_SEQUENCE", "1")
+    test_startup_and_substeps(name)
