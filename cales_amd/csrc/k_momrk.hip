@@ -63,10 +63,10 @@ __global__ __launch_bounds__(64 * (TYM + 2), 4) void k_momrk(Geom g, MomRkArgs A
       const double duo = ldb(A.duo, c), dvo = ldb(A.dvo, c), dwo = ldb(A.dwo, c);
       const int km = (k - 1) & 3, kc = k & 3, kp = (k + 1) & 3;
 #define LS(f, sl, di, dj) sh[f][sl][ty + (dj)][tx + 1 + (di)]
-      const double u_ccm = LS(0, km, 0, 0), u_pcm = LS(0, km, 1, 0), u_cpm = LS(0, km, 0, 1), u_cmc = LS(0, kc, 0, -1), u_mcc = LS(0, kc, -1, 0),
+      const double u_ccm = LS(0, km, 0, 0), u_cmc = LS(0, kc, 0, -1), u_mcc = LS(0, kc, -1, 0),
                    u_ccc = LS(0, kc, 0, 0), u_pcc = LS(0, kc, 1, 0), u_mpc = LS(0, kc, -1, 1), u_cpc = LS(0, kc, 0, 1), u_mcp = LS(0, kp, -1, 0),
                    u_ccp = LS(0, kp, 0, 0);
-      const double v_ccm = LS(1, km, 0, 0), v_cpm = LS(1, km, 0, 1), v_cmc = LS(1, kc, 0, -1), v_pmc = LS(1, kc, 1, -1), v_mcc = LS(1, kc, -1, 0),
+      const double v_ccm = LS(1, km, 0, 0), v_cmc = LS(1, kc, 0, -1), v_pmc = LS(1, kc, 1, -1), v_mcc = LS(1, kc, -1, 0),
                    v_ccc = LS(1, kc, 0, 0), v_pcc = LS(1, kc, 1, 0), v_cpc = LS(1, kc, 0, 1), v_cmp = LS(1, kp, 0, -1), v_ccp = LS(1, kp, 0, 0);
       const double w_ccm = LS(2, km, 0, 0), w_pcm = LS(2, km, 1, 0), w_cpm = LS(2, km, 0, 1), w_cmc = LS(2, kc, 0, -1), w_mcc = LS(2, kc, -1, 0),
                    w_ccc = LS(2, kc, 0, 0), w_pcc = LS(2, kc, 1, 0), w_cpc = LS(2, kc, 0, 1), w_ccp = LS(2, kp, 0, 0);

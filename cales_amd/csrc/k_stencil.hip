@@ -25,10 +25,10 @@ __global__ __launch_bounds__(BX *BY) void k_mom(Geom g, const double *__restrict
   const size_t c = g.ix(i, j, k);
   const long sj = g.s1, sk = g.s12;
 #define LD(a, di, dj, dk) a[c + (di) + (dj)*sj + (dk)*sk]
-  const double u_ccm = LD(u, 0, 0, -1), u_pcm = LD(u, 1, 0, -1), u_cpm = LD(u, 0, 1, -1), u_cmc = LD(u, 0, -1, 0),
+  const double u_ccm = LD(u, 0, 0, -1), u_cmc = LD(u, 0, -1, 0),
                u_mcc = LD(u, -1, 0, 0), u_ccc = LD(u, 0, 0, 0), u_pcc = LD(u, 1, 0, 0), u_mpc = LD(u, -1, 1, 0),
                u_cpc = LD(u, 0, 1, 0), u_mcp = LD(u, -1, 0, 1), u_ccp = LD(u, 0, 0, 1);
-  const double v_ccm = LD(v, 0, 0, -1), v_cpm = LD(v, 0, 1, -1), v_cmc = LD(v, 0, -1, 0), v_pmc = LD(v, 1, -1, 0),
+  const double v_ccm = LD(v, 0, 0, -1), v_cmc = LD(v, 0, -1, 0), v_pmc = LD(v, 1, -1, 0),
                v_mcc = LD(v, -1, 0, 0), v_ccc = LD(v, 0, 0, 0), v_pcc = LD(v, 1, 0, 0), v_cpc = LD(v, 0, 1, 0),
                v_cmp = LD(v, 0, -1, 1), v_ccp = LD(v, 0, 0, 1);
   const double w_ccm = LD(w, 0, 0, -1), w_pcm = LD(w, 1, 0, -1), w_cpm = LD(w, 0, 1, -1), w_cmc = LD(w, 0, -1, 0),
