@@ -104,6 +104,7 @@ struct cales_ctx {
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evpool;
   double *d_del = nullptr;   // Smagorinsky filter width per plane (fast path)
+  int bc_skip = 0;         // bit d-1: boundp/bounduvw leave direction d alone (set around calls whose consumers do not need it)
   int field_ofs = 0;       // doubles between a field's allocation and its element (0,0,0)
 };
 

@@ -116,6 +116,7 @@ int op_boundp_multi(cales_ctx *c, int nf, double **p, int which) {
   if (int e = halo_self(c, nf, p)) return e;
   for (int idir = 1; idir <= 3; ++idir) {
     if (!ISB(c, 0, idir) && !ISB(c, 1, idir)) continue;
+    if (c->bc_skip >> (idir - 1) & 1) continue;
     BcJobs J; J.njobs = 0; J.idir = idir;
     const double dr0 = idir < 3 ? c->dl[idir - 1] : c->dzc[0], dr1 = idir < 3 ? c->dl[idir - 1] : c->dzc[c->n[2]];
     const char c0 = cbc[0 + 2 * (idir - 1)], c1 = cbc[1 + 2 * (idir - 1)];
@@ -278,6 +279,7 @@ int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm
   DBound *bnd[3] = {&bu, &bv, &bw};
   for (int idir = 1; idir <= 3; ++idir) {
     if (!ISB(c, 0, idir) && !ISB(c, 1, idir)) continue;
+    if (c->bc_skip >> (idir - 1) & 1) continue;
     BcJobs J; J.njobs = 0; J.idir = idir;
     const bool periodic = CBV(c, 0, idir, idir) == 'P' && CBV(c, 1, idir, idir) == 'P';
     const bool impose_norm = (!is_correc) || periodic;

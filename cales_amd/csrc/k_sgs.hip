@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void k_alph2(Geom g, double w0, double w1, dou
 #ifndef TYB
 #define TYB 14
 #endif
-struct Filter6Args { const double *in[6]; double *out[6]; int kchunk, zlo, zhi; };
+struct Filter6Args { const double *in[6]; double *out[6]; int kchunk, zlo, zhi, perx; };   // perx: x ghost columns are not stored, wrap around
 // K_B: top-hat filter of six fields (the products |S|Sij). Tile = 64 x TYB outputs from i = 1 + 64 bx (whole 128-B lines in and
 // out); x combination first, on the plane just loaded (lanes 0 and 63 also load the x-halo cell beside them), then three
 // x-combined planes of the own cell roll in registers for the z combination, y neighbours through LDS.
@@ -270,7 +270,8 @@ __global__ __launch_bounds__(64 * (TYB + 2)) void k_filter6_tile(Geom g, Filter6
   const int ih = tx == 0 ? i - 1 : i + 1;
   const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1, hok = edge && ih <= g.n1 + 1 && j <= g.n2 + 1;
   const bool outok = ty >= 1 && ty <= TYB && i <= g.n1 && j <= g.n2;
-  const OFF c0 = ldok ? (OFF)g.ix(i, j, 0) * 8 : 0, ch = hok ? (OFF)g.ix(ih, j, 0) * 8 : 0, sk = (OFF)g.s12 * 8;   // byte offsets
+  const int iw = (A.perx && i == g.n1 + 1) ? 1 : i, ihw = A.perx ? (ih == 0 ? g.n1 : (ih == g.n1 + 1 ? 1 : ih)) : ih;     // periodic x without ghost columns
+  const OFF c0 = ldok ? (OFF)g.ix(iw, j, 0) * 8 : 0, ch = hok ? (OFF)g.ix(ihw, j, 0) * 8 : 0, sk = (OFF)g.s12 * 8;   // byte offsets
   auto load = [&](int kk, double *r, double *h) {
 #pragma unroll
     for (int q = 0; q < 6; ++q) { r[q] = ldok ? ldb(A.in[q], c0 + (OFF)kk * sk) : 0.; h[q] = hok ? ldb(A.in[q], ch + (OFF)kk * sk) : 0.; }
@@ -329,6 +330,7 @@ struct LijMijArgs {
   double dxi, dyi;
   int kchunk, nblk, zlo, zhi;
   int wmlo, wmhi; double flo, fhi;      // wall-model z faces: ghost planes of uf,vf by extrapolate(...,lwm), sgs.f90:683-748
+  int perx;                             // x ghost columns of uc.., uf.. are not stored: wrap around
 };
 template <typename OFF>
 __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijArgs A) {
@@ -341,7 +343,8 @@ __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijA
   const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1;
   const bool outok = tx >= 1 && tx <= 62 && ty >= 1 && ty <= TYF && i <= g.n1 && j <= g.n2;
   const bool inner = ty >= 1 && ty <= TYF;
-  const OFF c0 = ldok ? (OFF)g.ix(i, j, 0) * 8 : 0, sk = (OFF)g.s12 * 8;      // byte offsets
+  const int iw = A.perx ? (i == 0 ? g.n1 : (i == g.n1 + 1 ? 1 : i)) : i;
+  const OFF c0 = ldok ? (OFF)g.ix(iw, j, 0) * 8 : 0, sk = (OFF)g.s12 * 8;      // byte offsets
   double sm[3], sc[3], sp[3], sn[3], fn[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
@@ -619,13 +622,23 @@ static int dsmag_fast(cales_ctx *c) {
     if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 0>), mg, mb, 0, c->stream, c->g, S); else hipLaunchKernelGGL((k_strain_tile<size_t, 0>), mg, mb, 0, c->stream, c->g, S); }
   // sgs-type ghost cells: only the periodic exchange matters (products of ghosts = ghosts of products; the wall ghosts are
   // replaced by the extrapolation rule inside the filters)
-  if (int e = op_boundp_multi(c, 6, ssij, 1)) return e;
-  if (int e = op_bounduvw(c, c->bcuf, c->bcvf, c->bcwf, 0, 0, c->uf, c->vf, c->wf)) return e;
-  { double *cc[3] = {c->uc, c->vc, c->wc}; if (int e = op_boundp_multi(c, 3, cc, 1)) return e; }
+  // These twelve scratch fields are read by the tile kernels only: with periodic x their ghost columns are not filled (the
+  // kernels wrap around instead; an x ghost update touches four cache lines per row for two values), and the z ghost planes
+  // of the quantities the wall rule covers are never read.
+  const int perx = (CBP(c, 0, 1) == 'P' && CBP(c, 1, 1) == 'P' && getenv("CALES_DSMAG_XGHOSTS") == nullptr) ? 1 : 0;
+  const int skipz = (zlo && zhi) ? 4 : 0;
+  c->bc_skip = perx | skipz;
+  int e_ = op_boundp_multi(c, 6, ssij, 1);
+  c->bc_skip = perx;
+  if (!e_) e_ = op_bounduvw(c, c->bcuf, c->bcvf, c->bcwf, 0, 0, c->uf, c->vf, c->wf);
+  c->bc_skip = perx | skipz;
+  if (!e_) { double *cc[3] = {c->uc, c->vc, c->wc}; e_ = op_boundp_multi(c, 3, cc, 1); }
+  c->bc_skip = 0;
+  if (e_) return e_;
   // K_B: filter(|S| Sij)
   { ProfScope ps(c, "filter_s0sij");
     tiles(TYB, 64, mb, mg, kch);
-    Filter6Args A; A.kchunk = kch; A.zlo = zlo; A.zhi = zhi;
+    Filter6Args A; A.kchunk = kch; A.zlo = zlo; A.zhi = zhi; A.perx = perx;
     for (int m = 0; m < 6; ++m) { A.in[m] = ssij[m]; A.out[m] = mij[m]; }
     if (small) hipLaunchKernelGGL(k_filter6_tile<unsigned>, mg, mb, 0, c->stream, c->g, A); else hipLaunchKernelGGL(k_filter6_tile<size_t>, mg, mb, 0, c->stream, c->g, A); }
   // K_DF: strain rate of the filtered velocity, Mij, Lij, contractions and plane partial sums in one pass
@@ -635,7 +648,7 @@ static int dsmag_fast(cales_ctx *c) {
     L.uc[0] = c->uc; L.uc[1] = c->vc; L.uc[2] = c->wc; L.uf[0] = c->uf; L.uf[1] = c->vf; L.uf[2] = c->wf;
     for (int m = 0; m < 6; ++m) L.mf[m] = mij[m];
     L.part = c->wk[0]; L.dzci = c->d_dzci; L.dzfi = c->d_dzfi; L.dxi = c->dli[0]; L.dyi = c->dli[1];
-    L.kchunk = kch; L.nblk = mg.x * mg.y; L.zlo = zlo; L.zhi = zhi; L.wmlo = wmlo; L.wmhi = wmhi; L.flo = flo; L.fhi = fhi;
+    L.kchunk = kch; L.nblk = mg.x * mg.y; L.zlo = zlo; L.zhi = zhi; L.wmlo = wmlo; L.wmhi = wmhi; L.flo = flo; L.fhi = fhi; L.perx = perx;
     if ((size_t)2 * n[2] * L.nblk > c->ntot) { c->err = "dsmag: partial-sum scratch too small"; return 1; }
     if (small) hipLaunchKernelGGL(k_lij_mij_tile<unsigned>, mg, mb, 0, c->stream, c->g, L); else hipLaunchKernelGGL(k_lij_mij_tile<size_t>, mg, mb, 0, c->stream, c->g, L);
     hipLaunchKernelGGL(k_plane_fold, dim3(2 * n[2]), dim3(256), 0, c->stream, n[2], L.nblk, c->wk[0], c->d_p1d); }
