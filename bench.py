@@ -182,7 +182,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"turbulent channel {case.ng[0]}x{case.ng[1]}x{case.ng[2]}, sgstype={case.sgstype}, "
                                    "PP/PP/NN pressure BCs, bulk forcing in x (BASELINE.json configs[2]); 3 RK substeps/step",
-                       "decomposition": f"y-slabs x{world}" if world > 1 else "single GPU", "dt": dt},
+                       "decomposition": f"y-slabs x{world}" if world > 1 else "single GPU", "dt": dt,
+                       "exchanges": ("RCCL from the library" if getattr(h, "native", False) else "torch.distributed callbacks") if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": ach / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": WORDS[dom] * 8.0 * nloc, "avg_launch_ms": ms / calls, "launches": calls},

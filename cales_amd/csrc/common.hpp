@@ -104,6 +104,7 @@ struct cales_ctx {
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evpool;
   double *d_del = nullptr;   // Smagorinsky filter width per plane (fast path)
+  void *native_comm = nullptr;   // RCCL communicator + staging buffers when the library does the exchanges itself (comm_rccl.cpp)
   int bc_skip = 0;         // bit d-1: boundp/bounduvw leave direction d alone (set around calls whose consumers do not need it)
   int field_ofs = 0;       // doubles between a field's allocation and its element (0,0,0)
 };
@@ -155,6 +156,7 @@ int op_fillps(cales_ctx *c, double dtrki);
 int op_updt_rhs_b(cales_ctx *c);
 int op_solver(cales_ctx *c);
 int op_helmholtz_z(cales_ctx *c, int ivel, double alpha);
+extern "C" void cales_comm_release_native(cales_ctx *c);
 int op_correc(cales_ctx *c, double dtrk);
 int op_correc_updatep(cales_ctx *c, double dtrk, double alpha, int upd);
 int op_updatep(cales_ctx *c, double alpha);

@@ -15,6 +15,7 @@ libcales_hip.so packs/unpacks on the device and calls back for the three exchang
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 from typing import List, Optional
 
@@ -157,7 +158,7 @@ class SlabHotPath(HotPath):
     """HotPath of one rank of a y-slab decomposition. `comm_factory(A, B, periodic_y, stream)` builds the exchanger."""
 
     def __init__(self, case: Case, dist=None, torch=None, nranks: Optional[int] = None, rank: Optional[int] = None,
-                 loopback: Optional[LoopbackWorld] = None):
+                 loopback: Optional[LoopbackWorld] = None, native: Optional[bool] = None):
         if torch is None:
             import torch as _t
             torch = _t
@@ -176,6 +177,13 @@ class SlabHotPath(HotPath):
         n = C.c_int64(0)
         self._chk(self.L.cales_comm_buffer_doubles(self.h, C.byref(n)))
         self.nbuf = n.value
+        # exchanges: by the library itself with RCCL (default for real process groups on GPUs; CALES_COMM=torch disables), or
+        # through callbacks into torch.distributed / the loopback world
+        if native is None:
+            native = loopback is None and os.environ.get("CALES_COMM", "rccl") == "rccl" and dist.get_backend() == "nccl"
+        self.native = bool(native) and self._init_native(dist)
+        if self.native:
+            return
         with torch.cuda.stream(self.stream):
             self.A = torch.zeros(self.nbuf, dtype=torch.float64, device="cuda")
             self.B = torch.zeros(self.nbuf, dtype=torch.float64, device="cuda")
@@ -191,6 +199,21 @@ class SlabHotPath(HotPath):
                     ARED_CB(lambda u, o, n_, op: self._guard(self.comm.allreduce, o, n_, op)))
         self._chk(self.L.cales_set_comm(self.h, self._cb[0], self._cb[1], self._cb[2], None,
                                         C.c_void_p(self.A.data_ptr()), C.c_void_p(self.B.data_ptr()), C.c_int64(self.nbuf)))
+
+    def _init_native(self, dist) -> bool:
+        """Rank 0 creates the RCCL rendezvous token, torch.distributed carries it, every rank joins (collective). All ranks
+        take the same branch: the decision travels with the broadcast."""
+        token = [None]
+        if dist.get_rank() == 0:
+            buf = (C.c_ubyte * 128)()
+            if self.L.cales_comm_unique_id(buf) == 0:
+                token[0] = bytes(buf)
+        dist.broadcast_object_list(token, src=0)
+        if token[0] is None:
+            return False
+        buf = (C.c_ubyte * 128).from_buffer_copy(token[0])
+        self._chk(self.L.cales_comm_init_rccl(self.h, buf))
+        return True
 
     def _guard(self, fn, *a) -> int:
         try:

@@ -106,6 +106,15 @@ typedef int (*cales_allreduce_cb)(void *user, int64_t off, int64_t count, int op
 int cales_comm_buffer_doubles(const cales_ctx *ctx, int64_t *n);      /* required size of A and of B */
 int cales_set_comm(cales_ctx *ctx, cales_halo_cb halo, cales_alltoall_cb a2a, cales_allreduce_cb allred, void *user,
                    double *bufA, double *bufB, int64_t nbuf);
+/* Native alternative to cales_set_comm: the library performs the three exchanges itself with RCCL (xGMI) on the context's
+ * stream -- grouped ncclSend/ncclRecv for the halo rows, ncclAllToAll for the transposition of the Poisson solve (one pair
+ * per solve where src/solver.f90:50-66 needs four pencil transposes), ncclAllReduce for the reductions. Rank 0 obtains the
+ * rendezvous token, the host distributes it (MPI_Bcast, torch.distributed, a file ...), then every rank calls
+ * cales_comm_init_rccl, which is collective. RCCL is opened at run time; without it these calls fail and cales_set_comm remains. */
+#define CALES_COMM_ID_BYTES 128
+int cales_comm_unique_id(void *id_out);                       /* rank 0 only; writes CALES_COMM_ID_BYTES bytes */
+int cales_comm_init_rccl(cales_ctx *ctx, const void *id);     /* all ranks */
+int cales_comm_selftest(void);                                /* one-rank communicator: halo order, all-to-all, all-reduce; 0 = ok */
 /* initial field of the rank's slab only (local haloed arrays); the volume mean is summed in the global order */
 int cales_initflow_slab(const cales_case *c, const char *inivel, int is_wallturb, double *u, double *v, double *w, double *p);
 

@@ -80,3 +80,17 @@ def test_slab_initflow_equals_global():
             assert capi.lib().cales_initflow_slab(C.byref(cs), case.inivel.encode(), int(case.is_wallturb), *[_p(a) for a in loc]) == 0
             for a, b in zip(loc, (u, v, w, p)):
                 assert np.array_equal(a[1:-1, 1:-1, 1:-1], b[1:-1, r * n2l + 1:(r + 1) * n2l + 1, 1:-1])
+
+
+def test_native_rccl_selftest():
+    """comm_rccl.cpp on a one-rank communicator: send/recv order of the halo rows, all-to-all, all-reduce."""
+    from cales_amd import capi
+    assert capi.lib().cales_comm_selftest() == 0
+
+
+def test_native_rccl_one_rank_process_group():
+    """The launch path of `bench.py --gpus N` with N = 1 forced through the slab layer (tests/_nccl1_worker.py)."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "_nccl1_worker.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "NCCL1 OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
