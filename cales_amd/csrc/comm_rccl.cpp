@@ -10,6 +10,7 @@
 // RCCL is opened with dlopen: the library keeps loading (and the single-GPU path keeps working) where it is absent.
 #include "common.hpp"
 #include <dlfcn.h>
+#include <link.h>
 #include <rccl/rccl.h>
 
 namespace {
@@ -29,10 +30,20 @@ struct RcclApi {
 };
 RcclApi g_api;
 
+// A process that already carries an RCCL (PyTorch wheels bundle their own, built for the HIP runtime they also bundle) must
+// keep using THAT copy: a second copy from another ROCm release would run on a runtime it was not built for.
+int find_loaded_rccl(struct dl_phdr_info *info, size_t, void *out) {
+  const char *nm = info->dlpi_name;
+  if (nm && std::strstr(nm, "librccl.so")) { *static_cast<std::string *>(out) = nm; return 1; }
+  return 0;
+}
 bool load_api() {
   if (g_api.lib) return true;
+  std::string loaded;
+  dl_iterate_phdr(find_loaded_rccl, &loaded);
+  if (!loaded.empty()) g_api.lib = dlopen(loaded.c_str(), RTLD_NOW | RTLD_LOCAL);
   const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char *nm : names) { g_api.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (g_api.lib) break; }
+  for (const char *nm : names) { if (g_api.lib) break; g_api.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL); }
   if (!g_api.lib) { g_api.err = "RCCL not found (dlopen librccl.so.1)"; return false; }
   bool ok = true;
   auto sym = [&](const char *nm) { void *p = dlsym(g_api.lib, nm); if (!p) { ok = false; g_api.err = std::string("RCCL symbol missing: ") + nm; } return p; };
