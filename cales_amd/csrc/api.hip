@@ -275,6 +275,7 @@ int cales_bulk_mean(cales_ctx *c, int field, int c_or_f, double *mean) {
 int cales_fillps(cales_ctx *c, double dtrki) { return op_fillps(c, dtrki); }
 int cales_updt_rhs_b(cales_ctx *c) { return op_updt_rhs_b(c); }
 int cales_solver(cales_ctx *c) { return op_solver(c); }
+int cales_helmholtz(cales_ctx *c, int ivel, double alpha) { return op_helmholtz(c, ivel, alpha); }
 int cales_helmholtz_z(cales_ctx *c, int ivel, double alpha) { if (ivel < 1 || ivel > 3) { c->err = "ivel must be 1..3"; return 1; } return op_helmholtz_z(c, ivel, alpha); }
 int cales_correc(cales_ctx *c, double dtrk) { return op_correc(c, dtrk); }
 int cales_updatep(cales_ctx *c, double alpha) { return op_updatep(c, alpha); }
@@ -296,13 +297,16 @@ int cales_step(cales_ctx *c, double dt) {
     if (c->C.impdiff == 2) {
       alpha = -.5 * c->visc * dtrk;
       for (int iv = 1; iv <= 3; ++iv) if (int e = op_helmholtz_z(c, iv, alpha)) return e;
+    } else if (c->C.impdiff == 1) {
+      alpha = -.5 * c->visc * dtrk;
+      for (int iv = 1; iv <= 3; ++iv) if (int e = op_helmholtz(c, iv, alpha)) return e;
     }
     if (int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 0, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W])) return e;
     if (int e = op_fillps(c, dtrki)) return e;
     if (int e = op_updt_rhs_b(c)) return e;
     if (int e = op_solver(c)) return e;
     if (int e = op_boundp(c, c->f[CALES_PP], 0)) return e;
-    const bool fuse_cu = getenv("CALES_UNFUSED_CORREC") == nullptr;     // updatep only needs pp: one pass with correc
+    const bool fuse_cu = getenv("CALES_UNFUSED_CORREC") == nullptr && c->C.impdiff != 1;     // updatep only needs pp: one pass with correc
     if (int e = (fuse_cu ? op_correc_updatep(c, dtrk, alpha, 1) : op_correc(c, dtrk))) return e;
     if (int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 1, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W])) return e;
     if (!fuse_cu) { if (int e = op_updatep(c, alpha)) return e; }

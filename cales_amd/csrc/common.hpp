@@ -157,6 +157,7 @@ int op_updt_rhs_b(cales_ctx *c);
 int op_solver(cales_ctx *c);
 int op_helmholtz_z(cales_ctx *c, int ivel, double alpha);
 extern "C" void cales_comm_release_native(cales_ctx *c);
+int op_helmholtz(cales_ctx *c, int ivel, double alpha);
 int op_correc(cales_ctx *c, double dtrk);
 int op_correc_updatep(cales_ctx *c, double dtrk, double alpha, int upd);
 int op_updatep(cales_ctx *c, double alpha);

@@ -233,8 +233,11 @@ int hs_check_case(const cales_case *cs, std::string &msg) {
   if (cs->sgstype < 0 || cs->sgstype > 2) { msg = "unknown SGS model"; return 1; }
   if (cs->sgstype == 1 && cs->nranks > 2 && cs->cbcvel[0 + 2 * 1 + 6 * 1] == 'D' && cs->cbcvel[1 + 2 * 1 + 6 * 1] == 'D') {
     msg = "more than two subdomains between two opposite walls (sanity.f90:98-111)"; return 1; }
-  if (cs->impdiff == 1) { msg = "3-D implicit diffusion (_IMPDIFF without _IMPDIFF_1D) is not provided by this build"; return 1; }
-  if (cs->impdiff != 0 && cs->impdiff != 2) { msg = "impdiff must be 0 or 2"; return 1; }
+  if (cs->impdiff == 1) {   // Helmholtz solves of the velocity need face-centred transform kinds unless x and y are periodic
+    for (int iv = 0; iv < 3; ++iv) for (int q = 0; q < 4; ++q)
+      if (cs->cbcvel[6 * iv + q] != 'P') { msg = "3-D implicit diffusion (_IMPDIFF without _IMPDIFF_1D) is provided for periodic x and y only"; return 1; }
+  }
+  if (cs->impdiff < 0 || cs->impdiff > 2) { msg = "impdiff must be 0, 1 or 2"; return 1; }
   // transforms offered in x,y: periodic and cell-centred Neumann-Neumann (what the reference's GPU path offers, sanity.f90:265-273)
   for (int d = 0; d < 2; ++d) { const std::string bp = pr(cs->cbcpre, d); if (bp != "PP" && bp != "NN") { msg = "pressure BC pair in x/y must be PP or NN on the device path"; return 1; } }
   return 0;

@@ -133,6 +133,7 @@ __global__ __launch_bounds__(64 * (TYM + 2), 4) void k_momrk(Geom g, MomRkArgs A
                             (visc_kp * (dwdz_kp + dwdz_kp) - visc_km * (dwdz_km + dwdz_km)) * dzci_k;
       double du, dv, dw, dud = 0., dvd = 0., dwd = 0.;
       if (IMP == 2) { du = dudt_s + dudtd_xy; dv = dvdt_s + dvdtd_xy; dw = dwdt_s + dwdtd_xy; dud = dudtd_z; dvd = dvdtd_z; dwd = dwdtd_z; }   // mom.f90:278-284
+      else if (IMP == 1) { du = dudt_s; dv = dvdt_s; dw = dwdt_s; dud = dudtd_xy + dudtd_z; dvd = dvdtd_xy + dvdtd_z; dwd = dwdtd_xy + dwdtd_z; }       // mom.f90:285-288
       else { du = dudt_s + dudtd_xy + dudtd_z; dv = dvdt_s + dvdtd_xy + dvdtd_z; dw = dwdt_s + dwdtd_xy + dwdtd_z; }                        // mom.f90:297-302
       // ---- RK update (rk.f90:81-91)
       double un = u_ccc + A.f1 * du + A.f2 * duo + A.f12 * (A.bfx - dxi * (p_pcc - p_ccc));
@@ -163,6 +164,7 @@ int op_momrk(cales_ctx *c, double f1, double f2, double f12) {
   gr.z = (n[2] + kchunk - 1) / kchunk; A.kchunk = kchunk;
   const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32) && getenv("CALES_WIDE_OFFSETS") == nullptr;      // 32-bit byte offsets
   if (c->C.impdiff == 2) { if (small) hipLaunchKernelGGL((k_momrk<2, unsigned>), gr, b, 0, c->stream, c->g, A); else hipLaunchKernelGGL((k_momrk<2, size_t>), gr, b, 0, c->stream, c->g, A); }
+  else if (c->C.impdiff == 1) { if (small) hipLaunchKernelGGL((k_momrk<1, unsigned>), gr, b, 0, c->stream, c->g, A); else hipLaunchKernelGGL((k_momrk<1, size_t>), gr, b, 0, c->stream, c->g, A); }
   else { if (small) hipLaunchKernelGGL((k_momrk<0, unsigned>), gr, b, 0, c->stream, c->g, A); else hipLaunchKernelGGL((k_momrk<0, size_t>), gr, b, 0, c->stream, c->g, A); }
   HIPCHK(c, hipGetLastError());
   for (int q = 0; q < 3; ++q) std::swap(c->f[CALES_U + q], c->f2[q]);

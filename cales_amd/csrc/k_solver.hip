@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void k_gaussel_split(Geom g, int nz, int ncol,
 // Non-periodic z, complex modes: the real and the imaginary part of a mode are two independent systems with the same
 // matrix, so they go to two neighbouring lanes (lane -> mode lane/2, part lane%2; a wave still covers 512 contiguous bytes
 // per row). Twice the waves of k_gaussel<double2,0> for the same traffic: the sweeps are latency-bound chains.
-__global__ __launch_bounds__(256) void k_gaussel_ri(Geom g, int nz, int ncol, int nrow, int mofs, int nmode, Spec S,
+__global__ __launch_bounds__(256) void k_gaussel_ri(Geom g, int nz, int ncol, int nrow, int mofs, int nmode, Spec S, double lscale,
                                                     const double *__restrict__ a, const double *__restrict__ b,
                                                     const double *__restrict__ c, const double *__restrict__ lamx,
                                                     const double *__restrict__ lamy, double *__restrict__ p, double *__restrict__ dscr) {
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void k_gaussel_ri(Geom g, int nz, int ncol, in
   const size_t e0 = 2 * S.at_mode(g, m, j, 1) + part;
   const size_t st = 2 * (S.blocked ? (size_t)S.cw * S.n2l : (size_t)g.s12 / 2);
   const size_t s0 = (size_t)m + (size_t)ncol * (size_t)(j - 1), sst = (size_t)ncol * nrow;   // scratch [k][j][m]
-  const double lam = lamx[m + mofs] + lamy[j - 1];
+  const double lam = (lamx[m + mofs] + lamy[j - 1]) * lscale;     // lscale = alpha for the Helmholtz solves (main.f90:441), 1 for the pressure
   double z = 1. / (b[0] + lam + CALES_EPS), d = c[0] * z;
   double v = p[e0] * z;
   p[e0] = v; dscr[s0] = d;      // both lanes of a pair store the same c' (one merged write); each reads back what it wrote
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void k_gaussel_ri(Geom g, int nz, int ncol, in
 }
 
 template <typename VT, int PERIODIC>
-__global__ __launch_bounds__(256) void k_gaussel(Geom g, int nz, int ncol, int nrow, int i0, int mofs, int nmode, Spec S,
+__global__ __launch_bounds__(256) void k_gaussel(Geom g, int nz, int ncol, int nrow, int i0, int mofs, int nmode, Spec S, double lscale,
                                                  const double *__restrict__ a, const double *__restrict__ b,
                                                  const double *__restrict__ c, const double *__restrict__ lamx,
                                                  const double *__restrict__ lamy, double *__restrict__ pd, double *__restrict__ dscr,
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void k_gaussel(Geom g, int nz, int ncol, int n
   const size_t e0 = W == 2 ? S.at_mode(g, m, j, 1) : g.ix(m + i0, j, 1);    // element index of k=1 in units of VT
   const size_t st = W == 2 ? (S.blocked ? (size_t)S.cw * S.n2l : (size_t)g.s12 / 2) : (size_t)g.s12;
   const size_t s0 = (size_t)m + (size_t)ncol * (size_t)(j - 1), sst = (size_t)ncol * nrow;   // scratch [k][j][m]
-  const double lam = (lamx ? lamx[m + mofs] : 0.) + (lamy ? lamy[j - 1] : 0.);
+  const double lam = ((lamx ? lamx[m + mofs] : 0.) + (lamy ? lamy[j - 1] : 0.)) * lscale;
   const int n = PERIODIC ? nz - 1 : nz;
   // forward elimination
   double z = 1. / (b[0] + lam + CALES_EPS), d = c[0] * z;
@@ -565,7 +565,7 @@ int solver_setup(cales_ctx *c) {
   if (mk(n2g, n2g, &c->d_twy)) return 1;
   if (mk(4 * n1, n1 / 2 + 1, &c->d_twy_post)) return 1;      // DCT weights e^{-i pi k/(2 n1)}, k = 0..n1/2 (x)
   if (mk(4 * n2g, n2g, &c->scr_twyd)) return 1;              // e^{-i pi k/(2 n2)}, k = 0..n2-1 (y)
-  if (c->C.impdiff == 2)
+  if (c->C.impdiff)
     for (int iv = 0; iv < 3; ++iv) {
       hs_tridmatrix(&c->cbcvel[6 * iv + 4], n3, c->dzci.data(), c->dzfi.data(), iv == 2 ? 'f' : 'c', a.data(), b.data(), cc.data());
       HIPCHK(c, hipMalloc(&c->d_av[iv], 3 * n3 * sizeof(double)));   // a | b | c (unscaled); scaled copies follow
@@ -584,13 +584,14 @@ void solver_teardown(cales_ctx *c) {
   for (int iv = 0; iv < 3; ++iv) hipFree(c->d_av[iv]);
 }
 
-int op_solver(cales_ctx *c) {
+// FFT x, FFT y, tridiagonal z, and back, in place on `pp`; (da,db,dc,nz,lscale) = (a,b,c,n3,1) for the pressure Poisson equation,
+// (alpha a, alpha b + 1, alpha c, n3 - q, alpha) for the Helmholtz equation of a velocity component (main.f90:435-445)
+static int solve_field(cales_ctx *c, double *pp, const double *da, const double *db, const double *dc, int nz, double lscale, bool periodic_z) {
   SolverPlans *sp = find_plans(c);
   if (!sp) { c->err = "solver not initialised"; return 1; }
-  const int *n = c->n; double *pp = c->f[CALES_PP];
+  const int *n = c->n;
   const int mh = n[0] / 2 + 1, n2g = c->C.ng[1];
   const long nrows = (long)n[1] * n[2];
-  const bool periodic_z = CBP(c, 0, 3) == 'P' && CBP(c, 1, 3) == 'P';
   const bool dist = c->P > 1;
   if (dist && !c->comm.on) { c->err = "solver: nranks > 1 but no communication hooks registered (cales_set_comm)"; return 1; }
   Spec S; S.blocked = dist ? 1 : 0; S.cw = c->cw; S.n2l = n[1]; S.n3 = n[2];
@@ -617,11 +618,11 @@ int op_solver(cales_ctx *c) {
     else hipLaunchKernelGGL(k_fft_y<0>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
   { ProfScope ps(c, "gaussel_z");
     dim3 b(64, 4), gr((ncol + 63) / 64, (n2g + 3) / 4);
-    if (c->xkind) hipLaunchKernelGGL(k_gaussel_split, gr, b, 0, c->stream, c->g, n[2], ncol, n2g, mofs, c->C.ng[0] / 2, S, c->d_a, c->d_b, c->d_c, c->d_lamx, c->d_lamy,
+    if (c->xkind) hipLaunchKernelGGL(k_gaussel_split, gr, b, 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, da, db, dc, c->d_lamx, c->d_lamy,
                                      (double2 *)mode_spec, (double2 *)c->scr1);
-    else if (periodic_z) hipLaunchKernelGGL((k_gaussel<double2, 1>), gr, b, 0, c->stream, c->g, n[2], ncol, n2g, 0, mofs, mh, S, c->d_a, c->d_b, c->d_c, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2);
-    else if (getenv("CALES_GAUSSEL_PAIR")) hipLaunchKernelGGL((k_gaussel<double2, 0>), gr, b, 0, c->stream, c->g, n[2], ncol, n2g, 0, mofs, mh, S, c->d_a, c->d_b, c->d_c, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2);
-    else hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, n[2], ncol, n2g, mofs, mh, S, c->d_a, c->d_b, c->d_c, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1); }
+    else if (periodic_z) hipLaunchKernelGGL((k_gaussel<double2, 1>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2);
+    else if (getenv("CALES_GAUSSEL_PAIR")) hipLaunchKernelGGL((k_gaussel<double2, 0>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2);
+    else hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1); }
   { ProfScope ps(c, "fft_y_bwd");
     if (sp->y8) hipLaunchKernelGGL(k_fft_y8<1>, dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, S, mode_spec);
     else hipLaunchKernelGGL(k_fft_y<1>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
@@ -633,6 +634,10 @@ int op_solver(cales_ctx *c) {
                        (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec); }
   HIPCHK(c, hipGetLastError());
   return 0;
+}
+
+int op_solver(cales_ctx *c) {
+  return solve_field(c, c->f[CALES_PP], c->d_a, c->d_b, c->d_c, c->n[2], 1., CBP(c, 0, 3) == 'P' && CBP(c, 1, 3) == 'P');
 }
 
 // z-implicit Helmholtz solve of one velocity component (solver.f90:182-233 with aa,bb,cc of main.f90:435-437)
@@ -654,8 +659,24 @@ int op_helmholtz_z(cales_ctx *c, int ivel, double alpha) {
   dim3 b(64, 4), gr((n[0] + 63) / 64, (n[1] + 3) / 4);
   double *fld = c->f[CALES_U + ivel - 1];
   Spec S; S.blocked = 0; S.cw = 0; S.n2l = n[1]; S.n3 = n3;
-  if (periodic) hipLaunchKernelGGL((k_gaussel<double, 1>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, abc, abc + n3, abc + 2 * n3, (const double *)nullptr, (const double *)nullptr, fld, c->scr1, c->scr2);
-  else hipLaunchKernelGGL((k_gaussel<double, 0>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, abc, abc + n3, abc + 2 * n3, (const double *)nullptr, (const double *)nullptr, fld, c->scr1, c->scr2);
+  if (periodic) hipLaunchKernelGGL((k_gaussel<double, 1>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, 1., abc, abc + n3, abc + 2 * n3, (const double *)nullptr, (const double *)nullptr, fld, c->scr1, c->scr2);
+  else hipLaunchKernelGGL((k_gaussel<double, 0>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, 1., abc, abc + n3, abc + 2 * n3, (const double *)nullptr, (const double *)nullptr, fld, c->scr1, c->scr2);
   HIPCHK(c, hipGetLastError());
   return 0;
+}
+
+// 3-D implicit diffusion (_IMPDIFF without _IMPDIFF_1D, main.f90:423-491): (1 + alpha L) q = q* by the same transforms as the
+// pressure solve. Provided for periodic x and y, where the eigenvalues and transforms of a velocity component are those of
+// the pressure (initsolver.f90:66-98 does not depend on the staggering for 'PP'); cales_check_case rejects the rest.
+int op_helmholtz(cales_ctx *c, int ivel, double alpha) {
+  if (c->C.impdiff != 1) { c->err = "helmholtz needs impdiff = 1"; return 1; }
+  if (c->xkind || c->ykind) { c->err = "helmholtz (3-D implicit diffusion) needs periodic x and y"; return 1; }
+  ProfScope ps(c, "helmholtz_xyz");
+  const int n3 = c->n[2];
+  if (int e = op_rhs_b_velz(c, ivel, alpha)) return e;      // x and y boundary planes vanish for periodic directions
+  double *abc = c->d_red + 64 + 16 * (n3 + 2);
+  hipLaunchKernelGGL(k_scale_abc, dim3((n3 + 63) / 64), dim3(64), 0, c->stream, n3, alpha, c->d_av[ivel - 1], c->d_bv[ivel - 1], c->d_cv[ivel - 1], abc, abc + n3, abc + 2 * n3);
+  const char *bcz = &c->cbcvel[6 * (ivel - 1) + 4];
+  const int q = (ivel == 3 && bcz[1] == 'D') ? 1 : 0;
+  return solve_field(c, c->f[CALES_U + ivel - 1], abc, abc + n3, abc + 2 * n3, n3 - q, alpha, bcz[0] == 'P' && bcz[1] == 'P');
 }

@@ -95,6 +95,9 @@ __global__ __launch_bounds__(BX *BY) void k_mom(Geom g, const double *__restrict
   if (IMP == 2) {          // _IMPDIFF_1D: mom.f90:278-284
     dudt[c] = dudt_s + dudtd_xy; dvdt[c] = dvdt_s + dvdtd_xy; dwdt[c] = dwdt_s + dwdtd_xy;
     dudtd[c] = dudtd_z; dvdtd[c] = dvdtd_z; dwdtd[c] = dwdtd_z;
+  } else if (IMP == 1) {   // _IMPDIFF, all directions implicit: mom.f90:285-288
+    dudt[c] = dudt_s; dvdt[c] = dvdt_s; dwdt[c] = dwdt_s;
+    dudtd[c] = dudtd_xy + dudtd_z; dvdtd[c] = dvdtd_xy + dvdtd_z; dwdtd[c] = dwdtd_xy + dwdtd_z;
   } else {                 // explicit: mom.f90:297-302
     dudt[c] = dudt_s + dudtd_xy + dudtd_z; dvdt[c] = dvdt_s + dvdtd_xy + dvdtd_z; dwdt[c] = dwdt_s + dwdtd_xy + dwdtd_z;
   }
@@ -106,6 +109,9 @@ int op_mom(cales_ctx *c) {
   double **f = c->f;
   if (c->C.impdiff == 2)
     hipLaunchKernelGGL(k_mom<2>, gr, b, 0, c->stream, c->g, f[CALES_U], f[CALES_V], f[CALES_W], f[CALES_VISCT], c->d_dzci, c->d_dzfi,
+                       c->dli[0], c->dli[1], c->visc, f[CALES_DUDT], f[CALES_DVDT], f[CALES_DWDT], f[CALES_DUDTD], f[CALES_DVDTD], f[CALES_DWDTD]);
+  else if (c->C.impdiff == 1)
+    hipLaunchKernelGGL(k_mom<1>, gr, b, 0, c->stream, c->g, f[CALES_U], f[CALES_V], f[CALES_W], f[CALES_VISCT], c->d_dzci, c->d_dzfi,
                        c->dli[0], c->dli[1], c->visc, f[CALES_DUDT], f[CALES_DVDT], f[CALES_DWDT], f[CALES_DUDTD], f[CALES_DVDTD], f[CALES_DWDTD]);
   else
     hipLaunchKernelGGL(k_mom<0>, gr, b, 0, c->stream, c->g, f[CALES_U], f[CALES_V], f[CALES_W], f[CALES_VISCT], c->d_dzci, c->d_dzfi,
@@ -375,19 +381,23 @@ int op_correc(cales_ctx *c, double dt) {
 
 // ------------------------------------------------------------------------------------------ updatep (updatep.f90:30-47)
 template <int IMP>
-__global__ __launch_bounds__(BX *BY) void k_updatep(Geom g, double alpha, const double *__restrict__ dzci, const double *__restrict__ dzfi,
-                                                     const double *__restrict__ pp, double *__restrict__ p) {
+__global__ __launch_bounds__(BX *BY) void k_updatep(Geom g, double alpha, double dxi, double dyi, const double *__restrict__ dzci,
+                                                     const double *__restrict__ dzfi, const double *__restrict__ pp, double *__restrict__ p) {
   const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;
   if (i > g.n1 || j > g.n2) return;
   const size_t c = g.ix(i, j, k);
   if (IMP == 0) p[c] = p[c] + pp[c];
+  else if (IMP == 1)       // updatep.f90:35-42 with the x and y terms
+    p[c] = p[c] + pp[c] + alpha * ((pp[c + 1] - 2. * pp[c] + pp[c - 1]) * (dxi * dxi) + (pp[c + g.s1] - 2. * pp[c] + pp[c - g.s1]) * (dyi * dyi) +
+                                   ((pp[c + g.s12] - pp[c]) * dzci[k] - (pp[c] - pp[c - g.s12]) * dzci[k - 1]) * dzfi[k]);
   else p[c] = p[c] + pp[c] + alpha * (((pp[c + g.s12] - pp[c]) * dzci[k] - (pp[c] - pp[c - g.s12]) * dzci[k - 1]) * dzfi[k]);
 }
 int op_updatep(cales_ctx *c, double alpha) {
   ProfScope ps(c, "updatep");
   dim3 b(BX, BY, 1), gr = grid3(c->n[0], c->n[1], c->n[2], b);
-  if (c->C.impdiff == 2) hipLaunchKernelGGL(k_updatep<2>, gr, b, 0, c->stream, c->g, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], c->f[CALES_P]);
-  else hipLaunchKernelGGL(k_updatep<0>, gr, b, 0, c->stream, c->g, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], c->f[CALES_P]);
+  if (c->C.impdiff == 2) hipLaunchKernelGGL(k_updatep<2>, gr, b, 0, c->stream, c->g, alpha, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, c->f[CALES_PP], c->f[CALES_P]);
+  else if (c->C.impdiff == 1) hipLaunchKernelGGL(k_updatep<1>, gr, b, 0, c->stream, c->g, alpha, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, c->f[CALES_PP], c->f[CALES_P]);
+  else hipLaunchKernelGGL(k_updatep<0>, gr, b, 0, c->stream, c->g, alpha, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, c->f[CALES_PP], c->f[CALES_P]);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -447,7 +457,7 @@ __global__ __launch_bounds__(256) void k_chkdt_partial(Geom g, double dxi, doubl
     dti = fmax(fmax(fmax(dti, dtix), dtiy), dtiz);
     const double viscx = 0.5 * (s[c] + s[c + 1]), viscy = 0.5 * (s[c] + s[c + sj]), viscz = 0.5 * (s[c] + s[c + sk]);
     double dtidx = viscx * (dl2i + zf2), dtidy = viscy * (dl2i + zf2), dtidz = viscz * (dl2i + zc2);
-    dtidx += visc * dl2i; dtidy += visc * dl2i; dtidz += visc * dl2i;
+    if (IMP != 1) { dtidx += visc * dl2i; dtidy += visc * dl2i; dtidz += visc * dl2i; }
     if (IMP == 0) { dtidx += visc * zf2; dtidy += visc * zf2; dtidz += visc * zc2; }
     dtid = fmax(fmax(fmax(dtid, dtidx), dtidy), dtidz);
   }
@@ -459,6 +469,9 @@ int op_chkdt(cales_ctx *c, double *dtmax) {
   double **f = c->f;
   if (c->C.impdiff == 2)
     hipLaunchKernelGGL(k_chkdt_partial<2>, dim3(nbx, c->n[2]), dim3(256), 0, c->stream, c->g, 1. / c->dl[0], 1. / c->dl[1], c->visc, c->d_dzci,
+                       c->d_dzfi, f[CALES_VISCT], f[CALES_U], f[CALES_V], f[CALES_W], c->d_red + 64, c->d_red + 64 + np);
+  else if (c->C.impdiff == 1)
+    hipLaunchKernelGGL(k_chkdt_partial<1>, dim3(nbx, c->n[2]), dim3(256), 0, c->stream, c->g, 1. / c->dl[0], 1. / c->dl[1], c->visc, c->d_dzci,
                        c->d_dzfi, f[CALES_VISCT], f[CALES_U], f[CALES_V], f[CALES_W], c->d_red + 64, c->d_red + 64 + np);
   else
     hipLaunchKernelGGL(k_chkdt_partial<0>, dim3(nbx, c->n[2]), dim3(256), 0, c->stream, c->g, 1. / c->dl[0], 1. / c->dl[1], c->visc, c->d_dzci,

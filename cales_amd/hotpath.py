@@ -155,6 +155,10 @@ class HotPath:
     def helmholtz_z(self, ivel: int, alpha: float):
         self._chk(self.L.cales_helmholtz_z(self.h, int(ivel), float(alpha)))
 
+    def helmholtz(self, ivel: int, alpha: float):
+        """3-D implicit diffusion of one velocity component (impdiff = 1; main.f90:423-491)."""
+        self._chk(self.L.cales_helmholtz(self.h, int(ivel), float(alpha)))
+
     def correc(self, dtrk: float):
         self._chk(self.L.cales_correc(self.h, float(dtrk)))
 

@@ -31,7 +31,7 @@ typedef struct cales_case {
   double  bforce[3]; int32_t is_forced[3]; double velf[3];
   int32_t sgstype;        /* 0 'none', 1 'smag', 2 'dsmag'  (src/sgs.f90:61-153) */
   int32_t lwm[6]; double hwm;
-  int32_t impdiff;        /* 0 explicit; 2 = _IMPDIFF + _IMPDIFF_1D (z-implicit). 1 (3-D implicit) is rejected */
+  int32_t impdiff;        /* 0 explicit; 2 = _IMPDIFF + _IMPDIFF_1D (z-implicit); 1 = _IMPDIFF (3-D implicit; periodic x and y only) */
   int32_t nranks, rank;   /* y-slab decomposition: rank owns rows rank*ng2/nranks+1 ... */
 } cales_case;
 
@@ -71,7 +71,9 @@ int cales_get_bcvel(cales_ctx *ctx, int ivel, double *x, double *y, double *z); 
 int cales_bounduvw(cales_ctx *ctx, int is_updt_wm, int is_correc);          /* src/bound.f90:18   */
 int cales_boundp(cales_ctx *ctx, int field, int which);                     /* src/bound.f90:156; which 0 cbcpre/bcp, 1 cbcsgs/bcs */
 int cales_mom(cales_ctx *ctx);                                              /* src/mom.f90:17 -> CALES_DUDT.. */
-int cales_rk(cales_ctx *ctx, int irk, double dt);                           /* src/rk.f90:17 (forcing f stays on the device) */
+int cales_rk(cales_ctx *ctx, int irk, double dt);                           /* src/rk.f90:17 (forcing f stays on the device). The ghost
+                                                                              * cells of u,v,w are undefined on return (the reference leaves the old values);
+                                                                              * bounduvw follows in every caller (src/main.f90:493) */
 int cales_bulk_forcing(cales_ctx *ctx);                                     /* src/mom.f90:311    */
 int cales_get_forcing(cales_ctx *ctx, double f[3]);                         /* f of the last cales_rk (sync)  */
 int cales_bulk_mean(cales_ctx *ctx, int field, int c_or_f, double *mean);   /* src/utils.f90:16 (sync) */
@@ -79,6 +81,7 @@ int cales_fillps(cales_ctx *ctx, double dtrki);                             /* s
 int cales_updt_rhs_b(cales_ctx *ctx);                                       /* src/bound.f90:562, pressure r.h.s. */
 int cales_solver(cales_ctx *ctx);                                           /* src/solver.f90:20 on CALES_PP */
 int cales_helmholtz_z(cales_ctx *ctx, int ivel, double alpha);              /* main.f90:425-445: updt_rhs_b + solver_gaussel_z */
+int cales_helmholtz(cales_ctx *ctx, int ivel, double alpha);                /* impdiff = 1, main.f90:423-491: updt_rhs_b + solver on a velocity component (periodic x,y) */
 int cales_correc(cales_ctx *ctx, double dtrk);                              /* src/correc.f90:14  */
 int cales_updatep(cales_ctx *ctx, double alpha);                            /* src/updatep.f90:14 */
 int cales_cmpt_sgs(cales_ctx *ctx);                                         /* src/sgs.f90:21     */

@@ -875,6 +875,40 @@ void o_solver_gaussel_z(ostate *s, int ivel, double alpha, double *q) {  /* solv
   free(aa); free(bb); free(cc);
 }
 
+/* 3-D implicit diffusion (_IMPDIFF without _IMPDIFF_1D), main.f90:423-491: (1 + alpha L) q = q* for one velocity component
+ * through solver.f90:20-80 with lambdaxy*alpha and aa,bb,cc = a*alpha, b*alpha+1, c*alpha. Restated for x and y PERIODIC,
+ * where transforms, eigenvalues and normalisation do not depend on the staggering of the component (initsolver.f90:66-98)
+ * and equal those of the pressure; other BC sets need the face-centred transform kinds and return 1. */
+int o_solver_helmholtz(ostate *s, int ivel, double alpha, double *q) {
+  const int *n = s->n; const size_t s1 = s->s1, s2 = s->s2; int n3 = n[2];
+  const char *bcv = &s->cbcvel[6*(ivel-1)];
+  if (!(bcv[0] == 'P' && bcv[1] == 'P' && bcv[2] == 'P' && bcv[3] == 'P' && CBP(0,1) == 'P' && CBP(0,2) == 'P')) return 1;
+  double *aa = dalloc(n3), *bb = dalloc(n3), *cc = dalloc(n3);
+  for (int k = 0; k < n3; k++) { aa[k] = s->av[ivel-1][k]*alpha; bb[k] = s->bv[ivel-1][k]*alpha + 1.; cc[k] = s->cv[ivel-1][k]*alpha; }
+  int qq = (ivel == 3 && bcv[5] == 'D') ? 1 : 0, periodic = bcv[4] == 'P' && bcv[5] == 'P';
+  #pragma omp parallel for collapse(2) num_threads(s->nthreads)
+  for (int k = 1; k <= n[2]; k++) for (int j = 1; j <= n[1]; j++) o_r2r(O_R2HC, n[0], &q[IX(1,j,k)], 1);
+  #pragma omp parallel for collapse(2) num_threads(s->nthreads)
+  for (int k = 1; k <= n[2]; k++) for (int i = 1; i <= n[0]; i++) o_r2r(O_R2HC, n[1], &q[IX(i,1,k)], (int)s1);
+  #pragma omp parallel num_threads(s->nthreads)
+  {
+    double *work = (double *)malloc(sizeof(double)*4*n3);
+    #pragma omp for collapse(2)
+    for (int j = 1; j <= n[1]; j++) for (int i = 1; i <= n[0]; i++)
+      gaussel_line(n3 - qq, aa, bb, cc, s->lambdaxy[(i-1) + (size_t)n[0]*(j-1)]*alpha, periodic, &q[IX(i,j,1)], (int)(s1*s2), work);
+    free(work);
+  }
+  #pragma omp parallel for collapse(2) num_threads(s->nthreads)
+  for (int k = 1; k <= n[2]; k++) for (int i = 1; i <= n[0]; i++) o_r2r(O_HC2R, n[1], &q[IX(i,1,k)], (int)s1);
+  #pragma omp parallel for collapse(2) num_threads(s->nthreads)
+  for (int k = 1; k <= n[2]; k++) for (int j = 1; j <= n[1]; j++) {
+    o_r2r(O_HC2R, n[0], &q[IX(1,j,k)], 1);
+    for (int i = 1; i <= n[0]; i++) q[IX(i,j,k)] = q[IX(i,j,k)]*s->normfft;
+  }
+  free(aa); free(bb); free(cc);
+  return 0;
+}
+
 /* ------------------------------------------------------------------ diagnostics */
 double o_chkdt(ostate *s, const double *visct, const double *u, const double *v, const double *w) { /* chkdt.f90:17-99 */
   const int *n = s->n; const size_t s1 = s->s1, s2 = s->s2; const double *dzci = s->dzci, *dzfi = s->dzfi;
@@ -1163,6 +1197,10 @@ void o_step(ostate *s, double dt, double *u, double *v, double *w, double *p, do
       alpha = -.5*s->visc*dtrk;
       double *q[3] = {u, v, w};
       for (int iv = 1; iv <= 3; iv++) { o_updt_rhs_b_velz(s, iv, alpha, q[iv-1]); o_solver_gaussel_z(s, iv, alpha, q[iv-1]); }
+    } else if (s->P.impdiff == 1) {      /* x and y periodic only: their boundary r.h.s. planes vanish */
+      alpha = -.5*s->visc*dtrk;
+      double *q[3] = {u, v, w};
+      for (int iv = 1; iv <= 3; iv++) { o_updt_rhs_b_velz(s, iv, alpha, q[iv-1]); o_solver_helmholtz(s, iv, alpha, q[iv-1]); }
     }
     for (int c = 0; c < 3; c++) dpdl[c] = dpdl[c] + f[c];
     o_bounduvw(s, 1, 0, u, v, w);

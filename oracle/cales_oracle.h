@@ -66,6 +66,7 @@ void o_updt_rhs_b_p(ostate *s, double *pp);
 void o_updt_rhs_b_velz(ostate *s, int ivel, double alpha, double *q);
 void o_solver(ostate *s, double *pp);                          /* Poisson, cbcpre, 'c','c','c' */
 void o_solver_gaussel_z(ostate *s, int ivel, double alpha, double *q);
+int o_solver_helmholtz(ostate *s, int ivel, double alpha, double *q);   /* 3-D implicit diffusion, x and y periodic */
 void o_correc(ostate *s, double dtrk, const double *pp, double *u, double *v, double *w);
 void o_updatep(ostate *s, double alpha, const double *pp, double *p);
 void o_cmpt_sgs(ostate *s, const double *u, const double *v, const double *w, double *visct);

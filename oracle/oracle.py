@@ -170,6 +170,11 @@ class Oracle:
     def solver_gaussel_z(self, ivel, alpha, q):
         self.lib.o_solver_gaussel_z(self.h, int(ivel), C.c_double(alpha), _p(q))
 
+    def solver_helmholtz(self, ivel, alpha, q):
+        """(1 + alpha L) q = q* of main.f90:423-491 (3-D implicit diffusion); x and y periodic only."""
+        if self.lib.o_solver_helmholtz(self.h, int(ivel), C.c_double(alpha), _p(q)):
+            raise ValueError("o_solver_helmholtz: needs periodic x and y")
+
     def correc(self, dtrk, pp, u, v, w):
         self.lib.o_correc(self.h, C.c_double(dtrk), _p(pp), _p(u), _p(v), _p(w))
 

@@ -41,7 +41,9 @@ def test_poisson_solve(name, ng):
                                             ("halfchan_imp1d", (16, 16, 16), 3), ("chan_smag", (24, 20, 12), 10),
                                             # tile kernels: partial tiles in x and y, several x tiles, k chunks, wall-modelled z faces
                                             ("chan_dsmag", (80, 20, 12), 3), ("chan_dsmag_wm", (128, 30, 70), 2), ("chan_smag_wm", (96, 18, 40), 3),
-                                            ("duct_smag_wm", (16, 24, 24), 4), ("cavity_nnn", (16, 16, 16), 5)])
+                                            ("duct_smag_wm", (16, 24, 24), 4), ("cavity_nnn", (16, 16, 16), 5),
+                                            # 3-D implicit diffusion (impdiff = 1): Helmholtz solves of u,v,w through the FFT solver
+                                            ("couette_imp3d_ops", (16, 16, 16), 4), ("couette_imp3d_ops", (32, 20, 24), 3)])
 def test_time_steps(name, ng, nsteps):
     """u,v,w <= 1e-9, p (mean removed) <= 1e-8 after the steps; divmax same order of magnitude"""
     from cales_amd.hotpath import initflow

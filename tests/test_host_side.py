@@ -89,7 +89,10 @@ def test_check_case_rules():
     bad = case.copy(); bad.bcpre[0, 0] = 1.                    # x,y pressure BC values must be zero
     with pytest.raises(CalesError):
         check_case(bad)
-    bad = case.copy(); bad.impdiff = 1                         # 3-D implicit diffusion: not provided
+    ok = case.copy(); ok.impdiff = 1                           # 3-D implicit diffusion: periodic x and y only
+    if all(ch == "P" for ch in ok.cbcvel[:, :2, :].ravel()):
+        check_case(ok)
+    bad = load_golden("duct_smag_wm")[1]; bad.impdiff = 1; bad.lwm[:] = 0
     with pytest.raises(CalesError):
         check_case(bad)
     with pytest.raises(CalesError):

@@ -56,3 +56,28 @@ def test_laplacian_identity(name):
     o.solver(p); o.boundp(p, 0)
     res = laplacian(o, case, p) - r[1:-1, 1:-1, 1:-1]
     assert np.abs(res).max() < 1e-11 * max(1., np.abs(r).max() * case.dli.max() ** 2 * 0 + 1)
+
+
+@pytest.mark.parametrize("ivel", [1, 2, 3])
+def test_helmholtz_3d_identity(ivel):
+    """3-D implicit diffusion (main.f90:423-491): (1 + alpha L_h) applied to the oracle's solution gives back the r.h.s.;
+    L_h = periodic second differences in x,y + the tridiagonal a,b,c of the component (initsolver.f90:100-169)."""
+    g, case = load_golden("couette_imp3d_ops")
+    case.ng[:] = (12, 10, 14)
+    o = Oracle(case)
+    n1, n2, n3 = case.ng
+    nz = n3 - 1 if ivel == 3 else n3              # w lives on the faces: the wall face is not an unknown (solver.f90:49)
+    _, a, b, c, _ = o.solver_operands(ivel)
+    rng = np.random.RandomState(ivel)
+    rhs = o.zeros(); rhs[1:-1, 1:-1, 1:nz + 1] = rng.rand(n1, n2, nz) - 0.5
+    q = rhs.copy(order="F")
+    alpha = -0.37
+    o.solver_helmholtz(ivel, alpha, q)
+    x = q[1:-1, 1:-1, 1:nz + 1]
+    dxi2, dyi2 = (n1 / case.l[0]) ** 2, (n2 / case.l[1]) ** 2
+    lap = (np.roll(x, -1, 0) - 2 * x + np.roll(x, 1, 0)) * dxi2 + (np.roll(x, -1, 1) - 2 * x + np.roll(x, 1, 1)) * dyi2
+    lz = b[None, None, :nz] * x
+    lz[:, :, 1:] += a[None, None, 1:nz] * x[:, :, :-1]
+    lz[:, :, :-1] += c[None, None, :nz - 1] * x[:, :, 1:]
+    back = x + alpha * (lap + lz)
+    assert np.abs(back - rhs[1:-1, 1:-1, 1:nz + 1]).max() < 1e-12
