@@ -3,7 +3,7 @@
 ! (reference src/main.f90:135-632), and hands every per-step operator to libcales_hip.so through
 ! ISO_C_BINDING (module cales_c). One rank / one GPU; the multi-GPU host is cales_amd/decomp.py.
 !
-! usage: cales [impdiff]      (impdiff = 0 explicit [default], 2 z-implicit: the reference's build switches
+! usage: cales [impdiff]      (impdiff = 0 explicit [default], 1 implicit in x,y,z for periodic x,y, 2 z-implicit: the reference's build switches
 !                              _IMPDIFF/_IMPDIFF_1D are run-time here); reads ./input.nml
 program cales
   use, intrinsic :: iso_c_binding
