@@ -401,12 +401,13 @@ template <> __device__ inline double vfma<double>(double a, double s, double b) 
 __global__ __launch_bounds__(256) void k_gaussel_split(Geom g, int nz, int ncol, int nrow, int mofs, int nmode, Spec S,
                                                        const double *__restrict__ a, const double *__restrict__ b, const double *__restrict__ c,
                                                        const double *__restrict__ lamx, const double *__restrict__ lamy,
-                                                       double2 *__restrict__ p, double2 *__restrict__ dscr) {
+                                                       double2 *__restrict__ p, double2 *__restrict__ dscr, int fixnull) {
   const int m = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y + 1;
   if (m >= ncol || j > nrow || m + mofs >= nmode) return;
   const size_t e0 = S.at_mode(g, m, j, 1), st = S.blocked ? (size_t)S.cw * S.n2l : (size_t)g.s12 / 2;
   const size_t s0 = (size_t)m + (size_t)ncol * (size_t)(j - 1), sst = (size_t)ncol * nrow;
   const double l1 = lamx[2 * (m + mofs)] + lamy[j - 1], l2 = lamx[2 * (m + mofs) + 1] + lamy[j - 1];
+  const bool null1 = fixnull && l1 == 0., null2 = fixnull && l2 == 0.;      // see k_gaussel_ri
   double z1 = 1. / (b[0] + l1 + CALES_EPS), z2 = 1. / (b[0] + l2 + CALES_EPS), d1 = c[0] * z1, d2 = c[0] * z2;
   double2 v = p[e0]; v.x *= z1; v.y *= z2; p[e0] = v; dscr[s0] = make_double2(d1, d2);
   for (int l = 1; l < nz; ++l) {
@@ -414,6 +415,7 @@ __global__ __launch_bounds__(256) void k_gaussel_split(Geom g, int nz, int ncol,
     d1 = c[l] * z1; d2 = c[l] * z2;
     const double2 q = p[e0 + l * st];
     v = make_double2((q.x - a[l] * v.x) * z1, (q.y - a[l] * v.y) * z2);
+    if (l == nz - 1) { if (null1) v.x = 0.; if (null2) v.y = 0.; }
     p[e0 + l * st] = v; dscr[s0 + l * sst] = make_double2(d1, d2);
   }
   for (int l = nz - 2; l >= 0; --l) {
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(256) void k_gaussel_split(Geom g, int nz, int ncol,
 __global__ __launch_bounds__(256) void k_gaussel_ri(Geom g, int nz, int ncol, int nrow, int mofs, int nmode, Spec S, double lscale,
                                                     const double *__restrict__ a, const double *__restrict__ b,
                                                     const double *__restrict__ c, const double *__restrict__ lamx,
-                                                    const double *__restrict__ lamy, double *__restrict__ p, double *__restrict__ dscr) {
+                                                    const double *__restrict__ lamy, double *__restrict__ p, double *__restrict__ dscr, int fixnull) {
   // threads run over (row, mode, part) linearly, so a block touches one contiguous piece of a plane per step
   const long q = (long)blockIdx.x * 256 + threadIdx.x;
   const int t = (int)(q % (2 * ncol)), m = t >> 1, part = t & 1, j = (int)(q / (2 * ncol)) + 1;
@@ -446,6 +448,10 @@ __global__ __launch_bounds__(256) void k_gaussel_ri(Geom g, int nz, int ncol, in
     z = 1. / (bb - a[l] * d + CALES_EPS);
     d = c[l] * z;
     v = (p[e0 + l * st] - a[l] * v) * z;
+    // The mode with zero eigenvalue of an all-Neumann/periodic problem is singular: its last pivot is 0 + eps and the reference
+    // (solver.f90:160-178) returns [round-off of the r.h.s.]/eps there -- an arbitrary, possibly huge constant added to the
+    // pressure, which then costs digits in every pressure difference. The constant is free: take the member with p(n) = 0.
+    if (l == nz - 1 && fixnull && lam == 0.) v = 0.;
     p[e0 + l * st] = v; dscr[s0 + l * sst] = d;
   }
   for (int l = nz - 2; l >= 0; --l) {
@@ -459,7 +465,7 @@ __global__ __launch_bounds__(256) void k_gaussel(Geom g, int nz, int ncol, int n
                                                  const double *__restrict__ a, const double *__restrict__ b,
                                                  const double *__restrict__ c, const double *__restrict__ lamx,
                                                  const double *__restrict__ lamy, double *__restrict__ pd, double *__restrict__ dscr,
-                                                 double *__restrict__ p2scr) {
+                                                 double *__restrict__ p2scr, int fixnull) {
   const int m = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y + 1;
   if (m >= ncol || j > nrow || m + mofs >= nmode) return;
   constexpr int W = sizeof(VT) / sizeof(double);
@@ -480,6 +486,7 @@ __global__ __launch_bounds__(256) void k_gaussel(Geom g, int nz, int ncol, int n
     z = 1. / (bb - a[l] * d + CALES_EPS);
     d = c[l] * z;
     v = vmul(vfms(p[e0 + l * st], a[l], v), z);
+    if (!PERIODIC && l == n - 1 && fixnull && lam == 0.) v = vmul(v, 0.);      // null mode: see k_gaussel_ri
     p[e0 + l * st] = v; dscr[s0 + l * sst] = d;
     if (PERIODIC) { const double r2 = (l == n - 1) ? -c[n - 1] : 0.; v2 = (r2 - a[l] * v2) * z; p2scr[s0 + l * sst] = v2; }
   }
@@ -494,7 +501,7 @@ __global__ __launch_bounds__(256) void k_gaussel(Geom g, int nz, int ncol, int n
     const double p21 = p2scr[s0], p2n = p2scr[s0 + (size_t)(n - 1) * sst];
     const double den = (b[nz - 1] + lam) + c[nz - 1] * p21 + a[nz - 1] * p2n + CALES_EPS;
     VT pn = vfms(vfms(p[e0 + (size_t)(nz - 1) * st], c[nz - 1], p11), a[nz - 1], p1n);
-    pn = vmul(pn, 1. / den);
+    pn = vmul(pn, (fixnull && lam == 0.) ? 0. : 1. / den);      // null mode of the triply periodic problem: p(n) = 0
     p[e0 + (size_t)(nz - 1) * st] = pn;
     for (int l = 0; l < n; ++l) p[e0 + l * st] = vfma(p[e0 + l * st], p2scr[s0 + l * sst], pn);
   }
@@ -586,7 +593,7 @@ void solver_teardown(cales_ctx *c) {
 
 // FFT x, FFT y, tridiagonal z, and back, in place on `pp`; (da,db,dc,nz,lscale) = (a,b,c,n3,1) for the pressure Poisson equation,
 // (alpha a, alpha b + 1, alpha c, n3 - q, alpha) for the Helmholtz equation of a velocity component (main.f90:435-445)
-static int solve_field(cales_ctx *c, double *pp, const double *da, const double *db, const double *dc, int nz, double lscale, bool periodic_z) {
+static int solve_field(cales_ctx *c, double *pp, const double *da, const double *db, const double *dc, int nz, double lscale, bool periodic_z, bool poisson) {
   SolverPlans *sp = find_plans(c);
   if (!sp) { c->err = "solver not initialised"; return 1; }
   const int *n = c->n;
@@ -616,13 +623,15 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
   { ProfScope ps(c, "fft_y_fwd");
     if (sp->y8) hipLaunchKernelGGL(k_fft_y8<0>, dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, S, mode_spec);
     else hipLaunchKernelGGL(k_fft_y<0>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
+  // pressure equation without a Dirichlet condition in z: the zero-eigenvalue mode (if x and y have one) is singular
+  const int fixnull = (poisson && CBP(c, 0, 3) != 'D' && CBP(c, 1, 3) != 'D' && getenv("CALES_KEEP_NULL_MODE") == nullptr) ? 1 : 0;
   { ProfScope ps(c, "gaussel_z");
     dim3 b(64, 4), gr((ncol + 63) / 64, (n2g + 3) / 4);
     if (c->xkind) hipLaunchKernelGGL(k_gaussel_split, gr, b, 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, da, db, dc, c->d_lamx, c->d_lamy,
-                                     (double2 *)mode_spec, (double2 *)c->scr1);
-    else if (periodic_z) hipLaunchKernelGGL((k_gaussel<double2, 1>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2);
-    else if (getenv("CALES_GAUSSEL_PAIR")) hipLaunchKernelGGL((k_gaussel<double2, 0>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2);
-    else hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1); }
+                                     (double2 *)mode_spec, (double2 *)c->scr1, fixnull);
+    else if (periodic_z) hipLaunchKernelGGL((k_gaussel<double2, 1>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2, fixnull);
+    else if (getenv("CALES_GAUSSEL_PAIR")) hipLaunchKernelGGL((k_gaussel<double2, 0>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2, fixnull);
+    else hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, fixnull); }
   { ProfScope ps(c, "fft_y_bwd");
     if (sp->y8) hipLaunchKernelGGL(k_fft_y8<1>, dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, S, mode_spec);
     else hipLaunchKernelGGL(k_fft_y<1>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
@@ -637,7 +646,7 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
 }
 
 int op_solver(cales_ctx *c) {
-  return solve_field(c, c->f[CALES_PP], c->d_a, c->d_b, c->d_c, c->n[2], 1., CBP(c, 0, 3) == 'P' && CBP(c, 1, 3) == 'P');
+  return solve_field(c, c->f[CALES_PP], c->d_a, c->d_b, c->d_c, c->n[2], 1., CBP(c, 0, 3) == 'P' && CBP(c, 1, 3) == 'P', true);
 }
 
 // z-implicit Helmholtz solve of one velocity component (solver.f90:182-233 with aa,bb,cc of main.f90:435-437)
@@ -659,8 +668,8 @@ int op_helmholtz_z(cales_ctx *c, int ivel, double alpha) {
   dim3 b(64, 4), gr((n[0] + 63) / 64, (n[1] + 3) / 4);
   double *fld = c->f[CALES_U + ivel - 1];
   Spec S; S.blocked = 0; S.cw = 0; S.n2l = n[1]; S.n3 = n3;
-  if (periodic) hipLaunchKernelGGL((k_gaussel<double, 1>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, 1., abc, abc + n3, abc + 2 * n3, (const double *)nullptr, (const double *)nullptr, fld, c->scr1, c->scr2);
-  else hipLaunchKernelGGL((k_gaussel<double, 0>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, 1., abc, abc + n3, abc + 2 * n3, (const double *)nullptr, (const double *)nullptr, fld, c->scr1, c->scr2);
+  if (periodic) hipLaunchKernelGGL((k_gaussel<double, 1>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, 1., abc, abc + n3, abc + 2 * n3, (const double *)nullptr, (const double *)nullptr, fld, c->scr1, c->scr2, 0);
+  else hipLaunchKernelGGL((k_gaussel<double, 0>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, 1., abc, abc + n3, abc + 2 * n3, (const double *)nullptr, (const double *)nullptr, fld, c->scr1, c->scr2, 0);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -678,5 +687,5 @@ int op_helmholtz(cales_ctx *c, int ivel, double alpha) {
   hipLaunchKernelGGL(k_scale_abc, dim3((n3 + 63) / 64), dim3(64), 0, c->stream, n3, alpha, c->d_av[ivel - 1], c->d_bv[ivel - 1], c->d_cv[ivel - 1], abc, abc + n3, abc + 2 * n3);
   const char *bcz = &c->cbcvel[6 * (ivel - 1) + 4];
   const int q = (ivel == 3 && bcz[1] == 'D') ? 1 : 0;
-  return solve_field(c, c->f[CALES_U + ivel - 1], abc, abc + n3, abc + 2 * n3, n3 - q, alpha, bcz[0] == 'P' && bcz[1] == 'P');
+  return solve_field(c, c->f[CALES_U + ivel - 1], abc, abc + n3, abc + 2 * n3, n3 - q, alpha, bcz[0] == 'P' && bcz[1] == 'P', false);
 }

@@ -39,6 +39,9 @@ CASES = {
     "tgv_ppp": ("dns/triperiodic/input.nml",
                 {r"ng\(1:3\) = .*": "ng(1:3) = 12, 10, 8", r"l\(1:3\) = .*": "l(1:3) = 6.283185307179586, 6.283185307179586, 6.283185307179586",
                  r"visci = .*": "visci = 1600.", r"inivel = .*": "inivel = 'tgv'"}, 0),
+    "tgv_dsmag_ppp": ("dns/triperiodic/input.nml",
+                      {r"ng\(1:3\) = .*": "ng(1:3) = 12, 10, 8", r"l\(1:3\) = .*": "l(1:3) = 6.283185307179586, 6.283185307179586, 6.283185307179586",
+                       r"visci = .*": "visci = 1600.", r"inivel = .*": "inivel = 'tgv'", r"sgstype = 'none'": "sgstype = 'dsmag'"}, 0),
     "chan_smag_wm": ("les/_manuscript_turbulent_channel_wall_model/input.nml",
                      {r"ng\(1:3\) = .*": "ng(1:3) = 12, 8, 10", r"visci = .*": "visci = 5640."}, 0),
     "chan_smag": ("les/_manuscript_turbulent_channel/input.nml",

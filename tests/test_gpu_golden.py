@@ -10,7 +10,7 @@ from tests.util import RK, F, load_golden, relerr
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-13
-DEVICE_CASES = ["tgv_ppp", "chan_smag_wm", "chan_smag", "chan_dsmag", "chan_dsmag_wm", "halfchan_imp1d",
+DEVICE_CASES = ["tgv_ppp", "tgv_dsmag_ppp", "chan_smag_wm", "chan_smag", "chan_dsmag", "chan_dsmag_wm", "halfchan_imp1d",
                 "duct_smag_wm", "duct_smag_wm_imp1d", "cavity_nnn"]    # PP and NN (DCT) pressure transforms in x,y
 
 
@@ -133,7 +133,7 @@ def test_wide_offset_kernels(name, monkeypatch):
 
 
 @pytest.mark.parametrize("env", ["CALES_DSMAG_REFERENCE_SEQUENCE", "CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC"])
-@pytest.mark.parametrize("name", ["chan_dsmag", "chan_dsmag_wm", "duct_smag_wm_imp1d"])
+@pytest.mark.parametrize("name", ["chan_dsmag", "chan_dsmag_wm", "tgv_dsmag_ppp", "duct_smag_wm_imp1d"])
 def test_unfused_paths(name, env, monkeypatch):
     """The kernel-per-loop forms behind the operator-level entries (general dsmag sequence, mom + rk_update, correc +
     updatep) stay selectable and are held to the same end-of-step tolerances."""

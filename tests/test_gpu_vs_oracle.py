@@ -40,7 +40,7 @@ def test_poisson_solve(name, ng):
 @pytest.mark.parametrize("name,ng,nsteps", [("tgv_ppp", (32, 24, 16), 5), ("chan_smag_wm", (32, 16, 16), 5), ("chan_dsmag", (32, 16, 16), 5),
                                             ("halfchan_imp1d", (16, 16, 16), 3), ("chan_smag", (24, 20, 12), 10),
                                             # tile kernels: partial tiles in x and y, several x tiles, k chunks, wall-modelled z faces
-                                            ("chan_dsmag", (80, 20, 12), 3), ("chan_dsmag_wm", (128, 30, 70), 2), ("chan_smag_wm", (96, 18, 40), 3),
+                                            ("chan_dsmag", (80, 20, 12), 3), ("tgv_dsmag_ppp", (72, 16, 40), 3), ("chan_dsmag_wm", (128, 30, 70), 2), ("chan_smag_wm", (96, 18, 40), 3),
                                             ("duct_smag_wm", (16, 24, 24), 4), ("cavity_nnn", (16, 16, 16), 5),
                                             # 3-D implicit diffusion (impdiff = 1): Helmholtz solves of u,v,w through the FFT solver
                                             ("couette_imp3d_ops", (16, 16, 16), 4), ("couette_imp3d_ops", (32, 20, 24), 3)])
@@ -69,8 +69,11 @@ def test_time_steps(name, ng, nsteps):
     assert relerr(gp[1:-1, 1:-1, 1:-1] - gp[1:-1, 1:-1, 1:-1].mean(), p[1:-1, 1:-1, 1:-1] - p[1:-1, 1:-1, 1:-1].mean()) < 1e-8
     assert relerr(gvis, visct) < 1e-7
     dg, do = h.chkdiv(), o.chkdiv(u, v, w)
-    # divergence after projection: round-off level, not worse than a decade above the oracle's (a smaller one is fine)
-    assert dg[1] < 1e-11 and dg[1] < 20. * do[1] + 1e-14
+    # divergence after projection: round-off level, not worse than a decade above the oracle's (a smaller one is fine).
+    # Triply periodic boxes whose n3 is not a power of two are the exception: initgrid's default-real arithmetic
+    # (initgrid.f90:63) leaves dzf non-uniform at 1e-7, the singular Poisson problem is then incompatible and the reference
+    # algorithm itself (restated by the oracle) stops at ~1e-9.
+    assert dg[1] < 20. * do[1] + 1e-14 and (dg[1] < 1e-11 or do[1] > 1e-11)
     h.close()
 
 
