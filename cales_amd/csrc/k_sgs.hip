@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void k_alph2(Geom g, double w0, double w1, dou
 // written as whole 128-B lines; the read-only K_DF uses 62 x TY outputs with the x halo inside the wave. With the wall rule
 // Q(0) = 2Q(1)-Q(2) ghost planes of extrapolated quantities are never read.
 #ifndef TYB
-#define TYB 14
+#define TYB 8       // measured at 512^3: 8 (divides the usual n2, 10 waves per block) beats 14 and 6
 #endif
 struct Filter6Args { const double *in[6]; double *out[6]; int kchunk, zlo, zhi, perx; };   // perx: x ghost columns are not stored, wrap around
 // K_B: top-hat filter of six fields (the products |S|Sij). Tile = 64 x TYB outputs from i = 1 + 64 bx (whole 128-B lines in and
@@ -321,7 +321,7 @@ __device__ inline void uiuj(const double *s, double *q) {
 // rate of the test-filtered velocity from an LDS ring of three raw planes of uf,vf,wf, Mij = 2 (filter(|S|Sij) - alph2 |Sf| Sfij)
 // (sgs.f90:261-272), the contractions (sgs.f90:344-355) and the per-plane partial sums. Mij is never stored.
 #ifndef TYF
-#define TYF 14
+#define TYF 8       // measured: 8 and 10 beat 14 (spills at 1024 threads), 6, 9, 11, 12
 #endif
 struct LijMijArgs {
   const double *uc[3], *uf[3], *mf[6];
