@@ -10,7 +10,9 @@
 // Algorithmic traffic: 14 words/cell (5 in + 3 old r.h.s. in + 3 velocities + 3 r.h.s. out) instead of 7 + 13.
 #include "common.hpp"
 
+#ifndef TYM
 #define TYM 6
+#endif
 
 struct MomRkArgs {
   const double *u, *v, *w, *s, *p, *duo, *dvo, *dwo;
