@@ -31,6 +31,7 @@ def _single(case, nsteps):
 
 @pytest.mark.parametrize("name,ng,P", [("chan_smag_wm", (32, 24, 16), 2), ("chan_smag_wm", (32, 24, 16), 4),
                                        ("chan_dsmag", (24, 32, 16), 4), ("tgv_ppp", (16, 24, 12), 3),
+                                       ("chan_dsmag_wm", (72, 32, 40), 2), ("tgv_dsmag_ppp", (32, 24, 16), 3),
                                        ("halfchan_imp1d", (16, 16, 12), 2), ("chan_smag", (64, 16, 8), 8),
                                        ("duct_smag_wm", (16, 24, 24), 2), ("duct_smag_wm_imp1d", (16, 24, 24), 2), ("cavity_nnn", (16, 24, 12), 4)])
 def test_slab_ranks_match_single_rank(name, ng, P):
