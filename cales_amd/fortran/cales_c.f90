@@ -93,5 +93,25 @@ module cales_c
     integer(c_int) function cales_updatep(ctx,alpha) bind(C,name='cales_updatep')
       import; type(c_ptr), value :: ctx; real(c_double), value :: alpha
     end function
+    integer(c_int) function cales_bulk_forcing(ctx) bind(C,name='cales_bulk_forcing')
+      import; type(c_ptr), value :: ctx
+    end function
+    integer(c_int) function cales_updt_rhs_b(ctx) bind(C,name='cales_updt_rhs_b')
+      import; type(c_ptr), value :: ctx
+    end function
+    integer(c_int) function cales_helmholtz_z(ctx,ivel,alpha) bind(C,name='cales_helmholtz_z')   ! _IMPDIFF + _IMPDIFF_1D
+      import; type(c_ptr), value :: ctx; integer(c_int), value :: ivel; real(c_double), value :: alpha
+    end function
+    integer(c_int) function cales_helmholtz(ctx,ivel,alpha) bind(C,name='cales_helmholtz')       ! _IMPDIFF (periodic x,y)
+      import; type(c_ptr), value :: ctx; integer(c_int), value :: ivel; real(c_double), value :: alpha
+    end function
+    ! multi-GPU, exchanges done by the library with RCCL: rank 0 fills id(128), the host broadcasts it
+    ! (call MPI_Bcast(id,128,MPI_BYTE,0,comm,ierr)), every rank joins
+    integer(c_int) function cales_comm_unique_id(id) bind(C,name='cales_comm_unique_id')
+      import; character(kind=c_char) :: id(128)
+    end function
+    integer(c_int) function cales_comm_init_rccl(ctx,id) bind(C,name='cales_comm_init_rccl')
+      import; type(c_ptr), value :: ctx; character(kind=c_char), intent(in) :: id(128)
+    end function
   end interface
 end module cales_c
