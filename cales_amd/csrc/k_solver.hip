@@ -160,11 +160,12 @@ __device__ inline void fft_line8(int N, cpx *buf, int t, const cpx *__restrict__
   }
 }
 
+__device__ inline int dct_src(int e, int n) { return e < n / 2 ? 2 * e : 2 * (n - 1 - e) + 1; }   // Makhoul: v[e] = x[dct_src(e)]
 // x pass for nh = n1/2 = 2^p. Persistent: a block owns `iters` consecutive groups of R rows, R = blockDim.x / (nh/8);
 // the next group's rows are prefetched into registers while the current one is transformed; twiddles live in LDS.
 template <int INV>
-__global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const cpx *__restrict__ twg, const cpx *__restrict__ twpg,
-                                                 double *__restrict__ p, double scale, Spec S, double2 *__restrict__ spec) {
+__global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, int kind, const cpx *__restrict__ twg, const cpx *__restrict__ twpg,
+                                                 const cpx *__restrict__ twd, double *__restrict__ p, double scale, Spec S, double2 *__restrict__ spec) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int T = nh >> 3, R = blockDim.x / T, row = threadIdx.x / T, t = threadIdx.x % T, ld = lpad(nh) + 2;
   cpx *tw = reinterpret_cast<cpx *>(smem), *twp = tw + nh;                   // nh + (nh+1) twiddles
@@ -181,11 +182,22 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const
     if (!INV) {
       const double *rowp = p + g.ix(0, j, k);
 #pragma unroll
-      for (int e = 0; e < NE; ++e) { const int q = t + e * T; nxt[e] = cpx{rowp[1 + 2 * q], rowp[2 + 2 * q]}; }
-    } else {
+      for (int e = 0; e < NE; ++e) { const int q = t + e * T; nxt[e] = cpx{rowp[1 + 2 * q], rowp[2 + 2 * q]}; }      // Makhoul's order is applied in LDS
+    } else if (!kind) {
 #pragma unroll
       for (int e = 0; e < NE; ++e) { const double2 v = spec[S.at_slab(g, t + e * T, j, k)]; nxt[e] = cpx{v.x, v.y}; }
       if (t == 0) { const double2 v = spec[S.at_slab(g, nh, j, k)]; nxt[NE] = cpx{v.x, v.y}; }
+    } else {            // DCT-III input: X_k = conj(w_k) (Y_k - i Y_{n-k}), Y_n := 0, from the n real coefficients of the row
+      const double *sd = reinterpret_cast<const double *>(spec);
+      const int n = 2 * nh;
+      auto coef = [&](int kk) {
+        const double yk = sd[2 * S.at_slab(g, kk >> 1, j, k) + (kk & 1)];
+        const int r2 = n - kk; const double ym = kk == 0 ? 0. : sd[2 * S.at_slab(g, r2 >> 1, j, k) + (r2 & 1)];
+        return cmul(cconj(twd[kk]), cpx{yk, -ym});
+      };
+#pragma unroll
+      for (int e = 0; e < NE; ++e) nxt[e] = coef(t + e * T);
+      if (t == 0) nxt[NE] = coef(nh);
     }
   };
   long r = ((long)blockIdx.x * iters) * R + row;
@@ -193,8 +205,17 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const
   for (int it = 0; it < iters; ++it, r += R) {
     const bool live = r < nrows;
     int j = 1, k = 1; if (live) rowptr(r, j, k);
+    if (kind && !INV) {          // x[2q] -> v[q], x[2q+1] -> v[n-1-q] (v = the real sequence the r2c transform sees, two reals per complex slot)
+      double *Ad = reinterpret_cast<double *>(A);
 #pragma unroll
-    for (int e = 0; e < NE; ++e) A[lpad(t + e * T)] = nxt[e];
+      for (int e = 0; e < NE; ++e) {
+        const int q = t + e * T, r = 2 * nh - 1 - q;
+        Ad[2 * lpad(q >> 1) + (q & 1)] = nxt[e].x; Ad[2 * lpad(r >> 1) + (r & 1)] = nxt[e].y;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) A[lpad(t + e * T)] = nxt[e];
+    }
     if (INV && t == 0) A[lpad(nh)] = nxt[NE];
     __syncthreads();
     if (it + 1 < iters) fetch(r + R);                                        // in flight during the transform
@@ -208,8 +229,17 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const
           const cpx D = csub(zk, zm), O = {0.5 * D.y, -0.5 * D.x};     // -i/2 * (zk - conj(zm))
           const cpx wO = cmul(twp[kk], O);
           const cpx xk = cadd(E, wO), xm = cconj(csub(E, wO));
-          spec[S.at_slab(g, kk, j, k)] = make_double2(xk.x, xk.y);
-          spec[S.at_slab(g, nh - kk, j, k)] = make_double2(xm.x, xm.y);
+          if (!kind) {
+            spec[S.at_slab(g, kk, j, k)] = make_double2(xk.x, xk.y);
+            spec[S.at_slab(g, nh - kk, j, k)] = make_double2(xm.x, xm.y);
+          } else {      // DCT-II coefficients Y_k = 2 Re(w_k V_k), Y_{n-k} = -2 Im(w_k V_k) at the real slots of the row
+            double *sd = reinterpret_cast<double *>(spec);
+            const int n = 2 * nh, k2 = nh - kk;
+            const cpx a = cmul(twd[kk], xk), b2 = cmul(twd[k2], xm);
+            auto put = [&](int rr, double val) { if (rr < n) sd[2 * S.at_slab(g, rr >> 1, j, k) + (rr & 1)] = val; };
+            put(kk, 2. * a.x); if (kk) put(n - kk, -2. * a.y);
+            put(k2, 2. * b2.x); if (k2 && k2 != n - k2) put(n - k2, -2. * b2.y);
+          }
         }
       }
     } else {
@@ -226,7 +256,13 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const
       fft_line8<1>(nh, A, t, tw);
       if (live) {
 #pragma unroll
-        for (int e = 0; e < NE; ++e) { const int q = t + e * T; const cpx z = A[lpad(q)]; rowp[1 + 2 * q] = z.x * scale; rowp[2 + 2 * q] = z.y * scale; }
+        for (int e = 0; e < NE; ++e) {
+          const int q = t + e * T;
+          if (kind) {            // x[2q] = v[q], x[2q+1] = v[n-1-q], read back through the same LDS mapping
+            const double *Ad = reinterpret_cast<const double *>(A); const int r = 2 * nh - 1 - q;
+            rowp[1 + 2 * q] = Ad[2 * lpad(q >> 1) + (q & 1)] * scale; rowp[2 + 2 * q] = Ad[2 * lpad(r >> 1) + (r & 1)] * scale;
+          } else { const cpx z = A[lpad(q)]; rowp[1 + 2 * q] = z.x * scale; rowp[2 + 2 * q] = z.y * scale; }
+        }
       }
     }
     __syncthreads();
@@ -236,7 +272,8 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const
 // y pass for N = n2 = 2^p: CB = blockDim.x / (N/8) adjacent complex columns; persistent over `kchunk` planes with
 // register prefetch of the next plane; twiddles in LDS.
 template <int INV>
-__global__ __launch_bounds__(512) void k_fft_y8(Geom g, int N, int ncols, int kchunk, const cpx *__restrict__ twg, Spec S, double2 *__restrict__ pc) {
+__global__ __launch_bounds__(512) void k_fft_y8(Geom g, int N, int ncols, int kchunk, int kind, const cpx *__restrict__ twg,
+                                                 const cpx *__restrict__ twd, Spec S, double2 *__restrict__ pc) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int T = N >> 3, CB = blockDim.x / T, ld = lpad(N) + 1;
   const int m0 = blockIdx.x * CB, kbeg = blockIdx.y * kchunk + 1, kend = min(kbeg + kchunk - 1, g.n3);
@@ -251,17 +288,43 @@ __global__ __launch_bounds__(512) void k_fft_y8(Geom g, int N, int ncols, int kc
       if (m0 + col < ncols) { const double2 v = pc[S.at_mode(g, m0 + col, j + 1, k)]; nxt[e] = cpx{v.x, v.y}; }
     }
   };
+  // kind 1 (Neumann-Neumann, DCT-II/III on the real and the imaginary part alike): Makhoul order in, weights out (forward);
+  // weights in, Makhoul order out (inverse) -- see k_fft_y
+  auto makhoul = [&](int j) { return (j & 1) ? N - 1 - (j >> 1) : (j >> 1); };
   fetch(kbeg);
   for (int k = kbeg; k <= kend; ++k) {
 #pragma unroll
-    for (int e = 0; e < NE; ++e) { const int q = threadIdx.x + e * blockDim.x, col = q % CB, j = q / CB; base[(size_t)col * ld + lpad(j)] = nxt[e]; }
+    for (int e = 0; e < NE; ++e) {
+      const int q = threadIdx.x + e * blockDim.x, col = q % CB, j = q / CB;
+      base[(size_t)col * ld + lpad((kind && !INV) ? makhoul(j) : j)] = nxt[e];
+    }
     __syncthreads();
     if (k < kend) fetch(k + 1);                                               // in flight during the transform
+    if (kind && INV) {            // Z_k = conj(w_k) (C_k - i C_{N-k}), C_N := 0
+      cpx tmp[NE];
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int q = threadIdx.x + e * blockDim.x, col = q % CB, kk = q / CB;
+        const cpx ck = base[(size_t)col * ld + lpad(kk)], cm = kk == 0 ? cpx{0., 0.} : base[(size_t)col * ld + lpad(N - kk)];
+        tmp[e] = cmul(cconj(twd[kk]), cpx{ck.x + cm.y, ck.y - cm.x});
+      }
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < NE; ++e) { const int q = threadIdx.x + e * blockDim.x, col = q % CB, kk = q / CB; base[(size_t)col * ld + lpad(kk)] = tmp[e]; }
+      __syncthreads();
+    }
     fft_line8<INV>(N, base + (size_t)(threadIdx.x / T) * ld, threadIdx.x % T, tw);
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
       const int q = threadIdx.x + e * blockDim.x, c2 = q % CB, j = q / CB;
-      if (m0 + c2 < ncols) { const cpx v = base[(size_t)c2 * ld + lpad(j)]; pc[S.at_mode(g, m0 + c2, j + 1, k)] = make_double2(v.x, v.y); }
+      if (m0 + c2 < ncols) {
+        const cpx *Zc = base + (size_t)c2 * ld;
+        cpx v;
+        if (!kind) v = Zc[lpad(j)];
+        else if (!INV) { const cpx w = twd[j]; v = cadd(cmul(w, Zc[lpad(j)]), cmul(cconj(w), Zc[lpad((N - j) % N)])); }   // C_j = w_j V_j + conj(w_j) V_{N-j}
+        else v = Zc[lpad(makhoul(j))];
+        pc[S.at_mode(g, m0 + c2, j + 1, k)] = make_double2(v.x, v.y);
+      }
     }
     __syncthreads();
   }
@@ -272,7 +335,6 @@ __global__ __launch_bounds__(512) void k_fft_y8(Geom g, int N, int ncols, int kc
 // kind 0: periodic (FFTW R2HC/HC2R); kind 1: Neumann-Neumann cell-centred (REDFT10/REDFT01 = DCT-II/III) by Makhoul's
 // reordering v[i] = x[2i], v[n-1-i] = x[2i+1] around the same real FFT: Y_k = 2 Re(w_k V_k), Y_{n-k} = -2 Im(w_k V_k),
 // w_k = e^{-i pi k/(2n)} (table twd); the n real coefficients Y_0..Y_{n-1} are stored at the real slots 0..n-1 of the row.
-__device__ inline int dct_src(int e, int n) { return e < n / 2 ? 2 * e : 2 * (n - 1 - e) + 1; }   // v[e] = x[dct_src(e)]
 template <int INV>
 __global__ __launch_bounds__(256) void k_fft_x(Geom g, FftPlan P, int R, int kind, const cpx *__restrict__ tw, const cpx *__restrict__ twp,
                                                 const cpx *__restrict__ twd, double *__restrict__ p, double scale, Spec S, double2 *__restrict__ spec) {
@@ -532,7 +594,7 @@ int solver_setup(cales_ctx *c) {
   if (sp.shx > 64 * 1024 || sp.shy > 64 * 1024) { c->err = "solver: line too long for the LDS-resident transform"; return 1; }
   // power-of-two lines take the radix-8 register kernels
   auto pow2 = [](int v) { return v >= 16 && (v & (v - 1)) == 0; };
-  sp.x8 = pow2(n1 / 2) && n1 / 2 <= 1024 && !c->xkind; sp.y8 = pow2(n2g) && n2g <= 1024 && !c->ykind;
+  sp.x8 = pow2(n1 / 2) && n1 / 2 <= 1024; sp.y8 = pow2(n2g) && n2g <= 1024;
   if (sp.x8) { const int T = (n1 / 2) / 8; sp.x8_threads = T >= 256 ? T : (256 / T) * T;
                sp.shx8 = ((size_t)(sp.x8_threads / T) * (n1 / 2 + n1 / 16 + 2) + (n1 + 1)) * sizeof(cpx); }
   if (sp.y8) { const int T = n2g / 8; int CB = std::max(1, std::min(std::max(8, 256 / T), 512 / T));
@@ -615,13 +677,13 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
   int ykchunk = 1; { const long cg = (ncol + CB8 - 1) / CB8; while (ykchunk < 8 && cg * (n[2] / (ykchunk * 2)) >= 2048 && n[2] % (ykchunk * 2) == 0) ykchunk *= 2; }
   const int ychunks = (n[2] + ykchunk - 1) / ykchunk;
   { ProfScope ps(c, "fft_x_fwd");
-    if (sp->x8) hipLaunchKernelGGL(k_fft_x8<0>, dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
-                                   (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, pp, 1., S, slab_spec);
+    if (sp->x8) hipLaunchKernelGGL(k_fft_x8<0>, dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters, c->xkind,
+                                   (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec);
     else hipLaunchKernelGGL(k_fft_x<0>, dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx, c->xkind,
                        (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec); }
   if (dist) { ProfScope ps(c, "alltoall"); if (c->comm.a2a(c->comm.user, 0, a2a_count)) { c->err = "alltoall callback failed"; return 1; } }
   { ProfScope ps(c, "fft_y_fwd");
-    if (sp->y8) hipLaunchKernelGGL(k_fft_y8<0>, dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, S, mode_spec);
+    if (sp->y8) hipLaunchKernelGGL(k_fft_y8<0>, dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
     else hipLaunchKernelGGL(k_fft_y<0>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
   // pressure equation without a Dirichlet condition in z: the zero-eigenvalue mode (if x and y have one) is singular
   const int fixnull = (poisson && CBP(c, 0, 3) != 'D' && CBP(c, 1, 3) != 'D' && getenv("CALES_KEEP_NULL_MODE") == nullptr) ? 1 : 0;
@@ -633,12 +695,12 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
     else if (getenv("CALES_GAUSSEL_PAIR")) hipLaunchKernelGGL((k_gaussel<double2, 0>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2, fixnull);
     else hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, fixnull); }
   { ProfScope ps(c, "fft_y_bwd");
-    if (sp->y8) hipLaunchKernelGGL(k_fft_y8<1>, dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, S, mode_spec);
+    if (sp->y8) hipLaunchKernelGGL(k_fft_y8<1>, dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
     else hipLaunchKernelGGL(k_fft_y<1>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
   if (dist) { ProfScope ps(c, "alltoall"); if (c->comm.a2a(c->comm.user, 1, a2a_count)) { c->err = "alltoall callback failed"; return 1; } }
   { ProfScope ps(c, "fft_x_bwd");
-    if (sp->x8) hipLaunchKernelGGL(k_fft_x8<1>, dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
-                                   (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, pp, c->normfft, S, slab_spec);
+    if (sp->x8) hipLaunchKernelGGL(k_fft_x8<1>, dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters, c->xkind,
+                                   (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec);
     else hipLaunchKernelGGL(k_fft_x<1>, dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx, c->xkind,
                        (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec); }
   HIPCHK(c, hipGetLastError());

@@ -12,10 +12,15 @@ def main():
     ap.add_argument("--sgs", default="dsmag")
     ap.add_argument("--ops", nargs="+", default=["cmpt_sgs"])
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--golden", default=None, help="take the case (BCs, forcing, sgs, impdiff) from tests/golden/<name>.npz instead of the bench channel")
     a = ap.parse_args()
     import bench
     from cales_amd.hotpath import HotPath, initflow
-    case = bench.channel_case(a.ng, a.sgs)
+    if a.golden:
+        from tests.util import load_golden
+        _, case = load_golden(a.golden); case.ng[:] = a.ng
+    else:
+        case = bench.channel_case(a.ng, a.sgs)
     h = HotPath(case)
     h.upload(*initflow(case)); h.startup()
     dt = 0.5 * h.chkdt()
