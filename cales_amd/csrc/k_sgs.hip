@@ -8,7 +8,7 @@
 #define BY 4
 
 // ------------------------------------------------------------------------------------------ extrapolate
-struct ExJob { double *p; int idir, ibound; double factor; };
+struct ExJob { double *p; int idir, ibound; double factor; double *save; int restore; };   // save: plane buffer for the overwritten ghosts
 struct ExJobs { int njobs; ExJob job[18]; };
 __global__ __launch_bounds__(256) void k_extrapolate(Geom g, ExJobs J) {
   const ExJob jb = J.job[blockIdx.z];
@@ -20,14 +20,26 @@ __global__ __launch_bounds__(256) void k_extrapolate(Geom g, ExJobs J) {
   double *p = jb.p + (idir == 1 ? g.ix(0, a, b) : idir == 2 ? g.ix(a, 0, b) : g.ix(a, b, 0));
 #define P(m) p[(long)(m)*st]
   const double f = jb.factor;
+  const int gh = jb.ibound == 0 ? 0 : n + 1;
+  if (jb.save) {                      // in-place use on a live field: keep / give back the ghost value
+    const size_t q = (size_t)a + (size_t)(na + 2) * b;
+    if (jb.restore) { P(gh) = jb.save[q]; return; }
+    jb.save[q] = P(gh);
+  }
   if (idir < 3) { if (jb.ibound == 0) P(0) = 2. * P(1) - P(2); else P(n + 1) = 2. * P(n) - P(n - 1); }
   else { if (jb.ibound == 0) P(0) = (1. + f) * P(1) - f * P(2); else P(n + 1) = (1. + f) * P(n) - f * P(n - 1); }
 #undef P
 }
 // mode 0: `lwm` form (wall-model faces, z factors from the grid), 1: `cbc` form (all no-slip walls, factor 1)
-static int extrapolate(cales_ctx *c, int nf, double **p, const int *iface, int mode) {
+// save != nullptr: the fields are live (u,v,w themselves): the ghosts they lose are kept in `save` (restore = 0) and given back
+// afterwards (restore = 1, directions in reverse order so that edge cells see the same sequence backwards)
+static int extrapolate(cales_ctx *c, int nf, double **p, const int *iface, int mode, double *save = nullptr, int restore = 0) {
   const int *n = c->n;
-  for (int idir = 1; idir <= 3; ++idir) {      // one launch per direction, order x,y,z as the reference
+  // save slots: [direction][field][side], each the size of that direction's ghost plane
+  const size_t psz[3] = {(size_t)(n[1] + 2) * (n[2] + 2), (size_t)(n[0] + 2) * (n[2] + 2), (size_t)(n[0] + 2) * (n[1] + 2)};
+  const size_t poff[3] = {0, 6 * psz[0], 6 * (psz[0] + psz[1])};
+  for (int step = 1; step <= 3; ++step) {      // one launch per direction, order x,y,z as the reference
+    const int idir = restore ? 4 - step : step;
     ExJobs J; J.njobs = 0;
     for (int q = 0; q < nf; ++q) for (int ib = 0; ib <= 1; ++ib) {
       bool done;
@@ -38,7 +50,8 @@ static int extrapolate(cales_ctx *c, int nf, double **p, const int *iface, int m
         factor = ib == 0 ? (1. / c->dzci[0]) * c->dzci[1] : (1. / c->dzci[n[2]]) * c->dzci[n[2] - 1];
       }
       if (!done) continue;
-      ExJob &j = J.job[J.njobs++]; j.p = p[q]; j.idir = idir; j.ibound = ib; j.factor = factor;
+      ExJob &j = J.job[J.njobs++]; j.p = p[q]; j.idir = idir; j.ibound = ib; j.factor = factor; j.save = nullptr; j.restore = restore;
+      if (save) j.save = save + poff[idir - 1] + (size_t)(q * 2 + ib) * psz[idir - 1];
     }
     if (!J.njobs) continue;
     const int na = idir == 1 ? n[1] : n[0], nb = idir == 3 ? n[1] : n[2];
@@ -713,12 +726,21 @@ int op_cmpt_sgs(cales_ctx *c) {
   if (c->C.sgstype == 2 && dsmag_fast_ok(c)) return dsmag_fast(c);
   if (c->C.sgstype == 1 && smag_fast_ok(c)) return smag_fast(c);
   double **wk = c->wk;
-  // wk(1:3) = u,v,w ; extrapolate at wall-model faces ; strain rate (sgs.f90:84-92 / 173-181)
-  hipLaunchKernelGGL(k_copy3, lin_grid(nt), dim3(256), 0, c->stream, nt, f[CALES_U], f[CALES_V], f[CALES_W], wk[0], wk[1], wk[2]);
   const int if123[3] = {1, 2, 3};
-  if (int e = extrapolate(c, 3, wk, if123, 0)) return e;
   if (c->C.sgstype == 1) {
-    if (int e = strain_rate(c, wk[0], wk[1], wk[2], c->s0, nullptr)) return e;
+    // wk(1:3) = u,v,w ; extrapolate at wall-model faces ; strain rate (sgs.f90:84-92) -- without the copies: the ghost cells of
+    // u,v,w at the wall-model faces are replaced in place, kept in wk(1), and given back before anything else reads them
+    double *uvw[3] = {f[CALES_U], f[CALES_V], f[CALES_W]};
+    const size_t need = 6 * ((size_t)(n[1] + 2) * (n[2] + 2) + (size_t)(n[0] + 2) * (n[2] + 2) + (size_t)(n[0] + 2) * (n[1] + 2));
+    if (need <= c->ntot) {
+      if (int e = extrapolate(c, 3, uvw, if123, 0, wk[0], 0)) return e;
+      if (int e = strain_rate(c, uvw[0], uvw[1], uvw[2], c->s0, nullptr)) return e;
+      if (int e = extrapolate(c, 3, uvw, if123, 0, wk[0], 1)) return e;
+    } else {            // degenerate grids: the copies of the reference
+      hipLaunchKernelGGL(k_copy3, lin_grid(nt), dim3(256), 0, c->stream, nt, f[CALES_U], f[CALES_V], f[CALES_W], wk[0], wk[1], wk[2]);
+      if (int e = extrapolate(c, 3, wk, if123, 0)) return e;
+      if (int e = strain_rate(c, wk[0], wk[1], wk[2], c->s0, nullptr)) return e;
+    }
     SmagArgs A; A.w0 = c->is_wall[0]; A.w1 = c->is_wall[1]; A.w2 = c->is_wall[2]; A.w3 = c->is_wall[3]; A.w4 = c->is_wall[4]; A.w5 = c->is_wall[5];
     A.dl1 = c->dl[0]; A.dl2 = c->dl[1]; A.l3 = c->C.l[2]; A.dxi = c->dli[0]; A.dyi = c->dli[1]; A.visc = c->visc;
     A.sumw = 0.; for (int q = 0; q < 6; ++q) A.sumw += c->is_wall[q];
@@ -726,7 +748,9 @@ int op_cmpt_sgs(cales_ctx *c) {
     HIPCHK(c, hipGetLastError());
     return 0;
   }
-  // ---- dynamic model (sgs.f90:153-380)
+  // ---- dynamic model (sgs.f90:153-380): wk(1:3) = u,v,w ; extrapolate at wall-model faces ; strain rate (sgs.f90:173-181)
+  hipLaunchKernelGGL(k_copy3, lin_grid(nt), dim3(256), 0, c->stream, nt, f[CALES_U], f[CALES_V], f[CALES_W], wk[0], wk[1], wk[2]);
+  if (int e = extrapolate(c, 3, wk, if123, 0)) return e;
   double **sij = c->sij, **mij = c->mij, **lij = c->sij;
   if (int e = strain_rate(c, wk[0], wk[1], wk[2], c->s0, sij)) return e;
   hipLaunchKernelGGL(k_copy1, lin_grid(nt), dim3(256), 0, c->stream, nt, c->s0, visct);
