@@ -43,15 +43,16 @@ def _read_fld(path, ng):
 
 
 @pytest.mark.skipif(not os.path.exists(EXE), reason="Fortran host not built (amdflang absent)")
-@pytest.mark.parametrize("name", ["tgv_ppp", "chan_smag_wm"])
+@pytest.mark.parametrize("name", ["tgv_ppp", "chan_smag_wm", "duct_smag_wm_imp1d", "couette_imp3d_ops"])
 def test_fortran_host_equals_python_host(tmp_path, name):
     from cales_amd.hotpath import HotPath, initflow
     from cales_amd.nml import parse_text
     text = _nml(name, nstep=4, icheck=2, iout0d=2, isave=100000)
     text = re.sub(r"stop_type\(1:3\) = .*", "stop_type(1:3) = T, F, F", text)
-    out = _run(str(tmp_path), text)
+    imp = int(load_golden(name)[1].impdiff)           # the reference's build switches are a run-time argument of the host
+    out = _run(str(tmp_path), text, args=(str(imp),) if imp else ())
     assert "*** Fim ***" in out
-    case = parse_text(text)
+    case = parse_text(text); case.impdiff = imp
     ng = tuple(int(x) for x in case.ng)
     (u, v, w, p), time, istep = _read_fld(os.path.join(tmp_path, "fld.bin"), ng)
     assert istep == 4
