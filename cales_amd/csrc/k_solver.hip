@@ -169,9 +169,11 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, int k
   extern __shared__ __align__(16) unsigned char smem[];
   const int T = nh >> 3, R = blockDim.x / T, row = threadIdx.x / T, t = threadIdx.x % T, ld = lpad(nh) + 2;
   cpx *tw = reinterpret_cast<cpx *>(smem), *twp = tw + nh;                   // nh + (nh+1) twiddles
-  cpx *A = twp + nh + 1 + (size_t)row * ld;
+  cpx *twl = twp + nh + 1;                                                    // DCT weights (kind 1): nh+1 more
+  cpx *A = twl + (kind ? nh + 1 : 0) + (size_t)row * ld;
   for (int q = threadIdx.x; q < nh; q += blockDim.x) tw[q] = twg[q];
   for (int q = threadIdx.x; q <= nh; q += blockDim.x) twp[q] = twpg[q];
+  if (kind) for (int q = threadIdx.x; q <= nh; q += blockDim.x) twl[q] = twd[q];
   const long nrows = (long)g.n2 * g.n3;
   const int NE = 8;                                                          // elements per thread and row: nh / T
   cpx nxt[NE + 1];
@@ -187,17 +189,9 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, int k
 #pragma unroll
       for (int e = 0; e < NE; ++e) { const double2 v = spec[S.at_slab(g, t + e * T, j, k)]; nxt[e] = cpx{v.x, v.y}; }
       if (t == 0) { const double2 v = spec[S.at_slab(g, nh, j, k)]; nxt[NE] = cpx{v.x, v.y}; }
-    } else {            // DCT-III input: X_k = conj(w_k) (Y_k - i Y_{n-k}), Y_n := 0, from the n real coefficients of the row
-      const double *sd = reinterpret_cast<const double *>(spec);
-      const int n = 2 * nh;
-      auto coef = [&](int kk) {
-        const double yk = sd[2 * S.at_slab(g, kk >> 1, j, k) + (kk & 1)];
-        const int r2 = n - kk; const double ym = kk == 0 ? 0. : sd[2 * S.at_slab(g, r2 >> 1, j, k) + (r2 & 1)];
-        return cmul(cconj(twd[kk]), cpx{yk, -ym});
-      };
+    } else {            // DCT-III: the n real coefficients of the row as nh coalesced pairs; combined in LDS below
 #pragma unroll
-      for (int e = 0; e < NE; ++e) nxt[e] = coef(t + e * T);
-      if (t == 0) nxt[NE] = coef(nh);
+      for (int e = 0; e < NE; ++e) { const double2 v = spec[S.at_slab(g, t + e * T, j, k)]; nxt[e] = cpx{v.x, v.y}; }
     }
   };
   long r = ((long)blockIdx.x * iters) * R + row;
@@ -216,9 +210,26 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, int k
 #pragma unroll
       for (int e = 0; e < NE; ++e) A[lpad(t + e * T)] = nxt[e];
     }
-    if (INV && t == 0) A[lpad(nh)] = nxt[NE];
+    if (INV && !kind && t == 0) A[lpad(nh)] = nxt[NE];
     __syncthreads();
     if (it + 1 < iters) fetch(r + R);                                        // in flight during the transform
+    if (INV && kind) {           // X_k = conj(w_k) (Y_k - i Y_{n-k}), Y_n := 0, k = 0..nh, from the coefficients staged in A
+      const double *Ad = reinterpret_cast<const double *>(A); const int n = 2 * nh;
+      auto coef = [&](int kk) {
+        const double yk = Ad[2 * lpad(kk >> 1) + (kk & 1)];
+        const int r2 = n - kk; const double ym = kk == 0 ? 0. : Ad[2 * lpad(r2 >> 1) + (r2 & 1)];
+        return cmul(cconj(twl[kk]), cpx{yk, -ym});
+      };
+      cpx xk[NE + 1];
+#pragma unroll
+      for (int e = 0; e < NE; ++e) xk[e] = coef(t + e * T);
+      if (t == 0) xk[NE] = coef(nh);
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < NE; ++e) A[lpad(t + e * T)] = xk[e];
+      if (t == 0) A[lpad(nh)] = xk[NE];
+      __syncthreads();
+    }
     double *rowp = p + g.ix(0, j, k);
     if (!INV) {
       fft_line8<0>(nh, A, t, tw);
@@ -235,7 +246,7 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, int k
           } else {      // DCT-II coefficients Y_k = 2 Re(w_k V_k), Y_{n-k} = -2 Im(w_k V_k) at the real slots of the row
             double *sd = reinterpret_cast<double *>(spec);
             const int n = 2 * nh, k2 = nh - kk;
-            const cpx a = cmul(twd[kk], xk), b2 = cmul(twd[k2], xm);
+            const cpx a = cmul(twl[kk], xk), b2 = cmul(twl[k2], xm);
             auto put = [&](int rr, double val) { if (rr < n) sd[2 * S.at_slab(g, rr >> 1, j, k) + (rr & 1)] = val; };
             put(kk, 2. * a.x); if (kk) put(n - kk, -2. * a.y);
             put(k2, 2. * b2.x); if (k2 && k2 != n - k2) put(n - k2, -2. * b2.y);
@@ -493,15 +504,18 @@ __global__ __launch_bounds__(256) void k_gaussel_split(Geom g, int nz, int ncol,
 __global__ __launch_bounds__(256) void k_gaussel_ri(Geom g, int nz, int ncol, int nrow, int mofs, int nmode, Spec S, double lscale,
                                                     const double *__restrict__ a, const double *__restrict__ b,
                                                     const double *__restrict__ c, const double *__restrict__ lamx,
-                                                    const double *__restrict__ lamy, double *__restrict__ p, double *__restrict__ dscr, int fixnull) {
+                                                    const double *__restrict__ lamy, double *__restrict__ p, double *__restrict__ dscr, int fixnull, int xreal) {
   // threads run over (row, mode, part) linearly, so a block touches one contiguous piece of a plane per step
   const long q = (long)blockIdx.x * 256 + threadIdx.x;
   const int t = (int)(q % (2 * ncol)), m = t >> 1, part = t & 1, j = (int)(q / (2 * ncol)) + 1;
   if (j > nrow || m + mofs >= nmode) return;
   const size_t e0 = 2 * S.at_mode(g, m, j, 1) + part;
   const size_t st = 2 * (S.blocked ? (size_t)S.cw * S.n2l : (size_t)g.s12 / 2);
-  const size_t s0 = (size_t)m + (size_t)ncol * (size_t)(j - 1), sst = (size_t)ncol * nrow;   // scratch [k][j][m]
-  const double lam = (lamx[m + mofs] + lamy[j - 1]) * lscale;     // lscale = alpha for the Helmholtz solves (main.f90:441), 1 for the pressure
+  // scratch [k][j][m]: one c' per complex mode (both parts store the same value), one per lane when the parts are different modes
+  const size_t s0 = xreal ? (size_t)t + (size_t)2 * ncol * (size_t)(j - 1) : (size_t)m + (size_t)ncol * (size_t)(j - 1);
+  const size_t sst = (xreal ? (size_t)2 : (size_t)1) * ncol * nrow;
+  // xreal (Neumann-Neumann in x): the two reals of a pair are different modes with their own eigenvalue
+  const double lam = ((xreal ? lamx[2 * (m + mofs) + part] : lamx[m + mofs]) + lamy[j - 1]) * lscale;     // lscale = alpha for the Helmholtz solves (main.f90:441), 1 for the pressure
   double z = 1. / (b[0] + lam + CALES_EPS), d = c[0] * z;
   double v = p[e0] * z;
   p[e0] = v; dscr[s0] = d;      // both lanes of a pair store the same c' (one merged write); each reads back what it wrote
@@ -596,7 +610,7 @@ int solver_setup(cales_ctx *c) {
   auto pow2 = [](int v) { return v >= 16 && (v & (v - 1)) == 0; };
   sp.x8 = pow2(n1 / 2) && n1 / 2 <= 1024; sp.y8 = pow2(n2g) && n2g <= 1024;
   if (sp.x8) { const int T = (n1 / 2) / 8; sp.x8_threads = T >= 256 ? T : (256 / T) * T;
-               sp.shx8 = ((size_t)(sp.x8_threads / T) * (n1 / 2 + n1 / 16 + 2) + (n1 + 1)) * sizeof(cpx); }
+               sp.shx8 = ((size_t)(sp.x8_threads / T) * (n1 / 2 + n1 / 16 + 2) + (n1 + 1) + (c->xkind ? n1 / 2 + 1 : 0)) * sizeof(cpx); }
   if (sp.y8) { const int T = n2g / 8; int CB = std::max(1, std::min(std::max(8, 256 / T), 512 / T));
                while (CB > 1 && ((size_t)CB * (n2g + n2g / 8 + 1) + n2g) * sizeof(cpx) > 64 * 1024) CB /= 2;
                sp.y8_threads = CB * T; sp.shy8 = ((size_t)CB * (n2g + n2g / 8 + 1) + n2g) * sizeof(cpx); }
@@ -689,11 +703,14 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
   const int fixnull = (poisson && CBP(c, 0, 3) != 'D' && CBP(c, 1, 3) != 'D' && getenv("CALES_KEEP_NULL_MODE") == nullptr) ? 1 : 0;
   { ProfScope ps(c, "gaussel_z");
     dim3 b(64, 4), gr((ncol + 63) / 64, (n2g + 3) / 4);
-    if (c->xkind) hipLaunchKernelGGL(k_gaussel_split, gr, b, 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, da, db, dc, c->d_lamx, c->d_lamy,
+    if (c->xkind && !periodic_z && getenv("CALES_GAUSSEL_PAIR") == nullptr)
+      hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, lscale, da, db, dc,
+                         c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, fixnull, 1);
+    else if (c->xkind) hipLaunchKernelGGL(k_gaussel_split, gr, b, 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, da, db, dc, c->d_lamx, c->d_lamy,
                                      (double2 *)mode_spec, (double2 *)c->scr1, fixnull);
     else if (periodic_z) hipLaunchKernelGGL((k_gaussel<double2, 1>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2, fixnull);
     else if (getenv("CALES_GAUSSEL_PAIR")) hipLaunchKernelGGL((k_gaussel<double2, 0>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2, fixnull);
-    else hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, fixnull); }
+    else hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, fixnull, 0); }
   { ProfScope ps(c, "fft_y_bwd");
     if (sp->y8) hipLaunchKernelGGL(k_fft_y8<1>, dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
     else hipLaunchKernelGGL(k_fft_y<1>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
