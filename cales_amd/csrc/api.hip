@@ -211,6 +211,7 @@ int cales_local_size(const cales_ctx *c, int32_t n[3], int32_t lo[3]) { for (int
 // ------------------------------------------------------------------------------------------ copies
 int cales_set_field(cales_ctx *c, int field, const double *host) {
   if (field < 0 || field >= CALES_NFIELDS || !c->f[field]) { c->err = "bad field id"; return 1; }
+  if (field == CALES_VISCT) c->visct_zero = false;
   const size_t nh = (size_t)(c->n[0] + 2) * (c->n[1] + 2) * (c->n[2] + 2);
   const dim3 b(64, 4, 1), gr((c->n[0] + 2 + 63) / 64, (c->n[1] + 2 + 3) / 4, c->n[2] + 2);
   HIPCHK(c, hipMemcpyAsync(c->scr1, host, nh * sizeof(double), hipMemcpyHostToDevice, c->stream));     // scr1: scratch between operators

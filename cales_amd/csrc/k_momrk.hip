@@ -22,7 +22,8 @@ struct MomRkArgs {
   int kchunk;
 };
 
-template <int IMP, typename OFF>
+// NOS = 1: no subgrid model (visct is identically zero, sgs.f90:62-68): its loads, LDS traffic and terms are compiled out
+template <int IMP, typename OFF, int NOS>
 __global__ __launch_bounds__(64 * (TYM + 2), 4) void k_momrk(Geom g, MomRkArgs A) {
   __shared__ double sh[4][4][TYM + 2][66];
   __shared__ double shp[3][TYM + 2][66];
@@ -38,19 +39,19 @@ __global__ __launch_bounds__(64 * (TYM + 2), 4) void k_momrk(Geom g, MomRkArgs A
   // tile -- wave 0 the left column, wave TYM+1 the right one; lane l -> row l/5, field l%5. One register instead of five.
   const bool hwave = ty == 0 || ty == TYM + 1;
   const int hr = tx / 5, hf_ = tx % 5, hxs = ty == 0 ? 0 : 65, hi_ = ty == 0 ? bx_ * 64 : bx_ * 64 + 65, hj = by_ * TYM + hr;
-  const bool hok = hwave && tx < 5 * (TYM + 2) && hi_ <= g.n1 + 1 && hj <= g.n2 + 1;
+  const bool hok = hwave && tx < 5 * (TYM + 2) && hi_ <= g.n1 + 1 && hj <= g.n2 + 1 && !(NOS && hf_ == 3);
   const double *hp = nullptr;
   if (hok) { const double *fp = hf_ == 0 ? A.u : hf_ == 1 ? A.v : hf_ == 2 ? A.w : hf_ == 3 ? A.s : A.p; hp = fp + g.ix(hi_, hj, 0); }
   const size_t sk64 = (size_t)g.s12;
   auto ld5 = [&](int k, double *q, double &h) {
-    if (ldok && k <= g.n3 + 1) { const OFF c = c0 + (OFF)k * sk; q[0] = ldb(A.u, c); q[1] = ldb(A.v, c); q[2] = ldb(A.w, c); q[3] = ldb(A.s, c); q[4] = ldb(A.p, c); }
+    if (ldok && k <= g.n3 + 1) { const OFF c = c0 + (OFF)k * sk; q[0] = ldb(A.u, c); q[1] = ldb(A.v, c); q[2] = ldb(A.w, c); q[3] = NOS ? 0. : ldb(A.s, c); q[4] = ldb(A.p, c); }
     else { q[0] = q[1] = q[2] = q[3] = q[4] = 0.; }
     h = (hok && k <= g.n3 + 1) ? hp[(size_t)k * sk64] : 0.;
   };
   // plane kk of the five fields -> ring slot kk&3 (u,v,w,visct) and kk%3 (p)
   auto put = [&](int kk, const double *q, double h) {
 #pragma unroll
-    for (int f = 0; f < 4; ++f) sh[f][kk & 3][ty][tx + 1] = q[f];
+    for (int f = 0; f < (NOS ? 3 : 4); ++f) sh[f][kk & 3][ty][tx + 1] = q[f];
     shp[kk % 3][ty][tx + 1] = q[4];
     if (hok) { if (hf_ < 4) sh[hf_][kk & 3][hr][hxs] = h; else shp[kk % 3][hr][hxs] = h; }
   };
@@ -72,10 +73,12 @@ __global__ __launch_bounds__(64 * (TYM + 2), 4) void k_momrk(Geom g, MomRkArgs A
                    v_ccc = LS(1, kc, 0, 0), v_pcc = LS(1, kc, 1, 0), v_cpc = LS(1, kc, 0, 1), v_cmp = LS(1, kp, 0, -1), v_ccp = LS(1, kp, 0, 0);
       const double w_ccm = LS(2, km, 0, 0), w_pcm = LS(2, km, 1, 0), w_cpm = LS(2, km, 0, 1), w_cmc = LS(2, kc, 0, -1), w_mcc = LS(2, kc, -1, 0),
                    w_ccc = LS(2, kc, 0, 0), w_pcc = LS(2, kc, 1, 0), w_cpc = LS(2, kc, 0, 1), w_ccp = LS(2, kp, 0, 0);
-      const double s_ccm = LS(3, km, 0, 0), s_pcm = LS(3, km, 1, 0), s_cpm = LS(3, km, 0, 1), s_cmc = LS(3, kc, 0, -1), s_pmc = LS(3, kc, 1, -1),
-                   s_mcc = LS(3, kc, -1, 0), s_ccc = LS(3, kc, 0, 0), s_pcc = LS(3, kc, 1, 0), s_mpc = LS(3, kc, -1, 1), s_cpc = LS(3, kc, 0, 1),
-                   s_cmp = LS(3, kp, 0, -1), s_mcp = LS(3, kp, -1, 0), s_ccp = LS(3, kp, 0, 0), s_ppc = LS(3, kc, 1, 1), s_pcp = LS(3, kp, 1, 0),
-                   s_cpp = LS(3, kp, 0, 1);
+#define LSV(sl, di, dj) (NOS ? 0. : LS(3, sl, di, dj))
+      const double s_ccm = LSV(km, 0, 0), s_pcm = LSV(km, 1, 0), s_cpm = LSV(km, 0, 1), s_cmc = LSV(kc, 0, -1), s_pmc = LSV(kc, 1, -1),
+                   s_mcc = LSV(kc, -1, 0), s_ccc = LSV(kc, 0, 0), s_pcc = LSV(kc, 1, 0), s_mpc = LSV(kc, -1, 1), s_cpc = LSV(kc, 0, 1),
+                   s_cmp = LSV(kp, 0, -1), s_mcp = LSV(kp, -1, 0), s_ccp = LSV(kp, 0, 0), s_ppc = LSV(kc, 1, 1), s_pcp = LSV(kp, 1, 0),
+                   s_cpp = LSV(kp, 0, 1);
+#undef LSV
 #undef LS
       const int pc = k % 3, pn = (k + 1) % 3;
       const double p_ccc = shp[pc][ty][tx + 1], p_pcc = shp[pc][ty][tx + 2], p_cpc = shp[pc][ty + 1][tx + 1], p_ccp = shp[pn][ty][tx + 1];
@@ -165,9 +168,16 @@ int op_momrk(cales_ctx *c, double f1, double f2, double f12) {
   while ((long)gr.x * gr.y * ((n[2] + kchunk - 1) / kchunk) < 2048 && kchunk > 32) kchunk = (kchunk + 1) / 2;
   gr.z = (n[2] + kchunk - 1) / kchunk; A.kchunk = kchunk;
   const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32) && getenv("CALES_WIDE_OFFSETS") == nullptr;      // 32-bit byte offsets
-  if (c->C.impdiff == 2) { if (small) hipLaunchKernelGGL((k_momrk<2, unsigned>), gr, b, 0, c->stream, c->g, A); else hipLaunchKernelGGL((k_momrk<2, size_t>), gr, b, 0, c->stream, c->g, A); }
-  else if (c->C.impdiff == 1) { if (small) hipLaunchKernelGGL((k_momrk<1, unsigned>), gr, b, 0, c->stream, c->g, A); else hipLaunchKernelGGL((k_momrk<1, size_t>), gr, b, 0, c->stream, c->g, A); }
-  else { if (small) hipLaunchKernelGGL((k_momrk<0, unsigned>), gr, b, 0, c->stream, c->g, A); else hipLaunchKernelGGL((k_momrk<0, size_t>), gr, b, 0, c->stream, c->g, A); }
+  const int nos = c->C.sgstype == 0 && c->visct_zero;     // visct known to be identically zero (never set by the host since the last zeroing)
+#define MOMRK_LAUNCH(IMP_)                                                                                             \
+  do {                                                                                                                 \
+    if (small) { if (nos) hipLaunchKernelGGL((k_momrk<IMP_, unsigned, 1>), gr, b, 0, c->stream, c->g, A);              \
+                 else hipLaunchKernelGGL((k_momrk<IMP_, unsigned, 0>), gr, b, 0, c->stream, c->g, A); }                \
+    else { if (nos) hipLaunchKernelGGL((k_momrk<IMP_, size_t, 1>), gr, b, 0, c->stream, c->g, A);                      \
+           else hipLaunchKernelGGL((k_momrk<IMP_, size_t, 0>), gr, b, 0, c->stream, c->g, A); }                        \
+  } while (0)
+  if (c->C.impdiff == 2) MOMRK_LAUNCH(2); else if (c->C.impdiff == 1) MOMRK_LAUNCH(1); else MOMRK_LAUNCH(0);
+#undef MOMRK_LAUNCH
   HIPCHK(c, hipGetLastError());
   for (int q = 0; q < 3; ++q) std::swap(c->f[CALES_U + q], c->f2[q]);
   return 0;

@@ -712,7 +712,7 @@ int op_cmpt_sgs(cales_ctx *c) {
   const int *n = c->n; const size_t nt = c->ntot;
   double **f = c->f; double *visct = f[CALES_VISCT];
   if (c->C.sgstype == 0) {           // 'none': visct = 0 once (sgs.f90:62-68)
-    if (c->sgs_first) { c->sgs_first = false; HIPCHK(c, hipMemsetAsync(visct, 0, nt * sizeof(double), c->stream)); }
+    if (c->sgs_first) { c->sgs_first = false; HIPCHK(c, hipMemsetAsync(visct, 0, nt * sizeof(double), c->stream)); c->visct_zero = true; }
     return 0;
   }
   ProfScope ps(c, c->C.sgstype == 1 ? "cmpt_sgs_smag" : "cmpt_sgs_dsmag");
