@@ -163,10 +163,11 @@ __device__ inline void fft_line8(int N, cpx *buf, int t, const cpx *__restrict__
 __device__ inline int dct_src(int e, int n) { return e < n / 2 ? 2 * e : 2 * (n - 1 - e) + 1; }   // Makhoul: v[e] = x[dct_src(e)]
 // x pass for nh = n1/2 = 2^p. Persistent: a block owns `iters` consecutive groups of R rows, R = blockDim.x / (nh/8);
 // the next group's rows are prefetched into registers while the current one is transformed; twiddles live in LDS.
-template <int INV>
-__global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, int kind, const cpx *__restrict__ twg, const cpx *__restrict__ twpg,
+template <int INV, int KIND>
+__global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const cpx *__restrict__ twg, const cpx *__restrict__ twpg,
                                                  const cpx *__restrict__ twd, double *__restrict__ p, double scale, Spec S, double2 *__restrict__ spec) {
   extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int kind = KIND;                                                 // 0 periodic (R2HC/HC2R), 1 Neumann-Neumann (DCT-II/III)
   const int T = nh >> 3, R = blockDim.x / T, row = threadIdx.x / T, t = threadIdx.x % T, ld = lpad(nh) + 2;
   cpx *tw = reinterpret_cast<cpx *>(smem), *twp = tw + nh;                   // nh + (nh+1) twiddles
   cpx *twl = twp + nh + 1;                                                    // DCT weights (kind 1): nh+1 more
@@ -282,10 +283,11 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, int k
 
 // y pass for N = n2 = 2^p: CB = blockDim.x / (N/8) adjacent complex columns; persistent over `kchunk` planes with
 // register prefetch of the next plane; twiddles in LDS.
-template <int INV>
-__global__ __launch_bounds__(512) void k_fft_y8(Geom g, int N, int ncols, int kchunk, int kind, const cpx *__restrict__ twg,
+template <int INV, int KIND>
+__global__ __launch_bounds__(512) void k_fft_y8(Geom g, int N, int ncols, int kchunk, const cpx *__restrict__ twg,
                                                  const cpx *__restrict__ twd, Spec S, double2 *__restrict__ pc) {
   extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int kind = KIND;
   const int T = N >> 3, CB = blockDim.x / T, ld = lpad(N) + 1;
   const int m0 = blockIdx.x * CB, kbeg = blockIdx.y * kchunk + 1, kend = min(kbeg + kchunk - 1, g.n3);
   cpx *tw = reinterpret_cast<cpx *>(smem), *base = tw + N;
@@ -691,13 +693,16 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
   int ykchunk = 1; { const long cg = (ncol + CB8 - 1) / CB8; while (ykchunk < 8 && cg * (n[2] / (ykchunk * 2)) >= 2048 && n[2] % (ykchunk * 2) == 0) ykchunk *= 2; }
   const int ychunks = (n[2] + ykchunk - 1) / ykchunk;
   { ProfScope ps(c, "fft_x_fwd");
-    if (sp->x8) hipLaunchKernelGGL(k_fft_x8<0>, dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters, c->xkind,
+    if (sp->x8 && c->xkind) hipLaunchKernelGGL((k_fft_x8<0, 1>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
+                                   (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec);
+    else if (sp->x8) hipLaunchKernelGGL((k_fft_x8<0, 0>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec);
     else hipLaunchKernelGGL(k_fft_x<0>, dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx, c->xkind,
                        (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec); }
   if (dist) { ProfScope ps(c, "alltoall"); if (c->comm.a2a(c->comm.user, 0, a2a_count)) { c->err = "alltoall callback failed"; return 1; } }
   { ProfScope ps(c, "fft_y_fwd");
-    if (sp->y8) hipLaunchKernelGGL(k_fft_y8<0>, dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
+    if (sp->y8 && c->ykind) hipLaunchKernelGGL((k_fft_y8<0, 1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
+    else if (sp->y8) hipLaunchKernelGGL((k_fft_y8<0, 0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
     else hipLaunchKernelGGL(k_fft_y<0>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
   // pressure equation without a Dirichlet condition in z: the zero-eigenvalue mode (if x and y have one) is singular
   const int fixnull = (poisson && CBP(c, 0, 3) != 'D' && CBP(c, 1, 3) != 'D' && getenv("CALES_KEEP_NULL_MODE") == nullptr) ? 1 : 0;
@@ -712,11 +717,14 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
     else if (getenv("CALES_GAUSSEL_PAIR")) hipLaunchKernelGGL((k_gaussel<double2, 0>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2, fixnull);
     else hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, fixnull, 0); }
   { ProfScope ps(c, "fft_y_bwd");
-    if (sp->y8) hipLaunchKernelGGL(k_fft_y8<1>, dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
+    if (sp->y8 && c->ykind) hipLaunchKernelGGL((k_fft_y8<1, 1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
+    else if (sp->y8) hipLaunchKernelGGL((k_fft_y8<1, 0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
     else hipLaunchKernelGGL(k_fft_y<1>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
   if (dist) { ProfScope ps(c, "alltoall"); if (c->comm.a2a(c->comm.user, 1, a2a_count)) { c->err = "alltoall callback failed"; return 1; } }
   { ProfScope ps(c, "fft_x_bwd");
-    if (sp->x8) hipLaunchKernelGGL(k_fft_x8<1>, dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters, c->xkind,
+    if (sp->x8 && c->xkind) hipLaunchKernelGGL((k_fft_x8<1, 1>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
+                                   (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec);
+    else if (sp->x8) hipLaunchKernelGGL((k_fft_x8<1, 0>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec);
     else hipLaunchKernelGGL(k_fft_x<1>, dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx, c->xkind,
                        (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec); }
