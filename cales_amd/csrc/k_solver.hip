@@ -52,6 +52,15 @@ __device__ inline void fft_stage(const cpx *__restrict__ in, cpx *__restrict__ o
       const cpx r1 = {-(s1 * b.y + s2 * d.y), s1 * b.x + s2 * d.x}, r2 = {-(s2 * b.y - s1 * d.y), s2 * b.x - s1 * d.x};
       out[j0] = cadd(v[0], cadd(a, c)); out[j0 + Ns] = cadd(m1, r1); out[j0 + 4 * Ns] = csub(m1, r1);
       out[j0 + 2 * Ns] = cadd(m2, r2); out[j0 + 3 * Ns] = csub(m2, r2);
+    } else {                       // other odd primes (7, 11, 13): direct DFT of the butterfly, W_R^m = tw[m N/R]
+      const int wR = N / R;
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        cpx acc = v[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r) { cpx w = tw[((q * r) % R) * wR]; if (INV) w.y = -w.y; acc = cadd(acc, cmul(v[r], w)); }
+        out[j0 + q * Ns] = acc;
+      }
     }
   }
 }
@@ -63,6 +72,7 @@ static bool make_plan(int N, FftPlan &P) {
   while (m % 2 == 0) { P.radix[P.nst++] = 2; m /= 2; }
   while (m % 3 == 0) { P.radix[P.nst++] = 3; m /= 3; }
   while (m % 5 == 0) { P.radix[P.nst++] = 5; m /= 5; }
+  for (int pr : {7, 11, 13}) while (m % pr == 0 && P.nst < 16) { P.radix[P.nst++] = pr; m /= pr; }
   return m == 1;
 }
 // runs all stages; returns the buffer holding the result (a or b). All threads of the block must call it.
@@ -74,7 +84,10 @@ __device__ inline cpx *fft_line(const FftPlan &P, cpx *a, cpx *b, int t, int T, 
     if (R == 4) fft_stage<4, INV>(a, b, P.N, Ns, t, T, tw);
     else if (R == 2) fft_stage<2, INV>(a, b, P.N, Ns, t, T, tw);
     else if (R == 3) fft_stage<3, INV>(a, b, P.N, Ns, t, T, tw);
-    else fft_stage<5, INV>(a, b, P.N, Ns, t, T, tw);
+    else if (R == 5) fft_stage<5, INV>(a, b, P.N, Ns, t, T, tw);
+    else if (R == 7) fft_stage<7, INV>(a, b, P.N, Ns, t, T, tw);
+    else if (R == 11) fft_stage<11, INV>(a, b, P.N, Ns, t, T, tw);
+    else fft_stage<13, INV>(a, b, P.N, Ns, t, T, tw);
     Ns *= R;
     __syncthreads();
     cpx *tmp = a; a = b; b = tmp;
@@ -599,7 +612,7 @@ int solver_setup(cales_ctx *c) {
   if (c->xkind && !c->ykind) { c->err = "solver: NN in x with periodic y is not provided (x modes would pair into complex columns with different eigenvalues)"; return 1; }
   if (c->xkind && c->C.cbcpre[4] == 'P') { c->err = "solver: NN in x with periodic z is not provided"; return 1; }
   SolverPlans sp;
-  if (!make_plan(n1 / 2, sp.px) || !make_plan(n2g, sp.py)) { c->err = "solver: ng(1)/2 and ng(2) must factor into 2,3,5"; return 1; }
+  if (!make_plan(n1 / 2, sp.px) || !make_plan(n2g, sp.py)) { c->err = "solver: ng(1)/2 and ng(2) must factor into 2,3,5,7,11,13"; return 1; }
   // rows per block in x: aim at ~nh/4 threads per row, 256 threads per block
   { int T = std::max(1, std::min(256, (n1 / 2) / 4)); int p2 = 1; while (p2 * 2 <= T) p2 *= 2; T = p2; sp.Rx = 256 / T; }
   sp.shx = (size_t)sp.Rx * 2 * (n1 / 2 + 1) * sizeof(cpx);

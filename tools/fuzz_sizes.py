@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Random small grid sizes, two steps, GPU against the oracle (development aid; the committed tests cover fixed sizes)."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.util import load_golden, relerr
+from cales_amd.hotpath import HotPath, initflow
+from oracle.oracle import Oracle
+
+rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+names = ["chan_dsmag", "chan_dsmag_wm", "chan_smag_wm", "tgv_dsmag_ppp", "cavity_nnn", "duct_smag_wm_imp1d", "couette_imp3d_ops", "chan_smag"]
+bad = 0
+for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
+    name = names[trial % len(names)]
+    ng = tuple(int(2 * rng.randint(2, 40)) for _ in range(2)) + (int(2 * rng.randint(5, 40)),)
+    g, case = load_golden(name); case.ng[:] = ng
+    if case.inivel == "hcp": case.inivel = "poi"
+    try:
+        h = HotPath(case)
+    except Exception as e:
+        print(name, ng, "create refused:", str(e)[:80]); continue
+    o = Oracle(case, nthreads=8)
+    u, v, w, p = initflow(case)
+    for a in (u, v, w): a[1:-1, 1:-1, 1:-1] += 0.02 * (rng.rand(*ng) - 0.5)
+    h.upload(u, v, w, p); h.startup()
+    visct, pp = o.zeros(), o.zeros()
+    o.bounduvw(u, v, w, True, False); o.boundp(p, 0); o.cmpt_sgs(u, v, w, visct); o.boundp(visct, 1)
+    dt = 0.5 * o.chkdt(visct, u, v, w)
+    for _ in range(2):
+        h.step(dt); o.step(dt, u, v, w, p, pp, visct)
+    gu, gv, gw, gp, gvis = h.download()
+    errs = [relerr(a, b) for a, b in ((gu, u), (gv, v), (gw, w))] + [relerr(gvis, visct)]
+    ok = max(errs[:3]) < 1e-9 and errs[3] < 1e-6
+    bad += not ok
+    print("OK " if ok else "BAD", name, ng, " ".join("%.1e" % e for e in errs), "div %.1e / oracle %.1e" % (h.chkdiv()[1], o.chkdiv(u, v, w)[1]), flush=True)
+    h.close()
+print("bad:", bad)
