@@ -19,7 +19,9 @@ def _hot(case):
                                      ("chan_smag", (512, 64, 6)), ("chan_smag", (60, 90, 10)), ("chan_smag", (2048, 16, 4)),
                                      ("tgv_ppp", (32, 32, 16)), ("tgv_ppp", (24, 20, 18)), ("halfchan_imp1d", (16, 1024, 4)),
                                      ("duct_smag_wm", (32, 64, 16)), ("duct_smag_wm", (24, 30, 12)), ("duct_smag_wm", (128, 256, 8)),
-                                     ("cavity_nnn", (32, 16, 12)), ("cavity_nnn", (20, 36, 10)), ("cavity_nnn", (256, 128, 6))])
+                                     ("cavity_nnn", (32, 16, 12)), ("cavity_nnn", (20, 36, 10)), ("cavity_nnn", (256, 128, 6)),
+                                     # line lengths with factors 7, 11, 13 (direct-DFT butterflies)
+                                     ("chan_smag", (28, 22, 10)), ("cavity_nnn", (52, 14, 8)), ("duct_smag_wm", (44, 26, 12))])
 def test_poisson_solve(name, ng):
     g, case = load_golden(name)
     case.ng[:] = ng
