@@ -89,9 +89,12 @@ def test_native_rccl_selftest():
     assert capi.lib().cales_comm_selftest() == 0
 
 
-def test_native_rccl_one_rank_process_group():
-    """The launch path of `bench.py --gpus N` with N = 1 forced through the slab layer (tests/_nccl1_worker.py)."""
+@pytest.mark.parametrize("layer", ["rccl", "torch"])
+def test_one_rank_nccl_process_group(layer):
+    """The launch path of `bench.py --gpus N` with N = 1 forced through the slab layer (tests/_nccl1_worker.py), with the
+    library's own RCCL exchanges and with the torch.distributed callbacks."""
     import os, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, os.path.join(here, "_nccl1_worker.py")], capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, CALES_COMM=layer, MASTER_PORT=str(29571 + (layer == "torch")))
+    r = subprocess.run([sys.executable, os.path.join(here, "_nccl1_worker.py")], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "NCCL1 OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
