@@ -181,7 +181,7 @@ int cales_create(const cales_case *cs, void *stream, cales_ctx **out) {
   if (field_alloc(c, &c->scr1) || field_alloc(c, &c->scr2)) return fail(9);
   for (int q = 0; q < 3; ++q) if (field_alloc(c, &c->f2[q])) return fail(9);
   c->red_blocks = 8;
-  if (dev_alloc(c, &c->d_red, 64 + 16 * (size_t)(n3 + 2) + 4 * (size_t)(n3 + 2)) || dev_alloc(c, &c->d_force, 8)) return fail(10);
+  if (dev_alloc(c, &c->d_red, 64 + 16 * (size_t)(n3 + 2) + 6 * (size_t)(n3 + 2)) || dev_alloc(c, &c->d_force, 8)) return fail(10);
   c->res = c->d_red;
   if (hipHostMalloc((void **)&c->h_red, 64 * sizeof(double)) != hipSuccess) { c->err = "hipHostMalloc failed"; return fail(11); }
   // sgs scratch (sgs.f90:70-83,154-171)

@@ -749,6 +749,27 @@ int op_solver(cales_ctx *c) {
   return solve_field(c, c->f[CALES_PP], c->d_a, c->d_b, c->d_c, c->n[2], 1., CBP(c, 0, 3) == 'P' && CBP(c, 1, 3) == 'P', true);
 }
 
+// z-only Helmholtz systems have the same matrix for every column (no eigenvalue shift): the pivots z_l and c'_l of the
+// Thomas recurrence (solver.f90:160-178, same operations in the same order) are computed once by one thread, and the
+// sweeps of the field read them instead of dividing and of storing a c' per cell.
+__global__ void k_thomas_coef(int n, const double *__restrict__ a, const double *__restrict__ b, const double *__restrict__ c,
+                              double *__restrict__ zz, double *__restrict__ dd) {
+  if (threadIdx.x || blockIdx.x) return;
+  double z = 1. / (b[0] + CALES_EPS), d = c[0] * z;
+  zz[0] = z; dd[0] = d;
+  for (int l = 1; l < n; ++l) { z = 1. / (b[l] - a[l] * d + CALES_EPS); d = c[l] * z; zz[l] = z; dd[l] = d; }
+}
+__global__ __launch_bounds__(256) void k_gaussel_cols(Geom g, int nz, const double *__restrict__ a, const double *__restrict__ zz,
+                                                      const double *__restrict__ dd, double *__restrict__ p) {
+  const int i = blockIdx.x * 64 + threadIdx.x + 1, j = blockIdx.y * 4 + threadIdx.y + 1;
+  if (i > g.n1 || j > g.n2) return;
+  const size_t e0 = g.ix(i, j, 1), st = (size_t)g.s12;
+  double v = p[e0] * zz[0];
+  p[e0] = v;
+  for (int l = 1; l < nz; ++l) { v = (p[e0 + l * st] - a[l] * v) * zz[l]; p[e0 + l * st] = v; }
+  for (int l = nz - 2; l >= 0; --l) { v = p[e0 + l * st] - dd[l] * v; p[e0 + l * st] = v; }
+}
+
 // z-implicit Helmholtz solve of one velocity component (solver.f90:182-233 with aa,bb,cc of main.f90:435-437)
 __global__ void k_scale_abc(int n, double alpha, const double *a, const double *b, const double *c, double *aa, double *bb, double *cc) {
   const int k = blockIdx.x * 64 + threadIdx.x;
@@ -769,7 +790,12 @@ int op_helmholtz_z(cales_ctx *c, int ivel, double alpha) {
   double *fld = c->f[CALES_U + ivel - 1];
   Spec S; S.blocked = 0; S.cw = 0; S.n2l = n[1]; S.n3 = n3;
   if (periodic) hipLaunchKernelGGL((k_gaussel<double, 1>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, 1., abc, abc + n3, abc + 2 * n3, (const double *)nullptr, (const double *)nullptr, fld, c->scr1, c->scr2, 0);
-  else hipLaunchKernelGGL((k_gaussel<double, 0>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, 1., abc, abc + n3, abc + 2 * n3, (const double *)nullptr, (const double *)nullptr, fld, c->scr1, c->scr2, 0);
+  else if (getenv("CALES_HELMHOLTZ_Z_PER_COLUMN")) hipLaunchKernelGGL((k_gaussel<double, 0>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, 1., abc, abc + n3, abc + 2 * n3, (const double *)nullptr, (const double *)nullptr, fld, c->scr1, c->scr2, 0);
+  else {
+    double *zz = abc + 3 * n3, *dd = abc + 4 * n3;       // behind the scaled coefficients (cales_create reserves 6 (n3+2) doubles)
+    hipLaunchKernelGGL(k_thomas_coef, dim3(1), dim3(64), 0, c->stream, n3 - q, abc, abc + n3, abc + 2 * n3, zz, dd);
+    hipLaunchKernelGGL(k_gaussel_cols, gr, b, 0, c->stream, c->g, n3 - q, abc, zz, dd, fld);
+  }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
