@@ -293,11 +293,16 @@ int cales_step(cales_ctx *c, double dt) {
   for (int irk = 1; irk <= 3; ++irk) {
     const double dtrk = (rk[irk - 1][0] + rk[irk - 1][1]) * dt, dtrki = 1. / dtrk;
     double alpha = 0.;
-    if (int e = op_rk(c, irk, dt)) return e;
-    if (int e = op_bulk_forcing(c)) return e;
+    // z-implicit diffusion: the Helmholtz sweeps form their r.h.s. themselves (k_gaussel_cols_rhs); needs the shared-pivot form
+    const char *bz = &c->cbcvel[4];
+    c->defer_imp_rhs = c->C.impdiff == 2 && getenv("CALES_HELMHOLTZ_Z_PER_COLUMN") == nullptr && getenv("CALES_UNFUSED_IMP_RHS") == nullptr &&
+                       !(bz[0] == 'P' && bz[1] == 'P') && !(bz[6] == 'P' && bz[7] == 'P') && !(bz[12] == 'P' && bz[13] == 'P');
+    if (int e = op_rk(c, irk, dt)) { c->defer_imp_rhs = false; return e; }
+    if (int e = op_bulk_forcing(c)) { c->defer_imp_rhs = false; return e; }
     if (c->C.impdiff == 2) {
       alpha = -.5 * c->visc * dtrk;
-      for (int iv = 1; iv <= 3; ++iv) if (int e = op_helmholtz_z(c, iv, alpha)) return e;
+      for (int iv = 1; iv <= 3; ++iv) if (int e = op_helmholtz_z(c, iv, alpha)) { c->defer_imp_rhs = false; return e; }
+      c->defer_imp_rhs = false;
     } else if (c->C.impdiff == 1) {
       alpha = -.5 * c->visc * dtrk;
       for (int iv = 1; iv <= 3; ++iv) if (int e = op_helmholtz(c, iv, alpha)) return e;

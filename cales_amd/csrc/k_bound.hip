@@ -356,7 +356,7 @@ int op_updt_rhs_b(cales_ctx *c) {
 // host from the CURRENT bc planes would need a download; the planes of wall-model faces change every substep,
 // so the term is evaluated on the device from the plane directly.
 __global__ __launch_bounds__(256) void k_rhs_b_velz(Geom g, double *p, const double *bcplane, int ib, char ctype, char c_or_f, double dlc,
-                                                    double dlf, double alpha, int pos) {
+                                                    double dlf, double alpha, int pos, double *plane_out) {
   const int i = blockIdx.x * 64 + threadIdx.x + 1, j = blockIdx.y * 4 + threadIdx.y + 1;
   if (i > g.n1 || j > g.n2) return;
   const double bcv = bcplane[i + (size_t)(g.n1 + 2) * j];
@@ -364,21 +364,25 @@ __global__ __launch_bounds__(256) void k_rhs_b_velz(Geom g, double *p, const dou
   double r = 0.;
   if (c_or_f == 'c') { if (ctype == 'D') r = -2. * bcv / dlc / dlf; else if (ctype == 'N') r = sgn * bcv / dlf; }
   else               { if (ctype == 'D') r = -bcv / dlc / dlf;      else if (ctype == 'N') r = sgn * bcv / dlc; }
-  p[g.ix(i, j, pos)] += r * alpha;
+  if (plane_out) plane_out[(size_t)(i - 1) + (size_t)g.n1 * (j - 1)] = r * alpha;      // added by the fused Helmholtz sweep, in the reference's order
+  else p[g.ix(i, j, pos)] += r * alpha;
 }
-int op_rhs_b_velz(cales_ctx *c, int ivel, double alpha) {
+// planes != nullptr: the two contributions go to planes[0 / n1*n2] instead of being added to the field; has[ib] tells which exist
+int op_rhs_b_velz(cales_ctx *c, int ivel, double alpha, double *planes, int *has) {
   const int *n = c->n; const int n3 = n[2];
   const char cf = ivel == 3 ? 'f' : 'c';
   const DBound &bc = ivel == 1 ? c->bcu : ivel == 2 ? c->bcv : c->bcw;
   const char *cbc = &c->cbcvel[6 * (ivel - 1) + 4];
   const int q = (cf == 'f' && cbc[1] == 'D') ? 1 : 0;
   // bound.f90:479-482: dzc01_c=[dzc(0),dzc(n)], dzf01_c=[dzf(1),dzf(n)]; dzc01_f=[dzc(1),dzc(n-1)], dzf01_f=[dzf(1),dzf(n)]
+  if (has) has[0] = has[1] = 0;
   for (int ib = 0; ib <= 1; ++ib) {
     if (!ISB(c, ib, 3) || cbc[ib] == 'P') continue;
+    if (has) has[ib] = 1;
     const double dlc = cf == 'c' ? (ib ? c->dzc[n3] : c->dzc[0]) : (ib ? c->dzc[n3 - 1] : c->dzc[1]);
     const double dlf = ib ? c->dzf[n3] : c->dzf[1];
     hipLaunchKernelGGL(k_rhs_b_velz, dim3((n[0] + 63) / 64, (n[1] + 3) / 4), dim3(64, 4), 0, c->stream, c->g, c->f[CALES_U + ivel - 1],
-                       plane(bc, 3, ib, n), ib, cbc[ib], cf, dlc, dlf, alpha, ib ? n3 - q : 1);
+                       plane(bc, 3, ib, n), ib, cbc[ib], cf, dlc, dlf, alpha, ib ? n3 - q : 1, planes ? planes + (size_t)ib * n[0] * n[1] : nullptr);
   }
   HIPCHK(c, hipGetLastError());
   return 0;

@@ -770,17 +770,44 @@ __global__ __launch_bounds__(256) void k_gaussel_cols(Geom g, int nz, const doub
   for (int l = nz - 2; l >= 0; --l) { v = p[e0 + l * st] - dd[l] * v; p[e0 + l * st] = v; }
 }
 
+// The same sweeps for the z-implicit time step (cales_step): the r.h.s. of rk.f90:108-118 and main.f90:422-433 is formed on
+// the fly in the reference's order -- (u - hf12*dudtd) + f + rhs_b -- so the separate passes over u (9 + 2 words) disappear.
+// nq = nz or nz+1: plane nz+1 (the wall face of w) is not an unknown but still receives the first two terms.
+__global__ __launch_bounds__(256) void k_gaussel_cols_rhs(Geom g, int nz, int nq, const double *__restrict__ a, const double *__restrict__ zz,
+                                                          const double *__restrict__ dd, double *__restrict__ p, const double *__restrict__ dud,
+                                                          double hf12, const double *__restrict__ force, const double *__restrict__ rb, int has_lo,
+                                                          int has_hi) {
+  const int i = blockIdx.x * 64 + threadIdx.x + 1, j = blockIdx.y * 4 + threadIdx.y + 1;
+  if (i > g.n1 || j > g.n2) return;
+  const size_t e0 = g.ix(i, j, 1), st = (size_t)g.s12, pq = (size_t)(i - 1) + (size_t)g.n1 * (j - 1);
+  const bool forced = force != nullptr; const double f = forced ? force[0] : 0.;
+  auto rhs = [&](int l) {
+    double t = p[e0 + l * st] - hf12 * dud[e0 + l * st];
+    if (forced) t = t + f;
+    if (l == 0 && has_lo) t = t + rb[pq];
+    if (l == nz - 1 && has_hi) t = t + rb[pq + (size_t)g.n1 * g.n2];
+    return t;
+  };
+  double v = rhs(0) * zz[0];
+  p[e0] = v;
+  for (int l = 1; l < nz; ++l) { v = (rhs(l) - a[l] * v) * zz[l]; p[e0 + l * st] = v; }
+  if (nq > nz) p[e0 + (size_t)nz * st] = rhs(nz);
+  for (int l = nz - 2; l >= 0; --l) { v = p[e0 + l * st] - dd[l] * v; p[e0 + l * st] = v; }
+}
+
 // z-implicit Helmholtz solve of one velocity component (solver.f90:182-233 with aa,bb,cc of main.f90:435-437)
 __global__ void k_scale_abc(int n, double alpha, const double *a, const double *b, const double *c, double *aa, double *bb, double *cc) {
   const int k = blockIdx.x * 64 + threadIdx.x;
   if (k < n) { aa[k] = a[k] * alpha; bb[k] = b[k] * alpha + 1.; cc[k] = c[k] * alpha; }
 }
-int op_rhs_b_velz(cales_ctx *c, int ivel, double alpha);
+int op_rhs_b_velz(cales_ctx *c, int ivel, double alpha, double *planes = nullptr, int *has = nullptr);
 int op_helmholtz_z(cales_ctx *c, int ivel, double alpha) {
   if (c->C.impdiff != 2) { c->err = "helmholtz_z needs impdiff = 2"; return 1; }
   ProfScope ps(c, "helmholtz_z");
   const int *n = c->n; const int n3 = n[2];
-  if (int e = op_rhs_b_velz(c, ivel, alpha)) return e;
+  const bool fused = c->defer_imp_rhs;
+  int has[2] = {0, 0};
+  if (int e = op_rhs_b_velz(c, ivel, alpha, fused ? c->scr2 : nullptr, fused ? has : nullptr)) return e;
   double *abc = c->d_red + 64 + 16 * (n3 + 2);     // scaled coefficients live behind the reduction partials
   hipLaunchKernelGGL(k_scale_abc, dim3((n3 + 63) / 64), dim3(64), 0, c->stream, n3, alpha, c->d_av[ivel - 1], c->d_bv[ivel - 1], c->d_cv[ivel - 1], abc, abc + n3, abc + 2 * n3);
   const char *bcz = &c->cbcvel[6 * (ivel - 1) + 4];
@@ -794,7 +821,9 @@ int op_helmholtz_z(cales_ctx *c, int ivel, double alpha) {
   else {
     double *zz = abc + 3 * n3, *dd = abc + 4 * n3;       // behind the scaled coefficients (cales_create reserves 6 (n3+2) doubles)
     hipLaunchKernelGGL(k_thomas_coef, dim3(1), dim3(64), 0, c->stream, n3 - q, abc, abc + n3, abc + 2 * n3, zz, dd);
-    hipLaunchKernelGGL(k_gaussel_cols, gr, b, 0, c->stream, c->g, n3 - q, abc, zz, dd, fld);
+    if (fused) hipLaunchKernelGGL(k_gaussel_cols_rhs, gr, b, 0, c->stream, c->g, n3 - q, n3, abc, zz, dd, fld, c->f[CALES_DUDTD + ivel - 1], c->hf12,
+                                  c->C.is_forced[ivel - 1] ? c->d_force + (ivel - 1) : (const double *)nullptr, c->scr2, has[0], has[1]);
+    else hipLaunchKernelGGL(k_gaussel_cols, gr, b, 0, c->stream, c->g, n3 - q, abc, zz, dd, fld);
   }
   HIPCHK(c, hipGetLastError());
   return 0;

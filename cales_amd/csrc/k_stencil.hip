@@ -257,7 +257,8 @@ int op_rk(cales_ctx *c, int irk, double dt) {
   for (int q = 0; q < 3; ++q) std::swap(f[CALES_DUDT + q], f[CALES_DUDTO + q]);     // swap, rk.f90:98-100
   hipLaunchKernelGGL(k_zero_force, dim3(1), dim3(64), 0, c->stream, c->d_force);
   for (int q = 0; q < 3; ++q) if (c->C.is_forced[q]) if (int e = forcing_component(c, q)) return e;
-  if (c->C.impdiff) {
+  c->hf12 = .5 * f12;
+  if (c->C.impdiff && !c->defer_imp_rhs) {
     ProfScope ps(c, "rk_imp_rhs");
     hipLaunchKernelGGL(k_rk_imp_rhs, gr, b, 0, c->stream, c->g, .5 * f12, f[CALES_U], f[CALES_V], f[CALES_W], f[CALES_DUDTD], f[CALES_DVDTD], f[CALES_DWDTD]);
   }
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(BX *BY) void k_bulk_forcing(Geom g, double *__restr
   if (fz) w[c] += force[2];
 }
 int op_bulk_forcing(cales_ctx *c) {
-  if (!(c->C.is_forced[0] || c->C.is_forced[1] || c->C.is_forced[2])) return 0;
+  if (!(c->C.is_forced[0] || c->C.is_forced[1] || c->C.is_forced[2]) || c->defer_imp_rhs) return 0;
   ProfScope ps(c, "bulk_forcing");
   dim3 b(BX, BY, 1), gr = grid3(c->n[0], c->n[1], c->n[2], b);
   hipLaunchKernelGGL(k_bulk_forcing, gr, b, 0, c->stream, c->g, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W], c->d_force,
