@@ -147,8 +147,7 @@ __global__ __launch_bounds__(BX *BY) void k_smag(Geom g, SmagArgs A, const doubl
     const double dw_plus = dw_min * sqrt(tauw_s) * (1. / A.visc);
     fd = 1. - exp(-dw_plus / 25.);
   }
-  const double del = pow(A.dl1 * A.dl2 * dzf[k], 1. / 3.);
-  const double t = 0.11 * del * fd;           // c_smag, src/param.f90:33
+  const double t = 0.11 * dzf[k] * fd;        // dzf[] here is the table (dx dy dzf(k))^(1/3) of k_smag_del (sgs.f90:145); c_smag, src/param.f90:33
   const size_t c = g.ix(i, j, k);
   visct[c] = (t * t) * s0[c];
 }
@@ -744,7 +743,11 @@ int op_cmpt_sgs(cales_ctx *c) {
     SmagArgs A; A.w0 = c->is_wall[0]; A.w1 = c->is_wall[1]; A.w2 = c->is_wall[2]; A.w3 = c->is_wall[3]; A.w4 = c->is_wall[4]; A.w5 = c->is_wall[5];
     A.dl1 = c->dl[0]; A.dl2 = c->dl[1]; A.l3 = c->C.l[2]; A.dxi = c->dli[0]; A.dyi = c->dli[1]; A.visc = c->visc;
     A.sumw = 0.; for (int q = 0; q < 6; ++q) A.sumw += c->is_wall[q];
-    hipLaunchKernelGGL(k_smag, gr, b, 0, c->stream, c->g, A, c->d_zc, c->d_dzci, c->d_dzf, f[CALES_U], f[CALES_V], f[CALES_W], c->s0, visct);
+    if (!c->d_del) {
+      HIPCHK(c, hipMalloc(&c->d_del, (n[2] + 2) * sizeof(double)));
+      hipLaunchKernelGGL(k_smag_del, dim3((n[2] + 2 + 63) / 64), dim3(64), 0, c->stream, n[2] + 2, c->dl[0], c->dl[1], c->d_dzf, c->d_del);
+    }
+    hipLaunchKernelGGL(k_smag, gr, b, 0, c->stream, c->g, A, c->d_zc, c->d_dzci, c->d_del, f[CALES_U], f[CALES_V], f[CALES_W], c->s0, visct);
     HIPCHK(c, hipGetLastError());
     return 0;
   }
