@@ -495,13 +495,13 @@ __global__ __launch_bounds__(64 * (TYS + 2)) void k_strain_tile(Geom g, StrainTi
     if (A.zlo) {
       const double t1 = u[g.ix(i, j, 1)] - u[g.ix(i, j, 0)] + u[g.ix(i - 1, j, 1)] - u[g.ix(i - 1, j, 0)];
       const double t2 = v[g.ix(i, j, 1)] - v[g.ix(i, j, 0)] + v[g.ix(i, j - 1, 1)] - v[g.ix(i, j - 1, 0)];
-      tw_lo = 0.5 * A.visc * (sqrt(t1 * t1 + t2 * t2) * A.dzci[0]);
+      tw_lo = sqrt(0.5 * A.visc * (sqrt(t1 * t1 + t2 * t2) * A.dzci[0]));      // sqrt(tauw), constant along the column
     }
     if (A.zhi) {
       const int n3 = g.n3;
       const double t1 = u[g.ix(i, j, n3)] - u[g.ix(i, j, n3 + 1)] + u[g.ix(i - 1, j, n3)] - u[g.ix(i - 1, j, n3 + 1)];
       const double t2 = v[g.ix(i, j, n3)] - v[g.ix(i, j, n3 + 1)] + v[g.ix(i, j - 1, n3)] - v[g.ix(i, j - 1, n3 + 1)];
-      tw_hi = 0.5 * A.visc * (sqrt(t1 * t1 + t2 * t2) * A.dzci[n3]);
+      tw_hi = sqrt(0.5 * A.visc * (sqrt(t1 * t1 + t2 * t2) * A.dzci[n3]));
     }
   }
   int km = (kbeg - 1) % 3, kc = kbeg % 3, kp = (kbeg + 1) % 3;
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(64 * (TYS + 2)) void k_strain_tile(Geom g, StrainTi
         if (A.zlo || A.zhi) {     // nearest wall: the lower one wins a tie (minloc, sgs.f90:116)
           const double dlo = A.zlo ? A.zc[k] : CALES_BIG, dhi = A.zhi ? A.l3 - A.zc[k] : CALES_BIG;
           const bool up = dhi < dlo;
-          const double dw_plus = (up ? dhi : dlo) * sqrt(up ? tw_hi : tw_lo) * (1. / A.visc);
+          const double dw_plus = (up ? dhi : dlo) * (up ? tw_hi : tw_lo) * (1. / A.visc);
           fd = 1. - exp(-dw_plus / 25.);
         }
         const double t = 0.11 * A.del[k] * fd;      // c_smag, src/param.f90:33
