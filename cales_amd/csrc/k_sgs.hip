@@ -447,7 +447,7 @@ __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijA
 // K_A + K_C in one pass over u,v,w: strain rate (sgs.f90:571-630) stored as |S| and |S|Sij, cell-centred velocity (sgs.f90:860-869) and the
 // test-filtered velocity (sgs.f90:632-679 with the wall rule), all from an LDS ring of three raw planes.
 #ifndef TYS
-#define TYS 6
+#define TYS 14      // measured at 512^3 (A/B on one box): 14 beats 6 and 10 for the dynamic-model pass (-7 %) and the Smagorinsky pass (-26 %)
 #endif
 struct StrainTileArgs {
   const double *u[3];
