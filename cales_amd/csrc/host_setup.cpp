@@ -238,7 +238,9 @@ int hs_check_case(const cales_case *cs, std::string &msg) {
       if (cs->cbcvel[6 * iv + q] != 'P') { msg = "3-D implicit diffusion (_IMPDIFF without _IMPDIFF_1D) is provided for periodic x and y only"; return 1; }
   }
   if (cs->impdiff < 0 || cs->impdiff > 2) { msg = "impdiff must be 0, 1 or 2"; return 1; }
-  // transforms offered in x,y: periodic and cell-centred Neumann-Neumann (what the reference's GPU path offers, sanity.f90:265-273)
-  for (int d = 0; d < 2; ++d) { const std::string bp = pr(cs->cbcpre, d); if (bp != "PP" && bp != "NN") { msg = "pressure BC pair in x/y must be PP or NN on the device path"; return 1; } }
+  // transforms offered: in y periodic and cell-centred Neumann-Neumann (what the reference's GPU path offers in x and y,
+  // sanity.f90:265-273); in x also DD, ND, DN (inflow/outflow; the reference's CPU path through FFTW's r2r kinds)
+  { const std::string by = pr(cs->cbcpre, 1); if (by != "PP" && by != "NN") { msg = "pressure BC pair in y must be PP or NN on the device path"; return 1; } }
+  { const std::string bx = pr(cs->cbcpre, 0); if (bx != "PP" && bx != "NN" && bx != "DD" && bx != "ND" && bx != "DN") { msg = "unknown pressure BC pair in x"; return 1; } }
   return 0;
 }

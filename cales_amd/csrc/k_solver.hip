@@ -374,8 +374,14 @@ __global__ __launch_bounds__(256) void k_fft_x(Geom g, FftPlan P, int R, int kin
   double *rowp = p + g.ix(0, j, k);
   double *specd = reinterpret_cast<double *>(spec);
   if (!INV) {
-    if (live) for (int q = t; q < nh; q += T)
-      A[q] = kind ? cpx{rowp[1 + dct_src(2 * q, n)], rowp[1 + dct_src(2 * q + 1, n)]} : cpx{rowp[1 + 2 * q], rowp[2 + 2 * q]};
+    if (live) for (int q = t; q < nh; q += T) {
+      if (!kind) A[q] = cpx{rowp[1 + 2 * q], rowp[2 + 2 * q]};
+      else {       // kind 2 (Dirichlet-Dirichlet, RODFT10 = DST-II): DST-II(x)_k = DCT-II((-1)^j x_j)_{n-1-k}
+        const int s0 = dct_src(2 * q, n), s1 = dct_src(2 * q + 1, n);
+        const double g0 = (kind == 2 && (s0 & 1)) ? -1. : 1., g1 = (kind == 2 && (s1 & 1)) ? -1. : 1.;
+        A[q] = cpx{g0 * rowp[1 + s0], g1 * rowp[1 + s1]};
+      }
+    }
     __syncthreads();
     cpx *Z = fft_line<0>(P, A, B, t, T, tw);
     if (live) {
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(256) void k_fft_x(Geom g, FftPlan P, int R, int kin
           const int k2 = nh - kk;
           const cpx a = cmul(twd[kk], xk), b2 = cmul(twd[k2], xm);
           // real slot r lives in pair r/2, component r%2
-          auto put = [&](int rr, double val) { if (rr < n) specd[2 * S.at_slab(g, rr >> 1, j, k) + (rr & 1)] = val; };
+          auto put = [&](int rr, double val) { if (rr < n) { const int sl = kind == 2 ? n - 1 - rr : rr; specd[2 * S.at_slab(g, sl >> 1, j, k) + (sl & 1)] = val; } };
           put(kk, 2. * a.x); if (kk) put(n - kk, -2. * a.y);
           put(k2, 2. * b2.x); if (k2 && k2 != n - k2) put(n - k2, -2. * b2.y);
         }
@@ -402,8 +408,10 @@ __global__ __launch_bounds__(256) void k_fft_x(Geom g, FftPlan P, int R, int kin
     if (live) {
       if (!kind) { for (int kk = t; kk <= nh; kk += T) { const double2 v = spec[S.at_slab(g, kk, j, k)]; B[kk] = cpx{v.x, v.y}; } }
       else for (int kk = t; kk <= nh; kk += T) {                      // X_k = conj(w_k) (Y_k - i Y_{n-k}), Y_n := 0
-        const double yk = specd[2 * S.at_slab(g, kk >> 1, j, k) + (kk & 1)];
-        const int r2 = n - kk; const double ym = kk == 0 ? 0. : specd[2 * S.at_slab(g, r2 >> 1, j, k) + (r2 & 1)];
+        // kind 2 (RODFT01 = DST-III): DST-III(y)_j = (-1)^j DCT-III(y reversed)_j
+        const int sk_ = kind == 2 ? n - 1 - kk : kk, r2 = n - kk, sr = kind == 2 ? n - 1 - r2 : r2;
+        const double yk = (sk_ >= 0 && sk_ < n) ? specd[2 * S.at_slab(g, sk_ >> 1, j, k) + (sk_ & 1)] : 0.;
+        const double ym = kk == 0 ? 0. : specd[2 * S.at_slab(g, sr >> 1, j, k) + (sr & 1)];
         B[kk] = cmul(cconj(twd[kk]), cpx{yk, -ym});
       }
     }
@@ -418,8 +426,44 @@ __global__ __launch_bounds__(256) void k_fft_x(Geom g, FftPlan P, int R, int kin
     cpx *z = fft_line<1>(P, A, B, t, T, tw);
     if (live) for (int q = t; q < nh; q += T) {
       if (!kind) { rowp[1 + 2 * q] = z[q].x * scale; rowp[2 + 2 * q] = z[q].y * scale; }
-      else { rowp[1 + dct_src(2 * q, n)] = z[q].x * scale; rowp[1 + dct_src(2 * q + 1, n)] = z[q].y * scale; }
+      else {
+        const int s0 = dct_src(2 * q, n), s1 = dct_src(2 * q + 1, n);
+        rowp[1 + s0] = ((kind == 2 && (s0 & 1)) ? -scale : scale) * z[q].x; rowp[1 + s1] = ((kind == 2 && (s1 & 1)) ? -scale : scale) * z[q].y;
+      }
     }
+  }
+}
+
+// kinds 3 (Neumann-Dirichlet, REDFT11 = DCT-IV) and 4 (Dirichlet-Neumann, RODFT11 = DST-IV) in x; both are their own inverse up
+// to the factor 2n that normfft carries. DCT-IV of n reals through one nh = n/2 point complex transform:
+//   v_q = (x_{2q} + i x_{n-1-2q}) e^{-i pi (4q+1)/(4n)},  V = FFT_nh(v),  c_k = V_k e^{-i pi k/n},  y_{2k} = 2 Re c_k,  y_{n-1-2k} = -2 Im c_k;
+// DST-IV(x)_k = (-1)^k DCT-IV(x reversed)_k. tw4 = [e^{-i pi (4q+1)/(4n)}, q < nh | e^{-i pi k/n}, k < nh].
+// INV = 0 reads the physical row and writes the coefficient slots (as the NN transform does), INV = 1 the other way with `scale`.
+template <int INV, int DST>
+__global__ __launch_bounds__(256) void k_fft_x4(Geom g, FftPlan P, int R, const cpx *__restrict__ tw, const cpx *__restrict__ tw4,
+                                                 double *__restrict__ p, double scale, Spec S, double2 *__restrict__ spec) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int nh = P.N, n = 2 * nh, T = blockDim.x / R, row = threadIdx.x / T, t = threadIdx.x % T;
+  const int ld = nh + 1;
+  cpx *A = reinterpret_cast<cpx *>(smem) + (size_t)row * 2 * ld, *B = A + ld;
+  const long r = (long)blockIdx.x * R + row, nrows = (long)g.n2 * g.n3;
+  const bool live = r < nrows;
+  const int j = live ? (int)(r % g.n2) + 1 : 1, k = live ? (int)(r / g.n2) + 1 : 1;
+  double *rowp = p + g.ix(0, j, k);
+  double *specd = reinterpret_cast<double *>(spec);
+  auto phys = [&](int e) -> double & { return rowp[1 + e]; };
+  auto coef = [&](int e) -> double & { return specd[2 * S.at_slab(g, e >> 1, j, k) + (e & 1)]; };
+  if (live) for (int q = t; q < nh; q += T) {
+    double a = INV ? coef(2 * q) : phys(2 * q), b = INV ? coef(n - 1 - 2 * q) : phys(n - 1 - 2 * q);
+    if (DST) { const double tmp = a; a = b; b = tmp; }                // reversed input
+    A[q] = cmul(cpx{a, b}, tw4[q]);
+  }
+  __syncthreads();
+  cpx *Z = fft_line<0>(P, A, B, t, T, tw);
+  if (live) for (int kk = t; kk < nh; kk += T) {
+    const cpx c = cmul(Z[kk], tw4[nh + kk]);
+    const double ye = 2. * c.x * (INV ? scale : 1.), yo = (DST ? 2. : -2.) * c.y * (INV ? scale : 1.);     // DST: (-1)^k on the odd slots
+    if (INV) { phys(2 * kk) = ye; phys(n - 1 - 2 * kk) = yo; } else { coef(2 * kk) = ye; coef(n - 1 - 2 * kk) = yo; }
   }
 }
 
@@ -607,10 +651,13 @@ static SolverPlans *find_plans(cales_ctx *c) { for (auto &s : g_slots) if (s.ctx
 int solver_setup(cales_ctx *c) {
   const int *n = c->n; const int n1 = c->C.ng[0], n2g = c->C.ng[1], n3 = n[2];
   const std::string bx = std::string(1, c->C.cbcpre[0]) + c->C.cbcpre[1], by = std::string(1, c->C.cbcpre[2]) + c->C.cbcpre[3];
-  if ((bx != "PP" && bx != "NN") || (by != "PP" && by != "NN")) { c->err = "solver: pressure BC pairs in x/y must be PP or NN (cell-centred) on the device path"; return 1; }
-  c->xkind = bx == "NN" ? 1 : 0; c->ykind = by == "NN" ? 1 : 0;
-  if (c->xkind && !c->ykind) { c->err = "solver: NN in x with periodic y is not provided (x modes would pair into complex columns with different eigenvalues)"; return 1; }
-  if (c->xkind && c->C.cbcpre[4] == 'P') { c->err = "solver: NN in x with periodic z is not provided"; return 1; }
+  // transform kinds of the cell-centred pressure (fft.f90:192-245): 0 PP (R2HC/HC2R), 1 NN (REDFT10/01), 2 DD (RODFT10/01), 3 ND (REDFT11), 4 DN (RODFT11)
+  auto kind_of = [](const std::string &b) { return b == "PP" ? 0 : b == "NN" ? 1 : b == "DD" ? 2 : b == "ND" ? 3 : b == "DN" ? 4 : -1; };
+  c->xkind = kind_of(bx); c->ykind = kind_of(by);
+  if (c->xkind < 0 || c->ykind < 0) { c->err = "solver: unknown pressure BC pair in x or y"; return 1; }
+  if (c->ykind > 1) { c->err = "solver: in y the pressure BC pairs PP and NN are provided (DD, ND, DN only in x)"; return 1; }
+  if (c->xkind && !c->ykind) { c->err = "solver: a non-periodic x with periodic y is not provided (x modes would pair into complex columns with different eigenvalues)"; return 1; }
+  if (c->xkind && c->C.cbcpre[4] == 'P') { c->err = "solver: a non-periodic x with periodic z is not provided"; return 1; }
   SolverPlans sp;
   if (!make_plan(n1 / 2, sp.px) || !make_plan(n2g, sp.py)) { c->err = "solver: ng(1)/2 and ng(2) must factor into 2,3,5,7,11,13"; return 1; }
   // rows per block in x: aim at ~nh/4 threads per row, 256 threads per block
@@ -623,7 +670,7 @@ int solver_setup(cales_ctx *c) {
   if (sp.shx > 64 * 1024 || sp.shy > 64 * 1024) { c->err = "solver: line too long for the LDS-resident transform"; return 1; }
   // power-of-two lines take the radix-8 register kernels
   auto pow2 = [](int v) { return v >= 16 && (v & (v - 1)) == 0; };
-  sp.x8 = pow2(n1 / 2) && n1 / 2 <= 1024; sp.y8 = pow2(n2g) && n2g <= 1024;
+  sp.x8 = pow2(n1 / 2) && n1 / 2 <= 1024 && c->xkind <= 1; sp.y8 = pow2(n2g) && n2g <= 1024;
   if (sp.x8) { const int T = (n1 / 2) / 8; sp.x8_threads = T >= 256 ? T : (256 / T) * T;
                sp.shx8 = ((size_t)(sp.x8_threads / T) * (n1 / 2 + n1 / 16 + 2) + (n1 + 1) + (c->xkind ? n1 / 2 + 1 : 0)) * sizeof(cpx); }
   if (sp.y8) { const int T = n2g / 8; int CB = std::max(1, std::min(std::max(8, 256 / T), 512 / T));
@@ -632,7 +679,7 @@ int solver_setup(cales_ctx *c) {
   if (getenv("CALES_FFT_GENERIC")) sp.x8 = sp.y8 = false;
   // eigenvalues (initsolver.f90:66-98); x: modes 0..n1/2 (half-complex symmetry), y: modes 0..n2-1
   std::vector<double> lx(n1 + 2, 0.), ly(n2g);
-  hs_eigenvalues(n1, c->xkind ? "NN" : "PP", 'c', lx.data()); hs_eigenvalues(n2g, c->ykind ? "NN" : "PP", 'c', ly.data());
+  hs_eigenvalues(n1, bx.c_str(), 'c', lx.data()); hs_eigenvalues(n2g, by.c_str(), 'c', ly.data());
   for (auto &v : lx) v = v * (c->dli[0] * c->dli[0]);
   for (auto &v : ly) v = v * (c->dli[1] * c->dli[1]);
   const int mh = n1 / 2 + 1;
@@ -663,6 +710,13 @@ int solver_setup(cales_ctx *c) {
   if (mk(n2g, n2g, &c->d_twy)) return 1;
   if (mk(4 * n1, n1 / 2 + 1, &c->d_twy_post)) return 1;      // DCT weights e^{-i pi k/(2 n1)}, k = 0..n1/2 (x)
   if (mk(4 * n2g, n2g, &c->scr_twyd)) return 1;              // e^{-i pi k/(2 n2)}, k = 0..n2-1 (y)
+  if (c->xkind >= 3) {            // DCT-IV weights (k_fft_x4)
+    const int nh = n1 / 2; std::vector<double> t(4 * (size_t)nh); const double pi = std::acos(-1.0);
+    for (int q = 0; q < nh; ++q) { const double a1 = -pi * (4. * q + 1.) / (4. * n1), a2 = -pi * q / (double)n1;
+                                   t[2 * q] = std::cos(a1); t[2 * q + 1] = std::sin(a1); t[2 * (nh + q)] = std::cos(a2); t[2 * (nh + q) + 1] = std::sin(a2); }
+    HIPCHK(c, hipMalloc(&c->d_tw4x, t.size() * sizeof(double)));
+    HIPCHK(c, hipMemcpy(c->d_tw4x, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   if (c->C.impdiff)
     for (int iv = 0; iv < 3; ++iv) {
       hs_tridmatrix(&c->cbcvel[6 * iv + 4], n3, c->dzci.data(), c->dzfi.data(), iv == 2 ? 'f' : 'c', a.data(), b.data(), cc.data());
@@ -678,7 +732,7 @@ int solver_setup(cales_ctx *c) {
 void solver_teardown(cales_ctx *c) {
   for (size_t q = 0; q < g_slots.size(); ++q) if (g_slots[q].ctx == c) { g_slots.erase(g_slots.begin() + q); break; }
   hipFree(c->d_lamx); hipFree(c->d_lamy); hipFree(c->d_a); hipFree(c->d_b); hipFree(c->d_c);
-  hipFree(c->d_twx); hipFree(c->d_twx_post); hipFree(c->d_twy); hipFree(c->d_twy_post); hipFree(c->scr_twyd);
+  hipFree(c->d_twx); hipFree(c->d_twx_post); hipFree(c->d_twy); hipFree(c->d_twy_post); hipFree(c->scr_twyd); hipFree(c->d_tw4x);
   for (int iv = 0; iv < 3; ++iv) hipFree(c->d_av[iv]);
 }
 
@@ -710,6 +764,10 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec);
     else if (sp->x8) hipLaunchKernelGGL((k_fft_x8<0, 0>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec);
+    else if (c->xkind == 3) hipLaunchKernelGGL((k_fft_x4<0, 0>), dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
+                       (const cpx *)c->d_twx, (const cpx *)c->d_tw4x, pp, 1., S, slab_spec);
+    else if (c->xkind == 4) hipLaunchKernelGGL((k_fft_x4<0, 1>), dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
+                       (const cpx *)c->d_twx, (const cpx *)c->d_tw4x, pp, 1., S, slab_spec);
     else hipLaunchKernelGGL(k_fft_x<0>, dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx, c->xkind,
                        (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec); }
   if (dist) { ProfScope ps(c, "alltoall"); if (c->comm.a2a(c->comm.user, 0, a2a_count)) { c->err = "alltoall callback failed"; return 1; } }
@@ -739,6 +797,10 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec);
     else if (sp->x8) hipLaunchKernelGGL((k_fft_x8<1, 0>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec);
+    else if (c->xkind == 3) hipLaunchKernelGGL((k_fft_x4<1, 0>), dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
+                       (const cpx *)c->d_twx, (const cpx *)c->d_tw4x, pp, c->normfft, S, slab_spec);
+    else if (c->xkind == 4) hipLaunchKernelGGL((k_fft_x4<1, 1>), dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
+                       (const cpx *)c->d_twx, (const cpx *)c->d_tw4x, pp, c->normfft, S, slab_spec);
     else hipLaunchKernelGGL(k_fft_x<1>, dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx, c->xkind,
                        (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec); }
   HIPCHK(c, hipGetLastError());

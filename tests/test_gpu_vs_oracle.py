@@ -94,3 +94,53 @@ def test_projection_properties_at_size():
     assert divmax < 5e-12 and np.isfinite(divtot)
     assert abs(h.bulk_mean("u", "f") - 1.0) < 1e-12
     h.close()
+
+
+@pytest.mark.parametrize("bx", ["ND", "DN", "DD"])
+@pytest.mark.parametrize("ng", [(32, 16, 12), (20, 36, 10), (128, 64, 8), (52, 14, 8)])
+def test_poisson_solve_open_x(bx, ng):
+    """Pressure Dirichlet on one or both x faces (inflow/outflow, examples/dns/developing_duct): RODFT10/01, REDFT11, RODFT11
+    in x (fft.f90:192-245) with Neumann-Neumann y and z."""
+    g, case = load_golden("cavity_nnn")
+    case.ng[:] = ng
+    for side in (0, 1):
+        case.cbcpre[side, 0] = bx[side]
+        case.cbcvel[side, 0, :] = "N" if bx[side] == "D" else "D"       # sanity.f90:150-170: velocity N where the pressure is D
+        case.bcvel[side, 0, :] = 0.
+    o = Oracle(case, nthreads=8); h = _hot(case)
+    rng = np.random.RandomState(sum(ng))
+    rhs = o.zeros(); rhs[1:-1, 1:-1, 1:-1] = rng.rand(*ng) - 0.5
+    ref = rhs.copy(order="F"); o.solver(ref)
+    h.set("pp", rhs); h.solver()
+    a = h.get("pp")[1:-1, 1:-1, 1:-1]; b = ref[1:-1, 1:-1, 1:-1]
+    assert np.abs(a - b).max() < 1e-11 * np.abs(b).max(), (bx, ng)      # non-singular: no mean to remove
+    h.close()
+
+
+def test_time_steps_inflow_outflow_duct():
+    """examples/dns/developing_duct BCs (inflow u = 1 at x = 0, outflow with Dirichlet pressure at x = l, walls in y and z):
+    REDFT11 in x, REDFT10/01 in y; several steps against the oracle."""
+    from cales_amd.hotpath import initflow
+    g, case = load_golden("cavity_nnn")
+    case.ng[:] = (32, 16, 12)
+    case.cbcpre[:, 0] = ["N", "D"]
+    case.cbcvel[0, 0, :] = "D"; case.cbcvel[1, 0, :] = "N"
+    case.bcvel[:] = 0.; case.bcvel[0, 0, 0] = 1.                     # u = 1 on the inflow face, lid at rest
+    o = Oracle(case, nthreads=8); h = _hot(case)
+    u, v, w, p = initflow(case)
+    rng = np.random.RandomState(5)
+    for a in (u, v, w):
+        a[1:-1, 1:-1, 1:-1] += 0.02 * (rng.rand(*case.ng) - 0.5)
+    h.upload(u, v, w, p); h.startup()
+    visct, pp = o.zeros(), o.zeros()
+    o.bounduvw(u, v, w, True, False); o.boundp(p, 0); o.cmpt_sgs(u, v, w, visct); o.boundp(visct, 1)
+    dt = 0.5 * o.chkdt(visct, u, v, w)
+    assert abs(h.chkdt() / (2 * dt) - 1) < 1e-12
+    for _ in range(4):
+        h.step(dt); o.step(dt, u, v, w, p, pp, visct)
+    gu, gv, gw, gp, _ = h.download()
+    for a, b, nm in ((gu, u, "u"), (gv, v, "v"), (gw, w, "w")):
+        assert relerr(a, b) < 1e-9, nm
+    assert relerr(gp[1:-1, 1:-1, 1:-1], p[1:-1, 1:-1, 1:-1]) < 1e-8            # Dirichlet pressure: no free constant
+    assert h.chkdiv()[1] < 1e-11
+    h.close()
