@@ -595,6 +595,57 @@ __global__ __launch_bounds__(256) void k_gaussel_ri(Geom g, int nz, int ncol, in
   }
 }
 
+// Non-periodic x (real modes r = 2m, 2m+1 paired into one complex column) with PERIODIC y: the y transform of the pair gives
+// Z_ky = A_ky + i B_ky, A and B the (Hermitian) spectra of the two real columns, which have DIFFERENT x eigenvalues. Rows ky and
+// N-ky are separated, A = (Z_ky + conj Z_{N-ky})/2, B = (Z_ky - conj Z_{N-ky})/(2i), the four real systems (Re/Im of A and B) go to
+// four neighbouring lanes, and the rows are rebuilt as Z_ky = a + i b, Z_{N-ky} = conj(a) + i conj(b). In place: every lane keeps
+// its intermediate values in one of the four slots (Re/Im of the two rows) and finally overwrites that slot.
+template <int CTRL> __device__ inline double quad_bcast(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__global__ __launch_bounds__(256) void k_gaussel_herm(Geom g, int nz, int ncol, int N, int mofs, int nmode, Spec S,
+                                                      const double *__restrict__ a, const double *__restrict__ b,
+                                                      const double *__restrict__ c, const double *__restrict__ lamx,
+                                                      const double *__restrict__ lamy, double *__restrict__ p, double *__restrict__ dscr, int fixnull) {
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  const int t = (int)(q % (4 * ncol)), m = t >> 2, role = t & 3, ky = (int)(q / (4 * ncol));     // role: Re a, Im a, Re b, Im b
+  const bool live = ky <= N / 2 && m + mofs < nmode;
+  const int kn = (N - ky) % N; const bool self = kn == ky;
+  // double offsets of plane 1: components of rows ky+1 and kn+1 (at_mode rows are 1-based)
+  const size_t ek = live ? 2 * S.at_mode(g, m, ky + 1, 1) : 0, en = live ? 2 * S.at_mode(g, m, kn + 1, 1) : 0;
+  const size_t st = 2 * (S.blocked ? (size_t)S.cw * S.n2l : (size_t)g.s12 / 2);
+  const size_t s0 = (size_t)t + (size_t)4 * ncol * (size_t)ky, sst = (size_t)4 * ncol * (N / 2 + 1);
+  const double lam = live ? lamx[2 * (m + mofs) + (role >> 1)] + lamy[ky] : 1.;
+  // my slot: role 0 -> Re row ky, 1 -> Im row ky, 2 -> Re row kn, 3 -> Im row kn; self-conjugate rows: role 2 -> Im row ky, roles 1,3 idle
+  const bool active = live && !(self && (role & 1));
+  const size_t slot = self ? (role == 0 ? ek : ek + 1) : (role == 0 ? ek : role == 1 ? ek + 1 : role == 2 ? en : en + 1);
+  auto rhs = [&](int l) -> double {
+    if (!live) return 0.;
+    const double zrk = p[ek + l * st], zik = p[ek + 1 + l * st], zrn = p[en + l * st], zin = p[en + 1 + l * st];
+    return role == 0 ? 0.5 * (zrk + zrn) : role == 1 ? 0.5 * (zik - zin) : role == 2 ? 0.5 * (zik + zin) : 0.5 * (zrn - zrk);
+  };
+  double z = 1. / (b[0] + lam + CALES_EPS), d = c[0] * z;
+  double v = rhs(0) * z;
+  if (active) { p[slot] = v; dscr[s0] = d; }
+  for (int l = 1; l < nz; ++l) {
+    z = 1. / ((b[l] + lam) - a[l] * d + CALES_EPS);
+    d = c[l] * z;
+    v = (rhs(l) - a[l] * v) * z;
+    if (l == nz - 1 && fixnull && lam == 0.) v = 0.;       // null mode: see k_gaussel_ri
+    if (active) { p[slot + l * st] = v; dscr[s0 + l * sst] = d; }
+  }
+  // back substitution; after each plane the quad holds (Re a, Im a, Re b, Im b) and rebuilds the two rows
+  for (int l = nz - 1; l >= 0; --l) {
+    if (l < nz - 1) v = active ? p[slot + l * st] - dscr[s0 + l * sst] * v : 0.;
+    else if (!active) v = 0.;
+    const double ra = quad_bcast<0x00>(v), ia = quad_bcast<0x55>(v), rb = quad_bcast<0xAA>(v), ib = quad_bcast<0xFF>(v);
+    const double out = self ? (role == 0 ? ra : rb) : (role == 0 ? ra - ib : role == 1 ? ia + rb : role == 2 ? ra + ib : rb - ia);
+    if (active) p[slot + l * st] = out;
+  }
+}
+
 template <typename VT, int PERIODIC>
 __global__ __launch_bounds__(256) void k_gaussel(Geom g, int nz, int ncol, int nrow, int i0, int mofs, int nmode, Spec S, double lscale,
                                                  const double *__restrict__ a, const double *__restrict__ b,
@@ -656,7 +707,6 @@ int solver_setup(cales_ctx *c) {
   c->xkind = kind_of(bx); c->ykind = kind_of(by);
   if (c->xkind < 0 || c->ykind < 0) { c->err = "solver: unknown pressure BC pair in x or y"; return 1; }
   if (c->ykind > 1) { c->err = "solver: in y the pressure BC pairs PP and NN are provided (DD, ND, DN only in x)"; return 1; }
-  if (c->xkind && !c->ykind) { c->err = "solver: a non-periodic x with periodic y is not provided (x modes would pair into complex columns with different eigenvalues)"; return 1; }
   if (c->xkind && c->C.cbcpre[4] == 'P') { c->err = "solver: a non-periodic x with periodic z is not provided"; return 1; }
   SolverPlans sp;
   if (!make_plan(n1 / 2, sp.px) || !make_plan(n2g, sp.py)) { c->err = "solver: ng(1)/2 and ng(2) must factor into 2,3,5,7,11,13"; return 1; }
@@ -779,7 +829,10 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
   const int fixnull = (poisson && CBP(c, 0, 3) != 'D' && CBP(c, 1, 3) != 'D' && getenv("CALES_KEEP_NULL_MODE") == nullptr) ? 1 : 0;
   { ProfScope ps(c, "gaussel_z");
     dim3 b(64, 4), gr((ncol + 63) / 64, (n2g + 3) / 4);
-    if (c->xkind && !periodic_z && getenv("CALES_GAUSSEL_PAIR") == nullptr)
+    if (c->xkind && !c->ykind)       // real x modes paired into complex columns + periodic y: Hermitian separation of rows ky and N-ky
+      hipLaunchKernelGGL(k_gaussel_herm, dim3((unsigned)(((long)4 * ncol * (n2g / 2 + 1) + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S,
+                         da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, fixnull);
+    else if (c->xkind && !periodic_z && getenv("CALES_GAUSSEL_PAIR") == nullptr)
       hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, lscale, da, db, dc,
                          c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, fixnull, 1);
     else if (c->xkind) hipLaunchKernelGGL(k_gaussel_split, gr, b, 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, da, db, dc, c->d_lamx, c->d_lamy,

@@ -12,6 +12,8 @@ pytestmark = pytest.mark.gpu
 
 def _hot(case):
     from cales_amd.hotpath import HotPath
+    if case.sgstype == "none" and case.cbcvel[0, 0, 0] != "P":      # see tests/test_gpu_golden.py
+        case.cbcsgs[:, 0] = "D"
     return HotPath(case)
 
 
@@ -43,7 +45,7 @@ def test_poisson_solve(name, ng):
                                             ("halfchan_imp1d", (16, 16, 16), 3), ("chan_smag", (24, 20, 12), 10),
                                             # tile kernels: partial tiles in x and y, several x tiles, k chunks, wall-modelled z faces
                                             ("chan_dsmag", (80, 20, 12), 3), ("tgv_dsmag_ppp", (72, 16, 40), 3), ("chan_dsmag_wm", (128, 30, 70), 2), ("chan_smag_wm", (96, 18, 40), 3),
-                                            ("duct_smag_wm", (16, 24, 24), 4), ("cavity_nnn", (16, 16, 16), 5),
+                                            ("duct_smag_wm", (16, 24, 24), 4), ("cavity_nnn", (16, 16, 16), 5), ("devchan_nd", (32, 16, 16), 4), ("devchan_nd", (40, 18, 12), 3),
                                             # 3-D implicit diffusion (impdiff = 1): Helmholtz solves of u,v,w through the FFT solver
                                             ("couette_imp3d_ops", (16, 16, 16), 4), ("couette_imp3d_ops", (32, 20, 24), 3)])
 def test_time_steps(name, ng, nsteps):
@@ -143,4 +145,32 @@ def test_time_steps_inflow_outflow_duct():
         assert relerr(a, b) < 1e-9, nm
     assert relerr(gp[1:-1, 1:-1, 1:-1], p[1:-1, 1:-1, 1:-1]) < 1e-8            # Dirichlet pressure: no free constant
     assert h.chkdiv()[1] < 1e-11
+    h.close()
+
+
+@pytest.mark.parametrize("bx", ["ND", "NN", "DN", "DD"])
+@pytest.mark.parametrize("ng", [(32, 16, 12), (20, 30, 10), (64, 128, 8), (28, 22, 10)])
+def test_poisson_solve_open_x_periodic_y(bx, ng):
+    """examples/dns/developing_channel: non-periodic x with PERIODIC y -- the pairs of real x modes have different eigenvalues
+    and are separated through the Hermitian symmetry of their y spectra (k_gaussel_herm)."""
+    g, case = load_golden("chan_smag")
+    case.ng[:] = ng
+    for side in (0, 1):
+        case.cbcpre[side, 0] = bx[side]
+        case.cbcvel[side, 0, :] = "N" if bx[side] == "D" else "D"
+        case.bcvel[side, 0, :] = 0.
+    case.cbcsgs[:, 0] = "D"                                     # sanity.f90:191-203
+    case.is_forced[:] = False; case.sgstype = "none"; case.lwm[:] = 0
+    o = Oracle(case, nthreads=8); h = _hot(case)
+    rng = np.random.RandomState(sum(ng))
+    rhs = o.zeros(); rhs[1:-1, 1:-1, 1:-1] = rng.rand(*ng) - 0.5
+    if bx == "NN":
+        dzf = o.grid()["dzf"][1:-1]
+        rhs[1:-1, 1:-1, 1:-1] -= (rhs[1:-1, 1:-1, 1:-1] * dzf).sum() / (dzf.sum() * ng[0] * ng[1])     # singular problem: compatible r.h.s.
+    ref = rhs.copy(order="F"); o.solver(ref)
+    h.set("pp", rhs); h.solver()
+    a = h.get("pp")[1:-1, 1:-1, 1:-1]; b = ref[1:-1, 1:-1, 1:-1]
+    if bx == "NN":
+        a = a - a.mean(); b = b - b.mean()
+    assert np.abs(a - b).max() < 1e-11 * np.abs(b).max(), (bx, ng)
     h.close()
