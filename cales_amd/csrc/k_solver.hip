@@ -595,6 +595,141 @@ __global__ __launch_bounds__(256) void k_gaussel_ri(Geom g, int nz, int ncol, in
   }
 }
 
+// Non-periodic z, one rank: the whole z extent of 16 neighbouring columns (one 128-B line per plane) is brought into LDS, solved
+// there and written back -- 2 words per cell instead of the 5.3 of the marching sweep, which has to store c' and d'.
+// One wave per mode (NV = 2: real and imaginary part share the matrix; NV = 1: real x modes, one column each); lane = chunk of M
+// consecutive planes (64 M >= nz). Substructuring: every lane eliminates the M-1 interior rows of its chunk against the two
+// separator values beside them (`+eps` pivots as in solver.f90:160-178), the 64 separator rows (last row of every chunk) form a
+// tridiagonal system solved across the wave by parallel cyclic reduction, and the interiors follow by back substitution. Same
+// equations as the Thomas sweep, other association (differences at round-off level times the conditioning of the column).
+// Rows beyond nz are identity rows. Reciprocals: v_rcp_f64 + two Newton steps (full precision for normal numbers).
+// LDS layout [column][chunk][M+1] (+4 doubles per column): conflict-free for the lane-per-chunk accesses and the plane-wise copies.
+__device__ inline double rcp_nr(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(r, fma(-x, r, 1.), r);
+  return fma(r, fma(-x, r, 1.), r);
+}
+template <int M, int NV>
+__global__ __launch_bounds__(1024 / NV, (M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_gaussel_tile(Geom g, int nz, int ndbl, double lscale, const double *__restrict__ a,
+                                                            const double *__restrict__ b, const double *__restrict__ c,
+                                                            const double *__restrict__ lamx, const double *__restrict__ lamy,
+                                                            double *__restrict__ p, int fixnull) {
+  extern __shared__ double shz[];
+  constexpr int CP = M + 1, P = 64 * CP + 4, NT = 1024 / NV, KP = NT / 16, NQ = 64 * M / KP;
+  const int t = threadIdx.x, j = blockIdx.y + 1;
+  const size_t base = g.ix(0, j, 1) + (size_t)16 * blockIdx.x;      // doubles from p (= element i = 1 of row (0,0))
+  {
+    const int x = t & 15, kk = t >> 4;
+    const bool ok = 16 * (int)blockIdx.x + x < ndbl;
+    double v[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { const int k = kk + KP * q; v[q] = (ok && k < nz) ? p[base + x + (size_t)k * g.s12] : 0.; }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { const int k = kk + KP * q; shz[x * P + k + k / M] = v[q]; }
+  }
+  __syncthreads();
+  const int x = (t >> 6) * NV, ch = t & 63, d = 16 * (int)blockIdx.x + x;
+  if (d < ndbl) {
+    const double lam = ((NV == 1 ? lamx[d] : lamx[d >> 1]) + lamy[j - 1]) * lscale;
+    const bool nullc = fixnull && lam == 0.;      // singular mode: the member with p(nz) = 0, see k_gaussel_ri
+    double *col = shz + x * P + ch * CP;
+    const int k0 = ch * M;
+    double cp[M - 1], V[M - 1], R[NV][M - 1];
+    double cprev = 0., vprev = 0., rprev[NV] = {};
+#pragma unroll
+    for (int r = 0; r < M - 1; ++r) {
+      const int k = k0 + r;
+      const bool live = k < nz && !(nullc && k == nz - 1);
+      const double A = (live && k > 0) ? a[k] : 0., C = (live && k < nz - 1) ? c[k] : 0., B = live ? b[k] + lam : 1.;
+      const double z = rcp_nr(B - A * cprev + CALES_EPS);
+      cp[r] = C * z; V[r] = (r == 0 ? A : -A * vprev) * z;
+#pragma unroll
+      for (int q = 0; q < NV; ++q) { const double D = live ? col[q * P + r] : 0.; R[q][r] = (D - A * rprev[q]) * z; rprev[q] = R[q][r]; }
+      cprev = cp[r]; vprev = V[r];
+    }
+    // first interior row of the chunk as a function of the separators beside it
+    double Vb = V[M - 2], Wb = cp[M - 2], Rb[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) Rb[q] = R[q][M - 2];
+#pragma unroll
+    for (int r = M - 3; r >= 0; --r) {
+      Vb = V[r] - cp[r] * Vb; Wb = -cp[r] * Wb;
+#pragma unroll
+      for (int q = 0; q < NV; ++q) Rb[q] = R[q][r] - cp[r] * Rb[q];
+    }
+    const bool last = ch == 63;
+    // (cross-lane reads are issued by all lanes and masked afterwards: a lane switched off by a branch would be read as zero)
+    double Vn = __shfl_down(Vb, 1, 64), Wn = __shfl_down(Wb, 1, 64);
+    if (last) { Vn = 0.; Wn = 0.; }
+    // separator row
+    double al, be, ga, de[NV];
+    {
+      const int k = k0 + M - 1;
+      const bool live = k < nz && !(nullc && k == nz - 1);
+      const double A = (live && k > 0) ? a[k] : 0., C = (live && k < nz - 1) ? c[k] : 0., B = live ? b[k] + lam : 1.;
+      al = -A * V[M - 2]; be = B - A * cp[M - 2] - C * Vn; ga = -C * Wn;
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        double Rn = __shfl_down(Rb[q], 1, 64);
+        if (last) Rn = 0.;
+        const double D = live ? col[q * P + M - 1] : 0.;
+        de[q] = D - A * R[q][M - 2] - C * Rn;
+      }
+    }
+    // parallel cyclic reduction over the 64 separators
+#pragma unroll
+    for (int h = 1; h < 64; h <<= 1) {
+      const bool lo = ch >= h, hi = ch + h < 64;
+      const double rb = rcp_nr(be);
+      const double rbm = __shfl_up(rb, h, 64), rbp = __shfl_down(rb, h, 64);
+      const double k1 = lo ? al * rbm : 0., k2 = hi ? ga * rbp : 0.;
+      const double alm = __shfl_up(al, h, 64), gam = __shfl_up(ga, h, 64), alp = __shfl_down(al, h, 64), gap = __shfl_down(ga, h, 64);
+      be = be - gam * k1 - alp * k2;
+#pragma unroll
+      for (int q = 0; q < NV; ++q) de[q] = de[q] - __shfl_up(de[q], h, 64) * k1 - __shfl_down(de[q], h, 64) * k2;
+      al = -alm * k1; ga = -gap * k2;
+    }
+    const double rb = rcp_nr(be);
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const double s = de[q] * rb;
+      double sp = __shfl_up(s, 1, 64);
+      if (ch == 0) sp = 0.;
+      double xv = R[q][M - 2] - V[M - 2] * sp - cp[M - 2] * s;
+      col[q * P + M - 2] = xv;
+#pragma unroll
+      for (int r = M - 3; r >= 0; --r) { xv = R[q][r] - V[r] * sp - cp[r] * xv; col[q * P + r] = xv; }
+      col[q * P + M - 1] = s;
+    }
+  }
+  __syncthreads();
+  {
+    const int x = t & 15, kk = t >> 4;
+    const bool ok = 16 * (int)blockIdx.x + x < ndbl;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { const int k = kk + KP * q; if (ok && k < nz) p[base + x + (size_t)k * g.s12] = shz[x * P + k + k / M]; }
+  }
+}
+template <int M, int NV>
+static void launch_gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, double lscale, const double *da, const double *db, const double *dc,
+                                double *p, int fixnull) {
+  constexpr int lds = 16 * (64 * (M + 1) + 4) * 8;
+  static bool once = false;
+  if (!once) { hipFuncSetAttribute((const void *)k_gaussel_tile<M, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
+  hipLaunchKernelGGL((k_gaussel_tile<M, NV>), dim3((ndbl + 15) / 16, nrow), dim3(1024 / NV), lds, c->stream, c->g, nz, ndbl, lscale, da, db, dc,
+                     c->d_lamx, c->d_lamy, p, fixnull);
+}
+template <int NV>
+static bool gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, double lscale, const double *da, const double *db, const double *dc,
+                         double *p, int fixnull) {
+  if (nz < 2 || nz > 1024 || getenv("CALES_GAUSSEL_MARCH")) return false;
+  if (nz <= 128) launch_gaussel_tile<2, NV>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull);
+  else if (nz <= 256) launch_gaussel_tile<4, NV>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull);
+  else if (nz <= 512) launch_gaussel_tile<8, NV>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull);
+  else launch_gaussel_tile<16, NV>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull);
+  return true;
+}
+
 // Non-periodic x (real modes r = 2m, 2m+1 paired into one complex column) with PERIODIC y: the y transform of the pair gives
 // Z_ky = A_ky + i B_ky, A and B the (Hermitian) spectra of the two real columns, which have DIFFERENT x eigenvalues. Rows ky and
 // N-ky are separated, A = (Z_ky + conj Z_{N-ky})/2, B = (Z_ky - conj Z_{N-ky})/(2i), the four real systems (Re/Im of A and B) go to
@@ -832,6 +967,9 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
     if (c->xkind && !c->ykind)       // real x modes paired into complex columns + periodic y: Hermitian separation of rows ky and N-ky
       hipLaunchKernelGGL(k_gaussel_herm, dim3((unsigned)(((long)4 * ncol * (n2g / 2 + 1) + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S,
                          da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, fixnull);
+    else if (!dist && !periodic_z && getenv("CALES_GAUSSEL_PAIR") == nullptr && (fixnull || !poisson || CBP(c, 0, 3) == 'D' || CBP(c, 1, 3) == 'D') &&
+             (c->xkind ? gaussel_tile<1>(c, nz, 2 * (c->C.ng[0] / 2), n2g, lscale, da, db, dc, (double *)mode_spec, fixnull)
+                       : gaussel_tile<2>(c, nz, 2 * mh, n2g, lscale, da, db, dc, (double *)mode_spec, fixnull))) {}
     else if (c->xkind && !periodic_z && getenv("CALES_GAUSSEL_PAIR") == nullptr)
       hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, lscale, da, db, dc,
                          c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, fixnull, 1);

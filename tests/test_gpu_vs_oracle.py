@@ -23,7 +23,10 @@ def _hot(case):
                                      ("duct_smag_wm", (32, 64, 16)), ("duct_smag_wm", (24, 30, 12)), ("duct_smag_wm", (128, 256, 8)),
                                      ("cavity_nnn", (32, 16, 12)), ("cavity_nnn", (20, 36, 10)), ("cavity_nnn", (256, 128, 6)),
                                      # line lengths with factors 7, 11, 13 (direct-DFT butterflies)
-                                     ("chan_smag", (28, 22, 10)), ("cavity_nnn", (52, 14, 8)), ("duct_smag_wm", (44, 26, 12))])
+                                     ("chan_smag", (28, 22, 10)), ("cavity_nnn", (52, 14, 8)), ("duct_smag_wm", (44, 26, 12)),
+                                     # deep z: the in-LDS tridiagonal tile with 2, 4, 8, 16 planes per lane, partial last chunks
+                                     ("chan_smag", (16, 8, 100)), ("chan_smag", (16, 8, 130)), ("cavity_nnn", (40, 8, 300)),
+                                     ("chan_smag", (16, 4, 512)), ("duct_smag_wm", (16, 8, 514)), ("chan_smag", (8, 4, 1024))])
 def test_poisson_solve(name, ng):
     g, case = load_golden(name)
     case.ng[:] = ng
@@ -39,6 +42,22 @@ def test_poisson_solve(name, ng):
     err = np.abs((a - a.mean()) - (b - b.mean())).max()
     assert err < 1e-11 * np.abs(b - b.mean()).max() + 1e-14 * abs(b.mean()), (ng, err)
     h.close()
+
+
+@pytest.mark.parametrize("name,ng", [("chan_smag", (32, 16, 24)), ("cavity_nnn", (24, 20, 70)), ("halfchan_imp1d", (16, 16, 200))])
+def test_tridiagonal_paths_agree(name, ng, monkeypatch):
+    """the in-LDS substructured sweep (default on one rank) against the marching Thomas sweep (CALES_GAUSSEL_MARCH)"""
+    g, case = load_golden(name)
+    case.ng[:] = ng
+    rng = np.random.RandomState(5)
+    rhs = np.zeros(tuple(x + 2 for x in ng), order="F"); rhs[1:-1, 1:-1, 1:-1] = rng.rand(*ng) - 0.5
+    out = []
+    for march in (False, True):
+        if march:
+            monkeypatch.setenv("CALES_GAUSSEL_MARCH", "1")
+        h = _hot(case); h.set("pp", rhs); h.solver()
+        a = h.get("pp")[1:-1, 1:-1, 1:-1]; out.append(a - a.mean()); h.close()
+    assert np.abs(out[0] - out[1]).max() < 1e-11 * np.abs(out[1]).max()
 
 
 @pytest.mark.parametrize("name,ng,nsteps", [("tgv_ppp", (32, 24, 16), 5), ("chan_smag_wm", (32, 16, 16), 5), ("chan_dsmag", (32, 16, 16), 5),
