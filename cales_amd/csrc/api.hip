@@ -290,6 +290,7 @@ __global__ void k_zero6(double *f) { if (threadIdx.x < 6) f[threadIdx.x] = 0.; }
 int cales_step(cales_ctx *c, double dt) {
   static const double rk[3][2] = {{32. / 60., 0.}, {25. / 60., -17. / 60.}, {45. / 60., -25. / 60.}};
   hipLaunchKernelGGL(k_zero6, dim3(1), dim3(64), 0, c->stream, c->d_force);     // dpdl(:) = 0
+  struct Reset { cales_ctx *c; ~Reset() { c->defer_force = false; c->defer_imp_rhs = false; } } reset{c};      // also on the error returns
   for (int irk = 1; irk <= 3; ++irk) {
     const double dtrk = (rk[irk - 1][0] + rk[irk - 1][1]) * dt, dtrki = 1. / dtrk;
     double alpha = 0.;
@@ -297,7 +298,14 @@ int cales_step(cales_ctx *c, double dt) {
     const char *bz = &c->cbcvel[4];
     c->defer_imp_rhs = c->C.impdiff == 2 && getenv("CALES_HELMHOLTZ_Z_PER_COLUMN") == nullptr && getenv("CALES_UNFUSED_IMP_RHS") == nullptr &&
                        !(bz[0] == 'P' && bz[1] == 'P') && !(bz[6] == 'P' && bz[7] == 'P') && !(bz[12] == 'P' && bz[13] == 'P');
-    if (int e = op_rk(c, irk, dt)) { c->defer_imp_rhs = false; return e; }
+    // explicit step without wall model, forced directions periodic: the velocity between the forcing and the correction is only
+    // differenced along the forced direction (fillps) -- the increment is added by the correction kernel, one pass less
+    const bool fuse_cu = getenv("CALES_UNFUSED_CORREC") == nullptr && c->C.impdiff != 1;     // updatep only needs pp: one pass with correc
+    { bool ok = c->C.impdiff == 0 && fuse_cu && getenv("CALES_UNFUSED_FORCING") == nullptr;
+      for (int q = 0; q < 6; ++q) ok = ok && c->C.lwm[q] == 0;
+      for (int d = 0; d < 3; ++d) if (c->C.is_forced[d]) ok = ok && c->cbcvel[6 * d + 2 * d] == 'P' && c->cbcvel[6 * d + 2 * d + 1] == 'P';
+      c->defer_force = ok && (c->C.is_forced[0] || c->C.is_forced[1] || c->C.is_forced[2]); }
+    if (int e = op_rk(c, irk, dt)) { c->defer_imp_rhs = false; c->defer_force = false; return e; }
     if (int e = op_bulk_forcing(c)) { c->defer_imp_rhs = false; return e; }
     if (c->C.impdiff == 2) {
       alpha = -.5 * c->visc * dtrk;
@@ -312,8 +320,7 @@ int cales_step(cales_ctx *c, double dt) {
     if (int e = op_updt_rhs_b(c)) return e;
     if (int e = op_solver(c)) return e;
     if (int e = op_boundp(c, c->f[CALES_PP], 0)) return e;
-    const bool fuse_cu = getenv("CALES_UNFUSED_CORREC") == nullptr && c->C.impdiff != 1;     // updatep only needs pp: one pass with correc
-    if (int e = (fuse_cu ? op_correc_updatep(c, dtrk, alpha, 1) : op_correc(c, dtrk))) return e;
+    { const int e = fuse_cu ? op_correc_updatep(c, dtrk, alpha, 1) : op_correc(c, dtrk); c->defer_force = false; if (e) return e; }
     if (int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 1, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W])) return e;
     if (!fuse_cu) { if (int e = op_updatep(c, alpha)) return e; }
     if (int e = op_boundp(c, c->f[CALES_P], 0)) return e;

@@ -107,6 +107,7 @@ struct cales_ctx {
   double *d_del = nullptr;   // Smagorinsky filter width per plane (fast path)
   void *native_comm = nullptr;   // RCCL communicator + staging buffers when the library does the exchanges itself (comm_rccl.cpp)
   bool visct_zero = true;  // CALES_VISCT still holds the zeros it was created / reset with (no SGS model: lets kernels skip it)
+  bool defer_force = false;      // explicit step, forced directions periodic, no wall model: u += f is applied by the correction kernel
   bool defer_imp_rhs = false; double hf12 = 0.;   // z-implicit step: u -= hf12*dudtd and u += f are applied inside the Helmholtz sweep
   int bc_skip = 0;         // bit d-1: boundp/bounduvw leave direction d alone (set around calls whose consumers do not need it)
   int field_ofs = 0;       // doubles between a field's allocation and its element (0,0,0)

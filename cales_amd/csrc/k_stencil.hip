@@ -277,7 +277,7 @@ __global__ __launch_bounds__(BX *BY) void k_bulk_forcing(Geom g, double *__restr
   if (fz) w[c] += force[2];
 }
 int op_bulk_forcing(cales_ctx *c) {
-  if (!(c->C.is_forced[0] || c->C.is_forced[1] || c->C.is_forced[2]) || c->defer_imp_rhs) return 0;
+  if (!(c->C.is_forced[0] || c->C.is_forced[1] || c->C.is_forced[2]) || c->defer_imp_rhs || c->defer_force) return 0;
   ProfScope ps(c, "bulk_forcing");
   dim3 b(BX, BY, 1), gr = grid3(c->n[0], c->n[1], c->n[2], b);
   hipLaunchKernelGGL(k_bulk_forcing, gr, b, 0, c->stream, c->g, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W], c->d_force,
@@ -320,11 +320,14 @@ __global__ __launch_bounds__(BX *BY) void k_correc(Geom g, double fi, double fj,
 // Line-aligned form of the same loops, optionally fused with updatep (updatep.f90:30-47; UPD = 1 explicit, 2 z-implicit):
 // a wave covers the 64 cells i = 1 + 64 bx + lane of one row (whole 128-B lines), p(i+1) comes from the next lane, pp is
 // read once for both operators. The ghost columns i = 0 and i = n1+1 of the reference's ranges are left to k_correc_edge.
+// fmask != 0 (cales_step, see defer_force): the bulk-forcing increment of this substep (mom.f90:311-335, interior cells) is
+// added here instead of in a pass of its own -- (u + f) - dt dp/dx, the same two roundings in the same order.
 // (A k-marching variant with the pressure planes in registers measured slower: the kernel is a pure stream.)
 template <int UPD>
 __global__ __launch_bounds__(BX *BY) void k_correc_cell(Geom g, double fi, double fj, double dt, double alpha, const double *__restrict__ dzci,
                                                          const double *__restrict__ dzfi, const double *__restrict__ pp, double *__restrict__ u,
-                                                         double *__restrict__ v, double *__restrict__ w, double *__restrict__ p) {
+                                                         double *__restrict__ v, double *__restrict__ w, double *__restrict__ p,
+                                                         const double *__restrict__ force, int fmask) {
   const int tx = threadIdx.x, i = blockIdx.x * BX + tx + 1, j = blockIdx.y * BY + threadIdx.y, k = blockIdx.z;
   if (j > g.n2 + 1) return;
   const bool on = i <= g.n1, lastlane = tx == BX - 1 || i == g.n1;
@@ -333,10 +336,12 @@ __global__ __launch_bounds__(BX *BY) void k_correc_cell(Geom g, double fi, doubl
   double px = lane_next(pc);
   if (lastlane) px = pp[c + 1];
   if (!on) return;
-  u[c] = u[c] - fi * (px - pc);
-  if (j <= g.n2) v[c] = v[c] - fj * (pp[c + g.s1] - pc);
+  const bool inner = j >= 1 && j <= g.n2 && k >= 1 && k <= g.n3;
+  const double f0 = (fmask & 1) && inner ? force[0] : 0., f1 = (fmask & 2) && inner ? force[1] : 0., f2 = (fmask & 4) && inner ? force[2] : 0.;
+  u[c] = (fmask & 1 ? u[c] + f0 : u[c]) - fi * (px - pc);
+  if (j <= g.n2) v[c] = (fmask & 2 ? v[c] + f1 : v[c]) - fj * (pp[c + g.s1] - pc);
   const double pn = k <= g.n3 ? pp[c + g.s12] : 0.;
-  if (k <= g.n3) w[c] = w[c] - dt * dzci[k] * (pn - pc);
+  if (k <= g.n3) w[c] = (fmask & 4 ? w[c] + f2 : w[c]) - dt * dzci[k] * (pn - pc);
   if (UPD && j >= 1 && j <= g.n2 && k >= 1 && k <= g.n3) {
     if (UPD == 1) p[c] = p[c] + pc;
     else p[c] = p[c] + pc + alpha * (((pn - pc) * dzci[k] - (pc - pp[c - g.s12]) * dzci[k - 1]) * dzfi[k]);
@@ -362,9 +367,10 @@ int op_correc_updatep(cales_ctx *c, double dt, double alpha, int upd) {
   double *f_[4] = {c->f[CALES_U], c->f[CALES_V], c->f[CALES_W], c->f[CALES_P]};
   const double fi = dt * c->dli[0], fj = dt * c->dli[1];
   const int mode = !upd ? 0 : (c->C.impdiff == 2 ? 2 : 1);
-  if (mode == 0) hipLaunchKernelGGL(k_correc_cell<0>, gr, b, 0, c->stream, c->g, fi, fj, dt, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], f_[0], f_[1], f_[2], f_[3]);
-  else if (mode == 1) hipLaunchKernelGGL(k_correc_cell<1>, gr, b, 0, c->stream, c->g, fi, fj, dt, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], f_[0], f_[1], f_[2], f_[3]);
-  else hipLaunchKernelGGL(k_correc_cell<2>, gr, b, 0, c->stream, c->g, fi, fj, dt, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], f_[0], f_[1], f_[2], f_[3]);
+  const int fmask = c->defer_force ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;
+  if (mode == 0) hipLaunchKernelGGL(k_correc_cell<0>, gr, b, 0, c->stream, c->g, fi, fj, dt, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], f_[0], f_[1], f_[2], f_[3], c->d_force, fmask);
+  else if (mode == 1) hipLaunchKernelGGL(k_correc_cell<1>, gr, b, 0, c->stream, c->g, fi, fj, dt, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], f_[0], f_[1], f_[2], f_[3], c->d_force, fmask);
+  else hipLaunchKernelGGL(k_correc_cell<2>, gr, b, 0, c->stream, c->g, fi, fj, dt, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], f_[0], f_[1], f_[2], f_[3], c->d_force, fmask);
   hipLaunchKernelGGL(k_correc_edge, dim3((n[1] + 2 + 63) / 64, (n[2] + 2 + 3) / 4, 2), dim3(64, 4, 1), 0, c->stream, c->g, fi, fj, dt, c->d_dzci, c->f[CALES_PP],
                      f_[0], f_[1], f_[2]);
   HIPCHK(c, hipGetLastError());
