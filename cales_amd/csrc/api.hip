@@ -290,7 +290,7 @@ __global__ void k_zero6(double *f) { if (threadIdx.x < 6) f[threadIdx.x] = 0.; }
 int cales_step(cales_ctx *c, double dt) {
   static const double rk[3][2] = {{32. / 60., 0.}, {25. / 60., -17. / 60.}, {45. / 60., -25. / 60.}};
   hipLaunchKernelGGL(k_zero6, dim3(1), dim3(64), 0, c->stream, c->d_force);     // dpdl(:) = 0
-  struct Reset { cales_ctx *c; ~Reset() { c->defer_force = false; c->defer_imp_rhs = false; } } reset{c};      // also on the error returns
+  struct Reset { cales_ctx *c; ~Reset() { c->defer_force = false; c->defer_imp_rhs = false; c->fuse_fillps_dti = 0.; } } reset{c};      // also on the error returns
   for (int irk = 1; irk <= 3; ++irk) {
     const double dtrk = (rk[irk - 1][0] + rk[irk - 1][1]) * dt, dtrki = 1. / dtrk;
     double alpha = 0.;
@@ -316,9 +316,12 @@ int cales_step(cales_ctx *c, double dt) {
       for (int iv = 1; iv <= 3; ++iv) if (int e = op_helmholtz(c, iv, alpha)) return e;
     }
     if (int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 0, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W])) return e;
-    if (int e = op_fillps(c, dtrki)) return e;
-    if (int e = op_updt_rhs_b(c)) return e;
-    if (int e = op_solver(c)) return e;
+    // homogeneous pressure BCs (no boundary r.h.s.) and a radix-8 x plan: fillps is done by the forward x transform
+    bool fuse_fill = getenv("CALES_UNFUSED_FILLPS") == nullptr && getenv("CALES_UNALIGNED") == nullptr && solver_can_fuse_fillps(c);
+    for (int d = 0; d < 3; ++d) fuse_fill = fuse_fill && ((c->C.bcpre[2 * d] == 0. && c->C.bcpre[2 * d + 1] == 0.) || c->C.cbcpre[2 * d] == 'P');
+    if (fuse_fill) c->fuse_fillps_dti = dtrki;
+    else { if (int e = op_fillps(c, dtrki)) return e; if (int e = op_updt_rhs_b(c)) return e; }
+    { const int e = op_solver(c); c->fuse_fillps_dti = 0.; if (e) return e; }
     if (int e = op_boundp(c, c->f[CALES_PP], 0)) return e;
     { const int e = fuse_cu ? op_correc_updatep(c, dtrk, alpha, 1) : op_correc(c, dtrk); c->defer_force = false; if (e) return e; }
     if (int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 1, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W])) return e;

@@ -107,6 +107,7 @@ struct cales_ctx {
   double *d_del = nullptr;   // Smagorinsky filter width per plane (fast path)
   void *native_comm = nullptr;   // RCCL communicator + staging buffers when the library does the exchanges itself (comm_rccl.cpp)
   bool visct_zero = true;  // CALES_VISCT still holds the zeros it was created / reset with (no SGS model: lets kernels skip it)
+  double fuse_fillps_dti = 0.;   // != 0: the forward x transform of the next pressure solve forms pp = div(u*)/dtrk itself (cales_step)
   bool defer_force = false;      // explicit step, forced directions periodic, no wall model: u += f is applied by the correction kernel
   bool defer_imp_rhs = false; double hf12 = 0.;   // z-implicit step: u -= hf12*dudtd and u += f are applied inside the Helmholtz sweep
   int bc_skip = 0;         // bit d-1: boundp/bounduvw leave direction d alone (set around calls whose consumers do not need it)
@@ -163,6 +164,7 @@ int op_helmholtz_z(cales_ctx *c, int ivel, double alpha);
 extern "C" void cales_comm_release_native(cales_ctx *c);
 int op_helmholtz(cales_ctx *c, int ivel, double alpha);
 int op_correc(cales_ctx *c, double dtrk);
+bool solver_can_fuse_fillps(cales_ctx *c);
 int op_correc_updatep(cales_ctx *c, double dtrk, double alpha, int upd);
 int op_updatep(cales_ctx *c, double alpha);
 int op_cmpt_sgs(cales_ctx *c);

@@ -11,8 +11,10 @@
 #include "common.hpp"
 
 #ifndef TYM
-#define TYM 6
+#define TYM 10      // measured at 512^3: 10 (12 waves, 120 KB of LDS, one block per CU) 2.89 ms, 6 (two blocks per CU) 2.92-3.00, 8: 3.17
 #endif
+
+static_assert(5 * (TYM + 2) <= 64, "the x-halo columns of a tile are fetched by the 64 lanes of one wave, 5 fields per row");
 
 struct MomRkArgs {
   const double *u, *v, *w, *s, *p, *duo, *dvo, *dwo;
@@ -24,7 +26,7 @@ struct MomRkArgs {
 
 // NOS = 1: no subgrid model (visct is identically zero, sgs.f90:62-68): its loads, LDS traffic and terms are compiled out
 template <int IMP, typename OFF, int NOS>
-__global__ __launch_bounds__(64 * (TYM + 2), 4) void k_momrk(Geom g, MomRkArgs A) {
+__global__ __launch_bounds__(64 * (TYM + 2), (TYM <= 6 ? 4 : 3)) void k_momrk(Geom g, MomRkArgs A) {
   __shared__ double sh[4][4][TYM + 2][66];
   __shared__ double shp[3][TYM + 2][66];
   const int tx = threadIdx.x, ty = threadIdx.y;

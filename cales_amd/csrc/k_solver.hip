@@ -176,9 +176,13 @@ __device__ inline void fft_line8(int N, cpx *buf, int t, const cpx *__restrict__
 __device__ inline int dct_src(int e, int n) { return e < n / 2 ? 2 * e : 2 * (n - 1 - e) + 1; }   // Makhoul: v[e] = x[dct_src(e)]
 // x pass for nh = n1/2 = 2^p. Persistent: a block owns `iters` consecutive groups of R rows, R = blockDim.x / (nh/8);
 // the next group's rows are prefetched into registers while the current one is transformed; twiddles live in LDS.
-template <int INV, int KIND>
+// FILL = 1 (forward only, cales_step): the rows are not read from pp but formed from the velocities, pp = div(u*)/dtrk
+// (fillps.f90:36-47, same expression as k_fillps) -- the separate fillps pass and its write + re-read of pp disappear.
+struct FillArgs { const double *u, *v, *w, *dzfi; double dti, dtidxi, dtidyi; };
+template <int INV, int KIND, int FILL = 0>
 __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const cpx *__restrict__ twg, const cpx *__restrict__ twpg,
-                                                 const cpx *__restrict__ twd, double *__restrict__ p, double scale, Spec S, double2 *__restrict__ spec) {
+                                                 const cpx *__restrict__ twd, double *__restrict__ p, double scale, Spec S, double2 *__restrict__ spec,
+                                                 FillArgs F = FillArgs{}) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int kind = KIND;                                                 // 0 periodic (R2HC/HC2R), 1 Neumann-Neumann (DCT-II/III)
   const int T = nh >> 3, R = blockDim.x / T, row = threadIdx.x / T, t = threadIdx.x % T, ld = lpad(nh) + 2;
@@ -195,7 +199,19 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const
   auto fetch = [&](long r) {
     if (r >= nrows) return;
     int j, k; rowptr(r, j, k);
-    if (!INV) {
+    if (!INV && FILL) {
+      const size_t c0 = g.ix(0, j, k);
+      const double dz = F.dzfi[k];
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const size_t c = c0 + 1 + 2 * (t + e * T);      // cell i = 1 + 2q and its right neighbour: aligned pairs
+        const double2 uu = *reinterpret_cast<const double2 *>(F.u + c); const double um = F.u[c - 1];
+        const double2 vv = *reinterpret_cast<const double2 *>(F.v + c), vm = *reinterpret_cast<const double2 *>(F.v + c - g.s1);
+        const double2 ww = *reinterpret_cast<const double2 *>(F.w + c), wm = *reinterpret_cast<const double2 *>(F.w + c - g.s12);
+        nxt[e] = cpx{((ww.x - wm.x) * F.dti * dz + (vv.x - vm.x) * F.dtidyi + (uu.x - um) * F.dtidxi),
+                     ((ww.y - wm.y) * F.dti * dz + (vv.y - vm.y) * F.dtidyi + (uu.y - uu.x) * F.dtidxi)};
+      }
+    } else if (!INV) {
       const double *rowp = p + g.ix(0, j, k);
 #pragma unroll
       for (int e = 0; e < NE; ++e) { const int q = t + e * T; nxt[e] = cpx{rowp[1 + 2 * q], rowp[2 + 2 * q]}; }      // Makhoul's order is applied in LDS
@@ -834,6 +850,8 @@ struct PlanSlot { cales_ctx *ctx; SolverPlans sp; };
 static std::vector<PlanSlot> g_slots;
 static SolverPlans *find_plans(cales_ctx *c) { for (auto &s : g_slots) if (s.ctx == c) return &s.sp; return nullptr; }
 
+bool solver_can_fuse_fillps(cales_ctx *c) { SolverPlans *sp = find_plans(c); return sp && sp->x8; }
+
 int solver_setup(cales_ctx *c) {
   const int *n = c->n; const int n1 = c->C.ng[0], n2g = c->C.ng[1], n3 = n[2];
   const std::string bx = std::string(1, c->C.cbcpre[0]) + c->C.cbcpre[1], by = std::string(1, c->C.cbcpre[2]) + c->C.cbcpre[3];
@@ -944,7 +962,15 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
   const unsigned xblocks = (unsigned)((xgroups + xiters - 1) / xiters);
   int ykchunk = 1; { const long cg = (ncol + CB8 - 1) / CB8; while (ykchunk < 8 && cg * (n[2] / (ykchunk * 2)) >= 2048 && n[2] % (ykchunk * 2) == 0) ykchunk *= 2; }
   const int ychunks = (n[2] + ykchunk - 1) / ykchunk;
-  { ProfScope ps(c, "fft_x_fwd");
+  if (poisson && c->fuse_fillps_dti != 0. && sp->x8) {
+    ProfScope ps(c, "fillps_fft_x_fwd");
+    const double dti = c->fuse_fillps_dti;
+    FillArgs F{c->f[CALES_U], c->f[CALES_V], c->f[CALES_W], c->d_dzfi, dti, dti * c->dli[0], dti * c->dli[1]};
+    if (c->xkind) hipLaunchKernelGGL((k_fft_x8<0, 1, 1>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
+                                     (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec, F);
+    else hipLaunchKernelGGL((k_fft_x8<0, 0, 1>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
+                            (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec, F);
+  } else { ProfScope ps(c, "fft_x_fwd");
     if (sp->x8 && c->xkind) hipLaunchKernelGGL((k_fft_x8<0, 1>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec);
     else if (sp->x8) hipLaunchKernelGGL((k_fft_x8<0, 0>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,

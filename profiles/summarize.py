@@ -58,7 +58,7 @@ def main():
     # what bench.py reads for roofline.traffic: timer name -> kernel-name prefix, per-launch HBM bytes of each kernel
     b2k = {"mom_rk_fused": "k_momrk", "strain_filter_uvw": "k_strain_tile", "filter_s0sij": "k_filter6_tile",
            "lij_mij_contract": "k_lij_mij_tile", "correc": "k_correc", "fillps": "k_fillps", "updatep": "k_updatep",
-           "gaussel_z": "k_gaussel", "fft_x_fwd": "k_fft_x8<0", "fft_x_bwd": "k_fft_x8<1", "fft_y_fwd": "k_fft_y8<0",
+           "gaussel_z": "k_gaussel", "fft_x_fwd": "k_fft_x8<0, 0, 0", "fillps_fft_x_fwd": "k_fft_x8<0, 0, 1", "correc_updatep": "k_correc_cell", "fft_x_bwd": "k_fft_x8<1", "fft_y_fwd": "k_fft_y8<0",
            "fft_y_bwd": "k_fft_y8<1"}
     if ncell:
         json.dump({"source": f"profiles/{rnd}_kernels.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 read x2)",

@@ -136,11 +136,11 @@ def test_wide_offset_kernels(name, monkeypatch):
     test_fused_step_matches_operator_sequence(name)
 
 
-@pytest.mark.parametrize("env", ["CALES_DSMAG_REFERENCE_SEQUENCE", "CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFUSED_FORCING", "CALES_GAUSSEL_MARCH"])
+@pytest.mark.parametrize("env", ["CALES_DSMAG_REFERENCE_SEQUENCE", "CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_GAUSSEL_MARCH"])
 @pytest.mark.parametrize("name", ["chan_dsmag", "chan_dsmag_wm", "tgv_dsmag_ppp", "duct_smag_wm_imp1d"])
 def test_unfused_paths(name, env, monkeypatch):
     """The kernel-per-loop forms behind the operator-level entries (general dsmag sequence, mom + rk_update, correc +
-    updatep, bulk forcing as a pass of its own, marching tridiagonal sweep) stay selectable and are held to the same
+    updatep, bulk forcing and fillps as passes of their own, marching tridiagonal sweep) stay selectable and are held to the same
     end-of-step tolerances."""
     monkeypatch.setenv(env, "1")
     test_fused_step_matches_operator_sequence(name)
