@@ -95,7 +95,7 @@ void cales_destroy(cales_ctx *c) {
   DBound *bs[11] = {&c->bcu, &c->bcv, &c->bcw, &c->bcp, &c->bcs, &c->bcuf, &c->bcvf, &c->bcwf, &c->bcu_mag, &c->bcv_mag, &c->bcw_mag};
   for (auto *b : bs) free_bound(*b);
   for (int d = 0; d < 3; ++d) hipFree(c->rhsbp[d]);
-  field_free(c, c->scr1); field_free(c, c->scr2); hipFree(c->d_red); hipFree(c->d_force); hipHostFree(c->h_red);
+  field_free(c, c->scr1); field_free(c, c->scr2); hipFree(c->d_red); hipFree(c->d_force); if (c->d_mpart) hipFree(c->d_mpart); hipHostFree(c->h_red);
   field_free(c, c->s0); field_free(c, c->uc); field_free(c, c->vc); field_free(c, c->wc); field_free(c, c->uf); field_free(c, c->vf); field_free(c, c->wf); field_free(c, c->alph2); if (!c->p1d_in_comm) hipFree(c->d_p1d);
   for (int m = 0; m < 6; ++m) { field_free(c, c->wk[m]); field_free(c, c->sij[m]); field_free(c, c->mij[m]); }
   cales_comm_release_native(c);
@@ -290,7 +290,7 @@ __global__ void k_zero6(double *f) { if (threadIdx.x < 6) f[threadIdx.x] = 0.; }
 int cales_step(cales_ctx *c, double dt) {
   static const double rk[3][2] = {{32. / 60., 0.}, {25. / 60., -17. / 60.}, {45. / 60., -25. / 60.}};
   hipLaunchKernelGGL(k_zero6, dim3(1), dim3(64), 0, c->stream, c->d_force);     // dpdl(:) = 0
-  struct Reset { cales_ctx *c; ~Reset() { c->defer_force = false; c->defer_imp_rhs = false; c->fuse_fillps_dti = 0.; } } reset{c};      // also on the error returns
+  struct Reset { cales_ctx *c; ~Reset() { c->defer_force = false; c->defer_imp_rhs = false; c->fuse_fillps_dti = 0.; c->fuse_mean_mask = 0; } } reset{c};      // also on the error returns
   for (int irk = 1; irk <= 3; ++irk) {
     const double dtrk = (rk[irk - 1][0] + rk[irk - 1][1]) * dt, dtrki = 1. / dtrk;
     double alpha = 0.;
@@ -305,7 +305,13 @@ int cales_step(cales_ctx *c, double dt) {
       for (int q = 0; q < 6; ++q) ok = ok && c->C.lwm[q] == 0;
       for (int d = 0; d < 3; ++d) if (c->C.is_forced[d]) ok = ok && c->cbcvel[6 * d + 2 * d] == 'P' && c->cbcvel[6 * d + 2 * d + 1] == 'P';
       c->defer_force = ok && (c->C.is_forced[0] || c->C.is_forced[1] || c->C.is_forced[2]); }
-    if (int e = op_rk(c, irk, dt)) { c->defer_imp_rhs = false; c->defer_force = false; return e; }
+    // homogeneous pressure BCs (no boundary r.h.s.) and a radix-8 x plan: fillps is done by the forward x transform, which then
+    // also sums the bulk means of the forced components (their increment is only needed by the correction kernel)
+    bool fuse_fill = getenv("CALES_UNFUSED_FILLPS") == nullptr && getenv("CALES_UNALIGNED") == nullptr && solver_can_fuse_fillps(c);
+    for (int d = 0; d < 3; ++d) fuse_fill = fuse_fill && ((c->C.bcpre[2 * d] == 0. && c->C.bcpre[2 * d + 1] == 0.) || c->C.cbcpre[2 * d] == 'P');
+    c->fuse_mean_mask = (fuse_fill && c->defer_force && getenv("CALES_UNFUSED_MEAN") == nullptr)
+                            ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;
+    if (int e = op_rk(c, irk, dt)) return e;
     if (int e = op_bulk_forcing(c)) { c->defer_imp_rhs = false; return e; }
     if (c->C.impdiff == 2) {
       alpha = -.5 * c->visc * dtrk;
@@ -316,9 +322,6 @@ int cales_step(cales_ctx *c, double dt) {
       for (int iv = 1; iv <= 3; ++iv) if (int e = op_helmholtz(c, iv, alpha)) return e;
     }
     if (int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 0, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W])) return e;
-    // homogeneous pressure BCs (no boundary r.h.s.) and a radix-8 x plan: fillps is done by the forward x transform
-    bool fuse_fill = getenv("CALES_UNFUSED_FILLPS") == nullptr && getenv("CALES_UNALIGNED") == nullptr && solver_can_fuse_fillps(c);
-    for (int d = 0; d < 3; ++d) fuse_fill = fuse_fill && ((c->C.bcpre[2 * d] == 0. && c->C.bcpre[2 * d + 1] == 0.) || c->C.cbcpre[2 * d] == 'P');
     if (fuse_fill) c->fuse_fillps_dti = dtrki;
     else { if (int e = op_fillps(c, dtrki)) return e; if (int e = op_updt_rhs_b(c)) return e; }
     { const int e = op_solver(c); c->fuse_fillps_dti = 0.; if (e) return e; }

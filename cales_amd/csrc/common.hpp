@@ -107,6 +107,7 @@ struct cales_ctx {
   double *d_del = nullptr;   // Smagorinsky filter width per plane (fast path)
   void *native_comm = nullptr;   // RCCL communicator + staging buffers when the library does the exchanges itself (comm_rccl.cpp)
   bool visct_zero = true;  // CALES_VISCT still holds the zeros it was created / reset with (no SGS model: lets kernels skip it)
+  int fuse_mean_mask = 0; double *d_mpart = nullptr; size_t n_mpart = 0;      // bulk means of the forced components are summed by that pass too
   double fuse_fillps_dti = 0.;   // != 0: the forward x transform of the next pressure solve forms pp = div(u*)/dtrk itself (cales_step)
   bool defer_force = false;      // explicit step, forced directions periodic, no wall model: u += f is applied by the correction kernel
   bool defer_imp_rhs = false; double hf12 = 0.;   // z-implicit step: u -= hf12*dudtd and u += f are applied inside the Helmholtz sweep
@@ -165,6 +166,7 @@ extern "C" void cales_comm_release_native(cales_ctx *c);
 int op_helmholtz(cales_ctx *c, int ivel, double alpha);
 int op_correc(cales_ctx *c, double dtrk);
 bool solver_can_fuse_fillps(cales_ctx *c);
+int op_force_from_partials(cales_ctx *c, int mask, const double *part, int nblk);
 int op_correc_updatep(cales_ctx *c, double dtrk, double alpha, int upd);
 int op_updatep(cales_ctx *c, double alpha);
 int op_cmpt_sgs(cales_ctx *c);

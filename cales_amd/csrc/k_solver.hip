@@ -178,7 +178,9 @@ __device__ inline int dct_src(int e, int n) { return e < n / 2 ? 2 * e : 2 * (n 
 // the next group's rows are prefetched into registers while the current one is transformed; twiddles live in LDS.
 // FILL = 1 (forward only, cales_step): the rows are not read from pp but formed from the velocities, pp = div(u*)/dtrk
 // (fillps.f90:36-47, same expression as k_fillps) -- the separate fillps pass and its write + re-read of pp disappear.
-struct FillArgs { const double *u, *v, *w, *dzfi; double dti, dtidxi, dtidyi; };
+// mean_mask != 0: the pass also sums comp*grid_vol_ratio(k) of the forced velocity components it reads anyway (bulk_mean,
+// utils.f90:35-44), one partial per block and component -> the separate reduction pass over u disappears.
+struct FillArgs { const double *u, *v, *w, *dzfi; double dti, dtidxi, dtidyi; int mean_mask; const double *gvr_f, *gvr_c; double *part; };
 template <int INV, int KIND, int FILL = 0>
 __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const cpx *__restrict__ twg, const cpx *__restrict__ twpg,
                                                  const cpx *__restrict__ twd, double *__restrict__ p, double scale, Spec S, double2 *__restrict__ spec,
@@ -195,6 +197,7 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const
   const long nrows = (long)g.n2 * g.n3;
   const int NE = 8;                                                          // elements per thread and row: nh / T
   cpx nxt[NE + 1];
+  double macc[3] = {0., 0., 0.};
   auto rowptr = [&](long r, int &j, int &k) { j = (int)(r % g.n2) + 1; k = (int)(r / g.n2) + 1; };
   auto fetch = [&](long r) {
     if (r >= nrows) return;
@@ -210,6 +213,9 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const
         const double2 ww = *reinterpret_cast<const double2 *>(F.w + c), wm = *reinterpret_cast<const double2 *>(F.w + c - g.s12);
         nxt[e] = cpx{((ww.x - wm.x) * F.dti * dz + (vv.x - vm.x) * F.dtidyi + (uu.x - um) * F.dtidxi),
                      ((ww.y - wm.y) * F.dti * dz + (vv.y - vm.y) * F.dtidyi + (uu.y - uu.x) * F.dtidxi)};
+        if (F.mean_mask & 1) macc[0] += (uu.x + uu.y) * F.gvr_f[k];
+        if (F.mean_mask & 2) macc[1] += (vv.x + vv.y) * F.gvr_f[k];
+        if (F.mean_mask & 4) macc[2] += (ww.x + ww.y) * F.gvr_c[k];
       }
     } else if (!INV) {
       const double *rowp = p + g.ix(0, j, k);
@@ -307,6 +313,19 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const
       }
     }
     __syncthreads();
+  }
+  if (FILL && F.mean_mask) {      // smem is free again: wave sums, then one partial per block and component
+    double *red = reinterpret_cast<double *>(smem);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      if (!(F.mean_mask >> q & 1)) continue;
+      double v = macc[q];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+      __syncthreads();
+      if (threadIdx.x == 0) { double a = 0.; for (unsigned w = 0; w < blockDim.x / 64; ++w) a += red[w]; F.part[(size_t)q * gridDim.x + blockIdx.x] = a; }
+      __syncthreads();
+    }
   }
 }
 
@@ -965,11 +984,16 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
   if (poisson && c->fuse_fillps_dti != 0. && sp->x8) {
     ProfScope ps(c, "fillps_fft_x_fwd");
     const double dti = c->fuse_fillps_dti;
-    FillArgs F{c->f[CALES_U], c->f[CALES_V], c->f[CALES_W], c->d_dzfi, dti, dti * c->dli[0], dti * c->dli[1]};
+    FillArgs F{c->f[CALES_U], c->f[CALES_V], c->f[CALES_W], c->d_dzfi, dti, dti * c->dli[0], dti * c->dli[1], c->fuse_mean_mask, c->d_gvr_f, c->d_gvr_c, nullptr};
+    if (F.mean_mask) {
+      if (c->n_mpart < 3 * (size_t)xblocks) { if (c->d_mpart) hipFree(c->d_mpart); HIPCHK(c, hipMalloc(&c->d_mpart, 3 * (size_t)xblocks * sizeof(double))); c->n_mpart = 3 * (size_t)xblocks; }
+      F.part = c->d_mpart;
+    }
     if (c->xkind) hipLaunchKernelGGL((k_fft_x8<0, 1, 1>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
                                      (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec, F);
     else hipLaunchKernelGGL((k_fft_x8<0, 0, 1>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
                             (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec, F);
+    if (F.mean_mask) if (int e = op_force_from_partials(c, F.mean_mask, F.part, (int)xblocks)) return e;
   } else { ProfScope ps(c, "fft_x_fwd");
     if (sp->x8 && c->xkind) hipLaunchKernelGGL((k_fft_x8<0, 1>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec);

@@ -232,6 +232,18 @@ static int forcing_component(cales_ctx *c, int comp) {   // cmpt_bulk_forcing, r
   return 0;
 }
 
+// the same from per-block partial sums made by another pass (k_fft_x8<0,KIND,1>): part[comp*nblk + b]
+int op_force_from_partials(cales_ctx *c, int mask, const double *part, int nblk) {
+  for (int comp = 0; comp < 3; ++comp) {
+    if (!(mask >> comp & 1)) continue;
+    hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, part + (size_t)comp * nblk, nblk, 0, c->res, 8 + comp);
+    if (int e = allreduce_res(c, 8 + comp, 1, 0)) return e;
+    hipLaunchKernelGGL(k_force_finish, dim3(1), dim3(64), 0, c->stream, c->res, 8 + comp, c->C.velf[comp], c->d_force, comp);
+  }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 __global__ void k_zero_force(double *force) { if (threadIdx.x < 3) force[threadIdx.x] = 0.; }
 
 int op_rk(cales_ctx *c, int irk, double dt) {
@@ -256,7 +268,7 @@ int op_rk(cales_ctx *c, int irk, double dt) {
   }
   for (int q = 0; q < 3; ++q) std::swap(f[CALES_DUDT + q], f[CALES_DUDTO + q]);     // swap, rk.f90:98-100
   hipLaunchKernelGGL(k_zero_force, dim3(1), dim3(64), 0, c->stream, c->d_force);
-  for (int q = 0; q < 3; ++q) if (c->C.is_forced[q]) if (int e = forcing_component(c, q)) return e;
+  for (int q = 0; q < 3; ++q) if (c->C.is_forced[q] && !(c->fuse_mean_mask >> q & 1)) if (int e = forcing_component(c, q)) return e;
   c->hf12 = .5 * f12;
   if (c->C.impdiff && !c->defer_imp_rhs) {
     ProfScope ps(c, "rk_imp_rhs");
