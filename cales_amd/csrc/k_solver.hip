@@ -644,9 +644,16 @@ __device__ inline double rcp_nr(double x) {
   r = fma(r, fma(-x, r, 1.), r);
   return fma(r, fma(-x, r, 1.), r);
 }
+// a,b,c of the 64 M rows (identity rows beyond nz, no coupling out of the first and the last row) as [which][r][chunk]: the
+// lanes of a wave (= chunks) read consecutive doubles
+__global__ void k_abc_chunked(int nz, int M, const double *__restrict__ a, const double *__restrict__ b, const double *__restrict__ c, double *__restrict__ t) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= 64 * M) return;
+  const int o = (k % M) * 64 + k / M;
+  t[o] = (k > 0 && k < nz) ? a[k] : 0.; t[64 * M + o] = k < nz ? b[k] : 1.; t[128 * M + o] = k < nz - 1 ? c[k] : 0.;
+}
 template <int M, int NV>
-__global__ __launch_bounds__(1024 / NV, (M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_gaussel_tile(Geom g, int nz, int ndbl, double lscale, const double *__restrict__ a,
-                                                            const double *__restrict__ b, const double *__restrict__ c,
+__global__ __launch_bounds__(1024 / NV, (M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_gaussel_tile(Geom g, int nz, int ndbl, double lscale, const double *__restrict__ abc,
                                                             const double *__restrict__ lamx, const double *__restrict__ lamy,
                                                             double *__restrict__ p, int fixnull) {
   extern __shared__ double shz[];
@@ -669,28 +676,28 @@ __global__ __launch_bounds__(1024 / NV, (M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_g
     const bool nullc = fixnull && lam == 0.;      // singular mode: the member with p(nz) = 0, see k_gaussel_ri
     double *col = shz + x * P + ch * CP;
     const int k0 = ch * M;
-    double cp[M - 1], V[M - 1], R[NV][M - 1];
+    double cp[M - 1], V[M - 1];      // the swept right-hand sides go back to their LDS slots (registers: no spills at 4 waves/SIMD)
     double cprev = 0., vprev = 0., rprev[NV] = {};
 #pragma unroll
     for (int r = 0; r < M - 1; ++r) {
       const int k = k0 + r;
-      const bool live = k < nz && !(nullc && k == nz - 1);
-      const double A = (live && k > 0) ? a[k] : 0., C = (live && k < nz - 1) ? c[k] : 0., B = live ? b[k] + lam : 1.;
+      const bool pin = nullc && k == nz - 1, live = k < nz && !pin;
+      const double A = pin ? 0. : abc[r * 64 + ch], C = pin ? 0. : abc[128 * M + r * 64 + ch], B = pin ? 1. : abc[64 * M + r * 64 + ch] + (k < nz ? lam : 0.);
       const double z = rcp_nr(B - A * cprev + CALES_EPS);
       cp[r] = C * z; V[r] = (r == 0 ? A : -A * vprev) * z;
 #pragma unroll
-      for (int q = 0; q < NV; ++q) { const double D = live ? col[q * P + r] : 0.; R[q][r] = (D - A * rprev[q]) * z; rprev[q] = R[q][r]; }
+      for (int q = 0; q < NV; ++q) { const double D = live ? col[q * P + r] : 0.; rprev[q] = (D - A * rprev[q]) * z; col[q * P + r] = rprev[q]; }
       cprev = cp[r]; vprev = V[r];
     }
     // first interior row of the chunk as a function of the separators beside it
     double Vb = V[M - 2], Wb = cp[M - 2], Rb[NV];
 #pragma unroll
-    for (int q = 0; q < NV; ++q) Rb[q] = R[q][M - 2];
+    for (int q = 0; q < NV; ++q) Rb[q] = rprev[q];
 #pragma unroll
     for (int r = M - 3; r >= 0; --r) {
       Vb = V[r] - cp[r] * Vb; Wb = -cp[r] * Wb;
 #pragma unroll
-      for (int q = 0; q < NV; ++q) Rb[q] = R[q][r] - cp[r] * Rb[q];
+      for (int q = 0; q < NV; ++q) Rb[q] = col[q * P + r] - cp[r] * Rb[q];
     }
     const bool last = ch == 63;
     // (cross-lane reads are issued by all lanes and masked afterwards: a lane switched off by a branch would be read as zero)
@@ -699,16 +706,16 @@ __global__ __launch_bounds__(1024 / NV, (M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_g
     // separator row
     double al, be, ga, de[NV];
     {
-      const int k = k0 + M - 1;
-      const bool live = k < nz && !(nullc && k == nz - 1);
-      const double A = (live && k > 0) ? a[k] : 0., C = (live && k < nz - 1) ? c[k] : 0., B = live ? b[k] + lam : 1.;
+      const int k = k0 + M - 1, r = M - 1;
+      const bool pin = nullc && k == nz - 1, live = k < nz && !pin;
+      const double A = pin ? 0. : abc[r * 64 + ch], C = pin ? 0. : abc[128 * M + r * 64 + ch], B = pin ? 1. : abc[64 * M + r * 64 + ch] + (k < nz ? lam : 0.);
       al = -A * V[M - 2]; be = B - A * cp[M - 2] - C * Vn; ga = -C * Wn;
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
         double Rn = __shfl_down(Rb[q], 1, 64);
         if (last) Rn = 0.;
         const double D = live ? col[q * P + M - 1] : 0.;
-        de[q] = D - A * R[q][M - 2] - C * Rn;
+        de[q] = D - A * rprev[q] - C * Rn;
       }
     }
     // parallel cyclic reduction over the 64 separators
@@ -730,10 +737,10 @@ __global__ __launch_bounds__(1024 / NV, (M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_g
       const double s = de[q] * rb;
       double sp = __shfl_up(s, 1, 64);
       if (ch == 0) sp = 0.;
-      double xv = R[q][M - 2] - V[M - 2] * sp - cp[M - 2] * s;
+      double xv = rprev[q] - V[M - 2] * sp - cp[M - 2] * s;
       col[q * P + M - 2] = xv;
 #pragma unroll
-      for (int r = M - 3; r >= 0; --r) { xv = R[q][r] - V[r] * sp - cp[r] * xv; col[q * P + r] = xv; }
+      for (int r = M - 3; r >= 0; --r) { xv = col[q * P + r] - V[r] * sp - cp[r] * xv; col[q * P + r] = xv; }
       col[q * P + M - 1] = s;
     }
   }
@@ -751,7 +758,9 @@ static void launch_gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, double
   constexpr int lds = 16 * (64 * (M + 1) + 4) * 8;
   static bool once = false;
   if (!once) { hipFuncSetAttribute((const void *)k_gaussel_tile<M, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
-  hipLaunchKernelGGL((k_gaussel_tile<M, NV>), dim3((ndbl + 15) / 16, nrow), dim3(1024 / NV), lds, c->stream, c->g, nz, ndbl, lscale, da, db, dc,
+  if (!c->d_abct) { if (hipMalloc(&c->d_abct, 3 * 64 * 16 * sizeof(double)) != hipSuccess) { c->d_abct = nullptr; return; } }
+  hipLaunchKernelGGL(k_abc_chunked, dim3((64 * M + 255) / 256), dim3(256), 0, c->stream, nz, M, da, db, dc, c->d_abct);
+  hipLaunchKernelGGL((k_gaussel_tile<M, NV>), dim3((ndbl + 15) / 16, nrow), dim3(1024 / NV), lds, c->stream, c->g, nz, ndbl, lscale, c->d_abct,
                      c->d_lamx, c->d_lamy, p, fixnull);
 }
 template <int NV>
