@@ -652,27 +652,40 @@ __global__ void k_abc_chunked(int nz, int M, const double *__restrict__ a, const
   const int o = (k % M) * 64 + k / M;
   t[o] = (k > 0 && k < nz) ? a[k] : 0.; t[64 * M + o] = k < nz ? b[k] : 1.; t[128 * M + o] = k < nz - 1 ? c[k] : 0.;
 }
+// Segments of columns (blockIdx.y): one rank -- row j of the in-place spectrum (ndbl doubles, plane stride s12); several ranks --
+// the block of peer blockIdx.y in the layout [peer][k][jl][m], whose (jl, m) planes are contiguous runs of 2 cw n2l doubles.
+struct TileMap { int blocked, cw, n2l, mofs, nmode; size_t kstride, segstride; };
 template <int M, int NV>
 __global__ __launch_bounds__(1024 / NV, (M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_gaussel_tile(Geom g, int nz, int ndbl, double lscale, const double *__restrict__ abc,
                                                             const double *__restrict__ lamx, const double *__restrict__ lamy,
-                                                            double *__restrict__ p, int fixnull) {
+                                                            double *__restrict__ p, int fixnull, TileMap T) {
   extern __shared__ double shz[];
   constexpr int CP = M + 1, P = 64 * CP + 4, NT = 1024 / NV, KP = NT / 16, NQ = 64 * M / KP;
-  const int t = threadIdx.x, j = blockIdx.y + 1;
-  const size_t base = g.ix(0, j, 1) + (size_t)16 * blockIdx.x;      // doubles from p (= element i = 1 of row (0,0))
+  const int t = threadIdx.x;
+  const size_t base = (T.blocked ? T.segstride * blockIdx.y : g.ix(0, blockIdx.y + 1, 1)) + (size_t)16 * blockIdx.x;      // doubles from p
+  const size_t kst = T.blocked ? T.kstride : (size_t)g.s12;
   {
     const int x = t & 15, kk = t >> 4;
     const bool ok = 16 * (int)blockIdx.x + x < ndbl;
     double v[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) { const int k = kk + KP * q; v[q] = (ok && k < nz) ? p[base + x + (size_t)k * g.s12] : 0.; }
+    for (int q = 0; q < NQ; ++q) { const int k = kk + KP * q; v[q] = (ok && k < nz) ? p[base + x + (size_t)k * kst] : 0.; }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { const int k = kk + KP * q; shz[x * P + k + k / M] = v[q]; }
   }
   __syncthreads();
   const int x = (t >> 6) * NV, ch = t & 63, d = 16 * (int)blockIdx.x + x;
-  if (d < ndbl) {
-    const double lam = ((NV == 1 ? lamx[d] : lamx[d >> 1]) + lamy[j - 1]) * lscale;
+  // column d of the segment -> x mode and global row
+  int mode = NV == 1 ? d : d >> 1, j = blockIdx.y + 1;
+  bool colok = d < ndbl;
+  if (T.blocked) {
+    const int f = d >> 1, mm = f % T.cw, jl = f / T.cw;
+    j = blockIdx.y * T.n2l + jl + 1;
+    mode = NV == 1 ? 2 * (mm + T.mofs) + (d & 1) : mm + T.mofs;
+    colok = colok && mm + T.mofs < T.nmode;      // padding modes of the last rank: skipped (their slots are never read)
+  }
+  if (colok) {
+    const double lam = (lamx[mode] + lamy[j - 1]) * lscale;
     const bool nullc = fixnull && lam == 0.;      // singular mode: the member with p(nz) = 0, see k_gaussel_ri
     double *col = shz + x * P + ch * CP;
     const int k0 = ch * M;
@@ -749,28 +762,29 @@ __global__ __launch_bounds__(1024 / NV, (M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_g
     const int x = t & 15, kk = t >> 4;
     const bool ok = 16 * (int)blockIdx.x + x < ndbl;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) { const int k = kk + KP * q; if (ok && k < nz) p[base + x + (size_t)k * g.s12] = shz[x * P + k + k / M]; }
+    for (int q = 0; q < NQ; ++q) { const int k = kk + KP * q; if (ok && k < nz) p[base + x + (size_t)k * kst] = shz[x * P + k + k / M]; }
   }
 }
 template <int M, int NV>
 static void launch_gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, double lscale, const double *da, const double *db, const double *dc,
-                                double *p, int fixnull) {
+                                double *p, int fixnull, const TileMap &T) {
   constexpr int lds = 16 * (64 * (M + 1) + 4) * 8;
   static bool once = false;
   if (!once) { hipFuncSetAttribute((const void *)k_gaussel_tile<M, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
   if (!c->d_abct) { if (hipMalloc(&c->d_abct, 3 * 64 * 16 * sizeof(double)) != hipSuccess) { c->d_abct = nullptr; return; } }
   hipLaunchKernelGGL(k_abc_chunked, dim3((64 * M + 255) / 256), dim3(256), 0, c->stream, nz, M, da, db, dc, c->d_abct);
   hipLaunchKernelGGL((k_gaussel_tile<M, NV>), dim3((ndbl + 15) / 16, nrow), dim3(1024 / NV), lds, c->stream, c->g, nz, ndbl, lscale, c->d_abct,
-                     c->d_lamx, c->d_lamy, p, fixnull);
+                     c->d_lamx, c->d_lamy, p, fixnull, T);
 }
+// one rank: ndbl doubles of each of the nrow rows; several ranks (T.blocked): nrow = peers, ndbl = 2 cw n2l doubles per plane of a peer block
 template <int NV>
 static bool gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, double lscale, const double *da, const double *db, const double *dc,
-                         double *p, int fixnull) {
+                         double *p, int fixnull, const TileMap &T) {
   if (nz < 2 || nz > 1024 || getenv("CALES_GAUSSEL_MARCH")) return false;
-  if (nz <= 128) launch_gaussel_tile<2, NV>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull);
-  else if (nz <= 256) launch_gaussel_tile<4, NV>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull);
-  else if (nz <= 512) launch_gaussel_tile<8, NV>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull);
-  else launch_gaussel_tile<16, NV>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull);
+  if (nz <= 128) launch_gaussel_tile<2, NV>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T);
+  else if (nz <= 256) launch_gaussel_tile<4, NV>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T);
+  else if (nz <= 512) launch_gaussel_tile<8, NV>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T);
+  else launch_gaussel_tile<16, NV>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T);
   return true;
 }
 
@@ -1026,9 +1040,13 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
     if (c->xkind && !c->ykind)       // real x modes paired into complex columns + periodic y: Hermitian separation of rows ky and N-ky
       hipLaunchKernelGGL(k_gaussel_herm, dim3((unsigned)(((long)4 * ncol * (n2g / 2 + 1) + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S,
                          da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, fixnull);
-    else if (!dist && !periodic_z && getenv("CALES_GAUSSEL_PAIR") == nullptr && (fixnull || !poisson || CBP(c, 0, 3) == 'D' || CBP(c, 1, 3) == 'D') &&
-             (c->xkind ? gaussel_tile<1>(c, nz, 2 * (c->C.ng[0] / 2), n2g, lscale, da, db, dc, (double *)mode_spec, fixnull)
-                       : gaussel_tile<2>(c, nz, 2 * mh, n2g, lscale, da, db, dc, (double *)mode_spec, fixnull))) {}
+    else if (!periodic_z && getenv("CALES_GAUSSEL_PAIR") == nullptr && (fixnull || !poisson || CBP(c, 0, 3) == 'D' || CBP(c, 1, 3) == 'D') &&
+             [&]() {
+               TileMap T{}; T.blocked = dist ? 1 : 0; T.cw = c->cw; T.n2l = n[1]; T.mofs = mofs; T.nmode = c->xkind ? c->C.ng[0] / 2 : mh;
+               T.kstride = (size_t)2 * c->cw * n[1]; T.segstride = T.kstride * n[2];
+               const int ndbl = dist ? 2 * c->cw * n[1] : (c->xkind ? 2 * (c->C.ng[0] / 2) : 2 * mh), nseg = dist ? c->P : n2g;
+               return c->xkind ? gaussel_tile<1>(c, nz, ndbl, nseg, lscale, da, db, dc, (double *)mode_spec, fixnull, T)
+                               : gaussel_tile<2>(c, nz, ndbl, nseg, lscale, da, db, dc, (double *)mode_spec, fixnull, T); }()) {}
     else if (c->xkind && !periodic_z && getenv("CALES_GAUSSEL_PAIR") == nullptr)
       hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, lscale, da, db, dc,
                          c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, fixnull, 1);
