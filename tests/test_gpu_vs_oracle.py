@@ -117,6 +117,41 @@ def test_projection_properties_at_size():
     h.close()
 
 
+def test_bench_config_properties_full_size():
+    """BASELINE.json's metric configuration itself (512^3 channel, dynamic Smagorinsky, bulk forcing; bench.py's case file):
+    after two steps the projected field is divergence-free to round-off, the bulk velocity is held, the eddy viscosity is
+    finite and non-negative; the Poisson solve satisfies L_h(solve(r)) = r on sampled planes."""
+    import bench
+    from cales_amd.hotpath import HotPath, initflow
+    case = bench.channel_case((512, 512, 512), "dsmag")
+    h = HotPath(case)
+    h.upload(*initflow(case)); h.startup()
+    dt = 0.5 * h.chkdt()
+    for _ in range(2):
+        h.step(dt)
+    divtot, divmax = h.chkdiv()
+    assert divmax < 1e-11 and np.isfinite(divtot)
+    assert abs(h.bulk_mean("u", "f") - 1.0) < 1e-12
+    visct = h.get("visct")[1:-1, 1:-1, 1:-1]
+    assert visct.min() >= 0. and np.isfinite(visct).all()
+    del visct
+    # discrete Laplacian of the solution == right-hand side (interior planes of a few y rows; x periodic, z Neumann handled by the ghost cells)
+    rng = np.random.RandomState(7)
+    rhs = np.zeros((514, 514, 514), order="F"); rhs[1:-1, 1:-1, 1:-1] = rng.rand(512, 512, 512) - 0.5
+    from oracle.oracle import Oracle
+    small = bench.channel_case((8, 8, 512), "dsmag"); dzf = Oracle(small).grid()["dzf"][1:-1]; dzc = Oracle(small).grid()["dzc"]
+    rhs[1:-1, 1:-1, 1:-1] -= (rhs[1:-1, 1:-1, 1:-1] * dzf).sum() / (dzf.sum() * 512 * 512)
+    h.set("pp", rhs); h.solver(); h.boundp("pp", 0)
+    p = h.get("pp")
+    dxi, dyi = 512 / case.l[0], 512 / case.l[1]
+    for j in (1, 200, 512):
+        c = p[1:-1, j, 1:-1]
+        lap = ((p[2:, j, 1:-1] - 2 * c + p[:-2, j, 1:-1]) * dxi ** 2 + (p[1:-1, j + 1, 1:-1] - 2 * c + p[1:-1, j - 1, 1:-1]) * dyi ** 2 +
+               ((p[1:-1, j, 2:] - c) / dzc[1:-1] - (c - p[1:-1, j, :-2]) / dzc[:-2]) / dzf)
+        assert np.abs(lap - rhs[1:-1, j, 1:-1]).max() < 1e-9 * np.abs(lap).max()
+    h.close()
+
+
 @pytest.mark.parametrize("bx", ["ND", "DN", "DD"])
 @pytest.mark.parametrize("ng", [(32, 16, 12), (20, 36, 10), (128, 64, 8), (52, 14, 8)])
 def test_poisson_solve_open_x(bx, ng):

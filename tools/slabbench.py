@@ -13,8 +13,14 @@ import numpy as np
 class SelfComm:
     def __init__(self, torch, A, B, P):
         self.t, self.A, self.B, self.P = torch, A, B, P
+        self.calls = {"halo": [0, 0], "alltoall": [0, 0], "allreduce": [0, 0]}      # calls, doubles sent
+
+    def reset(self):
+        for v in self.calls.values():
+            v[0] = v[1] = 0
 
     def halo(self, off_slo, off_shi, off_rlo, off_rhi, count):
+        self.calls["halo"][0] += 1; self.calls["halo"][1] += 2 * count
         self.B[off_rlo:off_rlo + count].copy_(self.A[off_shi:off_shi + count])
         self.B[off_rhi:off_rhi + count].copy_(self.A[off_slo:off_slo + count])
         return 0
@@ -22,10 +28,12 @@ class SelfComm:
     def alltoall(self, direction, count):
         src, dst = (self.A, self.B) if direction == 0 else (self.B, self.A)
         n = self.P * count
+        self.calls["alltoall"][0] += 1; self.calls["alltoall"][1] += (self.P - 1) * count
         dst[:n].copy_(src[:n])
         return 0
 
     def allreduce(self, off, count, op):
+        self.calls["allreduce"][0] += 1; self.calls["allreduce"][1] += count
         return 0
 
 
@@ -50,6 +58,7 @@ def main():
     for _ in range(a.steps):
         h.step(dt)
     h.sync(); t = (time.perf_counter() - t0) / a.steps
+    h.comm.reset()
     h.profile_reset(); h.profile(True)
     for _ in range(a.steps):
         h.step(dt)
@@ -58,6 +67,7 @@ def main():
     tot = sum(v[1] for k, v in st.items() if not k.startswith("cmpt_sgs")) / a.steps
     print(f"rank 0 of {a.ranks}, slab {h.n}: {1e3 * t:.3f} ms/step wall (local copies instead of exchanges), kernels {tot:.3f} ms/step")
     print("  " + "  ".join(f"{k}={v[1] / a.steps:.3f}" for k, v in sorted(st.items(), key=lambda kv: -kv[1][1])[:30]))
+    print("  exchanges per step: " + ", ".join(f"{k}: {v[0] / a.steps:.0f} calls, {8e-6 * v[1] / a.steps:.1f} MB out" for k, v in h.comm.calls.items()))
     h.close()
 
 
