@@ -51,6 +51,25 @@ def channel_case(ng, sgs):
     return case
 
 
+def _transpose_report(out, stats, case, world, a, solve):
+    if world <= 1 or not stats.get("alltoall", (0, 0))[0]:
+        return
+    # the y <-> x-mode re-slab of the Poisson solve (replaces the reference's 2decomp/cuDecomp pencil transposes, solver.f90:50-66):
+    # per call every rank sends (P-1) blocks of n3 * (n2/P) * ceil((n1/2+1)/P) complex modes; duration from HIP events on the
+    # context's stream around the exchange on rank 0 (with the library's own RCCL calls these bracket ncclAllToAll itself)
+    cw = -(-(int(case.ng[0]) // 2 + 1) // world)
+    blk = int(case.ng[2]) * (int(case.ng[1]) // world) * cw * 16.0
+    calls, ms = stats["alltoall"]
+    solve1 = {k: stats[k][1] / stats[k][0] for k in solve + ["fillps_fft_x_fwd"] if stats.get(k, (0, 0))[0]}
+    out["transpose"] = {"alltoall_calls_per_step": calls / a.steps, "alltoall_ms_per_call": ms / calls,
+                        "bytes_out_per_rank_per_call": (world - 1) * blk,
+                        "GBps_out_per_rank": (world - 1) * blk / (ms / calls * 1e-3) / 1e9,
+                        "GBps_per_link": blk / (ms / calls * 1e-3) / 1e9,
+                        "solve_kernels_ms_per_solve_rank0": sum(solve1.values()), "solve_alltoall_ms_per_solve": 2 * ms / calls,
+                        "note": "pencil-transpose scaling efficiency = t_solve(1 GPU) / (P * t_solve(P)), t_solve = solve kernels + 2 all-to-alls; "
+                                "the driver computes it from the per-N lines"}
+
+
 def cpu_baseline(case_full, seconds_budget=25.0):
     """Oracle (oracle/cales_oracle.c, OpenMP) timed on the host on a bounded sample: same physics, 128x128x64."""
     from oracle.oracle import Oracle
@@ -218,6 +237,10 @@ def main():
             "kernels_ms_per_step": {k: round(v[1] / a.steps, 4) for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])},
             "divmax": divmax,
         }
+        try:
+            _transpose_report(out, stats, case, world, a, solve)
+        except Exception as e:      # never lose the bench line over the extra report
+            out["transpose"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(case)
         print(json.dumps(out))
