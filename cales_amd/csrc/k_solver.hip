@@ -517,7 +517,10 @@ __global__ __launch_bounds__(256) void k_fft_y(Geom g, FftPlan P, int CB, int nc
   for (int q = threadIdx.x; q < CB * N; q += blockDim.x) {
     const int col = q % CB, j = q / CB;
     if (m0 + col < ncols) {
-      const double2 v = pc[S.at_mode(g, m0 + col, j + 1, k)];
+      double2 v = pc[S.at_mode(g, m0 + col, j + 1, k)];
+      // kind 2 (Dirichlet-Dirichlet, RODFT10/01): DST-II(x)_k = DCT-II((-1)^j x_j)_{N-1-k} -- the rows keep the reversed order (the y
+      // eigenvalues are stored reversed, solver_setup) and only the signs of the odd rows change, on the way in and on the way out
+      if (kind == 2 && !INV && (j & 1)) { v.x = -v.x; v.y = -v.y; }
       int dst = j;
       if (kind && !INV) dst = (j & 1) ? N - 1 - (j >> 1) : (j >> 1);
       base[(size_t)col * 2 * ld + ((kind && INV) ? ld : 0) + dst] = cpx{v.x, v.y};
@@ -545,6 +548,7 @@ __global__ __launch_bounds__(256) void k_fft_y(Geom g, FftPlan P, int CB, int nc
       if (!kind) v = Zc[j];
       else if (!INV) { const cpx w = twd[j]; v = cadd(cmul(w, Zc[j]), cmul(cconj(w), Zc[(N - j) % N])); }
       else v = Zc[(j & 1) ? N - 1 - (j >> 1) : (j >> 1)];
+      if (kind == 2 && INV && (j & 1)) { v.x = -v.x; v.y = -v.y; }
       pc[S.at_mode(g, m0 + c2, j + 1, k)] = make_double2(v.x, v.y);
     }
   }
@@ -901,7 +905,7 @@ int solver_setup(cales_ctx *c) {
   auto kind_of = [](const std::string &b) { return b == "PP" ? 0 : b == "NN" ? 1 : b == "DD" ? 2 : b == "ND" ? 3 : b == "DN" ? 4 : -1; };
   c->xkind = kind_of(bx); c->ykind = kind_of(by);
   if (c->xkind < 0 || c->ykind < 0) { c->err = "solver: unknown pressure BC pair in x or y"; return 1; }
-  if (c->ykind > 1) { c->err = "solver: in y the pressure BC pairs PP and NN are provided (DD, ND, DN only in x)"; return 1; }
+  if (c->ykind > 2) { c->err = "solver: in y the pressure BC pairs PP, NN and DD are provided (ND, DN only in x)"; return 1; }
   if (c->xkind && c->C.cbcpre[4] == 'P') { c->err = "solver: a non-periodic x with periodic z is not provided"; return 1; }
   SolverPlans sp;
   if (!make_plan(n1 / 2, sp.px) || !make_plan(n2g, sp.py)) { c->err = "solver: ng(1)/2 and ng(2) must factor into 2,3,5,7,11,13"; return 1; }
@@ -921,12 +925,14 @@ int solver_setup(cales_ctx *c) {
   if (sp.y8) { const int T = n2g / 8; int CB = std::max(1, std::min(std::max(8, 256 / T), 512 / T));
                while (CB > 1 && ((size_t)CB * (n2g + n2g / 8 + 1) + n2g) * sizeof(cpx) > 64 * 1024) CB /= 2;
                sp.y8_threads = CB * T; sp.shy8 = ((size_t)CB * (n2g + n2g / 8 + 1) + n2g) * sizeof(cpx); }
+  if (c->ykind == 2) sp.y8 = false;      // the sign changes of the Dirichlet-Dirichlet transform live in the generic y kernel only
   if (getenv("CALES_FFT_GENERIC")) sp.x8 = sp.y8 = false;
   // eigenvalues (initsolver.f90:66-98); x: modes 0..n1/2 (half-complex symmetry), y: modes 0..n2-1
   std::vector<double> lx(n1 + 2, 0.), ly(n2g);
   hs_eigenvalues(n1, bx.c_str(), 'c', lx.data()); hs_eigenvalues(n2g, by.c_str(), 'c', ly.data());
   for (auto &v : lx) v = v * (c->dli[0] * c->dli[0]);
   for (auto &v : ly) v = v * (c->dli[1] * c->dli[1]);
+  if (c->ykind == 2) std::reverse(ly.begin(), ly.end());      // row r of the transformed field holds coefficient N-1-r (see k_fft_y)
   const int mh = n1 / 2 + 1;
   c->cw = (mh + c->P - 1) / c->P;                            // complex mode columns per rank (last block padded)
   if (c->P > 1 && (size_t)c->cw * n2g * n3 > c->ntot) { c->err = "solver: scratch too small for the mode-block layout"; return 1; }
