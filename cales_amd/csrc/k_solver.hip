@@ -906,7 +906,7 @@ int solver_setup(cales_ctx *c) {
   c->xkind = kind_of(bx); c->ykind = kind_of(by);
   if (c->xkind < 0 || c->ykind < 0) { c->err = "solver: unknown pressure BC pair in x or y"; return 1; }
   if (c->ykind > 2) { c->err = "solver: in y the pressure BC pairs PP, NN and DD are provided (ND, DN only in x)"; return 1; }
-  if (c->xkind && c->C.cbcpre[4] == 'P') { c->err = "solver: a non-periodic x with periodic z is not provided"; return 1; }
+  if (c->xkind && c->C.cbcpre[4] == 'P' && (!c->ykind || c->P > 1)) { c->err = "solver: a non-periodic x with periodic z needs a non-periodic y and one rank"; return 1; }
   SolverPlans sp;
   if (!make_plan(n1 / 2, sp.px) || !make_plan(n2g, sp.py)) { c->err = "solver: ng(1)/2 and ng(2) must factor into 2,3,5,7,11,13"; return 1; }
   // rows per block in x: aim at ~nh/4 threads per row, 256 threads per block
@@ -1056,6 +1056,9 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
     else if (c->xkind && !periodic_z && getenv("CALES_GAUSSEL_PAIR") == nullptr)
       hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, lscale, da, db, dc,
                          c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, fixnull, 1);
+    else if (periodic_z && c->xkind)      // real x modes (one eigenvalue each) with the periodic-z closure: scalar columns of the in-place spectrum, one rank
+      hipLaunchKernelGGL((k_gaussel<double, 1>), dim3((2 * (c->C.ng[0] / 2) + 63) / 64, (n2g + 3) / 4), b, 0, c->stream, c->g, nz, 2 * (c->C.ng[0] / 2), n2g, 1, 0, 2 * (c->C.ng[0] / 2), S, lscale,
+                         da, db, dc, c->d_lamx, c->d_lamy, pp, c->scr1, c->scr2, fixnull);
     else if (c->xkind) hipLaunchKernelGGL(k_gaussel_split, gr, b, 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, da, db, dc, c->d_lamx, c->d_lamy,
                                      (double2 *)mode_spec, (double2 *)c->scr1, fixnull);
     else if (periodic_z) hipLaunchKernelGGL((k_gaussel<double2, 1>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2, fixnull);

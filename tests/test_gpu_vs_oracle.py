@@ -265,3 +265,31 @@ def test_poisson_solve_open_y(bx, ng):
         assert relerr(x, y) < 1e-9, nm
     assert relerr(gp[1:-1, 1:-1, 1:-1], p[1:-1, 1:-1, 1:-1]) < 1e-8
     h.close()
+
+
+@pytest.mark.parametrize("bxy", [("NN", "NN"), ("DD", "NN"), ("ND", "DD"), ("NN", "DD")])
+@pytest.mark.parametrize("ng", [(32, 16, 12), (20, 36, 10), (28, 22, 16)])
+def test_poisson_solve_walls_xy_periodic_z(bxy, ng):
+    """A duct along z: non-periodic x and y with PERIODIC z (cyclic tridiagonal closure, solver.f90:124-133, on the real x modes)."""
+    g, case = load_golden("cavity_nnn")
+    case.ng[:] = ng
+    for d, pair in ((0, bxy[0]), (1, bxy[1])):
+        for side in (0, 1):
+            case.cbcpre[side, d] = pair[side]
+            case.cbcvel[side, d, :] = "N" if pair[side] == "D" else "D"
+            case.bcvel[side, d, :] = 0.
+    case.cbcpre[:, 2] = "P"; case.cbcvel[:, 2, :] = "P"; case.cbcsgs[:, 2] = "P"; case.bcvel[:, 2, :] = 0.
+    case.gtype = 1; case.gr = 0.                                       # periodic z: uniform grid
+    o = Oracle(case, nthreads=8); h = _hot(case)
+    rng = np.random.RandomState(sum(ng))
+    rhs = o.zeros(); rhs[1:-1, 1:-1, 1:-1] = rng.rand(*ng) - 0.5
+    singular = bxy == ("NN", "NN")
+    if singular:
+        rhs[1:-1, 1:-1, 1:-1] -= rhs[1:-1, 1:-1, 1:-1].mean()
+    ref = rhs.copy(order="F"); o.solver(ref)
+    h.set("pp", rhs); h.solver()
+    a = h.get("pp")[1:-1, 1:-1, 1:-1]; b = ref[1:-1, 1:-1, 1:-1]
+    if singular:
+        a = a - a.mean(); b = b - b.mean()
+    assert np.abs(a - b).max() < 1e-11 * np.abs(b).max() + (1e-14 * abs(ref[1:-1, 1:-1, 1:-1].mean()) if singular else 0.), (bxy, ng)
+    h.close()
