@@ -107,6 +107,7 @@ struct cales_ctx {
   double *d_del = nullptr;   // Smagorinsky filter width per plane (fast path)
   void *native_comm = nullptr;   // RCCL communicator + staging buffers when the library does the exchanges itself (comm_rccl.cpp)
   bool visct_zero = true;  // CALES_VISCT still holds the zeros it was created / reset with (no SGS model: lets kernels skip it)
+  double *d_stat = nullptr;      // partial sums and result of the plane statistics
   double *d_abct = nullptr;      // tridiagonal coefficients in the chunked order of k_gaussel_tile
   int fuse_mean_mask = 0; double *d_mpart = nullptr; size_t n_mpart = 0;      // bulk means of the forced components are summed by that pass too
   double fuse_fillps_dti = 0.;   // != 0: the forward x transform of the next pressure solve forms pp = div(u*)/dtrk itself (cales_step)
@@ -166,6 +167,7 @@ int op_helmholtz_z(cales_ctx *c, int ivel, double alpha);
 extern "C" void cales_comm_release_native(cales_ctx *c);
 int op_helmholtz(cales_ctx *c, int ivel, double alpha);
 int op_correc(cales_ctx *c, double dtrk);
+int op_stats_chan(cales_ctx *c, double *buf);
 bool solver_can_fuse_fillps(cales_ctx *c);
 int op_force_from_partials(cales_ctx *c, int mask, const double *part, int nblk);
 int op_correc_updatep(cales_ctx *c, double dtrk, double alpha, int upd);

@@ -452,6 +452,76 @@ int op_chkdiv(cales_ctx *c, double *divtot, double *divmax) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------ plane statistics (output.f90:509-700)
+// First block of out1d_single_point_chan (idir = 3): 27 sums per z plane -- velocity moments up to the fourth, <uw> at the cell
+// edge, pressure, vorticity and its squares, the modelled stresses, <visct>, <du/dz> -- times dx dy/(lx ly). One block row per
+// plane, partial sums in a fixed order (deterministic); the divisions by the spacings are kept as the reference writes them.
+#define NSTAT 27
+__global__ __launch_bounds__(256) void k_stats_chan_partial(Geom g, double dx, double dy, const double *__restrict__ dzc, const double *__restrict__ dzf,
+                                                            const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ w,
+                                                            const double *__restrict__ p, const double *__restrict__ s, double *__restrict__ part) {
+  __shared__ double sh[4];
+  const int k = blockIdx.y + 1;
+  double b[NSTAT];
+#pragma unroll
+  for (int q = 0; q < NSTAT; ++q) b[q] = 0.;
+  const long nplane = (long)g.n1 * g.n2, sj = g.s1, sk = g.s12;
+  const double zc = dzc[k], zfp = dzf[k + 1], zf = dzf[k];
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nplane; q += (long)gridDim.x * 256) {
+    const int i = (int)(q % g.n1) + 1, j = (int)(q / g.n1) + 1;
+    const size_t c = g.ix(i, j, k);
+    const double uc = u[c], vc = v[c], wc = w[c], pc = p[c];
+    const double u_kp = u[c + sk], u_ip = u[c + 1], u_im = u[c - 1], u_jp = u[c + sj];
+    const double v_kp = v[c + sk], v_ip = v[c + 1], v_jp = v[c + sj], v_jm = v[c - sj];
+    const double w_ip = w[c + 1], w_jp = w[c + sj], w_kp = w[c + sk], w_km = w[c - sk];
+    b[0] += uc; b[1] += vc; b[2] += wc;
+    b[3] += uc * uc; b[4] += vc * vc; b[5] += wc * wc;
+    b[6] += 0.25 * (u_kp + uc) * (wc + w_ip);
+    b[7] += uc * uc * uc; b[8] += vc * vc * vc; b[9] += wc * wc * wc;
+    b[10] += (uc * uc) * (uc * uc); b[11] += (vc * vc) * (vc * vc); b[12] += (wc * wc) * (wc * wc);
+    b[13] += pc; b[14] += pc * pc;
+    const double ox = (w_jp - wc) / dy - (v_kp - vc) / zc, oy = (u_kp - uc) / zc - (w_ip - wc) / dx, oz = (v_ip - vc) / dx - (u_jp - uc) / dy;
+    b[15] += ox; b[16] += oy; b[17] += oz; b[18] += ox * ox; b[19] += oy * oy; b[20] += oz * oz;
+    const double s_ccc = s[c], s_pcc = s[c + 1], s_cpc = s[c + sj], s_ccp = s[c + sk], s_pcp = s[c + 1 + sk];
+    const double dudx_ip = (u_ip - uc) / dx, dudx_im = (uc - u_im) / dx, dvdy_jp = (v_jp - vc) / dy, dvdy_jm = (vc - v_jm) / dy;
+    const double dwdz_kp = (w_kp - wc) / zfp, dwdz_km = (wc - w_km) / zf, dudz = (u_kp - uc) / zc, dwdx = (w_ip - wc) / dx;
+    b[21] -= 0.5 * (s_pcc * (dudx_ip + dudx_ip) + s_ccc * (dudx_im + dudx_im));
+    b[22] -= 0.5 * (s_cpc * (dvdy_jp + dvdy_jp) + s_ccc * (dvdy_jm + dvdy_jm));
+    b[23] -= 0.5 * (s_ccp * (dwdz_kp + dwdz_kp) + s_ccc * (dwdz_km + dwdz_km));
+    b[24] -= 0.25 * (s_ccc + s_pcc + s_ccp + s_pcp) * (dudz + dwdx);
+    b[25] += s_ccc;
+    b[26] += dudz;
+  }
+#pragma unroll
+  for (int q = 0; q < NSTAT; ++q) {
+    const double r = block_reduce<0>(b[q], sh);
+    if (threadIdx.x == 0) part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NSTAT + q] = r;
+  }
+}
+__global__ void k_stats_fold(int n3, int nbx, double ratio, const double *__restrict__ part, double *__restrict__ out) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= NSTAT * n3) return;
+  const int q = t % NSTAT, k = t / NSTAT;
+  double a = 0.;
+  for (int bx = 0; bx < nbx; ++bx) a += part[((size_t)k * nbx + bx) * NSTAT + q];
+  out[t] = a * ratio;
+}
+// buf: (27, n3) column-major on the host; with several ranks the sums of THIS rank's rows (the caller adds the ranks, output.f90:691)
+int op_stats_chan(cales_ctx *c, double *buf) {
+  const int nbx = 8, n3 = c->n[2];
+  const size_t need = (size_t)NSTAT * n3 * (nbx + 1);
+  if (!c->d_stat) HIPCHK(c, hipMalloc(&c->d_stat, need * sizeof(double)));
+  double *part = c->d_stat, *out = c->d_stat + (size_t)NSTAT * n3 * nbx;
+  hipLaunchKernelGGL(k_stats_chan_partial, dim3(nbx, n3), dim3(256), 0, c->stream, c->g, c->dl[0], c->dl[1], c->d_dzc, c->d_dzf, c->f[CALES_U], c->f[CALES_V],
+                     c->f[CALES_W], c->f[CALES_P], c->f[CALES_VISCT], part);
+  const double ratio = c->dl[0] * c->dl[1] / (c->C.l[0] * c->C.l[1]);
+  hipLaunchKernelGGL(k_stats_fold, dim3((NSTAT * n3 + 255) / 256), dim3(256), 0, c->stream, n3, nbx, ratio, part, out);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(buf, out, (size_t)NSTAT * n3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------ chkdt (chkdt.f90:50-98)
 template <int IMP>
 __global__ __launch_bounds__(256) void k_chkdt_partial(Geom g, double dxi, double dyi, double visc, const double *__restrict__ dzci,

@@ -180,6 +180,7 @@ program cales
       end if
     end if
     write(fldnum,'(i7.7)') istep
+    if(iout1d > 0.and.mod(istep,max(iout1d,1)) == 0) call out1d_chan_stats('velstats_fld_'//fldnum)     ! main.f90:575-579, out1d.h90
     if((isave > 0.and.mod(istep,max(isave,1)) == 0).or.(is_done.and..not.kill)) then     ! main.f90:590-611
       if(is_overwrite_save) then
         filename = 'fld.bin'
@@ -219,6 +220,19 @@ contains
     print*, '    check `input.nml`.'
     error stop
   end subroutine abortit
+  subroutine out1d_chan_stats(fname)    ! the velstats_fld_*.out/.bin pair of out1d_single_point_chan, src/output.f90:683-699
+    character(len=*), intent(in) :: fname
+    real(rp), allocatable :: buf(:,:)
+    integer :: iu,kk,q
+    allocate(buf(27,ng(3)))
+    call chk(cales_out1d_single_point_chan(ctx,buf))
+    open(newunit=iu,file=fname//'.out')
+    do kk=1,ng(3)
+      write(iu,'(*(es24.16e3,1x))') zc(kk),zf(kk),(buf(q,kk),q=1,27),dzc(kk),dzf(kk)
+    end do
+    close(iu)
+    open(newunit=iu,file=fname//'.bin',access='stream'); write(iu) buf; close(iu)
+  end subroutine out1d_chan_stats
   subroutine out0d(fname,n,vv)    ! src/output.f90:18-37
     character(len=*), intent(in) :: fname
     integer, intent(in) :: n

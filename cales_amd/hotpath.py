@@ -178,6 +178,12 @@ class HotPath:
         self._chk(self.L.cales_chkdiv(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def stats_chan(self) -> np.ndarray:
+        """First block of out1d_single_point_chan (src/output.f90:509-700): 27 plane statistics per z plane, shape (27, n3)."""
+        buf = np.zeros((27, self.n[2]), order="F")
+        self._chk(self.L.cales_out1d_single_point_chan(self.h, _p(buf)))
+        return buf
+
     def step(self, dt: float):
         """Three RK substeps, src/main.f90:417-508, queued without host synchronisation."""
         self._chk(self.L.cales_step(self.h, float(dt)))

@@ -87,6 +87,11 @@ int cales_updatep(cales_ctx *ctx, double alpha);                            /* s
 int cales_cmpt_sgs(cales_ctx *ctx);                                         /* src/sgs.f90:21     */
 int cales_chkdt(cales_ctx *ctx, double *dtmax);                             /* src/chkdt.f90:17 (sync) */
 int cales_chkdiv(cales_ctx *ctx, double *divtot, double *divmax);           /* src/chkdiv.f90:16 (sync) */
+/* plane statistics of the channel: first block of out1d_single_point_chan (src/output.f90:509-700, idir = 3), the 27 columns of
+ * velstats_fld_*.out/.bin between the coordinates and the spacings; buf(27, n3) column-major on the host (sync). With several
+ * ranks: the sums over this rank's rows -- the caller adds the ranks as the reference does (output.f90:691). */
+#define CALES_NSTATS_CHAN 27
+int cales_out1d_single_point_chan(cales_ctx *ctx, double *buf);
 
 /* one time step = 3 RK substeps in the order of src/main.f90:417-508; no host synchronisation */
 int cales_step(cales_ctx *ctx, double dt);

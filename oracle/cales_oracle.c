@@ -949,6 +949,42 @@ void o_chkdiv(ostate *s, const double *u, const double *v, const double *w, doub
   *divtot = dt_; *divmax = dm;
 }
 
+/* ------------------------------------------------------------------ plane statistics: first block of out1d_single_point_chan
+   (output.f90:509-700, idir = 3): 27 sums per z plane times dx dy/(lx ly); buf is (27, n3) in Fortran order.
+   TEST INFRASTRUCTURE; parity unpinned (output.f90 needs 2decomp-fft and cannot be built here). */
+void o_stats_chan(ostate *s, const double *u, const double *v, const double *w, const double *p, const double *visct, double *buf) {
+  const int *n = s->n; const size_t s1 = s->s1, s2 = s->s2;
+  const double dx = s->dl[0], dy = s->dl[1], ratio = dx*dy/(s->P.l[0]*s->P.l[1]);
+  for (int k = 1; k <= n[2]; k++) {
+    double b[27]; for (int q = 0; q < 27; q++) b[q] = 0.;
+    for (int j = 1; j <= n[1]; j++) for (int i = 1; i <= n[0]; i++) {
+      const double uc = u[IX(i,j,k)], vc = v[IX(i,j,k)], wc = w[IX(i,j,k)], pc = p[IX(i,j,k)];
+      b[0] += uc; b[1] += vc; b[2] += wc;
+      b[3] += uc*uc; b[4] += vc*vc; b[5] += wc*wc;
+      b[6] += 0.25*(u[IX(i,j,k+1)] + uc)*(wc + w[IX(i+1,j,k)]);
+      b[7] += uc*uc*uc; b[8] += vc*vc*vc; b[9] += wc*wc*wc;
+      b[10] += (uc*uc)*(uc*uc); b[11] += (vc*vc)*(vc*vc); b[12] += (wc*wc)*(wc*wc);
+      b[13] += pc; b[14] += pc*pc;
+      const double ox = (w[IX(i,j+1,k)] - wc)/dy - (v[IX(i,j,k+1)] - vc)/s->dzc[k];
+      const double oy = (u[IX(i,j,k+1)] - uc)/s->dzc[k] - (w[IX(i+1,j,k)] - wc)/dx;
+      const double oz = (v[IX(i+1,j,k)] - vc)/dx - (u[IX(i,j+1,k)] - uc)/dy;
+      b[15] += ox; b[16] += oy; b[17] += oz; b[18] += ox*ox; b[19] += oy*oy; b[20] += oz*oz;
+      const double s_ccc = visct[IX(i,j,k)], s_pcc = visct[IX(i+1,j,k)], s_cpc = visct[IX(i,j+1,k)], s_ccp = visct[IX(i,j,k+1)], s_pcp = visct[IX(i+1,j,k+1)];
+      const double dudx_ip = (u[IX(i+1,j,k)] - uc)/dx, dudx_im = (uc - u[IX(i-1,j,k)])/dx;
+      const double dvdy_jp = (v[IX(i,j+1,k)] - vc)/dy, dvdy_jm = (vc - v[IX(i,j-1,k)])/dy;
+      const double dwdz_kp = (w[IX(i,j,k+1)] - wc)/s->dzf[k+1], dwdz_km = (wc - w[IX(i,j,k-1)])/s->dzf[k];
+      const double dudz = (u[IX(i,j,k+1)] - uc)/s->dzc[k], dwdx = (w[IX(i+1,j,k)] - wc)/dx;
+      b[21] -= 0.5*(s_pcc*(dudx_ip + dudx_ip) + s_ccc*(dudx_im + dudx_im));
+      b[22] -= 0.5*(s_cpc*(dvdy_jp + dvdy_jp) + s_ccc*(dvdy_jm + dvdy_jm));
+      b[23] -= 0.5*(s_ccp*(dwdz_kp + dwdz_kp) + s_ccc*(dwdz_km + dwdz_km));
+      b[24] -= 0.25*(s_ccc + s_pcc + s_ccp + s_pcp)*(dudz + dwdx);
+      b[25] += s_ccc;
+      b[26] += dudz;
+    }
+    for (int q = 0; q < 27; q++) buf[q + 27*(size_t)(k-1)] = b[q]*ratio;
+  }
+}
+
 /* ------------------------------------------------------------------ SGS: src/sgs.f90 */
 static void extrapolate(ostate *s, double *p, int iface, int use_cbc) {   /* sgs.f90:682-767 */
   const int *n = s->n; const size_t s1 = s->s1, s2 = s->s2; int done[6]; double factor0, factor1;

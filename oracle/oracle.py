@@ -192,6 +192,12 @@ class Oracle:
         self.lib.o_chkdiv(self.h, _p(u), _p(v), _p(w), C.byref(a), C.byref(b))
         return a.value, b.value
 
+    def stats_chan(self, u, v, w, p, visct) -> np.ndarray:
+        """first block of out1d_single_point_chan (output.f90:509-700): (27, n3) plane statistics"""
+        buf = np.zeros((27, self.n[2]), order="F")
+        self.lib.o_stats_chan(self.h, _p(u), _p(v), _p(w), _p(p), _p(visct), _p(buf))
+        return buf
+
     def step(self, dt, u, v, w, p, pp, visct):
         dpdl = np.zeros(3)
         self.lib.o_step(self.h, C.c_double(dt), _p(u), _p(v), _p(w), _p(p), _p(pp), _p(visct), _p(dpdl))

@@ -47,7 +47,7 @@ def _read_fld(path, ng):
 def test_fortran_host_equals_python_host(tmp_path, name):
     from cales_amd.hotpath import HotPath, initflow
     from cales_amd.nml import parse_text
-    text = _nml(name, nstep=4, icheck=2, iout0d=2, isave=100000)
+    text = _nml(name, nstep=4, icheck=2, iout0d=2, iout1d=4, isave=100000)
     text = re.sub(r"stop_type\(1:3\) = .*", "stop_type(1:3) = T, F, F", text)
     imp = int(load_golden(name)[1].impdiff)           # the reference's build switches are a run-time argument of the host
     out = _run(str(tmp_path), text, args=(str(imp),) if imp else ())
@@ -76,6 +76,11 @@ def test_fortran_host_equals_python_host(tmp_path, name):
     grid = np.fromfile(os.path.join(tmp_path, "grid.bin"))
     g, _ = load_golden(name)
     assert np.allclose(grid[:ng[2]], g["g_dzc"][1:-1], rtol=1e-15)
+    # plane statistics written at iout1d (out1d.h90 -> out1d_single_point_chan): zc, zf, 27 columns, dzc, dzf per plane + raw .bin
+    st = h.stats_chan()
+    txt = np.loadtxt(os.path.join(tmp_path, "velstats_fld_0000004.out"))
+    assert txt.shape == (ng[2], 31) and np.array_equal(txt[:, 2:29], st.T)
+    assert np.array_equal(np.fromfile(os.path.join(tmp_path, "velstats_fld_0000004.bin")).reshape((27, ng[2]), order="F"), st)
     h.close()
 
 

@@ -293,3 +293,29 @@ def test_poisson_solve_walls_xy_periodic_z(bxy, ng):
         a = a - a.mean(); b = b - b.mean()
     assert np.abs(a - b).max() < 1e-11 * np.abs(b).max() + (1e-14 * abs(ref[1:-1, 1:-1, 1:-1].mean()) if singular else 0.), (bxy, ng)
     h.close()
+
+
+@pytest.mark.parametrize("name,ng", [("chan_dsmag", (32, 16, 12)), ("chan_smag_wm", (40, 18, 20)), ("cavity_nnn", (20, 36, 10)), ("tgv_ppp", (24, 20, 18))])
+def test_plane_statistics(name, ng):
+    """cales_out1d_single_point_chan (27 plane sums of output.f90:509-700) against the oracle's restatement after two steps."""
+    from cales_amd.hotpath import initflow
+    g, case = load_golden(name)
+    case.ng[:] = ng
+    if case.inivel == "hcp":
+        case.inivel = "poi"
+    o = Oracle(case, nthreads=8); h = _hot(case)
+    u, v, w, p = initflow(case)
+    rng = np.random.RandomState(3)
+    for a in (u, v, w):
+        a[1:-1, 1:-1, 1:-1] += 0.05 * (rng.rand(*ng) - 0.5)
+    h.upload(u, v, w, p); h.startup()
+    dt = 0.5 * h.chkdt()
+    for _ in range(2):
+        h.step(dt)
+    gu, gv, gw, gp, gvis = h.download()
+    ref = o.stats_chan(*(F(a) for a in (gu, gv, gw, gp, gvis)))
+    got = h.stats_chan()
+    # sums of signed terms: relative to the largest plane value of the statistic, plus the round-off of plane sums that cancel to ~0
+    tol = 1e-12 * np.abs(ref).max(axis=1, keepdims=True) + 1e-13
+    assert (np.abs(got - ref) <= tol).all(), np.argwhere(np.abs(got - ref) > tol)[:5]
+    h.close()

@@ -81,3 +81,22 @@ def test_helmholtz_3d_identity(ivel):
     lz[:, :, :-1] += c[None, None, :nz - 1] * x[:, :, 1:]
     back = x + alpha * (lap + lz)
     assert np.abs(back - rhs[1:-1, 1:-1, 1:nz + 1]).max() < 1e-12
+
+
+def test_plane_statistics_known_answers():
+    """o_stats_chan (first block of out1d_single_point_chan, output.f90:509-700) on fields with known plane averages:
+    u = a + b z gives <u> = a + b zc, <u^2>, <du/dz> = b, spanwise vorticity b; visct = const with that shear gives the modelled <uw>."""
+    g, case = load_golden("chan_dsmag")
+    o = Oracle(case)
+    gr = o.grid(); zc = gr["zc"]
+    a, b, nu = 0.7, 1.3, 0.25
+    u = o.zeros(); v = o.zeros(); w = o.zeros(); p = o.zeros(); vis = o.zeros()
+    u[:, :, :] = (a + b * zc)[None, None, :]; p[:] = -2.; vis[:] = nu
+    st = o.stats_chan(u, v, w, p, vis)
+    k = np.arange(1, o.n[2] + 1)
+    assert np.allclose(st[0], a + b * zc[k], rtol=1e-13) and np.allclose(st[3], (a + b * zc[k]) ** 2, rtol=1e-13)
+    assert np.allclose(st[13], -2.) and np.allclose(st[14], 4.) and np.allclose(st[25], nu)
+    assert np.allclose(st[26], b, rtol=1e-12) and np.allclose(st[16], b, rtol=1e-12) and np.allclose(st[19], b * b, rtol=1e-12)
+    assert np.allclose(st[24], -nu * b, rtol=1e-12)                       # -visct (du/dz + dw/dx) at the cell edge
+    for q in (1, 2, 4, 5, 6, 15, 17, 21, 22, 23):
+        assert np.abs(st[q]).max() < 1e-13
