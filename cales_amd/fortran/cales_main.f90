@@ -181,6 +181,19 @@ program cales
     end if
     write(fldnum,'(i7.7)') istep
     if(iout1d > 0.and.mod(istep,max(iout1d,1)) == 0) call out1d_chan_stats('velstats_fld_'//fldnum)     ! main.f90:575-579, out1d.h90
+    if((iout2d > 0.and.mod(istep,max(iout2d,1)) == 0).or.(iout3d > 0.and.mod(istep,max(iout3d,1)) == 0)) then     ! main.f90:580-589
+      call chk(cales_download_state(ctx,u,v,w,p,visct))
+      if(iout2d > 0.and.mod(istep,max(iout2d,1)) == 0) then     ! out2d.h90: the plane j = ng(2)/2 of the five fields
+        call visu_2d('vex_slice_fld_'//fldnum//'.bin','Velocity_X',u); call visu_2d('vey_slice_fld_'//fldnum//'.bin','Velocity_Y',v)
+        call visu_2d('vez_slice_fld_'//fldnum//'.bin','Velocity_Z',w); call visu_2d('pre_slice_fld_'//fldnum//'.bin','Pressure_P',p)
+        call visu_2d('visct_slice_fld_'//fldnum//'.bin','Viscosity',visct)
+      end if
+      if(iout3d > 0.and.mod(istep,max(iout3d,1)) == 0) then     ! out3d.h90: the five fields without halos
+        call visu_3d('vex_fld_'//fldnum//'.bin','Velocity_X',u); call visu_3d('vey_fld_'//fldnum//'.bin','Velocity_Y',v)
+        call visu_3d('vez_fld_'//fldnum//'.bin','Velocity_Z',w); call visu_3d('pre_fld_'//fldnum//'.bin','Pressure',p)
+        call visu_3d('visct_fld_'//fldnum//'.bin','Viscosity',visct)
+      end if
+    end if
     if((isave > 0.and.mod(istep,max(isave,1)) == 0).or.(is_done.and..not.kill)) then     ! main.f90:590-611
       if(is_overwrite_save) then
         filename = 'fld.bin'
@@ -220,6 +233,29 @@ contains
     print*, '    check `input.nml`.'
     error stop
   end subroutine abortit
+  subroutine visu_log(flog,fbin,varname,nmin,nmax)    ! write_log_output, src/output.f90:244-272
+    character(len=*), intent(in) :: flog,fbin,varname
+    integer, intent(in) :: nmin(3),nmax(3)
+    integer :: iu
+    open(newunit=iu,file=flog,position='append')
+    write(iu,'(A30,A15,9I5,E16.7E3,I7)') fbin,varname,nmin,nmax,[1,1,1],time,istep
+    close(iu)
+  end subroutine visu_log
+  subroutine visu_2d(fbin,varname,q)    ! write_visu_2d with inorm = 2, islice = ng(2)/2, src/output.f90:289-315
+    character(len=*), intent(in) :: fbin,varname
+    real(rp), intent(in) :: q(0:,0:,0:)
+    integer :: iu,js
+    js = ng(2)/2
+    open(newunit=iu,file=fbin,access='stream',status='replace'); write(iu) q(1:ng(1),js,1:ng(3)); close(iu)
+    call visu_log('log_visu_2d_slice_1.out',fbin,varname,[1,js,1],[ng(1),js,ng(3)])
+  end subroutine visu_2d
+  subroutine visu_3d(fbin,varname,q)    ! write_visu_3d with nskip = 1, src/output.f90:274-287
+    character(len=*), intent(in) :: fbin,varname
+    real(rp), intent(in) :: q(0:,0:,0:)
+    integer :: iu
+    open(newunit=iu,file=fbin,access='stream',status='replace'); write(iu) q(1:ng(1),1:ng(2),1:ng(3)); close(iu)
+    call visu_log('log_visu_3d.out',fbin,varname,[1,1,1],ng)
+  end subroutine visu_3d
   subroutine out1d_chan_stats(fname)    ! the velstats_fld_*.out/.bin pair of out1d_single_point_chan, src/output.f90:683-699
     character(len=*), intent(in) :: fname
     real(rp), allocatable :: buf(:,:)

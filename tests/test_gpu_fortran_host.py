@@ -47,7 +47,7 @@ def _read_fld(path, ng):
 def test_fortran_host_equals_python_host(tmp_path, name):
     from cales_amd.hotpath import HotPath, initflow
     from cales_amd.nml import parse_text
-    text = _nml(name, nstep=4, icheck=2, iout0d=2, iout1d=4, isave=100000)
+    text = _nml(name, nstep=4, icheck=2, iout0d=2, iout1d=4, iout2d=4, iout3d=4, isave=100000)
     text = re.sub(r"stop_type\(1:3\) = .*", "stop_type(1:3) = T, F, F", text)
     imp = int(load_golden(name)[1].impdiff)           # the reference's build switches are a run-time argument of the host
     out = _run(str(tmp_path), text, args=(str(imp),) if imp else ())
@@ -81,6 +81,13 @@ def test_fortran_host_equals_python_host(tmp_path, name):
     txt = np.loadtxt(os.path.join(tmp_path, "velstats_fld_0000004.out"))
     assert txt.shape == (ng[2], 31) and np.array_equal(txt[:, 2:29], st.T)
     assert np.array_equal(np.fromfile(os.path.join(tmp_path, "velstats_fld_0000004.bin")).reshape((27, ng[2]), order="F"), st)
+    # plane and volume dumps (out2d.h90 / out3d.h90 defaults) with their log lines (output.f90:244-272)
+    sl = np.fromfile(os.path.join(tmp_path, "vex_slice_fld_0000004.bin")).reshape((ng[0], ng[2]), order="F")
+    assert np.array_equal(sl, gu[1:-1, ng[1] // 2, 1:-1])
+    vol = np.fromfile(os.path.join(tmp_path, "pre_fld_0000004.bin")).reshape(ng, order="F")
+    assert np.array_equal(vol, gp[1:-1, 1:-1, 1:-1])
+    logl = open(os.path.join(tmp_path, "log_visu_3d.out")).read().splitlines()
+    assert len(logl) == 5 and logl[0].split()[:2] == ["vex_fld_0000004.bin", "Velocity_X"] and int(logl[0].split()[-1]) == 4
     h.close()
 
 
