@@ -923,8 +923,13 @@ int solver_setup(cales_ctx *c) {
   if (sp.x8) { const int T = (n1 / 2) / 8; sp.x8_threads = T >= 256 ? T : (256 / T) * T;
                sp.shx8 = ((size_t)(sp.x8_threads / T) * (n1 / 2 + n1 / 16 + 2) + (n1 + 1) + (c->xkind ? n1 / 2 + 1 : 0)) * sizeof(cpx); }
   if (sp.y8) { const int T = n2g / 8; int CB = std::max(1, std::min(std::max(8, 256 / T), 512 / T));
-               while (CB > 1 && ((size_t)CB * (n2g + n2g / 8 + 1) + n2g) * sizeof(cpx) > 64 * 1024) CB /= 2;
-               sp.y8_threads = CB * T; sp.shy8 = ((size_t)CB * (n2g + n2g / 8 + 1) + n2g) * sizeof(cpx); }
+               while (CB > 1 && ((size_t)CB * (n2g + n2g / 8 + 1) + n2g) * sizeof(cpx) > 150 * 1024) CB /= 2;
+               sp.y8_threads = CB * T; sp.shy8 = ((size_t)CB * (n2g + n2g / 8 + 1) + n2g) * sizeof(cpx);
+               if (sp.shy8 > 64 * 1024) {      // n2 = 1024: 4 columns (64-B row segments) need 90 KB of LDS
+                 hipFuncSetAttribute((const void *)k_fft_y8<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8);
+                 hipFuncSetAttribute((const void *)k_fft_y8<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8);
+                 hipFuncSetAttribute((const void *)k_fft_y8<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8);
+                 hipFuncSetAttribute((const void *)k_fft_y8<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8); } }
   if (c->ykind == 2) sp.y8 = false;      // the sign changes of the Dirichlet-Dirichlet transform live in the generic y kernel only
   if (getenv("CALES_FFT_GENERIC")) sp.x8 = sp.y8 = false;
   // eigenvalues (initsolver.f90:66-98); x: modes 0..n1/2 (half-complex symmetry), y: modes 0..n2-1
