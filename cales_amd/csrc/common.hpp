@@ -108,6 +108,7 @@ struct cales_ctx {
   void *native_comm = nullptr;   // RCCL communicator + staging buffers when the library does the exchanges itself (comm_rccl.cpp)
   bool visct_zero = true;  // CALES_VISCT still holds the zeros it was created / reset with (no SGS model: lets kernels skip it)
   double *d_stat = nullptr;      // partial sums and result of the plane statistics
+  bool abct_ready = false, force_zeroed = false;
   double *d_abct = nullptr;      // tridiagonal coefficients in the chunked order of k_gaussel_tile
   int fuse_mean_mask = 0; double *d_mpart = nullptr; size_t n_mpart = 0;      // bulk means of the forced components are summed by that pass too
   double fuse_fillps_dti = 0.;   // != 0: the forward x transform of the next pressure solve forms pp = div(u*)/dtrk itself (cales_step)

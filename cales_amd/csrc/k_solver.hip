@@ -775,9 +775,13 @@ static void launch_gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, double
   constexpr int lds = 16 * (64 * (M + 1) + 4) * 8;
   static bool once = false;
   if (!once) { hipFuncSetAttribute((const void *)k_gaussel_tile<M, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
-  if (!c->d_abct) { if (hipMalloc(&c->d_abct, 3 * 64 * 16 * sizeof(double)) != hipSuccess) { c->d_abct = nullptr; return; } }
-  hipLaunchKernelGGL(k_abc_chunked, dim3((64 * M + 255) / 256), dim3(256), 0, c->stream, nz, M, da, db, dc, c->d_abct);
-  hipLaunchKernelGGL((k_gaussel_tile<M, NV>), dim3((ndbl + 15) / 16, nrow), dim3(1024 / NV), lds, c->stream, c->g, nz, ndbl, lscale, c->d_abct,
+  if (!c->d_abct) { if (hipMalloc(&c->d_abct, 2 * 3 * 64 * 16 * sizeof(double)) != hipSuccess) { c->d_abct = nullptr; return; } }
+  // the pressure operands never change: their table is built once (Helmholtz operands are rescaled every substep -> second table)
+  const bool pressure = da == c->d_a;
+  double *tab = c->d_abct + (pressure ? 0 : 3 * 64 * 16);
+  if (!pressure || !c->abct_ready) hipLaunchKernelGGL(k_abc_chunked, dim3((64 * M + 255) / 256), dim3(256), 0, c->stream, nz, M, da, db, dc, tab);
+  if (pressure) c->abct_ready = true;
+  hipLaunchKernelGGL((k_gaussel_tile<M, NV>), dim3((ndbl + 15) / 16, nrow), dim3(1024 / NV), lds, c->stream, c->g, nz, ndbl, lscale, tab,
                      c->d_lamx, c->d_lamy, p, fixnull, T);
 }
 // one rank: ndbl doubles of each of the nrow rows; several ranks (T.blocked): nrow = peers, ndbl = 2 cw n2l doubles per plane of a peer block

@@ -196,6 +196,14 @@ __global__ __launch_bounds__(256) void k_fold(const double *__restrict__ part, i
   const double r = op ? block_reduce<1>(acc, sh) : block_reduce<0>(acc, sh);
   if (threadIdx.x == 0) out[slot] = r;
 }
+// fold of the partial sums + f = velf - mean in one launch (one rank: no all-reduce between the two)
+__global__ __launch_bounds__(256) void k_fold_force(const double *__restrict__ part, int np, double velf, double *__restrict__ res, int slot, double *__restrict__ force, int comp) {
+  __shared__ double sh[4];
+  double acc = 0.;
+  for (int q = threadIdx.x; q < np; q += 256) acc += part[q];
+  const double r = block_reduce<0>(acc, sh);
+  if (threadIdx.x == 0) { res[slot] = r; const double f = velf - r; force[comp] = f; force[3 + comp] += f; }
+}
 // f = velf - mean (rk.f90:209-221), dpdl += f (main.f90:492)
 __global__ void k_force_finish(const double *__restrict__ res, int slot, double velf, double *__restrict__ force, int comp) {
   if (threadIdx.x == 0) { const double f = velf - res[slot]; force[comp] = f; force[3 + comp] += f; }
@@ -225,9 +233,12 @@ static int forcing_component(cales_ctx *c, int comp) {   // cmpt_bulk_forcing, r
   dim3 gr(nbx, c->n[2]);
   const double *p = c->f[CALES_U + comp];
   hipLaunchKernelGGL(k_bulk_mean_partial, gr, dim3(256), 0, c->stream, c->g, p, comp == 2 ? c->d_gvr_c : c->d_gvr_f, c->d_red + 64);
-  hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, nbx * c->n[2], 0, c->res, 8 + comp);
-  if (int e = allreduce_res(c, 8 + comp, 1, 0)) return e;
-  hipLaunchKernelGGL(k_force_finish, dim3(1), dim3(64), 0, c->stream, c->res, 8 + comp, c->C.velf[comp], c->d_force, comp);
+  if (c->P == 1) hipLaunchKernelGGL(k_fold_force, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, nbx * c->n[2], c->C.velf[comp], c->res, 8 + comp, c->d_force, comp);
+  else {
+    hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, nbx * c->n[2], 0, c->res, 8 + comp);
+    if (int e = allreduce_res(c, 8 + comp, 1, 0)) return e;
+    hipLaunchKernelGGL(k_force_finish, dim3(1), dim3(64), 0, c->stream, c->res, 8 + comp, c->C.velf[comp], c->d_force, comp);
+  }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -236,6 +247,7 @@ static int forcing_component(cales_ctx *c, int comp) {   // cmpt_bulk_forcing, r
 int op_force_from_partials(cales_ctx *c, int mask, const double *part, int nblk) {
   for (int comp = 0; comp < 3; ++comp) {
     if (!(mask >> comp & 1)) continue;
+    if (c->P == 1) { hipLaunchKernelGGL(k_fold_force, dim3(1), dim3(256), 0, c->stream, part + (size_t)comp * nblk, nblk, c->C.velf[comp], c->res, 8 + comp, c->d_force, comp); continue; }
     hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, part + (size_t)comp * nblk, nblk, 0, c->res, 8 + comp);
     if (int e = allreduce_res(c, 8 + comp, 1, 0)) return e;
     hipLaunchKernelGGL(k_force_finish, dim3(1), dim3(64), 0, c->stream, c->res, 8 + comp, c->C.velf[comp], c->d_force, comp);
@@ -267,7 +279,8 @@ int op_rk(cales_ctx *c, int irk, double dt) {
                          f[CALES_DUDTO], f[CALES_DVDTO], f[CALES_DWDTO], (double *)nullptr, (double *)nullptr, (double *)nullptr);
   }
   for (int q = 0; q < 3; ++q) std::swap(f[CALES_DUDT + q], f[CALES_DUDTO + q]);     // swap, rk.f90:98-100
-  hipLaunchKernelGGL(k_zero_force, dim3(1), dim3(64), 0, c->stream, c->d_force);
+  if (!(c->C.is_forced[0] && c->C.is_forced[1] && c->C.is_forced[2]) && !c->force_zeroed) {      // unforced components stay zero for good
+    hipLaunchKernelGGL(k_zero_force, dim3(1), dim3(64), 0, c->stream, c->d_force); c->force_zeroed = true; }
   for (int q = 0; q < 3; ++q) if (c->C.is_forced[q] && !(c->fuse_mean_mask >> q & 1)) if (int e = forcing_component(c, q)) return e;
   c->hf12 = .5 * f12;
   if (c->C.impdiff && !c->defer_imp_rhs) {
