@@ -658,7 +658,10 @@ __global__ void k_abc_chunked(int nz, int M, const double *__restrict__ a, const
 }
 // Segments of columns (blockIdx.y): one rank -- row j of the in-place spectrum (ndbl doubles, plane stride s12); several ranks --
 // the block of peer blockIdx.y in the layout [peer][k][jl][m], whose (jl, m) planes are contiguous runs of 2 cw n2l doubles.
-struct TileMap { int blocked, cw, n2l, mofs, nmode; size_t kstride, segstride; };
+struct TileMap { int blocked, cw, n2l, mofs, nmode; size_t kstride, segstride;
+                 // z-only Helmholtz sweeps of real fields (no eigenvalue shift): nolam; cales_step forms the r.h.s. of rk.f90:108-118 and
+                 // main.f90:422-433 while loading, (u - hf12*dudtd) + f + rhs_b, and plane nz+1 (wall face of w) receives the first two terms
+                 int nolam, nq, has_lo, has_hi; const double *dud, *force, *rb; double hf12; };
 template <int M, int NV>
 __global__ __launch_bounds__(1024 / NV, (M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_gaussel_tile(Geom g, int nz, int ndbl, double lscale, const double *__restrict__ abc,
                                                             const double *__restrict__ lamx, const double *__restrict__ lamy,
@@ -674,6 +677,21 @@ __global__ __launch_bounds__(1024 / NV, (M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_g
     double v[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { const int k = kk + KP * q; v[q] = (ok && k < nz) ? p[base + x + (size_t)k * kst] : 0.; }
+    if (T.dud) {
+      const double f = T.force ? T.force[0] : 0.;
+      const size_t pq = (size_t)(16 * blockIdx.x + x) + (size_t)g.n1 * blockIdx.y;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int k = kk + KP * q;
+        if (ok && k < T.nq) {
+          double t = (k < nz ? v[q] : p[base + x + (size_t)k * kst]) - T.hf12 * T.dud[base + x + (size_t)k * kst];
+          if (T.force) t = t + f;
+          if (k == 0 && T.has_lo) t = t + T.rb[pq];
+          if (k == nz - 1 && T.has_hi) t = t + T.rb[pq + (size_t)g.n1 * g.n2];
+          if (k < nz) v[q] = t; else p[base + x + (size_t)k * kst] = t;
+        }
+      }
+    }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { const int k = kk + KP * q; shz[x * P + k + k / M] = v[q]; }
   }
@@ -689,7 +707,7 @@ __global__ __launch_bounds__(1024 / NV, (M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_g
     colok = colok && mm + T.mofs < T.nmode;      // padding modes of the last rank: skipped (their slots are never read)
   }
   if (colok) {
-    const double lam = (lamx[mode] + lamy[j - 1]) * lscale;
+    const double lam = T.nolam ? 0. : (lamx[mode] + lamy[j - 1]) * lscale;
     const bool nullc = fixnull && lam == 0.;      // singular mode: the member with p(nz) = 0, see k_gaussel_ri
     double *col = shz + x * P + ch * CP;
     const int k0 = ch * M;
@@ -1166,6 +1184,12 @@ int op_helmholtz_z(cales_ctx *c, int ivel, double alpha) {
   Spec S; S.blocked = 0; S.cw = 0; S.n2l = n[1]; S.n3 = n3;
   if (periodic) hipLaunchKernelGGL((k_gaussel<double, 1>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, 1., abc, abc + n3, abc + 2 * n3, (const double *)nullptr, (const double *)nullptr, fld, c->scr1, c->scr2, 0);
   else if (getenv("CALES_HELMHOLTZ_Z_PER_COLUMN")) hipLaunchKernelGGL((k_gaussel<double, 0>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, 1., abc, abc + n3, abc + 2 * n3, (const double *)nullptr, (const double *)nullptr, fld, c->scr1, c->scr2, 0);
+  else if (c->P >= 1 && n3 - q >= 2 && n3 - q <= 512 && n3 <= 64 * (n3 - q <= 128 ? 2 : n3 - q <= 256 ? 4 : 8) && getenv("CALES_GAUSSEL_MARCH") == nullptr && [&]() {
+             // the in-LDS tile of the pressure solve on the real field: u, dudtd in, u out (3 words instead of 5)
+             TileMap T{}; T.nolam = 1; T.nq = n3;
+             if (fused) { T.dud = c->f[CALES_DUDTD + ivel - 1] + 1; T.hf12 = c->hf12; T.force = c->C.is_forced[ivel - 1] ? c->d_force + (ivel - 1) : nullptr;
+                          T.rb = c->scr2; T.has_lo = has[0]; T.has_hi = has[1]; }
+             return gaussel_tile<2>(c, n3 - q, n[0], n[1], 1., abc, abc + n3, abc + 2 * n3, fld + 1, 0, T); }()) {}
   else {
     double *zz = abc + 3 * n3, *dd = abc + 4 * n3;       // behind the scaled coefficients (cales_create reserves 6 (n3+2) doubles)
     hipLaunchKernelGGL(k_thomas_coef, dim3(1), dim3(64), 0, c->stream, n3 - q, abc, abc + n3, abc + 2 * n3, zz, dd);
