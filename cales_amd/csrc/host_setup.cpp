@@ -147,11 +147,17 @@ int hs_initflow(const cales_case *cs, const char *inivel_, int is_wallturb, doub
     is_mean = true;
   } else if (inivel == "zer") {
   } else if (inivel == "uni") { for (int k = 1; k <= n3; ++k) u1d[k] = uref;
-  } else if (inivel == "pdc") {
-    const double lref = l[2] / 2.;
+  } else if (inivel == "hcp") {      // half channel: the lower half of the Poiseuille profile of a channel of height 2 lz (initflow.f90:93-102)
+    for (int k = 1; k <= n3; ++k) { const double z = zc[k] / (2 * l[2]); u1d[k] = 6. * z * (1. - z) * ubulk; }
+    is_mean = true;
+  } else if (inivel == "pdc" || inivel == "hdc") {      // pressure-driven (half) channel, initflow.f90:157-180
+    double lref = l[2] / 2.;
+    if (inivel != "pdc") lref = 2. * lref;
     if (is_wallturb) { uref = std::pow(cs->bforce[0] * lref, 0.5); const double retau = uref * lref / visc, reb = std::pow(retau / .09, 1. / .88); ubulk = reb * visc / (2 * lref); }
     else ubulk = cs->bforce[0] * (lref * lref) / (3. * visc);
-    poiseuille(ubulk); is_mean = true;
+    if (inivel == "pdc") poiseuille(ubulk);
+    else for (int k = 1; k <= n3; ++k) { const double z = zc[k] / (2 * l[2]); u1d[k] = 6. * z * (1. - z) * ubulk; }
+    is_mean = true;
   } else if (inivel == "tgv") { is3d = true;
     for (int k = 1; k <= n3; ++k) { const double zcc = zc[k] / l[2] * 2. * pi;
       for (int jl = 1; jl <= n2; ++jl) { const int j = jl + jlo; const double yc = (j - .5) * dl[1] / l[1] * 2. * pi, yf = (j - .0) * dl[1] / l[1] * 2. * pi;

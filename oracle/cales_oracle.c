@@ -1162,10 +1162,15 @@ int o_initflow(ostate *s, const char *inivel, int is_wallturb, double *u, double
     for (int k = 1; k <= n3; k++) { double z = zc[k]/l[2]; u1d[k] = 6.*z*(1. - z)*ubulk; u1d[k] = u1d[k] - ubulk; } is_mean = 1;
   } else if (!strcmp(inivel, "zer")) { for (int k = 1; k <= n3; k++) u1d[k] = 0.;
   } else if (!strcmp(inivel, "uni")) { for (int k = 1; k <= n3; k++) u1d[k] = uref;
-  } else if (!strcmp(inivel, "pdc")) { double lref = l[2]/2.;
+  } else if (!strcmp(inivel, "hcp")) {      /* initflow.f90:93-102 */
+    for (int k = 1; k <= n3; k++) { double z = zc[k]/(2*l[2]); u1d[k] = 6.*z*(1. - z)*ubulk; } is_mean = 1;
+  } else if (!strcmp(inivel, "pdc") || !strcmp(inivel, "hdc")) { double lref = l[2]/2.;      /* initflow.f90:157-180 */
+    if (strcmp(inivel, "pdc")) lref = 2.*lref;
     if (is_wallturb) { uref = pow(bforce[0]*lref, (double)0.5f); double retau = uref*lref/visc, reb = pow(retau/.09, 1./.88); ubulk = reb*visc/(2*lref); }
     else ubulk = (bforce[0]*(lref*lref)/(3.*visc));
-    for (int k = 1; k <= n3; k++) { double z = zc[k]/l[2]; u1d[k] = 6.*z*(1. - z)*ubulk; } is_mean = 1;
+    if (!strcmp(inivel, "pdc")) for (int k = 1; k <= n3; k++) { double z = zc[k]/l[2]; u1d[k] = 6.*z*(1. - z)*ubulk; }
+    else for (int k = 1; k <= n3; k++) { double z = zc[k]/(2*l[2]); u1d[k] = 6.*z*(1. - z)*ubulk; }
+    is_mean = 1;
   } else if (!strcmp(inivel, "tgv")) { is3d = 1;
     for (int k = 1; k <= n[2]; k++) { double zcc = zc[k]/l[2]*2.*pi;
       for (int j = 1; j <= n[1]; j++) { double yc = (j - .5)*dl[1]/l[1]*2.*pi, yf = (j - .0)*dl[1]/l[1]*2.*pi;

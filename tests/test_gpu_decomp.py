@@ -40,8 +40,6 @@ def _single(case, nsteps):
 def test_slab_ranks_match_single_rank(name, ng, P):
     from cales_amd.decomp import run_loopback
     case = _case(name, ng)
-    if case.inivel == "hcp":
-        case.inivel = "poi"
     nsteps = 2
     u, v, w, p, visct, dt, div, dpdl = _single(case, nsteps)
 

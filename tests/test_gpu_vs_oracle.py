@@ -72,8 +72,6 @@ def test_time_steps(name, ng, nsteps):
     from cales_amd.hotpath import initflow
     g, case = load_golden(name)
     case.ng[:] = ng
-    if case.inivel == "hcp":
-        case.inivel = "poi"
     o = Oracle(case, nthreads=8); h = _hot(case)
     u, v, w, p = initflow(case)
     rng = np.random.RandomState(1)
@@ -301,8 +299,6 @@ def test_plane_statistics(name, ng):
     from cales_amd.hotpath import initflow
     g, case = load_golden(name)
     case.ng[:] = ng
-    if case.inivel == "hcp":
-        case.inivel = "poi"
     o = Oracle(case, nthreads=8); h = _hot(case)
     u, v, w, p = initflow(case)
     rng = np.random.RandomState(3)

@@ -52,13 +52,42 @@ def test_initgrid_matches_reference():
         q += 1
 
 
-@pytest.mark.parametrize("name", [c for c in FULL_CASES if c != "halfchan_imp1d"])
+@pytest.mark.parametrize("name", FULL_CASES)
 def test_initflow_matches_reference(name):
     from cales_amd.hotpath import initflow
     g, case = load_golden(name)
     for a, k in zip(initflow(case), "uvwp"):
         ref = g["if_" + k]
         assert np.abs(a - ref).max() <= 2e-15 * max(1., np.abs(ref).max()), k
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libcales_ref.so")),
+                    reason="oracle/_ref (the compiled reference) is only present in the build container")
+@pytest.mark.parametrize("inivel,wallturb", [("hdc", "F"), ("hdc", "T"), ("pdc", "T"), ("hcp", "F")])
+def test_pressure_driven_profiles_match_compiled_reference(inivel, wallturb, tmp_path):
+    """initial fields without a committed golden, against the reference's own initflow (oracle/_ref) where it is built;
+    one case per process: the reference reads input.nml from the working directory"""
+    import re
+    import subprocess
+    import sys
+    from cales_amd.hotpath import initflow
+    from cales_amd.nml import parse_text
+    g, _ = load_golden("halfchan_imp1d")
+    text = str(g["input_nml"])
+    text = re.sub(r"inivel = .*", f"inivel = '{inivel}'", text)
+    text = re.sub(r"is_wallturb = .*", f"is_wallturb = {wallturb}", text)
+    text = re.sub(r"bforce\(1:3\) = .*", "bforce(1:3) = 0.7, 0., 0.", text)
+    text = re.sub(r"is_forced\(1:3\) = .*", "is_forced(1:3) = F, F, F", text)
+    open(tmp_path / "input.nml", "w").write(text)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from oracle.ref.refpy import Ref; "
+            "u, v, w, p = Ref(0).initflow(); np.savez('out.npz', u=u, v=v, w=w, p=p)" % root)
+    subprocess.run([sys.executable, "-c", code], cwd=tmp_path, check=True, timeout=300)
+    ref = np.load(tmp_path / "out.npz")
+    case = parse_text(text)
+    for a, k in zip(initflow(case), "uvwp"):
+        assert np.abs(a - ref[k]).max() <= 2e-15 * max(1., np.abs(ref[k]).max()), k
+    assert np.abs(ref["u"]).max() > 0.
 
 
 def test_rng_initial_fields_are_refused():

@@ -51,9 +51,7 @@ def test_grids():
 def test_initflow(name):
     g, case = load_golden(name)
     o = Oracle(case)
-    u, v, w, p = o.initflow(case.inivel, case.is_wallturb) if case.inivel != "hcp" else (None,) * 4
-    if u is None:
-        pytest.skip("hcp not restated")
+    u, v, w, p = o.initflow(case.inivel, case.is_wallturb)
     for a, k in zip((u, v, w, p), "uvwp"):
         ref = g["if_" + k]
         assert np.abs(a - ref).max() <= 2e-15 * max(1., np.abs(ref).max()), k
