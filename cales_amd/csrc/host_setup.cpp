@@ -4,6 +4,7 @@
 //
 // Fortran default-real (single precision) literals of the reference are reproduced where they
 // change the value: the golden vectors in tests/golden come from the reference itself.
+#include <cstdint>
 #include "common.hpp"
 
 static const double kPi = std::acos(-1.0);
@@ -132,7 +133,7 @@ int hs_initflow(const cales_case *cs, const char *inivel_, int is_wallturb, doub
   std::vector<double> dzc(n3 + 2), dzf(n3 + 2), zc(n3 + 2), zf(n3 + 2);
   hs_initgrid(cs->gtype, n3, cs->gr, l[2], dzc.data(), dzf.data(), zc.data(), zf.data());
   auto bcvel = [&](int side, int dir, int vel) { return cs->bcvel[side + 2 * (dir - 1) + 6 * (vel - 1)]; };
-  double uref = 1., ubulk = uref; bool is_mean = false, is3d = false, is2d = false;
+  double uref = 1., ubulk = uref; bool is_mean = false, is3d = false, is2d = false, is_noise = false;
   if (cs->is_forced[0]) ubulk = cs->velf[0];
   std::vector<double> u1d(n3 + 2, 0.), u2d;        // u2d(jg,k): x-independent duct profile for ALL global rows
   auto poiseuille = [&](double norm) { for (int k = 1; k <= n3; ++k) { const double z = zc[k] / l[2]; u1d[k] = 6. * z * (1. - z) * norm; } };
@@ -190,17 +191,44 @@ int hs_initflow(const cales_case *cs, const char *inivel_, int is_wallturb, doub
       const double tp = 2. / pi;
       u2d[j + (size_t)(n2g + 2) * k] = .5 * (lz * lz) * (1. - eta * eta - 4. * (tp * tp * tp) * sum_term);
     }
+  } else if (inivel == "log" || inivel == "hcl") {      // log-law profile of a (half) channel + noise (initflow.f90:76-91,392-406)
+    const double lz = inivel == "log" ? l[2] : 2 * l[2], reb = ubulk * lz / visc;
+    const double retau = (double)0.09f * std::pow(reb, (double)0.88f);      // default-real literals of the reference
+    for (int k = 1; k <= n3; ++k) {
+      double z = zc[k] / lz * 2. * retau;
+      if (z >= retau) z = 2. * retau - z;
+      u1d[k] = 2.5 * std::log(z) + 5.5;
+      if (z <= (double)11.6f) u1d[k] = z;
+    }
+    is_noise = true; is_mean = true;
+  } else if (inivel == "tbl") {      // temporal boundary layer of thickness 1 (initflow.f90:60-62,374-390) + noise
+    const double theta = 54. * visc / uref;
+    for (int k = 1; k <= n3; ++k) u1d[k] = (0.5 + 0.5 * std::tanh((1. / (2. * theta)) * (1. - zc[k] / 1.))) * uref;
+    is_noise = true;
   } else {
-    return (inivel == "log" || inivel == "hcl" || inivel == "tbl") ? 2 : 1;   // RNG-based kinds are not offered
+    return 1;
   }
+  // add_noise (initflow.f90:285-315): +-5 % of uniform noise per component, one draw per GLOBAL cell so that the field does not depend
+  // on the decomposition. The reference draws from the Fortran run-time's random_number (different for every compiler); here a
+  // counter-based generator (splitmix64 of seed and global cell index) -- same distribution, not the same numbers.
+  auto noise = [&](uint64_t seed, int i, int jg, int k) {
+    uint64_t z = seed * 0x9E3779B97F4A7C15ULL + (((uint64_t)(k - 1) * n2g + (uint64_t)(jg - 1)) * n1 + (uint64_t)(i - 1));
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL; z ^= z >> 27; z *= 0x94D049BB133111EBULL; z ^= z >> 31;
+    const double rn = (double)(z >> 11) * (1. / 9007199254740992.);
+    return 2. * (rn - .5) * (double)0.05f;
+  };
   auto prof = [&](int jg, int k) { return is2d ? u2d[jg + (size_t)(n2g + 2) * k] : u1d[k]; };
   if (!is3d) for (int k = 1; k <= n3; ++k) for (int jl = 1; jl <= n2; ++jl) {
     const double val = prof(jl + jlo, k);
     for (int i = (is2d ? 0 : 1); i <= (is2d ? n1 + 1 : n1); ++i) { const size_t q = IX(i, jl, k); u[q] = val; v[q] = 0.; w[q] = 0.; p[q] = 0.; } }
+  if (is_noise) for (int k = 1; k <= n3; ++k) for (int jl = 1; jl <= n2; ++jl) for (int i = 1; i <= n1; ++i) {
+    const size_t q = IX(i, jl, k); u[q] += noise(123, i, jl + jlo, k); v[q] += noise(456, i, jl + jlo, k); w[q] += noise(789, i, jl + jlo, k); }
   if (is_mean && inivel != "iop") {   // set_mean over the global domain, same summation order as one rank
     double meanold = 0.;
     for (int k = 1; k <= n3; ++k) { const double gvr = dzf[k] / l[2] * (dl[0] / l[0]) * (dl[1] / l[1]);
-      for (int j = 1; j <= n2g; ++j) { const double t = prof(j, k) * gvr; for (int i = 1; i <= n1; ++i) meanold = meanold + t; } }
+      for (int j = 1; j <= n2g; ++j) { const double t = prof(j, k) * gvr;
+        if (is_noise) for (int i = 1; i <= n1; ++i) meanold = meanold + (prof(j, k) + noise(123, i, j, k)) * gvr;
+        else for (int i = 1; i <= n1; ++i) meanold = meanold + t; } }
     if (meanold != 0.) for (int k = 1; k <= n3; ++k) for (int jl = 1; jl <= n2; ++jl) for (int i = 1; i <= n1; ++i)
       u[IX(i, jl, k)] = u[IX(i, jl, k)] / meanold * ubulk;
   }

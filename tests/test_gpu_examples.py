@@ -26,8 +26,6 @@ def test_example_case_runs(name):
     from cales_amd.hotpath import HotPath, initflow
     case = parse_text(EXAMPLES[name])
     case.ng[:] = [_shrink(int(x)) for x in case.ng]
-    if case.inivel in ("log", "hcl", "tbl"):            # RNG-based initial fields (add_noise, compiler-specific) are not offered
-        case.inivel = "poi"
     if case.sgstype == "none" and case.cbcvel[0, 0, 0] != "P":
         case.cbcsgs[:, 0] = "D"                         # the two developing_* examples ship an entry sanity.f90:191-203 rejects
     if np.any(case.lwm != 0):

@@ -10,6 +10,7 @@ import pytest
 
 from cales_amd import capi
 from cales_amd.nml import NamelistError, parse_text
+from oracle.oracle import Oracle
 from tests.util import FULL_CASES, GOLD, load_golden, relerr
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -90,15 +91,41 @@ def test_pressure_driven_profiles_match_compiled_reference(inivel, wallturb, tmp
     assert np.abs(ref["u"]).max() > 0.
 
 
-def test_rng_initial_fields_are_refused():
+def test_unknown_initial_field_is_refused():
     from cales_amd.hotpath import CalesError, initflow
     g, case = load_golden("chan_smag")
-    case.inivel = "log"
-    with pytest.raises(CalesError):
-        initflow(case)
     case.inivel = "nonsense"
     with pytest.raises(CalesError):
         initflow(case)
+
+
+@pytest.mark.parametrize("kind", ["log", "hcl", "tbl"])
+def test_noisy_initial_fields(kind):
+    """log-law / temporal-boundary-layer profiles with +-5 % noise (initflow.f90:60-91,285-315). The reference's noise comes from the
+    Fortran run-time's random_number (compiler-specific), so only the deterministic part and the statistics are checked: plane
+    means follow the profile, the bulk velocity is ubulk after set_mean, the noise is bounded and decomposition-independent."""
+    import ctypes as C
+    from cales_amd import capi
+    from cales_amd.hotpath import _p, initflow
+    g, case = load_golden("chan_smag")
+    case.ng[:] = (32, 16, 24); case.inivel = kind; case.is_wallturb = False
+    u, v, w, p = initflow(case)
+    ui = u[1:-1, 1:-1, 1:-1]
+    prof = ui.mean(axis=(0, 1))
+    amp = np.abs(ui - prof).max()
+    assert 0. < amp < 0.06 and np.abs(v[1:-1, 1:-1, 1:-1]).max() <= 0.05 and np.abs(w[1:-1, 1:-1, 1:-1]).max() <= 0.05
+    if kind != "tbl":
+        o = Oracle(case); gr = o.grid()
+        assert abs((ui * gr["dzf"][1:-1]).sum() / (gr["dzf"][1:-1].sum() * 32 * 16) - 1.) < 1e-12           # ubulk = velf = 1
+        assert prof[0] < prof[3] < prof[11]                                                                  # log layer grows from the wall
+    else:
+        assert prof[0] > 0.9 and prof[-1] < 0.1
+    # rows of a 2-rank decomposition == rows of the global field
+    for r in range(2):
+        cs = capi.make_case(case, 2, r)
+        loc = [np.zeros((34, 10, 26), order="F") for _ in range(4)]
+        assert capi.lib().cales_initflow_slab(C.byref(cs), kind.encode(), 0, *[_p(a) for a in loc]) == 0
+        assert np.array_equal(loc[0][1:-1, 1:-1, 1:-1], u[1:-1, 1 + 8 * r:9 + 8 * r, 1:-1])
 
 
 def test_check_case_rules():
