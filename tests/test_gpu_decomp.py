@@ -36,7 +36,8 @@ def _single(case, nsteps):
                                        ("chan_dsmag_wm", (72, 32, 40), 2), ("tgv_dsmag_ppp", (32, 24, 16), 3),
                                        ("halfchan_imp1d", (16, 16, 12), 2), ("chan_smag", (64, 16, 8), 8),
                                        ("duct_smag_wm", (16, 24, 24), 2), ("duct_smag_wm_imp1d", (16, 24, 24), 2), ("cavity_nnn", (16, 24, 12), 4),
-                                       ("devchan_nd", (32, 24, 12), 3)])
+                                       ("devchan_nd", (32, 24, 12), 3),
+                                       ("couette_imp3d_ops", (32, 24, 16), 2), ("chan_dsmag", (128, 32, 136), 2)])
 def test_slab_ranks_match_single_rank(name, ng, P):
     from cales_amd.decomp import run_loopback
     case = _case(name, ng)
