@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Smallest grids (2..12 cells per direction), two steps, GPU against the oracle (development aid)."""
+import itertools, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.util import load_golden, relerr
+from cales_amd.hotpath import HotPath, initflow
+from oracle.oracle import Oracle
+
+names = ["tgv_ppp", "chan_smag", "chan_dsmag", "cavity_nnn", "halfchan_imp1d", "couette_imp3d_ops", "devchan_nd"]
+bad = 0
+rng = np.random.RandomState(0)
+sizes = [(2, 2, 2), (2, 4, 2), (4, 2, 6), (6, 6, 4), (2, 8, 8), (8, 2, 4), (4, 4, 2), (10, 6, 12), (12, 10, 2)]
+for name, ng in itertools.product(names, sizes):
+    g, case = load_golden(name); case.ng[:] = ng
+    if case.sgstype == "none" and case.cbcvel[0, 0, 0] != "P":
+        case.cbcsgs[:, 0] = "D"
+    try:
+        h = HotPath(case)
+    except Exception as e:
+        print(name, ng, "create refused:", str(e)[:90]); continue
+    o = Oracle(case, nthreads=2)
+    u, v, w, p = initflow(case)
+    for a in (u, v, w): a[1:-1, 1:-1, 1:-1] += 0.02 * (rng.rand(*ng) - 0.5)
+    h.upload(u, v, w, p); h.startup()
+    visct, pp = o.zeros(), o.zeros()
+    o.bounduvw(u, v, w, True, False); o.boundp(p, 0); o.cmpt_sgs(u, v, w, visct); o.boundp(visct, 1)
+    dt = 0.5 * o.chkdt(visct, u, v, w)
+    for _ in range(2):
+        h.step(dt); o.step(dt, u, v, w, p, pp, visct)
+    gu, gv, gw, gp, gvis = h.download()
+    errs = [relerr(a, b) for a, b in ((gu, u), (gv, v), (gw, w))] + [relerr(gvis, visct) if np.abs(visct).max() > 0 else 0.]
+    ok = np.isfinite(errs).all() and max(errs[:3]) < 1e-9 and errs[3] < 1e-6
+    bad += not ok
+    print("OK " if ok else "BAD", name, ng, " ".join("%.1e" % e for e in errs), flush=True)
+    h.close()
+print("bad:", bad)
