@@ -95,7 +95,7 @@ void cales_destroy(cales_ctx *c) {
   DBound *bs[11] = {&c->bcu, &c->bcv, &c->bcw, &c->bcp, &c->bcs, &c->bcuf, &c->bcvf, &c->bcwf, &c->bcu_mag, &c->bcv_mag, &c->bcw_mag};
   for (auto *b : bs) free_bound(*b);
   for (int d = 0; d < 3; ++d) hipFree(c->rhsbp[d]);
-  field_free(c, c->scr1); field_free(c, c->scr2); hipFree(c->d_red); hipFree(c->d_force); if (c->d_mpart) hipFree(c->d_mpart); if (c->d_abct) hipFree(c->d_abct); if (c->d_stat) hipFree(c->d_stat); hipHostFree(c->h_red);
+  field_free(c, c->scr1); field_free(c, c->scr2); hipFree(c->d_red); hipFree(c->d_force); if (c->d_mpart) hipFree(c->d_mpart); if (c->d_abct) hipFree(c->d_abct); if (c->d_cs) hipFree(c->d_cs); if (c->d_stat) hipFree(c->d_stat); hipHostFree(c->h_red);
   field_free(c, c->s0); field_free(c, c->uc); field_free(c, c->vc); field_free(c, c->wc); field_free(c, c->uf); field_free(c, c->vf); field_free(c, c->wf); field_free(c, c->alph2); if (!c->p1d_in_comm) hipFree(c->d_p1d);
   for (int m = 0; m < 6; ++m) { field_free(c, c->wk[m]); field_free(c, c->sij[m]); field_free(c, c->mij[m]); }
   cales_comm_release_native(c);
@@ -211,7 +211,7 @@ int cales_local_size(const cales_ctx *c, int32_t n[3], int32_t lo[3]) { for (int
 // ------------------------------------------------------------------------------------------ copies
 int cales_set_field(cales_ctx *c, int field, const double *host) {
   if (field < 0 || field >= CALES_NFIELDS || !c->f[field]) { c->err = "bad field id"; return 1; }
-  if (field == CALES_VISCT) c->visct_zero = false;
+  if (field == CALES_VISCT) { c->visct_zero = false; c->visct_lazy = false; }
   const size_t nh = (size_t)(c->n[0] + 2) * (c->n[1] + 2) * (c->n[2] + 2);
   const dim3 b(64, 4, 1), gr((c->n[0] + 2 + 63) / 64, (c->n[1] + 2 + 3) / 4, c->n[2] + 2);
   HIPCHK(c, hipMemcpyAsync(c->scr1, host, nh * sizeof(double), hipMemcpyHostToDevice, c->stream));     // scr1: scratch between operators
@@ -221,6 +221,7 @@ int cales_set_field(cales_ctx *c, int field, const double *host) {
 }
 int cales_get_field(cales_ctx *c, int field, double *host) {
   if (field < 0 || field >= CALES_NFIELDS || !c->f[field]) { c->err = "bad field id"; return 1; }
+  if (field == CALES_VISCT) if (int e = materialize_visct(c)) return e;
   const size_t nh = (size_t)(c->n[0] + 2) * (c->n[1] + 2) * (c->n[2] + 2);
   const dim3 b(64, 4, 1), gr((c->n[0] + 2 + 63) / 64, (c->n[1] + 2 + 3) / 4, c->n[2] + 2);
   hipLaunchKernelGGL(k_repack, gr, b, 0, c->stream, c->g, 0, c->f[field], c->scr1);

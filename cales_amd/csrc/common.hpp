@@ -107,6 +107,9 @@ struct cales_ctx {
   double *d_del = nullptr;   // Smagorinsky filter width per plane (fast path)
   void *native_comm = nullptr;   // RCCL communicator + staging buffers when the library does the exchanges itself (comm_rccl.cpp)
   bool visct_zero = true;  // CALES_VISCT still holds the zeros it was created / reset with (no SGS model: lets kernels skip it)
+  // dynamic model, fast path: the eddy-viscosity field holds |S| and d_cs(0:n3+1) the clipped plane coefficients <LM>/<MM> until somebody
+  // other than the fused momentum kernel reads it (materialize_visct); visct = |S| * cs(k) is the same product either way
+  bool visct_lazy = false; double *d_cs = nullptr;
   double *d_stat = nullptr;      // partial sums and result of the plane statistics
   bool abct_ready = false, force_zeroed = false;
   double *d_abct = nullptr;      // tridiagonal coefficients in the chunked order of k_gaussel_tile
@@ -168,6 +171,7 @@ int op_helmholtz_z(cales_ctx *c, int ivel, double alpha);
 extern "C" void cales_comm_release_native(cales_ctx *c);
 int op_helmholtz(cales_ctx *c, int ivel, double alpha);
 int op_correc(cales_ctx *c, double dtrk);
+int materialize_visct(cales_ctx *c);
 int op_stats_chan(cales_ctx *c, double *buf);
 bool solver_can_fuse_fillps(cales_ctx *c);
 int op_force_from_partials(cales_ctx *c, int mask, const double *part, int nblk);

@@ -20,6 +20,7 @@ struct MomRkArgs {
   const double *u, *v, *w, *s, *p, *duo, *dvo, *dwo;
   double *un, *vn, *wn, *du, *dv, *dw, *dud, *dvd, *dwd;
   const double *dzci, *dzfi;
+  const double *cs;      // != nullptr: s holds |S| of the dynamic model and visct = s * cs(k) (see visct_lazy in common.hpp)
   double dxi, dyi, visc, f1, f2, f12, bfx, bfy, bfz;
   int kchunk;
 };
@@ -46,9 +47,11 @@ __global__ __launch_bounds__(64 * (TYM + 2), (TYM <= 6 ? 4 : 3)) void k_momrk(Ge
   if (hok) { const double *fp = hf_ == 0 ? A.u : hf_ == 1 ? A.v : hf_ == 2 ? A.w : hf_ == 3 ? A.s : A.p; hp = fp + g.ix(hi_, hj, 0); }
   const size_t sk64 = (size_t)g.s12;
   auto ld5 = [&](int k, double *q, double &h) {
-    if (ldok && k <= g.n3 + 1) { const OFF c = c0 + (OFF)k * sk; q[0] = ldb(A.u, c); q[1] = ldb(A.v, c); q[2] = ldb(A.w, c); q[3] = NOS ? 0. : ldb(A.s, c); q[4] = ldb(A.p, c); }
+    const double csk = (!NOS && A.cs && k <= g.n3 + 1) ? A.cs[k] : 1.;
+    if (ldok && k <= g.n3 + 1) { const OFF c = c0 + (OFF)k * sk; q[0] = ldb(A.u, c); q[1] = ldb(A.v, c); q[2] = ldb(A.w, c); q[3] = NOS ? 0. : ldb(A.s, c) * csk; q[4] = ldb(A.p, c); }
     else { q[0] = q[1] = q[2] = q[3] = q[4] = 0.; }
     h = (hok && k <= g.n3 + 1) ? hp[(size_t)k * sk64] : 0.;
+    if (hf_ == 3) h = h * csk;
   };
   // plane kk of the five fields -> ring slot kk&3 (u,v,w,visct) and kk%3 (p)
   auto put = [&](int kk, const double *q, double h) {
@@ -163,6 +166,7 @@ int op_momrk(cales_ctx *c, double f1, double f2, double f12) {
   A.duo = f[CALES_DUDTO]; A.dvo = f[CALES_DVDTO]; A.dwo = f[CALES_DWDTO];
   A.un = c->f2[0]; A.vn = c->f2[1]; A.wn = c->f2[2];
   A.du = f[CALES_DUDT]; A.dv = f[CALES_DVDT]; A.dw = f[CALES_DWDT]; A.dud = f[CALES_DUDTD]; A.dvd = f[CALES_DVDTD]; A.dwd = f[CALES_DWDTD];
+  A.cs = c->visct_lazy ? c->d_cs : nullptr;
   A.dzci = c->d_dzci; A.dzfi = c->d_dzfi; A.dxi = c->dli[0]; A.dyi = c->dli[1]; A.visc = c->visc;
   A.f1 = f1; A.f2 = f2; A.f12 = f12; A.bfx = c->C.bforce[0]; A.bfy = c->C.bforce[1]; A.bfz = c->C.bforce[2];
   dim3 b(64, TYM + 2, 1), gr((n[0] + 63) / 64, (n[1] + TYM - 1) / TYM, 1);

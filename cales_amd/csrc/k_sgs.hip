@@ -238,6 +238,27 @@ __global__ __launch_bounds__(BX *BY) void k_dsmag_final(Geom g, double gar, cons
   double vt = s0[c] * lm / mm;
   visct[c] = fmax(vt, 0.);
 }
+// plane coefficients of the lazy form: cs(k) = max(<LM>/<MM>, 0) for k = 1..n3 (NaN -> 0 as fmax does in k_dsmag_final), ghost planes from
+// the z boundary type of the field (periodic: wrap; wall: the neighbour's, the ghost value of |S| carries the sign)
+__global__ void k_dsmag_coef(int n3, double gar, const double *__restrict__ p1d, double *__restrict__ cs, int periodic_z) {
+  for (int k = threadIdx.x + 1; k <= n3; k += blockDim.x) { const double lm = p1d[k - 1] * gar, mm = p1d[n3 + k - 1] * gar; cs[k] = fmax(lm / mm, 0.); }
+  __syncthreads();
+  if (threadIdx.x == 0) { cs[0] = periodic_z ? cs[n3] : cs[1]; cs[n3 + 1] = periodic_z ? cs[1] : cs[n3]; }
+}
+__global__ __launch_bounds__(256) void k_scale_planes(Geom g, const double *__restrict__ cs, double *__restrict__ f) {
+  const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
+  if (i > g.n1 + 1 || j > g.n2 + 1) return;
+  const size_t c = g.ix(i, j, k);
+  f[c] = f[c] * cs[k];
+}
+int materialize_visct(cales_ctx *c) {
+  if (!c->visct_lazy) return 0;
+  c->visct_lazy = false;
+  const int *n = c->n;
+  hipLaunchKernelGGL(k_scale_planes, dim3((n[0] + 2 + 63) / 64, (n[1] + 2 + 3) / 4, n[2] + 2), dim3(64, 4, 1), 0, c->stream, c->g, c->d_cs, c->f[CALES_VISCT]);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
 __global__ __launch_bounds__(256) void k_alph2(Geom g, double w0, double w1, double w2, double w3, double w4, double w5, double *__restrict__ alph2) {
   const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;    // sgs.f90:783-816
   if (i > g.n1 + 1 || j > g.n2 + 1) return;
@@ -626,12 +647,15 @@ static int dsmag_fast(cales_ctx *c) {
   };
   dim3 mb, mg; int kch;
   const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32) && getenv("CALES_WIDE_OFFSETS") == nullptr;      // 32-bit byte offsets (ldb/stb)
+  // lazy form (homogeneous sgs BCs): |S| goes straight into the eddy-viscosity field and the last pass only makes the n3 plane coefficients
+  bool lazy = getenv("CALES_DSMAG_EAGER") == nullptr;
+  for (int q = 0; q < 6; ++q) lazy = lazy && c->C.bcsgs[q] == 0.;
   // K_AC: |S|, |S|Sij, cell-centred and test-filtered velocity in one pass over u,v,w (no wall-model faces ->
   // extrapolate(...,lwm) is a no-op; u,v are extrapolated through the z walls, w on the faces is not, sgs.f90:705-710)
   { ProfScope ps(c, "strain_filter_uvw");
     tiles(TYS, 64, mb, mg, kch);
     StrainTileArgs S;
-    S.u[0] = f[CALES_U]; S.u[1] = f[CALES_V]; S.u[2] = f[CALES_W]; S.s0 = c->s0;
+    S.u[0] = f[CALES_U]; S.u[1] = f[CALES_V]; S.u[2] = f[CALES_W]; S.s0 = lazy ? visct : c->s0;
     for (int m = 0; m < 6; ++m) S.ssij[m] = ssij[m];
     S.uc[0] = c->uc; S.uc[1] = c->vc; S.uc[2] = c->wc; S.uf[0] = c->uf; S.uf[1] = c->vf; S.uf[2] = c->wf;
     S.dzci = c->d_dzci; S.dzfi = c->d_dzfi; S.dxi = c->dli[0]; S.dyi = c->dli[1]; S.kchunk = kch; S.zlo = zlo; S.zhi = zhi; S.wmlo = wmlo; S.wmhi = wmhi; S.flo = flo; S.fhi = fhi;
@@ -670,7 +694,11 @@ static int dsmag_fast(cales_ctx *c) {
     hipLaunchKernelGGL(k_plane_fold, dim3(2 * n[2]), dim3(256), 0, c->stream, n[2], L.nblk, c->wk[0], c->d_p1d); }
   if (c->P > 1) { if (int e = allreduce_res(c, (int)(c->d_p1d - c->res), 2 * n[2], 0)) return e; }   // sgs.f90:475
   const double gar = c->dl[0] * c->dl[1] / (c->C.l[0] * c->C.l[1]);
-  hipLaunchKernelGGL(k_dsmag_final, gr, b, 0, c->stream, c->g, gar, c->d_p1d, c->s0, visct);
+  if (lazy) {
+    if (!c->d_cs) HIPCHK(c, hipMalloc(&c->d_cs, (n[2] + 2) * sizeof(double)));
+    hipLaunchKernelGGL(k_dsmag_coef, dim3(1), dim3(256), 0, c->stream, n[2], gar, c->d_p1d, c->d_cs, CBP(c, 0, 3) == 'P' && CBP(c, 1, 3) == 'P' ? 1 : 0);
+    c->visct_lazy = true;
+  } else hipLaunchKernelGGL(k_dsmag_final, gr, b, 0, c->stream, c->g, gar, c->d_p1d, c->s0, visct);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -718,6 +746,7 @@ int op_cmpt_sgs(cales_ctx *c) {
     if (c->sgs_first) { c->sgs_first = false; HIPCHK(c, hipMemsetAsync(visct, 0, nt * sizeof(double), c->stream)); c->visct_zero = true; }
     return 0;
   }
+  c->visct_lazy = false;      // the field is rewritten from scratch
   ProfScope ps(c, c->C.sgstype == 1 ? "cmpt_sgs_smag" : "cmpt_sgs_dsmag");
   dim3 b(BX, BY, 1), gr = grid3(n[0], n[1], n[2], b);
   if (c->sgs_first) {

@@ -104,6 +104,7 @@ __global__ __launch_bounds__(BX *BY) void k_mom(Geom g, const double *__restrict
 }
 
 int op_mom(cales_ctx *c) {
+  if (int e = materialize_visct(c)) return e;
   ProfScope ps(c, "mom_xyz_ad");
   dim3 b(BX, BY, 1), gr = grid3(c->n[0], c->n[1], c->n[2], b);
   double **f = c->f;
@@ -521,6 +522,7 @@ __global__ void k_stats_fold(int n3, int nbx, double ratio, const double *__rest
 }
 // buf: (27, n3) column-major on the host; with several ranks the sums of THIS rank's rows (the caller adds the ranks, output.f90:691)
 int op_stats_chan(cales_ctx *c, double *buf) {
+  if (int e = materialize_visct(c)) return e;
   const int nbx = 8, n3 = c->n[2];
   const size_t need = (size_t)NSTAT * n3 * (nbx + 1);
   if (!c->d_stat) HIPCHK(c, hipMalloc(&c->d_stat, need * sizeof(double)));
@@ -567,6 +569,7 @@ __global__ __launch_bounds__(256) void k_chkdt_partial(Geom g, double dxi, doubl
   if (threadIdx.x == 0) { const size_t o = (size_t)blockIdx.y * gridDim.x + blockIdx.x; pa[o] = ra; pd[o] = rd; }
 }
 int op_chkdt(cales_ctx *c, double *dtmax) {
+  if (int e = materialize_visct(c)) return e;
   const int nbx = 8, np = nbx * c->n[2];
   double **f = c->f;
   if (c->C.impdiff == 2)
