@@ -313,7 +313,8 @@ int cales_step(cales_ctx *c, double dt) {
     for (int d = 0; d < 3; ++d) fuse_fill = fuse_fill && ((c->C.bcpre[2 * d] == 0. && c->C.bcpre[2 * d + 1] == 0.) || c->C.cbcpre[2 * d] == 'P');
     c->fuse_mean_mask = (fuse_fill && c->defer_force && getenv("CALES_UNFUSED_MEAN") == nullptr)
                             ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;
-    if (int e = op_rk(c, irk, dt)) return e;
+    c->skip_rhs_store = irk == 3 && getenv("CALES_KEEP_LAST_RHS") == nullptr;
+    { const int e = op_rk(c, irk, dt); c->skip_rhs_store = false; if (e) return e; }
     if (int e = op_bulk_forcing(c)) { c->defer_imp_rhs = false; return e; }
     if (c->C.impdiff == 2) {
       alpha = -.5 * c->visc * dtrk;

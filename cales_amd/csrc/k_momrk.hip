@@ -23,6 +23,9 @@ struct MomRkArgs {
   const double *cs;      // != nullptr: s holds |S| of the dynamic model and visct = s * cs(k) (see visct_lazy in common.hpp)
   double dxi, dyi, visc, f1, f2, f12, bfx, bfy, bfz;
   int kchunk;
+  // low-storage RK3 (param.f90:27-29): the first substep has f2 = 0 -> the old r.h.s. is not read; inside cales_step the r.h.s. of the
+  // third substep is never used (the next step starts with f2 = 0) -> not written
+  int rd_old, wr_new;
 };
 
 // NOS = 1: no subgrid model (visct is identically zero, sgs.f90:62-68): its loads, LDS traffic and terms are compiled out
@@ -68,7 +71,8 @@ __global__ __launch_bounds__(64 * (TYM + 2), (TYM <= 6 ? 4 : 3)) void k_momrk(Ge
     ld5(k + 2, pf, hf);                                     // prefetch, in flight during the stencil
     if (outok) {
       const OFF c = c0 + (OFF)k * sk;
-      const double duo = ldb(A.duo, c), dvo = ldb(A.dvo, c), dwo = ldb(A.dwo, c);
+      double duo = 0., dvo = 0., dwo = 0.;
+      if (A.rd_old) { duo = ldb(A.duo, c); dvo = ldb(A.dvo, c); dwo = ldb(A.dwo, c); }
       const int km = (k - 1) & 3, kc = k & 3, kp = (k + 1) & 3;
 #define LS(f, sl, di, dj) sh[f][sl][ty + (dj)][tx + 1 + (di)]
       const double u_ccm = LS(0, km, 0, 0), u_cmc = LS(0, kc, 0, -1), u_mcc = LS(0, kc, -1, 0),
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(64 * (TYM + 2), (TYM <= 6 ? 4 : 3)) void k_momrk(Ge
       double wn = w_ccc + A.f1 * dw + A.f2 * dwo + A.f12 * (A.bfz - dzci_k * (p_ccp - p_ccc));
       if (IMP) { un = un + A.f12 * dud; vn = vn + A.f12 * dvd; wn = wn + A.f12 * dwd; stb(A.dud, c, dud); stb(A.dvd, c, dvd); stb(A.dwd, c, dwd); }
       stb(A.un, c, un); stb(A.vn, c, vn); stb(A.wn, c, wn);
-      stb(A.du, c, du); stb(A.dv, c, dv); stb(A.dw, c, dw);
+      if (A.wr_new) { stb(A.du, c, du); stb(A.dv, c, dv); stb(A.dw, c, dw); }
     }
     put(k + 2, pf, hf);        // slots (k+2)&3 and (k+2)%3 were last read in iteration k-1, i.e. before this iteration's barrier
   }
@@ -168,6 +172,7 @@ int op_momrk(cales_ctx *c, double f1, double f2, double f12) {
   A.du = f[CALES_DUDT]; A.dv = f[CALES_DVDT]; A.dw = f[CALES_DWDT]; A.dud = f[CALES_DUDTD]; A.dvd = f[CALES_DVDTD]; A.dwd = f[CALES_DWDTD];
   A.cs = c->visct_lazy ? c->d_cs : nullptr;
   A.dzci = c->d_dzci; A.dzfi = c->d_dzfi; A.dxi = c->dli[0]; A.dyi = c->dli[1]; A.visc = c->visc;
+  A.rd_old = f2 != 0.; A.wr_new = !c->skip_rhs_store;
   A.f1 = f1; A.f2 = f2; A.f12 = f12; A.bfx = c->C.bforce[0]; A.bfy = c->C.bforce[1]; A.bfz = c->C.bforce[2];
   dim3 b(64, TYM + 2, 1), gr((n[0] + 63) / 64, (n[1] + TYM - 1) / TYM, 1);
   int kchunk = n[2];

@@ -136,7 +136,7 @@ def test_wide_offset_kernels(name, monkeypatch):
     test_fused_step_matches_operator_sequence(name)
 
 
-@pytest.mark.parametrize("env", ["CALES_DSMAG_REFERENCE_SEQUENCE", "CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_GAUSSEL_MARCH", "CALES_DSMAG_EAGER"])
+@pytest.mark.parametrize("env", ["CALES_DSMAG_REFERENCE_SEQUENCE", "CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_GAUSSEL_MARCH", "CALES_DSMAG_EAGER", "CALES_KEEP_LAST_RHS"])
 @pytest.mark.parametrize("name", ["chan_dsmag", "chan_dsmag_wm", "tgv_dsmag_ppp", "duct_smag_wm_imp1d"])
 def test_unfused_paths(name, env, monkeypatch):
     """The kernel-per-loop forms behind the operator-level entries (general dsmag sequence, mom + rk_update, correc +
