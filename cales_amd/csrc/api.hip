@@ -292,7 +292,8 @@ __global__ void k_zero6(double *f) { if (threadIdx.x < 6) f[threadIdx.x] = 0.; }
 int cales_step(cales_ctx *c, double dt) {
   static const double rk[3][2] = {{32. / 60., 0.}, {25. / 60., -17. / 60.}, {45. / 60., -25. / 60.}};
   hipLaunchKernelGGL(k_zero6, dim3(1), dim3(64), 0, c->stream, c->d_force);     // dpdl(:) = 0
-  struct Reset { cales_ctx *c; ~Reset() { c->defer_force = false; c->defer_imp_rhs = false; c->fuse_fillps_dti = 0.; c->fuse_mean_mask = 0; } } reset{c};      // also on the error returns
+  c->in_step = true;
+  struct Reset { cales_ctx *c; ~Reset() { c->in_step = false; c->defer_force = false; c->defer_imp_rhs = false; c->fuse_fillps_dti = 0.; c->fuse_mean_mask = 0; } } reset{c};      // also on the error returns
   for (int irk = 1; irk <= 3; ++irk) {
     const double dtrk = (rk[irk - 1][0] + rk[irk - 1][1]) * dt, dtrki = 1. / dtrk;
     double alpha = 0.;

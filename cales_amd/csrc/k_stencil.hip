@@ -397,8 +397,11 @@ int op_correc_updatep(cales_ctx *c, double dt, double alpha, int upd) {
   if (mode == 0) hipLaunchKernelGGL(k_correc_cell<0>, gr, b, 0, c->stream, c->g, fi, fj, dt, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], f_[0], f_[1], f_[2], f_[3], c->d_force, fmask);
   else if (mode == 1) hipLaunchKernelGGL(k_correc_cell<1>, gr, b, 0, c->stream, c->g, fi, fj, dt, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], f_[0], f_[1], f_[2], f_[3], c->d_force, fmask);
   else hipLaunchKernelGGL(k_correc_cell<2>, gr, b, 0, c->stream, c->g, fi, fj, dt, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], f_[0], f_[1], f_[2], f_[3], c->d_force, fmask);
-  hipLaunchKernelGGL(k_correc_edge, dim3((n[1] + 2 + 63) / 64, (n[2] + 2 + 3) / 4, 2), dim3(64, 4, 1), 0, c->stream, c->g, fi, fj, dt, c->d_dzci, c->f[CALES_PP],
-                     f_[0], f_[1], f_[2]);
+  // periodic x: the ghost columns are overwritten by the periodic copy of the bounduvw that always follows (main.f90:500) -- inside
+  // cales_step their correction is dead work
+  if (!(c->in_step && c->cbcvel[0] == 'P' && c->cbcvel[1] == 'P'))
+    hipLaunchKernelGGL(k_correc_edge, dim3((n[1] + 2 + 63) / 64, (n[2] + 2 + 3) / 4, 2), dim3(64, 4, 1), 0, c->stream, c->g, fi, fj, dt, c->d_dzci, c->f[CALES_PP],
+                       f_[0], f_[1], f_[2]);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
