@@ -34,7 +34,8 @@ WORDS = {"mom_xyz_ad": 7, "rk_update": 13, "fillps": 4, "correc": 7, "updatep": 
          "fft_x_fwd": 2, "fft_y_fwd": 2, "gaussel_z": 2, "fft_y_bwd": 2, "fft_x_bwd": 2,
          "fillps_fft_x_fwd": 4,     # fillps folded into the forward x transform: u,v,w in, spectrum out
          "correc_updatep": 9,       # pp,u,v,w,p in; u,v,w,p out
-         "mom_rk_fused": 14,        # u,v,w,visct,p + 3 old r.h.s. in; u,v,w + 3 r.h.s. out
+         "mom_rk_fused": 12,        # u,v,w,visct,p + 3 old r.h.s. in; u,v,w + 3 r.h.s. out = 14, less the old r.h.s. of substep 1 (weight 0)
+                                    # and the r.h.s. of substep 3 (never read): 11, 14, 11 -> 12 on average over a step
          "strain_filter_uvw": 16,   # u,v,w in; |S|, 6 |S|Sij, 3 cell-centred, 3 test-filtered velocities out
          "filter_s0sij": 12,        # 6 in, 6 out
          "lij_mij_contract": 12,    # 3 + 3 + 6 in; plane partial sums out
@@ -225,11 +226,11 @@ def main():
             "poisson_solve": {"ms": solve_ms, "words_per_cell": solve_words, "passes": solve_note,
                               "algorithmic_GBps": solve_words * 8.0 * nloc / (solve_ms * 1e-3) / 1e9 if solve_ms else None,
                               "frac_of_hbm_peak": solve_words * 8.0 * nloc / (solve_ms * 1e-3) / HBM_PEAK if solve_ms else None},
-            # north_star: ">= 50 % of the HBM roofline on the Poisson + RK sweep": one solve (10 words) + one fused
-            # momentum/RK pass (14 words) over the time of exactly those kernels
+            # north_star: ">= 50 % of the HBM roofline on the Poisson + RK sweep": one (fillps +) solve + one fused
+            # momentum/RK pass (its compulsory words, averaged over the three substeps) over the time of exactly those kernels
             "poisson_plus_rk": (lambda ms, w: {"ms": ms, "words_per_cell": w, "algorithmic_GBps": w * 8.0 * nloc / (ms * 1e-3) / 1e9,
                                                "frac_of_hbm_peak": w * 8.0 * nloc / (ms * 1e-3) / HBM_PEAK})(
-                solve_ms + stats["mom_rk_fused"][1] / stats["mom_rk_fused"][0], solve_words + 14) if solve_ms and stats.get("mom_rk_fused", (0, 0))[0] else None,
+                solve_ms + stats["mom_rk_fused"][1] / stats["mom_rk_fused"][0], solve_words + WORDS["mom_rk_fused"]) if solve_ms and stats.get("mom_rk_fused", (0, 0))[0] else None,
             # traffic the reference's kernel-per-loop sequence would move for the same step, over the measured time: >1 is
             # possible and only says that fusion removed traffic; it is NOT a roofline fraction
             "step_vs_reference_traffic": {"reference_GB_per_step": 3 * 8.0 * ncell * W_STEP[case.sgstype] / 1e9,
