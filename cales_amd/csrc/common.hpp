@@ -226,5 +226,11 @@ __device__ inline void stencil_block(int &bx, int &by, int &bz) {
 #endif
 
 // tile kernels split k into chunks until at least this many blocks exist (several rounds per CU balance the chip)
+// k extent of the chunks the marching tile kernels split the z range into. CALES_KCHUNK overrides (experiments).
+static inline int tile_kchunk(long nxy_blocks, int n3) {
+  static const int forced = getenv("CALES_KCHUNK") ? atoi(getenv("CALES_KCHUNK")) : 0;
+  if (forced > 0) return forced < n3 ? forced : n3;
+  return 0;
+}
 static inline long tile_min_blocks() { static const long v = getenv("CALES_TILE_MIN_BLOCKS") ? atol(getenv("CALES_TILE_MIN_BLOCKS")) : 2048; return v; }
 static inline dim3 grid3(int nx, int ny, int nz, dim3 b) { return dim3((nx + b.x - 1) / b.x, (ny + b.y - 1) / b.y, (nz + b.z - 1) / b.z); }

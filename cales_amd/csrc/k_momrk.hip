@@ -177,6 +177,7 @@ int op_momrk(cales_ctx *c, double f1, double f2, double f12) {
   dim3 b(64, TYM + 2, 1), gr((n[0] + 63) / 64, (n[1] + TYM - 1) / TYM, 1);
   int kchunk = n[2];
   while ((long)gr.x * gr.y * ((n[2] + kchunk - 1) / kchunk) < tile_min_blocks() && kchunk > 32) kchunk = (kchunk + 1) / 2;
+  if (int fk = tile_kchunk((long)gr.x * gr.y, n[2])) kchunk = fk;
   gr.z = (n[2] + kchunk - 1) / kchunk; A.kchunk = kchunk;
   const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32) && getenv("CALES_WIDE_OFFSETS") == nullptr;      // 32-bit byte offsets
   const int nos = c->C.sgstype == 0 && c->visct_zero;     // visct known to be identically zero (never set by the host since the last zeroing)

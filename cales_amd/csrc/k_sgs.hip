@@ -643,6 +643,7 @@ static int dsmag_fast(cales_ctx *c) {
     mb = dim3(64, ty + 2, 1); mg = dim3((n[0] + wx - 1) / wx, (n[1] + ty - 1) / ty, 1);
     kchunk = n[2];
     while ((long)mg.x * mg.y * ((n[2] + kchunk - 1) / kchunk) < tile_min_blocks() && kchunk > 32) kchunk = (kchunk + 1) / 2;
+    if (int fk = tile_kchunk((long)mg.x * mg.y, n[2])) kchunk = fk;
     mg.z = (n[2] + kchunk - 1) / kchunk;
   };
   dim3 mb, mg; int kch;
@@ -724,6 +725,7 @@ static int smag_fast(cales_ctx *c) {
   dim3 mb(64, TYS + 2, 1), mg((n[0] + 63) / 64, (n[1] + TYS - 1) / TYS, 1);
   int kch = n[2];
   while ((long)mg.x * mg.y * ((n[2] + kch - 1) / kch) < tile_min_blocks() && kch > 32) kch = (kch + 1) / 2;
+  if (int fk = tile_kchunk((long)mg.x * mg.y, n[2])) kch = fk;
   mg.z = (n[2] + kch - 1) / kch;
   StrainTileArgs S = {};
   S.u[0] = f[CALES_U]; S.u[1] = f[CALES_V]; S.u[2] = f[CALES_W]; S.visct = f[CALES_VISCT];
