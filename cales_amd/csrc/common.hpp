@@ -104,6 +104,7 @@ struct cales_ctx {
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evpool;
   double *d_tw4x = nullptr;  // DCT-IV weights of the x transform (pressure ND / DN)
+  double *d_tw4y = nullptr, *d_twy4 = nullptr;      // the same for y, and the twiddles of its N/2-point lines
   double *d_del = nullptr;   // Smagorinsky filter width per plane (fast path)
   void *native_comm = nullptr;   // RCCL communicator + staging buffers when the library does the exchanges itself (comm_rccl.cpp)
   bool visct_zero = true;  // CALES_VISCT still holds the zeros it was created / reset with (no SGS model: lets kernels skip it)

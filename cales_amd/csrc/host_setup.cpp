@@ -274,7 +274,7 @@ int hs_check_case(const cales_case *cs, std::string &msg) {
   if (cs->impdiff < 0 || cs->impdiff > 2) { msg = "impdiff must be 0, 1 or 2"; return 1; }
   // transforms offered: in y periodic and cell-centred Neumann-Neumann (what the reference's GPU path offers in x and y,
   // sanity.f90:265-273); in x also DD, ND, DN (inflow/outflow; the reference's CPU path through FFTW's r2r kinds)
-  { const std::string by = pr(cs->cbcpre, 1); if (by != "PP" && by != "NN" && by != "DD") { msg = "pressure BC pair in y must be PP, NN or DD on the device path"; return 1; } }
+  { const std::string by = pr(cs->cbcpre, 1); if (by != "PP" && by != "NN" && by != "DD" && by != "ND" && by != "DN") { msg = "unknown pressure BC pair in y"; return 1; } }
   { const std::string bx = pr(cs->cbcpre, 0); if (bx != "PP" && bx != "NN" && bx != "DD" && bx != "ND" && bx != "DN") { msg = "unknown pressure BC pair in x"; return 1; } }
   return 0;
 }

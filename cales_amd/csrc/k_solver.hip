@@ -329,6 +329,44 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const
   }
 }
 
+// DCT-IV / DST-IV along y (pressure Neumann on one y face and Dirichlet on the other: REDFT11 / RODFT11, fft.f90:192-245), the y twin of
+// k_fft_x4: the real and the imaginary part of a column are two real sequences, each transformed by an N/2-point complex FFT of
+// (x_{2q} + i x_{N-1-2q}) e^{-i pi (4q+1)/(4N)} with the post-twiddle e^{-i pi k/N}. Both kinds are their own inverse up to 2N
+// (left to the inverse x pass), so the same kernel serves both directions. CB columns = 2 CB lines per block.
+template <int DST>
+__global__ __launch_bounds__(256) void k_fft_y4(Geom g, FftPlan P, int CB, int ncols, const cpx *__restrict__ tw, const cpx *__restrict__ tw4,
+                                                Spec S, double2 *__restrict__ pc) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int nh = P.N, N = 2 * nh, ld = nh + 1, T = blockDim.x / (2 * CB);
+  const int m0 = blockIdx.x * CB, k = blockIdx.y + 1;
+  cpx *base = reinterpret_cast<cpx *>(smem);                                  // line l = 2 col + part: A at base + l*2*ld, B behind it
+  for (int q = threadIdx.x; q < CB * nh; q += blockDim.x) {
+    const int col = q % CB, qq = q / CB;
+    if (m0 + col < ncols) {
+      double2 a = pc[S.at_mode(g, m0 + col, 2 * qq + 1, k)], b = pc[S.at_mode(g, m0 + col, N - 1 - 2 * qq + 1, k)];
+      if (DST) { const double2 tmp = a; a = b; b = tmp; }                     // reversed input
+      base[(size_t)(2 * col) * 2 * ld + qq] = cmul(cpx{a.x, b.x}, tw4[qq]);
+      base[(size_t)(2 * col + 1) * 2 * ld + qq] = cmul(cpx{a.y, b.y}, tw4[qq]);
+    }
+  }
+  __syncthreads();
+  const int line = threadIdx.x / T, t = threadIdx.x % T;
+  cpx *A = base + (size_t)line * 2 * ld, *B = A + ld;
+  cpx *Z = fft_line<0>(P, A, B, t, T, tw);
+  const bool swapped = (Z != A);
+  __syncthreads();
+  for (int q = threadIdx.x; q < CB * nh; q += blockDim.x) {
+    const int col = q % CB, kk = q / CB;
+    if (m0 + col < ncols) {
+      const cpx *Z0 = base + (size_t)(2 * col) * 2 * ld + (swapped ? ld : 0), *Z1 = Z0 + 2 * ld;
+      const cpx c0 = cmul(Z0[kk], tw4[nh + kk]), c1 = cmul(Z1[kk], tw4[nh + kk]);
+      const double so = DST ? 2. : -2.;                                        // DST: (-1)^k on the odd slots
+      pc[S.at_mode(g, m0 + col, 2 * kk + 1, k)] = make_double2(2. * c0.x, 2. * c1.x);
+      pc[S.at_mode(g, m0 + col, N - 1 - 2 * kk + 1, k)] = make_double2(so * c0.y, so * c1.y);
+    }
+  }
+}
+
 // y pass for N = n2 = 2^p: CB = blockDim.x / (N/8) adjacent complex columns; persistent over `kchunk` planes with
 // register prefetch of the next plane; twiddles in LDS.
 template <int INV, int KIND>
@@ -913,7 +951,7 @@ __global__ __launch_bounds__(256) void k_gaussel(Geom g, int nz, int ncol, int n
 }
 
 // ------------------------------------------------------------------------------------------ host side
-struct SolverPlans { FftPlan px, py; int Rx, CBy; size_t shx, shy; bool x8, y8; int x8_threads, y8_threads; size_t shx8, shy8; };
+struct SolverPlans { FftPlan py4; int CBy4; size_t shy4; FftPlan px, py; int Rx, CBy; size_t shx, shy; bool x8, y8; int x8_threads, y8_threads; size_t shx8, shy8; };
 struct PlanSlot { cales_ctx *ctx; SolverPlans sp; };
 static std::vector<PlanSlot> g_slots;
 static SolverPlans *find_plans(cales_ctx *c) { for (auto &s : g_slots) if (s.ctx == c) return &s.sp; return nullptr; }
@@ -927,7 +965,7 @@ int solver_setup(cales_ctx *c) {
   auto kind_of = [](const std::string &b) { return b == "PP" ? 0 : b == "NN" ? 1 : b == "DD" ? 2 : b == "ND" ? 3 : b == "DN" ? 4 : -1; };
   c->xkind = kind_of(bx); c->ykind = kind_of(by);
   if (c->xkind < 0 || c->ykind < 0) { c->err = "solver: unknown pressure BC pair in x or y"; return 1; }
-  if (c->ykind > 2) { c->err = "solver: in y the pressure BC pairs PP, NN and DD are provided (ND, DN only in x)"; return 1; }
+  if (c->ykind >= 3 && (n2g % 2)) { c->err = "solver: ND/DN in y need an even ng(2)"; return 1; }
   if (c->xkind && c->C.cbcpre[4] == 'P' && (!c->ykind || c->P > 1)) { c->err = "solver: a non-periodic x with periodic z needs a non-periodic y and one rank"; return 1; }
   SolverPlans sp;
   if (!make_plan(n1 / 2, sp.px) || !make_plan(n2g, sp.py)) { c->err = "solver: ng(1)/2 and ng(2) must factor into 2,3,5,7,11,13"; return 1; }
@@ -952,6 +990,18 @@ int solver_setup(cales_ctx *c) {
                  hipFuncSetAttribute((const void *)k_fft_y8<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8);
                  hipFuncSetAttribute((const void *)k_fft_y8<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8);
                  hipFuncSetAttribute((const void *)k_fft_y8<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8); } }
+  if (c->ykind >= 3) {      // DCT-IV / DST-IV in y: N/2-point lines, two per complex column
+    if (!make_plan(n2g / 2, sp.py4)) { c->err = "solver: ng(2)/2 must factor into 2,3,5,7,11,13"; return 1; }
+    sp.CBy4 = 4; sp.shy4 = (size_t)2 * sp.CBy4 * 2 * (n2g / 2 + 1) * sizeof(cpx);
+    while (sp.shy4 > 60 * 1024 && sp.CBy4 > 1) { sp.CBy4 /= 2; sp.shy4 = (size_t)2 * sp.CBy4 * 2 * (n2g / 2 + 1) * sizeof(cpx); }
+    if (sp.shy4 > 64 * 1024) { c->err = "solver: y line too long for the LDS-resident DCT-IV"; return 1; }
+    sp.y8 = false;
+    std::vector<double> t(4 * (size_t)(n2g / 2)); const double pi = std::acos(-1.0); const int nh2 = n2g / 2;
+    for (int q = 0; q < nh2; ++q) { const double a1 = -pi * (4. * q + 1.) / (4. * n2g), a2 = -pi * q / (double)n2g;
+                                    t[2 * q] = std::cos(a1); t[2 * q + 1] = std::sin(a1); t[2 * (nh2 + q)] = std::cos(a2); t[2 * (nh2 + q) + 1] = std::sin(a2); }
+    HIPCHK(c, hipMalloc(&c->d_tw4y, t.size() * sizeof(double)));
+    HIPCHK(c, hipMemcpy(c->d_tw4y, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   if (c->ykind == 2) sp.y8 = false;      // the sign changes of the Dirichlet-Dirichlet transform live in the generic y kernel only
   if (getenv("CALES_FFT_GENERIC")) sp.x8 = sp.y8 = false;
   // eigenvalues (initsolver.f90:66-98); x: modes 0..n1/2 (half-complex symmetry), y: modes 0..n2-1
@@ -988,6 +1038,7 @@ int solver_setup(cales_ctx *c) {
   if (mk(n2g, n2g, &c->d_twy)) return 1;
   if (mk(4 * n1, n1 / 2 + 1, &c->d_twy_post)) return 1;      // DCT weights e^{-i pi k/(2 n1)}, k = 0..n1/2 (x)
   if (mk(4 * n2g, n2g, &c->scr_twyd)) return 1;              // e^{-i pi k/(2 n2)}, k = 0..n2-1 (y)
+  if (c->ykind >= 3) { if (mk(n2g / 2, n2g / 2, &c->d_twy4)) return 1; }      // N/2-point lines of k_fft_y4
   if (c->xkind >= 3) {            // DCT-IV weights (k_fft_x4)
     const int nh = n1 / 2; std::vector<double> t(4 * (size_t)nh); const double pi = std::acos(-1.0);
     for (int q = 0; q < nh; ++q) { const double a1 = -pi * (4. * q + 1.) / (4. * n1), a2 = -pi * q / (double)n1;
@@ -1010,7 +1061,7 @@ int solver_setup(cales_ctx *c) {
 void solver_teardown(cales_ctx *c) {
   for (size_t q = 0; q < g_slots.size(); ++q) if (g_slots[q].ctx == c) { g_slots.erase(g_slots.begin() + q); break; }
   hipFree(c->d_lamx); hipFree(c->d_lamy); hipFree(c->d_a); hipFree(c->d_b); hipFree(c->d_c);
-  hipFree(c->d_twx); hipFree(c->d_twx_post); hipFree(c->d_twy); hipFree(c->d_twy_post); hipFree(c->scr_twyd); hipFree(c->d_tw4x);
+  hipFree(c->d_twx); hipFree(c->d_twx_post); hipFree(c->d_twy); hipFree(c->d_twy_post); hipFree(c->scr_twyd); hipFree(c->d_tw4x); if (c->d_tw4y) hipFree(c->d_tw4y); if (c->d_twy4) hipFree(c->d_twy4);
   for (int iv = 0; iv < 3; ++iv) hipFree(c->d_av[iv]);
 }
 
@@ -1063,7 +1114,9 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
                        (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec); }
   if (dist) { ProfScope ps(c, "alltoall"); if (c->comm.a2a(c->comm.user, 0, a2a_count)) { c->err = "alltoall callback failed"; return 1; } }
   { ProfScope ps(c, "fft_y_fwd");
-    if (sp->y8 && c->ykind) hipLaunchKernelGGL((k_fft_y8<0, 1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
+    if (c->ykind == 3) hipLaunchKernelGGL(k_fft_y4<0>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
+    else if (c->ykind == 4) hipLaunchKernelGGL(k_fft_y4<1>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
+    else if (sp->y8 && c->ykind) hipLaunchKernelGGL((k_fft_y8<0, 1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
     else if (sp->y8) hipLaunchKernelGGL((k_fft_y8<0, 0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
     else hipLaunchKernelGGL(k_fft_y<0>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
   // pressure equation without a Dirichlet condition in z: the zero-eigenvalue mode (if x and y have one) is singular
@@ -1092,7 +1145,9 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
     else if (getenv("CALES_GAUSSEL_PAIR")) hipLaunchKernelGGL((k_gaussel<double2, 0>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2, fixnull);
     else hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, fixnull, 0); }
   { ProfScope ps(c, "fft_y_bwd");
-    if (sp->y8 && c->ykind) hipLaunchKernelGGL((k_fft_y8<1, 1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
+    if (c->ykind == 3) hipLaunchKernelGGL(k_fft_y4<0>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
+    else if (c->ykind == 4) hipLaunchKernelGGL(k_fft_y4<1>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
+    else if (sp->y8 && c->ykind) hipLaunchKernelGGL((k_fft_y8<1, 1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
     else if (sp->y8) hipLaunchKernelGGL((k_fft_y8<1, 0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
     else hipLaunchKernelGGL(k_fft_y<1>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
   if (dist) { ProfScope ps(c, "alltoall"); if (c->comm.a2a(c->comm.user, 1, a2a_count)) { c->err = "alltoall callback failed"; return 1; } }

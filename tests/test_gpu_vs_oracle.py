@@ -228,17 +228,19 @@ def test_poisson_solve_open_x_periodic_y(bx, ng):
     h.close()
 
 
-@pytest.mark.parametrize("bx", ["NN", "DD", "ND"])
+@pytest.mark.parametrize("by", ["DD", "ND", "DN"])
+@pytest.mark.parametrize("bx", ["NN", "DD", "ND", "PP"])
 @pytest.mark.parametrize("ng", [(32, 16, 12), (20, 36, 10), (64, 128, 8), (28, 22, 10)])
-def test_poisson_solve_open_y(bx, ng):
-    """Pressure Dirichlet on both y faces (RODFT10/01 in y: the Neumann-Neumann kernel on sign-alternated rows, reversed eigenvalues)
-    combined with Neumann or open x faces; also three steps of such a box against the oracle."""
+def test_poisson_solve_open_y(bx, by, ng):
+    """Pressure Dirichlet on one or both y faces (RODFT10/01: the Neumann-Neumann kernel on sign-alternated rows, reversed eigenvalues;
+    REDFT11 / RODFT11: k_fft_y4) combined with Neumann or open x faces; also three steps of such a box against the oracle."""
     g, case = load_golden("cavity_nnn")
     case.ng[:] = ng
-    for d, pair in ((0, bx), (1, "DD")):
+    for d, pair in ((0, bx), (1, by)):
         for side in (0, 1):
             case.cbcpre[side, d] = pair[side]
-            case.cbcvel[side, d, :] = "N" if pair[side] == "D" else "D"
+            case.cbcvel[side, d, :] = "P" if pair[side] == "P" else ("N" if pair[side] == "D" else "D")
+            case.cbcsgs[side, d] = "P" if pair[side] == "P" else "D"
             case.bcvel[side, d, :] = 0.
     o = Oracle(case, nthreads=8); h = _hot(case)
     rng = np.random.RandomState(sum(ng))
