@@ -46,8 +46,9 @@ enum cales_field { CALES_U = 0, CALES_V = 1, CALES_W = 2, CALES_P = 3, CALES_PP 
 /* ---- host-only helpers (no GPU needed) -------------------------------------------------- */
 /* src/initgrid.f90:15  initgrid(gtype,n,gr,lz,dzc,dzf,zc,zf); arrays (0:n+1) */
 int cales_initgrid(int gtype, int n, double gr, double lz, double *dzc, double *dzf, double *zc, double *zf);
-/* src/initflow.f90:17  initflow(inivel,...,u,v,w,p): deterministic kinds only
- * (zer uni cou poi iop pdc tgv tgw ant duc); global haloed host arrays; returns 2 for RNG-based kinds */
+/* src/initflow.f90:17  initflow(inivel,...,u,v,w,p): zer uni cou poi iop pdc hdc hcp tgv tgw ant duc bit-compatible with the
+ * reference; log hcl tbl with their +-5 % noise from a counter-based generator (the reference uses the Fortran run-time's
+ * random_number: same distribution, other numbers); global haloed host arrays; returns 1 for an unknown kind */
 int cales_initflow(const cales_case *c, const char *inivel, int is_wallturb, double *u, double *v, double *w, double *p);
 /* src/sanity.f90:33-67 rules restated; returns 0 if the case is accepted */
 int cales_check_case(const cales_case *c, char *msg, int msglen);
