@@ -113,6 +113,7 @@ struct cales_ctx {
   bool visct_lazy = false; double *d_cs = nullptr;
   bool in_step = false;             // inside cales_step: the operator order is known, dead ghost work can be dropped
   bool skip_rhs_store = false;      // cales_step, third substep: see MomRkArgs::wr_new
+  double *d_stat2 = nullptr;
   double *d_stat = nullptr;      // partial sums and result of the plane statistics
   bool abct_ready = false, force_zeroed = false;
   double *d_abct = nullptr;      // tridiagonal coefficients in the chunked order of k_gaussel_tile
@@ -176,6 +177,7 @@ int op_helmholtz(cales_ctx *c, int ivel, double alpha);
 int op_correc(cales_ctx *c, double dtrk);
 int materialize_visct(cales_ctx *c);
 int op_stats_chan(cales_ctx *c, double *buf);
+int op_stats_chan_budget(cales_ctx *c, double *budget, double *leak);
 bool solver_can_fuse_fillps(cales_ctx *c);
 int op_force_from_partials(cales_ctx *c, int mask, const double *part, int nblk);
 int op_correc_updatep(cales_ctx *c, double dtrk, double alpha, int upd);

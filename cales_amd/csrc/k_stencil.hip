@@ -540,6 +540,134 @@ int op_stats_chan(cales_ctx *c, double *buf) {
   return 0;
 }
 
+// Second block of out1d_single_point_chan (output.f90:700-1001): the 38 plane sums of the mean-kinetic-energy and Reynolds-stress
+// budgets (transport, pressure-strain, dissipation pieces at cell centres and cell edges), same launch shape as the first block.
+#define NBUDGET 38
+__global__ __launch_bounds__(256) void k_stats_budget_partial(Geom g, double dx, double dy, const double *__restrict__ dzc, const double *__restrict__ dzf,
+                                                              const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ w,
+                                                              const double *__restrict__ p, double *__restrict__ part) {
+  __shared__ double sh[4];
+  const int k = blockIdx.y + 1;
+  double b[NBUDGET];
+#pragma unroll
+  for (int q = 0; q < NBUDGET; ++q) b[q] = 0.;
+  const long nplane = (long)g.n1 * g.n2, sj = g.s1, sk = g.s12;
+  const double zc = dzc[k], zcm = dzc[k - 1], zf = dzf[k], zfp = dzf[k + 1];
+  auto sq = [](double x) { return x * x; };
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nplane; q += (long)gridDim.x * 256) {
+    const int i = (int)(q % g.n1) + 1, j = (int)(q / g.n1) + 1;
+    const size_t c = g.ix(i, j, k);
+    const double uc = u[c], u_kp = u[c + sk], u_km = u[c - sk], u_im = u[c - 1], u_jp = u[c + sj], u_jm = u[c - sj];
+    const double u_im_kp = u[c - 1 + sk], u_im_km = u[c - 1 - sk], u_im_jp = u[c - 1 + sj], u_im_jm = u[c - 1 - sj];
+    const double vc = v[c], v_kp = v[c + sk], v_km = v[c - sk], v_ip = v[c + 1], v_im = v[c - 1], v_jm = v[c - sj];
+    const double v_ip_jm = v[c + 1 - sj], v_im_jm = v[c - 1 - sj], v_jm_kp = v[c - sj + sk], v_jm_km = v[c - sj - sk];
+    const double wc = w[c], w_kp = w[c + sk], w_km = w[c - sk], w_ip = w[c + 1], w_im = w[c - 1], w_jp = w[c + sj], w_jm = w[c - sj];
+    const double w_ip_km = w[c + 1 - sk], w_im_km = w[c - 1 - sk], w_jp_km = w[c + sj - sk], w_jm_km = w[c - sj - sk], w_ip_kp = w[c + 1 + sk];
+    const double pc = p[c], p_kp = p[c + sk];
+    const double dudz4 = 0.25 * ((u_kp - uc) / zc + (uc - u_km) / zcm + (u_im_kp - u_im) / zc + (u_im - u_im_km) / zcm);
+    const double dwdx4 = 0.25 * ((w_ip - wc) / dx + (wc - w_im) / dx + (w_ip_km - w_km) / dx + (w_km - w_im_km) / dx);
+    const double dudy4 = 0.25 * ((u_jp - uc) / dy + (uc - u_jm) / dy + (u_im_jp - u_im) / dy + (u_im - u_im_jm) / dy);
+    const double dwdy4 = 0.25 * ((w_jp - wc) / dy + (wc - w_jm) / dy + (w_jp_km - w_km) / dy + (w_km - w_jm_km) / dy);
+    b[0] += uc;
+    b[1] += 0.5 * (uc + u_kp);
+    b[2] += (u_kp - uc) / zc;
+    b[3] += (u_kp * u_kp - uc * uc) / zc;
+    b[4] += 0.25 * (u_kp + uc) * (wc + w_ip);
+    b[5] += 0.25 * (u_im + uc) * (wc + w_km);
+    b[6] += dudz4;
+    b[7] += 0.125 * sq(u_kp + uc) * (wc + w_ip);
+    b[8] += pc;
+    b[9] += (uc - u_im) / dx * pc;
+    b[10] += sq((uc - u_im) / dx) + 0.25 * (sq((u_jp - uc) / dy) + sq((uc - u_jm) / dy) + sq((u_im_jp - u_im) / dy) + sq((u_im - u_im_jm) / dy)) +
+             0.25 * (sq((u_kp - uc) / zc) + sq((uc - u_km) / zcm) + sq((u_im_kp - u_im) / zc) + sq((u_im - u_im_km) / zcm));
+    b[11] += (v_kp * v_kp - vc * vc) / zc;
+    b[12] += 0.125 * sq(v_kp + vc) * (wc + w_jp);
+    b[13] += (vc - v_jm) / dy * pc;
+    b[14] += 0.25 * (sq((v_ip - vc) / dx) + sq((vc - v_im) / dx) + sq((v_ip_jm - v_jm) / dx) + sq((v_jm - v_im_jm) / dx)) + sq((vc - v_jm) / dy) +
+             0.25 * (sq((v_kp - vc) / zc) + sq((vc - v_km) / zcm) + sq((v_jm_kp - v_jm) / zc) + sq((v_jm - v_jm_km) / zcm));
+    b[15] += 0.5 * ((w_kp * w_kp - wc * wc) / zfp + (wc * wc - w_km * w_km) / zf);
+    b[16] += wc * wc * wc;
+    b[17] += wc * 0.5 * (p_kp + pc);
+    b[18] += (wc - w_km) / zf * pc;
+    b[19] += 0.25 * (sq((w_ip - wc) / dx) + sq((wc - w_im) / dx) + sq((w_ip_km - w_km) / dx) + sq((w_km - w_im_km) / dx)) +
+             0.25 * (sq((w_jp - wc) / dy) + sq((wc - w_jm) / dy) + sq((w_jp_km - w_km) / dy) + sq((w_km - w_jm_km) / dy)) + sq((wc - w_km) / zf);
+    b[20] += 0.5 * (wc * wc + w_km * w_km);
+    b[21] += (0.25 * (wc + w_kp + w_ip_kp + w_ip) * u_kp - 0.25 * (wc + w_km + w_ip_km + w_ip) * uc) / zc;
+    b[22] += wc * wc;
+    b[23] += 0.125 * (u_kp + uc) * sq(wc + w_ip);
+    b[24] += 0.5 * (p_kp + pc);
+    b[25] += 0.25 * (uc + u_kp + u_im_kp + u_im) * 0.5 * (p_kp + pc);
+    b[26] += dudz4 * pc + dwdx4 * pc;
+    b[27] += (uc - u_im) / dx * dwdx4 + dudy4 * dwdy4 + dudz4 * ((wc - w_km) / zf);
+    b[28] += (u_kp - uc) / zc;
+    b[29] += sq((uc - u_im) / dx); b[30] += sq((u_jp - uc) / dy); b[31] += sq((u_kp - uc) / zc);
+    b[32] += sq((v_ip - vc) / dx); b[33] += sq((vc - v_jm) / dy); b[34] += sq((v_kp - vc) / zc);
+    b[35] += sq((w_ip - wc) / dx); b[36] += sq((w_jp - wc) / dy); b[37] += sq((wc - w_km) / zf);
+  }
+#pragma unroll
+  for (int q = 0; q < NBUDGET; ++q) {
+    const double r = block_reduce<0>(b[q], sh);
+    if (threadIdx.x == 0) part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NBUDGET + q] = r;
+  }
+}
+// Third block (output.f90:1005-1041): six divergence measures per plane -- max |div|, sum |div|, sum div, and the same weighted by dzf(k)
+__global__ __launch_bounds__(256) void k_stats_leak_partial(Geom g, double dx, double dy, const double *__restrict__ dzf, const double *__restrict__ u,
+                                                            const double *__restrict__ v, const double *__restrict__ w, double *__restrict__ part) {
+  __shared__ double sh[4];
+  const int k = blockIdx.y + 1;
+  double mx = 0., sa = 0., sd = 0.;
+  const long nplane = (long)g.n1 * g.n2;
+  const double zf = dzf[k];
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nplane; q += (long)gridDim.x * 256) {
+    const int i = (int)(q % g.n1) + 1, j = (int)(q / g.n1) + 1;
+    const size_t c = g.ix(i, j, k);
+    const double div = (w[c] - w[c - g.s12]) / zf + (v[c] - v[c - g.s1]) / dy + (u[c] - u[c - 1]) / dx;
+    mx = fmax(mx, fabs(div)); sa += fabs(div); sd += div;
+  }
+  const double rm = block_reduce<1>(mx, sh), ra = block_reduce<0>(sa, sh), rd = block_reduce<0>(sd, sh);
+  if (threadIdx.x == 0) { double *o = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3; o[0] = rm; o[1] = ra; o[2] = rd; }
+}
+__global__ void k_stats_fold_n(int nstat, int n3, int nbx, double ratio, const double *__restrict__ part, double *__restrict__ out) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= nstat * n3) return;
+  const int q = t % nstat, k = t / nstat;
+  double a = 0.;
+  for (int bx = 0; bx < nbx; ++bx) a += part[((size_t)k * nbx + bx) * nstat + q];
+  out[t] = a * ratio;
+}
+__global__ void k_stats_leak_fold(int n3, int nbx, double ratio, const double *__restrict__ dzf, const double *__restrict__ part, double *__restrict__ out) {
+  const int k = blockIdx.x * 64 + threadIdx.x;      // plane k+1
+  if (k >= n3) return;
+  double mx = 0., sa = 0., sd = 0.;
+  for (int bx = 0; bx < nbx; ++bx) { const double *o = part + ((size_t)k * nbx + bx) * 3; mx = fmax(mx, o[0]); sa += o[1]; sd += o[2]; }
+  const double zf = dzf[k + 1];
+  double *r = out + 6 * (size_t)k;
+  r[0] = mx; r[1] = sa * ratio; r[2] = sd * ratio; r[3] = mx * zf; r[4] = sa * zf * ratio; r[5] = sd * zf * ratio;
+}
+// budget: (38, n3), leak: (6, n3), column-major on the host (either may be NULL); this rank's rows when there are several ranks
+int op_stats_chan_budget(cales_ctx *c, double *budget, double *leak) {
+  const int nbx = 8, n3 = c->n[2];
+  const size_t need = (size_t)NBUDGET * n3 * (nbx + 1);
+  if (!c->d_stat2) HIPCHK(c, hipMalloc(&c->d_stat2, need * sizeof(double)));
+  double *part = c->d_stat2, *out = c->d_stat2 + (size_t)NBUDGET * n3 * nbx;
+  const double ratio = c->dl[0] * c->dl[1] / (c->C.l[0] * c->C.l[1]);
+  if (budget) {
+    hipLaunchKernelGGL(k_stats_budget_partial, dim3(nbx, n3), dim3(256), 0, c->stream, c->g, c->dl[0], c->dl[1], c->d_dzc, c->d_dzf, c->f[CALES_U], c->f[CALES_V],
+                       c->f[CALES_W], c->f[CALES_P], part);
+    hipLaunchKernelGGL(k_stats_fold_n, dim3((NBUDGET * n3 + 255) / 256), dim3(256), 0, c->stream, NBUDGET, n3, nbx, ratio, part, out);
+    HIPCHK(c, hipMemcpyAsync(budget, out, (size_t)NBUDGET * n3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  if (leak) {
+    hipLaunchKernelGGL(k_stats_leak_partial, dim3(nbx, n3), dim3(256), 0, c->stream, c->g, c->dl[0], c->dl[1], c->d_dzf, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W], part);
+    hipLaunchKernelGGL(k_stats_leak_fold, dim3((n3 + 63) / 64), dim3(64), 0, c->stream, n3, nbx, ratio, c->d_dzf, part, out);
+    HIPCHK(c, hipMemcpyAsync(leak, out, (size_t)6 * n3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------ chkdt (chkdt.f90:50-98)
 template <int IMP>
 __global__ __launch_bounds__(256) void k_chkdt_partial(Geom g, double dxi, double dyi, double visc, const double *__restrict__ dzci,

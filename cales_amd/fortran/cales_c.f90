@@ -67,6 +67,9 @@ module cales_c
     integer(c_int) function cales_out1d_single_point_chan(ctx,buf) bind(C,name='cales_out1d_single_point_chan')
       import; type(c_ptr), value :: ctx; real(c_double) :: buf(27,*)
     end function
+    integer(c_int) function cales_out1d_chan_budgets(ctx,budget,leakage) bind(C,name='cales_out1d_chan_budgets')
+      import; type(c_ptr), value :: ctx; real(c_double) :: budget(38,*),leakage(6,*)
+    end function
     integer(c_int) function cales_step(ctx,dt) bind(C,name='cales_step')
       import; type(c_ptr), value :: ctx; real(c_double), value :: dt
     end function

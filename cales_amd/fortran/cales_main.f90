@@ -258,7 +258,7 @@ contains
   end subroutine visu_3d
   subroutine out1d_chan_stats(fname)    ! the velstats_fld_*.out/.bin pair of out1d_single_point_chan, src/output.f90:683-699
     character(len=*), intent(in) :: fname
-    real(rp), allocatable :: buf(:,:)
+    real(rp), allocatable :: buf(:,:),leak(:,:)
     integer :: iu,kk,q
     allocate(buf(27,ng(3)))
     call chk(cales_out1d_single_point_chan(ctx,buf))
@@ -268,6 +268,21 @@ contains
     end do
     close(iu)
     open(newunit=iu,file=fname//'.bin',access='stream'); write(iu) buf; close(iu)
+    deallocate(buf)
+    allocate(buf(38,ng(3)),leak(6,ng(3)))      ! budgets and leakage, src/output.f90:990-1055
+    call chk(cales_out1d_chan_budgets(ctx,buf,leak))
+    open(newunit=iu,file=fname//'_reystr_budget.out')
+    do kk=1,ng(3)
+      write(iu,'(*(es24.16e3,1x))') zc(kk),zf(kk),(buf(q,kk),q=1,38),dzc(kk),dzf(kk)
+    end do
+    close(iu)
+    open(newunit=iu,file=fname//'_reystr_budget.bin',access='stream'); write(iu) buf; close(iu)
+    open(newunit=iu,file=fname//'_leakage.out')
+    do kk=1,ng(3)
+      write(iu,'(*(es24.16e3,1x))') zc(kk),zf(kk),(leak(q,kk),q=1,6),dzc(kk),dzf(kk)
+    end do
+    close(iu)
+    open(newunit=iu,file=fname//'_leakage.bin',access='stream'); write(iu) leak; close(iu)
   end subroutine out1d_chan_stats
   subroutine out0d(fname,n,vv)    ! src/output.f90:18-37
     character(len=*), intent(in) :: fname

@@ -184,6 +184,12 @@ class HotPath:
         self._chk(self.L.cales_out1d_single_point_chan(self.h, _p(buf)))
         return buf
 
+    def stats_chan_budgets(self):
+        """Second and third block of out1d_single_point_chan (src/output.f90:700-1055): (38, n3) budget sums and (6, n3) divergence measures."""
+        b = np.zeros((38, self.n[2]), order="F"); l = np.zeros((6, self.n[2]), order="F")
+        self._chk(self.L.cales_out1d_chan_budgets(self.h, _p(b), _p(l)))
+        return b, l
+
     def step(self, dt: float):
         """Three RK substeps, src/main.f90:417-508, queued without host synchronisation."""
         self._chk(self.L.cales_step(self.h, float(dt)))

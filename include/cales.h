@@ -93,6 +93,11 @@ int cales_chkdiv(cales_ctx *ctx, double *divtot, double *divmax);           /* s
  * ranks: the sums over this rank's rows -- the caller adds the ranks as the reference does (output.f90:691). */
 #define CALES_NSTATS_CHAN 27
 int cales_out1d_single_point_chan(cales_ctx *ctx, double *buf);
+/* second and third block of the same routine (src/output.f90:700-1055): budget(38, n3) = the columns of velstats_fld_*_reystr_budget.out/.bin,
+ * leakage(6, n3) = those of velstats_fld_*_leakage.out/.bin; either pointer may be NULL (sync) */
+#define CALES_NBUDGET_CHAN 38
+#define CALES_NLEAKAGE_CHAN 6
+int cales_out1d_chan_budgets(cales_ctx *ctx, double *budget, double *leakage);
 
 /* one time step = 3 RK substeps in the order of src/main.f90:417-508; no host synchronisation */
 int cales_step(cales_ctx *ctx, double dt);

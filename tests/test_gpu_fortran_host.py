@@ -81,6 +81,9 @@ def test_fortran_host_equals_python_host(tmp_path, name):
     txt = np.loadtxt(os.path.join(tmp_path, "velstats_fld_0000004.out"))
     assert txt.shape == (ng[2], 31) and np.array_equal(txt[:, 2:29], st.T)
     assert np.array_equal(np.fromfile(os.path.join(tmp_path, "velstats_fld_0000004.bin")).reshape((27, ng[2]), order="F"), st)
+    bud, leak = h.stats_chan_budgets()
+    assert np.array_equal(np.fromfile(os.path.join(tmp_path, "velstats_fld_0000004_reystr_budget.bin")).reshape((38, ng[2]), order="F"), bud)
+    assert np.array_equal(np.loadtxt(os.path.join(tmp_path, "velstats_fld_0000004_leakage.out"))[:, 2:8], leak.T)
     # plane and volume dumps (out2d.h90 / out3d.h90 defaults) with their log lines (output.f90:244-272)
     sl = np.fromfile(os.path.join(tmp_path, "vex_slice_fld_0000004.bin")).reshape((ng[0], ng[2]), order="F")
     assert np.array_equal(sl, gu[1:-1, ng[1] // 2, 1:-1])

@@ -317,3 +317,30 @@ def test_plane_statistics(name, ng):
     tol = 1e-12 * np.abs(ref).max(axis=1, keepdims=True) + 1e-13
     assert (np.abs(got - ref) <= tol).all(), np.argwhere(np.abs(got - ref) > tol)[:5]
     h.close()
+
+
+@pytest.mark.parametrize("name,ng", [("chan_dsmag", (32, 16, 12)), ("chan_smag_wm", (40, 18, 20)), ("cavity_nnn", (20, 36, 10))])
+def test_plane_budgets_and_leakage(name, ng):
+    """cales_out1d_chan_budgets (38 + 6 plane measures of output.f90:700-1055) against the numpy restatement oracle/stats_np.py"""
+    from cales_amd.hotpath import initflow
+    from oracle import stats_np
+    g, case = load_golden(name)
+    case.ng[:] = ng
+    o = Oracle(case); h = _hot(case)
+    u, v, w, p = initflow(case)
+    rng = np.random.RandomState(4)
+    for a in (u, v, w):
+        a[1:-1, 1:-1, 1:-1] += 0.05 * (rng.rand(*ng) - 0.5)
+    h.upload(u, v, w, p); h.startup()
+    dt = 0.5 * h.chkdt()
+    for _ in range(2):
+        h.step(dt)
+    gu, gv, gw, gp, _ = h.download()
+    gr = o.grid(); dx, dy = float(case.l[0]) / ng[0], float(case.l[1]) / ng[1]
+    rb = stats_np.budget_terms(gu, gv, gw, gp, dx, dy, gr["dzc"], gr["dzf"], float(case.l[0]), float(case.l[1]))
+    rl = stats_np.leakage_terms(gu, gv, gw, dx, dy, gr["dzf"], float(case.l[0]), float(case.l[1]))
+    bud, leak = h.stats_chan_budgets()
+    for got, ref in ((bud, rb), (leak, rl)):
+        tol = 1e-12 * np.abs(ref).max(axis=1, keepdims=True) + 1e-12 * max(np.abs(gu).max() * ng[0] / float(case.l[0]), 1.) ** 2
+        assert (np.abs(got - ref) <= tol).all(), np.argwhere(np.abs(got - ref) > tol)[:5]
+    h.close()

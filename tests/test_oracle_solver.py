@@ -100,3 +100,31 @@ def test_plane_statistics_known_answers():
     assert np.allclose(st[24], -nu * b, rtol=1e-12)                       # -visct (du/dz + dw/dx) at the cell edge
     for q in (1, 2, 4, 5, 6, 15, 17, 21, 22, 23):
         assert np.abs(st[q]).max() < 1e-13
+
+
+def test_plane_budgets_known_answers():
+    """oracle/stats_np.py (second and third block of out1d_single_point_chan, output.f90:700-1055) on fields with known plane values:
+    u = a + b z (shear), v = c x-independent sine in x? no: v = s sin(2 pi x / lx), w = 0, p = p0."""
+    from oracle import stats_np
+    g, case = load_golden("chan_dsmag")
+    o = Oracle(case); gr = o.grid(); zc = gr["zc"]; n1, n2, n3 = o.n
+    lx, ly = float(case.l[0]), float(case.l[1]); dx, dy = lx / n1, ly / n2
+    a, b, s0, p0 = 0.7, 1.3, 0.4, -2.
+    u = o.zeros(); v = o.zeros(); w = o.zeros(); p = o.zeros()
+    u[:, :, :] = (a + b * zc)[None, None, :]
+    xc = (np.arange(n1 + 2) - 0.5) * dx
+    v[:, :, :] = (s0 * np.sin(2 * np.pi * xc / lx))[:, None, None]
+    p[:] = p0
+    bt = stats_np.budget_terms(u, v, w, p, dx, dy, gr["dzc"], gr["dzf"], lx, ly)
+    lk = stats_np.leakage_terms(u, v, w, dx, dy, gr["dzf"], lx, ly)
+    k = np.arange(1, n3 + 1)
+    assert np.allclose(bt[0], a + b * zc[k], rtol=1e-13) and np.allclose(bt[8], p0) and np.allclose(bt[24], p0)
+    for q in (2, 6, 28):                                   # du/dz at the edge, its 4-point cell-centre average, the split term
+        assert np.allclose(bt[q], b, rtol=1e-12), q
+    assert np.allclose(bt[31], b * b, rtol=1e-12) and np.allclose(bt[10], b * b, rtol=1e-12)      # (du/dz)^2; uu dissipation = that alone
+    dvdx2 = (s0 * 2 * np.sin(np.pi * dx / lx) / dx) ** 2 / 2          # plane mean of the squared one-cell difference of the sine
+    assert np.allclose(bt[32], dvdx2, rtol=1e-12) and np.allclose(bt[14], dvdx2, rtol=1e-12)
+    assert np.allclose(bt[26], b * p0, rtol=1e-12)                    # pressure-strain of uw: <du/dz> p
+    for q in (4, 5, 9, 13, 15, 16, 17, 18, 19, 20, 21, 22, 23, 27, 33, 35, 36, 37):
+        assert np.abs(bt[q]).max() < 1e-13, q
+    assert np.abs(lk).max() < 1e-13
