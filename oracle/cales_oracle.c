@@ -882,31 +882,55 @@ void o_solver_gaussel_z(ostate *s, int ivel, double alpha, double *q) {  /* solv
 int o_solver_helmholtz(ostate *s, int ivel, double alpha, double *q) {
   const int *n = s->n; const size_t s1 = s->s1, s2 = s->s2; int n3 = n[2];
   const char *bcv = &s->cbcvel[6*(ivel-1)];
-  if (!(bcv[0] == 'P' && bcv[1] == 'P' && bcv[2] == 'P' && bcv[3] == 'P' && CBP(0,1) == 'P' && CBP(0,2) == 'P')) return 1;
+  char cf[3] = {'c','c','c'}; cf[ivel-1] = 'f';
+  /* transform kinds, sizes, eigenvalues and normalisation of THIS component (initsolver.f90:66-98 with c_or_f, fft.f90:63-143) */
+  int kf[2], kb[2], cut[2]; double nrm[2][2], normfft = 1.;
+  double *lam[2];
+  for (int d = 0; d < 2; d++) {
+    find_fft(bcv + 2*d, cf[d], &kf[d], &kb[d], nrm[d]);
+    cut[d] = (bcv[2*d] == 'D' && bcv[2*d+1] == 'D' && cf[d] == 'f') ? 1 : 0;      /* one point less with Dirichlet at the faces */
+    lam[d] = dalloc(n[d]); eigenvalues(n[d], bcv + 2*d, cf[d], lam[d]);
+    for (int l = 0; l < n[d]; l++) lam[d][l] = lam[d][l]*(s->dli[d]*s->dli[d]);
+    normfft = normfft*nrm[d][0]*(s->P.ng[d] + nrm[d][1] - cut[d]);
+  }
+  normfft = 1./normfft;
   double *aa = dalloc(n3), *bb = dalloc(n3), *cc = dalloc(n3);
   for (int k = 0; k < n3; k++) { aa[k] = s->av[ivel-1][k]*alpha; bb[k] = s->bv[ivel-1][k]*alpha + 1.; cc[k] = s->cv[ivel-1][k]*alpha; }
   int qq = (ivel == 3 && bcv[5] == 'D') ? 1 : 0, periodic = bcv[4] == 'P' && bcv[5] == 'P';
   #pragma omp parallel for collapse(2) num_threads(s->nthreads)
-  for (int k = 1; k <= n[2]; k++) for (int j = 1; j <= n[1]; j++) o_r2r(O_R2HC, n[0], &q[IX(1,j,k)], 1);
+  for (int k = 1; k <= n[2]; k++) for (int j = 1; j <= n[1]; j++) o_r2r(kf[0], n[0] - cut[0], &q[IX(1,j,k)], 1);
   #pragma omp parallel for collapse(2) num_threads(s->nthreads)
-  for (int k = 1; k <= n[2]; k++) for (int i = 1; i <= n[0]; i++) o_r2r(O_R2HC, n[1], &q[IX(i,1,k)], (int)s1);
+  for (int k = 1; k <= n[2]; k++) for (int i = 1; i <= n[0]; i++) o_r2r(kf[1], n[1] - cut[1], &q[IX(i,1,k)], (int)s1);
   #pragma omp parallel num_threads(s->nthreads)
   {
     double *work = (double *)malloc(sizeof(double)*4*n3);
     #pragma omp for collapse(2)
     for (int j = 1; j <= n[1]; j++) for (int i = 1; i <= n[0]; i++)
-      gaussel_line(n3 - qq, aa, bb, cc, s->lambdaxy[(i-1) + (size_t)n[0]*(j-1)]*alpha, periodic, &q[IX(i,j,1)], (int)(s1*s2), work);
+      gaussel_line(n3 - qq, aa, bb, cc, (lam[0][i-1] + lam[1][j-1])*alpha, periodic, &q[IX(i,j,1)], (int)(s1*s2), work);
     free(work);
   }
   #pragma omp parallel for collapse(2) num_threads(s->nthreads)
-  for (int k = 1; k <= n[2]; k++) for (int i = 1; i <= n[0]; i++) o_r2r(O_HC2R, n[1], &q[IX(i,1,k)], (int)s1);
+  for (int k = 1; k <= n[2]; k++) for (int i = 1; i <= n[0]; i++) o_r2r(kb[1], n[1] - cut[1], &q[IX(i,1,k)], (int)s1);
   #pragma omp parallel for collapse(2) num_threads(s->nthreads)
   for (int k = 1; k <= n[2]; k++) for (int j = 1; j <= n[1]; j++) {
-    o_r2r(O_HC2R, n[0], &q[IX(1,j,k)], 1);
-    for (int i = 1; i <= n[0]; i++) q[IX(i,j,k)] = q[IX(i,j,k)]*s->normfft;
+    o_r2r(kb[0], n[0] - cut[0], &q[IX(1,j,k)], 1);
+    for (int i = 1; i <= n[0]; i++) q[IX(i,j,k)] = q[IX(i,j,k)]*normfft;
   }
-  free(aa); free(bb); free(cc);
+  free(aa); free(bb); free(cc); free(lam[0]); free(lam[1]);
   return 0;
+}
+/* boundary r.h.s. of all three directions for the 3-D implicit step (main.f90:424-431) */
+void o_updt_rhs_b_vel(ostate *s, int ivel, double alpha, double *q) {
+  const int *n = s->n; char cf[3] = {'c','c','c'}; cf[ivel-1] = 'f';
+  size_t nx = (size_t)n[1]*n[2]*2, ny = (size_t)n[0]*n[2]*2, nz = (size_t)n[0]*n[1]*2;
+  double *rx = dalloc(nx), *ry = dalloc(ny), *rz = dalloc(nz);
+  const obound *bc = ivel == 1 ? &s->bcu : ivel == 2 ? &s->bcv : &s->bcw;
+  cmpt_rhs_b(s, &s->cbcvel[6*(ivel-1)], bc, cf, rx, ry, rz);
+  for (size_t i = 0; i < nx; i++) rx[i] = rx[i]*alpha;
+  for (size_t i = 0; i < ny; i++) ry[i] = ry[i]*alpha;
+  for (size_t i = 0; i < nz; i++) rz[i] = rz[i]*alpha;
+  updt_rhs_b(s, cf, &s->cbcvel[6*(ivel-1)], rx, ry, rz, q);
+  free(rx); free(ry); free(rz);
 }
 
 /* ------------------------------------------------------------------ diagnostics */
@@ -1241,7 +1265,7 @@ void o_step(ostate *s, double dt, double *u, double *v, double *w, double *p, do
     } else if (s->P.impdiff == 1) {      /* x and y periodic only: their boundary r.h.s. planes vanish */
       alpha = -.5*s->visc*dtrk;
       double *q[3] = {u, v, w};
-      for (int iv = 1; iv <= 3; iv++) { o_updt_rhs_b_velz(s, iv, alpha, q[iv-1]); o_solver_helmholtz(s, iv, alpha, q[iv-1]); }
+      for (int iv = 1; iv <= 3; iv++) { o_updt_rhs_b_vel(s, iv, alpha, q[iv-1]); o_solver_helmholtz(s, iv, alpha, q[iv-1]); }
     }
     for (int c = 0; c < 3; c++) dpdl[c] = dpdl[c] + f[c];
     o_bounduvw(s, 1, 0, u, v, w);

@@ -63,6 +63,7 @@ void o_bulk_forcing(ostate *s, const double *f, double *u, double *v, double *w)
 double o_bulk_mean(ostate *s, int c_or_f, const double *p);
 void o_fillps(ostate *s, double dtrki, const double *u, const double *v, const double *w, double *pp);
 void o_updt_rhs_b_p(ostate *s, double *pp);
+void o_updt_rhs_b_vel(ostate *s, int ivel, double alpha, double *q);
 void o_updt_rhs_b_velz(ostate *s, int ivel, double alpha, double *q);
 void o_solver(ostate *s, double *pp);                          /* Poisson, cbcpre, 'c','c','c' */
 void o_solver_gaussel_z(ostate *s, int ivel, double alpha, double *q);

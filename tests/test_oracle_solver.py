@@ -128,3 +128,39 @@ def test_plane_budgets_known_answers():
     for q in (4, 5, 9, 13, 15, 16, 17, 18, 19, 20, 21, 22, 23, 27, 33, 35, 36, 37):
         assert np.abs(bt[q]).max() < 1e-13, q
     assert np.abs(lk).max() < 1e-13
+
+
+@pytest.mark.parametrize("ivel", [1, 2, 3])
+def test_helmholtz_3d_identity_walls(ivel):
+    """The same identity in a box with no-slip walls on all six faces (face-centred RODFT00 along the component's own direction,
+    RODFT10/01 along the others, find_fft/eigenvalues with c_or_f, initsolver.f90:66-98, fft.f90:192-245): (1 + alpha L_h) x = r with
+    the discrete Laplacian of the staggered component -- ghost = -interior for a cell-centred direction, wall faces = 0 for its own."""
+    g, case = load_golden("cavity_nnn")
+    case.ng[:] = (12, 10, 14); case.impdiff = 1
+    o = Oracle(case)
+    n = [int(x) for x in case.ng]
+    nn = list(n); nn[ivel - 1] -= 1                       # the wall face of the component is not an unknown
+    _, a, b, c, _ = o.solver_operands(ivel)
+    rng = np.random.RandomState(10 + ivel)
+    rhs = o.zeros(); rhs[1:nn[0] + 1, 1:nn[1] + 1, 1:nn[2] + 1] = rng.rand(*nn) - 0.5
+    q = rhs.copy(order="F")
+    alpha = -0.37
+    o.solver_helmholtz(ivel, alpha, q)
+    x = q[1:nn[0] + 1, 1:nn[1] + 1, 1:nn[2] + 1]
+
+    def d2(x, axis, own, h2i):
+        pad = [(1, 1) if ax == axis else (0, 0) for ax in range(3)]
+        e = np.pad(x, pad)                                # zero wall faces (own direction)
+        if not own:                                       # cell-centred: ghost = -first interior value (wall value 0 half a cell away)
+            idx0 = [slice(None)] * 3; idx1 = [slice(None)] * 3
+            idx0[axis] = 0; idx1[axis] = 1; e[tuple(idx0)] = -e[tuple(idx1)]
+            idx0[axis] = -1; idx1[axis] = -2; e[tuple(idx0)] = -e[tuple(idx1)]
+        sl = lambda s_: tuple(s_ if ax == axis else slice(None) for ax in range(3))
+        return (e[sl(slice(2, None))] - 2 * e[sl(slice(1, -1))] + e[sl(slice(0, -2))]) * h2i
+    lap = d2(x, 0, ivel == 1, (n[0] / case.l[0]) ** 2) + d2(x, 1, ivel == 2, (n[1] / case.l[1]) ** 2)
+    nz = nn[2]
+    lz = b[None, None, :nz] * x
+    lz[:, :, 1:] += a[None, None, 1:nz] * x[:, :, :-1]
+    lz[:, :, :-1] += c[None, None, :nz - 1] * x[:, :, 1:]
+    back = x + alpha * (lap + lz)
+    assert np.abs(back - rhs[1:nn[0] + 1, 1:nn[1] + 1, 1:nn[2] + 1]).max() < 1e-12
