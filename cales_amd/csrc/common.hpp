@@ -111,6 +111,7 @@ struct cales_ctx {
   // dynamic model, fast path: the eddy-viscosity field holds |S| and d_cs(0:n3+1) the clipped plane coefficients <LM>/<MM> until somebody
   // other than the fused momentum kernel reads it (materialize_visct); visct = |S| * cs(k) is the same product either way
   bool visct_lazy = false; double *d_cs = nullptr;
+  void *cur_velset = nullptr;       // k_solver.hip: transform set of the velocity component being solved by op_helmholtz
   bool in_step = false;             // inside cales_step: the operator order is known, dead ghost work can be dropped
   bool skip_rhs_store = false;      // cales_step, third substep: see MomRkArgs::wr_new
   double *d_stat2 = nullptr;

@@ -267,9 +267,14 @@ int hs_check_case(const cales_case *cs, std::string &msg) {
   if (cs->sgstype < 0 || cs->sgstype > 2) { msg = "unknown SGS model"; return 1; }
   if (cs->sgstype == 1 && cs->nranks > 2 && cs->cbcvel[0 + 2 * 1 + 6 * 1] == 'D' && cs->cbcvel[1 + 2 * 1 + 6 * 1] == 'D') {
     msg = "more than two subdomains between two opposite walls (sanity.f90:98-111)"; return 1; }
-  if (cs->impdiff == 1) {   // Helmholtz solves of the velocity need face-centred transform kinds unless x and y are periodic
-    for (int iv = 0; iv < 3; ++iv) for (int q = 0; q < 4; ++q)
-      if (cs->cbcvel[6 * iv + q] != 'P') { msg = "3-D implicit diffusion (_IMPDIFF without _IMPDIFF_1D) is provided for periodic x and y only"; return 1; }
+  if (cs->impdiff == 1) {   // Helmholtz solves of the velocity: periodic or no-slip/no-penetration (homogeneous Dirichlet) pairs in x and y
+    for (int iv = 0; iv < 3; ++iv) for (int d = 0; d < 2; ++d) {
+      const std::string b = pr(cs->cbcvel + 6 * iv, d);
+      if (b != "PP" && b != "DD") { msg = "3-D implicit diffusion (_IMPDIFF without _IMPDIFF_1D) is provided for periodic or wall (DD) velocity BCs in x and y"; return 1; }
+      if (b == "DD" && (cs->bcvel[0 + 2 * d + 6 * iv] != 0. || cs->bcvel[1 + 2 * d + 6 * iv] != 0.)) {
+        msg = "3-D implicit diffusion: wall velocities in x and y must be zero (moving walls only in z)"; return 1; }
+    }
+    if (cs->nranks > 1) for (int iv = 0; iv < 2; ++iv) if (pr(cs->cbcvel + 6 * iv, iv) == "DD") { msg = "3-D implicit diffusion with walls in x or y needs one rank"; return 1; }
   }
   if (cs->impdiff < 0 || cs->impdiff > 2) { msg = "impdiff must be 0, 1 or 2"; return 1; }
   // transforms offered: in y periodic and cell-centred Neumann-Neumann (what the reference's GPU path offers in x and y,

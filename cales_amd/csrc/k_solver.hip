@@ -12,6 +12,8 @@
 // Spectral layout differs from FFTW's half-complex order; eigenvalues are laid out to match, so the
 // solution p = solver(rhs) is the same discrete function (checked against the oracle).
 #include "common.hpp"
+#include <list>
+#include <mutex>
 
 struct cpx { double x, y; };
 __device__ inline cpx cadd(cpx a, cpx b) { return {a.x + b.x, a.y + b.y}; }
@@ -327,6 +329,41 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const
       __syncthreads();
     }
   }
+}
+
+// DST-I (RODFT00, fft.f90:192-245 with c_or_f = 'f' and Dirichlet on both faces): the transform of a velocity component along its own
+// wall-normal direction in the 3-D implicit step -- n-1 unknowns j = 1..n-1 between the wall faces 0 and n. Odd extension to 2n points
+// through one complex FFT of length 2n per line: Z_k = sum z_j e^{-i pi j k/n} = -i Y_k with Y_k = 2 sum x_j sin(pi j k/n). Linear, so a
+// complex column (y direction: real and imaginary part of an x mode) goes through as it is; self-inverse up to 2n.
+// DIR 0: rows along x of a real field (p + 1 = element i = 1), one row per block, coefficient k at the place of x_k, scaled by `scale`;
+// DIR 1: columns along y of the complex spectrum, one column per block.
+template <int DIR>
+__global__ __launch_bounds__(256) void k_dst1(Geom g, FftPlan P, int ncols, const cpx *__restrict__ tw, double *__restrict__ p, double scale,
+                                              Spec S, double2 *__restrict__ pc) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int N2 = P.N, n = N2 / 2, ld = N2 + 1, t = threadIdx.x, T = blockDim.x;
+  cpx *A = reinterpret_cast<cpx *>(smem), *B = A + ld;
+  int j = 0, k = 0, m = 0;
+  if (DIR == 0) { const long r = blockIdx.x; j = (int)(r % g.n2) + 1; k = (int)(r / g.n2) + 1; }
+  else { m = blockIdx.x; k = blockIdx.y + 1; }
+  double *specd = reinterpret_cast<double *>(pc);
+  auto slot = [&](int e) -> double & { return specd[2 * S.at_slab(g, e >> 1, j, k) + (e & 1)]; };      // real x mode e of row (j,k)
+  for (int q = t; q < N2; q += T) {
+    cpx z = {0., 0.};
+    const int jj = q < n ? q : N2 - q;                    // |index| of the odd extension; 0 and n are the wall faces
+    if (q != 0 && q != n) {
+      if (DIR == 0) z.x = slot(jj - 1); else { const double2 v = pc[S.at_mode(g, m, jj, k)]; z = cpx{v.x, v.y}; }
+      if (q > n) { z.x = -z.x; z.y = -z.y; }
+    }
+    A[q] = z;
+  }
+  __syncthreads();
+  cpx *Z = fft_line<0>(P, A, B, t, T, tw);
+  for (int kk = t + 1; kk < n; kk += T) {                 // Y_k = i Z_k
+    const cpx y = {-Z[kk].y, Z[kk].x};
+    if (DIR == 0) slot(kk - 1) = y.x * scale; else pc[S.at_mode(g, m, kk, k)] = make_double2(y.x * scale, y.y * scale);
+  }
+  (void)ncols; (void)p;
 }
 
 // DCT-IV / DST-IV along y (pressure Neumann on one y face and Dirichlet on the other: REDFT11 / RODFT11, fft.f90:192-245), the y twin of
@@ -952,9 +989,14 @@ __global__ __launch_bounds__(256) void k_gaussel(Geom g, int nz, int ncol, int n
 
 // ------------------------------------------------------------------------------------------ host side
 struct SolverPlans { FftPlan py4; int CBy4; size_t shy4; FftPlan px, py; int Rx, CBy; size_t shx, shy; bool x8, y8; int x8_threads, y8_threads; size_t shx8, shy8; };
-struct PlanSlot { cales_ctx *ctx; SolverPlans sp; };
-static std::vector<PlanSlot> g_slots;
-static SolverPlans *find_plans(cales_ctx *c) { for (auto &s : g_slots) if (s.ctx == c) return &s.sp; return nullptr; }
+struct VelSet { bool ready = false; int xkind = 0, ykind = 0; double *lamx = nullptr, *lamy = nullptr; double normfft = 1.; FftPlan p1x, p1y; double *tw1x = nullptr, *tw1y = nullptr; };
+struct PlanSlot { cales_ctx *ctx; SolverPlans sp; VelSet vs[3]; };
+// one entry per context; a list (stable addresses) behind a mutex: contexts are created and destroyed from several host threads in the
+// loopback tests while others hold pointers to their own entry
+static std::list<PlanSlot> g_slots;
+static std::mutex g_slots_mx;
+static PlanSlot *find_slot(cales_ctx *c) { std::lock_guard<std::mutex> lk(g_slots_mx); for (auto &s : g_slots) if (s.ctx == c) return &s; return nullptr; }
+static SolverPlans *find_plans(cales_ctx *c) { PlanSlot *s = find_slot(c); return s ? &s->sp : nullptr; }
 
 bool solver_can_fuse_fillps(cales_ctx *c) { SolverPlans *sp = find_plans(c); return sp && sp->x8; }
 
@@ -1055,11 +1097,14 @@ int solver_setup(cales_ctx *c) {
       HIPCHK(c, hipMemcpy(c->d_bv[iv], b.data(), n3 * sizeof(double), hipMemcpyHostToDevice));
       HIPCHK(c, hipMemcpy(c->d_cv[iv], cc.data(), n3 * sizeof(double), hipMemcpyHostToDevice));
     }
-  g_slots.push_back({c, sp});
+  { PlanSlot ps_; ps_.ctx = c; ps_.sp = sp; std::lock_guard<std::mutex> lk(g_slots_mx); g_slots.push_back(ps_); }
   return 0;
 }
 void solver_teardown(cales_ctx *c) {
-  for (size_t q = 0; q < g_slots.size(); ++q) if (g_slots[q].ctx == c) { g_slots.erase(g_slots.begin() + q); break; }
+  { std::lock_guard<std::mutex> lk(g_slots_mx);
+    for (auto it = g_slots.begin(); it != g_slots.end(); ++it) if (it->ctx == c) {
+      for (auto &V : it->vs) { if (V.lamx) hipFree(V.lamx); if (V.lamy) hipFree(V.lamy); if (V.tw1x) hipFree(V.tw1x); if (V.tw1y) hipFree(V.tw1y); }
+      g_slots.erase(it); break; } }
   hipFree(c->d_lamx); hipFree(c->d_lamy); hipFree(c->d_a); hipFree(c->d_b); hipFree(c->d_c);
   hipFree(c->d_twx); hipFree(c->d_twx_post); hipFree(c->d_twy); hipFree(c->d_twy_post); hipFree(c->scr_twyd); hipFree(c->d_tw4x); if (c->d_tw4y) hipFree(c->d_tw4y); if (c->d_twy4) hipFree(c->d_twy4);
   for (int iv = 0; iv < 3; ++iv) hipFree(c->d_av[iv]);
@@ -1074,6 +1119,9 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
   const int mh = n[0] / 2 + 1, n2g = c->C.ng[1];
   const long nrows = (long)n[1] * n[2];
   const bool dist = c->P > 1;
+  // the radix-8 kernels know the periodic and the Neumann-Neumann transform; a velocity component of the 3-D implicit step may need others
+  const bool use8x = sp->x8 && c->xkind <= 1, use8y = sp->y8 && c->ykind <= 1;
+  const VelSet *VS = static_cast<const VelSet *>(c->cur_velset);      // transform set of the velocity component being solved (nullptr: the pressure's)
   if (dist && !c->comm.on) { c->err = "solver: nranks > 1 but no communication hooks registered (cales_set_comm)"; return 1; }
   Spec S; S.blocked = dist ? 1 : 0; S.cw = c->cw; S.n2l = n[1]; S.n3 = n[2];
   double2 *slab_spec = dist ? reinterpret_cast<double2 *>(c->comm.A) : reinterpret_cast<double2 *>(pp + 1);   // in place: modes of row (j,k) from i = 1
@@ -1081,7 +1129,7 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
   const int ncol = dist ? c->cw : mh, mofs = dist ? c->rank * c->cw : 0;
   const int64_t a2a_count = (int64_t)n[2] * n[1] * c->cw * 2;
   const int nh = c->C.ng[0] / 2;
-  const int Rx8 = sp->x8 ? sp->x8_threads / (nh / 8) : 1, CB8 = sp->y8 ? sp->y8_threads / (n2g / 8) : 1;
+  const int Rx8 = use8x ? sp->x8_threads / (nh / 8) : 1, CB8 = use8y ? sp->y8_threads / (n2g / 8) : 1;
   // persistent blocks: several row groups / planes per block so that the register prefetch overlaps the transforms
   const long xgroups = (nrows + Rx8 - 1) / Rx8;
   int xiters = 1; while (xiters < 8 && xgroups / (xiters * 2) >= 2048) xiters *= 2;
@@ -1102,10 +1150,11 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
                             (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec, F);
     if (F.mean_mask) if (int e = op_force_from_partials(c, F.mean_mask, F.part, (int)xblocks)) return e;
   } else { ProfScope ps(c, "fft_x_fwd");
-    if (sp->x8 && c->xkind) hipLaunchKernelGGL((k_fft_x8<0, 1>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
+    if (use8x && c->xkind) hipLaunchKernelGGL((k_fft_x8<0, 1>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec);
-    else if (sp->x8) hipLaunchKernelGGL((k_fft_x8<0, 0>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
+    else if (use8x) hipLaunchKernelGGL((k_fft_x8<0, 0>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec);
+    else if (c->xkind == 5) hipLaunchKernelGGL(k_dst1<0>, dim3((unsigned)nrows), dim3(256), (size_t)2 * (VS->p1x.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1x, 0, (const cpx *)VS->tw1x, pp, 1., S, slab_spec);
     else if (c->xkind == 3) hipLaunchKernelGGL((k_fft_x4<0, 0>), dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
                        (const cpx *)c->d_twx, (const cpx *)c->d_tw4x, pp, 1., S, slab_spec);
     else if (c->xkind == 4) hipLaunchKernelGGL((k_fft_x4<0, 1>), dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
@@ -1114,10 +1163,11 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
                        (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec); }
   if (dist) { ProfScope ps(c, "alltoall"); if (c->comm.a2a(c->comm.user, 0, a2a_count)) { c->err = "alltoall callback failed"; return 1; } }
   { ProfScope ps(c, "fft_y_fwd");
-    if (c->ykind == 3) hipLaunchKernelGGL(k_fft_y4<0>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
+    if (c->ykind == 5) hipLaunchKernelGGL(k_dst1<1>, dim3(ncol, n[2]), dim3(256), (size_t)2 * (VS->p1y.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1y, ncol, (const cpx *)VS->tw1y, pp, 1., S, mode_spec);
+    else if (c->ykind == 3) hipLaunchKernelGGL(k_fft_y4<0>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
     else if (c->ykind == 4) hipLaunchKernelGGL(k_fft_y4<1>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
-    else if (sp->y8 && c->ykind) hipLaunchKernelGGL((k_fft_y8<0, 1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
-    else if (sp->y8) hipLaunchKernelGGL((k_fft_y8<0, 0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
+    else if (use8y && c->ykind) hipLaunchKernelGGL((k_fft_y8<0, 1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
+    else if (use8y) hipLaunchKernelGGL((k_fft_y8<0, 0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
     else hipLaunchKernelGGL(k_fft_y<0>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
   // pressure equation without a Dirichlet condition in z: the zero-eigenvalue mode (if x and y have one) is singular
   const int fixnull = (poisson && CBP(c, 0, 3) != 'D' && CBP(c, 1, 3) != 'D' && getenv("CALES_KEEP_NULL_MODE") == nullptr) ? 1 : 0;
@@ -1145,17 +1195,19 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
     else if (getenv("CALES_GAUSSEL_PAIR")) hipLaunchKernelGGL((k_gaussel<double2, 0>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2, fixnull);
     else hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, fixnull, 0); }
   { ProfScope ps(c, "fft_y_bwd");
-    if (c->ykind == 3) hipLaunchKernelGGL(k_fft_y4<0>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
+    if (c->ykind == 5) hipLaunchKernelGGL(k_dst1<1>, dim3(ncol, n[2]), dim3(256), (size_t)2 * (VS->p1y.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1y, ncol, (const cpx *)VS->tw1y, pp, 1., S, mode_spec);
+    else if (c->ykind == 3) hipLaunchKernelGGL(k_fft_y4<0>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
     else if (c->ykind == 4) hipLaunchKernelGGL(k_fft_y4<1>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
-    else if (sp->y8 && c->ykind) hipLaunchKernelGGL((k_fft_y8<1, 1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
-    else if (sp->y8) hipLaunchKernelGGL((k_fft_y8<1, 0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
+    else if (use8y && c->ykind) hipLaunchKernelGGL((k_fft_y8<1, 1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
+    else if (use8y) hipLaunchKernelGGL((k_fft_y8<1, 0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
     else hipLaunchKernelGGL(k_fft_y<1>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
   if (dist) { ProfScope ps(c, "alltoall"); if (c->comm.a2a(c->comm.user, 1, a2a_count)) { c->err = "alltoall callback failed"; return 1; } }
   { ProfScope ps(c, "fft_x_bwd");
-    if (sp->x8 && c->xkind) hipLaunchKernelGGL((k_fft_x8<1, 1>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
+    if (use8x && c->xkind) hipLaunchKernelGGL((k_fft_x8<1, 1>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec);
-    else if (sp->x8) hipLaunchKernelGGL((k_fft_x8<1, 0>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
+    else if (use8x) hipLaunchKernelGGL((k_fft_x8<1, 0>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec);
+    else if (c->xkind == 5) hipLaunchKernelGGL(k_dst1<0>, dim3((unsigned)nrows), dim3(256), (size_t)2 * (VS->p1x.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1x, 0, (const cpx *)VS->tw1x, pp, c->normfft, S, slab_spec);
     else if (c->xkind == 3) hipLaunchKernelGGL((k_fft_x4<1, 0>), dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
                        (const cpx *)c->d_twx, (const cpx *)c->d_tw4x, pp, c->normfft, S, slab_spec);
     else if (c->xkind == 4) hipLaunchKernelGGL((k_fft_x4<1, 1>), dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
@@ -1259,15 +1311,64 @@ int op_helmholtz_z(cales_ctx *c, int ivel, double alpha) {
 // 3-D implicit diffusion (_IMPDIFF without _IMPDIFF_1D, main.f90:423-491): (1 + alpha L) q = q* by the same transforms as the
 // pressure solve. Provided for periodic x and y, where the eigenvalues and transforms of a velocity component are those of
 // the pressure (initsolver.f90:66-98 does not depend on the staggering for 'PP'); cales_check_case rejects the rest.
+// Transform set of one velocity component for the 3-D implicit step: kinds and eigenvalues follow its BC pairs and its staggering
+// (initsolver.f90:66-98, find_fft with c_or_f): periodic -> 0; walls -> RODFT10/01 (kind 2) across the component, RODFT00 (kind 5,
+// one unknown less) along it. Built on first use; other pairs (open boundaries) are refused by cales_check_case.
+static int velset_build(cales_ctx *c, int slot, int iv, VelSet &V) {
+  const int n1 = c->C.ng[0], n2g = c->C.ng[1];
+  const char *bc = &c->cbcvel[6 * iv];
+  auto kind = [&](int d) -> int {
+    const std::string b = std::string(1, bc[2 * d]) + bc[2 * d + 1];
+    if (b == "PP") return 0;
+    if (b == "DD") return d == iv ? 5 : 2;
+    return -1;
+  };
+  V.xkind = kind(0); V.ykind = kind(1);
+  if (V.xkind < 0 || V.ykind < 0) { c->err = "helmholtz: velocity BC pairs in x and y must be PP or DD (walls)"; return 1; }
+  if ((V.xkind == 5 || V.ykind == 5) && c->P > 1) { c->err = "helmholtz: walls along the component's own direction need one rank"; return 1; }
+  if (V.xkind && !V.ykind && c->cbcvel[6 * iv + 4] == 'P') { c->err = "helmholtz: non-periodic x with periodic y and z is not provided"; return 1; }
+  std::vector<double> lx(n1 + 2, 0.), ly(n2g);
+  const std::string bx = std::string(1, bc[0]) + bc[1], by = std::string(1, bc[2]) + bc[3];
+  hs_eigenvalues(n1, bx.c_str(), iv == 0 ? 'f' : 'c', lx.data()); hs_eigenvalues(n2g, by.c_str(), iv == 1 ? 'f' : 'c', ly.data());
+  for (auto &v : lx) v = v * (c->dli[0] * c->dli[0]);
+  for (auto &v : ly) v = v * (c->dli[1] * c->dli[1]);
+  if (V.ykind == 2) std::reverse(ly.begin(), ly.end());      // see solver_setup
+  HIPCHK(c, hipMalloc(&V.lamx, (n1 + 2) * sizeof(double))); HIPCHK(c, hipMalloc(&V.lamy, n2g * sizeof(double)));
+  HIPCHK(c, hipMemcpy(V.lamx, lx.data(), (n1 + 2) * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(V.lamy, ly.data(), n2g * sizeof(double), hipMemcpyHostToDevice));
+  // fft.f90:99,136,142: norm = 1 (PP), 2 n ('c' walls), 2 (n + 1 - 1) ('f' walls)
+  V.normfft = 1. / ((V.xkind ? 2. : 1.) * (double)n1 * (V.ykind ? 2. : 1.) * (double)n2g);
+  auto mk = [&](int N, double **dev) -> int {
+    std::vector<double> t(2 * (size_t)N); const double pi = std::acos(-1.0);
+    for (int q = 0; q < N; ++q) { const double ang = -2. * pi * q / N; t[2 * q] = std::cos(ang); t[2 * q + 1] = std::sin(ang); }
+    HIPCHK(c, hipMalloc(dev, t.size() * sizeof(double)));
+    HIPCHK(c, hipMemcpy(*dev, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+  };
+  if (V.xkind == 5) { if (!make_plan(2 * n1, V.p1x) || (size_t)2 * (2 * n1 + 1) * sizeof(cpx) > 150 * 1024) { c->err = "helmholtz: x line not supported by the DST-I kernel"; return 1; } if (mk(2 * n1, &V.tw1x)) return 1; }
+  if (V.ykind == 5) { if (!make_plan(2 * n2g, V.p1y) || (size_t)2 * (2 * n2g + 1) * sizeof(cpx) > 150 * 1024) { c->err = "helmholtz: y line not supported by the DST-I kernel"; return 1; } if (mk(2 * n2g, &V.tw1y)) return 1; }
+  if (V.xkind == 5 || V.ykind == 5) hipFuncSetAttribute((const void *)k_dst1<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), hipFuncSetAttribute((const void *)k_dst1<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  (void)slot;
+  V.ready = true;
+  return 0;
+}
 int op_helmholtz(cales_ctx *c, int ivel, double alpha) {
   if (c->C.impdiff != 1) { c->err = "helmholtz needs impdiff = 1"; return 1; }
-  if (c->xkind || c->ykind) { c->err = "helmholtz (3-D implicit diffusion) needs periodic x and y"; return 1; }
+  PlanSlot *slot = find_slot(c);
+  if (!slot) { c->err = "solver not initialised"; return 1; }
+  VelSet &V = slot->vs[ivel - 1];
+  if (!V.ready) if (int e = velset_build(c, 0, ivel - 1, V)) return e;
   ProfScope ps(c, "helmholtz_xyz");
   const int n3 = c->n[2];
-  if (int e = op_rhs_b_velz(c, ivel, alpha)) return e;      // x and y boundary planes vanish for periodic directions
+  if (int e = op_rhs_b_velz(c, ivel, alpha)) return e;      // x and y boundary planes: homogeneous (cales_check_case) or periodic
   double *abc = c->d_red + 64 + 16 * (n3 + 2);
   hipLaunchKernelGGL(k_scale_abc, dim3((n3 + 63) / 64), dim3(64), 0, c->stream, n3, alpha, c->d_av[ivel - 1], c->d_bv[ivel - 1], c->d_cv[ivel - 1], abc, abc + n3, abc + 2 * n3);
   const char *bcz = &c->cbcvel[6 * (ivel - 1) + 4];
   const int q = (ivel == 3 && bcz[1] == 'D') ? 1 : 0;
-  return solve_field(c, c->f[CALES_U + ivel - 1], abc, abc + n3, abc + 2 * n3, n3 - q, alpha, bcz[0] == 'P' && bcz[1] == 'P', false);
+  // the solve runs with the component's kinds, eigenvalues and normalisation in place of the pressure's
+  const int xk = c->xkind, yk = c->ykind; double *lx = c->d_lamx, *ly = c->d_lamy; const double nf = c->normfft;
+  c->xkind = V.xkind; c->ykind = V.ykind; c->d_lamx = V.lamx; c->d_lamy = V.lamy; c->normfft = V.normfft; c->cur_velset = &V;
+  const int e = solve_field(c, c->f[CALES_U + ivel - 1], abc, abc + n3, abc + 2 * n3, n3 - q, alpha, bcz[0] == 'P' && bcz[1] == 'P', false);
+  c->xkind = xk; c->ykind = yk; c->d_lamx = lx; c->d_lamy = ly; c->normfft = nf; c->cur_velset = nullptr;
+  return e;
 }

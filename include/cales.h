@@ -31,7 +31,7 @@ typedef struct cales_case {
   double  bforce[3]; int32_t is_forced[3]; double velf[3];
   int32_t sgstype;        /* 0 'none', 1 'smag', 2 'dsmag'  (src/sgs.f90:61-153) */
   int32_t lwm[6]; double hwm;
-  int32_t impdiff;        /* 0 explicit; 2 = _IMPDIFF + _IMPDIFF_1D (z-implicit); 1 = _IMPDIFF (3-D implicit; periodic x and y only) */
+  int32_t impdiff;        /* 0 explicit; 2 = _IMPDIFF + _IMPDIFF_1D (z-implicit); 1 = _IMPDIFF (3-D implicit; periodic or no-slip wall pairs in x and y) */
   int32_t nranks, rank;   /* y-slab decomposition: rank owns rows rank*ng2/nranks+1 ... */
 } cales_case;
 

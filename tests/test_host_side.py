@@ -145,10 +145,15 @@ def test_check_case_rules():
     bad = case.copy(); bad.bcpre[0, 0] = 1.                    # x,y pressure BC values must be zero
     with pytest.raises(CalesError):
         check_case(bad)
-    ok = case.copy(); ok.impdiff = 1                           # 3-D implicit diffusion: periodic x and y only
+    ok = case.copy(); ok.impdiff = 1                           # 3-D implicit diffusion: periodic or wall pairs in x and y
     if all(ch == "P" for ch in ok.cbcvel[:, :2, :].ravel()):
         check_case(ok)
-    bad = load_golden("duct_smag_wm")[1]; bad.impdiff = 1; bad.lwm[:] = 0
+    ok = load_golden("duct_smag_wm")[1]; ok.impdiff = 1; ok.lwm[:] = 0      # walls in y (no wall model)
+    check_case(ok)
+    bad = ok.copy(); bad.bcvel[0, 1, 0] = 0.3                  # ... but no moving wall in x or y
+    with pytest.raises(CalesError):
+        check_case(bad)
+    bad = load_golden("devchan_nd")[1]; bad.impdiff = 1; bad.cbcsgs[:, 0] = "D"      # ... and no open boundary
     with pytest.raises(CalesError):
         check_case(bad)
     with pytest.raises(CalesError):
