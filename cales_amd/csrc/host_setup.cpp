@@ -274,7 +274,6 @@ int hs_check_case(const cales_case *cs, std::string &msg) {
       if (b == "DD" && (cs->bcvel[0 + 2 * d + 6 * iv] != 0. || cs->bcvel[1 + 2 * d + 6 * iv] != 0.)) {
         msg = "3-D implicit diffusion: wall velocities in x and y must be zero (moving walls only in z)"; return 1; }
     }
-    if (cs->nranks > 1) for (int iv = 0; iv < 2; ++iv) if (pr(cs->cbcvel + 6 * iv, iv) == "DD") { msg = "3-D implicit diffusion with walls in x or y needs one rank"; return 1; }
   }
   if (cs->impdiff < 0 || cs->impdiff > 2) { msg = "impdiff must be 0, 1 or 2"; return 1; }
   // transforms offered: in y periodic and cell-centred Neumann-Neumann (what the reference's GPU path offers in x and y,

@@ -335,8 +335,8 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const
 // wall-normal direction in the 3-D implicit step -- n-1 unknowns j = 1..n-1 between the wall faces 0 and n. Odd extension to 2n points
 // through one complex FFT of length 2n per line: Z_k = sum z_j e^{-i pi j k/n} = -i Y_k with Y_k = 2 sum x_j sin(pi j k/n). Linear, so a
 // complex column (y direction: real and imaginary part of an x mode) goes through as it is; self-inverse up to 2n.
-// DIR 0: rows along x of a real field (p + 1 = element i = 1), one row per block, coefficient k at the place of x_k, scaled by `scale`;
-// DIR 1: columns along y of the complex spectrum, one column per block.
+// DIR 0 / 2: rows along x, forward (field row -> real x modes, slab side of the spectrum) / inverse (modes -> field row, times `scale`),
+// one row per block, coefficient k at the place of x_k; DIR 1: columns along y of the complex spectrum, one column per block.
 template <int DIR>
 __global__ __launch_bounds__(256) void k_dst1(Geom g, FftPlan P, int ncols, const cpx *__restrict__ tw, double *__restrict__ p, double scale,
                                               Spec S, double2 *__restrict__ pc) {
@@ -344,15 +344,16 @@ __global__ __launch_bounds__(256) void k_dst1(Geom g, FftPlan P, int ncols, cons
   const int N2 = P.N, n = N2 / 2, ld = N2 + 1, t = threadIdx.x, T = blockDim.x;
   cpx *A = reinterpret_cast<cpx *>(smem), *B = A + ld;
   int j = 0, k = 0, m = 0;
-  if (DIR == 0) { const long r = blockIdx.x; j = (int)(r % g.n2) + 1; k = (int)(r / g.n2) + 1; }
+  if (DIR != 1) { const long r = blockIdx.x; j = (int)(r % g.n2) + 1; k = (int)(r / g.n2) + 1; }
   else { m = blockIdx.x; k = blockIdx.y + 1; }
   double *specd = reinterpret_cast<double *>(pc);
   auto slot = [&](int e) -> double & { return specd[2 * S.at_slab(g, e >> 1, j, k) + (e & 1)]; };      // real x mode e of row (j,k)
+  double *rowp = p + g.ix(0, j, k);                                                                  // field row: x_e at rowp[e]
   for (int q = t; q < N2; q += T) {
     cpx z = {0., 0.};
     const int jj = q < n ? q : N2 - q;                    // |index| of the odd extension; 0 and n are the wall faces
     if (q != 0 && q != n) {
-      if (DIR == 0) z.x = slot(jj - 1); else { const double2 v = pc[S.at_mode(g, m, jj, k)]; z = cpx{v.x, v.y}; }
+      if (DIR == 0) z.x = rowp[jj]; else if (DIR == 2) z.x = slot(jj - 1); else { const double2 v = pc[S.at_mode(g, m, jj, k)]; z = cpx{v.x, v.y}; }
       if (q > n) { z.x = -z.x; z.y = -z.y; }
     }
     A[q] = z;
@@ -361,9 +362,9 @@ __global__ __launch_bounds__(256) void k_dst1(Geom g, FftPlan P, int ncols, cons
   cpx *Z = fft_line<0>(P, A, B, t, T, tw);
   for (int kk = t + 1; kk < n; kk += T) {                 // Y_k = i Z_k
     const cpx y = {-Z[kk].y, Z[kk].x};
-    if (DIR == 0) slot(kk - 1) = y.x * scale; else pc[S.at_mode(g, m, kk, k)] = make_double2(y.x * scale, y.y * scale);
+    if (DIR == 0) slot(kk - 1) = y.x * scale; else if (DIR == 2) rowp[kk] = y.x * scale; else pc[S.at_mode(g, m, kk, k)] = make_double2(y.x * scale, y.y * scale);
   }
-  (void)ncols; (void)p;
+  (void)ncols;
 }
 
 // DCT-IV / DST-IV along y (pressure Neumann on one y face and Dirichlet on the other: REDFT11 / RODFT11, fft.f90:192-245), the y twin of
@@ -1207,7 +1208,7 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec);
     else if (use8x) hipLaunchKernelGGL((k_fft_x8<1, 0>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec);
-    else if (c->xkind == 5) hipLaunchKernelGGL(k_dst1<0>, dim3((unsigned)nrows), dim3(256), (size_t)2 * (VS->p1x.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1x, 0, (const cpx *)VS->tw1x, pp, c->normfft, S, slab_spec);
+    else if (c->xkind == 5) hipLaunchKernelGGL(k_dst1<2>, dim3((unsigned)nrows), dim3(256), (size_t)2 * (VS->p1x.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1x, 0, (const cpx *)VS->tw1x, pp, c->normfft, S, slab_spec);
     else if (c->xkind == 3) hipLaunchKernelGGL((k_fft_x4<1, 0>), dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
                        (const cpx *)c->d_twx, (const cpx *)c->d_tw4x, pp, c->normfft, S, slab_spec);
     else if (c->xkind == 4) hipLaunchKernelGGL((k_fft_x4<1, 1>), dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
@@ -1325,7 +1326,6 @@ static int velset_build(cales_ctx *c, int slot, int iv, VelSet &V) {
   };
   V.xkind = kind(0); V.ykind = kind(1);
   if (V.xkind < 0 || V.ykind < 0) { c->err = "helmholtz: velocity BC pairs in x and y must be PP or DD (walls)"; return 1; }
-  if ((V.xkind == 5 || V.ykind == 5) && c->P > 1) { c->err = "helmholtz: walls along the component's own direction need one rank"; return 1; }
   if (V.xkind && !V.ykind && c->cbcvel[6 * iv + 4] == 'P') { c->err = "helmholtz: non-periodic x with periodic y and z is not provided"; return 1; }
   std::vector<double> lx(n1 + 2, 0.), ly(n2g);
   const std::string bx = std::string(1, bc[0]) + bc[1], by = std::string(1, bc[2]) + bc[3];
@@ -1347,7 +1347,7 @@ static int velset_build(cales_ctx *c, int slot, int iv, VelSet &V) {
   };
   if (V.xkind == 5) { if (!make_plan(2 * n1, V.p1x) || (size_t)2 * (2 * n1 + 1) * sizeof(cpx) > 150 * 1024) { c->err = "helmholtz: x line not supported by the DST-I kernel"; return 1; } if (mk(2 * n1, &V.tw1x)) return 1; }
   if (V.ykind == 5) { if (!make_plan(2 * n2g, V.p1y) || (size_t)2 * (2 * n2g + 1) * sizeof(cpx) > 150 * 1024) { c->err = "helmholtz: y line not supported by the DST-I kernel"; return 1; } if (mk(2 * n2g, &V.tw1y)) return 1; }
-  if (V.xkind == 5 || V.ykind == 5) hipFuncSetAttribute((const void *)k_dst1<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), hipFuncSetAttribute((const void *)k_dst1<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  if (V.xkind == 5 || V.ykind == 5) hipFuncSetAttribute((const void *)k_dst1<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), hipFuncSetAttribute((const void *)k_dst1<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), hipFuncSetAttribute((const void *)k_dst1<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
   (void)slot;
   V.ready = true;
   return 0;

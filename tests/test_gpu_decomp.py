@@ -11,8 +11,11 @@ pytestmark = pytest.mark.gpu
 
 
 def _case(name, ng):
-    g, case = load_golden(name)
+    imp3d = name == "cavity_imp3d"
+    g, case = load_golden("cavity_nnn" if imp3d else name)
     case.ng[:] = ng
+    if imp3d:
+        case.impdiff = 1
     if case.sgstype == "none" and case.cbcvel[0, 0, 0] != "P":      # see tests/test_gpu_golden.py
         case.cbcsgs[:, 0] = "D"
     return case
@@ -37,7 +40,9 @@ def _single(case, nsteps):
                                        ("halfchan_imp1d", (16, 16, 12), 2), ("chan_smag", (64, 16, 8), 8),
                                        ("duct_smag_wm", (16, 24, 24), 2), ("duct_smag_wm_imp1d", (16, 24, 24), 2), ("cavity_nnn", (16, 24, 12), 4),
                                        ("devchan_nd", (32, 24, 12), 3),
-                                       ("couette_imp3d_ops", (32, 24, 16), 2), ("chan_dsmag", (128, 32, 136), 2)])
+                                       ("couette_imp3d_ops", (32, 24, 16), 2), ("chan_dsmag", (128, 32, 136), 2),
+                                       # 3-D implicit diffusion with no-slip walls in x and y (wall-normal DST-I in the slab and in the mode-block layout)
+                                       ("cavity_imp3d", (32, 24, 12), 2), ("cavity_imp3d", (20, 36, 10), 4)])
 def test_slab_ranks_match_single_rank(name, ng, P):
     from cales_amd.decomp import run_loopback
     case = _case(name, ng)
