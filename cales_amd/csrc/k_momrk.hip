@@ -161,6 +161,18 @@ __global__ __launch_bounds__(64 * (TYM + 2), (TYM <= 6 ? 4 : 3)) void k_momrk(Ge
   }
 }
 
+// The reference updates u,v,w in place, so their ghost cells keep the values of the last bounduvw until the next one -- and the wall model
+// reads them when its sampling height lies between the wall and the first cell centre (index_wm = 1 or n: wmodel.f90:120-131 with i1 = 0 /
+// n+1). The fused kernel writes the new velocities to a second set of buffers: with a wall model the ghost layers travel along.
+struct GhostCopy { const double *src[3]; double *dst[3]; };
+__global__ __launch_bounds__(256) void k_copy_ghosts(Geom g, int idir, GhostCopy G) {
+  const int na = idir == 1 ? g.n2 : g.n1, nb = idir == 3 ? g.n2 : g.n3, n = idir == 1 ? g.n1 : idir == 2 ? g.n2 : g.n3;
+  const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y, f = blockIdx.z >> 1, side = blockIdx.z & 1;
+  if (a > na + 1 || b > nb + 1) return;
+  const int m = side ? n + 1 : 0;
+  const size_t c = idir == 1 ? g.ix(m, a, b) : idir == 2 ? g.ix(a, m, b) : g.ix(a, b, m);
+  G.dst[f][c] = G.src[f][c];
+}
 // mom_xyz_ad + update of rk (rk.f90:74-94); leaves the new velocities in c->f[CALES_U..W] (pointers swapped with c->f2)
 int op_momrk(cales_ctx *c, double f1, double f2, double f12) {
   ProfScope ps(c, "mom_rk_fused");
@@ -191,6 +203,15 @@ int op_momrk(cales_ctx *c, double f1, double f2, double f12) {
   if (c->C.impdiff == 2) MOMRK_LAUNCH(2); else if (c->C.impdiff == 1) MOMRK_LAUNCH(1); else MOMRK_LAUNCH(0);
 #undef MOMRK_LAUNCH
   HIPCHK(c, hipGetLastError());
+  bool wm = false; for (int q = 0; q < 6; ++q) wm = wm || c->C.lwm[q] != 0;
+  if (wm) {
+    GhostCopy G; for (int q = 0; q < 3; ++q) { G.src[q] = c->f[CALES_U + q]; G.dst[q] = c->f2[q]; }
+    for (int idir = 1; idir <= 3; ++idir) {
+      const int na = idir == 1 ? n[1] : n[0], nb = idir == 3 ? n[1] : n[2];
+      hipLaunchKernelGGL(k_copy_ghosts, dim3((na + 2 + 63) / 64, (nb + 2 + 3) / 4, 6), dim3(64, 4, 1), 0, c->stream, c->g, idir, G);
+    }
+    HIPCHK(c, hipGetLastError());
+  }
   for (int q = 0; q < 3; ++q) std::swap(c->f[CALES_U + q], c->f2[q]);
   return 0;
 }
