@@ -17,5 +17,6 @@ dt = 0.5 * o.chkdt(visct, u, v, w)
 for s in range(2):
     h.step(dt); o.step(dt, u, v, w, p, pp, visct)
     gu, gv, gw, gp, gvis = h.download()
+    print("   finite gpu/oracle:", [bool(np.isfinite(a).all()) for a in (gu, gv, gw, gvis)], [bool(np.isfinite(a).all()) for a in (u, v, w, visct)])
     print(os.environ.get("TAG", ""), "step", s, " ".join("%.1e" % relerr(a, b) for a, b in ((gu, u), (gv, v), (gw, w), (gvis, visct))), flush=True)
 h.close()
