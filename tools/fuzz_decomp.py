@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Random sizes and rank counts: emulated y-slab ranks on one GPU against the single-rank run (development aid)."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.util import load_golden, relerr
+from tests.test_gpu_decomp import _single, _case
+from cales_amd.decomp import run_loopback
+
+rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+names = ["chan_dsmag", "chan_dsmag_wm", "chan_smag_wm", "tgv_dsmag_ppp", "cavity_nnn", "duct_smag_wm_imp1d", "couette_imp3d_ops", "cavity_imp3d", "devchan_nd", "halfchan_imp1d"]
+bad = 0
+for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 20):
+    name = names[trial % len(names)]
+    P = int(rng.choice([2, 3, 4]))
+    ng = (int(2 * rng.randint(4, 40)), int(2 * P * rng.randint(2, 8)), int(2 * rng.randint(5, 40)))
+    if name.startswith("duct") and P > 2:
+        P = 2; ng = (ng[0], int(4 * rng.randint(3, 10)), ng[2])
+    try:
+        case = _case(name, ng)
+        u, v, w, p, visct, dt, div, dpdl = _single(case, 2)
+    except Exception as e:
+        print(name, ng, P, "refused:", str(e)[:80]); continue
+
+    def body(h, r):
+        h.upload_initial(); h.startup()
+        dtr = 0.5 * h.chkdt()
+        for _ in range(2):
+            h.step(dtr)
+        return h.download() + [h.lo, h.n]
+    try:
+        res = run_loopback(case, P, body)
+    except Exception as e:
+        print("BAD", name, ng, P, "loopback failed:", str(e)[:100]); bad += 1; continue
+    worst = 0.
+    for r, (ur, vr, wr, pr, visr, lo, n) in enumerate(res):
+        j0 = lo[1] - 1; sl = slice(j0 + 1, j0 + n[1] + 1)
+        for a, b in ((ur, u), (vr, v), (wr, w), (visr, visct)):
+            worst = max(worst, relerr(a[:, 1:-1, :], b[:, sl, :]))
+    ok = worst < 1e-9
+    bad += not ok
+    print("OK " if ok else "BAD", name, ng, "P", P, "%.1e" % worst, flush=True)
+print("bad:", bad)
