@@ -67,6 +67,26 @@ __device__ inline void fft_stage(const cpx *__restrict__ in, cpx *__restrict__ o
   }
 }
 
+// any other prime factor (17, 19, 23, ...): the same direct DFT with a run-time radix, operands re-read from LDS (R^2 complex
+// multiply-adds per butterfly: meant for the odd sizes FFTW would also take, not for speed)
+template <int INV>
+__device__ inline void fft_stage_any(const cpx *__restrict__ in, cpx *__restrict__ out, int N, int Ns, int R, int t, int T, const cpx *__restrict__ tw) {
+  const int M = N / R, tstep = N / (Ns * R), wR = N / R;
+  for (int j = t; j < M; j += T) {
+    const int k = j % Ns, j0 = (j - k) * R + k;
+    for (int q = 0; q < R; ++q) {
+      cpx acc = {0., 0.};
+      for (int r = 0; r < R; ++r) {
+        cpx v = in[j + r * M];
+        if (Ns > 1 && r > 0) { cpx w = tw[k * r * tstep]; if (INV) w.y = -w.y; v = cmul(v, w); }
+        cpx w2 = tw[((q * r) % R) * wR]; if (INV) w2.y = -w2.y;
+        acc = cadd(acc, cmul(v, w2));
+      }
+      out[j0 + q * Ns] = acc;
+    }
+  }
+}
+
 struct FftPlan { int N, nst, radix[16]; };
 static bool make_plan(int N, FftPlan &P) {
   P.N = N; P.nst = 0; int m = N;
@@ -75,6 +95,7 @@ static bool make_plan(int N, FftPlan &P) {
   while (m % 3 == 0) { P.radix[P.nst++] = 3; m /= 3; }
   while (m % 5 == 0) { P.radix[P.nst++] = 5; m /= 5; }
   for (int pr : {7, 11, 13}) while (m % pr == 0 && P.nst < 16) { P.radix[P.nst++] = pr; m /= pr; }
+  for (int pr = 17; pr <= 127 && m > 1; pr += 2) while (m % pr == 0 && P.nst < 16) { P.radix[P.nst++] = pr; m /= pr; }      // fft_stage_any
   return m == 1;
 }
 // runs all stages; returns the buffer holding the result (a or b). All threads of the block must call it.
@@ -89,7 +110,8 @@ __device__ inline cpx *fft_line(const FftPlan &P, cpx *a, cpx *b, int t, int T, 
     else if (R == 5) fft_stage<5, INV>(a, b, P.N, Ns, t, T, tw);
     else if (R == 7) fft_stage<7, INV>(a, b, P.N, Ns, t, T, tw);
     else if (R == 11) fft_stage<11, INV>(a, b, P.N, Ns, t, T, tw);
-    else fft_stage<13, INV>(a, b, P.N, Ns, t, T, tw);
+    else if (R == 13) fft_stage<13, INV>(a, b, P.N, Ns, t, T, tw);
+    else fft_stage_any<INV>(a, b, P.N, Ns, R, t, T, tw);
     Ns *= R;
     __syncthreads();
     cpx *tmp = a; a = b; b = tmp;
@@ -1011,7 +1033,7 @@ int solver_setup(cales_ctx *c) {
   if (c->ykind >= 3 && (n2g % 2)) { c->err = "solver: ND/DN in y need an even ng(2)"; return 1; }
   if (c->xkind && c->C.cbcpre[4] == 'P' && (!c->ykind || c->P > 1)) { c->err = "solver: a non-periodic x with periodic z needs a non-periodic y and one rank"; return 1; }
   SolverPlans sp;
-  if (!make_plan(n1 / 2, sp.px) || !make_plan(n2g, sp.py)) { c->err = "solver: ng(1)/2 and ng(2) must factor into 2,3,5,7,11,13"; return 1; }
+  if (!make_plan(n1 / 2, sp.px) || !make_plan(n2g, sp.py)) { c->err = "solver: ng(1)/2 and ng(2) must factor into primes <= 127"; return 1; }
   // rows per block in x: aim at ~nh/4 threads per row, 256 threads per block
   { int T = std::max(1, std::min(256, (n1 / 2) / 4)); int p2 = 1; while (p2 * 2 <= T) p2 *= 2; T = p2; sp.Rx = 256 / T; }
   sp.shx = (size_t)sp.Rx * 2 * (n1 / 2 + 1) * sizeof(cpx);
@@ -1034,7 +1056,7 @@ int solver_setup(cales_ctx *c) {
                  hipFuncSetAttribute((const void *)k_fft_y8<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8);
                  hipFuncSetAttribute((const void *)k_fft_y8<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8); } }
   if (c->ykind >= 3) {      // DCT-IV / DST-IV in y: N/2-point lines, two per complex column
-    if (!make_plan(n2g / 2, sp.py4)) { c->err = "solver: ng(2)/2 must factor into 2,3,5,7,11,13"; return 1; }
+    if (!make_plan(n2g / 2, sp.py4)) { c->err = "solver: ng(2)/2 must factor into primes <= 127"; return 1; }
     sp.CBy4 = 4; sp.shy4 = (size_t)2 * sp.CBy4 * 2 * (n2g / 2 + 1) * sizeof(cpx);
     while (sp.shy4 > 60 * 1024 && sp.CBy4 > 1) { sp.CBy4 /= 2; sp.shy4 = (size_t)2 * sp.CBy4 * 2 * (n2g / 2 + 1) * sizeof(cpx); }
     if (sp.shy4 > 64 * 1024) { c->err = "solver: y line too long for the LDS-resident DCT-IV"; return 1; }

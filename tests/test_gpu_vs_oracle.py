@@ -24,6 +24,8 @@ def _hot(case):
                                      ("cavity_nnn", (32, 16, 12)), ("cavity_nnn", (20, 36, 10)), ("cavity_nnn", (256, 128, 6)),
                                      # line lengths with factors 7, 11, 13 (direct-DFT butterflies)
                                      ("chan_smag", (28, 22, 10)), ("cavity_nnn", (52, 14, 8)), ("duct_smag_wm", (44, 26, 12)),
+                                     # other prime factors (17, 19, 23, 37): run-time radix stage
+                                     ("chan_smag", (34, 38, 10)), ("cavity_nnn", (46, 74, 8)), ("duct_smag_wm", (38, 34, 12)),
                                      # deep z: the in-LDS tridiagonal tile with 2, 4, 8, 16 planes per lane, partial last chunks
                                      ("chan_smag", (16, 8, 100)), ("chan_smag", (16, 8, 130)), ("cavity_nnn", (40, 8, 300)),
                                      ("chan_smag", (16, 4, 512)), ("duct_smag_wm", (16, 8, 514)), ("chan_smag", (8, 4, 1024))])
