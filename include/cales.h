@@ -73,7 +73,8 @@ int cales_bounduvw(cales_ctx *ctx, int is_updt_wm, int is_correc);          /* s
 int cales_boundp(cales_ctx *ctx, int field, int which);                     /* src/bound.f90:156; which 0 cbcpre/bcp, 1 cbcsgs/bcs */
 int cales_mom(cales_ctx *ctx);                                              /* src/mom.f90:17 -> CALES_DUDT.. */
 int cales_rk(cales_ctx *ctx, int irk, double dt);                           /* src/rk.f90:17 (forcing f stays on the device). The ghost
-                                                                              * cells of u,v,w are undefined on return (the reference leaves the old values);
+                                                                              * cells of u,v,w keep the values of the last bounduvw (as in the reference) when a
+                                                                              * wall model is active -- it may sample them -- and are undefined otherwise;
                                                                               * bounduvw follows in every caller (src/main.f90:493) */
 int cales_bulk_forcing(cales_ctx *ctx);                                     /* src/mom.f90:311    */
 int cales_get_forcing(cales_ctx *ctx, double f[3]);                         /* f of the last cales_rk (sync)  */
