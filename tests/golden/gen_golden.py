@@ -54,6 +54,15 @@ CASES = {
                      {r"ng\(1:3\) = .*": "ng(1:3) = 8, 10, 10"}, 0),
     "duct_smag_wm_imp1d": ("les/_manuscript_turbulent_duct_wall_model/input.nml",
                            {r"ng\(1:3\) = .*": "ng(1:3) = 8, 10, 10"}, 2),
+    # dynamic Smagorinsky with walls in y/z or x/y/z: the kernel-per-loop sequence of sgs.f90:153-380 and
+    # the x/y branches of `extrapolate` (sgs.f90:719-766)
+    "duct_dsmag_wm": ("les/_manuscript_turbulent_duct_wall_model/input.nml",
+                      {r"ng\(1:3\) = .*": "ng(1:3) = 8, 10, 10", r"sgstype = 'smag'": "sgstype = 'dsmag'"}, 0),
+    "duct_dsmag": ("les/_manuscript_turbulent_duct_wall_model/input.nml",
+                   {r"ng\(1:3\) = .*": "ng(1:3) = 8, 10, 12", r"sgstype = 'smag'": "sgstype = 'dsmag'",
+                    r"lwm\(0:1,1:3\) = .*": "lwm(0:1,1:3) = 0,0, 0,0, 0,0", r"gr = 0\.": "gr = 1.5"}, 0),
+    "cavity_dsmag": ("dns/lid_driven_cavity/input.nml",
+                     {r"ng\(1:3\) = .*": "ng(1:3) = 10, 8, 12", r"gr = 0\.": "gr = 1.5", r"sgstype = 'none'": "sgstype = 'dsmag'"}, 0),
     "cavity_nnn": ("dns/lid_driven_cavity/input.nml",
                    {r"ng\(1:3\) = .*": "ng(1:3) = 10, 8, 12", r"gr = 0\.": "gr = 1.5"}, 0),
     "devchan_nd": ("dns/developing_channel/input.nml",

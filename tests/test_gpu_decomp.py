@@ -40,6 +40,8 @@ def _single(case, nsteps):
                                        ("halfchan_imp1d", (16, 16, 12), 2), ("chan_smag", (64, 16, 8), 8),
                                        ("duct_smag_wm", (16, 24, 24), 2), ("duct_smag_wm_imp1d", (16, 24, 24), 2), ("cavity_nnn", (16, 24, 12), 4),
                                        ("devchan_nd", (32, 24, 12), 3),
+                                       # dynamic model with walls in y/z and in x/y/z (kernel-per-loop sequence, slab halos of its scratch fields)
+                                       ("duct_dsmag_wm", (16, 24, 20), 2), ("duct_dsmag", (16, 24, 12), 3), ("cavity_dsmag", (16, 24, 12), 2),
                                        ("couette_imp3d_ops", (32, 24, 16), 2), ("chan_dsmag", (128, 32, 136), 2),
                                        # 3-D implicit diffusion with no-slip walls in x and y (wall-normal DST-I in the slab and in the mode-block layout)
                                        ("cavity_imp3d", (32, 24, 12), 2), ("cavity_imp3d", (20, 36, 10), 4)])
