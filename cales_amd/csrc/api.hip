@@ -80,6 +80,9 @@ int cales_check_case(const cales_case *cs, char *msg, int msglen) {
   return rc;
 }
 
+int cales_device_count(int *ndev) { if (!ndev) return 1; *ndev = 0; return hipGetDeviceCount(ndev) == hipSuccess ? 0 : 2; }
+int cales_set_device(int dev) { return hipSetDevice(dev) == hipSuccess ? 0 : 1; }
+
 // ------------------------------------------------------------------------------------------ context
 const char *cales_last_error(const cales_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -113,6 +116,7 @@ int cales_create(const cales_case *cs, void *stream, cales_ctx **out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_err = "no HIP device: the CaLES hot path has no CPU fallback"; return 3; }
   cales_ctx *c = new cales_ctx();
   c->C = *cs;
+  c->fl.read_env();      // the CALES_* switches are fixed for the life of the context
   // zero all device pointers
   for (auto &p : c->f) p = nullptr;
   c->d_dzc = c->d_dzf = c->d_zc = c->d_zf = c->d_dzci = c->d_dzfi = c->d_gvr_c = c->d_gvr_f = nullptr;
@@ -139,8 +143,8 @@ int cales_create(const cales_case *cs, void *stream, cales_ctx **out) {
   // Row pitch: a multiple of 16 doubles (128 B) with room for the n1/2+1 complex modes of a row stored from i = 1; with the
   // 15-double offset of dev_alloc, element i = 1 of every row is 128-B aligned, so kernels whose waves handle 64 consecutive
   // cells from i = 1 read and write whole cache lines (partial-line writes cost ~1.5x, tools/micro/wrtile.hip).
-  g.s1 = getenv("CALES_UNALIGNED") ? g.n1 + 4 - (g.n1 & 1) : (g.n1 + 3 + 15) / 16 * 16;
-  c->field_ofs = getenv("CALES_UNALIGNED") ? 0 : 15;
+  g.s1 = c->fl.unaligned ? g.n1 + 4 - (g.n1 & 1) : (g.n1 + 3 + 15) / 16 * 16;
+  c->field_ofs = c->fl.unaligned ? 0 : 15;
   g.s12 = (long)g.s1 * (g.n2 + 2); g.jlo = c->lo[1] - 1; g.ng2 = cs->ng[1];
   c->ntot = (size_t)g.s12 * (g.n3 + 2);
   const int n3 = c->n[2];
@@ -300,22 +304,22 @@ int cales_step(cales_ctx *c, double dt) {
     double alpha = 0.;
     // z-implicit diffusion: the Helmholtz sweeps form their r.h.s. themselves (k_gaussel_cols_rhs); needs the shared-pivot form
     const char *bz = &c->cbcvel[4];
-    c->defer_imp_rhs = c->C.impdiff == 2 && getenv("CALES_HELMHOLTZ_Z_PER_COLUMN") == nullptr && getenv("CALES_UNFUSED_IMP_RHS") == nullptr &&
+    c->defer_imp_rhs = c->C.impdiff == 2 && !c->fl.helmholtz_z_per_column && !c->fl.unfused_imp_rhs &&
                        !(bz[0] == 'P' && bz[1] == 'P') && !(bz[6] == 'P' && bz[7] == 'P') && !(bz[12] == 'P' && bz[13] == 'P');
     // explicit step without wall model, forced directions periodic: the velocity between the forcing and the correction is only
     // differenced along the forced direction (fillps) -- the increment is added by the correction kernel, one pass less
-    const bool fuse_cu = getenv("CALES_UNFUSED_CORREC") == nullptr && c->C.impdiff != 1;     // updatep only needs pp: one pass with correc
-    { bool ok = c->C.impdiff == 0 && fuse_cu && getenv("CALES_UNFUSED_FORCING") == nullptr;
+    const bool fuse_cu = !c->fl.unfused_correc && c->C.impdiff != 1;     // updatep only needs pp: one pass with correc
+    { bool ok = c->C.impdiff == 0 && fuse_cu && !c->fl.unfused_forcing;
       for (int q = 0; q < 6; ++q) ok = ok && c->C.lwm[q] == 0;
       for (int d = 0; d < 3; ++d) if (c->C.is_forced[d]) ok = ok && c->cbcvel[6 * d + 2 * d] == 'P' && c->cbcvel[6 * d + 2 * d + 1] == 'P';
       c->defer_force = ok && (c->C.is_forced[0] || c->C.is_forced[1] || c->C.is_forced[2]); }
     // homogeneous pressure BCs (no boundary r.h.s.) and a radix-8 x plan: fillps is done by the forward x transform, which then
     // also sums the bulk means of the forced components (their increment is only needed by the correction kernel)
-    bool fuse_fill = getenv("CALES_UNFUSED_FILLPS") == nullptr && getenv("CALES_UNALIGNED") == nullptr && solver_can_fuse_fillps(c);
+    bool fuse_fill = !c->fl.unfused_fillps && !c->fl.unaligned && solver_can_fuse_fillps(c);
     for (int d = 0; d < 3; ++d) fuse_fill = fuse_fill && ((c->C.bcpre[2 * d] == 0. && c->C.bcpre[2 * d + 1] == 0.) || c->C.cbcpre[2 * d] == 'P');
-    c->fuse_mean_mask = (fuse_fill && c->defer_force && getenv("CALES_UNFUSED_MEAN") == nullptr)
+    c->fuse_mean_mask = (fuse_fill && c->defer_force && !c->fl.unfused_mean)
                             ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;
-    c->skip_rhs_store = irk == 3 && getenv("CALES_KEEP_LAST_RHS") == nullptr;
+    c->skip_rhs_store = irk == 3 && !c->fl.keep_last_rhs;
     { const int e = op_rk(c, irk, dt); c->skip_rhs_store = false; if (e) return e; }
     if (int e = op_bulk_forcing(c)) { c->defer_imp_rhs = false; return e; }
     if (c->C.impdiff == 2) {
@@ -369,7 +373,7 @@ int cales_set_comm(cales_ctx *c, cales_halo_cb halo, cales_alltoall_cb a2a, cale
   // reduction results live in the tail of A so that the host can all-reduce them in place
   const int64_t tail = CALES_RES_TAIL + 2 * (int64_t)(c->n[2] + 2);
   c->res = bufA + (nbuf - tail);
-  if (c->d_p1d) { hipFree(c->d_p1d); }
+  if (c->d_p1d && !c->p1d_in_comm) hipFree(c->d_p1d);      // a second call must not free the interior pointer set by the first
   c->d_p1d = c->res + 64;
   c->p1d_in_comm = true;
   return 0;

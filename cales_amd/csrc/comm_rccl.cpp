@@ -82,13 +82,17 @@ int native_halo(void *user, int64_t off_slo, int64_t off_shi, int64_t off_rlo, i
   // With two ranks and periodic y both neighbours are the same peer: the k-th send to a peer pairs with its k-th receive
   // from us, so "my lowest row" must be sent first and "its lowest row" (my upper ghost) received first.
   NCHK(c, g_api.GroupStart());
-  if (lo >= 0) NCHK(c, g_api.Send(nc->A + off_slo, (size_t)count, ncclDouble, lo, nc->comm, c->stream));
+  // an error inside the group must still close it: an open group would queue every later collective of this thread for ever
+  ncclResult_t rc = ncclSuccess;
+  auto add = [&](ncclResult_t r) { if (rc == ncclSuccess) rc = r; };
+  if (lo >= 0) add(g_api.Send(nc->A + off_slo, (size_t)count, ncclDouble, lo, nc->comm, c->stream));
   if (hi >= 0) {
-    NCHK(c, g_api.Recv(nc->B + off_rhi, (size_t)count, ncclDouble, hi, nc->comm, c->stream));
-    NCHK(c, g_api.Send(nc->A + off_shi, (size_t)count, ncclDouble, hi, nc->comm, c->stream));
+    add(g_api.Recv(nc->B + off_rhi, (size_t)count, ncclDouble, hi, nc->comm, c->stream));
+    add(g_api.Send(nc->A + off_shi, (size_t)count, ncclDouble, hi, nc->comm, c->stream));
   }
-  if (lo >= 0) NCHK(c, g_api.Recv(nc->B + off_rlo, (size_t)count, ncclDouble, lo, nc->comm, c->stream));
-  NCHK(c, g_api.GroupEnd());
+  if (lo >= 0) add(g_api.Recv(nc->B + off_rlo, (size_t)count, ncclDouble, lo, nc->comm, c->stream));
+  add(g_api.GroupEnd());
+  if (rc != ncclSuccess) { c->err = std::string("RCCL: ") + g_api.GetErrorString(rc) + " in the halo exchange"; return 1; }
   return 0;
 }
 int native_alltoall(void *user, int dir, int64_t count) {

@@ -52,10 +52,39 @@ struct Spec {
   }
 };
 
+// Run-time switches: read from the environment ONCE, by cales_create; the launch path only looks at these fields.
+struct Flags {
+  bool unaligned = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_eager = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, gaussel_pair = false, unfused_rk = false;
+  int kchunk = 0; long tile_min_blocks = 2048;
+  void read_env() {
+    unaligned = getenv("CALES_UNALIGNED") != nullptr;
+    helmholtz_z_per_column = getenv("CALES_HELMHOLTZ_Z_PER_COLUMN") != nullptr;
+    unfused_imp_rhs = getenv("CALES_UNFUSED_IMP_RHS") != nullptr;
+    unfused_correc = getenv("CALES_UNFUSED_CORREC") != nullptr;
+    unfused_forcing = getenv("CALES_UNFUSED_FORCING") != nullptr;
+    unfused_fillps = getenv("CALES_UNFUSED_FILLPS") != nullptr;
+    unfused_mean = getenv("CALES_UNFUSED_MEAN") != nullptr;
+    keep_last_rhs = getenv("CALES_KEEP_LAST_RHS") != nullptr;
+    wide_offsets = getenv("CALES_WIDE_OFFSETS") != nullptr;
+    dsmag_reference_sequence = getenv("CALES_DSMAG_REFERENCE_SEQUENCE") != nullptr;
+    dsmag_eager = getenv("CALES_DSMAG_EAGER") != nullptr;
+    dsmag_xghosts = getenv("CALES_DSMAG_XGHOSTS") != nullptr;
+    smag_reference_sequence = getenv("CALES_SMAG_REFERENCE_SEQUENCE") != nullptr;
+    gaussel_march = getenv("CALES_GAUSSEL_MARCH") != nullptr;
+    fft_generic = getenv("CALES_FFT_GENERIC") != nullptr;
+    keep_null_mode = getenv("CALES_KEEP_NULL_MODE") != nullptr;
+    gaussel_pair = getenv("CALES_GAUSSEL_PAIR") != nullptr;
+    unfused_rk = getenv("CALES_UNFUSED_RK") != nullptr;
+    kchunk = getenv("CALES_KCHUNK") ? atoi(getenv("CALES_KCHUNK")) : 0;
+    tile_min_blocks = getenv("CALES_TILE_MIN_BLOCKS") ? atol(getenv("CALES_TILE_MIN_BLOCKS")) : 2048;
+  }
+};
+
 struct KernelStat { std::string name; int64_t calls = 0; double ms = 0.; };
 
 struct cales_ctx {
   cales_case C;
+  Flags fl;
   Geom g;
   int n[3], lo[3];
   double dl[3], dli[3], visc;
@@ -204,15 +233,17 @@ template <typename OFF> __device__ inline void stb(double *b, OFF o, double v) {
 
 // ---- cross-lane moves on the vector ALU (DPP) instead of ds_bpermute: no LDS-pipe traffic, short latency ----
 template <int CTRL, int ROWMASK = 0xf>
-__device__ inline double dpp_f64(double v) {       // lanes without a source (or masked rows) receive 0
+__device__ inline double dpp_f64(double v) {       // lanes without a source receive 0 (bound_ctrl); rows masked out keep v itself
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xf, false);
+  // old = the source register and bound_ctrl: no register has to be zeroed before every move (the old form cost one v_mov per dpp move)
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 __device__ inline double lane_prev(double v) { return dpp_f64<0x138>(v); }   // wave_shr:1, lane i <- lane i-1 (lane 0 <- 0)
 __device__ inline double lane_next(double v) { return dpp_f64<0x130>(v); }   // wave_shl:1, lane i <- lane i+1 (lane 63 <- 0)
-// sum over the 64 lanes, valid in lane 63 only (row_shr 1,2,4,8 then row_bcast 15 and 31)
+// sum over the 64 lanes, valid in lane 63 only (row_shr 1,2,4,8 then row_bcast 15 and 31; the rows the two broadcasts mask out
+// add their own value to themselves -- they never reach lane 63)
 __device__ inline double wave_sum_lane63(double s) {
   s += dpp_f64<0x111>(s); s += dpp_f64<0x112>(s); s += dpp_f64<0x114>(s); s += dpp_f64<0x118>(s);
   s += dpp_f64<0x142, 0xa>(s); s += dpp_f64<0x143, 0xc>(s);
@@ -231,10 +262,10 @@ __device__ inline void stencil_block(int &bx, int &by, int &bz) {
 
 // tile kernels split k into chunks until at least this many blocks exist (several rounds per CU balance the chip)
 // k extent of the chunks the marching tile kernels split the z range into. CALES_KCHUNK overrides (experiments).
-static inline int tile_kchunk(long nxy_blocks, int n3) {
-  static const int forced = getenv("CALES_KCHUNK") ? atoi(getenv("CALES_KCHUNK")) : 0;
+static inline int tile_kchunk(const cales_ctx *c, long nxy_blocks, int n3) {
+  const int forced = c->fl.kchunk;
   if (forced > 0) return forced < n3 ? forced : n3;
   return 0;
 }
-static inline long tile_min_blocks() { static const long v = getenv("CALES_TILE_MIN_BLOCKS") ? atol(getenv("CALES_TILE_MIN_BLOCKS")) : 2048; return v; }
+static inline long tile_min_blocks(const cales_ctx *c) { return c->fl.tile_min_blocks; }
 static inline dim3 grid3(int nx, int ny, int nz, dim3 b) { return dim3((nx + b.x - 1) / b.x, (ny + b.y - 1) / b.y, (nz + b.z - 1) / b.z); }

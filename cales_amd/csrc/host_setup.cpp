@@ -246,7 +246,8 @@ int hs_initflow(const cales_case *cs, const char *inivel_, int is_wallturb, doub
 // ---------------------------------------------------------------- src/sanity.f90:33-274 (rules)
 int hs_check_case(const cales_case *cs, std::string &msg) {
   auto pr = [&](const char *a, int dir) { return std::string(1, a[0 + 2 * dir]) + std::string(1, a[1 + 2 * dir]); };
-  for (int d = 0; d < 3; ++d) if (cs->ng[d] < 2 || cs->ng[d] % 2) { msg = "ng(:) must be even and >= 2"; return 1; }
+  // the x and y transforms work on half-length complex lines / paired rows: even ng(1), ng(2); ng(3) is free (as in the reference)
+  for (int d = 0; d < 3; ++d) if (cs->ng[d] < 2 || (d < 2 && cs->ng[d] % 2)) { msg = "ng(1:2) must be even, ng(:) >= 2"; return 1; }
   if (cs->nranks < 1 || cs->ng[1] % cs->nranks || (cs->ng[0] / 2) % 1) { msg = "ng(2) must be divisible by the number of ranks"; return 1; }
   for (int d = 0; d < 3; ++d) {
     const std::string bp = pr(cs->cbcpre, d);
@@ -264,6 +265,24 @@ int hs_check_case(const cales_case *cs, std::string &msg) {
     for (int s = 0; s < 2; ++s) if (cs->lwm[s + 2 * d] != 0)
       for (int ivel = 0; ivel < 3; ++ivel) if (cs->cbcvel[s + 2 * d + 6 * ivel] != 'D') { msg = "wall-model faces must have Dirichlet velocity BCs (sanity.f90:209-221)"; return 1; }
   }
+  // wall-model sampling height inside the slab (sanity.f90:224-231; x and z extents are global, y is evaluated with the local
+  // rows of the rank that owns the wall, as the reference does): outside this range hs_initbc's index search would leave the grid
+  { bool any = false; for (int q = 0; q < 6; ++q) any = any || cs->lwm[q] != 0;
+    if (any) {
+      const int n3 = cs->ng[2], n2l = cs->ng[1] / cs->nranks;
+      std::vector<double> dzc(n3 + 2), dzf(n3 + 2), zc(n3 + 2), zf(n3 + 2);
+      hs_initgrid(cs->gtype, n3, cs->gr, cs->l[2], dzc.data(), dzf.data(), zc.data(), zf.data());
+      double dl[2]; for (int d = 0; d < 2; ++d) dl[d] = cs->l[d] / (double)(1.f * (float)cs->ng[d]);      // param.f90:153
+      const double h = cs->hwm; bool ok = true;
+      const bool per_y = cs->cbcpre[2] == 'P' && cs->cbcpre[3] == 'P', per_z = cs->cbcpre[4] == 'P' && cs->cbcpre[5] == 'P';
+      for (int s = 0; s < 2; ++s) {
+        if (cs->lwm[s] != 0) ok = ok && h > 0.5 * dl[0] && h < (cs->ng[0] - 0.5) * dl[0];
+        if (cs->lwm[2 + s] != 0 && !per_y) ok = ok && h > 0.5 * dl[1] && h < (n2l - 0.5) * dl[1];
+      }
+      if (cs->lwm[4] != 0 && !per_z) ok = ok && h > zc[1] && h < zc[n3];
+      if (cs->lwm[5] != 0 && !per_z) ok = ok && h > cs->l[2] - zc[n3] && h < cs->l[2] - zc[1];
+      if (!ok) { msg = "invalid wall model height (sanity.f90:224-231)"; return 1; }
+    } }
   if (cs->sgstype < 0 || cs->sgstype > 2) { msg = "unknown SGS model"; return 1; }
   if (cs->sgstype == 1 && cs->nranks > 2 && cs->cbcvel[0 + 2 * 1 + 6 * 1] == 'D' && cs->cbcvel[1 + 2 * 1 + 6 * 1] == 'D') {
     msg = "more than two subdomains between two opposite walls (sanity.f90:98-111)"; return 1; }
@@ -275,7 +294,18 @@ int hs_check_case(const cales_case *cs, std::string &msg) {
         msg = "3-D implicit diffusion: wall velocities in x and y must be zero (moving walls only in z)"; return 1; }
     }
   }
+  if (cs->impdiff == 1 && (cs->lwm[0] != 0 || cs->lwm[1] != 0 || cs->lwm[2] != 0 || cs->lwm[3] != 0)) {
+    msg = "wall model BCs cannot be used in x and y when 3-D implicit diffusion is applied (sanity.f90:256-262)"; return 1; }
   if (cs->impdiff < 0 || cs->impdiff > 2) { msg = "impdiff must be 0, 1 or 2"; return 1; }
+  // capability limits of the solver (k_solver.hip: solver_setup, velset_build), refused here so that check_case / create is the single gate
+  { const bool px = cs->cbcpre[0] == 'P', py = cs->cbcpre[2] == 'P', pz = cs->cbcpre[4] == 'P';
+    if (!px && pz && (py || cs->nranks > 1)) { msg = "a non-periodic x with periodic z needs a non-periodic y and one rank"; return 1; }
+    if ((cs->cbcpre[2] == 'N') != (cs->cbcpre[3] == 'N') && (cs->ng[1] % 2)) { msg = "ND/DN pressure BCs in y need an even ng(2)"; return 1; }
+    if (cs->impdiff == 1)
+      for (int iv = 0; iv < 3; ++iv) {
+        const char *b = cs->cbcvel + 6 * iv;
+        if (b[0] != 'P' && b[2] == 'P' && b[4] == 'P') { msg = "3-D implicit diffusion: non-periodic x with periodic y and z is not provided"; return 1; }
+      } }
   // transforms offered: in y periodic and cell-centred Neumann-Neumann (what the reference's GPU path offers in x and y,
   // sanity.f90:265-273); in x also DD, ND, DN (inflow/outflow; the reference's CPU path through FFTW's r2r kinds)
   { const std::string by = pr(cs->cbcpre, 1); if (by != "PP" && by != "NN" && by != "DD" && by != "ND" && by != "DN") { msg = "unknown pressure BC pair in y"; return 1; } }

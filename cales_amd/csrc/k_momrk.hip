@@ -188,10 +188,10 @@ int op_momrk(cales_ctx *c, double f1, double f2, double f12) {
   A.f1 = f1; A.f2 = f2; A.f12 = f12; A.bfx = c->C.bforce[0]; A.bfy = c->C.bforce[1]; A.bfz = c->C.bforce[2];
   dim3 b(64, TYM + 2, 1), gr((n[0] + 63) / 64, (n[1] + TYM - 1) / TYM, 1);
   int kchunk = n[2];
-  while ((long)gr.x * gr.y * ((n[2] + kchunk - 1) / kchunk) < tile_min_blocks() && kchunk > 32) kchunk = (kchunk + 1) / 2;
-  if (int fk = tile_kchunk((long)gr.x * gr.y, n[2])) kchunk = fk;
+  while ((long)gr.x * gr.y * ((n[2] + kchunk - 1) / kchunk) < tile_min_blocks(c) && kchunk > 32) kchunk = (kchunk + 1) / 2;
+  if (int fk = tile_kchunk(c, (long)gr.x * gr.y, n[2])) kchunk = fk;
   gr.z = (n[2] + kchunk - 1) / kchunk; A.kchunk = kchunk;
-  const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32) && getenv("CALES_WIDE_OFFSETS") == nullptr;      // 32-bit byte offsets
+  const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32) && !c->fl.wide_offsets;      // 32-bit byte offsets
   const int nos = c->C.sgstype == 0 && c->visct_zero;     // visct known to be identically zero (never set by the host since the last zeroing)
 #define MOMRK_LAUNCH(IMP_)                                                                                             \
   do {                                                                                                                 \

@@ -3,6 +3,7 @@
 // strain_rate (sgs.f90:1019-1110), extrapolate (682-767), filter3d (616-680), interpolate (850-870),
 // ave1d_channel (433-482) and cmpt_alph2 (769-822).
 #include "common.hpp"
+#include <type_traits>
 
 #define BX 64
 #define BY 4
@@ -397,12 +398,15 @@ __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijA
     for (int q = 1; q <= TYF; ++q) { a += shr[b][0][q]; bsum += shr[b][1][q]; }
     A.part[(size_t)(k - 1) * A.nblk + blk] = a; A.part[(size_t)(g.n3 + k - 1) * A.nblk + blk] = bsum;
   };
-  for (int k = kbeg; k <= kend; ++k) {
+  // one plane; LO / HI = the plane next to a z wall (compile-time: the interior planes carry no wall logic at all). At a wall the
+  // ghost plane of every filtered quantity is the extrapolation Q(0) = 2Q(1) - Q(2), so its z combination Q(0) + 2Q(1) + Q(2) is 4 Q(1)
+  auto plane = [&](const int k, auto lo_c, auto hi_c) {
+    constexpr bool LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
     const int km = (k - 1) & 3, kc = k & 3, kp = (k + 1) & 3, buf = k & 1;
     const OFF idx = c0 + (OFF)k * sk;
 #pragma unroll
     for (int q = 0; q < 3; ++q)
-      ring[kp][q][ty][tx] = (A.wmhi && k == g.n3 && q < 2) ? (1. + A.fhi) * ring[kc][q][ty][tx] - A.fhi * ring[km][q][ty][tx] : fn[q];
+      ring[kp][q][ty][tx] = (HI && A.wmhi && q < 2) ? (1. + A.fhi) * ring[kc][q][ty][tx] - A.fhi * ring[km][q][ty][tx] : fn[q];
     if (k + 2 <= g.n3 + 1) {
 #pragma unroll
       for (int q = 0; q < 3; ++q) { sn[q] = ldok ? ldb(A.uc[q], idx + 2 * sk) : 0.; fn[q] = ldok ? ldb(A.uf[q], idx + 2 * sk) : 0.; }
@@ -411,13 +415,11 @@ __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijA
 #pragma unroll
     for (int q = 0; q < 6; ++q) mf[q] = outok ? ldb(A.mf[q], idx) : 0.;
     double qm[9], qc[9], qp[9], r[9];
-    uiuj(sm, qm); uiuj(sc, qc); uiuj(sp, qp);
-    const bool lo = A.zlo && k == 1, hi = A.zhi && k == g.n3;
+    uiuj(sc, qc);
+    if (!LO && !HI) { uiuj(sm, qm); uiuj(sp, qp); }
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
-      const double vm = lo ? 2. * qc[q] - qp[q] : qm[q];
-      const double vp = hi ? 2. * qc[q] - qm[q] : qp[q];
-      const double G = vm + 2. * qc[q] + vp;
+      const double G = (LO || HI) ? 4. * qc[q] : qm[q] + 2. * qc[q] + qp[q];
       r[q] = lane_prev(G) + 2. * G + lane_next(G);
       sh[buf][q][ty][tx] = r[q];
     }
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijA
       sij[5] = .125 * ((v_ccp - v_ccc) * zc + (w_cpc - w_ccc) * dyi + (v_ccc - v_ccm) * zm + (w_cpm - w_ccm) * dyi +
                        (v_cmp - v_cmc) * zc + (w_ccc - w_cmc) * dyi + (v_cmc - v_cmm) * zm + (w_ccm - w_cmm) * dyi);
       const double s0 = sqrt(2. * (sij[0] * sij[0] + sij[1] * sij[1] + sij[2] * sij[2] + 2. * (sij[3] * sij[3] + sij[4] * sij[4] + sij[5] * sij[5])));
-      const double a2s0 = (lo || hi ? 2.52 : 4.00) * s0;      // alph2 (sgs.f90:783-816)
+      const double a2s0 = (LO || HI ? 2.52 : 4.00) * s0;      // alph2 (sgs.f90:783-816)
       const double m0 = 2. * (mf[0] - a2s0 * sij[0]), m1 = 2. * (mf[1] - a2s0 * sij[1]), m2 = 2. * (mf[2] - a2s0 * sij[2]),
                    m3 = 2. * (mf[3] - a2s0 * sij[3]), m4 = 2. * (mf[4] - a2s0 * sij[4]), m5 = 2. * (mf[5] - a2s0 * sij[5]);
       lm = m0 * l0 + m1 * l1 + m2 * l2 + (m3 * l3 + m4 * l4 + m5 * l5) * 2.;       // sgs.f90:344-349
@@ -462,7 +464,14 @@ __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijA
     if (tx == 63) { shr[buf][0][ty] = lm; shr[buf][1][ty] = mm; }
 #pragma unroll
     for (int q = 0; q < 3; ++q) { sm[q] = sc[q]; sc[q] = sp[q]; sp[q] = sn[q]; }
-    (void)inner;
+  };
+  {
+    const std::true_type T; const std::false_type F_;
+    int k = kbeg;
+    const int klast = (A.zhi && kend == g.n3) ? kend - 1 : kend;       // n3 >= 3: the two wall planes are distinct
+    if (A.zlo && k == 1 && k <= kend) { plane(k, T, F_); ++k; }
+    for (; k <= klast; ++k) plane(k, F_, F_);
+    if (k <= kend) plane(k, F_, T);
   }
   __syncthreads();
   if (tx == 0 && ty == 0 && kend >= kbeg) fold(kend, kend & 1);
@@ -627,7 +636,7 @@ int op_boundp_multi(cales_ctx *c, int nf, double **p, int which);
 static bool dsmag_fast_ok(const cales_ctx *c) {
   for (int q = 0; q < 4; ++q) if (c->is_wall[q] != 0.) return false;      // walls in x or y: general path
   for (int q = 0; q < 4; ++q) if (c->C.lwm[q] != 0) return false;         // wall model on x or y faces: general path
-  return c->n[2] >= 3 && getenv("CALES_DSMAG_REFERENCE_SEQUENCE") == nullptr;
+  return c->n[2] >= 3 && !c->fl.dsmag_reference_sequence;
 }
 static int dsmag_fast(cales_ctx *c) {
   const int *n = c->n; double **f = c->f; double *visct = f[CALES_VISCT];
@@ -642,14 +651,14 @@ static int dsmag_fast(cales_ctx *c) {
   auto tiles = [&](int ty, int wx, dim3 &mb, dim3 &mg, int &kchunk) {
     mb = dim3(64, ty + 2, 1); mg = dim3((n[0] + wx - 1) / wx, (n[1] + ty - 1) / ty, 1);
     kchunk = n[2];
-    while ((long)mg.x * mg.y * ((n[2] + kchunk - 1) / kchunk) < tile_min_blocks() && kchunk > 32) kchunk = (kchunk + 1) / 2;
-    if (int fk = tile_kchunk((long)mg.x * mg.y, n[2])) kchunk = fk;
+    while ((long)mg.x * mg.y * ((n[2] + kchunk - 1) / kchunk) < tile_min_blocks(c) && kchunk > 32) kchunk = (kchunk + 1) / 2;
+    if (int fk = tile_kchunk(c, (long)mg.x * mg.y, n[2])) kchunk = fk;
     mg.z = (n[2] + kchunk - 1) / kchunk;
   };
   dim3 mb, mg; int kch;
-  const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32) && getenv("CALES_WIDE_OFFSETS") == nullptr;      // 32-bit byte offsets (ldb/stb)
+  const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32) && !c->fl.wide_offsets;      // 32-bit byte offsets (ldb/stb)
   // lazy form (homogeneous sgs BCs): |S| goes straight into the eddy-viscosity field and the last pass only makes the n3 plane coefficients
-  bool lazy = getenv("CALES_DSMAG_EAGER") == nullptr;
+  bool lazy = !c->fl.dsmag_eager;
   for (int q = 0; q < 6; ++q) lazy = lazy && c->C.bcsgs[q] == 0.;
   // K_AC: |S|, |S|Sij, cell-centred and test-filtered velocity in one pass over u,v,w (no wall-model faces ->
   // extrapolate(...,lwm) is a no-op; u,v are extrapolated through the z walls, w on the faces is not, sgs.f90:705-710)
@@ -666,7 +675,7 @@ static int dsmag_fast(cales_ctx *c) {
   // These twelve scratch fields are read by the tile kernels only: with periodic x their ghost columns are not filled (the
   // kernels wrap around instead; an x ghost update touches four cache lines per row for two values), and the z ghost planes
   // of the quantities the wall rule covers are never read.
-  const int perx = (CBP(c, 0, 1) == 'P' && CBP(c, 1, 1) == 'P' && getenv("CALES_DSMAG_XGHOSTS") == nullptr) ? 1 : 0;
+  const int perx = (CBP(c, 0, 1) == 'P' && CBP(c, 1, 1) == 'P' && !c->fl.dsmag_xghosts) ? 1 : 0;
   const int skipz = (zlo && zhi) ? 4 : 0;
   c->bc_skip = perx | skipz;
   int e_ = op_boundp_multi(c, 6, ssij, 1);
@@ -710,7 +719,7 @@ static inline dim3 lin_grid(size_t n) { size_t b = (n + 255) / 256; if (b > 4096
 // damping in one pass of the tile kernel, u,v,w -> visct (4 words/cell instead of the 20 of copy + extrapolate + strain + smag)
 static bool smag_fast_ok(const cales_ctx *c) {
   for (int q = 0; q < 4; ++q) if (c->is_wall[q] != 0. || c->C.lwm[q] != 0) return false;
-  return c->n[2] >= 3 && getenv("CALES_SMAG_REFERENCE_SEQUENCE") == nullptr;
+  return c->n[2] >= 3 && !c->fl.smag_reference_sequence;
 }
 __global__ void k_smag_del(int n, double dl1, double dl2, const double *__restrict__ dzf, double *__restrict__ del) {
   const int k = blockIdx.x * 64 + threadIdx.x;
@@ -724,8 +733,8 @@ static int smag_fast(cales_ctx *c) {
   }
   dim3 mb(64, TYS + 2, 1), mg((n[0] + 63) / 64, (n[1] + TYS - 1) / TYS, 1);
   int kch = n[2];
-  while ((long)mg.x * mg.y * ((n[2] + kch - 1) / kch) < tile_min_blocks() && kch > 32) kch = (kch + 1) / 2;
-  if (int fk = tile_kchunk((long)mg.x * mg.y, n[2])) kch = fk;
+  while ((long)mg.x * mg.y * ((n[2] + kch - 1) / kch) < tile_min_blocks(c) && kch > 32) kch = (kch + 1) / 2;
+  if (int fk = tile_kchunk(c, (long)mg.x * mg.y, n[2])) kch = fk;
   mg.z = (n[2] + kch - 1) / kch;
   StrainTileArgs S = {};
   S.u[0] = f[CALES_U]; S.u[1] = f[CALES_V]; S.u[2] = f[CALES_W]; S.visct = f[CALES_VISCT];
@@ -734,7 +743,7 @@ static int smag_fast(cales_ctx *c) {
   S.wmlo = ISB(c, 0, 3) && LWM(c, 0, 3) != 0; S.wmhi = ISB(c, 1, 3) && LWM(c, 1, 3) != 0;
   S.flo = (1. / c->dzci[0]) * c->dzci[1]; S.fhi = (1. / c->dzci[n[2]]) * c->dzci[n[2] - 1];
   S.zc = c->d_zc; S.del = c->d_del; S.l3 = c->C.l[2]; S.visc = c->visc;
-  const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32) && getenv("CALES_WIDE_OFFSETS") == nullptr;
+  const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32) && !c->fl.wide_offsets;
   if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 1>), mg, mb, 0, c->stream, c->g, S);
   else hipLaunchKernelGGL((k_strain_tile<size_t, 1>), mg, mb, 0, c->stream, c->g, S);
   HIPCHK(c, hipGetLastError());

@@ -904,7 +904,7 @@ static void launch_gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, double
 template <int NV>
 static bool gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, double lscale, const double *da, const double *db, const double *dc,
                          double *p, int fixnull, const TileMap &T) {
-  if (nz < 2 || nz > 1024 || getenv("CALES_GAUSSEL_MARCH")) return false;
+  if (nz < 2 || nz > 1024 || c->fl.gaussel_march) return false;
   if (nz <= 128) launch_gaussel_tile<2, NV>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T);
   else if (nz <= 256) launch_gaussel_tile<4, NV>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T);
   else if (nz <= 512) launch_gaussel_tile<8, NV>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T);
@@ -1068,7 +1068,7 @@ int solver_setup(cales_ctx *c) {
     HIPCHK(c, hipMemcpy(c->d_tw4y, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   if (c->ykind == 2) sp.y8 = false;      // the sign changes of the Dirichlet-Dirichlet transform live in the generic y kernel only
-  if (getenv("CALES_FFT_GENERIC")) sp.x8 = sp.y8 = false;
+  if (c->fl.fft_generic) sp.x8 = sp.y8 = false;
   // eigenvalues (initsolver.f90:66-98); x: modes 0..n1/2 (half-complex symmetry), y: modes 0..n2-1
   std::vector<double> lx(n1 + 2, 0.), ly(n2g);
   hs_eigenvalues(n1, bx.c_str(), 'c', lx.data()); hs_eigenvalues(n2g, by.c_str(), 'c', ly.data());
@@ -1193,20 +1193,20 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
     else if (use8y) hipLaunchKernelGGL((k_fft_y8<0, 0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
     else hipLaunchKernelGGL(k_fft_y<0>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
   // pressure equation without a Dirichlet condition in z: the zero-eigenvalue mode (if x and y have one) is singular
-  const int fixnull = (poisson && CBP(c, 0, 3) != 'D' && CBP(c, 1, 3) != 'D' && getenv("CALES_KEEP_NULL_MODE") == nullptr) ? 1 : 0;
+  const int fixnull = (poisson && CBP(c, 0, 3) != 'D' && CBP(c, 1, 3) != 'D' && !c->fl.keep_null_mode) ? 1 : 0;
   { ProfScope ps(c, "gaussel_z");
     dim3 b(64, 4), gr((ncol + 63) / 64, (n2g + 3) / 4);
     if (c->xkind && !c->ykind)       // real x modes paired into complex columns + periodic y: Hermitian separation of rows ky and N-ky
       hipLaunchKernelGGL(k_gaussel_herm, dim3((unsigned)(((long)4 * ncol * (n2g / 2 + 1) + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S,
                          da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, fixnull);
-    else if (!periodic_z && getenv("CALES_GAUSSEL_PAIR") == nullptr && (fixnull || !poisson || CBP(c, 0, 3) == 'D' || CBP(c, 1, 3) == 'D') &&
+    else if (!periodic_z && !c->fl.gaussel_pair && (fixnull || !poisson || CBP(c, 0, 3) == 'D' || CBP(c, 1, 3) == 'D') &&
              [&]() {
                TileMap T{}; T.blocked = dist ? 1 : 0; T.cw = c->cw; T.n2l = n[1]; T.mofs = mofs; T.nmode = c->xkind ? c->C.ng[0] / 2 : mh;
                T.kstride = (size_t)2 * c->cw * n[1]; T.segstride = T.kstride * n[2];
                const int ndbl = dist ? 2 * c->cw * n[1] : (c->xkind ? 2 * (c->C.ng[0] / 2) : 2 * mh), nseg = dist ? c->P : n2g;
                return c->xkind ? gaussel_tile<1>(c, nz, ndbl, nseg, lscale, da, db, dc, (double *)mode_spec, fixnull, T)
                                : gaussel_tile<2>(c, nz, ndbl, nseg, lscale, da, db, dc, (double *)mode_spec, fixnull, T); }()) {}
-    else if (c->xkind && !periodic_z && getenv("CALES_GAUSSEL_PAIR") == nullptr)
+    else if (c->xkind && !periodic_z && !c->fl.gaussel_pair)
       hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, lscale, da, db, dc,
                          c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, fixnull, 1);
     else if (periodic_z && c->xkind)      // real x modes (one eigenvalue each) with the periodic-z closure: scalar columns of the in-place spectrum, one rank
@@ -1215,7 +1215,7 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
     else if (c->xkind) hipLaunchKernelGGL(k_gaussel_split, gr, b, 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, da, db, dc, c->d_lamx, c->d_lamy,
                                      (double2 *)mode_spec, (double2 *)c->scr1, fixnull);
     else if (periodic_z) hipLaunchKernelGGL((k_gaussel<double2, 1>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2, fixnull);
-    else if (getenv("CALES_GAUSSEL_PAIR")) hipLaunchKernelGGL((k_gaussel<double2, 0>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2, fixnull);
+    else if (c->fl.gaussel_pair) hipLaunchKernelGGL((k_gaussel<double2, 0>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2, fixnull);
     else hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, fixnull, 0); }
   { ProfScope ps(c, "fft_y_bwd");
     if (c->ykind == 5) hipLaunchKernelGGL(k_dst1<1>, dim3(ncol, n[2]), dim3(256), (size_t)2 * (VS->p1y.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1y, ncol, (const cpx *)VS->tw1y, pp, 1., S, mode_spec);
@@ -1313,8 +1313,8 @@ int op_helmholtz_z(cales_ctx *c, int ivel, double alpha) {
   double *fld = c->f[CALES_U + ivel - 1];
   Spec S; S.blocked = 0; S.cw = 0; S.n2l = n[1]; S.n3 = n3;
   if (periodic) hipLaunchKernelGGL((k_gaussel<double, 1>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, 1., abc, abc + n3, abc + 2 * n3, (const double *)nullptr, (const double *)nullptr, fld, c->scr1, c->scr2, 0);
-  else if (getenv("CALES_HELMHOLTZ_Z_PER_COLUMN")) hipLaunchKernelGGL((k_gaussel<double, 0>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, 1., abc, abc + n3, abc + 2 * n3, (const double *)nullptr, (const double *)nullptr, fld, c->scr1, c->scr2, 0);
-  else if (c->P >= 1 && n3 - q >= 2 && n3 - q <= 512 && n3 <= 64 * (n3 - q <= 128 ? 2 : n3 - q <= 256 ? 4 : 8) && getenv("CALES_GAUSSEL_MARCH") == nullptr && [&]() {
+  else if (c->fl.helmholtz_z_per_column) hipLaunchKernelGGL((k_gaussel<double, 0>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, 1., abc, abc + n3, abc + 2 * n3, (const double *)nullptr, (const double *)nullptr, fld, c->scr1, c->scr2, 0);
+  else if (c->P >= 1 && n3 - q >= 2 && n3 - q <= 512 && n3 <= 64 * (n3 - q <= 128 ? 2 : n3 - q <= 256 ? 4 : 8) && !c->fl.gaussel_march && [&]() {
              // the in-LDS tile of the pressure solve on the real field: u, dudtd in, u out (3 words instead of 5)
              TileMap T{}; T.nolam = 1; T.nq = n3;
              if (fused) { T.dud = c->f[CALES_DUDTD + ivel - 1] + 1; T.hf12 = c->hf12; T.force = c->C.is_forced[ivel - 1] ? c->d_force + (ivel - 1) : nullptr;

@@ -264,7 +264,7 @@ int op_rk(cales_ctx *c, int irk, double dt) {
   const double f1 = rk[irk - 1][0] * dt, f2 = rk[irk - 1][1] * dt, f12 = f1 + f2;
   double **f = c->f;
   dim3 b(BX, BY, 1), gr = grid3(c->n[0], c->n[1], c->n[2], b);
-  const bool unfused = getenv("CALES_UNFUSED_RK") != nullptr;
+  const bool unfused = c->fl.unfused_rk;
   if (!unfused && c->n[2] >= 2) {
     if (int e = op_momrk(c, f1, f2, f12)) return e;
   } else {
@@ -406,7 +406,7 @@ int op_correc_updatep(cales_ctx *c, double dt, double alpha, int upd) {
   return 0;
 }
 int op_correc(cales_ctx *c, double dt) {
-  if (getenv("CALES_UNFUSED_CORREC") == nullptr) return op_correc_updatep(c, dt, 0., 0);
+  if (!c->fl.unfused_correc) return op_correc_updatep(c, dt, 0., 0);
   ProfScope ps(c, "correc");
   dim3 b(BX, BY, 1), gr = grid3(c->n[0] + 2, c->n[1] + 2, c->n[2] + 2, b);
   hipLaunchKernelGGL(k_correc, gr, b, 0, c->stream, c->g, dt * c->dli[0], dt * c->dli[1], dt, c->d_dzci, c->f[CALES_PP], c->f[CALES_U],

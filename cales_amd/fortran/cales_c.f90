@@ -119,5 +119,16 @@ module cales_c
     integer(c_int) function cales_comm_init_rccl(ctx,id) bind(C,name='cales_comm_init_rccl')
       import; type(c_ptr), value :: ctx; character(kind=c_char), intent(in) :: id(128)
     end function
+    integer(c_int) function cales_device_count(ndev) bind(C,name='cales_device_count')
+      import; integer(c_int) :: ndev
+    end function
+    integer(c_int) function cales_set_device(dev) bind(C,name='cales_set_device')
+      import; integer(c_int), value :: dev
+    end function
+    ! the rank's rows of the initial field: local haloed arrays (0:n1+1,0:n2/nranks+1,0:n3+1)
+    integer(c_int) function cales_initflow_slab(c,inivel,is_wallturb,u,v,w,p) bind(C,name='cales_initflow_slab')
+      import; type(cales_case), intent(in) :: c; character(kind=c_char) :: inivel(*); integer(c_int), value :: is_wallturb
+      real(c_double) :: u(*),v(*),w(*),p(*)
+    end function
   end interface
 end module cales_c

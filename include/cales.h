@@ -53,6 +53,11 @@ int cales_initflow(const cales_case *c, const char *inivel, int is_wallturb, dou
 /* src/sanity.f90:33-67 rules restated; returns 0 if the case is accepted */
 int cales_check_case(const cales_case *c, char *msg, int msglen);
 
+/* ---- device selection (one process per GPU: a multi-rank host picks its device before cales_create; the reference does this in
+ * src/initmpi.f90:64-73 with acc_set_device_num(mod(local rank, ndev))) ----------------------------- */
+int cales_device_count(int *ndev);
+int cales_set_device(int dev);
+
 /* ---- context ------------------------------------------------------------------------------ */
 /* stream: a hipStream_t to queue on, or NULL to let the context create its own */
 int  cales_create(const cales_case *c, void *stream, cales_ctx **out);

@@ -50,14 +50,15 @@ CASES = {
                    {r"ng\(1:3\) = .*": "ng(1:3) = 12, 8, 10", r"gr = 5\.": "gr = 2.", r"sgstype = 'smag'": "sgstype = 'dsmag'"}, 0),
     "chan_dsmag_wm": ("les/_manuscript_turbulent_channel_wall_model/input.nml",
                       {r"ng\(1:3\) = .*": "ng(1:3) = 12, 8, 10", r"visci = .*": "visci = 5640.", r"sgstype = 'smag'": "sgstype = 'dsmag'"}, 0),
+    # hwm: the example's 0.1 equals zc(1) of the shrunk grid, which sanity.f90:224-231 refuses (zc(1) < hwm)
     "duct_smag_wm": ("les/_manuscript_turbulent_duct_wall_model/input.nml",
-                     {r"ng\(1:3\) = .*": "ng(1:3) = 8, 10, 10"}, 0),
+                     {r"ng\(1:3\) = .*": "ng(1:3) = 8, 10, 10", r"hwm = 0\.1": "hwm = 0.25"}, 0),
     "duct_smag_wm_imp1d": ("les/_manuscript_turbulent_duct_wall_model/input.nml",
-                           {r"ng\(1:3\) = .*": "ng(1:3) = 8, 10, 10"}, 2),
+                           {r"ng\(1:3\) = .*": "ng(1:3) = 8, 10, 10", r"hwm = 0\.1": "hwm = 0.25"}, 2),
     # dynamic Smagorinsky with walls in y/z or x/y/z: the kernel-per-loop sequence of sgs.f90:153-380 and
     # the x/y branches of `extrapolate` (sgs.f90:719-766)
     "duct_dsmag_wm": ("les/_manuscript_turbulent_duct_wall_model/input.nml",
-                      {r"ng\(1:3\) = .*": "ng(1:3) = 8, 10, 10", r"sgstype = 'smag'": "sgstype = 'dsmag'"}, 0),
+                      {r"ng\(1:3\) = .*": "ng(1:3) = 8, 10, 10", r"sgstype = 'smag'": "sgstype = 'dsmag'", r"hwm = 0\.1": "hwm = 0.25"}, 0),
     "duct_dsmag": ("les/_manuscript_turbulent_duct_wall_model/input.nml",
                    {r"ng\(1:3\) = .*": "ng(1:3) = 8, 10, 12", r"sgstype = 'smag'": "sgstype = 'dsmag'",
                     r"lwm\(0:1,1:3\) = .*": "lwm(0:1,1:3) = 0,0, 0,0, 0,0", r"gr = 0\.": "gr = 1.5"}, 0),

@@ -107,3 +107,22 @@ def test_one_rank_nccl_process_group(layer):
     env = dict(os.environ, CALES_COMM=layer, MASTER_PORT=str(29571 + (layer == "torch")))
     r = subprocess.run([sys.executable, os.path.join(here, "_nccl1_worker.py")], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "NCCL1 OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("layer", ["rccl", "torch"])
+def test_n_rank_nccl_process_group(layer):
+    """Real peers: one process per GPU through torch.distributed.run, the exchanges of comm_rccl.cpp (grouped send/recv pairing incl.
+    P = 2 periodic with both neighbours the same peer, ncclAllToAll block layout, all-reduces) against the single-rank run. RCCL
+    refuses two ranks on one device, so this needs at least two GPUs and is skipped on the one-GPU test box."""
+    import os, subprocess, sys
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs")
+    P = 2 if n < 4 else 4
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, CALES_COMM=layer)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={P}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29581 + (layer == "torch")), os.path.join(here, "_ncclN_worker.py")],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "NCCLN OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

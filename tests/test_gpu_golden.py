@@ -179,8 +179,8 @@ def test_imp3d_operators():
         assert relerr(h.get(k)[1:-1, 1:-1, 1:-1], g["m_" + k][1:-1, 1:-1, 1:-1] if g["m_" + k].shape == h.zeros().shape else g["m_" + k]) < TOL, k
     for env in (None, "CALES_UNFUSED_RK"):
         import os
-        if env:
-            os.environ[env] = "1"
+        if env:      # the switches are read when a context is created
+            os.environ[env] = "1"; h.close(); h = _hot(case)
         try:
             h.upload(*(F(g["s0_" + k]) for k in "uvwp")); h.set("visct", F(g["s0_visct"]))
             for k in ("dudto", "dvdto", "dwdto"):
@@ -194,6 +194,7 @@ def test_imp3d_operators():
         finally:
             if env:
                 del os.environ[env]
+    h.upload(*(F(g["s0_" + k]) for k in "uvwp")); h.set("visct", F(g["s0_visct"]))
     assert abs(h.chkdt() / float(g["dt_cfl"]) - 1) < 1e-13
     h.set("p", F(g["s0_p"])); h.set("pp", F(g["upd_pp"]))
     h.updatep(float(g["upd_alpha"]))

@@ -403,3 +403,79 @@ def test_time_steps_imp3d_with_walls(name, ng, sgs):
     assert relerr(a - a.mean(), b - b.mean()) < 1e-8
     assert h.chkdiv()[1] < 1e-11
     h.close()
+
+
+def _laplacian_identity(h, case, grid, rng, planes, tol=1e-9):
+    """L_h(solve(r)) == r on the sampled y rows, for Neumann or periodic pressure BCs (ghost cells from boundp)."""
+    n1, n2, n3 = (int(x) for x in case.ng)
+    rhs = np.zeros((n1 + 2, n2 + 2, n3 + 2), order="F")
+    rhs[1:-1, 1:-1, 1:-1] = rng.rand(n1, n2, n3) - 0.5
+    dzf, dzc = grid["dzf"][1:-1], grid["dzc"]
+    rhs[1:-1, 1:-1, 1:-1] -= (rhs[1:-1, 1:-1, 1:-1] * dzf).sum() / (dzf.sum() * n1 * n2)      # compatible r.h.s. (singular problem)
+    h.set("pp", rhs); h.solver(); h.boundp("pp", 0)
+    p = h.get("pp")
+    dxi, dyi = n1 / case.l[0], n2 / case.l[1]
+    for j in planes:
+        c = p[1:-1, j, 1:-1]
+        lap = ((p[2:, j, 1:-1] - 2 * c + p[:-2, j, 1:-1]) * dxi ** 2 + (p[1:-1, j + 1, 1:-1] - 2 * c + p[1:-1, j - 1, 1:-1]) * dyi ** 2 +
+               ((p[1:-1, j, 2:] - c) / dzc[1:-1] - (c - p[1:-1, j, :-2]) / dzc[:-2]) / dzf)
+        assert np.abs(lap - rhs[1:-1, j, 1:-1]).max() < tol * np.abs(lap).max(), j
+
+
+def test_c4_duct_full_size():
+    """BASELINE.json configs[3] at FULL size on one GPU: square duct 512x256x256, wall model on the four walls, z-implicit
+    (Crank-Nicolson) viscous terms -> Helmholtz sweeps + DCT Poisson solve. Size-independent properties after three steps (the
+    reference's own abort rules, main.f90:523-544: finite divergence, divmax below its bound), bulk velocity held by the forcing,
+    eddy viscosity finite and non-negative, and L_h(solve(r)) = r for the Neumann-Neumann (y, z) solve on sampled rows."""
+    from cales_amd.hotpath import initflow
+    g, case = load_golden("duct_smag_wm_imp1d")
+    case.ng[:] = (512, 256, 256)
+    h = _hot(case)
+    h.upload(*initflow(case)); h.startup()
+    dt = 0.5 * h.chkdt()
+    for _ in range(3):
+        h.step(dt)
+    divtot, divmax = h.chkdiv()
+    assert divmax < 1e-11 and np.isfinite(divtot)
+    assert abs(h.bulk_mean("u", "f") - 1.0) < 1e-12
+    visct = h.get("visct")[1:-1, 1:-1, 1:-1]
+    assert visct.min() >= 0. and np.isfinite(visct).all()
+    del visct
+    small = case.copy(); small.ng[:] = (8, 8, 256)
+    _laplacian_identity(h, case, Oracle(small).grid(), np.random.RandomState(11), (1, 100, 256))
+    h.close()
+
+
+def test_c5_cavity_full_size():
+    """BASELINE.json configs[4] on one GPU: lid-driven cavity, all-Neumann pressure (DCT in x and y), fields of 8.6 GB at 1024^3
+    (64-bit offset kernels, 16 planes per lane in the tridiagonal tile). 1024^3 needs ~40 GB of host memory for the initial fields;
+    with less the test runs 1024x1024x512 (4.3-GB fields, still the 64-bit kernels) and says so. Two steps: divergence at
+    round-off, finite fields, L_h(solve(r)) = r on sampled rows."""
+    from cales_amd.hotpath import initflow
+    free_gb = int(open("/proc/meminfo").read().split("MemAvailable:")[1].split()[0]) / 2 ** 20
+    n3 = 1024 if free_gb > 90 else 512
+    g, case = load_golden("cavity_nnn")
+    case.ng[:] = (1024, 1024, n3)
+    print(f"cavity 1024x1024x{n3} (host MemAvailable {free_gb:.0f} GB)")
+    h = _hot(case)
+    u, v, w, p = initflow(case)
+    h.upload(u, v, w, p); del u, v, w, p
+    h.startup()
+    dt = 0.5 * h.chkdt()
+    for _ in range(2):
+        h.step(dt)
+    divtot, divmax = h.chkdiv()
+    assert divmax < 1e-11 and np.isfinite(divtot)
+    small = case.copy(); small.ng[:] = (8, 8, n3)
+    _laplacian_identity(h, case, Oracle(small).grid(), np.random.RandomState(13), (1, 500, 1024))
+    uu = h.get("u")
+    assert np.isfinite(uu).all() and np.abs(uu[1:-1, 1:-1, -1] + uu[1:-1, 1:-1, -2] - 2.).max() < 1e-13      # lid: u = 1 at the top wall
+    h.close()
+
+
+@pytest.mark.parametrize("name,ng", [("chan_smag", (512, 512, 8)), ("cavity_nnn", (1024, 512, 4)), ("cavity_nnn", (512, 1024, 4)),
+                                     ("duct_smag_wm", (512, 256, 16)), ("chan_smag", (1024, 1024, 2))])
+def test_poisson_solve_production_lengths(name, ng):
+    """The production line lengths (512- and 1024-point r2c/c2c FFTs and DCTs in x and y) against the oracle itself on thin slabs,
+    so the large transforms are checked by value and not only through the operator identity."""
+    test_poisson_solve(name, ng)
