@@ -477,6 +477,150 @@ __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijA
   if (tx == 0 && ty == 0 && kend >= kbeg) fold(kend, kend & 1);
 }
 
+// K_B + K_D + K_F in one pass (the default): as k_lij_mij_tile, but the test filter of the six products |S|Sij is formed on the fly
+// instead of being read back from a pass of its own -- 12 words per cell less (k_filter6_tile's 6 in + 6 out), 12 in and nothing
+// but partial sums out. The kernel is bound by its vector instructions (profiles/r02a_sq.md: k_lij_mij_tile VALU busy 0.61, LDS 0.31),
+// not by LDS or HBM, and LDS has no room for six more double-buffered filter sums, so the y combination of |S|Sij uses neither:
+// every output row loads its own row and the two rows beside it (the neighbours' rows are L1/L2 hits: the same block loads them in
+// the same iteration) and combines them in registers; x by DPP, z from two rolling x/y-combined planes. Tiles of 62 x TYL outputs
+// with TYL = 6: 8 waves per block, two per SIMD, which leaves 256 VGPRs for the 18 more loads in flight.
+#ifndef TYL
+#define TYL 6
+#endif
+struct LmfArgs { LijMijArgs L; const double *ss[6]; };
+template <typename OFF>
+__global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) {
+  const LijMijArgs &A = B.L;
+  __shared__ double sh[2][9][TYL + 2][64];
+  __shared__ double ring[4][3][TYL + 2][64];
+  __shared__ double shr[2][2][TYL + 2];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int i = blockIdx.x * 62 + tx, j = blockIdx.y * TYL + ty;
+  const int kbeg = blockIdx.z * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
+  const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1;
+  const bool outok = tx >= 1 && tx <= 62 && ty >= 1 && ty <= TYL && i <= g.n1 && j <= g.n2;
+  const bool ssok = ty >= 1 && ty <= TYL && i <= g.n1 + 1 && j <= g.n2;      // rows that filter |S|Sij (all 64 lanes: x neighbours by DPP)
+  const int iw = A.perx ? (i == 0 ? g.n1 : (i == g.n1 + 1 ? 1 : i)) : i;
+  const OFF c0 = ldok ? (OFF)g.ix(iw, j, 0) * 8 : 0, sk = (OFF)g.s12 * 8, sj = (OFF)g.s1 * 8;      // byte offsets
+  double sm[3], sc[3], sp[3], sn[3], fn[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    sm[q] = ldok ? ldb(A.uc[q], c0 + (OFF)(kbeg - 1) * sk) : 0.;
+    sc[q] = ldok ? ldb(A.uc[q], c0 + (OFF)kbeg * sk) : 0.;
+    sp[q] = ldok ? ldb(A.uc[q], c0 + (OFF)(kbeg + 1) * sk) : 0.;
+    ring[(kbeg - 1) & 3][q][ty][tx] = ldok ? ldb(A.uf[q], c0 + (OFF)(kbeg - 1) * sk) : 0.;
+    ring[kbeg & 3][q][ty][tx] = ldok ? ldb(A.uf[q], c0 + (OFF)kbeg * sk) : 0.;
+    fn[q] = ldok ? ldb(A.uf[q], c0 + (OFF)(kbeg + 1) * sk) : 0.;
+    if (A.wmlo && kbeg == 1 && q < 2) ring[0][q][ty][tx] = (1. + A.flo) * ring[1][q][ty][tx] - A.flo * fn[q];
+  }
+  // |S|Sij: y and x combination of one plane (three rows in, lanes beside by DPP)
+  auto ssload = [&](int kk, double (*raw)[3]) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const OFF o = c0 + (OFF)kk * sk;
+      raw[q][0] = ssok ? ldb(B.ss[q], o - sj) : 0.; raw[q][1] = ssok ? ldb(B.ss[q], o) : 0.; raw[q][2] = ssok ? ldb(B.ss[q], o + sj) : 0.;
+    }
+  };
+  auto sscomb = [&](const double (*raw)[3], double *X) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const double Y = raw[q][0] + 2. * raw[q][1] + raw[q][2];
+      X[q] = lane_prev(Y) + 2. * Y + lane_next(Y);
+    }
+  };
+  double xm[6], xc[6], xp[6], rw[6][3];
+  // the ghost plane below a wall is never used (LO planes take 4 xc); it is read all the same when the chunk starts inside the field
+  ssload(kbeg - 1, rw); sscomb(rw, xm);
+  ssload(kbeg, rw); sscomb(rw, xc);
+  ssload(kbeg + 1, rw);
+  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+  auto fold = [&](int k, int b) {      // block sums of plane k, fixed order
+    double a = 0., bsum = 0.;
+    for (int q = 1; q <= TYL; ++q) { a += shr[b][0][q]; bsum += shr[b][1][q]; }
+    A.part[(size_t)(k - 1) * A.nblk + blk] = a; A.part[(size_t)(g.n3 + k - 1) * A.nblk + blk] = bsum;
+  };
+  auto plane = [&](const int k, auto lo_c, auto hi_c) {
+    constexpr bool LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+    const int km = (k - 1) & 3, kc = k & 3, kp = (k + 1) & 3, buf = k & 1;
+    const OFF idx = c0 + (OFF)k * sk;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      ring[kp][q][ty][tx] = (HI && A.wmhi && q < 2) ? (1. + A.fhi) * ring[kc][q][ty][tx] - A.fhi * ring[km][q][ty][tx] : fn[q];
+    sscomb(rw, xp);                                    // plane k+1 of |S|Sij (its loads were issued one plane ago)
+    if (k + 2 <= g.n3 + 1) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { sn[q] = ldok ? ldb(A.uc[q], idx + 2 * sk) : 0.; fn[q] = ldok ? ldb(A.uf[q], idx + 2 * sk) : 0.; }
+      ssload(k + 2, rw);
+    }
+    double qm[9], qc[9], qp[9], r[9];
+    uiuj(sc, qc);
+    if (!LO && !HI) { uiuj(sm, qm); uiuj(sp, qp); }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const double G = (LO || HI) ? 4. * qc[q] : qm[q] + 2. * qc[q] + qp[q];
+      r[q] = lane_prev(G) + 2. * G + lane_next(G);
+      sh[buf][q][ty][tx] = r[q];
+    }
+    __syncthreads();
+    if (k > kbeg && tx == 0 && ty == 0) fold(k - 1, buf ^ 1);
+    double lm = 0., mm = 0.;
+    if (outok) {
+      double F[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) F[q] = (sh[buf][q][ty - 1][tx] + 2. * r[q] + sh[buf][q][ty + 1][tx]) / 64.;
+      const double l0 = F[3] - F[0] * F[0], l1 = F[4] - F[1] * F[1], l2 = F[5] - F[2] * F[2], l3 = F[6] - F[0] * F[1],
+                   l4 = F[7] - F[0] * F[2], l5 = F[8] - F[1] * F[2];
+#define RU(dk, dj, di) ring[dk][0][ty + (dj)][tx + (di)]
+#define RV(dk, dj, di) ring[dk][1][ty + (dj)][tx + (di)]
+#define RW(dk, dj, di) ring[dk][2][ty + (dj)][tx + (di)]
+      const double u_mcm = RU(km, 0, -1), u_ccm = RU(km, 0, 0), u_mmc = RU(kc, -1, -1), u_cmc = RU(kc, -1, 0), u_mcc = RU(kc, 0, -1),
+                   u_ccc = RU(kc, 0, 0), u_mpc = RU(kc, 1, -1), u_cpc = RU(kc, 1, 0), u_mcp = RU(kp, 0, -1), u_ccp = RU(kp, 0, 0);
+      const double v_cmm = RV(km, -1, 0), v_ccm = RV(km, 0, 0), v_mmc = RV(kc, -1, -1), v_cmc = RV(kc, -1, 0), v_pmc = RV(kc, -1, 1),
+                   v_mcc = RV(kc, 0, -1), v_ccc = RV(kc, 0, 0), v_pcc = RV(kc, 0, 1), v_cmp = RV(kp, -1, 0), v_ccp = RV(kp, 0, 0);
+      const double w_cmm = RW(km, -1, 0), w_mcm = RW(km, 0, -1), w_ccm = RW(km, 0, 0), w_pcm = RW(km, 0, 1), w_cpm = RW(km, 1, 0),
+                   w_cmc = RW(kc, -1, 0), w_mcc = RW(kc, 0, -1), w_ccc = RW(kc, 0, 0), w_pcc = RW(kc, 0, 1), w_cpc = RW(kc, 1, 0);
+#undef RU
+#undef RV
+#undef RW
+      const double dxi = A.dxi, dyi = A.dyi, zc = A.dzci[k], zm = A.dzci[k - 1];
+      double sij[6];
+      sij[0] = (u_ccc - u_mcc) * dxi; sij[1] = (v_ccc - v_cmc) * dyi; sij[2] = (w_ccc - w_ccm) * A.dzfi[k];
+      sij[3] = .125 * ((u_cpc - u_ccc) * dyi + (v_pcc - v_ccc) * dxi + (u_ccc - u_cmc) * dyi + (v_pmc - v_cmc) * dxi +
+                       (u_mpc - u_mcc) * dyi + (v_ccc - v_mcc) * dxi + (u_mcc - u_mmc) * dyi + (v_cmc - v_mmc) * dxi);
+      sij[4] = .125 * ((u_ccp - u_ccc) * zc + (w_pcc - w_ccc) * dxi + (u_ccc - u_ccm) * zm + (w_pcm - w_ccm) * dxi +
+                       (u_mcp - u_mcc) * zc + (w_ccc - w_mcc) * dxi + (u_mcc - u_mcm) * zm + (w_ccm - w_mcm) * dxi);
+      sij[5] = .125 * ((v_ccp - v_ccc) * zc + (w_cpc - w_ccc) * dyi + (v_ccc - v_ccm) * zm + (w_cpm - w_ccm) * dyi +
+                       (v_cmp - v_cmc) * zc + (w_ccc - w_cmc) * dyi + (v_cmc - v_cmm) * zm + (w_ccm - w_cmm) * dyi);
+      const double s0 = sqrt(2. * (sij[0] * sij[0] + sij[1] * sij[1] + sij[2] * sij[2] + 2. * (sij[3] * sij[3] + sij[4] * sij[4] + sij[5] * sij[5])));
+      const double a2s0 = (LO || HI ? 2.52 : 4.00) * s0;      // alph2 (sgs.f90:783-816)
+      double m[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const double G = (LO || HI) ? 4. * xc[q] : xm[q] + 2. * xc[q] + xp[q];      // filter(|S|Sij) * 64
+        m[q] = 2. * (G * (1. / 64.) - a2s0 * sij[q]);                             // Mij, sgs.f90:261-272
+      }
+      lm = m[0] * l0 + m[1] * l1 + m[2] * l2 + (m[3] * l3 + m[4] * l4 + m[5] * l5) * 2.;       // sgs.f90:344-349
+      mm = m[0] * m[0] + m[1] * m[1] + m[2] * m[2] + (m[3] * m[3] + m[4] * m[4] + m[5] * m[5]) * 2.;       // sgs.f90:350-355
+    }
+    lm = wave_sum_lane63(lm); mm = wave_sum_lane63(mm);
+    if (tx == 63) { shr[buf][0][ty] = lm; shr[buf][1][ty] = mm; }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { sm[q] = sc[q]; sc[q] = sp[q]; sp[q] = sn[q]; }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { xm[q] = xc[q]; xc[q] = xp[q]; }
+  };
+  {
+    const std::true_type T; const std::false_type F_;
+    int k = kbeg;
+    const int klast = (A.zhi && kend == g.n3) ? kend - 1 : kend;
+    if (A.zlo && k == 1 && k <= kend) { plane(k, T, F_); ++k; }
+    for (; k <= klast; ++k) plane(k, F_, F_);
+    if (k <= kend) plane(k, F_, T);
+  }
+  __syncthreads();
+  if (tx == 0 && ty == 0 && kend >= kbeg) fold(kend, kend & 1);
+}
+
 // K_A + K_C in one pass over u,v,w: strain rate (sgs.f90:571-630) stored as |S| and |S|Sij, cell-centred velocity (sgs.f90:860-869) and the
 // test-filtered velocity (sgs.f90:632-679 with the wall rule), all from an LDS ring of three raw planes.
 #ifndef TYS
@@ -685,6 +829,21 @@ static int dsmag_fast(cales_ctx *c) {
   if (!e_) { double *cc[3] = {c->uc, c->vc, c->wc}; e_ = op_boundp_multi(c, 3, cc, 1); }
   c->bc_skip = 0;
   if (e_) return e_;
+  LijMijArgs L;
+  L.uc[0] = c->uc; L.uc[1] = c->vc; L.uc[2] = c->wc; L.uf[0] = c->uf; L.uf[1] = c->vf; L.uf[2] = c->wf;
+  for (int m = 0; m < 6; ++m) L.mf[m] = mij[m];
+  L.part = c->wk[0]; L.dzci = c->d_dzci; L.dzfi = c->d_dzfi; L.dxi = c->dli[0]; L.dyi = c->dli[1];
+  L.zlo = zlo; L.zhi = zhi; L.wmlo = wmlo; L.wmhi = wmhi; L.flo = flo; L.fhi = fhi; L.perx = perx;
+  if (!c->fl.dsmag_unfused_filter) {
+    // K_B + K_DF in one pass: filter(|S|Sij) on the fly, strain rate of the filtered velocity, Mij, Lij, contractions, plane partial sums
+    ProfScope ps(c, "lij_mij_filter_contract");
+    tiles(TYL, 62, mb, mg, kch);
+    L.kchunk = kch; L.nblk = mg.x * mg.y;
+    if ((size_t)2 * n[2] * L.nblk > c->ntot) { c->err = "dsmag: partial-sum scratch too small"; return 1; }
+    LmfArgs B; B.L = L; for (int m = 0; m < 6; ++m) B.ss[m] = ssij[m];
+    if (small) hipLaunchKernelGGL(k_lmf_tile<unsigned>, mg, mb, 0, c->stream, c->g, B); else hipLaunchKernelGGL(k_lmf_tile<size_t>, mg, mb, 0, c->stream, c->g, B);
+    hipLaunchKernelGGL(k_plane_fold, dim3(2 * n[2]), dim3(256), 0, c->stream, n[2], L.nblk, c->wk[0], c->d_p1d);
+  } else {
   // K_B: filter(|S| Sij)
   { ProfScope ps(c, "filter_s0sij");
     tiles(TYB, 64, mb, mg, kch);
@@ -694,14 +853,11 @@ static int dsmag_fast(cales_ctx *c) {
   // K_DF: strain rate of the filtered velocity, Mij, Lij, contractions and plane partial sums in one pass
   { ProfScope ps(c, "lij_mij_contract");
     tiles(TYF, 62, mb, mg, kch);
-    LijMijArgs L;
-    L.uc[0] = c->uc; L.uc[1] = c->vc; L.uc[2] = c->wc; L.uf[0] = c->uf; L.uf[1] = c->vf; L.uf[2] = c->wf;
-    for (int m = 0; m < 6; ++m) L.mf[m] = mij[m];
-    L.part = c->wk[0]; L.dzci = c->d_dzci; L.dzfi = c->d_dzfi; L.dxi = c->dli[0]; L.dyi = c->dli[1];
-    L.kchunk = kch; L.nblk = mg.x * mg.y; L.zlo = zlo; L.zhi = zhi; L.wmlo = wmlo; L.wmhi = wmhi; L.flo = flo; L.fhi = fhi; L.perx = perx;
+    L.kchunk = kch; L.nblk = mg.x * mg.y;
     if ((size_t)2 * n[2] * L.nblk > c->ntot) { c->err = "dsmag: partial-sum scratch too small"; return 1; }
     if (small) hipLaunchKernelGGL(k_lij_mij_tile<unsigned>, mg, mb, 0, c->stream, c->g, L); else hipLaunchKernelGGL(k_lij_mij_tile<size_t>, mg, mb, 0, c->stream, c->g, L);
     hipLaunchKernelGGL(k_plane_fold, dim3(2 * n[2]), dim3(256), 0, c->stream, n[2], L.nblk, c->wk[0], c->d_p1d); }
+  }
   if (c->P > 1) { if (int e = allreduce_res(c, (int)(c->d_p1d - c->res), 2 * n[2], 0)) return e; }   // sgs.f90:475
   const double gar = c->dl[0] * c->dl[1] / (c->C.l[0] * c->C.l[1]);
   if (lazy) {

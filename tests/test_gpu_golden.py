@@ -194,7 +194,6 @@ def test_imp3d_operators():
         finally:
             if env:
                 del os.environ[env]
-    h.upload(*(F(g["s0_" + k]) for k in "uvwp")); h.set("visct", F(g["s0_visct"]))
     assert abs(h.chkdt() / float(g["dt_cfl"]) - 1) < 1e-13
     h.set("p", F(g["s0_p"])); h.set("pp", F(g["upd_pp"]))
     h.updatep(float(g["upd_alpha"]))
