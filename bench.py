@@ -39,6 +39,7 @@ WORDS = {"mom_xyz_ad": 7, "rk_update": 13, "fillps": 4, "correc": 7, "updatep": 
          "strain_filter_uvw": 16,   # u,v,w in; |S|, 6 |S|Sij, 3 cell-centred, 3 test-filtered velocities out
          "filter_s0sij": 12,        # 6 in, 6 out
          "lij_mij_contract": 12,    # 3 + 3 + 6 in; plane partial sums out
+         "lij_mij_filter_contract": 12,   # the same pass with the test filter of |S|Sij formed on the fly: 3 + 3 + 6 (raw |S|Sij) in; partial sums out
          "strain_rate": 10, "filter3d": 2}
 W_STEP = {"none": 44, "smag": 51, "dsmag": 178}   # words/cell/substep of the REFERENCE's loop nests; x3 per step
 
