@@ -6,21 +6,29 @@
 static thread_local std::string g_create_err;
 
 // ------------------------------------------------------------------------------------------ profiling
-int prof_begin(cales_ctx *c, const char *name) {
+int stream_after(cales_ctx *c, hipStream_t later, hipStream_t earlier) {
+  if (c->sync_ev.size() < 64) { hipEvent_t e; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->sync_ev.push_back(e); c->sync_next = c->sync_ev.size() - 1; }
+  hipEvent_t e = c->sync_ev[c->sync_next]; c->sync_next = (c->sync_next + 1) % c->sync_ev.size();
+  HIPCHK(c, hipEventRecord(e, earlier));
+  HIPCHK(c, hipStreamWaitEvent(later, e, 0));
+  return 0;
+}
+int prof_begin(cales_ctx *c, const char *name, hipStream_t s) {
   int slot = -1;
   for (size_t q = 0; q < c->stats.size(); ++q) if (c->stats[q].name == name) { slot = (int)q; break; }
   if (slot < 0) { KernelStat s; s.name = name; c->stats.push_back(s); slot = (int)c->stats.size() - 1; }
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (!c->evpool.empty()) { ev = c->evpool.back(); c->evpool.pop_back(); }
   else { hipEventCreate(&ev.first); hipEventCreate(&ev.second); }
-  hipEventRecord(ev.first, c->stream);
+  hipEventRecord(ev.first, s ? s : c->stream);
   c->pending.push_back({slot, ev});
   return (int)c->pending.size() - 1;
 }
-void prof_end(cales_ctx *c, int idx) { hipEventRecord(c->pending[idx].second.second, c->stream); }
+void prof_end(cales_ctx *c, int idx, hipStream_t s) { hipEventRecord(c->pending[idx].second.second, s ? s : c->stream); }
 void prof_flush(cales_ctx *c) {
   if (c->pending.empty()) return;
   hipStreamSynchronize(c->stream);
+  if (c->comm_stream) hipStreamSynchronize(c->comm_stream);
   for (auto &pe : c->pending) {
     float ms = 0.f;
     hipEventElapsedTime(&ms, pe.second.first, pe.second.second);
@@ -93,6 +101,8 @@ void cales_destroy(cales_ctx *c) {
   hipStreamSynchronize(c->stream);
   prof_flush(c);
   for (auto &ev : c->evpool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+  if (c->comm_stream) { hipStreamSynchronize(c->comm_stream); hipStreamDestroy(c->comm_stream); }
+  for (auto &e : c->sync_ev) hipEventDestroy(e);
   solver_teardown(c);
   for (int q = 0; q < CALES_NFIELDS; ++q) field_free(c, c->f[q]);
   for (int q = 0; q < 3; ++q) field_free(c, c->f2[q]);
@@ -378,6 +388,13 @@ int cales_set_comm(cales_ctx *c, cales_halo_cb halo, cales_alltoall_cb a2a, cale
   if (c->d_p1d && !c->p1d_in_comm) hipFree(c->d_p1d);      // a second call must not free the interior pointer set by the first
   c->d_p1d = c->res + 64;
   c->p1d_in_comm = true;
+  return 0;
+}
+int cales_set_comm_overlap(cales_ctx *c, cales_halo_s_cb halo_s, cales_alltoall_part_cb a2a_part) {
+  if (!c->comm.on) { c->err = "cales_set_comm_overlap: call cales_set_comm first"; return 1; }
+  if (c->fl.no_overlap) return 0;      // CALES_NO_OVERLAP: keep every exchange in order on the one stream (A/B measurements, tests)
+  if (!c->comm_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  c->comm.halo_s = halo_s; c->comm.a2a_part = a2a_part;
   return 0;
 }
 int cales_initflow_slab(const cales_case *cs, const char *inivel, int is_wallturb, double *u, double *v, double *w, double *p) {

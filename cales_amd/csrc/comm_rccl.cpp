@@ -75,7 +75,7 @@ inline void neighbours(const cales_ctx *c, int &lo, int &hi) {
   hi = (c->per_y || c->rank < c->P - 1) ? (c->rank + 1) % c->P : -1;
 }
 
-int native_halo(void *user, int64_t off_slo, int64_t off_shi, int64_t off_rlo, int64_t off_rhi, int64_t count) {
+int native_halo_on(void *user, int64_t off_slo, int64_t off_shi, int64_t off_rlo, int64_t off_rhi, int64_t count, hipStream_t st) {
   cales_ctx *c = static_cast<cales_ctx *>(user);
   NativeComm *nc = static_cast<NativeComm *>(c->native_comm);
   int lo, hi; neighbours(c, lo, hi);
@@ -85,14 +85,39 @@ int native_halo(void *user, int64_t off_slo, int64_t off_shi, int64_t off_rlo, i
   // an error inside the group must still close it: an open group would queue every later collective of this thread for ever
   ncclResult_t rc = ncclSuccess;
   auto add = [&](ncclResult_t r) { if (rc == ncclSuccess) rc = r; };
-  if (lo >= 0) add(g_api.Send(nc->A + off_slo, (size_t)count, ncclDouble, lo, nc->comm, c->stream));
+  if (lo >= 0) add(g_api.Send(nc->A + off_slo, (size_t)count, ncclDouble, lo, nc->comm, st));
   if (hi >= 0) {
-    add(g_api.Recv(nc->B + off_rhi, (size_t)count, ncclDouble, hi, nc->comm, c->stream));
-    add(g_api.Send(nc->A + off_shi, (size_t)count, ncclDouble, hi, nc->comm, c->stream));
+    add(g_api.Recv(nc->B + off_rhi, (size_t)count, ncclDouble, hi, nc->comm, st));
+    add(g_api.Send(nc->A + off_shi, (size_t)count, ncclDouble, hi, nc->comm, st));
   }
-  if (lo >= 0) add(g_api.Recv(nc->B + off_rlo, (size_t)count, ncclDouble, lo, nc->comm, c->stream));
+  if (lo >= 0) add(g_api.Recv(nc->B + off_rlo, (size_t)count, ncclDouble, lo, nc->comm, st));
   add(g_api.GroupEnd());
   if (rc != ncclSuccess) { c->err = std::string("RCCL: ") + g_api.GetErrorString(rc) + " in the halo exchange"; return 1; }
+  return 0;
+}
+int native_halo(void *user, int64_t off_slo, int64_t off_shi, int64_t off_rlo, int64_t off_rhi, int64_t count) {
+  return native_halo_on(user, off_slo, off_shi, off_rlo, off_rhi, count, static_cast<cales_ctx *>(user)->stream);
+}
+int native_halo_s(void *user, int64_t off_slo, int64_t off_shi, int64_t off_rlo, int64_t off_rhi, int64_t count, void *stream) {
+  return native_halo_on(user, off_slo, off_shi, off_rlo, off_rhi, count, static_cast<hipStream_t>(stream));
+}
+// one k-chunk of the slab <-> mode-block transposition: P sends and P receives of `count` doubles in one group (the own block too:
+// RCCL copies it on the device), on the stream the library hands over
+int native_alltoall_part(void *user, int dir, int64_t peer_stride, int64_t off, int64_t count, void *stream) {
+  cales_ctx *c = static_cast<cales_ctx *>(user);
+  NativeComm *nc = static_cast<NativeComm *>(c->native_comm);
+  const double *src = dir == 0 ? nc->A : nc->B; double *dst = dir == 0 ? nc->B : nc->A;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  NCHK(c, g_api.GroupStart());
+  ncclResult_t rc = ncclSuccess;
+  for (int p = 0; p < c->P; ++p) {
+    const ncclResult_t r1 = g_api.Send(src + (size_t)p * peer_stride + off, (size_t)count, ncclDouble, p, nc->comm, st);
+    const ncclResult_t r2 = g_api.Recv(dst + (size_t)p * peer_stride + off, (size_t)count, ncclDouble, p, nc->comm, st);
+    if (rc == ncclSuccess) rc = r1 != ncclSuccess ? r1 : r2;
+  }
+  const ncclResult_t r3 = g_api.GroupEnd();
+  if (rc == ncclSuccess) rc = r3;
+  if (rc != ncclSuccess) { c->err = std::string("RCCL: ") + g_api.GetErrorString(rc) + " in a slice of the all-to-all"; return 1; }
   return 0;
 }
 int native_alltoall(void *user, int dir, int64_t count) {
@@ -140,7 +165,8 @@ int cales_comm_init_rccl(cales_ctx *c, const void *id_in) {
     c->err = "cales_comm_init_rccl: hipMalloc of the staging buffers failed"; g_api.CommDestroy(nc->comm); hipFree(nc->A); delete nc; return 1;
   }
   c->native_comm = nc;
-  return cales_set_comm(c, native_halo, native_alltoall, native_allreduce, c, nc->A, nc->B, n);
+  if (int e = cales_set_comm(c, native_halo, native_alltoall, native_allreduce, c, nc->A, nc->B, n)) return e;
+  return cales_set_comm_overlap(c, native_halo_s, native_alltoall_part);
 }
 
 // called by cales_destroy

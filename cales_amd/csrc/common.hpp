@@ -30,6 +30,7 @@ struct Comm {
   cales_halo_cb halo = nullptr; cales_alltoall_cb a2a = nullptr; cales_allreduce_cb allred = nullptr; void *user = nullptr;
   double *A = nullptr, *B = nullptr; int64_t nbuf = 0;   // two device staging buffers owned by the host (doubles)
   bool on = false;
+  cales_halo_s_cb halo_s = nullptr; cales_alltoall_part_cb a2a_part = nullptr;   // exchanges on the second stream (cales_set_comm_overlap)
 };
 
 // Where the spectral (after the x transform) data of the Poisson solve lives.
@@ -54,7 +55,7 @@ struct Spec {
 
 // Run-time switches: read from the environment ONCE, by cales_create; the launch path only looks at these fields.
 struct Flags {
-  bool unaligned = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_eager = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, gaussel_pair = false, unfused_rk = false, dsmag_unfused_filter = false;
+  bool unaligned = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_eager = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, gaussel_pair = false, unfused_rk = false, dsmag_unfused_filter = false, no_overlap = false;
   int kchunk = 0; long tile_min_blocks = 2048;
   void read_env() {
     unaligned = getenv("CALES_UNALIGNED") != nullptr;
@@ -76,6 +77,7 @@ struct Flags {
     gaussel_pair = getenv("CALES_GAUSSEL_PAIR") != nullptr;
     unfused_rk = getenv("CALES_UNFUSED_RK") != nullptr;
     dsmag_unfused_filter = getenv("CALES_DSMAG_UNFUSED_FILTER") != nullptr;
+    no_overlap = getenv("CALES_NO_OVERLAP") != nullptr;
     kchunk = getenv("CALES_KCHUNK") ? atoi(getenv("CALES_KCHUNK")) : 0;
     tile_min_blocks = getenv("CALES_TILE_MIN_BLOCKS") ? atol(getenv("CALES_TILE_MIN_BLOCKS")) : 2048;
   }
@@ -90,6 +92,8 @@ struct cales_ctx {
   int n[3], lo[3];
   double dl[3], dli[3], visc;
   hipStream_t stream; bool own_stream;
+  hipStream_t comm_stream = nullptr;      // exchanges that overlap kernels (created by cales_set_comm_overlap)
+  std::vector<hipEvent_t> sync_ev; size_t sync_next = 0;      // ordering events between the two streams (no timing), reused round-robin
   std::string err;
   // host copies of the grid
   std::vector<double> dzc, dzf, zc, zf, dzci, dzfi, gvr_c, gvr_f;
@@ -152,6 +156,7 @@ struct cales_ctx {
   double fuse_fillps_dti = 0.;   // != 0: the forward x transform of the next pressure solve forms pp = div(u*)/dtrk itself (cales_step)
   bool defer_force = false;      // explicit step, forced directions periodic, no wall model: u += f is applied by the correction kernel
   bool defer_imp_rhs = false; double hf12 = 0.;   // z-implicit step: u -= hf12*dudtd and u += f are applied inside the Helmholtz sweep
+  bool defer_halo = false; std::vector<double *> deferred;      // y-halo exchanges collected for halo_flush_deferred (k_bound.hip)
   int bc_skip = 0;         // bit d-1: boundp/bounduvw leave direction d alone (set around calls whose consumers do not need it)
   int field_ofs = 0;       // doubles between a field's allocation and its element (0,0,0)
 };
@@ -173,13 +178,16 @@ struct cales_ctx {
   } while (0)
 
 // profiling bracket: PROF_BEGIN(ctx,"name"); launch...; PROF_END(ctx)
-int  prof_begin(cales_ctx *c, const char *name);
-void prof_end(cales_ctx *c, int slot);
+int  prof_begin(cales_ctx *c, const char *name, hipStream_t s = nullptr);
+void prof_end(cales_ctx *c, int slot, hipStream_t s = nullptr);
+// `later` waits for everything queued on `earlier` so far
+int  stream_after(cales_ctx *c, hipStream_t later, hipStream_t earlier);
 void prof_flush(cales_ctx *c);
 struct ProfScope {
   cales_ctx *c; int slot;
-  ProfScope(cales_ctx *c_, const char *name) : c(c_), slot(c_->prof ? prof_begin(c_, name) : -1) {}
-  ~ProfScope() { if (slot >= 0) prof_end(c, slot); }
+  hipStream_t s;
+  ProfScope(cales_ctx *c_, const char *name, hipStream_t s_ = nullptr) : c(c_), slot(c_->prof ? prof_begin(c_, name, s_) : -1), s(s_) {}
+  ~ProfScope() { if (slot >= 0) prof_end(c, slot, s); }
 };
 
 // ---- host-side set-up (host_setup.cpp)
@@ -194,6 +202,7 @@ void   hs_bc_rhs(const char *cbc2, const double *bc, int na, int nb, const doubl
 // ---- device operators (k_*.hip); all asynchronous on c->stream
 int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm, int is_correc, double *u, double *v, double *w);
 int op_boundp(cales_ctx *c, double *p, int which);
+int halo_flush_deferred(cales_ctx *c);
 int op_mom(cales_ctx *c);
 int op_rk(cales_ctx *c, int irk, double dt);
 int op_momrk(cales_ctx *c, double f1, double f2, double f12);

@@ -78,20 +78,39 @@ __global__ __launch_bounds__(256) void k_unpack_y(Geom g, HaloFields H, const do
   if (has_lo) H.p[f][g.ix(i, 0, k)] = lo[q];
   if (has_hi) H.p[f][g.ix(i, g.n2 + 1, k)] = hi[q];
 }
-static int halo_y_comm(cales_ctx *c, int nf, double **flds) {
-  if (!c->comm.on) { c->err = "nranks > 1 but no communication hooks registered (cales_set_comm)"; return 1; }
+static int halo_y_on(cales_ctx *c, int nf, double **flds, hipStream_t st, bool overlapped) {
   const int64_t plane = (int64_t)c->g.s1 * (c->n[2] + 2), cnt = plane * nf;
   if (4 * cnt > c->comm.nbuf) { c->err = "halo staging buffer too small"; return 1; }
   HaloFields H; H.nf = nf; for (int q = 0; q < nf; ++q) H.p[q] = flds[q];
   dim3 b(64, 4, 1), gr((c->g.s1 + 63) / 64, (c->n[2] + 2 + 3) / 4, nf);
-  hipLaunchKernelGGL(k_pack_y, gr, b, 0, c->stream, c->g, H, c->comm.A, c->comm.A + cnt);
-  if (c->comm.halo(c->comm.user, 0, cnt, 0, cnt, cnt)) { c->err = "halo callback failed"; return 1; }
+  hipLaunchKernelGGL(k_pack_y, gr, b, 0, st, c->g, H, c->comm.A, c->comm.A + cnt);
+  { ProfScope ps(c, "halo_exchange", st);
+    const int rc = overlapped ? c->comm.halo_s(c->comm.user, 0, cnt, 0, cnt, cnt, (void *)st) : c->comm.halo(c->comm.user, 0, cnt, 0, cnt, cnt);
+    if (rc) { c->err = "halo callback failed"; return 1; } }
   const int has_lo = (c->per_y || c->rank > 0) ? 1 : 0, has_hi = (c->per_y || c->rank < c->P - 1) ? 1 : 0;
-  hipLaunchKernelGGL(k_unpack_y, gr, b, 0, c->stream, c->g, H, c->comm.B, c->comm.B + cnt, has_lo, has_hi);
+  hipLaunchKernelGGL(k_unpack_y, gr, b, 0, st, c->g, H, c->comm.B, c->comm.B + cnt, has_lo, has_hi);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
-
+static int halo_y_comm(cales_ctx *c, int nf, double **flds) {
+  if (!c->comm.on) { c->err = "nranks > 1 but no communication hooks registered (cales_set_comm)"; return 1; }
+  if (c->defer_halo) { for (int q = 0; q < nf; ++q) c->deferred.push_back(flds[q]); return 0; }      // exchanged later, beside kernels (halo_flush_deferred)
+  return halo_y_on(c, nf, flds, c->stream, false);
+}
+// The y-halo rows of the fields collected while c->defer_halo was set travel on the second stream, after everything queued on the
+// context's stream so far (their ghost-cell kernels included: what those wrote into the ghost rows is overwritten by the rows
+// that arrive, whose own x/z ghost cells the neighbour has already set -- the same values the in-order sequence produces).
+// The caller makes the context's stream wait (stream_after) before the first kernel that reads those ghost rows.
+int halo_flush_deferred(cales_ctx *c) {
+  if (c->deferred.empty()) return 0;
+  if (int e = stream_after(c, c->comm_stream, c->stream)) return e;
+  for (size_t q0 = 0; q0 < c->deferred.size(); q0 += 8) {
+    const int nf = (int)std::min<size_t>(8, c->deferred.size() - q0);
+    if (int e = halo_y_on(c, nf, c->deferred.data() + q0, c->comm_stream, true)) { c->deferred.clear(); return e; }
+  }
+  c->deferred.clear();
+  return 0;
+}
 // halo exchange in the non-pencil directions: y across slabs (or a periodic copy on one rank), z always local
 static int halo_self(cales_ctx *c, int nf, double **flds) {
   if (c->P > 1) { if (int e = halo_y_comm(c, nf, flds)) return e; }

@@ -487,7 +487,7 @@ __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijA
 #ifndef TYL
 #define TYL 6
 #endif
-struct LmfArgs { LijMijArgs L; const double *ss[6]; };
+struct LmfArgs { LijMijArgs L; const double *ss[6]; int by0; };      // by0: first y tile of this launch (interior and edge tiles of a slab are launched apart)
 template <typename OFF>
 __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) {
   const LijMijArgs &A = B.L;
@@ -495,7 +495,8 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
   __shared__ double ring[4][3][TYL + 2][64];
   __shared__ double shr[2][2][TYL + 2];
   const int tx = threadIdx.x, ty = threadIdx.y;
-  const int i = blockIdx.x * 62 + tx, j = blockIdx.y * TYL + ty;
+  const int by = B.by0 + blockIdx.y;
+  const int i = blockIdx.x * 62 + tx, j = by * TYL + ty;
   const int kbeg = blockIdx.z * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
   const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1;
   const bool outok = tx >= 1 && tx <= 62 && ty >= 1 && ty <= TYL && i <= g.n1 && j <= g.n2;
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
   ssload(kbeg - 1, rw); sscomb(rw, xm);
   ssload(kbeg, rw); sscomb(rw, xc);
   ssload(kbeg + 1, rw);
-  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+  const int blk = by * gridDim.x + blockIdx.x;
   auto fold = [&](int k, int b) {      // block sums of plane k, fixed order
     double a = 0., bsum = 0.;
     for (int q = 1; q <= TYL; ++q) { a += shr[b][0][q]; bsum += shr[b][1][q]; }
@@ -821,14 +822,18 @@ static int dsmag_fast(cales_ctx *c) {
   // of the quantities the wall rule covers are never read.
   const int perx = (CBP(c, 0, 1) == 'P' && CBP(c, 1, 1) == 'P' && !c->fl.dsmag_xghosts) ? 1 : 0;
   const int skipz = (zlo && zhi) ? 4 : 0;
+  // several ranks with the second stream: the y-halo rows of the twelve scratch fields travel while the interior tiles of the last pass run
+  const bool overlap = c->P > 1 && c->comm.halo_s && c->comm_stream && !c->fl.dsmag_unfused_filter;
+  c->defer_halo = overlap;
   c->bc_skip = perx | skipz;
   int e_ = op_boundp_multi(c, 6, ssij, 1);
   c->bc_skip = perx;
   if (!e_) e_ = op_bounduvw(c, c->bcuf, c->bcvf, c->bcwf, 0, 0, c->uf, c->vf, c->wf);
   c->bc_skip = perx | skipz;
   if (!e_) { double *cc[3] = {c->uc, c->vc, c->wc}; e_ = op_boundp_multi(c, 3, cc, 1); }
-  c->bc_skip = 0;
-  if (e_) return e_;
+  c->bc_skip = 0; c->defer_halo = false;
+  if (!e_ && overlap) e_ = halo_flush_deferred(c);
+  if (e_) { c->deferred.clear(); return e_; }
   LijMijArgs L;
   L.uc[0] = c->uc; L.uc[1] = c->vc; L.uc[2] = c->wc; L.uf[0] = c->uf; L.uf[1] = c->vf; L.uf[2] = c->wf;
   for (int m = 0; m < 6; ++m) L.mf[m] = mij[m];
@@ -841,7 +846,18 @@ static int dsmag_fast(cales_ctx *c) {
     L.kchunk = kch; L.nblk = mg.x * mg.y;
     if ((size_t)2 * n[2] * L.nblk > c->ntot) { c->err = "dsmag: partial-sum scratch too small"; return 1; }
     LmfArgs B; B.L = L; for (int m = 0; m < 6; ++m) B.ss[m] = ssij[m];
-    if (small) hipLaunchKernelGGL(k_lmf_tile<unsigned>, mg, mb, 0, c->stream, c->g, B); else hipLaunchKernelGGL(k_lmf_tile<size_t>, mg, mb, 0, c->stream, c->g, B);
+    auto launch = [&](int by0, int nby) {
+      if (nby <= 0) return;
+      B.by0 = by0; const dim3 gg(mg.x, nby, mg.z);
+      if (small) hipLaunchKernelGGL(k_lmf_tile<unsigned>, gg, mb, 0, c->stream, c->g, B); else hipLaunchKernelGGL(k_lmf_tile<size_t>, gg, mb, 0, c->stream, c->g, B);
+    };
+    if (overlap) {
+      // tiles that read the ghost rows j = 0 or j = n2+1 wait for the rows in flight; the others run beside the exchange
+      int hi0 = (int)mg.y; while (hi0 > 1 && (hi0 - 1) * TYL + TYL + 1 >= n[1] + 1) --hi0;      // first tile (> 0) that reaches row n2+1
+      launch(1, hi0 - 1);
+      if (int e = stream_after(c, c->stream, c->comm_stream)) return e;
+      launch(0, 1); launch(hi0, (int)mg.y - hi0);
+    } else launch(0, (int)mg.y);
     hipLaunchKernelGGL(k_plane_fold, dim3(2 * n[2]), dim3(256), 0, c->stream, n[2], L.nblk, c->wk[0], c->d_p1d);
   } else {
   // K_B: filter(|S| Sij)

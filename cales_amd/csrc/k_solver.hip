@@ -204,11 +204,11 @@ __device__ inline int dct_src(int e, int n) { return e < n / 2 ? 2 * e : 2 * (n 
 // (fillps.f90:36-47, same expression as k_fillps) -- the separate fillps pass and its write + re-read of pp disappear.
 // mean_mask != 0: the pass also sums comp*grid_vol_ratio(k) of the forced velocity components it reads anyway (bulk_mean,
 // utils.f90:35-44), one partial per block and component -> the separate reduction pass over u disappears.
-struct FillArgs { const double *u, *v, *w, *dzfi; double dti, dtidxi, dtidyi; int mean_mask; const double *gvr_f, *gvr_c; double *part; };
+struct FillArgs { const double *u, *v, *w, *dzfi; double dti, dtidxi, dtidyi; int mean_mask; const double *gvr_f, *gvr_c; double *part; int pstride = 0, pofs = 0; };      // pstride: partial sums per component over all launches of a chunked pass (0: gridDim.x)
 template <int INV, int KIND, int FILL = 0>
 __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const cpx *__restrict__ twg, const cpx *__restrict__ twpg,
                                                  const cpx *__restrict__ twd, double *__restrict__ p, double scale, Spec S, double2 *__restrict__ spec,
-                                                 FillArgs F = FillArgs{}) {
+                                                 FillArgs F = FillArgs{}, long rbeg = 0, long rend = -1) {      // rows [rbeg, rend) of the (j,k) row list: a k-chunk of the pipelined solve
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int kind = KIND;                                                 // 0 periodic (R2HC/HC2R), 1 Neumann-Neumann (DCT-II/III)
   const int T = nh >> 3, R = blockDim.x / T, row = threadIdx.x / T, t = threadIdx.x % T, ld = lpad(nh) + 2;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const
   for (int q = threadIdx.x; q < nh; q += blockDim.x) tw[q] = twg[q];
   for (int q = threadIdx.x; q <= nh; q += blockDim.x) twp[q] = twpg[q];
   if (kind) for (int q = threadIdx.x; q <= nh; q += blockDim.x) twl[q] = twd[q];
-  const long nrows = (long)g.n2 * g.n3;
+  const long nrows = rend < 0 ? (long)g.n2 * g.n3 : rend;
   const int NE = 8;                                                          // elements per thread and row: nh / T
   cpx nxt[NE + 1];
   double macc[3] = {0., 0., 0.};
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const
       for (int e = 0; e < NE; ++e) { const double2 v = spec[S.at_slab(g, t + e * T, j, k)]; nxt[e] = cpx{v.x, v.y}; }
     }
   };
-  long r = ((long)blockIdx.x * iters) * R + row;
+  long r = rbeg + ((long)blockIdx.x * iters) * R + row;
   fetch(r);
   for (int it = 0; it < iters; ++it, r += R) {
     const bool live = r < nrows;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const
       for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
       if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
       __syncthreads();
-      if (threadIdx.x == 0) { double a = 0.; for (unsigned w = 0; w < blockDim.x / 64; ++w) a += red[w]; F.part[(size_t)q * gridDim.x + blockIdx.x] = a; }
+      if (threadIdx.x == 0) { double a = 0.; for (unsigned w = 0; w < blockDim.x / 64; ++w) a += red[w]; F.part[(size_t)q * (F.pstride ? F.pstride : gridDim.x) + F.pofs + blockIdx.x] = a; }
       __syncthreads();
     }
   }
@@ -431,11 +431,11 @@ __global__ __launch_bounds__(256) void k_fft_y4(Geom g, FftPlan P, int CB, int n
 // register prefetch of the next plane; twiddles in LDS.
 template <int INV, int KIND>
 __global__ __launch_bounds__(512) void k_fft_y8(Geom g, int N, int ncols, int kchunk, const cpx *__restrict__ twg,
-                                                 const cpx *__restrict__ twd, Spec S, double2 *__restrict__ pc) {
+                                                 const cpx *__restrict__ twd, Spec S, double2 *__restrict__ pc, int k0 = 0, int k1 = -1) {      // planes k0+1..k1 (k1 < 0: all)
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int kind = KIND;
   const int T = N >> 3, CB = blockDim.x / T, ld = lpad(N) + 1;
-  const int m0 = blockIdx.x * CB, kbeg = blockIdx.y * kchunk + 1, kend = min(kbeg + kchunk - 1, g.n3);
+  const int m0 = blockIdx.x * CB, kbeg = k0 + blockIdx.y * kchunk + 1, kend = min(kbeg + kchunk - 1, k1 < 0 ? g.n3 : k1);
   cpx *tw = reinterpret_cast<cpx *>(smem), *base = tw + N;
   for (int q = threadIdx.x; q < N; q += blockDim.x) tw[q] = twg[q];
   const int NE = 8;                                                          // CB*N / blockDim.x
@@ -1159,6 +1159,59 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
   const unsigned xblocks = (unsigned)((xgroups + xiters - 1) / xiters);
   int ykchunk = 1; { const long cg = (ncol + CB8 - 1) / CB8; while (ykchunk < 8 && cg * (n[2] / (ykchunk * 2)) >= 2048 && n[2] % (ykchunk * 2) == 0) ykchunk *= 2; }
   const int ychunks = (n[2] + ykchunk - 1) / ykchunk;
+  // ---- pipelined exchange (cales_set_comm_overlap): the spectrum travels in k-chunks on the second stream while the x transforms of
+  // the next chunk and the y transforms of the previous one run on the context's stream (the reference's cuDecomp pipelined
+  // transposes, src/initmpi.f90:94-139). Radix-8 periodic / Neumann-Neumann transforms only; everything else keeps the single exchange.
+  int NCH = 1;
+  if (dist && c->comm.a2a_part && c->comm_stream && use8x && use8y) { if (n[2] % 4 == 0 && n[2] >= 32) NCH = 4; else if (n[2] % 2 == 0 && n[2] >= 8) NCH = 2; }
+  const bool pipe = NCH > 1;
+  const int kpc = n[2] / NCH;                                   // planes per chunk
+  const int64_t a2a_stride = a2a_count, a2a_chunk = (int64_t)kpc * n[1] * c->cw * 2;
+  const long rows_c = (long)n[1] * kpc, xgroups_c = (rows_c + Rx8 - 1) / Rx8;
+  int xiters_c = 1; while (xiters_c < 8 && xgroups_c / (xiters_c * 2) >= 2048 / NCH) xiters_c *= 2;
+  const unsigned xblocks_c = (unsigned)((xgroups_c + xiters_c - 1) / xiters_c);
+  int ykchunk_c = 1; { const long cg = (ncol + CB8 - 1) / CB8; while (ykchunk_c < 8 && cg * (kpc / (ykchunk_c * 2)) >= 2048 / NCH && kpc % (ykchunk_c * 2) == 0) ykchunk_c *= 2; }
+  hipEvent_t ev_arrived[4];
+  auto mark = [&](hipStream_t st, hipEvent_t &e) -> int {
+    if (c->sync_ev.size() < 64) { hipEvent_t ne; HIPCHK(c, hipEventCreateWithFlags(&ne, hipEventDisableTiming)); c->sync_ev.push_back(ne); c->sync_next = c->sync_ev.size() - 1; }
+    e = c->sync_ev[c->sync_next]; c->sync_next = (c->sync_next + 1) % c->sync_ev.size();
+    HIPCHK(c, hipEventRecord(e, st)); return 0; };
+  auto exchange_chunk = [&](int dir, int ch) -> int {          // comm stream: after everything queued on the context's stream so far
+    if (int e = stream_after(c, c->comm_stream, c->stream)) return e;
+    { ProfScope ps(c, "alltoall", c->comm_stream);
+      if (c->comm.a2a_part(c->comm.user, dir, a2a_stride, (int64_t)ch * a2a_chunk, a2a_chunk, (void *)c->comm_stream)) { c->err = "alltoall_part callback failed"; return 1; } }
+    return mark(c->comm_stream, ev_arrived[ch]); };
+  if (pipe) {
+    const bool fill = poisson && c->fuse_fillps_dti != 0. && sp->x8;
+    FillArgs F{};
+    if (fill) {
+      const double dti = c->fuse_fillps_dti;
+      F = FillArgs{c->f[CALES_U], c->f[CALES_V], c->f[CALES_W], c->d_dzfi, dti, dti * c->dli[0], dti * c->dli[1], c->fuse_mean_mask, c->d_gvr_f, c->d_gvr_c, nullptr};
+      if (F.mean_mask) {
+        const size_t need = 3 * (size_t)xblocks_c * NCH;
+        if (c->n_mpart < need) { if (c->d_mpart) hipFree(c->d_mpart); HIPCHK(c, hipMalloc(&c->d_mpart, need * sizeof(double))); c->n_mpart = need; }
+        F.part = c->d_mpart; F.pstride = (int)(xblocks_c * NCH);
+      }
+    }
+    for (int ch = 0; ch < NCH; ++ch) {
+      const long rb = (long)n[1] * kpc * ch, re = rb + rows_c;
+      { ProfScope ps(c, fill ? "fillps_fft_x_fwd" : "fft_x_fwd");
+        F.pofs = (int)(xblocks_c * ch);
+        if (fill && c->xkind) hipLaunchKernelGGL((k_fft_x8<0, 1, 1>), dim3(xblocks_c), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters_c, (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec, F, rb, re);
+        else if (fill) hipLaunchKernelGGL((k_fft_x8<0, 0, 1>), dim3(xblocks_c), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters_c, (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec, F, rb, re);
+        else if (c->xkind) hipLaunchKernelGGL((k_fft_x8<0, 1>), dim3(xblocks_c), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters_c, (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec, FillArgs{}, rb, re);
+        else hipLaunchKernelGGL((k_fft_x8<0, 0>), dim3(xblocks_c), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters_c, (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec, FillArgs{}, rb, re); }
+      if (int e = exchange_chunk(0, ch)) return e;
+    }
+    if (fill && F.mean_mask) if (int e = op_force_from_partials(c, F.mean_mask, F.part, (int)(xblocks_c * NCH))) return e;
+    for (int ch = 0; ch < NCH; ++ch) {
+      HIPCHK(c, hipStreamWaitEvent(c->stream, ev_arrived[ch], 0));
+      ProfScope ps(c, "fft_y_fwd");
+      const dim3 gy((ncol + CB8 - 1) / CB8, (kpc + ykchunk_c - 1) / ykchunk_c);
+      if (c->ykind) hipLaunchKernelGGL((k_fft_y8<0, 1>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1));
+      else hipLaunchKernelGGL((k_fft_y8<0, 0>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1));
+    }
+  } else {
   if (poisson && c->fuse_fillps_dti != 0. && sp->x8) {
     ProfScope ps(c, "fillps_fft_x_fwd");
     const double dti = c->fuse_fillps_dti;
@@ -1192,6 +1245,7 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
     else if (use8y && c->ykind) hipLaunchKernelGGL((k_fft_y8<0, 1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
     else if (use8y) hipLaunchKernelGGL((k_fft_y8<0, 0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
     else hipLaunchKernelGGL(k_fft_y<0>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
+  }
   // pressure equation without a Dirichlet condition in z: the zero-eigenvalue mode (if x and y have one) is singular
   const int fixnull = (poisson && CBP(c, 0, 3) != 'D' && CBP(c, 1, 3) != 'D' && !c->fl.keep_null_mode) ? 1 : 0;
   { ProfScope ps(c, "gaussel_z");
@@ -1217,6 +1271,22 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
     else if (periodic_z) hipLaunchKernelGGL((k_gaussel<double2, 1>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2, fixnull);
     else if (c->fl.gaussel_pair) hipLaunchKernelGGL((k_gaussel<double2, 0>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2, fixnull);
     else hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, fixnull, 0); }
+  if (pipe) {
+    for (int ch = 0; ch < NCH; ++ch) {
+      { ProfScope ps(c, "fft_y_bwd");
+        const dim3 gy((ncol + CB8 - 1) / CB8, (kpc + ykchunk_c - 1) / ykchunk_c);
+        if (c->ykind) hipLaunchKernelGGL((k_fft_y8<1, 1>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1));
+        else hipLaunchKernelGGL((k_fft_y8<1, 0>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1)); }
+      if (int e = exchange_chunk(1, ch)) return e;
+    }
+    for (int ch = 0; ch < NCH; ++ch) {
+      HIPCHK(c, hipStreamWaitEvent(c->stream, ev_arrived[ch], 0));
+      ProfScope ps(c, "fft_x_bwd");
+      const long rb = (long)n[1] * kpc * ch, re = rb + rows_c;
+      if (c->xkind) hipLaunchKernelGGL((k_fft_x8<1, 1>), dim3(xblocks_c), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters_c, (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec, FillArgs{}, rb, re);
+      else hipLaunchKernelGGL((k_fft_x8<1, 0>), dim3(xblocks_c), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters_c, (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec, FillArgs{}, rb, re);
+    }
+  } else {
   { ProfScope ps(c, "fft_y_bwd");
     if (c->ykind == 5) hipLaunchKernelGGL(k_dst1<1>, dim3(ncol, n[2]), dim3(256), (size_t)2 * (VS->p1y.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1y, ncol, (const cpx *)VS->tw1y, pp, 1., S, mode_spec);
     else if (c->ykind == 3) hipLaunchKernelGGL(k_fft_y4<0>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
@@ -1237,6 +1307,7 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
                        (const cpx *)c->d_twx, (const cpx *)c->d_tw4x, pp, c->normfft, S, slab_spec);
     else hipLaunchKernelGGL(k_fft_x<1>, dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx, c->xkind,
                        (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec); }
+  }
   HIPCHK(c, hipGetLastError());
   return 0;
 }

@@ -28,6 +28,8 @@ from .nml import Case
 HALO_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64)
 A2A_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int64)
 ARED_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int)
+HALO_S_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p)
+A2A_PART_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p)
 
 
 def slab_rows(ng2: int, nranks: int, rank: int):
@@ -98,6 +100,37 @@ class TorchComm:
         d.all_reduce(self.A[off:off + count], op=rop, group=self.group)
         return 0
 
+    def _on(self, stream):
+        """context that issues the collectives on the library's second stream (a raw hipStream_t), or a no-op on CPU tensors"""
+        import contextlib
+        if not stream or self.backend == "gloo":
+            return contextlib.nullcontext()
+        return self.torch.cuda.stream(self.torch.cuda.ExternalStream(int(stream)))
+
+    def halo_s(self, off_slo, off_shi, off_rlo, off_rhi, count, stream) -> int:
+        with self._on(stream):
+            return self.halo(off_slo, off_shi, off_rlo, off_rhi, count)
+
+    def alltoall_part(self, direction, peer_stride, off, count, stream) -> int:
+        """One k-chunk of the transposition (include/cales.h, cales_alltoall_part_cb): slice [off, off+count) of every peer block."""
+        src, dst = (self.A, self.B) if direction == 0 else (self.B, self.A)
+        sl = [slice(q * peer_stride + off, q * peer_stride + off + count) for q in range(self.P)]
+        d = self.dist
+        with self._on(stream):
+            if self.backend == "gloo":
+                ops = []
+                for q in range(self.P):
+                    if q == self.r:
+                        dst[sl[q]].copy_(src[sl[q]])
+                    else:
+                        ops.append(d.P2POp(d.isend, src[sl[q]], q, self.group))
+                        ops.append(d.P2POp(d.irecv, dst[sl[q]], q, self.group))
+                for req in d.batch_isend_irecv(ops) if ops else []:
+                    req.wait()
+            else:
+                d.all_to_all([dst[x] for x in sl], [src[x] for x in sl], group=self.group)
+        return 0
+
 
 class LoopbackWorld:
     """Shared state of P emulated ranks (threads) on one device."""
@@ -138,6 +171,32 @@ class LoopbackComm:
             for q in range(self.P):     # block r of rank q's send buffer -> my block q
                 dst[q * count:(q + 1) * count].copy_(src_all[q][self.r * count:(self.r + 1) * count])
         self._rendezvous()
+        return 0
+
+    def _ext(self, stream):
+        return self.torch.cuda.ExternalStream(int(stream)) if stream else self.stream
+
+    def halo_s(self, off_slo, off_shi, off_rlo, off_rhi, count, stream) -> int:
+        st = self._ext(stream)
+        lo, hi = y_neighbours(self.r, self.P, self.per)
+        st.synchronize(); self.w.barrier.wait()
+        with self.torch.cuda.stream(st):
+            if lo is not None:
+                self.B[off_rlo:off_rlo + count].copy_(self.w.A[lo][off_shi:off_shi + count])
+            if hi is not None:
+                self.B[off_rhi:off_rhi + count].copy_(self.w.A[hi][off_slo:off_slo + count])
+        st.synchronize(); self.w.barrier.wait()
+        return 0
+
+    def alltoall_part(self, direction, peer_stride, off, count, stream) -> int:
+        st = self._ext(stream)
+        src_all = self.w.A if direction == 0 else self.w.B
+        dst = self.B if direction == 0 else self.A
+        st.synchronize(); self.w.barrier.wait()
+        with self.torch.cuda.stream(st):
+            for q in range(self.P):     # slice of block r of rank q's send buffer -> the same slice of my block q
+                dst[q * peer_stride + off:q * peer_stride + off + count].copy_(src_all[q][self.r * peer_stride + off:self.r * peer_stride + off + count])
+        st.synchronize(); self.w.barrier.wait()
         return 0
 
     def allreduce(self, off, count, op) -> int:
@@ -199,6 +258,10 @@ class SlabHotPath(HotPath):
                     ARED_CB(lambda u, o, n_, op: self._guard(self.comm.allreduce, o, n_, op)))
         self._chk(self.L.cales_set_comm(self.h, self._cb[0], self._cb[1], self._cb[2], None,
                                         C.c_void_p(self.A.data_ptr()), C.c_void_p(self.B.data_ptr()), C.c_int64(self.nbuf)))
+        # exchanges beside the kernels on the library's second stream (CALES_NO_OVERLAP keeps them in order on the one stream)
+        self._cb2 = (HALO_S_CB(lambda u, a, b, c_, d, n_, st: self._guard2(self.comm.halo_s, a, b, c_, d, n_, st)),
+                     A2A_PART_CB(lambda u, d, ps, o, n_, st: self._guard2(self.comm.alltoall_part, d, ps, o, n_, st)))
+        self._chk(self.L.cales_set_comm_overlap(self.h, self._cb2[0], self._cb2[1]))
 
     def _init_native(self, dist) -> bool:
         """Rank 0 creates the RCCL rendezvous token, torch.distributed carries it, every rank joins (collective). All ranks
@@ -219,6 +282,15 @@ class SlabHotPath(HotPath):
         try:
             with self.torch.cuda.stream(self.stream):
                 return int(fn(*a))
+        except Exception as e:           # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            self._cb_error = e
+            return 1
+
+    def _guard2(self, fn, *a) -> int:
+        try:
+            return int(fn(*a))
         except Exception as e:           # never let an exception cross the C boundary
             import traceback
             traceback.print_exc()

@@ -126,6 +126,18 @@ typedef int (*cales_allreduce_cb)(void *user, int64_t off, int64_t count, int op
 int cales_comm_buffer_doubles(const cales_ctx *ctx, int64_t *n);      /* required size of A and of B */
 int cales_set_comm(cales_ctx *ctx, cales_halo_cb halo, cales_alltoall_cb a2a, cales_allreduce_cb allred, void *user,
                    double *bufA, double *bufB, int64_t nbuf);
+/* Optional, after cales_set_comm: exchanges that may run BESIDE the kernels (the reference's non-blocking halos, src/bound.f90:619-696
+ * `_ASYNC_HALO`, and cuDecomp's pipelined transposes, src/initmpi.f90:94-139). The library owns a second HIP stream and the events
+ * between the two; it hands that stream to these callbacks, which must enqueue ALL their work on it (no host synchronisation):
+ *   halo_s:        as `halo`, on `stream`
+ *   alltoall_part: a slice of the all-to-all: for every peer p, send src[p*peer_stride + off, +count) to p and receive p's slice into
+ *                  dst[p*peer_stride + off, +count); dir 0: src = A, dst = B; dir 1: src = B, dst = A. The Poisson solve then sends the
+ *                  spectrum in k-chunks: the x transforms of chunk c+1 and the y transforms of chunk c-1 run while chunk c travels;
+ *                  the y halos of the dynamic model's twelve scratch fields travel while the interior tiles of its last pass run.
+ * Without this call (or with NULL entries) every exchange is issued in order on the context's stream, as before. */
+typedef int (*cales_halo_s_cb)(void *user, int64_t off_send_lo, int64_t off_send_hi, int64_t off_recv_lo, int64_t off_recv_hi, int64_t count, void *stream);
+typedef int (*cales_alltoall_part_cb)(void *user, int dir, int64_t peer_stride, int64_t off, int64_t count, void *stream);
+int cales_set_comm_overlap(cales_ctx *ctx, cales_halo_s_cb halo_s, cales_alltoall_part_cb a2a_part);
 /* Native alternative to cales_set_comm: the library performs the three exchanges itself with RCCL (xGMI) on the context's
  * stream -- grouped ncclSend/ncclRecv for the halo rows, ncclAllToAll for the transposition of the Poisson solve (one pair
  * per solve where src/solver.f90:50-66 needs four pencil transposes), ncclAllReduce for the reductions. Rank 0 obtains the
