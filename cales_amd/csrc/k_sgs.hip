@@ -636,7 +636,29 @@ struct StrainTileArgs {
   int wmlo, wmhi; double flo, fhi;      // wall-model z faces: ghost planes of u,v by extrapolate(...,lwm), sgs.f90:683-748
   // SMAG = 1 (static Smagorinsky with van Driest damping for z walls, sgs.f90:98-152): the only output is visct
   double *visct; const double *zc, *del; double l3, visc;      // del(k) = (dx dy dzf(k))^(1/3)
+  // SMAG = 1 with walls in y (ducts): wylo/wyhi = no-slip y walls owned by this rank (van Driest distance and shear, the latter from
+  // twy(side, k, i) = sqrt(tau_w) of k_wall_shear_y); wmylo/wmyhi = wall-model y faces: the strain rate sees ghost rows of u and w
+  // extrapolated from the interior (extrapolate(...,lwm) along y, sgs.f90:683-748)
+  int wylo, wyhi, wmylo, wmyhi; const double *twy; double dl2;
 };
+// sqrt(tau_w) at the two y walls for every (i, k): the argument of the van Driest damping of the cells whose nearest wall is a y wall
+// (sgs.f90:117-143, cases 3 and 4 of the select), from the fields themselves (their ghost cells, not the extrapolated ones)
+__global__ __launch_bounds__(256) void k_wall_shear_y(Geom g, const double *__restrict__ u, const double *__restrict__ w, double visc, double dyi,
+                                                      int lo, int hi, double *__restrict__ twy) {
+  const int i = blockIdx.x * 64 + threadIdx.x + 1, k = blockIdx.y * 4 + threadIdx.y + 1;
+  if (i > g.n1 || k > g.n3) return;
+  const int n2 = g.n2;
+  if (lo) {
+    const double t1 = u[g.ix(i, 1, k)] - u[g.ix(i, 0, k)] + u[g.ix(i - 1, 1, k)] - u[g.ix(i - 1, 0, k)];
+    const double t2 = w[g.ix(i, 1, k)] - w[g.ix(i, 0, k)] + w[g.ix(i, 1, k - 1)] - w[g.ix(i, 0, k - 1)];
+    twy[(size_t)k * g.s1 + i] = sqrt(0.5 * visc * (sqrt(t1 * t1 + t2 * t2) * dyi));
+  }
+  if (hi) {
+    const double t1 = u[g.ix(i, n2, k)] - u[g.ix(i, n2 + 1, k)] + u[g.ix(i - 1, n2, k)] - u[g.ix(i - 1, n2 + 1, k)];
+    const double t2 = w[g.ix(i, n2, k)] - w[g.ix(i, n2 + 1, k)] + w[g.ix(i, n2, k - 1)] - w[g.ix(i, n2 + 1, k - 1)];
+    twy[(size_t)(g.n3 + 2 + k) * g.s1 + i] = sqrt(0.5 * visc * (sqrt(t1 * t1 + t2 * t2) * dyi));
+  }
+}
 template <typename OFF, int SMAG>
 __global__ __launch_bounds__(64 * (TYS + 2)) void k_strain_tile(Geom g, StrainTileArgs A) {
   // (one barrier per plane with four ring slots and double-buffered sums, as in k_lij_mij_tile, measured 13 % slower here)
@@ -651,16 +673,23 @@ __global__ __launch_bounds__(64 * (TYS + 2)) void k_strain_tile(Geom g, StrainTi
   const bool outok = ty >= 1 && ty <= TYS && i <= g.n1 && j <= g.n2;
   const OFF c0 = ldok ? (OFF)g.ix(i, j, 0) * 8 : 0, ch = hok ? (OFF)g.ix(ih, j, 0) * 8 : 0, sk = (OFF)g.s12 * 8;   // byte offsets
   double fn[3], fh[3];
+  // ghost rows at wall-model y faces (SMAG pass of ducts): u and w are replaced by 2 Q(1) - Q(2) along y; v, normal to the face, is not
+  const int yex = !SMAG ? 0 : (A.wmylo && j == 0) ? 1 : (A.wmyhi && j == g.n2 + 1) ? -1 : 0;
+  const OFF sjb = (OFF)g.s1 * 8;
+  auto ld = [&](int q, OFF o) -> double {
+    if (SMAG && yex != 0 && q != 1) return yex > 0 ? 2. * ldb(A.u[q], o + sjb) - ldb(A.u[q], o + 2 * sjb) : 2. * ldb(A.u[q], o - sjb) - ldb(A.u[q], o - 2 * sjb);
+    return ldb(A.u[q], o);
+  };
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
-    ring[(kbeg - 1) % 3][q][ty][tx + 1] = ldok ? ldb(A.u[q], c0 + (OFF)(kbeg - 1) * sk) : 0.;
-    ring[kbeg % 3][q][ty][tx + 1] = ldok ? ldb(A.u[q], c0 + (OFF)kbeg * sk) : 0.;
+    ring[(kbeg - 1) % 3][q][ty][tx + 1] = ldok ? ld(q, c0 + (OFF)(kbeg - 1) * sk) : 0.;
+    ring[kbeg % 3][q][ty][tx + 1] = ldok ? ld(q, c0 + (OFF)kbeg * sk) : 0.;
     if (edge) {
-      ring[(kbeg - 1) % 3][q][ty][hx] = hok ? ldb(A.u[q], ch + (OFF)(kbeg - 1) * sk) : 0.;
-      ring[kbeg % 3][q][ty][hx] = hok ? ldb(A.u[q], ch + (OFF)kbeg * sk) : 0.;
+      ring[(kbeg - 1) % 3][q][ty][hx] = hok ? ld(q, ch + (OFF)(kbeg - 1) * sk) : 0.;
+      ring[kbeg % 3][q][ty][hx] = hok ? ld(q, ch + (OFF)kbeg * sk) : 0.;
     }
-    fn[q] = ldok ? ldb(A.u[q], c0 + (OFF)(kbeg + 1) * sk) : 0.;
-    fh[q] = hok ? ldb(A.u[q], ch + (OFF)(kbeg + 1) * sk) : 0.;
+    fn[q] = ldok ? ld(q, c0 + (OFF)(kbeg + 1) * sk) : 0.;
+    fh[q] = hok ? ld(q, ch + (OFF)(kbeg + 1) * sk) : 0.;
     if (A.wmlo && kbeg == 1 && q < 2) {
       ring[0][q][ty][tx + 1] = (1. + A.flo) * ring[1][q][ty][tx + 1] - A.flo * fn[q];
       if (edge) ring[0][q][ty][hx] = (1. + A.flo) * ring[1][q][ty][hx] - A.flo * fh[q];
@@ -694,7 +723,7 @@ __global__ __launch_bounds__(64 * (TYS + 2)) void k_strain_tile(Geom g, StrainTi
     }
     if (k + 2 <= g.n3 + 1) {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) { fn[q] = ldok ? ldb(A.u[q], idx + 2 * sk) : 0.; fh[q] = hok ? ldb(A.u[q], ch + (OFF)(k + 2) * sk) : 0.; }
+      for (int q = 0; q < 3; ++q) { fn[q] = ldok ? ld(q, idx + 2 * sk) : 0.; fh[q] = hok ? ld(q, ch + (OFF)(k + 2) * sk) : 0.; }
     }
     __syncthreads();
     const bool lo = A.zlo && k == 1, hi = A.zhi && k == g.n3;
@@ -739,10 +768,16 @@ __global__ __launch_bounds__(64 * (TYS + 2)) void k_strain_tile(Geom g, StrainTi
       const double s0v = sqrt(2. * (s11 * s11 + s22 * s22 + s33 * s33 + 2. * (s12 * s12 + s13 * s13 + s23 * s23)));
       if (SMAG) {
         double fd = 1.;
-        if (A.zlo || A.zhi) {     // nearest wall: the lower one wins a tie (minloc, sgs.f90:116)
-          const double dlo = A.zlo ? A.zc[k] : CALES_BIG, dhi = A.zhi ? A.l3 - A.zc[k] : CALES_BIG;
-          const bool up = dhi < dlo;
-          const double dw_plus = (up ? dhi : dlo) * (up ? tw_hi : tw_lo) * (1. / A.visc);
+        if (A.zlo || A.zhi || A.wylo || A.wyhi) {     // nearest wall in the order y-, y+, z-, z+: the first one wins a tie (minloc, sgs.f90:116)
+          const int jg = j + g.jlo;                  // distances to the y walls use global rows
+          double dmin = A.wylo ? A.dl2 * (jg - 0.5) : CALES_BIG, tw = 0.; int loc = 2;
+          { const double d = A.wyhi ? A.dl2 * (g.ng2 - jg + 0.5) : CALES_BIG; if (d < dmin) { dmin = d; loc = 3; } }
+          { const double d = A.zlo ? A.zc[k] : CALES_BIG; if (d < dmin) { dmin = d; loc = 4; } }
+          { const double d = A.zhi ? A.l3 - A.zc[k] : CALES_BIG; if (d < dmin) { dmin = d; loc = 5; } }
+          if (loc == 2) tw = A.twy[(size_t)k * g.s1 + i];
+          else if (loc == 3) tw = A.twy[(size_t)(g.n3 + 2 + k) * g.s1 + i];
+          else tw = loc == 4 ? tw_lo : tw_hi;
+          const double dw_plus = dmin * tw * (1. / A.visc);
           fd = 1. - exp(-dw_plus / 25.);
         }
         const double t = 0.11 * A.del[k] * fd;      // c_smag, src/param.f90:33
@@ -890,8 +925,8 @@ static inline dim3 lin_grid(size_t n) { size_t b = (n + 255) / 256; if (b > 4096
 // Static Smagorinsky for cases whose only walls are in z (channels, with or without wall model): strain rate and van Driest
 // damping in one pass of the tile kernel, u,v,w -> visct (4 words/cell instead of the 20 of copy + extrapolate + strain + smag)
 static bool smag_fast_ok(const cales_ctx *c) {
-  for (int q = 0; q < 4; ++q) if (c->is_wall[q] != 0. || c->C.lwm[q] != 0) return false;
-  return c->n[2] >= 3 && !c->fl.smag_reference_sequence;
+  for (int q = 0; q < 2; ++q) if (c->is_wall[q] != 0. || c->C.lwm[q] != 0) return false;      // walls or wall model in x: general path
+  return c->n[2] >= 3 && c->n[1] >= 2 && !c->fl.smag_reference_sequence;
 }
 __global__ void k_smag_del(int n, double dl1, double dl2, const double *__restrict__ dzf, double *__restrict__ del) {
   const int k = blockIdx.x * 64 + threadIdx.x;
@@ -915,6 +950,18 @@ static int smag_fast(cales_ctx *c) {
   S.wmlo = ISB(c, 0, 3) && LWM(c, 0, 3) != 0; S.wmhi = ISB(c, 1, 3) && LWM(c, 1, 3) != 0;
   S.flo = (1. / c->dzci[0]) * c->dzci[1]; S.fhi = (1. / c->dzci[n[2]]) * c->dzci[n[2] - 1];
   S.zc = c->d_zc; S.del = c->d_del; S.l3 = c->C.l[2]; S.visc = c->visc;
+  // walls in y (ducts): is_wall(2:3) is a property of the case; the rank that owns a wall supplies its shear (at most two ranks
+  // between two opposite walls, sanity.f90:98-111, so every cell's nearest y wall is its own rank's)
+  S.wylo = c->is_wall[2] != 0.; S.wyhi = c->is_wall[3] != 0.; S.dl2 = c->dl[1];
+  S.wmylo = ISB(c, 0, 2) && LWM(c, 0, 2) != 0; S.wmyhi = ISB(c, 1, 2) && LWM(c, 1, 2) != 0;
+  S.twy = nullptr;
+  if (S.wylo || S.wyhi) {
+    double *twy = c->wk[0];      // scratch field: 2 x (n3+2) rows of s1 values
+    if ((size_t)2 * (n[2] + 2) * c->g.s1 > c->ntot) { c->err = "smag: wall-shear scratch too small"; return 1; }
+    hipLaunchKernelGGL(k_wall_shear_y, dim3((n[0] + 63) / 64, (n[2] + 3) / 4), dim3(64, 4), 0, c->stream, c->g, f[CALES_U], f[CALES_W], c->visc, c->dli[1],
+                       S.wylo && ISB(c, 0, 2) ? 1 : 0, S.wyhi && ISB(c, 1, 2) ? 1 : 0, twy);
+    S.twy = twy;
+  }
   const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32) && !c->fl.wide_offsets;
   if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 1>), mg, mb, 0, c->stream, c->g, S);
   else hipLaunchKernelGGL((k_strain_tile<size_t, 1>), mg, mb, 0, c->stream, c->g, S);

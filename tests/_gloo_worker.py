@@ -76,6 +76,12 @@ def main():
         Ac[m // cw, :, :, m % cw] = X[m].T                                    # [k][jl]
     comm.alltoall(0, 2 * n3 * n2l * cw)
     Bc = B[:2 * P * n3 * n2l * cw].numpy().view(np.complex128).reshape(P, n3, n2l, cw)
+    # the same exchange in k-chunks (cales_alltoall_part_cb: a slice of every peer block, what the pipelined solve sends): same bytes
+    whole = B[:2 * P * n3 * n2l * cw].clone(); B[:2 * P * n3 * n2l * cw] = 0.
+    nch = 2 if n3 % 2 == 0 else 1
+    for ch in range(nch):
+        comm.alltoall_part(0, 2 * n3 * n2l * cw, ch * 2 * (n3 // nch) * n2l * cw, 2 * (n3 // nch) * n2l * cw, None)
+    assert torch.equal(whole, B[:2 * P * n3 * n2l * cw]), "chunked all-to-all differs from the single exchange"
     T = np.transpose(Bc, (3, 0, 2, 1)).reshape(cw, n2g, n3)                   # (mm, j global, k)
     Xg = np.fft.rfft(rhs[1:-1, 1:-1, 1:-1], axis=0)
     for mm in range(cw):
