@@ -62,6 +62,62 @@ static inline void add_job(BcJobs &J, double *p, char ctype, int ibound, int cen
   j.p = p; j.bc = bc; j.dr = dr; j.ctype = ctype; j.centered = (char)centered; j.ibound = (char)ibound;
 }
 
+// ---- all three directions in ONE launch, for the common BC sets: x periodic, y periodic (or exchanged between slabs), any
+// pointwise z condition. The reference applies x, then y, then z, and later directions also fill the corner ghosts of earlier ones
+// (bound.f90:158-199). With periodic x and y that sequence is a composition with a closed form -- every ghost cell is the z
+// operation applied to the periodically wrapped interior cell -- so each thread computes its ghost cell from interior cells only
+// and no ordering between the directions is left. Saves two of the three launches of every bounduvw / boundp (19 -> 7 per substep
+// for a channel), which is what small grids are bound by.
+struct MField { double *p; const double *bc0, *bc1; double dr0, dr1; char t0, t1, centered; };      // z sides: 'P','D','N' or 0 (leave z alone)
+struct MJobs { int nf, do_x, wrap_y, do_z; MField f[8]; };
+__global__ __launch_bounds__(256) void k_bc_merged(Geom g, MJobs J) {
+  const int region = blockIdx.z % 3; const MField F = J.f[blockIdx.z / 3];
+  const int n1 = g.n1, n2 = g.n2, n3 = g.n3;
+  const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y;
+  auto wx = [&](int i) { return !J.do_x ? i : i == 0 ? n1 : i == n1 + 1 ? 1 : i; };
+  auto wy = [&](int j) { return !J.wrap_y ? j : j == 0 ? n2 : j == n2 + 1 ? 1 : j; };
+  const bool top_face = J.do_z && F.t1 == 'D' && !F.centered;      // plane n3 itself is boundary data (face-centred normal component)
+  double *p = F.p;
+  if (region == 0) {               // z ghost planes of the column (a, b), ghost columns included
+    if (!J.do_z || a > n1 + 1 || b > n2 + 1) return;
+    const int ia = wx(a), jb = wy(b);
+    const size_t q2 = (size_t)a + (size_t)(n1 + 2) * b;
+    if (F.t0 == 'P') { p[g.ix(a, b, 0)] = p[g.ix(ia, jb, n3)]; p[g.ix(a, b, n3 + 1)] = p[g.ix(ia, jb, 1)]; return; }
+    if (F.t0 == 'D') p[g.ix(a, b, 0)] = F.centered ? 2. * F.bc0[q2] - p[g.ix(ia, jb, 1)] : F.bc0[q2];
+    else if (F.t0 == 'N') p[g.ix(a, b, 0)] = -F.dr0 * F.bc0[q2] + p[g.ix(ia, jb, 1)];
+    if (F.t1 == 'D') {
+      if (F.centered) p[g.ix(a, b, n3 + 1)] = 2. * F.bc1[q2] - p[g.ix(ia, jb, n3)];
+      else { p[g.ix(a, b, n3 + 1)] = p[g.ix(ia, jb, n3 - 1)]; p[g.ix(a, b, n3)] = F.bc1[q2]; }
+    } else if (F.t1 == 'N') p[g.ix(a, b, n3 + 1)] = F.dr1 * F.bc1[q2] + p[g.ix(ia, jb, n3)];
+  } else if (region == 1) {        // x ghost columns of the rows (b, k), k = 1..n3 (ghost rows included)
+    const int k = a + 1;
+    const int bb = b;              // here the block's x index runs over k and its y index over b: see the launch
+    if (!J.do_x || k > n3 || bb > n2 + 1 || (top_face && k == n3)) return;
+    const int jb = wy(bb);
+    p[g.ix(0, bb, k)] = p[g.ix(n1, jb, k)]; p[g.ix(n1 + 1, bb, k)] = p[g.ix(1, jb, k)];
+  } else {                         // y ghost rows, i = 1..n1, k = 1..n3
+    const int i = a + 1, k = b + 1;
+    if (!J.wrap_y || i > n1 || k > n3 || (top_face && k == n3)) return;
+    p[g.ix(i, 0, k)] = p[g.ix(i, n2, k)]; p[g.ix(i, n2 + 1, k)] = p[g.ix(i, 1, k)];
+  }
+}
+static int launch_merged(cales_ctx *c, MJobs &J) {
+  if (!J.nf) return 0;
+  const int *n = c->n;
+  // one grid for the three regions: region 0 needs (n1+2) x (n2+2), region 1 n3 x (n2+2), region 2 n1 x n3 threads
+  const int ex = std::max(n[0] + 2, n[2]), ey = std::max(n[1] + 2, n[2]);
+  hipLaunchKernelGGL(k_bc_merged, dim3((ex + 63) / 64, (ey + 3) / 4, 3 * J.nf), dim3(64, 4, 1), 0, c->stream, c->g, J);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+// x periodic, y periodic on one rank or exchanged between slabs, z pointwise
+static bool merged_ok(const cales_ctx *c, const char *cbx, const char *cby) {
+  if (c->fl.unmerged_bc) return false;
+  if (!(cbx[0] == 'P' && cbx[1] == 'P')) return false;
+  if (!(cby[0] == 'P' && cby[1] == 'P')) return false;
+  return true;
+}
+
 // y-slab neighbours (bound.f90:619-696 for idir = 2): pack the first/last interior rows of nf fields into the
 // staging buffer A, let the host exchange them, unpack into the ghost rows. Planes include the x/z ghosts.
 struct HaloFields { int nf; double *p[8]; };
@@ -132,6 +188,17 @@ static int halo_self(cales_ctx *c, int nf, double **flds) {
 int op_boundp_multi(cales_ctx *c, int nf, double **p, int which) {
   ProfScope ps(c, "boundp");
   const char *cbc = which == 0 ? c->C.cbcpre : c->C.cbcsgs; const DBound &bc = which == 0 ? c->bcp : c->bcs;
+  if (merged_ok(c, cbc, cbc + 2) && nf <= 8) {      // x, y periodic: all three directions in one launch (k_bc_merged)
+    if (c->P > 1) { if (int e = halo_y_comm(c, nf, p)) return e; }
+    const bool per_z = cbc[4] == 'P' && cbc[5] == 'P';
+    MJobs J; J.nf = nf; J.do_x = !(c->bc_skip & 1); J.wrap_y = c->P == 1; J.do_z = per_z || !(c->bc_skip & 4);
+    for (int q = 0; q < nf; ++q) {
+      MField &F = J.f[q]; F.p = p[q]; F.centered = 1;
+      F.t0 = per_z ? 'P' : cbc[4]; F.t1 = per_z ? 'P' : cbc[5];
+      F.bc0 = plane(bc, 3, 0, c->n); F.bc1 = plane(bc, 3, 1, c->n); F.dr0 = c->dzc[0]; F.dr1 = c->dzc[c->n[2]];
+    }
+    return launch_merged(c, J);
+  }
   if (int e = halo_self(c, nf, p)) return e;
   for (int idir = 1; idir <= 3; ++idir) {
     if (!ISB(c, 0, idir) && !ISB(c, 1, idir)) continue;
@@ -294,8 +361,30 @@ int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm
   ProfScope ps(c, "bounduvw");
   const int *n = c->n;
   double *fl[3] = {u, v, w};
-  if (int e = halo_self(c, 3, fl)) return e;
   DBound *bnd[3] = {&bu, &bv, &bw};
+  bool merged = merged_ok(c, c->C.cbcpre, c->C.cbcpre + 2);       // velocity and pressure are periodic together (sanity.f90:163-175)
+  for (int ivel = 1; ivel <= 3 && merged; ++ivel) {
+    for (int d = 1; d <= 2; ++d) merged = merged && CBV(c, 0, d, ivel) == 'P' && CBV(c, 1, d, ivel) == 'P';
+    if (ivel == 3 && (CBV(c, 0, 3, 3) == 'N' || CBV(c, 1, 3, 3) == 'N')) merged = false;      // face-centred Neumann reads the plane it rewrites
+  }
+  if (merged) {
+    if (c->P > 1) { if (int e = halo_y_comm(c, 3, fl)) return e; }
+    const bool per_z = CBV(c, 0, 3, 3) == 'P' && CBV(c, 1, 3, 3) == 'P';
+    MJobs J; J.nf = 3; J.do_x = !(c->bc_skip & 1); J.wrap_y = c->P == 1; J.do_z = per_z || !(c->bc_skip & 4);
+    for (int ivel = 1; ivel <= 3; ++ivel) {
+      MField &F = J.f[ivel - 1]; F.p = fl[ivel - 1];
+      const bool normal = ivel == 3;
+      F.centered = normal ? 0 : 1;
+      F.bc0 = plane(*bnd[ivel - 1], 3, 0, n); F.bc1 = plane(*bnd[ivel - 1], 3, 1, n);
+      F.dr0 = normal ? c->dzf[0] : c->dzc[0]; F.dr1 = normal ? c->dzf[n[2]] : c->dzc[n[2]];
+      if (per_z) { F.t0 = F.t1 = 'P'; continue; }
+      F.t0 = CBV(c, 0, 3, ivel); F.t1 = CBV(c, 1, 3, ivel);
+      if (normal && is_correc) F.t0 = F.t1 = 0;                                 // the corrected normal velocity keeps its wall value (bound.f90:60-75)
+      if (!normal) { if (LWM(c, 0, 3) != 0) F.t0 = 0; if (LWM(c, 1, 3) != 0) F.t1 = 0; }      // set below from the wall-model stress
+    }
+    if (int e = launch_merged(c, J)) return e;
+  } else {
+  if (int e = halo_self(c, 3, fl)) return e;
   for (int idir = 1; idir <= 3; ++idir) {
     if (!ISB(c, 0, idir) && !ISB(c, 1, idir)) continue;
     if (c->bc_skip >> (idir - 1) & 1) continue;
@@ -322,6 +411,7 @@ int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm
       }
     }
     if (int e = launch_jobs(c, J)) return e;
+  }
   }
   if (is_updt_wm) if (int e = updt_wallmodelbc(c, bu, bv, bw, u, v, w)) return e;
   for (int idir = 1; idir <= 3; ++idir) {   // tangential Neumann BCs carrying the wall-model stress (bound.f90:125-148)

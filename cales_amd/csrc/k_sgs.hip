@@ -832,6 +832,8 @@ static int dsmag_fast(cales_ctx *c) {
     mb = dim3(64, ty + 2, 1); mg = dim3((n[0] + wx - 1) / wx, (n[1] + ty - 1) / ty, 1);
     kchunk = n[2];
     while ((long)mg.x * mg.y * ((n[2] + kchunk - 1) / kchunk) < tile_min_blocks(c) && kchunk > 32) kchunk = (kchunk + 1) / 2;
+    // small grids: fewer blocks than two per CU leave most of the chip idle; shorter chunks (their three-plane prologue weighs more) beat that
+    while ((long)mg.x * mg.y * ((n[2] + kchunk - 1) / kchunk) < 512 && kchunk > 8) kchunk = (kchunk + 1) / 2;
     if (int fk = tile_kchunk(c, (long)mg.x * mg.y, n[2])) kchunk = fk;
     mg.z = (n[2] + kchunk - 1) / kchunk;
   };
@@ -941,6 +943,8 @@ static int smag_fast(cales_ctx *c) {
   dim3 mb(64, TYS + 2, 1), mg((n[0] + 63) / 64, (n[1] + TYS - 1) / TYS, 1);
   int kch = n[2];
   while ((long)mg.x * mg.y * ((n[2] + kch - 1) / kch) < tile_min_blocks(c) && kch > 32) kch = (kch + 1) / 2;
+  // small grids: fewer blocks than two per CU leave most of the chip idle; shorter chunks (their three-plane prologue weighs more) beat that
+  while ((long)mg.x * mg.y * ((n[2] + kch - 1) / kch) < 512 && kch > 8) kch = (kch + 1) / 2;
   if (int fk = tile_kchunk(c, (long)mg.x * mg.y, n[2])) kch = fk;
   mg.z = (n[2] + kch - 1) / kch;
   StrainTileArgs S = {};

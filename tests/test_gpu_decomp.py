@@ -73,6 +73,14 @@ def test_slab_ranks_match_single_rank(name, ng, P):
     assert relerr(pg[1:-1, :, 1:-1] - pg[1:-1, :, 1:-1].mean(), pref[1:-1, :, 1:-1] - pref[1:-1, :, 1:-1].mean()) < 1e-9
 
 
+@pytest.mark.parametrize("name,ng,P", [("chan_dsmag", (128, 32, 136), 2), ("chan_dsmag_wm", (72, 32, 40), 4), ("cavity_nnn", (16, 24, 12), 4), ("halfchan_imp1d", (16, 16, 12), 2)])
+def test_slab_ranks_in_order_exchanges(name, ng, P, monkeypatch):
+    """CALES_NO_OVERLAP: every exchange in order on the one stream (no k-chunks, no deferred halos) -- the path a host without
+    cales_set_comm_overlap gets; the default runs of test_slab_ranks_match_single_rank use the second stream."""
+    monkeypatch.setenv("CALES_NO_OVERLAP", "1")
+    test_slab_ranks_match_single_rank(name, ng, P)
+
+
 def test_slab_initflow_equals_global():
     """cales_initflow_slab (host only) == rows of the global initial field, bit for bit."""
     import ctypes as C

@@ -144,7 +144,8 @@ def test_wide_offset_kernels(name, monkeypatch):
     test_fused_step_matches_operator_sequence(name)
 
 
-@pytest.mark.parametrize("env", ["CALES_DSMAG_REFERENCE_SEQUENCE", "CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_GAUSSEL_MARCH", "CALES_DSMAG_EAGER", "CALES_KEEP_LAST_RHS"])
+@pytest.mark.parametrize("env", ["CALES_DSMAG_REFERENCE_SEQUENCE", "CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_GAUSSEL_MARCH", "CALES_DSMAG_EAGER", "CALES_KEEP_LAST_RHS",
+                                 "CALES_DSMAG_UNFUSED_FILTER", "CALES_UNMERGED_BC"])
 @pytest.mark.parametrize("name", ["chan_dsmag", "chan_dsmag_wm", "tgv_dsmag_ppp", "duct_smag_wm_imp1d"])
 def test_unfused_paths(name, env, monkeypatch):
     """The kernel-per-loop forms behind the operator-level entries (general dsmag sequence, mom + rk_update, correc +
@@ -154,7 +155,16 @@ def test_unfused_paths(name, env, monkeypatch):
     test_fused_step_matches_operator_sequence(name)
 
 
-@pytest.mark.parametrize("name", ["chan_smag", "chan_smag_wm"])
+@pytest.mark.parametrize("name", DEVICE_CASES)
+def test_unmerged_bc_operator_level(name, monkeypatch):
+    """The one-launch ghost-cell kernel (x, y periodic: every ghost cell = the z operation on the wrapped interior cell) is the default
+    where it applies; the direction-by-direction sequence of bound.f90:158-199 behind CALES_UNMERGED_BC must give the same ghost cells,
+    corners included: both are held to the reference's planes stage by stage."""
+    monkeypatch.setenv("CALES_UNMERGED_BC", "1")
+    test_startup_and_substeps(name)
+
+
+@pytest.mark.parametrize("name", ["chan_smag", "chan_smag_wm", "duct_smag_wm"])
 def test_smag_reference_sequence(name, monkeypatch):
     """Static Smagorinsky through the kernel-per-loop sequence (the path ducts and cavities take)."""
     monkeypatch.setenv("CALES_SMAG_REFERENCE_SEQUENCE", "1")
