@@ -273,8 +273,14 @@ int cales_boundp(cales_ctx *c, int field, int which) {
   if (field < 0 || field >= CALES_NFIELDS || !c->f[field]) { c->err = "bad field id"; return 1; }
   return op_boundp(c, c->f[field], which);
 }
+int cales_get_forcing(cales_ctx *c, double f[3]);
 int cales_mom(cales_ctx *c) { return op_mom(c); }
 int cales_rk(cales_ctx *c, int irk, double dt) { if (irk < 1 || irk > 3) { c->err = "irk must be 1..3"; return 1; } return op_rk(c, irk, dt); }
+int cales_rk_par(cales_ctx *c, const double rkpar[2], double dt, double f_out[3]) {
+  if (!rkpar) { c->err = "cales_rk_par: rkpar is NULL"; return 1; }
+  if (int e = op_rk_par(c, rkpar[0], rkpar[1], dt)) return e;
+  return f_out ? cales_get_forcing(c, f_out) : 0;
+}
 int cales_bulk_forcing(cales_ctx *c) { return op_bulk_forcing(c); }
 int cales_get_forcing(cales_ctx *c, double f[3]) {
   HIPCHK(c, hipMemcpyAsync(c->h_red + 32, c->d_force, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));

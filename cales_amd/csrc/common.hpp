@@ -206,6 +206,7 @@ int op_boundp(cales_ctx *c, double *p, int which);
 int halo_flush_deferred(cales_ctx *c);
 int op_mom(cales_ctx *c);
 int op_rk(cales_ctx *c, int irk, double dt);
+int op_rk_par(cales_ctx *c, double rkpar1, double rkpar2, double dt);
 int op_momrk(cales_ctx *c, double f1, double f2, double f12);
 int op_bulk_forcing(cales_ctx *c);
 int op_bulk_mean_dev(cales_ctx *c, const double *p, int c_or_f, double *d_out);   // result to device scalar

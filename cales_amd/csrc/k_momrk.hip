@@ -189,8 +189,8 @@ int op_momrk(cales_ctx *c, double f1, double f2, double f12) {
   dim3 b(64, TYM + 2, 1), gr((n[0] + 63) / 64, (n[1] + TYM - 1) / TYM, 1);
   int kchunk = n[2];
   while ((long)gr.x * gr.y * ((n[2] + kchunk - 1) / kchunk) < tile_min_blocks(c) && kchunk > 32) kchunk = (kchunk + 1) / 2;
-  // small grids: fewer blocks than two per CU leave most of the chip idle; shorter chunks (their three-plane prologue weighs more) beat that
-  while ((long)gr.x * gr.y * ((n[2] + kchunk - 1) / kchunk) < 512 && kchunk > 8) kchunk = (kchunk + 1) / 2;
+  // small grids: fewer blocks than one per CU leave most of the chip idle; shorter chunks (their three-plane prologue weighs more) beat that
+  while ((long)gr.x * gr.y * ((n[2] + kchunk - 1) / kchunk) < 256 && kchunk > 8) kchunk = (kchunk + 1) / 2;
   if (int fk = tile_kchunk(c, (long)gr.x * gr.y, n[2])) kchunk = fk;
   gr.z = (n[2] + kchunk - 1) / kchunk; A.kchunk = kchunk;
   const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32) && !c->fl.wide_offsets;      // 32-bit byte offsets

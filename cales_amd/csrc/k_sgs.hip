@@ -485,7 +485,7 @@ __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijA
 // the same iteration) and combines them in registers; x by DPP, z from two rolling x/y-combined planes. Tiles of 62 x TYL outputs
 // with TYL = 6: 8 waves per block, two per SIMD, which leaves 256 VGPRs for the 18 more loads in flight.
 #ifndef TYL
-#define TYL 6
+#define TYL 8
 #endif
 struct LmfArgs { LijMijArgs L; const double *ss[6]; int by0; };      // by0: first y tile of this launch (interior and edge tiles of a slab are launched apart)
 template <typename OFF>
@@ -547,11 +547,9 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
 #pragma unroll
     for (int q = 0; q < 3; ++q)
       ring[kp][q][ty][tx] = (HI && A.wmhi && q < 2) ? (1. + A.fhi) * ring[kc][q][ty][tx] - A.fhi * ring[km][q][ty][tx] : fn[q];
-    sscomb(rw, xp);                                    // plane k+1 of |S|Sij (its loads were issued one plane ago)
     if (k + 2 <= g.n3 + 1) {
 #pragma unroll
       for (int q = 0; q < 3; ++q) { sn[q] = ldok ? ldb(A.uc[q], idx + 2 * sk) : 0.; fn[q] = ldok ? ldb(A.uf[q], idx + 2 * sk) : 0.; }
-      ssload(k + 2, rw);
     }
     double qm[9], qc[9], qp[9], r[9];
     uiuj(sc, qc);
@@ -564,6 +562,9 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
     }
     __syncthreads();
     if (k > kbeg && tx == 0 && ty == 0) fold(k - 1, buf ^ 1);
+    // plane k+1 of |S|Sij: its 18 loads were issued at the end of the previous plane and are folded into six values here, before
+    // the register-hungry part; the next 18 are issued after it (keeps the kernel under the 168 VGPRs that ten waves per block need)
+    sscomb(rw, xp);
     double lm = 0., mm = 0.;
     if (outok) {
       double F[9];
@@ -571,27 +572,32 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
       for (int q = 0; q < 9; ++q) F[q] = (sh[buf][q][ty - 1][tx] + 2. * r[q] + sh[buf][q][ty + 1][tx]) / 64.;
       const double l0 = F[3] - F[0] * F[0], l1 = F[4] - F[1] * F[1], l2 = F[5] - F[2] * F[2], l3 = F[6] - F[0] * F[1],
                    l4 = F[7] - F[0] * F[2], l5 = F[8] - F[1] * F[2];
+      // strain rate of the test-filtered velocity (sgs.f90:571-630). The eight differences of each off-diagonal component telescope
+      // pairwise wherever the metric factor is the same (x and y: always; z: not, the grid is stretched), e.g.
+      // (u_cpc-u_ccc)+(u_ccc-u_cmc)+(u_mpc-u_mcc)+(u_mcc-u_mmc) = u_cpc-u_cmc+u_mpc-u_mmc: fewer operations and fewer values in flight
+      // (this pass is bound by its vector instructions and registers). Same sum in another association: round-off level differences.
 #define RU(dk, dj, di) ring[dk][0][ty + (dj)][tx + (di)]
 #define RV(dk, dj, di) ring[dk][1][ty + (dj)][tx + (di)]
 #define RW(dk, dj, di) ring[dk][2][ty + (dj)][tx + (di)]
-      const double u_mcm = RU(km, 0, -1), u_ccm = RU(km, 0, 0), u_mmc = RU(kc, -1, -1), u_cmc = RU(kc, -1, 0), u_mcc = RU(kc, 0, -1),
-                   u_ccc = RU(kc, 0, 0), u_mpc = RU(kc, 1, -1), u_cpc = RU(kc, 1, 0), u_mcp = RU(kp, 0, -1), u_ccp = RU(kp, 0, 0);
-      const double v_cmm = RV(km, -1, 0), v_ccm = RV(km, 0, 0), v_mmc = RV(kc, -1, -1), v_cmc = RV(kc, -1, 0), v_pmc = RV(kc, -1, 1),
-                   v_mcc = RV(kc, 0, -1), v_ccc = RV(kc, 0, 0), v_pcc = RV(kc, 0, 1), v_cmp = RV(kp, -1, 0), v_ccp = RV(kp, 0, 0);
-      const double w_cmm = RW(km, -1, 0), w_mcm = RW(km, 0, -1), w_ccm = RW(km, 0, 0), w_pcm = RW(km, 0, 1), w_cpm = RW(km, 1, 0),
-                   w_cmc = RW(kc, -1, 0), w_mcc = RW(kc, 0, -1), w_ccc = RW(kc, 0, 0), w_pcc = RW(kc, 0, 1), w_cpc = RW(kc, 1, 0);
+      const double dxi = A.dxi, dyi = A.dyi, zc = A.dzci[k], zm = A.dzci[k - 1];
+      double sij[6];
+      { const double u_ccc = RU(kc, 0, 0), u_mcc = RU(kc, 0, -1), v_ccc = RV(kc, 0, 0), v_cmc = RV(kc, -1, 0), w_ccc = RW(kc, 0, 0), w_ccm = RW(km, 0, 0);
+        sij[0] = (u_ccc - u_mcc) * dxi; sij[1] = (v_ccc - v_cmc) * dyi; sij[2] = (w_ccc - w_ccm) * A.dzfi[k];
+        // s12 = 1/8 [ dyi (u_cpc - u_cmc + u_mpc - u_mmc) + dxi (v_pcc + v_pmc - v_mcc - v_mmc) ]
+        const double du = (RU(kc, 1, 0) - RU(kc, -1, 0)) + (RU(kc, 1, -1) - RU(kc, -1, -1));
+        const double dv = (RV(kc, 0, 1) - RV(kc, 0, -1)) + (RV(kc, -1, 1) - RV(kc, -1, -1));
+        sij[3] = .125 * (du * dyi + dv * dxi);
+        // s13 = 1/8 [ zc (u_ccp - u_ccc + u_mcp - u_mcc) + zm (u_ccc - u_ccm + u_mcc - u_mcm) + dxi (w_pcc + w_pcm - w_mcc - w_mcm) ]
+        const double up = (RU(kp, 0, 0) - u_ccc) + (RU(kp, 0, -1) - u_mcc), um = (u_ccc - RU(km, 0, 0)) + (u_mcc - RU(km, 0, -1));
+        const double dw = (RW(kc, 0, 1) - RW(kc, 0, -1)) + (RW(km, 0, 1) - RW(km, 0, -1));
+        sij[4] = .125 * (up * zc + um * zm + dw * dxi);
+        // s23 = 1/8 [ zc (v_ccp - v_ccc + v_cmp - v_cmc) + zm (v_ccc - v_ccm + v_cmc - v_cmm) + dyi (w_cpc + w_cpm - w_cmc - w_cmm) ]
+        const double vp = (RV(kp, 0, 0) - v_ccc) + (RV(kp, -1, 0) - v_cmc), vm = (v_ccc - RV(km, 0, 0)) + (v_cmc - RV(km, -1, 0));
+        const double dw2 = (RW(kc, 1, 0) - RW(kc, -1, 0)) + (RW(km, 1, 0) - RW(km, -1, 0));
+        sij[5] = .125 * (vp * zc + vm * zm + dw2 * dyi); }
 #undef RU
 #undef RV
 #undef RW
-      const double dxi = A.dxi, dyi = A.dyi, zc = A.dzci[k], zm = A.dzci[k - 1];
-      double sij[6];
-      sij[0] = (u_ccc - u_mcc) * dxi; sij[1] = (v_ccc - v_cmc) * dyi; sij[2] = (w_ccc - w_ccm) * A.dzfi[k];
-      sij[3] = .125 * ((u_cpc - u_ccc) * dyi + (v_pcc - v_ccc) * dxi + (u_ccc - u_cmc) * dyi + (v_pmc - v_cmc) * dxi +
-                       (u_mpc - u_mcc) * dyi + (v_ccc - v_mcc) * dxi + (u_mcc - u_mmc) * dyi + (v_cmc - v_mmc) * dxi);
-      sij[4] = .125 * ((u_ccp - u_ccc) * zc + (w_pcc - w_ccc) * dxi + (u_ccc - u_ccm) * zm + (w_pcm - w_ccm) * dxi +
-                       (u_mcp - u_mcc) * zc + (w_ccc - w_mcc) * dxi + (u_mcc - u_mcm) * zm + (w_ccm - w_mcm) * dxi);
-      sij[5] = .125 * ((v_ccp - v_ccc) * zc + (w_cpc - w_ccc) * dyi + (v_ccc - v_ccm) * zm + (w_cpm - w_ccm) * dyi +
-                       (v_cmp - v_cmc) * zc + (w_ccc - w_cmc) * dyi + (v_cmc - v_cmm) * zm + (w_ccm - w_cmm) * dyi);
       const double s0 = sqrt(2. * (sij[0] * sij[0] + sij[1] * sij[1] + sij[2] * sij[2] + 2. * (sij[3] * sij[3] + sij[4] * sij[4] + sij[5] * sij[5])));
       const double a2s0 = (LO || HI ? 2.52 : 4.00) * s0;      // alph2 (sgs.f90:783-816)
       double m[6];
@@ -603,6 +609,7 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
       lm = m[0] * l0 + m[1] * l1 + m[2] * l2 + (m[3] * l3 + m[4] * l4 + m[5] * l5) * 2.;       // sgs.f90:344-349
       mm = m[0] * m[0] + m[1] * m[1] + m[2] * m[2] + (m[3] * m[3] + m[4] * m[4] + m[5] * m[5]) * 2.;       // sgs.f90:350-355
     }
+    if (k + 2 <= g.n3 + 1) ssload(k + 2, rw);
     lm = wave_sum_lane63(lm); mm = wave_sum_lane63(mm);
     if (tx == 63) { shr[buf][0][ty] = lm; shr[buf][1][ty] = mm; }
 #pragma unroll
@@ -832,8 +839,8 @@ static int dsmag_fast(cales_ctx *c) {
     mb = dim3(64, ty + 2, 1); mg = dim3((n[0] + wx - 1) / wx, (n[1] + ty - 1) / ty, 1);
     kchunk = n[2];
     while ((long)mg.x * mg.y * ((n[2] + kchunk - 1) / kchunk) < tile_min_blocks(c) && kchunk > 32) kchunk = (kchunk + 1) / 2;
-    // small grids: fewer blocks than two per CU leave most of the chip idle; shorter chunks (their three-plane prologue weighs more) beat that
-    while ((long)mg.x * mg.y * ((n[2] + kchunk - 1) / kchunk) < 512 && kchunk > 8) kchunk = (kchunk + 1) / 2;
+    // small grids: fewer blocks than one per CU leave most of the chip idle; shorter chunks (their three-plane prologue weighs more) beat that
+    while ((long)mg.x * mg.y * ((n[2] + kchunk - 1) / kchunk) < 256 && kchunk > 8) kchunk = (kchunk + 1) / 2;
     if (int fk = tile_kchunk(c, (long)mg.x * mg.y, n[2])) kchunk = fk;
     mg.z = (n[2] + kchunk - 1) / kchunk;
   };
@@ -943,8 +950,8 @@ static int smag_fast(cales_ctx *c) {
   dim3 mb(64, TYS + 2, 1), mg((n[0] + 63) / 64, (n[1] + TYS - 1) / TYS, 1);
   int kch = n[2];
   while ((long)mg.x * mg.y * ((n[2] + kch - 1) / kch) < tile_min_blocks(c) && kch > 32) kch = (kch + 1) / 2;
-  // small grids: fewer blocks than two per CU leave most of the chip idle; shorter chunks (their three-plane prologue weighs more) beat that
-  while ((long)mg.x * mg.y * ((n[2] + kch - 1) / kch) < 512 && kch > 8) kch = (kch + 1) / 2;
+  // small grids: fewer blocks than one per CU leave most of the chip idle; shorter chunks (their three-plane prologue weighs more) beat that
+  while ((long)mg.x * mg.y * ((n[2] + kch - 1) / kch) < 256 && kch > 8) kch = (kch + 1) / 2;
   if (int fk = tile_kchunk(c, (long)mg.x * mg.y, n[2])) kch = fk;
   mg.z = (n[2] + kch - 1) / kch;
   StrainTileArgs S = {};

@@ -261,7 +261,11 @@ __global__ void k_zero_force(double *force) { if (threadIdx.x < 3) force[threadI
 
 int op_rk(cales_ctx *c, int irk, double dt) {
   static const double rk[3][2] = {{32. / 60., 0.}, {25. / 60., -17. / 60.}, {45. / 60., -25. / 60.}};   // param.f90:27-29
-  const double f1 = rk[irk - 1][0] * dt, f2 = rk[irk - 1][1] * dt, f12 = f1 + f2;
+  return op_rk_par(c, rk[irk - 1][0], rk[irk - 1][1], dt);
+}
+// rk(rkpar, ..., dt, ...) of rk.f90:17 with the caller's coefficients
+int op_rk_par(cales_ctx *c, double rkpar1, double rkpar2, double dt) {
+  const double f1 = rkpar1 * dt, f2 = rkpar2 * dt, f12 = f1 + f2;
   double **f = c->f;
   dim3 b(BX, BY, 1), gr = grid3(c->n[0], c->n[1], c->n[2], b);
   const bool unfused = c->fl.unfused_rk;

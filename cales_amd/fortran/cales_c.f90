@@ -87,6 +87,9 @@ module cales_c
     integer(c_int) function cales_rk(ctx,irk,dt) bind(C,name='cales_rk')
       import; type(c_ptr), value :: ctx; integer(c_int), value :: irk; real(c_double), value :: dt
     end function
+    integer(c_int) function cales_rk_par(ctx,rkpar,dt,f) bind(C,name='cales_rk_par')      ! rk(rkpar,...,dt,...,f), src/rk.f90:17
+      import; type(c_ptr), value :: ctx; real(c_double), intent(in) :: rkpar(2); real(c_double), value :: dt; real(c_double) :: f(3)
+    end function
     integer(c_int) function cales_fillps(ctx,dtrki) bind(C,name='cales_fillps')
       import; type(c_ptr), value :: ctx; real(c_double), value :: dtrki
     end function

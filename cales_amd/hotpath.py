@@ -135,6 +135,12 @@ class HotPath:
         self._chk(self.L.cales_get_forcing(self.h, _p(f)))
         return f
 
+    def rk_par(self, rkpar, dt: float) -> np.ndarray:
+        """rk(rkpar, ..., dt, ..., f) with the caller's coefficients (src/rk.f90:17)"""
+        rp = np.ascontiguousarray(rkpar, dtype=np.float64); f = np.zeros(3)
+        self._chk(self.L.cales_rk_par(self.h, _p(rp), float(dt), _p(f)))
+        return f
+
     def bulk_forcing(self):
         self._chk(self.L.cales_bulk_forcing(self.h))
 

@@ -81,6 +81,9 @@ int cales_rk(cales_ctx *ctx, int irk, double dt);                           /* s
                                                                               * cells of u,v,w keep the values of the last bounduvw (as in the reference) when a
                                                                               * wall model is active -- it may sample them -- and are undefined otherwise;
                                                                               * bounduvw follows in every caller (src/main.f90:493) */
+/* the same with the caller's Runge-Kutta coefficients: rk(rkpar, ..., dt, ..., f) of src/rk.f90:17 as the reference declares it
+ * (rkpar = rkcoeff(:,irk), src/param.f90:27-29); f_out may be NULL, otherwise the forcing f(1:3) is returned (sync) */
+int cales_rk_par(cales_ctx *ctx, const double rkpar[2], double dt, double f_out[3]);
 int cales_bulk_forcing(cales_ctx *ctx);                                     /* src/mom.f90:311    */
 int cales_get_forcing(cales_ctx *ctx, double f[3]);                         /* f of the last cales_rk (sync)  */
 int cales_bulk_mean(cales_ctx *ctx, int field, int c_or_f, double *mean);   /* src/utils.f90:16 (sync) */

@@ -209,3 +209,18 @@ def test_imp3d_operators():
     h.updatep(float(g["upd_alpha"]))
     assert relerr(h.get("p")[1:-1, 1:-1, 1:-1], g["upd_p"][1:-1, 1:-1, 1:-1]) < TOL
     h.close()
+
+
+@pytest.mark.parametrize("name", ["chan_smag", "tgv_ppp"])
+def test_rk_with_caller_coefficients(name):
+    """cales_rk_par(rkpar, dt) = the reference's rk(rkpar, ...) signature (rk.f90:17): with rkcoeff(:, irk) of param.f90:27-29 it is
+    the golden substep; the forcing comes back through f_out."""
+    g, case = load_golden(name)
+    h = _hot(case)
+    h.upload(*(F(g["s0_" + k]) for k in "uvwp")); h.set("visct", F(g["s0_visct"]))
+    f = h.rk_par(RK[0], float(g["dt"]))
+    assert np.abs(f - g["r1_s1_f"]).max() < 1e-13
+    h.bulk_forcing()
+    for k in "uvw":
+        assert relerr(h.get(k)[1:-1, 1:-1, 1:-1], g["r1_s1_" + k][1:-1, 1:-1, 1:-1]) < TOL, k
+    h.close()
