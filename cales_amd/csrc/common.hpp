@@ -56,7 +56,7 @@ struct Spec {
 // Run-time switches: read from the environment ONCE, by cales_create; the launch path only looks at these fields.
 struct Flags {
   bool unaligned = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_eager = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, gaussel_pair = false, unfused_rk = false, dsmag_unfused_filter = false, no_overlap = false, unmerged_bc = false;
-  int kchunk = 0; long tile_min_blocks = 2048;
+  int kchunk = 0; long tile_min_blocks = 2048; int smag_ty = 10;
   void read_env() {
     unaligned = getenv("CALES_UNALIGNED") != nullptr;
     helmholtz_z_per_column = getenv("CALES_HELMHOLTZ_Z_PER_COLUMN") != nullptr;
@@ -81,6 +81,7 @@ struct Flags {
     unmerged_bc = getenv("CALES_UNMERGED_BC") != nullptr;
     kchunk = getenv("CALES_KCHUNK") ? atoi(getenv("CALES_KCHUNK")) : 0;
     tile_min_blocks = getenv("CALES_TILE_MIN_BLOCKS") ? atol(getenv("CALES_TILE_MIN_BLOCKS")) : 2048;
+    { const int t = getenv("CALES_SMAG_TY") ? atoi(getenv("CALES_SMAG_TY")) : 10; smag_ty = (t == 6 || t == 14) ? t : 10; }
   }
 };
 

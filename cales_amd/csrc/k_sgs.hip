@@ -666,18 +666,18 @@ __global__ __launch_bounds__(256) void k_wall_shear_y(Geom g, const double *__re
     twy[(size_t)(g.n3 + 2 + k) * g.s1 + i] = sqrt(0.5 * visc * (sqrt(t1 * t1 + t2 * t2) * dyi));
   }
 }
-template <typename OFF, int SMAG>
-__global__ __launch_bounds__(64 * (TYS + 2)) void k_strain_tile(Geom g, StrainTileArgs A) {
+template <typename OFF, int SMAG, int TY>
+__global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTileArgs A) {
   // (one barrier per plane with four ring slots and double-buffered sums, as in k_lij_mij_tile, measured 13 % slower here)
-  __shared__ double ring[3][3][TYS + 2][66];      // rows: x-halo cell, 64 own cells, x-halo cell
-  __shared__ double shs[SMAG ? 1 : 3][TYS + 2][64];
+  __shared__ double ring[3][3][TY + 2][66];      // rows: x-halo cell, 64 own cells, x-halo cell
+  __shared__ double shs[SMAG ? 1 : 3][TY + 2][64];
   const int tx = threadIdx.x, ty = threadIdx.y;
-  const int i = blockIdx.x * 64 + tx + 1, j = blockIdx.y * TYS + ty;        // whole 128-B lines in and out (see cales_create)
+  const int i = blockIdx.x * 64 + tx + 1, j = blockIdx.y * TY + ty;        // whole 128-B lines in and out (see cales_create)
   const int kbeg = blockIdx.z * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
   const bool edge = tx == 0 || tx == 63;
   const int ih = tx == 0 ? i - 1 : i + 1, hx = tx == 0 ? 0 : 65;
   const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1, hok = edge && ih <= g.n1 + 1 && j <= g.n2 + 1;
-  const bool outok = ty >= 1 && ty <= TYS && i <= g.n1 && j <= g.n2;
+  const bool outok = ty >= 1 && ty <= TY && i <= g.n1 && j <= g.n2;
   const OFF c0 = ldok ? (OFF)g.ix(i, j, 0) * 8 : 0, ch = hok ? (OFF)g.ix(ih, j, 0) * 8 : 0, sk = (OFF)g.s12 * 8;   // byte offsets
   double fn[3], fh[3];
   // ghost rows at wall-model y faces (SMAG pass of ducts): u and w are replaced by 2 Q(1) - Q(2) along y; v, normal to the face, is not
@@ -858,7 +858,7 @@ static int dsmag_fast(cales_ctx *c) {
     for (int m = 0; m < 6; ++m) S.ssij[m] = ssij[m];
     S.uc[0] = c->uc; S.uc[1] = c->vc; S.uc[2] = c->wc; S.uf[0] = c->uf; S.uf[1] = c->vf; S.uf[2] = c->wf;
     S.dzci = c->d_dzci; S.dzfi = c->d_dzfi; S.dxi = c->dli[0]; S.dyi = c->dli[1]; S.kchunk = kch; S.zlo = zlo; S.zhi = zhi; S.wmlo = wmlo; S.wmhi = wmhi; S.flo = flo; S.fhi = fhi;
-    if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 0>), mg, mb, 0, c->stream, c->g, S); else hipLaunchKernelGGL((k_strain_tile<size_t, 0>), mg, mb, 0, c->stream, c->g, S); }
+    if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 0, TYS>), mg, mb, 0, c->stream, c->g, S); else hipLaunchKernelGGL((k_strain_tile<size_t, 0, TYS>), mg, mb, 0, c->stream, c->g, S); }
   // sgs-type ghost cells: only the periodic exchange matters (products of ghosts = ghosts of products; the wall ghosts are
   // replaced by the extrapolation rule inside the filters)
   // These twelve scratch fields are read by the tile kernels only: with periodic x their ghost columns are not filled (the
@@ -947,7 +947,10 @@ static int smag_fast(cales_ctx *c) {
     HIPCHK(c, hipMalloc(&c->d_del, (n[2] + 2) * sizeof(double)));
     hipLaunchKernelGGL(k_smag_del, dim3((n[2] + 2 + 63) / 64), dim3(64), 0, c->stream, n[2] + 2, c->dl[0], c->dl[1], c->d_dzf, c->d_del);
   }
-  dim3 mb(64, TYS + 2, 1), mg((n[0] + 63) / 64, (n[1] + TYS - 1) / TYS, 1);
+  // tile height of the Smagorinsky pass: the pass is bound by latency (one barrier pair per plane, two square roots and an exponential per
+  // cell), not by bandwidth, so several small blocks per CU beat one block of sixteen waves (measured: 10 rows beat 14 by 5-33 % from 256x128x128 to 512^3 and 6 rows lose; CALES_SMAG_TY = 6, 10, 14 for A/B runs)
+  const int TYM = c->fl.smag_ty;
+  dim3 mb(64, TYM + 2, 1), mg((n[0] + 63) / 64, (n[1] + TYM - 1) / TYM, 1);
   int kch = n[2];
   while ((long)mg.x * mg.y * ((n[2] + kch - 1) / kch) < tile_min_blocks(c) && kch > 32) kch = (kch + 1) / 2;
   // small grids: fewer blocks than one per CU leave most of the chip idle; shorter chunks (their three-plane prologue weighs more) beat that
@@ -974,8 +977,10 @@ static int smag_fast(cales_ctx *c) {
     S.twy = twy;
   }
   const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32) && !c->fl.wide_offsets;
-  if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 1>), mg, mb, 0, c->stream, c->g, S);
-  else hipLaunchKernelGGL((k_strain_tile<size_t, 1>), mg, mb, 0, c->stream, c->g, S);
+#define SMAG_LAUNCH(TYV) do { if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 1, TYV>), mg, mb, 0, c->stream, c->g, S); \
+                              else hipLaunchKernelGGL((k_strain_tile<size_t, 1, TYV>), mg, mb, 0, c->stream, c->g, S); } while (0)
+  if (TYM == 6) SMAG_LAUNCH(6); else if (TYM == 10) SMAG_LAUNCH(10); else SMAG_LAUNCH(14);
+#undef SMAG_LAUNCH
   HIPCHK(c, hipGetLastError());
   return 0;
 }
