@@ -36,6 +36,19 @@ class SelfComm:
         self.calls["allreduce"][0] += 1; self.calls["allreduce"][1] += count
         return 0
 
+    # the same on the library's second stream (cales_set_comm_overlap): k-chunks of the transposition, deferred scratch-field halos
+    def halo_s(self, off_slo, off_shi, off_rlo, off_rhi, count, stream):
+        with self.t.cuda.stream(self.t.cuda.ExternalStream(int(stream))):
+            return self.halo(off_slo, off_shi, off_rlo, off_rhi, count)
+
+    def alltoall_part(self, direction, peer_stride, off, count, stream):
+        src, dst = (self.A, self.B) if direction == 0 else (self.B, self.A)
+        self.calls["alltoall"][0] += 1; self.calls["alltoall"][1] += (self.P - 1) * count
+        with self.t.cuda.stream(self.t.cuda.ExternalStream(int(stream))):
+            for q in range(self.P):
+                dst[q * peer_stride + off:q * peer_stride + off + count].copy_(src[q * peer_stride + off:q * peer_stride + off + count])
+        return 0
+
 
 def main():
     ap = argparse.ArgumentParser()
