@@ -90,8 +90,7 @@ __global__ __launch_bounds__(256) void k_bc_merged(Geom g, MJobs J) {
       else { p[g.ix(a, b, n3 + 1)] = p[g.ix(ia, jb, n3 - 1)]; p[g.ix(a, b, n3)] = F.bc1[q2]; }
     } else if (F.t1 == 'N') p[g.ix(a, b, n3 + 1)] = F.dr1 * F.bc1[q2] + p[g.ix(ia, jb, n3)];
   } else if (region == 1) {        // x ghost columns of the rows (b, k), k = 1..n3 (ghost rows included)
-    const int k = a + 1;
-    const int bb = b;              // here the block's x index runs over k and its y index over b: see the launch
+    const int bb = a, k = b + 1;   // lanes along y (rows 4 KB apart share DRAM pages; along z they would be a plane apart), blocks along z
     if (!J.do_x || k > n3 || bb > n2 + 1 || (top_face && k == n3)) return;
     const int jb = wy(bb);
     p[g.ix(0, bb, k)] = p[g.ix(n1, jb, k)]; p[g.ix(n1 + 1, bb, k)] = p[g.ix(1, jb, k)];
@@ -104,8 +103,8 @@ __global__ __launch_bounds__(256) void k_bc_merged(Geom g, MJobs J) {
 static int launch_merged(cales_ctx *c, MJobs &J) {
   if (!J.nf) return 0;
   const int *n = c->n;
-  // one grid for the three regions: region 0 needs (n1+2) x (n2+2), region 1 n3 x (n2+2), region 2 n1 x n3 threads
-  const int ex = std::max(n[0] + 2, n[2]), ey = std::max(n[1] + 2, n[2]);
+  // one grid for the three regions: region 0 needs (n1+2) x (n2+2), region 1 (n2+2) x n3, region 2 n1 x n3 threads
+  const int ex = std::max(n[0] + 2, n[1] + 2), ey = std::max(n[1] + 2, n[2]);
   hipLaunchKernelGGL(k_bc_merged, dim3((ex + 63) / 64, (ey + 3) / 4, 3 * J.nf), dim3(64, 4, 1), 0, c->stream, c->g, J);
   HIPCHK(c, hipGetLastError());
   return 0;
