@@ -365,6 +365,8 @@ struct LijMijArgs {
   int kchunk, nblk, zlo, zhi;
   int wmlo, wmhi; double flo, fhi;      // wall-model z faces: ghost planes of uf,vf by extrapolate(...,lwm), sgs.f90:683-748
   int perx;                             // x ghost columns of uc.., uf.. are not stored: wrap around
+  // y walls owned by this rank (k_lmf_tile only): wall rule of the filters along y, alph2 of the wall rows; wall-model y faces: ghost rows of u_f, w_f
+  int wylo, wyhi, wmylo, wmyhi;
 };
 template <typename OFF>
 __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijArgs A) {
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijA
 #define TYL 8
 #endif
 struct LmfArgs { LijMijArgs L; const double *ss[6]; int by0; };      // by0: first y tile of this launch (interior and edge tiles of a slab are launched apart)
-template <typename OFF>
+template <typename OFF, int YW>      // YW = 1: walls or wall-model faces in y (ducts); 0: the channel instantiation carries none of that logic
 __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) {
   const LijMijArgs &A = B.L;
   __shared__ double sh[2][9][TYL + 2][64];
@@ -504,14 +506,21 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
   const int iw = A.perx ? (i == 0 ? g.n1 : (i == g.n1 + 1 ? 1 : i)) : i;
   const OFF c0 = ldok ? (OFF)g.ix(iw, j, 0) * 8 : 0, sk = (OFF)g.s12 * 8, sj = (OFF)g.s1 * 8;      // byte offsets
   double sm[3], sc[3], sp[3], sn[3], fn[3];
+  // ghost rows of u_f and w_f at wall-model y faces: 2 Q(1) - Q(2) along y (extrapolate(...,lwm) after bounduvw, sgs.f90:683-748); v_f keeps its own
+  const int yex = !YW ? 0 : (A.wmylo && j == 0) ? 1 : (A.wmyhi && j == g.n2 + 1) ? -1 : 0;
+  auto ldf = [&](int q, OFF o) -> double {
+    if (YW && yex != 0 && q != 1) return yex > 0 ? 2. * ldb(A.uf[q], o + sj) - ldb(A.uf[q], o + 2 * sj) : 2. * ldb(A.uf[q], o - sj) - ldb(A.uf[q], o - 2 * sj);
+    return ldb(A.uf[q], o);
+  };
+  const bool ylo = YW && A.wylo && j == 1, yhi = YW && A.wyhi && j == g.n2;      // rows next to a y wall: ghost row of every filtered quantity = 2 Q(1) - Q(2)
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     sm[q] = ldok ? ldb(A.uc[q], c0 + (OFF)(kbeg - 1) * sk) : 0.;
     sc[q] = ldok ? ldb(A.uc[q], c0 + (OFF)kbeg * sk) : 0.;
     sp[q] = ldok ? ldb(A.uc[q], c0 + (OFF)(kbeg + 1) * sk) : 0.;
-    ring[(kbeg - 1) & 3][q][ty][tx] = ldok ? ldb(A.uf[q], c0 + (OFF)(kbeg - 1) * sk) : 0.;
-    ring[kbeg & 3][q][ty][tx] = ldok ? ldb(A.uf[q], c0 + (OFF)kbeg * sk) : 0.;
-    fn[q] = ldok ? ldb(A.uf[q], c0 + (OFF)(kbeg + 1) * sk) : 0.;
+    ring[(kbeg - 1) & 3][q][ty][tx] = ldok ? ldf(q, c0 + (OFF)(kbeg - 1) * sk) : 0.;
+    ring[kbeg & 3][q][ty][tx] = ldok ? ldf(q, c0 + (OFF)kbeg * sk) : 0.;
+    fn[q] = ldok ? ldf(q, c0 + (OFF)(kbeg + 1) * sk) : 0.;
     if (A.wmlo && kbeg == 1 && q < 2) ring[0][q][ty][tx] = (1. + A.flo) * ring[1][q][ty][tx] - A.flo * fn[q];
   }
   // |S|Sij: y and x combination of one plane (three rows in, lanes beside by DPP)
@@ -525,7 +534,7 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
   auto sscomb = [&](const double (*raw)[3], double *X) {
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
-      const double Y = raw[q][0] + 2. * raw[q][1] + raw[q][2];
+      const double Y = (ylo ? 2. * raw[q][1] - raw[q][2] : raw[q][0]) + 2. * raw[q][1] + (yhi ? 2. * raw[q][1] - raw[q][0] : raw[q][2]);
       X[q] = lane_prev(Y) + 2. * Y + lane_next(Y);
     }
   };
@@ -549,7 +558,7 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
       ring[kp][q][ty][tx] = (HI && A.wmhi && q < 2) ? (1. + A.fhi) * ring[kc][q][ty][tx] - A.fhi * ring[km][q][ty][tx] : fn[q];
     if (k + 2 <= g.n3 + 1) {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) { sn[q] = ldok ? ldb(A.uc[q], idx + 2 * sk) : 0.; fn[q] = ldok ? ldb(A.uf[q], idx + 2 * sk) : 0.; }
+      for (int q = 0; q < 3; ++q) { sn[q] = ldok ? ldb(A.uc[q], idx + 2 * sk) : 0.; fn[q] = ldok ? ldf(q, idx + 2 * sk) : 0.; }
     }
     double qm[9], qc[9], qp[9], r[9];
     uiuj(sc, qc);
@@ -569,7 +578,10 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
     if (outok) {
       double F[9];
 #pragma unroll
-      for (int q = 0; q < 9; ++q) F[q] = (sh[buf][q][ty - 1][tx] + 2. * r[q] + sh[buf][q][ty + 1][tx]) / 64.;
+      for (int q = 0; q < 9; ++q) {
+        const double dn = sh[buf][q][ty - 1][tx], up = sh[buf][q][ty + 1][tx];
+        F[q] = ((ylo ? 2. * r[q] - up : dn) + 2. * r[q] + (yhi ? 2. * r[q] - dn : up)) / 64.;
+      }
       const double l0 = F[3] - F[0] * F[0], l1 = F[4] - F[1] * F[1], l2 = F[5] - F[2] * F[2], l3 = F[6] - F[0] * F[1],
                    l4 = F[7] - F[0] * F[2], l5 = F[8] - F[1] * F[2];
       // strain rate of the test-filtered velocity (sgs.f90:571-630). The eight differences of each off-diagonal component telescope
@@ -599,7 +611,7 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
 #undef RV
 #undef RW
       const double s0 = sqrt(2. * (sij[0] * sij[0] + sij[1] * sij[1] + sij[2] * sij[2] + 2. * (sij[3] * sij[3] + sij[4] * sij[4] + sij[5] * sij[5])));
-      const double a2s0 = (LO || HI ? 2.52 : 4.00) * s0;      // alph2 (sgs.f90:783-816)
+      const double a2s0 = (LO || HI || ylo || yhi ? 2.52 : 4.00) * s0;      // alph2: cells next to any wall (sgs.f90:783-816)
       double m[6];
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
@@ -681,10 +693,10 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
   const OFF c0 = ldok ? (OFF)g.ix(i, j, 0) * 8 : 0, ch = hok ? (OFF)g.ix(ih, j, 0) * 8 : 0, sk = (OFF)g.s12 * 8;   // byte offsets
   double fn[3], fh[3];
   // ghost rows at wall-model y faces (SMAG pass of ducts): u and w are replaced by 2 Q(1) - Q(2) along y; v, normal to the face, is not
-  const int yex = !SMAG ? 0 : (A.wmylo && j == 0) ? 1 : (A.wmyhi && j == g.n2 + 1) ? -1 : 0;
+  const int yex = (A.wmylo && j == 0) ? 1 : (A.wmyhi && j == g.n2 + 1) ? -1 : 0;
   const OFF sjb = (OFF)g.s1 * 8;
   auto ld = [&](int q, OFF o) -> double {
-    if (SMAG && yex != 0 && q != 1) return yex > 0 ? 2. * ldb(A.u[q], o + sjb) - ldb(A.u[q], o + 2 * sjb) : 2. * ldb(A.u[q], o - sjb) - ldb(A.u[q], o - 2 * sjb);
+    if (yex != 0 && q != 1) return yex > 0 ? 2. * ldb(A.u[q], o + sjb) - ldb(A.u[q], o + 2 * sjb) : 2. * ldb(A.u[q], o - sjb) - ldb(A.u[q], o - 2 * sjb);
     return ldb(A.u[q], o);
   };
 #pragma unroll
@@ -798,8 +810,15 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
     }
     __syncthreads();
     if (!SMAG && outok) {
+      // next to a no-slip y wall the ghost row of u and w is the extrapolation 2 Q(1) - Q(2) (extrapolate(...,cbc), sgs.f90:705-710): its
+      // y combination is 4 Q(1); v, normal to the wall, keeps its ghost row
+      const bool ylo = A.wylo && j == 1, yhi = A.wyhi && j == g.n2;
 #pragma unroll
-      for (int q = 0; q < 3; ++q) stb(A.uf[q], idx, (shs[q][ty - 1][tx] + 2. * r[q] + shs[q][ty + 1][tx]) / 64.);
+      for (int q = 0; q < 3; ++q) {
+        const double dn = shs[q][ty - 1][tx], up = shs[q][ty + 1][tx];
+        const double a = (ylo && q != 1) ? 2. * r[q] - up : dn, b = (yhi && q != 1) ? 2. * r[q] - dn : up;
+        stb(A.uf[q], idx, (a + 2. * r[q] + b) / 64.);
+      }
     }
     const int t = km; km = kc; kc = kp; kp = t;
   }
@@ -821,8 +840,9 @@ int allreduce_res(cales_ctx *c, int slot, int count, int op);
 int op_boundp(cales_ctx *c, double *p, int which);
 int op_boundp_multi(cales_ctx *c, int nf, double **p, int which);
 static bool dsmag_fast_ok(const cales_ctx *c) {
-  for (int q = 0; q < 4; ++q) if (c->is_wall[q] != 0.) return false;      // walls in x or y: general path
-  for (int q = 0; q < 4; ++q) if (c->C.lwm[q] != 0) return false;         // wall model on x or y faces: general path
+  for (int q = 0; q < 2; ++q) if (c->is_wall[q] != 0. || c->C.lwm[q] != 0) return false;      // walls or wall model in x: general path
+  // walls / wall model in y (ducts): the fused last pass knows the wall rule along y, the two-pass form does not
+  for (int q = 2; q < 4; ++q) if ((c->is_wall[q] != 0. || c->C.lwm[q] != 0) && (c->fl.dsmag_unfused_filter || c->n[1] < 3)) return false;
   return c->n[2] >= 3 && !c->fl.dsmag_reference_sequence;
 }
 static int dsmag_fast(cales_ctx *c) {
@@ -834,6 +854,9 @@ static int dsmag_fast(cales_ctx *c) {
   // grid factor, sgs.f90:683-748) instead of the stress-carrying ghost cells
   const int wmlo = ISB(c, 0, 3) && LWM(c, 0, 3) != 0, wmhi = ISB(c, 1, 3) && LWM(c, 1, 3) != 0;
   const double flo = (1. / c->dzci[0]) * c->dzci[1], fhi = (1. / c->dzci[n[2]]) * c->dzci[n[2] - 1];
+  // y walls of a duct, on the rank that owns them: wall rule of the filters along y; wall-model y faces: extrapolated ghost rows for the strain rates
+  const int wylo = ISB(c, 0, 2) && c->is_wall[2] != 0., wyhi = ISB(c, 1, 2) && c->is_wall[3] != 0.;
+  const int wmylo = ISB(c, 0, 2) && LWM(c, 0, 2) != 0, wmyhi = ISB(c, 1, 2) && LWM(c, 1, 2) != 0;
   // tiles of 62 x TY columns marching in k; k is also split into chunks so that several rounds of blocks balance the chip
   auto tiles = [&](int ty, int wx, dim3 &mb, dim3 &mg, int &kchunk) {
     mb = dim3(64, ty + 2, 1); mg = dim3((n[0] + wx - 1) / wx, (n[1] + ty - 1) / ty, 1);
@@ -858,6 +881,7 @@ static int dsmag_fast(cales_ctx *c) {
     for (int m = 0; m < 6; ++m) S.ssij[m] = ssij[m];
     S.uc[0] = c->uc; S.uc[1] = c->vc; S.uc[2] = c->wc; S.uf[0] = c->uf; S.uf[1] = c->vf; S.uf[2] = c->wf;
     S.dzci = c->d_dzci; S.dzfi = c->d_dzfi; S.dxi = c->dli[0]; S.dyi = c->dli[1]; S.kchunk = kch; S.zlo = zlo; S.zhi = zhi; S.wmlo = wmlo; S.wmhi = wmhi; S.flo = flo; S.fhi = fhi;
+    S.wylo = wylo; S.wyhi = wyhi; S.wmylo = wmylo; S.wmyhi = wmyhi; S.twy = nullptr; S.dl2 = c->dl[1];
     if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 0, TYS>), mg, mb, 0, c->stream, c->g, S); else hipLaunchKernelGGL((k_strain_tile<size_t, 0, TYS>), mg, mb, 0, c->stream, c->g, S); }
   // sgs-type ghost cells: only the periodic exchange matters (products of ghosts = ghosts of products; the wall ghosts are
   // replaced by the extrapolation rule inside the filters)
@@ -883,6 +907,7 @@ static int dsmag_fast(cales_ctx *c) {
   for (int m = 0; m < 6; ++m) L.mf[m] = mij[m];
   L.part = c->wk[0]; L.dzci = c->d_dzci; L.dzfi = c->d_dzfi; L.dxi = c->dli[0]; L.dyi = c->dli[1];
   L.zlo = zlo; L.zhi = zhi; L.wmlo = wmlo; L.wmhi = wmhi; L.flo = flo; L.fhi = fhi; L.perx = perx;
+  L.wylo = wylo; L.wyhi = wyhi; L.wmylo = wmylo; L.wmyhi = wmyhi;
   if (!c->fl.dsmag_unfused_filter) {
     // K_B + K_DF in one pass: filter(|S|Sij) on the fly, strain rate of the filtered velocity, Mij, Lij, contractions, plane partial sums
     ProfScope ps(c, "lij_mij_filter_contract");
@@ -893,7 +918,9 @@ static int dsmag_fast(cales_ctx *c) {
     auto launch = [&](int by0, int nby) {
       if (nby <= 0) return;
       B.by0 = by0; const dim3 gg(mg.x, nby, mg.z);
-      if (small) hipLaunchKernelGGL(k_lmf_tile<unsigned>, gg, mb, 0, c->stream, c->g, B); else hipLaunchKernelGGL(k_lmf_tile<size_t>, gg, mb, 0, c->stream, c->g, B);
+      const bool yw = wylo || wyhi || wmylo || wmyhi;
+      if (yw) { if (small) hipLaunchKernelGGL((k_lmf_tile<unsigned, 1>), gg, mb, 0, c->stream, c->g, B); else hipLaunchKernelGGL((k_lmf_tile<size_t, 1>), gg, mb, 0, c->stream, c->g, B); }
+      else if (small) hipLaunchKernelGGL((k_lmf_tile<unsigned, 0>), gg, mb, 0, c->stream, c->g, B); else hipLaunchKernelGGL((k_lmf_tile<size_t, 0>), gg, mb, 0, c->stream, c->g, B);
     };
     if (overlap) {
       // tiles that read the ghost rows j = 0 or j = n2+1 wait for the rows in flight; the others run beside the exchange

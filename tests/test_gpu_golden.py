@@ -24,7 +24,7 @@ def _hot(case):
     return HotPath(case)
 
 
-WALLED_DSMAG = ["duct_dsmag_wm", "duct_dsmag", "cavity_dsmag"]    # walls in x/y: the kernel-per-loop sequence is the only path
+WALLED_DSMAG = ["cavity_dsmag"]    # walls in x: the kernel-per-loop sequence is the only path (ducts, y walls, go through the tile passes)
 
 
 @pytest.mark.parametrize("name", DEVICE_CASES)
@@ -146,7 +146,7 @@ def test_wide_offset_kernels(name, monkeypatch):
 
 @pytest.mark.parametrize("env", ["CALES_DSMAG_REFERENCE_SEQUENCE", "CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_GAUSSEL_MARCH", "CALES_DSMAG_EAGER", "CALES_KEEP_LAST_RHS",
                                  "CALES_DSMAG_UNFUSED_FILTER", "CALES_UNMERGED_BC"])
-@pytest.mark.parametrize("name", ["chan_dsmag", "chan_dsmag_wm", "tgv_dsmag_ppp", "duct_smag_wm_imp1d"])
+@pytest.mark.parametrize("name", ["chan_dsmag", "chan_dsmag_wm", "tgv_dsmag_ppp", "duct_smag_wm_imp1d", "duct_dsmag_wm"])
 def test_unfused_paths(name, env, monkeypatch):
     """The kernel-per-loop forms behind the operator-level entries (general dsmag sequence, mom + rk_update, correc +
     updatep, bulk forcing and fillps as passes of their own, marching tridiagonal sweep) stay selectable and are held to the same
@@ -171,7 +171,7 @@ def test_smag_reference_sequence(name, monkeypatch):
     test_startup_and_substeps(name, general_sgs=True)
 
 
-@pytest.mark.parametrize("name", ["chan_dsmag", "chan_dsmag_wm", "tgv_dsmag_ppp"])
+@pytest.mark.parametrize("name", ["chan_dsmag", "chan_dsmag_wm", "tgv_dsmag_ppp", "duct_dsmag_wm", "duct_dsmag"])
 def test_dsmag_reference_sequence(name, monkeypatch):
     """Dynamic Smagorinsky through the kernel-per-loop sequence of sgs.f90:153-380, operator by operator at 1e-13."""
     monkeypatch.setenv("CALES_DSMAG_REFERENCE_SEQUENCE", "1")

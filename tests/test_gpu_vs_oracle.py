@@ -66,7 +66,9 @@ def test_tridiagonal_paths_agree(name, ng, monkeypatch):
                                             ("halfchan_imp1d", (16, 16, 16), 3), ("chan_smag", (24, 20, 12), 10),
                                             # tile kernels: partial tiles in x and y, several x tiles, k chunks, wall-modelled z faces
                                             ("chan_dsmag", (80, 20, 12), 3), ("tgv_dsmag_ppp", (72, 16, 40), 3), ("chan_dsmag_wm", (128, 30, 70), 2), ("chan_smag_wm", (96, 18, 40), 3),
-                                            ("duct_smag_wm", (16, 24, 24), 4), ("cavity_nnn", (16, 16, 16), 5), ("devchan_nd", (32, 16, 16), 4), ("devchan_nd", (40, 18, 12), 3),
+                                            ("duct_smag_wm", (16, 24, 24), 4), ("cavity_nnn", (16, 16, 16), 5),
+                                            # dynamic model in ducts: tile passes with the wall rule along y; partial y tiles, several x tiles, wall-model and no-slip walls
+                                            ("duct_dsmag_wm", (80, 20, 24), 3), ("duct_dsmag", (72, 18, 20), 3), ("duct_dsmag", (16, 8, 12), 4), ("cavity_dsmag", (16, 16, 12), 3), ("devchan_nd", (32, 16, 16), 4), ("devchan_nd", (40, 18, 12), 3),
                                             # wall-model sampling height inside the first cell (index_wm = 1 / n): the wall model reads the ghost cells
                                             # of the last bounduvw, which have to survive the double-buffered velocity update
                                             ("duct_smag_wm", (16, 8, 24), 3), ("duct_smag_wm_imp1d", (50, 8, 76), 2), ("chan_smag_wm", (32, 16, 8), 3),
