@@ -1172,6 +1172,9 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
   const unsigned xblocks_c = (unsigned)((xgroups_c + xiters_c - 1) / xiters_c);
   int ykchunk_c = 1; { const long cg = (ncol + CB8 - 1) / CB8; while (ykchunk_c < 8 && cg * (kpc / (ykchunk_c * 2)) >= 2048 / NCH && kpc % (ykchunk_c * 2) == 0) ykchunk_c *= 2; }
   hipEvent_t ev_arrived[4];
+  // the bulk means summed by the fused fillps pass: several ranks all-reduce them on the context's stream, and RCCL orders the operations of
+  // one communicator across streams -- issued between the chunk exchanges it would hold the y transforms back, so it follows the z sweep
+  int pend_mean_mask = 0, pend_mean_nblk = 0; const double *pend_mean_part = nullptr;
   auto mark = [&](hipStream_t st, hipEvent_t &e) -> int {
     if (c->sync_ev.size() < 64) { hipEvent_t ne; HIPCHK(c, hipEventCreateWithFlags(&ne, hipEventDisableTiming)); c->sync_ev.push_back(ne); c->sync_next = c->sync_ev.size() - 1; }
     e = c->sync_ev[c->sync_next]; c->sync_next = (c->sync_next + 1) % c->sync_ev.size();
@@ -1203,7 +1206,7 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
         else hipLaunchKernelGGL((k_fft_x8<0, 0>), dim3(xblocks_c), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters_c, (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec, FillArgs{}, rb, re); }
       if (int e = exchange_chunk(0, ch)) return e;
     }
-    if (fill && F.mean_mask) if (int e = op_force_from_partials(c, F.mean_mask, F.part, (int)(xblocks_c * NCH))) return e;
+    if (fill && F.mean_mask) { pend_mean_mask = F.mean_mask; pend_mean_part = F.part; pend_mean_nblk = (int)(xblocks_c * NCH); }
     for (int ch = 0; ch < NCH; ++ch) {
       HIPCHK(c, hipStreamWaitEvent(c->stream, ev_arrived[ch], 0));
       ProfScope ps(c, "fft_y_fwd");
@@ -1271,6 +1274,7 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
     else if (periodic_z) hipLaunchKernelGGL((k_gaussel<double2, 1>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2, fixnull);
     else if (c->fl.gaussel_pair) hipLaunchKernelGGL((k_gaussel<double2, 0>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2, fixnull);
     else hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, fixnull, 0); }
+  if (pend_mean_mask) if (int e = op_force_from_partials(c, pend_mean_mask, pend_mean_part, pend_mean_nblk)) return e;
   if (pipe) {
     for (int ch = 0; ch < NCH; ++ch) {
       { ProfScope ps(c, "fft_y_bwd");
