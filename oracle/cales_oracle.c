@@ -975,7 +975,8 @@ void o_chkdiv(ostate *s, const double *u, const double *v, const double *w, doub
 
 /* ------------------------------------------------------------------ plane statistics: first block of out1d_single_point_chan
    (output.f90:509-700, idir = 3): 27 sums per z plane times dx dy/(lx ly); buf is (27, n3) in Fortran order.
-   TEST INFRASTRUCTURE; parity unpinned (output.f90 needs 2decomp-fft and cannot be built here). */
+   TEST INFRASTRUCTURE; pinned: tests/test_oracle_golden.py::test_plane_statistics compares it with the output of the reference's own
+   routine (compiled from its lines by oracle/ref/Makefile) on the 14 golden end-of-step states, <= 4e-16 of each column's largest entry. */
 void o_stats_chan(ostate *s, const double *u, const double *v, const double *w, const double *p, const double *visct, double *buf) {
   const int *n = s->n; const size_t s1 = s->s1, s2 = s->s2;
   const double dx = s->dl[0], dy = s->dl[1], ratio = dx*dy/(s->P.l[0]*s->P.l[1]);

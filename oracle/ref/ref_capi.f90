@@ -382,3 +382,23 @@ subroutine ref_chkdiv(u,v,w,divtot,divmax) bind(C,name='ref_chkdiv')
   real(c_double), intent(out) :: divtot,divmax
   call chkdiv(lo,hi,dli,dzfi,u,v,w,divtot,divmax)
 end subroutine ref_chkdiv
+!
+! out1d_single_point_chan (src/output.f90:509-1061, idir = 3): writes <fname>.out/.bin (27 plane statistics),
+! <fname>_reystr_budget.out/.bin (38) and <fname>_leakage.out/.bin (6) into the current directory
+subroutine ref_out1d_single_point_chan(fname_c,nchar,u,v,w,p,visct) bind(C,name='ref_out1d_single_point_chan')
+  use, intrinsic :: iso_c_binding
+  use ref_state
+  use mod_param, only: ng,l,dl
+  use mod_output_stats, only: out1d_single_point_chan
+  implicit none
+  integer(c_int), intent(in), value :: nchar
+  character(kind=c_char), intent(in) :: fname_c(nchar)
+  real(c_double), intent(in), dimension(0:n(1)+1,0:n(2)+1,0:n(3)+1) :: u,v,w,p,visct
+  character(len=:), allocatable :: fname
+  integer :: q
+  allocate(character(len=nchar) :: fname)
+  do q = 1,nchar
+    fname(q:q) = fname_c(q)
+  end do
+  call out1d_single_point_chan(fname,ng,lo,hi,3,l,dl,dzc,dzf,zc,zf,u,v,w,p,visct)
+end subroutine ref_out1d_single_point_chan

@@ -134,5 +134,14 @@ class Ref:
         self.lib.ref_chkdiv(_p(u), _p(v), _p(w), C.byref(a), C.byref(b))
         return a.value, b.value
 
+    def out1d_single_point_chan(self, u, v, w, p, visct, fname="velstats_ref"):
+        """the reference's plane statistics of the current directory's case: (27, n3), (38, n3), (6, n3) arrays read back from the
+        .bin files the routine writes (src/output.f90:683-699, 990-1055)"""
+        b = fname.encode()
+        self.lib.ref_out1d_single_point_chan(b, C.c_int(len(b)), _p(u), _p(v), _p(w), _p(p), _p(visct))
+        n3 = self.n[2]
+        rd = lambda suffix, nv: np.fromfile(fname + suffix + ".bin").reshape((nv, n3), order="F")
+        return rd("", 27), rd("_reystr_budget", 38), rd("_leakage", 6)
+
     def finalize(self):
         self.lib.ref_finalize()

@@ -200,6 +200,10 @@ def run_case(name, out):
         G[K + "div"] = np.array(ref.chkdiv(u, v, w))
     G["dpdl"] = -dpdl / dt
     G["dt_cfl_end"] = np.array(ref.chkdt(visct, u, v, w))
+    # plane statistics of the end-of-step state by the reference's own out1d_single_point_chan (src/output.f90:509-1061; built from
+    # the routine's lines by oracle/ref/Makefile): 27 single-point sums, 38 budget sums, 6 divergence measures per plane
+    st, bud, leak = ref.out1d_single_point_chan(u, v, w, p, visct)
+    G["st_chan"], G["st_budget"], G["st_leak"] = st, bud, leak
     np.savez_compressed(out, **G)
     print(name, "divmax after step:", G["r3_div"][1], "file KB:", os.path.getsize(out) // 1024)
     ref.finalize()

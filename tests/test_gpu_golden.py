@@ -224,3 +224,19 @@ def test_rk_with_caller_coefficients(name):
     for k in "uvw":
         assert relerr(h.get(k)[1:-1, 1:-1, 1:-1], g["r1_s1_" + k][1:-1, 1:-1, 1:-1]) < TOL, k
     h.close()
+
+
+@pytest.mark.parametrize("name", DEVICE_CASES)
+def test_plane_statistics_against_reference(name):
+    """cales_out1d_single_point_chan / cales_out1d_chan_budgets on the golden end-of-step state against the output of the reference's own
+    out1d_single_point_chan (src/output.f90:509-1061, compiled from its lines by oracle/ref/Makefile): 27 + 38 + 6 columns per plane.
+    The device sums planes in two deterministic levels, the reference in one loop: 1e-12 of each column's largest entry (measured ≤ 1e-14)."""
+    g, case = load_golden(name)
+    h = _hot(case)
+    h.upload(*(F(g[k]) for k in ("r3_s7_u", "r3_s7_v", "r3_s7_w", "r3_s8_p"))); h.set("visct", F(g["r3_s9_visct"]))
+    st = h.stats_chan(); bud, leak = h.stats_chan_budgets()
+    for got, ref, nm in ((st, g["st_chan"], "single-point"), (bud, g["st_budget"], "budget"), (leak, g["st_leak"], "leakage")):
+        scale = np.abs(ref).max(axis=1, keepdims=True)
+        # columns that vanish by cancellation (mean w, mean vorticity of a periodic box ...) are held to 1e-14 of the block's largest column
+        assert (np.abs(got - ref) <= 1e-12 * scale + 1e-14 * np.abs(ref).max()).all(), (nm, np.abs(got - ref).max(axis=1) / np.maximum(scale[:, 0], 1e-300))
+    h.close()

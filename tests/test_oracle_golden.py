@@ -164,3 +164,24 @@ def test_imp3d_operators():
     o.updatep(float(g["upd_alpha"]), F(g["upd_pp"]), p)
     assert relerr(p, g["upd_p"]) < TOL
     assert abs(o.chkdt(s0[4], u, v, w) / float(g["dt_cfl"]) - 1) < 1e-14
+
+
+@pytest.mark.parametrize("name", FULL_CASES)
+def test_plane_statistics(name):
+    """The plane statistics of the reference's default out1d.h90 (out1d_single_point_chan, src/output.f90:509-1061: 27 single-point
+    sums, 38 budget sums, 6 divergence measures per z plane), produced by the reference's own routine on the golden end-of-step state:
+    the C restatement o_stats_chan and the numpy restatement oracle/stats_np.py reproduce them (same terms, the plane sums in another
+    order: 1e-13 of each column's largest entry; the two max-norm leakage columns exactly)."""
+    from oracle import stats_np
+    g, case = load_golden(name)
+    o = Oracle(case)
+    u, v, w, p, vis = (F(g[k]) for k in ("r3_s7_u", "r3_s7_v", "r3_s7_w", "r3_s8_p", "r3_s9_visct"))
+    st = o.stats_chan(u, v, w, p, vis)
+    gr = o.grid()
+    dx, dy = float(case.dl[0]), float(case.dl[1])
+    bud = stats_np.budget_terms(u, v, w, p, dx, dy, gr["dzc"], gr["dzf"], float(case.l[0]), float(case.l[1]))
+    leak = stats_np.leakage_terms(u, v, w, dx, dy, gr["dzf"], float(case.l[0]), float(case.l[1]))
+    for got, ref, nm in ((st, g["st_chan"], "single-point"), (bud, g["st_budget"], "budget"), (leak, g["st_leak"], "leakage")):
+        assert got.shape == ref.shape, nm
+        scale = np.maximum(np.abs(ref).max(axis=1, keepdims=True), 1e-300)
+        assert (np.abs(got - ref) <= 1e-13 * scale).all(), (nm, np.abs(got - ref).max(axis=1) / scale[:, 0])      # measured: 4e-16, 3e-14, 1e-15
