@@ -835,13 +835,11 @@ static void gaussel_line(int n, const double *a, const double *b, const double *
 }
 
 /* ------------------------------------------------------------------ Poisson solve: src/solver.f90:20-80 (one rank) */
-void o_solver(ostate *s, double *p) {
+/* the z sweep of the solve alone: gaussel / gaussel_periodic with lambdaxy, solver.f90:56-61,82-151 (pinned: `sol_gz_*` golden vectors made by
+   the reference's own routines) */
+void o_solver_zsweep(ostate *s, double *p) {
   const int *n = s->n; const size_t s1 = s->s1, s2 = s->s2;
   int periodic_z = CBP(0,3) == 'P' && CBP(1,3) == 'P';
-  #pragma omp parallel for collapse(2) num_threads(s->nthreads)
-  for (int k = 1; k <= n[2]; k++) for (int j = 1; j <= n[1]; j++) o_r2r(s->kind_fwd[0], n[0], &p[IX(1,j,k)], 1);
-  #pragma omp parallel for collapse(2) num_threads(s->nthreads)
-  for (int k = 1; k <= n[2]; k++) for (int i = 1; i <= n[0]; i++) o_r2r(s->kind_fwd[1], n[1], &p[IX(i,1,k)], (int)s1);
   #pragma omp parallel num_threads(s->nthreads)
   {
     double *work = (double *)malloc(sizeof(double)*4*n[2]);
@@ -850,6 +848,14 @@ void o_solver(ostate *s, double *p) {
       gaussel_line(n[2], s->a, s->b, s->c, s->lambdaxy[(i-1) + (size_t)n[0]*(j-1)], periodic_z, &p[IX(i,j,1)], (int)(s1*s2), work);
     free(work);
   }
+}
+void o_solver(ostate *s, double *p) {
+  const int *n = s->n; const size_t s1 = s->s1, s2 = s->s2;
+  #pragma omp parallel for collapse(2) num_threads(s->nthreads)
+  for (int k = 1; k <= n[2]; k++) for (int j = 1; j <= n[1]; j++) o_r2r(s->kind_fwd[0], n[0], &p[IX(1,j,k)], 1);
+  #pragma omp parallel for collapse(2) num_threads(s->nthreads)
+  for (int k = 1; k <= n[2]; k++) for (int i = 1; i <= n[0]; i++) o_r2r(s->kind_fwd[1], n[1], &p[IX(i,1,k)], (int)s1);
+  o_solver_zsweep(s, p);
   #pragma omp parallel for collapse(2) num_threads(s->nthreads)
   for (int k = 1; k <= n[2]; k++) for (int i = 1; i <= n[0]; i++) o_r2r(s->kind_bwd[1], n[1], &p[IX(i,1,k)], (int)s1);
   #pragma omp parallel for collapse(2) num_threads(s->nthreads)

@@ -7,10 +7,14 @@
  * image is checked against golden vectors produced by the reference itself
  * (oracle/ref -> oracle/_ref, tests/golden/gen_golden.py, tests/test_oracle_golden.py).
  * PARITY UNPINNED at one boundary: the r2r transforms (FFTW 3.x, not vendored,
- * src/fft.f90:70-85,179-190) and the solver driver around them (src/solver.f90, needs
- * 2decomp-fft). They are restated from the FFTW manual's definitions, checked against
- * scipy.fft (same conventions) and by the discrete identity L_h(solve(r)) = r built
- * from the reference's own fillps/correc stencils.
+ * src/fft.f90:70-85,179-190) and the call order of the solver driver around them
+ * (src/solver.f90:20-80, needs 2decomp-fft). The transforms are restated from the FFTW
+ * manual's definitions, checked against scipy.fft (same conventions) and by the discrete
+ * identity L_h(solve(r)) = r built from the reference's own fillps/correc stencils. The
+ * plain-arithmetic parts of the solver ARE pinned to the reference's own routines, compiled
+ * from their lines (oracle/ref/Makefile): eigenvalues, tridmatrix (initsolver.f90:66-169),
+ * gaussel, gaussel_periodic, dgtsv_homebrewed (solver.f90:82-179), and with them all of
+ * solver_gaussel_z (a transposition around gaussel).
  *
  * All 3-D arrays are Fortran-ordered with one halo cell: a(0:n1+1,0:n2+1,0:n3+1).
  */
@@ -66,6 +70,7 @@ void o_updt_rhs_b_p(ostate *s, double *pp);
 void o_updt_rhs_b_vel(ostate *s, int ivel, double alpha, double *q);
 void o_updt_rhs_b_velz(ostate *s, int ivel, double alpha, double *q);
 void o_solver(ostate *s, double *pp);                          /* Poisson, cbcpre, 'c','c','c' */
+void o_solver_zsweep(ostate *s, double *pp);                   /* its tridiagonal sweep alone (solver.f90:56-61,82-151) */
 void o_solver_gaussel_z(ostate *s, int ivel, double alpha, double *q);
 int o_solver_helmholtz(ostate *s, int ivel, double alpha, double *q);   /* 3-D implicit diffusion, x and y periodic */
 void o_correc(ostate *s, double dtrk, const double *pp, double *u, double *v, double *w);

@@ -167,6 +167,9 @@ class Oracle:
     def solver(self, pp):
         self.lib.o_solver(self.h, _p(pp))
 
+    def solver_zsweep(self, pp):
+        self.lib.o_solver_zsweep(self.h, _p(pp))
+
     def solver_gaussel_z(self, ivel, alpha, q):
         self.lib.o_solver_gaussel_z(self.h, int(ivel), C.c_double(alpha), _p(q))
 

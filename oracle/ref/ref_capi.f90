@@ -402,3 +402,52 @@ subroutine ref_out1d_single_point_chan(fname_c,nchar,u,v,w,p,visct) bind(C,name=
   end do
   call out1d_single_point_chan(fname,ng,lo,hi,3,l,dl,dzc,dzf,zc,zf,u,v,w,p,visct)
 end subroutine ref_out1d_single_point_chan
+!
+! the plain-arithmetic routines of initsolver.f90 / solver.f90 (compiled from their own lines, see the Makefile)
+subroutine ref_eigenvalues(n,cbc2,c_or_f,lambda) bind(C,name='ref_eigenvalues')
+  use, intrinsic :: iso_c_binding
+  use mod_initsolver_pure, only: eigenvalues
+  implicit none
+  integer(c_int), intent(in), value :: n
+  character(kind=c_char), intent(in) :: cbc2(0:1),c_or_f
+  real(c_double), intent(out) :: lambda(n)
+  character(len=1) :: cbc(0:1)
+  cbc(0) = cbc2(0); cbc(1) = cbc2(1)
+  call eigenvalues(n,cbc,c_or_f,lambda)
+end subroutine ref_eigenvalues
+subroutine ref_tridmatrix(cbc2,n,dzi,dzci,dzfi,c_or_f,a,b,c) bind(C,name='ref_tridmatrix')
+  use, intrinsic :: iso_c_binding
+  use mod_initsolver_pure, only: tridmatrix
+  implicit none
+  integer(c_int), intent(in), value :: n
+  real(c_double), intent(in), value :: dzi
+  character(kind=c_char), intent(in) :: cbc2(0:1),c_or_f
+  real(c_double), intent(in) :: dzci(0:n+1),dzfi(0:n+1)
+  real(c_double), intent(out) :: a(n),b(n),c(n)
+  character(len=1) :: cbc(0:1)
+  cbc(0) = cbc2(0); cbc(1) = cbc2(1)
+  call tridmatrix(cbc,n,dzi,dzci,dzfi,c_or_f,a,b,c)
+end subroutine ref_tridmatrix
+! gaussel / gaussel_periodic on p(1-nh:nx+nh,1-nh:ny+nh,1-nh:nz+nh), n unknowns per column (n = nz - q), with or without lambdaxy
+subroutine ref_gaussel(periodic,nx,ny,nz,n,nh,a,b,c,p,has_lam,lambdaxy) bind(C,name='ref_gaussel')
+  use, intrinsic :: iso_c_binding
+  use mod_solver_pure, only: gaussel,gaussel_periodic
+  implicit none
+  integer(c_int), intent(in), value :: periodic,nx,ny,nz,n,nh,has_lam
+  real(c_double), intent(in) :: a(nz),b(nz),c(nz)
+  real(c_double), intent(inout) :: p(1-nh:nx+nh,1-nh:ny+nh,1-nh:nz+nh)
+  real(c_double), intent(in) :: lambdaxy(nx,ny)
+  if(periodic /= 0) then
+    if(has_lam /= 0) then
+      call gaussel_periodic(nx,ny,n,nh,a,b,c,p,lambdaxy)
+    else
+      call gaussel_periodic(nx,ny,n,nh,a,b,c,p)
+    end if
+  else
+    if(has_lam /= 0) then
+      call gaussel(nx,ny,n,nh,a,b,c,p,lambdaxy)
+    else
+      call gaussel(nx,ny,n,nh,a,b,c,p)
+    end if
+  end if
+end subroutine ref_gaussel

@@ -143,5 +143,24 @@ class Ref:
         rd = lambda suffix, nv: np.fromfile(fname + suffix + ".bin").reshape((nv, n3), order="F")
         return rd("", 27), rd("_reystr_budget", 38), rd("_leakage", 6)
 
+    # ---- plain-arithmetic routines of initsolver.f90:66-169 and solver.f90:82-179
+    def eigenvalues(self, n, cbc2, c_or_f):
+        lam = np.zeros(int(n))
+        self.lib.ref_eigenvalues(C.c_int(int(n)), "".join(cbc2).encode(), c_or_f.encode(), _p(lam))
+        return lam
+
+    def tridmatrix(self, cbc2, n, dzi, dzci, dzfi, c_or_f):
+        a, b, c = (np.zeros(int(n)) for _ in range(3))
+        self.lib.ref_tridmatrix("".join(cbc2).encode(), C.c_int(int(n)), C.c_double(dzi), _p(np.ascontiguousarray(dzci)), _p(np.ascontiguousarray(dzfi)),
+                                c_or_f.encode(), _p(a), _p(b), _p(c))
+        return a, b, c
+
+    def gaussel(self, p, a, b, c, n, nh=0, lambdaxy=None, periodic=False):
+        """in place on p (Fortran order, halo nh); n = unknowns per column"""
+        nx, ny, nz = (s_ - 2 * nh for s_ in p.shape)
+        lam = lambdaxy if lambdaxy is not None else np.zeros((nx, ny), order="F")
+        self.lib.ref_gaussel(C.c_int(int(periodic)), C.c_int(nx), C.c_int(ny), C.c_int(nz), C.c_int(int(n)), C.c_int(nh), _p(a), _p(b), _p(c), _p(p),
+                             C.c_int(int(lambdaxy is not None)), _p(np.asfortranarray(lam)))
+
     def finalize(self):
         self.lib.ref_finalize()

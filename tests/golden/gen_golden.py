@@ -133,6 +133,18 @@ def run_case(name, out):
         return
 
     orc = Oracle(case)
+    # operands and z sweep of the Poisson solve by the reference's own eigenvalues / tridmatrix / gaussel (initsolver.f90:66-169,
+    # solver.f90:82-179; compiled from their lines, oracle/ref/Makefile)
+    gr_ = ref.grid(); dzci_ref, dzfi_ref = 1. / gr_["dzc"], 1. / gr_["dzf"]
+    cbp = par["cbcpre"]
+    lamx = ref.eigenvalues(ref.n[0], cbp[:, 0], "c"); lamy = ref.eigenvalues(ref.n[1], cbp[:, 1], "c")
+    sa, sb, sc = ref.tridmatrix(cbp[:, 2], ref.n[2], par["dli"][2], dzci_ref, dzfi_ref, "c")
+    G.update(sol_lamx=lamx, sol_lamy=lamy, sol_a=sa, sol_b=sb, sol_c=sc)
+    rngz = np.random.RandomState(2024)
+    pz = np.asfortranarray(rngz.rand(*ref.n) - 0.5); G["sol_gz_in"] = pz.copy()
+    lamxy = np.asfortranarray(lamx[:, None] * par["dli"][0] ** 2 + lamy[None, :] * par["dli"][1] ** 2)
+    ref.gaussel(pz, sa, sb, sc, ref.n[2], 0, lamxy, periodic=(cbp[0, 2] == "P" and cbp[1, 2] == "P"))
+    G["sol_gz_out"] = pz
     u, v, w, p = ref.initflow()
     G.update(if_u=u.copy(), if_v=v.copy(), if_w=w.copy(), if_p=p.copy())
     rng = np.random.RandomState(12345)
@@ -170,6 +182,17 @@ def run_case(name, out):
             for iv, q in ((1, u), (2, v), (3, w)):
                 ref.updt_rhs_b_velz(iv, alpha, q)
             G.update({K + "s1a_u": u.copy(), K + "s1a_v": v.copy(), K + "s1a_w": w.copy()})
+            # the same sweeps by the reference's own gaussel / tridmatrix (solver.f90:82-151,182-233 without the transposes; initsolver.f90:127-169,
+            # main.f90:435-445): solver_gaussel_z is a transposition around exactly this call
+            uvw_ref = []
+            for iv, q in ((1, u), (2, v), (3, w)):
+                cbz = par["cbcvel_after_initbc"][:, 2, iv - 1]; cf = "f" if iv == 3 else "c"
+                a_, b_, c_ = ref.tridmatrix(cbz, ref.n[2], par["dli"][2], dzci_ref, dzfi_ref, cf)
+                qq = 1 if (cf == "f" and cbz[1] == "D") else 0
+                pz = np.asfortranarray(q[1:-1, 1:-1, 1:-1].copy())
+                ref.gaussel(pz, a_ * alpha, b_ * alpha + 1., c_ * alpha, ref.n[2] - qq, 0, None, periodic=(cbz[0] == "P" and cbz[1] == "P"))
+                r_ = q.copy(); r_[1:-1, 1:-1, 1:-1] = pz; uvw_ref.append(r_)
+            G.update({K + "s1b_u": uvw_ref[0], K + "s1b_v": uvw_ref[1], K + "s1b_w": uvw_ref[2]})
             for iv, q in ((1, u), (2, v), (3, w)):
                 orc.solver_gaussel_z(iv, alpha, q)
             G.update({K + "s1b_u_orc": u.copy(), K + "s1b_v_orc": v.copy(), K + "s1b_w_orc": w.copy()})

@@ -185,3 +185,28 @@ def test_plane_statistics(name):
         assert got.shape == ref.shape, nm
         scale = np.maximum(np.abs(ref).max(axis=1, keepdims=True), 1e-300)
         assert (np.abs(got - ref) <= 1e-13 * scale).all(), (nm, np.abs(got - ref).max(axis=1) / scale[:, 0])      # measured: 4e-16, 3e-14, 1e-15
+
+
+@pytest.mark.parametrize("name", FULL_CASES)
+def test_solver_operands_and_z_sweep(name):
+    """eigenvalues, tridmatrix (initsolver.f90:66-169) and the tridiagonal sweep gaussel / gaussel_periodic / dgtsv_homebrewed with its
+    `+eps` pivots (solver.f90:82-179), by the reference's own routines (compiled from their lines by oracle/ref/Makefile): the restatement
+    reproduces the operands to round-off of the eigenvalue formula and the sweep bit for bit."""
+    g, case = load_golden(name)
+    o = Oracle(case)
+    lam, a, b, c, _ = o.solver_operands(0)
+    lam_ref = g["sol_lamx"][:, None] * case.dli[0] ** 2 + g["sol_lamy"][None, :] * case.dli[1] ** 2
+    assert np.abs(lam - lam_ref).max() <= 4e-16 * np.abs(lam_ref).max()
+    for x, k in ((a, "sol_a"), (b, "sol_b"), (c, "sol_c")):
+        assert np.array_equal(x, g[k]), k
+    pz = o.zeros(); pz[1:-1, 1:-1, 1:-1] = g["sol_gz_in"]
+    o.solver_zsweep(pz)
+    out = pz[1:-1, 1:-1, 1:-1]
+    if np.array_equal(lam, lam_ref):
+        assert np.array_equal(out, g["sol_gz_out"])
+    else:       # eigenvalues differing in the last bit move the singular/near-singular columns by that much
+        assert relerr(out, g["sol_gz_out"]) < 1e-10
+    if case.impdiff == 2:       # solver_gaussel_z == a transposition around gaussel: bit-identical to the reference's routine
+        for irk in (1, 2, 3):
+            for k in "uvw":
+                assert np.array_equal(g[f"r{irk}_s1b_{k}"], g[f"r{irk}_s1b_{k}_orc"]), (irk, k)
