@@ -8,7 +8,8 @@ from tests.test_gpu_decomp import _single, _case
 from cales_amd.decomp import run_loopback
 
 rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
-names = ["chan_dsmag", "chan_dsmag_wm", "chan_smag_wm", "tgv_dsmag_ppp", "cavity_nnn", "duct_smag_wm_imp1d", "couette_imp3d_ops", "cavity_imp3d", "devchan_nd", "halfchan_imp1d"]
+names = ["chan_dsmag", "chan_dsmag_wm", "chan_smag_wm", "tgv_dsmag_ppp", "cavity_nnn", "duct_smag_wm_imp1d", "couette_imp3d_ops", "cavity_imp3d", "devchan_nd", "halfchan_imp1d",
+         "duct_dsmag_wm", "duct_dsmag", "cavity_dsmag", "duct_smag_wm", "tgv_ppp", "chan_smag"]
 bad = 0
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 20):
     name = names[trial % len(names)]
@@ -18,6 +19,8 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 20):
         P = 2; ng = (ng[0], int(4 * rng.randint(3, 10)), ng[2])
     try:
         case = _case(name, ng)
+        if np.any(case.lwm != 0):      # a sampling height the reference accepts on this grid and slab (sanity.f90:224-231)
+            case.hwm = max(float(case.hwm), 1.6 * max(float(case.l[d]) / ng[d] for d in range(3) if case.lwm[:, d].any()))
         u, v, w, p, visct, dt, div, dpdl = _single(case, 2)
     except Exception as e:
         print(name, ng, P, "refused:", str(e)[:80]); continue

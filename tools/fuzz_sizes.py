@@ -7,13 +7,21 @@ from tests.util import load_golden, relerr
 from cales_amd.hotpath import HotPath, initflow
 from oracle.oracle import Oracle
 
+def case_lwm(name):
+    return load_golden(name)[1].lwm != 0
+
+
 rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
-names = ["chan_dsmag", "chan_dsmag_wm", "chan_smag_wm", "tgv_dsmag_ppp", "cavity_nnn", "duct_smag_wm_imp1d", "couette_imp3d_ops", "chan_smag"]
+names = ["chan_dsmag", "chan_dsmag_wm", "chan_smag_wm", "tgv_dsmag_ppp", "cavity_nnn", "duct_smag_wm_imp1d", "couette_imp3d_ops", "chan_smag",
+         "duct_dsmag_wm", "duct_dsmag", "cavity_dsmag", "duct_smag_wm", "tgv_ppp", "devchan_nd", "halfchan_imp1d"]
 bad = 0
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
     name = names[trial % len(names)]
-    ng = tuple(int(2 * rng.randint(2, 40)) for _ in range(2)) + (int(2 * rng.randint(5, 40)),)
+    ng = tuple(int(2 * rng.randint(2, 40)) for _ in range(2)) + (int(rng.randint(9, 80)),)      # ng(3) may be odd
+    if np.any(case_lwm(name)): ng = ng[:2] + (max(ng[2], 12),)
     g, case = load_golden(name); case.ng[:] = ng
+    if np.any(case.lwm != 0):      # a sampling height the reference accepts on this grid (sanity.f90:224-231)
+        case.hwm = max(float(case.hwm), 1.6 * max(float(case.l[d]) / ng[d] for d in range(3) if case.lwm[:, d].any()))
     if case.inivel == "hcp": case.inivel = "poi"
     try:
         h = HotPath(case)
