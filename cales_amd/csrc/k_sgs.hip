@@ -678,7 +678,7 @@ __global__ __launch_bounds__(256) void k_wall_shear_y(Geom g, const double *__re
     twy[(size_t)(g.n3 + 2 + k) * g.s1 + i] = sqrt(0.5 * visc * (sqrt(t1 * t1 + t2 * t2) * dyi));
   }
 }
-template <typename OFF, int SMAG, int TY>
+template <typename OFF, int SMAG, int TY, int YW>      // YW = 1: walls or wall-model faces in y (ducts); the channel instantiations carry none of that logic
 __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTileArgs A) {
   // (one barrier per plane with four ring slots and double-buffered sums, as in k_lij_mij_tile, measured 13 % slower here)
   __shared__ double ring[3][3][TY + 2][66];      // rows: x-halo cell, 64 own cells, x-halo cell
@@ -693,10 +693,10 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
   const OFF c0 = ldok ? (OFF)g.ix(i, j, 0) * 8 : 0, ch = hok ? (OFF)g.ix(ih, j, 0) * 8 : 0, sk = (OFF)g.s12 * 8;   // byte offsets
   double fn[3], fh[3];
   // ghost rows at wall-model y faces (SMAG pass of ducts): u and w are replaced by 2 Q(1) - Q(2) along y; v, normal to the face, is not
-  const int yex = (A.wmylo && j == 0) ? 1 : (A.wmyhi && j == g.n2 + 1) ? -1 : 0;
+  const int yex = !YW ? 0 : (A.wmylo && j == 0) ? 1 : (A.wmyhi && j == g.n2 + 1) ? -1 : 0;
   const OFF sjb = (OFF)g.s1 * 8;
   auto ld = [&](int q, OFF o) -> double {
-    if (yex != 0 && q != 1) return yex > 0 ? 2. * ldb(A.u[q], o + sjb) - ldb(A.u[q], o + 2 * sjb) : 2. * ldb(A.u[q], o - sjb) - ldb(A.u[q], o - 2 * sjb);
+    if (YW && yex != 0 && q != 1) return yex > 0 ? 2. * ldb(A.u[q], o + sjb) - ldb(A.u[q], o + 2 * sjb) : 2. * ldb(A.u[q], o - sjb) - ldb(A.u[q], o - 2 * sjb);
     return ldb(A.u[q], o);
   };
 #pragma unroll
@@ -787,10 +787,10 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
       const double s0v = sqrt(2. * (s11 * s11 + s22 * s22 + s33 * s33 + 2. * (s12 * s12 + s13 * s13 + s23 * s23)));
       if (SMAG) {
         double fd = 1.;
-        if (A.zlo || A.zhi || A.wylo || A.wyhi) {     // nearest wall in the order y-, y+, z-, z+: the first one wins a tie (minloc, sgs.f90:116)
+        if (A.zlo || A.zhi || (YW && (A.wylo || A.wyhi))) {     // nearest wall in the order y-, y+, z-, z+: the first one wins a tie (minloc, sgs.f90:116)
           const int jg = j + g.jlo;                  // distances to the y walls use global rows
-          double dmin = A.wylo ? A.dl2 * (jg - 0.5) : CALES_BIG, tw = 0.; int loc = 2;
-          { const double d = A.wyhi ? A.dl2 * (g.ng2 - jg + 0.5) : CALES_BIG; if (d < dmin) { dmin = d; loc = 3; } }
+          double dmin = YW && A.wylo ? A.dl2 * (jg - 0.5) : CALES_BIG, tw = 0.; int loc = 2;
+          { const double d = YW && A.wyhi ? A.dl2 * (g.ng2 - jg + 0.5) : CALES_BIG; if (d < dmin) { dmin = d; loc = 3; } }
           { const double d = A.zlo ? A.zc[k] : CALES_BIG; if (d < dmin) { dmin = d; loc = 4; } }
           { const double d = A.zhi ? A.l3 - A.zc[k] : CALES_BIG; if (d < dmin) { dmin = d; loc = 5; } }
           if (loc == 2) tw = A.twy[(size_t)k * g.s1 + i];
@@ -812,7 +812,7 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
     if (!SMAG && outok) {
       // next to a no-slip y wall the ghost row of u and w is the extrapolation 2 Q(1) - Q(2) (extrapolate(...,cbc), sgs.f90:705-710): its
       // y combination is 4 Q(1); v, normal to the wall, keeps its ghost row
-      const bool ylo = A.wylo && j == 1, yhi = A.wyhi && j == g.n2;
+      const bool ylo = YW && A.wylo && j == 1, yhi = YW && A.wyhi && j == g.n2;
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         const double dn = shs[q][ty - 1][tx], up = shs[q][ty + 1][tx];
@@ -882,7 +882,8 @@ static int dsmag_fast(cales_ctx *c) {
     S.uc[0] = c->uc; S.uc[1] = c->vc; S.uc[2] = c->wc; S.uf[0] = c->uf; S.uf[1] = c->vf; S.uf[2] = c->wf;
     S.dzci = c->d_dzci; S.dzfi = c->d_dzfi; S.dxi = c->dli[0]; S.dyi = c->dli[1]; S.kchunk = kch; S.zlo = zlo; S.zhi = zhi; S.wmlo = wmlo; S.wmhi = wmhi; S.flo = flo; S.fhi = fhi;
     S.wylo = wylo; S.wyhi = wyhi; S.wmylo = wmylo; S.wmyhi = wmyhi; S.twy = nullptr; S.dl2 = c->dl[1];
-    if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 0, TYS>), mg, mb, 0, c->stream, c->g, S); else hipLaunchKernelGGL((k_strain_tile<size_t, 0, TYS>), mg, mb, 0, c->stream, c->g, S); }
+    if (wylo || wyhi || wmylo || wmyhi) { if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 0, TYS, 1>), mg, mb, 0, c->stream, c->g, S); else hipLaunchKernelGGL((k_strain_tile<size_t, 0, TYS, 1>), mg, mb, 0, c->stream, c->g, S); }
+    else if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 0, TYS, 0>), mg, mb, 0, c->stream, c->g, S); else hipLaunchKernelGGL((k_strain_tile<size_t, 0, TYS, 0>), mg, mb, 0, c->stream, c->g, S); }
   // sgs-type ghost cells: only the periodic exchange matters (products of ghosts = ghosts of products; the wall ghosts are
   // replaced by the extrapolation rule inside the filters)
   // These twelve scratch fields are read by the tile kernels only: with periodic x their ghost columns are not filled (the
@@ -1004,8 +1005,11 @@ static int smag_fast(cales_ctx *c) {
     S.twy = twy;
   }
   const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32) && !c->fl.wide_offsets;
-#define SMAG_LAUNCH(TYV) do { if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 1, TYV>), mg, mb, 0, c->stream, c->g, S); \
-                              else hipLaunchKernelGGL((k_strain_tile<size_t, 1, TYV>), mg, mb, 0, c->stream, c->g, S); } while (0)
+  const bool yw = S.wylo || S.wyhi || S.wmylo || S.wmyhi;
+#define SMAG_LAUNCH(TYV) do { if (yw) { if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 1, TYV, 1>), mg, mb, 0, c->stream, c->g, S); \
+                                         else hipLaunchKernelGGL((k_strain_tile<size_t, 1, TYV, 1>), mg, mb, 0, c->stream, c->g, S); } \
+                              else if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 1, TYV, 0>), mg, mb, 0, c->stream, c->g, S); \
+                              else hipLaunchKernelGGL((k_strain_tile<size_t, 1, TYV, 0>), mg, mb, 0, c->stream, c->g, S); } while (0)
   if (TYM == 6) SMAG_LAUNCH(6); else if (TYM == 10) SMAG_LAUNCH(10); else SMAG_LAUNCH(14);
 #undef SMAG_LAUNCH
   HIPCHK(c, hipGetLastError());
