@@ -380,7 +380,6 @@ __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijA
   const int kbeg = blockIdx.z * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
   const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1;
   const bool outok = tx >= 1 && tx <= 62 && ty >= 1 && ty <= TYF && i <= g.n1 && j <= g.n2;
-  const bool inner = ty >= 1 && ty <= TYF;
   const int iw = A.perx ? (i == 0 ? g.n1 : (i == g.n1 + 1 ? 1 : i)) : i;
   const OFF c0 = ldok ? (OFF)g.ix(iw, j, 0) * 8 : 0, sk = (OFF)g.s12 * 8;      // byte offsets
   double sm[3], sc[3], sp[3], sn[3], fn[3];
