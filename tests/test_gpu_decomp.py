@@ -43,6 +43,10 @@ def _single(case, nsteps):
                                        # dynamic model with walls in y/z and in x/y/z (kernel-per-loop sequence, slab halos of its scratch fields)
                                        ("duct_dsmag_wm", (16, 24, 20), 2), ("duct_dsmag", (16, 24, 12), 3), ("cavity_dsmag", (16, 24, 12), 2),
                                        ("couette_imp3d_ops", (32, 24, 16), 2), ("chan_dsmag", (128, 32, 136), 2),
+                                       # power-of-two lines in x and y: the radix-8 transforms, hence the k-chunked exchange beside them (NCH = 4 / 2), with the
+                                       # bulk means fused into the forward pass or not (wall model), Neumann-Neumann kinds, periodic z, a duct with the dynamic model
+                                       ("chan_dsmag_wm", (64, 32, 32), 4), ("cavity_nnn", (64, 32, 32), 2), ("tgv_ppp", (32, 32, 16), 2), ("duct_dsmag_wm", (32, 32, 32), 2),
+                                       ("chan_smag", (128, 64, 64), 8),
                                        # 3-D implicit diffusion with no-slip walls in x and y (wall-normal DST-I in the slab and in the mode-block layout)
                                        ("cavity_imp3d", (32, 24, 12), 2), ("cavity_imp3d", (20, 36, 10), 4)])
 def test_slab_ranks_match_single_rank(name, ng, P):
