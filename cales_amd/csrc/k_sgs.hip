@@ -484,7 +484,9 @@ __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijA
 // not by LDS or HBM, and LDS has no room for six more double-buffered filter sums, so the y combination of |S|Sij uses neither:
 // every output row loads its own row and the two rows beside it (the neighbours' rows are L1/L2 hits: the same block loads them in
 // the same iteration) and combines them in registers; x by DPP, z from two rolling x/y-combined planes. Tiles of 62 x TYL outputs
-// with TYL = 6: 8 waves per block, two per SIMD, which leaves 256 VGPRs for the 18 more loads in flight.
+// with TYL = 8: ten waves per block need <= 168 VGPRs, which holds (without spills in the plane loop) because the 18 loads are issued
+// after the register-hungry strain-rate part and folded into six values right after the next barrier; 62 x 6 tiles with eight waves
+// measured 4.47 ms against 4.09, variants that spill in the loop 13 ms (profiles/r02d_sq.md: VALU 0.44, waves waiting 0.50).
 #ifndef TYL
 #define TYL 8
 #endif
