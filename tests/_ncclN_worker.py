@@ -14,7 +14,7 @@ from cales_amd.decomp import SlabHotPath
 from cales_amd.hotpath import HotPath, initflow
 from tests.util import load_golden
 
-local = int(os.environ.get("LOCAL_RANK", "0"))
+local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)      # (two ranks on one device are refused by RCCL: "Duplicate GPU detected", tried on the one-GPU box)
 torch.cuda.set_device(local)
 dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 P, r = dist.get_world_size(), dist.get_rank()
