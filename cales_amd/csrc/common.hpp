@@ -55,7 +55,7 @@ struct Spec {
 
 // Run-time switches: read from the environment ONCE, by cales_create; the launch path only looks at these fields.
 struct Flags {
-  bool unaligned = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_eager = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, gaussel_pair = false, unfused_rk = false, dsmag_unfused_filter = false, no_overlap = false, unmerged_bc = false;
+  bool unaligned = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_eager = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, gaussel_pair = false, unfused_rk = false, dsmag_unfused_filter = false, no_overlap = false, unmerged_bc = false, smag_tile = false;
   int kchunk = 0; long tile_min_blocks = 2048; int smag_ty = 10;
   void read_env() {
     unaligned = getenv("CALES_UNALIGNED") != nullptr;
@@ -71,6 +71,7 @@ struct Flags {
     dsmag_eager = getenv("CALES_DSMAG_EAGER") != nullptr;
     dsmag_xghosts = getenv("CALES_DSMAG_XGHOSTS") != nullptr;
     smag_reference_sequence = getenv("CALES_SMAG_REFERENCE_SEQUENCE") != nullptr;
+    smag_tile = getenv("CALES_SMAG_TILE") != nullptr;
     gaussel_march = getenv("CALES_GAUSSEL_MARCH") != nullptr;
     fft_generic = getenv("CALES_FFT_GENERIC") != nullptr;
     keep_null_mode = getenv("CALES_KEEP_NULL_MODE") != nullptr;

@@ -660,6 +660,7 @@ struct StrainTileArgs {
   // twy(side, k, i) = sqrt(tau_w) of k_wall_shear_y); wmylo/wmyhi = wall-model y faces: the strain rate sees ghost rows of u and w
   // extrapolated from the interior (extrapolate(...,lwm) along y, sgs.f90:683-748)
   int wylo, wyhi, wmylo, wmyhi; const double *twy; double dl2;
+  int gx, gy, gz, sub;      // k_smag_rows: its own block -> (x tile, row group, k chunk) map
 };
 // sqrt(tau_w) at the two y walls for every (i, k): the argument of the van Driest damping of the cells whose nearest wall is a y wall
 // (sgs.f90:117-143, cases 3 and 4 of the select), from the fields themselves (their ghost cells, not the extrapolated ones)
@@ -822,6 +823,109 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
       }
     }
     const int t = km; km = kc; kc = kp; kp = t;
+  }
+}
+// Static Smagorinsky, row-marching form (default): one wave per row of 62 cells marching in k with everything in registers -- x neighbours by
+// DPP lane moves, the rows j-1 and j+1 loaded again by this wave (they are their own waves' rows: cache hits), z neighbours rolled from plane
+// to plane. No LDS and no barriers: the tile form above is bound by its barrier pair per plane with two square roots and an exponential per
+// cell in between (0.26 of the HBM peak); here waves never wait for each other and the VGPR count alone sets the occupancy.
+// Same arithmetic, in the same order, as k_strain_tile<SMAG = 1> (sgs.f90:98-152, 598-680).
+constexpr int SROWS = 4;      // rows (waves) per block
+template <typename OFF, int YW>
+__global__ __launch_bounds__(64 * SROWS) void k_smag_rows(Geom g, StrainTileArgs A) {
+  const int tx = threadIdx.x;
+  // consecutive blocks go to the eight XCDs in turn: each XCD takes bands of `sub` row groups with all their x tiles and k chunks, so
+  // that the rows two waves both load (j-1, j+1, the shared columns of neighbouring x tiles) meet in one L2 instead of being fetched
+  // from memory by two (measured 1.8 x the compulsory reads with the plain 3-D grid)
+  int bx, by, bz;
+  { unsigned s = blockIdx.x >> 3; const unsigned xcd = blockIdx.x & 7u;
+    bx = s % A.gx; s /= A.gx; const unsigned sb = s % A.sub; s /= A.sub; bz = s % A.gz; s /= A.gz;
+    by = (s * 8 + xcd) * A.sub + sb; }
+  if (by >= A.gy) return;
+  const int i = bx * 62 + tx, j = by * SROWS + threadIdx.y + 1;
+  if (j > g.n2) return;
+  const int kbeg = bz * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
+  const bool ldok = i <= g.n1 + 1, outok = tx >= 1 && tx <= 62 && i <= g.n1;
+  const OFF sj = (OFF)g.s1 * 8, sk = (OFF)g.s12 * 8;
+  const OFF c0 = ldok ? (OFF)g.ix(i, j, 0) * 8 : (OFF)g.ix(0, j, 0) * 8;
+  // ghost rows at wall-model y faces: u and w are replaced by 2 Q(1) - Q(2) along y; v, normal to the face, is not (extrapolate(...,lwm), sgs.f90:683-748)
+  const bool exlo = YW && A.wmylo && j == 1, exhi = YW && A.wmyhi && j == g.n2;
+  // (lanes beyond the row read cell 0 of the field and planes beyond n3+1 are clamped: every load is unconditional, nothing branches around it)
+  auto ldu = [&](int q, int dj, int k) -> double {      // q = 0 (u) or 2 (w), dj = -1, 0, +1
+    const OFF o = c0 + (OFF)k * sk;
+    if (YW && dj < 0 && exlo) return 2. * ldb(A.u[q], o) - ldb(A.u[q], o + sj);
+    if (YW && dj > 0 && exhi) return 2. * ldb(A.u[q], o) - ldb(A.u[q], o - sj);
+    return ldb(A.u[q], dj < 0 ? o - sj : dj > 0 ? o + sj : o);
+  };
+  auto ldv = [&](int dj, int k) -> double { return ldb(A.u[1], c0 + (OFF)k * sk - (dj < 0 ? sj : 0)); };
+  // planes k-1, k, k+1 of u(j), v(j-1), v(j); plane k of u(j-1), u(j+1); planes k-1, k of w(j-1), w(j), w(j+1)
+  double u0m = ldu(0, 0, kbeg - 1), u0c = ldu(0, 0, kbeg), u0p = ldu(0, 0, kbeg + 1);
+  double vAm = ldv(-1, kbeg - 1), vAc = ldv(-1, kbeg), vAp = ldv(-1, kbeg + 1);
+  double vCm = ldv(0, kbeg - 1), vCc = ldv(0, kbeg), vCp = ldv(0, kbeg + 1);
+  double uA = ldu(0, -1, kbeg), uB = ldu(0, 1, kbeg);
+  double wAm = ldu(2, -1, kbeg - 1), wCm = ldu(2, 0, kbeg - 1), wBm = ldu(2, 1, kbeg - 1);
+  double wAc = ldu(2, -1, kbeg), wCc = ldu(2, 0, kbeg), wBc = ldu(2, 1, kbeg);
+  // van Driest: wall units from the shear at the nearer z wall of this column (sgs.f90:117-143), read from the fields themselves
+  // (their ghost cells, not the extrapolated ones)
+  double tw_lo = 0., tw_hi = 0.;
+  if (outok) {
+    const double *u = A.u[0], *v = A.u[1];
+    if (A.zlo) {
+      const double t1 = u[g.ix(i, j, 1)] - u[g.ix(i, j, 0)] + u[g.ix(i - 1, j, 1)] - u[g.ix(i - 1, j, 0)];
+      const double t2 = v[g.ix(i, j, 1)] - v[g.ix(i, j, 0)] + v[g.ix(i, j - 1, 1)] - v[g.ix(i, j - 1, 0)];
+      tw_lo = sqrt(0.5 * A.visc * (sqrt(t1 * t1 + t2 * t2) * A.dzci[0]));
+    }
+    if (A.zhi) {
+      const int n3 = g.n3;
+      const double t1 = u[g.ix(i, j, n3)] - u[g.ix(i, j, n3 + 1)] + u[g.ix(i - 1, j, n3)] - u[g.ix(i - 1, j, n3 + 1)];
+      const double t2 = v[g.ix(i, j, n3)] - v[g.ix(i, j, n3 + 1)] + v[g.ix(i, j - 1, n3)] - v[g.ix(i, j - 1, n3 + 1)];
+      tw_hi = sqrt(0.5 * A.visc * (sqrt(t1 * t1 + t2 * t2) * A.dzci[n3]));
+    }
+  }
+  const double dxi = A.dxi, dyi = A.dyi;
+  for (int k = kbeg; k <= kend; ++k) {
+    // next iteration's planes, in flight during this one's arithmetic
+    const int k2 = min(k + 2, g.n3 + 1), k1 = k + 1;
+    const double u0n = ldu(0, 0, k2), vAn = ldv(-1, k2), vCn = ldv(0, k2);
+    const double uAn = ldu(0, -1, k1), uBn = ldu(0, 1, k1);
+    const double wAn = ldu(2, -1, k1), wCn = ldu(2, 0, k1), wBn = ldu(2, 1, k1);
+    // wall-model z faces: ghost planes of u, v by extrapolation with the grid factor
+    double u_ccm = u0m, v_cmm = vAm, v_ccm = vCm, u_ccp = u0p, v_cmp = vAp, v_ccp = vCp;
+    if (A.wmlo && k == 1) { u_ccm = (1. + A.flo) * u0c - A.flo * u0p; v_cmm = (1. + A.flo) * vAc - A.flo * vAp; v_ccm = (1. + A.flo) * vCc - A.flo * vCp; }
+    if (A.wmhi && k == g.n3) { u_ccp = (1. + A.fhi) * u0c - A.fhi * u0m; v_cmp = (1. + A.fhi) * vAc - A.fhi * vAm; v_ccp = (1. + A.fhi) * vCc - A.fhi * vCm; }
+    const double u_ccc = u0c, u_cmc = uA, u_cpc = uB, v_cmc = vAc, v_ccc = vCc;
+    const double w_cmm = wAm, w_ccm = wCm, w_cpm = wBm, w_cmc = wAc, w_ccc = wCc, w_cpc = wBc;
+    const double u_mcm = lane_prev(u_ccm), u_mcc = lane_prev(u_ccc), u_mcp = lane_prev(u_ccp), u_mmc = lane_prev(u_cmc), u_mpc = lane_prev(u_cpc);
+    const double v_mmc = lane_prev(v_cmc), v_pmc = lane_next(v_cmc), v_mcc = lane_prev(v_ccc), v_pcc = lane_next(v_ccc);
+    const double w_mcm = lane_prev(w_ccm), w_pcm = lane_next(w_ccm), w_mcc = lane_prev(w_ccc), w_pcc = lane_next(w_ccc);
+    const double zc = A.dzci[k], zm = A.dzci[k - 1];
+    const double s11 = (u_ccc - u_mcc) * dxi, s22 = (v_ccc - v_cmc) * dyi, s33 = (w_ccc - w_ccm) * A.dzfi[k];
+    const double s12 = .125 * ((u_cpc - u_ccc) * dyi + (v_pcc - v_ccc) * dxi + (u_ccc - u_cmc) * dyi + (v_pmc - v_cmc) * dxi +
+                               (u_mpc - u_mcc) * dyi + (v_ccc - v_mcc) * dxi + (u_mcc - u_mmc) * dyi + (v_cmc - v_mmc) * dxi);
+    const double s13 = .125 * ((u_ccp - u_ccc) * zc + (w_pcc - w_ccc) * dxi + (u_ccc - u_ccm) * zm + (w_pcm - w_ccm) * dxi +
+                               (u_mcp - u_mcc) * zc + (w_ccc - w_mcc) * dxi + (u_mcc - u_mcm) * zm + (w_ccm - w_mcm) * dxi);
+    const double s23 = .125 * ((v_ccp - v_ccc) * zc + (w_cpc - w_ccc) * dyi + (v_ccc - v_ccm) * zm + (w_cpm - w_ccm) * dyi +
+                               (v_cmp - v_cmc) * zc + (w_ccc - w_cmc) * dyi + (v_cmc - v_cmm) * zm + (w_ccm - w_cmm) * dyi);
+    const double s0v = sqrt(2. * (s11 * s11 + s22 * s22 + s33 * s33 + 2. * (s12 * s12 + s13 * s13 + s23 * s23)));
+    if (outok) {
+      double fd = 1.;
+      if (A.zlo || A.zhi || (YW && (A.wylo || A.wyhi))) {     // nearest wall in the order y-, y+, z-, z+: the first one wins a tie (minloc, sgs.f90:116)
+        const int jg = j + g.jlo;
+        double dmin = YW && A.wylo ? A.dl2 * (jg - 0.5) : CALES_BIG, tw = 0.; int loc = 2;
+        { const double d = YW && A.wyhi ? A.dl2 * (g.ng2 - jg + 0.5) : CALES_BIG; if (d < dmin) { dmin = d; loc = 3; } }
+        { const double d = A.zlo ? A.zc[k] : CALES_BIG; if (d < dmin) { dmin = d; loc = 4; } }
+        { const double d = A.zhi ? A.l3 - A.zc[k] : CALES_BIG; if (d < dmin) { dmin = d; loc = 5; } }
+        if (YW && loc == 2) tw = A.twy[(size_t)k * g.s1 + i];
+        else if (YW && loc == 3) tw = A.twy[(size_t)(g.n3 + 2 + k) * g.s1 + i];
+        else tw = loc == 4 ? tw_lo : tw_hi;
+        const double dw_plus = dmin * tw * (1. / A.visc);
+        fd = 1. - exp(-dw_plus / 25.);
+      }
+      const double t = 0.11 * A.del[k] * fd;      // c_smag, src/param.f90:33
+      stb(A.visct, c0 + (OFF)k * sk, (t * t) * s0v);
+    }
+    u0m = u0c; u0c = u0p; u0p = u0n; vAm = vAc; vAc = vAp; vAp = vAn; vCm = vCc; vCc = vCp; vCp = vCn;
+    uA = uAn; uB = uBn; wAm = wAc; wCm = wCc; wBm = wBc; wAc = wAn; wCc = wCn; wBc = wBn;
   }
 }
 // p1d[which*n3 + k-1] = sum over the blocks' partials, fixed order (ave1d_channel, sgs.f90:462-472)
@@ -1007,6 +1111,24 @@ static int smag_fast(cales_ctx *c) {
   }
   const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32) && !c->fl.wide_offsets;
   const bool yw = S.wylo || S.wyhi || S.wmylo || S.wmyhi;
+  if (!c->fl.smag_tile) {
+    // row-marching form: one wave per row of 62 cells; chunks of k so that every CU holds several blocks' worth of independent waves
+    const dim3 rb(64, SROWS, 1);
+    S.gx = (n[0] + 61) / 62; S.gy = (n[1] + SROWS - 1) / SROWS;
+    int kr = n[2];
+    // sixteen waves per CU at a time: enough blocks for eight rounds or more, or the last round's idle CUs show (chunks pay a three-plane prologue)
+    while ((long)S.gx * S.gy * ((n[2] + kr - 1) / kr) < 8192 && kr > 32) kr = (kr + 1) / 2;
+    while ((long)S.gx * S.gy * ((n[2] + kr - 1) / kr) < 1024 && kr > 8) kr = (kr + 1) / 2;
+    if (int fk = tile_kchunk(c, (long)S.gx * S.gy, n[2])) kr = fk;
+    S.gz = (n[2] + kr - 1) / kr; S.kchunk = kr;
+    S.sub = std::min(8, (S.gy + 7) / 8);
+    const int ngrp = (S.gy + 8 * S.sub - 1) / (8 * S.sub);
+    const dim3 rg(8u * S.gx * S.sub * S.gz * ngrp, 1, 1);
+    if (yw) { if (small) hipLaunchKernelGGL((k_smag_rows<unsigned, 1>), rg, rb, 0, c->stream, c->g, S); else hipLaunchKernelGGL((k_smag_rows<size_t, 1>), rg, rb, 0, c->stream, c->g, S); }
+    else if (small) hipLaunchKernelGGL((k_smag_rows<unsigned, 0>), rg, rb, 0, c->stream, c->g, S); else hipLaunchKernelGGL((k_smag_rows<size_t, 0>), rg, rb, 0, c->stream, c->g, S);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
 #define SMAG_LAUNCH(TYV) do { if (yw) { if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 1, TYV, 1>), mg, mb, 0, c->stream, c->g, S); \
                                          else hipLaunchKernelGGL((k_strain_tile<size_t, 1, TYV, 1>), mg, mb, 0, c->stream, c->g, S); } \
                               else if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 1, TYV, 0>), mg, mb, 0, c->stream, c->g, S); \

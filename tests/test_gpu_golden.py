@@ -171,6 +171,13 @@ def test_smag_reference_sequence(name, monkeypatch):
     test_startup_and_substeps(name, general_sgs=True)
 
 
+@pytest.mark.parametrize("name", ["chan_smag", "chan_smag_wm", "duct_smag_wm", "duct_smag_wm_imp1d"])
+def test_smag_tile_form(name, monkeypatch):
+    """Static Smagorinsky through the LDS tile kernel (CALES_SMAG_TILE) instead of the default row-marching kernel: same planes at 1e-13."""
+    monkeypatch.setenv("CALES_SMAG_TILE", "1")
+    test_startup_and_substeps(name)
+
+
 @pytest.mark.parametrize("name", ["chan_dsmag", "chan_dsmag_wm", "tgv_dsmag_ppp", "duct_dsmag_wm", "duct_dsmag"])
 def test_dsmag_reference_sequence(name, monkeypatch):
     """Dynamic Smagorinsky through the kernel-per-loop sequence of sgs.f90:153-380, operator by operator at 1e-13."""
