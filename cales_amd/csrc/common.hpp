@@ -242,6 +242,12 @@ void solver_teardown(cales_ctx *c);
 // ---- global accesses as base pointer (kernel argument, scalar registers) + BYTE offset. With OFF = unsigned the compiler
 // emits the saddr + 32-bit voffset form: one VGPR per access stream instead of a 64-bit address per field (tile kernels
 // stream up to 17 fields). Hosts pick OFF = unsigned when a field is smaller than 4 GB, size_t otherwise.
+// element k of a small read-only coefficient array (grid spacings, zc, ...) through the scalar cache: the constant address space makes the
+// load an s_load (lgkmcnt) whatever stores the kernel makes, so waiting for it never drains the vector loads in flight (a global_load of the
+// same value costs an s_waitcnt vmcnt(0) in the middle of a prefetch)
+// (in the LDS-heavy last dsmag pass the same change measured 7 % slower -- scalar loads share lgkmcnt with the LDS reads and return
+// out of order, so waiting for one drains the LDS queue -- and that kernel keeps its vector loads)
+__device__ inline double ldc(const double *p, int k) { return ((const __attribute__((address_space(4))) double *)p)[k]; }
 template <typename OFF> __device__ inline double ldb(const double *b, OFF o) { return *(const double *)((const char *)b + o); }
 template <typename OFF> __device__ inline void stb(double *b, OFF o, double v) { *(double *)((char *)b + o) = v; }
 

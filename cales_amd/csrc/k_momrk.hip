@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64 * (TYM + 2), (TYM <= 6 ? 4 : 3)) void k_momrk(Ge
   if (hok) { const double *fp = hf_ == 0 ? A.u : hf_ == 1 ? A.v : hf_ == 2 ? A.w : hf_ == 3 ? A.s : A.p; hp = fp + g.ix(hi_, hj, 0); }
   const size_t sk64 = (size_t)g.s12;
   auto ld5 = [&](int k, double *q, double &h) {
-    const double csk = (!NOS && A.cs && k <= g.n3 + 1) ? A.cs[k] : 1.;
+    const double csk = (!NOS && A.cs && k <= g.n3 + 1) ? ldc(A.cs, k) : 1.;
     if (ldok && k <= g.n3 + 1) { const OFF c = c0 + (OFF)k * sk; q[0] = ldb(A.u, c); q[1] = ldb(A.v, c); q[2] = ldb(A.w, c); q[3] = NOS ? 0. : ldb(A.s, c) * csk; q[4] = ldb(A.p, c); }
     else { q[0] = q[1] = q[2] = q[3] = q[4] = 0.; }
     h = (hok && k <= g.n3 + 1) ? hp[(size_t)k * sk64] : 0.;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64 * (TYM + 2), (TYM <= 6 ? 4 : 3)) void k_momrk(Ge
       const int pc = k % 3, pn = (k + 1) % 3;
       const double p_ccc = shp[pc][ty][tx + 1], p_pcc = shp[pc][ty][tx + 2], p_cpc = shp[pc][ty + 1][tx + 1], p_ccp = shp[pn][ty][tx + 1];
       const double dxi = A.dxi, dyi = A.dyi, visc = A.visc;
-      const double dzci_k = A.dzci[k], dzci_m = A.dzci[k - 1], dzfi_k = A.dzfi[k], dzfi_p = A.dzfi[k + 1];
+      const double dzci_k = ldc(A.dzci, k), dzci_m = ldc(A.dzci, k - 1), dzfi_k = ldc(A.dzfi, k), dzfi_p = ldc(A.dzfi, k + 1);
       double visc_ip, visc_im, visc_jp, visc_jm, visc_kp, visc_km;
       // ---- x momentum (mom.f90:143-186)
       visc_ip = s_pcc; visc_im = s_ccc;

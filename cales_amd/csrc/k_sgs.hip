@@ -778,8 +778,8 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
 #undef RU
 #undef RV
 #undef RW
-      const double dxi = A.dxi, dyi = A.dyi, zc = A.dzci[k], zm = A.dzci[k - 1];
-      const double s11 = (u_ccc - u_mcc) * dxi, s22 = (v_ccc - v_cmc) * dyi, s33 = (w_ccc - w_ccm) * A.dzfi[k];
+      const double dxi = A.dxi, dyi = A.dyi, zc = ldc(A.dzci, k), zm = ldc(A.dzci, k - 1);
+      const double s11 = (u_ccc - u_mcc) * dxi, s22 = (v_ccc - v_cmc) * dyi, s33 = (w_ccc - w_ccm) * ldc(A.dzfi, k);
       const double s12 = .125 * ((u_cpc - u_ccc) * dyi + (v_pcc - v_ccc) * dxi + (u_ccc - u_cmc) * dyi + (v_pmc - v_cmc) * dxi +
                                  (u_mpc - u_mcc) * dyi + (v_ccc - v_mcc) * dxi + (u_mcc - u_mmc) * dyi + (v_cmc - v_mmc) * dxi);
       const double s13 = .125 * ((u_ccp - u_ccc) * zc + (w_pcc - w_ccc) * dxi + (u_ccc - u_ccm) * zm + (w_pcm - w_ccm) * dxi +
@@ -793,15 +793,15 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
           const int jg = j + g.jlo;                  // distances to the y walls use global rows
           double dmin = YW && A.wylo ? A.dl2 * (jg - 0.5) : CALES_BIG, tw = 0.; int loc = 2;
           { const double d = YW && A.wyhi ? A.dl2 * (g.ng2 - jg + 0.5) : CALES_BIG; if (d < dmin) { dmin = d; loc = 3; } }
-          { const double d = A.zlo ? A.zc[k] : CALES_BIG; if (d < dmin) { dmin = d; loc = 4; } }
-          { const double d = A.zhi ? A.l3 - A.zc[k] : CALES_BIG; if (d < dmin) { dmin = d; loc = 5; } }
+          { const double d = A.zlo ? ldc(A.zc, k) : CALES_BIG; if (d < dmin) { dmin = d; loc = 4; } }
+          { const double d = A.zhi ? A.l3 - ldc(A.zc, k) : CALES_BIG; if (d < dmin) { dmin = d; loc = 5; } }
           if (loc == 2) tw = A.twy[(size_t)k * g.s1 + i];
           else if (loc == 3) tw = A.twy[(size_t)(g.n3 + 2 + k) * g.s1 + i];
           else tw = loc == 4 ? tw_lo : tw_hi;
           const double dw_plus = dmin * tw * (1. / A.visc);
           fd = 1. - exp(-dw_plus / 25.);
         }
-        const double t = 0.11 * A.del[k] * fd;      // c_smag, src/param.f90:33
+        const double t = 0.11 * ldc(A.del, k) * fd;      // c_smag, src/param.f90:33
         stb(A.visct, idx, (t * t) * s0v);
       } else {
         stb(A.s0, idx, s0v);                                              // stands for visct = s0 (sgs.f90:184) until the final kernel
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
 // Same arithmetic, in the same order, as k_strain_tile<SMAG = 1> (sgs.f90:98-152, 598-680).
 constexpr int SROWS = 4;      // rows (waves) per block
 template <typename OFF, int YW>
-__global__ __launch_bounds__(64 * SROWS) void k_smag_rows(Geom g, StrainTileArgs A) {
+__global__ __launch_bounds__(64 * SROWS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_smag_rows(Geom g, StrainTileArgs A) {
   const int tx = threadIdx.x;
   // consecutive blocks go to the eight XCDs in turn: each XCD takes bands of `sub` row groups with all their x tiles and k chunks, so
   // that the rows two waves both load (j-1, j+1, the shared columns of neighbouring x tiles) meet in one L2 instead of being fetched
@@ -898,8 +898,8 @@ __global__ __launch_bounds__(64 * SROWS) void k_smag_rows(Geom g, StrainTileArgs
     const double u_mcm = lane_prev(u_ccm), u_mcc = lane_prev(u_ccc), u_mcp = lane_prev(u_ccp), u_mmc = lane_prev(u_cmc), u_mpc = lane_prev(u_cpc);
     const double v_mmc = lane_prev(v_cmc), v_pmc = lane_next(v_cmc), v_mcc = lane_prev(v_ccc), v_pcc = lane_next(v_ccc);
     const double w_mcm = lane_prev(w_ccm), w_pcm = lane_next(w_ccm), w_mcc = lane_prev(w_ccc), w_pcc = lane_next(w_ccc);
-    const double zc = A.dzci[k], zm = A.dzci[k - 1];
-    const double s11 = (u_ccc - u_mcc) * dxi, s22 = (v_ccc - v_cmc) * dyi, s33 = (w_ccc - w_ccm) * A.dzfi[k];
+    const double zc = ldc(A.dzci, k), zm = ldc(A.dzci, k - 1);
+    const double s11 = (u_ccc - u_mcc) * dxi, s22 = (v_ccc - v_cmc) * dyi, s33 = (w_ccc - w_ccm) * ldc(A.dzfi, k);
     const double s12 = .125 * ((u_cpc - u_ccc) * dyi + (v_pcc - v_ccc) * dxi + (u_ccc - u_cmc) * dyi + (v_pmc - v_cmc) * dxi +
                                (u_mpc - u_mcc) * dyi + (v_ccc - v_mcc) * dxi + (u_mcc - u_mmc) * dyi + (v_cmc - v_mmc) * dxi);
     const double s13 = .125 * ((u_ccp - u_ccc) * zc + (w_pcc - w_ccc) * dxi + (u_ccc - u_ccm) * zm + (w_pcm - w_ccm) * dxi +
@@ -913,15 +913,15 @@ __global__ __launch_bounds__(64 * SROWS) void k_smag_rows(Geom g, StrainTileArgs
         const int jg = j + g.jlo;
         double dmin = YW && A.wylo ? A.dl2 * (jg - 0.5) : CALES_BIG, tw = 0.; int loc = 2;
         { const double d = YW && A.wyhi ? A.dl2 * (g.ng2 - jg + 0.5) : CALES_BIG; if (d < dmin) { dmin = d; loc = 3; } }
-        { const double d = A.zlo ? A.zc[k] : CALES_BIG; if (d < dmin) { dmin = d; loc = 4; } }
-        { const double d = A.zhi ? A.l3 - A.zc[k] : CALES_BIG; if (d < dmin) { dmin = d; loc = 5; } }
+        { const double d = A.zlo ? ldc(A.zc, k) : CALES_BIG; if (d < dmin) { dmin = d; loc = 4; } }
+        { const double d = A.zhi ? A.l3 - ldc(A.zc, k) : CALES_BIG; if (d < dmin) { dmin = d; loc = 5; } }
         if (YW && loc == 2) tw = A.twy[(size_t)k * g.s1 + i];
         else if (YW && loc == 3) tw = A.twy[(size_t)(g.n3 + 2 + k) * g.s1 + i];
         else tw = loc == 4 ? tw_lo : tw_hi;
         const double dw_plus = dmin * tw * (1. / A.visc);
         fd = 1. - exp(-dw_plus / 25.);
       }
-      const double t = 0.11 * A.del[k] * fd;      // c_smag, src/param.f90:33
+      const double t = 0.11 * ldc(A.del, k) * fd;      // c_smag, src/param.f90:33
       stb(A.visct, c0 + (OFF)k * sk, (t * t) * s0v);
     }
     u0m = u0c; u0c = u0p; u0p = u0n; vAm = vAc; vAc = vAp; vAp = vAn; vCm = vCc; vCc = vCp; vCp = vCn;
