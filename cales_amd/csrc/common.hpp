@@ -55,7 +55,7 @@ struct Spec {
 
 // Run-time switches: read from the environment ONCE, by cales_create; the launch path only looks at these fields.
 struct Flags {
-  bool unaligned = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_eager = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, gaussel_pair = false, unfused_rk = false, dsmag_unfused_filter = false, no_overlap = false, unmerged_bc = false, smag_tile = false;
+  bool unaligned = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_eager = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, gaussel_pair = false, unfused_rk = false, dsmag_unfused_filter = false, no_overlap = false, unmerged_bc = false, smag_tile = false, plain_grid = false, band_grid = false;
   int kchunk = 0; long tile_min_blocks = 2048; int smag_ty = 10;
   void read_env() {
     unaligned = getenv("CALES_UNALIGNED") != nullptr;
@@ -72,6 +72,8 @@ struct Flags {
     dsmag_xghosts = getenv("CALES_DSMAG_XGHOSTS") != nullptr;
     smag_reference_sequence = getenv("CALES_SMAG_REFERENCE_SEQUENCE") != nullptr;
     smag_tile = getenv("CALES_SMAG_TILE") != nullptr;
+    plain_grid = getenv("CALES_PLAIN_GRID") != nullptr;
+    band_grid = getenv("CALES_BAND_GRID") != nullptr;
     gaussel_march = getenv("CALES_GAUSSEL_MARCH") != nullptr;
     fft_generic = getenv("CALES_FFT_GENERIC") != nullptr;
     keep_null_mode = getenv("CALES_KEEP_NULL_MODE") != nullptr;
@@ -270,6 +272,23 @@ __device__ inline double wave_sum_lane63(double s) {
   return s;
 }
 
+// Block -> tile map of the plane-marching tile kernels, launched as a 1-D grid: consecutive blocks go to the eight XCDs in turn, and each XCD
+// takes bands of `sub` consecutive y tiles with all their x tiles and k chunks (x fastest, then y inside the band, then k), so that the halo
+// rows and columns two neighbouring tiles both read meet in one XCD's L2 instead of being fetched over the fabric twice. With the plain 3-D
+// grid every y neighbour sits on another XCD. The grid is padded to whole bands; blocks of the padding return at once (false).
+struct BandMap { int gx, gy, gz, sub; };
+static inline BandMap band_map(int gx, int gy, int gz) { BandMap m{gx, gy, gz, 1}; m.sub = gy >= 64 ? 8 : (gy + 7) / 8; if (m.sub < 1) m.sub = 1; return m; }
+// The plain 3-D grid already gives every XCD fixed x-tile columns (y neighbours in one L2) when the number of x tiles divides 8 or is a multiple
+// of it -- the 64-wide tiles of power-of-two grids: there the bands bring nothing (momentum pass 8.0 -> 8.6 ms/step at 512^3, measured) and
+// are not used; the 62-wide tiles (9 per 512 cells: the XCD of a tile then runs along diagonals) and odd sizes take the bands.
+static inline bool band_wanted(int gx) { return !(gx % 8 == 0 || 8 % gx == 0); }
+static inline unsigned band_blocks(const BandMap &m) { return 8u * m.gx * m.sub * m.gz * ((m.gy + 8 * m.sub - 1) / (8 * m.sub)); }
+__device__ inline bool band_block(const BandMap &m, int &bx, int &by, int &bz) {
+  unsigned s = blockIdx.x >> 3; const unsigned xcd = blockIdx.x & 7u;
+  bx = s % m.gx; s /= m.gx; const unsigned sb = s % m.sub; s /= m.sub; bz = s % m.gz; s /= m.gz;
+  by = (s * 8 + xcd) * m.sub + sb;
+  return by < m.gy;
+}
 __device__ inline void stencil_block(int &bx, int &by, int &bz) {
   const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z, SUB = 8;
   if (gy % SUB != 0 || (gx * (gy / SUB)) % 8 != 0) { bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z; return; }

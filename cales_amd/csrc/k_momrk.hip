@@ -23,6 +23,7 @@ struct MomRkArgs {
   const double *cs;      // != nullptr: s holds |S| of the dynamic model and visct = s * cs(k) (see visct_lazy in common.hpp)
   double dxi, dyi, visc, f1, f2, f12, bfx, bfy, bfz;
   int kchunk;
+  BandMap bm;      // block -> tile map of the 1-D launch (bm.gx = 0: plain 3-D grid)
   // low-storage RK3 (param.f90:27-29): the first substep has f2 = 0 -> the old r.h.s. is not read; inside cales_step the r.h.s. of the
   // third substep is never used (the next step starts with f2 = 0) -> not written
   int rd_old, wr_new;
@@ -34,7 +35,8 @@ __global__ __launch_bounds__(64 * (TYM + 2), (TYM <= 6 ? 4 : 3)) void k_momrk(Ge
   __shared__ double sh[4][4][TYM + 2][66];
   __shared__ double shp[3][TYM + 2][66];
   const int tx = threadIdx.x, ty = threadIdx.y;
-  const int bx_ = blockIdx.x, by_ = blockIdx.y, bz_ = blockIdx.z;
+  int bx_ = blockIdx.x, by_ = blockIdx.y, bz_ = blockIdx.z;
+  if (A.bm.gx && !band_block(A.bm, bx_, by_, bz_)) return;
   const int i = bx_ * 64 + tx + 1, j = by_ * TYM + ty;
   const int kbeg = bz_ * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
   const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1;
@@ -193,6 +195,8 @@ int op_momrk(cales_ctx *c, double f1, double f2, double f12) {
   while ((long)gr.x * gr.y * ((n[2] + kchunk - 1) / kchunk) < 256 && kchunk > 8) kchunk = (kchunk + 1) / 2;
   if (int fk = tile_kchunk(c, (long)gr.x * gr.y, n[2])) kchunk = fk;
   gr.z = (n[2] + kchunk - 1) / kchunk; A.kchunk = kchunk;
+  A.bm = BandMap{0, 0, 0, 0};
+  if (!c->fl.plain_grid && (band_wanted(gr.x) || c->fl.band_grid)) { A.bm = band_map(gr.x, gr.y, gr.z); gr = dim3(band_blocks(A.bm), 1, 1); }
   const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32) && !c->fl.wide_offsets;      // 32-bit byte offsets
   const int nos = c->C.sgstype == 0 && c->visct_zero;     // visct known to be identically zero (never set by the host since the last zeroing)
 #define MOMRK_LAUNCH(IMP_)                                                                                             \

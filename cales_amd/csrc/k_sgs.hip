@@ -490,7 +490,7 @@ __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijA
 #ifndef TYL
 #define TYL 8
 #endif
-struct LmfArgs { LijMijArgs L; const double *ss[6]; int by0; };      // by0: first y tile of this launch (interior and edge tiles of a slab are launched apart)
+struct LmfArgs { LijMijArgs L; const double *ss[6]; int by0; BandMap bm; int gx; };      // bm: block map of this launch (bm.gx = 0: plain 3-D grid); gx: x tiles of the whole field      // by0: first y tile of this launch (interior and edge tiles of a slab are launched apart)
 template <typename OFF, int YW>      // YW = 1: walls or wall-model faces in y (ducts); 0: the channel instantiation carries none of that logic
 __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) {
   const LijMijArgs &A = B.L;
@@ -498,9 +498,11 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
   __shared__ double ring[4][3][TYL + 2][64];
   __shared__ double shr[2][2][TYL + 2];
   const int tx = threadIdx.x, ty = threadIdx.y;
-  const int by = B.by0 + blockIdx.y;
-  const int i = blockIdx.x * 62 + tx, j = by * TYL + ty;
-  const int kbeg = blockIdx.z * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (B.bm.gx && !band_block(B.bm, bx, by, bz)) return;
+  by += B.by0;
+  const int i = bx * 62 + tx, j = by * TYL + ty;
+  const int kbeg = bz * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
   const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1;
   const bool outok = tx >= 1 && tx <= 62 && ty >= 1 && ty <= TYL && i <= g.n1 && j <= g.n2;
   const bool ssok = ty >= 1 && ty <= TYL && i <= g.n1 + 1 && j <= g.n2;      // rows that filter |S|Sij (all 64 lanes: x neighbours by DPP)
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
   ssload(kbeg - 1, rw); sscomb(rw, xm);
   ssload(kbeg, rw); sscomb(rw, xc);
   ssload(kbeg + 1, rw);
-  const int blk = by * gridDim.x + blockIdx.x;
+  const int blk = by * B.gx + bx;
   auto fold = [&](int k, int b) {      // block sums of plane k, fixed order
     double a = 0., bsum = 0.;
     for (int q = 1; q <= TYL; ++q) { a += shr[b][0][q]; bsum += shr[b][1][q]; }
@@ -660,7 +662,7 @@ struct StrainTileArgs {
   // twy(side, k, i) = sqrt(tau_w) of k_wall_shear_y); wmylo/wmyhi = wall-model y faces: the strain rate sees ghost rows of u and w
   // extrapolated from the interior (extrapolate(...,lwm) along y, sgs.f90:683-748)
   int wylo, wyhi, wmylo, wmyhi; const double *twy; double dl2;
-  int gx, gy, gz, sub;      // k_smag_rows: its own block -> (x tile, row group, k chunk) map
+  BandMap bm;      // block -> (x tile, y tile, k chunk) map of the 1-D launches (bm.gx = 0: plain 3-D grid)
 };
 // sqrt(tau_w) at the two y walls for every (i, k): the argument of the van Driest damping of the cells whose nearest wall is a y wall
 // (sgs.f90:117-143, cases 3 and 4 of the select), from the fields themselves (their ghost cells, not the extrapolated ones)
@@ -686,8 +688,10 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
   __shared__ double ring[3][3][TY + 2][66];      // rows: x-halo cell, 64 own cells, x-halo cell
   __shared__ double shs[SMAG ? 1 : 3][TY + 2][64];
   const int tx = threadIdx.x, ty = threadIdx.y;
-  const int i = blockIdx.x * 64 + tx + 1, j = blockIdx.y * TY + ty;        // whole 128-B lines in and out (see cales_create)
-  const int kbeg = blockIdx.z * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (A.bm.gx && !band_block(A.bm, bx, by, bz)) return;
+  const int i = bx * 64 + tx + 1, j = by * TY + ty;        // whole 128-B lines in and out (see cales_create)
+  const int kbeg = bz * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
   const bool edge = tx == 0 || tx == 63;
   const int ih = tx == 0 ? i - 1 : i + 1, hx = tx == 0 ? 0 : 65;
   const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1, hok = edge && ih <= g.n1 + 1 && j <= g.n2 + 1;
@@ -834,14 +838,10 @@ constexpr int SROWS = 4;      // rows (waves) per block
 template <typename OFF, int YW>
 __global__ __launch_bounds__(64 * SROWS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_smag_rows(Geom g, StrainTileArgs A) {
   const int tx = threadIdx.x;
-  // consecutive blocks go to the eight XCDs in turn: each XCD takes bands of `sub` row groups with all their x tiles and k chunks, so
-  // that the rows two waves both load (j-1, j+1, the shared columns of neighbouring x tiles) meet in one L2 instead of being fetched
-  // from memory by two (measured 1.8 x the compulsory reads with the plain 3-D grid)
+  // band map (common.hpp): the rows two waves both load (j-1, j+1, the shared columns of neighbouring x tiles) meet in one L2 instead of
+  // being fetched from memory by two (measured 1.8 x the compulsory reads with the plain 3-D grid, 1.27 x with the bands)
   int bx, by, bz;
-  { unsigned s = blockIdx.x >> 3; const unsigned xcd = blockIdx.x & 7u;
-    bx = s % A.gx; s /= A.gx; const unsigned sb = s % A.sub; s /= A.sub; bz = s % A.gz; s /= A.gz;
-    by = (s * 8 + xcd) * A.sub + sb; }
-  if (by >= A.gy) return;
+  if (!band_block(A.bm, bx, by, bz)) return;
   const int i = bx * 62 + tx, j = by * SROWS + threadIdx.y + 1;
   if (j > g.n2) return;
   const int kbeg = bz * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
@@ -987,6 +987,8 @@ static int dsmag_fast(cales_ctx *c) {
     S.uc[0] = c->uc; S.uc[1] = c->vc; S.uc[2] = c->wc; S.uf[0] = c->uf; S.uf[1] = c->vf; S.uf[2] = c->wf;
     S.dzci = c->d_dzci; S.dzfi = c->d_dzfi; S.dxi = c->dli[0]; S.dyi = c->dli[1]; S.kchunk = kch; S.zlo = zlo; S.zhi = zhi; S.wmlo = wmlo; S.wmhi = wmhi; S.flo = flo; S.fhi = fhi;
     S.wylo = wylo; S.wyhi = wyhi; S.wmylo = wmylo; S.wmyhi = wmyhi; S.twy = nullptr; S.dl2 = c->dl[1];
+    S.bm = BandMap{0, 0, 0, 0};
+    if (!c->fl.plain_grid && (band_wanted(mg.x) || c->fl.band_grid)) { S.bm = band_map(mg.x, mg.y, mg.z); mg = dim3(band_blocks(S.bm), 1, 1); }
     if (wylo || wyhi || wmylo || wmyhi) { if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 0, TYS, 1>), mg, mb, 0, c->stream, c->g, S); else hipLaunchKernelGGL((k_strain_tile<size_t, 0, TYS, 1>), mg, mb, 0, c->stream, c->g, S); }
     else if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 0, TYS, 0>), mg, mb, 0, c->stream, c->g, S); else hipLaunchKernelGGL((k_strain_tile<size_t, 0, TYS, 0>), mg, mb, 0, c->stream, c->g, S); }
   // sgs-type ghost cells: only the periodic exchange matters (products of ghosts = ghosts of products; the wall ghosts are
@@ -1023,7 +1025,9 @@ static int dsmag_fast(cales_ctx *c) {
     LmfArgs B; B.L = L; for (int m = 0; m < 6; ++m) B.ss[m] = ssij[m];
     auto launch = [&](int by0, int nby) {
       if (nby <= 0) return;
-      B.by0 = by0; const dim3 gg(mg.x, nby, mg.z);
+      B.by0 = by0; B.gx = mg.x; dim3 gg(mg.x, nby, mg.z);
+      B.bm = BandMap{0, 0, 0, 0};
+      if (!c->fl.plain_grid && (band_wanted(mg.x) || c->fl.band_grid)) { B.bm = band_map(mg.x, nby, mg.z); gg = dim3(band_blocks(B.bm), 1, 1); }
       const bool yw = wylo || wyhi || wmylo || wmyhi;
       if (yw) { if (small) hipLaunchKernelGGL((k_lmf_tile<unsigned, 1>), gg, mb, 0, c->stream, c->g, B); else hipLaunchKernelGGL((k_lmf_tile<size_t, 1>), gg, mb, 0, c->stream, c->g, B); }
       else if (small) hipLaunchKernelGGL((k_lmf_tile<unsigned, 0>), gg, mb, 0, c->stream, c->g, B); else hipLaunchKernelGGL((k_lmf_tile<size_t, 0>), gg, mb, 0, c->stream, c->g, B);
@@ -1114,16 +1118,14 @@ static int smag_fast(cales_ctx *c) {
   if (!c->fl.smag_tile) {
     // row-marching form: one wave per row of 62 cells; chunks of k so that every CU holds several blocks' worth of independent waves
     const dim3 rb(64, SROWS, 1);
-    S.gx = (n[0] + 61) / 62; S.gy = (n[1] + SROWS - 1) / SROWS;
+    const int rgx = (n[0] + 61) / 62, rgy = (n[1] + SROWS - 1) / SROWS;
     int kr = n[2];
     // sixteen waves per CU at a time: enough blocks for eight rounds or more, or the last round's idle CUs show (chunks pay a three-plane prologue)
-    while ((long)S.gx * S.gy * ((n[2] + kr - 1) / kr) < 8192 && kr > 32) kr = (kr + 1) / 2;
-    while ((long)S.gx * S.gy * ((n[2] + kr - 1) / kr) < 1024 && kr > 8) kr = (kr + 1) / 2;
-    if (int fk = tile_kchunk(c, (long)S.gx * S.gy, n[2])) kr = fk;
-    S.gz = (n[2] + kr - 1) / kr; S.kchunk = kr;
-    S.sub = std::min(8, (S.gy + 7) / 8);
-    const int ngrp = (S.gy + 8 * S.sub - 1) / (8 * S.sub);
-    const dim3 rg(8u * S.gx * S.sub * S.gz * ngrp, 1, 1);
+    while ((long)rgx * rgy * ((n[2] + kr - 1) / kr) < 8192 && kr > 32) kr = (kr + 1) / 2;
+    while ((long)rgx * rgy * ((n[2] + kr - 1) / kr) < 1024 && kr > 8) kr = (kr + 1) / 2;
+    if (int fk = tile_kchunk(c, (long)rgx * rgy, n[2])) kr = fk;
+    S.kchunk = kr; S.bm = band_map(rgx, rgy, (n[2] + kr - 1) / kr);
+    const dim3 rg(band_blocks(S.bm), 1, 1);
     if (yw) { if (small) hipLaunchKernelGGL((k_smag_rows<unsigned, 1>), rg, rb, 0, c->stream, c->g, S); else hipLaunchKernelGGL((k_smag_rows<size_t, 1>), rg, rb, 0, c->stream, c->g, S); }
     else if (small) hipLaunchKernelGGL((k_smag_rows<unsigned, 0>), rg, rb, 0, c->stream, c->g, S); else hipLaunchKernelGGL((k_smag_rows<size_t, 0>), rg, rb, 0, c->stream, c->g, S);
     HIPCHK(c, hipGetLastError());
