@@ -286,12 +286,12 @@ int hs_check_case(const cales_case *cs, std::string &msg) {
   if (cs->sgstype < 0 || cs->sgstype > 2) { msg = "unknown SGS model"; return 1; }
   if (cs->sgstype == 1 && cs->nranks > 2 && cs->cbcvel[0 + 2 * 1 + 6 * 1] == 'D' && cs->cbcvel[1 + 2 * 1 + 6 * 1] == 'D') {
     msg = "more than two subdomains between two opposite walls (sanity.f90:98-111)"; return 1; }
-  if (cs->impdiff == 1) {   // Helmholtz solves of the velocity: periodic or no-slip/no-penetration (homogeneous Dirichlet) pairs in x and y
+  if (cs->impdiff == 1) {   // Helmholtz solves of the velocity: every BC pair of find_fft (fft.f90:192-245), cell- and face-centred
     for (int iv = 0; iv < 3; ++iv) for (int d = 0; d < 2; ++d) {
       const std::string b = pr(cs->cbcvel + 6 * iv, d);
-      if (b != "PP" && b != "DD") { msg = "3-D implicit diffusion (_IMPDIFF without _IMPDIFF_1D) is provided for periodic or wall (DD) velocity BCs in x and y"; return 1; }
-      if (b == "DD" && (cs->bcvel[0 + 2 * d + 6 * iv] != 0. || cs->bcvel[1 + 2 * d + 6 * iv] != 0.)) {
-        msg = "3-D implicit diffusion: wall velocities in x and y must be zero (moving walls only in z)"; return 1; }
+      if (b != "PP" && b != "DD" && b != "NN" && b != "ND" && b != "DN") { msg = "3-D implicit diffusion: unknown velocity BC pair in x or y"; return 1; }
+      if (d == 1 && d != iv && (b == "ND" || b == "DN") && (cs->ng[1] % 2)) { msg = "3-D implicit diffusion: ND/DN velocity BCs across y need an even ng(2)"; return 1; }
+      if (b != "PP" && d == 0 && cs->cbcvel[6 * iv + 4] == 'P' && cs->nranks > 1) { msg = "3-D implicit diffusion: a non-periodic x with periodic z needs one rank"; return 1; }
     }
   }
   if (cs->impdiff == 1 && (cs->lwm[0] != 0 || cs->lwm[1] != 0 || cs->lwm[2] != 0 || cs->lwm[3] != 0)) {

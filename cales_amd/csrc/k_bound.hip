@@ -475,6 +475,37 @@ __global__ __launch_bounds__(256) void k_rhs_b_velz(Geom g, double *p, const dou
   if (plane_out) plane_out[(size_t)(i - 1) + (size_t)g.n1 * (j - 1)] = r * alpha;      // added by the fused Helmholtz sweep, in the reference's order
   else p[g.ix(i, j, pos)] += r * alpha;
 }
+// The same term on the x (idir = 1) and y (idir = 2) faces for the 3-D implicit step (main.f90:424-431: rhsbx, rhsby times alpha, added by
+// updt_rhs_b to the first and the last unknown plane of the direction, bound.f90:578-603): inflow profiles, moving side walls.
+__global__ __launch_bounds__(256) void k_rhs_b_velxy(Geom g, double *p, const double *bcplane, int idir, int ib, char ctype, char c_or_f, double dl,
+                                                     double alpha, int pos) {
+  const int a = blockIdx.x * 64 + threadIdx.x + 1, k = blockIdx.y * 4 + threadIdx.y + 1;      // a = j (x faces) or i (y faces)
+  const int na = idir == 1 ? g.n2 : g.n1;
+  if (a > na || k > g.n3) return;
+  const double bcv = bcplane[a + (size_t)(na + 2) * k];
+  const double sgn = ib == 0 ? 1. : -1.;
+  double r = 0.;
+  if (c_or_f == 'c') { if (ctype == 'D') r = -2. * bcv / dl / dl; else if (ctype == 'N') r = sgn * bcv / dl; }
+  else               { if (ctype == 'D') r = -bcv / dl / dl;      else if (ctype == 'N') r = sgn * bcv / dl; }
+  p[idir == 1 ? g.ix(pos, a, k) : g.ix(a, pos, k)] += r * alpha;
+}
+int op_rhs_b_velxy(cales_ctx *c, int ivel, double alpha) {
+  const int *n = c->n;
+  const DBound &bc = ivel == 1 ? c->bcu : ivel == 2 ? c->bcv : c->bcw;
+  for (int idir = 1; idir <= 2; ++idir) {
+    const char cf = ivel == idir ? 'f' : 'c';
+    const char *cbc = &c->cbcvel[6 * (ivel - 1) + 2 * (idir - 1)];
+    const int q = (cf == 'f' && cbc[1] == 'D') ? 1 : 0;
+    const int na = idir == 1 ? n[1] : n[0];
+    for (int ib = 0; ib <= 1; ++ib) {
+      if (!ISB(c, ib, idir) || cbc[ib] == 'P') continue;
+      hipLaunchKernelGGL(k_rhs_b_velxy, dim3((na + 63) / 64, (n[2] + 3) / 4), dim3(64, 4), 0, c->stream, c->g, c->f[CALES_U + ivel - 1],
+                         plane(bc, idir, ib, n), idir, ib, cbc[ib], cf, c->dl[idir - 1], alpha, ib ? n[idir - 1] - q : 1);
+    }
+  }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
 // planes != nullptr: the two contributions go to planes[0 / n1*n2] instead of being added to the field; has[ib] tells which exist
 int op_rhs_b_velz(cales_ctx *c, int ivel, double alpha, double *planes, int *has) {
   const int *n = c->n; const int n3 = n[2];

@@ -353,17 +353,22 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const
   }
 }
 
-// DST-I (RODFT00, fft.f90:192-245 with c_or_f = 'f' and Dirichlet on both faces): the transform of a velocity component along its own
-// wall-normal direction in the 3-D implicit step -- n-1 unknowns j = 1..n-1 between the wall faces 0 and n. Odd extension to 2n points
-// through one complex FFT of length 2n per line: Z_k = sum z_j e^{-i pi j k/n} = -i Y_k with Y_k = 2 sum x_j sin(pi j k/n). Linear, so a
-// complex column (y direction: real and imaginary part of an x mode) goes through as it is; self-inverse up to 2n.
+// Face-centred transform kinds of a velocity component along its OWN direction in the 3-D implicit step (find_fft with c_or_f = 'f',
+// fft.f90:221-243), each through ONE complex FFT of the symmetric extension of the line (one line per block; these are the rare paths):
+//   kind 5  'DD'  RODFT00 both ways, n-1 unknowns between the wall faces 0 and n: odd extension to 2n points, Y_k = i Z_k
+//   kind 6  'NN'  REDFT00 both ways, n points: even extension to 2(n-1) points, Y_k = Z_k
+//   kind 7  'DN'  RODFT01 forward: Y_k = (-1)^k x_{n-1} + 2 sum_{j<n-1} x_j sin(pi (j+1)(k+1/2)/n) = (i/2) Z_{2k+1} of the extension w of 4n points,
+//                 odd about 0 and 2n and even about n (w_j' = x_{j'-1}, j' = 1..n); RODFT10 backward: Y_k = 2 sum x_j sin(pi (j+1/2)(k+1)/n) = i Z_{k+1}
+//                 of z_{2j+1} = x_j, z_{4n-2j-1} = -x_j (4n points)
+// ('ND' face-centred is REDFT10/01, the cell-centred Neumann pair: kind 1 with its own eigenvalues.) All are linear with real coefficients, so a
+// complex column (y direction: real and imaginary part of an x mode) goes through as it is.
 // DIR 0 / 2: rows along x, forward (field row -> real x modes, slab side of the spectrum) / inverse (modes -> field row, times `scale`),
-// one row per block, coefficient k at the place of x_k; DIR 1: columns along y of the complex spectrum, one column per block.
+// one row per block, coefficient k at the place of x_k; DIR 1: columns along y of the complex spectrum, one column per block (bwd: inverse).
 template <int DIR>
 __global__ __launch_bounds__(256) void k_dst1(Geom g, FftPlan P, int ncols, const cpx *__restrict__ tw, double *__restrict__ p, double scale,
-                                              Spec S, double2 *__restrict__ pc) {
+                                              Spec S, double2 *__restrict__ pc, int kind = 5, int bwd = 0) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const int N2 = P.N, n = N2 / 2, ld = N2 + 1, t = threadIdx.x, T = blockDim.x;
+  const int N2 = P.N, n = kind == 5 ? N2 / 2 : kind == 6 ? N2 / 2 + 1 : N2 / 4, ld = N2 + 1, t = threadIdx.x, T = blockDim.x;
   cpx *A = reinterpret_cast<cpx *>(smem), *B = A + ld;
   int j = 0, k = 0, m = 0;
   if (DIR != 1) { const long r = blockIdx.x; j = (int)(r % g.n2) + 1; k = (int)(r / g.n2) + 1; }
@@ -371,21 +376,36 @@ __global__ __launch_bounds__(256) void k_dst1(Geom g, FftPlan P, int ncols, cons
   double *specd = reinterpret_cast<double *>(pc);
   auto slot = [&](int e) -> double & { return specd[2 * S.at_slab(g, e >> 1, j, k) + (e & 1)]; };      // real x mode e of row (j,k)
   double *rowp = p + g.ix(0, j, k);                                                                  // field row: x_e at rowp[e]
+  auto rd = [&](int pos) -> cpx {      // value number pos (1-based) of the line
+    if (DIR == 0) return cpx{rowp[pos], 0.};
+    if (DIR == 2) return cpx{slot(pos - 1), 0.};
+    const double2 v = pc[S.at_mode(g, m, pos, k)]; return cpx{v.x, v.y};
+  };
+  auto wr = [&](int pos, cpx y) {
+    if (DIR == 0) slot(pos - 1) = y.x * scale; else if (DIR == 2) rowp[pos] = y.x * scale; else pc[S.at_mode(g, m, pos, k)] = make_double2(y.x * scale, y.y * scale);
+  };
+  const bool inv = DIR == 2 || (DIR == 1 && bwd);
   for (int q = t; q < N2; q += T) {
     cpx z = {0., 0.};
-    const int jj = q < n ? q : N2 - q;                    // |index| of the odd extension; 0 and n are the wall faces
-    if (q != 0 && q != n) {
-      if (DIR == 0) z.x = rowp[jj]; else if (DIR == 2) z.x = slot(jj - 1); else { const double2 v = pc[S.at_mode(g, m, jj, k)]; z = cpx{v.x, v.y}; }
-      if (q > n) { z.x = -z.x; z.y = -z.y; }
+    if (kind == 5) {
+      const int jj = q < n ? q : N2 - q;                    // |index| of the odd extension; 0 and n are the wall faces
+      if (q != 0 && q != n) { z = rd(jj); if (q > n) { z.x = -z.x; z.y = -z.y; } }
+    } else if (kind == 6) {
+      z = rd((q < n ? q : N2 - q) + 1);
+    } else if (!inv) {
+      const int r = q <= 2 * n ? q : N2 - q;
+      if (r != 0 && r != 2 * n) { z = rd(r <= n ? r : 2 * n - r); if (q > 2 * n) { z.x = -z.x; z.y = -z.y; } }
+    } else if (q & 1) {
+      if (q < 2 * n) z = rd((q - 1) / 2 + 1); else { z = rd((N2 - q - 1) / 2 + 1); z.x = -z.x; z.y = -z.y; }
     }
     A[q] = z;
   }
   __syncthreads();
   cpx *Z = fft_line<0>(P, A, B, t, T, tw);
-  for (int kk = t + 1; kk < n; kk += T) {                 // Y_k = i Z_k
-    const cpx y = {-Z[kk].y, Z[kk].x};
-    if (DIR == 0) slot(kk - 1) = y.x * scale; else if (DIR == 2) rowp[kk] = y.x * scale; else pc[S.at_mode(g, m, kk, k)] = make_double2(y.x * scale, y.y * scale);
-  }
+  if (kind == 5) { for (int kk = t + 1; kk < n; kk += T) wr(kk, cpx{-Z[kk].y, Z[kk].x}); }                  // Y_k = i Z_k
+  else if (kind == 6) { for (int kk = t; kk < n; kk += T) wr(kk + 1, Z[kk]); }
+  else if (!inv) { for (int kk = t; kk < n; kk += T) wr(kk + 1, cpx{-0.5 * Z[2 * kk + 1].y, 0.5 * Z[2 * kk + 1].x}); }      // every x_j sits twice in (0, 2n)
+  else { for (int kk = t; kk < n; kk += T) wr(kk + 1, cpx{-Z[kk + 1].y, Z[kk + 1].x}); }
   (void)ncols;
 }
 
@@ -667,7 +687,7 @@ template <> __device__ inline double vfma<double>(double a, double s, double b) 
 // ncol x nrow columns; spectral solve: S maps (m, j) (mode side), mofs = global index of local mode 0, nmode = number of
 // real modes (padding columns beyond it are skipped). Real fields (VT = double): in-place haloed array, i0 = 1.
 // NN in x: the two reals of a pair are different modes -> two scalar recurrences (pivots d1,d2 kept as a double2)
-__global__ __launch_bounds__(256) void k_gaussel_split(Geom g, int nz, int ncol, int nrow, int mofs, int nmode, Spec S,
+__global__ __launch_bounds__(256) void k_gaussel_split(Geom g, int nz, int ncol, int nrow, int mofs, int nmode, Spec S, double lscale,
                                                        const double *__restrict__ a, const double *__restrict__ b, const double *__restrict__ c,
                                                        const double *__restrict__ lamx, const double *__restrict__ lamy,
                                                        double2 *__restrict__ p, double2 *__restrict__ dscr, int fixnull) {
@@ -675,7 +695,7 @@ __global__ __launch_bounds__(256) void k_gaussel_split(Geom g, int nz, int ncol,
   if (m >= ncol || j > nrow || m + mofs >= nmode) return;
   const size_t e0 = S.at_mode(g, m, j, 1), st = S.blocked ? (size_t)S.cw * S.n2l : (size_t)g.s12 / 2;
   const size_t s0 = (size_t)m + (size_t)ncol * (size_t)(j - 1), sst = (size_t)ncol * nrow;
-  const double l1 = lamx[2 * (m + mofs)] + lamy[j - 1], l2 = lamx[2 * (m + mofs) + 1] + lamy[j - 1];
+  const double l1 = (lamx[2 * (m + mofs)] + lamy[j - 1]) * lscale, l2 = (lamx[2 * (m + mofs) + 1] + lamy[j - 1]) * lscale;
   const bool null1 = fixnull && l1 == 0., null2 = fixnull && l2 == 0.;      // see k_gaussel_ri
   double z1 = 1. / (b[0] + l1 + CALES_EPS), z2 = 1. / (b[0] + l2 + CALES_EPS), d1 = c[0] * z1, d2 = c[0] * z2;
   double2 v = p[e0]; v.x *= z1; v.y *= z2; p[e0] = v; dscr[s0] = make_double2(d1, d2);
@@ -922,7 +942,7 @@ template <int CTRL> __device__ inline double quad_bcast(double v) {
   lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
-__global__ __launch_bounds__(256) void k_gaussel_herm(Geom g, int nz, int ncol, int N, int mofs, int nmode, Spec S,
+__global__ __launch_bounds__(256) void k_gaussel_herm(Geom g, int nz, int ncol, int N, int mofs, int nmode, Spec S, double lscale,
                                                       const double *__restrict__ a, const double *__restrict__ b,
                                                       const double *__restrict__ c, const double *__restrict__ lamx,
                                                       const double *__restrict__ lamy, double *__restrict__ p, double *__restrict__ dscr, int fixnull) {
@@ -934,7 +954,7 @@ __global__ __launch_bounds__(256) void k_gaussel_herm(Geom g, int nz, int ncol, 
   const size_t ek = live ? 2 * S.at_mode(g, m, ky + 1, 1) : 0, en = live ? 2 * S.at_mode(g, m, kn + 1, 1) : 0;
   const size_t st = 2 * (S.blocked ? (size_t)S.cw * S.n2l : (size_t)g.s12 / 2);
   const size_t s0 = (size_t)t + (size_t)4 * ncol * (size_t)ky, sst = (size_t)4 * ncol * (N / 2 + 1);
-  const double lam = live ? lamx[2 * (m + mofs) + (role >> 1)] + lamy[ky] : 1.;
+  const double lam = live ? (lamx[2 * (m + mofs) + (role >> 1)] + lamy[ky]) * lscale : 1.;      // lscale: alpha of a Helmholtz solve (lambdaxy*alpha, main.f90:438)
   // my slot: role 0 -> Re row ky, 1 -> Im row ky, 2 -> Re row kn, 3 -> Im row kn; self-conjugate rows: role 2 -> Im row ky, roles 1,3 idle
   const bool active = live && !(self && (role & 1));
   const size_t slot = self ? (role == 0 ? ek : ek + 1) : (role == 0 ? ek : role == 1 ? ek + 1 : role == 2 ? en : en + 1);
@@ -1233,7 +1253,7 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec);
     else if (use8x) hipLaunchKernelGGL((k_fft_x8<0, 0>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec);
-    else if (c->xkind == 5) hipLaunchKernelGGL(k_dst1<0>, dim3((unsigned)nrows), dim3(256), (size_t)2 * (VS->p1x.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1x, 0, (const cpx *)VS->tw1x, pp, 1., S, slab_spec);
+    else if (c->xkind >= 5) hipLaunchKernelGGL(k_dst1<0>, dim3((unsigned)nrows), dim3(256), (size_t)2 * (VS->p1x.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1x, 0, (const cpx *)VS->tw1x, pp, 1., S, slab_spec, c->xkind, 0);
     else if (c->xkind == 3) hipLaunchKernelGGL((k_fft_x4<0, 0>), dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
                        (const cpx *)c->d_twx, (const cpx *)c->d_tw4x, pp, 1., S, slab_spec);
     else if (c->xkind == 4) hipLaunchKernelGGL((k_fft_x4<0, 1>), dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
@@ -1242,7 +1262,7 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
                        (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec); }
   if (dist) { ProfScope ps(c, "alltoall"); if (c->comm.a2a(c->comm.user, 0, a2a_count)) { c->err = "alltoall callback failed"; return 1; } }
   { ProfScope ps(c, "fft_y_fwd");
-    if (c->ykind == 5) hipLaunchKernelGGL(k_dst1<1>, dim3(ncol, n[2]), dim3(256), (size_t)2 * (VS->p1y.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1y, ncol, (const cpx *)VS->tw1y, pp, 1., S, mode_spec);
+    if (c->ykind >= 5) hipLaunchKernelGGL(k_dst1<1>, dim3(ncol, n[2]), dim3(256), (size_t)2 * (VS->p1y.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1y, ncol, (const cpx *)VS->tw1y, pp, 1., S, mode_spec, c->ykind, 0);
     else if (c->ykind == 3) hipLaunchKernelGGL(k_fft_y4<0>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
     else if (c->ykind == 4) hipLaunchKernelGGL(k_fft_y4<1>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
     else if (use8y && c->ykind) hipLaunchKernelGGL((k_fft_y8<0, 1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
@@ -1254,7 +1274,7 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
   { ProfScope ps(c, "gaussel_z");
     dim3 b(64, 4), gr((ncol + 63) / 64, (n2g + 3) / 4);
     if (c->xkind && !c->ykind)       // real x modes paired into complex columns + periodic y: Hermitian separation of rows ky and N-ky
-      hipLaunchKernelGGL(k_gaussel_herm, dim3((unsigned)(((long)4 * ncol * (n2g / 2 + 1) + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S,
+      hipLaunchKernelGGL(k_gaussel_herm, dim3((unsigned)(((long)4 * ncol * (n2g / 2 + 1) + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, lscale,
                          da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, fixnull);
     else if (!periodic_z && !c->fl.gaussel_pair && (fixnull || !poisson || CBP(c, 0, 3) == 'D' || CBP(c, 1, 3) == 'D') &&
              [&]() {
@@ -1269,7 +1289,7 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
     else if (periodic_z && c->xkind)      // real x modes (one eigenvalue each) with the periodic-z closure: scalar columns of the in-place spectrum, one rank
       hipLaunchKernelGGL((k_gaussel<double, 1>), dim3((2 * (c->C.ng[0] / 2) + 63) / 64, (n2g + 3) / 4), b, 0, c->stream, c->g, nz, 2 * (c->C.ng[0] / 2), n2g, 1, 0, 2 * (c->C.ng[0] / 2), S, lscale,
                          da, db, dc, c->d_lamx, c->d_lamy, pp, c->scr1, c->scr2, fixnull);
-    else if (c->xkind) hipLaunchKernelGGL(k_gaussel_split, gr, b, 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, da, db, dc, c->d_lamx, c->d_lamy,
+    else if (c->xkind) hipLaunchKernelGGL(k_gaussel_split, gr, b, 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, lscale, da, db, dc, c->d_lamx, c->d_lamy,
                                      (double2 *)mode_spec, (double2 *)c->scr1, fixnull);
     else if (periodic_z) hipLaunchKernelGGL((k_gaussel<double2, 1>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2, fixnull);
     else if (c->fl.gaussel_pair) hipLaunchKernelGGL((k_gaussel<double2, 0>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2, fixnull);
@@ -1292,7 +1312,7 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
     }
   } else {
   { ProfScope ps(c, "fft_y_bwd");
-    if (c->ykind == 5) hipLaunchKernelGGL(k_dst1<1>, dim3(ncol, n[2]), dim3(256), (size_t)2 * (VS->p1y.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1y, ncol, (const cpx *)VS->tw1y, pp, 1., S, mode_spec);
+    if (c->ykind >= 5) hipLaunchKernelGGL(k_dst1<1>, dim3(ncol, n[2]), dim3(256), (size_t)2 * (VS->p1y.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1y, ncol, (const cpx *)VS->tw1y, pp, 1., S, mode_spec, c->ykind, 1);
     else if (c->ykind == 3) hipLaunchKernelGGL(k_fft_y4<0>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
     else if (c->ykind == 4) hipLaunchKernelGGL(k_fft_y4<1>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
     else if (use8y && c->ykind) hipLaunchKernelGGL((k_fft_y8<1, 1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
@@ -1304,7 +1324,7 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec);
     else if (use8x) hipLaunchKernelGGL((k_fft_x8<1, 0>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec);
-    else if (c->xkind == 5) hipLaunchKernelGGL(k_dst1<2>, dim3((unsigned)nrows), dim3(256), (size_t)2 * (VS->p1x.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1x, 0, (const cpx *)VS->tw1x, pp, c->normfft, S, slab_spec);
+    else if (c->xkind >= 5) hipLaunchKernelGGL(k_dst1<2>, dim3((unsigned)nrows), dim3(256), (size_t)2 * (VS->p1x.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1x, 0, (const cpx *)VS->tw1x, pp, c->normfft, S, slab_spec, c->xkind, 1);
     else if (c->xkind == 3) hipLaunchKernelGGL((k_fft_x4<1, 0>), dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
                        (const cpx *)c->d_twx, (const cpx *)c->d_tw4x, pp, c->normfft, S, slab_spec);
     else if (c->xkind == 4) hipLaunchKernelGGL((k_fft_x4<1, 1>), dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
@@ -1372,6 +1392,7 @@ __global__ void k_scale_abc(int n, double alpha, const double *a, const double *
   if (k < n) { aa[k] = a[k] * alpha; bb[k] = b[k] * alpha + 1.; cc[k] = c[k] * alpha; }
 }
 int op_rhs_b_velz(cales_ctx *c, int ivel, double alpha, double *planes = nullptr, int *has = nullptr);
+int op_rhs_b_velxy(cales_ctx *c, int ivel, double alpha);
 int op_helmholtz_z(cales_ctx *c, int ivel, double alpha) {
   if (c->C.impdiff != 2) { c->err = "helmholtz_z needs impdiff = 2"; return 1; }
   ProfScope ps(c, "helmholtz_z");
@@ -1407,23 +1428,31 @@ int op_helmholtz_z(cales_ctx *c, int ivel, double alpha) {
 }
 
 // 3-D implicit diffusion (_IMPDIFF without _IMPDIFF_1D, main.f90:423-491): (1 + alpha L) q = q* by the same transforms as the
-// pressure solve. Provided for periodic x and y, where the eigenvalues and transforms of a velocity component are those of
-// the pressure (initsolver.f90:66-98 does not depend on the staggering for 'PP'); cales_check_case rejects the rest.
-// Transform set of one velocity component for the 3-D implicit step: kinds and eigenvalues follow its BC pairs and its staggering
-// (initsolver.f90:66-98, find_fft with c_or_f): periodic -> 0; walls -> RODFT10/01 (kind 2) across the component, RODFT00 (kind 5,
-// one unknown less) along it. Built on first use; other pairs (open boundaries) are refused by cales_check_case.
-static int velset_build(cales_ctx *c, int slot, int iv, VelSet &V) {
+// pressure solve, with the transform set of the velocity component: kinds, eigenvalues and normalisation follow its BC pairs and its
+// staggering (initsolver.f90:66-98, find_fft with c_or_f, fft.f90:192-245):
+//   across the component ('c'):  PP 0 | NN 1 (REDFT10/01) | DD 2 (RODFT10/01) | ND 3 (REDFT11) | DN 4 (RODFT11)      -- the pressure's kernels
+//   along it ('f'):              PP 0 | NN 6 (REDFT00) | DD 5 (RODFT00, one unknown less) | ND 1 (REDFT10/01) | DN 7 (RODFT01 / RODFT10)
+// Built on first use. (As in the reference, the face-centred NN and ND sets are not exact inverses of the discrete operator -- REDFT00 of n
+// points goes with eigenvalues of period n, REDFT10 with half-integer ones; measured on the oracle: residual of (1 + alpha L) x = r of a
+// few per cent -- while PP, DD and DN are exact to round-off. They are provided because the reference provides them.)
+static int velset_build(cales_ctx *c, SolverPlans &sp, int iv, VelSet &V) {
   const int n1 = c->C.ng[0], n2g = c->C.ng[1];
   const char *bc = &c->cbcvel[6 * iv];
   auto kind = [&](int d) -> int {
     const std::string b = std::string(1, bc[2 * d]) + bc[2 * d + 1];
+    const bool own = d == iv;
     if (b == "PP") return 0;
-    if (b == "DD") return d == iv ? 5 : 2;
+    if (b == "NN") return own ? 6 : 1;
+    if (b == "DD") return own ? 5 : 2;
+    if (b == "ND") return own ? 1 : 3;
+    if (b == "DN") return own ? 7 : 4;
     return -1;
   };
   V.xkind = kind(0); V.ykind = kind(1);
-  if (V.xkind < 0 || V.ykind < 0) { c->err = "helmholtz: velocity BC pairs in x and y must be PP or DD (walls)"; return 1; }
+  if (V.xkind < 0 || V.ykind < 0) { c->err = "helmholtz: unknown velocity BC pair in x or y"; return 1; }
   if (V.xkind && !V.ykind && c->cbcvel[6 * iv + 4] == 'P') { c->err = "helmholtz: non-periodic x with periodic y and z is not provided"; return 1; }
+  if (V.xkind && c->cbcvel[6 * iv + 4] == 'P' && c->P > 1) { c->err = "helmholtz: a non-periodic x with periodic z needs one rank"; return 1; }
+  if ((V.ykind == 3 || V.ykind == 4) && (n2g % 2)) { c->err = "helmholtz: ND/DN in y need an even ng(2)"; return 1; }
   std::vector<double> lx(n1 + 2, 0.), ly(n2g);
   const std::string bx = std::string(1, bc[0]) + bc[1], by = std::string(1, bc[2]) + bc[3];
   hs_eigenvalues(n1, bx.c_str(), iv == 0 ? 'f' : 'c', lx.data()); hs_eigenvalues(n2g, by.c_str(), iv == 1 ? 'f' : 'c', ly.data());
@@ -1433,8 +1462,9 @@ static int velset_build(cales_ctx *c, int slot, int iv, VelSet &V) {
   HIPCHK(c, hipMalloc(&V.lamx, (n1 + 2) * sizeof(double))); HIPCHK(c, hipMalloc(&V.lamy, n2g * sizeof(double)));
   HIPCHK(c, hipMemcpy(V.lamx, lx.data(), (n1 + 2) * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(V.lamy, ly.data(), n2g * sizeof(double), hipMemcpyHostToDevice));
-  // fft.f90:99,136,142: norm = 1 (PP), 2 n ('c' walls), 2 (n + 1 - 1) ('f' walls)
-  V.normfft = 1. / ((V.xkind ? 2. : 1.) * (double)n1 * (V.ykind ? 2. : 1.) * (double)n2g);
+  // fft.f90:99,136,142: normfft = prod norm(1) (n + norm(2) - ix): 1 n (PP), 2 n ('c' pairs, 'f' ND/DN), 2 (n + 1 - 1) ('f' DD), 2 (n - 1) ('f' NN)
+  auto nrm = [](int kd, int nn) -> double { return kd == 0 ? (double)nn : kd == 6 ? 2. * (nn - 1) : 2. * nn; };
+  V.normfft = 1. / (nrm(V.xkind, n1) * nrm(V.ykind, n2g));
   auto mk = [&](int N, double **dev) -> int {
     std::vector<double> t(2 * (size_t)N); const double pi = std::acos(-1.0);
     for (int q = 0; q < N; ++q) { const double ang = -2. * pi * q / N; t[2 * q] = std::cos(ang); t[2 * q + 1] = std::sin(ang); }
@@ -1442,10 +1472,33 @@ static int velset_build(cales_ctx *c, int slot, int iv, VelSet &V) {
     HIPCHK(c, hipMemcpy(*dev, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
     return 0;
   };
-  if (V.xkind == 5) { if (!make_plan(2 * n1, V.p1x) || (size_t)2 * (2 * n1 + 1) * sizeof(cpx) > 150 * 1024) { c->err = "helmholtz: x line not supported by the DST-I kernel"; return 1; } if (mk(2 * n1, &V.tw1x)) return 1; }
-  if (V.ykind == 5) { if (!make_plan(2 * n2g, V.p1y) || (size_t)2 * (2 * n2g + 1) * sizeof(cpx) > 150 * 1024) { c->err = "helmholtz: y line not supported by the DST-I kernel"; return 1; } if (mk(2 * n2g, &V.tw1y)) return 1; }
-  if (V.xkind == 5 || V.ykind == 5) hipFuncSetAttribute((const void *)k_dst1<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), hipFuncSetAttribute((const void *)k_dst1<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), hipFuncSetAttribute((const void *)k_dst1<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-  (void)slot;
+  auto next = [](int kd, int nn) { return kd == 5 ? 2 * nn : kd == 6 ? 2 * (nn - 1) : 4 * nn; };      // points of the symmetric extension (k_dst1)
+  if (V.xkind >= 5) { const int N = next(V.xkind, n1);
+    if (N < 2 || !make_plan(N, V.p1x) || (size_t)2 * (N + 1) * sizeof(cpx) > 150 * 1024) { c->err = "helmholtz: x line not supported by the face-centred transform kernel"; return 1; } if (mk(N, &V.tw1x)) return 1; }
+  if (V.ykind >= 5) { const int N = next(V.ykind, n2g);
+    if (N < 2 || !make_plan(N, V.p1y) || (size_t)2 * (N + 1) * sizeof(cpx) > 150 * 1024) { c->err = "helmholtz: y line not supported by the face-centred transform kernel"; return 1; } if (mk(N, &V.tw1y)) return 1; }
+  if (V.xkind >= 5 || V.ykind >= 5) hipFuncSetAttribute((const void *)k_dst1<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), hipFuncSetAttribute((const void *)k_dst1<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), hipFuncSetAttribute((const void *)k_dst1<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  // the DCT-IV / DST-IV kernels (kinds 3, 4) read tables that solver_setup makes only when the pressure needs them
+  const double pi = std::acos(-1.0);
+  if ((V.xkind == 3 || V.xkind == 4) && !c->d_tw4x) {
+    const int nh = n1 / 2; std::vector<double> t(4 * (size_t)nh);
+    for (int q = 0; q < nh; ++q) { const double a1 = -pi * (4. * q + 1.) / (4. * n1), a2 = -pi * q / (double)n1;
+                                   t[2 * q] = std::cos(a1); t[2 * q + 1] = std::sin(a1); t[2 * (nh + q)] = std::cos(a2); t[2 * (nh + q) + 1] = std::sin(a2); }
+    HIPCHK(c, hipMalloc(&c->d_tw4x, t.size() * sizeof(double)));
+    HIPCHK(c, hipMemcpy(c->d_tw4x, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  if ((V.ykind == 3 || V.ykind == 4) && !c->d_tw4y) {
+    if (!make_plan(n2g / 2, sp.py4)) { c->err = "helmholtz: ng(2)/2 must factor into primes <= 127"; return 1; }
+    sp.CBy4 = 4; sp.shy4 = (size_t)2 * sp.CBy4 * 2 * (n2g / 2 + 1) * sizeof(cpx);
+    while (sp.shy4 > 60 * 1024 && sp.CBy4 > 1) { sp.CBy4 /= 2; sp.shy4 = (size_t)2 * sp.CBy4 * 2 * (n2g / 2 + 1) * sizeof(cpx); }
+    if (sp.shy4 > 64 * 1024) { c->err = "helmholtz: y line too long for the LDS-resident DCT-IV"; return 1; }
+    const int nh2 = n2g / 2; std::vector<double> t(4 * (size_t)nh2);
+    for (int q = 0; q < nh2; ++q) { const double a1 = -pi * (4. * q + 1.) / (4. * n2g), a2 = -pi * q / (double)n2g;
+                                    t[2 * q] = std::cos(a1); t[2 * q + 1] = std::sin(a1); t[2 * (nh2 + q)] = std::cos(a2); t[2 * (nh2 + q) + 1] = std::sin(a2); }
+    HIPCHK(c, hipMalloc(&c->d_tw4y, t.size() * sizeof(double)));
+    HIPCHK(c, hipMemcpy(c->d_tw4y, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (!c->d_twy4) { if (mk(n2g / 2, &c->d_twy4)) return 1; }
+  }
   V.ready = true;
   return 0;
 }
@@ -1454,10 +1507,11 @@ int op_helmholtz(cales_ctx *c, int ivel, double alpha) {
   PlanSlot *slot = find_slot(c);
   if (!slot) { c->err = "solver not initialised"; return 1; }
   VelSet &V = slot->vs[ivel - 1];
-  if (!V.ready) if (int e = velset_build(c, 0, ivel - 1, V)) return e;
+  if (!V.ready) if (int e = velset_build(c, slot->sp, ivel - 1, V)) return e;
   ProfScope ps(c, "helmholtz_xyz");
   const int n3 = c->n[2];
-  if (int e = op_rhs_b_velz(c, ivel, alpha)) return e;      // x and y boundary planes: homogeneous (cales_check_case) or periodic
+  if (int e = op_rhs_b_velxy(c, ivel, alpha)) return e;      // main.f90:424-431: boundary terms of the x and y faces, then z
+  if (int e = op_rhs_b_velz(c, ivel, alpha)) return e;
   double *abc = c->d_red + 64 + 16 * (n3 + 2);
   hipLaunchKernelGGL(k_scale_abc, dim3((n3 + 63) / 64), dim3(64), 0, c->stream, n3, alpha, c->d_av[ivel - 1], c->d_bv[ivel - 1], c->d_cv[ivel - 1], abc, abc + n3, abc + 2 * n3);
   const char *bcz = &c->cbcvel[6 * (ivel - 1) + 4];

@@ -91,7 +91,7 @@ int cales_fillps(cales_ctx *ctx, double dtrki);                             /* s
 int cales_updt_rhs_b(cales_ctx *ctx);                                       /* src/bound.f90:562, pressure r.h.s. */
 int cales_solver(cales_ctx *ctx);                                           /* src/solver.f90:20 on CALES_PP */
 int cales_helmholtz_z(cales_ctx *ctx, int ivel, double alpha);              /* main.f90:425-445: updt_rhs_b + solver_gaussel_z */
-int cales_helmholtz(cales_ctx *ctx, int ivel, double alpha);                /* impdiff = 1, main.f90:423-491: updt_rhs_b + solver on a velocity component (periodic x,y) */
+int cales_helmholtz(cales_ctx *ctx, int ivel, double alpha);                /* impdiff = 1, main.f90:423-491: cmpt_rhs_b + updt_rhs_b (x, y, z faces) + solver on a velocity component, any BC pair of find_fft */
 int cales_correc(cales_ctx *ctx, double dtrk);                              /* src/correc.f90:14  */
 int cales_updatep(cales_ctx *ctx, double alpha);                            /* src/updatep.f90:14 */
 int cales_cmpt_sgs(cales_ctx *ctx);                                         /* src/sgs.f90:21     */

@@ -882,9 +882,9 @@ void o_solver_gaussel_z(ostate *s, int ivel, double alpha, double *q) {  /* solv
 }
 
 /* 3-D implicit diffusion (_IMPDIFF without _IMPDIFF_1D), main.f90:423-491: (1 + alpha L) q = q* for one velocity component
- * through solver.f90:20-80 with lambdaxy*alpha and aa,bb,cc = a*alpha, b*alpha+1, c*alpha. Restated for x and y PERIODIC,
- * where transforms, eigenvalues and normalisation do not depend on the staggering of the component (initsolver.f90:66-98)
- * and equal those of the pressure; other BC sets need the face-centred transform kinds and return 1. */
+ * through solver.f90:20-80 with lambdaxy*alpha and aa,bb,cc = a*alpha, b*alpha+1, c*alpha, and the transform kinds, sizes,
+ * eigenvalues and normalisation of the component: find_fft / eigenvalues with c_or_f = 'f' along its own direction
+ * (initsolver.f90:66-98, fft.f90:63-143,192-245). */
 int o_solver_helmholtz(ostate *s, int ivel, double alpha, double *q) {
   const int *n = s->n; const size_t s1 = s->s1, s2 = s->s2; int n3 = n[2];
   const char *bcv = &s->cbcvel[6*(ivel-1)];

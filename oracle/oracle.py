@@ -164,6 +164,10 @@ class Oracle:
     def updt_rhs_b_velz(self, ivel, alpha, q):
         self.lib.o_updt_rhs_b_velz(self.h, int(ivel), C.c_double(alpha), _p(q))
 
+    def updt_rhs_b_vel(self, ivel, alpha, q):
+        """Boundary terms of all three directions for the 3-D implicit step (main.f90:424-431)."""
+        self.lib.o_updt_rhs_b_vel(self.h, int(ivel), C.c_double(alpha), _p(q))
+
     def solver(self, pp):
         self.lib.o_solver(self.h, _p(pp))
 
@@ -174,9 +178,9 @@ class Oracle:
         self.lib.o_solver_gaussel_z(self.h, int(ivel), C.c_double(alpha), _p(q))
 
     def solver_helmholtz(self, ivel, alpha, q):
-        """(1 + alpha L) q = q* of main.f90:423-491 (3-D implicit diffusion); x and y periodic only."""
+        """(1 + alpha L) q = q* of main.f90:423-491 (3-D implicit diffusion) with the component's own transform kinds."""
         if self.lib.o_solver_helmholtz(self.h, int(ivel), C.c_double(alpha), _p(q)):
-            raise ValueError("o_solver_helmholtz: needs periodic x and y")
+            raise ValueError("o_solver_helmholtz failed")
 
     def correc(self, dtrk, pp, u, v, w):
         self.lib.o_correc(self.h, C.c_double(dtrk), _p(pp), _p(u), _p(v), _p(w))

@@ -378,6 +378,87 @@ def test_helmholtz_3d_with_walls(name, ng, ivel):
     h.close()
 
 
+def _open_case(xset, yset, ng, inflow=True):
+    """devchan_nd with other BC pairs: xset / yset = (pair of the normal velocity, pair of the two tangential ones) in x / y, None = periodic; the
+    pressure takes the complementary pair of the normal velocity (sanity.f90:140-189), z keeps its walls. Dirichlet faces get non-zero values."""
+    g, case = load_golden("devchan_nd")
+    case.ng[:] = ng; case.impdiff = 1; case.sgstype = "none"; case.lwm[:] = 0
+    case.bcvel[:] = 0.; case.bcpre[:] = 0.
+    comp = {"D": "N", "N": "D", "P": "P"}
+    for d, pairs in ((0, xset), (1, yset)):
+        for iv in range(3):
+            pr = "PP" if pairs is None else (pairs[0] if iv == d else pairs[1])
+            for side in (0, 1):
+                case.cbcvel[side, d, iv] = pr[side]
+                if inflow and pr[side] == "D":
+                    case.bcvel[side, d, iv] = (0.7, 0.3, -0.2)[iv] * (1. if side == 0 else -0.5)
+        prn = "PP" if pairs is None else pairs[0]
+        for side in (0, 1):
+            case.cbcpre[side, d] = comp[prn[side]]
+    case.cbcsgs[:] = np.where(case.cbcvel[:, :, 0] == "P", "P", "D")
+    case.is_forced[:] = False; case.bforce[:] = 0.
+    return case
+
+
+OPEN_SETS = [(("DN", "NN"), None, (16, 12, 10)),      # the developing channel: inflow / outflow (RODFT01/10 along u, REDFT10/01 across)
+             (("DN", "DN"), None, (24, 8, 12)),       # tangential components Dirichlet at the inflow (RODFT11)
+             (("ND", "ND"), None, (16, 12, 10)),      # REDFT10/01 with half-integer eigenvalues along u, REDFT11 across
+             (("NN", "DD"), None, (18, 10, 10)),      # REDFT00 along u (2 (n-1)-point extension: 34 = 2 x 17)
+             (None, ("DN", "NN"), (12, 16, 10)),      # the same along y
+             (None, ("ND", "DN"), (12, 24, 10)),
+             (None, ("NN", "ND"), (10, 18, 12)),
+             (("DN", "NN"), ("DD", "DD"), (16, 12, 10)),      # inflow / outflow between side walls
+             (("DD", "DD"), ("DN", "DN"), (12, 16, 10))]
+
+
+@pytest.mark.parametrize("xset,yset,ng", OPEN_SETS)
+@pytest.mark.parametrize("ivel", [1, 2, 3])
+def test_helmholtz_3d_open_boundaries(xset, yset, ng, ivel):
+    """cales_helmholtz with open boundaries / inflow profiles / moving side walls in x and y: every BC pair of find_fft (fft.f90:192-245) for
+    the component's own direction (face-centred: REDFT00, RODFT00, REDFT10/01, RODFT01/10) and across it (the pressure's kinds), with the
+    boundary terms of the x and y faces (bc_rhs / updt_rhs_b, bound.f90:501-603), against the oracle's restatement of the same."""
+    case = _open_case(xset, yset, ng)
+    o = Oracle(case, nthreads=4); h = _hot(case)
+    nn = list(ng)
+    for d in range(2):
+        if d == ivel - 1 and case.cbcvel[0, d, ivel - 1] == "D" and case.cbcvel[1, d, ivel - 1] == "D":
+            nn[d] -= 1
+    if ivel == 3:
+        nn[2] -= 1
+    rng = np.random.RandomState(30 + ivel)
+    rhs = o.zeros(); rhs[1:nn[0] + 1, 1:nn[1] + 1, 1:nn[2] + 1] = rng.rand(*nn) - 0.5
+    alpha = -0.21
+    ref = rhs.copy(order="F"); o.updt_rhs_b_vel(ivel, alpha, ref); o.solver_helmholtz(ivel, alpha, ref)
+    h.set("uvw"[ivel - 1], rhs); h.helmholtz(ivel, alpha)
+    got = h.get("uvw"[ivel - 1])
+    a = got[1:nn[0] + 1, 1:nn[1] + 1, 1:nn[2] + 1]; b = ref[1:nn[0] + 1, 1:nn[1] + 1, 1:nn[2] + 1]
+    assert np.abs(a - b).max() < 1e-12 * np.abs(b).max(), (xset, yset, ng, ivel)
+    h.close()
+
+
+@pytest.mark.parametrize("xset,yset,ng", [OPEN_SETS[0], OPEN_SETS[1], OPEN_SETS[4], OPEN_SETS[7]])
+def test_time_steps_imp3d_open(xset, yset, ng):
+    """Three steps of an inflow / outflow box with 3-D implicit diffusion (impdiff = 1): momentum split, boundary terms of the inflow faces,
+    Helmholtz solves with the open-boundary transform kinds, pressure solve (REDFT11 / RODFT11), against the oracle."""
+    case = _open_case(xset, yset, ng)
+    o = Oracle(case, nthreads=8); h = _hot(case)
+    rng = np.random.RandomState(4)
+    u, v, w, p = (o.zeros() for _ in range(4))
+    for a, m in ((u, 0.7), (v, 0.3), (w, 0.)):
+        a[1:-1, 1:-1, 1:-1] = m + 0.05 * (rng.rand(*ng) - 0.5)
+    h.upload(u, v, w, p); h.startup()
+    visct, pp = o.zeros(), o.zeros()
+    o.bounduvw(u, v, w, True, False); o.boundp(p, 0); o.cmpt_sgs(u, v, w, visct); o.boundp(visct, 1)
+    dt = 0.4 * o.chkdt(visct, u, v, w)
+    for _ in range(3):
+        h.step(dt); o.step(dt, u, v, w, p, pp, visct)
+    gu, gv, gw, gp, _ = h.download()
+    for a, b, nm in ((gu, u, "u"), (gv, v, "v"), (gw, w, "w")):
+        assert relerr(a, b) < 1e-9, nm
+    assert relerr(gp[1:-1, 1:-1, 1:-1], p[1:-1, 1:-1, 1:-1]) < 1e-8
+    h.close()
+
+
 @pytest.mark.parametrize("name,ng,sgs", [("cavity_nnn", (32, 16, 12), "none"), ("cavity_nnn", (20, 36, 10), "none"), ("duct_smag_wm", (16, 24, 20), "smag")])
 def test_time_steps_imp3d_with_walls(name, ng, sgs):
     """Three steps with 3-D implicit diffusion (impdiff = 1) in a lid-driven cavity and a duct without wall model: momentum split,

@@ -150,10 +150,12 @@ def test_check_case_rules():
         check_case(ok)
     ok = load_golden("duct_smag_wm")[1]; ok.impdiff = 1; ok.lwm[:] = 0      # walls in y (no wall model)
     check_case(ok)
-    bad = ok.copy(); bad.bcvel[0, 1, 0] = 0.3                  # ... but no moving wall in x or y
-    with pytest.raises(CalesError):
-        check_case(bad)
-    bad = load_golden("devchan_nd")[1]; bad.impdiff = 1; bad.cbcsgs[:, 0] = "D"      # ... and no open boundary
+    ok2 = ok.copy(); ok2.bcvel[0, 1, 0] = 0.3                  # ... a moving wall in y
+    check_case(ok2)
+    ok2 = load_golden("devchan_nd")[1]; ok2.impdiff = 1; ok2.cbcsgs[:, 0] = "D"      # ... and an open boundary (inflow / outflow in x)
+    check_case(ok2)
+    bad = ok2.copy(); bad.cbcvel[:, 1, :] = "D"; bad.cbcvel[1, 1, 0] = "N"; bad.cbcvel[1, 1, 2] = "N"; bad.cbcpre[:, 1] = "N"; bad.cbcsgs[:, 1] = "D"
+    bad.ng[1] = 9                                              # ND/DN pairs across y go through half-length lines: even ng(2) only
     with pytest.raises(CalesError):
         check_case(bad)
     with pytest.raises(CalesError):
