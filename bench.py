@@ -157,7 +157,10 @@ def main():
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
 
+    from cales_amd import capi
     from cales_amd.hotpath import initflow
+    capi_single = capi.SINGLE                      # CALES_PRECISION=single: the -D_SINGLE_PRECISION build (not the headline number: BASELINE.json quotes FP64)
+    RB = 4.0 if capi_single else 8.0               # bytes per real
     case = channel_case(a.ng, a.sgs)
     if world == 1:
         from cales_amd.hotpath import HotPath
@@ -223,7 +226,7 @@ def main():
         leaf = {k: v for k, v in stats.items() if k in WORDS and v[0] > 0}
         dom = max(leaf, key=lambda k: leaf[k][1])
         calls, ms = leaf[dom]
-        ach = WORDS[dom] * 8.0 * nloc / (ms / calls * 1e-3)
+        ach = WORDS[dom] * RB * nloc / (ms / calls * 1e-3)
         # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (profiles/summarize.py), if present
         traffic, traffic_src = None, None
         try:
@@ -245,26 +248,26 @@ def main():
         out = {
             "metric": "time-steps/sec", "value": a.steps / t, "unit": "time-steps/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_step, "ms_per_step_with_kernel_events": 1e3 * t_prof / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f32" if capi_single else "f64", "data": "synthetic",
             "config": {"workload": f"turbulent channel {case.ng[0]}x{case.ng[1]}x{case.ng[2]}, sgstype={case.sgstype}, "
                                    "PP/PP/NN pressure BCs, bulk forcing in x (BASELINE.json configs[2]); 3 RK substeps/step",
                        "decomposition": f"y-slabs x{world}" if world > 1 else "single GPU", "dt": dt,
                        "exchanges": ("RCCL from the library" if getattr(h, "native", False) else "torch.distributed callbacks") if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": ach / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": WORDS[dom] * 8.0 * nloc, "avg_launch_ms": ms / calls, "launches": calls},
+                         "algorithmic_bytes_per_launch": WORDS[dom] * RB * nloc, "avg_launch_ms": ms / calls, "launches": calls},
             "poisson_solve": {"ms": solve_ms, "words_per_cell": solve_words, "passes": solve_note,
-                              "algorithmic_GBps": solve_words * 8.0 * nloc / (solve_ms * 1e-3) / 1e9 if solve_ms else None,
-                              "frac_of_hbm_peak": solve_words * 8.0 * nloc / (solve_ms * 1e-3) / HBM_PEAK if solve_ms else None},
+                              "algorithmic_GBps": solve_words * RB * nloc / (solve_ms * 1e-3) / 1e9 if solve_ms else None,
+                              "frac_of_hbm_peak": solve_words * RB * nloc / (solve_ms * 1e-3) / HBM_PEAK if solve_ms else None},
             # north_star: ">= 50 % of the HBM roofline on the Poisson + RK sweep": one (fillps +) solve + one fused
             # momentum/RK pass (its compulsory words, averaged over the three substeps) over the time of exactly those kernels
-            "poisson_plus_rk": (lambda ms, w: {"ms": ms, "words_per_cell": w, "algorithmic_GBps": w * 8.0 * nloc / (ms * 1e-3) / 1e9,
-                                               "frac_of_hbm_peak": w * 8.0 * nloc / (ms * 1e-3) / HBM_PEAK})(
+            "poisson_plus_rk": (lambda ms, w: {"ms": ms, "words_per_cell": w, "algorithmic_GBps": w * RB * nloc / (ms * 1e-3) / 1e9,
+                                               "frac_of_hbm_peak": w * RB * nloc / (ms * 1e-3) / HBM_PEAK})(
                 solve_ms + stats["mom_rk_fused"][1] / stats["mom_rk_fused"][0], solve_words + WORDS["mom_rk_fused"]) if solve_ms and stats.get("mom_rk_fused", (0, 0))[0] else None,
             # traffic the reference's kernel-per-loop sequence would move for the same step, over the measured time: >1 is
             # possible and only says that fusion removed traffic; it is NOT a roofline fraction
-            "step_vs_reference_traffic": {"reference_GB_per_step": 3 * 8.0 * ncell * W_STEP[case.sgstype] / 1e9,
-                                          "equivalent_frac_of_hbm_peak": 3 * 8.0 * ncell * W_STEP[case.sgstype] / (t / a.steps) / (world * HBM_PEAK)},
+            "step_vs_reference_traffic": {"reference_GB_per_step": 3 * RB * ncell * W_STEP[case.sgstype] / 1e9,
+                                          "equivalent_frac_of_hbm_peak": 3 * RB * ncell * W_STEP[case.sgstype] / (t / a.steps) / (world * HBM_PEAK)},
             "kernels_ms_per_step": {k: round(v[1] / a.steps, 4) for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])},
             "divmax": divmax,
             "icheck": {"every": icheck, "blocks_in_timed_region": sum(1 for c in checks if a.warmup < c[0] <= a.warmup + a.steps),

@@ -39,34 +39,34 @@ void prof_flush(cales_ctx *c) {
 }
 
 // ------------------------------------------------------------------------------------------ helpers
-static int dev_alloc(cales_ctx *c, double **p, size_t n, bool zero = true) {
-  HIPCHK(c, hipMalloc(p, (n ? n : 1) * sizeof(double)));
-  if (zero) HIPCHK(c, hipMemset(*p, 0, (n ? n : 1) * sizeof(double)));
+static int dev_alloc(cales_ctx *c, real **p, size_t n, bool zero = true) {
+  HIPCHK(c, hipMalloc(p, (n ? n : 1) * sizeof(real)));
+  if (zero) HIPCHK(c, hipMemset(*p, 0, (n ? n : 1) * sizeof(real)));
   return 0;
 }
 // 3-D fields: pitch-padded rows, shifted so that element (1,j,k) sits on a 128-B boundary (see cales_create). (Skewing the start of
 // every field by a different number of cache lines, so that the same cell of different fields does not fall on the same L2 set,
 // was measured at 512^3 with six strides and changed no kernel by more than the run-to-run noise.)
-static int field_alloc(cales_ctx *c, double **p) {
-  double *base = nullptr;
-  if (dev_alloc(c, &base, c->ntot + 16)) return 1;
+static int field_alloc(cales_ctx *c, real **p) {
+  real *base = nullptr;
+  if (dev_alloc(c, &base, c->ntot + LINE_REALS)) return 1;
   *p = base + c->field_ofs;
   return 0;
 }
-static void field_free(cales_ctx *c, double *p) { if (p) hipFree(p - c->field_ofs); }
+static void field_free(cales_ctx *c, real *p) { if (p) hipFree(p - c->field_ofs); }
 // host layout (0:n1+1,0:n2+1,0:n3+1), x contiguous  <->  device layout with row pitch s1
-__global__ __launch_bounds__(256) void k_repack(Geom g, int to_device, double *__restrict__ dev, double *__restrict__ packed) {
+__global__ __launch_bounds__(256) void k_repack(Geom g, int to_device, real *__restrict__ dev, real *__restrict__ packed) {
   const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
   if (i > g.n1 + 1 || j > g.n2 + 1) return;
   const size_t h = (size_t)i + (size_t)(g.n1 + 2) * ((size_t)j + (size_t)(g.n2 + 2) * k);
   if (to_device) dev[g.ix(i, j, k)] = packed[h]; else packed[h] = dev[g.ix(i, j, k)];
 }
-static int upload_vec(cales_ctx *c, double **p, const std::vector<double> &v) {
+static int upload_vec(cales_ctx *c, real **p, const std::vector<real> &v) {
   if (dev_alloc(c, p, v.size(), false)) return 1;
-  HIPCHK(c, hipMemcpy(*p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(*p, v.data(), v.size() * sizeof(real), hipMemcpyHostToDevice));
   return 0;
 }
-static int upload_bound(cales_ctx *c, DBound &b, std::vector<double> h[3]) {
+static int upload_bound(cales_ctx *c, DBound &b, std::vector<real> h[3]) {
   return upload_vec(c, &b.x, h[0]) || upload_vec(c, &b.y, h[1]) || upload_vec(c, &b.z, h[2]);
 }
 static void free_bound(DBound &b) { hipFree(b.x); hipFree(b.y); hipFree(b.z); }
@@ -74,12 +74,12 @@ static void free_bound(DBound &b) { hipFree(b.x); hipFree(b.y); hipFree(b.z); }
 extern "C" {
 
 // ------------------------------------------------------------------------------------------ host-only helpers
-int cales_initgrid(int gtype, int n, double gr, double lz, double *dzc, double *dzf, double *zc, double *zf) {
+int cales_initgrid(int gtype, int n, real gr, real lz, real *dzc, real *dzf, real *zc, real *zf) {
   if (n < 1 || !dzc || !dzf || !zc || !zf) return 1;
   hs_initgrid(gtype, n, gr, lz, dzc, dzf, zc, zf);
   return 0;
 }
-int cales_initflow(const cales_case *cs, const char *inivel, int is_wallturb, double *u, double *v, double *w, double *p) {
+int cales_initflow(const cales_case *cs, const char *inivel, int is_wallturb, real *u, real *v, real *w, real *p) {
   if (!cs || !inivel || !u || !v || !w || !p) return 1;
   return hs_initflow(cs, inivel, is_wallturb, u, v, w, p, 0, 1);
 }
@@ -90,6 +90,7 @@ int cales_check_case(const cales_case *cs, char *msg, int msglen) {
   return rc;
 }
 
+int cales_real_size(void) { return (int)sizeof(real); }
 int cales_device_count(int *ndev) { if (!ndev) return 1; *ndev = 0; return hipGetDeviceCount(ndev) == hipSuccess ? 0 : 2; }
 int cales_set_device(int dev) { return hipSetDevice(dev) == hipSuccess ? 0 : 1; }
 
@@ -148,15 +149,15 @@ int cales_create(const cales_case *cs, void *stream, cales_ctx **out) {
   c->P = P; c->rank = r; c->per_y = cs->cbcpre[2] == 'P' && cs->cbcpre[3] == 'P';
   c->n[0] = cs->ng[0]; c->n[1] = cs->ng[1] / P; c->n[2] = cs->ng[2];
   c->lo[0] = 1; c->lo[1] = r * c->n[1] + 1; c->lo[2] = 1;
-  for (int d = 0; d < 3; ++d) { c->dl[d] = cs->l[d] / (double)(1.f * (float)cs->ng[d]); c->dli[d] = 1. / c->dl[d]; }   // param.f90:153-154
+  for (int d = 0; d < 3; ++d) { c->dl[d] = cs->l[d] / (real)(1.f * (float)cs->ng[d]); c->dli[d] = 1. / c->dl[d]; }   // param.f90:153-154
   c->visc = 1. / cs->visci;
   Geom &g = c->g;
   g.n1 = c->n[0]; g.n2 = c->n[1]; g.n3 = c->n[2];
-  // Row pitch: a multiple of 16 doubles (128 B) with room for the n1/2+1 complex modes of a row stored from i = 1; with the
-  // 15-double offset of dev_alloc, element i = 1 of every row is 128-B aligned, so kernels whose waves handle 64 consecutive
+  // Row pitch: a multiple of one cache line (128 B = 16 doubles / 32 floats) with room for the n1/2+1 complex modes of a row stored from i = 1; with the
+  // one-line-minus-one-element offset of dev_alloc, element i = 1 of every row is 128-B aligned, so kernels whose waves handle 64 consecutive
   // cells from i = 1 read and write whole cache lines (partial-line writes cost ~1.5x, tools/micro/wrtile.hip).
-  g.s1 = c->fl.unaligned ? g.n1 + 4 - (g.n1 & 1) : (g.n1 + 3 + 15) / 16 * 16;
-  c->field_ofs = c->fl.unaligned ? 0 : 15;
+  g.s1 = c->fl.unaligned ? g.n1 + 4 - (g.n1 & 1) : (g.n1 + 3 + LINE_REALS - 1) / LINE_REALS * LINE_REALS;
+  c->field_ofs = c->fl.unaligned ? 0 : LINE_REALS - 1;
   g.s12 = (long)g.s1 * (g.n2 + 2); g.jlo = c->lo[1] - 1; g.ng2 = cs->ng[1];
   c->ntot = (size_t)g.s12 * (g.n3 + 2);
   const int n3 = c->n[2];
@@ -179,14 +180,14 @@ int cales_create(const cales_case *cs, void *stream, cales_ctx **out) {
     const bool per_z = cs->cbcpre[4] == 'P' && cs->cbcpre[5] == 'P';
     c->is_bound[4] = c->is_bound[5] = per_z ? 0 : 1; }
   // boundary-condition tables (bound.f90:726-867)
-  std::vector<double> hb[11][3];
+  std::vector<real> hb[11][3];
   hs_initbc(c, hb);
   for (int q = 0; q < 11; ++q) if (upload_bound(c, *bs[q], hb[q])) return fail(6);
   // pressure boundary r.h.s. (main.f90:317, bound.f90:447-499)
   { const int *n = c->n;
-    const double dx01[2] = {c->dl[0], c->dl[0]}, dy01[2] = {c->dl[1], c->dl[1]};
-    const double dzc01[2] = {c->dzc[0], c->dzc[n3]}, dzf01[2] = {c->dzf[1], c->dzf[n3]};
-    std::vector<double> rx((size_t)n[1] * n[2] * 2), ry((size_t)n[0] * n[2] * 2), rz((size_t)n[0] * n[1] * 2);
+    const real dx01[2] = {c->dl[0], c->dl[0]}, dy01[2] = {c->dl[1], c->dl[1]};
+    const real dzc01[2] = {c->dzc[0], c->dzc[n3]}, dzf01[2] = {c->dzf[1], c->dzf[n3]};
+    std::vector<real> rx((size_t)n[1] * n[2] * 2), ry((size_t)n[0] * n[2] * 2), rz((size_t)n[0] * n[1] * 2);
     hs_bc_rhs(&cs->cbcpre[0], hb[3][0].data(), n[1], n[2], dx01, dx01, 'c', rx.data());
     hs_bc_rhs(&cs->cbcpre[2], hb[3][1].data(), n[0], n[2], dy01, dy01, 'c', ry.data());
     hs_bc_rhs(&cs->cbcpre[4], hb[3][2].data(), n[0], n[1], dzc01, dzf01, 'c', rz.data());
@@ -199,7 +200,7 @@ int cales_create(const cales_case *cs, void *stream, cales_ctx **out) {
   c->red_blocks = 8;
   if (dev_alloc(c, &c->d_red, 64 + 16 * (size_t)(n3 + 2) + 6 * (size_t)(n3 + 2)) || dev_alloc(c, &c->d_force, 8)) return fail(10);
   c->res = c->d_red;
-  if (hipHostMalloc((void **)&c->h_red, 64 * sizeof(double)) != hipSuccess) { c->err = "hipHostMalloc failed"; return fail(11); }
+  if (hipHostMalloc((void **)&c->h_red, 64 * sizeof(real)) != hipSuccess) { c->err = "hipHostMalloc failed"; return fail(11); }
   // sgs scratch (sgs.f90:70-83,154-171)
   for (int d = 1; d <= 3; ++d) for (int s = 0; s <= 1; ++s) c->is_wall[s + 2 * (d - 1)] = (ISB(c, s, d) && CBV(c, s, d, d) == 'D') ? 1. : 0.;
   // wall flags are global properties of the case, not of the slab (distances use global indices)
@@ -225,30 +226,30 @@ int cales_sync(cales_ctx *c) { HIPCHK(c, hipStreamSynchronize(c->stream)); retur
 int cales_local_size(const cales_ctx *c, int32_t n[3], int32_t lo[3]) { for (int d = 0; d < 3; ++d) { n[d] = c->n[d]; lo[d] = c->lo[d]; } return 0; }
 
 // ------------------------------------------------------------------------------------------ copies
-int cales_set_field(cales_ctx *c, int field, const double *host) {
+int cales_set_field(cales_ctx *c, int field, const real *host) {
   if (field < 0 || field >= CALES_NFIELDS || !c->f[field]) { c->err = "bad field id"; return 1; }
   if (field == CALES_VISCT) { c->visct_zero = false; c->visct_lazy = false; }
   const size_t nh = (size_t)(c->n[0] + 2) * (c->n[1] + 2) * (c->n[2] + 2);
   const dim3 b(64, 4, 1), gr((c->n[0] + 2 + 63) / 64, (c->n[1] + 2 + 3) / 4, c->n[2] + 2);
-  HIPCHK(c, hipMemcpyAsync(c->scr1, host, nh * sizeof(double), hipMemcpyHostToDevice, c->stream));     // scr1: scratch between operators
+  HIPCHK(c, hipMemcpyAsync(c->scr1, host, nh * sizeof(real), hipMemcpyHostToDevice, c->stream));     // scr1: scratch between operators
   hipLaunchKernelGGL(k_repack, gr, b, 0, c->stream, c->g, 1, c->f[field], c->scr1);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }
-int cales_get_field(cales_ctx *c, int field, double *host) {
+int cales_get_field(cales_ctx *c, int field, real *host) {
   if (field < 0 || field >= CALES_NFIELDS || !c->f[field]) { c->err = "bad field id"; return 1; }
   if (field == CALES_VISCT) if (int e = materialize_visct(c)) return e;
   const size_t nh = (size_t)(c->n[0] + 2) * (c->n[1] + 2) * (c->n[2] + 2);
   const dim3 b(64, 4, 1), gr((c->n[0] + 2 + 63) / 64, (c->n[1] + 2 + 3) / 4, c->n[2] + 2);
   hipLaunchKernelGGL(k_repack, gr, b, 0, c->stream, c->g, 0, c->f[field], c->scr1);
-  HIPCHK(c, hipMemcpyAsync(host, c->scr1, nh * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(host, c->scr1, nh * sizeof(real), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }
-int cales_upload_state(cales_ctx *c, const double *u, const double *v, const double *w, const double *p) {
+int cales_upload_state(cales_ctx *c, const real *u, const real *v, const real *w, const real *p) {
   return cales_set_field(c, CALES_U, u) || cales_set_field(c, CALES_V, v) || cales_set_field(c, CALES_W, w) || cales_set_field(c, CALES_P, p);
 }
-int cales_download_state(cales_ctx *c, double *u, double *v, double *w, double *p, double *visct) {
+int cales_download_state(cales_ctx *c, real *u, real *v, real *w, real *p, real *visct) {
   if (u && cales_get_field(c, CALES_U, u)) return 1;
   if (v && cales_get_field(c, CALES_V, v)) return 1;
   if (w && cales_get_field(c, CALES_W, w)) return 1;
@@ -256,12 +257,12 @@ int cales_download_state(cales_ctx *c, double *u, double *v, double *w, double *
   if (visct && cales_get_field(c, CALES_VISCT, visct)) return 1;
   return 0;
 }
-int cales_get_bcvel(cales_ctx *c, int ivel, double *x, double *y, double *z) {
+int cales_get_bcvel(cales_ctx *c, int ivel, real *x, real *y, real *z) {
   const DBound &b = ivel == 1 ? c->bcu : ivel == 2 ? c->bcv : c->bcw; const int *n = c->n;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(x, b.x, sizeof(double) * (size_t)(n[1] + 2) * (n[2] + 2) * 2, hipMemcpyDeviceToHost));
-  HIPCHK(c, hipMemcpy(y, b.y, sizeof(double) * (size_t)(n[0] + 2) * (n[2] + 2) * 2, hipMemcpyDeviceToHost));
-  HIPCHK(c, hipMemcpy(z, b.z, sizeof(double) * (size_t)(n[0] + 2) * (n[1] + 2) * 2, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(x, b.x, sizeof(real) * (size_t)(n[1] + 2) * (n[2] + 2) * 2, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(y, b.y, sizeof(real) * (size_t)(n[0] + 2) * (n[2] + 2) * 2, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(z, b.z, sizeof(real) * (size_t)(n[0] + 2) * (n[1] + 2) * 2, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -273,53 +274,53 @@ int cales_boundp(cales_ctx *c, int field, int which) {
   if (field < 0 || field >= CALES_NFIELDS || !c->f[field]) { c->err = "bad field id"; return 1; }
   return op_boundp(c, c->f[field], which);
 }
-int cales_get_forcing(cales_ctx *c, double f[3]);
+int cales_get_forcing(cales_ctx *c, real f[3]);
 int cales_mom(cales_ctx *c) { return op_mom(c); }
-int cales_rk(cales_ctx *c, int irk, double dt) { if (irk < 1 || irk > 3) { c->err = "irk must be 1..3"; return 1; } return op_rk(c, irk, dt); }
-int cales_rk_par(cales_ctx *c, const double rkpar[2], double dt, double f_out[3]) {
+int cales_rk(cales_ctx *c, int irk, real dt) { if (irk < 1 || irk > 3) { c->err = "irk must be 1..3"; return 1; } return op_rk(c, irk, dt); }
+int cales_rk_par(cales_ctx *c, const real rkpar[2], real dt, real f_out[3]) {
   if (!rkpar) { c->err = "cales_rk_par: rkpar is NULL"; return 1; }
   if (int e = op_rk_par(c, rkpar[0], rkpar[1], dt)) return e;
   return f_out ? cales_get_forcing(c, f_out) : 0;
 }
 int cales_bulk_forcing(cales_ctx *c) { return op_bulk_forcing(c); }
-int cales_get_forcing(cales_ctx *c, double f[3]) {
-  HIPCHK(c, hipMemcpyAsync(c->h_red + 32, c->d_force, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+int cales_get_forcing(cales_ctx *c, real f[3]) {
+  HIPCHK(c, hipMemcpyAsync(c->h_red + 32, c->d_force, 3 * sizeof(real), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int q = 0; q < 3; ++q) f[q] = c->h_red[32 + q];
   return 0;
 }
-int cales_bulk_mean(cales_ctx *c, int field, int c_or_f, double *mean) {
+int cales_bulk_mean(cales_ctx *c, int field, int c_or_f, real *mean) {
   if (field < 0 || field >= CALES_NFIELDS || !c->f[field]) { c->err = "bad field id"; return 1; }
   if (int e = op_bulk_mean_dev(c, c->f[field], c_or_f, nullptr)) return e;
-  HIPCHK(c, hipMemcpyAsync(c->h_red + 16, c->res + 16, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_red + 16, c->res + 16, sizeof(real), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   *mean = c->h_red[16];
   return 0;
 }
-int cales_fillps(cales_ctx *c, double dtrki) { return op_fillps(c, dtrki); }
+int cales_fillps(cales_ctx *c, real dtrki) { return op_fillps(c, dtrki); }
 int cales_updt_rhs_b(cales_ctx *c) { return op_updt_rhs_b(c); }
 int cales_solver(cales_ctx *c) { return op_solver(c); }
-int cales_helmholtz(cales_ctx *c, int ivel, double alpha) { return op_helmholtz(c, ivel, alpha); }
-int cales_helmholtz_z(cales_ctx *c, int ivel, double alpha) { if (ivel < 1 || ivel > 3) { c->err = "ivel must be 1..3"; return 1; } return op_helmholtz_z(c, ivel, alpha); }
-int cales_correc(cales_ctx *c, double dtrk) { return op_correc(c, dtrk); }
-int cales_updatep(cales_ctx *c, double alpha) { return op_updatep(c, alpha); }
+int cales_helmholtz(cales_ctx *c, int ivel, real alpha) { return op_helmholtz(c, ivel, alpha); }
+int cales_helmholtz_z(cales_ctx *c, int ivel, real alpha) { if (ivel < 1 || ivel > 3) { c->err = "ivel must be 1..3"; return 1; } return op_helmholtz_z(c, ivel, alpha); }
+int cales_correc(cales_ctx *c, real dtrk) { return op_correc(c, dtrk); }
+int cales_updatep(cales_ctx *c, real alpha) { return op_updatep(c, alpha); }
 int cales_cmpt_sgs(cales_ctx *c) { return op_cmpt_sgs(c); }
-int cales_chkdt(cales_ctx *c, double *dtmax) { return op_chkdt(c, dtmax); }
-int cales_chkdiv(cales_ctx *c, double *divtot, double *divmax) { return op_chkdiv(c, divtot, divmax); }
-int cales_out1d_single_point_chan(cales_ctx *c, double *buf) { if (!c || !buf) return 1; return op_stats_chan(c, buf); }
-int cales_out1d_chan_budgets(cales_ctx *c, double *budget, double *leakage) { if (!c) return 1; return op_stats_chan_budget(c, budget, leakage); }
+int cales_chkdt(cales_ctx *c, real *dtmax) { return op_chkdt(c, dtmax); }
+int cales_chkdiv(cales_ctx *c, real *divtot, real *divmax) { return op_chkdiv(c, divtot, divmax); }
+int cales_out1d_single_point_chan(cales_ctx *c, real *buf) { if (!c || !buf) return 1; return op_stats_chan(c, buf); }
+int cales_out1d_chan_budgets(cales_ctx *c, real *budget, real *leakage) { if (!c) return 1; return op_stats_chan_budget(c, budget, leakage); }
 
 // ------------------------------------------------------------------------------------------ time step (main.f90:412-508)
-__global__ void k_zero6(double *f) { if (threadIdx.x < 6) f[threadIdx.x] = 0.; }
+__global__ void k_zero6(real *f) { if (threadIdx.x < 6) f[threadIdx.x] = 0.; }
 
-int cales_step(cales_ctx *c, double dt) {
-  static const double rk[3][2] = {{32. / 60., 0.}, {25. / 60., -17. / 60.}, {45. / 60., -25. / 60.}};
+int cales_step(cales_ctx *c, real dt) {
+  static const real rk[3][2] = {{32. / 60., 0.}, {25. / 60., -17. / 60.}, {45. / 60., -25. / 60.}};
   hipLaunchKernelGGL(k_zero6, dim3(1), dim3(64), 0, c->stream, c->d_force);     // dpdl(:) = 0
   c->in_step = true;
   struct Reset { cales_ctx *c; ~Reset() { c->in_step = false; c->defer_force = false; c->defer_imp_rhs = false; c->fuse_fillps_dti = 0.; c->fuse_mean_mask = 0; } } reset{c};      // also on the error returns
   for (int irk = 1; irk <= 3; ++irk) {
-    const double dtrk = (rk[irk - 1][0] + rk[irk - 1][1]) * dt, dtrki = 1. / dtrk;
-    double alpha = 0.;
+    const real dtrk = (rk[irk - 1][0] + rk[irk - 1][1]) * dt, dtrki = 1. / dtrk;
+    real alpha = 0.;
     // z-implicit diffusion: the Helmholtz sweeps form their r.h.s. themselves (k_gaussel_cols_rhs); needs the shared-pivot form
     const char *bz = &c->cbcvel[4];
     c->defer_imp_rhs = c->C.impdiff == 2 && !c->fl.helmholtz_z_per_column && !c->fl.unfused_imp_rhs &&
@@ -363,10 +364,10 @@ int cales_step(cales_ctx *c, double dt) {
   c->h_red[40] = dt;
   return 0;
 }
-int cales_get_dpdl(cales_ctx *c, double dpdl[3]) {
-  HIPCHK(c, hipMemcpyAsync(c->h_red + 32, c->d_force, 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+int cales_get_dpdl(cales_ctx *c, real dpdl[3]) {
+  HIPCHK(c, hipMemcpyAsync(c->h_red + 32, c->d_force, 6 * sizeof(real), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  const double dti = 1. / c->h_red[40];
+  const real dti = 1. / c->h_red[40];
   for (int q = 0; q < 3; ++q) dpdl[q] = -c->h_red[35 + q] * dti;
   return 0;
 }
@@ -381,13 +382,13 @@ int cales_comm_buffer_doubles(const cales_ctx *c, int64_t *n) {
   return 0;
 }
 int cales_set_comm(cales_ctx *c, cales_halo_cb halo, cales_alltoall_cb a2a, cales_allreduce_cb allred, void *user,
-                   double *bufA, double *bufB, int64_t nbuf) {
+                   real *bufA, real *bufB, int64_t nbuf) {
   int64_t need = 0; cales_comm_buffer_doubles(c, &need);
   if (!halo || !a2a || !allred || !bufA || !bufB || nbuf < need) { c->err = "cales_set_comm: missing callback/buffer or buffers too small"; return 1; }
   c->comm.halo = halo; c->comm.a2a = a2a; c->comm.allred = allred; c->comm.user = user;
   c->comm.A = bufA; c->comm.B = bufB; c->comm.nbuf = nbuf; c->comm.on = true;
-  HIPCHK(c, hipMemsetAsync(bufA, 0, nbuf * sizeof(double), c->stream));
-  HIPCHK(c, hipMemsetAsync(bufB, 0, nbuf * sizeof(double), c->stream));
+  HIPCHK(c, hipMemsetAsync(bufA, 0, nbuf * sizeof(real), c->stream));
+  HIPCHK(c, hipMemsetAsync(bufB, 0, nbuf * sizeof(real), c->stream));
   // reduction results live in the tail of A so that the host can all-reduce them in place
   const int64_t tail = CALES_RES_TAIL + 2 * (int64_t)(c->n[2] + 2);
   c->res = bufA + (nbuf - tail);
@@ -407,7 +408,7 @@ int cales_set_comm_overlap(cales_ctx *c, cales_halo_s_cb halo_s, cales_alltoall_
   c->comm.halo_s = halo_s; c->comm.a2a_part = a2a_part;
   return 0;
 }
-int cales_initflow_slab(const cales_case *cs, const char *inivel, int is_wallturb, double *u, double *v, double *w, double *p) {
+int cales_initflow_slab(const cales_case *cs, const char *inivel, int is_wallturb, real *u, real *v, real *w, real *p) {
   if (!cs || !inivel || !u || !v || !w || !p) return 1;
   return hs_initflow(cs, inivel, is_wallturb, u, v, w, p, cs->rank, cs->nranks);
 }
@@ -416,7 +417,7 @@ int cales_initflow_slab(const cales_case *cs, const char *inivel, int is_walltur
 int cales_profile_enable(cales_ctx *c, int on) { prof_flush(c); c->prof = on != 0; return 0; }
 int cales_profile_reset(cales_ctx *c) { prof_flush(c); c->stats.clear(); return 0; }
 int cales_profile_count(cales_ctx *c) { prof_flush(c); return (int)c->stats.size(); }
-int cales_profile_get(cales_ctx *c, int idx, char *name, int namelen, int64_t *calls, double *total_ms) {
+int cales_profile_get(cales_ctx *c, int idx, char *name, int namelen, int64_t *calls, real *total_ms) {
   prof_flush(c);
   if (idx < 0 || idx >= (int)c->stats.size()) return 1;
   if (name && namelen > 0) std::snprintf(name, namelen, "%s", c->stats[idx].name.c_str());

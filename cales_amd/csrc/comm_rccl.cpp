@@ -9,6 +9,12 @@
 //
 // RCCL is opened with dlopen: the library keeps loading (and the single-GPU path keeps working) where it is absent.
 #include "common.hpp"
+// ncclDataType_t of `real` (nccl.h: ncclFloat = 7, ncclDouble = 8)
+#ifdef CALES_SINGLE
+#define NCCL_REAL ncclFloat
+#else
+#define NCCL_REAL ncclDouble
+#endif
 #include <dlfcn.h>
 #include <link.h>
 #include <rccl/rccl.h>
@@ -61,7 +67,7 @@ bool load_api() {
   return ok;
 }
 
-struct NativeComm { ncclComm_t comm = nullptr; double *A = nullptr, *B = nullptr; };
+struct NativeComm { ncclComm_t comm = nullptr; real *A = nullptr, *B = nullptr; };
 
 #define NCHK(c, call)                                                                                     \
   do {                                                                                                    \
@@ -85,12 +91,12 @@ int native_halo_on(void *user, int64_t off_slo, int64_t off_shi, int64_t off_rlo
   // an error inside the group must still close it: an open group would queue every later collective of this thread for ever
   ncclResult_t rc = ncclSuccess;
   auto add = [&](ncclResult_t r) { if (rc == ncclSuccess) rc = r; };
-  if (lo >= 0) add(g_api.Send(nc->A + off_slo, (size_t)count, ncclDouble, lo, nc->comm, st));
+  if (lo >= 0) add(g_api.Send(nc->A + off_slo, (size_t)count, NCCL_REAL, lo, nc->comm, st));
   if (hi >= 0) {
-    add(g_api.Recv(nc->B + off_rhi, (size_t)count, ncclDouble, hi, nc->comm, st));
-    add(g_api.Send(nc->A + off_shi, (size_t)count, ncclDouble, hi, nc->comm, st));
+    add(g_api.Recv(nc->B + off_rhi, (size_t)count, NCCL_REAL, hi, nc->comm, st));
+    add(g_api.Send(nc->A + off_shi, (size_t)count, NCCL_REAL, hi, nc->comm, st));
   }
-  if (lo >= 0) add(g_api.Recv(nc->B + off_rlo, (size_t)count, ncclDouble, lo, nc->comm, st));
+  if (lo >= 0) add(g_api.Recv(nc->B + off_rlo, (size_t)count, NCCL_REAL, lo, nc->comm, st));
   add(g_api.GroupEnd());
   if (rc != ncclSuccess) { c->err = std::string("RCCL: ") + g_api.GetErrorString(rc) + " in the halo exchange"; return 1; }
   return 0;
@@ -106,13 +112,13 @@ int native_halo_s(void *user, int64_t off_slo, int64_t off_shi, int64_t off_rlo,
 int native_alltoall_part(void *user, int dir, int64_t peer_stride, int64_t off, int64_t count, void *stream) {
   cales_ctx *c = static_cast<cales_ctx *>(user);
   NativeComm *nc = static_cast<NativeComm *>(c->native_comm);
-  const double *src = dir == 0 ? nc->A : nc->B; double *dst = dir == 0 ? nc->B : nc->A;
+  const real *src = dir == 0 ? nc->A : nc->B; real *dst = dir == 0 ? nc->B : nc->A;
   hipStream_t st = static_cast<hipStream_t>(stream);
   NCHK(c, g_api.GroupStart());
   ncclResult_t rc = ncclSuccess;
   for (int p = 0; p < c->P; ++p) {
-    const ncclResult_t r1 = g_api.Send(src + (size_t)p * peer_stride + off, (size_t)count, ncclDouble, p, nc->comm, st);
-    const ncclResult_t r2 = g_api.Recv(dst + (size_t)p * peer_stride + off, (size_t)count, ncclDouble, p, nc->comm, st);
+    const ncclResult_t r1 = g_api.Send(src + (size_t)p * peer_stride + off, (size_t)count, NCCL_REAL, p, nc->comm, st);
+    const ncclResult_t r2 = g_api.Recv(dst + (size_t)p * peer_stride + off, (size_t)count, NCCL_REAL, p, nc->comm, st);
     if (rc == ncclSuccess) rc = r1 != ncclSuccess ? r1 : r2;
   }
   const ncclResult_t r3 = g_api.GroupEnd();
@@ -123,15 +129,15 @@ int native_alltoall_part(void *user, int dir, int64_t peer_stride, int64_t off, 
 int native_alltoall(void *user, int dir, int64_t count) {
   cales_ctx *c = static_cast<cales_ctx *>(user);
   NativeComm *nc = static_cast<NativeComm *>(c->native_comm);
-  const double *src = dir == 0 ? nc->A : nc->B; double *dst = dir == 0 ? nc->B : nc->A;
-  NCHK(c, g_api.AllToAll(src, dst, (size_t)count, ncclDouble, nc->comm, c->stream));
+  const real *src = dir == 0 ? nc->A : nc->B; real *dst = dir == 0 ? nc->B : nc->A;
+  NCHK(c, g_api.AllToAll(src, dst, (size_t)count, NCCL_REAL, nc->comm, c->stream));
   return 0;
 }
 int native_allreduce(void *user, int64_t off, int64_t count, int op) {
   cales_ctx *c = static_cast<cales_ctx *>(user);
   NativeComm *nc = static_cast<NativeComm *>(c->native_comm);
   const ncclRedOp_t rop = op == 0 ? ncclSum : (op == 1 ? ncclMax : ncclMin);
-  NCHK(c, g_api.AllReduce(nc->A + off, nc->A + off, (size_t)count, ncclDouble, rop, nc->comm, c->stream));
+  NCHK(c, g_api.AllReduce(nc->A + off, nc->A + off, (size_t)count, NCCL_REAL, rop, nc->comm, c->stream));
   return 0;
 }
 }  // namespace
@@ -161,7 +167,7 @@ int cales_comm_init_rccl(cales_ctx *c, const void *id_in) {
   const ncclResult_t r = g_api.CommInitRank(&nc->comm, c->P, id, c->rank);
   if (r != ncclSuccess) { c->err = std::string("ncclCommInitRank: ") + g_api.GetErrorString(r); delete nc; return 1; }
   int64_t n = 0; cales_comm_buffer_doubles(c, &n);
-  if (hipMalloc(&nc->A, n * sizeof(double)) != hipSuccess || hipMalloc(&nc->B, n * sizeof(double)) != hipSuccess) {
+  if (hipMalloc(&nc->A, n * sizeof(real)) != hipSuccess || hipMalloc(&nc->B, n * sizeof(real)) != hipSuccess) {
     c->err = "cales_comm_init_rccl: hipMalloc of the staging buffers failed"; g_api.CommDestroy(nc->comm); hipFree(nc->A); delete nc; return 1;
   }
   c->native_comm = nc;
@@ -185,25 +191,25 @@ int cales_comm_selftest(void) {
   ncclUniqueId id; ncclComm_t comm;
   if (g_api.GetUniqueId(&id) != ncclSuccess) return 101;
   if (g_api.CommInitRank(&comm, 1, id, 0) != ncclSuccess) return 102;
-  const size_t cnt = 1000; double *A = nullptr, *B = nullptr;
-  if (hipMalloc(&A, 4 * cnt * sizeof(double)) != hipSuccess || hipMalloc(&B, 4 * cnt * sizeof(double)) != hipSuccess) return 103;
-  std::vector<double> h(4 * cnt); for (size_t q = 0; q < 4 * cnt; ++q) h[q] = (double)q;
-  hipMemcpy(A, h.data(), 4 * cnt * sizeof(double), hipMemcpyHostToDevice); hipMemset(B, 0, 4 * cnt * sizeof(double));
+  const size_t cnt = 1000; real *A = nullptr, *B = nullptr;
+  if (hipMalloc(&A, 4 * cnt * sizeof(real)) != hipSuccess || hipMalloc(&B, 4 * cnt * sizeof(real)) != hipSuccess) return 103;
+  std::vector<real> h(4 * cnt); for (size_t q = 0; q < 4 * cnt; ++q) h[q] = (real)q;
+  hipMemcpy(A, h.data(), 4 * cnt * sizeof(real), hipMemcpyHostToDevice); hipMemset(B, 0, 4 * cnt * sizeof(real));
   hipStream_t s; hipStreamCreate(&s);
   int rc = 0;
   // the order of native_halo with lo = hi = 0
   if (g_api.GroupStart() != ncclSuccess) rc = 104;
-  if (!rc && g_api.Send(A, cnt, ncclDouble, 0, comm, s) != ncclSuccess) rc = 105;                 // my "lo" row
-  if (!rc && g_api.Recv(B + cnt, cnt, ncclDouble, 0, comm, s) != ncclSuccess) rc = 106;           // -> upper ghost
-  if (!rc && g_api.Send(A + cnt, cnt, ncclDouble, 0, comm, s) != ncclSuccess) rc = 107;           // my "hi" row
-  if (!rc && g_api.Recv(B, cnt, ncclDouble, 0, comm, s) != ncclSuccess) rc = 108;                 // -> lower ghost
+  if (!rc && g_api.Send(A, cnt, NCCL_REAL, 0, comm, s) != ncclSuccess) rc = 105;                 // my "lo" row
+  if (!rc && g_api.Recv(B + cnt, cnt, NCCL_REAL, 0, comm, s) != ncclSuccess) rc = 106;           // -> upper ghost
+  if (!rc && g_api.Send(A + cnt, cnt, NCCL_REAL, 0, comm, s) != ncclSuccess) rc = 107;           // my "hi" row
+  if (!rc && g_api.Recv(B, cnt, NCCL_REAL, 0, comm, s) != ncclSuccess) rc = 108;                 // -> lower ghost
   if (!rc && g_api.GroupEnd() != ncclSuccess) rc = 109;
-  if (!rc && g_api.AllToAll(A + 2 * cnt, B + 2 * cnt, cnt, ncclDouble, comm, s) != ncclSuccess) rc = 110;
-  if (!rc && g_api.AllReduce(A + 3 * cnt, A + 3 * cnt, cnt, ncclDouble, ncclSum, comm, s) != ncclSuccess) rc = 111;
+  if (!rc && g_api.AllToAll(A + 2 * cnt, B + 2 * cnt, cnt, NCCL_REAL, comm, s) != ncclSuccess) rc = 110;
+  if (!rc && g_api.AllReduce(A + 3 * cnt, A + 3 * cnt, cnt, NCCL_REAL, ncclSum, comm, s) != ncclSuccess) rc = 111;
   if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = 112;
   if (!rc) {
-    std::vector<double> b(4 * cnt), a(4 * cnt);
-    hipMemcpy(b.data(), B, 4 * cnt * sizeof(double), hipMemcpyDeviceToHost); hipMemcpy(a.data(), A, 4 * cnt * sizeof(double), hipMemcpyDeviceToHost);
+    std::vector<real> b(4 * cnt), a(4 * cnt);
+    hipMemcpy(b.data(), B, 4 * cnt * sizeof(real), hipMemcpyDeviceToHost); hipMemcpy(a.data(), A, 4 * cnt * sizeof(real), hipMemcpyDeviceToHost);
     for (size_t q = 0; q < cnt && !rc; ++q) {
       if (b[cnt + q] != h[q]) rc = 120;              // upper ghost = the (only) neighbour's lowest row
       else if (b[q] != h[cnt + q]) rc = 121;         // lower ghost = its highest row

@@ -10,8 +10,21 @@
 #include <vector>
 #include "../../include/cales.h"
 
+// The working precision rp of the reference (src/precision.f90:11-20): FP64, or FP32 when the library is built with -DCALES_SINGLE
+// (the reference's -D_SINGLE_PRECISION; libcales_hip_sp.so). `real` is cales_real of include/cales.h.
+typedef cales_real real;
+#ifdef CALES_SINGLE
+typedef float2 real2;
+#define CALES_EPS 1.1920929e-07f            /* epsilon(1._rp), reference src/param.f90:20 */
+#define CALES_BIG 3.4028235e38f             /* huge(1._rp), src/param.f90:25 */
+#else
+typedef double2 real2;
 #define CALES_EPS 2.220446049250313e-16     /* epsilon(1._rp), reference src/param.f90:20 */
 #define CALES_BIG 1.7976931348623157e308    /* huge(1._rp), src/param.f90:25 */
+#endif
+constexpr int RSZ = (int)sizeof(real);          // bytes per element: the byte offsets of ldb/stb
+constexpr int LINE_REALS = 128 / RSZ;           // elements per 128-B cache line (16 / 32): row pitch and field offset are laid out in lines
+__host__ __device__ inline real2 make_real2(real x, real y) { real2 r; r.x = x; r.y = y; return r; }
 
 struct Geom {              // passed by value to kernels
   int n1, n2, n3;          // local interior sizes
@@ -23,12 +36,12 @@ struct Geom {              // passed by value to kernels
   __host__ __device__ inline size_t ix(int i, int j, int k) const { return (size_t)i + (size_t)s1 * (size_t)j + (size_t)s12 * (size_t)k; }
 };
 
-struct DBound { double *x, *y, *z; };   // device BC planes (0:na+1,0:nb+1,0:1), reference src/typedef.f90:10-14
+struct DBound { real *x, *y, *z; };   // device BC planes (0:na+1,0:nb+1,0:1), reference src/typedef.f90:10-14
 
 // Communication hooks (include/cales.h): y-slab neighbours, slab<->mode-block all-to-all, all-reduce.
 struct Comm {
   cales_halo_cb halo = nullptr; cales_alltoall_cb a2a = nullptr; cales_allreduce_cb allred = nullptr; void *user = nullptr;
-  double *A = nullptr, *B = nullptr; int64_t nbuf = 0;   // two device staging buffers owned by the host (doubles)
+  real *A = nullptr, *B = nullptr; int64_t nbuf = 0;   // two device staging buffers owned by the host (doubles)
   bool on = false;
   cales_halo_s_cb halo_s = nullptr; cales_alltoall_part_cb a2a_part = nullptr;   // exchanges on the second stream (cales_set_comm_overlap)
 };
@@ -88,80 +101,80 @@ struct Flags {
   }
 };
 
-struct KernelStat { std::string name; int64_t calls = 0; double ms = 0.; };
+struct KernelStat { std::string name; int64_t calls = 0; real ms = 0.; };
 
 struct cales_ctx {
   cales_case C;
   Flags fl;
   Geom g;
   int n[3], lo[3];
-  double dl[3], dli[3], visc;
+  real dl[3], dli[3], visc;
   hipStream_t stream; bool own_stream;
   hipStream_t comm_stream = nullptr;      // exchanges that overlap kernels (created by cales_set_comm_overlap)
   std::vector<hipEvent_t> sync_ev; size_t sync_next = 0;      // ordering events between the two streams (no timing), reused round-robin
   std::string err;
   // host copies of the grid
-  std::vector<double> dzc, dzf, zc, zf, dzci, dzfi, gvr_c, gvr_f;
+  std::vector<real> dzc, dzf, zc, zf, dzci, dzfi, gvr_c, gvr_f;
   char cbcvel[18];
   int is_bound[6], index_wm[6];
   // device grid (0:n3+1)
-  double *d_dzc, *d_dzf, *d_zc, *d_zf, *d_dzci, *d_dzfi, *d_gvr_c, *d_gvr_f;
+  real *d_dzc, *d_dzf, *d_zc, *d_zf, *d_dzci, *d_dzfi, *d_gvr_c, *d_gvr_f;
   // fields
-  double *f[CALES_NFIELDS];
-  double *f2[3] = {nullptr, nullptr, nullptr};   // second velocity buffers of the fused mom+RK kernel (pointers are swapped with f[U..W])
+  real *f[CALES_NFIELDS];
+  real *f2[3] = {nullptr, nullptr, nullptr};   // second velocity buffers of the fused mom+RK kernel (pointers are swapped with f[U..W])
   size_t ntot;
   // BC planes
   DBound bcu, bcv, bcw, bcp, bcs, bcuf, bcvf, bcwf, bcu_mag, bcv_mag, bcw_mag;
-  double *rhsbp[3];        // (na,nb,0:1)
-  double *rhsbz_vel;       // scratch (n1,n2,0:1) for z-implicit Helmholtz r.h.s.
+  real *rhsbp[3];        // (na,nb,0:1)
+  real *rhsbz_vel;       // scratch (n1,n2,0:1) for z-implicit Helmholtz r.h.s.
   // solver
-  double *d_lamx, *d_lamy;     // eigenvalues per stored spectral index
-  double *d_a, *d_b, *d_c;     // tridiagonal (n3)
-  double *d_av[3], *d_bv[3], *d_cv[3];
-  double normfft;
+  real *d_lamx, *d_lamy;     // eigenvalues per stored spectral index
+  real *d_a, *d_b, *d_c;     // tridiagonal (n3)
+  real *d_av[3], *d_bv[3], *d_cv[3];
+  real normfft;
   int xkind, ykind;            // 0: periodic (r2c / c2c), 1: Neumann-Neumann cell-centred (DCT-II/III)
-  double *d_twx, *d_twy;       // twiddle tables
-  double *d_twx_post, *d_twy_post;    // d_twy_post: DCT weights of the x direction
-  double *scr_twyd = nullptr;           // DCT weights of the y direction
-  double *scr1, *scr2;         // solver scratch (haloed size)
+  real *d_twx, *d_twy;       // twiddle tables
+  real *d_twx_post, *d_twy_post;    // d_twy_post: DCT weights of the x direction
+  real *scr_twyd = nullptr;           // DCT weights of the y direction
+  real *scr1, *scr2;         // solver scratch (haloed size)
   // reductions
-  double *d_red; double *h_red;       // partial sums / results (pinned host)
-  double *d_force;                    // f(3) + dpdl(3) accumulators on device
+  real *d_red; real *h_red;       // partial sums / results (pinned host)
+  real *d_force;                    // f(3) + dpdl(3) accumulators on device
   int red_blocks;
   // sgs scratch
-  double *s0, *wk[6], *sij[6], *mij[6], *uc, *vc, *wc, *uf, *vf, *wf, *alph2, *d_p1d;
-  double is_wall[6];
+  real *s0, *wk[6], *sij[6], *mij[6], *uc, *vc, *wc, *uf, *vf, *wf, *alph2, *d_p1d;
+  real is_wall[6];
   bool sgs_first;
   // decomposition
   int P = 1, rank = 0; bool per_y = true; int cw = 0;      // cw: complex mode columns per rank (padded)
   Comm comm;
   bool p1d_in_comm = false;
-  double *res = nullptr;                // reduction results (inside comm.A when comm is on, so they can be all-reduced)
+  real *res = nullptr;                // reduction results (inside comm.A when comm is on, so they can be all-reduced)
   // profiling
   bool prof = false;
   std::vector<KernelStat> stats;
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evpool;
-  double *d_tw4x = nullptr;  // DCT-IV weights of the x transform (pressure ND / DN)
-  double *d_tw4y = nullptr, *d_twy4 = nullptr;      // the same for y, and the twiddles of its N/2-point lines
-  double *d_del = nullptr;   // Smagorinsky filter width per plane (fast path)
+  real *d_tw4x = nullptr;  // DCT-IV weights of the x transform (pressure ND / DN)
+  real *d_tw4y = nullptr, *d_twy4 = nullptr;      // the same for y, and the twiddles of its N/2-point lines
+  real *d_del = nullptr;   // Smagorinsky filter width per plane (fast path)
   void *native_comm = nullptr;   // RCCL communicator + staging buffers when the library does the exchanges itself (comm_rccl.cpp)
   bool visct_zero = true;  // CALES_VISCT still holds the zeros it was created / reset with (no SGS model: lets kernels skip it)
   // dynamic model, fast path: the eddy-viscosity field holds |S| and d_cs(0:n3+1) the clipped plane coefficients <LM>/<MM> until somebody
   // other than the fused momentum kernel reads it (materialize_visct); visct = |S| * cs(k) is the same product either way
-  bool visct_lazy = false; double *d_cs = nullptr;
+  bool visct_lazy = false; real *d_cs = nullptr;
   void *cur_velset = nullptr;       // k_solver.hip: transform set of the velocity component being solved by op_helmholtz
   bool in_step = false;             // inside cales_step: the operator order is known, dead ghost work can be dropped
   bool skip_rhs_store = false;      // cales_step, third substep: see MomRkArgs::wr_new
-  double *d_stat2 = nullptr;
-  double *d_stat = nullptr;      // partial sums and result of the plane statistics
+  real *d_stat2 = nullptr;
+  real *d_stat = nullptr;      // partial sums and result of the plane statistics
   bool abct_ready = false, force_zeroed = false;
-  double *d_abct = nullptr;      // tridiagonal coefficients in the chunked order of k_gaussel_tile
-  int fuse_mean_mask = 0; double *d_mpart = nullptr; size_t n_mpart = 0;      // bulk means of the forced components are summed by that pass too
-  double fuse_fillps_dti = 0.;   // != 0: the forward x transform of the next pressure solve forms pp = div(u*)/dtrk itself (cales_step)
+  real *d_abct = nullptr;      // tridiagonal coefficients in the chunked order of k_gaussel_tile
+  int fuse_mean_mask = 0; real *d_mpart = nullptr; size_t n_mpart = 0;      // bulk means of the forced components are summed by that pass too
+  real fuse_fillps_dti = 0.;   // != 0: the forward x transform of the next pressure solve forms pp = div(u*)/dtrk itself (cales_step)
   bool defer_force = false;      // explicit step, forced directions periodic, no wall model: u += f is applied by the correction kernel
-  bool defer_imp_rhs = false; double hf12 = 0.;   // z-implicit step: u -= hf12*dudtd and u += f are applied inside the Helmholtz sweep
-  bool defer_halo = false; std::vector<double *> deferred;      // y-halo exchanges collected for halo_flush_deferred (k_bound.hip)
+  bool defer_imp_rhs = false; real hf12 = 0.;   // z-implicit step: u -= hf12*dudtd and u += f are applied inside the Helmholtz sweep
+  bool defer_halo = false; std::vector<real *> deferred;      // y-halo exchanges collected for halo_flush_deferred (k_bound.hip)
   int bc_skip = 0;         // bit d-1: boundp/bounduvw leave direction d alone (set around calls whose consumers do not need it)
   int field_ofs = 0;       // doubles between a field's allocation and its element (0,0,0)
 };
@@ -196,41 +209,41 @@ struct ProfScope {
 };
 
 // ---- host-side set-up (host_setup.cpp)
-void   hs_initgrid(int gtype, int n, double gr, double lz, double *dzc, double *dzf, double *zc, double *zf);
-void   hs_initbc(cales_ctx *c, std::vector<double> hb[11][3]);
-void   hs_eigenvalues(int n, const char *cbc2, char c_or_f, double *lambda);
-void   hs_tridmatrix(const char *cbc2, int n, const double *dzci, const double *dzfi, char c_or_f, double *a, double *b, double *c);
-int    hs_initflow(const cales_case *cs, const char *inivel, int is_wallturb, double *u, double *v, double *w, double *p, int rank, int nranks);
+void   hs_initgrid(int gtype, int n, real gr, real lz, real *dzc, real *dzf, real *zc, real *zf);
+void   hs_initbc(cales_ctx *c, std::vector<real> hb[11][3]);
+void   hs_eigenvalues(int n, const char *cbc2, char c_or_f, real *lambda);
+void   hs_tridmatrix(const char *cbc2, int n, const real *dzci, const real *dzfi, char c_or_f, real *a, real *b, real *c);
+int    hs_initflow(const cales_case *cs, const char *inivel, int is_wallturb, real *u, real *v, real *w, real *p, int rank, int nranks);
 int    hs_check_case(const cales_case *cs, std::string &msg);
-void   hs_bc_rhs(const char *cbc2, const double *bc, int na, int nb, const double *dlc, const double *dlf, char c_or_f, double *rhs);
+void   hs_bc_rhs(const char *cbc2, const real *bc, int na, int nb, const real *dlc, const real *dlf, char c_or_f, real *rhs);
 
 // ---- device operators (k_*.hip); all asynchronous on c->stream
-int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm, int is_correc, double *u, double *v, double *w);
-int op_boundp(cales_ctx *c, double *p, int which);
+int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm, int is_correc, real *u, real *v, real *w);
+int op_boundp(cales_ctx *c, real *p, int which);
 int halo_flush_deferred(cales_ctx *c);
 int op_mom(cales_ctx *c);
-int op_rk(cales_ctx *c, int irk, double dt);
-int op_rk_par(cales_ctx *c, double rkpar1, double rkpar2, double dt);
-int op_momrk(cales_ctx *c, double f1, double f2, double f12);
+int op_rk(cales_ctx *c, int irk, real dt);
+int op_rk_par(cales_ctx *c, real rkpar1, real rkpar2, real dt);
+int op_momrk(cales_ctx *c, real f1, real f2, real f12);
 int op_bulk_forcing(cales_ctx *c);
-int op_bulk_mean_dev(cales_ctx *c, const double *p, int c_or_f, double *d_out);   // result to device scalar
-int op_fillps(cales_ctx *c, double dtrki);
+int op_bulk_mean_dev(cales_ctx *c, const real *p, int c_or_f, real *d_out);   // result to device scalar
+int op_fillps(cales_ctx *c, real dtrki);
 int op_updt_rhs_b(cales_ctx *c);
 int op_solver(cales_ctx *c);
-int op_helmholtz_z(cales_ctx *c, int ivel, double alpha);
+int op_helmholtz_z(cales_ctx *c, int ivel, real alpha);
 extern "C" void cales_comm_release_native(cales_ctx *c);
-int op_helmholtz(cales_ctx *c, int ivel, double alpha);
-int op_correc(cales_ctx *c, double dtrk);
+int op_helmholtz(cales_ctx *c, int ivel, real alpha);
+int op_correc(cales_ctx *c, real dtrk);
 int materialize_visct(cales_ctx *c);
-int op_stats_chan(cales_ctx *c, double *buf);
-int op_stats_chan_budget(cales_ctx *c, double *budget, double *leak);
+int op_stats_chan(cales_ctx *c, real *buf);
+int op_stats_chan_budget(cales_ctx *c, real *budget, real *leak);
 bool solver_can_fuse_fillps(cales_ctx *c);
-int op_force_from_partials(cales_ctx *c, int mask, const double *part, int nblk);
-int op_correc_updatep(cales_ctx *c, double dtrk, double alpha, int upd);
-int op_updatep(cales_ctx *c, double alpha);
+int op_force_from_partials(cales_ctx *c, int mask, const real *part, int nblk);
+int op_correc_updatep(cales_ctx *c, real dtrk, real alpha, int upd);
+int op_updatep(cales_ctx *c, real alpha);
 int op_cmpt_sgs(cales_ctx *c);
-int op_chkdt(cales_ctx *c, double *dtmax);
-int op_chkdiv(cales_ctx *c, double *divtot, double *divmax);
+int op_chkdt(cales_ctx *c, real *dtmax);
+int op_chkdiv(cales_ctx *c, real *divtot, real *divmax);
 int solver_setup(cales_ctx *c);
 void solver_teardown(cales_ctx *c);
 
@@ -249,24 +262,29 @@ void solver_teardown(cales_ctx *c);
 // same value costs an s_waitcnt vmcnt(0) in the middle of a prefetch)
 // (in the LDS-heavy last dsmag pass the same change measured 7 % slower -- scalar loads share lgkmcnt with the LDS reads and return
 // out of order, so waiting for one drains the LDS queue -- and that kernel keeps its vector loads)
-__device__ inline double ldc(const double *p, int k) { return ((const __attribute__((address_space(4))) double *)p)[k]; }
-template <typename OFF> __device__ inline double ldb(const double *b, OFF o) { return *(const double *)((const char *)b + o); }
-template <typename OFF> __device__ inline void stb(double *b, OFF o, double v) { *(double *)((char *)b + o) = v; }
+__device__ inline real ldc(const real *p, int k) { return ((const __attribute__((address_space(4))) real *)p)[k]; }
+template <typename OFF> __device__ inline real ldb(const real *b, OFF o) { return *(const real *)((const char *)b + o); }
+template <typename OFF> __device__ inline void stb(real *b, OFF o, real v) { *(real *)((char *)b + o) = v; }
 
 // ---- cross-lane moves on the vector ALU (DPP) instead of ds_bpermute: no LDS-pipe traffic, short latency ----
 template <int CTRL, int ROWMASK = 0xf>
-__device__ inline double dpp_f64(double v) {       // lanes without a source receive 0 (bound_ctrl); rows masked out keep v itself
+__device__ inline real dpp_f64(real v) {       // lanes without a source receive 0 (bound_ctrl); rows masked out keep v itself
+#ifdef CALES_SINGLE
+  const int w = __float_as_int(v);
+  return __int_as_float(__builtin_amdgcn_update_dpp(w, w, CTRL, ROWMASK, 0xf, true));
+#else
   int lo = __double2loint(v), hi = __double2hiint(v);
   // old = the source register and bound_ctrl: no register has to be zeroed before every move (the old form cost one v_mov per dpp move)
   lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xf, true);
   hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xf, true);
   return __hiloint2double(hi, lo);
+#endif
 }
-__device__ inline double lane_prev(double v) { return dpp_f64<0x138>(v); }   // wave_shr:1, lane i <- lane i-1 (lane 0 <- 0)
-__device__ inline double lane_next(double v) { return dpp_f64<0x130>(v); }   // wave_shl:1, lane i <- lane i+1 (lane 63 <- 0)
+__device__ inline real lane_prev(real v) { return dpp_f64<0x138>(v); }   // wave_shr:1, lane i <- lane i-1 (lane 0 <- 0)
+__device__ inline real lane_next(real v) { return dpp_f64<0x130>(v); }   // wave_shl:1, lane i <- lane i+1 (lane 63 <- 0)
 // sum over the 64 lanes, valid in lane 63 only (row_shr 1,2,4,8 then row_bcast 15 and 31; the rows the two broadcasts mask out
 // add their own value to themselves -- they never reach lane 63)
-__device__ inline double wave_sum_lane63(double s) {
+__device__ inline real wave_sum_lane63(real s) {
   s += dpp_f64<0x111>(s); s += dpp_f64<0x112>(s); s += dpp_f64<0x114>(s); s += dpp_f64<0x118>(s);
   s += dpp_f64<0x142, 0xa>(s); s += dpp_f64<0x143, 0xc>(s);
   return s;

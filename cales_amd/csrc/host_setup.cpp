@@ -7,10 +7,10 @@
 #include <cstdint>
 #include "common.hpp"
 
-static const double kPi = std::acos(-1.0);
+static const real kPi = std::acos(-1.0);
 
 // ---------------------------------------------------------------- src/initgrid.f90:83-196
-static double stretch(int gtype, int kg, int nzg, double alpha, double z0) {
+static real stretch(int gtype, int kg, int nzg, real alpha, real z0) {
   switch (gtype) {
   case 2: return alpha != 0. ? 1.0 * (1. + std::tanh((z0 - 1.0) * alpha) / std::tanh(alpha / 1.)) : z0;
   case 3: return alpha != 0. ? 1. - 1.0 * (1. + std::tanh((1. - z0 - 1.0) * alpha) / std::tanh(alpha / 1.)) : z0;
@@ -19,25 +19,25 @@ static double stretch(int gtype, int kg, int nzg, double alpha, double z0) {
     return z0 <= 0.5 ? 0.5 * (1. - 1. + std::tanh(2. * alpha * (z0 - 0.)) / std::tanh(alpha))
                      : 0.5 * (1. + 1. + std::tanh(2. * alpha * (z0 - 1.)) / std::tanh(alpha));
   case 5: {   // Pirozzoli & Orlandi 'natural' stretching
-    const double kb = 32., al = kPi / 1.5, c_eta = 0.8, dyp = 0.05;
-    const double nh = nzg / 2., rn = nh / kb;
-    const double retau = 1. / (1. + rn * rn) * (dyp * nh + std::pow(3. / 4. * al * c_eta * nh, 4. / 3.) * (rn * rn));
-    const double k = 1. * std::min(kg, nzg - kg), rk = k / kb;
-    double z = 1. / (1. + rk * rk) * (dyp * k + std::pow(3. / 4. * al * c_eta * k, 4. / 3.) * (rk * rk)) / (2. * retau);
+    const real kb = 32., al = kPi / 1.5, c_eta = 0.8, dyp = 0.05;
+    const real nh = nzg / 2., rn = nh / kb;
+    const real retau = 1. / (1. + rn * rn) * (dyp * nh + std::pow(3. / 4. * al * c_eta * nh, 4. / 3.) * (rn * rn));
+    const real k = 1. * std::min(kg, nzg - kg), rk = k / kb;
+    real z = 1. / (1. + rk * rk) * (dyp * k + std::pow(3. / 4. * al * c_eta * k, 4. / 3.) * (rk * rk)) / (2. * retau);
     return kg > nzg - kg ? 1. - z : z; }
   case 6: {   // Larsson's wall-model grid; `dzc = 0.1*32./nzg` is a default-real expression
-    const double dzc = (double)(0.1f * 32.f / (float)nzg);
+    const real dzc = (real)(0.1f * 32.f / (float)nzg);
     return z0 - (dzc * nzg / 2. - 1.) / (2. * kPi) * std::sin(2. * kPi * z0); }
   default:    // 1: clustered at both ends
     return alpha != 0. ? 0.5 * (1. + std::tanh((z0 - 0.5) * alpha) / std::tanh(alpha / 2.)) : z0;
   }
 }
 
-void hs_initgrid(int gtype, int n, double gr, double lz, double *dzc, double *dzf, double *zc, double *zf) {
+void hs_initgrid(int gtype, int n, real gr, real lz, real *dzc, real *dzf, real *zc, real *zf) {
   // src/initgrid.f90:15-81
   zf[0] = 0.;
   for (int k = 1; k <= n; ++k) {
-    const double z0 = (double)(((float)k - 0.f) / (1.f * (float)n));   // `(k-0.)/(1.*n)`: default real
+    const real z0 = (real)(((float)k - 0.f) / (1.f * (float)n));   // `(k-0.)/(1.*n)`: default real
     zf[k] = stretch(gtype, k, n, gr, z0) * lz;
   }
   for (int k = 1; k <= n; ++k) dzf[k] = zf[k] - zf[k - 1];
@@ -50,7 +50,7 @@ void hs_initgrid(int gtype, int n, double gr, double lz, double *dzc, double *dz
 
 // ---------------------------------------------------------------- src/bound.f90:726-867
 // hb[b][d]: host images of the 11 `bound` objects (order: bcu bcv bcw bcp bcs bcuf bcvf bcwf bcu_mag bcv_mag bcw_mag)
-void hs_initbc(cales_ctx *c, std::vector<double> hb[11][3]) {
+void hs_initbc(cales_ctx *c, std::vector<real> hb[11][3]) {
   const int *n = c->n;
   std::memcpy(c->cbcvel, c->C.cbcvel, 18);
   for (int idir = 1; idir <= 3; ++idir)
@@ -58,7 +58,7 @@ void hs_initbc(cales_ctx *c, std::vector<double> hb[11][3]) {
       if (LWM(c, s, idir) != 0)
         for (int ivel = 1; ivel <= 3; ++ivel) CBV(c, s, idir, ivel) = (ivel == idir) ? 'D' : 'N';
   const size_t pl[3] = {(size_t)(n[1] + 2) * (n[2] + 2), (size_t)(n[0] + 2) * (n[2] + 2), (size_t)(n[0] + 2) * (n[1] + 2)};
-  auto fill = [&](int b, const double *v6) {
+  auto fill = [&](int b, const real *v6) {
     for (int d = 0; d < 3; ++d) {
       hb[b][d].assign(2 * pl[d], 0.);
       for (int s = 0; s < 2; ++s) std::fill(hb[b][d].begin() + s * pl[d], hb[b][d].begin() + (s + 1) * pl[d], v6[s + 2 * d]);
@@ -68,7 +68,7 @@ void hs_initbc(cales_ctx *c, std::vector<double> hb[11][3]) {
   fill(3, c->C.bcpre); fill(4, c->C.bcsgs);
   for (int b = 0; b < 3; ++b) for (int d = 0; d < 3; ++d) { hb[5 + b][d] = hb[b][d]; hb[8 + b][d] = hb[b][d]; }
   // wall-model interpolation index = first cell centre at or beyond height h, counted from the wall
-  const double h = c->C.hwm; const double *dl = c->dl; const double *zc = c->zc.data(); const double l3 = c->C.l[2];
+  const real h = c->C.hwm; const real *dl = c->dl; const real *zc = c->zc.data(); const real l3 = c->C.l[2];
   for (int q = 0; q < 6; ++q) c->index_wm[q] = 0;
   // x and y planes are rank-local in x; in y the slab owning the wall evaluates with LOCAL row numbers (as the reference)
   if (ISB(c, 0, 1) && LWM(c, 0, 1) != 0) { int i = 1; while ((i - 0.5) * dl[0] < h) ++i; IWM(c, 0, 1) = i; }
@@ -80,12 +80,12 @@ void hs_initbc(cales_ctx *c, std::vector<double> hb[11][3]) {
 }
 
 // src/bound.f90:501-560
-void hs_bc_rhs(const char *cbc2, const double *bc, int na, int nb, const double *dlc, const double *dlf, char c_or_f, double *rhs) {
+void hs_bc_rhs(const char *cbc2, const real *bc, int na, int nb, const real *dlc, const real *dlf, char c_or_f, real *rhs) {
   const size_t pl = (size_t)(na + 2) * (nb + 2), rl = (size_t)na * nb;
   for (int s = 0; s <= 1; ++s) {
-    const double sgn = s == 0 ? 1. : -1.;
+    const real sgn = s == 0 ? 1. : -1.;
     for (int b = 1; b <= nb; ++b) for (int a = 1; a <= na; ++a) {
-      const double v = bc[a + (size_t)(na + 2) * b + s * pl]; double r = 0.;
+      const real v = bc[a + (size_t)(na + 2) * b + s * pl]; real r = 0.;
       if (c_or_f == 'c') { if (cbc2[s] == 'D') r = -2. * v / dlc[s] / dlf[s]; else if (cbc2[s] == 'N') r = sgn * v / dlf[s]; }
       else               { if (cbc2[s] == 'D') r = -v / dlc[s] / dlf[s];      else if (cbc2[s] == 'N') r = sgn * v / dlc[s]; }
       rhs[(a - 1) + (size_t)na * (b - 1) + s * rl] = r;
@@ -94,10 +94,10 @@ void hs_bc_rhs(const char *cbc2, const double *bc, int na, int nb, const double 
 }
 
 // ---------------------------------------------------------------- src/initsolver.f90:66-169
-void hs_eigenvalues(int n, const char *cbc2, char c_or_f, double *lambda) {
+void hs_eigenvalues(int n, const char *cbc2, char c_or_f, real *lambda) {
   const bool pp = cbc2[0] == 'P' && cbc2[1] == 'P', nn = cbc2[0] == 'N' && cbc2[1] == 'N', dd = cbc2[0] == 'D' && cbc2[1] == 'D';
   for (int l = 1; l <= n; ++l) {
-    double v;
+    real v;
     if (pp) v = -2. * (1. - std::cos((2 * (l - 1)) * kPi / (1. * n)));
     else if (nn) v = -2. * (1. - std::cos((l - 1) * kPi / (1. * n)));
     else if (dd) v = (c_or_f == 'c') ? -2. * (1. - std::cos(l * kPi / (1. * n))) : (l < n ? -2. * (1. - std::cos(l * kPi / (1. * n))) : 0.);
@@ -105,20 +105,20 @@ void hs_eigenvalues(int n, const char *cbc2, char c_or_f, double *lambda) {
     lambda[l - 1] = v;
   }
 }
-void hs_tridmatrix(const char *cbc2, int n, const double *dzci, const double *dzfi, char c_or_f, double *a, double *b, double *c) {
+void hs_tridmatrix(const char *cbc2, int n, const real *dzci, const real *dzfi, char c_or_f, real *a, real *b, real *c) {
   for (int k = 1; k <= n; ++k) {
     if (c_or_f == 'c') { a[k - 1] = dzfi[k] * dzci[k - 1]; c[k - 1] = dzfi[k] * dzci[k]; }
     else               { a[k - 1] = dzfi[k] * dzci[k];     c[k - 1] = dzfi[k + 1] * dzci[k]; }
     b[k - 1] = -(a[k - 1] + c[k - 1]);
   }
-  double factor[2];
+  real factor[2];
   for (int s = 0; s < 2; ++s) factor[s] = cbc2[s] == 'P' ? 0. : cbc2[s] == 'D' ? -1. : 1.;
   if (c_or_f == 'c') { b[0] += factor[0] * a[0]; b[n - 1] += factor[1] * c[n - 1]; }
   else { if (cbc2[0] == 'N') b[0] += factor[0] * a[0]; if (cbc2[1] == 'N') b[n - 1] += factor[1] * c[n - 1]; }
 }
 
 // ---------------------------------------------------------------- src/initflow.f90:17-283
-int hs_initflow(const cales_case *cs, const char *inivel_, int is_wallturb, double *u, double *v, double *w, double *p, int rank, int nranks) {
+int hs_initflow(const cales_case *cs, const char *inivel_, int is_wallturb, real *u, real *v, real *w, real *p, int rank, int nranks) {
   // Fills the y-slab of `rank` (local haloed arrays, rows jl = 1..n2l <-> global j = jl + jlo). The volume mean
   // of set_mean (initflow.f90:317-338) is accumulated over the GLOBAL index range in the reference's loop order,
   // so every rank rescales by the same number a one-rank run would use.
@@ -128,18 +128,18 @@ int hs_initflow(const cales_case *cs, const char *inivel_, int is_wallturb, doub
   const size_t s1 = n1 + 2, s2 = n2 + 2;
   auto IX = [&](int i, int j, int k) { return (size_t)i + s1 * ((size_t)j + s2 * (size_t)k); };
   const std::string inivel(inivel_);
-  double dl[3]; for (int d = 0; d < 3; ++d) dl[d] = cs->l[d] / (double)(1.f * (float)cs->ng[d]);
-  const double *l = cs->l; const double visc = 1. / cs->visci, pi = kPi;
-  std::vector<double> dzc(n3 + 2), dzf(n3 + 2), zc(n3 + 2), zf(n3 + 2);
+  real dl[3]; for (int d = 0; d < 3; ++d) dl[d] = cs->l[d] / (real)(1.f * (float)cs->ng[d]);
+  const real *l = cs->l; const real visc = 1. / cs->visci, pi = kPi;
+  std::vector<real> dzc(n3 + 2), dzf(n3 + 2), zc(n3 + 2), zf(n3 + 2);
   hs_initgrid(cs->gtype, n3, cs->gr, l[2], dzc.data(), dzf.data(), zc.data(), zf.data());
   auto bcvel = [&](int side, int dir, int vel) { return cs->bcvel[side + 2 * (dir - 1) + 6 * (vel - 1)]; };
-  double uref = 1., ubulk = uref; bool is_mean = false, is3d = false, is2d = false, is_noise = false;
+  real uref = 1., ubulk = uref; bool is_mean = false, is3d = false, is2d = false, is_noise = false;
   if (cs->is_forced[0]) ubulk = cs->velf[0];
-  std::vector<double> u1d(n3 + 2, 0.), u2d;        // u2d(jg,k): x-independent duct profile for ALL global rows
-  auto poiseuille = [&](double norm) { for (int k = 1; k <= n3; ++k) { const double z = zc[k] / l[2]; u1d[k] = 6. * z * (1. - z) * norm; } };
+  std::vector<real> u1d(n3 + 2, 0.), u2d;        // u2d(jg,k): x-independent duct profile for ALL global rows
+  auto poiseuille = [&](real norm) { for (int k = 1; k <= n3; ++k) { const real z = zc[k] / l[2]; u1d[k] = 6. * z * (1. - z) * norm; } };
   if (inivel == "cou") {
     uref = bcvel(0, 3, 1) - bcvel(1, 3, 1);
-    for (int k = 1; k <= n3; ++k) { const double z = zc[k] / l[2]; u1d[k] = .5 * (1. - 2. * z) * uref; }
+    for (int k = 1; k <= n3; ++k) { const real z = zc[k] / l[2]; u1d[k] = .5 * (1. - 2. * z) * uref; }
     uref = std::fabs(uref);
   } else if (inivel == "poi") { poiseuille(ubulk); is_mean = true;
   } else if (inivel == "iop") {
@@ -149,31 +149,31 @@ int hs_initflow(const cales_case *cs, const char *inivel_, int is_wallturb, doub
   } else if (inivel == "zer") {
   } else if (inivel == "uni") { for (int k = 1; k <= n3; ++k) u1d[k] = uref;
   } else if (inivel == "hcp") {      // half channel: the lower half of the Poiseuille profile of a channel of height 2 lz (initflow.f90:93-102)
-    for (int k = 1; k <= n3; ++k) { const double z = zc[k] / (2 * l[2]); u1d[k] = 6. * z * (1. - z) * ubulk; }
+    for (int k = 1; k <= n3; ++k) { const real z = zc[k] / (2 * l[2]); u1d[k] = 6. * z * (1. - z) * ubulk; }
     is_mean = true;
   } else if (inivel == "pdc" || inivel == "hdc") {      // pressure-driven (half) channel, initflow.f90:157-180
-    double lref = l[2] / 2.;
+    real lref = l[2] / 2.;
     if (inivel != "pdc") lref = 2. * lref;
-    if (is_wallturb) { uref = std::pow(cs->bforce[0] * lref, 0.5); const double retau = uref * lref / visc, reb = std::pow(retau / .09, 1. / .88); ubulk = reb * visc / (2 * lref); }
+    if (is_wallturb) { uref = std::pow(cs->bforce[0] * lref, 0.5); const real retau = uref * lref / visc, reb = std::pow(retau / .09, 1. / .88); ubulk = reb * visc / (2 * lref); }
     else ubulk = cs->bforce[0] * (lref * lref) / (3. * visc);
     if (inivel == "pdc") poiseuille(ubulk);
-    else for (int k = 1; k <= n3; ++k) { const double z = zc[k] / (2 * l[2]); u1d[k] = 6. * z * (1. - z) * ubulk; }
+    else for (int k = 1; k <= n3; ++k) { const real z = zc[k] / (2 * l[2]); u1d[k] = 6. * z * (1. - z) * ubulk; }
     is_mean = true;
   } else if (inivel == "tgv") { is3d = true;
-    for (int k = 1; k <= n3; ++k) { const double zcc = zc[k] / l[2] * 2. * pi;
-      for (int jl = 1; jl <= n2; ++jl) { const int j = jl + jlo; const double yc = (j - .5) * dl[1] / l[1] * 2. * pi, yf = (j - .0) * dl[1] / l[1] * 2. * pi;
-        for (int i = 1; i <= n1; ++i) { const double xc = (i - .5) * dl[0] / l[0] * 2. * pi, xf = (i - .0) * dl[0] / l[0] * 2. * pi; const size_t q = IX(i, jl, k);
+    for (int k = 1; k <= n3; ++k) { const real zcc = zc[k] / l[2] * 2. * pi;
+      for (int jl = 1; jl <= n2; ++jl) { const int j = jl + jlo; const real yc = (j - .5) * dl[1] / l[1] * 2. * pi, yf = (j - .0) * dl[1] / l[1] * 2. * pi;
+        for (int i = 1; i <= n1; ++i) { const real xc = (i - .5) * dl[0] / l[0] * 2. * pi, xf = (i - .0) * dl[0] / l[0] * 2. * pi; const size_t q = IX(i, jl, k);
           u[q] = std::sin(xf) * std::cos(yc) * std::cos(zcc) * uref; v[q] = -std::cos(xc) * std::sin(yf) * std::cos(zcc) * uref; w[q] = 0.; p[q] = 0.; } } }
   } else if (inivel == "tgw") { is3d = true;
-    for (int k = 1; k <= n3; ++k) for (int jl = 1; jl <= n2; ++jl) { const int j = jl + jlo; const double yc = (j - .5) * dl[1], yf = (j - .0) * dl[1];
-      for (int i = 1; i <= n1; ++i) { const double xc = (i - .5) * dl[0], xf = (i - .0) * dl[0]; const size_t q = IX(i, jl, k);
+    for (int k = 1; k <= n3; ++k) for (int jl = 1; jl <= n2; ++jl) { const int j = jl + jlo; const real yc = (j - .5) * dl[1], yf = (j - .0) * dl[1];
+      for (int i = 1; i <= n1; ++i) { const real xc = (i - .5) * dl[0], xf = (i - .0) * dl[0]; const size_t q = IX(i, jl, k);
         u[q] = std::cos(xf) * std::sin(yc) * uref; v[q] = -std::sin(xc) * std::cos(yf) * uref; w[q] = 0.;
         p[q] = -(std::cos(2. * xc) + std::cos(2. * yc)) / 4. * (uref * uref); } }
   } else if (inivel == "ant") { is3d = true;
-    const double cf = (double)(4.f * std::sqrt(2.f) / 3.f / std::sqrt(3.f));    // default-real constant (initflow.f90:146)
-    for (int k = 1; k <= n3; ++k) { const double zcc = zc[k] / l[2] * 2. * pi + 0.5 * pi, zff = zf[k] / l[2] * 2. * pi + 0.5 * pi;
-      for (int jl = 1; jl <= n2; ++jl) { const int j = jl + jlo; const double yc = (j - .5) * dl[1] / l[1] * 2. * pi + 0.5 * pi, yf = (j - .0) * dl[1] / l[1] * 2. * pi + 0.5 * pi;
-        for (int i = 1; i <= n1; ++i) { const double xc = (i - .5) * dl[0] / l[0] * 2. * pi + 0.5 * pi, xf = (i - .0) * dl[0] / l[0] * 2. * pi + 0.5 * pi; const size_t q = IX(i, jl, k);
+    const real cf = (real)(4.f * std::sqrt(2.f) / 3.f / std::sqrt(3.f));    // default-real constant (initflow.f90:146)
+    for (int k = 1; k <= n3; ++k) { const real zcc = zc[k] / l[2] * 2. * pi + 0.5 * pi, zff = zf[k] / l[2] * 2. * pi + 0.5 * pi;
+      for (int jl = 1; jl <= n2; ++jl) { const int j = jl + jlo; const real yc = (j - .5) * dl[1] / l[1] * 2. * pi + 0.5 * pi, yf = (j - .0) * dl[1] / l[1] * 2. * pi + 0.5 * pi;
+        for (int i = 1; i <= n1; ++i) { const real xc = (i - .5) * dl[0] / l[0] * 2. * pi + 0.5 * pi, xf = (i - .0) * dl[0] / l[0] * 2. * pi + 0.5 * pi; const size_t q = IX(i, jl, k);
           u[q] = cf * (std::sin(xf - 5. * pi / 6.) * std::cos(yc - 1. * pi / 6.) * std::sin(zcc) - std::sin(xf - 1. * pi / 6.) * std::sin(yc) * std::cos(zcc - 5. * pi / 6.)) * uref;
           v[q] = cf * (std::sin(xc) * std::sin(yf - 5. * pi / 6.) * std::sin(zcc - 1. * pi / 6.) - std::cos(xc - 5. * pi / 6.) * std::sin(yf - 1. * pi / 6.) * std::sin(zcc)) * uref;
           w[q] = cf * (std::cos(xc - 1. * pi / 6.) * std::sin(yc) * std::sin(zff - 5. * pi / 6.) - std::sin(xc) * std::cos(yc - 5. * pi / 6.) * std::sin(zff - 1. * pi / 6.)) * uref;
@@ -181,28 +181,28 @@ int hs_initflow(const cales_case *cs, const char *inivel_, int is_wallturb, doub
   } else if (inivel == "duc") { is2d = true; is_mean = true;
     u2d.assign((size_t)(n2g + 2) * (n3 + 2), 0.);
     for (int k = 1; k <= n3; ++k) for (int j = 1; j <= n2g; ++j) {
-      double sum_term = 0.; const double ly = .5 * l[1], lz = .5 * l[2], xi = -1. + (j + 1 - 1.5) * dl[1] / ly, eta = -1. + zc[k] / lz;
+      real sum_term = 0.; const real ly = .5 * l[1], lz = .5 * l[2], xi = -1. + (j + 1 - 1.5) * dl[1] / ly, eta = -1. + zc[k] / lz;
       for (int m = 0; m <= 100; ++m) {
-        const double cosh_term = std::cosh((2 * m + 1) * pi * ly / (2 * lz) * xi) / std::cosh((2 * m + 1) * pi * ly / (2 * lz));
-        const double cos_term = std::cos((2 * m + 1) * pi / 2 * eta);
-        const double term = ((m & 1) ? -1. : 1.) / (double)((2 * m + 1) * (2 * m + 1) * (2 * m + 1)) * cosh_term * cos_term;
+        const real cosh_term = std::cosh((2 * m + 1) * pi * ly / (2 * lz) * xi) / std::cosh((2 * m + 1) * pi * ly / (2 * lz));
+        const real cos_term = std::cos((2 * m + 1) * pi / 2 * eta);
+        const real term = ((m & 1) ? -1. : 1.) / (real)((2 * m + 1) * (2 * m + 1) * (2 * m + 1)) * cosh_term * cos_term;
         sum_term = sum_term + term;
       }
-      const double tp = 2. / pi;
+      const real tp = 2. / pi;
       u2d[j + (size_t)(n2g + 2) * k] = .5 * (lz * lz) * (1. - eta * eta - 4. * (tp * tp * tp) * sum_term);
     }
   } else if (inivel == "log" || inivel == "hcl") {      // log-law profile of a (half) channel + noise (initflow.f90:76-91,392-406)
-    const double lz = inivel == "log" ? l[2] : 2 * l[2], reb = ubulk * lz / visc;
-    const double retau = (double)0.09f * std::pow(reb, (double)0.88f);      // default-real literals of the reference
+    const real lz = inivel == "log" ? l[2] : 2 * l[2], reb = ubulk * lz / visc;
+    const real retau = (real)0.09f * std::pow(reb, (real)0.88f);      // default-real literals of the reference
     for (int k = 1; k <= n3; ++k) {
-      double z = zc[k] / lz * 2. * retau;
+      real z = zc[k] / lz * 2. * retau;
       if (z >= retau) z = 2. * retau - z;
       u1d[k] = 2.5 * std::log(z) + 5.5;
-      if (z <= (double)11.6f) u1d[k] = z;
+      if (z <= (real)11.6f) u1d[k] = z;
     }
     is_noise = true; is_mean = true;
   } else if (inivel == "tbl") {      // temporal boundary layer of thickness 1 (initflow.f90:60-62,374-390) + noise
-    const double theta = 54. * visc / uref;
+    const real theta = 54. * visc / uref;
     for (int k = 1; k <= n3; ++k) u1d[k] = (0.5 + 0.5 * std::tanh((1. / (2. * theta)) * (1. - zc[k] / 1.))) * uref;
     is_noise = true;
   } else {
@@ -214,30 +214,30 @@ int hs_initflow(const cales_case *cs, const char *inivel_, int is_wallturb, doub
   auto noise = [&](uint64_t seed, int i, int jg, int k) {
     uint64_t z = seed * 0x9E3779B97F4A7C15ULL + (((uint64_t)(k - 1) * n2g + (uint64_t)(jg - 1)) * n1 + (uint64_t)(i - 1));
     z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL; z ^= z >> 27; z *= 0x94D049BB133111EBULL; z ^= z >> 31;
-    const double rn = (double)(z >> 11) * (1. / 9007199254740992.);
-    return 2. * (rn - .5) * (double)0.05f;
+    const real rn = (real)(z >> 11) * (1. / 9007199254740992.);
+    return 2. * (rn - .5) * (real)0.05f;
   };
   auto prof = [&](int jg, int k) { return is2d ? u2d[jg + (size_t)(n2g + 2) * k] : u1d[k]; };
   if (!is3d) for (int k = 1; k <= n3; ++k) for (int jl = 1; jl <= n2; ++jl) {
-    const double val = prof(jl + jlo, k);
+    const real val = prof(jl + jlo, k);
     for (int i = (is2d ? 0 : 1); i <= (is2d ? n1 + 1 : n1); ++i) { const size_t q = IX(i, jl, k); u[q] = val; v[q] = 0.; w[q] = 0.; p[q] = 0.; } }
   if (is_noise) for (int k = 1; k <= n3; ++k) for (int jl = 1; jl <= n2; ++jl) for (int i = 1; i <= n1; ++i) {
     const size_t q = IX(i, jl, k); u[q] += noise(123, i, jl + jlo, k); v[q] += noise(456, i, jl + jlo, k); w[q] += noise(789, i, jl + jlo, k); }
   if (is_mean && inivel != "iop") {   // set_mean over the global domain, same summation order as one rank
-    double meanold = 0.;
-    for (int k = 1; k <= n3; ++k) { const double gvr = dzf[k] / l[2] * (dl[0] / l[0]) * (dl[1] / l[1]);
-      for (int j = 1; j <= n2g; ++j) { const double t = prof(j, k) * gvr;
+    real meanold = 0.;
+    for (int k = 1; k <= n3; ++k) { const real gvr = dzf[k] / l[2] * (dl[0] / l[0]) * (dl[1] / l[1]);
+      for (int j = 1; j <= n2g; ++j) { const real t = prof(j, k) * gvr;
         if (is_noise) for (int i = 1; i <= n1; ++i) meanold = meanold + (prof(j, k) + noise(123, i, j, k)) * gvr;
         else for (int i = 1; i <= n1; ++i) meanold = meanold + t; } }
     if (meanold != 0.) for (int k = 1; k <= n3; ++k) for (int jl = 1; jl <= n2; ++jl) for (int i = 1; i <= n1; ++i)
       u[IX(i, jl, k)] = u[IX(i, jl, k)] / meanold * ubulk;
   }
   if (is_wallturb) {                  // streamwise vortex pair, initflow.f90:218-246
-    for (int k = 1; k <= n3; ++k) { const double zcc = 2. * zc[k] / l[2] - 1., zff = 2. * (zc[k] / l[2] + .5 * dzf[k] / l[2]) - 1.;
-      for (int jl = 1; jl <= n2; ++jl) { const int j = jl + jlo; const double yc = ((j - 0.5) * dl[1] - .5 * l[1]) * 2. / l[2], yf = ((j - 0.0) * dl[1] - .5 * l[1]) * 2. / l[2];
-        for (int i = 1; i <= n1; ++i) { const double xc = ((i - 0.5) * dl[0] - .5 * l[0]) * 2. / l[2]; const size_t q = IX(i, jl, k);
-          const double gxy = xc * std::exp(-4. * (4. * (yf * yf) + xc * xc)), dfz = -4. * zcc * (1. - zcc * zcc);
-          const double fz = (1. - zff * zff) * (1. - zff * zff), dgxy = std::exp(-4. * (4. * (yc * yc) + xc * xc)) * (1. - 8. * (xc * xc));
+    for (int k = 1; k <= n3; ++k) { const real zcc = 2. * zc[k] / l[2] - 1., zff = 2. * (zc[k] / l[2] + .5 * dzf[k] / l[2]) - 1.;
+      for (int jl = 1; jl <= n2; ++jl) { const int j = jl + jlo; const real yc = ((j - 0.5) * dl[1] - .5 * l[1]) * 2. / l[2], yf = ((j - 0.0) * dl[1] - .5 * l[1]) * 2. / l[2];
+        for (int i = 1; i <= n1; ++i) { const real xc = ((i - 0.5) * dl[0] - .5 * l[0]) * 2. / l[2]; const size_t q = IX(i, jl, k);
+          const real gxy = xc * std::exp(-4. * (4. * (yf * yf) + xc * xc)), dfz = -4. * zcc * (1. - zcc * zcc);
+          const real fz = (1. - zff * zff) * (1. - zff * zff), dgxy = std::exp(-4. * (4. * (yc * yc) + xc * xc)) * (1. - 8. * (xc * xc));
           v[q] = -1. * gxy * dfz * ubulk * 1.5; w[q] = 1. * fz * dgxy * ubulk * 1.5; p[q] = 0.; } } }
   }
   return 0;
@@ -270,10 +270,10 @@ int hs_check_case(const cales_case *cs, std::string &msg) {
   { bool any = false; for (int q = 0; q < 6; ++q) any = any || cs->lwm[q] != 0;
     if (any) {
       const int n3 = cs->ng[2], n2l = cs->ng[1] / cs->nranks;
-      std::vector<double> dzc(n3 + 2), dzf(n3 + 2), zc(n3 + 2), zf(n3 + 2);
+      std::vector<real> dzc(n3 + 2), dzf(n3 + 2), zc(n3 + 2), zf(n3 + 2);
       hs_initgrid(cs->gtype, n3, cs->gr, cs->l[2], dzc.data(), dzf.data(), zc.data(), zf.data());
-      double dl[2]; for (int d = 0; d < 2; ++d) dl[d] = cs->l[d] / (double)(1.f * (float)cs->ng[d]);      // param.f90:153
-      const double h = cs->hwm; bool ok = true;
+      real dl[2]; for (int d = 0; d < 2; ++d) dl[d] = cs->l[d] / (real)(1.f * (float)cs->ng[d]);      // param.f90:153
+      const real h = cs->hwm; bool ok = true;
       const bool per_y = cs->cbcpre[2] == 'P' && cs->cbcpre[3] == 'P', per_z = cs->cbcpre[4] == 'P' && cs->cbcpre[5] == 'P';
       for (int s = 0; s < 2; ++s) {
         if (cs->lwm[s] != 0) ok = ok && h > 0.5 * dl[0] && h < (cs->ng[0] - 0.5) * dl[0];

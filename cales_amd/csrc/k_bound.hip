@@ -8,9 +8,9 @@
 #include "common.hpp"
 
 struct BcJob {
-  double *p;          // field
-  const double *bc;   // plane of side `ibound` (already offset), (0:na+1,0:nb+1)
-  double dr;
+  real *p;          // field
+  const real *bc;   // plane of side `ibound` (already offset), (0:na+1,0:nb+1)
+  real dr;
   char ctype;         // 'P','D','N'
   char centered;
   char ibound;
@@ -25,13 +25,13 @@ __global__ __launch_bounds__(256) void k_set_bc(Geom g, BcJobs J) {
   if (a > na + 1 || b > nb + 1) return;
   const long st = idir == 1 ? 1 : idir == 2 ? (long)g.s1 : g.s12;
   const size_t base = idir == 1 ? g.ix(0, a, b) : idir == 2 ? g.ix(a, 0, b) : g.ix(a, b, 0);
-  double *p = jb.p + base;
+  real *p = jb.p + base;
 #define P(m) p[(long)(m)*st]
-  const double bcv = jb.bc ? jb.bc[a + (size_t)(na + 2) * b] : 0.;
-  const double sgn = (jb.ctype == 'D' && jb.centered) ? -1. : 1.;
+  const real bcv = jb.bc ? jb.bc[a + (size_t)(na + 2) * b] : 0.;
+  const real sgn = (jb.ctype == 'D' && jb.centered) ? -1. : 1.;
   switch (jb.ctype) {
   case 'P':   // bound.f90:220-248 (one job handles both ends)
-    { const double lo = P(n), hi = P(1); P(0) = lo; P(n + 1) = hi; } break;
+    { const real lo = P(n), hi = P(1); P(0) = lo; P(n + 1) = hi; } break;
   case 'D':   // bound.f90:249-319
     if (jb.centered) { if (jb.ibound == 0) P(0) = 2. * bcv + sgn * P(1); else P(n + 1) = 2. * bcv + sgn * P(n); }
     else { if (jb.ibound == 0) P(0) = bcv; else { P(n + 1) = P(n - 1); P(n) = bcv; } }
@@ -52,12 +52,12 @@ static int launch_jobs(cales_ctx *c, BcJobs &J) {
   HIPCHK(c, hipGetLastError());
   return 0;
 }
-static inline const double *plane(const DBound &b, int idir, int ibound, const int *n) {
+static inline const real *plane(const DBound &b, int idir, int ibound, const int *n) {
   const size_t pl = idir == 1 ? (size_t)(n[1] + 2) * (n[2] + 2) : idir == 2 ? (size_t)(n[0] + 2) * (n[2] + 2) : (size_t)(n[0] + 2) * (n[1] + 2);
-  const double *base = idir == 1 ? b.x : idir == 2 ? b.y : b.z;
+  const real *base = idir == 1 ? b.x : idir == 2 ? b.y : b.z;
   return base + (size_t)ibound * pl;
 }
-static inline void add_job(BcJobs &J, double *p, char ctype, int ibound, int centered, const double *bc, double dr) {
+static inline void add_job(BcJobs &J, real *p, char ctype, int ibound, int centered, const real *bc, real dr) {
   BcJob &j = J.job[J.njobs++];
   j.p = p; j.bc = bc; j.dr = dr; j.ctype = ctype; j.centered = (char)centered; j.ibound = (char)ibound;
 }
@@ -68,7 +68,7 @@ static inline void add_job(BcJobs &J, double *p, char ctype, int ibound, int cen
 // operation applied to the periodically wrapped interior cell -- so each thread computes its ghost cell from interior cells only
 // and no ordering between the directions is left. Saves two of the three launches of every bounduvw / boundp (19 -> 7 per substep
 // for a channel), which is what small grids are bound by.
-struct MField { double *p; const double *bc0, *bc1; double dr0, dr1; char t0, t1, centered; };      // z sides: 'P','D','N' or 0 (leave z alone)
+struct MField { real *p; const real *bc0, *bc1; real dr0, dr1; char t0, t1, centered; };      // z sides: 'P','D','N' or 0 (leave z alone)
 struct MJobs { int nf, do_x, wrap_y, do_z; MField f[8]; };
 __global__ __launch_bounds__(256) void k_bc_merged(Geom g, MJobs J) {
   const int region = blockIdx.z % 3; const MField F = J.f[blockIdx.z / 3];
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_bc_merged(Geom g, MJobs J) {
   auto wx = [&](int i) { return !J.do_x ? i : i == 0 ? n1 : i == n1 + 1 ? 1 : i; };
   auto wy = [&](int j) { return !J.wrap_y ? j : j == 0 ? n2 : j == n2 + 1 ? 1 : j; };
   const bool top_face = J.do_z && F.t1 == 'D' && !F.centered;      // plane n3 itself is boundary data (face-centred normal component)
-  double *p = F.p;
+  real *p = F.p;
   if (region == 0) {               // z ghost planes of the column (a, b), ghost columns included
     if (!J.do_z || a > n1 + 1 || b > n2 + 1) return;
     const int ia = wx(a), jb = wy(b);
@@ -119,21 +119,21 @@ static bool merged_ok(const cales_ctx *c, const char *cbx, const char *cby) {
 
 // y-slab neighbours (bound.f90:619-696 for idir = 2): pack the first/last interior rows of nf fields into the
 // staging buffer A, let the host exchange them, unpack into the ghost rows. Planes include the x/z ghosts.
-struct HaloFields { int nf; double *p[8]; };
-__global__ __launch_bounds__(256) void k_pack_y(Geom g, HaloFields H, double *__restrict__ lo, double *__restrict__ hi) {
+struct HaloFields { int nf; real *p[8]; };
+__global__ __launch_bounds__(256) void k_pack_y(Geom g, HaloFields H, real *__restrict__ lo, real *__restrict__ hi) {
   const int i = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y * 4 + threadIdx.y, f = blockIdx.z;
   if (i > g.n1 + 1 || k > g.n3 + 1) return;
   const size_t q = (size_t)i + (size_t)g.s1 * ((size_t)k + (size_t)(g.n3 + 2) * f);
   lo[q] = H.p[f][g.ix(i, 1, k)]; hi[q] = H.p[f][g.ix(i, g.n2, k)];
 }
-__global__ __launch_bounds__(256) void k_unpack_y(Geom g, HaloFields H, const double *__restrict__ lo, const double *__restrict__ hi, int has_lo, int has_hi) {
+__global__ __launch_bounds__(256) void k_unpack_y(Geom g, HaloFields H, const real *__restrict__ lo, const real *__restrict__ hi, int has_lo, int has_hi) {
   const int i = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y * 4 + threadIdx.y, f = blockIdx.z;
   if (i > g.n1 + 1 || k > g.n3 + 1) return;
   const size_t q = (size_t)i + (size_t)g.s1 * ((size_t)k + (size_t)(g.n3 + 2) * f);
   if (has_lo) H.p[f][g.ix(i, 0, k)] = lo[q];
   if (has_hi) H.p[f][g.ix(i, g.n2 + 1, k)] = hi[q];
 }
-static int halo_y_on(cales_ctx *c, int nf, double **flds, hipStream_t st, bool overlapped) {
+static int halo_y_on(cales_ctx *c, int nf, real **flds, hipStream_t st, bool overlapped) {
   const int64_t plane = (int64_t)c->g.s1 * (c->n[2] + 2), cnt = plane * nf;
   if (4 * cnt > c->comm.nbuf) { c->err = "halo staging buffer too small"; return 1; }
   HaloFields H; H.nf = nf; for (int q = 0; q < nf; ++q) H.p[q] = flds[q];
@@ -147,7 +147,7 @@ static int halo_y_on(cales_ctx *c, int nf, double **flds, hipStream_t st, bool o
   HIPCHK(c, hipGetLastError());
   return 0;
 }
-static int halo_y_comm(cales_ctx *c, int nf, double **flds) {
+static int halo_y_comm(cales_ctx *c, int nf, real **flds) {
   if (!c->comm.on) { c->err = "nranks > 1 but no communication hooks registered (cales_set_comm)"; return 1; }
   if (c->defer_halo) { for (int q = 0; q < nf; ++q) c->deferred.push_back(flds[q]); return 0; }      // exchanged later, beside kernels (halo_flush_deferred)
   return halo_y_on(c, nf, flds, c->stream, false);
@@ -167,7 +167,7 @@ int halo_flush_deferred(cales_ctx *c) {
   return 0;
 }
 // halo exchange in the non-pencil directions: y across slabs (or a periodic copy on one rank), z always local
-static int halo_self(cales_ctx *c, int nf, double **flds) {
+static int halo_self(cales_ctx *c, int nf, real **flds) {
   if (c->P > 1) { if (int e = halo_y_comm(c, nf, flds)) return e; }
   for (int idir = (c->P > 1 ? 3 : 2); idir <= 3; ++idir) {
     const bool periodic = idir == 2 ? c->per_y : !ISB(c, 0, 3);
@@ -184,7 +184,7 @@ static int halo_self(cales_ctx *c, int nf, double **flds) {
 
 // ------------------------------------------------------------------------------------------ boundp (bound.f90:156-200)
 // nf <= 8 fields with the same BC set in one halo exchange and as few launches as the job table allows
-int op_boundp_multi(cales_ctx *c, int nf, double **p, int which) {
+int op_boundp_multi(cales_ctx *c, int nf, real **p, int which) {
   ProfScope ps(c, "boundp");
   const char *cbc = which == 0 ? c->C.cbcpre : c->C.cbcsgs; const DBound &bc = which == 0 ? c->bcp : c->bcs;
   if (merged_ok(c, cbc, cbc + 2) && nf <= 8) {      // x, y periodic: all three directions in one launch (k_bc_merged)
@@ -203,7 +203,7 @@ int op_boundp_multi(cales_ctx *c, int nf, double **p, int which) {
     if (!ISB(c, 0, idir) && !ISB(c, 1, idir)) continue;
     if (c->bc_skip >> (idir - 1) & 1) continue;
     BcJobs J; J.njobs = 0; J.idir = idir;
-    const double dr0 = idir < 3 ? c->dl[idir - 1] : c->dzc[0], dr1 = idir < 3 ? c->dl[idir - 1] : c->dzc[c->n[2]];
+    const real dr0 = idir < 3 ? c->dl[idir - 1] : c->dzc[0], dr1 = idir < 3 ? c->dl[idir - 1] : c->dzc[c->n[2]];
     const char c0 = cbc[0 + 2 * (idir - 1)], c1 = cbc[1 + 2 * (idir - 1)];
     for (int q = 0; q < nf; ++q) {
       if (J.njobs + 2 > 6) { if (int e = launch_jobs(c, J)) return e; J.njobs = 0; }
@@ -217,28 +217,28 @@ int op_boundp_multi(cales_ctx *c, int nf, double **p, int which) {
   }
   return 0;
 }
-int op_boundp(cales_ctx *c, double *p, int which) { double *fl[1] = {p}; return op_boundp_multi(c, 1, fl, which); }
+int op_boundp(cales_ctx *c, real *p, int which) { real *fl[1] = {p}; return op_boundp_multi(c, 1, fl, which); }
 
 // ------------------------------------------------------------------------------------------ wall model (wmodel.f90:65-335)
-__device__ inline double vel_relative(double v1, double v2, double coef, double mag) {
-  double r = (1. - coef) * v1 + coef * v2;
+__device__ inline real vel_relative(real v1, real v2, real coef, real mag) {
+  real r = (1. - coef) * v1 + coef * v2;
   return r - mag;
 }
-__device__ inline void wallmodel(int mtype, double uh, double vh, double h, double l1d, double visc, double &t1, double &t2) {
-  const double kap = 0.41, blog = 5.20;
-  double upar = sqrt(uh * uh + vh * vh), tauw_tot;
+__device__ inline void wallmodel(int mtype, real uh, real vh, real h, real l1d, real visc, real &t1, real &t2) {
+  const real kap = 0.41, blog = 5.20;
+  real upar = sqrt(uh * uh + vh * vh), tauw_tot;
   if (mtype == 1) {
-    double conv = 1., utau = fmax(sqrt(upar / h * visc), visc / h * exp(-kap * blog));
+    real conv = 1., utau = fmax(sqrt(upar / h * visc), visc / h * exp(-kap * blog));
     while (conv > 0.5e-4) {
-      const double utau_old = utau;
-      const double f = upar / utau - 1. / kap * log(h * utau / visc) - blog;
-      const double fp = -1. / utau * (upar / utau + 1. / kap);
+      const real utau_old = utau;
+      const real f = upar / utau - 1. / kap * log(h * utau / visc) - blog;
+      const real fp = -1. / utau * (upar / utau + 1. / kap);
       utau = fabs(utau - f / fp);
       conv = fabs(utau / utau_old - 1.);
     }
     tauw_tot = utau * utau;
   } else {
-    const double del = 0.5 * l1d, umax = upar / (h / del * (2. - h / del));
+    const real del = 0.5 * l1d, umax = upar / (h / del * (2. - h / del));
     tauw_tot = 2. / del * umax * visc;
   }
   t1 = tauw_tot * uh / (upar + CALES_EPS); t2 = tauw_tot * vh / (upar + CALES_EPS);
@@ -246,40 +246,40 @@ __device__ inline void wallmodel(int mtype, double uh, double vh, double h, doub
 
 struct WmArgs {
   int idir, ibound, mtype, i1, i2;   // i1/i2: near / far interpolation index along idir
-  double coef, sgn, h, l1d, visc;
-  const double *u, *v, *w;           // velocity fields
-  double *bc_a, *bc_b;               // planes (side ibound) receiving the first / second tangential component
-  const double *mag_a, *mag_b;       // *_mag planes (side ibound)
-  const double *zc, *zf, *dzc;
+  real coef, sgn, h, l1d, visc;
+  const real *u, *v, *w;           // velocity fields
+  real *bc_a, *bc_b;               // planes (side ibound) receiving the first / second tangential component
+  const real *mag_a, *mag_b;       // *_mag planes (side ibound)
+  const real *zc, *zf, *dzc;
 };
 // blockIdx.z = 0: first tangential component loop, 1: second (wmodel.f90:138-153/154-170, 189-204/205-221, 240-255/256-271)
 __global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmArgs A) {
   const int na = A.idir == 1 ? g.n2 : g.n1, nb = A.idir == 3 ? g.n2 : g.n3;
   const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y, comp = blockIdx.z;
   const size_t ld = na + 2;
-  const double visci = 1. / A.visc;
-  double t1, t2;
+  const real visci = 1. / A.visc;
+  real t1, t2;
 #define M(pl, a_, b_) pl[(a_) + ld * (b_)]
   if (A.idir == 1) {          // wall normal x; a = j, b = k; tangential: v (first), w (second)
     const int i1 = A.i1, i2 = A.i2;
     if (comp == 0) {
       if (a > na || b < 1 || b > nb) return;           // j = 0..n2, k = 1..n3
       const int j = a, k = b;
-      const double v1 = A.v[g.ix(i1, j, k)], v2 = A.v[g.ix(i2, j, k)];
-      const double w1 = 0.25 * (A.w[g.ix(i1, j, k)] + A.w[g.ix(i1, j + 1, k)] + A.w[g.ix(i1, j, k - 1)] + A.w[g.ix(i1, j + 1, k - 1)]);
-      const double w2 = 0.25 * (A.w[g.ix(i2, j, k)] + A.w[g.ix(i2, j + 1, k)] + A.w[g.ix(i2, j, k - 1)] + A.w[g.ix(i2, j + 1, k - 1)]);
-      const double v_mag = M(A.mag_a, j, k), w_mag = 0.25 * (M(A.mag_b, j, k) + M(A.mag_b, j + 1, k) + M(A.mag_b, j, k - 1) + M(A.mag_b, j + 1, k - 1));
+      const real v1 = A.v[g.ix(i1, j, k)], v2 = A.v[g.ix(i2, j, k)];
+      const real w1 = 0.25 * (A.w[g.ix(i1, j, k)] + A.w[g.ix(i1, j + 1, k)] + A.w[g.ix(i1, j, k - 1)] + A.w[g.ix(i1, j + 1, k - 1)]);
+      const real w2 = 0.25 * (A.w[g.ix(i2, j, k)] + A.w[g.ix(i2, j + 1, k)] + A.w[g.ix(i2, j, k - 1)] + A.w[g.ix(i2, j + 1, k - 1)]);
+      const real v_mag = M(A.mag_a, j, k), w_mag = 0.25 * (M(A.mag_b, j, k) + M(A.mag_b, j + 1, k) + M(A.mag_b, j, k - 1) + M(A.mag_b, j + 1, k - 1));
       wallmodel(A.mtype, vel_relative(v1, v2, A.coef, v_mag), vel_relative(w1, w2, A.coef, w_mag), A.h, A.l1d, A.visc, t1, t2);
       M(A.bc_a, j, k) = A.sgn * visci * t1;
     } else {
       if (a < 1 || a > na || b > nb) return;           // j = 1..n2, k = 0..n3
       const int j = a, k = b;
-      const double wei = (A.zf[k] - A.zc[k]) / A.dzc[k];
-      const double v1 = 0.5 * ((1. - wei) * (A.v[g.ix(i1, j - 1, k)] + A.v[g.ix(i1, j, k)]) + wei * (A.v[g.ix(i1, j - 1, k + 1)] + A.v[g.ix(i1, j, k + 1)]));
-      const double v2 = 0.5 * ((1. - wei) * (A.v[g.ix(i2, j - 1, k)] + A.v[g.ix(i2, j, k)]) + wei * (A.v[g.ix(i2, j - 1, k + 1)] + A.v[g.ix(i2, j, k + 1)]));
-      const double w1 = A.w[g.ix(i1, j, k)], w2 = A.w[g.ix(i2, j, k)];
-      const double v_mag = 0.5 * ((1. - wei) * (M(A.mag_a, j - 1, k) + M(A.mag_a, j, k)) + wei * (M(A.mag_a, j - 1, k + 1) + M(A.mag_a, j, k + 1)));
-      const double w_mag = M(A.mag_b, j, k);
+      const real wei = (A.zf[k] - A.zc[k]) / A.dzc[k];
+      const real v1 = 0.5 * ((1. - wei) * (A.v[g.ix(i1, j - 1, k)] + A.v[g.ix(i1, j, k)]) + wei * (A.v[g.ix(i1, j - 1, k + 1)] + A.v[g.ix(i1, j, k + 1)]));
+      const real v2 = 0.5 * ((1. - wei) * (A.v[g.ix(i2, j - 1, k)] + A.v[g.ix(i2, j, k)]) + wei * (A.v[g.ix(i2, j - 1, k + 1)] + A.v[g.ix(i2, j, k + 1)]));
+      const real w1 = A.w[g.ix(i1, j, k)], w2 = A.w[g.ix(i2, j, k)];
+      const real v_mag = 0.5 * ((1. - wei) * (M(A.mag_a, j - 1, k) + M(A.mag_a, j, k)) + wei * (M(A.mag_a, j - 1, k + 1) + M(A.mag_a, j, k + 1)));
+      const real w_mag = M(A.mag_b, j, k);
       wallmodel(A.mtype, vel_relative(v1, v2, A.coef, v_mag), vel_relative(w1, w2, A.coef, w_mag), A.h, A.l1d, A.visc, t1, t2);
       M(A.bc_b, j, k) = A.sgn * visci * t2;
     }
@@ -288,21 +288,21 @@ __global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmArgs A) {
     if (comp == 0) {
       if (a > na || b < 1 || b > nb) return;           // i = 0..n1, k = 1..n3
       const int i = a, k = b;
-      const double u1 = A.u[g.ix(i, j1, k)], u2 = A.u[g.ix(i, j2, k)];
-      const double w1 = 0.25 * (A.w[g.ix(i, j1, k)] + A.w[g.ix(i + 1, j1, k)] + A.w[g.ix(i, j1, k - 1)] + A.w[g.ix(i + 1, j1, k - 1)]);
-      const double w2 = 0.25 * (A.w[g.ix(i, j2, k)] + A.w[g.ix(i + 1, j2, k)] + A.w[g.ix(i, j2, k - 1)] + A.w[g.ix(i + 1, j2, k - 1)]);
-      const double u_mag = M(A.mag_a, i, k), w_mag = 0.25 * (M(A.mag_b, i, k) + M(A.mag_b, i + 1, k) + M(A.mag_b, i, k - 1) + M(A.mag_b, i + 1, k - 1));
+      const real u1 = A.u[g.ix(i, j1, k)], u2 = A.u[g.ix(i, j2, k)];
+      const real w1 = 0.25 * (A.w[g.ix(i, j1, k)] + A.w[g.ix(i + 1, j1, k)] + A.w[g.ix(i, j1, k - 1)] + A.w[g.ix(i + 1, j1, k - 1)]);
+      const real w2 = 0.25 * (A.w[g.ix(i, j2, k)] + A.w[g.ix(i + 1, j2, k)] + A.w[g.ix(i, j2, k - 1)] + A.w[g.ix(i + 1, j2, k - 1)]);
+      const real u_mag = M(A.mag_a, i, k), w_mag = 0.25 * (M(A.mag_b, i, k) + M(A.mag_b, i + 1, k) + M(A.mag_b, i, k - 1) + M(A.mag_b, i + 1, k - 1));
       wallmodel(A.mtype, vel_relative(u1, u2, A.coef, u_mag), vel_relative(w1, w2, A.coef, w_mag), A.h, A.l1d, A.visc, t1, t2);
       M(A.bc_a, i, k) = A.sgn * visci * t1;
     } else {
       if (a < 1 || a > na || b > nb) return;           // i = 1..n1, k = 0..n3
       const int i = a, k = b;
-      const double wei = (A.zf[k] - A.zc[k]) / A.dzc[k];
-      const double u1 = 0.5 * ((1. - wei) * (A.u[g.ix(i - 1, j1, k)] + A.u[g.ix(i, j1, k)]) + wei * (A.u[g.ix(i - 1, j1, k + 1)] + A.u[g.ix(i, j1, k + 1)]));
-      const double u2 = 0.5 * ((1. - wei) * (A.u[g.ix(i - 1, j2, k)] + A.u[g.ix(i, j2, k)]) + wei * (A.u[g.ix(i - 1, j2, k + 1)] + A.u[g.ix(i, j2, k + 1)]));
-      const double w1 = A.w[g.ix(i, j1, k)], w2 = A.w[g.ix(i, j2, k)];
-      const double u_mag = 0.5 * ((1. - wei) * (M(A.mag_a, i - 1, k) + M(A.mag_a, i, k)) + wei * (M(A.mag_a, i - 1, k + 1) + M(A.mag_a, i, k + 1)));
-      const double w_mag = M(A.mag_b, i, k);
+      const real wei = (A.zf[k] - A.zc[k]) / A.dzc[k];
+      const real u1 = 0.5 * ((1. - wei) * (A.u[g.ix(i - 1, j1, k)] + A.u[g.ix(i, j1, k)]) + wei * (A.u[g.ix(i - 1, j1, k + 1)] + A.u[g.ix(i, j1, k + 1)]));
+      const real u2 = 0.5 * ((1. - wei) * (A.u[g.ix(i - 1, j2, k)] + A.u[g.ix(i, j2, k)]) + wei * (A.u[g.ix(i - 1, j2, k + 1)] + A.u[g.ix(i, j2, k + 1)]));
+      const real w1 = A.w[g.ix(i, j1, k)], w2 = A.w[g.ix(i, j2, k)];
+      const real u_mag = 0.5 * ((1. - wei) * (M(A.mag_a, i - 1, k) + M(A.mag_a, i, k)) + wei * (M(A.mag_a, i - 1, k + 1) + M(A.mag_a, i, k + 1)));
+      const real w_mag = M(A.mag_b, i, k);
       wallmodel(A.mtype, vel_relative(u1, u2, A.coef, u_mag), vel_relative(w1, w2, A.coef, w_mag), A.h, A.l1d, A.visc, t1, t2);
       M(A.bc_b, i, k) = A.sgn * visci * t2;
     }
@@ -311,20 +311,20 @@ __global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmArgs A) {
     if (comp == 0) {
       if (a > na || b < 1 || b > nb) return;           // i = 0..n1, j = 1..n2
       const int i = a, j = b;
-      const double u1 = A.u[g.ix(i, j, k1)], u2 = A.u[g.ix(i, j, k2)];
-      const double v1 = 0.25 * (A.v[g.ix(i, j, k1)] + A.v[g.ix(i + 1, j, k1)] + A.v[g.ix(i, j - 1, k1)] + A.v[g.ix(i + 1, j - 1, k1)]);
-      const double v2 = 0.25 * (A.v[g.ix(i, j, k2)] + A.v[g.ix(i + 1, j, k2)] + A.v[g.ix(i, j - 1, k2)] + A.v[g.ix(i + 1, j - 1, k2)]);
-      const double u_mag = M(A.mag_a, i, j), v_mag = 0.25 * (M(A.mag_b, i, j) + M(A.mag_b, i + 1, j) + M(A.mag_b, i, j - 1) + M(A.mag_b, i + 1, j - 1));
+      const real u1 = A.u[g.ix(i, j, k1)], u2 = A.u[g.ix(i, j, k2)];
+      const real v1 = 0.25 * (A.v[g.ix(i, j, k1)] + A.v[g.ix(i + 1, j, k1)] + A.v[g.ix(i, j - 1, k1)] + A.v[g.ix(i + 1, j - 1, k1)]);
+      const real v2 = 0.25 * (A.v[g.ix(i, j, k2)] + A.v[g.ix(i + 1, j, k2)] + A.v[g.ix(i, j - 1, k2)] + A.v[g.ix(i + 1, j - 1, k2)]);
+      const real u_mag = M(A.mag_a, i, j), v_mag = 0.25 * (M(A.mag_b, i, j) + M(A.mag_b, i + 1, j) + M(A.mag_b, i, j - 1) + M(A.mag_b, i + 1, j - 1));
       wallmodel(A.mtype, vel_relative(u1, u2, A.coef, u_mag), vel_relative(v1, v2, A.coef, v_mag), A.h, A.l1d, A.visc, t1, t2);
       M(A.bc_a, i, j) = A.sgn * visci * t1;
     } else {
       if (a < 1 || a > na || b > nb) return;           // i = 1..n1, j = 0..n2
       const int i = a, j = b;
-      const double u1 = 0.25 * (A.u[g.ix(i - 1, j, k1)] + A.u[g.ix(i, j, k1)] + A.u[g.ix(i - 1, j + 1, k1)] + A.u[g.ix(i, j + 1, k1)]);
-      const double u2 = 0.25 * (A.u[g.ix(i - 1, j, k2)] + A.u[g.ix(i, j, k2)] + A.u[g.ix(i - 1, j + 1, k2)] + A.u[g.ix(i, j + 1, k2)]);
-      const double v1 = A.v[g.ix(i, j, k1)], v2 = A.v[g.ix(i, j, k2)];
-      const double u_mag = 0.25 * (M(A.mag_a, i - 1, j) + M(A.mag_a, i, j) + M(A.mag_a, i - 1, j + 1) + M(A.mag_a, i, j + 1));
-      const double v_mag = M(A.mag_b, i, j);
+      const real u1 = 0.25 * (A.u[g.ix(i - 1, j, k1)] + A.u[g.ix(i, j, k1)] + A.u[g.ix(i - 1, j + 1, k1)] + A.u[g.ix(i, j + 1, k1)]);
+      const real u2 = 0.25 * (A.u[g.ix(i - 1, j, k2)] + A.u[g.ix(i, j, k2)] + A.u[g.ix(i - 1, j + 1, k2)] + A.u[g.ix(i, j + 1, k2)]);
+      const real v1 = A.v[g.ix(i, j, k1)], v2 = A.v[g.ix(i, j, k2)];
+      const real u_mag = 0.25 * (M(A.mag_a, i - 1, j) + M(A.mag_a, i, j) + M(A.mag_a, i - 1, j + 1) + M(A.mag_a, i, j + 1));
+      const real v_mag = M(A.mag_b, i, j);
       wallmodel(A.mtype, vel_relative(u1, u2, A.coef, u_mag), vel_relative(v1, v2, A.coef, v_mag), A.h, A.l1d, A.visc, t1, t2);
       M(A.bc_b, i, j) = A.sgn * visci * t2;
     }
@@ -332,8 +332,8 @@ __global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmArgs A) {
 #undef M
 }
 
-static int updt_wallmodelbc(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, const double *u, const double *v, const double *w) {
-  const int *n = c->n; const double h = c->C.hwm; const double *dl = c->dl;
+static int updt_wallmodelbc(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, const real *u, const real *v, const real *w) {
+  const int *n = c->n; const real h = c->C.hwm; const real *dl = c->dl;
   for (int idir = 1; idir <= 3; ++idir) for (int ib = 0; ib <= 1; ++ib) {
     if (!(ISB(c, ib, idir) && LWM(c, ib, idir) != 0)) continue;
     WmArgs A; A.idir = idir; A.ibound = ib; A.mtype = LWM(c, ib, idir); A.h = h; A.visc = c->visc; A.l1d = c->C.l[idir - 1];
@@ -345,7 +345,7 @@ static int updt_wallmodelbc(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, co
     else { A.coef = ib == 0 ? (h - c->zc[A.i1]) / c->dzc[A.i1] : (h - (c->C.l[2] - c->zc[A.i1])) / (c->dzc[A.i2]); }
     DBound *ba = idir == 1 ? &bv : &bu, *bb = idir == 3 ? &bv : &bw;
     const DBound *ma = idir == 1 ? &c->bcv_mag : &c->bcu_mag, *mb = idir == 3 ? &c->bcv_mag : &c->bcw_mag;
-    A.bc_a = const_cast<double *>(plane(*ba, idir, ib, n)); A.bc_b = const_cast<double *>(plane(*bb, idir, ib, n));
+    A.bc_a = const_cast<real *>(plane(*ba, idir, ib, n)); A.bc_b = const_cast<real *>(plane(*bb, idir, ib, n));
     A.mag_a = plane(*ma, idir, ib, n); A.mag_b = plane(*mb, idir, ib, n);
     const int na = idir == 1 ? n[1] : n[0], nb = idir == 3 ? n[1] : n[2];
     dim3 b(64, 4, 1), gr((na + 2 + 63) / 64, (nb + 2 + 3) / 4, 2);
@@ -356,10 +356,10 @@ static int updt_wallmodelbc(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, co
 }
 
 // ------------------------------------------------------------------------------------------ bounduvw (bound.f90:18-154)
-int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm, int is_correc, double *u, double *v, double *w) {
+int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm, int is_correc, real *u, real *v, real *w) {
   ProfScope ps(c, "bounduvw");
   const int *n = c->n;
-  double *fl[3] = {u, v, w};
+  real *fl[3] = {u, v, w};
   DBound *bnd[3] = {&bu, &bv, &bw};
   bool merged = merged_ok(c, c->C.cbcpre, c->C.cbcpre + 2);       // velocity and pressure are periodic together (sanity.f90:163-175)
   for (int ivel = 1; ivel <= 3 && merged; ++ivel) {
@@ -390,10 +390,10 @@ int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm
     BcJobs J; J.njobs = 0; J.idir = idir;
     const bool periodic = CBV(c, 0, idir, idir) == 'P' && CBV(c, 1, idir, idir) == 'P';
     const bool impose_norm = (!is_correc) || periodic;
-    const double drn0 = idir < 3 ? c->dl[idir - 1] : c->dzf[0], drn1 = idir < 3 ? c->dl[idir - 1] : c->dzf[n[2]];
-    const double drt0 = idir < 3 ? c->dl[idir - 1] : c->dzc[0], drt1 = idir < 3 ? c->dl[idir - 1] : c->dzc[n[2]];
+    const real drn0 = idir < 3 ? c->dl[idir - 1] : c->dzf[0], drn1 = idir < 3 ? c->dl[idir - 1] : c->dzf[n[2]];
+    const real drt0 = idir < 3 ? c->dl[idir - 1] : c->dzc[0], drt1 = idir < 3 ? c->dl[idir - 1] : c->dzc[n[2]];
     for (int ivel = 1; ivel <= 3; ++ivel) {
-      double *p = fl[ivel - 1];
+      real *p = fl[ivel - 1];
       const bool normal = ivel == idir;
       const char c0 = CBV(c, 0, idir, ivel), c1 = CBV(c, 1, idir, ivel);
       if (normal) {
@@ -415,7 +415,7 @@ int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm
   if (is_updt_wm) if (int e = updt_wallmodelbc(c, bu, bv, bw, u, v, w)) return e;
   for (int idir = 1; idir <= 3; ++idir) {   // tangential Neumann BCs carrying the wall-model stress (bound.f90:125-148)
     BcJobs J; J.njobs = 0; J.idir = idir;
-    const double drt0 = idir < 3 ? c->dl[idir - 1] : c->dzc[0], drt1 = idir < 3 ? c->dl[idir - 1] : c->dzc[n[2]];
+    const real drt0 = idir < 3 ? c->dl[idir - 1] : c->dzc[0], drt1 = idir < 3 ? c->dl[idir - 1] : c->dzc[n[2]];
     for (int ib = 0; ib <= 1; ++ib) {
       if (!(ISB(c, ib, idir) && LWM(c, ib, idir) != 0)) continue;
       for (int ivel = 1; ivel <= 3; ++ivel) if (ivel != idir)
@@ -427,14 +427,14 @@ int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm
 }
 
 // ------------------------------------------------------------------------------------------ updt_rhs_b (bound.f90:562-617)
-struct RhsJob { double *p; const double *rhs; int idir, pos, na, nb; };
+struct RhsJob { real *p; const real *rhs; int idir, pos, na, nb; };
 __global__ __launch_bounds__(256) void k_updt_rhs_b(Geom g, RhsJob J) {
   const int a = blockIdx.x * 64 + threadIdx.x + 1, b = blockIdx.y * 4 + threadIdx.y + 1;
   if (a > J.na || b > J.nb) return;
   const size_t q = J.idir == 1 ? g.ix(J.pos, a, b) : J.idir == 2 ? g.ix(a, J.pos, b) : g.ix(a, b, J.pos);
   J.p[q] += J.rhs[(a - 1) + (size_t)J.na * (b - 1)];
 }
-static int rhs_b_dir(cales_ctx *c, double *p, int idir, const char *cbc6, const char *cf, const double *rhs, double scale_unused) {
+static int rhs_b_dir(cales_ctx *c, real *p, int idir, const char *cbc6, const char *cf, const real *rhs, real scale_unused) {
   const int *n = c->n;
   const int na = idir == 1 ? n[1] : n[0], nb = idir == 3 ? n[1] : n[2];
   const int q = (cf[idir - 1] == 'f' && cbc6[1 + 2 * (idir - 1)] == 'D') ? 1 : 0;
@@ -463,13 +463,13 @@ int op_updt_rhs_b(cales_ctx *c) {
 // z part of the Helmholtz boundary r.h.s. for one velocity component (main.f90:425-433): rhsbz computed on the
 // host from the CURRENT bc planes would need a download; the planes of wall-model faces change every substep,
 // so the term is evaluated on the device from the plane directly.
-__global__ __launch_bounds__(256) void k_rhs_b_velz(Geom g, double *p, const double *bcplane, int ib, char ctype, char c_or_f, double dlc,
-                                                    double dlf, double alpha, int pos, double *plane_out) {
+__global__ __launch_bounds__(256) void k_rhs_b_velz(Geom g, real *p, const real *bcplane, int ib, char ctype, char c_or_f, real dlc,
+                                                    real dlf, real alpha, int pos, real *plane_out) {
   const int i = blockIdx.x * 64 + threadIdx.x + 1, j = blockIdx.y * 4 + threadIdx.y + 1;
   if (i > g.n1 || j > g.n2) return;
-  const double bcv = bcplane[i + (size_t)(g.n1 + 2) * j];
-  const double sgn = ib == 0 ? 1. : -1.;
-  double r = 0.;
+  const real bcv = bcplane[i + (size_t)(g.n1 + 2) * j];
+  const real sgn = ib == 0 ? 1. : -1.;
+  real r = 0.;
   if (c_or_f == 'c') { if (ctype == 'D') r = -2. * bcv / dlc / dlf; else if (ctype == 'N') r = sgn * bcv / dlf; }
   else               { if (ctype == 'D') r = -bcv / dlc / dlf;      else if (ctype == 'N') r = sgn * bcv / dlc; }
   if (plane_out) plane_out[(size_t)(i - 1) + (size_t)g.n1 * (j - 1)] = r * alpha;      // added by the fused Helmholtz sweep, in the reference's order
@@ -477,19 +477,19 @@ __global__ __launch_bounds__(256) void k_rhs_b_velz(Geom g, double *p, const dou
 }
 // The same term on the x (idir = 1) and y (idir = 2) faces for the 3-D implicit step (main.f90:424-431: rhsbx, rhsby times alpha, added by
 // updt_rhs_b to the first and the last unknown plane of the direction, bound.f90:578-603): inflow profiles, moving side walls.
-__global__ __launch_bounds__(256) void k_rhs_b_velxy(Geom g, double *p, const double *bcplane, int idir, int ib, char ctype, char c_or_f, double dl,
-                                                     double alpha, int pos) {
+__global__ __launch_bounds__(256) void k_rhs_b_velxy(Geom g, real *p, const real *bcplane, int idir, int ib, char ctype, char c_or_f, real dl,
+                                                     real alpha, int pos) {
   const int a = blockIdx.x * 64 + threadIdx.x + 1, k = blockIdx.y * 4 + threadIdx.y + 1;      // a = j (x faces) or i (y faces)
   const int na = idir == 1 ? g.n2 : g.n1;
   if (a > na || k > g.n3) return;
-  const double bcv = bcplane[a + (size_t)(na + 2) * k];
-  const double sgn = ib == 0 ? 1. : -1.;
-  double r = 0.;
+  const real bcv = bcplane[a + (size_t)(na + 2) * k];
+  const real sgn = ib == 0 ? 1. : -1.;
+  real r = 0.;
   if (c_or_f == 'c') { if (ctype == 'D') r = -2. * bcv / dl / dl; else if (ctype == 'N') r = sgn * bcv / dl; }
   else               { if (ctype == 'D') r = -bcv / dl / dl;      else if (ctype == 'N') r = sgn * bcv / dl; }
   p[idir == 1 ? g.ix(pos, a, k) : g.ix(a, pos, k)] += r * alpha;
 }
-int op_rhs_b_velxy(cales_ctx *c, int ivel, double alpha) {
+int op_rhs_b_velxy(cales_ctx *c, int ivel, real alpha) {
   const int *n = c->n;
   const DBound &bc = ivel == 1 ? c->bcu : ivel == 2 ? c->bcv : c->bcw;
   for (int idir = 1; idir <= 2; ++idir) {
@@ -507,7 +507,7 @@ int op_rhs_b_velxy(cales_ctx *c, int ivel, double alpha) {
   return 0;
 }
 // planes != nullptr: the two contributions go to planes[0 / n1*n2] instead of being added to the field; has[ib] tells which exist
-int op_rhs_b_velz(cales_ctx *c, int ivel, double alpha, double *planes, int *has) {
+int op_rhs_b_velz(cales_ctx *c, int ivel, real alpha, real *planes, int *has) {
   const int *n = c->n; const int n3 = n[2];
   const char cf = ivel == 3 ? 'f' : 'c';
   const DBound &bc = ivel == 1 ? c->bcu : ivel == 2 ? c->bcv : c->bcw;
@@ -518,8 +518,8 @@ int op_rhs_b_velz(cales_ctx *c, int ivel, double alpha, double *planes, int *has
   for (int ib = 0; ib <= 1; ++ib) {
     if (!ISB(c, ib, 3) || cbc[ib] == 'P') continue;
     if (has) has[ib] = 1;
-    const double dlc = cf == 'c' ? (ib ? c->dzc[n3] : c->dzc[0]) : (ib ? c->dzc[n3 - 1] : c->dzc[1]);
-    const double dlf = ib ? c->dzf[n3] : c->dzf[1];
+    const real dlc = cf == 'c' ? (ib ? c->dzc[n3] : c->dzc[0]) : (ib ? c->dzc[n3 - 1] : c->dzc[1]);
+    const real dlf = ib ? c->dzf[n3] : c->dzf[1];
     hipLaunchKernelGGL(k_rhs_b_velz, dim3((n[0] + 63) / 64, (n[1] + 3) / 4), dim3(64, 4), 0, c->stream, c->g, c->f[CALES_U + ivel - 1],
                        plane(bc, 3, ib, n), ib, cbc[ib], cf, dlc, dlf, alpha, ib ? n3 - q : 1, planes ? planes + (size_t)ib * n[0] * n[1] : nullptr);
   }

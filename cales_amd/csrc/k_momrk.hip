@@ -17,11 +17,11 @@
 static_assert(5 * (TYM + 2) <= 64, "the x-halo columns of a tile are fetched by the 64 lanes of one wave, 5 fields per row");
 
 struct MomRkArgs {
-  const double *u, *v, *w, *s, *p, *duo, *dvo, *dwo;
-  double *un, *vn, *wn, *du, *dv, *dw, *dud, *dvd, *dwd;
-  const double *dzci, *dzfi;
-  const double *cs;      // != nullptr: s holds |S| of the dynamic model and visct = s * cs(k) (see visct_lazy in common.hpp)
-  double dxi, dyi, visc, f1, f2, f12, bfx, bfy, bfz;
+  const real *u, *v, *w, *s, *p, *duo, *dvo, *dwo;
+  real *un, *vn, *wn, *du, *dv, *dw, *dud, *dvd, *dwd;
+  const real *dzci, *dzfi;
+  const real *cs;      // != nullptr: s holds |S| of the dynamic model and visct = s * cs(k) (see visct_lazy in common.hpp)
+  real dxi, dyi, visc, f1, f2, f12, bfx, bfy, bfz;
   int kchunk;
   BandMap bm;      // block -> tile map of the 1-D launch (bm.gx = 0: plain 3-D grid)
   // low-storage RK3 (param.f90:27-29): the first substep has f2 = 0 -> the old r.h.s. is not read; inside cales_step the r.h.s. of the
@@ -32,8 +32,8 @@ struct MomRkArgs {
 // NOS = 1: no subgrid model (visct is identically zero, sgs.f90:62-68): its loads, LDS traffic and terms are compiled out
 template <int IMP, typename OFF, int NOS>
 __global__ __launch_bounds__(64 * (TYM + 2), (TYM <= 6 ? 4 : 3)) void k_momrk(Geom g, MomRkArgs A) {
-  __shared__ double sh[4][4][TYM + 2][66];
-  __shared__ double shp[3][TYM + 2][66];
+  __shared__ real sh[4][4][TYM + 2][66];
+  __shared__ real shp[3][TYM + 2][66];
   const int tx = threadIdx.x, ty = threadIdx.y;
   int bx_ = blockIdx.x, by_ = blockIdx.y, bz_ = blockIdx.z;
   if (A.bm.gx && !band_block(A.bm, bx_, by_, bz_)) return;
@@ -41,75 +41,75 @@ __global__ __launch_bounds__(64 * (TYM + 2), (TYM <= 6 ? 4 : 3)) void k_momrk(Ge
   const int kbeg = bz_ * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
   const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1;
   const bool outok = ty >= 1 && ty <= TYM && i <= g.n1 && j <= g.n2;
-  const OFF c0 = ldok ? (OFF)g.ix(i, j, 0) * 8 : 0;        // byte offsets (see ldb in common.hpp)
-  const OFF sk = (OFF)g.s12 * 8;
+  const OFF c0 = ldok ? (OFF)g.ix(i, j, 0) * RSZ : 0;        // byte offsets (see ldb in common.hpp)
+  const OFF sk = (OFF)g.s12 * RSZ;
   // x-halo columns (i = 64 bx and 64 bx + 65): the two y-halo waves, which have no outputs, fetch them for all rows of the
   // tile -- wave 0 the left column, wave TYM+1 the right one; lane l -> row l/5, field l%5. One register instead of five.
   const bool hwave = ty == 0 || ty == TYM + 1;
   const int hr = tx / 5, hf_ = tx % 5, hxs = ty == 0 ? 0 : 65, hi_ = ty == 0 ? bx_ * 64 : bx_ * 64 + 65, hj = by_ * TYM + hr;
   const bool hok = hwave && tx < 5 * (TYM + 2) && hi_ <= g.n1 + 1 && hj <= g.n2 + 1 && !(NOS && hf_ == 3);
-  const double *hp = nullptr;
-  if (hok) { const double *fp = hf_ == 0 ? A.u : hf_ == 1 ? A.v : hf_ == 2 ? A.w : hf_ == 3 ? A.s : A.p; hp = fp + g.ix(hi_, hj, 0); }
+  const real *hp = nullptr;
+  if (hok) { const real *fp = hf_ == 0 ? A.u : hf_ == 1 ? A.v : hf_ == 2 ? A.w : hf_ == 3 ? A.s : A.p; hp = fp + g.ix(hi_, hj, 0); }
   const size_t sk64 = (size_t)g.s12;
-  auto ld5 = [&](int k, double *q, double &h) {
-    const double csk = (!NOS && A.cs && k <= g.n3 + 1) ? ldc(A.cs, k) : 1.;
+  auto ld5 = [&](int k, real *q, real &h) {
+    const real csk = (!NOS && A.cs && k <= g.n3 + 1) ? ldc(A.cs, k) : 1.;
     if (ldok && k <= g.n3 + 1) { const OFF c = c0 + (OFF)k * sk; q[0] = ldb(A.u, c); q[1] = ldb(A.v, c); q[2] = ldb(A.w, c); q[3] = NOS ? 0. : ldb(A.s, c) * csk; q[4] = ldb(A.p, c); }
     else { q[0] = q[1] = q[2] = q[3] = q[4] = 0.; }
     h = (hok && k <= g.n3 + 1) ? hp[(size_t)k * sk64] : 0.;
     if (hf_ == 3) h = h * csk;
   };
   // plane kk of the five fields -> ring slot kk&3 (u,v,w,visct) and kk%3 (p)
-  auto put = [&](int kk, const double *q, double h) {
+  auto put = [&](int kk, const real *q, real h) {
 #pragma unroll
     for (int f = 0; f < (NOS ? 3 : 4); ++f) sh[f][kk & 3][ty][tx + 1] = q[f];
     shp[kk % 3][ty][tx + 1] = q[4];
     if (hok) { if (hf_ < 4) sh[hf_][kk & 3][hr][hxs] = h; else shp[kk % 3][hr][hxs] = h; }
   };
-  { double q[5], h;
+  { real q[5], h;
     ld5(kbeg - 1, q, h); put(kbeg - 1, q, h); ld5(kbeg, q, h); put(kbeg, q, h); ld5(kbeg + 1, q, h); put(kbeg + 1, q, h); }
   for (int k = kbeg; k <= kend; ++k) {
     __syncthreads();
-    double pf[5], hf;
+    real pf[5], hf;
     ld5(k + 2, pf, hf);                                     // prefetch, in flight during the stencil
     if (outok) {
       const OFF c = c0 + (OFF)k * sk;
-      double duo = 0., dvo = 0., dwo = 0.;
+      real duo = 0., dvo = 0., dwo = 0.;
       if (A.rd_old) { duo = ldb(A.duo, c); dvo = ldb(A.dvo, c); dwo = ldb(A.dwo, c); }
       const int km = (k - 1) & 3, kc = k & 3, kp = (k + 1) & 3;
 #define LS(f, sl, di, dj) sh[f][sl][ty + (dj)][tx + 1 + (di)]
-      const double u_ccm = LS(0, km, 0, 0), u_cmc = LS(0, kc, 0, -1), u_mcc = LS(0, kc, -1, 0),
+      const real u_ccm = LS(0, km, 0, 0), u_cmc = LS(0, kc, 0, -1), u_mcc = LS(0, kc, -1, 0),
                    u_ccc = LS(0, kc, 0, 0), u_pcc = LS(0, kc, 1, 0), u_mpc = LS(0, kc, -1, 1), u_cpc = LS(0, kc, 0, 1), u_mcp = LS(0, kp, -1, 0),
                    u_ccp = LS(0, kp, 0, 0);
-      const double v_ccm = LS(1, km, 0, 0), v_cmc = LS(1, kc, 0, -1), v_pmc = LS(1, kc, 1, -1), v_mcc = LS(1, kc, -1, 0),
+      const real v_ccm = LS(1, km, 0, 0), v_cmc = LS(1, kc, 0, -1), v_pmc = LS(1, kc, 1, -1), v_mcc = LS(1, kc, -1, 0),
                    v_ccc = LS(1, kc, 0, 0), v_pcc = LS(1, kc, 1, 0), v_cpc = LS(1, kc, 0, 1), v_cmp = LS(1, kp, 0, -1), v_ccp = LS(1, kp, 0, 0);
-      const double w_ccm = LS(2, km, 0, 0), w_pcm = LS(2, km, 1, 0), w_cpm = LS(2, km, 0, 1), w_cmc = LS(2, kc, 0, -1), w_mcc = LS(2, kc, -1, 0),
+      const real w_ccm = LS(2, km, 0, 0), w_pcm = LS(2, km, 1, 0), w_cpm = LS(2, km, 0, 1), w_cmc = LS(2, kc, 0, -1), w_mcc = LS(2, kc, -1, 0),
                    w_ccc = LS(2, kc, 0, 0), w_pcc = LS(2, kc, 1, 0), w_cpc = LS(2, kc, 0, 1), w_ccp = LS(2, kp, 0, 0);
 #define LSV(sl, di, dj) (NOS ? 0. : LS(3, sl, di, dj))
-      const double s_ccm = LSV(km, 0, 0), s_pcm = LSV(km, 1, 0), s_cpm = LSV(km, 0, 1), s_cmc = LSV(kc, 0, -1), s_pmc = LSV(kc, 1, -1),
+      const real s_ccm = LSV(km, 0, 0), s_pcm = LSV(km, 1, 0), s_cpm = LSV(km, 0, 1), s_cmc = LSV(kc, 0, -1), s_pmc = LSV(kc, 1, -1),
                    s_mcc = LSV(kc, -1, 0), s_ccc = LSV(kc, 0, 0), s_pcc = LSV(kc, 1, 0), s_mpc = LSV(kc, -1, 1), s_cpc = LSV(kc, 0, 1),
                    s_cmp = LSV(kp, 0, -1), s_mcp = LSV(kp, -1, 0), s_ccp = LSV(kp, 0, 0), s_ppc = LSV(kc, 1, 1), s_pcp = LSV(kp, 1, 0),
                    s_cpp = LSV(kp, 0, 1);
 #undef LSV
 #undef LS
       const int pc = k % 3, pn = (k + 1) % 3;
-      const double p_ccc = shp[pc][ty][tx + 1], p_pcc = shp[pc][ty][tx + 2], p_cpc = shp[pc][ty + 1][tx + 1], p_ccp = shp[pn][ty][tx + 1];
-      const double dxi = A.dxi, dyi = A.dyi, visc = A.visc;
-      const double dzci_k = ldc(A.dzci, k), dzci_m = ldc(A.dzci, k - 1), dzfi_k = ldc(A.dzfi, k), dzfi_p = ldc(A.dzfi, k + 1);
-      double visc_ip, visc_im, visc_jp, visc_jm, visc_kp, visc_km;
+      const real p_ccc = shp[pc][ty][tx + 1], p_pcc = shp[pc][ty][tx + 2], p_cpc = shp[pc][ty + 1][tx + 1], p_ccp = shp[pn][ty][tx + 1];
+      const real dxi = A.dxi, dyi = A.dyi, visc = A.visc;
+      const real dzci_k = ldc(A.dzci, k), dzci_m = ldc(A.dzci, k - 1), dzfi_k = ldc(A.dzfi, k), dzfi_p = ldc(A.dzfi, k + 1);
+      real visc_ip, visc_im, visc_jp, visc_jm, visc_kp, visc_km;
       // ---- x momentum (mom.f90:143-186)
       visc_ip = s_pcc; visc_im = s_ccc;
       visc_jp = 0.25 * (s_ccc + s_pcc + s_cpc + s_ppc); visc_jm = 0.25 * (s_ccc + s_pcc + s_cmc + s_pmc);
       visc_kp = 0.25 * (s_ccc + s_pcc + s_ccp + s_pcp); visc_km = 0.25 * (s_ccc + s_pcc + s_ccm + s_pcm);
-      const double dudx_ip = (u_pcc - u_ccc) * dxi, dudx_im = (u_ccc - u_mcc) * dxi, dudy_jp = (u_cpc - u_ccc) * dyi,
+      const real dudx_ip = (u_pcc - u_ccc) * dxi, dudx_im = (u_ccc - u_mcc) * dxi, dudy_jp = (u_cpc - u_ccc) * dyi,
                    dudy_jm = (u_ccc - u_cmc) * dyi, dudz_kp = (u_ccp - u_ccc) * dzci_k, dudz_km = (u_ccc - u_ccm) * dzci_m;
-      const double dvdx_jp = (v_pcc - v_ccc) * dxi, dvdx_jm = (v_pmc - v_cmc) * dxi, dwdx_kp = (w_pcc - w_ccc) * dxi,
+      const real dvdx_jp = (v_pcc - v_ccc) * dxi, dvdx_jm = (v_pmc - v_cmc) * dxi, dwdx_kp = (w_pcc - w_ccc) * dxi,
                    dwdx_km = (w_pcm - w_ccm) * dxi;
-      const double uu_ip = 0.25 * (u_pcc + u_ccc) * (u_ccc + u_pcc), uu_im = 0.25 * (u_mcc + u_ccc) * (u_ccc + u_mcc),
+      const real uu_ip = 0.25 * (u_pcc + u_ccc) * (u_ccc + u_pcc), uu_im = 0.25 * (u_mcc + u_ccc) * (u_ccc + u_mcc),
                    vu_jp = 0.25 * (v_pcc + v_ccc) * (u_ccc + u_cpc), vu_jm = 0.25 * (v_pmc + v_cmc) * (u_ccc + u_cmc),
                    wu_kp = 0.25 * (w_pcc + w_ccc) * (u_ccc + u_ccp), wu_km = 0.25 * (w_pcm + w_ccm) * (u_ccc + u_ccm);
-      const double dudtd_xy = visc * (dudx_ip - dudx_im) * dxi + visc * (dudy_jp - dudy_jm) * dyi;
-      const double dudtd_z = visc * (dudz_kp - dudz_km) * dzfi_k;
-      const double dudt_s = -(uu_ip - uu_im) * dxi - (vu_jp - vu_jm) * dyi - (wu_kp - wu_km) * dzfi_k +
+      const real dudtd_xy = visc * (dudx_ip - dudx_im) * dxi + visc * (dudy_jp - dudy_jm) * dyi;
+      const real dudtd_z = visc * (dudz_kp - dudz_km) * dzfi_k;
+      const real dudt_s = -(uu_ip - uu_im) * dxi - (vu_jp - vu_jm) * dyi - (wu_kp - wu_km) * dzfi_k +
                             (visc_ip * (dudx_ip + dudx_ip) - visc_im * (dudx_im + dudx_im)) * dxi +
                             (visc_jp * (dudy_jp + dvdx_jp) - visc_jm * (dudy_jm + dvdx_jm)) * dyi +
                             (visc_kp * (dudz_kp + dwdx_kp) - visc_km * (dudz_km + dwdx_km)) * dzfi_k;
@@ -117,16 +117,16 @@ __global__ __launch_bounds__(64 * (TYM + 2), (TYM <= 6 ? 4 : 3)) void k_momrk(Ge
       visc_ip = 0.25 * (s_ccc + s_cpc + s_pcc + s_ppc); visc_im = 0.25 * (s_ccc + s_cpc + s_mcc + s_mpc);
       visc_jp = s_cpc; visc_jm = s_ccc;
       visc_kp = 0.25 * (s_ccc + s_cpc + s_ccp + s_cpp); visc_km = 0.25 * (s_ccc + s_cpc + s_ccm + s_cpm);
-      const double dvdx_ip = (v_pcc - v_ccc) * dxi, dvdx_im = (v_ccc - v_mcc) * dxi, dvdy_jp = (v_cpc - v_ccc) * dyi,
+      const real dvdx_ip = (v_pcc - v_ccc) * dxi, dvdx_im = (v_ccc - v_mcc) * dxi, dvdy_jp = (v_cpc - v_ccc) * dyi,
                    dvdy_jm = (v_ccc - v_cmc) * dyi, dvdz_kp = (v_ccp - v_ccc) * dzci_k, dvdz_km = (v_ccc - v_ccm) * dzci_m;
-      const double dudy_ip = (u_cpc - u_ccc) * dyi, dudy_im = (u_mpc - u_mcc) * dyi, dwdy_kp = (w_cpc - w_ccc) * dyi,
+      const real dudy_ip = (u_cpc - u_ccc) * dyi, dudy_im = (u_mpc - u_mcc) * dyi, dwdy_kp = (w_cpc - w_ccc) * dyi,
                    dwdy_km = (w_cpm - w_ccm) * dyi;
-      const double uv_ip = 0.25 * (u_ccc + u_cpc) * (v_ccc + v_pcc), uv_im = 0.25 * (u_mcc + u_mpc) * (v_ccc + v_mcc),
+      const real uv_ip = 0.25 * (u_ccc + u_cpc) * (v_ccc + v_pcc), uv_im = 0.25 * (u_mcc + u_mpc) * (v_ccc + v_mcc),
                    vv_jp = 0.25 * (v_ccc + v_cpc) * (v_ccc + v_cpc), vv_jm = 0.25 * (v_ccc + v_cmc) * (v_ccc + v_cmc),
                    wv_kp = 0.25 * (w_ccc + w_cpc) * (v_ccc + v_ccp), wv_km = 0.25 * (w_ccm + w_cpm) * (v_ccc + v_ccm);
-      const double dvdtd_xy = visc * (dvdx_ip - dvdx_im) * dxi + visc * (dvdy_jp - dvdy_jm) * dyi;
-      const double dvdtd_z = visc * (dvdz_kp - dvdz_km) * dzfi_k;
-      const double dvdt_s = -(uv_ip - uv_im) * dxi - (vv_jp - vv_jm) * dyi - (wv_kp - wv_km) * dzfi_k +
+      const real dvdtd_xy = visc * (dvdx_ip - dvdx_im) * dxi + visc * (dvdy_jp - dvdy_jm) * dyi;
+      const real dvdtd_z = visc * (dvdz_kp - dvdz_km) * dzfi_k;
+      const real dvdt_s = -(uv_ip - uv_im) * dxi - (vv_jp - vv_jm) * dyi - (wv_kp - wv_km) * dzfi_k +
                             (visc_ip * (dvdx_ip + dudy_ip) - visc_im * (dvdx_im + dudy_im)) * dxi +
                             (visc_jp * (dvdy_jp + dvdy_jp) - visc_jm * (dvdy_jm + dvdy_jm)) * dyi +
                             (visc_kp * (dvdz_kp + dwdy_kp) - visc_km * (dvdz_km + dwdy_km)) * dzfi_k;
@@ -134,27 +134,27 @@ __global__ __launch_bounds__(64 * (TYM + 2), (TYM <= 6 ? 4 : 3)) void k_momrk(Ge
       visc_ip = 0.25 * (s_ccc + s_ccp + s_pcc + s_pcp); visc_im = 0.25 * (s_ccc + s_ccp + s_mcc + s_mcp);
       visc_jp = 0.25 * (s_ccc + s_ccp + s_cpc + s_cpp); visc_jm = 0.25 * (s_ccc + s_ccp + s_cmc + s_cmp);
       visc_kp = s_ccp; visc_km = s_ccc;
-      const double dwdx_ip = (w_pcc - w_ccc) * dxi, dwdx_im = (w_ccc - w_mcc) * dxi, dwdy_jp = (w_cpc - w_ccc) * dyi,
+      const real dwdx_ip = (w_pcc - w_ccc) * dxi, dwdx_im = (w_ccc - w_mcc) * dxi, dwdy_jp = (w_cpc - w_ccc) * dyi,
                    dwdy_jm = (w_ccc - w_cmc) * dyi, dwdz_kp = (w_ccp - w_ccc) * dzfi_p, dwdz_km = (w_ccc - w_ccm) * dzfi_k;
-      const double dudz_ip = (u_ccp - u_ccc) * dzci_k, dudz_im = (u_mcp - u_mcc) * dzci_k, dvdz_jp = (v_ccp - v_ccc) * dzci_k,
+      const real dudz_ip = (u_ccp - u_ccc) * dzci_k, dudz_im = (u_mcp - u_mcc) * dzci_k, dvdz_jp = (v_ccp - v_ccc) * dzci_k,
                    dvdz_jm = (v_cmp - v_cmc) * dzci_k;
-      const double uw_ip = 0.25 * (u_ccc + u_ccp) * (w_ccc + w_pcc), uw_im = 0.25 * (u_mcc + u_mcp) * (w_ccc + w_mcc),
+      const real uw_ip = 0.25 * (u_ccc + u_ccp) * (w_ccc + w_pcc), uw_im = 0.25 * (u_mcc + u_mcp) * (w_ccc + w_mcc),
                    vw_jp = 0.25 * (v_ccc + v_ccp) * (w_ccc + w_cpc), vw_jm = 0.25 * (v_cmc + v_cmp) * (w_ccc + w_cmc),
                    ww_kp = 0.25 * (w_ccc + w_ccp) * (w_ccc + w_ccp), ww_km = 0.25 * (w_ccc + w_ccm) * (w_ccc + w_ccm);
-      const double dwdtd_xy = visc * (dwdx_ip - dwdx_im) * dxi + visc * (dwdy_jp - dwdy_jm) * dyi;
-      const double dwdtd_z = visc * (dwdz_kp - dwdz_km) * dzci_k;
-      const double dwdt_s = -(uw_ip - uw_im) * dxi - (vw_jp - vw_jm) * dyi - (ww_kp - ww_km) * dzci_k +
+      const real dwdtd_xy = visc * (dwdx_ip - dwdx_im) * dxi + visc * (dwdy_jp - dwdy_jm) * dyi;
+      const real dwdtd_z = visc * (dwdz_kp - dwdz_km) * dzci_k;
+      const real dwdt_s = -(uw_ip - uw_im) * dxi - (vw_jp - vw_jm) * dyi - (ww_kp - ww_km) * dzci_k +
                             (visc_ip * (dwdx_ip + dudz_ip) - visc_im * (dwdx_im + dudz_im)) * dxi +
                             (visc_jp * (dwdy_jp + dvdz_jp) - visc_jm * (dwdy_jm + dvdz_jm)) * dyi +
                             (visc_kp * (dwdz_kp + dwdz_kp) - visc_km * (dwdz_km + dwdz_km)) * dzci_k;
-      double du, dv, dw, dud = 0., dvd = 0., dwd = 0.;
+      real du, dv, dw, dud = 0., dvd = 0., dwd = 0.;
       if (IMP == 2) { du = dudt_s + dudtd_xy; dv = dvdt_s + dvdtd_xy; dw = dwdt_s + dwdtd_xy; dud = dudtd_z; dvd = dvdtd_z; dwd = dwdtd_z; }   // mom.f90:278-284
       else if (IMP == 1) { du = dudt_s; dv = dvdt_s; dw = dwdt_s; dud = dudtd_xy + dudtd_z; dvd = dvdtd_xy + dvdtd_z; dwd = dwdtd_xy + dwdtd_z; }       // mom.f90:285-288
       else { du = dudt_s + dudtd_xy + dudtd_z; dv = dvdt_s + dvdtd_xy + dvdtd_z; dw = dwdt_s + dwdtd_xy + dwdtd_z; }                        // mom.f90:297-302
       // ---- RK update (rk.f90:81-91)
-      double un = u_ccc + A.f1 * du + A.f2 * duo + A.f12 * (A.bfx - dxi * (p_pcc - p_ccc));
-      double vn = v_ccc + A.f1 * dv + A.f2 * dvo + A.f12 * (A.bfy - dyi * (p_cpc - p_ccc));
-      double wn = w_ccc + A.f1 * dw + A.f2 * dwo + A.f12 * (A.bfz - dzci_k * (p_ccp - p_ccc));
+      real un = u_ccc + A.f1 * du + A.f2 * duo + A.f12 * (A.bfx - dxi * (p_pcc - p_ccc));
+      real vn = v_ccc + A.f1 * dv + A.f2 * dvo + A.f12 * (A.bfy - dyi * (p_cpc - p_ccc));
+      real wn = w_ccc + A.f1 * dw + A.f2 * dwo + A.f12 * (A.bfz - dzci_k * (p_ccp - p_ccc));
       if (IMP) { un = un + A.f12 * dud; vn = vn + A.f12 * dvd; wn = wn + A.f12 * dwd; stb(A.dud, c, dud); stb(A.dvd, c, dvd); stb(A.dwd, c, dwd); }
       stb(A.un, c, un); stb(A.vn, c, vn); stb(A.wn, c, wn);
       if (A.wr_new) { stb(A.du, c, du); stb(A.dv, c, dv); stb(A.dw, c, dw); }
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64 * (TYM + 2), (TYM <= 6 ? 4 : 3)) void k_momrk(Ge
 // The reference updates u,v,w in place, so their ghost cells keep the values of the last bounduvw until the next one -- and the wall model
 // reads them when its sampling height lies between the wall and the first cell centre (index_wm = 1 or n: wmodel.f90:120-131 with i1 = 0 /
 // n+1). The fused kernel writes the new velocities to a second set of buffers: with a wall model the ghost layers travel along.
-struct GhostCopy { const double *src[3]; double *dst[3]; };
+struct GhostCopy { const real *src[3]; real *dst[3]; };
 __global__ __launch_bounds__(256) void k_copy_ghosts(Geom g, int idir, GhostCopy G) {
   const int na = idir == 1 ? g.n2 : g.n1, nb = idir == 3 ? g.n2 : g.n3, n = idir == 1 ? g.n1 : idir == 2 ? g.n2 : g.n3;
   const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y, f = blockIdx.z >> 1, side = blockIdx.z & 1;
@@ -176,9 +176,9 @@ __global__ __launch_bounds__(256) void k_copy_ghosts(Geom g, int idir, GhostCopy
   G.dst[f][c] = G.src[f][c];
 }
 // mom_xyz_ad + update of rk (rk.f90:74-94); leaves the new velocities in c->f[CALES_U..W] (pointers swapped with c->f2)
-int op_momrk(cales_ctx *c, double f1, double f2, double f12) {
+int op_momrk(cales_ctx *c, real f1, real f2, real f12) {
   ProfScope ps(c, "mom_rk_fused");
-  const int *n = c->n; double **f = c->f;
+  const int *n = c->n; real **f = c->f;
   MomRkArgs A;
   A.u = f[CALES_U]; A.v = f[CALES_V]; A.w = f[CALES_W]; A.s = f[CALES_VISCT]; A.p = f[CALES_P];
   A.duo = f[CALES_DUDTO]; A.dvo = f[CALES_DVDTO]; A.dwo = f[CALES_DWDTO];
@@ -197,7 +197,7 @@ int op_momrk(cales_ctx *c, double f1, double f2, double f12) {
   gr.z = (n[2] + kchunk - 1) / kchunk; A.kchunk = kchunk;
   A.bm = BandMap{0, 0, 0, 0};
   if (!c->fl.plain_grid && (band_wanted(gr.x) || c->fl.band_grid)) { A.bm = band_map(gr.x, gr.y, gr.z); gr = dim3(band_blocks(A.bm), 1, 1); }
-  const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32) && !c->fl.wide_offsets;      // 32-bit byte offsets
+  const bool small = (c->ntot + 16) * sizeof(real) < (1ull << 32) && !c->fl.wide_offsets;      // 32-bit byte offsets
   const int nos = c->C.sgstype == 0 && c->visct_zero;     // visct known to be identically zero (never set by the host since the last zeroing)
 #define MOMRK_LAUNCH(IMP_)                                                                                             \
   do {                                                                                                                 \

@@ -9,7 +9,7 @@
 #define BY 4
 
 // ------------------------------------------------------------------------------------------ extrapolate
-struct ExJob { double *p; int idir, ibound; double factor; double *save; int restore; };   // save: plane buffer for the overwritten ghosts
+struct ExJob { real *p; int idir, ibound; real factor; real *save; int restore; };   // save: plane buffer for the overwritten ghosts
 struct ExJobs { int njobs; ExJob job[18]; };
 __global__ __launch_bounds__(256) void k_extrapolate(Geom g, ExJobs J) {
   const ExJob jb = J.job[blockIdx.z];
@@ -18,9 +18,9 @@ __global__ __launch_bounds__(256) void k_extrapolate(Geom g, ExJobs J) {
   const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y;
   if (a > na + 1 || b > nb + 1) return;
   const long st = idir == 1 ? 1 : idir == 2 ? (long)g.s1 : g.s12;
-  double *p = jb.p + (idir == 1 ? g.ix(0, a, b) : idir == 2 ? g.ix(a, 0, b) : g.ix(a, b, 0));
+  real *p = jb.p + (idir == 1 ? g.ix(0, a, b) : idir == 2 ? g.ix(a, 0, b) : g.ix(a, b, 0));
 #define P(m) p[(long)(m)*st]
-  const double f = jb.factor;
+  const real f = jb.factor;
   const int gh = jb.ibound == 0 ? 0 : n + 1;
   if (jb.save) {                      // in-place use on a live field: keep / give back the ghost value
     const size_t q = (size_t)a + (size_t)(na + 2) * b;
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void k_extrapolate(Geom g, ExJobs J) {
 // mode 0: `lwm` form (wall-model faces, z factors from the grid), 1: `cbc` form (all no-slip walls, factor 1)
 // save != nullptr: the fields are live (u,v,w themselves): the ghosts they lose are kept in `save` (restore = 0) and given back
 // afterwards (restore = 1, directions in reverse order so that edge cells see the same sequence backwards)
-static int extrapolate(cales_ctx *c, int nf, double **p, const int *iface, int mode, double *save = nullptr, int restore = 0) {
+static int extrapolate(cales_ctx *c, int nf, real **p, const int *iface, int mode, real *save = nullptr, int restore = 0) {
   const int *n = c->n;
   // save slots: [direction][field][side], each the size of that direction's ghost plane
   const size_t psz[3] = {(size_t)(n[1] + 2) * (n[2] + 2), (size_t)(n[0] + 2) * (n[2] + 2), (size_t)(n[0] + 2) * (n[1] + 2)};
@@ -44,7 +44,7 @@ static int extrapolate(cales_ctx *c, int nf, double **p, const int *iface, int m
     ExJobs J; J.njobs = 0;
     for (int q = 0; q < nf; ++q) for (int ib = 0; ib <= 1; ++ib) {
       bool done;
-      double factor = 1.;
+      real factor = 1.;
       if (mode == 1) done = ISB(c, ib, idir) && CBV(c, ib, idir, idir) == 'D' && iface[q] != idir;
       else {
         done = ISB(c, ib, idir) && LWM(c, ib, idir) != 0 && iface[q] != idir;
@@ -64,70 +64,70 @@ static int extrapolate(cales_ctx *c, int nf, double **p, const int *iface, int m
 
 // ------------------------------------------------------------------------------------------ strain_rate
 template <int WITH_SIJ>
-__global__ __launch_bounds__(BX *BY) void k_strain(Geom g, double dxi, double dyi, const double *__restrict__ dzci,
-                                                    const double *__restrict__ dzfi, const double *__restrict__ u,
-                                                    const double *__restrict__ v, const double *__restrict__ w, double *__restrict__ s0,
-                                                    double *__restrict__ s11o, double *__restrict__ s22o, double *__restrict__ s33o,
-                                                    double *__restrict__ s12o, double *__restrict__ s13o, double *__restrict__ s23o) {
+__global__ __launch_bounds__(BX *BY) void k_strain(Geom g, real dxi, real dyi, const real *__restrict__ dzci,
+                                                    const real *__restrict__ dzfi, const real *__restrict__ u,
+                                                    const real *__restrict__ v, const real *__restrict__ w, real *__restrict__ s0,
+                                                    real *__restrict__ s11o, real *__restrict__ s22o, real *__restrict__ s33o,
+                                                    real *__restrict__ s12o, real *__restrict__ s13o, real *__restrict__ s23o) {
   int bx_, by_, bz_; stencil_block(bx_, by_, bz_);
   const int i = bx_ * BX + threadIdx.x + 1, j = by_ * BY + threadIdx.y + 1, k = bz_ + 1;
   if (i > g.n1 || j > g.n2) return;
   const size_t c = g.ix(i, j, k);
   const long sj = g.s1, sk = g.s12;
 #define LD(a, di, dj, dk) a[c + (di) + (dj)*sj + (dk)*sk]
-  const double u_mcm = LD(u, -1, 0, -1), u_ccm = LD(u, 0, 0, -1), u_mmc = LD(u, -1, -1, 0), u_cmc = LD(u, 0, -1, 0), u_mcc = LD(u, -1, 0, 0),
+  const real u_mcm = LD(u, -1, 0, -1), u_ccm = LD(u, 0, 0, -1), u_mmc = LD(u, -1, -1, 0), u_cmc = LD(u, 0, -1, 0), u_mcc = LD(u, -1, 0, 0),
                u_ccc = LD(u, 0, 0, 0), u_mpc = LD(u, -1, 1, 0), u_cpc = LD(u, 0, 1, 0), u_mcp = LD(u, -1, 0, 1), u_ccp = LD(u, 0, 0, 1);
-  const double v_cmm = LD(v, 0, -1, -1), v_ccm = LD(v, 0, 0, -1), v_mmc = LD(v, -1, -1, 0), v_cmc = LD(v, 0, -1, 0), v_pmc = LD(v, 1, -1, 0),
+  const real v_cmm = LD(v, 0, -1, -1), v_ccm = LD(v, 0, 0, -1), v_mmc = LD(v, -1, -1, 0), v_cmc = LD(v, 0, -1, 0), v_pmc = LD(v, 1, -1, 0),
                v_mcc = LD(v, -1, 0, 0), v_ccc = LD(v, 0, 0, 0), v_pcc = LD(v, 1, 0, 0), v_cmp = LD(v, 0, -1, 1), v_ccp = LD(v, 0, 0, 1);
-  const double w_cmm = LD(w, 0, -1, -1), w_mcm = LD(w, -1, 0, -1), w_ccm = LD(w, 0, 0, -1), w_pcm = LD(w, 1, 0, -1), w_cpm = LD(w, 0, 1, -1),
+  const real w_cmm = LD(w, 0, -1, -1), w_mcm = LD(w, -1, 0, -1), w_ccm = LD(w, 0, 0, -1), w_pcm = LD(w, 1, 0, -1), w_cpm = LD(w, 0, 1, -1),
                w_cmc = LD(w, 0, -1, 0), w_mcc = LD(w, -1, 0, 0), w_ccc = LD(w, 0, 0, 0), w_pcc = LD(w, 1, 0, 0), w_cpc = LD(w, 0, 1, 0);
 #undef LD
-  const double zc = dzci[k], zm = dzci[k - 1];
-  const double s11 = (u_ccc - u_mcc) * dxi, s22 = (v_ccc - v_cmc) * dyi, s33 = (w_ccc - w_ccm) * dzfi[k];
-  const double s12 = .125 * ((u_cpc - u_ccc) * dyi + (v_pcc - v_ccc) * dxi + (u_ccc - u_cmc) * dyi + (v_pmc - v_cmc) * dxi +
+  const real zc = dzci[k], zm = dzci[k - 1];
+  const real s11 = (u_ccc - u_mcc) * dxi, s22 = (v_ccc - v_cmc) * dyi, s33 = (w_ccc - w_ccm) * dzfi[k];
+  const real s12 = .125 * ((u_cpc - u_ccc) * dyi + (v_pcc - v_ccc) * dxi + (u_ccc - u_cmc) * dyi + (v_pmc - v_cmc) * dxi +
                              (u_mpc - u_mcc) * dyi + (v_ccc - v_mcc) * dxi + (u_mcc - u_mmc) * dyi + (v_cmc - v_mmc) * dxi);
-  const double s13 = .125 * ((u_ccp - u_ccc) * zc + (w_pcc - w_ccc) * dxi + (u_ccc - u_ccm) * zm + (w_pcm - w_ccm) * dxi +
+  const real s13 = .125 * ((u_ccp - u_ccc) * zc + (w_pcc - w_ccc) * dxi + (u_ccc - u_ccm) * zm + (w_pcm - w_ccm) * dxi +
                              (u_mcp - u_mcc) * zc + (w_ccc - w_mcc) * dxi + (u_mcc - u_mcm) * zm + (w_ccm - w_mcm) * dxi);
-  const double s23 = .125 * ((v_ccp - v_ccc) * zc + (w_cpc - w_ccc) * dyi + (v_ccc - v_ccm) * zm + (w_cpm - w_ccm) * dyi +
+  const real s23 = .125 * ((v_ccp - v_ccc) * zc + (w_cpc - w_ccc) * dyi + (v_ccc - v_ccm) * zm + (w_cpm - w_ccm) * dyi +
                              (v_cmp - v_cmc) * zc + (w_ccc - w_cmc) * dyi + (v_cmc - v_cmm) * zm + (w_ccm - w_cmm) * dyi);
-  const double s0v = sqrt(2. * (s11 * s11 + s22 * s22 + s33 * s33 + 2. * (s12 * s12 + s13 * s13 + s23 * s23)));
+  const real s0v = sqrt(2. * (s11 * s11 + s22 * s22 + s33 * s33 + 2. * (s12 * s12 + s13 * s13 + s23 * s23)));
   s0[c] = s0v;
   if (WITH_SIJ) { s11o[c] = s11; s22o[c] = s22; s33o[c] = s33; s12o[c] = s12; s13o[c] = s13; s23o[c] = s23; }
 }
-static int strain_rate(cales_ctx *c, const double *u, const double *v, const double *w, double *s0, double **sij) {
+static int strain_rate(cales_ctx *c, const real *u, const real *v, const real *w, real *s0, real **sij) {
   ProfScope ps(c, "strain_rate");
   dim3 b(BX, BY, 1), gr = grid3(c->n[0], c->n[1], c->n[2], b);
   if (sij) hipLaunchKernelGGL(k_strain<1>, gr, b, 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, u, v, w, s0, sij[0], sij[1], sij[2], sij[3], sij[4], sij[5]);
-  else hipLaunchKernelGGL(k_strain<0>, gr, b, 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, u, v, w, s0, (double *)nullptr,
-                          (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr);
+  else hipLaunchKernelGGL(k_strain<0>, gr, b, 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, u, v, w, s0, (real *)nullptr,
+                          (real *)nullptr, (real *)nullptr, (real *)nullptr, (real *)nullptr, (real *)nullptr);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
 
 // ------------------------------------------------------------------------------------------ static Smagorinsky (sgs.f90:98-152)
-struct SmagArgs { double w0, w1, w2, w3, w4, w5, dl1, dl2, l3, dxi, dyi, visc, sumw; };
-__global__ __launch_bounds__(BX *BY) void k_smag(Geom g, SmagArgs A, const double *__restrict__ zc, const double *__restrict__ dzci,
-                                                  const double *__restrict__ dzf, const double *__restrict__ u, const double *__restrict__ v,
-                                                  const double *__restrict__ w, const double *__restrict__ s0, double *__restrict__ visct) {
+struct SmagArgs { real w0, w1, w2, w3, w4, w5, dl1, dl2, l3, dxi, dyi, visc, sumw; };
+__global__ __launch_bounds__(BX *BY) void k_smag(Geom g, SmagArgs A, const real *__restrict__ zc, const real *__restrict__ dzci,
+                                                  const real *__restrict__ dzf, const real *__restrict__ u, const real *__restrict__ v,
+                                                  const real *__restrict__ w, const real *__restrict__ s0, real *__restrict__ visct) {
   int bx_, by_, bz_; stencil_block(bx_, by_, bz_);
   const int i = bx_ * BX + threadIdx.x + 1, j = by_ * BY + threadIdx.y + 1, k = bz_ + 1;
   if (i > g.n1 || j > g.n2) return;
-  double fd;
+  real fd;
   if (A.sumw == 0.) fd = 1.;
   else {
     const int jg = j + g.jlo;                    // global row: distances to the y walls use global indices
-    double dw[6];
+    real dw[6];
     dw[0] = A.dl1 * (i - 0.5); dw[1] = A.dl1 * (g.n1 - i + 0.5);
     dw[2] = A.dl2 * (jg - 0.5); dw[3] = A.dl2 * (g.ng2 - jg + 0.5);
     dw[4] = zc[k]; dw[5] = A.l3 - zc[k];
-    const double isw[6] = {A.w0, A.w1, A.w2, A.w3, A.w4, A.w5};
+    const real isw[6] = {A.w0, A.w1, A.w2, A.w3, A.w4, A.w5};
     int loc = 0;
 #pragma unroll
     for (int q = 0; q < 6; ++q) dw[q] = dw[q] * isw[q] + CALES_BIG * (1. - isw[q]);
 #pragma unroll
     for (int q = 1; q < 6; ++q) if (dw[q] < dw[loc]) loc = q;
-    const double dw_min = dw[loc];
-    double t1, t2, sc;
+    const real dw_min = dw[loc];
+    real t1, t2, sc;
     const int n1 = g.n1, n2 = g.n2, n3 = g.n3;
     switch (loc) {
     case 0: t1 = v[g.ix(1, j, k)] - v[g.ix(0, j, k)] + v[g.ix(1, j - 1, k)] - v[g.ix(0, j - 1, k)];
@@ -143,41 +143,41 @@ __global__ __launch_bounds__(BX *BY) void k_smag(Geom g, SmagArgs A, const doubl
     default: t1 = u[g.ix(i, j, n3)] - u[g.ix(i, j, n3 + 1)] + u[g.ix(i - 1, j, n3)] - u[g.ix(i - 1, j, n3 + 1)];
              t2 = v[g.ix(i, j, n3)] - v[g.ix(i, j, n3 + 1)] + v[g.ix(i, j - 1, n3)] - v[g.ix(i, j - 1, n3 + 1)]; sc = dzci[n3]; break;
     }
-    double tauw_s = sqrt(t1 * t1 + t2 * t2) * sc;
+    real tauw_s = sqrt(t1 * t1 + t2 * t2) * sc;
     tauw_s = 0.5 * A.visc * tauw_s;
-    const double dw_plus = dw_min * sqrt(tauw_s) * (1. / A.visc);
+    const real dw_plus = dw_min * sqrt(tauw_s) * (1. / A.visc);
     fd = 1. - exp(-dw_plus / 25.);
   }
-  const double t = 0.11 * dzf[k] * fd;        // dzf[] here is the table (dx dy dzf(k))^(1/3) of k_smag_del (sgs.f90:145); c_smag, src/param.f90:33
+  const real t = 0.11 * dzf[k] * fd;        // dzf[] here is the table (dx dy dzf(k))^(1/3) of k_smag_del (sgs.f90:145); c_smag, src/param.f90:33
   const size_t c = g.ix(i, j, k);
   visct[c] = (t * t) * s0[c];
 }
 
 // ------------------------------------------------------------------------------------------ small dsmag kernels
-__global__ __launch_bounds__(256) void k_copy3(size_t n, const double *__restrict__ a, const double *__restrict__ b, const double *__restrict__ c_,
-                                               double *__restrict__ x, double *__restrict__ y, double *__restrict__ z) {
+__global__ __launch_bounds__(256) void k_copy3(size_t n, const real *__restrict__ a, const real *__restrict__ b, const real *__restrict__ c_,
+                                               real *__restrict__ x, real *__restrict__ y, real *__restrict__ z) {
   for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) { x[q] = a[q]; y[q] = b[q]; z[q] = c_[q]; }
 }
-__global__ __launch_bounds__(256) void k_copy1(size_t n, const double *__restrict__ a, double *__restrict__ x) {
+__global__ __launch_bounds__(256) void k_copy1(size_t n, const real *__restrict__ a, real *__restrict__ x) {
   for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) x[q] = a[q];
 }
-struct P6 { double *p[6]; };
-struct CP6 { const double *p[6]; };
-__global__ __launch_bounds__(256) void k_s0sij(size_t n, const double *__restrict__ s0, CP6 sij, P6 wk) {   // sgs.f90:198-210 (all cells)
+struct P6 { real *p[6]; };
+struct CP6 { const real *p[6]; };
+__global__ __launch_bounds__(256) void k_s0sij(size_t n, const real *__restrict__ s0, CP6 sij, P6 wk) {   // sgs.f90:198-210 (all cells)
   for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) {
-    const double s = s0[q];
+    const real s = s0[q];
 #pragma unroll
     for (int m = 0; m < 6; ++m) wk.p[m][q] = s * sij.p[m][q];
   }
 }
-__global__ __launch_bounds__(256) void k_uiuj(size_t n, const double *__restrict__ uc, const double *__restrict__ vc, const double *__restrict__ wc, P6 wk) {
+__global__ __launch_bounds__(256) void k_uiuj(size_t n, const real *__restrict__ uc, const real *__restrict__ vc, const real *__restrict__ wc, P6 wk) {
   for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) {   // sgs.f90:283-295
-    const double a = uc[q], b = vc[q], c_ = wc[q];
+    const real a = uc[q], b = vc[q], c_ = wc[q];
     wk.p[0][q] = a * a; wk.p[1][q] = b * b; wk.p[2][q] = c_ * c_; wk.p[3][q] = a * b; wk.p[4][q] = a * c_; wk.p[5][q] = b * c_;
   }
 }
 // filter3d (sgs.f90:632-679): 27-point top-hat, weights 8/4/2/1 over 64
-__global__ __launch_bounds__(BX *BY) void k_filter3d(Geom g, const double *__restrict__ p, double *__restrict__ pf) {
+__global__ __launch_bounds__(BX *BY) void k_filter3d(Geom g, const real *__restrict__ p, real *__restrict__ pf) {
   int bx_, by_, bz_; stencil_block(bx_, by_, bz_);
   const int i = bx_ * BX + threadIdx.x + 1, j = by_ * BY + threadIdx.y + 1, k = bz_ + 1;
   if (i > g.n1 || j > g.n2) return;
@@ -190,39 +190,39 @@ __global__ __launch_bounds__(BX *BY) void k_filter3d(Geom g, const double *__res
            1. * (Q(-1, -1, -1) + Q(1, -1, -1) + Q(-1, 1, -1) + Q(1, 1, -1) + Q(-1, -1, 1) + Q(1, -1, 1) + Q(-1, 1, 1) + Q(1, 1, 1))) / 64.;
 #undef Q
 }
-__global__ __launch_bounds__(BX *BY) void k_mij(Geom g, P6 mij, const double *__restrict__ alph2, const double *__restrict__ s0, CP6 sij) {
+__global__ __launch_bounds__(BX *BY) void k_mij(Geom g, P6 mij, const real *__restrict__ alph2, const real *__restrict__ s0, CP6 sij) {
   const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;   // sgs.f90:262-272
   if (i > g.n1 || j > g.n2) return;
   const size_t c = g.ix(i, j, k);
-  const double a = alph2[c], s = s0[c];
+  const real a = alph2[c], s = s0[c];
 #pragma unroll
   for (int m = 0; m < 6; ++m) mij.p[m][c] = 2. * (mij.p[m][c] - a * s * sij.p[m][c]);
 }
-__global__ __launch_bounds__(BX *BY) void k_interp(Geom g, const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ w,
-                                                    double *__restrict__ uc, double *__restrict__ vc, double *__restrict__ wc) {
+__global__ __launch_bounds__(BX *BY) void k_interp(Geom g, const real *__restrict__ u, const real *__restrict__ v, const real *__restrict__ w,
+                                                    real *__restrict__ uc, real *__restrict__ vc, real *__restrict__ wc) {
   const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;   // sgs.f90:860-869
   if (i > g.n1 || j > g.n2) return;
   const size_t c = g.ix(i, j, k);
   uc[c] = 0.5 * (u[c] + u[c - 1]); vc[c] = 0.5 * (v[c] + v[c - g.s1]); wc[c] = 0.5 * (w[c] + w[c - g.s12]);
 }
-__global__ __launch_bounds__(BX *BY) void k_contract(Geom g, CP6 mij, CP6 lij, const double *__restrict__ uf, const double *__restrict__ vf,
-                                                      const double *__restrict__ wf, double *__restrict__ lm, double *__restrict__ mm) {
+__global__ __launch_bounds__(BX *BY) void k_contract(Geom g, CP6 mij, CP6 lij, const real *__restrict__ uf, const real *__restrict__ vf,
+                                                      const real *__restrict__ wf, real *__restrict__ lm, real *__restrict__ mm) {
   const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;   // sgs.f90:328-358
   if (i > g.n1 || j > g.n2) return;
   const size_t c = g.ix(i, j, k);
-  double m_[6], l_[6];
+  real m_[6], l_[6];
 #pragma unroll
   for (int m = 0; m < 6; ++m) { m_[m] = mij.p[m][c]; l_[m] = lij.p[m][c]; }
-  const double a = uf[c], b = vf[c], d = wf[c];
+  const real a = uf[c], b = vf[c], d = wf[c];
   l_[0] -= a * a; l_[1] -= b * b; l_[2] -= d * d; l_[3] -= a * b; l_[4] -= a * d; l_[5] -= b * d;
   lm[c] = m_[0] * l_[0] + m_[1] * l_[1] + m_[2] * l_[2] + (m_[3] * l_[3] + m_[4] * l_[4] + m_[5] * l_[5]) * 2.;
   mm[c] = m_[0] * m_[0] + m_[1] * m_[1] + m_[2] * m_[2] + (m_[3] * m_[3] + m_[4] * m_[4] + m_[5] * m_[5]) * 2.;
 }
 // ave1d_channel (sgs.f90:462-480): plane sums of two fields -> p1d(2, n3); one block per (k, field)
-__global__ __launch_bounds__(256) void k_plane_sum(Geom g, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ p1d) {
-  __shared__ double sh[4];
-  const int k = blockIdx.x + 1; const double *p = blockIdx.y ? b : a;
-  double acc = 0.;
+__global__ __launch_bounds__(256) void k_plane_sum(Geom g, const real *__restrict__ a, const real *__restrict__ b, real *__restrict__ p1d) {
+  __shared__ real sh[4];
+  const int k = blockIdx.x + 1; const real *p = blockIdx.y ? b : a;
+  real acc = 0.;
   const long np = (long)g.n1 * g.n2;
   for (long q = threadIdx.x; q < np; q += 256) acc += p[g.ix((int)(q % g.n1) + 1, (int)(q / g.n1) + 1, k)];
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
@@ -231,22 +231,22 @@ __global__ __launch_bounds__(256) void k_plane_sum(Geom g, const double *__restr
   if (threadIdx.x == 0) p1d[blockIdx.y * g.n3 + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 // visct = max(visct*<LM>/<MM>,0) (sgs.f90:372-380); the plane averages replace the broadcast arrays
-__global__ __launch_bounds__(BX *BY) void k_dsmag_final(Geom g, double gar, const double *__restrict__ p1d, const double *s0, double *visct) {
+__global__ __launch_bounds__(BX *BY) void k_dsmag_final(Geom g, real gar, const real *__restrict__ p1d, const real *s0, real *visct) {
   const int i = blockIdx.x * BX + threadIdx.x + 1, j = blockIdx.y * BY + threadIdx.y + 1, k = blockIdx.z + 1;
   if (i > g.n1 || j > g.n2) return;
   const size_t c = g.ix(i, j, k);
-  const double lm = p1d[k - 1] * gar, mm = p1d[g.n3 + k - 1] * gar;
-  double vt = s0[c] * lm / mm;
+  const real lm = p1d[k - 1] * gar, mm = p1d[g.n3 + k - 1] * gar;
+  real vt = s0[c] * lm / mm;
   visct[c] = fmax(vt, 0.);
 }
 // plane coefficients of the lazy form: cs(k) = max(<LM>/<MM>, 0) for k = 1..n3 (NaN -> 0 as fmax does in k_dsmag_final), ghost planes from
 // the z boundary type of the field (periodic: wrap; wall: the neighbour's, the ghost value of |S| carries the sign)
-__global__ void k_dsmag_coef(int n3, double gar, const double *__restrict__ p1d, double *__restrict__ cs, int periodic_z) {
-  for (int k = threadIdx.x + 1; k <= n3; k += blockDim.x) { const double lm = p1d[k - 1] * gar, mm = p1d[n3 + k - 1] * gar; cs[k] = fmax(lm / mm, 0.); }
+__global__ void k_dsmag_coef(int n3, real gar, const real *__restrict__ p1d, real *__restrict__ cs, int periodic_z) {
+  for (int k = threadIdx.x + 1; k <= n3; k += blockDim.x) { const real lm = p1d[k - 1] * gar, mm = p1d[n3 + k - 1] * gar; cs[k] = fmax(lm / mm, 0.); }
   __syncthreads();
   if (threadIdx.x == 0) { cs[0] = periodic_z ? cs[n3] : cs[1]; cs[n3 + 1] = periodic_z ? cs[1] : cs[n3]; }
 }
-__global__ __launch_bounds__(256) void k_scale_planes(Geom g, const double *__restrict__ cs, double *__restrict__ f) {
+__global__ __launch_bounds__(256) void k_scale_planes(Geom g, const real *__restrict__ cs, real *__restrict__ f) {
   const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
   if (i > g.n1 + 1 || j > g.n2 + 1) return;
   const size_t c = g.ix(i, j, k);
@@ -260,7 +260,7 @@ int materialize_visct(cales_ctx *c) {
   HIPCHK(c, hipGetLastError());
   return 0;
 }
-__global__ __launch_bounds__(256) void k_alph2(Geom g, double w0, double w1, double w2, double w3, double w4, double w5, double *__restrict__ alph2) {
+__global__ __launch_bounds__(256) void k_alph2(Geom g, real w0, real w1, real w2, real w3, real w4, real w5, real *__restrict__ alph2) {
   const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;    // sgs.f90:783-816
   if (i > g.n1 + 1 || j > g.n2 + 1) return;
   const int jg = j + g.jlo;
@@ -290,13 +290,13 @@ __global__ __launch_bounds__(256) void k_alph2(Geom g, double w0, double w1, dou
 #ifndef TYB
 #define TYB 8       // measured at 512^3: 8 (divides the usual n2, 10 waves per block) beats 14 and 6
 #endif
-struct Filter6Args { const double *in[6]; double *out[6]; int kchunk, zlo, zhi, perx; };   // perx: x ghost columns are not stored, wrap around
+struct Filter6Args { const real *in[6]; real *out[6]; int kchunk, zlo, zhi, perx; };   // perx: x ghost columns are not stored, wrap around
 // K_B: top-hat filter of six fields (the products |S|Sij). Tile = 64 x TYB outputs from i = 1 + 64 bx (whole 128-B lines in and
 // out); x combination first, on the plane just loaded (lanes 0 and 63 also load the x-halo cell beside them), then three
 // x-combined planes of the own cell roll in registers for the z combination, y neighbours through LDS.
 template <typename OFF>
 __global__ __launch_bounds__(64 * (TYB + 2)) void k_filter6_tile(Geom g, Filter6Args A) {
-  __shared__ double sh[2][6][TYB + 2][64];
+  __shared__ real sh[2][6][TYB + 2][64];
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int i = blockIdx.x * 64 + tx + 1, j = blockIdx.y * TYB + ty;        // ty = 0 / TYB+1 are halo rows
   const int kbeg = blockIdx.z * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
@@ -305,21 +305,21 @@ __global__ __launch_bounds__(64 * (TYB + 2)) void k_filter6_tile(Geom g, Filter6
   const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1, hok = edge && ih <= g.n1 + 1 && j <= g.n2 + 1;
   const bool outok = ty >= 1 && ty <= TYB && i <= g.n1 && j <= g.n2;
   const int iw = (A.perx && i == g.n1 + 1) ? 1 : i, ihw = A.perx ? (ih == 0 ? g.n1 : (ih == g.n1 + 1 ? 1 : ih)) : ih;     // periodic x without ghost columns
-  const OFF c0 = ldok ? (OFF)g.ix(iw, j, 0) * 8 : 0, ch = hok ? (OFF)g.ix(ihw, j, 0) * 8 : 0, sk = (OFF)g.s12 * 8;   // byte offsets
-  auto load = [&](int kk, double *r, double *h) {
+  const OFF c0 = ldok ? (OFF)g.ix(iw, j, 0) * RSZ : 0, ch = hok ? (OFF)g.ix(ihw, j, 0) * RSZ : 0, sk = (OFF)g.s12 * RSZ;   // byte offsets
+  auto load = [&](int kk, real *r, real *h) {
 #pragma unroll
     for (int q = 0; q < 6; ++q) { r[q] = ldok ? ldb(A.in[q], c0 + (OFF)kk * sk) : 0.; h[q] = hok ? ldb(A.in[q], ch + (OFF)kk * sk) : 0.; }
   };
-  auto xcomb = [&](const double *r, const double *h, double *X) {
+  auto xcomb = [&](const real *r, const real *h, real *X) {
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
-      double pv = lane_prev(r[q]), nx = lane_next(r[q]);
+      real pv = lane_prev(r[q]), nx = lane_next(r[q]);
       if (tx == 0) pv = h[q];
       if (tx == 63) nx = h[q];
       X[q] = pv + 2. * r[q] + nx;
     }
   };
-  double xm[6], xc[6], xp[6], rn[6], hn[6];
+  real xm[6], xc[6], xp[6], rn[6], hn[6];
   load(kbeg - 1, rn, hn); xcomb(rn, hn, xm);
   load(kbeg, rn, hn); xcomb(rn, hn, xc);
   load(kbeg + 1, rn, hn);
@@ -329,11 +329,11 @@ __global__ __launch_bounds__(64 * (TYB + 2)) void k_filter6_tile(Geom g, Filter6
     xcomb(rn, hn, xp);
     if (k + 2 <= g.n3 + 1) load(k + 2, rn, hn);                 // prefetch
     const bool lo = A.zlo && k == 1, hi = A.zhi && k == g.n3;
-    double G[6];
+    real G[6];
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
-      const double vm = lo ? 2. * xc[q] - xp[q] : xm[q];          // wall rule Q(0) = 2Q(1) - Q(2)
-      const double vp = hi ? 2. * xc[q] - xm[q] : xp[q];
+      const real vm = lo ? 2. * xc[q] - xp[q] : xm[q];          // wall rule Q(0) = 2Q(1) - Q(2)
+      const real vp = hi ? 2. * xc[q] - xm[q] : xp[q];
       G[q] = vm + 2. * xc[q] + vp;
       sh[buf][q][ty][tx] = G[q];
     }
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(64 * (TYB + 2)) void k_filter6_tile(Geom g, Filter6
     buf ^= 1;
   }
 }
-__device__ inline void uiuj(const double *s, double *q) {
+__device__ inline void uiuj(const real *s, real *q) {
   q[0] = s[0]; q[1] = s[1]; q[2] = s[2]; q[3] = s[0] * s[0]; q[4] = s[1] * s[1]; q[5] = s[2] * s[2];
   q[6] = s[0] * s[1]; q[7] = s[0] * s[2]; q[8] = s[1] * s[2];
 }
@@ -358,12 +358,12 @@ __device__ inline void uiuj(const double *s, double *q) {
 #define TYF 8       // measured: 8 and 10 beat 14 (spills at 1024 threads), 6, 9, 11, 12
 #endif
 struct LijMijArgs {
-  const double *uc[3], *uf[3], *mf[6];
-  double *part;
-  const double *dzci, *dzfi;
-  double dxi, dyi;
+  const real *uc[3], *uf[3], *mf[6];
+  real *part;
+  const real *dzci, *dzfi;
+  real dxi, dyi;
   int kchunk, nblk, zlo, zhi;
-  int wmlo, wmhi; double flo, fhi;      // wall-model z faces: ghost planes of uf,vf by extrapolate(...,lwm), sgs.f90:683-748
+  int wmlo, wmhi; real flo, fhi;      // wall-model z faces: ghost planes of uf,vf by extrapolate(...,lwm), sgs.f90:683-748
   int perx;                             // x ghost columns of uc.., uf.. are not stored: wrap around
   // y walls owned by this rank (k_lmf_tile only): wall rule of the filters along y, alph2 of the wall rows; wall-model y faces: ghost rows of u_f, w_f
   int wylo, wyhi, wmylo, wmyhi;
@@ -372,17 +372,17 @@ template <typename OFF>
 __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijArgs A) {
   // one barrier per plane: the filter sums and the partial sums are double-buffered and the ring of raw planes has a fourth
   // slot, so a wave that is already in the next plane never overwrites what a slower wave still reads (153 KB of LDS)
-  __shared__ double sh[2][9][TYF + 2][64];
-  __shared__ double ring[4][3][TYF + 2][64];
-  __shared__ double shr[2][2][TYF + 2];
+  __shared__ real sh[2][9][TYF + 2][64];
+  __shared__ real ring[4][3][TYF + 2][64];
+  __shared__ real shr[2][2][TYF + 2];
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int i = blockIdx.x * 62 + tx, j = blockIdx.y * TYF + ty;
   const int kbeg = blockIdx.z * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
   const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1;
   const bool outok = tx >= 1 && tx <= 62 && ty >= 1 && ty <= TYF && i <= g.n1 && j <= g.n2;
   const int iw = A.perx ? (i == 0 ? g.n1 : (i == g.n1 + 1 ? 1 : i)) : i;
-  const OFF c0 = ldok ? (OFF)g.ix(iw, j, 0) * 8 : 0, sk = (OFF)g.s12 * 8;      // byte offsets
-  double sm[3], sc[3], sp[3], sn[3], fn[3];
+  const OFF c0 = ldok ? (OFF)g.ix(iw, j, 0) * RSZ : 0, sk = (OFF)g.s12 * RSZ;      // byte offsets
+  real sm[3], sc[3], sp[3], sn[3], fn[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     sm[q] = ldok ? ldb(A.uc[q], c0 + (OFF)(kbeg - 1) * sk) : 0.;
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijA
   }
   const int blk = blockIdx.y * gridDim.x + blockIdx.x;
   auto fold = [&](int k, int b) {      // block sums of plane k, fixed order
-    double a = 0., bsum = 0.;
+    real a = 0., bsum = 0.;
     for (int q = 1; q <= TYF; ++q) { a += shr[b][0][q]; bsum += shr[b][1][q]; }
     A.part[(size_t)(k - 1) * A.nblk + blk] = a; A.part[(size_t)(g.n3 + k - 1) * A.nblk + blk] = bsum;
   };
@@ -412,41 +412,41 @@ __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijA
 #pragma unroll
       for (int q = 0; q < 3; ++q) { sn[q] = ldok ? ldb(A.uc[q], idx + 2 * sk) : 0.; fn[q] = ldok ? ldb(A.uf[q], idx + 2 * sk) : 0.; }
     }
-    double mf[6];
+    real mf[6];
 #pragma unroll
     for (int q = 0; q < 6; ++q) mf[q] = outok ? ldb(A.mf[q], idx) : 0.;
-    double qm[9], qc[9], qp[9], r[9];
+    real qm[9], qc[9], qp[9], r[9];
     uiuj(sc, qc);
     if (!LO && !HI) { uiuj(sm, qm); uiuj(sp, qp); }
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
-      const double G = (LO || HI) ? 4. * qc[q] : qm[q] + 2. * qc[q] + qp[q];
+      const real G = (LO || HI) ? 4. * qc[q] : qm[q] + 2. * qc[q] + qp[q];
       r[q] = lane_prev(G) + 2. * G + lane_next(G);
       sh[buf][q][ty][tx] = r[q];
     }
     __syncthreads();
     if (k > kbeg && tx == 0 && ty == 0) fold(k - 1, buf ^ 1);
-    double lm = 0., mm = 0.;
+    real lm = 0., mm = 0.;
     if (outok) {
-      double F[9];
+      real F[9];
 #pragma unroll
       for (int q = 0; q < 9; ++q) F[q] = (sh[buf][q][ty - 1][tx] + 2. * r[q] + sh[buf][q][ty + 1][tx]) / 64.;
-      const double l0 = F[3] - F[0] * F[0], l1 = F[4] - F[1] * F[1], l2 = F[5] - F[2] * F[2], l3 = F[6] - F[0] * F[1],
+      const real l0 = F[3] - F[0] * F[0], l1 = F[4] - F[1] * F[1], l2 = F[5] - F[2] * F[2], l3 = F[6] - F[0] * F[1],
                    l4 = F[7] - F[0] * F[2], l5 = F[8] - F[1] * F[2];
 #define RU(dk, dj, di) ring[dk][0][ty + (dj)][tx + (di)]
 #define RV(dk, dj, di) ring[dk][1][ty + (dj)][tx + (di)]
 #define RW(dk, dj, di) ring[dk][2][ty + (dj)][tx + (di)]
-      const double u_mcm = RU(km, 0, -1), u_ccm = RU(km, 0, 0), u_mmc = RU(kc, -1, -1), u_cmc = RU(kc, -1, 0), u_mcc = RU(kc, 0, -1),
+      const real u_mcm = RU(km, 0, -1), u_ccm = RU(km, 0, 0), u_mmc = RU(kc, -1, -1), u_cmc = RU(kc, -1, 0), u_mcc = RU(kc, 0, -1),
                    u_ccc = RU(kc, 0, 0), u_mpc = RU(kc, 1, -1), u_cpc = RU(kc, 1, 0), u_mcp = RU(kp, 0, -1), u_ccp = RU(kp, 0, 0);
-      const double v_cmm = RV(km, -1, 0), v_ccm = RV(km, 0, 0), v_mmc = RV(kc, -1, -1), v_cmc = RV(kc, -1, 0), v_pmc = RV(kc, -1, 1),
+      const real v_cmm = RV(km, -1, 0), v_ccm = RV(km, 0, 0), v_mmc = RV(kc, -1, -1), v_cmc = RV(kc, -1, 0), v_pmc = RV(kc, -1, 1),
                    v_mcc = RV(kc, 0, -1), v_ccc = RV(kc, 0, 0), v_pcc = RV(kc, 0, 1), v_cmp = RV(kp, -1, 0), v_ccp = RV(kp, 0, 0);
-      const double w_cmm = RW(km, -1, 0), w_mcm = RW(km, 0, -1), w_ccm = RW(km, 0, 0), w_pcm = RW(km, 0, 1), w_cpm = RW(km, 1, 0),
+      const real w_cmm = RW(km, -1, 0), w_mcm = RW(km, 0, -1), w_ccm = RW(km, 0, 0), w_pcm = RW(km, 0, 1), w_cpm = RW(km, 1, 0),
                    w_cmc = RW(kc, -1, 0), w_mcc = RW(kc, 0, -1), w_ccc = RW(kc, 0, 0), w_pcc = RW(kc, 0, 1), w_cpc = RW(kc, 1, 0);
 #undef RU
 #undef RV
 #undef RW
-      const double dxi = A.dxi, dyi = A.dyi, zc = A.dzci[k], zm = A.dzci[k - 1];
-      double sij[6];
+      const real dxi = A.dxi, dyi = A.dyi, zc = A.dzci[k], zm = A.dzci[k - 1];
+      real sij[6];
       sij[0] = (u_ccc - u_mcc) * dxi; sij[1] = (v_ccc - v_cmc) * dyi; sij[2] = (w_ccc - w_ccm) * A.dzfi[k];
       sij[3] = .125 * ((u_cpc - u_ccc) * dyi + (v_pcc - v_ccc) * dxi + (u_ccc - u_cmc) * dyi + (v_pmc - v_cmc) * dxi +
                        (u_mpc - u_mcc) * dyi + (v_ccc - v_mcc) * dxi + (u_mcc - u_mmc) * dyi + (v_cmc - v_mmc) * dxi);
@@ -454,9 +454,9 @@ __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijA
                        (u_mcp - u_mcc) * zc + (w_ccc - w_mcc) * dxi + (u_mcc - u_mcm) * zm + (w_ccm - w_mcm) * dxi);
       sij[5] = .125 * ((v_ccp - v_ccc) * zc + (w_cpc - w_ccc) * dyi + (v_ccc - v_ccm) * zm + (w_cpm - w_ccm) * dyi +
                        (v_cmp - v_cmc) * zc + (w_ccc - w_cmc) * dyi + (v_cmc - v_cmm) * zm + (w_ccm - w_cmm) * dyi);
-      const double s0 = sqrt(2. * (sij[0] * sij[0] + sij[1] * sij[1] + sij[2] * sij[2] + 2. * (sij[3] * sij[3] + sij[4] * sij[4] + sij[5] * sij[5])));
-      const double a2s0 = (LO || HI ? 2.52 : 4.00) * s0;      // alph2 (sgs.f90:783-816)
-      const double m0 = 2. * (mf[0] - a2s0 * sij[0]), m1 = 2. * (mf[1] - a2s0 * sij[1]), m2 = 2. * (mf[2] - a2s0 * sij[2]),
+      const real s0 = sqrt(2. * (sij[0] * sij[0] + sij[1] * sij[1] + sij[2] * sij[2] + 2. * (sij[3] * sij[3] + sij[4] * sij[4] + sij[5] * sij[5])));
+      const real a2s0 = (LO || HI ? 2.52 : 4.00) * s0;      // alph2 (sgs.f90:783-816)
+      const real m0 = 2. * (mf[0] - a2s0 * sij[0]), m1 = 2. * (mf[1] - a2s0 * sij[1]), m2 = 2. * (mf[2] - a2s0 * sij[2]),
                    m3 = 2. * (mf[3] - a2s0 * sij[3]), m4 = 2. * (mf[4] - a2s0 * sij[4]), m5 = 2. * (mf[5] - a2s0 * sij[5]);
       lm = m0 * l0 + m1 * l1 + m2 * l2 + (m3 * l3 + m4 * l4 + m5 * l5) * 2.;       // sgs.f90:344-349
       mm = m0 * m0 + m1 * m1 + m2 * m2 + (m3 * m3 + m4 * m4 + m5 * m5) * 2.;       // sgs.f90:350-355
@@ -490,13 +490,13 @@ __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijA
 #ifndef TYL
 #define TYL 8
 #endif
-struct LmfArgs { LijMijArgs L; const double *ss[6]; int by0; BandMap bm; int gx; };      // bm: block map of this launch (bm.gx = 0: plain 3-D grid); gx: x tiles of the whole field      // by0: first y tile of this launch (interior and edge tiles of a slab are launched apart)
+struct LmfArgs { LijMijArgs L; const real *ss[6]; int by0; BandMap bm; int gx; };      // bm: block map of this launch (bm.gx = 0: plain 3-D grid); gx: x tiles of the whole field      // by0: first y tile of this launch (interior and edge tiles of a slab are launched apart)
 template <typename OFF, int YW>      // YW = 1: walls or wall-model faces in y (ducts); 0: the channel instantiation carries none of that logic
 __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) {
   const LijMijArgs &A = B.L;
-  __shared__ double sh[2][9][TYL + 2][64];
-  __shared__ double ring[4][3][TYL + 2][64];
-  __shared__ double shr[2][2][TYL + 2];
+  __shared__ real sh[2][9][TYL + 2][64];
+  __shared__ real ring[4][3][TYL + 2][64];
+  __shared__ real shr[2][2][TYL + 2];
   const int tx = threadIdx.x, ty = threadIdx.y;
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   if (B.bm.gx && !band_block(B.bm, bx, by, bz)) return;
@@ -507,11 +507,11 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
   const bool outok = tx >= 1 && tx <= 62 && ty >= 1 && ty <= TYL && i <= g.n1 && j <= g.n2;
   const bool ssok = ty >= 1 && ty <= TYL && i <= g.n1 + 1 && j <= g.n2;      // rows that filter |S|Sij (all 64 lanes: x neighbours by DPP)
   const int iw = A.perx ? (i == 0 ? g.n1 : (i == g.n1 + 1 ? 1 : i)) : i;
-  const OFF c0 = ldok ? (OFF)g.ix(iw, j, 0) * 8 : 0, sk = (OFF)g.s12 * 8, sj = (OFF)g.s1 * 8;      // byte offsets
-  double sm[3], sc[3], sp[3], sn[3], fn[3];
+  const OFF c0 = ldok ? (OFF)g.ix(iw, j, 0) * RSZ : 0, sk = (OFF)g.s12 * RSZ, sj = (OFF)g.s1 * RSZ;      // byte offsets
+  real sm[3], sc[3], sp[3], sn[3], fn[3];
   // ghost rows of u_f and w_f at wall-model y faces: 2 Q(1) - Q(2) along y (extrapolate(...,lwm) after bounduvw, sgs.f90:683-748); v_f keeps its own
   const int yex = !YW ? 0 : (A.wmylo && j == 0) ? 1 : (A.wmyhi && j == g.n2 + 1) ? -1 : 0;
-  auto ldf = [&](int q, OFF o) -> double {
+  auto ldf = [&](int q, OFF o) -> real {
     if (YW && yex != 0 && q != 1) return yex > 0 ? 2. * ldb(A.uf[q], o + sj) - ldb(A.uf[q], o + 2 * sj) : 2. * ldb(A.uf[q], o - sj) - ldb(A.uf[q], o - 2 * sj);
     return ldb(A.uf[q], o);
   };
@@ -527,28 +527,28 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
     if (A.wmlo && kbeg == 1 && q < 2) ring[0][q][ty][tx] = (1. + A.flo) * ring[1][q][ty][tx] - A.flo * fn[q];
   }
   // |S|Sij: y and x combination of one plane (three rows in, lanes beside by DPP)
-  auto ssload = [&](int kk, double (*raw)[3]) {
+  auto ssload = [&](int kk, real (*raw)[3]) {
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
       const OFF o = c0 + (OFF)kk * sk;
       raw[q][0] = ssok ? ldb(B.ss[q], o - sj) : 0.; raw[q][1] = ssok ? ldb(B.ss[q], o) : 0.; raw[q][2] = ssok ? ldb(B.ss[q], o + sj) : 0.;
     }
   };
-  auto sscomb = [&](const double (*raw)[3], double *X) {
+  auto sscomb = [&](const real (*raw)[3], real *X) {
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
-      const double Y = (ylo ? 2. * raw[q][1] - raw[q][2] : raw[q][0]) + 2. * raw[q][1] + (yhi ? 2. * raw[q][1] - raw[q][0] : raw[q][2]);
+      const real Y = (ylo ? 2. * raw[q][1] - raw[q][2] : raw[q][0]) + 2. * raw[q][1] + (yhi ? 2. * raw[q][1] - raw[q][0] : raw[q][2]);
       X[q] = lane_prev(Y) + 2. * Y + lane_next(Y);
     }
   };
-  double xm[6], xc[6], xp[6], rw[6][3];
+  real xm[6], xc[6], xp[6], rw[6][3];
   // the ghost plane below a wall is never used (LO planes take 4 xc); it is read all the same when the chunk starts inside the field
   ssload(kbeg - 1, rw); sscomb(rw, xm);
   ssload(kbeg, rw); sscomb(rw, xc);
   ssload(kbeg + 1, rw);
   const int blk = by * B.gx + bx;
   auto fold = [&](int k, int b) {      // block sums of plane k, fixed order
-    double a = 0., bsum = 0.;
+    real a = 0., bsum = 0.;
     for (int q = 1; q <= TYL; ++q) { a += shr[b][0][q]; bsum += shr[b][1][q]; }
     A.part[(size_t)(k - 1) * A.nblk + blk] = a; A.part[(size_t)(g.n3 + k - 1) * A.nblk + blk] = bsum;
   };
@@ -563,12 +563,12 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
 #pragma unroll
       for (int q = 0; q < 3; ++q) { sn[q] = ldok ? ldb(A.uc[q], idx + 2 * sk) : 0.; fn[q] = ldok ? ldf(q, idx + 2 * sk) : 0.; }
     }
-    double qm[9], qc[9], qp[9], r[9];
+    real qm[9], qc[9], qp[9], r[9];
     uiuj(sc, qc);
     if (!LO && !HI) { uiuj(sm, qm); uiuj(sp, qp); }
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
-      const double G = (LO || HI) ? 4. * qc[q] : qm[q] + 2. * qc[q] + qp[q];
+      const real G = (LO || HI) ? 4. * qc[q] : qm[q] + 2. * qc[q] + qp[q];
       r[q] = lane_prev(G) + 2. * G + lane_next(G);
       sh[buf][q][ty][tx] = r[q];
     }
@@ -577,15 +577,15 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
     // plane k+1 of |S|Sij: its 18 loads were issued at the end of the previous plane and are folded into six values here, before
     // the register-hungry part; the next 18 are issued after it (keeps the kernel under the 168 VGPRs that ten waves per block need)
     sscomb(rw, xp);
-    double lm = 0., mm = 0.;
+    real lm = 0., mm = 0.;
     if (outok) {
-      double F[9];
+      real F[9];
 #pragma unroll
       for (int q = 0; q < 9; ++q) {
-        const double dn = sh[buf][q][ty - 1][tx], up = sh[buf][q][ty + 1][tx];
+        const real dn = sh[buf][q][ty - 1][tx], up = sh[buf][q][ty + 1][tx];
         F[q] = ((ylo ? 2. * r[q] - up : dn) + 2. * r[q] + (yhi ? 2. * r[q] - dn : up)) / 64.;
       }
-      const double l0 = F[3] - F[0] * F[0], l1 = F[4] - F[1] * F[1], l2 = F[5] - F[2] * F[2], l3 = F[6] - F[0] * F[1],
+      const real l0 = F[3] - F[0] * F[0], l1 = F[4] - F[1] * F[1], l2 = F[5] - F[2] * F[2], l3 = F[6] - F[0] * F[1],
                    l4 = F[7] - F[0] * F[2], l5 = F[8] - F[1] * F[2];
       // strain rate of the test-filtered velocity (sgs.f90:571-630). The eight differences of each off-diagonal component telescope
       // pairwise wherever the metric factor is the same (x and y: always; z: not, the grid is stretched), e.g.
@@ -594,31 +594,31 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
 #define RU(dk, dj, di) ring[dk][0][ty + (dj)][tx + (di)]
 #define RV(dk, dj, di) ring[dk][1][ty + (dj)][tx + (di)]
 #define RW(dk, dj, di) ring[dk][2][ty + (dj)][tx + (di)]
-      const double dxi = A.dxi, dyi = A.dyi, zc = A.dzci[k], zm = A.dzci[k - 1];
-      double sij[6];
-      { const double u_ccc = RU(kc, 0, 0), u_mcc = RU(kc, 0, -1), v_ccc = RV(kc, 0, 0), v_cmc = RV(kc, -1, 0), w_ccc = RW(kc, 0, 0), w_ccm = RW(km, 0, 0);
+      const real dxi = A.dxi, dyi = A.dyi, zc = A.dzci[k], zm = A.dzci[k - 1];
+      real sij[6];
+      { const real u_ccc = RU(kc, 0, 0), u_mcc = RU(kc, 0, -1), v_ccc = RV(kc, 0, 0), v_cmc = RV(kc, -1, 0), w_ccc = RW(kc, 0, 0), w_ccm = RW(km, 0, 0);
         sij[0] = (u_ccc - u_mcc) * dxi; sij[1] = (v_ccc - v_cmc) * dyi; sij[2] = (w_ccc - w_ccm) * A.dzfi[k];
         // s12 = 1/8 [ dyi (u_cpc - u_cmc + u_mpc - u_mmc) + dxi (v_pcc + v_pmc - v_mcc - v_mmc) ]
-        const double du = (RU(kc, 1, 0) - RU(kc, -1, 0)) + (RU(kc, 1, -1) - RU(kc, -1, -1));
-        const double dv = (RV(kc, 0, 1) - RV(kc, 0, -1)) + (RV(kc, -1, 1) - RV(kc, -1, -1));
+        const real du = (RU(kc, 1, 0) - RU(kc, -1, 0)) + (RU(kc, 1, -1) - RU(kc, -1, -1));
+        const real dv = (RV(kc, 0, 1) - RV(kc, 0, -1)) + (RV(kc, -1, 1) - RV(kc, -1, -1));
         sij[3] = .125 * (du * dyi + dv * dxi);
         // s13 = 1/8 [ zc (u_ccp - u_ccc + u_mcp - u_mcc) + zm (u_ccc - u_ccm + u_mcc - u_mcm) + dxi (w_pcc + w_pcm - w_mcc - w_mcm) ]
-        const double up = (RU(kp, 0, 0) - u_ccc) + (RU(kp, 0, -1) - u_mcc), um = (u_ccc - RU(km, 0, 0)) + (u_mcc - RU(km, 0, -1));
-        const double dw = (RW(kc, 0, 1) - RW(kc, 0, -1)) + (RW(km, 0, 1) - RW(km, 0, -1));
+        const real up = (RU(kp, 0, 0) - u_ccc) + (RU(kp, 0, -1) - u_mcc), um = (u_ccc - RU(km, 0, 0)) + (u_mcc - RU(km, 0, -1));
+        const real dw = (RW(kc, 0, 1) - RW(kc, 0, -1)) + (RW(km, 0, 1) - RW(km, 0, -1));
         sij[4] = .125 * (up * zc + um * zm + dw * dxi);
         // s23 = 1/8 [ zc (v_ccp - v_ccc + v_cmp - v_cmc) + zm (v_ccc - v_ccm + v_cmc - v_cmm) + dyi (w_cpc + w_cpm - w_cmc - w_cmm) ]
-        const double vp = (RV(kp, 0, 0) - v_ccc) + (RV(kp, -1, 0) - v_cmc), vm = (v_ccc - RV(km, 0, 0)) + (v_cmc - RV(km, -1, 0));
-        const double dw2 = (RW(kc, 1, 0) - RW(kc, -1, 0)) + (RW(km, 1, 0) - RW(km, -1, 0));
+        const real vp = (RV(kp, 0, 0) - v_ccc) + (RV(kp, -1, 0) - v_cmc), vm = (v_ccc - RV(km, 0, 0)) + (v_cmc - RV(km, -1, 0));
+        const real dw2 = (RW(kc, 1, 0) - RW(kc, -1, 0)) + (RW(km, 1, 0) - RW(km, -1, 0));
         sij[5] = .125 * (vp * zc + vm * zm + dw2 * dyi); }
 #undef RU
 #undef RV
 #undef RW
-      const double s0 = sqrt(2. * (sij[0] * sij[0] + sij[1] * sij[1] + sij[2] * sij[2] + 2. * (sij[3] * sij[3] + sij[4] * sij[4] + sij[5] * sij[5])));
-      const double a2s0 = (LO || HI || ylo || yhi ? 2.52 : 4.00) * s0;      // alph2: cells next to any wall (sgs.f90:783-816)
-      double m[6];
+      const real s0 = sqrt(2. * (sij[0] * sij[0] + sij[1] * sij[1] + sij[2] * sij[2] + 2. * (sij[3] * sij[3] + sij[4] * sij[4] + sij[5] * sij[5])));
+      const real a2s0 = (LO || HI || ylo || yhi ? 2.52 : 4.00) * s0;      // alph2: cells next to any wall (sgs.f90:783-816)
+      real m[6];
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
-        const double G = (LO || HI) ? 4. * xc[q] : xm[q] + 2. * xc[q] + xp[q];      // filter(|S|Sij) * 64
+        const real G = (LO || HI) ? 4. * xc[q] : xm[q] + 2. * xc[q] + xp[q];      // filter(|S|Sij) * 64
         m[q] = 2. * (G * (1. / 64.) - a2s0 * sij[q]);                             // Mij, sgs.f90:261-272
       }
       lm = m[0] * l0 + m[1] * l1 + m[2] * l2 + (m[3] * l3 + m[4] * l4 + m[5] * l5) * 2.;       // sgs.f90:344-349
@@ -650,43 +650,43 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
 #define TYS 14      // measured at 512^3 (A/B on one box): 14 beats 6 and 10 for the dynamic-model pass (-7 %) and the Smagorinsky pass (-26 %)
 #endif
 struct StrainTileArgs {
-  const double *u[3];
-  double *s0, *ssij[6], *uc[3], *uf[3];
-  const double *dzci, *dzfi;
-  double dxi, dyi;
+  const real *u[3];
+  real *s0, *ssij[6], *uc[3], *uf[3];
+  const real *dzci, *dzfi;
+  real dxi, dyi;
   int kchunk, zlo, zhi;
-  int wmlo, wmhi; double flo, fhi;      // wall-model z faces: ghost planes of u,v by extrapolate(...,lwm), sgs.f90:683-748
+  int wmlo, wmhi; real flo, fhi;      // wall-model z faces: ghost planes of u,v by extrapolate(...,lwm), sgs.f90:683-748
   // SMAG = 1 (static Smagorinsky with van Driest damping for z walls, sgs.f90:98-152): the only output is visct
-  double *visct; const double *zc, *del; double l3, visc;      // del(k) = (dx dy dzf(k))^(1/3)
+  real *visct; const real *zc, *del; real l3, visc;      // del(k) = (dx dy dzf(k))^(1/3)
   // SMAG = 1 with walls in y (ducts): wylo/wyhi = no-slip y walls owned by this rank (van Driest distance and shear, the latter from
   // twy(side, k, i) = sqrt(tau_w) of k_wall_shear_y); wmylo/wmyhi = wall-model y faces: the strain rate sees ghost rows of u and w
   // extrapolated from the interior (extrapolate(...,lwm) along y, sgs.f90:683-748)
-  int wylo, wyhi, wmylo, wmyhi; const double *twy; double dl2;
+  int wylo, wyhi, wmylo, wmyhi; const real *twy; real dl2;
   BandMap bm;      // block -> (x tile, y tile, k chunk) map of the 1-D launches (bm.gx = 0: plain 3-D grid)
 };
 // sqrt(tau_w) at the two y walls for every (i, k): the argument of the van Driest damping of the cells whose nearest wall is a y wall
 // (sgs.f90:117-143, cases 3 and 4 of the select), from the fields themselves (their ghost cells, not the extrapolated ones)
-__global__ __launch_bounds__(256) void k_wall_shear_y(Geom g, const double *__restrict__ u, const double *__restrict__ w, double visc, double dyi,
-                                                      int lo, int hi, double *__restrict__ twy) {
+__global__ __launch_bounds__(256) void k_wall_shear_y(Geom g, const real *__restrict__ u, const real *__restrict__ w, real visc, real dyi,
+                                                      int lo, int hi, real *__restrict__ twy) {
   const int i = blockIdx.x * 64 + threadIdx.x + 1, k = blockIdx.y * 4 + threadIdx.y + 1;
   if (i > g.n1 || k > g.n3) return;
   const int n2 = g.n2;
   if (lo) {
-    const double t1 = u[g.ix(i, 1, k)] - u[g.ix(i, 0, k)] + u[g.ix(i - 1, 1, k)] - u[g.ix(i - 1, 0, k)];
-    const double t2 = w[g.ix(i, 1, k)] - w[g.ix(i, 0, k)] + w[g.ix(i, 1, k - 1)] - w[g.ix(i, 0, k - 1)];
+    const real t1 = u[g.ix(i, 1, k)] - u[g.ix(i, 0, k)] + u[g.ix(i - 1, 1, k)] - u[g.ix(i - 1, 0, k)];
+    const real t2 = w[g.ix(i, 1, k)] - w[g.ix(i, 0, k)] + w[g.ix(i, 1, k - 1)] - w[g.ix(i, 0, k - 1)];
     twy[(size_t)k * g.s1 + i] = sqrt(0.5 * visc * (sqrt(t1 * t1 + t2 * t2) * dyi));
   }
   if (hi) {
-    const double t1 = u[g.ix(i, n2, k)] - u[g.ix(i, n2 + 1, k)] + u[g.ix(i - 1, n2, k)] - u[g.ix(i - 1, n2 + 1, k)];
-    const double t2 = w[g.ix(i, n2, k)] - w[g.ix(i, n2 + 1, k)] + w[g.ix(i, n2, k - 1)] - w[g.ix(i, n2 + 1, k - 1)];
+    const real t1 = u[g.ix(i, n2, k)] - u[g.ix(i, n2 + 1, k)] + u[g.ix(i - 1, n2, k)] - u[g.ix(i - 1, n2 + 1, k)];
+    const real t2 = w[g.ix(i, n2, k)] - w[g.ix(i, n2 + 1, k)] + w[g.ix(i, n2, k - 1)] - w[g.ix(i, n2 + 1, k - 1)];
     twy[(size_t)(g.n3 + 2 + k) * g.s1 + i] = sqrt(0.5 * visc * (sqrt(t1 * t1 + t2 * t2) * dyi));
   }
 }
 template <typename OFF, int SMAG, int TY, int YW>      // YW = 1: walls or wall-model faces in y (ducts); the channel instantiations carry none of that logic
 __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTileArgs A) {
   // (one barrier per plane with four ring slots and double-buffered sums, as in k_lij_mij_tile, measured 13 % slower here)
-  __shared__ double ring[3][3][TY + 2][66];      // rows: x-halo cell, 64 own cells, x-halo cell
-  __shared__ double shs[SMAG ? 1 : 3][TY + 2][64];
+  __shared__ real ring[3][3][TY + 2][66];      // rows: x-halo cell, 64 own cells, x-halo cell
+  __shared__ real shs[SMAG ? 1 : 3][TY + 2][64];
   const int tx = threadIdx.x, ty = threadIdx.y;
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   if (A.bm.gx && !band_block(A.bm, bx, by, bz)) return;
@@ -696,12 +696,12 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
   const int ih = tx == 0 ? i - 1 : i + 1, hx = tx == 0 ? 0 : 65;
   const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1, hok = edge && ih <= g.n1 + 1 && j <= g.n2 + 1;
   const bool outok = ty >= 1 && ty <= TY && i <= g.n1 && j <= g.n2;
-  const OFF c0 = ldok ? (OFF)g.ix(i, j, 0) * 8 : 0, ch = hok ? (OFF)g.ix(ih, j, 0) * 8 : 0, sk = (OFF)g.s12 * 8;   // byte offsets
-  double fn[3], fh[3];
+  const OFF c0 = ldok ? (OFF)g.ix(i, j, 0) * RSZ : 0, ch = hok ? (OFF)g.ix(ih, j, 0) * RSZ : 0, sk = (OFF)g.s12 * RSZ;   // byte offsets
+  real fn[3], fh[3];
   // ghost rows at wall-model y faces (SMAG pass of ducts): u and w are replaced by 2 Q(1) - Q(2) along y; v, normal to the face, is not
   const int yex = !YW ? 0 : (A.wmylo && j == 0) ? 1 : (A.wmyhi && j == g.n2 + 1) ? -1 : 0;
-  const OFF sjb = (OFF)g.s1 * 8;
-  auto ld = [&](int q, OFF o) -> double {
+  const OFF sjb = (OFF)g.s1 * RSZ;
+  auto ld = [&](int q, OFF o) -> real {
     if (YW && yex != 0 && q != 1) return yex > 0 ? 2. * ldb(A.u[q], o + sjb) - ldb(A.u[q], o + 2 * sjb) : 2. * ldb(A.u[q], o - sjb) - ldb(A.u[q], o - 2 * sjb);
     return ldb(A.u[q], o);
   };
@@ -722,18 +722,18 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
   }
   // van Driest: wall units from the shear at the nearer z wall of this column (sgs.f90:117-143), read from the fields
   // themselves (their ghost cells, not the extrapolated ones)
-  double tw_lo = 0., tw_hi = 0.;
+  real tw_lo = 0., tw_hi = 0.;
   if (SMAG && outok) {
-    const double *u = A.u[0], *v = A.u[1];
+    const real *u = A.u[0], *v = A.u[1];
     if (A.zlo) {
-      const double t1 = u[g.ix(i, j, 1)] - u[g.ix(i, j, 0)] + u[g.ix(i - 1, j, 1)] - u[g.ix(i - 1, j, 0)];
-      const double t2 = v[g.ix(i, j, 1)] - v[g.ix(i, j, 0)] + v[g.ix(i, j - 1, 1)] - v[g.ix(i, j - 1, 0)];
+      const real t1 = u[g.ix(i, j, 1)] - u[g.ix(i, j, 0)] + u[g.ix(i - 1, j, 1)] - u[g.ix(i - 1, j, 0)];
+      const real t2 = v[g.ix(i, j, 1)] - v[g.ix(i, j, 0)] + v[g.ix(i, j - 1, 1)] - v[g.ix(i, j - 1, 0)];
       tw_lo = sqrt(0.5 * A.visc * (sqrt(t1 * t1 + t2 * t2) * A.dzci[0]));      // sqrt(tauw), constant along the column
     }
     if (A.zhi) {
       const int n3 = g.n3;
-      const double t1 = u[g.ix(i, j, n3)] - u[g.ix(i, j, n3 + 1)] + u[g.ix(i - 1, j, n3)] - u[g.ix(i - 1, j, n3 + 1)];
-      const double t2 = v[g.ix(i, j, n3)] - v[g.ix(i, j, n3 + 1)] + v[g.ix(i, j - 1, n3)] - v[g.ix(i, j - 1, n3 + 1)];
+      const real t1 = u[g.ix(i, j, n3)] - u[g.ix(i, j, n3 + 1)] + u[g.ix(i - 1, j, n3)] - u[g.ix(i - 1, j, n3 + 1)];
+      const real t2 = v[g.ix(i, j, n3)] - v[g.ix(i, j, n3 + 1)] + v[g.ix(i, j - 1, n3)] - v[g.ix(i, j - 1, n3 + 1)];
       tw_hi = sqrt(0.5 * A.visc * (sqrt(t1 * t1 + t2 * t2) * A.dzci[n3]));
     }
   }
@@ -752,19 +752,19 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
     }
     __syncthreads();
     const bool lo = A.zlo && k == 1, hi = A.zhi && k == g.n3;
-    double r[3];
+    real r[3];
     if (!SMAG) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       auto zcomb = [&](int x) {
-        const double qm = ring[km][q][ty][x], qc = ring[kc][q][ty][x], qp = ring[kp][q][ty][x];
-        const double vm = (lo && q < 2) ? 2. * qc - qp : qm;      // u,v extrapolated through the walls, w (on the faces) not
-        const double vp = (hi && q < 2) ? 2. * qc - qm : qp;
+        const real qm = ring[km][q][ty][x], qc = ring[kc][q][ty][x], qp = ring[kp][q][ty][x];
+        const real vm = (lo && q < 2) ? 2. * qc - qp : qm;      // u,v extrapolated through the walls, w (on the faces) not
+        const real vp = (hi && q < 2) ? 2. * qc - qm : qp;
         return vm + 2. * qc + vp;
       };
-      const double G = zcomb(tx + 1);
-      double pv = lane_prev(G), nx = lane_next(G);
-      if (edge) { const double Gh = zcomb(hx); if (tx == 0) pv = Gh; else nx = Gh; }
+      const real G = zcomb(tx + 1);
+      real pv = lane_prev(G), nx = lane_next(G);
+      if (edge) { const real Gh = zcomb(hx); if (tx == 0) pv = Gh; else nx = Gh; }
       r[q] = pv + 2. * G + nx;
       shs[q][ty][tx] = r[q];
     }
@@ -773,39 +773,39 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
 #define RU(dk, dj, di) ring[dk][0][ty + (dj)][tx + 1 + (di)]
 #define RV(dk, dj, di) ring[dk][1][ty + (dj)][tx + 1 + (di)]
 #define RW(dk, dj, di) ring[dk][2][ty + (dj)][tx + 1 + (di)]
-      const double u_mcm = RU(km, 0, -1), u_ccm = RU(km, 0, 0), u_mmc = RU(kc, -1, -1), u_cmc = RU(kc, -1, 0), u_mcc = RU(kc, 0, -1),
+      const real u_mcm = RU(km, 0, -1), u_ccm = RU(km, 0, 0), u_mmc = RU(kc, -1, -1), u_cmc = RU(kc, -1, 0), u_mcc = RU(kc, 0, -1),
                    u_ccc = RU(kc, 0, 0), u_mpc = RU(kc, 1, -1), u_cpc = RU(kc, 1, 0), u_mcp = RU(kp, 0, -1), u_ccp = RU(kp, 0, 0);
-      const double v_cmm = RV(km, -1, 0), v_ccm = RV(km, 0, 0), v_mmc = RV(kc, -1, -1), v_cmc = RV(kc, -1, 0), v_pmc = RV(kc, -1, 1),
+      const real v_cmm = RV(km, -1, 0), v_ccm = RV(km, 0, 0), v_mmc = RV(kc, -1, -1), v_cmc = RV(kc, -1, 0), v_pmc = RV(kc, -1, 1),
                    v_mcc = RV(kc, 0, -1), v_ccc = RV(kc, 0, 0), v_pcc = RV(kc, 0, 1), v_cmp = RV(kp, -1, 0), v_ccp = RV(kp, 0, 0);
-      const double w_cmm = RW(km, -1, 0), w_mcm = RW(km, 0, -1), w_ccm = RW(km, 0, 0), w_pcm = RW(km, 0, 1), w_cpm = RW(km, 1, 0),
+      const real w_cmm = RW(km, -1, 0), w_mcm = RW(km, 0, -1), w_ccm = RW(km, 0, 0), w_pcm = RW(km, 0, 1), w_cpm = RW(km, 1, 0),
                    w_cmc = RW(kc, -1, 0), w_mcc = RW(kc, 0, -1), w_ccc = RW(kc, 0, 0), w_pcc = RW(kc, 0, 1), w_cpc = RW(kc, 1, 0);
 #undef RU
 #undef RV
 #undef RW
-      const double dxi = A.dxi, dyi = A.dyi, zc = ldc(A.dzci, k), zm = ldc(A.dzci, k - 1);
-      const double s11 = (u_ccc - u_mcc) * dxi, s22 = (v_ccc - v_cmc) * dyi, s33 = (w_ccc - w_ccm) * ldc(A.dzfi, k);
-      const double s12 = .125 * ((u_cpc - u_ccc) * dyi + (v_pcc - v_ccc) * dxi + (u_ccc - u_cmc) * dyi + (v_pmc - v_cmc) * dxi +
+      const real dxi = A.dxi, dyi = A.dyi, zc = ldc(A.dzci, k), zm = ldc(A.dzci, k - 1);
+      const real s11 = (u_ccc - u_mcc) * dxi, s22 = (v_ccc - v_cmc) * dyi, s33 = (w_ccc - w_ccm) * ldc(A.dzfi, k);
+      const real s12 = .125 * ((u_cpc - u_ccc) * dyi + (v_pcc - v_ccc) * dxi + (u_ccc - u_cmc) * dyi + (v_pmc - v_cmc) * dxi +
                                  (u_mpc - u_mcc) * dyi + (v_ccc - v_mcc) * dxi + (u_mcc - u_mmc) * dyi + (v_cmc - v_mmc) * dxi);
-      const double s13 = .125 * ((u_ccp - u_ccc) * zc + (w_pcc - w_ccc) * dxi + (u_ccc - u_ccm) * zm + (w_pcm - w_ccm) * dxi +
+      const real s13 = .125 * ((u_ccp - u_ccc) * zc + (w_pcc - w_ccc) * dxi + (u_ccc - u_ccm) * zm + (w_pcm - w_ccm) * dxi +
                                  (u_mcp - u_mcc) * zc + (w_ccc - w_mcc) * dxi + (u_mcc - u_mcm) * zm + (w_ccm - w_mcm) * dxi);
-      const double s23 = .125 * ((v_ccp - v_ccc) * zc + (w_cpc - w_ccc) * dyi + (v_ccc - v_ccm) * zm + (w_cpm - w_ccm) * dyi +
+      const real s23 = .125 * ((v_ccp - v_ccc) * zc + (w_cpc - w_ccc) * dyi + (v_ccc - v_ccm) * zm + (w_cpm - w_ccm) * dyi +
                                  (v_cmp - v_cmc) * zc + (w_ccc - w_cmc) * dyi + (v_cmc - v_cmm) * zm + (w_ccm - w_cmm) * dyi);
-      const double s0v = sqrt(2. * (s11 * s11 + s22 * s22 + s33 * s33 + 2. * (s12 * s12 + s13 * s13 + s23 * s23)));
+      const real s0v = sqrt(2. * (s11 * s11 + s22 * s22 + s33 * s33 + 2. * (s12 * s12 + s13 * s13 + s23 * s23)));
       if (SMAG) {
-        double fd = 1.;
+        real fd = 1.;
         if (A.zlo || A.zhi || (YW && (A.wylo || A.wyhi))) {     // nearest wall in the order y-, y+, z-, z+: the first one wins a tie (minloc, sgs.f90:116)
           const int jg = j + g.jlo;                  // distances to the y walls use global rows
-          double dmin = YW && A.wylo ? A.dl2 * (jg - 0.5) : CALES_BIG, tw = 0.; int loc = 2;
-          { const double d = YW && A.wyhi ? A.dl2 * (g.ng2 - jg + 0.5) : CALES_BIG; if (d < dmin) { dmin = d; loc = 3; } }
-          { const double d = A.zlo ? ldc(A.zc, k) : CALES_BIG; if (d < dmin) { dmin = d; loc = 4; } }
-          { const double d = A.zhi ? A.l3 - ldc(A.zc, k) : CALES_BIG; if (d < dmin) { dmin = d; loc = 5; } }
+          real dmin = YW && A.wylo ? A.dl2 * (jg - 0.5) : CALES_BIG, tw = 0.; int loc = 2;
+          { const real d = YW && A.wyhi ? A.dl2 * (g.ng2 - jg + 0.5) : CALES_BIG; if (d < dmin) { dmin = d; loc = 3; } }
+          { const real d = A.zlo ? ldc(A.zc, k) : CALES_BIG; if (d < dmin) { dmin = d; loc = 4; } }
+          { const real d = A.zhi ? A.l3 - ldc(A.zc, k) : CALES_BIG; if (d < dmin) { dmin = d; loc = 5; } }
           if (loc == 2) tw = A.twy[(size_t)k * g.s1 + i];
           else if (loc == 3) tw = A.twy[(size_t)(g.n3 + 2 + k) * g.s1 + i];
           else tw = loc == 4 ? tw_lo : tw_hi;
-          const double dw_plus = dmin * tw * (1. / A.visc);
+          const real dw_plus = dmin * tw * (1. / A.visc);
           fd = 1. - exp(-dw_plus / 25.);
         }
-        const double t = 0.11 * ldc(A.del, k) * fd;      // c_smag, src/param.f90:33
+        const real t = 0.11 * ldc(A.del, k) * fd;      // c_smag, src/param.f90:33
         stb(A.visct, idx, (t * t) * s0v);
       } else {
         stb(A.s0, idx, s0v);                                              // stands for visct = s0 (sgs.f90:184) until the final kernel
@@ -821,8 +821,8 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
       const bool ylo = YW && A.wylo && j == 1, yhi = YW && A.wyhi && j == g.n2;
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        const double dn = shs[q][ty - 1][tx], up = shs[q][ty + 1][tx];
-        const double a = (ylo && q != 1) ? 2. * r[q] - up : dn, b = (yhi && q != 1) ? 2. * r[q] - dn : up;
+        const real dn = shs[q][ty - 1][tx], up = shs[q][ty + 1][tx];
+        const real a = (ylo && q != 1) ? 2. * r[q] - up : dn, b = (yhi && q != 1) ? 2. * r[q] - dn : up;
         stb(A.uf[q], idx, (a + 2. * r[q] + b) / 64.);
       }
     }
@@ -846,82 +846,82 @@ __global__ __launch_bounds__(64 * SROWS) __attribute__((amdgpu_waves_per_eu(4, 4
   if (j > g.n2) return;
   const int kbeg = bz * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
   const bool ldok = i <= g.n1 + 1, outok = tx >= 1 && tx <= 62 && i <= g.n1;
-  const OFF sj = (OFF)g.s1 * 8, sk = (OFF)g.s12 * 8;
-  const OFF c0 = ldok ? (OFF)g.ix(i, j, 0) * 8 : (OFF)g.ix(0, j, 0) * 8;
+  const OFF sj = (OFF)g.s1 * RSZ, sk = (OFF)g.s12 * RSZ;
+  const OFF c0 = ldok ? (OFF)g.ix(i, j, 0) * RSZ : (OFF)g.ix(0, j, 0) * RSZ;
   // ghost rows at wall-model y faces: u and w are replaced by 2 Q(1) - Q(2) along y; v, normal to the face, is not (extrapolate(...,lwm), sgs.f90:683-748)
   const bool exlo = YW && A.wmylo && j == 1, exhi = YW && A.wmyhi && j == g.n2;
   // (lanes beyond the row read cell 0 of the field and planes beyond n3+1 are clamped: every load is unconditional, nothing branches around it)
-  auto ldu = [&](int q, int dj, int k) -> double {      // q = 0 (u) or 2 (w), dj = -1, 0, +1
+  auto ldu = [&](int q, int dj, int k) -> real {      // q = 0 (u) or 2 (w), dj = -1, 0, +1
     const OFF o = c0 + (OFF)k * sk;
     if (YW && dj < 0 && exlo) return 2. * ldb(A.u[q], o) - ldb(A.u[q], o + sj);
     if (YW && dj > 0 && exhi) return 2. * ldb(A.u[q], o) - ldb(A.u[q], o - sj);
     return ldb(A.u[q], dj < 0 ? o - sj : dj > 0 ? o + sj : o);
   };
-  auto ldv = [&](int dj, int k) -> double { return ldb(A.u[1], c0 + (OFF)k * sk - (dj < 0 ? sj : 0)); };
+  auto ldv = [&](int dj, int k) -> real { return ldb(A.u[1], c0 + (OFF)k * sk - (dj < 0 ? sj : 0)); };
   // planes k-1, k, k+1 of u(j), v(j-1), v(j); plane k of u(j-1), u(j+1); planes k-1, k of w(j-1), w(j), w(j+1)
-  double u0m = ldu(0, 0, kbeg - 1), u0c = ldu(0, 0, kbeg), u0p = ldu(0, 0, kbeg + 1);
-  double vAm = ldv(-1, kbeg - 1), vAc = ldv(-1, kbeg), vAp = ldv(-1, kbeg + 1);
-  double vCm = ldv(0, kbeg - 1), vCc = ldv(0, kbeg), vCp = ldv(0, kbeg + 1);
-  double uA = ldu(0, -1, kbeg), uB = ldu(0, 1, kbeg);
-  double wAm = ldu(2, -1, kbeg - 1), wCm = ldu(2, 0, kbeg - 1), wBm = ldu(2, 1, kbeg - 1);
-  double wAc = ldu(2, -1, kbeg), wCc = ldu(2, 0, kbeg), wBc = ldu(2, 1, kbeg);
+  real u0m = ldu(0, 0, kbeg - 1), u0c = ldu(0, 0, kbeg), u0p = ldu(0, 0, kbeg + 1);
+  real vAm = ldv(-1, kbeg - 1), vAc = ldv(-1, kbeg), vAp = ldv(-1, kbeg + 1);
+  real vCm = ldv(0, kbeg - 1), vCc = ldv(0, kbeg), vCp = ldv(0, kbeg + 1);
+  real uA = ldu(0, -1, kbeg), uB = ldu(0, 1, kbeg);
+  real wAm = ldu(2, -1, kbeg - 1), wCm = ldu(2, 0, kbeg - 1), wBm = ldu(2, 1, kbeg - 1);
+  real wAc = ldu(2, -1, kbeg), wCc = ldu(2, 0, kbeg), wBc = ldu(2, 1, kbeg);
   // van Driest: wall units from the shear at the nearer z wall of this column (sgs.f90:117-143), read from the fields themselves
   // (their ghost cells, not the extrapolated ones)
-  double tw_lo = 0., tw_hi = 0.;
+  real tw_lo = 0., tw_hi = 0.;
   if (outok) {
-    const double *u = A.u[0], *v = A.u[1];
+    const real *u = A.u[0], *v = A.u[1];
     if (A.zlo) {
-      const double t1 = u[g.ix(i, j, 1)] - u[g.ix(i, j, 0)] + u[g.ix(i - 1, j, 1)] - u[g.ix(i - 1, j, 0)];
-      const double t2 = v[g.ix(i, j, 1)] - v[g.ix(i, j, 0)] + v[g.ix(i, j - 1, 1)] - v[g.ix(i, j - 1, 0)];
+      const real t1 = u[g.ix(i, j, 1)] - u[g.ix(i, j, 0)] + u[g.ix(i - 1, j, 1)] - u[g.ix(i - 1, j, 0)];
+      const real t2 = v[g.ix(i, j, 1)] - v[g.ix(i, j, 0)] + v[g.ix(i, j - 1, 1)] - v[g.ix(i, j - 1, 0)];
       tw_lo = sqrt(0.5 * A.visc * (sqrt(t1 * t1 + t2 * t2) * A.dzci[0]));
     }
     if (A.zhi) {
       const int n3 = g.n3;
-      const double t1 = u[g.ix(i, j, n3)] - u[g.ix(i, j, n3 + 1)] + u[g.ix(i - 1, j, n3)] - u[g.ix(i - 1, j, n3 + 1)];
-      const double t2 = v[g.ix(i, j, n3)] - v[g.ix(i, j, n3 + 1)] + v[g.ix(i, j - 1, n3)] - v[g.ix(i, j - 1, n3 + 1)];
+      const real t1 = u[g.ix(i, j, n3)] - u[g.ix(i, j, n3 + 1)] + u[g.ix(i - 1, j, n3)] - u[g.ix(i - 1, j, n3 + 1)];
+      const real t2 = v[g.ix(i, j, n3)] - v[g.ix(i, j, n3 + 1)] + v[g.ix(i, j - 1, n3)] - v[g.ix(i, j - 1, n3 + 1)];
       tw_hi = sqrt(0.5 * A.visc * (sqrt(t1 * t1 + t2 * t2) * A.dzci[n3]));
     }
   }
-  const double dxi = A.dxi, dyi = A.dyi;
+  const real dxi = A.dxi, dyi = A.dyi;
   for (int k = kbeg; k <= kend; ++k) {
     // next iteration's planes, in flight during this one's arithmetic
     const int k2 = min(k + 2, g.n3 + 1), k1 = k + 1;
-    const double u0n = ldu(0, 0, k2), vAn = ldv(-1, k2), vCn = ldv(0, k2);
-    const double uAn = ldu(0, -1, k1), uBn = ldu(0, 1, k1);
-    const double wAn = ldu(2, -1, k1), wCn = ldu(2, 0, k1), wBn = ldu(2, 1, k1);
+    const real u0n = ldu(0, 0, k2), vAn = ldv(-1, k2), vCn = ldv(0, k2);
+    const real uAn = ldu(0, -1, k1), uBn = ldu(0, 1, k1);
+    const real wAn = ldu(2, -1, k1), wCn = ldu(2, 0, k1), wBn = ldu(2, 1, k1);
     // wall-model z faces: ghost planes of u, v by extrapolation with the grid factor
-    double u_ccm = u0m, v_cmm = vAm, v_ccm = vCm, u_ccp = u0p, v_cmp = vAp, v_ccp = vCp;
+    real u_ccm = u0m, v_cmm = vAm, v_ccm = vCm, u_ccp = u0p, v_cmp = vAp, v_ccp = vCp;
     if (A.wmlo && k == 1) { u_ccm = (1. + A.flo) * u0c - A.flo * u0p; v_cmm = (1. + A.flo) * vAc - A.flo * vAp; v_ccm = (1. + A.flo) * vCc - A.flo * vCp; }
     if (A.wmhi && k == g.n3) { u_ccp = (1. + A.fhi) * u0c - A.fhi * u0m; v_cmp = (1. + A.fhi) * vAc - A.fhi * vAm; v_ccp = (1. + A.fhi) * vCc - A.fhi * vCm; }
-    const double u_ccc = u0c, u_cmc = uA, u_cpc = uB, v_cmc = vAc, v_ccc = vCc;
-    const double w_cmm = wAm, w_ccm = wCm, w_cpm = wBm, w_cmc = wAc, w_ccc = wCc, w_cpc = wBc;
-    const double u_mcm = lane_prev(u_ccm), u_mcc = lane_prev(u_ccc), u_mcp = lane_prev(u_ccp), u_mmc = lane_prev(u_cmc), u_mpc = lane_prev(u_cpc);
-    const double v_mmc = lane_prev(v_cmc), v_pmc = lane_next(v_cmc), v_mcc = lane_prev(v_ccc), v_pcc = lane_next(v_ccc);
-    const double w_mcm = lane_prev(w_ccm), w_pcm = lane_next(w_ccm), w_mcc = lane_prev(w_ccc), w_pcc = lane_next(w_ccc);
-    const double zc = ldc(A.dzci, k), zm = ldc(A.dzci, k - 1);
-    const double s11 = (u_ccc - u_mcc) * dxi, s22 = (v_ccc - v_cmc) * dyi, s33 = (w_ccc - w_ccm) * ldc(A.dzfi, k);
-    const double s12 = .125 * ((u_cpc - u_ccc) * dyi + (v_pcc - v_ccc) * dxi + (u_ccc - u_cmc) * dyi + (v_pmc - v_cmc) * dxi +
+    const real u_ccc = u0c, u_cmc = uA, u_cpc = uB, v_cmc = vAc, v_ccc = vCc;
+    const real w_cmm = wAm, w_ccm = wCm, w_cpm = wBm, w_cmc = wAc, w_ccc = wCc, w_cpc = wBc;
+    const real u_mcm = lane_prev(u_ccm), u_mcc = lane_prev(u_ccc), u_mcp = lane_prev(u_ccp), u_mmc = lane_prev(u_cmc), u_mpc = lane_prev(u_cpc);
+    const real v_mmc = lane_prev(v_cmc), v_pmc = lane_next(v_cmc), v_mcc = lane_prev(v_ccc), v_pcc = lane_next(v_ccc);
+    const real w_mcm = lane_prev(w_ccm), w_pcm = lane_next(w_ccm), w_mcc = lane_prev(w_ccc), w_pcc = lane_next(w_ccc);
+    const real zc = ldc(A.dzci, k), zm = ldc(A.dzci, k - 1);
+    const real s11 = (u_ccc - u_mcc) * dxi, s22 = (v_ccc - v_cmc) * dyi, s33 = (w_ccc - w_ccm) * ldc(A.dzfi, k);
+    const real s12 = .125 * ((u_cpc - u_ccc) * dyi + (v_pcc - v_ccc) * dxi + (u_ccc - u_cmc) * dyi + (v_pmc - v_cmc) * dxi +
                                (u_mpc - u_mcc) * dyi + (v_ccc - v_mcc) * dxi + (u_mcc - u_mmc) * dyi + (v_cmc - v_mmc) * dxi);
-    const double s13 = .125 * ((u_ccp - u_ccc) * zc + (w_pcc - w_ccc) * dxi + (u_ccc - u_ccm) * zm + (w_pcm - w_ccm) * dxi +
+    const real s13 = .125 * ((u_ccp - u_ccc) * zc + (w_pcc - w_ccc) * dxi + (u_ccc - u_ccm) * zm + (w_pcm - w_ccm) * dxi +
                                (u_mcp - u_mcc) * zc + (w_ccc - w_mcc) * dxi + (u_mcc - u_mcm) * zm + (w_ccm - w_mcm) * dxi);
-    const double s23 = .125 * ((v_ccp - v_ccc) * zc + (w_cpc - w_ccc) * dyi + (v_ccc - v_ccm) * zm + (w_cpm - w_ccm) * dyi +
+    const real s23 = .125 * ((v_ccp - v_ccc) * zc + (w_cpc - w_ccc) * dyi + (v_ccc - v_ccm) * zm + (w_cpm - w_ccm) * dyi +
                                (v_cmp - v_cmc) * zc + (w_ccc - w_cmc) * dyi + (v_cmc - v_cmm) * zm + (w_ccm - w_cmm) * dyi);
-    const double s0v = sqrt(2. * (s11 * s11 + s22 * s22 + s33 * s33 + 2. * (s12 * s12 + s13 * s13 + s23 * s23)));
+    const real s0v = sqrt(2. * (s11 * s11 + s22 * s22 + s33 * s33 + 2. * (s12 * s12 + s13 * s13 + s23 * s23)));
     if (outok) {
-      double fd = 1.;
+      real fd = 1.;
       if (A.zlo || A.zhi || (YW && (A.wylo || A.wyhi))) {     // nearest wall in the order y-, y+, z-, z+: the first one wins a tie (minloc, sgs.f90:116)
         const int jg = j + g.jlo;
-        double dmin = YW && A.wylo ? A.dl2 * (jg - 0.5) : CALES_BIG, tw = 0.; int loc = 2;
-        { const double d = YW && A.wyhi ? A.dl2 * (g.ng2 - jg + 0.5) : CALES_BIG; if (d < dmin) { dmin = d; loc = 3; } }
-        { const double d = A.zlo ? ldc(A.zc, k) : CALES_BIG; if (d < dmin) { dmin = d; loc = 4; } }
-        { const double d = A.zhi ? A.l3 - ldc(A.zc, k) : CALES_BIG; if (d < dmin) { dmin = d; loc = 5; } }
+        real dmin = YW && A.wylo ? A.dl2 * (jg - 0.5) : CALES_BIG, tw = 0.; int loc = 2;
+        { const real d = YW && A.wyhi ? A.dl2 * (g.ng2 - jg + 0.5) : CALES_BIG; if (d < dmin) { dmin = d; loc = 3; } }
+        { const real d = A.zlo ? ldc(A.zc, k) : CALES_BIG; if (d < dmin) { dmin = d; loc = 4; } }
+        { const real d = A.zhi ? A.l3 - ldc(A.zc, k) : CALES_BIG; if (d < dmin) { dmin = d; loc = 5; } }
         if (YW && loc == 2) tw = A.twy[(size_t)k * g.s1 + i];
         else if (YW && loc == 3) tw = A.twy[(size_t)(g.n3 + 2 + k) * g.s1 + i];
         else tw = loc == 4 ? tw_lo : tw_hi;
-        const double dw_plus = dmin * tw * (1. / A.visc);
+        const real dw_plus = dmin * tw * (1. / A.visc);
         fd = 1. - exp(-dw_plus / 25.);
       }
-      const double t = 0.11 * ldc(A.del, k) * fd;      // c_smag, src/param.f90:33
+      const real t = 0.11 * ldc(A.del, k) * fd;      // c_smag, src/param.f90:33
       stb(A.visct, c0 + (OFF)k * sk, (t * t) * s0v);
     }
     u0m = u0c; u0c = u0p; u0p = u0n; vAm = vAc; vAc = vAp; vAp = vAn; vCm = vCc; vCc = vCp; vCp = vCn;
@@ -929,10 +929,10 @@ __global__ __launch_bounds__(64 * SROWS) __attribute__((amdgpu_waves_per_eu(4, 4
   }
 }
 // p1d[which*n3 + k-1] = sum over the blocks' partials, fixed order (ave1d_channel, sgs.f90:462-472)
-__global__ __launch_bounds__(256) void k_plane_fold(int n3, int nblk, const double *__restrict__ part, double *__restrict__ p1d) {
-  __shared__ double sh[4];
-  const double *p = part + (size_t)blockIdx.x * nblk;
-  double acc = 0.;
+__global__ __launch_bounds__(256) void k_plane_fold(int n3, int nblk, const real *__restrict__ part, real *__restrict__ p1d) {
+  __shared__ real sh[4];
+  const real *p = part + (size_t)blockIdx.x * nblk;
+  real acc = 0.;
   for (int q = threadIdx.x; q < nblk; q += 256) acc += p[q];
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
@@ -942,8 +942,8 @@ __global__ __launch_bounds__(256) void k_plane_fold(int n3, int nblk, const doub
 }
 
 int allreduce_res(cales_ctx *c, int slot, int count, int op);
-int op_boundp(cales_ctx *c, double *p, int which);
-int op_boundp_multi(cales_ctx *c, int nf, double **p, int which);
+int op_boundp(cales_ctx *c, real *p, int which);
+int op_boundp_multi(cales_ctx *c, int nf, real **p, int which);
 static bool dsmag_fast_ok(const cales_ctx *c) {
   for (int q = 0; q < 2; ++q) if (c->is_wall[q] != 0. || c->C.lwm[q] != 0) return false;      // walls or wall model in x: general path
   // walls / wall model in y (ducts): the fused last pass knows the wall rule along y, the two-pass form does not
@@ -951,14 +951,14 @@ static bool dsmag_fast_ok(const cales_ctx *c) {
   return c->n[2] >= 3 && !c->fl.dsmag_reference_sequence;
 }
 static int dsmag_fast(cales_ctx *c) {
-  const int *n = c->n; double **f = c->f; double *visct = f[CALES_VISCT];
+  const int *n = c->n; real **f = c->f; real *visct = f[CALES_VISCT];
   dim3 b(BX, BY, 1), gr = grid3(n[0], n[1], n[2], b);
-  double **ssij = c->sij, **mij = c->mij;
+  real **ssij = c->sij, **mij = c->mij;
   const int zlo = c->is_wall[4] != 0., zhi = c->is_wall[5] != 0.;
   // wall-model faces in z: the strain rates see ghost planes extrapolated from the interior (extrapolate(...,lwm) with the
   // grid factor, sgs.f90:683-748) instead of the stress-carrying ghost cells
   const int wmlo = ISB(c, 0, 3) && LWM(c, 0, 3) != 0, wmhi = ISB(c, 1, 3) && LWM(c, 1, 3) != 0;
-  const double flo = (1. / c->dzci[0]) * c->dzci[1], fhi = (1. / c->dzci[n[2]]) * c->dzci[n[2] - 1];
+  const real flo = (1. / c->dzci[0]) * c->dzci[1], fhi = (1. / c->dzci[n[2]]) * c->dzci[n[2] - 1];
   // y walls of a duct, on the rank that owns them: wall rule of the filters along y; wall-model y faces: extrapolated ghost rows for the strain rates
   const int wylo = ISB(c, 0, 2) && c->is_wall[2] != 0., wyhi = ISB(c, 1, 2) && c->is_wall[3] != 0.;
   const int wmylo = ISB(c, 0, 2) && LWM(c, 0, 2) != 0, wmyhi = ISB(c, 1, 2) && LWM(c, 1, 2) != 0;
@@ -973,7 +973,7 @@ static int dsmag_fast(cales_ctx *c) {
     mg.z = (n[2] + kchunk - 1) / kchunk;
   };
   dim3 mb, mg; int kch;
-  const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32) && !c->fl.wide_offsets;      // 32-bit byte offsets (ldb/stb)
+  const bool small = (c->ntot + 16) * sizeof(real) < (1ull << 32) && !c->fl.wide_offsets;      // 32-bit byte offsets (ldb/stb)
   // lazy form (homogeneous sgs BCs): |S| goes straight into the eddy-viscosity field and the last pass only makes the n3 plane coefficients
   bool lazy = !c->fl.dsmag_eager;
   for (int q = 0; q < 6; ++q) lazy = lazy && c->C.bcsgs[q] == 0.;
@@ -1006,7 +1006,7 @@ static int dsmag_fast(cales_ctx *c) {
   c->bc_skip = perx;
   if (!e_) e_ = op_bounduvw(c, c->bcuf, c->bcvf, c->bcwf, 0, 0, c->uf, c->vf, c->wf);
   c->bc_skip = perx | skipz;
-  if (!e_) { double *cc[3] = {c->uc, c->vc, c->wc}; e_ = op_boundp_multi(c, 3, cc, 1); }
+  if (!e_) { real *cc[3] = {c->uc, c->vc, c->wc}; e_ = op_boundp_multi(c, 3, cc, 1); }
   c->bc_skip = 0; c->defer_halo = false;
   if (!e_ && overlap) e_ = halo_flush_deferred(c);
   if (e_) { c->deferred.clear(); return e_; }
@@ -1056,9 +1056,9 @@ static int dsmag_fast(cales_ctx *c) {
     hipLaunchKernelGGL(k_plane_fold, dim3(2 * n[2]), dim3(256), 0, c->stream, n[2], L.nblk, c->wk[0], c->d_p1d); }
   }
   if (c->P > 1) { if (int e = allreduce_res(c, (int)(c->d_p1d - c->res), 2 * n[2], 0)) return e; }   // sgs.f90:475
-  const double gar = c->dl[0] * c->dl[1] / (c->C.l[0] * c->C.l[1]);
+  const real gar = c->dl[0] * c->dl[1] / (c->C.l[0] * c->C.l[1]);
   if (lazy) {
-    if (!c->d_cs) HIPCHK(c, hipMalloc(&c->d_cs, (n[2] + 2) * sizeof(double)));
+    if (!c->d_cs) HIPCHK(c, hipMalloc(&c->d_cs, (n[2] + 2) * sizeof(real)));
     hipLaunchKernelGGL(k_dsmag_coef, dim3(1), dim3(256), 0, c->stream, n[2], gar, c->d_p1d, c->d_cs, CBP(c, 0, 3) == 'P' && CBP(c, 1, 3) == 'P' ? 1 : 0);
     c->visct_lazy = true;
   } else hipLaunchKernelGGL(k_dsmag_final, gr, b, 0, c->stream, c->g, gar, c->d_p1d, c->s0, visct);
@@ -1074,14 +1074,14 @@ static bool smag_fast_ok(const cales_ctx *c) {
   for (int q = 0; q < 2; ++q) if (c->is_wall[q] != 0. || c->C.lwm[q] != 0) return false;      // walls or wall model in x: general path
   return c->n[2] >= 3 && c->n[1] >= 2 && !c->fl.smag_reference_sequence;
 }
-__global__ void k_smag_del(int n, double dl1, double dl2, const double *__restrict__ dzf, double *__restrict__ del) {
+__global__ void k_smag_del(int n, real dl1, real dl2, const real *__restrict__ dzf, real *__restrict__ del) {
   const int k = blockIdx.x * 64 + threadIdx.x;
   if (k < n) del[k] = pow(dl1 * dl2 * dzf[k], 1. / 3.);       // the filter width depends on k only (sgs.f90:145)
 }
 static int smag_fast(cales_ctx *c) {
-  const int *n = c->n; double **f = c->f;
+  const int *n = c->n; real **f = c->f;
   if (!c->d_del) {
-    HIPCHK(c, hipMalloc(&c->d_del, (n[2] + 2) * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->d_del, (n[2] + 2) * sizeof(real)));
     hipLaunchKernelGGL(k_smag_del, dim3((n[2] + 2 + 63) / 64), dim3(64), 0, c->stream, n[2] + 2, c->dl[0], c->dl[1], c->d_dzf, c->d_del);
   }
   // tile height of the Smagorinsky pass: the pass is bound by latency (one barrier pair per plane, two square roots and an exponential per
@@ -1107,13 +1107,13 @@ static int smag_fast(cales_ctx *c) {
   S.wmylo = ISB(c, 0, 2) && LWM(c, 0, 2) != 0; S.wmyhi = ISB(c, 1, 2) && LWM(c, 1, 2) != 0;
   S.twy = nullptr;
   if (S.wylo || S.wyhi) {
-    double *twy = c->wk[0];      // scratch field: 2 x (n3+2) rows of s1 values
+    real *twy = c->wk[0];      // scratch field: 2 x (n3+2) rows of s1 values
     if ((size_t)2 * (n[2] + 2) * c->g.s1 > c->ntot) { c->err = "smag: wall-shear scratch too small"; return 1; }
     hipLaunchKernelGGL(k_wall_shear_y, dim3((n[0] + 63) / 64, (n[2] + 3) / 4), dim3(64, 4), 0, c->stream, c->g, f[CALES_U], f[CALES_W], c->visc, c->dli[1],
                        S.wylo && ISB(c, 0, 2) ? 1 : 0, S.wyhi && ISB(c, 1, 2) ? 1 : 0, twy);
     S.twy = twy;
   }
-  const bool small = (c->ntot + 16) * sizeof(double) < (1ull << 32) && !c->fl.wide_offsets;
+  const bool small = (c->ntot + 16) * sizeof(real) < (1ull << 32) && !c->fl.wide_offsets;
   const bool yw = S.wylo || S.wyhi || S.wmylo || S.wmyhi;
   if (!c->fl.smag_tile) {
     // row-marching form: one wave per row of 62 cells; chunks of k so that every CU holds several blocks' worth of independent waves
@@ -1143,9 +1143,9 @@ static int smag_fast(cales_ctx *c) {
 
 int op_cmpt_sgs(cales_ctx *c) {
   const int *n = c->n; const size_t nt = c->ntot;
-  double **f = c->f; double *visct = f[CALES_VISCT];
+  real **f = c->f; real *visct = f[CALES_VISCT];
   if (c->C.sgstype == 0) {           // 'none': visct = 0 once (sgs.f90:62-68)
-    if (c->sgs_first) { c->sgs_first = false; HIPCHK(c, hipMemsetAsync(visct, 0, nt * sizeof(double), c->stream)); c->visct_zero = true; }
+    if (c->sgs_first) { c->sgs_first = false; HIPCHK(c, hipMemsetAsync(visct, 0, nt * sizeof(real), c->stream)); c->visct_zero = true; }
     return 0;
   }
   c->visct_lazy = false;      // the field is rewritten from scratch
@@ -1159,12 +1159,12 @@ int op_cmpt_sgs(cales_ctx *c) {
   }
   if (c->C.sgstype == 2 && dsmag_fast_ok(c)) return dsmag_fast(c);
   if (c->C.sgstype == 1 && smag_fast_ok(c)) return smag_fast(c);
-  double **wk = c->wk;
+  real **wk = c->wk;
   const int if123[3] = {1, 2, 3};
   if (c->C.sgstype == 1) {
     // wk(1:3) = u,v,w ; extrapolate at wall-model faces ; strain rate (sgs.f90:84-92) -- without the copies: the ghost cells of
     // u,v,w at the wall-model faces are replaced in place, kept in wk(1), and given back before anything else reads them
-    double *uvw[3] = {f[CALES_U], f[CALES_V], f[CALES_W]};
+    real *uvw[3] = {f[CALES_U], f[CALES_V], f[CALES_W]};
     const size_t need = 6 * ((size_t)(n[1] + 2) * (n[2] + 2) + (size_t)(n[0] + 2) * (n[2] + 2) + (size_t)(n[0] + 2) * (n[1] + 2));
     if (need <= c->ntot) {
       if (int e = extrapolate(c, 3, uvw, if123, 0, wk[0], 0)) return e;
@@ -1179,7 +1179,7 @@ int op_cmpt_sgs(cales_ctx *c) {
     A.dl1 = c->dl[0]; A.dl2 = c->dl[1]; A.l3 = c->C.l[2]; A.dxi = c->dli[0]; A.dyi = c->dli[1]; A.visc = c->visc;
     A.sumw = 0.; for (int q = 0; q < 6; ++q) A.sumw += c->is_wall[q];
     if (!c->d_del) {
-      HIPCHK(c, hipMalloc(&c->d_del, (n[2] + 2) * sizeof(double)));
+      HIPCHK(c, hipMalloc(&c->d_del, (n[2] + 2) * sizeof(real)));
       hipLaunchKernelGGL(k_smag_del, dim3((n[2] + 2 + 63) / 64), dim3(64), 0, c->stream, n[2] + 2, c->dl[0], c->dl[1], c->d_dzf, c->d_del);
     }
     hipLaunchKernelGGL(k_smag, gr, b, 0, c->stream, c->g, A, c->d_zc, c->d_dzci, c->d_del, f[CALES_U], f[CALES_V], f[CALES_W], c->s0, visct);
@@ -1189,7 +1189,7 @@ int op_cmpt_sgs(cales_ctx *c) {
   // ---- dynamic model (sgs.f90:153-380): wk(1:3) = u,v,w ; extrapolate at wall-model faces ; strain rate (sgs.f90:173-181)
   hipLaunchKernelGGL(k_copy3, lin_grid(nt), dim3(256), 0, c->stream, nt, f[CALES_U], f[CALES_V], f[CALES_W], wk[0], wk[1], wk[2]);
   if (int e = extrapolate(c, 3, wk, if123, 0)) return e;
-  double **sij = c->sij, **mij = c->mij, **lij = c->sij;
+  real **sij = c->sij, **mij = c->mij, **lij = c->sij;
   if (int e = strain_rate(c, wk[0], wk[1], wk[2], c->s0, sij)) return e;
   hipLaunchKernelGGL(k_copy1, lin_grid(nt), dim3(256), 0, c->stream, nt, c->s0, visct);
   if (int e = op_boundp(c, c->s0, 1)) return e;
@@ -1206,7 +1206,7 @@ int op_cmpt_sgs(cales_ctx *c) {
   hipLaunchKernelGGL(k_filter3d, gr, b, 0, c->stream, c->g, wk[1], c->vf);
   hipLaunchKernelGGL(k_filter3d, gr, b, 0, c->stream, c->g, wk[2], c->wf);
   if (int e = op_bounduvw(c, c->bcuf, c->bcvf, c->bcwf, 0, 0, c->uf, c->vf, c->wf)) return e;
-  double *ff[3] = {c->uf, c->vf, c->wf};
+  real *ff[3] = {c->uf, c->vf, c->wf};
   if (int e = extrapolate(c, 3, ff, if123, 0)) return e;
   if (int e = strain_rate(c, c->uf, c->vf, c->wf, c->s0, sij)) return e;
   hipLaunchKernelGGL(k_mij, gr, b, 0, c->stream, c->g, pmij, c->alph2, c->s0, csij);
@@ -1217,7 +1217,7 @@ int op_cmpt_sgs(cales_ctx *c) {
   hipLaunchKernelGGL(k_uiuj, lin_grid(nt), dim3(256), 0, c->stream, nt, c->uc, c->vc, c->wc, pwk);
   if (int e = extrapolate(c, 6, wk, if0, 1)) return e;
   for (int m = 0; m < 6; ++m) hipLaunchKernelGGL(k_filter3d, gr, b, 0, c->stream, c->g, wk[m], lij[m]);
-  double *cc[3] = {c->uc, c->vc, c->wc};
+  real *cc[3] = {c->uc, c->vc, c->wc};
   if (int e = extrapolate(c, 3, cc, if0, 1)) return e;
   hipLaunchKernelGGL(k_filter3d, gr, b, 0, c->stream, c->g, c->uc, c->uf);
   hipLaunchKernelGGL(k_filter3d, gr, b, 0, c->stream, c->g, c->vc, c->vf);
@@ -1226,7 +1226,7 @@ int op_cmpt_sgs(cales_ctx *c) {
   hipLaunchKernelGGL(k_contract, gr, b, 0, c->stream, c->g, cmij, clij, c->uf, c->vf, c->wf, wk[0], wk[1]);
   hipLaunchKernelGGL(k_plane_sum, dim3(n[2], 2), dim3(256), 0, c->stream, c->g, wk[0], wk[1], c->d_p1d);
   if (c->P > 1) { if (int e = allreduce_res(c, (int)(c->d_p1d - c->res), 2 * n[2], 0)) return e; }   // sgs.f90:475
-  const double gar = c->dl[0] * c->dl[1] / (c->C.l[0] * c->C.l[1]);
+  const real gar = c->dl[0] * c->dl[1] / (c->C.l[0] * c->C.l[1]);
   hipLaunchKernelGGL(k_dsmag_final, gr, b, 0, c->stream, c->g, gar, c->d_p1d, visct, visct);
   HIPCHK(c, hipGetLastError());
   return 0;

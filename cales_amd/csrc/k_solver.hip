@@ -3,7 +3,7 @@
 //
 // MI355X design (no hipFFT/rocFFT, no transposes on one GPU, no MFMA -- the pass is HBM-bound):
 //   x pass : batched real-to-complex FFT of the contiguous rows. The n1 reals of a row become n1/2+1
-//            complex modes that are written IN PLACE over the haloed row (n1+2 doubles = n1/2+1 double2).
+//            complex modes that are written IN PLACE over the haloed row (n1+2 doubles = n1/2+1 real2).
 //   y pass : batched complex FFT of the strided columns; a workgroup stages CB adjacent complex columns
 //            (CB*16 B contiguous per row) of one z-plane in LDS, transforms them there and writes back.
 //   z pass : Thomas algorithm, one thread per complex mode (re,im share the pivots), coalesced over x.
@@ -15,7 +15,7 @@
 #include <list>
 #include <mutex>
 
-struct cpx { double x, y; };
+struct cpx { real x, y; };
 __device__ inline cpx cadd(cpx a, cpx b) { return {a.x + b.x, a.y + b.y}; }
 __device__ inline cpx csub(cpx a, cpx b) { return {a.x - b.x, a.y - b.y}; }
 __device__ inline cpx cmul(cpx a, cpx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
@@ -42,13 +42,13 @@ __device__ inline void fft_stage(const cpx *__restrict__ in, cpx *__restrict__ o
       const cpx a0 = cadd(v[0], v[2]), a1 = csub(v[0], v[2]), a2 = cadd(v[1], v[3]), a3 = mul_mi<INV>(csub(v[1], v[3]));
       out[j0] = cadd(a0, a2); out[j0 + Ns] = cadd(a1, a3); out[j0 + 2 * Ns] = csub(a0, a2); out[j0 + 3 * Ns] = csub(a1, a3);
     } else if (R == 3) {
-      const double s3 = INV ? 0.86602540378443864676 : -0.86602540378443864676;
+      const real s3 = INV ? 0.86602540378443864676 : -0.86602540378443864676;
       const cpx s = cadd(v[1], v[2]), d = csub(v[1], v[2]);
       const cpx m = {v[0].x - 0.5 * s.x, v[0].y - 0.5 * s.y}, rot = {-s3 * d.y, s3 * d.x};   // i*s3*d
       out[j0] = cadd(v[0], s); out[j0 + Ns] = cadd(m, rot); out[j0 + 2 * Ns] = csub(m, rot);
     } else if (R == 5) {
-      const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
-      const double s1 = INV ? 0.95105651629515357212 : -0.95105651629515357212, s2 = INV ? 0.58778525229247312917 : -0.58778525229247312917;
+      const real c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
+      const real s1 = INV ? 0.95105651629515357212 : -0.95105651629515357212, s2 = INV ? 0.58778525229247312917 : -0.58778525229247312917;
       const cpx a = cadd(v[1], v[4]), b = csub(v[1], v[4]), c = cadd(v[2], v[3]), d = csub(v[2], v[3]);
       const cpx m1 = {v[0].x + c1 * a.x + c2 * c.x, v[0].y + c1 * a.y + c2 * c.y}, m2 = {v[0].x + c2 * a.x + c1 * c.x, v[0].y + c2 * a.y + c1 * c.y};
       const cpx r1 = {-(s1 * b.y + s2 * d.y), s1 * b.x + s2 * d.x}, r2 = {-(s2 * b.y - s1 * d.y), s2 * b.x - s1 * d.x};
@@ -126,7 +126,7 @@ __device__ inline cpx *fft_line(const FftPlan &P, cpx *a, cpx *b, int t, int T, 
 template <int INV> __device__ inline cpx tw_mul(cpx v, cpx w) { if (INV) w.y = -w.y; return cmul(v, w); }
 template <int INV>
 __device__ inline void fft8_regs(cpx *v) {   // natural order in -> natural order out
-  const double h = 0.70710678118654752440;
+  const real h = 0.70710678118654752440;
   cpx a0 = cadd(v[0], v[4]), a1 = cadd(v[1], v[5]), a2 = cadd(v[2], v[6]), a3 = cadd(v[3], v[7]);
   cpx b0 = csub(v[0], v[4]), b1 = csub(v[1], v[5]), b2 = csub(v[2], v[6]), b3 = csub(v[3], v[7]);
   // b_n *= w8^n  (forward w8 = e^{-i pi/4})
@@ -204,10 +204,10 @@ __device__ inline int dct_src(int e, int n) { return e < n / 2 ? 2 * e : 2 * (n 
 // (fillps.f90:36-47, same expression as k_fillps) -- the separate fillps pass and its write + re-read of pp disappear.
 // mean_mask != 0: the pass also sums comp*grid_vol_ratio(k) of the forced velocity components it reads anyway (bulk_mean,
 // utils.f90:35-44), one partial per block and component -> the separate reduction pass over u disappears.
-struct FillArgs { const double *u, *v, *w, *dzfi; double dti, dtidxi, dtidyi; int mean_mask; const double *gvr_f, *gvr_c; double *part; int pstride = 0, pofs = 0; };      // pstride: partial sums per component over all launches of a chunked pass (0: gridDim.x)
+struct FillArgs { const real *u, *v, *w, *dzfi; real dti, dtidxi, dtidyi; int mean_mask; const real *gvr_f, *gvr_c; real *part; int pstride = 0, pofs = 0; };      // pstride: partial sums per component over all launches of a chunked pass (0: gridDim.x)
 template <int INV, int KIND, int FILL = 0>
 __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const cpx *__restrict__ twg, const cpx *__restrict__ twpg,
-                                                 const cpx *__restrict__ twd, double *__restrict__ p, double scale, Spec S, double2 *__restrict__ spec,
+                                                 const cpx *__restrict__ twd, real *__restrict__ p, real scale, Spec S, real2 *__restrict__ spec,
                                                  FillArgs F = FillArgs{}, long rbeg = 0, long rend = -1) {      // rows [rbeg, rend) of the (j,k) row list: a k-chunk of the pipelined solve
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int kind = KIND;                                                 // 0 periodic (R2HC/HC2R), 1 Neumann-Neumann (DCT-II/III)
@@ -221,20 +221,20 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const
   const long nrows = rend < 0 ? (long)g.n2 * g.n3 : rend;
   const int NE = 8;                                                          // elements per thread and row: nh / T
   cpx nxt[NE + 1];
-  double macc[3] = {0., 0., 0.};
+  real macc[3] = {0., 0., 0.};
   auto rowptr = [&](long r, int &j, int &k) { j = (int)(r % g.n2) + 1; k = (int)(r / g.n2) + 1; };
   auto fetch = [&](long r) {
     if (r >= nrows) return;
     int j, k; rowptr(r, j, k);
     if (!INV && FILL) {
       const size_t c0 = g.ix(0, j, k);
-      const double dz = F.dzfi[k];
+      const real dz = F.dzfi[k];
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
         const size_t c = c0 + 1 + 2 * (t + e * T);      // cell i = 1 + 2q and its right neighbour: aligned pairs
-        const double2 uu = *reinterpret_cast<const double2 *>(F.u + c); const double um = F.u[c - 1];
-        const double2 vv = *reinterpret_cast<const double2 *>(F.v + c), vm = *reinterpret_cast<const double2 *>(F.v + c - g.s1);
-        const double2 ww = *reinterpret_cast<const double2 *>(F.w + c), wm = *reinterpret_cast<const double2 *>(F.w + c - g.s12);
+        const real2 uu = *reinterpret_cast<const real2 *>(F.u + c); const real um = F.u[c - 1];
+        const real2 vv = *reinterpret_cast<const real2 *>(F.v + c), vm = *reinterpret_cast<const real2 *>(F.v + c - g.s1);
+        const real2 ww = *reinterpret_cast<const real2 *>(F.w + c), wm = *reinterpret_cast<const real2 *>(F.w + c - g.s12);
         nxt[e] = cpx{((ww.x - wm.x) * F.dti * dz + (vv.x - vm.x) * F.dtidyi + (uu.x - um) * F.dtidxi),
                      ((ww.y - wm.y) * F.dti * dz + (vv.y - vm.y) * F.dtidyi + (uu.y - uu.x) * F.dtidxi)};
         if (F.mean_mask & 1) macc[0] += (uu.x + uu.y) * F.gvr_f[k];
@@ -242,16 +242,16 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const
         if (F.mean_mask & 4) macc[2] += (ww.x + ww.y) * F.gvr_c[k];
       }
     } else if (!INV) {
-      const double *rowp = p + g.ix(0, j, k);
+      const real *rowp = p + g.ix(0, j, k);
 #pragma unroll
       for (int e = 0; e < NE; ++e) { const int q = t + e * T; nxt[e] = cpx{rowp[1 + 2 * q], rowp[2 + 2 * q]}; }      // Makhoul's order is applied in LDS
     } else if (!kind) {
 #pragma unroll
-      for (int e = 0; e < NE; ++e) { const double2 v = spec[S.at_slab(g, t + e * T, j, k)]; nxt[e] = cpx{v.x, v.y}; }
-      if (t == 0) { const double2 v = spec[S.at_slab(g, nh, j, k)]; nxt[NE] = cpx{v.x, v.y}; }
+      for (int e = 0; e < NE; ++e) { const real2 v = spec[S.at_slab(g, t + e * T, j, k)]; nxt[e] = cpx{v.x, v.y}; }
+      if (t == 0) { const real2 v = spec[S.at_slab(g, nh, j, k)]; nxt[NE] = cpx{v.x, v.y}; }
     } else {            // DCT-III: the n real coefficients of the row as nh coalesced pairs; combined in LDS below
 #pragma unroll
-      for (int e = 0; e < NE; ++e) { const double2 v = spec[S.at_slab(g, t + e * T, j, k)]; nxt[e] = cpx{v.x, v.y}; }
+      for (int e = 0; e < NE; ++e) { const real2 v = spec[S.at_slab(g, t + e * T, j, k)]; nxt[e] = cpx{v.x, v.y}; }
     }
   };
   long r = rbeg + ((long)blockIdx.x * iters) * R + row;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const
     const bool live = r < nrows;
     int j = 1, k = 1; if (live) rowptr(r, j, k);
     if (kind && !INV) {          // x[2q] -> v[q], x[2q+1] -> v[n-1-q] (v = the real sequence the r2c transform sees, two reals per complex slot)
-      double *Ad = reinterpret_cast<double *>(A);
+      real *Ad = reinterpret_cast<real *>(A);
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
         const int q = t + e * T, r = 2 * nh - 1 - q;
@@ -274,10 +274,10 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const
     __syncthreads();
     if (it + 1 < iters) fetch(r + R);                                        // in flight during the transform
     if (INV && kind) {           // X_k = conj(w_k) (Y_k - i Y_{n-k}), Y_n := 0, k = 0..nh, from the coefficients staged in A
-      const double *Ad = reinterpret_cast<const double *>(A); const int n = 2 * nh;
+      const real *Ad = reinterpret_cast<const real *>(A); const int n = 2 * nh;
       auto coef = [&](int kk) {
-        const double yk = Ad[2 * lpad(kk >> 1) + (kk & 1)];
-        const int r2 = n - kk; const double ym = kk == 0 ? 0. : Ad[2 * lpad(r2 >> 1) + (r2 & 1)];
+        const real yk = Ad[2 * lpad(kk >> 1) + (kk & 1)];
+        const int r2 = n - kk; const real ym = kk == 0 ? 0. : Ad[2 * lpad(r2 >> 1) + (r2 & 1)];
         return cmul(cconj(twl[kk]), cpx{yk, -ym});
       };
       cpx xk[NE + 1];
@@ -290,24 +290,24 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const
       if (t == 0) A[lpad(nh)] = xk[NE];
       __syncthreads();
     }
-    double *rowp = p + g.ix(0, j, k);
+    real *rowp = p + g.ix(0, j, k);
     if (!INV) {
       fft_line8<0>(nh, A, t, tw);
       if (live) {
         for (int kk = t; kk <= nh / 2; kk += T) {
           const cpx zk = A[lpad(kk)], zm = cconj(A[lpad((nh - kk) % nh)]);
-          const cpx E = {0.5 * (zk.x + zm.x), 0.5 * (zk.y + zm.y)};
-          const cpx D = csub(zk, zm), O = {0.5 * D.y, -0.5 * D.x};     // -i/2 * (zk - conj(zm))
+          const cpx E = {(real)(0.5 * (zk.x + zm.x)), (real)(0.5 * (zk.y + zm.y))};
+          const cpx D = csub(zk, zm), O = {(real)(0.5 * D.y), (real)(-0.5 * D.x)};     // -i/2 * (zk - conj(zm))
           const cpx wO = cmul(twp[kk], O);
           const cpx xk = cadd(E, wO), xm = cconj(csub(E, wO));
           if (!kind) {
-            spec[S.at_slab(g, kk, j, k)] = make_double2(xk.x, xk.y);
-            spec[S.at_slab(g, nh - kk, j, k)] = make_double2(xm.x, xm.y);
+            spec[S.at_slab(g, kk, j, k)] = make_real2(xk.x, xk.y);
+            spec[S.at_slab(g, nh - kk, j, k)] = make_real2(xm.x, xm.y);
           } else {      // DCT-II coefficients Y_k = 2 Re(w_k V_k), Y_{n-k} = -2 Im(w_k V_k) at the real slots of the row
-            double *sd = reinterpret_cast<double *>(spec);
+            real *sd = reinterpret_cast<real *>(spec);
             const int n = 2 * nh, k2 = nh - kk;
             const cpx a = cmul(twl[kk], xk), b2 = cmul(twl[k2], xm);
-            auto put = [&](int rr, double val) { if (rr < n) sd[2 * S.at_slab(g, rr >> 1, j, k) + (rr & 1)] = val; };
+            auto put = [&](int rr, real val) { if (rr < n) sd[2 * S.at_slab(g, rr >> 1, j, k) + (rr & 1)] = val; };
             put(kk, 2. * a.x); if (kk) put(n - kk, -2. * a.y);
             put(k2, 2. * b2.x); if (k2 && k2 != n - k2) put(n - k2, -2. * b2.y);
           }
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const
         for (int e = 0; e < NE; ++e) {
           const int q = t + e * T;
           if (kind) {            // x[2q] = v[q], x[2q+1] = v[n-1-q], read back through the same LDS mapping
-            const double *Ad = reinterpret_cast<const double *>(A); const int r = 2 * nh - 1 - q;
+            const real *Ad = reinterpret_cast<const real *>(A); const int r = 2 * nh - 1 - q;
             rowp[1 + 2 * q] = Ad[2 * lpad(q >> 1) + (q & 1)] * scale; rowp[2 + 2 * q] = Ad[2 * lpad(r >> 1) + (r & 1)] * scale;
           } else { const cpx z = A[lpad(q)]; rowp[1 + 2 * q] = z.x * scale; rowp[2 + 2 * q] = z.y * scale; }
         }
@@ -339,15 +339,15 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const
     __syncthreads();
   }
   if (FILL && F.mean_mask) {      // smem is free again: wave sums, then one partial per block and component
-    double *red = reinterpret_cast<double *>(smem);
+    real *red = reinterpret_cast<real *>(smem);
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       if (!(F.mean_mask >> q & 1)) continue;
-      double v = macc[q];
+      real v = macc[q];
       for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
       if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
       __syncthreads();
-      if (threadIdx.x == 0) { double a = 0.; for (unsigned w = 0; w < blockDim.x / 64; ++w) a += red[w]; F.part[(size_t)q * (F.pstride ? F.pstride : gridDim.x) + F.pofs + blockIdx.x] = a; }
+      if (threadIdx.x == 0) { real a = 0.; for (unsigned w = 0; w < blockDim.x / 64; ++w) a += red[w]; F.part[(size_t)q * (F.pstride ? F.pstride : gridDim.x) + F.pofs + blockIdx.x] = a; }
       __syncthreads();
     }
   }
@@ -365,24 +365,24 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const
 // DIR 0 / 2: rows along x, forward (field row -> real x modes, slab side of the spectrum) / inverse (modes -> field row, times `scale`),
 // one row per block, coefficient k at the place of x_k; DIR 1: columns along y of the complex spectrum, one column per block (bwd: inverse).
 template <int DIR>
-__global__ __launch_bounds__(256) void k_dst1(Geom g, FftPlan P, int ncols, const cpx *__restrict__ tw, double *__restrict__ p, double scale,
-                                              Spec S, double2 *__restrict__ pc, int kind = 5, int bwd = 0) {
+__global__ __launch_bounds__(256) void k_dst1(Geom g, FftPlan P, int ncols, const cpx *__restrict__ tw, real *__restrict__ p, real scale,
+                                              Spec S, real2 *__restrict__ pc, int kind = 5, int bwd = 0) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int N2 = P.N, n = kind == 5 ? N2 / 2 : kind == 6 ? N2 / 2 + 1 : N2 / 4, ld = N2 + 1, t = threadIdx.x, T = blockDim.x;
   cpx *A = reinterpret_cast<cpx *>(smem), *B = A + ld;
   int j = 0, k = 0, m = 0;
   if (DIR != 1) { const long r = blockIdx.x; j = (int)(r % g.n2) + 1; k = (int)(r / g.n2) + 1; }
   else { m = blockIdx.x; k = blockIdx.y + 1; }
-  double *specd = reinterpret_cast<double *>(pc);
-  auto slot = [&](int e) -> double & { return specd[2 * S.at_slab(g, e >> 1, j, k) + (e & 1)]; };      // real x mode e of row (j,k)
-  double *rowp = p + g.ix(0, j, k);                                                                  // field row: x_e at rowp[e]
+  real *specd = reinterpret_cast<real *>(pc);
+  auto slot = [&](int e) -> real & { return specd[2 * S.at_slab(g, e >> 1, j, k) + (e & 1)]; };      // real x mode e of row (j,k)
+  real *rowp = p + g.ix(0, j, k);                                                                  // field row: x_e at rowp[e]
   auto rd = [&](int pos) -> cpx {      // value number pos (1-based) of the line
     if (DIR == 0) return cpx{rowp[pos], 0.};
     if (DIR == 2) return cpx{slot(pos - 1), 0.};
-    const double2 v = pc[S.at_mode(g, m, pos, k)]; return cpx{v.x, v.y};
+    const real2 v = pc[S.at_mode(g, m, pos, k)]; return cpx{v.x, v.y};
   };
   auto wr = [&](int pos, cpx y) {
-    if (DIR == 0) slot(pos - 1) = y.x * scale; else if (DIR == 2) rowp[pos] = y.x * scale; else pc[S.at_mode(g, m, pos, k)] = make_double2(y.x * scale, y.y * scale);
+    if (DIR == 0) slot(pos - 1) = y.x * scale; else if (DIR == 2) rowp[pos] = y.x * scale; else pc[S.at_mode(g, m, pos, k)] = make_real2(y.x * scale, y.y * scale);
   };
   const bool inv = DIR == 2 || (DIR == 1 && bwd);
   for (int q = t; q < N2; q += T) {
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void k_dst1(Geom g, FftPlan P, int ncols, cons
   cpx *Z = fft_line<0>(P, A, B, t, T, tw);
   if (kind == 5) { for (int kk = t + 1; kk < n; kk += T) wr(kk, cpx{-Z[kk].y, Z[kk].x}); }                  // Y_k = i Z_k
   else if (kind == 6) { for (int kk = t; kk < n; kk += T) wr(kk + 1, Z[kk]); }
-  else if (!inv) { for (int kk = t; kk < n; kk += T) wr(kk + 1, cpx{-0.5 * Z[2 * kk + 1].y, 0.5 * Z[2 * kk + 1].x}); }      // every x_j sits twice in (0, 2n)
+  else if (!inv) { for (int kk = t; kk < n; kk += T) wr(kk + 1, cpx{(real)(-0.5 * Z[2 * kk + 1].y), (real)(0.5 * Z[2 * kk + 1].x)}); }      // every x_j sits twice in (0, 2n)
   else { for (int kk = t; kk < n; kk += T) wr(kk + 1, cpx{-Z[kk + 1].y, Z[kk + 1].x}); }
   (void)ncols;
 }
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void k_dst1(Geom g, FftPlan P, int ncols, cons
 // (left to the inverse x pass), so the same kernel serves both directions. CB columns = 2 CB lines per block.
 template <int DST>
 __global__ __launch_bounds__(256) void k_fft_y4(Geom g, FftPlan P, int CB, int ncols, const cpx *__restrict__ tw, const cpx *__restrict__ tw4,
-                                                Spec S, double2 *__restrict__ pc) {
+                                                Spec S, real2 *__restrict__ pc) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int nh = P.N, N = 2 * nh, ld = nh + 1, T = blockDim.x / (2 * CB);
   const int m0 = blockIdx.x * CB, k = blockIdx.y + 1;
@@ -423,8 +423,8 @@ __global__ __launch_bounds__(256) void k_fft_y4(Geom g, FftPlan P, int CB, int n
   for (int q = threadIdx.x; q < CB * nh; q += blockDim.x) {
     const int col = q % CB, qq = q / CB;
     if (m0 + col < ncols) {
-      double2 a = pc[S.at_mode(g, m0 + col, 2 * qq + 1, k)], b = pc[S.at_mode(g, m0 + col, N - 1 - 2 * qq + 1, k)];
-      if (DST) { const double2 tmp = a; a = b; b = tmp; }                     // reversed input
+      real2 a = pc[S.at_mode(g, m0 + col, 2 * qq + 1, k)], b = pc[S.at_mode(g, m0 + col, N - 1 - 2 * qq + 1, k)];
+      if (DST) { const real2 tmp = a; a = b; b = tmp; }                     // reversed input
       base[(size_t)(2 * col) * 2 * ld + qq] = cmul(cpx{a.x, b.x}, tw4[qq]);
       base[(size_t)(2 * col + 1) * 2 * ld + qq] = cmul(cpx{a.y, b.y}, tw4[qq]);
     }
@@ -440,9 +440,9 @@ __global__ __launch_bounds__(256) void k_fft_y4(Geom g, FftPlan P, int CB, int n
     if (m0 + col < ncols) {
       const cpx *Z0 = base + (size_t)(2 * col) * 2 * ld + (swapped ? ld : 0), *Z1 = Z0 + 2 * ld;
       const cpx c0 = cmul(Z0[kk], tw4[nh + kk]), c1 = cmul(Z1[kk], tw4[nh + kk]);
-      const double so = DST ? 2. : -2.;                                        // DST: (-1)^k on the odd slots
-      pc[S.at_mode(g, m0 + col, 2 * kk + 1, k)] = make_double2(2. * c0.x, 2. * c1.x);
-      pc[S.at_mode(g, m0 + col, N - 1 - 2 * kk + 1, k)] = make_double2(so * c0.y, so * c1.y);
+      const real so = DST ? 2. : -2.;                                        // DST: (-1)^k on the odd slots
+      pc[S.at_mode(g, m0 + col, 2 * kk + 1, k)] = make_real2(2. * c0.x, 2. * c1.x);
+      pc[S.at_mode(g, m0 + col, N - 1 - 2 * kk + 1, k)] = make_real2(so * c0.y, so * c1.y);
     }
   }
 }
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void k_fft_y4(Geom g, FftPlan P, int CB, int n
 // register prefetch of the next plane; twiddles in LDS.
 template <int INV, int KIND>
 __global__ __launch_bounds__(512) void k_fft_y8(Geom g, int N, int ncols, int kchunk, const cpx *__restrict__ twg,
-                                                 const cpx *__restrict__ twd, Spec S, double2 *__restrict__ pc, int k0 = 0, int k1 = -1) {      // planes k0+1..k1 (k1 < 0: all)
+                                                 const cpx *__restrict__ twd, Spec S, real2 *__restrict__ pc, int k0 = 0, int k1 = -1) {      // planes k0+1..k1 (k1 < 0: all)
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int kind = KIND;
   const int T = N >> 3, CB = blockDim.x / T, ld = lpad(N) + 1;
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(512) void k_fft_y8(Geom g, int N, int ncols, int kc
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
       const int q = threadIdx.x + e * blockDim.x, col = q % CB, j = q / CB;
-      if (m0 + col < ncols) { const double2 v = pc[S.at_mode(g, m0 + col, j + 1, k)]; nxt[e] = cpx{v.x, v.y}; }
+      if (m0 + col < ncols) { const real2 v = pc[S.at_mode(g, m0 + col, j + 1, k)]; nxt[e] = cpx{v.x, v.y}; }
     }
   };
   // kind 1 (Neumann-Neumann, DCT-II/III on the real and the imaginary part alike): Makhoul order in, weights out (forward);
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(512) void k_fft_y8(Geom g, int N, int ncols, int kc
         if (!kind) v = Zc[lpad(j)];
         else if (!INV) { const cpx w = twd[j]; v = cadd(cmul(w, Zc[lpad(j)]), cmul(cconj(w), Zc[lpad((N - j) % N)])); }   // C_j = w_j V_j + conj(w_j) V_{N-j}
         else v = Zc[lpad(makhoul(j))];
-        pc[S.at_mode(g, m0 + c2, j + 1, k)] = make_double2(v.x, v.y);
+        pc[S.at_mode(g, m0 + c2, j + 1, k)] = make_real2(v.x, v.y);
       }
     }
     __syncthreads();
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(512) void k_fft_y8(Geom g, int N, int ncols, int kc
 // w_k = e^{-i pi k/(2n)} (table twd); the n real coefficients Y_0..Y_{n-1} are stored at the real slots 0..n-1 of the row.
 template <int INV>
 __global__ __launch_bounds__(256) void k_fft_x(Geom g, FftPlan P, int R, int kind, const cpx *__restrict__ tw, const cpx *__restrict__ twp,
-                                                const cpx *__restrict__ twd, double *__restrict__ p, double scale, Spec S, double2 *__restrict__ spec) {
+                                                const cpx *__restrict__ twd, real *__restrict__ p, real scale, Spec S, real2 *__restrict__ spec) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int nh = P.N, n = 2 * nh, T = blockDim.x / R, row = threadIdx.x / T, t = threadIdx.x % T;
   const int ld = nh + 1;
@@ -524,14 +524,14 @@ __global__ __launch_bounds__(256) void k_fft_x(Geom g, FftPlan P, int R, int kin
   const long r = (long)blockIdx.x * R + row, nrows = (long)g.n2 * g.n3;
   const bool live = r < nrows;
   const int j = live ? (int)(r % g.n2) + 1 : 1, k = live ? (int)(r / g.n2) + 1 : 1;
-  double *rowp = p + g.ix(0, j, k);
-  double *specd = reinterpret_cast<double *>(spec);
+  real *rowp = p + g.ix(0, j, k);
+  real *specd = reinterpret_cast<real *>(spec);
   if (!INV) {
     if (live) for (int q = t; q < nh; q += T) {
       if (!kind) A[q] = cpx{rowp[1 + 2 * q], rowp[2 + 2 * q]};
       else {       // kind 2 (Dirichlet-Dirichlet, RODFT10 = DST-II): DST-II(x)_k = DCT-II((-1)^j x_j)_{n-1-k}
         const int s0 = dct_src(2 * q, n), s1 = dct_src(2 * q + 1, n);
-        const double g0 = (kind == 2 && (s0 & 1)) ? -1. : 1., g1 = (kind == 2 && (s1 & 1)) ? -1. : 1.;
+        const real g0 = (kind == 2 && (s0 & 1)) ? -1. : 1., g1 = (kind == 2 && (s1 & 1)) ? -1. : 1.;
         A[q] = cpx{g0 * rowp[1 + s0], g1 * rowp[1 + s1]};
       }
     }
@@ -540,18 +540,18 @@ __global__ __launch_bounds__(256) void k_fft_x(Geom g, FftPlan P, int R, int kin
     if (live) {
       for (int kk = t; kk <= nh / 2; kk += T) {
         const cpx zk = Z[kk], zm = cconj(Z[(nh - kk) % nh]);
-        const cpx E = {0.5 * (zk.x + zm.x), 0.5 * (zk.y + zm.y)};
-        const cpx D = csub(zk, zm), O = {0.5 * D.y, -0.5 * D.x};     // -i/2 * (zk - conj(zm))
+        const cpx E = {(real)(0.5 * (zk.x + zm.x)), (real)(0.5 * (zk.y + zm.y))};
+        const cpx D = csub(zk, zm), O = {(real)(0.5 * D.y), (real)(-0.5 * D.x)};     // -i/2 * (zk - conj(zm))
         const cpx wO = cmul(twp[kk], O);
         const cpx xk = cadd(E, wO), xm = cconj(csub(E, wO));          // V_kk and V_{nh-kk}
         if (!kind) {
-          spec[S.at_slab(g, kk, j, k)] = make_double2(xk.x, xk.y);
-          spec[S.at_slab(g, nh - kk, j, k)] = make_double2(xm.x, xm.y);
+          spec[S.at_slab(g, kk, j, k)] = make_real2(xk.x, xk.y);
+          spec[S.at_slab(g, nh - kk, j, k)] = make_real2(xm.x, xm.y);
         } else {
           const int k2 = nh - kk;
           const cpx a = cmul(twd[kk], xk), b2 = cmul(twd[k2], xm);
           // real slot r lives in pair r/2, component r%2
-          auto put = [&](int rr, double val) { if (rr < n) { const int sl = kind == 2 ? n - 1 - rr : rr; specd[2 * S.at_slab(g, sl >> 1, j, k) + (sl & 1)] = val; } };
+          auto put = [&](int rr, real val) { if (rr < n) { const int sl = kind == 2 ? n - 1 - rr : rr; specd[2 * S.at_slab(g, sl >> 1, j, k) + (sl & 1)] = val; } };
           put(kk, 2. * a.x); if (kk) put(n - kk, -2. * a.y);
           put(k2, 2. * b2.x); if (k2 && k2 != n - k2) put(n - k2, -2. * b2.y);
         }
@@ -559,12 +559,12 @@ __global__ __launch_bounds__(256) void k_fft_x(Geom g, FftPlan P, int R, int kin
     }
   } else {
     if (live) {
-      if (!kind) { for (int kk = t; kk <= nh; kk += T) { const double2 v = spec[S.at_slab(g, kk, j, k)]; B[kk] = cpx{v.x, v.y}; } }
+      if (!kind) { for (int kk = t; kk <= nh; kk += T) { const real2 v = spec[S.at_slab(g, kk, j, k)]; B[kk] = cpx{v.x, v.y}; } }
       else for (int kk = t; kk <= nh; kk += T) {                      // X_k = conj(w_k) (Y_k - i Y_{n-k}), Y_n := 0
         // kind 2 (RODFT01 = DST-III): DST-III(y)_j = (-1)^j DCT-III(y reversed)_j
         const int sk_ = kind == 2 ? n - 1 - kk : kk, r2 = n - kk, sr = kind == 2 ? n - 1 - r2 : r2;
-        const double yk = (sk_ >= 0 && sk_ < n) ? specd[2 * S.at_slab(g, sk_ >> 1, j, k) + (sk_ & 1)] : 0.;
-        const double ym = kk == 0 ? 0. : specd[2 * S.at_slab(g, sr >> 1, j, k) + (sr & 1)];
+        const real yk = (sk_ >= 0 && sk_ < n) ? specd[2 * S.at_slab(g, sk_ >> 1, j, k) + (sk_ & 1)] : 0.;
+        const real ym = kk == 0 ? 0. : specd[2 * S.at_slab(g, sr >> 1, j, k) + (sr & 1)];
         B[kk] = cmul(cconj(twd[kk]), cpx{yk, -ym});
       }
     }
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(256) void k_fft_x(Geom g, FftPlan P, int R, int kin
 // INV = 0 reads the physical row and writes the coefficient slots (as the NN transform does), INV = 1 the other way with `scale`.
 template <int INV, int DST>
 __global__ __launch_bounds__(256) void k_fft_x4(Geom g, FftPlan P, int R, const cpx *__restrict__ tw, const cpx *__restrict__ tw4,
-                                                 double *__restrict__ p, double scale, Spec S, double2 *__restrict__ spec) {
+                                                 real *__restrict__ p, real scale, Spec S, real2 *__restrict__ spec) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int nh = P.N, n = 2 * nh, T = blockDim.x / R, row = threadIdx.x / T, t = threadIdx.x % T;
   const int ld = nh + 1;
@@ -602,20 +602,20 @@ __global__ __launch_bounds__(256) void k_fft_x4(Geom g, FftPlan P, int R, const 
   const long r = (long)blockIdx.x * R + row, nrows = (long)g.n2 * g.n3;
   const bool live = r < nrows;
   const int j = live ? (int)(r % g.n2) + 1 : 1, k = live ? (int)(r / g.n2) + 1 : 1;
-  double *rowp = p + g.ix(0, j, k);
-  double *specd = reinterpret_cast<double *>(spec);
-  auto phys = [&](int e) -> double & { return rowp[1 + e]; };
-  auto coef = [&](int e) -> double & { return specd[2 * S.at_slab(g, e >> 1, j, k) + (e & 1)]; };
+  real *rowp = p + g.ix(0, j, k);
+  real *specd = reinterpret_cast<real *>(spec);
+  auto phys = [&](int e) -> real & { return rowp[1 + e]; };
+  auto coef = [&](int e) -> real & { return specd[2 * S.at_slab(g, e >> 1, j, k) + (e & 1)]; };
   if (live) for (int q = t; q < nh; q += T) {
-    double a = INV ? coef(2 * q) : phys(2 * q), b = INV ? coef(n - 1 - 2 * q) : phys(n - 1 - 2 * q);
-    if (DST) { const double tmp = a; a = b; b = tmp; }                // reversed input
+    real a = INV ? coef(2 * q) : phys(2 * q), b = INV ? coef(n - 1 - 2 * q) : phys(n - 1 - 2 * q);
+    if (DST) { const real tmp = a; a = b; b = tmp; }                // reversed input
     A[q] = cmul(cpx{a, b}, tw4[q]);
   }
   __syncthreads();
   cpx *Z = fft_line<0>(P, A, B, t, T, tw);
   if (live) for (int kk = t; kk < nh; kk += T) {
     const cpx c = cmul(Z[kk], tw4[nh + kk]);
-    const double ye = 2. * c.x * (INV ? scale : 1.), yo = (DST ? 2. : -2.) * c.y * (INV ? scale : 1.);     // DST: (-1)^k on the odd slots
+    const real ye = 2. * c.x * (INV ? scale : 1.), yo = (DST ? 2. : -2.) * c.y * (INV ? scale : 1.);     // DST: (-1)^k on the odd slots
     if (INV) { phys(2 * kk) = ye; phys(n - 1 - 2 * kk) = yo; } else { coef(2 * kk) = ye; coef(n - 1 - 2 * kk) = yo; }
   }
 }
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256) void k_fft_x4(Geom g, FftPlan P, int R, const 
 // C_k = w_k V_k + conj(w_k) V_{N-k} (forward) and Z_k = conj(w_k) (C_k - i C_{N-k}), C_N := 0 (inverse).
 template <int INV>
 __global__ __launch_bounds__(256) void k_fft_y(Geom g, FftPlan P, int CB, int ncols, int kind, const cpx *__restrict__ tw,
-                                                const cpx *__restrict__ twd, Spec S, double2 *__restrict__ pc) {
+                                                const cpx *__restrict__ twd, Spec S, real2 *__restrict__ pc) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int N = P.N, ld = N + 1, T = blockDim.x / CB;
   const int m0 = blockIdx.x * CB, k = blockIdx.y + 1;
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256) void k_fft_y(Geom g, FftPlan P, int CB, int nc
   for (int q = threadIdx.x; q < CB * N; q += blockDim.x) {
     const int col = q % CB, j = q / CB;
     if (m0 + col < ncols) {
-      double2 v = pc[S.at_mode(g, m0 + col, j + 1, k)];
+      real2 v = pc[S.at_mode(g, m0 + col, j + 1, k)];
       // kind 2 (Dirichlet-Dirichlet, RODFT10/01): DST-II(x)_k = DCT-II((-1)^j x_j)_{N-1-k} -- the rows keep the reversed order (the y
       // eigenvalues are stored reversed, solver_setup) and only the signs of the odd rows change, on the way in and on the way out
       if (kind == 2 && !INV && (j & 1)) { v.x = -v.x; v.y = -v.y; }
@@ -667,60 +667,60 @@ __global__ __launch_bounds__(256) void k_fft_y(Geom g, FftPlan P, int CB, int nc
       else if (!INV) { const cpx w = twd[j]; v = cadd(cmul(w, Zc[j]), cmul(cconj(w), Zc[(N - j) % N])); }
       else v = Zc[(j & 1) ? N - 1 - (j >> 1) : (j >> 1)];
       if (kind == 2 && INV && (j & 1)) { v.x = -v.x; v.y = -v.y; }
-      pc[S.at_mode(g, m0 + c2, j + 1, k)] = make_double2(v.x, v.y);
+      pc[S.at_mode(g, m0 + c2, j + 1, k)] = make_real2(v.x, v.y);
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------ z pass (solver.f90:82-179)
-// VT = double2: spectral pairs (re,im) of mode m in row j; VT = double: real field columns i=1..n1.
-template <typename VT> __device__ inline VT vmul(VT a, double s);
-template <> __device__ inline double2 vmul<double2>(double2 a, double s) { return make_double2(a.x * s, a.y * s); }
-template <> __device__ inline double vmul<double>(double a, double s) { return a * s; }
-template <typename VT> __device__ inline VT vfms(VT a, double s, VT b);   // a - s*b
-template <> __device__ inline double2 vfms<double2>(double2 a, double s, double2 b) { return make_double2(a.x - s * b.x, a.y - s * b.y); }
-template <> __device__ inline double vfms<double>(double a, double s, double b) { return a - s * b; }
-template <typename VT> __device__ inline VT vfma(VT a, double s, VT b);   // a + s*b
-template <> __device__ inline double2 vfma<double2>(double2 a, double s, double2 b) { return make_double2(a.x + s * b.x, a.y + s * b.y); }
-template <> __device__ inline double vfma<double>(double a, double s, double b) { return a + s * b; }
+// VT = real2: spectral pairs (re,im) of mode m in row j; VT = real: real field columns i=1..n1.
+template <typename VT> __device__ inline VT vmul(VT a, real s);
+template <> __device__ inline real2 vmul<real2>(real2 a, real s) { return make_real2(a.x * s, a.y * s); }
+template <> __device__ inline real vmul<real>(real a, real s) { return a * s; }
+template <typename VT> __device__ inline VT vfms(VT a, real s, VT b);   // a - s*b
+template <> __device__ inline real2 vfms<real2>(real2 a, real s, real2 b) { return make_real2(a.x - s * b.x, a.y - s * b.y); }
+template <> __device__ inline real vfms<real>(real a, real s, real b) { return a - s * b; }
+template <typename VT> __device__ inline VT vfma(VT a, real s, VT b);   // a + s*b
+template <> __device__ inline real2 vfma<real2>(real2 a, real s, real2 b) { return make_real2(a.x + s * b.x, a.y + s * b.y); }
+template <> __device__ inline real vfma<real>(real a, real s, real b) { return a + s * b; }
 
 // ncol x nrow columns; spectral solve: S maps (m, j) (mode side), mofs = global index of local mode 0, nmode = number of
-// real modes (padding columns beyond it are skipped). Real fields (VT = double): in-place haloed array, i0 = 1.
-// NN in x: the two reals of a pair are different modes -> two scalar recurrences (pivots d1,d2 kept as a double2)
-__global__ __launch_bounds__(256) void k_gaussel_split(Geom g, int nz, int ncol, int nrow, int mofs, int nmode, Spec S, double lscale,
-                                                       const double *__restrict__ a, const double *__restrict__ b, const double *__restrict__ c,
-                                                       const double *__restrict__ lamx, const double *__restrict__ lamy,
-                                                       double2 *__restrict__ p, double2 *__restrict__ dscr, int fixnull) {
+// real modes (padding columns beyond it are skipped). Real fields (VT = real): in-place haloed array, i0 = 1.
+// NN in x: the two reals of a pair are different modes -> two scalar recurrences (pivots d1,d2 kept as a real2)
+__global__ __launch_bounds__(256) void k_gaussel_split(Geom g, int nz, int ncol, int nrow, int mofs, int nmode, Spec S, real lscale,
+                                                       const real *__restrict__ a, const real *__restrict__ b, const real *__restrict__ c,
+                                                       const real *__restrict__ lamx, const real *__restrict__ lamy,
+                                                       real2 *__restrict__ p, real2 *__restrict__ dscr, int fixnull) {
   const int m = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y + 1;
   if (m >= ncol || j > nrow || m + mofs >= nmode) return;
   const size_t e0 = S.at_mode(g, m, j, 1), st = S.blocked ? (size_t)S.cw * S.n2l : (size_t)g.s12 / 2;
   const size_t s0 = (size_t)m + (size_t)ncol * (size_t)(j - 1), sst = (size_t)ncol * nrow;
-  const double l1 = (lamx[2 * (m + mofs)] + lamy[j - 1]) * lscale, l2 = (lamx[2 * (m + mofs) + 1] + lamy[j - 1]) * lscale;
+  const real l1 = (lamx[2 * (m + mofs)] + lamy[j - 1]) * lscale, l2 = (lamx[2 * (m + mofs) + 1] + lamy[j - 1]) * lscale;
   const bool null1 = fixnull && l1 == 0., null2 = fixnull && l2 == 0.;      // see k_gaussel_ri
-  double z1 = 1. / (b[0] + l1 + CALES_EPS), z2 = 1. / (b[0] + l2 + CALES_EPS), d1 = c[0] * z1, d2 = c[0] * z2;
-  double2 v = p[e0]; v.x *= z1; v.y *= z2; p[e0] = v; dscr[s0] = make_double2(d1, d2);
+  real z1 = 1. / (b[0] + l1 + CALES_EPS), z2 = 1. / (b[0] + l2 + CALES_EPS), d1 = c[0] * z1, d2 = c[0] * z2;
+  real2 v = p[e0]; v.x *= z1; v.y *= z2; p[e0] = v; dscr[s0] = make_real2(d1, d2);
   for (int l = 1; l < nz; ++l) {
     z1 = 1. / ((b[l] + l1) - a[l] * d1 + CALES_EPS); z2 = 1. / ((b[l] + l2) - a[l] * d2 + CALES_EPS);
     d1 = c[l] * z1; d2 = c[l] * z2;
-    const double2 q = p[e0 + l * st];
-    v = make_double2((q.x - a[l] * v.x) * z1, (q.y - a[l] * v.y) * z2);
+    const real2 q = p[e0 + l * st];
+    v = make_real2((q.x - a[l] * v.x) * z1, (q.y - a[l] * v.y) * z2);
     if (l == nz - 1) { if (null1) v.x = 0.; if (null2) v.y = 0.; }
-    p[e0 + l * st] = v; dscr[s0 + l * sst] = make_double2(d1, d2);
+    p[e0 + l * st] = v; dscr[s0 + l * sst] = make_real2(d1, d2);
   }
   for (int l = nz - 2; l >= 0; --l) {
-    const double2 q = p[e0 + l * st], d = dscr[s0 + l * sst];
-    v = make_double2(q.x - d.x * v.x, q.y - d.y * v.y);
+    const real2 q = p[e0 + l * st], d = dscr[s0 + l * sst];
+    v = make_real2(q.x - d.x * v.x, q.y - d.y * v.y);
     p[e0 + l * st] = v;
   }
 }
 
 // Non-periodic z, complex modes: the real and the imaginary part of a mode are two independent systems with the same
 // matrix, so they go to two neighbouring lanes (lane -> mode lane/2, part lane%2; a wave still covers 512 contiguous bytes
-// per row). Twice the waves of k_gaussel<double2,0> for the same traffic: the sweeps are latency-bound chains.
-__global__ __launch_bounds__(256) void k_gaussel_ri(Geom g, int nz, int ncol, int nrow, int mofs, int nmode, Spec S, double lscale,
-                                                    const double *__restrict__ a, const double *__restrict__ b,
-                                                    const double *__restrict__ c, const double *__restrict__ lamx,
-                                                    const double *__restrict__ lamy, double *__restrict__ p, double *__restrict__ dscr, int fixnull, int xreal) {
+// per row). Twice the waves of k_gaussel<real2,0> for the same traffic: the sweeps are latency-bound chains.
+__global__ __launch_bounds__(256) void k_gaussel_ri(Geom g, int nz, int ncol, int nrow, int mofs, int nmode, Spec S, real lscale,
+                                                    const real *__restrict__ a, const real *__restrict__ b,
+                                                    const real *__restrict__ c, const real *__restrict__ lamx,
+                                                    const real *__restrict__ lamy, real *__restrict__ p, real *__restrict__ dscr, int fixnull, int xreal) {
   // threads run over (row, mode, part) linearly, so a block touches one contiguous piece of a plane per step
   const long q = (long)blockIdx.x * 256 + threadIdx.x;
   const int t = (int)(q % (2 * ncol)), m = t >> 1, part = t & 1, j = (int)(q / (2 * ncol)) + 1;
@@ -731,12 +731,12 @@ __global__ __launch_bounds__(256) void k_gaussel_ri(Geom g, int nz, int ncol, in
   const size_t s0 = xreal ? (size_t)t + (size_t)2 * ncol * (size_t)(j - 1) : (size_t)m + (size_t)ncol * (size_t)(j - 1);
   const size_t sst = (xreal ? (size_t)2 : (size_t)1) * ncol * nrow;
   // xreal (Neumann-Neumann in x): the two reals of a pair are different modes with their own eigenvalue
-  const double lam = ((xreal ? lamx[2 * (m + mofs) + part] : lamx[m + mofs]) + lamy[j - 1]) * lscale;     // lscale = alpha for the Helmholtz solves (main.f90:441), 1 for the pressure
-  double z = 1. / (b[0] + lam + CALES_EPS), d = c[0] * z;
-  double v = p[e0] * z;
+  const real lam = ((xreal ? lamx[2 * (m + mofs) + part] : lamx[m + mofs]) + lamy[j - 1]) * lscale;     // lscale = alpha for the Helmholtz solves (main.f90:441), 1 for the pressure
+  real z = 1. / (b[0] + lam + CALES_EPS), d = c[0] * z;
+  real v = p[e0] * z;
   p[e0] = v; dscr[s0] = d;      // both lanes of a pair store the same c' (one merged write); each reads back what it wrote
   for (int l = 1; l < nz; ++l) {
-    const double bb = b[l] + lam;
+    const real bb = b[l] + lam;
     z = 1. / (bb - a[l] * d + CALES_EPS);
     d = c[l] * z;
     v = (p[e0 + l * st] - a[l] * v) * z;
@@ -761,14 +761,14 @@ __global__ __launch_bounds__(256) void k_gaussel_ri(Geom g, int nz, int ncol, in
 // equations as the Thomas sweep, other association (differences at round-off level times the conditioning of the column).
 // Rows beyond nz are identity rows. Reciprocals: v_rcp_f64 + two Newton steps (full precision for normal numbers).
 // LDS layout [column][chunk][M+1] (+4 doubles per column): conflict-free for the lane-per-chunk accesses and the plane-wise copies.
-__device__ inline double rcp_nr(double x) {
-  double r = __builtin_amdgcn_rcp(x);
+__device__ inline real rcp_nr(real x) {
+  real r = __builtin_amdgcn_rcp(x);
   r = fma(r, fma(-x, r, 1.), r);
   return fma(r, fma(-x, r, 1.), r);
 }
 // a,b,c of the 64 M rows (identity rows beyond nz, no coupling out of the first and the last row) as [which][r][chunk]: the
 // lanes of a wave (= chunks) read consecutive doubles
-__global__ void k_abc_chunked(int nz, int M, const double *__restrict__ a, const double *__restrict__ b, const double *__restrict__ c, double *__restrict__ t) {
+__global__ void k_abc_chunked(int nz, int M, const real *__restrict__ a, const real *__restrict__ b, const real *__restrict__ c, real *__restrict__ t) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= 64 * M) return;
   const int o = (k % M) * 64 + k / M;
@@ -779,12 +779,12 @@ __global__ void k_abc_chunked(int nz, int M, const double *__restrict__ a, const
 struct TileMap { int blocked, cw, n2l, mofs, nmode; size_t kstride, segstride;
                  // z-only Helmholtz sweeps of real fields (no eigenvalue shift): nolam; cales_step forms the r.h.s. of rk.f90:108-118 and
                  // main.f90:422-433 while loading, (u - hf12*dudtd) + f + rhs_b, and plane nz+1 (wall face of w) receives the first two terms
-                 int nolam, nq, has_lo, has_hi; const double *dud, *force, *rb; double hf12; };
+                 int nolam, nq, has_lo, has_hi; const real *dud, *force, *rb; real hf12; };
 template <int M, int NV>
-__global__ __launch_bounds__(1024 / NV, (M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_gaussel_tile(Geom g, int nz, int ndbl, double lscale, const double *__restrict__ abc,
-                                                            const double *__restrict__ lamx, const double *__restrict__ lamy,
-                                                            double *__restrict__ p, int fixnull, TileMap T) {
-  extern __shared__ double shz[];
+__global__ __launch_bounds__(1024 / NV, (M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_gaussel_tile(Geom g, int nz, int ndbl, real lscale, const real *__restrict__ abc,
+                                                            const real *__restrict__ lamx, const real *__restrict__ lamy,
+                                                            real *__restrict__ p, int fixnull, TileMap T) {
+  extern __shared__ real shz[];
   constexpr int CP = M + 1, P = 64 * CP + 4, NT = 1024 / NV, KP = NT / 16, NQ = 64 * M / KP;
   const int t = threadIdx.x;
   const size_t base = (T.blocked ? T.segstride * blockIdx.y : g.ix(0, blockIdx.y + 1, 1)) + (size_t)16 * blockIdx.x;      // doubles from p
@@ -792,17 +792,17 @@ __global__ __launch_bounds__(1024 / NV, (M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_g
   {
     const int x = t & 15, kk = t >> 4;
     const bool ok = 16 * (int)blockIdx.x + x < ndbl;
-    double v[NQ];
+    real v[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { const int k = kk + KP * q; v[q] = (ok && k < nz) ? p[base + x + (size_t)k * kst] : 0.; }
     if (T.dud) {
-      const double f = T.force ? T.force[0] : 0.;
+      const real f = T.force ? T.force[0] : 0.;
       const size_t pq = (size_t)(16 * blockIdx.x + x) + (size_t)g.n1 * blockIdx.y;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const int k = kk + KP * q;
         if (ok && k < T.nq) {
-          double t = (k < nz ? v[q] : p[base + x + (size_t)k * kst]) - T.hf12 * T.dud[base + x + (size_t)k * kst];
+          real t = (k < nz ? v[q] : p[base + x + (size_t)k * kst]) - T.hf12 * T.dud[base + x + (size_t)k * kst];
           if (T.force) t = t + f;
           if (k == 0 && T.has_lo) t = t + T.rb[pq];
           if (k == nz - 1 && T.has_hi) t = t + T.rb[pq + (size_t)g.n1 * g.n2];
@@ -825,25 +825,25 @@ __global__ __launch_bounds__(1024 / NV, (M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_g
     colok = colok && mm + T.mofs < T.nmode;      // padding modes of the last rank: skipped (their slots are never read)
   }
   if (colok) {
-    const double lam = T.nolam ? 0. : (lamx[mode] + lamy[j - 1]) * lscale;
+    const real lam = T.nolam ? 0. : (lamx[mode] + lamy[j - 1]) * lscale;
     const bool nullc = fixnull && lam == 0.;      // singular mode: the member with p(nz) = 0, see k_gaussel_ri
-    double *col = shz + x * P + ch * CP;
+    real *col = shz + x * P + ch * CP;
     const int k0 = ch * M;
-    double cp[M - 1], V[M - 1];      // the swept right-hand sides go back to their LDS slots (registers: no spills at 4 waves/SIMD)
-    double cprev = 0., vprev = 0., rprev[NV] = {};
+    real cp[M - 1], V[M - 1];      // the swept right-hand sides go back to their LDS slots (registers: no spills at 4 waves/SIMD)
+    real cprev = 0., vprev = 0., rprev[NV] = {};
 #pragma unroll
     for (int r = 0; r < M - 1; ++r) {
       const int k = k0 + r;
       const bool pin = nullc && k == nz - 1, live = k < nz && !pin;
-      const double A = pin ? 0. : abc[r * 64 + ch], C = pin ? 0. : abc[128 * M + r * 64 + ch], B = pin ? 1. : abc[64 * M + r * 64 + ch] + (k < nz ? lam : 0.);
-      const double z = rcp_nr(B - A * cprev + CALES_EPS);
+      const real A = pin ? 0. : abc[r * 64 + ch], C = pin ? 0. : abc[128 * M + r * 64 + ch], B = pin ? 1. : abc[64 * M + r * 64 + ch] + (k < nz ? lam : 0.);
+      const real z = rcp_nr(B - A * cprev + CALES_EPS);
       cp[r] = C * z; V[r] = (r == 0 ? A : -A * vprev) * z;
 #pragma unroll
-      for (int q = 0; q < NV; ++q) { const double D = live ? col[q * P + r] : 0.; rprev[q] = (D - A * rprev[q]) * z; col[q * P + r] = rprev[q]; }
+      for (int q = 0; q < NV; ++q) { const real D = live ? col[q * P + r] : 0.; rprev[q] = (D - A * rprev[q]) * z; col[q * P + r] = rprev[q]; }
       cprev = cp[r]; vprev = V[r];
     }
     // first interior row of the chunk as a function of the separators beside it
-    double Vb = V[M - 2], Wb = cp[M - 2], Rb[NV];
+    real Vb = V[M - 2], Wb = cp[M - 2], Rb[NV];
 #pragma unroll
     for (int q = 0; q < NV; ++q) Rb[q] = rprev[q];
 #pragma unroll
@@ -854,20 +854,20 @@ __global__ __launch_bounds__(1024 / NV, (M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_g
     }
     const bool last = ch == 63;
     // (cross-lane reads are issued by all lanes and masked afterwards: a lane switched off by a branch would be read as zero)
-    double Vn = __shfl_down(Vb, 1, 64), Wn = __shfl_down(Wb, 1, 64);
+    real Vn = __shfl_down(Vb, 1, 64), Wn = __shfl_down(Wb, 1, 64);
     if (last) { Vn = 0.; Wn = 0.; }
     // separator row
-    double al, be, ga, de[NV];
+    real al, be, ga, de[NV];
     {
       const int k = k0 + M - 1, r = M - 1;
       const bool pin = nullc && k == nz - 1, live = k < nz && !pin;
-      const double A = pin ? 0. : abc[r * 64 + ch], C = pin ? 0. : abc[128 * M + r * 64 + ch], B = pin ? 1. : abc[64 * M + r * 64 + ch] + (k < nz ? lam : 0.);
+      const real A = pin ? 0. : abc[r * 64 + ch], C = pin ? 0. : abc[128 * M + r * 64 + ch], B = pin ? 1. : abc[64 * M + r * 64 + ch] + (k < nz ? lam : 0.);
       al = -A * V[M - 2]; be = B - A * cp[M - 2] - C * Vn; ga = -C * Wn;
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
-        double Rn = __shfl_down(Rb[q], 1, 64);
+        real Rn = __shfl_down(Rb[q], 1, 64);
         if (last) Rn = 0.;
-        const double D = live ? col[q * P + M - 1] : 0.;
+        const real D = live ? col[q * P + M - 1] : 0.;
         de[q] = D - A * rprev[q] - C * Rn;
       }
     }
@@ -875,22 +875,22 @@ __global__ __launch_bounds__(1024 / NV, (M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_g
 #pragma unroll
     for (int h = 1; h < 64; h <<= 1) {
       const bool lo = ch >= h, hi = ch + h < 64;
-      const double rb = rcp_nr(be);
-      const double rbm = __shfl_up(rb, h, 64), rbp = __shfl_down(rb, h, 64);
-      const double k1 = lo ? al * rbm : 0., k2 = hi ? ga * rbp : 0.;
-      const double alm = __shfl_up(al, h, 64), gam = __shfl_up(ga, h, 64), alp = __shfl_down(al, h, 64), gap = __shfl_down(ga, h, 64);
+      const real rb = rcp_nr(be);
+      const real rbm = __shfl_up(rb, h, 64), rbp = __shfl_down(rb, h, 64);
+      const real k1 = lo ? al * rbm : 0., k2 = hi ? ga * rbp : 0.;
+      const real alm = __shfl_up(al, h, 64), gam = __shfl_up(ga, h, 64), alp = __shfl_down(al, h, 64), gap = __shfl_down(ga, h, 64);
       be = be - gam * k1 - alp * k2;
 #pragma unroll
       for (int q = 0; q < NV; ++q) de[q] = de[q] - __shfl_up(de[q], h, 64) * k1 - __shfl_down(de[q], h, 64) * k2;
       al = -alm * k1; ga = -gap * k2;
     }
-    const double rb = rcp_nr(be);
+    const real rb = rcp_nr(be);
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
-      const double s = de[q] * rb;
-      double sp = __shfl_up(s, 1, 64);
+      const real s = de[q] * rb;
+      real sp = __shfl_up(s, 1, 64);
       if (ch == 0) sp = 0.;
-      double xv = rprev[q] - V[M - 2] * sp - cp[M - 2] * s;
+      real xv = rprev[q] - V[M - 2] * sp - cp[M - 2] * s;
       col[q * P + M - 2] = xv;
 #pragma unroll
       for (int r = M - 3; r >= 0; --r) { xv = col[q * P + r] - V[r] * sp - cp[r] * xv; col[q * P + r] = xv; }
@@ -906,15 +906,15 @@ __global__ __launch_bounds__(1024 / NV, (M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_g
   }
 }
 template <int M, int NV>
-static void launch_gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, double lscale, const double *da, const double *db, const double *dc,
-                                double *p, int fixnull, const TileMap &T) {
+static void launch_gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, real lscale, const real *da, const real *db, const real *dc,
+                                real *p, int fixnull, const TileMap &T) {
   constexpr int lds = 16 * (64 * (M + 1) + 4) * 8;
   static bool once = false;
   if (!once) { hipFuncSetAttribute((const void *)k_gaussel_tile<M, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
-  if (!c->d_abct) { if (hipMalloc(&c->d_abct, 2 * 3 * 64 * 16 * sizeof(double)) != hipSuccess) { c->d_abct = nullptr; return; } }
+  if (!c->d_abct) { if (hipMalloc(&c->d_abct, 2 * 3 * 64 * 16 * sizeof(real)) != hipSuccess) { c->d_abct = nullptr; return; } }
   // the pressure operands never change: their table is built once (Helmholtz operands are rescaled every substep -> second table)
   const bool pressure = da == c->d_a;
-  double *tab = c->d_abct + (pressure ? 0 : 3 * 64 * 16);
+  real *tab = c->d_abct + (pressure ? 0 : 3 * 64 * 16);
   if (!pressure || !c->abct_ready) hipLaunchKernelGGL(k_abc_chunked, dim3((64 * M + 255) / 256), dim3(256), 0, c->stream, nz, M, da, db, dc, tab);
   if (pressure) c->abct_ready = true;
   hipLaunchKernelGGL((k_gaussel_tile<M, NV>), dim3((ndbl + 15) / 16, nrow), dim3(1024 / NV), lds, c->stream, c->g, nz, ndbl, lscale, tab,
@@ -922,8 +922,8 @@ static void launch_gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, double
 }
 // one rank: ndbl doubles of each of the nrow rows; several ranks (T.blocked): nrow = peers, ndbl = 2 cw n2l doubles per plane of a peer block
 template <int NV>
-static bool gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, double lscale, const double *da, const double *db, const double *dc,
-                         double *p, int fixnull, const TileMap &T) {
+static bool gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, real lscale, const real *da, const real *db, const real *dc,
+                         real *p, int fixnull, const TileMap &T) {
   if (nz < 2 || nz > 1024 || c->fl.gaussel_march) return false;
   if (nz <= 128) launch_gaussel_tile<2, NV>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T);
   else if (nz <= 256) launch_gaussel_tile<4, NV>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T);
@@ -937,34 +937,38 @@ static bool gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, double lscale
 // N-ky are separated, A = (Z_ky + conj Z_{N-ky})/2, B = (Z_ky - conj Z_{N-ky})/(2i), the four real systems (Re/Im of A and B) go to
 // four neighbouring lanes, and the rows are rebuilt as Z_ky = a + i b, Z_{N-ky} = conj(a) + i conj(b). In place: every lane keeps
 // its intermediate values in one of the four slots (Re/Im of the two rows) and finally overwrites that slot.
-template <int CTRL> __device__ inline double quad_bcast(double v) {
+template <int CTRL> __device__ inline real quad_bcast(real v) {
+#ifdef CALES_SINGLE
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+#else
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
+#endif
 }
-__global__ __launch_bounds__(256) void k_gaussel_herm(Geom g, int nz, int ncol, int N, int mofs, int nmode, Spec S, double lscale,
-                                                      const double *__restrict__ a, const double *__restrict__ b,
-                                                      const double *__restrict__ c, const double *__restrict__ lamx,
-                                                      const double *__restrict__ lamy, double *__restrict__ p, double *__restrict__ dscr, int fixnull) {
+__global__ __launch_bounds__(256) void k_gaussel_herm(Geom g, int nz, int ncol, int N, int mofs, int nmode, Spec S, real lscale,
+                                                      const real *__restrict__ a, const real *__restrict__ b,
+                                                      const real *__restrict__ c, const real *__restrict__ lamx,
+                                                      const real *__restrict__ lamy, real *__restrict__ p, real *__restrict__ dscr, int fixnull) {
   const long q = (long)blockIdx.x * 256 + threadIdx.x;
   const int t = (int)(q % (4 * ncol)), m = t >> 2, role = t & 3, ky = (int)(q / (4 * ncol));     // role: Re a, Im a, Re b, Im b
   const bool live = ky <= N / 2 && m + mofs < nmode;
   const int kn = (N - ky) % N; const bool self = kn == ky;
-  // double offsets of plane 1: components of rows ky+1 and kn+1 (at_mode rows are 1-based)
+  // real offsets of plane 1: components of rows ky+1 and kn+1 (at_mode rows are 1-based)
   const size_t ek = live ? 2 * S.at_mode(g, m, ky + 1, 1) : 0, en = live ? 2 * S.at_mode(g, m, kn + 1, 1) : 0;
   const size_t st = 2 * (S.blocked ? (size_t)S.cw * S.n2l : (size_t)g.s12 / 2);
   const size_t s0 = (size_t)t + (size_t)4 * ncol * (size_t)ky, sst = (size_t)4 * ncol * (N / 2 + 1);
-  const double lam = live ? (lamx[2 * (m + mofs) + (role >> 1)] + lamy[ky]) * lscale : 1.;      // lscale: alpha of a Helmholtz solve (lambdaxy*alpha, main.f90:438)
+  const real lam = live ? (lamx[2 * (m + mofs) + (role >> 1)] + lamy[ky]) * lscale : 1.;      // lscale: alpha of a Helmholtz solve (lambdaxy*alpha, main.f90:438)
   // my slot: role 0 -> Re row ky, 1 -> Im row ky, 2 -> Re row kn, 3 -> Im row kn; self-conjugate rows: role 2 -> Im row ky, roles 1,3 idle
   const bool active = live && !(self && (role & 1));
   const size_t slot = self ? (role == 0 ? ek : ek + 1) : (role == 0 ? ek : role == 1 ? ek + 1 : role == 2 ? en : en + 1);
-  auto rhs = [&](int l) -> double {
+  auto rhs = [&](int l) -> real {
     if (!live) return 0.;
-    const double zrk = p[ek + l * st], zik = p[ek + 1 + l * st], zrn = p[en + l * st], zin = p[en + 1 + l * st];
+    const real zrk = p[ek + l * st], zik = p[ek + 1 + l * st], zrn = p[en + l * st], zin = p[en + 1 + l * st];
     return role == 0 ? 0.5 * (zrk + zrn) : role == 1 ? 0.5 * (zik - zin) : role == 2 ? 0.5 * (zik + zin) : 0.5 * (zrn - zrk);
   };
-  double z = 1. / (b[0] + lam + CALES_EPS), d = c[0] * z;
-  double v = rhs(0) * z;
+  real z = 1. / (b[0] + lam + CALES_EPS), d = c[0] * z;
+  real v = rhs(0) * z;
   if (active) { p[slot] = v; dscr[s0] = d; }
   for (int l = 1; l < nz; ++l) {
     z = 1. / ((b[l] + lam) - a[l] * d + CALES_EPS);
@@ -977,41 +981,41 @@ __global__ __launch_bounds__(256) void k_gaussel_herm(Geom g, int nz, int ncol, 
   for (int l = nz - 1; l >= 0; --l) {
     if (l < nz - 1) v = active ? p[slot + l * st] - dscr[s0 + l * sst] * v : 0.;
     else if (!active) v = 0.;
-    const double ra = quad_bcast<0x00>(v), ia = quad_bcast<0x55>(v), rb = quad_bcast<0xAA>(v), ib = quad_bcast<0xFF>(v);
-    const double out = self ? (role == 0 ? ra : rb) : (role == 0 ? ra - ib : role == 1 ? ia + rb : role == 2 ? ra + ib : rb - ia);
+    const real ra = quad_bcast<0x00>(v), ia = quad_bcast<0x55>(v), rb = quad_bcast<0xAA>(v), ib = quad_bcast<0xFF>(v);
+    const real out = self ? (role == 0 ? ra : rb) : (role == 0 ? ra - ib : role == 1 ? ia + rb : role == 2 ? ra + ib : rb - ia);
     if (active) p[slot + l * st] = out;
   }
 }
 
 template <typename VT, int PERIODIC>
-__global__ __launch_bounds__(256) void k_gaussel(Geom g, int nz, int ncol, int nrow, int i0, int mofs, int nmode, Spec S, double lscale,
-                                                 const double *__restrict__ a, const double *__restrict__ b,
-                                                 const double *__restrict__ c, const double *__restrict__ lamx,
-                                                 const double *__restrict__ lamy, double *__restrict__ pd, double *__restrict__ dscr,
-                                                 double *__restrict__ p2scr, int fixnull) {
+__global__ __launch_bounds__(256) void k_gaussel(Geom g, int nz, int ncol, int nrow, int i0, int mofs, int nmode, Spec S, real lscale,
+                                                 const real *__restrict__ a, const real *__restrict__ b,
+                                                 const real *__restrict__ c, const real *__restrict__ lamx,
+                                                 const real *__restrict__ lamy, real *__restrict__ pd, real *__restrict__ dscr,
+                                                 real *__restrict__ p2scr, int fixnull) {
   const int m = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y + 1;
   if (m >= ncol || j > nrow || m + mofs >= nmode) return;
-  constexpr int W = sizeof(VT) / sizeof(double);
+  constexpr int W = sizeof(VT) / sizeof(real);
   VT *p = reinterpret_cast<VT *>(pd);
   const size_t e0 = W == 2 ? S.at_mode(g, m, j, 1) : g.ix(m + i0, j, 1);    // element index of k=1 in units of VT
   const size_t st = W == 2 ? (S.blocked ? (size_t)S.cw * S.n2l : (size_t)g.s12 / 2) : (size_t)g.s12;
   const size_t s0 = (size_t)m + (size_t)ncol * (size_t)(j - 1), sst = (size_t)ncol * nrow;   // scratch [k][j][m]
-  const double lam = ((lamx ? lamx[m + mofs] : 0.) + (lamy ? lamy[j - 1] : 0.)) * lscale;
+  const real lam = ((lamx ? lamx[m + mofs] : 0.) + (lamy ? lamy[j - 1] : 0.)) * lscale;
   const int n = PERIODIC ? nz - 1 : nz;
   // forward elimination
-  double z = 1. / (b[0] + lam + CALES_EPS), d = c[0] * z;
+  real z = 1. / (b[0] + lam + CALES_EPS), d = c[0] * z;
   VT v = vmul(p[e0], z);
   p[e0] = v; dscr[s0] = d;
-  double v2 = 0.;
+  real v2 = 0.;
   if (PERIODIC) { v2 = (n == 1 ? -c[0] : -a[0]) * z; p2scr[s0] = v2; }
   for (int l = 1; l < n; ++l) {
-    const double bb = b[l] + lam;
+    const real bb = b[l] + lam;
     z = 1. / (bb - a[l] * d + CALES_EPS);
     d = c[l] * z;
     v = vmul(vfms(p[e0 + l * st], a[l], v), z);
     if (!PERIODIC && l == n - 1 && fixnull && lam == 0.) v = vmul(v, 0.);      // null mode: see k_gaussel_ri
     p[e0 + l * st] = v; dscr[s0 + l * sst] = d;
-    if (PERIODIC) { const double r2 = (l == n - 1) ? -c[n - 1] : 0.; v2 = (r2 - a[l] * v2) * z; p2scr[s0 + l * sst] = v2; }
+    if (PERIODIC) { const real r2 = (l == n - 1) ? -c[n - 1] : 0.; v2 = (r2 - a[l] * v2) * z; p2scr[s0 + l * sst] = v2; }
   }
   // back substitution
   for (int l = n - 2; l >= 0; --l) {
@@ -1021,8 +1025,8 @@ __global__ __launch_bounds__(256) void k_gaussel(Geom g, int nz, int ncol, int n
   }
   if (PERIODIC) {   // solver.f90:124-133
     const VT p11 = p[e0], p1n = p[e0 + (size_t)(n - 1) * st];
-    const double p21 = p2scr[s0], p2n = p2scr[s0 + (size_t)(n - 1) * sst];
-    const double den = (b[nz - 1] + lam) + c[nz - 1] * p21 + a[nz - 1] * p2n + CALES_EPS;
+    const real p21 = p2scr[s0], p2n = p2scr[s0 + (size_t)(n - 1) * sst];
+    const real den = (b[nz - 1] + lam) + c[nz - 1] * p21 + a[nz - 1] * p2n + CALES_EPS;
     VT pn = vfms(vfms(p[e0 + (size_t)(nz - 1) * st], c[nz - 1], p11), a[nz - 1], p1n);
     pn = vmul(pn, (fixnull && lam == 0.) ? 0. : 1. / den);      // null mode of the triply periodic problem: p(n) = 0
     p[e0 + (size_t)(nz - 1) * st] = pn;
@@ -1032,7 +1036,7 @@ __global__ __launch_bounds__(256) void k_gaussel(Geom g, int nz, int ncol, int n
 
 // ------------------------------------------------------------------------------------------ host side
 struct SolverPlans { FftPlan py4; int CBy4; size_t shy4; FftPlan px, py; int Rx, CBy; size_t shx, shy; bool x8, y8; int x8_threads, y8_threads; size_t shx8, shy8; };
-struct VelSet { bool ready = false; int xkind = 0, ykind = 0; double *lamx = nullptr, *lamy = nullptr; double normfft = 1.; FftPlan p1x, p1y; double *tw1x = nullptr, *tw1y = nullptr; };
+struct VelSet { bool ready = false; int xkind = 0, ykind = 0; real *lamx = nullptr, *lamy = nullptr; real normfft = 1.; FftPlan p1x, p1y; real *tw1x = nullptr, *tw1y = nullptr; };
 struct PlanSlot { cales_ctx *ctx; SolverPlans sp; VelSet vs[3]; };
 // one entry per context; a list (stable addresses) behind a mutex: contexts are created and destroyed from several host threads in the
 // loopback tests while others hold pointers to their own entry
@@ -1081,16 +1085,16 @@ int solver_setup(cales_ctx *c) {
     while (sp.shy4 > 60 * 1024 && sp.CBy4 > 1) { sp.CBy4 /= 2; sp.shy4 = (size_t)2 * sp.CBy4 * 2 * (n2g / 2 + 1) * sizeof(cpx); }
     if (sp.shy4 > 64 * 1024) { c->err = "solver: y line too long for the LDS-resident DCT-IV"; return 1; }
     sp.y8 = false;
-    std::vector<double> t(4 * (size_t)(n2g / 2)); const double pi = std::acos(-1.0); const int nh2 = n2g / 2;
-    for (int q = 0; q < nh2; ++q) { const double a1 = -pi * (4. * q + 1.) / (4. * n2g), a2 = -pi * q / (double)n2g;
+    std::vector<real> t(4 * (size_t)(n2g / 2)); const real pi = std::acos(-1.0); const int nh2 = n2g / 2;
+    for (int q = 0; q < nh2; ++q) { const real a1 = -pi * (4. * q + 1.) / (4. * n2g), a2 = -pi * q / (real)n2g;
                                     t[2 * q] = std::cos(a1); t[2 * q + 1] = std::sin(a1); t[2 * (nh2 + q)] = std::cos(a2); t[2 * (nh2 + q) + 1] = std::sin(a2); }
-    HIPCHK(c, hipMalloc(&c->d_tw4y, t.size() * sizeof(double)));
-    HIPCHK(c, hipMemcpy(c->d_tw4y, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&c->d_tw4y, t.size() * sizeof(real)));
+    HIPCHK(c, hipMemcpy(c->d_tw4y, t.data(), t.size() * sizeof(real), hipMemcpyHostToDevice));
   }
   if (c->ykind == 2) sp.y8 = false;      // the sign changes of the Dirichlet-Dirichlet transform live in the generic y kernel only
   if (c->fl.fft_generic) sp.x8 = sp.y8 = false;
   // eigenvalues (initsolver.f90:66-98); x: modes 0..n1/2 (half-complex symmetry), y: modes 0..n2-1
-  std::vector<double> lx(n1 + 2, 0.), ly(n2g);
+  std::vector<real> lx(n1 + 2, 0.), ly(n2g);
   hs_eigenvalues(n1, bx.c_str(), 'c', lx.data()); hs_eigenvalues(n2g, by.c_str(), 'c', ly.data());
   for (auto &v : lx) v = v * (c->dli[0] * c->dli[0]);
   for (auto &v : ly) v = v * (c->dli[1] * c->dli[1]);
@@ -1098,24 +1102,24 @@ int solver_setup(cales_ctx *c) {
   const int mh = n1 / 2 + 1;
   c->cw = (mh + c->P - 1) / c->P;                            // complex mode columns per rank (last block padded)
   if (c->P > 1 && (size_t)c->cw * n2g * n3 > c->ntot) { c->err = "solver: scratch too small for the mode-block layout"; return 1; }
-  HIPCHK(c, hipMalloc(&c->d_lamx, (n1 + 2) * sizeof(double))); HIPCHK(c, hipMalloc(&c->d_lamy, n2g * sizeof(double)));
-  HIPCHK(c, hipMemcpy(c->d_lamx, lx.data(), (n1 + 2) * sizeof(double), hipMemcpyHostToDevice));
-  HIPCHK(c, hipMemcpy(c->d_lamy, ly.data(), n2g * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMalloc(&c->d_lamx, (n1 + 2) * sizeof(real))); HIPCHK(c, hipMalloc(&c->d_lamy, n2g * sizeof(real)));
+  HIPCHK(c, hipMemcpy(c->d_lamx, lx.data(), (n1 + 2) * sizeof(real), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_lamy, ly.data(), n2g * sizeof(real), hipMemcpyHostToDevice));
   // tridiagonal (initsolver.f90:127-169), pressure: cell-centred
-  std::vector<double> a(n3), b(n3), cc(n3);
+  std::vector<real> a(n3), b(n3), cc(n3);
   hs_tridmatrix(&c->C.cbcpre[4], n3, c->dzci.data(), c->dzfi.data(), 'c', a.data(), b.data(), cc.data());
-  HIPCHK(c, hipMalloc(&c->d_a, n3 * sizeof(double))); HIPCHK(c, hipMalloc(&c->d_b, n3 * sizeof(double))); HIPCHK(c, hipMalloc(&c->d_c, n3 * sizeof(double)));
-  HIPCHK(c, hipMemcpy(c->d_a, a.data(), n3 * sizeof(double), hipMemcpyHostToDevice));
-  HIPCHK(c, hipMemcpy(c->d_b, b.data(), n3 * sizeof(double), hipMemcpyHostToDevice));
-  HIPCHK(c, hipMemcpy(c->d_c, cc.data(), n3 * sizeof(double), hipMemcpyHostToDevice));
-  c->normfft = 1. / ((c->xkind ? 2. : 1.) * (double)n1 * (c->ykind ? 2. : 1.) * (double)n2g);   // fft.f90:99,136,142; find_fft norm = [1,0] (PP) / [2,0] (NN)
+  HIPCHK(c, hipMalloc(&c->d_a, n3 * sizeof(real))); HIPCHK(c, hipMalloc(&c->d_b, n3 * sizeof(real))); HIPCHK(c, hipMalloc(&c->d_c, n3 * sizeof(real)));
+  HIPCHK(c, hipMemcpy(c->d_a, a.data(), n3 * sizeof(real), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_b, b.data(), n3 * sizeof(real), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_c, cc.data(), n3 * sizeof(real), hipMemcpyHostToDevice));
+  c->normfft = 1. / ((c->xkind ? 2. : 1.) * (real)n1 * (c->ykind ? 2. : 1.) * (real)n2g);   // fft.f90:99,136,142; find_fft norm = [1,0] (PP) / [2,0] (NN)
   // twiddles: exp(-2 pi i q/N)
-  auto mk = [&](int N, int cnt, double **dev) -> int {
-    std::vector<double> t(2 * (size_t)cnt);
-    const double pi = std::acos(-1.0);
-    for (int q = 0; q < cnt; ++q) { const double ang = -2. * pi * q / N; t[2 * q] = std::cos(ang); t[2 * q + 1] = std::sin(ang); }
-    HIPCHK(c, hipMalloc(dev, t.size() * sizeof(double)));
-    HIPCHK(c, hipMemcpy(*dev, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+  auto mk = [&](int N, int cnt, real **dev) -> int {
+    std::vector<real> t(2 * (size_t)cnt);
+    const real pi = std::acos(-1.0);
+    for (int q = 0; q < cnt; ++q) { const real ang = -2. * pi * q / N; t[2 * q] = std::cos(ang); t[2 * q + 1] = std::sin(ang); }
+    HIPCHK(c, hipMalloc(dev, t.size() * sizeof(real)));
+    HIPCHK(c, hipMemcpy(*dev, t.data(), t.size() * sizeof(real), hipMemcpyHostToDevice));
     return 0;
   };
   if (mk(n1 / 2, n1 / 2, &c->d_twx)) return 1;
@@ -1125,20 +1129,20 @@ int solver_setup(cales_ctx *c) {
   if (mk(4 * n2g, n2g, &c->scr_twyd)) return 1;              // e^{-i pi k/(2 n2)}, k = 0..n2-1 (y)
   if (c->ykind >= 3) { if (mk(n2g / 2, n2g / 2, &c->d_twy4)) return 1; }      // N/2-point lines of k_fft_y4
   if (c->xkind >= 3) {            // DCT-IV weights (k_fft_x4)
-    const int nh = n1 / 2; std::vector<double> t(4 * (size_t)nh); const double pi = std::acos(-1.0);
-    for (int q = 0; q < nh; ++q) { const double a1 = -pi * (4. * q + 1.) / (4. * n1), a2 = -pi * q / (double)n1;
+    const int nh = n1 / 2; std::vector<real> t(4 * (size_t)nh); const real pi = std::acos(-1.0);
+    for (int q = 0; q < nh; ++q) { const real a1 = -pi * (4. * q + 1.) / (4. * n1), a2 = -pi * q / (real)n1;
                                    t[2 * q] = std::cos(a1); t[2 * q + 1] = std::sin(a1); t[2 * (nh + q)] = std::cos(a2); t[2 * (nh + q) + 1] = std::sin(a2); }
-    HIPCHK(c, hipMalloc(&c->d_tw4x, t.size() * sizeof(double)));
-    HIPCHK(c, hipMemcpy(c->d_tw4x, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&c->d_tw4x, t.size() * sizeof(real)));
+    HIPCHK(c, hipMemcpy(c->d_tw4x, t.data(), t.size() * sizeof(real), hipMemcpyHostToDevice));
   }
   if (c->C.impdiff)
     for (int iv = 0; iv < 3; ++iv) {
       hs_tridmatrix(&c->cbcvel[6 * iv + 4], n3, c->dzci.data(), c->dzfi.data(), iv == 2 ? 'f' : 'c', a.data(), b.data(), cc.data());
-      HIPCHK(c, hipMalloc(&c->d_av[iv], 3 * n3 * sizeof(double)));   // a | b | c (unscaled); scaled copies follow
+      HIPCHK(c, hipMalloc(&c->d_av[iv], 3 * n3 * sizeof(real)));   // a | b | c (unscaled); scaled copies follow
       c->d_bv[iv] = c->d_av[iv] + n3; c->d_cv[iv] = c->d_av[iv] + 2 * n3;
-      HIPCHK(c, hipMemcpy(c->d_av[iv], a.data(), n3 * sizeof(double), hipMemcpyHostToDevice));
-      HIPCHK(c, hipMemcpy(c->d_bv[iv], b.data(), n3 * sizeof(double), hipMemcpyHostToDevice));
-      HIPCHK(c, hipMemcpy(c->d_cv[iv], cc.data(), n3 * sizeof(double), hipMemcpyHostToDevice));
+      HIPCHK(c, hipMemcpy(c->d_av[iv], a.data(), n3 * sizeof(real), hipMemcpyHostToDevice));
+      HIPCHK(c, hipMemcpy(c->d_bv[iv], b.data(), n3 * sizeof(real), hipMemcpyHostToDevice));
+      HIPCHK(c, hipMemcpy(c->d_cv[iv], cc.data(), n3 * sizeof(real), hipMemcpyHostToDevice));
     }
   { PlanSlot ps_; ps_.ctx = c; ps_.sp = sp; std::lock_guard<std::mutex> lk(g_slots_mx); g_slots.push_back(ps_); }
   return 0;
@@ -1155,7 +1159,7 @@ void solver_teardown(cales_ctx *c) {
 
 // FFT x, FFT y, tridiagonal z, and back, in place on `pp`; (da,db,dc,nz,lscale) = (a,b,c,n3,1) for the pressure Poisson equation,
 // (alpha a, alpha b + 1, alpha c, n3 - q, alpha) for the Helmholtz equation of a velocity component (main.f90:435-445)
-static int solve_field(cales_ctx *c, double *pp, const double *da, const double *db, const double *dc, int nz, double lscale, bool periodic_z, bool poisson) {
+static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, const real *dc, int nz, real lscale, bool periodic_z, bool poisson) {
   SolverPlans *sp = find_plans(c);
   if (!sp) { c->err = "solver not initialised"; return 1; }
   const int *n = c->n;
@@ -1167,8 +1171,8 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
   const VelSet *VS = static_cast<const VelSet *>(c->cur_velset);      // transform set of the velocity component being solved (nullptr: the pressure's)
   if (dist && !c->comm.on) { c->err = "solver: nranks > 1 but no communication hooks registered (cales_set_comm)"; return 1; }
   Spec S; S.blocked = dist ? 1 : 0; S.cw = c->cw; S.n2l = n[1]; S.n3 = n[2];
-  double2 *slab_spec = dist ? reinterpret_cast<double2 *>(c->comm.A) : reinterpret_cast<double2 *>(pp + 1);   // in place: modes of row (j,k) from i = 1
-  double2 *mode_spec = dist ? reinterpret_cast<double2 *>(c->comm.B) : reinterpret_cast<double2 *>(pp + 1);
+  real2 *slab_spec = dist ? reinterpret_cast<real2 *>(c->comm.A) : reinterpret_cast<real2 *>(pp + 1);   // in place: modes of row (j,k) from i = 1
+  real2 *mode_spec = dist ? reinterpret_cast<real2 *>(c->comm.B) : reinterpret_cast<real2 *>(pp + 1);
   const int ncol = dist ? c->cw : mh, mofs = dist ? c->rank * c->cw : 0;
   const int64_t a2a_count = (int64_t)n[2] * n[1] * c->cw * 2;
   const int nh = c->C.ng[0] / 2;
@@ -1194,7 +1198,7 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
   hipEvent_t ev_arrived[4];
   // the bulk means summed by the fused fillps pass: several ranks all-reduce them on the context's stream, and RCCL orders the operations of
   // one communicator across streams -- issued between the chunk exchanges it would hold the y transforms back, so it follows the z sweep
-  int pend_mean_mask = 0, pend_mean_nblk = 0; const double *pend_mean_part = nullptr;
+  int pend_mean_mask = 0, pend_mean_nblk = 0; const real *pend_mean_part = nullptr;
   auto mark = [&](hipStream_t st, hipEvent_t &e) -> int {
     if (c->sync_ev.size() < 64) { hipEvent_t ne; HIPCHK(c, hipEventCreateWithFlags(&ne, hipEventDisableTiming)); c->sync_ev.push_back(ne); c->sync_next = c->sync_ev.size() - 1; }
     e = c->sync_ev[c->sync_next]; c->sync_next = (c->sync_next + 1) % c->sync_ev.size();
@@ -1208,11 +1212,11 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
     const bool fill = poisson && c->fuse_fillps_dti != 0. && sp->x8;
     FillArgs F{};
     if (fill) {
-      const double dti = c->fuse_fillps_dti;
+      const real dti = c->fuse_fillps_dti;
       F = FillArgs{c->f[CALES_U], c->f[CALES_V], c->f[CALES_W], c->d_dzfi, dti, dti * c->dli[0], dti * c->dli[1], c->fuse_mean_mask, c->d_gvr_f, c->d_gvr_c, nullptr};
       if (F.mean_mask) {
         const size_t need = 3 * (size_t)xblocks_c * NCH;
-        if (c->n_mpart < need) { if (c->d_mpart) hipFree(c->d_mpart); HIPCHK(c, hipMalloc(&c->d_mpart, need * sizeof(double))); c->n_mpart = need; }
+        if (c->n_mpart < need) { if (c->d_mpart) hipFree(c->d_mpart); HIPCHK(c, hipMalloc(&c->d_mpart, need * sizeof(real))); c->n_mpart = need; }
         F.part = c->d_mpart; F.pstride = (int)(xblocks_c * NCH);
       }
     }
@@ -1237,10 +1241,10 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
   } else {
   if (poisson && c->fuse_fillps_dti != 0. && sp->x8) {
     ProfScope ps(c, "fillps_fft_x_fwd");
-    const double dti = c->fuse_fillps_dti;
+    const real dti = c->fuse_fillps_dti;
     FillArgs F{c->f[CALES_U], c->f[CALES_V], c->f[CALES_W], c->d_dzfi, dti, dti * c->dli[0], dti * c->dli[1], c->fuse_mean_mask, c->d_gvr_f, c->d_gvr_c, nullptr};
     if (F.mean_mask) {
-      if (c->n_mpart < 3 * (size_t)xblocks) { if (c->d_mpart) hipFree(c->d_mpart); HIPCHK(c, hipMalloc(&c->d_mpart, 3 * (size_t)xblocks * sizeof(double))); c->n_mpart = 3 * (size_t)xblocks; }
+      if (c->n_mpart < 3 * (size_t)xblocks) { if (c->d_mpart) hipFree(c->d_mpart); HIPCHK(c, hipMalloc(&c->d_mpart, 3 * (size_t)xblocks * sizeof(real))); c->n_mpart = 3 * (size_t)xblocks; }
       F.part = c->d_mpart;
     }
     if (c->xkind) hipLaunchKernelGGL((k_fft_x8<0, 1, 1>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
@@ -1275,25 +1279,25 @@ static int solve_field(cales_ctx *c, double *pp, const double *da, const double 
     dim3 b(64, 4), gr((ncol + 63) / 64, (n2g + 3) / 4);
     if (c->xkind && !c->ykind)       // real x modes paired into complex columns + periodic y: Hermitian separation of rows ky and N-ky
       hipLaunchKernelGGL(k_gaussel_herm, dim3((unsigned)(((long)4 * ncol * (n2g / 2 + 1) + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, lscale,
-                         da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, fixnull);
+                         da, db, dc, c->d_lamx, c->d_lamy, (real *)mode_spec, c->scr1, fixnull);
     else if (!periodic_z && !c->fl.gaussel_pair && (fixnull || !poisson || CBP(c, 0, 3) == 'D' || CBP(c, 1, 3) == 'D') &&
              [&]() {
                TileMap T{}; T.blocked = dist ? 1 : 0; T.cw = c->cw; T.n2l = n[1]; T.mofs = mofs; T.nmode = c->xkind ? c->C.ng[0] / 2 : mh;
                T.kstride = (size_t)2 * c->cw * n[1]; T.segstride = T.kstride * n[2];
                const int ndbl = dist ? 2 * c->cw * n[1] : (c->xkind ? 2 * (c->C.ng[0] / 2) : 2 * mh), nseg = dist ? c->P : n2g;
-               return c->xkind ? gaussel_tile<1>(c, nz, ndbl, nseg, lscale, da, db, dc, (double *)mode_spec, fixnull, T)
-                               : gaussel_tile<2>(c, nz, ndbl, nseg, lscale, da, db, dc, (double *)mode_spec, fixnull, T); }()) {}
+               return c->xkind ? gaussel_tile<1>(c, nz, ndbl, nseg, lscale, da, db, dc, (real *)mode_spec, fixnull, T)
+                               : gaussel_tile<2>(c, nz, ndbl, nseg, lscale, da, db, dc, (real *)mode_spec, fixnull, T); }()) {}
     else if (c->xkind && !periodic_z && !c->fl.gaussel_pair)
       hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, lscale, da, db, dc,
-                         c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, fixnull, 1);
+                         c->d_lamx, c->d_lamy, (real *)mode_spec, c->scr1, fixnull, 1);
     else if (periodic_z && c->xkind)      // real x modes (one eigenvalue each) with the periodic-z closure: scalar columns of the in-place spectrum, one rank
-      hipLaunchKernelGGL((k_gaussel<double, 1>), dim3((2 * (c->C.ng[0] / 2) + 63) / 64, (n2g + 3) / 4), b, 0, c->stream, c->g, nz, 2 * (c->C.ng[0] / 2), n2g, 1, 0, 2 * (c->C.ng[0] / 2), S, lscale,
+      hipLaunchKernelGGL((k_gaussel<real, 1>), dim3((2 * (c->C.ng[0] / 2) + 63) / 64, (n2g + 3) / 4), b, 0, c->stream, c->g, nz, 2 * (c->C.ng[0] / 2), n2g, 1, 0, 2 * (c->C.ng[0] / 2), S, lscale,
                          da, db, dc, c->d_lamx, c->d_lamy, pp, c->scr1, c->scr2, fixnull);
     else if (c->xkind) hipLaunchKernelGGL(k_gaussel_split, gr, b, 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, lscale, da, db, dc, c->d_lamx, c->d_lamy,
-                                     (double2 *)mode_spec, (double2 *)c->scr1, fixnull);
-    else if (periodic_z) hipLaunchKernelGGL((k_gaussel<double2, 1>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2, fixnull);
-    else if (c->fl.gaussel_pair) hipLaunchKernelGGL((k_gaussel<double2, 0>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, c->scr2, fixnull);
-    else hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (double *)mode_spec, c->scr1, fixnull, 0); }
+                                     (real2 *)mode_spec, (real2 *)c->scr1, fixnull);
+    else if (periodic_z) hipLaunchKernelGGL((k_gaussel<real2, 1>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (real *)mode_spec, c->scr1, c->scr2, fixnull);
+    else if (c->fl.gaussel_pair) hipLaunchKernelGGL((k_gaussel<real2, 0>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (real *)mode_spec, c->scr1, c->scr2, fixnull);
+    else hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (real *)mode_spec, c->scr1, fixnull, 0); }
   if (pend_mean_mask) if (int e = op_force_from_partials(c, pend_mean_mask, pend_mean_part, pend_mean_nblk)) return e;
   if (pipe) {
     for (int ch = 0; ch < NCH; ++ch) {
@@ -1343,19 +1347,19 @@ int op_solver(cales_ctx *c) {
 // z-only Helmholtz systems have the same matrix for every column (no eigenvalue shift): the pivots z_l and c'_l of the
 // Thomas recurrence (solver.f90:160-178, same operations in the same order) are computed once by one thread, and the
 // sweeps of the field read them instead of dividing and of storing a c' per cell.
-__global__ void k_thomas_coef(int n, const double *__restrict__ a, const double *__restrict__ b, const double *__restrict__ c,
-                              double *__restrict__ zz, double *__restrict__ dd) {
+__global__ void k_thomas_coef(int n, const real *__restrict__ a, const real *__restrict__ b, const real *__restrict__ c,
+                              real *__restrict__ zz, real *__restrict__ dd) {
   if (threadIdx.x || blockIdx.x) return;
-  double z = 1. / (b[0] + CALES_EPS), d = c[0] * z;
+  real z = 1. / (b[0] + CALES_EPS), d = c[0] * z;
   zz[0] = z; dd[0] = d;
   for (int l = 1; l < n; ++l) { z = 1. / (b[l] - a[l] * d + CALES_EPS); d = c[l] * z; zz[l] = z; dd[l] = d; }
 }
-__global__ __launch_bounds__(256) void k_gaussel_cols(Geom g, int nz, const double *__restrict__ a, const double *__restrict__ zz,
-                                                      const double *__restrict__ dd, double *__restrict__ p) {
+__global__ __launch_bounds__(256) void k_gaussel_cols(Geom g, int nz, const real *__restrict__ a, const real *__restrict__ zz,
+                                                      const real *__restrict__ dd, real *__restrict__ p) {
   const int i = blockIdx.x * 64 + threadIdx.x + 1, j = blockIdx.y * 4 + threadIdx.y + 1;
   if (i > g.n1 || j > g.n2) return;
   const size_t e0 = g.ix(i, j, 1), st = (size_t)g.s12;
-  double v = p[e0] * zz[0];
+  real v = p[e0] * zz[0];
   p[e0] = v;
   for (int l = 1; l < nz; ++l) { v = (p[e0 + l * st] - a[l] * v) * zz[l]; p[e0 + l * st] = v; }
   for (int l = nz - 2; l >= 0; --l) { v = p[e0 + l * st] - dd[l] * v; p[e0 + l * st] = v; }
@@ -1364,22 +1368,22 @@ __global__ __launch_bounds__(256) void k_gaussel_cols(Geom g, int nz, const doub
 // The same sweeps for the z-implicit time step (cales_step): the r.h.s. of rk.f90:108-118 and main.f90:422-433 is formed on
 // the fly in the reference's order -- (u - hf12*dudtd) + f + rhs_b -- so the separate passes over u (9 + 2 words) disappear.
 // nq = nz or nz+1: plane nz+1 (the wall face of w) is not an unknown but still receives the first two terms.
-__global__ __launch_bounds__(256) void k_gaussel_cols_rhs(Geom g, int nz, int nq, const double *__restrict__ a, const double *__restrict__ zz,
-                                                          const double *__restrict__ dd, double *__restrict__ p, const double *__restrict__ dud,
-                                                          double hf12, const double *__restrict__ force, const double *__restrict__ rb, int has_lo,
+__global__ __launch_bounds__(256) void k_gaussel_cols_rhs(Geom g, int nz, int nq, const real *__restrict__ a, const real *__restrict__ zz,
+                                                          const real *__restrict__ dd, real *__restrict__ p, const real *__restrict__ dud,
+                                                          real hf12, const real *__restrict__ force, const real *__restrict__ rb, int has_lo,
                                                           int has_hi) {
   const int i = blockIdx.x * 64 + threadIdx.x + 1, j = blockIdx.y * 4 + threadIdx.y + 1;
   if (i > g.n1 || j > g.n2) return;
   const size_t e0 = g.ix(i, j, 1), st = (size_t)g.s12, pq = (size_t)(i - 1) + (size_t)g.n1 * (j - 1);
-  const bool forced = force != nullptr; const double f = forced ? force[0] : 0.;
+  const bool forced = force != nullptr; const real f = forced ? force[0] : 0.;
   auto rhs = [&](int l) {
-    double t = p[e0 + l * st] - hf12 * dud[e0 + l * st];
+    real t = p[e0 + l * st] - hf12 * dud[e0 + l * st];
     if (forced) t = t + f;
     if (l == 0 && has_lo) t = t + rb[pq];
     if (l == nz - 1 && has_hi) t = t + rb[pq + (size_t)g.n1 * g.n2];
     return t;
   };
-  double v = rhs(0) * zz[0];
+  real v = rhs(0) * zz[0];
   p[e0] = v;
   for (int l = 1; l < nz; ++l) { v = (rhs(l) - a[l] * v) * zz[l]; p[e0 + l * st] = v; }
   if (nq > nz) p[e0 + (size_t)nz * st] = rhs(nz);
@@ -1387,29 +1391,29 @@ __global__ __launch_bounds__(256) void k_gaussel_cols_rhs(Geom g, int nz, int nq
 }
 
 // z-implicit Helmholtz solve of one velocity component (solver.f90:182-233 with aa,bb,cc of main.f90:435-437)
-__global__ void k_scale_abc(int n, double alpha, const double *a, const double *b, const double *c, double *aa, double *bb, double *cc) {
+__global__ void k_scale_abc(int n, real alpha, const real *a, const real *b, const real *c, real *aa, real *bb, real *cc) {
   const int k = blockIdx.x * 64 + threadIdx.x;
   if (k < n) { aa[k] = a[k] * alpha; bb[k] = b[k] * alpha + 1.; cc[k] = c[k] * alpha; }
 }
-int op_rhs_b_velz(cales_ctx *c, int ivel, double alpha, double *planes = nullptr, int *has = nullptr);
-int op_rhs_b_velxy(cales_ctx *c, int ivel, double alpha);
-int op_helmholtz_z(cales_ctx *c, int ivel, double alpha) {
+int op_rhs_b_velz(cales_ctx *c, int ivel, real alpha, real *planes = nullptr, int *has = nullptr);
+int op_rhs_b_velxy(cales_ctx *c, int ivel, real alpha);
+int op_helmholtz_z(cales_ctx *c, int ivel, real alpha) {
   if (c->C.impdiff != 2) { c->err = "helmholtz_z needs impdiff = 2"; return 1; }
   ProfScope ps(c, "helmholtz_z");
   const int *n = c->n; const int n3 = n[2];
   const bool fused = c->defer_imp_rhs;
   int has[2] = {0, 0};
   if (int e = op_rhs_b_velz(c, ivel, alpha, fused ? c->scr2 : nullptr, fused ? has : nullptr)) return e;
-  double *abc = c->d_red + 64 + 16 * (n3 + 2);     // scaled coefficients live behind the reduction partials
+  real *abc = c->d_red + 64 + 16 * (n3 + 2);     // scaled coefficients live behind the reduction partials
   hipLaunchKernelGGL(k_scale_abc, dim3((n3 + 63) / 64), dim3(64), 0, c->stream, n3, alpha, c->d_av[ivel - 1], c->d_bv[ivel - 1], c->d_cv[ivel - 1], abc, abc + n3, abc + 2 * n3);
   const char *bcz = &c->cbcvel[6 * (ivel - 1) + 4];
   const int q = (ivel == 3 && bcz[1] == 'D') ? 1 : 0;
   const bool periodic = bcz[0] == 'P' && bcz[1] == 'P';
   dim3 b(64, 4), gr((n[0] + 63) / 64, (n[1] + 3) / 4);
-  double *fld = c->f[CALES_U + ivel - 1];
+  real *fld = c->f[CALES_U + ivel - 1];
   Spec S; S.blocked = 0; S.cw = 0; S.n2l = n[1]; S.n3 = n3;
-  if (periodic) hipLaunchKernelGGL((k_gaussel<double, 1>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, 1., abc, abc + n3, abc + 2 * n3, (const double *)nullptr, (const double *)nullptr, fld, c->scr1, c->scr2, 0);
-  else if (c->fl.helmholtz_z_per_column) hipLaunchKernelGGL((k_gaussel<double, 0>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, 1., abc, abc + n3, abc + 2 * n3, (const double *)nullptr, (const double *)nullptr, fld, c->scr1, c->scr2, 0);
+  if (periodic) hipLaunchKernelGGL((k_gaussel<real, 1>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, 1., abc, abc + n3, abc + 2 * n3, (const real *)nullptr, (const real *)nullptr, fld, c->scr1, c->scr2, 0);
+  else if (c->fl.helmholtz_z_per_column) hipLaunchKernelGGL((k_gaussel<real, 0>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, 1., abc, abc + n3, abc + 2 * n3, (const real *)nullptr, (const real *)nullptr, fld, c->scr1, c->scr2, 0);
   else if (c->P >= 1 && n3 - q >= 2 && n3 - q <= 512 && n3 <= 64 * (n3 - q <= 128 ? 2 : n3 - q <= 256 ? 4 : 8) && !c->fl.gaussel_march && [&]() {
              // the in-LDS tile of the pressure solve on the real field: u, dudtd in, u out (3 words instead of 5)
              TileMap T{}; T.nolam = 1; T.nq = n3;
@@ -1417,10 +1421,10 @@ int op_helmholtz_z(cales_ctx *c, int ivel, double alpha) {
                           T.rb = c->scr2; T.has_lo = has[0]; T.has_hi = has[1]; }
              return gaussel_tile<2>(c, n3 - q, n[0], n[1], 1., abc, abc + n3, abc + 2 * n3, fld + 1, 0, T); }()) {}
   else {
-    double *zz = abc + 3 * n3, *dd = abc + 4 * n3;       // behind the scaled coefficients (cales_create reserves 6 (n3+2) doubles)
+    real *zz = abc + 3 * n3, *dd = abc + 4 * n3;       // behind the scaled coefficients (cales_create reserves 6 (n3+2) doubles)
     hipLaunchKernelGGL(k_thomas_coef, dim3(1), dim3(64), 0, c->stream, n3 - q, abc, abc + n3, abc + 2 * n3, zz, dd);
     if (fused) hipLaunchKernelGGL(k_gaussel_cols_rhs, gr, b, 0, c->stream, c->g, n3 - q, n3, abc, zz, dd, fld, c->f[CALES_DUDTD + ivel - 1], c->hf12,
-                                  c->C.is_forced[ivel - 1] ? c->d_force + (ivel - 1) : (const double *)nullptr, c->scr2, has[0], has[1]);
+                                  c->C.is_forced[ivel - 1] ? c->d_force + (ivel - 1) : (const real *)nullptr, c->scr2, has[0], has[1]);
     else hipLaunchKernelGGL(k_gaussel_cols, gr, b, 0, c->stream, c->g, n3 - q, abc, zz, dd, fld);
   }
   HIPCHK(c, hipGetLastError());
@@ -1453,23 +1457,23 @@ static int velset_build(cales_ctx *c, SolverPlans &sp, int iv, VelSet &V) {
   if (V.xkind && !V.ykind && c->cbcvel[6 * iv + 4] == 'P') { c->err = "helmholtz: non-periodic x with periodic y and z is not provided"; return 1; }
   if (V.xkind && c->cbcvel[6 * iv + 4] == 'P' && c->P > 1) { c->err = "helmholtz: a non-periodic x with periodic z needs one rank"; return 1; }
   if ((V.ykind == 3 || V.ykind == 4) && (n2g % 2)) { c->err = "helmholtz: ND/DN in y need an even ng(2)"; return 1; }
-  std::vector<double> lx(n1 + 2, 0.), ly(n2g);
+  std::vector<real> lx(n1 + 2, 0.), ly(n2g);
   const std::string bx = std::string(1, bc[0]) + bc[1], by = std::string(1, bc[2]) + bc[3];
   hs_eigenvalues(n1, bx.c_str(), iv == 0 ? 'f' : 'c', lx.data()); hs_eigenvalues(n2g, by.c_str(), iv == 1 ? 'f' : 'c', ly.data());
   for (auto &v : lx) v = v * (c->dli[0] * c->dli[0]);
   for (auto &v : ly) v = v * (c->dli[1] * c->dli[1]);
   if (V.ykind == 2) std::reverse(ly.begin(), ly.end());      // see solver_setup
-  HIPCHK(c, hipMalloc(&V.lamx, (n1 + 2) * sizeof(double))); HIPCHK(c, hipMalloc(&V.lamy, n2g * sizeof(double)));
-  HIPCHK(c, hipMemcpy(V.lamx, lx.data(), (n1 + 2) * sizeof(double), hipMemcpyHostToDevice));
-  HIPCHK(c, hipMemcpy(V.lamy, ly.data(), n2g * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMalloc(&V.lamx, (n1 + 2) * sizeof(real))); HIPCHK(c, hipMalloc(&V.lamy, n2g * sizeof(real)));
+  HIPCHK(c, hipMemcpy(V.lamx, lx.data(), (n1 + 2) * sizeof(real), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(V.lamy, ly.data(), n2g * sizeof(real), hipMemcpyHostToDevice));
   // fft.f90:99,136,142: normfft = prod norm(1) (n + norm(2) - ix): 1 n (PP), 2 n ('c' pairs, 'f' ND/DN), 2 (n + 1 - 1) ('f' DD), 2 (n - 1) ('f' NN)
-  auto nrm = [](int kd, int nn) -> double { return kd == 0 ? (double)nn : kd == 6 ? 2. * (nn - 1) : 2. * nn; };
+  auto nrm = [](int kd, int nn) -> real { return kd == 0 ? (real)nn : kd == 6 ? 2. * (nn - 1) : 2. * nn; };
   V.normfft = 1. / (nrm(V.xkind, n1) * nrm(V.ykind, n2g));
-  auto mk = [&](int N, double **dev) -> int {
-    std::vector<double> t(2 * (size_t)N); const double pi = std::acos(-1.0);
-    for (int q = 0; q < N; ++q) { const double ang = -2. * pi * q / N; t[2 * q] = std::cos(ang); t[2 * q + 1] = std::sin(ang); }
-    HIPCHK(c, hipMalloc(dev, t.size() * sizeof(double)));
-    HIPCHK(c, hipMemcpy(*dev, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+  auto mk = [&](int N, real **dev) -> int {
+    std::vector<real> t(2 * (size_t)N); const real pi = std::acos(-1.0);
+    for (int q = 0; q < N; ++q) { const real ang = -2. * pi * q / N; t[2 * q] = std::cos(ang); t[2 * q + 1] = std::sin(ang); }
+    HIPCHK(c, hipMalloc(dev, t.size() * sizeof(real)));
+    HIPCHK(c, hipMemcpy(*dev, t.data(), t.size() * sizeof(real), hipMemcpyHostToDevice));
     return 0;
   };
   auto next = [](int kd, int nn) { return kd == 5 ? 2 * nn : kd == 6 ? 2 * (nn - 1) : 4 * nn; };      // points of the symmetric extension (k_dst1)
@@ -1479,30 +1483,30 @@ static int velset_build(cales_ctx *c, SolverPlans &sp, int iv, VelSet &V) {
     if (N < 2 || !make_plan(N, V.p1y) || (size_t)2 * (N + 1) * sizeof(cpx) > 150 * 1024) { c->err = "helmholtz: y line not supported by the face-centred transform kernel"; return 1; } if (mk(N, &V.tw1y)) return 1; }
   if (V.xkind >= 5 || V.ykind >= 5) hipFuncSetAttribute((const void *)k_dst1<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), hipFuncSetAttribute((const void *)k_dst1<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), hipFuncSetAttribute((const void *)k_dst1<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
   // the DCT-IV / DST-IV kernels (kinds 3, 4) read tables that solver_setup makes only when the pressure needs them
-  const double pi = std::acos(-1.0);
+  const real pi = std::acos(-1.0);
   if ((V.xkind == 3 || V.xkind == 4) && !c->d_tw4x) {
-    const int nh = n1 / 2; std::vector<double> t(4 * (size_t)nh);
-    for (int q = 0; q < nh; ++q) { const double a1 = -pi * (4. * q + 1.) / (4. * n1), a2 = -pi * q / (double)n1;
+    const int nh = n1 / 2; std::vector<real> t(4 * (size_t)nh);
+    for (int q = 0; q < nh; ++q) { const real a1 = -pi * (4. * q + 1.) / (4. * n1), a2 = -pi * q / (real)n1;
                                    t[2 * q] = std::cos(a1); t[2 * q + 1] = std::sin(a1); t[2 * (nh + q)] = std::cos(a2); t[2 * (nh + q) + 1] = std::sin(a2); }
-    HIPCHK(c, hipMalloc(&c->d_tw4x, t.size() * sizeof(double)));
-    HIPCHK(c, hipMemcpy(c->d_tw4x, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&c->d_tw4x, t.size() * sizeof(real)));
+    HIPCHK(c, hipMemcpy(c->d_tw4x, t.data(), t.size() * sizeof(real), hipMemcpyHostToDevice));
   }
   if ((V.ykind == 3 || V.ykind == 4) && !c->d_tw4y) {
     if (!make_plan(n2g / 2, sp.py4)) { c->err = "helmholtz: ng(2)/2 must factor into primes <= 127"; return 1; }
     sp.CBy4 = 4; sp.shy4 = (size_t)2 * sp.CBy4 * 2 * (n2g / 2 + 1) * sizeof(cpx);
     while (sp.shy4 > 60 * 1024 && sp.CBy4 > 1) { sp.CBy4 /= 2; sp.shy4 = (size_t)2 * sp.CBy4 * 2 * (n2g / 2 + 1) * sizeof(cpx); }
     if (sp.shy4 > 64 * 1024) { c->err = "helmholtz: y line too long for the LDS-resident DCT-IV"; return 1; }
-    const int nh2 = n2g / 2; std::vector<double> t(4 * (size_t)nh2);
-    for (int q = 0; q < nh2; ++q) { const double a1 = -pi * (4. * q + 1.) / (4. * n2g), a2 = -pi * q / (double)n2g;
+    const int nh2 = n2g / 2; std::vector<real> t(4 * (size_t)nh2);
+    for (int q = 0; q < nh2; ++q) { const real a1 = -pi * (4. * q + 1.) / (4. * n2g), a2 = -pi * q / (real)n2g;
                                     t[2 * q] = std::cos(a1); t[2 * q + 1] = std::sin(a1); t[2 * (nh2 + q)] = std::cos(a2); t[2 * (nh2 + q) + 1] = std::sin(a2); }
-    HIPCHK(c, hipMalloc(&c->d_tw4y, t.size() * sizeof(double)));
-    HIPCHK(c, hipMemcpy(c->d_tw4y, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&c->d_tw4y, t.size() * sizeof(real)));
+    HIPCHK(c, hipMemcpy(c->d_tw4y, t.data(), t.size() * sizeof(real), hipMemcpyHostToDevice));
     if (!c->d_twy4) { if (mk(n2g / 2, &c->d_twy4)) return 1; }
   }
   V.ready = true;
   return 0;
 }
-int op_helmholtz(cales_ctx *c, int ivel, double alpha) {
+int op_helmholtz(cales_ctx *c, int ivel, real alpha) {
   if (c->C.impdiff != 1) { c->err = "helmholtz needs impdiff = 1"; return 1; }
   PlanSlot *slot = find_slot(c);
   if (!slot) { c->err = "solver not initialised"; return 1; }
@@ -1512,12 +1516,12 @@ int op_helmholtz(cales_ctx *c, int ivel, double alpha) {
   const int n3 = c->n[2];
   if (int e = op_rhs_b_velxy(c, ivel, alpha)) return e;      // main.f90:424-431: boundary terms of the x and y faces, then z
   if (int e = op_rhs_b_velz(c, ivel, alpha)) return e;
-  double *abc = c->d_red + 64 + 16 * (n3 + 2);
+  real *abc = c->d_red + 64 + 16 * (n3 + 2);
   hipLaunchKernelGGL(k_scale_abc, dim3((n3 + 63) / 64), dim3(64), 0, c->stream, n3, alpha, c->d_av[ivel - 1], c->d_bv[ivel - 1], c->d_cv[ivel - 1], abc, abc + n3, abc + 2 * n3);
   const char *bcz = &c->cbcvel[6 * (ivel - 1) + 4];
   const int q = (ivel == 3 && bcz[1] == 'D') ? 1 : 0;
   // the solve runs with the component's kinds, eigenvalues and normalisation in place of the pressure's
-  const int xk = c->xkind, yk = c->ykind; double *lx = c->d_lamx, *ly = c->d_lamy; const double nf = c->normfft;
+  const int xk = c->xkind, yk = c->ykind; real *lx = c->d_lamx, *ly = c->d_lamy; const real nf = c->normfft;
   c->xkind = V.xkind; c->ykind = V.ykind; c->d_lamx = V.lamx; c->d_lamy = V.lamy; c->normfft = V.normfft; c->cur_velset = &V;
   const int e = solve_field(c, c->f[CALES_U + ivel - 1], abc, abc + n3, abc + 2 * n3, n3 - q, alpha, bcz[0] == 'P' && bcz[1] == 'P', false);
   c->xkind = xk; c->ykind = yk; c->d_lamx = lx; c->d_lamy = ly; c->normfft = nf; c->cur_velset = nullptr;

@@ -51,7 +51,7 @@ def y_neighbours(rank: int, nranks: int, periodic: bool):
 
 
 class TorchComm:
-    """Exchanges over a torch.distributed process group; A and B are 1-D float64 tensors (GPU for nccl, CPU for gloo)."""
+    """Exchanges over a torch.distributed process group; A and B are 1-D tensors of the library's reals (float64, or float32 for the single-precision build) (GPU for nccl, CPU for gloo)."""
 
     def __init__(self, dist, torch, A, B, periodic_y: bool, group=None):
         self.dist, self.torch, self.A, self.B, self.per = dist, torch, A, B, periodic_y
@@ -244,8 +244,8 @@ class SlabHotPath(HotPath):
         if self.native:
             return
         with torch.cuda.stream(self.stream):
-            self.A = torch.zeros(self.nbuf, dtype=torch.float64, device="cuda")
-            self.B = torch.zeros(self.nbuf, dtype=torch.float64, device="cuda")
+            self.A = torch.zeros(self.nbuf, dtype=torch.float32 if capi.SINGLE else torch.float64, device="cuda")
+            self.B = torch.zeros(self.nbuf, dtype=torch.float32 if capi.SINGLE else torch.float64, device="cuda")
         self.stream.synchronize()
         per_y = bool(case.cbcpre[0, 1] == "P" and case.cbcpre[1, 1] == "P")
         if loopback is not None:

@@ -24,7 +24,15 @@ program cales
 #ifdef CALES_MPI
   include 'mpif.h'
 #endif
-  integer, parameter :: rp = c_double
+#if defined(CALES_MPI)
+#if defined(_SINGLE_PRECISION)
+#define MPI_REAL_RP MPI_REAL
+#else
+#define MPI_REAL_RP MPI_DOUBLE_PRECISION
+#endif
+#endif
+  integer, parameter :: rp = c_rp
+  integer(int64), parameter :: rsz = storage_size(1._rp)/8             ! bytes per real in the stream files
   real(rp), parameter :: small = epsilon(1._rp)*10**(precision(1._rp)/2)   ! src/param.f90:24
   ! ---- namelist variables, declared as in src/param.f90:37-76
   integer  :: ng(3),gtype,nstep,nsaves_max,icheck,iout0d,iout1d,iout2d,iout3d,isave,dims(2),lwm(0:1,3)
@@ -229,7 +237,7 @@ program cales
     if(stop_type(3)) then
       call system_clock(c1); tw = real(c1-c0,rp)/real(crate,rp)/3600.
 #ifdef CALES_MPI
-      sbuf(1) = tw; call MPI_ALLREDUCE(sbuf,rbuf,1,MPI_DOUBLE_PRECISION,MPI_MAX,MPI_COMM_WORLD,ierr); tw = rbuf(1)     ! every rank stops together
+      sbuf(1) = tw; call MPI_ALLREDUCE(sbuf,rbuf,1,MPI_REAL_RP,MPI_MAX,MPI_COMM_WORLD,ierr); tw = rbuf(1)     ! every rank stops together
 #endif
       if(tw    >= tw_max  ) is_done = is_done.or..true.
     end if
@@ -277,9 +285,9 @@ program cales
     call system_clock(c1); dt12 = real(c1-cstep0,rp)/real(crate,rp)
     dt12av = dt12; dt12min = dt12; dt12max = dt12
 #ifdef CALES_MPI
-    sbuf(1) = dt12; call MPI_ALLREDUCE(sbuf,rbuf,1,MPI_DOUBLE_PRECISION,MPI_SUM,MPI_COMM_WORLD,ierr); dt12av  = rbuf(1)/(1.*nranks)   ! main.f90:612-618
-    sbuf(1) = dt12; call MPI_ALLREDUCE(sbuf,rbuf,1,MPI_DOUBLE_PRECISION,MPI_MIN,MPI_COMM_WORLD,ierr); dt12min = rbuf(1)
-    sbuf(1) = dt12; call MPI_ALLREDUCE(sbuf,rbuf,1,MPI_DOUBLE_PRECISION,MPI_MAX,MPI_COMM_WORLD,ierr); dt12max = rbuf(1)
+    sbuf(1) = dt12; call MPI_ALLREDUCE(sbuf,rbuf,1,MPI_REAL_RP,MPI_SUM,MPI_COMM_WORLD,ierr); dt12av  = rbuf(1)/(1.*nranks)   ! main.f90:612-618
+    sbuf(1) = dt12; call MPI_ALLREDUCE(sbuf,rbuf,1,MPI_REAL_RP,MPI_MIN,MPI_COMM_WORLD,ierr); dt12min = rbuf(1)
+    sbuf(1) = dt12; call MPI_ALLREDUCE(sbuf,rbuf,1,MPI_REAL_RP,MPI_MAX,MPI_COMM_WORLD,ierr); dt12max = rbuf(1)
 #endif
     if(myid == 0) print*, 'Avrg, min & max elapsed time: '
     if(myid == 0) print*, dt12av,dt12min,dt12max
@@ -361,7 +369,7 @@ contains
     integer :: ie
     if(nranks == 1) return
     allocate(t(n)); t(:) = a(:)
-    call MPI_ALLREDUCE(t,a,n,MPI_DOUBLE_PRECISION,MPI_SUM,MPI_COMM_WORLD,ie)
+    call MPI_ALLREDUCE(t,a,n,MPI_REAL_RP,MPI_SUM,MPI_COMM_WORLD,ie)
 #endif
   end subroutine allsum
   subroutine visu_log(flog,fbin,varname,nmin,nmax)    ! write_log_output, src/output.f90:244-272
@@ -452,7 +460,7 @@ contains
     integer(int64) :: pos
     integer :: kk
     do kk=1,ng(3)
-      pos = 1 + 8*(((ifld*ng(3) + (kk-1))*ng(2) + jlo)*int(ng(1),int64))
+      pos = 1 + rsz*(((ifld*ng(3) + (kk-1))*ng(2) + jlo)*int(ng(1),int64))
       write(iu,pos=pos) q(1:ng(1),1:n2l,kk)
     end do
   end subroutine write_slab
@@ -463,7 +471,7 @@ contains
     integer(int64) :: pos
     integer :: kk
     do kk=1,ng(3)
-      pos = 1 + 8*(((ifld*ng(3) + (kk-1))*ng(2) + jlo)*int(ng(1),int64))
+      pos = 1 + rsz*(((ifld*ng(3) + (kk-1))*ng(2) + jlo)*int(ng(1),int64))
       read(iu,pos=pos) q(1:ng(1),1:n2l,kk)
     end do
   end subroutine read_slab
@@ -477,7 +485,7 @@ contains
     select case(io)
     case('r')
       inquire(file=fname,size=fsize)
-      good = (nfld*4+2)*8
+      good = (nfld*4+2)*rsz                    ! (4*N+2)*sizeof(rp), load.f90:44-52
       if(fsize /= good) then
         if(myid == 0) print*, '*** Simulation aborted due a checkpoint file with incorrect size ***'
         if(myid == 0) print*, '    file: ', fname, ' | expected size: ', good, '| actual size: ', fsize
@@ -485,14 +493,14 @@ contains
       end if
       open(newunit=iu,file=fname,action='read',form='unformatted',access='stream',status='old')
       call read_slab(iu,0_int64,u); call read_slab(iu,1_int64,v); call read_slab(iu,2_int64,w); call read_slab(iu,3_int64,p)
-      read(iu,pos=1+8*4*nfld) fldinfo
+      read(iu,pos=1+rsz*4*nfld) fldinfo
       close(iu)
       time = fldinfo(1); istep = nint(fldinfo(2))
     case('w')
       call open_shared(fname,iu)
       call write_slab(iu,0_int64,u); call write_slab(iu,1_int64,v); call write_slab(iu,2_int64,w); call write_slab(iu,3_int64,p)
       fldinfo = [time,1._rp*istep]
-      if(myid == 0) write(iu,pos=1+8*4*nfld) fldinfo
+      if(myid == 0) write(iu,pos=1+rsz*4*nfld) fldinfo
       close(iu)
       call barrier
     end select

@@ -16,22 +16,34 @@ from . import capi
 from .nml import Case
 
 RKCOEFF = ((32. / 60., 0.), (25. / 60., -17. / 60.), (45. / 60., -25. / 60.))   # src/param.f90:27-29
-SMALL = np.finfo(np.float64).eps * 10 ** (15 // 2)                                # src/param.f90:24
+SMALL = np.finfo(capi.np_real).eps * 10 ** ((6 if capi.SINGLE else 15) // 2)     # src/param.f90:24: epsilon(1._rp)*10**(precision(1._rp)/2)
 
 
 class CalesError(RuntimeError):
     pass
 
 
+REAL = capi.np_real      # numpy dtype of rp: float64, or float32 with CALES_PRECISION=single (capi.py)
+
+
 def _p(a: np.ndarray):
-    if a.dtype != np.float64 or not (a.flags.f_contiguous or a.ndim == 1):
-        raise ValueError("fields must be Fortran-ordered float64 arrays")
+    if a.dtype != REAL or not (a.flags.f_contiguous or a.ndim == 1):
+        raise ValueError(f"fields must be Fortran-ordered {np.dtype(REAL).name} arrays")
     return a.ctypes.data_as(C.c_void_p)
+
+
+class _In:
+    """An input array in the library's precision (a converted copy when the caller's dtype differs, e.g. float64 fields handed to the
+    single-precision build); keeps the copy alive for the duration of the call."""
+    def __init__(self, a):
+        a = np.asarray(a)
+        self.a = a if a.dtype == REAL and (a.flags.f_contiguous or a.ndim == 1) else np.asfortranarray(a, dtype=REAL)
+        self.p = self.a.ctypes.data_as(C.c_void_p)
 
 
 def initgrid(gtype: int, n: int, gr: float, lz: float) -> Dict[str, np.ndarray]:
     """src/initgrid.f90:15 (host helper of the library)."""
-    out = [np.zeros(n + 2) for _ in range(4)]
+    out = [np.zeros(n + 2, dtype=REAL) for _ in range(4)]
     rc = capi.lib().cales_initgrid(int(gtype), int(n), float(gr), float(lz), *[_p(a) for a in out])
     if rc:
         raise CalesError("cales_initgrid failed")
@@ -42,7 +54,7 @@ def initflow(case: Case) -> Tuple[np.ndarray, ...]:
     """src/initflow.f90:17, deterministic kinds; returns global haloed u,v,w,p."""
     cs = capi.make_case(case)
     shape = tuple(int(x) + 2 for x in case.ng)
-    u, v, w, p = (np.zeros(shape, order="F") for _ in range(4))
+    u, v, w, p = (np.zeros(shape, order="F", dtype=REAL) for _ in range(4))
     rc = capi.lib().cales_initflow(C.byref(cs), case.inivel.encode(), int(case.is_wallturb), _p(u), _p(v), _p(w), _p(p))
     if rc == 2:
         raise CalesError(f"inivel='{case.inivel}' relies on the Fortran RNG stream and is not offered")
@@ -91,10 +103,11 @@ class HotPath:
             pass
 
     def zeros(self) -> np.ndarray:
-        return np.zeros(self.shape, order="F")
+        return np.zeros(self.shape, order="F", dtype=REAL)
 
     def set(self, name: str, a: np.ndarray):
-        self._chk(self.L.cales_set_field(self.h, capi.FIELDS[name], _p(a)))
+        a = _In(a)
+        self._chk(self.L.cales_set_field(self.h, capi.FIELDS[name], a.p))
 
     def get(self, name: str) -> np.ndarray:
         a = self.zeros()
@@ -102,7 +115,8 @@ class HotPath:
         return a
 
     def upload(self, u, v, w, p):
-        self._chk(self.L.cales_upload_state(self.h, _p(u), _p(v), _p(w), _p(p)))
+        a = [_In(x) for x in (u, v, w, p)]
+        self._chk(self.L.cales_upload_state(self.h, *[x.p for x in a]))
 
     def download(self):
         out = [self.zeros() for _ in range(5)]
@@ -111,8 +125,8 @@ class HotPath:
 
     def bcvel_planes(self, ivel: int):
         n = self.n
-        x = np.zeros((n[1] + 2, n[2] + 2, 2), order="F"); y = np.zeros((n[0] + 2, n[2] + 2, 2), order="F")
-        z = np.zeros((n[0] + 2, n[1] + 2, 2), order="F")
+        x = np.zeros((n[1] + 2, n[2] + 2, 2), order="F", dtype=REAL); y = np.zeros((n[0] + 2, n[2] + 2, 2), order="F", dtype=REAL)
+        z = np.zeros((n[0] + 2, n[1] + 2, 2), order="F", dtype=REAL)
         self._chk(self.L.cales_get_bcvel(self.h, ivel, _p(x), _p(y), _p(z)))
         return x, y, z
 
@@ -131,13 +145,13 @@ class HotPath:
 
     def rk(self, irk: int, dt: float) -> np.ndarray:
         self._chk(self.L.cales_rk(self.h, int(irk), float(dt)))
-        f = np.zeros(3)
+        f = np.zeros(3, dtype=REAL)
         self._chk(self.L.cales_get_forcing(self.h, _p(f)))
         return f
 
     def rk_par(self, rkpar, dt: float) -> np.ndarray:
         """rk(rkpar, ..., dt, ..., f) with the caller's coefficients (src/rk.f90:17)"""
-        rp = np.ascontiguousarray(rkpar, dtype=np.float64); f = np.zeros(3)
+        rp = np.ascontiguousarray(rkpar, dtype=REAL); f = np.zeros(3, dtype=REAL)
         self._chk(self.L.cales_rk_par(self.h, _p(rp), float(dt), _p(f)))
         return f
 
@@ -145,7 +159,7 @@ class HotPath:
         self._chk(self.L.cales_bulk_forcing(self.h))
 
     def bulk_mean(self, field="u", c_or_f="f") -> float:
-        m = C.c_double(0.)
+        m = capi.c_real(0.)
         self._chk(self.L.cales_bulk_mean(self.h, capi.FIELDS[field], 1 if c_or_f == "f" else 0, C.byref(m)))
         return m.value
 
@@ -175,24 +189,24 @@ class HotPath:
         self._chk(self.L.cales_cmpt_sgs(self.h))
 
     def chkdt(self) -> float:
-        d = C.c_double(0.)
+        d = capi.c_real(0.)
         self._chk(self.L.cales_chkdt(self.h, C.byref(d)))
         return d.value
 
     def chkdiv(self) -> Tuple[float, float]:
-        a, b = C.c_double(0.), C.c_double(0.)
+        a, b = capi.c_real(0.), capi.c_real(0.)
         self._chk(self.L.cales_chkdiv(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def stats_chan(self) -> np.ndarray:
         """First block of out1d_single_point_chan (src/output.f90:509-700): 27 plane statistics per z plane, shape (27, n3)."""
-        buf = np.zeros((27, self.n[2]), order="F")
+        buf = np.zeros((27, self.n[2]), order="F", dtype=REAL)
         self._chk(self.L.cales_out1d_single_point_chan(self.h, _p(buf)))
         return buf
 
     def stats_chan_budgets(self):
         """Second and third block of out1d_single_point_chan (src/output.f90:700-1055): (38, n3) budget sums and (6, n3) divergence measures."""
-        b = np.zeros((38, self.n[2]), order="F"); l = np.zeros((6, self.n[2]), order="F")
+        b = np.zeros((38, self.n[2]), order="F", dtype=REAL); l = np.zeros((6, self.n[2]), order="F", dtype=REAL)
         self._chk(self.L.cales_out1d_chan_budgets(self.h, _p(b), _p(l)))
         return b, l
 
@@ -201,7 +215,7 @@ class HotPath:
         self._chk(self.L.cales_step(self.h, float(dt)))
 
     def dpdl(self) -> np.ndarray:
-        d = np.zeros(3)
+        d = np.zeros(3, dtype=REAL)
         self._chk(self.L.cales_get_dpdl(self.h, _p(d)))
         return d
 
@@ -219,7 +233,7 @@ class HotPath:
     def profile_stats(self) -> Dict[str, Tuple[int, float]]:
         out = {}
         for i in range(self.L.cales_profile_count(self.h)):
-            name = C.create_string_buffer(64); calls = C.c_int64(0); ms = C.c_double(0.)
+            name = C.create_string_buffer(64); calls = C.c_int64(0); ms = capi.c_real(0.)
             self.L.cales_profile_get(self.h, i, name, 64, C.byref(calls), C.byref(ms))
             out[name.value.decode()] = (calls.value, ms.value)
         return out

@@ -18,19 +18,29 @@
 extern "C" {
 #endif
 
+/* rp of the reference (src/precision.f90:11-20). libcales_hip.so is the FP64 build; libcales_hip_sp.so, built from the same sources with
+ * -DCALES_SINGLE, is the reference's -D_SINGLE_PRECISION: every real of this interface (fields, parameters, scalars) is then a float.
+ * cales_real_size() tells a host which one it has loaded. */
+#ifdef CALES_SINGLE
+typedef float cales_real;
+#else
+typedef double cales_real;
+#endif
+int cales_real_size(void);      /* 8 or 4 */
+
 /* The run-time image of input.nml (reference src/param.f90:37-76,95-119). Character and
  * multi-dimensional entries keep Fortran storage order, so a Fortran host can pass its
  * namelist variables unchanged: cbcvel(0:1,3,3) -> [side + 2*dir + 6*vel]. */
 typedef struct cales_case {
   int32_t ng[3];          /* global grid */
-  double  l[3];
-  int32_t gtype; double gr;
-  double  visci;
+  cales_real  l[3];
+  int32_t gtype; cales_real gr;
+  cales_real  visci;
   char    cbcvel[18], cbcpre[6], cbcsgs[6];
-  double  bcvel[18], bcpre[6], bcsgs[6];
-  double  bforce[3]; int32_t is_forced[3]; double velf[3];
+  cales_real  bcvel[18], bcpre[6], bcsgs[6];
+  cales_real  bforce[3]; int32_t is_forced[3]; cales_real velf[3];
   int32_t sgstype;        /* 0 'none', 1 'smag', 2 'dsmag'  (src/sgs.f90:61-153) */
-  int32_t lwm[6]; double hwm;
+  int32_t lwm[6]; cales_real hwm;
   int32_t impdiff;        /* 0 explicit; 2 = _IMPDIFF + _IMPDIFF_1D (z-implicit); 1 = _IMPDIFF (3-D implicit; periodic or no-slip wall pairs in x and y) */
   int32_t nranks, rank;   /* y-slab decomposition: rank owns rows rank*ng2/nranks+1 ... */
 } cales_case;
@@ -45,11 +55,11 @@ enum cales_field { CALES_U = 0, CALES_V = 1, CALES_W = 2, CALES_P = 3, CALES_PP 
 
 /* ---- host-only helpers (no GPU needed) -------------------------------------------------- */
 /* src/initgrid.f90:15  initgrid(gtype,n,gr,lz,dzc,dzf,zc,zf); arrays (0:n+1) */
-int cales_initgrid(int gtype, int n, double gr, double lz, double *dzc, double *dzf, double *zc, double *zf);
+int cales_initgrid(int gtype, int n, cales_real gr, cales_real lz, cales_real *dzc, cales_real *dzf, cales_real *zc, cales_real *zf);
 /* src/initflow.f90:17  initflow(inivel,...,u,v,w,p): zer uni cou poi iop pdc hdc hcp tgv tgw ant duc bit-compatible with the
  * reference; log hcl tbl with their +-5 % noise from a counter-based generator (the reference uses the Fortran run-time's
  * random_number: same distribution, other numbers); global haloed host arrays; returns 1 for an unknown kind */
-int cales_initflow(const cales_case *c, const char *inivel, int is_wallturb, double *u, double *v, double *w, double *p);
+int cales_initflow(const cales_case *c, const char *inivel, int is_wallturb, cales_real *u, cales_real *v, cales_real *w, cales_real *p);
 /* src/sanity.f90:33-67 rules restated; returns 0 if the case is accepted */
 int cales_check_case(const cales_case *c, char *msg, int msglen);
 
@@ -67,50 +77,50 @@ int  cales_sync(cales_ctx *ctx);
 int  cales_local_size(const cales_ctx *ctx, int32_t n[3], int32_t lo[3]);
 
 /* host <-> device (src/main.f90:368 `enter data copyin(u,v,w,p)`, :576-607 `update self`) */
-int cales_upload_state(cales_ctx *ctx, const double *u, const double *v, const double *w, const double *p);
-int cales_download_state(cales_ctx *ctx, double *u, double *v, double *w, double *p, double *visct);
-int cales_set_field(cales_ctx *ctx, int field, const double *host);
-int cales_get_field(cales_ctx *ctx, int field, double *host);
-int cales_get_bcvel(cales_ctx *ctx, int ivel, double *x, double *y, double *z);  /* bcu/bcv/bcw planes (typedef.f90:10) */
+int cales_upload_state(cales_ctx *ctx, const cales_real *u, const cales_real *v, const cales_real *w, const cales_real *p);
+int cales_download_state(cales_ctx *ctx, cales_real *u, cales_real *v, cales_real *w, cales_real *p, cales_real *visct);
+int cales_set_field(cales_ctx *ctx, int field, const cales_real *host);
+int cales_get_field(cales_ctx *ctx, int field, cales_real *host);
+int cales_get_bcvel(cales_ctx *ctx, int ivel, cales_real *x, cales_real *y, cales_real *z);  /* bcu/bcv/bcw planes (typedef.f90:10) */
 
 /* ---- operators, named after the reference routines they replace ------------------------- */
 int cales_bounduvw(cales_ctx *ctx, int is_updt_wm, int is_correc);          /* src/bound.f90:18   */
 int cales_boundp(cales_ctx *ctx, int field, int which);                     /* src/bound.f90:156; which 0 cbcpre/bcp, 1 cbcsgs/bcs */
 int cales_mom(cales_ctx *ctx);                                              /* src/mom.f90:17 -> CALES_DUDT.. */
-int cales_rk(cales_ctx *ctx, int irk, double dt);                           /* src/rk.f90:17 (forcing f stays on the device). The ghost
+int cales_rk(cales_ctx *ctx, int irk, cales_real dt);                           /* src/rk.f90:17 (forcing f stays on the device). The ghost
                                                                               * cells of u,v,w keep the values of the last bounduvw (as in the reference) when a
                                                                               * wall model is active -- it may sample them -- and are undefined otherwise;
                                                                               * bounduvw follows in every caller (src/main.f90:493) */
 /* the same with the caller's Runge-Kutta coefficients: rk(rkpar, ..., dt, ..., f) of src/rk.f90:17 as the reference declares it
  * (rkpar = rkcoeff(:,irk), src/param.f90:27-29); f_out may be NULL, otherwise the forcing f(1:3) is returned (sync) */
-int cales_rk_par(cales_ctx *ctx, const double rkpar[2], double dt, double f_out[3]);
+int cales_rk_par(cales_ctx *ctx, const cales_real rkpar[2], cales_real dt, cales_real f_out[3]);
 int cales_bulk_forcing(cales_ctx *ctx);                                     /* src/mom.f90:311    */
-int cales_get_forcing(cales_ctx *ctx, double f[3]);                         /* f of the last cales_rk (sync)  */
-int cales_bulk_mean(cales_ctx *ctx, int field, int c_or_f, double *mean);   /* src/utils.f90:16 (sync) */
-int cales_fillps(cales_ctx *ctx, double dtrki);                             /* src/fillps.f90:14  */
+int cales_get_forcing(cales_ctx *ctx, cales_real f[3]);                         /* f of the last cales_rk (sync)  */
+int cales_bulk_mean(cales_ctx *ctx, int field, int c_or_f, cales_real *mean);   /* src/utils.f90:16 (sync) */
+int cales_fillps(cales_ctx *ctx, cales_real dtrki);                             /* src/fillps.f90:14  */
 int cales_updt_rhs_b(cales_ctx *ctx);                                       /* src/bound.f90:562, pressure r.h.s. */
 int cales_solver(cales_ctx *ctx);                                           /* src/solver.f90:20 on CALES_PP */
-int cales_helmholtz_z(cales_ctx *ctx, int ivel, double alpha);              /* main.f90:425-445: updt_rhs_b + solver_gaussel_z */
-int cales_helmholtz(cales_ctx *ctx, int ivel, double alpha);                /* impdiff = 1, main.f90:423-491: cmpt_rhs_b + updt_rhs_b (x, y, z faces) + solver on a velocity component, any BC pair of find_fft */
-int cales_correc(cales_ctx *ctx, double dtrk);                              /* src/correc.f90:14  */
-int cales_updatep(cales_ctx *ctx, double alpha);                            /* src/updatep.f90:14 */
+int cales_helmholtz_z(cales_ctx *ctx, int ivel, cales_real alpha);              /* main.f90:425-445: updt_rhs_b + solver_gaussel_z */
+int cales_helmholtz(cales_ctx *ctx, int ivel, cales_real alpha);                /* impdiff = 1, main.f90:423-491: cmpt_rhs_b + updt_rhs_b (x, y, z faces) + solver on a velocity component, any BC pair of find_fft */
+int cales_correc(cales_ctx *ctx, cales_real dtrk);                              /* src/correc.f90:14  */
+int cales_updatep(cales_ctx *ctx, cales_real alpha);                            /* src/updatep.f90:14 */
 int cales_cmpt_sgs(cales_ctx *ctx);                                         /* src/sgs.f90:21     */
-int cales_chkdt(cales_ctx *ctx, double *dtmax);                             /* src/chkdt.f90:17 (sync) */
-int cales_chkdiv(cales_ctx *ctx, double *divtot, double *divmax);           /* src/chkdiv.f90:16 (sync) */
+int cales_chkdt(cales_ctx *ctx, cales_real *dtmax);                             /* src/chkdt.f90:17 (sync) */
+int cales_chkdiv(cales_ctx *ctx, cales_real *divtot, cales_real *divmax);           /* src/chkdiv.f90:16 (sync) */
 /* plane statistics of the channel: first block of out1d_single_point_chan (src/output.f90:509-700, idir = 3), the 27 columns of
  * velstats_fld_*.out/.bin between the coordinates and the spacings; buf(27, n3) column-major on the host (sync). With several
  * ranks: the sums over this rank's rows -- the caller adds the ranks as the reference does (output.f90:691). */
 #define CALES_NSTATS_CHAN 27
-int cales_out1d_single_point_chan(cales_ctx *ctx, double *buf);
+int cales_out1d_single_point_chan(cales_ctx *ctx, cales_real *buf);
 /* second and third block of the same routine (src/output.f90:700-1055): budget(38, n3) = the columns of velstats_fld_*_reystr_budget.out/.bin,
  * leakage(6, n3) = those of velstats_fld_*_leakage.out/.bin; either pointer may be NULL (sync) */
 #define CALES_NBUDGET_CHAN 38
 #define CALES_NLEAKAGE_CHAN 6
-int cales_out1d_chan_budgets(cales_ctx *ctx, double *budget, double *leakage);
+int cales_out1d_chan_budgets(cales_ctx *ctx, cales_real *budget, cales_real *leakage);
 
 /* one time step = 3 RK substeps in the order of src/main.f90:417-508; no host synchronisation */
-int cales_step(cales_ctx *ctx, double dt);
-int cales_get_dpdl(cales_ctx *ctx, double dpdl[3]);                         /* main.f90:492,508 (sync) */
+int cales_step(cales_ctx *ctx, cales_real dt);
+int cales_get_dpdl(cales_ctx *ctx, cales_real dpdl[3]);                         /* main.f90:492,508 (sync) */
 
 /* ---- multi-GPU: y-slab decomposition --------------------------------------
  * The reference exchanges halos with MPI_SENDRECV / cudecompUpdateHalos (src/bound.f90:619-723) and transposes
@@ -128,7 +138,7 @@ typedef int (*cales_alltoall_cb)(void *user, int dir, int64_t count);
 typedef int (*cales_allreduce_cb)(void *user, int64_t off, int64_t count, int op);
 int cales_comm_buffer_doubles(const cales_ctx *ctx, int64_t *n);      /* required size of A and of B */
 int cales_set_comm(cales_ctx *ctx, cales_halo_cb halo, cales_alltoall_cb a2a, cales_allreduce_cb allred, void *user,
-                   double *bufA, double *bufB, int64_t nbuf);
+                   cales_real *bufA, cales_real *bufB, int64_t nbuf);
 /* Optional, after cales_set_comm: exchanges that may run BESIDE the kernels (the reference's non-blocking halos, src/bound.f90:619-696
  * `_ASYNC_HALO`, and cuDecomp's pipelined transposes, src/initmpi.f90:94-139). The library owns a second HIP stream and the events
  * between the two; it hands that stream to these callbacks, which must enqueue ALL their work on it (no host synchronisation):
@@ -151,14 +161,14 @@ int cales_comm_unique_id(void *id_out);                       /* rank 0 only; wr
 int cales_comm_init_rccl(cales_ctx *ctx, const void *id);     /* all ranks */
 int cales_comm_selftest(void);                                /* one-rank communicator: halo order, all-to-all, all-reduce; 0 = ok */
 /* initial field of the rank's slab only (local haloed arrays); the volume mean is summed in the global order */
-int cales_initflow_slab(const cales_case *c, const char *inivel, int is_wallturb, double *u, double *v, double *w, double *p);
+int cales_initflow_slab(const cales_case *c, const char *inivel, int is_wallturb, cales_real *u, cales_real *v, cales_real *w, cales_real *p);
 
 /* ---- measurement -------------------------------------------------------------------------- */
 /* When enabled, every kernel launch is bracketed by HIP events on the context's stream. */
 int cales_profile_enable(cales_ctx *ctx, int on);
 int cales_profile_reset(cales_ctx *ctx);
 int cales_profile_count(cales_ctx *ctx);
-int cales_profile_get(cales_ctx *ctx, int idx, char *name, int namelen, int64_t *calls, double *total_ms);
+int cales_profile_get(cales_ctx *ctx, int idx, char *name, int namelen, int64_t *calls, cales_real *total_ms);
 /* algorithmic words (8 B) per cell per call of the named kernel group, for the roofline line */
 int cales_device_info(cales_ctx *ctx, char *name, int namelen, int64_t *hbm_bytes);
 

@@ -25,6 +25,33 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, s), s
 
 
+def test_single_precision_library_host_side():
+    """libcales_hip_sp.so (-DCALES_SINGLE, the reference's -D_SINGLE_PRECISION): exports the same symbols, reports four-byte reals, and its
+    host-only entries take float arguments: initgrid against the reference-made grids within single precision, check_case through the float struct.
+    (The precision is process-wide in the Python host -- CALES_PRECISION=single --, so this binds the second library by hand.)"""
+    import ctypes as C
+    path = os.path.join(ROOT, "cales_amd", "libcales_hip_sp.so")
+    assert os.path.exists(path), "build with python -c 'import __graft_entry__ as g; g.build()'"
+    if os.environ.get("CALES_NO_TORCH") != "1":
+        import torch  # noqa: F401  (one HIP runtime per process: see capi.lib)
+    L = C.CDLL(path)
+    for sname in capi.SYMBOLS:
+        assert hasattr(L, sname), sname
+    L.cales_real_size.restype = C.c_int
+    assert L.cales_real_size() == 4 and capi.lib().cales_real_size() == 8
+    g = np.load(os.path.join(GOLD, "grids.npz"))
+    L.cales_initgrid.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float] + [C.c_void_p] * 4
+    q = 0
+    while f"g{q}_spec" in g.files:
+        gtype, gr, n3, lz = g[f"g{q}_spec"]
+        out = [np.zeros(int(n3) + 2, dtype=np.float32) for _ in range(4)]
+        assert L.cales_initgrid(int(gtype), int(n3), float(gr), float(lz), *[a.ctypes.data_as(C.c_void_p) for a in out]) == 0
+        for a, k in zip(out, ("dzc", "dzf", "zc", "zf")):
+            assert np.abs(a - g[f"g{q}_{k}"]).max() < 2e-5 * np.abs(g[f"g{q}_{k}"]).max(), (q, k)
+        q += 1
+    assert q > 0
+
+
 def test_no_cpu_fallback_and_no_oracle_in_product():
     """cales_create must fail loudly without a HIP device; nothing under cales_amd/ touches oracle/."""
     for root, _, files in os.walk(os.path.join(ROOT, "cales_amd")):
