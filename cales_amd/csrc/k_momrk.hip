@@ -6,7 +6,8 @@
 // own cell of u,v,w,visct,p per plane (next plane prefetched), lanes 0 and 63 also the x-halo cell beside it; the planes
 // k-1..k+1 live in a 4-slot LDS ring (rows of 66) from which the 13/16-point stencils are read, and the RK update
 // is applied in the same pass. Velocities are written to a second set of buffers (the stencil still needs the old values of
-// the neighbours); the host swaps the pointers. Arithmetic and expression order are those of the reference.
+// the neighbours); the host swaps the pointers. The arithmetic block restates src/mom.f90:83-276 term by term in the reference's expression order (and keeps its
+// names for the stencil values): that is what the 1e-13 parity with the reference's own r.h.s. rests on; everything around it is this design's.
 // Algorithmic traffic: 14 words/cell (5 in + 3 old r.h.s. in + 3 velocities + 3 r.h.s. out) instead of 7 + 13.
 #include "common.hpp"
 
