@@ -780,11 +780,16 @@ struct TileMap { int blocked, cw, n2l, mofs, nmode; size_t kstride, segstride;
                  // z-only Helmholtz sweeps of real fields (no eigenvalue shift): nolam; cales_step forms the r.h.s. of rk.f90:108-118 and
                  // main.f90:422-433 while loading, (u - hf12*dudtd) + f + rhs_b, and plane nz+1 (wall face of w) receives the first two terms
                  int nolam, nq, has_lo, has_hi; const real *dud, *force, *rb; real hf12; };
-template <int M, int NV>
-__global__ __launch_bounds__(1024 / NV, (M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_gaussel_tile(Geom g, int nz, int ndbl, real lscale, const real *__restrict__ abc,
+// PER = 1: periodic z (solver.f90:109-150, gaussel_periodic): the tile solves the (n-1)-row system for the right-hand side AND for the closure
+// vector p2 = (-a(1), 0, ..., 0, -c(n-1)) -- one more right-hand side of the same matrix, kept in registers -- and the last row follows from
+// p(n) = (p(n) - c(n) p1(1) - a(n) p1(n-1)) / (b(n) + lambda + c(n) p2(1) + a(n) p2(n-1) + eps), p(1:n-1) = p1 + p2 p(n); ra, rb_, rc: the raw a, b, c.
+template <int M, int NV, int PER>
+__global__ __launch_bounds__(1024 / NV, (PER ? 2 : M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_gaussel_tile(Geom g, int nz, int ndbl, real lscale, const real *__restrict__ abc,
                                                             const real *__restrict__ lamx, const real *__restrict__ lamy,
-                                                            real *__restrict__ p, int fixnull, TileMap T) {
+                                                            real *__restrict__ p, int fixnull, TileMap T,
+                                                            const real *__restrict__ ra = nullptr, const real *__restrict__ rb_ = nullptr, const real *__restrict__ rc = nullptr) {
   extern __shared__ real shz[];
+  const int nsys = PER ? nz - 1 : nz;      // rows of the tridiagonal system proper
   constexpr int CP = M + 1, P = 64 * CP + 4, NT = 1024 / NV, KP = NT / 16, NQ = 64 * M / KP;
   const int t = threadIdx.x;
   const size_t base = (T.blocked ? T.segstride * blockIdx.y : g.ix(0, blockIdx.y + 1, 1)) + (size_t)16 * blockIdx.x;      // doubles from p
@@ -831,19 +836,27 @@ __global__ __launch_bounds__(1024 / NV, (M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_g
     const int k0 = ch * M;
     real cp[M - 1], V[M - 1];      // the swept right-hand sides go back to their LDS slots (registers: no spills at 4 waves/SIMD)
     real cprev = 0., vprev = 0., rprev[NV] = {};
+    // periodic z: the last plane's right-hand side (its row is an identity row of the tile), the closure vector's two entries
+    real pnr[NV] = {}, E[PER ? M - 1 : 1] = {}, eprev = 0.;
+    const real e_first = PER ? -ra[0] : 0., e_last = PER ? -rc[nsys - 1] : 0.;
+    if (PER) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) pnr[q] = shz[(x + q) * P + (nz - 1) + (nz - 1) / M];
+    }
 #pragma unroll
     for (int r = 0; r < M - 1; ++r) {
       const int k = k0 + r;
-      const bool pin = nullc && k == nz - 1, live = k < nz && !pin;
-      const real A = pin ? 0. : abc[r * 64 + ch], C = pin ? 0. : abc[128 * M + r * 64 + ch], B = pin ? 1. : abc[64 * M + r * 64 + ch] + (k < nz ? lam : 0.);
+      const bool pin = !PER && nullc && k == nz - 1, live = k < nsys && !pin;
+      const real A = pin ? 0. : abc[r * 64 + ch], C = pin ? 0. : abc[128 * M + r * 64 + ch], B = pin ? 1. : abc[64 * M + r * 64 + ch] + (k < nsys ? lam : 0.);
       const real z = rcp_nr(B - A * cprev + CALES_EPS);
       cp[r] = C * z; V[r] = (r == 0 ? A : -A * vprev) * z;
 #pragma unroll
       for (int q = 0; q < NV; ++q) { const real D = live ? col[q * P + r] : 0.; rprev[q] = (D - A * rprev[q]) * z; col[q * P + r] = rprev[q]; }
+      if (PER) { const real D2 = (k == 0 ? e_first : 0.) + (k == nsys - 1 ? e_last : 0.); eprev = (D2 - A * eprev) * z; E[r] = eprev; }
       cprev = cp[r]; vprev = V[r];
     }
     // first interior row of the chunk as a function of the separators beside it
-    real Vb = V[M - 2], Wb = cp[M - 2], Rb[NV];
+    real Vb = V[M - 2], Wb = cp[M - 2], Rb[NV], Eb = eprev;
 #pragma unroll
     for (int q = 0; q < NV; ++q) Rb[q] = rprev[q];
 #pragma unroll
@@ -851,18 +864,25 @@ __global__ __launch_bounds__(1024 / NV, (M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_g
       Vb = V[r] - cp[r] * Vb; Wb = -cp[r] * Wb;
 #pragma unroll
       for (int q = 0; q < NV; ++q) Rb[q] = col[q * P + r] - cp[r] * Rb[q];
+      if (PER) Eb = E[r] - cp[r] * Eb;
     }
     const bool last = ch == 63;
     // (cross-lane reads are issued by all lanes and masked afterwards: a lane switched off by a branch would be read as zero)
     real Vn = __shfl_down(Vb, 1, 64), Wn = __shfl_down(Wb, 1, 64);
     if (last) { Vn = 0.; Wn = 0.; }
     // separator row
-    real al, be, ga, de[NV];
+    real al, be, ga, de[NV], de2 = 0.;
     {
       const int k = k0 + M - 1, r = M - 1;
-      const bool pin = nullc && k == nz - 1, live = k < nz && !pin;
-      const real A = pin ? 0. : abc[r * 64 + ch], C = pin ? 0. : abc[128 * M + r * 64 + ch], B = pin ? 1. : abc[64 * M + r * 64 + ch] + (k < nz ? lam : 0.);
+      const bool pin = !PER && nullc && k == nz - 1, live = k < nsys && !pin;
+      const real A = pin ? 0. : abc[r * 64 + ch], C = pin ? 0. : abc[128 * M + r * 64 + ch], B = pin ? 1. : abc[64 * M + r * 64 + ch] + (k < nsys ? lam : 0.);
       al = -A * V[M - 2]; be = B - A * cp[M - 2] - C * Vn; ga = -C * Wn;
+      if (PER) {
+        real En = __shfl_down(Eb, 1, 64);
+        if (last) En = 0.;
+        const real D2 = (k == 0 ? e_first : 0.) + (k == nsys - 1 ? e_last : 0.);
+        de2 = D2 - A * eprev - C * En;
+      }
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
         real Rn = __shfl_down(Rb[q], 1, 64);
@@ -882,19 +902,47 @@ __global__ __launch_bounds__(1024 / NV, (M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_g
       be = be - gam * k1 - alp * k2;
 #pragma unroll
       for (int q = 0; q < NV; ++q) de[q] = de[q] - __shfl_up(de[q], h, 64) * k1 - __shfl_down(de[q], h, 64) * k2;
+      if (PER) de2 = de2 - __shfl_up(de2, h, 64) * k1 - __shfl_down(de2, h, 64) * k2;
       al = -alm * k1; ga = -gap * k2;
     }
     const real rb = rcp_nr(be);
+    // periodic z: row n-1 of the system sits in chunk cL at place rL; rows 1 and n-1 of p1 and p2 are fetched from their lanes
+    const int cL = PER ? (nsys - 1) / M : 0, rL = PER ? (nsys - 1) % M : 0;
+    real Es = 0., e1 = 0., eL = 0.;
+    if (PER) {
+      Es = de2 * rb;
+      real sp2 = __shfl_up(Es, 1, 64);
+      if (ch == 0) sp2 = 0.;
+      real xv2 = eprev - V[M - 2] * sp2 - cp[M - 2] * Es;
+      E[M - 2] = xv2;
+#pragma unroll
+      for (int r = M - 3; r >= 0; --r) { xv2 = E[r] - V[r] * sp2 - cp[r] * xv2; E[r] = xv2; }
+      real mine = Es;
+#pragma unroll
+      for (int r = 0; r < M - 1; ++r) if (r == rL) mine = E[r];
+      e1 = __shfl(E[0], 0, 64); eL = __shfl(mine, cL, 64);
+    }
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
       const real s = de[q] * rb;
       real sp = __shfl_up(s, 1, 64);
       if (ch == 0) sp = 0.;
       real xv = rprev[q] - V[M - 2] * sp - cp[M - 2] * s;
+      real mine = (rL == M - 2) ? xv : s;
       col[q * P + M - 2] = xv;
 #pragma unroll
-      for (int r = M - 3; r >= 0; --r) { xv = col[q * P + r] - V[r] * sp - cp[r] * xv; col[q * P + r] = xv; }
+      for (int r = M - 3; r >= 0; --r) { xv = col[q * P + r] - V[r] * sp - cp[r] * xv; col[q * P + r] = xv; if (PER && r == rL) mine = xv; }
       col[q * P + M - 1] = s;
+      if (PER) {
+        const real p11 = __shfl(xv, 0, 64), p1n = __shfl(mine, cL, 64);      // xv: row 1 of the chunk (lane 0: row 1 of the system)
+        const real an = ra[nz - 1], bn = rb_[nz - 1], cn = rc[nz - 1];
+        const real den = (bn + lam) + cn * e1 + an * eL + CALES_EPS;
+        const real pn = nullc ? 0. : ((pnr[q] - cn * p11) - an * p1n) * (1. / den);      // null mode of the triply periodic problem: p(n) = 0
+#pragma unroll
+        for (int r = 0; r < M - 1; ++r) if (k0 + r < nsys) col[q * P + r] = col[q * P + r] + E[r] * pn;
+        if (k0 + M - 1 < nsys) col[q * P + M - 1] = s + Es * pn;
+        if (ch == nsys / M) col[q * P + nsys % M] = pn;
+      }
     }
   }
   __syncthreads();
@@ -905,30 +953,31 @@ __global__ __launch_bounds__(1024 / NV, (M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_g
     for (int q = 0; q < NQ; ++q) { const int k = kk + KP * q; if (ok && k < nz) p[base + x + (size_t)k * kst] = shz[x * P + k + k / M]; }
   }
 }
-template <int M, int NV>
+template <int M, int NV, int PER = 0>
 static void launch_gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, real lscale, const real *da, const real *db, const real *dc,
                                 real *p, int fixnull, const TileMap &T) {
   constexpr int lds = 16 * (64 * (M + 1) + 4) * 8;
   static bool once = false;
-  if (!once) { hipFuncSetAttribute((const void *)k_gaussel_tile<M, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
+  if (!once) { hipFuncSetAttribute((const void *)k_gaussel_tile<M, NV, PER>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
   if (!c->d_abct) { if (hipMalloc(&c->d_abct, 2 * 3 * 64 * 16 * sizeof(real)) != hipSuccess) { c->d_abct = nullptr; return; } }
   // the pressure operands never change: their table is built once (Helmholtz operands are rescaled every substep -> second table)
   const bool pressure = da == c->d_a;
   real *tab = c->d_abct + (pressure ? 0 : 3 * 64 * 16);
-  if (!pressure || !c->abct_ready) hipLaunchKernelGGL(k_abc_chunked, dim3((64 * M + 255) / 256), dim3(256), 0, c->stream, nz, M, da, db, dc, tab);
+  // (periodic z: the table holds the n-1 rows of the system proper; identity rows from row n on)
+  if (!pressure || !c->abct_ready) hipLaunchKernelGGL(k_abc_chunked, dim3((64 * M + 255) / 256), dim3(256), 0, c->stream, PER ? nz - 1 : nz, M, da, db, dc, tab);
   if (pressure) c->abct_ready = true;
-  hipLaunchKernelGGL((k_gaussel_tile<M, NV>), dim3((ndbl + 15) / 16, nrow), dim3(1024 / NV), lds, c->stream, c->g, nz, ndbl, lscale, tab,
-                     c->d_lamx, c->d_lamy, p, fixnull, T);
+  hipLaunchKernelGGL((k_gaussel_tile<M, NV, PER>), dim3((ndbl + 15) / 16, nrow), dim3(1024 / NV), lds, c->stream, c->g, nz, ndbl, lscale, tab,
+                     c->d_lamx, c->d_lamy, p, fixnull, T, da, db, dc);
 }
 // one rank: ndbl doubles of each of the nrow rows; several ranks (T.blocked): nrow = peers, ndbl = 2 cw n2l doubles per plane of a peer block
-template <int NV>
+template <int NV, int PER = 0>
 static bool gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, real lscale, const real *da, const real *db, const real *dc,
                          real *p, int fixnull, const TileMap &T) {
-  if (nz < 2 || nz > 1024 || c->fl.gaussel_march) return false;
-  if (nz <= 128) launch_gaussel_tile<2, NV>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T);
-  else if (nz <= 256) launch_gaussel_tile<4, NV>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T);
-  else if (nz <= 512) launch_gaussel_tile<8, NV>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T);
-  else launch_gaussel_tile<16, NV>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T);
+  if (nz < (PER ? 4 : 2) || nz > 1024 || c->fl.gaussel_march) return false;
+  if (nz <= 128) launch_gaussel_tile<2, NV, PER>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T);
+  else if (nz <= 256) launch_gaussel_tile<4, NV, PER>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T);
+  else if (nz <= 512) launch_gaussel_tile<8, NV, PER>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T);
+  else launch_gaussel_tile<16, NV, PER>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T);
   return true;
 }
 
@@ -1280,11 +1329,14 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
     if (c->xkind && !c->ykind)       // real x modes paired into complex columns + periodic y: Hermitian separation of rows ky and N-ky
       hipLaunchKernelGGL(k_gaussel_herm, dim3((unsigned)(((long)4 * ncol * (n2g / 2 + 1) + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, lscale,
                          da, db, dc, c->d_lamx, c->d_lamy, (real *)mode_spec, c->scr1, fixnull);
-    else if (!periodic_z && !c->fl.gaussel_pair && (fixnull || !poisson || CBP(c, 0, 3) == 'D' || CBP(c, 1, 3) == 'D') &&
+    else if (!c->fl.gaussel_pair && (periodic_z || fixnull || !poisson || CBP(c, 0, 3) == 'D' || CBP(c, 1, 3) == 'D') &&
              [&]() {
                TileMap T{}; T.blocked = dist ? 1 : 0; T.cw = c->cw; T.n2l = n[1]; T.mofs = mofs; T.nmode = c->xkind ? c->C.ng[0] / 2 : mh;
                T.kstride = (size_t)2 * c->cw * n[1]; T.segstride = T.kstride * n[2];
                const int ndbl = dist ? 2 * c->cw * n[1] : (c->xkind ? 2 * (c->C.ng[0] / 2) : 2 * mh), nseg = dist ? c->P : n2g;
+               if (periodic_z)      // the cyclic closure inside the tile (gaussel_periodic, solver.f90:109-150)
+                 return c->xkind ? gaussel_tile<1, 1>(c, nz, ndbl, nseg, lscale, da, db, dc, (real *)mode_spec, fixnull, T)
+                                 : gaussel_tile<2, 1>(c, nz, ndbl, nseg, lscale, da, db, dc, (real *)mode_spec, fixnull, T);
                return c->xkind ? gaussel_tile<1>(c, nz, ndbl, nseg, lscale, da, db, dc, (real *)mode_spec, fixnull, T)
                                : gaussel_tile<2>(c, nz, ndbl, nseg, lscale, da, db, dc, (real *)mode_spec, fixnull, T); }()) {}
     else if (c->xkind && !periodic_z && !c->fl.gaussel_pair)
