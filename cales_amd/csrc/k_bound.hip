@@ -252,10 +252,15 @@ struct WmArgs {
   const real *mag_a, *mag_b;       // *_mag planes (side ibound)
   const real *zc, *zf, *dzc;
 };
-// blockIdx.z = 0: first tangential component loop, 1: second (wmodel.f90:138-153/154-170, 189-204/205-221, 240-255/256-271)
-__global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmArgs A) {
+// All wall-model faces of a bounduvw in one launch (a channel has two, a duct four): blockIdx.z = 2 face + component; the grid spans the
+// largest face and the blocks beyond a smaller one return.
+// component 0: first tangential component loop, 1: second (wmodel.f90:138-153/154-170, 189-204/205-221, 240-255/256-271)
+struct WmJobs { WmArgs a[6]; int n; };
+__global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmJobs J) {
+  const WmArgs &A = J.a[blockIdx.z >> 1];
   const int na = A.idir == 1 ? g.n2 : g.n1, nb = A.idir == 3 ? g.n2 : g.n3;
-  const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y, comp = blockIdx.z;
+  const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y, comp = blockIdx.z & 1;
+  if (a > na + 1 || b > nb + 1) return;
   const size_t ld = na + 2;
   const real visci = 1. / A.visc;
   real t1, t2;
@@ -334,9 +339,10 @@ __global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmArgs A) {
 
 static int updt_wallmodelbc(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, const real *u, const real *v, const real *w) {
   const int *n = c->n; const real h = c->C.hwm; const real *dl = c->dl;
+  WmJobs J; J.n = 0; int gx = 0, gy = 0;
   for (int idir = 1; idir <= 3; ++idir) for (int ib = 0; ib <= 1; ++ib) {
     if (!(ISB(c, ib, idir) && LWM(c, ib, idir) != 0)) continue;
-    WmArgs A; A.idir = idir; A.ibound = ib; A.mtype = LWM(c, ib, idir); A.h = h; A.visc = c->visc; A.l1d = c->C.l[idir - 1];
+    WmArgs &A = J.a[J.n++]; A.idir = idir; A.ibound = ib; A.mtype = LWM(c, ib, idir); A.h = h; A.visc = c->visc; A.l1d = c->C.l[idir - 1];
     A.u = u; A.v = v; A.w = w; A.zc = c->d_zc; A.zf = c->d_zf; A.dzc = c->d_dzc;
     const int index = IWM(c, ib, idir);
     A.i2 = index; A.i1 = ib == 0 ? index - 1 : index + 1; A.sgn = ib == 0 ? 1. : -1.;
@@ -348,9 +354,9 @@ static int updt_wallmodelbc(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, co
     A.bc_a = const_cast<real *>(plane(*ba, idir, ib, n)); A.bc_b = const_cast<real *>(plane(*bb, idir, ib, n));
     A.mag_a = plane(*ma, idir, ib, n); A.mag_b = plane(*mb, idir, ib, n);
     const int na = idir == 1 ? n[1] : n[0], nb = idir == 3 ? n[1] : n[2];
-    dim3 b(64, 4, 1), gr((na + 2 + 63) / 64, (nb + 2 + 3) / 4, 2);
-    hipLaunchKernelGGL(k_wallmodel, gr, b, 0, c->stream, c->g, A);
+    gx = std::max(gx, (na + 2 + 63) / 64); gy = std::max(gy, (nb + 2 + 3) / 4);
   }
+  if (J.n) hipLaunchKernelGGL(k_wallmodel, dim3(gx, gy, 2 * J.n), dim3(64, 4, 1), 0, c->stream, c->g, J);
   HIPCHK(c, hipGetLastError());
   return 0;
 }

@@ -168,9 +168,10 @@ __global__ __launch_bounds__(64 * (TYM + 2), (TYM <= 6 ? 4 : 3)) void k_momrk(Ge
 // reads them when its sampling height lies between the wall and the first cell centre (index_wm = 1 or n: wmodel.f90:120-131 with i1 = 0 /
 // n+1). The fused kernel writes the new velocities to a second set of buffers: with a wall model the ghost layers travel along.
 struct GhostCopy { const real *src[3]; real *dst[3]; };
-__global__ __launch_bounds__(256) void k_copy_ghosts(Geom g, int idir, GhostCopy G) {
+__global__ __launch_bounds__(256) void k_copy_ghosts(Geom g, GhostCopy G) {      // blockIdx.z = 6 (idir - 1) + 2 field + side; the grid spans the largest face
+  const int idir = blockIdx.z / 6 + 1, fs = blockIdx.z % 6;
   const int na = idir == 1 ? g.n2 : g.n1, nb = idir == 3 ? g.n2 : g.n3, n = idir == 1 ? g.n1 : idir == 2 ? g.n2 : g.n3;
-  const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y, f = blockIdx.z >> 1, side = blockIdx.z & 1;
+  const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y, f = fs >> 1, side = fs & 1;
   if (a > na + 1 || b > nb + 1) return;
   const int m = side ? n + 1 : 0;
   const size_t c = idir == 1 ? g.ix(m, a, b) : idir == 2 ? g.ix(a, m, b) : g.ix(a, b, m);
@@ -213,10 +214,8 @@ int op_momrk(cales_ctx *c, real f1, real f2, real f12) {
   bool wm = false; for (int q = 0; q < 6; ++q) wm = wm || c->C.lwm[q] != 0;
   if (wm) {
     GhostCopy G; for (int q = 0; q < 3; ++q) { G.src[q] = c->f[CALES_U + q]; G.dst[q] = c->f2[q]; }
-    for (int idir = 1; idir <= 3; ++idir) {
-      const int na = idir == 1 ? n[1] : n[0], nb = idir == 3 ? n[1] : n[2];
-      hipLaunchKernelGGL(k_copy_ghosts, dim3((na + 2 + 63) / 64, (nb + 2 + 3) / 4, 6), dim3(64, 4, 1), 0, c->stream, c->g, idir, G);
-    }
+    const int na = std::max(n[0], n[1]), nb = std::max(n[1], n[2]);
+    hipLaunchKernelGGL(k_copy_ghosts, dim3((na + 2 + 63) / 64, (nb + 2 + 3) / 4, 18), dim3(64, 4, 1), 0, c->stream, c->g, G);
     HIPCHK(c, hipGetLastError());
   }
   for (int q = 0; q < 3; ++q) std::swap(c->f[CALES_U + q], c->f2[q]);
