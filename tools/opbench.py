@@ -12,7 +12,7 @@ def main():
     ap.add_argument("--sgs", default="dsmag")
     ap.add_argument("--ops", nargs="+", default=["cmpt_sgs"])
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--noprof", action="store_true", help="no per-kernel events (what a production step looks like; lets cales_step replay its hipGraph)")
+    ap.add_argument("--noprof", action="store_true", help="no per-kernel events (what a production step looks like)")
     ap.add_argument("--golden", default=None, help="take the case (BCs, forcing, sgs, impdiff) from tests/golden/<name>.npz instead of the bench channel")
     a = ap.parse_args()
     import bench
