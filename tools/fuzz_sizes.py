@@ -8,18 +8,25 @@ from cales_amd.hotpath import HotPath, initflow
 from oracle.oracle import Oracle
 
 def case_lwm(name):
-    return load_golden(name)[1].lwm != 0
+    return np.zeros(1, bool) if name.startswith("open:") else load_golden(name)[1].lwm != 0
 
 
 rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 names = ["chan_dsmag", "chan_dsmag_wm", "chan_smag_wm", "tgv_dsmag_ppp", "cavity_nnn", "duct_smag_wm_imp1d", "couette_imp3d_ops", "chan_smag",
-         "duct_dsmag_wm", "duct_dsmag", "cavity_dsmag", "duct_smag_wm", "tgv_ppp", "devchan_nd", "halfchan_imp1d"]
+         "duct_dsmag_wm", "duct_dsmag", "cavity_dsmag", "duct_smag_wm", "tgv_ppp", "devchan_nd", "halfchan_imp1d",
+         "open:0", "open:1", "open:4", "open:5", "open:7", "open:8"]      # 3-D implicit diffusion with open boundaries (tests/test_gpu_vs_oracle.py OPEN_SETS)
 bad = 0
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
     name = names[trial % len(names)]
     ng = tuple(int(2 * rng.randint(2, 40)) for _ in range(2)) + (int(rng.randint(9, 80)),)      # ng(3) may be odd
     if np.any(case_lwm(name)): ng = ng[:2] + (max(ng[2], 12),)
-    g, case = load_golden(name); case.ng[:] = ng
+    if name.startswith("open:"):
+        from tests.test_gpu_vs_oracle import OPEN_SETS, _open_case
+        xs, ys, _ = OPEN_SETS[int(name[5:])]
+        case = _open_case(xs, ys, ng); case.inivel = "uni"
+    else:
+        g, case = load_golden(name); case.ng[:] = ng
+        if case.sgstype == "none" and case.cbcvel[0, 0, 0] != "P": case.cbcsgs[:, 0] = "D"      # see tests/test_gpu_golden.py
     if np.any(case.lwm != 0):      # a sampling height the reference accepts on this grid (sanity.f90:224-231)
         case.hwm = max(float(case.hwm), 1.6 * max(float(case.l[d]) / ng[d] for d in range(3) if case.lwm[:, d].any()))
     if case.inivel == "hcp": case.inivel = "poi"
