@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--ng", type=int, nargs=3, default=[512, 512, 512])
     ap.add_argument("--sgs", default="dsmag", choices=["none", "smag", "dsmag"])
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: several ranks on ONE GPU with host-staged messages (tests of the launch path on a one-GPU box; not a measurement)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -152,9 +154,14 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if a.backend == "gloo":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
 
@@ -212,7 +219,7 @@ def main():
     t_prof = time.perf_counter() - t0
     h.profile(False)
     if world > 1:
-        tt = torch.tensor([t, t_prof], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([t, t_prof], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t, t_prof = float(tt[0].item()), float(tt[1].item())
     stats = h.profile_stats()
@@ -253,7 +260,9 @@ def main():
             "config": {"workload": f"turbulent channel {case.ng[0]}x{case.ng[1]}x{case.ng[2]}, sgstype={case.sgstype}, "
                                    "PP/PP/NN pressure BCs, bulk forcing in x (BASELINE.json configs[2]); 3 RK substeps/step",
                        "decomposition": f"y-slabs x{world}" if world > 1 else "single GPU", "dt": dt,
-                       "exchanges": ("RCCL from the library" if getattr(h, "native", False) else "torch.distributed callbacks") if world > 1 else None},
+                       "exchanges": ("RCCL from the library" if getattr(h, "native", False) else
+                                     "gloo with host staging, ranks sharing one GPU: a test of the launch path, NOT a measurement" if a.backend == "gloo" else
+                                     "torch.distributed callbacks") if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": ach / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": WORDS[dom] * RB * nloc, "avg_launch_ms": ms / calls, "launches": calls},

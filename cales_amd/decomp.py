@@ -132,6 +132,65 @@ class TorchComm:
         return 0
 
 
+class StagedGlooComm(TorchComm):
+    """The same exchanges over a gloo process group with the library's buffers on the GPU: every message is staged through host memory
+    (device -> pinned host, gloo, host -> device), in order on the library's stream. Not a production path -- RCCL is (comm_rccl.cpp or
+    TorchComm on nccl) -- but it runs several real PROCESSES on ONE GPU, which RCCL refuses ("Duplicate GPU detected"): the process-level
+    orchestration of `bench.py --gpus N` and of the slab layer (rendezvous, rank order, slab-wise initial fields, reductions over ranks) is
+    executed on the one-GPU test box this way."""
+
+    def __init__(self, dist, torch, A, B, periodic_y: bool, group=None):
+        super().__init__(dist, torch, A, B, periodic_y, group)
+        self.dA, self.dB = A, B
+        self.hA = torch.empty(A.numel(), dtype=A.dtype).pin_memory()
+        self.hB = torch.empty(B.numel(), dtype=B.dtype).pin_memory()
+
+    def _down(self, dev, host, slices):
+        for sl in slices:
+            host[sl].copy_(dev[sl], non_blocking=True)
+        self.torch.cuda.current_stream().synchronize()
+
+    def _up(self, dev, host, slices):
+        for sl in slices:
+            dev[sl].copy_(host[sl], non_blocking=True)
+
+    def halo(self, off_slo, off_shi, off_rlo, off_rhi, count) -> int:
+        lo, hi = y_neighbours(self.r, self.P, self.per)
+        send = ([slice(off_slo, off_slo + count)] if lo is not None else []) + ([slice(off_shi, off_shi + count)] if hi is not None else [])
+        recv = ([slice(off_rhi, off_rhi + count)] if hi is not None else []) + ([slice(off_rlo, off_rlo + count)] if lo is not None else [])
+        self._down(self.dA, self.hA, send)
+        self.A, self.B = self.hA, self.hB
+        try:
+            super().halo(off_slo, off_shi, off_rlo, off_rhi, count)
+        finally:
+            self.A, self.B = self.dA, self.dB
+        self._up(self.dB, self.hB, recv)
+        return 0
+
+    def alltoall(self, direction, count) -> int:
+        n = self.P * count
+        dsrc, hsrc, ddst, hdst = (self.dA, self.hA, self.dB, self.hB) if direction == 0 else (self.dB, self.hB, self.dA, self.hA)
+        self._down(dsrc, hsrc, [slice(0, n)])
+        self.A, self.B = self.hA, self.hB
+        try:
+            super().alltoall(direction, count)
+        finally:
+            self.A, self.B = self.dA, self.dB
+        self._up(ddst, hdst, [slice(0, n)])
+        return 0
+
+    def allreduce(self, off, count, op) -> int:
+        sl = [slice(off, off + count)]
+        self._down(self.dA, self.hA, sl)
+        self.A = self.hA
+        try:
+            super().allreduce(off, count, op)
+        finally:
+            self.A = self.dA
+        self._up(self.dA, self.hA, sl)
+        return 0
+
+
 class LoopbackWorld:
     """Shared state of P emulated ranks (threads) on one device."""
 
@@ -250,6 +309,8 @@ class SlabHotPath(HotPath):
         per_y = bool(case.cbcpre[0, 1] == "P" and case.cbcpre[1, 1] == "P")
         if loopback is not None:
             self.comm = LoopbackComm(loopback, rank, torch, self.A, self.B, per_y, self.stream)
+        elif dist.get_backend() == "gloo":      # several processes on one GPU (tests): messages staged through the host
+            self.comm = StagedGlooComm(dist, torch, self.A, self.B, per_y)
         else:
             self.comm = TorchComm(dist, torch, self.A, self.B, per_y)
         # keep the ctypes thunks alive for the life of the context
@@ -261,7 +322,8 @@ class SlabHotPath(HotPath):
         # exchanges beside the kernels on the library's second stream (CALES_NO_OVERLAP keeps them in order on the one stream)
         self._cb2 = (HALO_S_CB(lambda u, a, b, c_, d, n_, st: self._guard2(self.comm.halo_s, a, b, c_, d, n_, st)),
                      A2A_PART_CB(lambda u, d, ps, o, n_, st: self._guard2(self.comm.alltoall_part, d, ps, o, n_, st)))
-        self._chk(self.L.cales_set_comm_overlap(self.h, self._cb2[0], self._cb2[1]))
+        if not isinstance(self.comm, StagedGlooComm):      # (the staged exchanges block the host: kept in order on the one stream)
+            self._chk(self.L.cales_set_comm_overlap(self.h, self._cb2[0], self._cb2[1]))
 
     def _init_native(self, dist) -> bool:
         """Rank 0 creates the RCCL rendezvous token, torch.distributed carries it, every rank joins (collective). All ranks

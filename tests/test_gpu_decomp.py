@@ -143,3 +143,36 @@ def test_n_rank_nccl_process_group(layer):
                         "--master-port", str(29581 + (layer == "torch")), os.path.join(here, "_ncclN_worker.py")],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "NCCLN OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_n_processes_one_gpu_staged_gloo(P):
+    """Real processes (torch.distributed.run, one per rank) sharing the ONE GPU of the test box: RCCL refuses that, so the exchanges go
+    through gloo with host staging (decomp.StagedGlooComm). Everything else is the production path of `bench.py --gpus N`: rendezvous, rank
+    order, slab-wise initial fields, packing kernels, mode-block layout, reductions -- against the single-rank run, as the nccl test does."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, CALES_TEST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={P}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29591 + P), os.path.join(here, "_ncclN_worker.py")],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "NCCLN OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_bench_two_processes_one_gpu():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), with the two ranks on the one GPU of the
+    test box and gloo instead of RCCL (which refuses two ranks per device): the launch contract, the slab layer, the icheck blocks with their
+    reductions over ranks, the max-over-ranks timing and the JSON line with its transposition report are executed end to end."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29611", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2",
+                        "--ng", "64", "64", "32", "--backend", "gloo", "--no-cpu"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["warmup"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 1.) < 1e-9
+    assert d["config"]["decomposition"] == "y-slabs x2" and "transpose" in d and d["transpose"]["alltoall_calls_per_step"] == 6.0
+    assert d["icheck"]["blocks_in_timed_region"] >= 1
