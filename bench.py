@@ -12,6 +12,8 @@ with the fields resident in HBM. dt is fixed to 0.5*dt_cfl(initial field) (SURVE
 N > 1: one process per GPU (torch.distributed.run), y-slab decomposition of the SAME 512^3 problem
 (strong scaling), see cales_amd/decomp.py.
 """
+import os as _os
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC between the ranks' processes (RCCL); must be set before the HIP runtime starts
 import argparse
 import json
 import os
