@@ -836,7 +836,8 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
 // Same arithmetic, in the same order, as k_strain_tile<SMAG = 1> (sgs.f90:98-152, 598-680).
 constexpr int SROWS = 4;      // rows (waves) per block
 template <typename OFF, int YW>
-__global__ __launch_bounds__(64 * SROWS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_smag_rows(Geom g, StrainTileArgs A) {
+// (four waves per SIMD -- 128 VGPRs -- for channels; the duct logic needs a few registers more and would spill under that cap)
+__global__ __launch_bounds__(64 * SROWS, (YW ? 3 : 4)) void k_smag_rows(Geom g, StrainTileArgs A) {
   const int tx = threadIdx.x;
   // band map (common.hpp): the rows two waves both load (j-1, j+1, the shared columns of neighbouring x tiles) meet in one L2 instead of
   // being fetched from memory by two (measured 1.8 x the compulsory reads with the plain 3-D grid, 1.27 x with the bands)
