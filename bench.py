@@ -148,7 +148,27 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: several ranks on ONE GPU with host-staged messages (tests of the launch path on a one-GPU box; not a measurement)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="N > 1: exchanges on the library's second stream beside kernels (CALES_OVERLAP=1; default: in order on one stream, the form "
+                         "with the fewest assumptions, until a node with real peers has confirmed the overlapped one)")
     a = ap.parse_args()
+    if a.overlap:
+        os.environ["CALES_OVERLAP"] = "1"
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: start the N ranks ourselves, as CHILD processes of a parent that never touches the GPU (nothing has
+        # imported torch or called HIP yet), the way the driver does (torch.distributed.run, one rank per GPU); rank 0's JSON line is relayed
+        # and the children's exit code is ours
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        sys.stdout.write(r.stdout if not lines else lines[-1] + "\n"); sys.stdout.flush()
+        raise SystemExit(r.returncode if r.returncode or lines else 1)
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -168,7 +188,7 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
 
     from cales_amd import capi
-    from cales_amd.hotpath import initflow
+    from cales_amd.hotpath import SMALL, initflow      # SMALL = epsilon(1._rp)*10**(precision(1._rp)/2) of the working precision (param.f90:24)
     capi_single = capi.SINGLE                      # CALES_PRECISION=single: the -D_SINGLE_PRECISION build (not the headline number: BASELINE.json quotes FP64)
     RB = 4.0 if capi_single else 8.0               # bytes per real
     case = channel_case(a.ng, a.sgs)
@@ -202,7 +222,7 @@ def main():
             if istep % icheck == 0:
                 dtmax = h.chkdt(); divtot, divmax = h.chkdiv()
                 checks.append((istep, dtmax, divtot, divmax))
-                if dt > dtmax * case.cfl or not np.isfinite(divtot) or divmax > 2.2e-9:       # main.f90:530,538 (fixed dt = 0.5 dt_cfl)
+                if dt > dtmax * case.cfl or not np.isfinite(divtot) or divmax > SMALL:       # main.f90:530,538 (fixed dt = 0.5 dt_cfl); small of param.f90:24
                     raise SystemExit(f"bench invalid at step {istep}: dtmax {dtmax}, divergence {divmax}")
 
     run_steps(0, a.warmup)
@@ -226,7 +246,7 @@ def main():
         t, t_prof = float(tt[0].item()), float(tt[1].item())
     stats = h.profile_stats()
     divtot, divmax = h.chkdiv()
-    if not np.isfinite(divtot) or divmax > 2.2e-9:       # the reference's abort rule, main.f90:538
+    if not np.isfinite(divtot) or divmax > SMALL:       # the reference's abort rule, main.f90:538
         raise SystemExit(f"bench invalid: divergence {divmax}")
 
     if rank == 0:
@@ -262,6 +282,8 @@ def main():
             "config": {"workload": f"turbulent channel {case.ng[0]}x{case.ng[1]}x{case.ng[2]}, sgstype={case.sgstype}, "
                                    "PP/PP/NN pressure BCs, bulk forcing in x (BASELINE.json configs[2]); 3 RK substeps/step",
                        "decomposition": f"y-slabs x{world}" if world > 1 else "single GPU", "dt": dt,
+                       "exchange_order": (("second stream beside kernels (CALES_OVERLAP=1)" if os.environ.get("CALES_OVERLAP", "0") not in ("", "0") and "CALES_NO_OVERLAP" not in os.environ
+                                           else "in order on the context's stream (default)") if world > 1 else None),
                        "exchanges": ("RCCL from the library" if getattr(h, "native", False) else
                                      "gloo with host staging, ranks sharing one GPU: a test of the launch path, NOT a measurement" if a.backend == "gloo" else
                                      "torch.distributed callbacks") if world > 1 else None},

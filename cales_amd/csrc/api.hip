@@ -399,7 +399,7 @@ int cales_set_comm(cales_ctx *c, cales_halo_cb halo, cales_alltoall_cb a2a, cale
 }
 int cales_set_comm_overlap(cales_ctx *c, cales_halo_s_cb halo_s, cales_alltoall_part_cb a2a_part) {
   if (!c->comm.on) { c->err = "cales_set_comm_overlap: call cales_set_comm first"; return 1; }
-  if (c->fl.no_overlap) return 0;      // CALES_NO_OVERLAP: keep every exchange in order on the one stream (A/B measurements, tests)
+  if (!c->fl.overlap) return 0;      // default: every exchange in order on the one stream; CALES_OVERLAP=1 opts into the second stream (Flags::read_env)
   if (!c->comm_stream) {      // highest priority: the send/receive kernels of an exchange should get their few workgroups at once, beside a full grid
     int least = 0, greatest = 0;
     HIPCHK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));

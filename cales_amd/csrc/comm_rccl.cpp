@@ -207,6 +207,41 @@ int cales_comm_selftest(void) {
   if (!rc && g_api.AllToAll(A + 2 * cnt, B + 2 * cnt, cnt, NCCL_REAL, comm, s) != ncclSuccess) rc = 110;
   if (!rc && g_api.AllReduce(A + 3 * cnt, A + 3 * cnt, cnt, NCCL_REAL, ncclSum, comm, s) != ncclSuccess) rc = 111;
   if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = 112;
+  // the exchanges of the second stream (native_alltoall_part, native_halo_s): a k-chunk = a slice of every peer block as one send/recv group on
+  // ANOTHER stream, ordered against the first by events only -- producer (a memset on s) -> event -> group on s2 -> event -> consumer copy on s
+  if (!rc) {
+    hipStream_t s2; hipEvent_t e1, e2; real *C_ = nullptr;
+    if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess || hipMalloc(&C_, cnt * sizeof(real)) != hipSuccess) rc = 130;
+    const size_t off = 100, part = 300;
+    if (!rc && hipMemsetAsync(B, 0, 4 * cnt * sizeof(real), s) != hipSuccess) rc = 131;
+    if (!rc && (hipEventRecord(e1, s) != hipSuccess || hipStreamWaitEvent(s2, e1, 0) != hipSuccess)) rc = 132;
+    if (!rc && g_api.GroupStart() != ncclSuccess) rc = 133;
+    if (!rc && g_api.Send(A + off, part, NCCL_REAL, 0, comm, s2) != ncclSuccess) rc = 134;
+    if (!rc && g_api.Recv(B + off, part, NCCL_REAL, 0, comm, s2) != ncclSuccess) rc = 135;
+    if (!rc && g_api.GroupEnd() != ncclSuccess) rc = 136;
+    if (!rc && (hipEventRecord(e2, s2) != hipSuccess || hipStreamWaitEvent(s, e2, 0) != hipSuccess)) rc = 137;
+    if (!rc && hipMemcpyAsync(C_, B, cnt * sizeof(real), hipMemcpyDeviceToDevice, s) != hipSuccess) rc = 138;
+    if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = 139;
+    if (!rc) {
+      std::vector<real> cc(cnt);
+      hipMemcpy(cc.data(), C_, cnt * sizeof(real), hipMemcpyDeviceToHost);
+      for (size_t q = 0; q < cnt && !rc; ++q) if (cc[q] != ((q >= off && q < off + part) ? h[q] : (real)0)) rc = 140;
+    }
+    hipStreamSynchronize(s2); hipStreamDestroy(s2); hipEventDestroy(e1); hipEventDestroy(e2); hipFree(C_);
+    // restore what the checks below expect of B
+    if (!rc) {
+      hipMemset(B, 0, 4 * cnt * sizeof(real));
+      if (g_api.GroupStart() != ncclSuccess) rc = 141;
+      if (!rc && g_api.Send(A, cnt, NCCL_REAL, 0, comm, s) != ncclSuccess) rc = 142;
+      if (!rc && g_api.Recv(B + cnt, cnt, NCCL_REAL, 0, comm, s) != ncclSuccess) rc = 143;
+      if (!rc && g_api.Send(A + cnt, cnt, NCCL_REAL, 0, comm, s) != ncclSuccess) rc = 144;
+      if (!rc && g_api.Recv(B, cnt, NCCL_REAL, 0, comm, s) != ncclSuccess) rc = 145;
+      if (!rc && g_api.GroupEnd() != ncclSuccess) rc = 146;
+      if (!rc && g_api.AllToAll(A + 2 * cnt, B + 2 * cnt, cnt, NCCL_REAL, comm, s) != ncclSuccess) rc = 147;
+      if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = 148;
+    }
+  }
   if (!rc) {
     std::vector<real> b(4 * cnt), a(4 * cnt);
     hipMemcpy(b.data(), B, 4 * cnt * sizeof(real), hipMemcpyDeviceToHost); hipMemcpy(a.data(), A, 4 * cnt * sizeof(real), hipMemcpyDeviceToHost);

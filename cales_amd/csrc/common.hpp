@@ -68,7 +68,7 @@ struct Spec {
 
 // Run-time switches: read from the environment ONCE, by cales_create; the launch path only looks at these fields.
 struct Flags {
-  bool unaligned = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_eager = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, gaussel_pair = false, unfused_rk = false, dsmag_unfused_filter = false, no_overlap = false, unmerged_bc = false, smag_tile = false, plain_grid = false, band_grid = false;
+  bool unaligned = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_eager = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, gaussel_pair = false, unfused_rk = false, dsmag_unfused_filter = false, overlap = false, unmerged_bc = false, smag_tile = false, plain_grid = false, band_grid = false;
   int kchunk = 0; long tile_min_blocks = 2048; int smag_ty = 10;
   void read_env() {
     unaligned = getenv("CALES_UNALIGNED") != nullptr;
@@ -93,7 +93,9 @@ struct Flags {
     gaussel_pair = getenv("CALES_GAUSSEL_PAIR") != nullptr;
     unfused_rk = getenv("CALES_UNFUSED_RK") != nullptr;
     dsmag_unfused_filter = getenv("CALES_DSMAG_UNFUSED_FILTER") != nullptr;
-    no_overlap = getenv("CALES_NO_OVERLAP") != nullptr;
+    // exchanges beside the kernels on a second stream: opt-in (CALES_OVERLAP=1) until a run with real peers has confirmed it -- the emulated
+    // ranks of the tests cannot show a gain, and the in-order exchanges are the form with the fewest assumptions (CALES_NO_OVERLAP wins)
+    overlap = getenv("CALES_OVERLAP") != nullptr && atoi(getenv("CALES_OVERLAP")) != 0 && getenv("CALES_NO_OVERLAP") == nullptr;
     unmerged_bc = getenv("CALES_UNMERGED_BC") != nullptr;
     kchunk = getenv("CALES_KCHUNK") ? atoi(getenv("CALES_KCHUNK")) : 0;
     tile_min_blocks = getenv("CALES_TILE_MIN_BLOCKS") ? atol(getenv("CALES_TILE_MIN_BLOCKS")) : 2048;
@@ -262,6 +264,9 @@ void solver_teardown(cales_ctx *c);
 // same value costs an s_waitcnt vmcnt(0) in the middle of a prefetch)
 // (in the LDS-heavy last dsmag pass the same change measured 7 % slower -- scalar loads share lgkmcnt with the LDS reads and return
 // out of order, so waiting for one drains the LDS queue -- and that kernel keeps its vector loads)
+// ONLY for data no kernel writes while a kernel reads it through here: the scalar cache is not coherent with vector stores inside a launch (it is
+// invalidated at kernel boundaries). The grid tables never change; the plane coefficients d_cs of the dynamic model are written by k_dsmag_coef and
+// read through ldc by LATER launches only (k_momrk) -- a kernel that both wrote and read them would see stale values.
 __device__ inline real ldc(const real *p, int k) { return ((const __attribute__((address_space(4))) real *)p)[k]; }
 template <typename OFF> __device__ inline real ldb(const real *b, OFF o) { return *(const real *)((const char *)b + o); }
 template <typename OFF> __device__ inline void stb(real *b, OFF o, real v) { *(real *)((char *)b + o) = v; }
@@ -282,8 +287,8 @@ __device__ inline real dpp_f64(real v) {       // lanes without a source receive
 }
 __device__ inline real lane_prev(real v) { return dpp_f64<0x138>(v); }   // wave_shr:1, lane i <- lane i-1 (lane 0 <- 0)
 __device__ inline real lane_next(real v) { return dpp_f64<0x130>(v); }   // wave_shl:1, lane i <- lane i+1 (lane 63 <- 0)
-// sum over the 64 lanes, valid in lane 63 only (row_shr 1,2,4,8 then row_bcast 15 and 31; the rows the two broadcasts mask out
-// add their own value to themselves -- they never reach lane 63)
+// sum over the 64 lanes, valid in lane 63 ONLY (row_shr 1,2,4,8 then row_bcast 15 and 31; the rows the two broadcasts mask out
+// add their own value to themselves, so every other lane ends with garbage -- callers must consume the result in lane 63 and nowhere else)
 __device__ inline real wave_sum_lane63(real s) {
   s += dpp_f64<0x111>(s); s += dpp_f64<0x112>(s); s += dpp_f64<0x114>(s); s += dpp_f64<0x118>(s);
   s += dpp_f64<0x142, 0xa>(s); s += dpp_f64<0x143, 0xc>(s);

@@ -108,7 +108,8 @@ static int strain_rate(cales_ctx *c, const real *u, const real *v, const real *w
 struct SmagArgs { real w0, w1, w2, w3, w4, w5, dl1, dl2, l3, dxi, dyi, visc, sumw; };
 __global__ __launch_bounds__(BX *BY) void k_smag(Geom g, SmagArgs A, const real *__restrict__ zc, const real *__restrict__ dzci,
                                                   const real *__restrict__ dzf, const real *__restrict__ u, const real *__restrict__ v,
-                                                  const real *__restrict__ w, const real *__restrict__ s0, real *__restrict__ visct) {
+                                                  const real *__restrict__ w, const real *__restrict__ s0, real *__restrict__ visct,
+                                                  const real *__restrict__ twy) {      // twy != null (several slabs): sqrt(tau_w) planes of the two y walls, see wall_shear_y_planes
   int bx_, by_, bz_; stencil_block(bx_, by_, bz_);
   const int i = bx_ * BX + threadIdx.x + 1, j = by_ * BY + threadIdx.y + 1, k = bz_ + 1;
   if (i > g.n1 || j > g.n2) return;
@@ -127,8 +128,12 @@ __global__ __launch_bounds__(BX *BY) void k_smag(Geom g, SmagArgs A, const real 
 #pragma unroll
     for (int q = 1; q < 6; ++q) if (dw[q] < dw[loc]) loc = q;
     const real dw_min = dw[loc];
-    real t1, t2, sc;
+    real t1 = 0., t2 = 0., sc = 0.;
     const int n1 = g.n1, n2 = g.n2, n3 = g.n3;
+    if (twy && (loc == 2 || loc == 3)) {      // the y walls belong to the first and the last slab: their shear arrives as planes (same arithmetic, k_wall_shear_y)
+      const real dw_plus = dw_min * twy[(size_t)(loc == 2 ? k : n3 + 2 + k) * g.s1 + i] * (1. / A.visc);
+      fd = 1. - exp(-dw_plus / 25.);
+    } else {
     switch (loc) {
     case 0: t1 = v[g.ix(1, j, k)] - v[g.ix(0, j, k)] + v[g.ix(1, j - 1, k)] - v[g.ix(0, j - 1, k)];
             t2 = w[g.ix(1, j, k)] - w[g.ix(0, j, k)] + w[g.ix(1, j, k - 1)] - w[g.ix(0, j, k - 1)]; sc = A.dxi; break;
@@ -147,6 +152,7 @@ __global__ __launch_bounds__(BX *BY) void k_smag(Geom g, SmagArgs A, const real 
     tauw_s = 0.5 * A.visc * tauw_s;
     const real dw_plus = dw_min * sqrt(tauw_s) * (1. / A.visc);
     fd = 1. - exp(-dw_plus / 25.);
+    }
   }
   const real t = 0.11 * dzf[k] * fd;        // dzf[] here is the table (dx dy dzf(k))^(1/3) of k_smag_del (sgs.f90:145); c_smag, src/param.f90:33
   const size_t c = g.ix(i, j, k);
@@ -1001,6 +1007,10 @@ static int dsmag_fast(cales_ctx *c) {
   const int skipz = (zlo && zhi) ? 4 : 0;
   // several ranks with the second stream: the y-halo rows of the twelve scratch fields travel while the interior tiles of the last pass run
   const bool overlap = c->P > 1 && c->comm.halo_s && c->comm_stream && !c->fl.dsmag_unfused_filter;
+  // (every check that can fail comes BEFORE the deferred exchange is queued: an error return behind halo_flush_deferred would leave the
+  //  exchange in flight on the second stream with nobody joining it)
+  { dim3 tb, tg; int tk; tiles(c->fl.dsmag_unfused_filter ? TYF : TYL, 62, tb, tg, tk);
+    if ((size_t)2 * n[2] * tg.x * tg.y > c->ntot) { c->err = "dsmag: partial-sum scratch too small"; return 1; } }
   c->defer_halo = overlap;
   c->bc_skip = perx | skipz;
   int e_ = op_boundp_multi(c, 6, ssij, 1);
@@ -1022,7 +1032,6 @@ static int dsmag_fast(cales_ctx *c) {
     ProfScope ps(c, "lij_mij_filter_contract");
     tiles(TYL, 62, mb, mg, kch);
     L.kchunk = kch; L.nblk = mg.x * mg.y;
-    if ((size_t)2 * n[2] * L.nblk > c->ntot) { c->err = "dsmag: partial-sum scratch too small"; return 1; }
     LmfArgs B; B.L = L; for (int m = 0; m < 6; ++m) B.ss[m] = ssij[m];
     auto launch = [&](int by0, int nby) {
       if (nby <= 0) return;
@@ -1052,7 +1061,6 @@ static int dsmag_fast(cales_ctx *c) {
   { ProfScope ps(c, "lij_mij_contract");
     tiles(TYF, 62, mb, mg, kch);
     L.kchunk = kch; L.nblk = mg.x * mg.y;
-    if ((size_t)2 * n[2] * L.nblk > c->ntot) { c->err = "dsmag: partial-sum scratch too small"; return 1; }
     if (small) hipLaunchKernelGGL(k_lij_mij_tile<unsigned>, mg, mb, 0, c->stream, c->g, L); else hipLaunchKernelGGL(k_lij_mij_tile<size_t>, mg, mb, 0, c->stream, c->g, L);
     hipLaunchKernelGGL(k_plane_fold, dim3(2 * n[2]), dim3(256), 0, c->stream, n[2], L.nblk, c->wk[0], c->d_p1d); }
   }
@@ -1079,6 +1087,30 @@ __global__ void k_smag_del(int n, real dl1, real dl2, const real *__restrict__ d
   const int k = blockIdx.x * 64 + threadIdx.x;
   if (k < n) del[k] = pow(dl1 * dl2 * dzf[k], 1. / 3.);       // the filter width depends on k only (sgs.f90:145)
 }
+// sqrt(tau_w) of the two y walls as planes twy(side, k, i) for the van Driest damping of cells whose nearest wall is a y wall (sgs.f90:117-143,
+// cases 3 and 4). One slab: straight from the fields. Several slabs: the walls belong to the first and the last slab, every other rank needs
+// their shear too -- the reference stays within "two subdomains between two opposite walls" (sanity.f90:98-111) because its 2-D pencil grid
+// can (initmpi.f90:230-259); y slabs cannot, so the owners fill their plane, everybody else zeros, and one sum over the slabs (x + 0 + ... + 0:
+// exact) hands both planes to every rank. The planes sit at the head of the staging buffer A, which is free between two exchanges.
+static int wall_shear_y_planes(cales_ctx *c, int wylo, int wyhi, const real **out) {
+  const int *n = c->n;
+  const size_t cnt = (size_t)2 * (n[2] + 2) * c->g.s1;
+  real *twy = c->wk[0];
+  if (c->P > 1) {
+    if (!c->comm.on) { c->err = "nranks > 1 but no communication hooks registered (cales_set_comm)"; return 1; }
+    if ((int64_t)cnt > c->res - c->comm.A) { c->err = "smag: staging buffer too small for the wall-shear planes"; return 1; }
+    twy = c->comm.A;
+    if (c->comm_stream) if (int e = stream_after(c, c->stream, c->comm_stream)) return e;      // nothing of an overlapped exchange may still use A
+    HIPCHK(c, hipMemsetAsync(twy, 0, cnt * sizeof(real), c->stream));
+  } else if (cnt > c->ntot) { c->err = "smag: wall-shear scratch too small"; return 1; }
+  const int lo = wylo && ISB(c, 0, 2) ? 1 : 0, hi = wyhi && ISB(c, 1, 2) ? 1 : 0;
+  if (lo || hi)
+    hipLaunchKernelGGL(k_wall_shear_y, dim3((n[0] + 63) / 64, (n[2] + 3) / 4), dim3(64, 4), 0, c->stream, c->g, c->f[CALES_U], c->f[CALES_W], c->visc, c->dli[1], lo, hi, twy);
+  HIPCHK(c, hipGetLastError());
+  if (c->P > 1 && c->comm.allred(c->comm.user, 0, (int64_t)cnt, 0)) { c->err = "allreduce callback failed (wall-shear planes)"; return 1; }
+  *out = twy;
+  return 0;
+}
 static int smag_fast(cales_ctx *c) {
   const int *n = c->n; real **f = c->f;
   if (!c->d_del) {
@@ -1102,18 +1134,11 @@ static int smag_fast(cales_ctx *c) {
   S.wmlo = ISB(c, 0, 3) && LWM(c, 0, 3) != 0; S.wmhi = ISB(c, 1, 3) && LWM(c, 1, 3) != 0;
   S.flo = (1. / c->dzci[0]) * c->dzci[1]; S.fhi = (1. / c->dzci[n[2]]) * c->dzci[n[2] - 1];
   S.zc = c->d_zc; S.del = c->d_del; S.l3 = c->C.l[2]; S.visc = c->visc;
-  // walls in y (ducts): is_wall(2:3) is a property of the case; the rank that owns a wall supplies its shear (at most two ranks
-  // between two opposite walls, sanity.f90:98-111, so every cell's nearest y wall is its own rank's)
+  // walls in y (ducts): is_wall(2:3) is a property of the case, distances use global rows, and the shear of both y walls reaches every slab
   S.wylo = c->is_wall[2] != 0.; S.wyhi = c->is_wall[3] != 0.; S.dl2 = c->dl[1];
   S.wmylo = ISB(c, 0, 2) && LWM(c, 0, 2) != 0; S.wmyhi = ISB(c, 1, 2) && LWM(c, 1, 2) != 0;
   S.twy = nullptr;
-  if (S.wylo || S.wyhi) {
-    real *twy = c->wk[0];      // scratch field: 2 x (n3+2) rows of s1 values
-    if ((size_t)2 * (n[2] + 2) * c->g.s1 > c->ntot) { c->err = "smag: wall-shear scratch too small"; return 1; }
-    hipLaunchKernelGGL(k_wall_shear_y, dim3((n[0] + 63) / 64, (n[2] + 3) / 4), dim3(64, 4), 0, c->stream, c->g, f[CALES_U], f[CALES_W], c->visc, c->dli[1],
-                       S.wylo && ISB(c, 0, 2) ? 1 : 0, S.wyhi && ISB(c, 1, 2) ? 1 : 0, twy);
-    S.twy = twy;
-  }
+  if (S.wylo || S.wyhi) { if (int e = wall_shear_y_planes(c, S.wylo, S.wyhi, &S.twy)) return e; }
   const bool small = (c->ntot + 16) * sizeof(real) < (1ull << 32) && !c->fl.wide_offsets;
   const bool yw = S.wylo || S.wyhi || S.wmylo || S.wmyhi;
   if (!c->fl.smag_tile) {
@@ -1183,7 +1208,9 @@ int op_cmpt_sgs(cales_ctx *c) {
       HIPCHK(c, hipMalloc(&c->d_del, (n[2] + 2) * sizeof(real)));
       hipLaunchKernelGGL(k_smag_del, dim3((n[2] + 2 + 63) / 64), dim3(64), 0, c->stream, n[2] + 2, c->dl[0], c->dl[1], c->d_dzf, c->d_del);
     }
-    hipLaunchKernelGGL(k_smag, gr, b, 0, c->stream, c->g, A, c->d_zc, c->d_dzci, c->d_del, f[CALES_U], f[CALES_V], f[CALES_W], c->s0, visct);
+    const real *twy = nullptr;      // several slabs: the shear of the y walls comes from the slabs that own them
+    if (c->P > 1 && (c->is_wall[2] != 0. || c->is_wall[3] != 0.)) { if (int e = wall_shear_y_planes(c, c->is_wall[2] != 0., c->is_wall[3] != 0., &twy)) return e; }
+    hipLaunchKernelGGL(k_smag, gr, b, 0, c->stream, c->g, A, c->d_zc, c->d_dzci, c->d_del, f[CALES_U], f[CALES_V], f[CALES_W], c->s0, visct, twy);
     HIPCHK(c, hipGetLastError());
     return 0;
   }

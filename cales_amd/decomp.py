@@ -192,13 +192,20 @@ class StagedGlooComm(TorchComm):
 
 
 class LoopbackWorld:
-    """Shared state of P emulated ranks (threads) on one device."""
+    """Shared state of P emulated ranks (threads) on one device. `events=True`: the exchanges are ordered by recorded HIP events only (no
+    host synchronisation of any stream), with a delay in front of every copy -- the form in which a missing consumer-side wait in the
+    library (hipStreamWaitEvent on the context's stream for data that arrives on the second stream) shows up as stale data instead of
+    being masked by the host waits of the plain form."""
 
-    def __init__(self, nranks: int):
+    def __init__(self, nranks: int, events: bool = False, delay_cycles: int = 200000):
         self.P = nranks
         self.barrier = threading.Barrier(nranks)
         self.A: List = [None] * nranks
         self.B: List = [None] * nranks
+        self.events = events
+        self.delay = delay_cycles
+        self.ev_ready: List = [None] * nranks
+        self.ev_done: List = [None] * nranks
 
 
 class LoopbackComm:
@@ -211,64 +218,90 @@ class LoopbackComm:
         self.stream.synchronize()
         self.w.barrier.wait()
 
-    def halo(self, off_slo, off_shi, off_rlo, off_rhi, count) -> int:
+    def _exchange(self, st, copies, after=None):
+        """Runs `copies()` (reads of the peers' buffers into mine) on stream `st` once every rank's buffers are ready, and returns when no peer
+        reads my buffers any more. Plain form: host waits on the stream around two thread barriers. Event form: every rank records an event
+        behind what it has queued, the threads meet (host only: the events are recorded, not complete), each stream waits for all events,
+        sleeps, copies, records a second event; `after()` (writes into my own buffers that peers were reading) follows the peers' second events."""
+        t, w = self.torch, self.w
+        if not w.events:
+            st.synchronize(); w.barrier.wait()
+            with t.cuda.stream(st):
+                out = copies()
+            st.synchronize(); w.barrier.wait()
+            if after is not None:
+                with t.cuda.stream(st):
+                    after(out)
+                st.synchronize(); w.barrier.wait()
+            return
+        ev = t.cuda.Event(); ev.record(st); w.ev_ready[self.r] = ev
+        w.barrier.wait()
+        with t.cuda.stream(st):
+            for q in range(self.P):
+                st.wait_event(w.ev_ready[q])
+            if w.delay:
+                t.cuda._sleep(w.delay)
+            out = copies()
+            ev2 = t.cuda.Event(); ev2.record(st); w.ev_done[self.r] = ev2
+        w.barrier.wait()
+        with t.cuda.stream(st):
+            for q in range(self.P):
+                st.wait_event(w.ev_done[q])
+            if after is not None:
+                after(out)
+        w.barrier.wait()      # the event slots are free for the next exchange
+
+    def _halo_copies(self, off_slo, off_shi, off_rlo, off_rhi, count):
         lo, hi = y_neighbours(self.r, self.P, self.per)
-        self._rendezvous()
-        with self.torch.cuda.stream(self.stream):
+
+        def copies():
             if lo is not None:      # lower neighbour's "hi" row -> my lower ghost
                 self.B[off_rlo:off_rlo + count].copy_(self.w.A[lo][off_shi:off_shi + count])
             if hi is not None:      # upper neighbour's "lo" row -> my upper ghost
                 self.B[off_rhi:off_rhi + count].copy_(self.w.A[hi][off_slo:off_slo + count])
-        self._rendezvous()
+        return copies
+
+    def halo(self, off_slo, off_shi, off_rlo, off_rhi, count) -> int:
+        self._exchange(self.stream, self._halo_copies(off_slo, off_shi, off_rlo, off_rhi, count))
         return 0
 
     def alltoall(self, direction, count) -> int:
         src_all = self.w.A if direction == 0 else self.w.B
         dst = self.B if direction == 0 else self.A
-        self._rendezvous()
-        with self.torch.cuda.stream(self.stream):
+
+        def copies():
             for q in range(self.P):     # block r of rank q's send buffer -> my block q
                 dst[q * count:(q + 1) * count].copy_(src_all[q][self.r * count:(self.r + 1) * count])
-        self._rendezvous()
+        self._exchange(self.stream, copies)
         return 0
 
     def _ext(self, stream):
         return self.torch.cuda.ExternalStream(int(stream)) if stream else self.stream
 
     def halo_s(self, off_slo, off_shi, off_rlo, off_rhi, count, stream) -> int:
-        st = self._ext(stream)
-        lo, hi = y_neighbours(self.r, self.P, self.per)
-        st.synchronize(); self.w.barrier.wait()
-        with self.torch.cuda.stream(st):
-            if lo is not None:
-                self.B[off_rlo:off_rlo + count].copy_(self.w.A[lo][off_shi:off_shi + count])
-            if hi is not None:
-                self.B[off_rhi:off_rhi + count].copy_(self.w.A[hi][off_slo:off_slo + count])
-        st.synchronize(); self.w.barrier.wait()
+        self._exchange(self._ext(stream), self._halo_copies(off_slo, off_shi, off_rlo, off_rhi, count))
         return 0
 
     def alltoall_part(self, direction, peer_stride, off, count, stream) -> int:
-        st = self._ext(stream)
         src_all = self.w.A if direction == 0 else self.w.B
         dst = self.B if direction == 0 else self.A
-        st.synchronize(); self.w.barrier.wait()
-        with self.torch.cuda.stream(st):
+
+        def copies():
             for q in range(self.P):     # slice of block r of rank q's send buffer -> the same slice of my block q
                 dst[q * peer_stride + off:q * peer_stride + off + count].copy_(src_all[q][self.r * peer_stride + off:self.r * peer_stride + off + count])
-        st.synchronize(); self.w.barrier.wait()
+        self._exchange(self._ext(stream), copies)
         return 0
 
     def allreduce(self, off, count, op) -> int:
         t = self.torch
-        self._rendezvous()
-        with t.cuda.stream(self.stream):
+
+        def reduce_():
             parts = t.stack([self.w.A[q][off:off + count] for q in range(self.P)])
-            red = parts.sum(0) if op == 0 else (parts.max(0).values if op == 1 else parts.min(0).values)
-        self.stream.synchronize()
-        self.w.barrier.wait()
-        with t.cuda.stream(self.stream):
+            return parts.sum(0) if op == 0 else (parts.max(0).values if op == 1 else parts.min(0).values)
+
+        def store(red):       # in place, once no peer reads my operand any more
             self.A[off:off + count].copy_(red)
-        self._rendezvous()
+        self._exchange(self.stream, reduce_, store)
         return 0
 
 
@@ -319,7 +352,7 @@ class SlabHotPath(HotPath):
                     ARED_CB(lambda u, o, n_, op: self._guard(self.comm.allreduce, o, n_, op)))
         self._chk(self.L.cales_set_comm(self.h, self._cb[0], self._cb[1], self._cb[2], None,
                                         C.c_void_p(self.A.data_ptr()), C.c_void_p(self.B.data_ptr()), C.c_int64(self.nbuf)))
-        # exchanges beside the kernels on the library's second stream (CALES_NO_OVERLAP keeps them in order on the one stream)
+        # exchanges beside the kernels on the library's second stream: registered always, used only with CALES_OVERLAP=1 (common.hpp Flags)
         self._cb2 = (HALO_S_CB(lambda u, a, b, c_, d, n_, st: self._guard2(self.comm.halo_s, a, b, c_, d, n_, st)),
                      A2A_PART_CB(lambda u, d, ps, o, n_, st: self._guard2(self.comm.alltoall_part, d, ps, o, n_, st)))
         if not isinstance(self.comm, StagedGlooComm):      # (the staged exchanges block the host: kept in order on the one stream)
@@ -379,10 +412,13 @@ class SlabHotPath(HotPath):
         self.set(name, np.asfortranarray(a[:, j0:j0 + self.n[1] + 2, :]))
 
 
-def run_loopback(case: Case, nranks: int, body):
-    """Runs `body(hotpath, rank)` on `nranks` emulated ranks (threads) sharing one GPU; returns the list of results."""
+def run_loopback(case: Case, nranks: int, body, events: Optional[bool] = None):
+    """Runs `body(hotpath, rank)` on `nranks` emulated ranks (threads) sharing one GPU; returns the list of results. `events` (default: the
+    environment variable CALES_LOOPBACK_EVENTS): exchanges ordered by HIP events only, see LoopbackWorld."""
     import torch
-    world = LoopbackWorld(nranks)
+    if events is None:
+        events = os.environ.get("CALES_LOOPBACK_EVENTS", "0") not in ("", "0")
+    world = LoopbackWorld(nranks, events=bool(events))
     out: List = [None] * nranks
     err: List = [None] * nranks
 

@@ -11,6 +11,10 @@ pytestmark = pytest.mark.gpu
 
 
 def _case(name, ng):
+    if name == "cavity_smag":      # static Smagorinsky with walls in x, y and z: the kernel-per-loop sequence (k_smag) with the y walls' shear planes
+        g, case = load_golden("cavity_dsmag")
+        case.ng[:] = ng; case.sgstype = "smag"
+        return case
     if name == "openy_imp3d":      # inflow / outflow along y (the decomposed direction), side walls in x, 3-D implicit diffusion
         from tests.test_gpu_vs_oracle import _open_case
         return _open_case(("DD", "DD"), ("DN", "NN"), ng)
@@ -37,11 +41,15 @@ def _single(case, nsteps):
     return out
 
 
-@pytest.mark.parametrize("name,ng,P", [("chan_smag_wm", (32, 24, 16), 2), ("chan_smag_wm", (32, 24, 16), 4),
+SLAB_CASES = [("chan_smag_wm", (32, 24, 16), 2), ("chan_smag_wm", (32, 24, 16), 4),
                                        ("chan_dsmag", (24, 32, 16), 4), ("tgv_ppp", (16, 24, 12), 3),
                                        ("chan_dsmag_wm", (72, 32, 40), 2), ("tgv_dsmag_ppp", (32, 24, 16), 3),
                                        ("halfchan_imp1d", (16, 16, 12), 2), ("chan_smag", (64, 16, 8), 8),
                                        ("duct_smag_wm", (16, 24, 24), 2), ("duct_smag_wm_imp1d", (16, 24, 24), 2), ("cavity_nnn", (16, 24, 12), 4),
+                                       # static Smagorinsky between y walls on more than two slabs (BASELINE configs[3] on 4 and 8 GPUs): van Driest with global rows and
+                                       # the shear planes of both y walls summed over the slabs; row-marching kernel, tile kernel (CALES_SMAG_TILE in the test below), k_smag
+                                       ("duct_smag_wm", (16, 32, 24), 4), ("duct_smag_wm", (16, 64, 24), 8), ("duct_smag_wm_imp1d", (16, 32, 24), 4),
+                                       ("duct_smag_wm_imp1d", (32, 64, 16), 8), ("duct_smag_wm", (16, 24, 24), 3), ("cavity_smag", (16, 24, 12), 4), ("cavity_smag", (16, 24, 12), 3),
                                        ("devchan_nd", (32, 24, 12), 3),
                                        # dynamic model with walls in y/z and in x/y/z (kernel-per-loop sequence, slab halos of its scratch fields)
                                        ("duct_dsmag_wm", (16, 24, 20), 2), ("duct_dsmag", (16, 24, 12), 3), ("cavity_dsmag", (16, 24, 12), 2),
@@ -53,10 +61,15 @@ def _single(case, nsteps):
                                        # 3-D implicit diffusion with no-slip walls in x and y (wall-normal DST-I in the slab and in the mode-block layout)
                                        ("cavity_imp3d", (32, 24, 12), 2), ("cavity_imp3d", (20, 36, 10), 4),
                                        # ... and with open boundaries: inflow / outflow along x (RODFT01/10 in the slab) and along y (in the mode-block layout)
-                                       ("devchan_imp3d", (32, 24, 12), 3), ("openy_imp3d", (16, 24, 12), 2), ("openy_imp3d", (20, 36, 10), 4)])
+                                       ("devchan_imp3d", (32, 24, 12), 3), ("openy_imp3d", (16, 24, 12), 2), ("openy_imp3d", (20, 36, 10), 4)]
+
+
+@pytest.mark.parametrize("name,ng,P", SLAB_CASES)
 def test_slab_ranks_match_single_rank(name, ng, P):
     from cales_amd.decomp import run_loopback
     case = _case(name, ng)
+    if P == 8 and name.startswith("duct_smag"):
+        case.hwm = 0.2      # the sampling height must lie inside the slab that owns the wall (sanity.f90:224-231): l(2)/8 = 0.25 is its upper bound here
     nsteps = 2
     u, v, w, p, visct, dt, div, dpdl = _single(case, nsteps)
 
@@ -82,11 +95,40 @@ def test_slab_ranks_match_single_rank(name, ng, P):
     assert relerr(pg[1:-1, :, 1:-1] - pg[1:-1, :, 1:-1].mean(), pref[1:-1, :, 1:-1] - pref[1:-1, :, 1:-1].mean()) < 1e-9
 
 
-@pytest.mark.parametrize("name,ng,P", [("chan_dsmag", (128, 32, 136), 2), ("chan_dsmag_wm", (72, 32, 40), 4), ("cavity_nnn", (16, 24, 12), 4), ("halfchan_imp1d", (16, 16, 12), 2)])
+@pytest.mark.parametrize("name,ng,P", SLAB_CASES)
+def test_slab_ranks_overlapped_event_ordered(name, ng, P, monkeypatch):
+    """CALES_OVERLAP=1: the exchanges of the Poisson solve (k-chunks) and the y halos of the dynamic model's scratch fields run on the library's
+    second stream beside kernels. The emulated ranks order their copies by recorded HIP events ONLY and delay every copy (decomp.LoopbackWorld,
+    events=True): a consumer kernel that did not wait for the event of the data it reads would see the previous contents. (The default of the
+    library is in order on one stream -- test_slab_ranks_match_single_rank above -- until a node with real peers has confirmed this path.)"""
+    monkeypatch.setenv("CALES_OVERLAP", "1")
+    monkeypatch.setenv("CALES_LOOPBACK_EVENTS", "1")
+    test_slab_ranks_match_single_rank(name, ng, P)
+
+
+@pytest.mark.parametrize("name,ng,P", [("chan_dsmag", (128, 32, 136), 2), ("chan_dsmag_wm", (72, 32, 40), 4), ("cavity_nnn", (64, 32, 32), 2), ("duct_dsmag_wm", (32, 32, 32), 2)])
+def test_slab_ranks_overlapped_host_synchronised(name, ng, P, monkeypatch):
+    """The same second-stream path with the plain loopback exchanges (host waits around every copy)."""
+    monkeypatch.setenv("CALES_OVERLAP", "1")
+    test_slab_ranks_match_single_rank(name, ng, P)
+
+
+@pytest.mark.parametrize("name,ng,P", [("chan_dsmag", (128, 32, 136), 2), ("halfchan_imp1d", (16, 16, 12), 2)])
 def test_slab_ranks_in_order_exchanges(name, ng, P, monkeypatch):
-    """CALES_NO_OVERLAP: every exchange in order on the one stream (no k-chunks, no deferred halos) -- the path a host without
-    cales_set_comm_overlap gets; the default runs of test_slab_ranks_match_single_rank use the second stream."""
+    """CALES_NO_OVERLAP wins over CALES_OVERLAP; in-order exchanges also with the event-ordered emulation."""
+    monkeypatch.setenv("CALES_OVERLAP", "1")
     monkeypatch.setenv("CALES_NO_OVERLAP", "1")
+    monkeypatch.setenv("CALES_LOOPBACK_EVENTS", "1")
+    test_slab_ranks_match_single_rank(name, ng, P)
+
+
+@pytest.mark.parametrize("name,ng,P", [("duct_smag_wm", (16, 32, 24), 4), ("duct_smag_wm_imp1d", (64, 32, 16), 8)])
+def test_slab_ranks_smag_tile_and_reference_sequence(name, ng, P, monkeypatch):
+    """The two other forms of the static-Smagorinsky pass on more than two slabs between y walls: the LDS tile kernel and the kernel-per-loop sequence."""
+    monkeypatch.setenv("CALES_SMAG_TILE", "1")
+    test_slab_ranks_match_single_rank(name, ng, P)
+    monkeypatch.delenv("CALES_SMAG_TILE")
+    monkeypatch.setenv("CALES_SMAG_REFERENCE_SEQUENCE", "1")
     test_slab_ranks_match_single_rank(name, ng, P)
 
 
@@ -126,8 +168,9 @@ def test_one_rank_nccl_process_group(layer):
     assert r.returncode == 0 and "NCCL1 OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("overlap", [0, 1])
 @pytest.mark.parametrize("layer", ["rccl", "torch"])
-def test_n_rank_nccl_process_group(layer):
+def test_n_rank_nccl_process_group(layer, overlap):
     """Real peers: one process per GPU through torch.distributed.run, the exchanges of comm_rccl.cpp (grouped send/recv pairing incl.
     P = 2 periodic with both neighbours the same peer, ncclAllToAll block layout, all-reduces) against the single-rank run. RCCL
     refuses two ranks on one device, so this needs at least two GPUs and is skipped on the one-GPU test box."""
@@ -138,9 +181,9 @@ def test_n_rank_nccl_process_group(layer):
         pytest.skip("needs >= 2 GPUs")
     P = 2 if n < 4 else 4
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, CALES_COMM=layer)
+    env = dict(os.environ, CALES_COMM=layer, CALES_OVERLAP=str(overlap))      # overlap = 1: k-chunked transposition and deferred halos on the second stream, with real peers
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={P}", "--master-addr", "127.0.0.1",
-                        "--master-port", str(29581 + (layer == "torch")), os.path.join(here, "_ncclN_worker.py")],
+                        "--master-port", str(29581 + (layer == "torch") + 2 * overlap), os.path.join(here, "_ncclN_worker.py")],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "NCCLN OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
@@ -176,3 +219,22 @@ def test_bench_two_processes_one_gpu():
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 1.) < 1e-9
     assert d["config"]["decomposition"] == "y-slabs x2" and "transpose" in d and d["transpose"]["alltoall_calls_per_step"] == 6.0
     assert d["icheck"]["blocks_in_timed_region"] >= 1
+
+
+def test_bench_bare_form_spawns_its_ranks():
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run (the form the driver records for N = 1): the parent, which never touches the GPU,
+    starts the two ranks as child processes, relays rank 0's one JSON line and returns their exit code."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--ng", "64", "64", "32",
+                        "--backend", "gloo", "--no-cpu"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["config"]["decomposition"] == "y-slabs x2"
+    # a failing rank must fail the parent: an unknown size is refused by every rank
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--ng", "64", "63", "32",
+                        "--backend", "gloo", "--no-cpu"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode != 0

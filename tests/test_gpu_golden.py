@@ -155,6 +155,37 @@ def test_unfused_paths(name, env, monkeypatch):
     test_fused_step_matches_operator_sequence(name)
 
 
+SWITCH_CASES = [
+    # one lane per complex mode in the marching z sweep; per-column pivots / separate implicit r.h.s. passes in the z-implicit step
+    ({"CALES_GAUSSEL_PAIR": "1"}, ["chan_dsmag", "chan_smag_wm", "tgv_ppp", "cavity_nnn"]),
+    ({"CALES_HELMHOLTZ_Z_PER_COLUMN": "1"}, ["duct_smag_wm_imp1d", "halfchan_imp1d"]),
+    ({"CALES_UNFUSED_IMP_RHS": "1"}, ["duct_smag_wm_imp1d", "halfchan_imp1d"]),
+    # ghost columns of the dynamic model's scratch fields filled instead of wrapped; rows without the 128-byte alignment
+    ({"CALES_DSMAG_XGHOSTS": "1"}, ["chan_dsmag", "chan_dsmag_wm", "tgv_dsmag_ppp", "duct_dsmag_wm"]),
+    ({"CALES_UNALIGNED": "1"}, ["chan_dsmag", "chan_smag_wm", "tgv_ppp", "duct_smag_wm_imp1d", "cavity_nnn", "devchan_nd"]),
+    # k chunks of the marching tile kernels: forced length (with its three-plane prologues inside the field) and the block-count threshold
+    ({"CALES_KCHUNK": "3"}, ["chan_dsmag", "chan_dsmag_wm", "chan_smag_wm", "duct_dsmag_wm", "duct_smag_wm_imp1d"]),
+    ({"CALES_KCHUNK": "5", "CALES_SMAG_TILE": "1"}, ["chan_smag_wm", "duct_smag_wm"]),
+    ({"CALES_TILE_MIN_BLOCKS": "1000000"}, ["chan_dsmag", "duct_smag_wm_imp1d"]),
+    ({"CALES_TILE_MIN_BLOCKS": "1"}, ["chan_dsmag", "duct_smag_wm_imp1d"]),
+    # tile heights of the LDS form of the static Smagorinsky pass
+    ({"CALES_SMAG_TILE": "1", "CALES_SMAG_TY": "6"}, ["chan_smag", "chan_smag_wm", "duct_smag_wm"]),
+    ({"CALES_SMAG_TILE": "1", "CALES_SMAG_TY": "14"}, ["chan_smag", "chan_smag_wm", "duct_smag_wm"]),
+]
+
+
+@pytest.mark.parametrize("envs,name", [(e, n) for e, names in SWITCH_CASES for n in names],
+                         ids=lambda v: "+".join(f"{k[6:]}={x}" for k, x in v.items()) if isinstance(v, dict) else v)
+def test_remaining_switches(envs, name, monkeypatch):
+    """Every run-time switch of DESIGN.md's table that selects an alternative code path is exercised against the reference-made goldens
+    (end-of-step state) -- a path in the product library that no test runs is either dead or a latent fault."""
+    for k, v in envs.items():
+        monkeypatch.setenv(k, v)
+    test_fused_step_matches_operator_sequence(name)
+    if "CALES_SMAG_TY" in envs or "CALES_KCHUNK" in envs:
+        test_startup_and_substeps(name)      # stage by stage at 1e-13 as well
+
+
 @pytest.mark.parametrize("name", DEVICE_CASES)
 def test_unmerged_bc_operator_level(name, monkeypatch):
     """The one-launch ghost-cell kernel (x, y periodic: every ghost cell = the z operation on the wrapped interior cell) is the default

@@ -46,6 +46,13 @@ def test_poisson_solve(name, ng):
     h.close()
 
 
+@pytest.mark.parametrize("name,ng", [("chan_smag", (64, 128, 8)), ("tgv_ppp", (32, 32, 16)), ("cavity_nnn", (256, 128, 6)), ("duct_smag_wm", (128, 256, 8)), ("chan_smag", (512, 64, 6))])
+def test_poisson_solve_generic_transforms(name, ng, monkeypatch):
+    """CALES_FFT_GENERIC: the mixed-radix Stockham kernels also for power-of-two lines (which otherwise take the radix-8 register kernels), same bar."""
+    monkeypatch.setenv("CALES_FFT_GENERIC", "1")
+    test_poisson_solve(name, ng)
+
+
 @pytest.mark.parametrize("name,ng", [("chan_smag", (32, 16, 24)), ("cavity_nnn", (24, 20, 70)), ("halfchan_imp1d", (16, 16, 200))])
 def test_tridiagonal_paths_agree(name, ng, monkeypatch):
     """the in-LDS substructured sweep (default on one rank) against the marching Thomas sweep (CALES_GAUSSEL_MARCH)"""

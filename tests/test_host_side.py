@@ -155,7 +155,7 @@ def test_noisy_initial_fields(kind):
         assert np.array_equal(loc[0][1:-1, 1:-1, 1:-1], u[1:-1, 1 + 8 * r:9 + 8 * r, 1:-1])
 
 
-def test_check_case_rules():
+def test_check_case_rules(monkeypatch):
     """the rules of reference src/sanity.f90:115-274 that bound what the kernels must support"""
     from cales_amd.hotpath import CalesError, check_case
     g, case = load_golden("chan_smag_wm")
@@ -177,10 +177,14 @@ def test_check_case_rules():
         check_case(ok)
     ok = load_golden("duct_smag_wm")[1]; ok.impdiff = 1; ok.lwm[:] = 0      # walls in y (no wall model)
     check_case(ok)
-    ok2 = ok.copy(); ok2.bcvel[0, 1, 0] = 0.3                  # ... a moving wall in y
-    check_case(ok2)
-    ok2 = load_golden("devchan_nd")[1]; ok2.impdiff = 1; ok2.cbcsgs[:, 0] = "D"      # ... and an open boundary (inflow / outflow in x)
-    check_case(ok2)
+    # beyond the reference's -D_IMPDIFF limits (sanity.f90:233-252: no NN pair, zero BC values in x and y): refused unless CALES_IMP3D_OPEN=1
+    mv = ok.copy(); mv.bcvel[0, 1, 0] = 0.3                    # a moving wall in y
+    ok2 = load_golden("devchan_nd")[1]; ok2.impdiff = 1; ok2.cbcsgs[:, 0] = "D"      # an open boundary (inflow / outflow in x)
+    for c_ in (mv, ok2):
+        with pytest.raises(CalesError):
+            check_case(c_)
+    monkeypatch.setenv("CALES_IMP3D_OPEN", "1")
+    check_case(mv); check_case(ok2)
     bad = ok2.copy(); bad.cbcvel[:, 1, :] = "D"; bad.cbcvel[1, 1, 0] = "N"; bad.cbcvel[1, 1, 2] = "N"; bad.cbcpre[:, 1] = "N"; bad.cbcsgs[:, 1] = "D"
     bad.ng[1] = 9                                              # ND/DN pairs across y go through half-length lines: even ng(2) only
     with pytest.raises(CalesError):
