@@ -179,6 +179,7 @@ struct cales_ctx {
   bool defer_halo = false; std::vector<real *> deferred;      // y-halo exchanges collected for halo_flush_deferred (k_bound.hip)
   int bc_skip = 0;         // bit d-1: boundp/bounduvw leave direction d alone (set around calls whose consumers do not need it)
   int field_ofs = 0;       // doubles between a field's allocation and its element (0,0,0)
+  real *d_nullw = nullptr; // work space of k_null_column (CALES_KEEP_NULL_MODE)
 };
 
 #define CBV(c, side, dir, vel) ((c)->cbcvel[(side) + 2 * ((dir) - 1) + 6 * ((vel) - 1)])

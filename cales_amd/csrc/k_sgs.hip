@@ -497,47 +497,62 @@ __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijA
 #define TYL 8
 #endif
 struct LmfArgs { LijMijArgs L; const real *ss[6]; int by0; BandMap bm; int gx; };      // bm: block map of this launch (bm.gx = 0: plain 3-D grid); gx: x tiles of the whole field      // by0: first y tile of this launch (interior and edge tiles of a slab are launched apart)
+// Every global access of the plane loop is UNCONDITIONAL (out-of-range lanes, rows and planes are clamped onto valid cells whose values are
+// never used): a load inside a divergent branch makes the compiler wait with s_waitcnt vmcnt(0) at the next use of ANY loaded value -- it
+// cannot count the operations in flight across the branch -- and that drained, right behind the barrier of every plane, the six loads of
+// plane k+2 issued a hundred instructions earlier (HBM latency, once per plane, for all ten waves). With straight-line loads the waits are
+// counted: the 18 |S|Sij loads are waited for with the 6 velocity loads of the next plane still in flight, and those with the next 18.
+// For the same reason the block sums of a chunk's planes are collected in LDS and stored after the loop (a store inside the loop is a
+// vector-memory operation in a branch as well), and the per-plane grid coefficients come through the scalar cache one plane ahead.
+constexpr int LMF_KMAX = 512;      // longest k chunk (block sums of a chunk in LDS: 2 x 512 x 8 B of the 9.9 KB the tile leaves)
 template <typename OFF, int YW>      // YW = 1: walls or wall-model faces in y (ducts); 0: the channel instantiation carries none of that logic
 __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) {
   const LijMijArgs &A = B.L;
   __shared__ real sh[2][9][TYL + 2][64];
   __shared__ real ring[4][3][TYL + 2][64];
   __shared__ real shr[2][2][TYL + 2];
+  __shared__ real bsum[2][LMF_KMAX];
   const int tx = threadIdx.x, ty = threadIdx.y;
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   if (B.bm.gx && !band_block(B.bm, bx, by, bz)) return;
   by += B.by0;
   const int i = bx * 62 + tx, j = by * TYL + ty;
   const int kbeg = bz * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
-  const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1;
   const bool outok = tx >= 1 && tx <= 62 && ty >= 1 && ty <= TYL && i <= g.n1 && j <= g.n2;
-  const bool ssok = ty >= 1 && ty <= TYL && i <= g.n1 + 1 && j <= g.n2;      // rows that filter |S|Sij (all 64 lanes: x neighbours by DPP)
   const int iw = A.perx ? (i == 0 ? g.n1 : (i == g.n1 + 1 ? 1 : i)) : i;
-  const OFF c0 = ldok ? (OFF)g.ix(iw, j, 0) * RSZ : 0, sk = (OFF)g.s12 * RSZ, sj = (OFF)g.s1 * RSZ;      // byte offsets
+  const int ic = min(iw, g.n1 + 1), jc = min(j, g.n2 + 1);      // clamped: lanes / rows beyond the field read its last ghost column / row
+  const OFF c0 = (OFF)g.ix(ic, jc, 0) * RSZ, sk = (OFF)g.s12 * RSZ, sj = (OFF)g.s1 * RSZ;      // byte offsets
+  // rows whose |S|Sij this thread combines: its own and the two beside it; the two halo waves (and rows beyond n2) take a row of the tile
+  // interior instead (cache hits, results unused)
+  const int jo = max(by * TYL + 1, min(min(j, by * TYL + TYL), g.n2));
+  const OFF c0s = (OFF)g.ix(ic, jo, 0) * RSZ;
   real sm[3], sc[3], sp[3], sn[3], fn[3];
-  // ghost rows of u_f and w_f at wall-model y faces: 2 Q(1) - Q(2) along y (extrapolate(...,lwm) after bounduvw, sgs.f90:683-748); v_f keeps its own
+  // ghost rows of u_f and w_f at wall-model y faces: 2 Q(1) - Q(2) along y (extrapolate(...,lwm) after bounduvw, sgs.f90:683-748); v_f keeps its own.
+  // Branch-free: every row loads two values, c1 Q(o1) - c2 Q(o2), with (c1, c2) = (1, 0) and o1 = o2 = its own cell away from such a face
   const int yex = !YW ? 0 : (A.wmylo && j == 0) ? 1 : (A.wmyhi && j == g.n2 + 1) ? -1 : 0;
+  const OFF e1 = yex > 0 ? sj : 0, e2 = yex > 0 ? 2 * sj : 0, b1 = yex < 0 ? sj : 0, b2 = yex < 0 ? 2 * sj : 0;      // o + e - b (unsigned offsets: no negative steps)
+  const real ec1 = yex != 0 ? 2. : 1., ec2 = yex != 0 ? 1. : 0.;
   auto ldf = [&](int q, OFF o) -> real {
-    if (YW && yex != 0 && q != 1) return yex > 0 ? 2. * ldb(A.uf[q], o + sj) - ldb(A.uf[q], o + 2 * sj) : 2. * ldb(A.uf[q], o - sj) - ldb(A.uf[q], o - 2 * sj);
+    if (YW && q != 1) return ec1 * ldb(A.uf[q], o + e1 - b1) - ec2 * ldb(A.uf[q], o + e2 - b2);
     return ldb(A.uf[q], o);
   };
   const bool ylo = YW && A.wylo && j == 1, yhi = YW && A.wyhi && j == g.n2;      // rows next to a y wall: ghost row of every filtered quantity = 2 Q(1) - Q(2)
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
-    sm[q] = ldok ? ldb(A.uc[q], c0 + (OFF)(kbeg - 1) * sk) : 0.;
-    sc[q] = ldok ? ldb(A.uc[q], c0 + (OFF)kbeg * sk) : 0.;
-    sp[q] = ldok ? ldb(A.uc[q], c0 + (OFF)(kbeg + 1) * sk) : 0.;
-    ring[(kbeg - 1) & 3][q][ty][tx] = ldok ? ldf(q, c0 + (OFF)(kbeg - 1) * sk) : 0.;
-    ring[kbeg & 3][q][ty][tx] = ldok ? ldf(q, c0 + (OFF)kbeg * sk) : 0.;
-    fn[q] = ldok ? ldf(q, c0 + (OFF)(kbeg + 1) * sk) : 0.;
+    sm[q] = ldb(A.uc[q], c0 + (OFF)(kbeg - 1) * sk);
+    sc[q] = ldb(A.uc[q], c0 + (OFF)kbeg * sk);
+    sp[q] = ldb(A.uc[q], c0 + (OFF)(kbeg + 1) * sk);
+    ring[(kbeg - 1) & 3][q][ty][tx] = ldf(q, c0 + (OFF)(kbeg - 1) * sk);
+    ring[kbeg & 3][q][ty][tx] = ldf(q, c0 + (OFF)kbeg * sk);
+    fn[q] = ldf(q, c0 + (OFF)(kbeg + 1) * sk);
     if (A.wmlo && kbeg == 1 && q < 2) ring[0][q][ty][tx] = (1. + A.flo) * ring[1][q][ty][tx] - A.flo * fn[q];
   }
   // |S|Sij: y and x combination of one plane (three rows in, lanes beside by DPP)
   auto ssload = [&](int kk, real (*raw)[3]) {
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
-      const OFF o = c0 + (OFF)kk * sk;
-      raw[q][0] = ssok ? ldb(B.ss[q], o - sj) : 0.; raw[q][1] = ssok ? ldb(B.ss[q], o) : 0.; raw[q][2] = ssok ? ldb(B.ss[q], o + sj) : 0.;
+      const OFF o = c0s + (OFF)kk * sk;
+      raw[q][0] = ldb(B.ss[q], o - sj); raw[q][1] = ldb(B.ss[q], o); raw[q][2] = ldb(B.ss[q], o + sj);
     }
   };
   auto sscomb = [&](const real (*raw)[3], real *X) {
@@ -554,21 +569,22 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
   ssload(kbeg + 1, rw);
   const int blk = by * B.gx + bx;
   auto fold = [&](int k, int b) {      // block sums of plane k, fixed order
-    real a = 0., bsum = 0.;
-    for (int q = 1; q <= TYL; ++q) { a += shr[b][0][q]; bsum += shr[b][1][q]; }
-    A.part[(size_t)(k - 1) * A.nblk + blk] = a; A.part[(size_t)(g.n3 + k - 1) * A.nblk + blk] = bsum;
+    real a = 0., bs = 0.;
+    for (int q = 1; q <= TYL; ++q) { a += shr[b][0][q]; bs += shr[b][1][q]; }
+    bsum[0][k - kbeg] = a; bsum[1][k - kbeg] = bs;
   };
+  // grid coefficients of the plane, one plane ahead through the scalar cache (uniform: scalar registers)
+  real zcm = ldc(A.dzci, kbeg - 1), zcc = ldc(A.dzci, kbeg), zfc = ldc(A.dzfi, kbeg);
   auto plane = [&](const int k, auto lo_c, auto hi_c) {
     constexpr bool LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
     const int km = (k - 1) & 3, kc = k & 3, kp = (k + 1) & 3, buf = k & 1;
-    const OFF idx = c0 + (OFF)k * sk;
+    const OFF idx = c0 + (OFF)min(k + 2, g.n3 + 1) * sk;      // plane k+2 (clamped behind the last ghost plane: loaded again, never used)
+    const real zcn = ldc(A.dzci, k + 1), zfn = ldc(A.dzfi, k + 1);
 #pragma unroll
     for (int q = 0; q < 3; ++q)
       ring[kp][q][ty][tx] = (HI && A.wmhi && q < 2) ? (1. + A.fhi) * ring[kc][q][ty][tx] - A.fhi * ring[km][q][ty][tx] : fn[q];
-    if (k + 2 <= g.n3 + 1) {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) { sn[q] = ldok ? ldb(A.uc[q], idx + 2 * sk) : 0.; fn[q] = ldok ? ldf(q, idx + 2 * sk) : 0.; }
-    }
+    for (int q = 0; q < 3; ++q) { sn[q] = ldb(A.uc[q], idx); fn[q] = ldf(q, idx); }
     real qm[9], qc[9], qp[9], r[9];
     uiuj(sc, qc);
     if (!LO && !HI) { uiuj(sm, qm); uiuj(sp, qp); }
@@ -600,10 +616,10 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
 #define RU(dk, dj, di) ring[dk][0][ty + (dj)][tx + (di)]
 #define RV(dk, dj, di) ring[dk][1][ty + (dj)][tx + (di)]
 #define RW(dk, dj, di) ring[dk][2][ty + (dj)][tx + (di)]
-      const real dxi = A.dxi, dyi = A.dyi, zc = A.dzci[k], zm = A.dzci[k - 1];
+      const real dxi = A.dxi, dyi = A.dyi, zc = zcc, zm = zcm;
       real sij[6];
       { const real u_ccc = RU(kc, 0, 0), u_mcc = RU(kc, 0, -1), v_ccc = RV(kc, 0, 0), v_cmc = RV(kc, -1, 0), w_ccc = RW(kc, 0, 0), w_ccm = RW(km, 0, 0);
-        sij[0] = (u_ccc - u_mcc) * dxi; sij[1] = (v_ccc - v_cmc) * dyi; sij[2] = (w_ccc - w_ccm) * A.dzfi[k];
+        sij[0] = (u_ccc - u_mcc) * dxi; sij[1] = (v_ccc - v_cmc) * dyi; sij[2] = (w_ccc - w_ccm) * zfc;
         // s12 = 1/8 [ dyi (u_cpc - u_cmc + u_mpc - u_mmc) + dxi (v_pcc + v_pmc - v_mcc - v_mmc) ]
         const real du = (RU(kc, 1, 0) - RU(kc, -1, 0)) + (RU(kc, 1, -1) - RU(kc, -1, -1));
         const real dv = (RV(kc, 0, 1) - RV(kc, 0, -1)) + (RV(kc, -1, 1) - RV(kc, -1, -1));
@@ -630,13 +646,14 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
       lm = m[0] * l0 + m[1] * l1 + m[2] * l2 + (m[3] * l3 + m[4] * l4 + m[5] * l5) * 2.;       // sgs.f90:344-349
       mm = m[0] * m[0] + m[1] * m[1] + m[2] * m[2] + (m[3] * m[3] + m[4] * m[4] + m[5] * m[5]) * 2.;       // sgs.f90:350-355
     }
-    if (k + 2 <= g.n3 + 1) ssload(k + 2, rw);
-    lm = wave_sum_lane63(lm); mm = wave_sum_lane63(mm);
+    ssload(min(k + 2, g.n3 + 1), rw);
+    lm = wave_sum_lane63(lm); mm = wave_sum_lane63(mm);      // (valid in lane 63 only)
     if (tx == 63) { shr[buf][0][ty] = lm; shr[buf][1][ty] = mm; }
 #pragma unroll
     for (int q = 0; q < 3; ++q) { sm[q] = sc[q]; sc[q] = sp[q]; sp[q] = sn[q]; }
 #pragma unroll
     for (int q = 0; q < 6; ++q) { xm[q] = xc[q]; xc[q] = xp[q]; }
+    zcm = zcc; zcc = zcn; zfc = zfn;
   };
   {
     const std::true_type T; const std::false_type F_;
@@ -648,6 +665,12 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
   }
   __syncthreads();
   if (tx == 0 && ty == 0 && kend >= kbeg) fold(kend, kend & 1);
+  __syncthreads();
+  // the chunk's block sums leave in one go
+  for (int q = ty * 64 + tx; q < 2 * (kend - kbeg + 1); q += 64 * (TYL + 2)) {
+    const int w = q & 1, kk = q >> 1;
+    A.part[(size_t)(w * g.n3 + kbeg + kk - 1) * A.nblk + blk] = bsum[w][kk];
+  }
 }
 
 // K_A + K_C in one pass over u,v,w: strain rate (sgs.f90:571-630) stored as |S| and |S|Sij, cell-centred velocity (sgs.f90:860-869) and the
@@ -1031,6 +1054,7 @@ static int dsmag_fast(cales_ctx *c) {
     // K_B + K_DF in one pass: filter(|S|Sij) on the fly, strain rate of the filtered velocity, Mij, Lij, contractions, plane partial sums
     ProfScope ps(c, "lij_mij_filter_contract");
     tiles(TYL, 62, mb, mg, kch);
+    while (kch > LMF_KMAX) { kch = (kch + 1) / 2; mg.z = (n[2] + kch - 1) / kch; }      // the kernel keeps a chunk's block sums in LDS
     L.kchunk = kch; L.nblk = mg.x * mg.y;
     LmfArgs B; B.L = L; for (int m = 0; m < 6; ++m) B.ss[m] = ssij[m];
     auto launch = [&](int by0, int nby) {

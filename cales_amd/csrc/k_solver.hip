@@ -1206,6 +1206,62 @@ void solver_teardown(cales_ctx *c) {
   for (int iv = 0; iv < 3; ++iv) hipFree(c->d_av[iv]);
 }
 
+// CALES_KEEP_NULL_MODE: the zero-eigenvalue column of a singular pressure problem (no Dirichlet condition in z) solved in the REFERENCE's own
+// sequential order -- dgtsv_homebrewed / gaussel_periodic with their +eps pivots, solver.f90:109-179, one operation at a time, no contraction.
+// Its solution is a constant C times the null vector plus a regular part, with C = (a sum that vanishes for a compatible r.h.s.) / (a pivot
+// that vanishes but for round-off and eps): both are defined by the order of the operations, so only the same order reproduces the reference's C
+// (1e4..1e7 on triply periodic boxes whose default-real grid arithmetic, initgrid.f90:63, leaves dzf non-uniform at 1e-8: there the r.h.s. is
+// incompatible at that level and the velocities inherit C times the round-off of the null vector). The substructured sweeps solve every other
+// column (regular: any order gives the same result to round-off); this one is saved before them (phase 0) and overwritten after (phase 1).
+// One thread; w holds 5 nz reals.
+// (`#pragma clang fp contract(off)` in every body: HIP compiles with -ffp-contract=fast, and __dadd_rn / __dmul_rn are plain operators there --
+// a fused multiply-add rounds once where the reference rounds twice, and the sign of a pivot of +-eps hangs on that bit)
+__device__ inline real r_add(real a, real b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ inline real r_mul(real a, real b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ inline void ref_dgtsv(int n, const real *a, const real *b, const real *c, real *p, real *d) {      // solver.f90:153-179
+#pragma clang fp contract(off)
+  const real eps = CALES_EPS;
+  real z = (real)1. / r_add(b[0], eps);
+  d[0] = r_mul(c[0], z); p[0] = r_mul(p[0], z);
+  for (int l = 1; l < n; ++l) {
+    z = (real)1. / r_add(r_add(b[l], -r_mul(a[l], d[l - 1])), eps);
+    d[l] = r_mul(c[l], z);
+    p[l] = r_mul(r_add(p[l], -r_mul(a[l], p[l - 1])), z);
+  }
+  for (int l = n - 2; l >= 0; --l) p[l] = r_add(p[l], -r_mul(d[l], p[l + 1]));
+}
+__global__ void k_null_column(Geom g, Spec S, int nz, int periodic, const real *__restrict__ a, const real *__restrict__ b, const real *__restrict__ c,
+                              const real *__restrict__ lamx, const real *__restrict__ lamy, real2 *__restrict__ p, real *__restrict__ w, int phase) {
+#pragma clang fp contract(off)
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const real lam = lamx[0] + lamy[0];
+  if (lam != 0.) return;      // x or y carries a Dirichlet condition: nothing is singular
+  real *bb = w, *d = w + nz, *p1 = w + 2 * nz, *p2 = w + 3 * nz, *col = w + 4 * nz;
+  if (phase == 0) { for (int l = 0; l < nz; ++l) col[l] = p[S.at_mode(g, 0, 1, l + 1)].x; return; }
+  for (int l = 0; l < nz; ++l) bb[l] = r_add(b[l], lam);
+  if (!periodic) ref_dgtsv(nz, a, bb, c, col, d);
+  else {      // gaussel_periodic, solver.f90:109-150
+    const int n = nz;
+    for (int l = 0; l < n - 1; ++l) p1[l] = col[l];
+    ref_dgtsv(n - 1, a, bb, c, p1, d);
+    for (int l = 0; l < n; ++l) p2[l] = 0.;
+    p2[0] = -a[0]; p2[n - 2] = -c[n - 2];
+    ref_dgtsv(n - 1, a, bb, c, p2, d);
+    const real num = r_add(r_add(col[n - 1], -r_mul(c[n - 1], p1[0])), -r_mul(a[n - 1], p1[n - 2]));
+    const real den = r_add(r_add(r_add(bb[n - 1], r_mul(c[n - 1], p2[0])), r_mul(a[n - 1], p2[n - 2])), (real)CALES_EPS);
+    const real pn = num / den;
+    col[n - 1] = pn;
+    for (int l = 0; l < n - 1; ++l) col[l] = r_add(p1[l], r_mul(p2[l], pn));
+  }
+  for (int l = 0; l < nz; ++l) p[S.at_mode(g, 0, 1, l + 1)].x = col[l];
+}
+
 // FFT x, FFT y, tridiagonal z, and back, in place on `pp`; (da,db,dc,nz,lscale) = (a,b,c,n3,1) for the pressure Poisson equation,
 // (alpha a, alpha b + 1, alpha c, n3 - q, alpha) for the Helmholtz equation of a velocity component (main.f90:435-445)
 static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, const real *dc, int nz, real lscale, bool periodic_z, bool poisson) {
@@ -1324,6 +1380,12 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
   }
   // pressure equation without a Dirichlet condition in z: the zero-eigenvalue mode (if x and y have one) is singular
   const int fixnull = (poisson && CBP(c, 0, 3) != 'D' && CBP(c, 1, 3) != 'D' && !c->fl.keep_null_mode) ? 1 : 0;
+  // CALES_KEEP_NULL_MODE: the singular column in the reference's sequential order (k_null_column); the rank that holds mode 0 does it
+  const bool refnull = poisson && lscale == (real)1. && CBP(c, 0, 3) != 'D' && CBP(c, 1, 3) != 'D' && c->fl.keep_null_mode && mofs == 0;
+  if (refnull) {
+    if (!c->d_nullw) HIPCHK(c, hipMalloc(&c->d_nullw, (size_t)5 * (c->C.ng[2] + 2) * sizeof(real)));
+    hipLaunchKernelGGL(k_null_column, dim3(1), dim3(64), 0, c->stream, c->g, S, nz, periodic_z ? 1 : 0, da, db, dc, c->d_lamx, c->d_lamy, mode_spec, c->d_nullw, 0);
+  }
   { ProfScope ps(c, "gaussel_z");
     dim3 b(64, 4), gr((ncol + 63) / 64, (n2g + 3) / 4);
     if (c->xkind && !c->ykind)       // real x modes paired into complex columns + periodic y: Hermitian separation of rows ky and N-ky
@@ -1350,6 +1412,7 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
     else if (periodic_z) hipLaunchKernelGGL((k_gaussel<real2, 1>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (real *)mode_spec, c->scr1, c->scr2, fixnull);
     else if (c->fl.gaussel_pair) hipLaunchKernelGGL((k_gaussel<real2, 0>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (real *)mode_spec, c->scr1, c->scr2, fixnull);
     else hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (real *)mode_spec, c->scr1, fixnull, 0); }
+  if (refnull) hipLaunchKernelGGL(k_null_column, dim3(1), dim3(64), 0, c->stream, c->g, S, nz, periodic_z ? 1 : 0, da, db, dc, c->d_lamx, c->d_lamy, mode_spec, c->d_nullw, 1);
   if (pend_mean_mask) if (int e = op_force_from_partials(c, pend_mean_mask, pend_mean_part, pend_mean_nblk)) return e;
   if (pipe) {
     for (int ch = 0; ch < NCH; ++ch) {

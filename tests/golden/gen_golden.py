@@ -272,4 +272,8 @@ if __name__ == "__main__":
         for name in CASES:
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--case", name])
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "--case", "grids"])
-        json.dump({"cases": list(CASES), "grids": GRIDS}, open(os.path.join(HERE, "manifest.json"), "w"), indent=1)
+    # the manifest follows whatever was (re)generated: case list, grid list and a digest of every vector file
+    import hashlib
+    json.dump({"cases": list(CASES), "grids": GRIDS,
+               "files": {f: hashlib.sha256(open(os.path.join(HERE, f), "rb").read()).hexdigest()[:16] for f in sorted(os.listdir(HERE)) if f.endswith(".npz")}},
+              open(os.path.join(HERE, "manifest.json"), "w"), indent=1)

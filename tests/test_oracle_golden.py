@@ -210,3 +210,15 @@ def test_solver_operands_and_z_sweep(name):
         for irk in (1, 2, 3):
             for k in "uvw":
                 assert np.array_equal(g[f"r{irk}_s1b_{k}"], g[f"r{irk}_s1b_{k}_orc"]), (irk, k)
+
+
+def test_manifest_lists_every_golden_file():
+    """tests/golden/manifest.json (written by gen_golden.py) names every case and carries the digest of every vector file as committed."""
+    import hashlib, json, os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    man = json.load(open(os.path.join(here, "manifest.json")))
+    files = sorted(f for f in os.listdir(here) if f.endswith(".npz"))
+    assert sorted(man["files"]) == files
+    assert sorted(c + ".npz" for c in man["cases"]) + ["grids.npz"] == sorted(files) or set(c + ".npz" for c in man["cases"]) | {"grids.npz"} == set(files)
+    for f in files:
+        assert hashlib.sha256(open(os.path.join(here, f), "rb").read()).hexdigest()[:16] == man["files"][f], f

@@ -27,3 +27,49 @@ def relerr(a, b):
     a = np.asarray(a); b = np.asarray(b)
     scale = max(np.abs(b).max(), 1e-300)
     return np.abs(a - b).max() / scale
+
+
+def triperiodic_solve_scipy(o, case, rhs):
+    """The reference's solve of a triply periodic pressure problem (solver.f90:20-80 with gaussel_periodic / dgtsv_homebrewed, :109-179, +eps pivots,
+    one operation at a time) evaluated with scipy's FFTs instead of the oracle's own: a second, independent evaluation of the SAME algorithm.
+    Columns are solved with the reference's sequential order, vectorised over the columns (numpy rounds every operation, no contraction)."""
+    import scipy.fft as sf
+    eps = np.finfo(float).eps
+    ng = tuple(int(x) for x in case.ng); n = ng[2]
+    lam, a, b, c, nrm = o.solver_operands(0)
+    hx = np.minimum(np.arange(ng[0]), ng[0] - np.arange(ng[0])); hy = np.minimum(np.arange(ng[1]), ng[1] - np.arange(ng[1]))
+    L = lam[np.ix_(hx, hy)].reshape(-1)      # eigenvalue of complex mode (kx, ky) = that of the half-complex entries of wavenumbers min(k, n - k)
+
+    def dgtsv(m, bb, p):
+        d = np.zeros_like(bb); z = 1. / (bb[0] + eps); d[0] = c[0] * z; p[0] = p[0] * z
+        for l in range(1, m):
+            z = 1. / (bb[l] - a[l] * d[l - 1] + eps); d[l] = c[l] * z; p[l] = (p[l] - a[l] * p[l - 1]) * z
+        for l in range(m - 2, -1, -1):
+            p[l] = p[l] - d[l] * p[l + 1]
+
+    def periodic(P):
+        bb = b[:, None] + L[None, :]
+        p1 = P[:n - 1].copy(); dgtsv(n - 1, bb, p1)
+        p2 = np.zeros((n - 1, P.shape[1])); p2[0] = -a[0]; p2[n - 2] = -c[n - 2]; dgtsv(n - 1, bb, p2)
+        pn = (P[n - 1] - c[n - 1] * p1[0] - a[n - 1] * p1[n - 2]) / (bb[n - 1] + c[n - 1] * p2[0] + a[n - 1] * p2[n - 2] + eps)
+        out = np.empty_like(P); out[n - 1] = pn; out[:n - 1] = p1 + p2 * pn
+        return out
+
+    X = sf.fft2(rhs[1:-1, 1:-1, 1:-1], axes=(0, 1)).reshape(-1, n).T.copy()
+    Y = periodic(X.real.copy()) + 1j * periodic(X.imag.copy())
+    return sf.ifft2(Y.T.reshape(ng[0], ng[1], n), axes=(0, 1)).real
+
+
+def perturbed_tgv_rhs(o, case, seed=7):
+    """div(u*)/dt of the Taylor-Green field with 2 % noise (what the first pressure solve of the fuzzers' cases sees); returns (pp, u, v, w, p, dt)."""
+    from cales_amd.hotpath import initflow
+    ng = tuple(int(x) for x in case.ng)
+    rng = np.random.RandomState(seed)
+    u, v, w, p = initflow(case)
+    for x in (u, v, w):
+        x[1:-1, 1:-1, 1:-1] += 0.02 * (rng.rand(*ng) - 0.5)
+    visct, pp = o.zeros(), o.zeros()
+    o.bounduvw(u, v, w, True, False); o.boundp(p, 0); o.cmpt_sgs(u, v, w, visct); o.boundp(visct, 1)
+    dt = 0.5 * o.chkdt(visct, u, v, w)
+    o.fillps(1. / dt, u, v, w, pp)
+    return pp, u, v, w, p, dt
