@@ -14,6 +14,8 @@ N > 1: one process per GPU (torch.distributed.run), y-slab decomposition of the 
 """
 import os as _os
 _os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC between the ranks' processes (RCCL); must be set before the HIP runtime starts
+# threads of the CPU baseline pinned to cores (read by the OpenMP run-time when it is loaded, i.e. before torch pulls it in)
+_os.environ.setdefault("OMP_PROC_BIND", "spread"); _os.environ.setdefault("OMP_PLACES", "cores")
 import argparse
 import json
 import os
@@ -26,6 +28,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
+HBM_COPY = 6.29e12         # B/s, the copy rate the same guide measures (79 % of the peak); this repo's own copies of 2 GiB reach 5.4-5.5 TB/s,
+                           # its read-only streams 6.3-6.4 (tools/micro/calib.hip, profiles/r03*_calibration.json)
 
 # ALGORITHMIC FP64 words per cell per launch = the words of the reference loop nests a kernel replaces (SURVEY.md 8a and
 # App. E). Fused kernels are credited with the sum of the loops they fuse, so `achieved` is an
@@ -82,32 +86,34 @@ def _transpose_report(out, stats, case, world, a, solve, h):
                                 "No N > 1 run on hardware exists yet (no multi-GPU box was available to the build)"}
 
 
-def cpu_baseline(case_full, seconds_budget=40.0):
-    """Oracle (oracle/cales_oracle.c, OpenMP) timed on the host on a bounded sample of the same case: 256x256x128 (1/16 of the
-    cells of the 512^3 workload; ~35 GB would be needed for the full size and one step would take most of a minute), on the team
-    size that runs it fastest among {32, 64, 128, all host threads} (tried in that order while the time budget lasts). `value` = the measured rate scaled by cell count to the
-    workload's size (an estimate, labelled so); `measured` holds what was actually timed."""
+def cpu_baseline(case_full, seconds_budget=40.0, full_budget=150.0, sample_dims=(256, 256, 128)):
+    """Oracle (oracle/cales_oracle.c, OpenMP) timed on the host's cores, twice:
+      1. a bounded sample, 256x256x128 (1/16 of the cells), on the team size that runs it fastest among {32, 64, 128, all host threads}
+         (threads pinned: OMP_PROC_BIND=spread, OMP_PLACES=cores, set at the top of this file; fields first-touched by the threads that use them);
+      2. ONE real step of the full workload (512^3: ~35 GB of host memory, ~30 s) with that team, when the host has the memory and the first
+         measurement says it fits `full_budget` seconds (a warm-up step comes first when there is time for two).
+    `value` is the full-size measurement when it exists, otherwise the sample's rate scaled by cell count (labelled `scaled`)."""
     from oracle.oracle import Oracle
-    case = case_full.copy()
-    case.ng[:] = tuple(min(int(a), b) for a, b in zip(case_full.ng, (256, 256, 128)))
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
-    def prepare(nthreads):
+    def prepare(case, nthreads):
         o = Oracle(case, nthreads=nthreads)
-        u, v, w, p = o.initflow(case.inivel, case.is_wallturb)
+        u, v, w, p = o.initflow(case.inivel, case.is_wallturb)          # (every field first touched by the team: Oracle.zeros)
         visct, pp = o.zeros(), o.zeros()
         o.bounduvw(u, v, w, True, False); o.boundp(p, 0); o.cmpt_sgs(u, v, w, visct); o.boundp(visct, 1)
         dt = 0.5 * o.chkdt(visct, u, v, w)
         return o, dt, (u, v, w, p, pp, visct)
 
+    case = case_full.copy()
+    case.ng[:] = tuple(min(int(a), b) for a, b in zip(case_full.ng, sample_dims))
     tried = {}
     t_begin = time.perf_counter()
     best = None
     for cores in sorted({min(avail, c) for c in (32, 64, 128, avail)}):
-        # a trial = one warm-up step (first touch, twiddles) + one timed step; stop trying larger teams when the budget is half used
+        # a trial = one warm-up step (twiddles, scratch first touch) + one timed step; stop trying larger teams when the budget is half used
         if tried and time.perf_counter() - t_begin > 0.5 * seconds_budget:
             break
-        o, dt, st = prepare(cores)
+        o, dt, st = prepare(case, cores)
         o.step(dt, *st)
         t0 = time.perf_counter(); o.step(dt, *st); tried[cores] = time.perf_counter() - t0
         if best is None or tried[cores] < tried[best[0]]:
@@ -119,7 +125,27 @@ def cpu_baseline(case_full, seconds_budget=40.0):
     while k < 1 or (time.perf_counter() - t_begin < seconds_budget and k < 10):
         o.step(dt, *st); k += 1
     t = (time.perf_counter() - t0) / k
+    o.close(); del o, st, best
     ncell_s = float(np.prod(case.ng)); ncell_f = float(np.prod(case_full.ng))
+    # ---- one real step at full size
+    full = None
+    est = t * ncell_f / ncell_s
+    try:
+        free_gb = int(open("/proc/meminfo").read().split("MemAvailable:")[1].split()[0]) / 2 ** 20
+    except (OSError, IndexError, ValueError):
+        free_gb = 0.
+    need_gb = 42. * 8. * float(np.prod([int(x) + 2 for x in case_full.ng])) / 2 ** 30      # fields of the oracle's dynamic model + the caller's six
+    if ncell_f > ncell_s and free_gb > 1.3 * need_gb and 1.6 * est < full_budget:
+        tf0 = time.perf_counter()
+        of, dtf, stf = prepare(case_full, cores)
+        t_setup = time.perf_counter() - tf0
+        warm = None
+        if t_setup + 2.4 * est < full_budget:
+            t0 = time.perf_counter(); of.step(dtf, *stf); warm = time.perf_counter() - t0
+        t0 = time.perf_counter(); of.step(dtf, *stf); tfull = time.perf_counter() - t0
+        full = {"grid": "x".join(str(int(x)) for x in case_full.ng), "s_per_step": tfull, "steps": 1, "warmup_step_s": warm, "setup_s": t_setup,
+                "threads": cores, "time_steps_per_s": 1.0 / tfull}
+        of.close(); del of, stf
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -128,14 +154,22 @@ def cpu_baseline(case_full, seconds_budget=40.0):
     except OSError:
         pass
     dims = "x".join(str(int(x)) for x in case.ng)
-    return {"value": (1.0 / t) * ncell_s / ncell_f, "unit": "time-steps/s", "cores": cores, "kind": "port",
-            "measured": {"grid": dims, "s_per_step": t, "steps": k, "time_steps_per_s": 1.0 / t,
+    scaled_value = (1.0 / t) * ncell_s / ncell_f
+    sample = (f"{k} steps of the same case at {dims} ({t:.3f} s/step, OpenMP over {cores} of {avail} host threads pinned to cores, fastest of {sorted(tried)}; "
+              f"scaled by cell count that is {scaled_value:.4f} steps/s at full size)")
+    if full:
+        sample = (f"ONE real step of the workload itself ({full['grid']}: {full['s_per_step']:.1f} s on {cores} threads"
+                  + (f", after a warm-up step of {full['warmup_step_s']:.1f} s" if full["warmup_step_s"] else ", no warm-up step") + "); besides it " + sample)
+    else:
+        sample += f"; no full-size step (host memory available {free_gb:.0f} GB, needed ~{1.3 * need_gb:.0f} GB; estimated {est:.0f} s per step)"
+    return {"value": full["time_steps_per_s"] if full else scaled_value, "unit": "time-steps/s", "cores": cores, "kind": "port",
+            "full_size": full,
+            "measured": {"grid": dims, "s_per_step": t, "steps": k, "time_steps_per_s": 1.0 / t, "scaled_to_full_size": scaled_value,
                          "s_per_step_by_threads": {str(c): round(v, 4) for c, v in sorted(tried.items())}},
-            "scaled": ncell_s != ncell_f, "cpu_model": model, "host_threads_available": avail,
-            "sample": f"{k} steps of the same case at {dims} ({t:.3f} s/step measured, OpenMP over {cores} of {avail} host threads, "
-                      f"fastest of {sorted(tried)}); `value` = that rate x {ncell_s / ncell_f:.4g} (cell-count scaling to "
-                      f"{'x'.join(str(int(x)) for x in case_full.ng)}: an estimate, FFT and cache effects of the larger grid not included). "
-                      "The oracle is a C port of the path, not the reference's 2decomp/FFTW build (FFTW is not in the image)"}
+            "scaled": full is None and ncell_s != ncell_f, "cpu_model": model, "host_threads_available": avail,
+            "omp": {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES")},
+            "sample": sample + ". The oracle is a C port of the path (OpenMP over planes), not the reference's 2decomp/FFTW build (FFTW is not in the image); "
+                               "the reference itself parallelises with one MPI rank per core"}
 
 
 def main():
@@ -288,11 +322,12 @@ def main():
                                      "gloo with host staging, ranks sharing one GPU: a test of the launch path, NOT a measurement" if a.backend == "gloo" else
                                      "torch.distributed callbacks") if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": ach / HBM_PEAK, "frac_of_guide_copy_rate": ach / HBM_COPY, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": WORDS[dom] * RB * nloc, "avg_launch_ms": ms / calls, "launches": calls},
             "poisson_solve": {"ms": solve_ms, "words_per_cell": solve_words, "passes": solve_note,
                               "algorithmic_GBps": solve_words * RB * nloc / (solve_ms * 1e-3) / 1e9 if solve_ms else None,
-                              "frac_of_hbm_peak": solve_words * RB * nloc / (solve_ms * 1e-3) / HBM_PEAK if solve_ms else None},
+                              "frac_of_hbm_peak": solve_words * RB * nloc / (solve_ms * 1e-3) / HBM_PEAK if solve_ms else None,
+                              "frac_of_guide_copy_rate": solve_words * RB * nloc / (solve_ms * 1e-3) / HBM_COPY if solve_ms else None},
             # north_star: ">= 50 % of the HBM roofline on the Poisson + RK sweep": one (fillps +) solve + one fused
             # momentum/RK pass (its compulsory words, averaged over the three substeps) over the time of exactly those kernels
             "poisson_plus_rk": (lambda ms, w: {"ms": ms, "words_per_cell": w, "algorithmic_GBps": w * RB * nloc / (ms * 1e-3) / 1e9,

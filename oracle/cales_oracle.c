@@ -428,6 +428,13 @@ void o_destroy(ostate *s) {
   for (int m = 0; m < 6; m++) { free(s->wk[m]); free(s->sij[m]); free(s->mij[m]); }
   free(s);
 }
+/* first touch of a haloed field by the threads that will work on its planes (timing aid of bench.py's cpu_baseline: a field allocated by the
+   caller and first written by one thread lives on that thread's NUMA node; the loops below are split over (k, j) like this one). No arithmetic. */
+void o_first_touch(const ostate *s, double *a) {
+  const int *n = s->n; const size_t s1 = s->s1, s2 = s->s2;
+  #pragma omp parallel for collapse(2) schedule(static) num_threads(s->nthreads)
+  for (int k = 0; k <= n[2] + 1; k++) for (int j = 0; j <= n[1] + 1; j++) memset(&a[(size_t)0 + s1*((size_t)j + s2*(size_t)k)], 0, sizeof(double)*s1);
+}
 void o_get_grid(const ostate *s, double *dzc, double *dzf, double *zc, double *zf) {
   size_t b = sizeof(double)*(s->n[2]+2);
   memcpy(dzc, s->dzc, b); memcpy(dzf, s->dzf, b); memcpy(zc, s->zc, b); memcpy(zf, s->zf, b);

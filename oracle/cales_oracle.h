@@ -47,6 +47,7 @@ ostate *o_create(const oparams *p);
 void    o_destroy(ostate *s);
 
 /* set-up products (src/initgrid.f90, src/bound.f90:726-867, src/initsolver.f90) */
+void o_first_touch(const ostate *s, double *a);
 void o_get_grid(const ostate *s, double *dzc, double *dzf, double *zc, double *zf);
 void o_get_index_wm(const ostate *s, int *index_wm);
 void o_get_cbcvel(const ostate *s, char *cbcvel);

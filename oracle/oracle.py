@@ -85,7 +85,10 @@ class Oracle:
 
     # ---- helpers
     def zeros(self) -> np.ndarray:
-        return np.zeros(self.shape, dtype=np.float64, order="F")
+        a = np.zeros(self.shape, dtype=np.float64, order="F")
+        if self.params.nthreads > 1 and a.nbytes > (1 << 26):      # large field, several threads: pages placed by the threads that will use them
+            self.lib.o_first_touch(self.h, _p(a))
+        return a
 
     def grid(self):
         n3 = self.n[2]
