@@ -14,7 +14,9 @@ N > 1: one process per GPU (torch.distributed.run), y-slab decomposition of the 
 """
 import os as _os
 _os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC between the ranks' processes (RCCL); must be set before the HIP runtime starts
-# threads of the CPU baseline pinned to cores (read by the OpenMP run-time when it is loaded, i.e. before torch pulls it in)
+# threads of the CPU baseline pinned to cores (read by the OpenMP run-time when it is loaded, i.e. before torch pulls it in). The host's thread count
+# is taken first: once the run-time has bound the main thread to its place, sched_getaffinity shows that one core only
+_HOST_THREADS = len(_os.sched_getaffinity(0)) if hasattr(_os, "sched_getaffinity") else (_os.cpu_count() or 1)
 _os.environ.setdefault("OMP_PROC_BIND", "spread"); _os.environ.setdefault("OMP_PLACES", "cores")
 import argparse
 import json
@@ -94,7 +96,7 @@ def cpu_baseline(case_full, seconds_budget=40.0, full_budget=150.0, sample_dims=
          measurement says it fits `full_budget` seconds (a warm-up step comes first when there is time for two).
     `value` is the full-size measurement when it exists, otherwise the sample's rate scaled by cell count (labelled `scaled`)."""
     from oracle.oracle import Oracle
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    avail = _HOST_THREADS
 
     def prepare(case, nthreads):
         o = Oracle(case, nthreads=nthreads)

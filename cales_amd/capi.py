@@ -31,7 +31,7 @@ SYMBOLS = ["cales_real_size", "cales_initgrid", "cales_initflow", "cales_check_c
            "cales_get_field", "cales_get_bcvel", "cales_bounduvw", "cales_boundp", "cales_mom", "cales_rk",
            "cales_bulk_forcing", "cales_get_forcing", "cales_bulk_mean", "cales_fillps", "cales_updt_rhs_b",
            "cales_solver", "cales_helmholtz_z", "cales_helmholtz", "cales_correc", "cales_updatep", "cales_cmpt_sgs", "cales_chkdt",
-           "cales_chkdiv", "cales_out1d_single_point_chan", "cales_out1d_chan_budgets", "cales_step", "cales_get_dpdl", "cales_profile_enable", "cales_profile_reset",
+           "cales_chkdiv", "cales_out1d_single_point_chan", "cales_out1d_chan_budgets", "cales_out1d", "cales_out1d_chan", "cales_out2d_duct", "cales_step", "cales_get_dpdl", "cales_profile_enable", "cales_profile_reset",
            "cales_profile_count", "cales_profile_get", "cales_device_info", "cales_comm_buffer_doubles", "cales_set_comm",
            "cales_initflow_slab", "cales_comm_unique_id", "cales_comm_init_rccl", "cales_comm_selftest",
            "cales_device_count", "cales_set_device", "cales_set_comm_overlap", "cales_rk_par"]
@@ -111,7 +111,7 @@ def lib() -> C.CDLL:
             "cales_fillps": [C.c_void_p, c_real], "cales_updt_rhs_b": [C.c_void_p], "cales_solver": [C.c_void_p],
             "cales_helmholtz_z": [C.c_void_p, C.c_int, c_real], "cales_helmholtz": [C.c_void_p, C.c_int, c_real], "cales_correc": [C.c_void_p, c_real],
             "cales_updatep": [C.c_void_p, c_real], "cales_cmpt_sgs": [C.c_void_p], "cales_chkdt": [C.c_void_p, dp],
-            "cales_chkdiv": [C.c_void_p, dp, dp], "cales_out1d_single_point_chan": [C.c_void_p, C.c_void_p], "cales_out1d_chan_budgets": [C.c_void_p, C.c_void_p, C.c_void_p], "cales_step": [C.c_void_p, c_real], "cales_get_dpdl": [C.c_void_p, dp],
+            "cales_chkdiv": [C.c_void_p, dp, dp], "cales_out1d_single_point_chan": [C.c_void_p, C.c_void_p], "cales_out1d_chan_budgets": [C.c_void_p, C.c_void_p, C.c_void_p], "cales_out1d": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p], "cales_out1d_chan": [C.c_void_p, C.c_void_p], "cales_out2d_duct": [C.c_void_p, C.c_void_p], "cales_step": [C.c_void_p, c_real], "cales_get_dpdl": [C.c_void_p, dp],
             "cales_profile_enable": [C.c_void_p, C.c_int], "cales_profile_reset": [C.c_void_p],
             "cales_profile_count": [C.c_void_p], "cales_profile_get": [C.c_void_p, C.c_int, C.c_char_p, C.c_int, dp, dp],
             "cales_device_info": [C.c_void_p, C.c_char_p, C.c_int, dp],

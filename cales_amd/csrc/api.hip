@@ -309,6 +309,9 @@ int cales_chkdt(cales_ctx *c, real *dtmax) { return op_chkdt(c, dtmax); }
 int cales_chkdiv(cales_ctx *c, real *divtot, real *divmax) { return op_chkdiv(c, divtot, divmax); }
 int cales_out1d_single_point_chan(cales_ctx *c, real *buf) { if (!c || !buf) return 1; return op_stats_chan(c, buf); }
 int cales_out1d_chan_budgets(cales_ctx *c, real *budget, real *leakage) { if (!c) return 1; return op_stats_chan_budget(c, budget, leakage); }
+int cales_out1d(cales_ctx *c, int field, int idir, int use_dzc, real *buf) { if (!c || !buf) return 1; return op_out1d(c, field, idir, use_dzc, buf); }
+int cales_out1d_chan(cales_ctx *c, real *buf) { if (!c || !buf) return 1; return op_out1d_chan(c, buf); }
+int cales_out2d_duct(cales_ctx *c, real *buf) { if (!c || !buf) return 1; return op_out2d_duct(c, buf); }
 
 // ------------------------------------------------------------------------------------------ time step (main.f90:412-508)
 __global__ void k_zero6(real *f) { if (threadIdx.x < 6) f[threadIdx.x] = 0.; }

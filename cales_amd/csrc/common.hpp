@@ -240,6 +240,9 @@ int op_correc(cales_ctx *c, real dtrk);
 int materialize_visct(cales_ctx *c);
 int op_stats_chan(cales_ctx *c, real *buf);
 int op_stats_chan_budget(cales_ctx *c, real *budget, real *leak);
+int op_out1d(cales_ctx *c, int field, int idir, int use_dzc, real *buf);
+int op_out1d_chan(cales_ctx *c, real *buf);
+int op_out2d_duct(cales_ctx *c, real *buf);
 bool solver_can_fuse_fillps(cales_ctx *c);
 int op_force_from_partials(cales_ctx *c, int mask, const real *part, int nblk);
 int op_correc_updatep(cales_ctx *c, real dtrk, real alpha, int upd);

@@ -672,6 +672,93 @@ int op_stats_chan_budget(cales_ctx *c, real *budget, real *leak) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------ profiles and duct statistics (output.f90:50-163, 317-507)
+// out1d (output.f90:50-163): the profile of a scalar along direction idir, averaged over the other two (weighted with dz(k) when z is one of them);
+// one block per entry of the profile, fixed summation order (threads stride the plane, wave and block sums in a fixed tree)
+__global__ __launch_bounds__(256) void k_out1d(Geom g, int idir, real ratio, const real *__restrict__ dz, const real *__restrict__ p, real *__restrict__ out) {
+  __shared__ real sh[4];
+  const int e = blockIdx.x + 1;
+  real acc = 0.;
+  if (idir == 3) {
+    const long np = (long)g.n1 * g.n2;
+    for (long q = threadIdx.x; q < np; q += 256) acc += p[g.ix((int)(q % g.n1) + 1, (int)(q / g.n1) + 1, e)];
+  } else if (idir == 2) {
+    const long np = (long)g.n1 * g.n3;
+    for (long q = threadIdx.x; q < np; q += 256) { const int k = (int)(q / g.n1) + 1; acc += p[g.ix((int)(q % g.n1) + 1, e, k)] * dz[k]; }
+  } else {
+    const long np = (long)g.n2 * g.n3;
+    for (long q = threadIdx.x; q < np; q += 256) { const int k = (int)(q / g.n2) + 1; acc += p[g.ix(e, (int)(q % g.n2) + 1, k)] * dz[k]; }
+  }
+  const real r = block_reduce<0>(acc, sh);
+  if (threadIdx.x == 0) out[e - 1] = r * ratio;
+}
+int op_out1d(cales_ctx *c, int field, int idir, int use_dzc, real *buf) {
+  if (field < 0 || field >= CALES_NFIELDS || idir < 1 || idir > 3) { c->err = "cales_out1d: bad field or direction"; return 1; }
+  if (field == CALES_VISCT) if (int e = materialize_visct(c)) return e;
+  const int ne = c->n[idir - 1];
+  real *out = nullptr; HIPCHK(c, hipMalloc(&out, (size_t)ne * sizeof(real)));
+  // grid_area_ratio of the reference: dl(1) dl(2) / (l(1) l(2)) along z, dl(1) / (l(1) l(3)) along y, dl(2) / (l(2) l(3)) along x
+  const real ratio = idir == 3 ? c->dl[0] * c->dl[1] / (c->C.l[0] * c->C.l[1]) : idir == 2 ? c->dl[0] / (c->C.l[0] * c->C.l[2]) : c->dl[1] / (c->C.l[1] * c->C.l[2]);
+  hipLaunchKernelGGL(k_out1d, dim3(ne), dim3(256), 0, c->stream, c->g, idir, ratio, use_dzc ? c->d_dzc : c->d_dzf, c->f[field], out);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(buf, out, (size_t)ne * sizeof(real), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  hipFree(out);
+  return 0;
+}
+// out1d_chan (output.f90:317-405, idir = 3): um, vm, wm, u2, v2, w2, uw per plane
+__global__ __launch_bounds__(256) void k_out1d_chan(Geom g, real ratio, const real *__restrict__ u, const real *__restrict__ v, const real *__restrict__ w, real *__restrict__ out) {
+  __shared__ real sh[4];
+  const int k = blockIdx.x + 1;
+  real b[7] = {0., 0., 0., 0., 0., 0., 0.};
+  const long np = (long)g.n1 * g.n2, sk = g.s12;
+  for (long q = threadIdx.x; q < np; q += 256) {
+    const size_t c = g.ix((int)(q % g.n1) + 1, (int)(q / g.n1) + 1, k);
+    const real uc = u[c], vc = v[c], wc = w[c], wm = w[c - sk];
+    b[0] += uc; b[1] += vc; b[2] += 0.50 * (wm + wc);
+    b[3] += uc * uc; b[4] += vc * vc; b[5] += 0.50 * (wc * wc + wm * wm);
+    b[6] += 0.25 * (u[c - 1] + uc) * (wm + wc);
+  }
+#pragma unroll
+  for (int q = 0; q < 7; ++q) { const real r = block_reduce<0>(b[q], sh); if (threadIdx.x == 0) out[q + 7 * (size_t)(k - 1)] = r * ratio; }
+}
+int op_out1d_chan(cales_ctx *c, real *buf) {
+  const int n3 = c->n[2];
+  real *out = nullptr; HIPCHK(c, hipMalloc(&out, (size_t)7 * n3 * sizeof(real)));
+  hipLaunchKernelGGL(k_out1d_chan, dim3(n3), dim3(256), 0, c->stream, c->g, c->dl[0] * c->dl[1] / (c->C.l[0] * c->C.l[1]), c->f[CALES_U], c->f[CALES_V], c->f[CALES_W], out);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(buf, out, (size_t)7 * n3 * sizeof(real), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  hipFree(out);
+  return 0;
+}
+// out2d_duct (output.f90:406-507, streamwise direction x): nine cell-centred averages along x for every (j, k); one wave per (j, k)
+__global__ __launch_bounds__(256) void k_out2d_duct(Geom g, real ratio, const real *__restrict__ u, const real *__restrict__ v, const real *__restrict__ w, real *__restrict__ out) {
+  const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6) + 1, k = blockIdx.y + 1;
+  if (j > g.n2) return;
+  real b[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.};
+  const long sj = g.s1, sk = g.s12;
+  for (int i = lane + 1; i <= g.n1; i += 64) {
+    const size_t c = g.ix(i, j, k);
+    const real uc = u[c], um = u[c - 1], vc = v[c], vm = v[c - sj], wc = w[c], wm = w[c - sk];
+    b[0] += uc; b[1] += 0.5 * (vm + vc); b[2] += 0.5 * (wm + wc);
+    b[3] += uc * uc; b[4] += 0.5 * (vm * vm + vc * vc); b[5] += 0.5 * (wm * wm + wc * wc);
+    b[6] += 0.25 * (um + uc) * (vm + vc); b[7] += 0.25 * (um + uc) * (wm + wc); b[8] += 0.25 * (vm + vc) * (wm + wc);
+  }
+#pragma unroll
+  for (int q = 0; q < 9; ++q) { const real r = wave_sum(b[q]); if (lane == 0) out[q + 9 * ((size_t)(j - 1) + (size_t)g.n2 * (k - 1))] = r * ratio; }
+}
+int op_out2d_duct(cales_ctx *c, real *buf) {
+  const int n2 = c->n[1], n3 = c->n[2];
+  real *out = nullptr; HIPCHK(c, hipMalloc(&out, (size_t)9 * n2 * n3 * sizeof(real)));
+  hipLaunchKernelGGL(k_out2d_duct, dim3((n2 + 3) / 4, n3), dim3(256), 0, c->stream, c->g, c->dl[0] / c->C.l[0], c->f[CALES_U], c->f[CALES_V], c->f[CALES_W], out);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(buf, out, (size_t)9 * n2 * n3 * sizeof(real), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  hipFree(out);
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------ chkdt (chkdt.f90:50-98)
 template <int IMP>
 __global__ __launch_bounds__(256) void k_chkdt_partial(Geom g, real dxi, real dyi, real visc, const real *__restrict__ dzci,

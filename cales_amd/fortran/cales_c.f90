@@ -76,6 +76,15 @@ module cales_c
     integer(c_int) function cales_out1d_chan_budgets(ctx,budget,leakage) bind(C,name='cales_out1d_chan_budgets')
       import; type(c_ptr), value :: ctx; real(c_rp) :: budget(38,*),leakage(6,*)
     end function
+    integer(c_int) function cales_out1d(ctx,field,idir,use_dzc,buf) bind(C,name='cales_out1d')
+      import; type(c_ptr), value :: ctx; integer(c_int), value :: field,idir,use_dzc; real(c_rp) :: buf(*)
+    end function
+    integer(c_int) function cales_out1d_chan(ctx,buf) bind(C,name='cales_out1d_chan')
+      import; type(c_ptr), value :: ctx; real(c_rp) :: buf(7,*)
+    end function
+    integer(c_int) function cales_out2d_duct(ctx,buf) bind(C,name='cales_out2d_duct')
+      import; type(c_ptr), value :: ctx; real(c_rp) :: buf(9,*)
+    end function
     integer(c_int) function cales_step(ctx,dt) bind(C,name='cales_step')
       import; type(c_ptr), value :: ctx; real(c_rp), value :: dt
     end function

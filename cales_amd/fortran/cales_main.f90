@@ -54,7 +54,7 @@ program cales
   integer(int64) :: c0,c1,crate,cstep0
   integer :: istep,iunit,ierr,k,m,impdiff,savecounter,rc
   integer :: myid,nranks,n2l,jlo          ! rank, number of ranks, rows of the slab, global row of local row 1 minus 1
-  logical :: is_done,kill,is_chan
+  logical :: is_done,kill,is_chan,is_duct
   character(len=512) :: iomsg,arg
   character(len=100) :: filename
   character(len=7) :: fldnum
@@ -146,6 +146,8 @@ program cales
   n2l = ng(2)/nranks; jlo = myid*n2l
   ! the plane statistics of out1d.h90's default (out1d_single_point_chan) are those of a channel: walls in z, periodic x and y
   is_chan = all(cbcpre(:,1) == 'P') .and. all(cbcpre(:,2) == 'P') .and. all(cbcvel(:,3,3) == 'D')
+  ! ... and the cross-stream maps of out2d_duct (the alternative its out1d.h90 names, src/out1d.h90:37) those of a duct along x: walls in y and z
+  is_duct = all(cbcpre(:,1) == 'P') .and. all(cbcvel(:,2,2) == 'D') .and. all(cbcvel(:,3,3) == 'D')
   !
   if(myid == 0) then
     print*, '*******************************'
@@ -320,6 +322,7 @@ contains
     ! out1d.h90 is a case-specific include of the reference; its default computes the channel statistics, which only mean
     ! something for a channel (walls in z, periodic x and y): other cases get no velstats files here
     if(do1d.and.is_chan) call out1d_chan_stats('velstats_fld_'//fldnum)
+    if(do1d.and.is_duct) call out2d_duct_stats('velstats_fld_'//fldnum//'.out')
     if(do2d.or.do3d) then     ! main.f90:580-589
       call chk(cales_download_state(ctx,u,v,w,p,visct))
       if(do2d) then     ! out2d.h90: the plane j = ng(2)/2 of the five fields
@@ -433,6 +436,23 @@ contains
     close(iu)
     open(newunit=iu,file=fname//'_leakage.bin',access='stream'); write(iu) leak; close(iu)
   end subroutine out1d_chan_stats
+  subroutine out2d_duct_stats(fname)    ! out2d_duct with the streamwise direction x, src/output.f90:406-507: its one text file, its format
+    character(len=*), intent(in) :: fname
+    real(rp), allocatable :: loc(:,:,:),glob(:,:,:)
+    integer :: iu,jj,kk,q
+    allocate(loc(9,n2l,ng(3)),glob(9,ng(2),ng(3)))
+    call chk(cales_out2d_duct(ctx,loc))
+    glob(:,:,:) = 0.; glob(:,jlo+1:jlo+n2l,:) = loc(:,:,:)      ! every rank holds its rows: the sum over ranks of output.f90:481-489
+    call allsum(glob,9*ng(2)*ng(3))
+    if(myid /= 0) return
+    open(newunit=iu,file=fname)
+    do kk=1,ng(3)
+      do jj=1,ng(2)
+        write(iu,'(11E16.7e3)') (jj-0.5)*(l(2)/(1.*ng(2))),zc(kk),(glob(q,jj,kk),q=1,9)
+      end do
+    end do
+    close(iu)
+  end subroutine out2d_duct_stats
   subroutine out0d(fname,n,vv)    ! src/output.f90:18-37
     character(len=*), intent(in) :: fname
     integer, intent(in) :: n

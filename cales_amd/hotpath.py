@@ -204,6 +204,24 @@ class HotPath:
         self._chk(self.L.cales_out1d_single_point_chan(self.h, _p(buf)))
         return buf
 
+    def out1d(self, field: str, idir: int, use_dzc: bool = False) -> np.ndarray:
+        """out1d (src/output.f90:50-163): profile of `field` along idir averaged over the other two directions (this rank's sums)."""
+        buf = np.zeros(self.n[idir - 1], dtype=capi.np_real)
+        self._chk(self.L.cales_out1d(self.h, capi.FIELDS[field], int(idir), int(use_dzc), _p(buf)))
+        return buf
+
+    def out1d_chan(self) -> np.ndarray:
+        """out1d_chan (src/output.f90:317-405): (7, n3) um, vm, wm, u2, v2, w2, uw per plane."""
+        buf = np.zeros((7, self.n[2]), dtype=capi.np_real, order="F")
+        self._chk(self.L.cales_out1d_chan(self.h, _p(buf)))
+        return buf
+
+    def out2d_duct(self) -> np.ndarray:
+        """out2d_duct (src/output.f90:406-507): (9, n2, n3) um, vm, wm, u2, v2, w2, uv, uw, vw at the cell centres of every (j, k)."""
+        buf = np.zeros((9, self.n[1], self.n[2]), dtype=capi.np_real, order="F")
+        self._chk(self.L.cales_out2d_duct(self.h, _p(buf)))
+        return buf
+
     def stats_chan_budgets(self):
         """Second and third block of out1d_single_point_chan (src/output.f90:700-1055): (38, n3) budget sums and (6, n3) divergence measures."""
         b = np.zeros((38, self.n[2]), order="F", dtype=REAL); l = np.zeros((6, self.n[2]), order="F", dtype=REAL)

@@ -117,6 +117,17 @@ int cales_out1d_single_point_chan(cales_ctx *ctx, cales_real *buf);
 #define CALES_NBUDGET_CHAN 38
 #define CALES_NLEAKAGE_CHAN 6
 int cales_out1d_chan_budgets(cales_ctx *ctx, cales_real *budget, cales_real *leakage);
+/* the other statistics routines a case may call from its out1d.h90 (src/out1d.h90:25-37), all sync, all returning THIS rank's sums (the caller
+ * adds / concatenates the ranks as the reference's MPI_ALLREDUCE does):
+ *   out1d      (src/output.f90:50-163): profile of `field` along idir (1, 2, 3) averaged over the other two directions, weighted with dzf(k)
+ *              (use_dzc = 0, cell-centred in z) or dzc(k) (use_dzc = 1: w) where z is averaged over; buf(n(idir))
+ *   out1d_chan (src/output.f90:317-405, idir = 3): um, vm, wm, u2, v2, w2, uw per plane; buf(7, n3)
+ *   out2d_duct (src/output.f90:406-507, streamwise x): um, vm, wm, u2, v2, w2, uv, uw, vw at cell centres for every (j, k); buf(9, n2, n3) */
+int cales_out1d(cales_ctx *ctx, int field, int idir, int use_dzc, cales_real *buf);
+#define CALES_NSTATS_OUT1D_CHAN 7
+int cales_out1d_chan(cales_ctx *ctx, cales_real *buf);
+#define CALES_NSTATS_DUCT 9
+int cales_out2d_duct(cales_ctx *ctx, cales_real *buf);
 
 /* one time step = 3 RK substeps in the order of src/main.f90:417-508; no host synchronisation */
 int cales_step(cales_ctx *ctx, cales_real dt);

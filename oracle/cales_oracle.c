@@ -264,7 +264,7 @@ static void fft_rec(int n, const cpx *in, int istride, cpx *out, const cpx *tw, 
   if (r == 0) { for (r = 7; r*r <= n; r += 2) if (n % r == 0) break; if (r*r > n) r = n; }
   int m = n/r;
   for (int q = 0; q < r; q++) fft_rec(m, in + (size_t)q*istride, istride*r, out + (size_t)q*m, tw, tstride*r);
-  cpx *t = (cpx *)malloc(sizeof(cpx)*r);
+  cpx tstack[64]; cpx *t = r <= 64 ? tstack : (cpx *)malloc(sizeof(cpx)*r);      /* (no allocator call per recursion level for the usual radices) */
   for (int k = 0; k < m; k++) {
     for (int q = 0; q < r; q++) {
       cpx x = out[(size_t)q*m + k], w = tw[(size_t)((long)q*k % n)*tstride];
@@ -279,11 +279,15 @@ static void fft_rec(int n, const cpx *in, int istride, cpx *out, const cpx *tw, 
       out[(size_t)p*m + k].re = sr; out[(size_t)p*m + k].im = si;
     }
   }
-  free(t);
+  if (t != tstack) free(t);
 }
 typedef struct { int n; cpx *tw; } twtab;
-static twtab g_tw[16]; static int g_ntw = 0;
+static twtab g_tw[16]; static volatile int g_ntw = 0;
 static const cpx *twiddles(int n) {
+  /* read-mostly table: the common case (the size is there) takes no lock -- a critical section around every line's look-up serialised the
+     transforms of all threads (the team of 64 ran slower than the team of 32). Entries are published by the counter, after they are complete. */
+  const int have = g_ntw;
+  for (int i = 0; i < have; i++) if (g_tw[i].n == n) return g_tw[i].tw;
   const cpx *res = NULL;
   #pragma omp critical(o_twid)
   {
@@ -291,7 +295,9 @@ static const cpx *twiddles(int n) {
     if (!res) {
       cpx *t = (cpx *)malloc(sizeof(cpx)*n);
       for (int q = 0; q < n; q++) { double a = -2.*PI*q/n; t[q].re = cos(a); t[q].im = sin(a); }
-      if (g_ntw < 16) { g_tw[g_ntw].n = n; g_tw[g_ntw].tw = t; g_ntw++; }
+      if (g_ntw < 16) { g_tw[g_ntw].n = n; g_tw[g_ntw].tw = t;
+        #pragma omp flush
+        g_ntw = g_ntw + 1; }
       res = t;
     }
   }
@@ -1020,6 +1026,46 @@ void o_stats_chan(ostate *s, const double *u, const double *v, const double *w, 
       b[26] += dudz;
     }
     for (int q = 0; q < 27; q++) buf[q + 27*(size_t)(k-1)] = b[q]*ratio;
+  }
+}
+
+/* out1d, out1d_chan (idir = 3), out2d_duct (streamwise x): src/output.f90:50-163, 317-405, 406-507. TEST INFRASTRUCTURE; pinned against the files the
+   reference's own routines write (compiled from their lines by oracle/ref/Makefile; they print 8 significant digits) */
+void o_out1d(ostate *s, int idir, int use_dzc, const double *p, double *buf) {
+  const int *n = s->n; const size_t s1 = s->s1, s2 = s->s2; const double *dz = use_dzc ? s->dzc : s->dzf;
+  const double dx = s->dl[0], dy = s->dl[1];
+  if (idir == 3) { const double r = dx*dy/(s->P.l[0]*s->P.l[1]);
+    for (int k = 1; k <= n[2]; k++) { double a = 0.; for (int j = 1; j <= n[1]; j++) for (int i = 1; i <= n[0]; i++) a += p[IX(i,j,k)]; buf[k-1] = a*r; }
+  } else if (idir == 2) { const double r = dx/(s->P.l[0]*s->P.l[2]);
+    for (int j = 1; j <= n[1]; j++) { double a = 0.; for (int k = 1; k <= n[2]; k++) for (int i = 1; i <= n[0]; i++) a += p[IX(i,j,k)]*dz[k]; buf[j-1] = a*r; }
+  } else { const double r = dy/(s->P.l[1]*s->P.l[2]);
+    for (int i = 1; i <= n[0]; i++) { double a = 0.; for (int k = 1; k <= n[2]; k++) for (int j = 1; j <= n[1]; j++) a += p[IX(i,j,k)]*dz[k]; buf[i-1] = a*r; }
+  }
+}
+void o_out1d_chan(ostate *s, const double *u, const double *v, const double *w, double *buf) {
+  const int *n = s->n; const size_t s1 = s->s1, s2 = s->s2; const double r = s->dl[0]*s->dl[1]/(s->P.l[0]*s->P.l[1]);
+  for (int k = 1; k <= n[2]; k++) {
+    double b[7] = {0.,0.,0.,0.,0.,0.,0.};
+    for (int j = 1; j <= n[1]; j++) for (int i = 1; i <= n[0]; i++) {
+      const double uc = u[IX(i,j,k)], vc = v[IX(i,j,k)], wc = w[IX(i,j,k)], wm = w[IX(i,j,k-1)];
+      b[0] += uc; b[1] += vc; b[2] += 0.50*(wm + wc);
+      b[3] += uc*uc; b[4] += vc*vc; b[5] += 0.50*(wc*wc + wm*wm);
+      b[6] += 0.25*(u[IX(i-1,j,k)] + uc)*(wm + wc);
+    }
+    for (int q = 0; q < 7; q++) buf[q + 7*(size_t)(k-1)] = b[q]*r;
+  }
+}
+void o_out2d_duct(ostate *s, const double *u, const double *v, const double *w, double *buf) {
+  const int *n = s->n; const size_t s1 = s->s1, s2 = s->s2; const double r = s->dl[0]/s->P.l[0];
+  for (int k = 1; k <= n[2]; k++) for (int j = 1; j <= n[1]; j++) {
+    double b[9] = {0.,0.,0.,0.,0.,0.,0.,0.,0.};
+    for (int i = 1; i <= n[0]; i++) {
+      const double uc = u[IX(i,j,k)], um = u[IX(i-1,j,k)], vc = v[IX(i,j,k)], vm = v[IX(i,j-1,k)], wc = w[IX(i,j,k)], wm = w[IX(i,j,k-1)];
+      b[0] += uc; b[1] += 0.5*(vm + vc); b[2] += 0.5*(wm + wc);
+      b[3] += uc*uc; b[4] += 0.5*(vm*vm + vc*vc); b[5] += 0.5*(wm*wm + wc*wc);
+      b[6] += 0.25*(um + uc)*(vm + vc); b[7] += 0.25*(um + uc)*(wm + wc); b[8] += 0.25*(vm + vc)*(wm + wc);
+    }
+    for (int q = 0; q < 9; q++) buf[q + 9*((size_t)(j-1) + (size_t)n[1]*(k-1))] = b[q]*r;
   }
 }
 

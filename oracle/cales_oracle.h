@@ -80,6 +80,9 @@ void o_cmpt_sgs(ostate *s, const double *u, const double *v, const double *w, do
 double o_chkdt(ostate *s, const double *visct, const double *u, const double *v, const double *w);
 void o_chkdiv(ostate *s, const double *u, const double *v, const double *w, double *divtot, double *divmax);
 void o_stats_chan(ostate *s, const double *u, const double *v, const double *w, const double *p, const double *visct, double *buf);
+void o_out1d(ostate *s, int idir, int use_dzc, const double *p, double *buf);
+void o_out1d_chan(ostate *s, const double *u, const double *v, const double *w, double *buf);
+void o_out2d_duct(ostate *s, const double *u, const double *v, const double *w, double *buf);
 
 /* one full time step = 3 RK substeps in the order of src/main.f90:417-507; f accumulates dpdl */
 void o_step(ostate *s, double dt, double *u, double *v, double *w, double *p, double *pp, double *visct,

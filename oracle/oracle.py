@@ -208,6 +208,24 @@ class Oracle:
         self.lib.o_stats_chan(self.h, _p(u), _p(v), _p(w), _p(p), _p(visct), _p(buf))
         return buf
 
+    def out1d(self, idir: int, p, use_dzc: bool = False) -> np.ndarray:
+        """out1d (output.f90:50-163): profile of p along idir averaged over the other two directions"""
+        buf = np.zeros(self.n[idir - 1])
+        self.lib.o_out1d(self.h, int(idir), int(use_dzc), _p(p), _p(buf))
+        return buf
+
+    def out1d_chan(self, u, v, w) -> np.ndarray:
+        """out1d_chan (output.f90:317-405): (7, n3) um, vm, wm, u2, v2, w2, uw"""
+        buf = np.zeros((7, self.n[2]), order="F")
+        self.lib.o_out1d_chan(self.h, _p(u), _p(v), _p(w), _p(buf))
+        return buf
+
+    def out2d_duct(self, u, v, w) -> np.ndarray:
+        """out2d_duct (output.f90:406-507): (9, n2, n3) um, vm, wm, u2, v2, w2, uv, uw, vw at the cell centres of every (j, k)"""
+        buf = np.zeros((9, self.n[1], self.n[2]), order="F")
+        self.lib.o_out2d_duct(self.h, _p(u), _p(v), _p(w), _p(buf))
+        return buf
+
     def step(self, dt, u, v, w, p, pp, visct):
         dpdl = np.zeros(3)
         self.lib.o_step(self.h, C.c_double(dt), _p(u), _p(v), _p(w), _p(p), _p(pp), _p(visct), _p(dpdl))

@@ -403,6 +403,50 @@ subroutine ref_out1d_single_point_chan(fname_c,nchar,u,v,w,p,visct) bind(C,name=
   call out1d_single_point_chan(fname,ng,lo,hi,3,l,dl,dzc,dzf,zc,zf,u,v,w,p,visct)
 end subroutine ref_out1d_single_point_chan
 !
+! out1d (src/output.f90:50-163), out1d_chan (317-405, idir = 3), out2d_duct (406-507, streamwise x): each writes ONE text file of 8 significant digits
+subroutine ref_out1d(fname_c,nchar,idir,use_dzc,p) bind(C,name='ref_out1d')
+  use, intrinsic :: iso_c_binding
+  use ref_state
+  use mod_param, only: ng,l,dl
+  use mod_output_stats, only: out1d
+  implicit none
+  integer(c_int), intent(in), value :: nchar,idir,use_dzc
+  character(kind=c_char), intent(in) :: fname_c(nchar)
+  real(c_double), intent(in), dimension(0:n(1)+1,0:n(2)+1,0:n(3)+1) :: p
+  character(len=:), allocatable :: fname
+  integer :: q
+  allocate(character(len=nchar) :: fname)
+  do q = 1,nchar
+    fname(q:q) = fname_c(q)
+  end do
+  if(use_dzc /= 0) then
+    call out1d(fname,ng,lo,hi,idir,l,dl,zf,dzc,p)
+  else
+    call out1d(fname,ng,lo,hi,idir,l,dl,zc,dzf,p)
+  end if
+end subroutine ref_out1d
+subroutine ref_out_uvw(which,fname_c,nchar,u,v,w) bind(C,name='ref_out_uvw')      ! which = 0: out1d_chan, 1: out2d_duct
+  use, intrinsic :: iso_c_binding
+  use ref_state
+  use mod_param, only: ng,l,dl
+  use mod_output_stats, only: out1d_chan,out2d_duct
+  implicit none
+  integer(c_int), intent(in), value :: which,nchar
+  character(kind=c_char), intent(in) :: fname_c(nchar)
+  real(c_double), intent(in), dimension(0:n(1)+1,0:n(2)+1,0:n(3)+1) :: u,v,w
+  character(len=:), allocatable :: fname
+  integer :: q
+  allocate(character(len=nchar) :: fname)
+  do q = 1,nchar
+    fname(q:q) = fname_c(q)
+  end do
+  if(which == 0) then
+    call out1d_chan(fname,ng,lo,hi,3,l,dl,zc,u,v,w)
+  else
+    call out2d_duct(fname,ng,lo,hi,1,l,dl,zc,u,v,w)
+  end if
+end subroutine ref_out_uvw
+!
 ! the plain-arithmetic routines of initsolver.f90 / solver.f90 (compiled from their own lines, see the Makefile)
 subroutine ref_eigenvalues(n,cbc2,c_or_f,lambda) bind(C,name='ref_eigenvalues')
   use, intrinsic :: iso_c_binding

@@ -143,6 +143,25 @@ class Ref:
         rd = lambda suffix, nv: np.fromfile(fname + suffix + ".bin").reshape((nv, n3), order="F")
         return rd("", 27), rd("_reystr_budget", 38), rd("_leakage", 6)
 
+    def out1d(self, idir, p, use_dzc=False, fname="out1d_ref.out"):
+        """the reference's out1d (src/output.f90:50-163): (coordinate, profile) as printed, 8 significant digits"""
+        b = fname.encode()
+        self.lib.ref_out1d(b, C.c_int(len(b)), C.c_int(int(idir)), C.c_int(int(use_dzc)), _p(p))
+        t = np.loadtxt(fname, ndmin=2)
+        return t[:, 0], t[:, 1]
+
+    def out1d_chan(self, u, v, w, fname="out1d_chan_ref.out"):
+        """out1d_chan (src/output.f90:317-405): the file's columns (z, um, vm, wm, u2, v2, w2, uw) as an (n3, 8) array"""
+        b = fname.encode()
+        self.lib.ref_out_uvw(C.c_int(0), b, C.c_int(len(b)), _p(u), _p(v), _p(w))
+        return np.loadtxt(fname, ndmin=2)
+
+    def out2d_duct(self, u, v, w, fname="out2d_duct_ref.out"):
+        """out2d_duct (src/output.f90:406-507): the file's rows (y, z, um, vm, wm, u2, v2, w2, uv, uw, vw), j fastest, as an (n2 n3, 11) array"""
+        b = fname.encode()
+        self.lib.ref_out_uvw(C.c_int(1), b, C.c_int(len(b)), _p(u), _p(v), _p(w))
+        return np.loadtxt(fname, ndmin=2)
+
     # ---- plain-arithmetic routines of initsolver.f90:66-169 and solver.f90:82-179
     def eigenvalues(self, n, cbc2, c_or_f):
         lam = np.zeros(int(n))

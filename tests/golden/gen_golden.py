@@ -260,18 +260,57 @@ np.savez({{tmp!r}} + '/g.npz', **g); r.finalize()
     print("grids: ok")
 
 
+def run_outstats(out):
+    """out1d, out1d_chan and out2d_duct of the reference (src/output.f90:50-163, 317-507; compiled from their lines, oracle/ref/Makefile) on the
+    end-of-step state of every full golden case (taken from the committed vectors: no case is re-run). The routines write text files of 8
+    significant digits; what they print is stored as it is read back."""
+    from oracle.ref.refpy import Ref
+    G = {}
+    for name in CASES:
+        _, _, imp = CASES[name]
+        if imp == 1:
+            continue                    # (operator-level vectors only: no end-of-step state)
+        g = np.load(os.path.join(HERE, name + ".npz"))
+        code = f"""
+import os, sys, tempfile, numpy as np
+sys.path.insert(0, {ROOT!r})
+from oracle.ref.refpy import Ref
+g = np.load({os.path.join(HERE, name + '.npz')!r})
+tmp = tempfile.mkdtemp(prefix="gold_"); open(os.path.join(tmp, "input.nml"), "w").write(str(g["input_nml"])); os.chdir(tmp)
+ref = Ref({imp})
+F = lambda a: np.asfortranarray(a)
+u, v, w = F(g["r3_s7_u"]), F(g["r3_s7_v"]), F(g["r3_s7_w"])
+o = {{}}
+for key, (idir, fld, dzc) in dict(u_z=(3, u, 0), v_y=(2, v, 0), w_x=(1, w, 1), w_z=(3, w, 1), u_y=(2, u, 0)).items():
+    x, y = ref.out1d(idir, fld, bool(dzc)); o["out1d_" + key] = np.stack([x, y])
+o["out1d_chan"] = ref.out1d_chan(u, v, w)
+o["out2d_duct"] = ref.out2d_duct(u, v, w)
+np.savez(os.path.join(tmp, "o.npz"), **o); print(tmp)
+ref.finalize()
+"""
+        tmp = subprocess.check_output([sys.executable, "-c", code], text=True).strip().splitlines()[-1]
+        o = np.load(os.path.join(tmp, "o.npz"))
+        for k in o.files:
+            G[name + "__" + k] = o[k]
+        print("outstats:", name, "ok")
+    np.savez_compressed(out, **G)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--case", default=None)
     a = ap.parse_args()
     if a.case == "grids":
         run_grids(os.path.join(HERE, "grids.npz"))
+    elif a.case == "outstats":
+        run_outstats(os.path.join(HERE, "outstats.npz"))
     elif a.case:
         run_case(a.case, os.path.join(HERE, a.case + ".npz"))
     else:
         for name in CASES:
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--case", name])
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "--case", "grids"])
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "--case", "outstats"])
     # the manifest follows whatever was (re)generated: case list, grid list and a digest of every vector file
     import hashlib
     json.dump({"cases": list(CASES), "grids": GRIDS,

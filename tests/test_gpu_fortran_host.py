@@ -81,8 +81,16 @@ def test_fortran_host_equals_python_host(tmp_path, name):
     # plane statistics written at iout1d (out1d.h90 -> out1d_single_point_chan): zc, zf, 27 columns, dzc, dzf per plane + raw .bin;
     # only for channels (walls in z, periodic x and y): the reference's out1d.h90 is a per-case include
     is_chan = bool((case.cbcpre[:, :2] == "P").all() and (case.cbcvel[:, 2, 2] == "D").all())
-    assert os.path.exists(os.path.join(tmp_path, "velstats_fld_0000004.out")) == is_chan
-    assert os.path.exists(os.path.join(tmp_path, "velstats_fld_0000000.out")) == is_chan      # initial field, main.f90:377-395
+    # ducts along x (walls in y and z) get the cross-stream maps of out2d_duct instead (src/out1d.h90:37): one text file in the reference's format
+    is_duct = bool((case.cbcpre[:, 0] == "P").all() and (case.cbcvel[:, 1, 1] == "D").all() and (case.cbcvel[:, 2, 2] == "D").all())
+    assert os.path.exists(os.path.join(tmp_path, "velstats_fld_0000004.out")) == (is_chan or is_duct)
+    assert os.path.exists(os.path.join(tmp_path, "velstats_fld_0000000.out")) == (is_chan or is_duct)      # initial field, main.f90:377-395
+    if is_duct:
+        from tests.test_oracle_golden import printed_equal
+        txt = np.loadtxt(os.path.join(tmp_path, "velstats_fld_0000004.out"))
+        assert txt.shape == (ng[1] * ng[2], 11)
+        printed_equal(h.out2d_duct().reshape(9, ng[1] * ng[2], order="F").T, txt[:, 2:], "out2d_duct as written by the host", floor=1e-13)
+        printed_equal(np.tile((np.arange(ng[1]) + 0.5) * float(case.l[1]) / ng[1], ng[2]), txt[:, 0], "y")
     if is_chan:
         st = h.stats_chan()
         txt = np.loadtxt(os.path.join(tmp_path, "velstats_fld_0000004.out"))

@@ -278,3 +278,51 @@ def test_plane_statistics_against_reference(name):
         # columns that vanish by cancellation (mean w, mean vorticity of a periodic box ...) are held to 1e-14 of the block's largest column
         assert (np.abs(got - ref) <= 1e-12 * scale + 1e-14 * np.abs(ref).max()).all(), (nm, np.abs(got - ref).max(axis=1) / np.maximum(scale[:, 0], 1e-300))
     h.close()
+
+
+@pytest.mark.parametrize("name", ["tgv_ppp", "chan_smag_wm", "chan_dsmag", "duct_smag_wm", "duct_smag_wm_imp1d", "duct_dsmag", "cavity_nnn", "devchan_nd", "halfchan_imp1d"])
+def test_profiles_and_duct_statistics(name):
+    """cales_out1d, cales_out1d_chan, cales_out2d_duct (src/output.f90:50-163, 317-507) on the end-of-step state of the golden cases: against what
+    the reference's own routines print (8 significant digits, tests/golden/outstats.npz) and against the oracle to 1e-13 of each column's scale
+    (fixed summation order on the device, another association than the reference's loops)."""
+    from oracle.oracle import Oracle
+    from tests.test_oracle_golden import outstats_of, printed_equal
+    g, case, G, (u, v, w) = outstats_of(name, None)
+    h = _hot(case); o = Oracle(case)
+    for k, a in zip("uvw", (u, v, w)):
+        h.set(k, a)
+    vmax = max(np.abs(a).max() for a in (u, v, w)); fl = 1e-13 * max(vmax, vmax ** 2)
+    close = lambda a, b: np.abs(np.asarray(a) - np.asarray(b)).max() <= 1e-13 * np.abs(b).max() + fl
+    for key, (idir, fld, dzc) in dict(u_z=(3, "u", 0), v_y=(2, "v", 0), w_x=(1, "w", 1), w_z=(3, "w", 1), u_y=(2, "u", 0)).items():
+        mine = h.out1d(fld, idir, bool(dzc))
+        fa = dict(u=u, v=v, w=w)[fld]
+        printed_equal(mine, G[f"{name}__out1d_{key}"][1], key, floor=1e-13 * np.abs(fa).max())
+        assert np.abs(mine - o.out1d(idir, fa, bool(dzc))).max() <= 1e-13 * np.abs(fa).max(), key
+    ch = h.out1d_chan()
+    printed_equal(ch.T, G[name + "__out1d_chan"][:, 1:], "out1d_chan", floor=fl)
+    oc = o.out1d_chan(u, v, w)
+    assert all(close(ch[q], oc[q]) for q in range(7))
+    n2, n3 = int(case.ng[1]), int(case.ng[2])
+    du = h.out2d_duct()
+    printed_equal(du.reshape(9, n2 * n3, order="F").T, G[name + "__out2d_duct"][:, 2:], "out2d_duct", floor=fl)
+    od = o.out2d_duct(u, v, w)
+    assert all(close(du[q], od[q]) for q in range(9))
+    h.close()
+
+
+def test_profiles_on_slabs_add_up():
+    """Several ranks: every rank returns the sums over its rows; added (profiles along x and z, the seven plane sums) or laid side by side
+    (profile along y, the duct maps) they are the one-rank result."""
+    from cales_amd.decomp import run_loopback
+    from cales_amd.hotpath import initflow
+    g, case = load_golden("duct_smag_wm"); case.ng[:] = (16, 24, 12); case.hwm = 0.3
+    h = _hot(case); u, v, w, p = initflow(case); h.upload(u, v, w, p); h.startup()
+    ref = dict(z=h.out1d("u", 3), y=h.out1d("u", 2), x=h.out1d("w", 1, True), chan=h.out1d_chan(), duct=h.out2d_duct()); h.close()
+
+    def body(hh, r):
+        hh.upload_initial(); hh.startup()
+        return dict(z=hh.out1d("u", 3), y=hh.out1d("u", 2), x=hh.out1d("w", 1, True), chan=hh.out1d_chan(), duct=hh.out2d_duct())
+    res = run_loopback(case, 3, body)
+    tol = lambda a, b: np.abs(a - b).max() <= 1e-13 * np.abs(b).max()
+    assert tol(sum(r["z"] for r in res), ref["z"]) and tol(sum(r["x"] for r in res), ref["x"]) and tol(sum(r["chan"] for r in res), ref["chan"])
+    assert tol(np.concatenate([r["y"] for r in res]), ref["y"]) and tol(np.concatenate([r["duct"] for r in res], axis=1), ref["duct"])

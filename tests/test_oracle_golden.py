@@ -2,6 +2,8 @@
 own compiled operators (tests/golden/gen_golden.py). Each operator is fed the GOLDEN input of its
 stage, so errors do not accumulate. Tolerance 1e-13 relative; most stages are
 bit-identical because the oracle keeps the reference's expression order."""
+import os
+
 import numpy as np
 import pytest
 
@@ -219,6 +221,45 @@ def test_manifest_lists_every_golden_file():
     man = json.load(open(os.path.join(here, "manifest.json")))
     files = sorted(f for f in os.listdir(here) if f.endswith(".npz"))
     assert sorted(man["files"]) == files
-    assert sorted(c + ".npz" for c in man["cases"]) + ["grids.npz"] == sorted(files) or set(c + ".npz" for c in man["cases"]) | {"grids.npz"} == set(files)
+    assert set(c + ".npz" for c in man["cases"]) | {"grids.npz", "outstats.npz"} == set(files)
     for f in files:
         assert hashlib.sha256(open(os.path.join(here, f), "rb").read()).hexdigest()[:16] == man["files"][f], f
+
+
+OUTSTATS_CASES = ["tgv_ppp", "chan_smag_wm", "chan_dsmag", "duct_smag_wm", "duct_smag_wm_imp1d", "duct_dsmag", "cavity_nnn", "devchan_nd", "halfchan_imp1d"]
+
+
+def printed_equal(mine, printed, what, floor=0.):
+    """`printed` = numbers read back from a file the reference wrote with E16.7e3, i.e. 0.ddddddd x 10^e: half a unit of the seventh digit is
+    between 5e-8 (mantissa near 1) and 5e-7 (mantissa near 0.1) of the value; sums that cancel to round-off are compared on the scale of the column
+    or, where the whole column is round-off (the plane mean of w in a closed box), on `floor` = 1e-13 of the scale of the field that was summed."""
+    mine, printed = np.asarray(mine, float), np.asarray(printed, float)
+    scale = np.abs(printed).max() if printed.size else 0.
+    assert np.all(np.abs(mine - printed) <= 5.1e-7 * np.abs(printed) + 1e-13 * scale + floor + 1e-300), (what, np.abs(mine - printed).max(), scale)
+
+
+def outstats_of(name, fn):
+    """(printed by the reference, computed by `fn(kind, ...)`) for the profiles and duct statistics of one golden case's end-of-step state"""
+    g, case = load_golden(name)
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "outstats.npz"))
+    u, v, w = F(g["r3_s7_u"]), F(g["r3_s7_v"]), F(g["r3_s7_w"])
+    return g, case, G, (u, v, w)
+
+
+@pytest.mark.parametrize("name", OUTSTATS_CASES)
+def test_profiles_and_duct_statistics_against_reference(name):
+    """out1d, out1d_chan, out2d_duct (src/output.f90:50-163, 317-507): the oracle against what the reference's own routines print (their lines are
+    compiled by oracle/ref/Makefile; tests/golden/gen_golden.py --case outstats) for the end-of-step state of the golden cases."""
+    g, case, G, (u, v, w) = outstats_of(name, None)
+    o = Oracle(case)
+    for key, (idir, fld, dzc) in dict(u_z=(3, u, 0), v_y=(2, v, 0), w_x=(1, w, 1), w_z=(3, w, 1), u_y=(2, u, 0)).items():
+        printed_equal(o.out1d(idir, fld, bool(dzc)), G[f"{name}__out1d_{key}"][1], key, floor=1e-13 * np.abs(fld).max())
+    vmax = max(np.abs(a).max() for a in (u, v, w))
+    printed_equal(o.out1d_chan(u, v, w).T, G[name + "__out1d_chan"][:, 1:], "out1d_chan", floor=1e-13 * max(vmax, vmax ** 2))
+    n2, n3 = int(case.ng[1]), int(case.ng[2])
+    duct = G[name + "__out2d_duct"]                                   # rows (y, z, 9 values), j fastest
+    printed_equal(o.out2d_duct(u, v, w).reshape(9, n2 * n3, order="F").T, duct[:, 2:], "out2d_duct", floor=1e-13 * max(vmax, vmax ** 2))
+    # the coordinates the files carry: cell centres in y (uniform) and z (the grid's zc)
+    dl2 = float(case.l[1]) / n2
+    printed_equal(np.tile((np.arange(n2) + 0.5) * dl2, n3), duct[:, 0], "y")
+    printed_equal(np.repeat(o.grid()["zc"][1:-1], n2), duct[:, 1], "z")
