@@ -504,13 +504,16 @@ struct LmfArgs { LijMijArgs L; const real *ss[6]; int by0; BandMap bm; int gx; }
 // counted: the 18 |S|Sij loads are waited for with the 6 velocity loads of the next plane still in flight, and those with the next 18.
 // For the same reason the block sums of a chunk's planes are collected in LDS and stored after the loop (a store inside the loop is a
 // vector-memory operation in a branch as well), and the per-plane grid coefficients come through the scalar cache one plane ahead.
-constexpr int LMF_KMAX = 512;      // longest k chunk (block sums of a chunk in LDS: 2 x 512 x 8 B of the 9.9 KB the tile leaves)
+constexpr int LMF_KMAX = 256;      // longest k chunk (block sums of a chunk in LDS: 2 x 256 x 8 B of the 9.9 KB the tile leaves)
 template <typename OFF, int YW>      // YW = 1: walls or wall-model faces in y (ducts); 0: the channel instantiation carries none of that logic
 __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) {
   const LijMijArgs &A = B.L;
   __shared__ real sh[2][9][TYL + 2][64];
   __shared__ real ring[4][3][TYL + 2][64];
-  __shared__ real shr[2][2][TYL + 2];
+  // plane sums: every working wave adds its lanes in fours (two DPP steps) and leaves sixteen partial sums per quantity; the first halo wave, idle
+  // behind the barrier, adds the 128 partials of the previous plane (the full six-step wave sum ran in all ten waves before: 24 vector instructions
+  // per plane and wave less in a pass that is bound by them)
+  __shared__ real psum[2][2][TYL][16];
   __shared__ real bsum[2][LMF_KMAX];
   const int tx = threadIdx.x, ty = threadIdx.y;
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
@@ -568,10 +571,11 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
   ssload(kbeg, rw); sscomb(rw, xc);
   ssload(kbeg + 1, rw);
   const int blk = by * B.gx + bx;
-  auto fold = [&](int k, int b) {      // block sums of plane k, fixed order
-    real a = 0., bs = 0.;
-    for (int q = 1; q <= TYL; ++q) { a += shr[b][0][q]; bs += shr[b][1][q]; }
-    bsum[0][k - kbeg] = a; bsum[1][k - kbeg] = bs;
+  auto fold = [&](int k, int b) {      // block sums of plane k by ONE whole wave, fixed order
+    const real *p0 = &psum[b][0][0][0], *p1 = &psum[b][1][0][0];
+    static_assert(TYL * 16 == 128, "two partials per lane");
+    const real a = wave_sum_lane63(p0[tx] + p0[tx + 64]), bs = wave_sum_lane63(p1[tx] + p1[tx + 64]);
+    if (tx == 63) { bsum[0][k - kbeg] = a; bsum[1][k - kbeg] = bs; }
   };
   // grid coefficients of the plane, one plane ahead through the scalar cache (uniform: scalar registers)
   real zcm = ldc(A.dzci, kbeg - 1), zcc = ldc(A.dzci, kbeg), zfc = ldc(A.dzfi, kbeg);
@@ -595,7 +599,7 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
       sh[buf][q][ty][tx] = r[q];
     }
     __syncthreads();
-    if (k > kbeg && tx == 0 && ty == 0) fold(k - 1, buf ^ 1);
+    if (k > kbeg && ty == 0) fold(k - 1, buf ^ 1);
     // plane k+1 of |S|Sij: its 18 loads were issued at the end of the previous plane and are folded into six values here, before
     // the register-hungry part; the next 18 are issued after it (keeps the kernel under the 168 VGPRs that ten waves per block need)
     sscomb(rw, xp);
@@ -647,8 +651,8 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
       mm = m[0] * m[0] + m[1] * m[1] + m[2] * m[2] + (m[3] * m[3] + m[4] * m[4] + m[5] * m[5]) * 2.;       // sgs.f90:350-355
     }
     ssload(min(k + 2, g.n3 + 1), rw);
-    lm = wave_sum_lane63(lm); mm = wave_sum_lane63(mm);      // (valid in lane 63 only)
-    if (tx == 63) { shr[buf][0][ty] = lm; shr[buf][1][ty] = mm; }
+    lm += dpp_f64<0x111>(lm); lm += dpp_f64<0x112>(lm); mm += dpp_f64<0x111>(mm); mm += dpp_f64<0x112>(mm);      // row_shr 1, 2: lanes 3, 7, 11, ... hold four lanes' sum
+    if ((tx & 3) == 3 && ty >= 1 && ty <= TYL) { psum[buf][0][ty - 1][tx >> 2] = lm; psum[buf][1][ty - 1][tx >> 2] = mm; }
 #pragma unroll
     for (int q = 0; q < 3; ++q) { sm[q] = sc[q]; sc[q] = sp[q]; sp[q] = sn[q]; }
 #pragma unroll
@@ -664,7 +668,7 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
     if (k <= kend) plane(k, F_, T);
   }
   __syncthreads();
-  if (tx == 0 && ty == 0 && kend >= kbeg) fold(kend, kend & 1);
+  if (ty == 0 && kend >= kbeg) fold(kend, kend & 1);
   __syncthreads();
   // the chunk's block sums leave in one go
   for (int q = ty * 64 + tx; q < 2 * (kend - kbeg + 1); q += 64 * (TYL + 2)) {
