@@ -68,7 +68,7 @@ struct Spec {
 
 // Run-time switches: read from the environment ONCE, by cales_create; the launch path only looks at these fields.
 struct Flags {
-  bool unaligned = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_eager = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, gaussel_pair = false, unfused_rk = false, dsmag_unfused_filter = false, overlap = false, unmerged_bc = false, smag_tile = false, plain_grid = false, band_grid = false;
+  bool unaligned = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_eager = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, gaussel_pair = false, unfused_rk = false, dsmag_unfused_filter = false, overlap = false, fft_staged = false, dsmag_store_uc = false, unmerged_bc = false, smag_tile = false, plain_grid = false, band_grid = false;
   int kchunk = 0; long tile_min_blocks = 2048; int smag_ty = 10;
   void read_env() {
     unaligned = getenv("CALES_UNALIGNED") != nullptr;
@@ -83,12 +83,14 @@ struct Flags {
     dsmag_reference_sequence = getenv("CALES_DSMAG_REFERENCE_SEQUENCE") != nullptr;
     dsmag_eager = getenv("CALES_DSMAG_EAGER") != nullptr;
     dsmag_xghosts = getenv("CALES_DSMAG_XGHOSTS") != nullptr;
+    dsmag_store_uc = getenv("CALES_DSMAG_STORE_UC") != nullptr;      // K_AC stores the cell-centred velocity (three fields) instead of the last pass forming it
     smag_reference_sequence = getenv("CALES_SMAG_REFERENCE_SEQUENCE") != nullptr;
     smag_tile = getenv("CALES_SMAG_TILE") != nullptr;
     plain_grid = getenv("CALES_PLAIN_GRID") != nullptr;
     band_grid = getenv("CALES_BAND_GRID") != nullptr;
     gaussel_march = getenv("CALES_GAUSSEL_MARCH") != nullptr;
     fft_generic = getenv("CALES_FFT_GENERIC") != nullptr;
+    fft_staged = getenv("CALES_FFT_STAGED") != nullptr;      // the radix-8 kernels with staging copies through LDS (k_fft_y8) instead of the register-ended ones
     keep_null_mode = getenv("CALES_KEEP_NULL_MODE") != nullptr;
     gaussel_pair = getenv("CALES_GAUSSEL_PAIR") != nullptr;
     unfused_rk = getenv("CALES_UNFUSED_RK") != nullptr;

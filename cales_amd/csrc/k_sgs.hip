@@ -373,6 +373,9 @@ struct LijMijArgs {
   int perx;                             // x ghost columns of uc.., uf.. are not stored: wrap around
   // y walls owned by this rank (k_lmf_tile only): wall rule of the filters along y, alph2 of the wall rows; wall-model y faces: ghost rows of u_f, w_f
   int wylo, wyhi, wmylo, wmyhi;
+  // k_lmf_tile<.., UCF = 1>: uc[] are the velocities u, v, w themselves and the cell-centred velocity (sgs.f90:860-869) is formed while loading;
+  // vcg = the field whose ghost row 0 holds v_c of the row below the slab (periodic copy or the neighbour's), the one value v(-1) would be needed for
+  const real *vcg; int perz;
 };
 template <typename OFF>
 __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijArgs A) {
@@ -505,7 +508,10 @@ struct LmfArgs { LijMijArgs L; const real *ss[6]; int by0; BandMap bm; int gx; }
 // For the same reason the block sums of a chunk's planes are collected in LDS and stored after the loop (a store inside the loop is a
 // vector-memory operation in a branch as well), and the per-plane grid coefficients come through the scalar cache one plane ahead.
 constexpr int LMF_KMAX = 256;      // longest k chunk (block sums of a chunk in LDS: 2 x 256 x 8 B of the 9.9 KB the tile leaves)
-template <typename OFF, int YW>      // YW = 1: walls or wall-model faces in y (ducts); 0: the channel instantiation carries none of that logic
+// UCF = 1: the cell-centred velocity u_c = (u(i) + u(i-1))/2, v_c = (v(j) + v(j-1))/2, w_c = (w(k) + w(k-1))/2 (sgs.f90:860-869, the same expressions
+// K_AC stored) is formed here from u, v, w: five loads per plane instead of three, and K_AC writes three fields less (3 of its 16 words; the pass is
+// bound by its writes) -- x periodic, z walls or periodic, y periodic / slab neighbours / walls; otherwise UCF = 0 reads the stored fields.
+template <typename OFF, int YW, int UCF>      // YW = 1: walls or wall-model faces in y (ducts); 0: the channel instantiation carries none of that logic
 __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) {
   const LijMijArgs &A = B.L;
   __shared__ real sh[2][9][TYL + 2][64];
@@ -540,11 +546,29 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
     return ldb(A.uf[q], o);
   };
   const bool ylo = YW && A.wylo && j == 1, yhi = YW && A.wyhi && j == g.n2;      // rows next to a y wall: ghost row of every filtered quantity = 2 Q(1) - Q(2)
+  // UCF: v(j) and v(j-1) of this thread's row, or -- ghost row 0, whose lower neighbour is not in the slab -- the stored v_c of that row with weight 1
+  const real *pva = (UCF && jc == 0) ? A.vcg : A.uc[1];
+  const OFF ovb = (UCF && jc > 0) ? sj : 0;
+  const real cva = (UCF && jc == 0) ? 1. : .5, cvb = (UCF && jc == 0) ? 0. : .5;
+  real wprev = 0.;
+  auto ucload = [&](int kk, real *o) {      // cell-centred velocity of plane kk (wprev = w of plane kk - 1 on entry, of plane kk on exit)
+    const OFF a = c0 + (OFF)kk * sk;
+    o[0] = .5 * (ldb(A.uc[0], a) + ldb(A.uc[0], a - (OFF)RSZ));
+    o[1] = cva * ldb(pva, a) + cvb * ldb(A.uc[1], a - ovb);
+    const real wn = ldb(A.uc[2], a); o[2] = .5 * (wn + wprev); wprev = wn;
+  };
+  if (UCF) {
+    const int k2 = kbeg - 2 >= 0 ? kbeg - 2 : (A.perz ? g.n3 - 1 : 0);      // w below the first plane (periodic z: wrapped; walls: never used)
+    wprev = ldb(A.uc[2], c0 + (OFF)k2 * sk);
+    ucload(kbeg - 1, sm); ucload(kbeg, sc); ucload(kbeg + 1, sp);
+  }
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
-    sm[q] = ldb(A.uc[q], c0 + (OFF)(kbeg - 1) * sk);
-    sc[q] = ldb(A.uc[q], c0 + (OFF)kbeg * sk);
-    sp[q] = ldb(A.uc[q], c0 + (OFF)(kbeg + 1) * sk);
+    if (!UCF) {
+      sm[q] = ldb(A.uc[q], c0 + (OFF)(kbeg - 1) * sk);
+      sc[q] = ldb(A.uc[q], c0 + (OFF)kbeg * sk);
+      sp[q] = ldb(A.uc[q], c0 + (OFF)(kbeg + 1) * sk);
+    }
     ring[(kbeg - 1) & 3][q][ty][tx] = ldf(q, c0 + (OFF)(kbeg - 1) * sk);
     ring[kbeg & 3][q][ty][tx] = ldf(q, c0 + (OFF)kbeg * sk);
     fn[q] = ldf(q, c0 + (OFF)(kbeg + 1) * sk);
@@ -587,8 +611,9 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
 #pragma unroll
     for (int q = 0; q < 3; ++q)
       ring[kp][q][ty][tx] = (HI && A.wmhi && q < 2) ? (1. + A.fhi) * ring[kc][q][ty][tx] - A.fhi * ring[km][q][ty][tx] : fn[q];
+    if (UCF) ucload(min(k + 2, g.n3 + 1), sn);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) { sn[q] = ldb(A.uc[q], idx); fn[q] = ldf(q, idx); }
+    for (int q = 0; q < 3; ++q) { if (!UCF) sn[q] = ldb(A.uc[q], idx); fn[q] = ldf(q, idx); }
     real qm[9], qc[9], qp[9], r[9];
     uiuj(sc, qc);
     if (!LO && !HI) { uiuj(sm, qm); uiuj(sp, qp); }
@@ -844,7 +869,7 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
         stb(A.s0, idx, s0v);                                              // stands for visct = s0 (sgs.f90:184) until the final kernel
         stb(A.ssij[0], idx, s0v * s11); stb(A.ssij[1], idx, s0v * s22); stb(A.ssij[2], idx, s0v * s33);      // |S|Sij (sgs.f90:198-210)
         stb(A.ssij[3], idx, s0v * s12); stb(A.ssij[4], idx, s0v * s13); stb(A.ssij[5], idx, s0v * s23);
-        stb(A.uc[0], idx, 0.5 * (u_ccc + u_mcc)); stb(A.uc[1], idx, 0.5 * (v_ccc + v_cmc)); stb(A.uc[2], idx, 0.5 * (w_ccc + w_ccm));
+        if (A.uc[0]) { stb(A.uc[0], idx, 0.5 * (u_ccc + u_mcc)); stb(A.uc[1], idx, 0.5 * (v_ccc + v_cmc)); stb(A.uc[2], idx, 0.5 * (w_ccc + w_ccm)); }      // (null: the last pass forms them itself)
       }
     }
     __syncthreads();
@@ -978,6 +1003,14 @@ __global__ __launch_bounds__(256) void k_plane_fold(int n3, int nblk, const real
 int allreduce_res(cales_ctx *c, int slot, int count, int op);
 int op_boundp(cales_ctx *c, real *p, int which);
 int op_boundp_multi(cales_ctx *c, int nf, real **p, int which);
+// v_c = (v(j) + v(j-1))/2 of the rows j = 1 and j = n2 (all i, k, ghost columns and planes included): the two rows whose copies the ghost-cell update /
+// the slab exchange puts into the ghost rows 0 and n2+1 of `vc` -- k_lmf_tile<.., UCF = 1> reads row 0 from there
+__global__ __launch_bounds__(256) void k_vc_edge_rows(Geom g, const real *__restrict__ v, real *__restrict__ vc) {
+  const int i = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y * 4 + threadIdx.y;
+  if (i > g.n1 + 1 || k > g.n3 + 1) return;
+  vc[g.ix(i, 1, k)] = 0.5 * (v[g.ix(i, 1, k)] + v[g.ix(i, 0, k)]);
+  vc[g.ix(i, g.n2, k)] = 0.5 * (v[g.ix(i, g.n2, k)] + v[g.ix(i, g.n2 - 1, k)]);
+}
 static bool dsmag_fast_ok(const cales_ctx *c) {
   for (int q = 0; q < 2; ++q) if (c->is_wall[q] != 0. || c->C.lwm[q] != 0) return false;      // walls or wall model in x: general path
   // walls / wall model in y (ducts): the fused last pass knows the wall rule along y, the two-pass form does not
@@ -1011,6 +1044,9 @@ static int dsmag_fast(cales_ctx *c) {
   // lazy form (homogeneous sgs BCs): |S| goes straight into the eddy-viscosity field and the last pass only makes the n3 plane coefficients
   bool lazy = !c->fl.dsmag_eager;
   for (int q = 0; q < 6; ++q) lazy = lazy && c->C.bcsgs[q] == 0.;
+  // the cell-centred velocity is not stored where the last pass can form it itself (k_lmf_tile<.., UCF = 1>): x periodic, z walls or periodic
+  const bool perz = CBP(c, 0, 3) == 'P' && CBP(c, 1, 3) == 'P';
+  const bool ucf = !c->fl.dsmag_unfused_filter && !c->fl.dsmag_store_uc && CBP(c, 0, 1) == 'P' && CBP(c, 1, 1) == 'P' && !c->fl.dsmag_xghosts && ((zlo && zhi) || perz);
   // K_AC: |S|, |S|Sij, cell-centred and test-filtered velocity in one pass over u,v,w (no wall-model faces ->
   // extrapolate(...,lwm) is a no-op; u,v are extrapolated through the z walls, w on the faces is not, sgs.f90:705-710)
   { ProfScope ps(c, "strain_filter_uvw");
@@ -1018,7 +1054,7 @@ static int dsmag_fast(cales_ctx *c) {
     StrainTileArgs S;
     S.u[0] = f[CALES_U]; S.u[1] = f[CALES_V]; S.u[2] = f[CALES_W]; S.s0 = lazy ? visct : c->s0;
     for (int m = 0; m < 6; ++m) S.ssij[m] = ssij[m];
-    S.uc[0] = c->uc; S.uc[1] = c->vc; S.uc[2] = c->wc; S.uf[0] = c->uf; S.uf[1] = c->vf; S.uf[2] = c->wf;
+    S.uc[0] = ucf ? nullptr : c->uc; S.uc[1] = ucf ? nullptr : c->vc; S.uc[2] = ucf ? nullptr : c->wc; S.uf[0] = c->uf; S.uf[1] = c->vf; S.uf[2] = c->wf;
     S.dzci = c->d_dzci; S.dzfi = c->d_dzfi; S.dxi = c->dli[0]; S.dyi = c->dli[1]; S.kchunk = kch; S.zlo = zlo; S.zhi = zhi; S.wmlo = wmlo; S.wmhi = wmhi; S.flo = flo; S.fhi = fhi;
     S.wylo = wylo; S.wyhi = wyhi; S.wmylo = wmylo; S.wmyhi = wmyhi; S.twy = nullptr; S.dl2 = c->dl[1];
     S.bm = BandMap{0, 0, 0, 0};
@@ -1044,12 +1080,16 @@ static int dsmag_fast(cales_ctx *c) {
   c->bc_skip = perx;
   if (!e_) e_ = op_bounduvw(c, c->bcuf, c->bcvf, c->bcwf, 0, 0, c->uf, c->vf, c->wf);
   c->bc_skip = perx | skipz;
-  if (!e_) { real *cc[3] = {c->uc, c->vc, c->wc}; e_ = op_boundp_multi(c, 3, cc, 1); }
+  if (!e_ && !ucf) { real *cc[3] = {c->uc, c->vc, c->wc}; e_ = op_boundp_multi(c, 3, cc, 1); }
+  if (!e_ && ucf && !(wylo && wyhi)) {      // v_c of the rows 1 and n2 only: their copies in the ghost rows (periodic wrap or the slab neighbours') are what the last pass reads for row 0
+    hipLaunchKernelGGL(k_vc_edge_rows, dim3((n[0] + 2 + 63) / 64, (n[2] + 2 + 3) / 4), dim3(64, 4), 0, c->stream, c->g, f[CALES_V], c->vc);
+    real *cc[1] = {c->vc}; e_ = op_boundp_multi(c, 1, cc, 1); }
   c->bc_skip = 0; c->defer_halo = false;
   if (!e_ && overlap) e_ = halo_flush_deferred(c);
   if (e_) { c->deferred.clear(); return e_; }
   LijMijArgs L;
-  L.uc[0] = c->uc; L.uc[1] = c->vc; L.uc[2] = c->wc; L.uf[0] = c->uf; L.uf[1] = c->vf; L.uf[2] = c->wf;
+  L.uc[0] = ucf ? f[CALES_U] : c->uc; L.uc[1] = ucf ? f[CALES_V] : c->vc; L.uc[2] = ucf ? f[CALES_W] : c->wc; L.uf[0] = c->uf; L.uf[1] = c->vf; L.uf[2] = c->wf;
+  L.vcg = c->vc; L.perz = perz ? 1 : 0;
   for (int m = 0; m < 6; ++m) L.mf[m] = mij[m];
   L.part = c->wk[0]; L.dzci = c->d_dzci; L.dzfi = c->d_dzfi; L.dxi = c->dli[0]; L.dyi = c->dli[1];
   L.zlo = zlo; L.zhi = zhi; L.wmlo = wmlo; L.wmhi = wmhi; L.flo = flo; L.fhi = fhi; L.perx = perx;
@@ -1067,8 +1107,9 @@ static int dsmag_fast(cales_ctx *c) {
       B.bm = BandMap{0, 0, 0, 0};
       if (!c->fl.plain_grid && (band_wanted(mg.x) || c->fl.band_grid)) { B.bm = band_map(mg.x, nby, mg.z); gg = dim3(band_blocks(B.bm), 1, 1); }
       const bool yw = wylo || wyhi || wmylo || wmyhi;
-      if (yw) { if (small) hipLaunchKernelGGL((k_lmf_tile<unsigned, 1>), gg, mb, 0, c->stream, c->g, B); else hipLaunchKernelGGL((k_lmf_tile<size_t, 1>), gg, mb, 0, c->stream, c->g, B); }
-      else if (small) hipLaunchKernelGGL((k_lmf_tile<unsigned, 0>), gg, mb, 0, c->stream, c->g, B); else hipLaunchKernelGGL((k_lmf_tile<size_t, 0>), gg, mb, 0, c->stream, c->g, B);
+#define LMF_LAUNCH(YWV, UCV) do { if (small) hipLaunchKernelGGL((k_lmf_tile<unsigned, YWV, UCV>), gg, mb, 0, c->stream, c->g, B); else hipLaunchKernelGGL((k_lmf_tile<size_t, YWV, UCV>), gg, mb, 0, c->stream, c->g, B); } while (0)
+      if (yw) { if (ucf) LMF_LAUNCH(1, 1); else LMF_LAUNCH(1, 0); } else { if (ucf) LMF_LAUNCH(0, 1); else LMF_LAUNCH(0, 0); }
+#undef LMF_LAUNCH
     };
     if (overlap) {
       // tiles that read the ghost rows j = 0 or j = n2+1 wait for the rows in flight; the others run beside the exchange

@@ -197,6 +197,57 @@ __device__ inline void fft_line8(int N, cpx *buf, int t, const cpx *__restrict__
   }
 }
 
+// The same transform with its ends in REGISTERS (decimation in frequency, the transposed flow graph of fft_line8): on entry v[e] = x[t + T e],
+// e = 0..7, T = N/8 -- the elements a thread gets from coalesced global loads anyway --, on exit v[e] = X[t + T e], the elements it can store the
+// same way. No staging copy in or out, one LDS round trip per stage boundary instead of two per stage, three barriers instead of eight for 512
+// points. N = R0 8^a with R0 = 1, 2, 4: the odd radix comes FIRST (from registers, butterflies over x[j + r N/R0] = register slots of one thread),
+// then radix-8 stages with Ns' = N/(8 R0), ..., 8, 1: stage (R, Ns') takes in[(j - k) R + k + r Ns'], k = j mod Ns', applies the butterfly, THEN the
+// twiddle w^(k r N / (Ns' R)) to output r, and leaves out[j + r N/R]; the last stage (Ns' = 1) has no twiddles and stays in registers.
+// In the skewed index map (lpad) the writes of a stage are consecutive in t and its reads strided: both conflict-free for the 8- and 16-lane groups
+// of 128-bit LDS accesses (the consecutive READS of fft_line8 were 2-way conflicts: half of its LDS cycles). All threads of the block call it.
+template <int INV>
+__device__ inline void fft_line8_dif(int N, cpx *buf, int t, const cpx *__restrict__ tw, cpx *v) {
+  const int T = N >> 3;
+  int R0 = N; while ((R0 & 7) == 0) R0 >>= 3;      // 1, 2 or 4
+  int Nsp;
+  if (R0 == 1) {                                 // radix 8 from registers: k = j = t, twiddle step 1
+    fft8_regs<INV>(v);
+    if (T == 1) return;
+#pragma unroll
+    for (int r = 1; r < 8; ++r) v[r] = tw_mul<INV>(v[r], tw[t * r]);
+    Nsp = T >> 3;
+  } else if (R0 == 4) {                          // two radix-4 butterflies: j = t + b T over the slots e = b, b + 2, b + 4, b + 6
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const cpx a0 = cadd(v[b], v[b + 4]), a1 = csub(v[b], v[b + 4]), a2 = cadd(v[b + 2], v[b + 6]), a3 = mul_mi<INV>(csub(v[b + 2], v[b + 6]));
+      const int j = t + b * T;
+      v[b] = cadd(a0, a2); v[b + 2] = tw_mul<INV>(cadd(a1, a3), tw[j]); v[b + 4] = tw_mul<INV>(csub(a0, a2), tw[2 * j]); v[b + 6] = tw_mul<INV>(csub(a1, a3), tw[3 * j]);
+    }
+    Nsp = T >> 2;                                // (N/4)/8
+  } else {                                       // four radix-2 butterflies: j = t + b T over the slots e = b, b + 4
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const cpx x0 = v[b], x1 = v[b + 4];
+      v[b] = cadd(x0, x1); v[b + 4] = tw_mul<INV>(csub(x0, x1), tw[t + b * T]);
+    }
+    Nsp = T >> 1;                                // (N/2)/8
+  }
+  while (true) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) buf[lpad(t + e * T)] = v[e];
+    __syncthreads();
+    const int k = t % Nsp, base = (t - k) * 8 + k, tstep = N / (Nsp * 8);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = buf[lpad(base + r * Nsp)];
+    fft8_regs<INV>(v);
+    if (Nsp == 1) break;
+#pragma unroll
+    for (int r = 1; r < 8; ++r) v[r] = tw_mul<INV>(v[r], tw[k * r * tstep]);
+    __syncthreads();                              // everybody has read: the line may be overwritten
+    Nsp >>= 3;
+  }
+}
+
 __device__ inline int dct_src(int e, int n) { return e < n / 2 ? 2 * e : 2 * (n - 1 - e) + 1; }   // Makhoul: v[e] = x[dct_src(e)]
 // x pass for nh = n1/2 = 2^p. Persistent: a block owns `iters` consecutive groups of R rows, R = blockDim.x / (nh/8);
 // the next group's rows are prefetched into registers while the current one is transformed; twiddles live in LDS.
@@ -506,6 +557,40 @@ __global__ __launch_bounds__(512) void k_fft_y8(Geom g, int N, int ncols, int kc
       }
     }
     __syncthreads();
+  }
+}
+
+// Periodic y transform with the line's ends in registers (fft_line8_dif): thread (c, t) = (threadIdx.x % CB, threadIdx.x / CB) owns the elements
+// j = t + T e of column m0 + c -- consecutive lanes = adjacent columns = whole 128-B segments of a row, on the way in and on the way out --, so the
+// transposed staging copies of k_fft_y8 (and their LDS bank conflicts) disappear. Line pitch = 4 (mod 16) complex slots: the 16-lane groups of a
+// 128-bit LDS read then cover 16 different slots (4 columns x 4 consecutive t).
+template <int INV>
+__global__ __launch_bounds__(512) void k_fft_y8r(Geom g, int N, int ncols, int kchunk, const cpx *__restrict__ twg, Spec S, real2 *__restrict__ pc, int k0 = 0, int k1 = -1) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int T = N >> 3, CB = blockDim.x / T, ld = ((lpad(N) + 15) & ~15) + 4;
+  const int c = threadIdx.x % CB, t = threadIdx.x / CB;
+  const int m0 = blockIdx.x * CB, kbeg = k0 + blockIdx.y * kchunk + 1, kend = min(kbeg + kchunk - 1, k1 < 0 ? g.n3 : k1);
+  cpx *tw = reinterpret_cast<cpx *>(smem), *line = tw + N + (size_t)c * ld;
+  for (int q = threadIdx.x; q < N; q += blockDim.x) tw[q] = twg[q];
+  const bool colok = m0 + c < ncols;
+  const int mc = colok ? m0 + c : ncols - 1;      // (columns beyond the last one repeat it: every load unconditional, nothing stored)
+  cpx nxt[8], v[8];
+  auto fetch = [&](int k) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const real2 q = pc[S.at_mode(g, mc, t + e * T + 1, k)]; nxt[e] = cpx{q.x, q.y}; }
+  };
+  fetch(kbeg);
+  __syncthreads();
+  for (int k = kbeg; k <= kend; ++k) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = nxt[e];
+    fetch(min(k + 1, kend));                                                   // in flight during the transform (the last plane again: unused)
+    fft_line8_dif<INV>(N, line, t, tw, v);
+    if (colok) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pc[S.at_mode(g, mc, t + e * T + 1, k)] = make_real2(v[e].x, v[e].y);
+    }
+    __syncthreads();                                                           // the last stage's reads are done before the next plane writes
   }
 }
 
@@ -1084,7 +1169,7 @@ __global__ __launch_bounds__(256) void k_gaussel(Geom g, int nz, int ncol, int n
 }
 
 // ------------------------------------------------------------------------------------------ host side
-struct SolverPlans { FftPlan py4; int CBy4; size_t shy4; FftPlan px, py; int Rx, CBy; size_t shx, shy; bool x8, y8; int x8_threads, y8_threads; size_t shx8, shy8; };
+struct SolverPlans { FftPlan py4; int CBy4; size_t shy4; FftPlan px, py; int Rx, CBy; size_t shx, shy; bool x8, y8; int x8_threads, y8_threads; size_t shx8, shy8, shy8r; };
 struct VelSet { bool ready = false; int xkind = 0, ykind = 0; real *lamx = nullptr, *lamy = nullptr; real normfft = 1.; FftPlan p1x, p1y; real *tw1x = nullptr, *tw1y = nullptr; };
 struct PlanSlot { cales_ctx *ctx; SolverPlans sp; VelSet vs[3]; };
 // one entry per context; a list (stable addresses) behind a mutex: contexts are created and destroyed from several host threads in the
@@ -1123,6 +1208,9 @@ int solver_setup(cales_ctx *c) {
   if (sp.y8) { const int T = n2g / 8; int CB = std::max(1, std::min(std::max(8, 256 / T), 512 / T));
                while (CB > 1 && ((size_t)CB * (n2g + n2g / 8 + 1) + n2g) * sizeof(cpx) > 150 * 1024) CB /= 2;
                sp.y8_threads = CB * T; sp.shy8 = ((size_t)CB * (n2g + n2g / 8 + 1) + n2g) * sizeof(cpx);
+               sp.shy8r = ((size_t)CB * ((((n2g + n2g / 8) + 15) & ~15) + 4) + n2g) * sizeof(cpx);      // k_fft_y8r: line pitch = 4 (mod 16) slots
+               if (sp.shy8r > 64 * 1024) { hipFuncSetAttribute((const void *)k_fft_y8r<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8r);
+                                           hipFuncSetAttribute((const void *)k_fft_y8r<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8r); }
                if (sp.shy8 > 64 * 1024) {      // n2 = 1024: 4 columns (64-B row segments) need 90 KB of LDS
                  hipFuncSetAttribute((const void *)k_fft_y8<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8);
                  hipFuncSetAttribute((const void *)k_fft_y8<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8);
@@ -1341,7 +1429,8 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
       ProfScope ps(c, "fft_y_fwd");
       const dim3 gy((ncol + CB8 - 1) / CB8, (kpc + ykchunk_c - 1) / ykchunk_c);
       if (c->ykind) hipLaunchKernelGGL((k_fft_y8<0, 1>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1));
-      else hipLaunchKernelGGL((k_fft_y8<0, 0>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1));
+      else if (c->fl.fft_staged) hipLaunchKernelGGL((k_fft_y8<0, 0>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1));
+        else hipLaunchKernelGGL((k_fft_y8r<0>), gy, dim3(sp->y8_threads), sp->shy8r, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, S, mode_spec, kpc * ch, kpc * (ch + 1));
     }
   } else {
   if (poisson && c->fuse_fillps_dti != 0. && sp->x8) {
@@ -1375,7 +1464,7 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
     else if (c->ykind == 3) hipLaunchKernelGGL(k_fft_y4<0>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
     else if (c->ykind == 4) hipLaunchKernelGGL(k_fft_y4<1>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
     else if (use8y && c->ykind) hipLaunchKernelGGL((k_fft_y8<0, 1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
-    else if (use8y) hipLaunchKernelGGL((k_fft_y8<0, 0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
+    else if (use8y) { if (c->fl.fft_staged) hipLaunchKernelGGL((k_fft_y8<0, 0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); else hipLaunchKernelGGL((k_fft_y8r<0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8r, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, S, mode_spec); }
     else hipLaunchKernelGGL(k_fft_y<0>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
   }
   // pressure equation without a Dirichlet condition in z: the zero-eigenvalue mode (if x and y have one) is singular
@@ -1419,7 +1508,8 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
       { ProfScope ps(c, "fft_y_bwd");
         const dim3 gy((ncol + CB8 - 1) / CB8, (kpc + ykchunk_c - 1) / ykchunk_c);
         if (c->ykind) hipLaunchKernelGGL((k_fft_y8<1, 1>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1));
-        else hipLaunchKernelGGL((k_fft_y8<1, 0>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1)); }
+        else if (c->fl.fft_staged) hipLaunchKernelGGL((k_fft_y8<1, 0>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1));
+        else hipLaunchKernelGGL((k_fft_y8r<1>), gy, dim3(sp->y8_threads), sp->shy8r, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, S, mode_spec, kpc * ch, kpc * (ch + 1)); }
       if (int e = exchange_chunk(1, ch)) return e;
     }
     for (int ch = 0; ch < NCH; ++ch) {
@@ -1435,7 +1525,7 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
     else if (c->ykind == 3) hipLaunchKernelGGL(k_fft_y4<0>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
     else if (c->ykind == 4) hipLaunchKernelGGL(k_fft_y4<1>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
     else if (use8y && c->ykind) hipLaunchKernelGGL((k_fft_y8<1, 1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
-    else if (use8y) hipLaunchKernelGGL((k_fft_y8<1, 0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
+    else if (use8y) { if (c->fl.fft_staged) hipLaunchKernelGGL((k_fft_y8<1, 0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); else hipLaunchKernelGGL((k_fft_y8r<1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8r, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, S, mode_spec); }
     else hipLaunchKernelGGL(k_fft_y<1>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
   if (dist) { ProfScope ps(c, "alltoall"); if (c->comm.a2a(c->comm.user, 1, a2a_count)) { c->err = "alltoall callback failed"; return 1; } }
   { ProfScope ps(c, "fft_x_bwd");
