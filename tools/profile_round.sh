@@ -12,6 +12,8 @@ O=$PWD/gpurun_out
 mkdir -p $O
 if [ ! -x tools/micro/calib ]; then (cd tools/micro && hipcc --offload-arch=gfx950 -O3 -o calib calib.hip); fi
 ./tools/micro/calib > $O/${TAG}_calib.jsonl 2>&1
+if [ ! -x tools/micro/segcopy ]; then (cd tools/micro && hipcc --offload-arch=gfx950 -O3 -o segcopy segcopy.hip); fi
+./tools/micro/segcopy > $O/${TAG}_segcopy.log 2>&1      # copy rate of the column-tile access pattern of the y transforms
 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $O/${TAG}_calib_fetch -- ./tools/micro/calib > /dev/null 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $O/${TAG}_calib_write -- ./tools/micro/calib > /dev/null 2>&1
 rocprofv3 --output-format csv --kernel-trace --stats -d $O/${TAG}_stats -- python3 bench.py $ARGS > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_stats.log
