@@ -168,6 +168,10 @@ SWITCH_CASES = [
     ({"CALES_KCHUNK": "5", "CALES_SMAG_TILE": "1"}, ["chan_smag_wm", "duct_smag_wm"]),
     ({"CALES_TILE_MIN_BLOCKS": "1000000"}, ["chan_dsmag", "duct_smag_wm_imp1d"]),
     ({"CALES_TILE_MIN_BLOCKS": "1"}, ["chan_dsmag", "duct_smag_wm_imp1d"]),
+    # dynamic model: K_AC stores the cell-centred velocity instead of the last pass forming it from u, v, w (ducts: the YW instantiations)
+    ({"CALES_DSMAG_STORE_UC": "1"}, ["chan_dsmag", "chan_dsmag_wm", "tgv_dsmag_ppp", "duct_dsmag_wm", "duct_dsmag"]),
+    # the y transform with staging copies through LDS instead of the register-ended one (golden sizes are not powers of two: see also test_gpu_vs_oracle)
+    ({"CALES_FFT_STAGED": "1"}, ["chan_dsmag", "tgv_ppp"]),
     # tile heights of the LDS form of the static Smagorinsky pass
     ({"CALES_SMAG_TILE": "1", "CALES_SMAG_TY": "6"}, ["chan_smag", "chan_smag_wm", "duct_smag_wm"]),
     ({"CALES_SMAG_TILE": "1", "CALES_SMAG_TY": "14"}, ["chan_smag", "chan_smag_wm", "duct_smag_wm"]),

@@ -28,7 +28,9 @@ def _hot(case):
                                      ("chan_smag", (34, 38, 10)), ("cavity_nnn", (46, 74, 8)), ("duct_smag_wm", (38, 34, 12)),
                                      # deep z: the in-LDS tridiagonal tile with 2, 4, 8, 16 planes per lane, partial last chunks
                                      ("chan_smag", (16, 8, 100)), ("chan_smag", (16, 8, 130)), ("cavity_nnn", (40, 8, 300)),
-                                     ("chan_smag", (16, 4, 512)), ("duct_smag_wm", (16, 8, 514)), ("chan_smag", (8, 4, 1024))])
+                                     ("chan_smag", (16, 4, 512)), ("duct_smag_wm", (16, 8, 514)), ("chan_smag", (8, 4, 1024)),
+                                     # periodic y lines of 16 ... 512 points: every first radix of the register-ended transform (8-2, 8-4, 8-8, 2-8-8, 4-8-8, 8-8-8)
+                                     ("chan_smag", (16, 16, 6)), ("chan_smag", (16, 32, 6)), ("tgv_ppp", (16, 64, 8)), ("chan_smag", (16, 256, 4)), ("tgv_ppp", (32, 512, 4))])
 def test_poisson_solve(name, ng):
     g, case = load_golden(name)
     case.ng[:] = ng
@@ -50,6 +52,14 @@ def test_poisson_solve(name, ng):
 def test_poisson_solve_generic_transforms(name, ng, monkeypatch):
     """CALES_FFT_GENERIC: the mixed-radix Stockham kernels also for power-of-two lines (which otherwise take the radix-8 register kernels), same bar."""
     monkeypatch.setenv("CALES_FFT_GENERIC", "1")
+    test_poisson_solve(name, ng)
+
+
+@pytest.mark.parametrize("name,ng", [("chan_smag", (64, 128, 8)), ("tgv_ppp", (32, 32, 16)), ("chan_smag", (512, 64, 6)), ("chan_smag", (16, 256, 4)), ("halfchan_imp1d", (16, 1024, 4))])
+def test_poisson_solve_staged_y_transform(name, ng, monkeypatch):
+    """CALES_FFT_STAGED: the periodic y transform of power-of-two lines through k_fft_y8 (staging copies in LDS) instead of the register-ended
+    k_fft_y8r (the default, which test_poisson_solve covers at 64, 128, 256, 512 and 1024 points: radix 8-8, 2-8-8, 4-8-8, 8-8-8, 2-8-8-8)."""
+    monkeypatch.setenv("CALES_FFT_STAGED", "1")
     test_poisson_solve(name, ng)
 
 
