@@ -15,8 +15,6 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 20):
     name = names[trial % len(names)]
     P = int(rng.choice([2, 3, 4]))
     ng = (int(2 * rng.randint(4, 40)), int(2 * P * rng.randint(2, 8)), int(2 * rng.randint(5, 40)))
-    if name.startswith("duct") and P > 2:
-        P = 2; ng = (ng[0], int(4 * rng.randint(3, 10)), ng[2])
     try:
         case = _case(name, ng)
         if np.any(case.lwm != 0):      # a sampling height the reference accepts on this grid and slab (sanity.f90:224-231)

@@ -46,7 +46,9 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
     gu, gv, gw, gp, gvis = h.download()
     errs = [relerr(a, b) for a, b in ((gu, u), (gv, v), (gw, w))] + [relerr(gvis, visct)]
     both_blew_up = not np.isfinite(u).all() and not np.isfinite(gu).all()      # unstable case: the reference blows up the same way
-    ok = both_blew_up or (max(errs[:3]) < 1e-9 and errs[3] < 1e-6)
+    # triply periodic boxes with n3 not a power of two: the reference's own answer is defined to 1e-8 only (tests/test_oracle_solver.py)
+    illposed = name.startswith("tgv") and (ng[2] & (ng[2] - 1)) != 0
+    ok = both_blew_up or (max(errs[:3]) < (1e-8 if illposed else 1e-9) and errs[3] < 1e-6)
     bad += not ok
     print("OK " if ok else "BAD", name, ng, " ".join("%.1e" % e for e in errs), "div %.1e / oracle %.1e" % (h.chkdiv()[1], o.chkdiv(u, v, w)[1]), flush=True)
     h.close()

@@ -30,7 +30,9 @@ for name, ng in itertools.product(names, sizes):
         h.step(dt); o.step(dt, u, v, w, p, pp, visct)
     gu, gv, gw, gp, gvis = h.download()
     errs = [relerr(a, b) for a, b in ((gu, u), (gv, v), (gw, w))] + [relerr(gvis, visct) if np.abs(visct).max() > 0 else 0.]
-    ok = np.isfinite(errs).all() and max(errs[:3]) < 1e-9 and errs[3] < 1e-6
+    # triply periodic boxes with n3 not a power of two: the reference's own answer is defined to 1e-8 only (tests/test_oracle_solver.py)
+    illposed = name.startswith("tgv") and (ng[2] & (ng[2] - 1)) != 0
+    ok = np.isfinite(errs).all() and max(errs[:3]) < (1e-8 if illposed else 1e-9) and errs[3] < 1e-6
     bad += not ok
     print("OK " if ok else "BAD", name, ng, " ".join("%.1e" % e for e in errs), flush=True)
     h.close()
