@@ -320,7 +320,14 @@ int cales_step(cales_ctx *c, real dt) {
   static const real rk[3][2] = {{32. / 60., 0.}, {25. / 60., -17. / 60.}, {45. / 60., -25. / 60.}};
   hipLaunchKernelGGL(k_zero6, dim3(1), dim3(64), 0, c->stream, c->d_force);     // dpdl(:) = 0
   c->in_step = true;
-  struct Reset { cales_ctx *c; ~Reset() { c->in_step = false; c->defer_force = false; c->defer_imp_rhs = false; c->fuse_fillps_dti = 0.; c->fuse_mean_mask = 0; } } reset{c};      // also on the error returns
+  struct Reset { cales_ctx *c; ~Reset() { c->in_step = false; c->step_xskip = false; c->defer_force = false; c->defer_imp_rhs = false; c->fuse_fillps_dti = 0.; c->fuse_mean_mask = 0; } } reset{c};      // also on the error returns
+  // periodic x, explicit diffusion, no wall model, the fused passes everywhere: every kernel of the step wraps around instead of reading x ghost
+  // columns, which are then left alone until the step returns (common.hpp, step_xskip)
+  { bool ok = !c->fl.xghosts_in_step && CBP(c, 0, 1) == 'P' && CBP(c, 1, 1) == 'P' && c->C.impdiff == 0 && !c->fl.unfused_rk && !c->fl.unfused_correc &&
+              !c->fl.unfused_fillps && !c->fl.unaligned && solver_can_fuse_fillps(c) && c->xkind == 0 && sgs_wraps_x(c);
+    for (int q = 0; q < 6; ++q) ok = ok && c->C.lwm[q] == 0;
+    for (int d = 0; d < 3; ++d) ok = ok && ((c->C.bcpre[2 * d] == 0. && c->C.bcpre[2 * d + 1] == 0.) || c->C.cbcpre[2 * d] == 'P');      // (fillps inside the x transform)
+    c->step_xskip = ok; }
   for (int irk = 1; irk <= 3; ++irk) {
     const real dtrk = (rk[irk - 1][0] + rk[irk - 1][1]) * dt, dtrki = 1. / dtrk;
     real alpha = 0.;
@@ -362,6 +369,14 @@ int cales_step(cales_ctx *c, real dt) {
     if (!fuse_cu) { if (int e = op_updatep(c, alpha)) return e; }
     if (int e = op_boundp(c, c->f[CALES_P], 0)) return e;
     if (int e = op_cmpt_sgs(c)) return e;
+    if (int e = op_boundp(c, c->f[CALES_VISCT], 1)) return e;
+  }
+  if (c->step_xskip) {      // the ghost cells of everything a caller may look at, all directions (the corners of the x ghost columns with the z ghost planes included)
+    c->step_xskip = false;
+    if (int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 0, 1, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W])) return e;
+    if (int e = op_xwrap_zghost(c, 3, c->f + CALES_U)) return e;
+    real *pq[2] = {c->f[CALES_P], c->f[CALES_PP]};
+    if (int e = op_boundp_multi(c, 2, pq, 0)) return e;
     if (int e = op_boundp(c, c->f[CALES_VISCT], 1)) return e;
   }
   c->h_red[40] = dt;

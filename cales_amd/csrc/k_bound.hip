@@ -120,6 +120,14 @@ static bool merged_ok(const cales_ctx *c, const char *cbx, const char *cby) {
 // y-slab neighbours (bound.f90:619-696 for idir = 2): pack the first/last interior rows of nf fields into the
 // staging buffer A, let the host exchange them, unpack into the ghost rows. Planes include the x/z ghosts.
 struct HaloFields { int nf; real *p[8]; };
+// x ghost columns of the two z ghost planes, rows 0..n2+1: the corners the velocity update after the projection leaves alone (bounduvw with
+// is_correc does not touch the z ghost planes of w, and the periodic copies of the step's earlier calls were skipped: cales_step, step_xskip)
+__global__ __launch_bounds__(256) void k_xwrap_zghost(Geom g, HaloFields H) {
+  const int j = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y ? g.n3 + 1 : 0;
+  if (j > g.n2 + 1) return;
+  real *p = H.p[blockIdx.z];
+  p[g.ix(0, j, k)] = p[g.ix(g.n1, j, k)]; p[g.ix(g.n1 + 1, j, k)] = p[g.ix(1, j, k)];
+}
 __global__ __launch_bounds__(256) void k_pack_y(Geom g, HaloFields H, real *__restrict__ lo, real *__restrict__ hi) {
   const int i = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y * 4 + threadIdx.y, f = blockIdx.z;
   if (i > g.n1 + 1 || k > g.n3 + 1) return;
@@ -190,7 +198,7 @@ int op_boundp_multi(cales_ctx *c, int nf, real **p, int which) {
   if (merged_ok(c, cbc, cbc + 2) && nf <= 8) {      // x, y periodic: all three directions in one launch (k_bc_merged)
     if (c->P > 1) { if (int e = halo_y_comm(c, nf, p)) return e; }
     const bool per_z = cbc[4] == 'P' && cbc[5] == 'P';
-    MJobs J; J.nf = nf; J.do_x = !(c->bc_skip & 1); J.wrap_y = c->P == 1; J.do_z = per_z || !(c->bc_skip & 4);
+    MJobs J; J.nf = nf; J.do_x = !(bc_skipped(c) & 1); J.wrap_y = c->P == 1; J.do_z = per_z || !(bc_skipped(c) & 4);
     for (int q = 0; q < nf; ++q) {
       MField &F = J.f[q]; F.p = p[q]; F.centered = 1;
       F.t0 = per_z ? 'P' : cbc[4]; F.t1 = per_z ? 'P' : cbc[5];
@@ -201,7 +209,7 @@ int op_boundp_multi(cales_ctx *c, int nf, real **p, int which) {
   if (int e = halo_self(c, nf, p)) return e;
   for (int idir = 1; idir <= 3; ++idir) {
     if (!ISB(c, 0, idir) && !ISB(c, 1, idir)) continue;
-    if (c->bc_skip >> (idir - 1) & 1) continue;
+    if (bc_skipped(c) >> (idir - 1) & 1) continue;
     BcJobs J; J.njobs = 0; J.idir = idir;
     const real dr0 = idir < 3 ? c->dl[idir - 1] : c->dzc[0], dr1 = idir < 3 ? c->dl[idir - 1] : c->dzc[c->n[2]];
     const char c0 = cbc[0 + 2 * (idir - 1)], c1 = cbc[1 + 2 * (idir - 1)];
@@ -375,7 +383,7 @@ int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm
   if (merged) {
     if (c->P > 1) { if (int e = halo_y_comm(c, 3, fl)) return e; }
     const bool per_z = CBV(c, 0, 3, 3) == 'P' && CBV(c, 1, 3, 3) == 'P';
-    MJobs J; J.nf = 3; J.do_x = !(c->bc_skip & 1); J.wrap_y = c->P == 1; J.do_z = per_z || !(c->bc_skip & 4);
+    MJobs J; J.nf = 3; J.do_x = !(bc_skipped(c) & 1); J.wrap_y = c->P == 1; J.do_z = per_z || !(bc_skipped(c) & 4);
     for (int ivel = 1; ivel <= 3; ++ivel) {
       MField &F = J.f[ivel - 1]; F.p = fl[ivel - 1];
       const bool normal = ivel == 3;
@@ -392,7 +400,7 @@ int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm
   if (int e = halo_self(c, 3, fl)) return e;
   for (int idir = 1; idir <= 3; ++idir) {
     if (!ISB(c, 0, idir) && !ISB(c, 1, idir)) continue;
-    if (c->bc_skip >> (idir - 1) & 1) continue;
+    if (bc_skipped(c) >> (idir - 1) & 1) continue;
     BcJobs J; J.njobs = 0; J.idir = idir;
     const bool periodic = CBV(c, 0, idir, idir) == 'P' && CBV(c, 1, idir, idir) == 'P';
     const bool impose_norm = (!is_correc) || periodic;
@@ -529,6 +537,13 @@ int op_rhs_b_velz(cales_ctx *c, int ivel, real alpha, real *planes, int *has) {
     hipLaunchKernelGGL(k_rhs_b_velz, dim3((n[0] + 63) / 64, (n[1] + 3) / 4), dim3(64, 4), 0, c->stream, c->g, c->f[CALES_U + ivel - 1],
                        plane(bc, 3, ib, n), ib, cbc[ib], cf, dlc, dlf, alpha, ib ? n3 - q : 1, planes ? planes + (size_t)ib * n[0] * n[1] : nullptr);
   }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+int op_xwrap_zghost(cales_ctx *c, int nf, real **f) {
+  HaloFields H; H.nf = nf; for (int q = 0; q < nf; ++q) H.p[q] = f[q];
+  hipLaunchKernelGGL(k_xwrap_zghost, dim3((c->n[1] + 2 + 255) / 256, 2, nf), dim3(256), 0, c->stream, c->g, H);
   HIPCHK(c, hipGetLastError());
   return 0;
 }

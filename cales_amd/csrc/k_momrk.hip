@@ -28,6 +28,7 @@ struct MomRkArgs {
   // low-storage RK3 (param.f90:27-29): the first substep has f2 = 0 -> the old r.h.s. is not read; inside cales_step the r.h.s. of the
   // third substep is never used (the next step starts with f2 = 0) -> not written
   int rd_old, wr_new;
+  int perx;      // x periodic: the x-halo columns of the tiles at the ends of a row are the wrapped interior columns (valid whether or not the ghost columns are up to date)
 };
 
 // NOS = 1: no subgrid model (visct is identically zero, sgs.f90:62-68): its loads, LDS traffic and terms are compiled out
@@ -42,13 +43,16 @@ __global__ __launch_bounds__(64 * (TYM + 2), (TYM <= 6 ? 4 : 3)) void k_momrk(Ge
   const int kbeg = bz_ * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
   const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1;
   const bool outok = ty >= 1 && ty <= TYM && i <= g.n1 && j <= g.n2;
-  const OFF c0 = ldok ? (OFF)g.ix(i, j, 0) * RSZ : 0;        // byte offsets (see ldb in common.hpp)
+  // (a row that does not fill its last tile: the lane beside the last cell loads the column right of it -- the wrapped first column when the ghost
+  //  columns are not maintained)
+  const OFF c0 = ldok ? (OFF)g.ix((A.perx && i == g.n1 + 1) ? 1 : i, j, 0) * RSZ : 0;        // byte offsets (see ldb in common.hpp)
   const OFF sk = (OFF)g.s12 * RSZ;
   // x-halo columns (i = 64 bx and 64 bx + 65): the two y-halo waves, which have no outputs, fetch them for all rows of the
   // tile -- wave 0 the left column, wave TYM+1 the right one; lane l -> row l/5, field l%5. One register instead of five.
   const bool hwave = ty == 0 || ty == TYM + 1;
-  const int hr = tx / 5, hf_ = tx % 5, hxs = ty == 0 ? 0 : 65, hi_ = ty == 0 ? bx_ * 64 : bx_ * 64 + 65, hj = by_ * TYM + hr;
-  const bool hok = hwave && tx < 5 * (TYM + 2) && hi_ <= g.n1 + 1 && hj <= g.n2 + 1 && !(NOS && hf_ == 3);
+  const int hr = tx / 5, hf_ = tx % 5, hxs = ty == 0 ? 0 : 65, hi0 = ty == 0 ? bx_ * 64 : bx_ * 64 + 65, hj = by_ * TYM + hr;
+  const int hi_ = !A.perx ? hi0 : hi0 == 0 ? g.n1 : hi0 == g.n1 + 1 ? 1 : hi0;
+  const bool hok = hwave && tx < 5 * (TYM + 2) && hi0 <= g.n1 + 1 && hj <= g.n2 + 1 && !(NOS && hf_ == 3);
   const real *hp = nullptr;
   if (hok) { const real *fp = hf_ == 0 ? A.u : hf_ == 1 ? A.v : hf_ == 2 ? A.w : hf_ == 3 ? A.s : A.p; hp = fp + g.ix(hi_, hj, 0); }
   const size_t sk64 = (size_t)g.s12;
@@ -189,6 +193,7 @@ int op_momrk(cales_ctx *c, real f1, real f2, real f12) {
   A.cs = c->visct_lazy ? c->d_cs : nullptr;
   A.dzci = c->d_dzci; A.dzfi = c->d_dzfi; A.dxi = c->dli[0]; A.dyi = c->dli[1]; A.visc = c->visc;
   A.rd_old = f2 != 0.; A.wr_new = !c->skip_rhs_store;
+  A.perx = c->step_xskip ? 1 : 0;      // (operator-level calls read the ghost columns the caller provided, as the reference does)
   A.f1 = f1; A.f2 = f2; A.f12 = f12; A.bfx = c->C.bforce[0]; A.bfy = c->C.bforce[1]; A.bfz = c->C.bforce[2];
   dim3 b(64, TYM + 2, 1), gr((n[0] + 63) / 64, (n[1] + TYM - 1) / TYM, 1);
   int kchunk = n[2];

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(BX *BY) void k_smag(Geom g, SmagArgs A, const real 
     for (int q = 1; q < 6; ++q) if (dw[q] < dw[loc]) loc = q;
     const real dw_min = dw[loc];
     real t1 = 0., t2 = 0., sc = 0.;
-    const int n1 = g.n1, n2 = g.n2, n3 = g.n3;
+    const int n1 = g.n1, n2 = g.n2, n3 = g.n3, im1 = i - 1;
     if (twy && (loc == 2 || loc == 3)) {      // the y walls belong to the first and the last slab: their shear arrives as planes (same arithmetic, k_wall_shear_y)
       const real dw_plus = dw_min * twy[(size_t)(loc == 2 ? k : n3 + 2 + k) * g.s1 + i] * (1. / A.visc);
       fd = 1. - exp(-dw_plus / 25.);
@@ -143,9 +143,9 @@ __global__ __launch_bounds__(BX *BY) void k_smag(Geom g, SmagArgs A, const real 
             t2 = w[g.ix(i, 1, k)] - w[g.ix(i, 0, k)] + w[g.ix(i, 1, k - 1)] - w[g.ix(i, 0, k - 1)]; sc = A.dyi; break;
     case 3: t1 = u[g.ix(i, n2, k)] - u[g.ix(i, n2 + 1, k)] + u[g.ix(i - 1, n2, k)] - u[g.ix(i - 1, n2 + 1, k)];
             t2 = w[g.ix(i, n2, k)] - w[g.ix(i, n2 + 1, k)] + w[g.ix(i, n2, k - 1)] - w[g.ix(i, n2 + 1, k - 1)]; sc = A.dyi; break;
-    case 4: t1 = u[g.ix(i, j, 1)] - u[g.ix(i, j, 0)] + u[g.ix(i - 1, j, 1)] - u[g.ix(i - 1, j, 0)];
+    case 4: t1 = u[g.ix(i, j, 1)] - u[g.ix(i, j, 0)] + u[g.ix(im1, j, 1)] - u[g.ix(im1, j, 0)];
             t2 = v[g.ix(i, j, 1)] - v[g.ix(i, j, 0)] + v[g.ix(i, j - 1, 1)] - v[g.ix(i, j - 1, 0)]; sc = dzci[0]; break;
-    default: t1 = u[g.ix(i, j, n3)] - u[g.ix(i, j, n3 + 1)] + u[g.ix(i - 1, j, n3)] - u[g.ix(i - 1, j, n3 + 1)];
+    default: t1 = u[g.ix(i, j, n3)] - u[g.ix(i, j, n3 + 1)] + u[g.ix(im1, j, n3)] - u[g.ix(im1, j, n3 + 1)];
              t2 = v[g.ix(i, j, n3)] - v[g.ix(i, j, n3 + 1)] + v[g.ix(i, j - 1, n3)] - v[g.ix(i, j - 1, n3 + 1)]; sc = dzci[n3]; break;
     }
     real tauw_s = sqrt(t1 * t1 + t2 * t2) * sc;
@@ -375,7 +375,7 @@ struct LijMijArgs {
   int wylo, wyhi, wmylo, wmyhi;
   // k_lmf_tile<.., UCF = 1>: uc[] are the velocities u, v, w themselves and the cell-centred velocity (sgs.f90:860-869) is formed while loading;
   // vcg = the field whose ghost row 0 holds v_c of the row below the slab (periodic copy or the neighbour's), the one value v(-1) would be needed for
-  const real *vcg; int perz;
+  const real *vcg; int perz, xwrap;      // xwrap: inside cales_step with stale x ghost columns, u(0) is read as u(n1)
 };
 template <typename OFF>
 __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijArgs A) {
@@ -551,9 +551,10 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
   const OFF ovb = (UCF && jc > 0) ? sj : 0;
   const real cva = (UCF && jc == 0) ? 1. : .5, cvb = (UCF && jc == 0) ? 0. : .5;
   real wprev = 0.;
+  const OFF c0m = (OFF)g.ix((A.xwrap && ic == 1) ? g.n1 : max(ic - 1, 0), jc, 0) * RSZ;      // u(i-1): the wrapped column left of the first cell of a row
   auto ucload = [&](int kk, real *o) {      // cell-centred velocity of plane kk (wprev = w of plane kk - 1 on entry, of plane kk on exit)
     const OFF a = c0 + (OFF)kk * sk;
-    o[0] = .5 * (ldb(A.uc[0], a) + ldb(A.uc[0], a - (OFF)RSZ));
+    o[0] = .5 * (ldb(A.uc[0], a) + ldb(A.uc[0], c0m + (OFF)kk * sk));
     o[1] = cva * ldb(pva, a) + cvb * ldb(A.uc[1], a - ovb);
     const real wn = ldb(A.uc[2], a); o[2] = .5 * (wn + wprev); wprev = wn;
   };
@@ -721,6 +722,7 @@ struct StrainTileArgs {
   // extrapolated from the interior (extrapolate(...,lwm) along y, sgs.f90:683-748)
   int wylo, wyhi, wmylo, wmyhi; const real *twy; real dl2;
   BandMap bm;      // block -> (x tile, y tile, k chunk) map of the 1-D launches (bm.gx = 0: plain 3-D grid)
+  int perx;        // x periodic: halo columns beyond the ends of a row are the wrapped interior columns (the ghost columns may be stale inside cales_step)
 };
 // sqrt(tau_w) at the two y walls for every (i, k): the argument of the van Driest damping of the cells whose nearest wall is a y wall
 // (sgs.f90:117-143, cases 3 and 4 of the select), from the fields themselves (their ghost cells, not the extrapolated ones)
@@ -751,10 +753,12 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
   const int i = bx * 64 + tx + 1, j = by * TY + ty;        // whole 128-B lines in and out (see cales_create)
   const int kbeg = bz * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
   const bool edge = tx == 0 || tx == 63;
-  const int ih = tx == 0 ? i - 1 : i + 1, hx = tx == 0 ? 0 : 65;
-  const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1, hok = edge && ih <= g.n1 + 1 && j <= g.n2 + 1;
+  const int ih0 = tx == 0 ? i - 1 : i + 1, hx = tx == 0 ? 0 : 65;
+  const int ih = !A.perx ? ih0 : ih0 == 0 ? g.n1 : ih0 == g.n1 + 1 ? 1 : ih0;
+  const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1, hok = edge && ih0 <= g.n1 + 1 && j <= g.n2 + 1;
   const bool outok = ty >= 1 && ty <= TY && i <= g.n1 && j <= g.n2;
-  const OFF c0 = ldok ? (OFF)g.ix(i, j, 0) * RSZ : 0, ch = hok ? (OFF)g.ix(ih, j, 0) * RSZ : 0, sk = (OFF)g.s12 * RSZ;   // byte offsets
+  const int iq = (A.perx && i == g.n1 + 1) ? 1 : i;      // (the column right of the last cell of the row, loaded by the last tile's lane beside it)
+  const OFF c0 = ldok ? (OFF)g.ix(iq, j, 0) * RSZ : 0, ch = hok ? (OFF)g.ix(ih, j, 0) * RSZ : 0, sk = (OFF)g.s12 * RSZ;   // byte offsets
   real fn[3], fh[3];
   // ghost rows at wall-model y faces (SMAG pass of ducts): u and w are replaced by 2 Q(1) - Q(2) along y; v, normal to the face, is not
   const int yex = !YW ? 0 : (A.wmylo && j == 0) ? 1 : (A.wmyhi && j == g.n2 + 1) ? -1 : 0;
@@ -783,14 +787,15 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
   real tw_lo = 0., tw_hi = 0.;
   if (SMAG && outok) {
     const real *u = A.u[0], *v = A.u[1];
+    const int im1 = (A.perx && i == 1) ? g.n1 : i - 1;
     if (A.zlo) {
-      const real t1 = u[g.ix(i, j, 1)] - u[g.ix(i, j, 0)] + u[g.ix(i - 1, j, 1)] - u[g.ix(i - 1, j, 0)];
+      const real t1 = u[g.ix(i, j, 1)] - u[g.ix(i, j, 0)] + u[g.ix(im1, j, 1)] - u[g.ix(im1, j, 0)];
       const real t2 = v[g.ix(i, j, 1)] - v[g.ix(i, j, 0)] + v[g.ix(i, j - 1, 1)] - v[g.ix(i, j - 1, 0)];
       tw_lo = sqrt(0.5 * A.visc * (sqrt(t1 * t1 + t2 * t2) * A.dzci[0]));      // sqrt(tauw), constant along the column
     }
     if (A.zhi) {
       const int n3 = g.n3;
-      const real t1 = u[g.ix(i, j, n3)] - u[g.ix(i, j, n3 + 1)] + u[g.ix(i - 1, j, n3)] - u[g.ix(i - 1, j, n3 + 1)];
+      const real t1 = u[g.ix(i, j, n3)] - u[g.ix(i, j, n3 + 1)] + u[g.ix(im1, j, n3)] - u[g.ix(im1, j, n3 + 1)];
       const real t2 = v[g.ix(i, j, n3)] - v[g.ix(i, j, n3 + 1)] + v[g.ix(i, j - 1, n3)] - v[g.ix(i, j - 1, n3 + 1)];
       tw_hi = sqrt(0.5 * A.visc * (sqrt(t1 * t1 + t2 * t2) * A.dzci[n3]));
     }
@@ -906,7 +911,8 @@ __global__ __launch_bounds__(64 * SROWS, (YW ? 3 : 4)) void k_smag_rows(Geom g, 
   const int kbeg = bz * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
   const bool ldok = i <= g.n1 + 1, outok = tx >= 1 && tx <= 62 && i <= g.n1;
   const OFF sj = (OFF)g.s1 * RSZ, sk = (OFF)g.s12 * RSZ;
-  const OFF c0 = ldok ? (OFF)g.ix(i, j, 0) * RSZ : (OFF)g.ix(0, j, 0) * RSZ;
+  const int iw = !A.perx ? i : i == 0 ? g.n1 : i == g.n1 + 1 ? 1 : i;      // periodic x: wrapped columns instead of the ghost columns
+  const OFF c0 = ldok ? (OFF)g.ix(iw, j, 0) * RSZ : (OFF)g.ix(1, j, 0) * RSZ;
   // ghost rows at wall-model y faces: u and w are replaced by 2 Q(1) - Q(2) along y; v, normal to the face, is not (extrapolate(...,lwm), sgs.f90:683-748)
   const bool exlo = YW && A.wmylo && j == 1, exhi = YW && A.wmyhi && j == g.n2;
   // (lanes beyond the row read cell 0 of the field and planes beyond n3+1 are clamped: every load is unconditional, nothing branches around it)
@@ -929,14 +935,15 @@ __global__ __launch_bounds__(64 * SROWS, (YW ? 3 : 4)) void k_smag_rows(Geom g, 
   real tw_lo = 0., tw_hi = 0.;
   if (outok) {
     const real *u = A.u[0], *v = A.u[1];
+    const int im1 = (A.perx && i == 1) ? g.n1 : i - 1;
     if (A.zlo) {
-      const real t1 = u[g.ix(i, j, 1)] - u[g.ix(i, j, 0)] + u[g.ix(i - 1, j, 1)] - u[g.ix(i - 1, j, 0)];
+      const real t1 = u[g.ix(i, j, 1)] - u[g.ix(i, j, 0)] + u[g.ix(im1, j, 1)] - u[g.ix(im1, j, 0)];
       const real t2 = v[g.ix(i, j, 1)] - v[g.ix(i, j, 0)] + v[g.ix(i, j - 1, 1)] - v[g.ix(i, j - 1, 0)];
       tw_lo = sqrt(0.5 * A.visc * (sqrt(t1 * t1 + t2 * t2) * A.dzci[0]));
     }
     if (A.zhi) {
       const int n3 = g.n3;
-      const real t1 = u[g.ix(i, j, n3)] - u[g.ix(i, j, n3 + 1)] + u[g.ix(i - 1, j, n3)] - u[g.ix(i - 1, j, n3 + 1)];
+      const real t1 = u[g.ix(i, j, n3)] - u[g.ix(i, j, n3 + 1)] + u[g.ix(im1, j, n3)] - u[g.ix(im1, j, n3 + 1)];
       const real t2 = v[g.ix(i, j, n3)] - v[g.ix(i, j, n3 + 1)] + v[g.ix(i, j - 1, n3)] - v[g.ix(i, j - 1, n3 + 1)];
       tw_hi = sqrt(0.5 * A.visc * (sqrt(t1 * t1 + t2 * t2) * A.dzci[n3]));
     }
@@ -1057,7 +1064,7 @@ static int dsmag_fast(cales_ctx *c) {
     S.uc[0] = ucf ? nullptr : c->uc; S.uc[1] = ucf ? nullptr : c->vc; S.uc[2] = ucf ? nullptr : c->wc; S.uf[0] = c->uf; S.uf[1] = c->vf; S.uf[2] = c->wf;
     S.dzci = c->d_dzci; S.dzfi = c->d_dzfi; S.dxi = c->dli[0]; S.dyi = c->dli[1]; S.kchunk = kch; S.zlo = zlo; S.zhi = zhi; S.wmlo = wmlo; S.wmhi = wmhi; S.flo = flo; S.fhi = fhi;
     S.wylo = wylo; S.wyhi = wyhi; S.wmylo = wmylo; S.wmyhi = wmyhi; S.twy = nullptr; S.dl2 = c->dl[1];
-    S.bm = BandMap{0, 0, 0, 0};
+    S.bm = BandMap{0, 0, 0, 0}; S.perx = c->step_xskip ? 1 : 0;
     if (!c->fl.plain_grid && (band_wanted(mg.x) || c->fl.band_grid)) { S.bm = band_map(mg.x, mg.y, mg.z); mg = dim3(band_blocks(S.bm), 1, 1); }
     if (wylo || wyhi || wmylo || wmyhi) { if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 0, TYS, 1>), mg, mb, 0, c->stream, c->g, S); else hipLaunchKernelGGL((k_strain_tile<size_t, 0, TYS, 1>), mg, mb, 0, c->stream, c->g, S); }
     else if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 0, TYS, 0>), mg, mb, 0, c->stream, c->g, S); else hipLaunchKernelGGL((k_strain_tile<size_t, 0, TYS, 0>), mg, mb, 0, c->stream, c->g, S); }
@@ -1089,7 +1096,7 @@ static int dsmag_fast(cales_ctx *c) {
   if (e_) { c->deferred.clear(); return e_; }
   LijMijArgs L;
   L.uc[0] = ucf ? f[CALES_U] : c->uc; L.uc[1] = ucf ? f[CALES_V] : c->vc; L.uc[2] = ucf ? f[CALES_W] : c->wc; L.uf[0] = c->uf; L.uf[1] = c->vf; L.uf[2] = c->wf;
-  L.vcg = c->vc; L.perz = perz ? 1 : 0;
+  L.vcg = c->vc; L.perz = perz ? 1 : 0; L.xwrap = c->step_xskip ? 1 : 0;
   for (int m = 0; m < 6; ++m) L.mf[m] = mij[m];
   L.part = c->wk[0]; L.dzci = c->d_dzci; L.dzfi = c->d_dzfi; L.dxi = c->dli[0]; L.dyi = c->dli[1];
   L.zlo = zlo; L.zhi = zhi; L.wmlo = wmlo; L.wmhi = wmhi; L.flo = flo; L.fhi = fhi; L.perx = perx;
@@ -1202,7 +1209,7 @@ static int smag_fast(cales_ctx *c) {
   S.zlo = c->is_wall[4] != 0.; S.zhi = c->is_wall[5] != 0.;
   S.wmlo = ISB(c, 0, 3) && LWM(c, 0, 3) != 0; S.wmhi = ISB(c, 1, 3) && LWM(c, 1, 3) != 0;
   S.flo = (1. / c->dzci[0]) * c->dzci[1]; S.fhi = (1. / c->dzci[n[2]]) * c->dzci[n[2] - 1];
-  S.zc = c->d_zc; S.del = c->d_del; S.l3 = c->C.l[2]; S.visc = c->visc;
+  S.zc = c->d_zc; S.del = c->d_del; S.l3 = c->C.l[2]; S.visc = c->visc; S.perx = c->step_xskip ? 1 : 0;
   // walls in y (ducts): is_wall(2:3) is a property of the case, distances use global rows, and the shear of both y walls reaches every slab
   S.wylo = c->is_wall[2] != 0.; S.wyhi = c->is_wall[3] != 0.; S.dl2 = c->dl[1];
   S.wmylo = ISB(c, 0, 2) && LWM(c, 0, 2) != 0; S.wmyhi = ISB(c, 1, 2) && LWM(c, 1, 2) != 0;
@@ -1236,6 +1243,12 @@ static int smag_fast(cales_ctx *c) {
   return 0;
 }
 
+// every kernel the SGS pass of this case launches reads wrapped interior columns where x is periodic (cales_step may leave the x ghost columns stale)
+bool sgs_wraps_x(const cales_ctx *c) {
+  if (c->C.sgstype == 0) return true;
+  if (c->C.sgstype == 1) return smag_fast_ok(c);
+  return dsmag_fast_ok(c) && !c->fl.dsmag_xghosts;
+}
 int op_cmpt_sgs(cales_ctx *c) {
   const int *n = c->n; const size_t nt = c->ntot;
   real **f = c->f; real *visct = f[CALES_VISCT];

@@ -255,7 +255,7 @@ __device__ inline int dct_src(int e, int n) { return e < n / 2 ? 2 * e : 2 * (n 
 // (fillps.f90:36-47, same expression as k_fillps) -- the separate fillps pass and its write + re-read of pp disappear.
 // mean_mask != 0: the pass also sums comp*grid_vol_ratio(k) of the forced velocity components it reads anyway (bulk_mean,
 // utils.f90:35-44), one partial per block and component -> the separate reduction pass over u disappears.
-struct FillArgs { const real *u, *v, *w, *dzfi; real dti, dtidxi, dtidyi; int mean_mask; const real *gvr_f, *gvr_c; real *part; int pstride = 0, pofs = 0; };      // pstride: partial sums per component over all launches of a chunked pass (0: gridDim.x)
+struct FillArgs { const real *u, *v, *w, *dzfi; real dti, dtidxi, dtidyi; int mean_mask; const real *gvr_f, *gvr_c; real *part; int pstride = 0, pofs = 0; int xwrap = 0; };      // xwrap = n1 with periodic x: u(0) is read as u(n1) (the ghost column may be stale inside cales_step), 0 otherwise      // pstride: partial sums per component over all launches of a chunked pass (0: gridDim.x)
 template <int INV, int KIND, int FILL = 0>
 __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const cpx *__restrict__ twg, const cpx *__restrict__ twpg,
                                                  const cpx *__restrict__ twd, real *__restrict__ p, real scale, Spec S, real2 *__restrict__ spec,
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
         const size_t c = c0 + 1 + 2 * (t + e * T);      // cell i = 1 + 2q and its right neighbour: aligned pairs
-        const real2 uu = *reinterpret_cast<const real2 *>(F.u + c); const real um = F.u[c - 1];
+        const real2 uu = *reinterpret_cast<const real2 *>(F.u + c); const real um = (F.xwrap && t + e * T == 0) ? F.u[c0 + F.xwrap] : F.u[c - 1];
         const real2 vv = *reinterpret_cast<const real2 *>(F.v + c), vm = *reinterpret_cast<const real2 *>(F.v + c - g.s1);
         const real2 ww = *reinterpret_cast<const real2 *>(F.w + c), wm = *reinterpret_cast<const real2 *>(F.w + c - g.s12);
         nxt[e] = cpx{((ww.x - wm.x) * F.dti * dz + (vv.x - vm.x) * F.dtidyi + (uu.x - um) * F.dtidxi),
@@ -1407,6 +1407,7 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
     if (fill) {
       const real dti = c->fuse_fillps_dti;
       F = FillArgs{c->f[CALES_U], c->f[CALES_V], c->f[CALES_W], c->d_dzfi, dti, dti * c->dli[0], dti * c->dli[1], c->fuse_mean_mask, c->d_gvr_f, c->d_gvr_c, nullptr};
+      F.xwrap = c->step_xskip ? n[0] : 0;
       if (F.mean_mask) {
         const size_t need = 3 * (size_t)xblocks_c * NCH;
         if (c->n_mpart < need) { if (c->d_mpart) hipFree(c->d_mpart); HIPCHK(c, hipMalloc(&c->d_mpart, need * sizeof(real))); c->n_mpart = need; }
@@ -1437,6 +1438,7 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
     ProfScope ps(c, "fillps_fft_x_fwd");
     const real dti = c->fuse_fillps_dti;
     FillArgs F{c->f[CALES_U], c->f[CALES_V], c->f[CALES_W], c->d_dzfi, dti, dti * c->dli[0], dti * c->dli[1], c->fuse_mean_mask, c->d_gvr_f, c->d_gvr_c, nullptr};
+    F.xwrap = c->step_xskip ? n[0] : 0;
     if (F.mean_mask) {
       if (c->n_mpart < 3 * (size_t)xblocks) { if (c->d_mpart) hipFree(c->d_mpart); HIPCHK(c, hipMalloc(&c->d_mpart, 3 * (size_t)xblocks * sizeof(real))); c->n_mpart = 3 * (size_t)xblocks; }
       F.part = c->d_mpart;

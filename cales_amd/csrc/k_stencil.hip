@@ -357,14 +357,14 @@ template <int UPD>
 __global__ __launch_bounds__(BX *BY) void k_correc_cell(Geom g, real fi, real fj, real dt, real alpha, const real *__restrict__ dzci,
                                                          const real *__restrict__ dzfi, const real *__restrict__ pp, real *__restrict__ u,
                                                          real *__restrict__ v, real *__restrict__ w, real *__restrict__ p,
-                                                         const real *__restrict__ force, int fmask) {
+                                                         const real *__restrict__ force, int fmask, int perx) {      // perx: pp(n1+1) is read as pp(1)
   const int tx = threadIdx.x, i = blockIdx.x * BX + tx + 1, j = blockIdx.y * BY + threadIdx.y, k = blockIdx.z;
   if (j > g.n2 + 1) return;
   const bool on = i <= g.n1, lastlane = tx == BX - 1 || i == g.n1;
   const size_t c = g.ix(on ? i : g.n1, j, k);
   const real pc = on ? pp[c] : 0.;
   real px = lane_next(pc);
-  if (lastlane) px = pp[c + 1];
+  if (lastlane) px = (perx && i == g.n1) ? pp[g.ix(1, j, k)] : pp[c + 1];
   if (!on) return;
   const bool inner = j >= 1 && j <= g.n2 && k >= 1 && k <= g.n3;
   const real f0 = (fmask & 1) && inner ? force[0] : 0., f1 = (fmask & 2) && inner ? force[1] : 0., f2 = (fmask & 4) && inner ? force[2] : 0.;
@@ -398,9 +398,10 @@ int op_correc_updatep(cales_ctx *c, real dt, real alpha, int upd) {
   const real fi = dt * c->dli[0], fj = dt * c->dli[1];
   const int mode = !upd ? 0 : (c->C.impdiff == 2 ? 2 : 1);
   const int fmask = c->defer_force ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;
-  if (mode == 0) hipLaunchKernelGGL(k_correc_cell<0>, gr, b, 0, c->stream, c->g, fi, fj, dt, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], f_[0], f_[1], f_[2], f_[3], c->d_force, fmask);
-  else if (mode == 1) hipLaunchKernelGGL(k_correc_cell<1>, gr, b, 0, c->stream, c->g, fi, fj, dt, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], f_[0], f_[1], f_[2], f_[3], c->d_force, fmask);
-  else hipLaunchKernelGGL(k_correc_cell<2>, gr, b, 0, c->stream, c->g, fi, fj, dt, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], f_[0], f_[1], f_[2], f_[3], c->d_force, fmask);
+  const int perx = c->step_xskip ? 1 : 0;      // (operator-level calls read the ghost column of pp the caller provided)
+  if (mode == 0) hipLaunchKernelGGL(k_correc_cell<0>, gr, b, 0, c->stream, c->g, fi, fj, dt, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], f_[0], f_[1], f_[2], f_[3], c->d_force, fmask, perx);
+  else if (mode == 1) hipLaunchKernelGGL(k_correc_cell<1>, gr, b, 0, c->stream, c->g, fi, fj, dt, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], f_[0], f_[1], f_[2], f_[3], c->d_force, fmask, perx);
+  else hipLaunchKernelGGL(k_correc_cell<2>, gr, b, 0, c->stream, c->g, fi, fj, dt, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], f_[0], f_[1], f_[2], f_[3], c->d_force, fmask, perx);
   // periodic x: the ghost columns are overwritten by the periodic copy of the bounduvw that always follows (main.f90:500) -- inside
   // cales_step their correction is dead work
   if (!(c->in_step && c->cbcvel[0] == 'P' && c->cbcvel[1] == 'P'))

@@ -90,7 +90,11 @@ def test_tridiagonal_paths_agree(name, ng, monkeypatch):
                                             # of the last bounduvw, which have to survive the double-buffered velocity update
                                             ("duct_smag_wm", (16, 8, 24), 3), ("duct_smag_wm_imp1d", (50, 8, 76), 2), ("chan_smag_wm", (32, 16, 8), 3),
                                             # 3-D implicit diffusion (impdiff = 1): Helmholtz solves of u,v,w through the FFT solver
-                                            ("couette_imp3d_ops", (16, 16, 16), 4), ("couette_imp3d_ops", (32, 20, 24), 3)])
+                                            ("couette_imp3d_ops", (16, 16, 16), 4), ("couette_imp3d_ops", (32, 20, 24), 3),
+                                            # power-of-two rows with periodic x: cales_step leaves the x ghost columns alone until it returns and its kernels
+                                            # wrap around (one full tile, two tiles, a row shorter than a tile; all ghost cells are compared at the end)
+                                            ("chan_dsmag", (64, 20, 12), 3), ("chan_dsmag", (128, 12, 20), 2), ("chan_smag", (64, 18, 12), 3), ("chan_smag", (128, 10, 16), 2),
+                                            ("chan_smag", (16, 12, 10), 3), ("tgv_dsmag_ppp", (64, 16, 24), 3), ("duct_dsmag", (64, 18, 20), 2), ("tgv_ppp", (128, 8, 8), 3)])
 def test_time_steps(name, ng, nsteps):
     """u,v,w <= 1e-9, p (mean removed) <= 1e-8 after the steps; divmax same order of magnitude"""
     from cales_amd.hotpath import initflow
@@ -120,6 +124,14 @@ def test_time_steps(name, ng, nsteps):
     # algorithm itself (restated by the oracle) stops at ~1e-9.
     assert dg[1] < 20. * do[1] + 1e-14 and (dg[1] < 1e-11 or do[1] > 1e-11)
     h.close()
+
+
+@pytest.mark.parametrize("name,ng,nsteps", [("chan_dsmag", (32, 16, 16), 3), ("chan_smag", (64, 18, 12), 2), ("tgv_ppp", (32, 24, 16), 3)])
+def test_time_steps_with_x_ghosts_kept(name, ng, nsteps, monkeypatch):
+    """CALES_XGHOSTS_IN_STEP: every ghost-cell operator of cales_step fills the x ghost columns and the kernels read them (the form the operator-level
+    entries always use) instead of wrapping around."""
+    monkeypatch.setenv("CALES_XGHOSTS_IN_STEP", "1")
+    test_time_steps(name, ng, nsteps)
 
 
 def _two_steps(case, ng, seed=7):
