@@ -257,7 +257,9 @@ __device__ inline int dct_src(int e, int n) { return e < n / 2 ? 2 * e : 2 * (n 
 // utils.f90:35-44), one partial per block and component -> the separate reduction pass over u disappears.
 struct FillArgs { const real *u, *v, *w, *dzfi; real dti, dtidxi, dtidyi; int mean_mask; const real *gvr_f, *gvr_c; real *part; int pstride = 0, pofs = 0; int xwrap = 0; };      // xwrap = n1 with periodic x: u(0) is read as u(n1) (the ghost column may be stale inside cales_step), 0 otherwise      // pstride: partial sums per component over all launches of a chunked pass (0: gridDim.x)
 template <int INV, int KIND, int FILL = 0>
-__global__ __launch_bounds__(256) void k_fft_x8(Geom g, int nh, int iters, const cpx *__restrict__ twg, const cpx *__restrict__ twpg,
+// (the Neumann forward pass with fillps held 256 VGPRs + 13 AGPRs, i.e. ONE wave per SIMD; two blocks per CU cap it at 256 in all: 18 spilled
+//  registers, 10.3 -> 7.3 ms at 1024^3)
+__global__ __launch_bounds__(256, (KIND == 1 && FILL == 1) ? 2 : 1) void k_fft_x8(Geom g, int nh, int iters, const cpx *__restrict__ twg, const cpx *__restrict__ twpg,
                                                  const cpx *__restrict__ twd, real *__restrict__ p, real scale, Spec S, real2 *__restrict__ spec,
                                                  FillArgs F = FillArgs{}, long rbeg = 0, long rend = -1) {      // rows [rbeg, rend) of the (j,k) row list: a k-chunk of the pipelined solve
   extern __shared__ __align__(16) unsigned char smem[];
@@ -506,7 +508,11 @@ __global__ __launch_bounds__(512) void k_fft_y8(Geom g, int N, int ncols, int kc
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int kind = KIND;
   const int T = N >> 3, CB = blockDim.x / T, ld = lpad(N) + 1;
-  const int m0 = blockIdx.x * CB, kbeg = k0 + blockIdx.y * kchunk + 1, kend = min(kbeg + kchunk - 1, k1 < 0 ? g.n3 : k1);
+  // 1024-point lines: four columns per block = HALF a 128-B line per row. Blocks are dealt to the eight XCDs in turn, so the two tiles of a line go
+  // to blocks b and b + 8: same XCD, dispatched together -- the second half of every line is then a hit in that XCD's L2 instead of a second fetch
+  int tile = blockIdx.x;
+  if (CB == 4 && tile < (int)(gridDim.x & ~15u)) { const int r = tile & 15; tile = (tile & ~15) + ((r & 7) << 1) + (r >> 3); }
+  const int m0 = tile * CB, kbeg = k0 + blockIdx.y * kchunk + 1, kend = min(kbeg + kchunk - 1, k1 < 0 ? g.n3 : k1);
   cpx *tw = reinterpret_cast<cpx *>(smem), *base = tw + N;
   for (int q = threadIdx.x; q < N; q += blockDim.x) tw[q] = twg[q];
   const int NE = 8;                                                          // CB*N / blockDim.x
@@ -569,7 +575,9 @@ __global__ __launch_bounds__(512) void k_fft_y8r(Geom g, int N, int ncols, int k
   extern __shared__ __align__(16) unsigned char smem[];
   const int T = N >> 3, CB = blockDim.x / T, ld = ((lpad(N) + 15) & ~15) + 4;
   const int c = threadIdx.x % CB, t = threadIdx.x / CB;
-  const int m0 = blockIdx.x * CB, kbeg = k0 + blockIdx.y * kchunk + 1, kend = min(kbeg + kchunk - 1, k1 < 0 ? g.n3 : k1);
+  int tile = blockIdx.x;      // (half-line tiles of 1024-point lines: both halves of a line on one XCD, see k_fft_y8)
+  if (CB == 4 && tile < (int)(gridDim.x & ~15u)) { const int r = tile & 15; tile = (tile & ~15) + ((r & 7) << 1) + (r >> 3); }
+  const int m0 = tile * CB, kbeg = k0 + blockIdx.y * kchunk + 1, kend = min(kbeg + kchunk - 1, k1 < 0 ? g.n3 : k1);
   cpx *tw = reinterpret_cast<cpx *>(smem), *line = tw + N + (size_t)c * ld;
   for (int q = threadIdx.x; q < N; q += blockDim.x) tw[q] = twg[q];
   const bool colok = m0 + c < ncols;
@@ -853,11 +861,11 @@ __device__ inline real rcp_nr(real x) {
 }
 // a,b,c of the 64 M rows (identity rows beyond nz, no coupling out of the first and the last row) as [which][r][chunk]: the
 // lanes of a wave (= chunks) read consecutive doubles
-__global__ void k_abc_chunked(int nz, int M, const real *__restrict__ a, const real *__restrict__ b, const real *__restrict__ c, real *__restrict__ t) {
+__global__ void k_abc_chunked(int nz, int M, const real *__restrict__ a, const real *__restrict__ b, const real *__restrict__ c, real *__restrict__ t, int nch = 64) {
   const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= 64 * M) return;
-  const int o = (k % M) * 64 + k / M;
-  t[o] = (k > 0 && k < nz) ? a[k] : 0.; t[64 * M + o] = k < nz ? b[k] : 1.; t[128 * M + o] = k < nz - 1 ? c[k] : 0.;
+  if (k >= nch * M) return;
+  const int o = (k % M) * nch + k / M;
+  t[o] = (k > 0 && k < nz) ? a[k] : 0.; t[nch * M + o] = k < nz ? b[k] : 1.; t[2 * nch * M + o] = k < nz - 1 ? c[k] : 0.;
 }
 // Segments of columns (blockIdx.y): one rank -- row j of the in-place spectrum (ndbl doubles, plane stride s12); several ranks --
 // the block of peer blockIdx.y in the layout [peer][k][jl][m], whose (jl, m) planes are contiguous runs of 2 cw n2l doubles.
@@ -868,26 +876,46 @@ struct TileMap { int blocked, cw, n2l, mofs, nmode; size_t kstride, segstride;
 // PER = 1: periodic z (solver.f90:109-150, gaussel_periodic): the tile solves the (n-1)-row system for the right-hand side AND for the closure
 // vector p2 = (-a(1), 0, ..., 0, -c(n-1)) -- one more right-hand side of the same matrix, kept in registers -- and the last row follows from
 // p(n) = (p(n) - c(n) p1(1) - a(n) p1(n-1)) / (b(n) + lambda + c(n) p2(1) + a(n) p2(n-1) + eps), p(1:n-1) = p1 + p2 p(n); ra, rb_, rc: the raw a, b, c.
+// (nz > 512 with real x modes -- M = 16, NV = 1, the 1024^3 cavity: 140 KB of LDS leave one block per CU, so traffic (3.5 ms) and solve of that pass
+//  do not overlap, and a 1024-thread block is capped at 128 registers. Round 3: the 29 spilled registers were not the 2 x 15 elimination coefficients
+//  but the sixteen global addresses and sixteen LDS places of the load phase, kept alive for the store phase -- as many bytes of scratch traffic as the
+//  tile itself (FETCH_SIZE / WRITE_SIZE 16 + 17 GB for 8.6 + 8.6 compulsory); formed again behind an opaque offset: 2 spilled registers, 7.7 -> 6.2 ms.
+//  Tried and dropped: half as many waves solving the tile in two rounds under the 256-register cap (8.2 ms); tiles of eight columns, two blocks per
+//  CU, the two half-line tiles of a line on the same XCD (8.6 ms); two waves per column with 8 planes per lane and a 2 x 2 interface system between
+//  their two cyclic reductions (no spills, 8.2 ms: twice the reductions, six more barriers per tile).)
+constexpr int gt_width(int, int) { return 16; }      // columns per tile: one 128-B line per plane
+#ifndef GT_TL
+#define GT_TL 1
+#endif
 template <int M, int NV, int PER>
-__global__ __launch_bounds__(1024 / NV, (PER ? 2 : M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_gaussel_tile(Geom g, int nz, int ndbl, real lscale, const real *__restrict__ abc,
+__global__ __launch_bounds__(64 * gt_width(M, NV) / NV, (PER ? 2 : M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_gaussel_tile(Geom g, int nz, int ndbl, real lscale, const real *__restrict__ abc,
                                                             const real *__restrict__ lamx, const real *__restrict__ lamy,
                                                             real *__restrict__ p, int fixnull, TileMap T,
                                                             const real *__restrict__ ra = nullptr, const real *__restrict__ rb_ = nullptr, const real *__restrict__ rc = nullptr) {
   extern __shared__ real shz[];
   const int nsys = PER ? nz - 1 : nz;      // rows of the tridiagonal system proper
-  constexpr int CP = M + 1, P = 64 * CP + 4, NT = 1024 / NV, KP = NT / 16, NQ = 64 * M / KP;
+  constexpr int W = gt_width(M, NV), CP = M + 1, P = 64 * CP + 4, NT = 64 * W / NV, KP = NT / W, NQ = 64 * M / KP;
   const int t = threadIdx.x;
-  const size_t base = (T.blocked ? T.segstride * blockIdx.y : g.ix(0, blockIdx.y + 1, 1)) + (size_t)16 * blockIdx.x;      // doubles from p
+  const int tile = blockIdx.x;
+  const size_t base = (T.blocked ? T.segstride * blockIdx.y : g.ix(0, blockIdx.y + 1, 1)) + (size_t)W * tile;      // doubles from p
   const size_t kst = T.blocked ? T.kstride : (size_t)g.s12;
+  // 16-plane chunks: every wave reads the 3 x 16 table entries of its lanes -- 1.5 x the tile's own traffic through the vector cache. The sub- and
+  // the superdiagonal go to the 16 KB of LDS the tile leaves free (GT_TL; the diagonal stays in the table)
+  constexpr bool TL = GT_TL && M == 16;
+  real *tabl = shz + W * P;
+  if (TL) { for (int q = t; q < 64 * M; q += NT) { tabl[q] = abc[q]; tabl[64 * M + q] = abc[128 * M + q]; } }
   {
-    const int x = t & 15, kk = t >> 4;
-    const bool ok = 16 * (int)blockIdx.x + x < ndbl;
+    const int x = t % W, kk = t / W;
+    const bool ok = W * tile + x < ndbl;
     real v[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) { const int k = kk + KP * q; v[q] = (ok && k < nz) ? p[base + x + (size_t)k * kst] : 0.; }
-    if (T.dud) {
+    for (int q = 0; q < NQ; ++q) {      // (measured: faster than unconditional loads from clamped places, 0.59 against 0.87 ms at 512^3)
+      const int k = kk + KP * q;
+      v[q] = (ok && k < nz) ? p[base + x + (size_t)k * kst] : 0.;
+    }
+    if (NV == 2 && T.dud) {      // (the z-only Helmholtz sweeps come as pairs of real columns that share the matrix: NV = 2 only)
       const real f = T.force ? T.force[0] : 0.;
-      const size_t pq = (size_t)(16 * blockIdx.x + x) + (size_t)g.n1 * blockIdx.y;
+      const size_t pq = (size_t)(W * tile + x) + (size_t)g.n1 * blockIdx.y;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const int k = kk + KP * q;
@@ -904,7 +932,7 @@ __global__ __launch_bounds__(1024 / NV, (PER ? 2 : M <= 8 ? 4 : NV == 1 ? 4 : 2)
     for (int q = 0; q < NQ; ++q) { const int k = kk + KP * q; shz[x * P + k + k / M] = v[q]; }
   }
   __syncthreads();
-  const int x = (t >> 6) * NV, ch = t & 63, d = 16 * (int)blockIdx.x + x;
+  const int x = (t >> 6) * NV, ch = t & 63, d = W * tile + x;
   // column d of the segment -> x mode and global row
   int mode = NV == 1 ? d : d >> 1, j = blockIdx.y + 1;
   bool colok = d < ndbl;
@@ -932,11 +960,14 @@ __global__ __launch_bounds__(1024 / NV, (PER ? 2 : M <= 8 ? 4 : NV == 1 ? 4 : 2)
     for (int r = 0; r < M - 1; ++r) {
       const int k = k0 + r;
       const bool pin = !PER && nullc && k == nz - 1, live = k < nsys && !pin;
-      const real A = pin ? 0. : abc[r * 64 + ch], C = pin ? 0. : abc[128 * M + r * 64 + ch], B = pin ? 1. : abc[64 * M + r * 64 + ch] + (k < nsys ? lam : 0.);
+      // (every load unconditional, the selection afterwards: a load inside a divergent branch is waited for on the spot -- sixteen serial
+      //  round trips to the table per chunk)
+      const real A0 = TL ? tabl[r * 64 + ch] : abc[r * 64 + ch], C0 = TL ? tabl[64 * M + r * 64 + ch] : abc[128 * M + r * 64 + ch], B0 = abc[64 * M + r * 64 + ch];
+      const real A = pin ? 0. : A0, C = pin ? 0. : C0, B = pin ? 1. : B0 + (k < nsys ? lam : 0.);
       const real z = rcp_nr(B - A * cprev + CALES_EPS);
       cp[r] = C * z; V[r] = (r == 0 ? A : -A * vprev) * z;
 #pragma unroll
-      for (int q = 0; q < NV; ++q) { const real D = live ? col[q * P + r] : 0.; rprev[q] = (D - A * rprev[q]) * z; col[q * P + r] = rprev[q]; }
+      for (int q = 0; q < NV; ++q) { const real D0 = col[q * P + r], D = live ? D0 : 0.; rprev[q] = (D - A * rprev[q]) * z; col[q * P + r] = rprev[q]; }
       if (PER) { const real D2 = (k == 0 ? e_first : 0.) + (k == nsys - 1 ? e_last : 0.); eprev = (D2 - A * eprev) * z; E[r] = eprev; }
       cprev = cp[r]; vprev = V[r];
     }
@@ -960,7 +991,8 @@ __global__ __launch_bounds__(1024 / NV, (PER ? 2 : M <= 8 ? 4 : NV == 1 ? 4 : 2)
     {
       const int k = k0 + M - 1, r = M - 1;
       const bool pin = !PER && nullc && k == nz - 1, live = k < nsys && !pin;
-      const real A = pin ? 0. : abc[r * 64 + ch], C = pin ? 0. : abc[128 * M + r * 64 + ch], B = pin ? 1. : abc[64 * M + r * 64 + ch] + (k < nsys ? lam : 0.);
+      const real A0 = TL ? tabl[r * 64 + ch] : abc[r * 64 + ch], C0 = TL ? tabl[64 * M + r * 64 + ch] : abc[128 * M + r * 64 + ch], B0 = abc[64 * M + r * 64 + ch];
+      const real A = pin ? 0. : A0, C = pin ? 0. : C0, B = pin ? 1. : B0 + (k < nsys ? lam : 0.);
       al = -A * V[M - 2]; be = B - A * cp[M - 2] - C * Vn; ga = -C * Wn;
       if (PER) {
         real En = __shfl_down(Eb, 1, 64);
@@ -972,7 +1004,7 @@ __global__ __launch_bounds__(1024 / NV, (PER ? 2 : M <= 8 ? 4 : NV == 1 ? 4 : 2)
       for (int q = 0; q < NV; ++q) {
         real Rn = __shfl_down(Rb[q], 1, 64);
         if (last) Rn = 0.;
-        const real D = live ? col[q * P + M - 1] : 0.;
+        const real D0 = col[q * P + M - 1], D = live ? D0 : 0.;
         de[q] = D - A * rprev[q] - C * Rn;
       }
     }
@@ -1032,16 +1064,22 @@ __global__ __launch_bounds__(1024 / NV, (PER ? 2 : M <= 8 ? 4 : NV == 1 ? 4 : 2)
   }
   __syncthreads();
   {
-    const int x = t & 15, kk = t >> 4;
-    const bool ok = 16 * (int)blockIdx.x + x < ndbl;
+    // (addresses formed again from an offset the compiler cannot recognise: it would otherwise keep those of the load phase alive through the
+    //  solve, in scratch memory where registers are short -- 19 of the 29 spilled registers of the 16-plane instantiation)
+    const int x = t % W, kk = t / W;
+    const bool ok = W * tile + x < ndbl;
+    size_t o = base + x + (size_t)kk * kst;
+    int kq = kk;      // (the LDS places likewise)
+    asm volatile("" : "+v"(o), "+v"(kq));
+    const size_t step = (size_t)KP * kst;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) { const int k = kk + KP * q; if (ok && k < nz) p[base + x + (size_t)k * kst] = shz[x * P + k + k / M]; }
+    for (int q = 0; q < NQ; ++q) { const int k = kq + KP * q; if (ok && k < nz) p[o] = shz[x * P + k + k / M]; o += step; }
   }
 }
 template <int M, int NV, int PER = 0>
 static void launch_gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, real lscale, const real *da, const real *db, const real *dc,
                                 real *p, int fixnull, const TileMap &T) {
-  constexpr int lds = 16 * (64 * (M + 1) + 4) * 8;
+  constexpr int W = gt_width(M, NV), lds = W * (64 * (M + 1) + 4) * 8 + (GT_TL && M == 16 ? 2 * 64 * M * 8 : 0);
   static bool once = false;
   if (!once) { hipFuncSetAttribute((const void *)k_gaussel_tile<M, NV, PER>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
   if (!c->d_abct) { if (hipMalloc(&c->d_abct, 2 * 3 * 64 * 16 * sizeof(real)) != hipSuccess) { c->d_abct = nullptr; return; } }
@@ -1051,7 +1089,7 @@ static void launch_gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, real l
   // (periodic z: the table holds the n-1 rows of the system proper; identity rows from row n on)
   if (!pressure || !c->abct_ready) hipLaunchKernelGGL(k_abc_chunked, dim3((64 * M + 255) / 256), dim3(256), 0, c->stream, PER ? nz - 1 : nz, M, da, db, dc, tab);
   if (pressure) c->abct_ready = true;
-  hipLaunchKernelGGL((k_gaussel_tile<M, NV, PER>), dim3((ndbl + 15) / 16, nrow), dim3(1024 / NV), lds, c->stream, c->g, nz, ndbl, lscale, tab,
+  hipLaunchKernelGGL((k_gaussel_tile<M, NV, PER>), dim3((ndbl + W - 1) / W, nrow), dim3(64 * W / NV), lds, c->stream, c->g, nz, ndbl, lscale, tab,
                      c->d_lamx, c->d_lamy, p, fixnull, T, da, db, dc);
 }
 // one rank: ndbl doubles of each of the nrow rows; several ranks (T.blocked): nrow = peers, ndbl = 2 cw n2l doubles per plane of a peer block

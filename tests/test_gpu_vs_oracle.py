@@ -29,6 +29,8 @@ def _hot(case):
                                      # deep z: the in-LDS tridiagonal tile with 2, 4, 8, 16 planes per lane, partial last chunks
                                      ("chan_smag", (16, 8, 100)), ("chan_smag", (16, 8, 130)), ("cavity_nnn", (40, 8, 300)),
                                      ("chan_smag", (16, 4, 512)), ("duct_smag_wm", (16, 8, 514)), ("chan_smag", (8, 4, 1024)),
+                                     # 513..1024 planes of real x modes (16 planes per lane, one matrix per column): full, partial and nearly empty last chunks; odd column counts
+                                     ("cavity_nnn", (16, 8, 1024)), ("cavity_nnn", (40, 4, 700)), ("cavity_nnn", (24, 6, 520)), ("devchan_nd", (16, 8, 600)), ("cavity_nnn", (18, 4, 1000)),
                                      # periodic y lines of 16 ... 512 points: every first radix of the register-ended transform (8-2, 8-4, 8-8, 2-8-8, 4-8-8, 8-8-8)
                                      ("chan_smag", (16, 16, 6)), ("chan_smag", (16, 32, 6)), ("tgv_ppp", (16, 64, 8)), ("chan_smag", (16, 256, 4)), ("tgv_ppp", (32, 512, 4))])
 def test_poisson_solve(name, ng):
@@ -63,7 +65,7 @@ def test_poisson_solve_staged_y_transform(name, ng, monkeypatch):
     test_poisson_solve(name, ng)
 
 
-@pytest.mark.parametrize("name,ng", [("chan_smag", (32, 16, 24)), ("cavity_nnn", (24, 20, 70)), ("halfchan_imp1d", (16, 16, 200))])
+@pytest.mark.parametrize("name,ng", [("chan_smag", (32, 16, 24)), ("cavity_nnn", (24, 20, 70)), ("halfchan_imp1d", (16, 16, 200)), ("cavity_nnn", (24, 20, 700))])
 def test_tridiagonal_paths_agree(name, ng, monkeypatch):
     """the in-LDS substructured sweep (default on one rank) against the marching Thomas sweep (CALES_GAUSSEL_MARCH)"""
     g, case = load_golden(name)

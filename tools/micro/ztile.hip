@@ -3,6 +3,7 @@
 // the marching Thomas kernel, which stores c' and d') can pay.  Build: hipcc --offload-arch=gfx950 -O3 ztile.hip -o ztile
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 template <int W, int NT>
 __global__ __launch_bounds__(NT) void k_ztile(double *p, long s1, long s12, int n1w, int n2, int n3) {
   extern __shared__ double sh[];
@@ -34,11 +35,14 @@ static void run(double *p, long s1, long s12, int n, const char *name) {
     if (rep == 2) printf("%s W=%d NT=%d: %.3f ms  %.2f TB/s\n", name, W, NT, ms, 16.0 * n * n * n / ms / 1e9);
   }
 }
-int main() {
-  const int n = 512; long s1 = 528, s12 = s1 * (n + 2); size_t ntot = (size_t)s12 * (n + 2);
+int main(int argc, char **argv) {
+  const int n = argc > 1 ? atoi(argv[1]) : 512; long s1 = n + 16, s12 = s1 * (n + 2); size_t ntot = (size_t)s12 * (n + 2);
   double *p; hipMalloc(&p, ntot * 8 + 65536); hipMemset(p, 0, ntot * 8);
+  printf("n = %d\n", n);
   run<16, 256>(p, s1, s12, n, "ztile"); run<16, 512>(p, s1, s12, n, "ztile"); run<16, 1024>(p, s1, s12, n, "ztile");
-  run<32, 512>(p, s1, s12, n, "ztile"); run<32, 1024>(p, s1, s12, n, "ztile");
+  if (n <= 512) { run<32, 512>(p, s1, s12, n, "ztile"); run<32, 1024>(p, s1, s12, n, "ztile"); }
+  // the same tiles if the spectrum were laid out [j][k][m] (z stride = one row, y stride = one plane)
+  run<16, 512>(p, s12, s1, n, "ztile, rows and planes swapped"); run<16, 1024>(p, s12, s1, n, "ztile, rows and planes swapped");
   {
     dim3 g(2, n), b(256); hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
