@@ -365,19 +365,33 @@ int cales_step(cales_ctx *c, real dt) {
     { const int e = op_solver(c); c->fuse_fillps_dti = 0.; if (e) return e; }
     if (int e = op_boundp(c, c->f[CALES_PP], 0)) return e;
     { const int e = fuse_cu ? op_correc_updatep(c, dtrk, alpha, 1) : op_correc(c, dtrk); c->defer_force = false; if (e) return e; }
-    if (int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 1, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W])) return e;
-    if (!fuse_cu) { if (int e = op_updatep(c, alpha)) return e; }
-    if (int e = op_boundp(c, c->f[CALES_P], 0)) return e;
+    // the pressure is final once the fused correction has run: its ghost cells ride along with those of the velocity (one launch, one slab exchange)
+    if (fuse_cu && !c->fl.unmerged_bc) { c->bc_nride = 1; c->bc_ride[0] = c->f[CALES_P]; c->bc_ride_which[0] = 0; }
+    { const int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 1, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W]);
+      const bool rode = fuse_cu && !c->fl.unmerged_bc && c->bc_nride == 0; c->bc_nride = 0;
+      if (e) return e;
+      if (!fuse_cu) { if (int e2 = op_updatep(c, alpha)) return e2; }
+      if (!rode) { if (int e2 = op_boundp(c, c->f[CALES_P], 0)) return e2; } }
     if (int e = op_cmpt_sgs(c)) return e;
-    if (int e = op_boundp(c, c->f[CALES_VISCT], 1)) return e;
+    // no subgrid model and homogeneous sgs BC values: the eddy viscosity is zero, ghost cells included, since start-up (sgs.f90:62-68)
+    bool visct_ghosts = !(c->C.sgstype == 0 && c->visct_zero && !c->sgs_first);
+    for (int q = 0; q < 6; ++q) if (c->C.bcsgs[q] != 0.) visct_ghosts = true;
+    if (visct_ghosts) { if (int e = op_boundp(c, c->f[CALES_VISCT], 1)) return e; }
   }
   if (c->step_xskip) {      // the ghost cells of everything a caller may look at, all directions (the corners of the x ghost columns with the z ghost planes included)
     c->step_xskip = false;
-    if (int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 0, 1, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W])) return e;
-    if (int e = op_xwrap_zghost(c, 3, c->f + CALES_U)) return e;
-    real *pq[2] = {c->f[CALES_P], c->f[CALES_PP]};
-    if (int e = op_boundp_multi(c, 2, pq, 0)) return e;
-    if (int e = op_boundp(c, c->f[CALES_VISCT], 1)) return e;
+    c->bc_nride = 3; c->bc_ride[0] = c->f[CALES_P]; c->bc_ride[1] = c->f[CALES_PP]; c->bc_ride[2] = c->f[CALES_VISCT];
+    c->bc_ride_which[0] = 0; c->bc_ride_which[1] = 0; c->bc_ride_which[2] = 1;
+    if (c->fl.unmerged_bc) c->bc_nride = 0;
+    { const int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 0, 1, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W]);
+      const bool rode = !c->fl.unmerged_bc && c->bc_nride == 0; c->bc_nride = 0;
+      if (e) return e;
+      if (!(CBV(c, 0, 3, 3) == 'P' && CBV(c, 1, 3, 3) == 'P')) { if (int e2 = op_xwrap_zghost(c, 3, c->f + CALES_U)) return e2; }      // (periodic z: the z copies of the launch above cover the corners)
+      if (!rode) {
+        real *pq[2] = {c->f[CALES_P], c->f[CALES_PP]};
+        if (int e2 = op_boundp_multi(c, 2, pq, 0)) return e2;
+        if (int e2 = op_boundp(c, c->f[CALES_VISCT], 1)) return e2;
+      } }
   }
   c->h_red[40] = dt;
   return 0;

@@ -180,6 +180,9 @@ struct cales_ctx {
   bool defer_force = false;      // explicit step, forced directions periodic, no wall model: u += f is applied by the correction kernel
   bool defer_imp_rhs = false; real hf12 = 0.;   // z-implicit step: u -= hf12*dudtd and u += f are applied inside the Helmholtz sweep
   bool defer_halo = false; std::vector<real *> deferred;      // y-halo exchanges collected for halo_flush_deferred (k_bound.hip)
+  // cell-centred fields whose ghost-cell update rides along with the next bounduvw that takes the one-launch path (cales_step: the pressure after the
+  // fused correction + pressure update; p, pp and the eddy viscosity at the end of the step); bounduvw clears the count when it has taken them
+  int bc_nride = 0; real *bc_ride[4] = {nullptr, nullptr, nullptr, nullptr}; int bc_ride_which[4] = {0, 0, 0, 0};
   int bc_skip = 0;         // bit d-1: boundp/bounduvw leave direction d alone (set around calls whose consumers do not need it)
   // cales_step with periodic x: the x ghost columns are not maintained between the operators of a step -- every kernel of the step reads the wrapped
   // interior column instead (a ghost-column update touches two cache lines per row and field for two values: 1.2 of 45 ms per step at 512^3) -- and

@@ -190,6 +190,14 @@ static int halo_self(cales_ctx *c, int nf, real **flds) {
   return 0;
 }
 
+// a cell-centred field with the pressure (which = 0) or the sgs (1) BC set as one entry of the one-launch kernel
+static void merged_pfield(cales_ctx *c, MField &F, real *p, int which) {
+  const char *cbc = which == 0 ? c->C.cbcpre : c->C.cbcsgs; const DBound &bc = which == 0 ? c->bcp : c->bcs;
+  const bool per_z = cbc[4] == 'P' && cbc[5] == 'P';
+  F.p = p; F.centered = 1;
+  F.t0 = per_z ? 'P' : cbc[4]; F.t1 = per_z ? 'P' : cbc[5];
+  F.bc0 = plane(bc, 3, 0, c->n); F.bc1 = plane(bc, 3, 1, c->n); F.dr0 = c->dzc[0]; F.dr1 = c->dzc[c->n[2]];
+}
 // ------------------------------------------------------------------------------------------ boundp (bound.f90:156-200)
 // nf <= 8 fields with the same BC set in one halo exchange and as few launches as the job table allows
 int op_boundp_multi(cales_ctx *c, int nf, real **p, int which) {
@@ -199,11 +207,7 @@ int op_boundp_multi(cales_ctx *c, int nf, real **p, int which) {
     if (c->P > 1) { if (int e = halo_y_comm(c, nf, p)) return e; }
     const bool per_z = cbc[4] == 'P' && cbc[5] == 'P';
     MJobs J; J.nf = nf; J.do_x = !(bc_skipped(c) & 1); J.wrap_y = c->P == 1; J.do_z = per_z || !(bc_skipped(c) & 4);
-    for (int q = 0; q < nf; ++q) {
-      MField &F = J.f[q]; F.p = p[q]; F.centered = 1;
-      F.t0 = per_z ? 'P' : cbc[4]; F.t1 = per_z ? 'P' : cbc[5];
-      F.bc0 = plane(bc, 3, 0, c->n); F.bc1 = plane(bc, 3, 1, c->n); F.dr0 = c->dzc[0]; F.dr1 = c->dzc[c->n[2]];
-    }
+    for (int q = 0; q < nf; ++q) merged_pfield(c, J.f[q], p[q], which);
     return launch_merged(c, J);
   }
   if (int e = halo_self(c, nf, p)) return e;
@@ -381,9 +385,20 @@ int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm
     if (ivel == 3 && (CBV(c, 0, 3, 3) == 'N' || CBV(c, 1, 3, 3) == 'N')) merged = false;      // face-centred Neumann reads the plane it rewrites
   }
   if (merged) {
-    if (c->P > 1) { if (int e = halo_y_comm(c, 3, fl)) return e; }
+    // riders (cales_step): cell-centred fields whose BC sets take the one-launch kernel too join this launch -- and this slab exchange
+    int nr = 0;
+    if (c->bc_nride > 0 && !(bc_skipped(c) & 4)) {
+      bool ok = true;
+      for (int q = 0; q < c->bc_nride; ++q) { const char *cb = c->bc_ride_which[q] == 0 ? c->C.cbcpre : c->C.cbcsgs; ok = ok && merged_ok(c, cb, cb + 2); }
+      if (ok) nr = c->bc_nride;
+    }
+    real *all[8] = {fl[0], fl[1], fl[2]};
+    for (int q = 0; q < nr; ++q) all[3 + q] = c->bc_ride[q];
+    if (c->P > 1) { if (int e = halo_y_comm(c, 3 + nr, all)) return e; }
     const bool per_z = CBV(c, 0, 3, 3) == 'P' && CBV(c, 1, 3, 3) == 'P';
-    MJobs J; J.nf = 3; J.do_x = !(bc_skipped(c) & 1); J.wrap_y = c->P == 1; J.do_z = per_z || !(bc_skipped(c) & 4);
+    MJobs J; J.nf = 3 + nr; J.do_x = !(bc_skipped(c) & 1); J.wrap_y = c->P == 1; J.do_z = per_z || !(bc_skipped(c) & 4);
+    for (int q = 0; q < nr; ++q) merged_pfield(c, J.f[3 + q], c->bc_ride[q], c->bc_ride_which[q]);
+    if (nr) c->bc_nride = 0;      // taken
     for (int ivel = 1; ivel <= 3; ++ivel) {
       MField &F = J.f[ivel - 1]; F.p = fl[ivel - 1];
       const bool normal = ivel == 3;
