@@ -372,17 +372,21 @@ int cales_step(cales_ctx *c, real dt) {
       if (e) return e;
       if (!fuse_cu) { if (int e2 = op_updatep(c, alpha)) return e2; }
       if (!rode) { if (int e2 = op_boundp(c, c->f[CALES_P], 0)) return e2; } }
+    c->visct_bc_done = false;
     if (int e = op_cmpt_sgs(c)) return e;
     // no subgrid model and homogeneous sgs BC values: the eddy viscosity is zero, ghost cells included, since start-up (sgs.f90:62-68)
     bool visct_ghosts = !(c->C.sgstype == 0 && c->visct_zero && !c->sgs_first);
     for (int q = 0; q < 6; ++q) if (c->C.bcsgs[q] != 0.) visct_ghosts = true;
-    if (visct_ghosts) { if (int e = op_boundp(c, c->f[CALES_VISCT], 1)) return e; }
+    if (visct_ghosts && !c->visct_bc_done) { if (int e = op_boundp(c, c->f[CALES_VISCT], 1)) return e; }
+    c->visct_bc_done = false;
   }
   if (c->step_xskip) {      // the ghost cells of everything a caller may look at, all directions (the corners of the x ghost columns with the z ghost planes included)
     c->step_xskip = false;
     c->bc_nride = 3; c->bc_ride[0] = c->f[CALES_P]; c->bc_ride[1] = c->f[CALES_PP]; c->bc_ride[2] = c->f[CALES_VISCT];
     c->bc_ride_which[0] = 0; c->bc_ride_which[1] = 0; c->bc_ride_which[2] = 1;
     if (c->fl.unmerged_bc) c->bc_nride = 0;
+    c->bc_no_halo = true;      // (only the x ghost columns are stale: the rows the neighbours sent are complete but for their two ends, which the local copies fill)
+    struct NoHalo { cales_ctx *c; ~NoHalo() { c->bc_no_halo = false; } } nohalo{c};
     { const int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 0, 1, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W]);
       const bool rode = !c->fl.unmerged_bc && c->bc_nride == 0; c->bc_nride = 0;
       if (e) return e;
@@ -408,7 +412,7 @@ int cales_get_dpdl(cales_ctx *c, real dpdl[3]) {
 #define CALES_RES_TAIL 4096
 int cales_comm_buffer_doubles(const cales_ctx *c, int64_t *n) {
   const int64_t a2a = 2 * (int64_t)c->P * c->n[2] * c->n[1] * c->cw;                 // [peer][k][jl][mm] complex
-  const int64_t halo = 4 * 8 * (int64_t)c->g.s1 * (c->n[2] + 2);                     // lo|hi x up to 8 fields (send in A, recv in B)
+  const int64_t halo = 4 * 12 * (int64_t)c->g.s1 * (c->n[2] + 2);                    // lo|hi x up to 12 fields (send in A, recv in B)
   const int64_t tail = CALES_RES_TAIL + 2 * (int64_t)(c->n[2] + 2);
   *n = std::max(a2a, halo) + tail;
   return 0;

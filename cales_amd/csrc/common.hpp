@@ -179,6 +179,8 @@ struct cales_ctx {
   real fuse_fillps_dti = 0.;   // != 0: the forward x transform of the next pressure solve forms pp = div(u*)/dtrk itself (cales_step)
   bool defer_force = false;      // explicit step, forced directions periodic, no wall model: u += f is applied by the correction kernel
   bool defer_imp_rhs = false; real hf12 = 0.;   // z-implicit step: u -= hf12*dudtd and u += f are applied inside the Helmholtz sweep
+  bool bc_no_halo = false;      // ghost-cell operators skip the slab exchange (the ghost rows are up to date)
+  bool visct_bc_done = false;   // cmpt_sgs has already updated the ghost cells of the eddy-viscosity field (dsmag, lazy form: with the scratch fields' exchange)
   bool defer_halo = false; std::vector<real *> deferred;      // y-halo exchanges collected for halo_flush_deferred (k_bound.hip)
   // cell-centred fields whose ghost-cell update rides along with the next bounduvw that takes the one-launch path (cales_step: the pressure after the
   // fused correction + pressure update; p, pp and the eddy viscosity at the end of the step); bounduvw clears the count when it has taken them
@@ -234,7 +236,7 @@ void   hs_bc_rhs(const char *cbc2, const real *bc, int na, int nb, const real *d
 int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm, int is_correc, real *u, real *v, real *w);
 int op_boundp(cales_ctx *c, real *p, int which);
 int op_boundp_multi(cales_ctx *c, int nf, real **p, int which);
-int halo_flush_deferred(cales_ctx *c);
+int halo_flush_deferred(cales_ctx *c, bool overlapped = true);
 int op_mom(cales_ctx *c);
 int op_rk(cales_ctx *c, int irk, real dt);
 int op_rk_par(cales_ctx *c, real rkpar1, real rkpar2, real dt);

@@ -119,7 +119,7 @@ static bool merged_ok(const cales_ctx *c, const char *cbx, const char *cby) {
 
 // y-slab neighbours (bound.f90:619-696 for idir = 2): pack the first/last interior rows of nf fields into the
 // staging buffer A, let the host exchange them, unpack into the ghost rows. Planes include the x/z ghosts.
-struct HaloFields { int nf; real *p[8]; };
+struct HaloFields { int nf; real *p[12]; };
 // x ghost columns of the two z ghost planes, rows 0..n2+1: the corners the velocity update after the projection leaves alone (bounduvw with
 // is_correc does not touch the z ghost planes of w, and the periodic copies of the step's earlier calls were skipped: cales_step, step_xskip)
 __global__ __launch_bounds__(256) void k_xwrap_zghost(Geom g, HaloFields H) {
@@ -157,6 +157,7 @@ static int halo_y_on(cales_ctx *c, int nf, real **flds, hipStream_t st, bool ove
 }
 static int halo_y_comm(cales_ctx *c, int nf, real **flds) {
   if (!c->comm.on) { c->err = "nranks > 1 but no communication hooks registered (cales_set_comm)"; return 1; }
+  if (c->bc_no_halo) return 0;      // the ghost rows already hold the neighbours' rows (end-of-step refresh of the x ghost columns, cales_step)
   if (c->defer_halo) { for (int q = 0; q < nf; ++q) c->deferred.push_back(flds[q]); return 0; }      // exchanged later, beside kernels (halo_flush_deferred)
   return halo_y_on(c, nf, flds, c->stream, false);
 }
@@ -164,12 +165,13 @@ static int halo_y_comm(cales_ctx *c, int nf, real **flds) {
 // context's stream so far (their ghost-cell kernels included: what those wrote into the ghost rows is overwritten by the rows
 // that arrive, whose own x/z ghost cells the neighbour has already set -- the same values the in-order sequence produces).
 // The caller makes the context's stream wait (stream_after) before the first kernel that reads those ghost rows.
-int halo_flush_deferred(cales_ctx *c) {
+// overlapped = false: the same batching in order on the context's stream -- one exchange for up to twelve fields instead of one per call.
+int halo_flush_deferred(cales_ctx *c, bool overlapped) {
   if (c->deferred.empty()) return 0;
-  if (int e = stream_after(c, c->comm_stream, c->stream)) return e;
-  for (size_t q0 = 0; q0 < c->deferred.size(); q0 += 8) {
-    const int nf = (int)std::min<size_t>(8, c->deferred.size() - q0);
-    if (int e = halo_y_on(c, nf, c->deferred.data() + q0, c->comm_stream, true)) { c->deferred.clear(); return e; }
+  if (overlapped) { if (int e = stream_after(c, c->comm_stream, c->stream)) return e; }
+  for (size_t q0 = 0; q0 < c->deferred.size(); q0 += 12) {
+    const int nf = (int)std::min<size_t>(12, c->deferred.size() - q0);
+    if (int e = halo_y_on(c, nf, c->deferred.data() + q0, overlapped ? c->comm_stream : c->stream, overlapped)) { c->deferred.clear(); return e; }
   }
   c->deferred.clear();
   return 0;

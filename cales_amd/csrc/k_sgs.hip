@@ -1081,7 +1081,10 @@ static int dsmag_fast(cales_ctx *c) {
   //  exchange in flight on the second stream with nobody joining it)
   { dim3 tb, tg; int tk; tiles(c->fl.dsmag_unfused_filter ? TYF : TYL, 62, tb, tg, tk);
     if ((size_t)2 * n[2] * tg.x * tg.y > c->ntot) { c->err = "dsmag: partial-sum scratch too small"; return 1; } }
-  c->defer_halo = overlap;
+  // several ranks: ONE exchange for the y-halo rows of all these fields (six |S|Sij, three filtered velocities, v_c, and |S| itself in the lazy form
+  // inside cales_step) instead of one per ghost-cell call; their ghost-cell kernels run first, the rows that then arrive carry the neighbour's
+  // x/z ghost cells
+  c->defer_halo = c->P > 1;
   c->bc_skip = perx | skipz;
   int e_ = op_boundp_multi(c, 6, ssij, 1);
   c->bc_skip = perx;
@@ -1091,8 +1094,10 @@ static int dsmag_fast(cales_ctx *c) {
   if (!e_ && ucf && !(wylo && wyhi)) {      // v_c of the rows 1 and n2 only: their copies in the ghost rows (periodic wrap or the slab neighbours') are what the last pass reads for row 0
     hipLaunchKernelGGL(k_vc_edge_rows, dim3((n[0] + 2 + 63) / 64, (n[2] + 2 + 3) / 4), dim3(64, 4), 0, c->stream, c->g, f[CALES_V], c->vc);
     real *cc[1] = {c->vc}; e_ = op_boundp_multi(c, 1, cc, 1); }
-  c->bc_skip = 0; c->defer_halo = false;
-  if (!e_ && overlap) e_ = halo_flush_deferred(c);
+  c->bc_skip = 0;
+  if (!e_ && lazy && c->in_step && c->P > 1) { e_ = op_boundp(c, visct, 1); c->visct_bc_done = !e_; }      // |S| is final (K_AC wrote it): its rows travel along
+  c->defer_halo = false;
+  if (!e_ && c->P > 1) e_ = halo_flush_deferred(c, overlap);
   if (e_) { c->deferred.clear(); return e_; }
   LijMijArgs L;
   L.uc[0] = ucf ? f[CALES_U] : c->uc; L.uc[1] = ucf ? f[CALES_V] : c->vc; L.uc[2] = ucf ? f[CALES_W] : c->wc; L.uf[0] = c->uf; L.uf[1] = c->vf; L.uf[2] = c->wf;
