@@ -132,6 +132,21 @@ def test_slab_ranks_smag_tile_and_reference_sequence(name, ng, P, monkeypatch):
     test_slab_ranks_match_single_rank(name, ng, P)
 
 
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("name,ng,P", [("chan_dsmag", (32, 32, 16), 4), ("duct_smag_wm_imp1d", (16, 24, 12), 3), ("tgv_dsmag_ppp", (32, 24, 16), 2)])
+def test_slab_ranks_with_switch_combinations(name, ng, P, seed, monkeypatch):
+    """Several slabs with three to five run-time switches at once (fixed seeds; overlap on for every other one): same bar as the plain slab test."""
+    rng = np.random.RandomState(2000 + seed)
+    pool = ["CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_DSMAG_EAGER", "CALES_GAUSSEL_MARCH",
+            "CALES_GAUSSEL_PAIR", "CALES_DSMAG_XGHOSTS", "CALES_WIDE_OFFSETS", "CALES_DSMAG_UNFUSED_FILTER", "CALES_UNMERGED_BC", "CALES_FFT_STAGED", "CALES_DSMAG_STORE_UC",
+            "CALES_XGHOSTS_IN_STEP", "CALES_BAND_GRID", "CALES_SMAG_TILE", "CALES_FFT_GENERIC", "CALES_HELMHOLTZ_Z_PER_COLUMN", "CALES_UNFUSED_IMP_RHS"]
+    for k in rng.choice(pool, size=rng.randint(3, 6), replace=False):
+        monkeypatch.setenv(str(k), "1")
+    if seed % 2:
+        monkeypatch.setenv("CALES_OVERLAP", "1")
+    test_slab_ranks_match_single_rank(name, ng, P)
+
+
 def test_slab_initflow_equals_global():
     """cales_initflow_slab (host only) == rows of the global initial field, bit for bit."""
     import ctypes as C

@@ -136,6 +136,28 @@ def test_time_steps_with_x_ghosts_kept(name, ng, nsteps, monkeypatch):
     test_time_steps(name, ng, nsteps)
 
 
+_BOOL_SWITCHES = ["CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_KEEP_LAST_RHS",
+                  "CALES_DSMAG_EAGER", "CALES_GAUSSEL_MARCH", "CALES_GAUSSEL_PAIR", "CALES_DSMAG_XGHOSTS", "CALES_WIDE_OFFSETS", "CALES_UNALIGNED",
+                  "CALES_DSMAG_UNFUSED_FILTER", "CALES_UNMERGED_BC", "CALES_FFT_STAGED", "CALES_DSMAG_STORE_UC", "CALES_XGHOSTS_IN_STEP", "CALES_BAND_GRID",
+                  "CALES_PLAIN_GRID", "CALES_SMAG_TILE", "CALES_FFT_GENERIC", "CALES_HELMHOLTZ_Z_PER_COLUMN", "CALES_UNFUSED_IMP_RHS",
+                  "CALES_DSMAG_REFERENCE_SEQUENCE", "CALES_SMAG_REFERENCE_SEQUENCE"]
+
+
+@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("name,ng", [("chan_dsmag", (32, 16, 16)), ("tgv_dsmag_ppp", (32, 16, 16)), ("chan_smag_wm", (32, 16, 12)), ("duct_smag_wm_imp1d", (16, 12, 12)),
+                                     ("chan_smag", (64, 12, 10))])
+def test_time_steps_with_switch_combinations(name, ng, seed, monkeypatch):
+    """The run-time switches select alternative code paths one at a time in the other tests; here three to six of them at once, drawn with a fixed
+    seed (the space of combinations cannot be enumerated: this samples it), against the oracle after two steps."""
+    rng = np.random.RandomState(1000 + seed)
+    chosen = rng.choice(_BOOL_SWITCHES, size=rng.randint(3, 7), replace=False)
+    for k in chosen:
+        monkeypatch.setenv(str(k), "1")
+    if rng.rand() < 0.5:
+        monkeypatch.setenv("CALES_KCHUNK", str(rng.randint(3, 9)))
+    test_time_steps(name, ng, 2)
+
+
 def _two_steps(case, ng, seed=7):
     from cales_amd.hotpath import initflow
     rng = np.random.RandomState(seed)
