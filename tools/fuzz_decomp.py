@@ -15,6 +15,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 20):
     name = names[trial % len(names)]
     P = int(rng.choice([2, 3, 4]))
     ng = (int(2 * rng.randint(4, 40)), int(2 * P * rng.randint(2, 8)), int(2 * rng.randint(5, 40)))
+    if trial % 3 == 2: ng = (int(2 ** rng.randint(4, 8)),) + ng[1:]      # power-of-two rows (see fuzz_sizes.py)
     try:
         case = _case(name, ng)
         if np.any(case.lwm != 0):      # a sampling height the reference accepts on this grid and slab (sanity.f90:224-231)
