@@ -136,6 +136,16 @@ def test_fused_step_matches_operator_sequence(name):
     h.close()
 
 
+@pytest.mark.parametrize("keep_x", [False, True], ids=["wrap", "xghosts"])
+@pytest.mark.parametrize("name", ["chan_dsmag_p2", "chan_smag_p2", "duct_dsmag_p2", "tgv_ppp_p2"])
+def test_fused_step_at_power_of_two_rows(name, keep_x, monkeypatch):
+    """Reference-made end-of-step states at power-of-two row lengths: radix-8 transforms, fillps inside the forward x pass, the x ghost columns left
+    alone until the step returns (and, with CALES_XGHOSTS_IN_STEP, updated by every ghost-cell operator as at the operator level)."""
+    if keep_x:
+        monkeypatch.setenv("CALES_XGHOSTS_IN_STEP", "1")
+    test_fused_step_matches_operator_sequence(name)
+
+
 @pytest.mark.parametrize("name", ["chan_dsmag", "duct_smag_wm_imp1d"])
 def test_wide_offset_kernels(name, monkeypatch):
     """Fields of 4 GB and more (e.g. the 1024^3 cavity) use the size_t instantiations of the tile kernels; force them

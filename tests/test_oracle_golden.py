@@ -214,6 +214,26 @@ def test_solver_operands_and_z_sweep(name):
                 assert np.array_equal(g[f"r{irk}_s1b_{k}"], g[f"r{irk}_s1b_{k}_orc"]), (irk, k)
 
 
+END_CASES = ["chan_dsmag_p2", "chan_smag_p2", "duct_dsmag_p2", "tgv_ppp_p2"]
+
+
+@pytest.mark.parametrize("name", END_CASES)
+def test_step_at_power_of_two_rows(name):
+    """End-of-step state made by the reference's modules at power-of-two row lengths (gen_golden.py END_ONLY): the oracle's whole step against it."""
+    g, case = load_golden(name)
+    o = Oracle(case, nthreads=4)
+    u, v, w, p = (F(g["s0raw_" + k]) for k in "uvwp")
+    visct, pp = o.zeros(), o.zeros()
+    o.bounduvw(u, v, w, True, False); o.boundp(p, 0); o.cmpt_sgs(u, v, w, visct); o.boundp(visct, 1)
+    assert abs(o.chkdt(visct, u, v, w) / float(g["dt_cfl"]) - 1) < 1e-12
+    dpdl = o.step(float(g["dt"]), u, v, w, p, pp, visct)
+    for a, k in zip((u, v, w), "uvw"):
+        assert relerr(a, g["r3_s7_" + k]) < 1e-12, k
+    assert relerr(p, g["r3_s8_p"]) < 1e-11
+    assert relerr(visct, g["r3_s9_visct"]) < 1e-10
+    assert np.abs(dpdl - g["dpdl"]).max() < 1e-10 * max(1., np.abs(g["dpdl"]).max())
+
+
 def test_manifest_lists_every_golden_file():
     """tests/golden/manifest.json (written by gen_golden.py) names every case and carries the digest of every vector file as committed."""
     import hashlib, json, os
