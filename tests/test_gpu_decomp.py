@@ -122,6 +122,18 @@ def test_slab_ranks_in_order_exchanges(name, ng, P, monkeypatch):
     test_slab_ranks_match_single_rank(name, ng, P)
 
 
+@pytest.mark.parametrize("events", [0, 1])
+@pytest.mark.parametrize("name,ng,P", [("chan_dsmag", (64, 32, 24), 4), ("duct_dsmag_wm", (32, 32, 32), 2), ("tgv_dsmag_ppp", (32, 24, 16), 3)])
+def test_slab_ranks_batched_scratch_field_exchange(name, ng, P, events, monkeypatch):
+    """The dynamic model's ghost-cell calls queue their rows and one exchange follows (in order): eleven fields when the last pass forms the cell-centred
+    velocity itself, thirteen = two exchanges (twelve + one) when K_AC stores it (CALES_DSMAG_STORE_UC); plain and event-ordered emulation."""
+    if events:
+        monkeypatch.setenv("CALES_LOOPBACK_EVENTS", "1")
+    test_slab_ranks_match_single_rank(name, ng, P)
+    monkeypatch.setenv("CALES_DSMAG_STORE_UC", "1")
+    test_slab_ranks_match_single_rank(name, ng, P)
+
+
 @pytest.mark.parametrize("name,ng,P", [("duct_smag_wm", (16, 32, 24), 4), ("duct_smag_wm_imp1d", (64, 32, 16), 8)])
 def test_slab_ranks_smag_tile_and_reference_sequence(name, ng, P, monkeypatch):
     """The two other forms of the static-Smagorinsky pass on more than two slabs between y walls: the LDS tile kernel and the kernel-per-loop sequence."""
