@@ -881,7 +881,7 @@ struct TileMap { int blocked, cw, n2l, mofs, nmode; size_t kstride, segstride;
 //  but the sixteen global addresses and sixteen LDS places of the load phase, kept alive for the store phase -- as many bytes of scratch traffic as the
 //  tile itself (FETCH_SIZE / WRITE_SIZE 16 + 17 GB for 8.6 + 8.6 compulsory); formed again behind an opaque offset: 2 spilled registers, 7.7 -> 6.2 ms.
 //  Tried and dropped: half as many waves solving the tile in two rounds under the 256-register cap (8.2 ms); tiles of eight columns, two blocks per
-//  CU, the two half-line tiles of a line on the same XCD (8.6 ms); two waves per column with 8 planes per lane and a 2 x 2 interface system between
+//  CU, the two half-line tiles of a line on the same XCD (8.6 ms with the spills, 6.4 ms without them against 6.2 for the full-line tile); two waves per column with 8 planes per lane and a 2 x 2 interface system between
 //  their two cyclic reductions (no spills, 8.2 ms: twice the reductions, six more barriers per tile).)
 constexpr int gt_width(int, int) { return 16; }      // columns per tile: one 128-B line per plane
 #ifndef GT_TL
