@@ -237,6 +237,35 @@ def test_triperiodic_default_pins_the_null_mode(ng):
     assert o.chkdiv(gu, gv, gw)[1] <= 2. * o.chkdiv(u, v, w)[1] + 1e-14
 
 
+@pytest.mark.parametrize("ng", [(74, 52, 26), (20, 58, 12), (76, 46, 19), (46, 74, 15)])
+@pytest.mark.parametrize("keep", [0, 1], ids=["pinned", "reference_null_mode"])
+def test_triperiodic_within_the_reference_algorithms_own_sensitivity(ng, keep, monkeypatch):
+    """Sizes the size fuzzer flagged at 1e-8..3e-8 (n3 not a power of two). The yardstick is the reference algorithm itself: how far ITS two-step
+    result moves when the initial field moves by one unit in the last place (tests/util.py one_ulp_sensitivity; 2e-8 at 74x52x26, 1e-15 for
+    well-posed boxes, tests/test_oracle_solver.py). The device -- default member p(n3) = 0 and CALES_KEEP_NULL_MODE alike -- stays within a small
+    multiple of it, and its divergence after projection is not worse than the oracle's."""
+    from tests.util import one_ulp_sensitivity
+    if keep:
+        monkeypatch.setenv("CALES_KEEP_NULL_MODE", "1")
+    g, case = load_golden("tgv_ppp"); case.ng[:] = ng
+    sens, (u, v, w, p, dt) = one_ulp_sensitivity(case, 2, seed=3)
+    from cales_amd.hotpath import initflow
+    h = _hot(case)
+    u0, v0, w0, p0 = initflow(case)
+    rng = np.random.RandomState(3)
+    for a in (u0, v0, w0):
+        a[1:-1, 1:-1, 1:-1] += 0.02 * (rng.rand(*ng) - 0.5)
+    h.upload(u0, v0, w0, p0); h.startup()
+    for _ in range(2):
+        h.step(dt)
+    gu, gv, gw, gp, gvis = h.download()
+    err = max(relerr(a, b) for a, b in ((gu, u), (gv, v), (gw, w)))
+    assert sens > 1e-11 and err < 4. * sens + 1e-12, (err, sens)
+    o = Oracle(case, nthreads=4)
+    assert h.chkdiv()[1] <= 2. * o.chkdiv(u, v, w)[1] + 1e-14
+    h.close()
+
+
 def test_projection_properties_at_size():
     """256x128x128 wall-modelled channel (BASELINE.json configs[1]): 3 steps, divergence ~ round-off, bulk velocity held."""
     import bench

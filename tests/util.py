@@ -73,3 +73,38 @@ def perturbed_tgv_rhs(o, case, seed=7):
     dt = 0.5 * o.chkdt(visct, u, v, w)
     o.fillps(1. / dt, u, v, w, pp)
     return pp, u, v, w, p, dt
+
+
+def oracle_steps(case, nsteps, seed, ulp_seed=None, nthreads=8):
+    """`nsteps` steps of the oracle from the perturbed initial field of the fuzzers / test_time_steps (2 % noise, RandomState(seed)); with `ulp_seed` every
+    initial velocity value is moved by ONE unit in the last place, random sign. Returns (u, v, w, p, dt)."""
+    from cales_amd.hotpath import initflow
+    from oracle.oracle import Oracle
+    ng = tuple(int(x) for x in case.ng)
+    o = Oracle(case, nthreads=nthreads)
+    rng = np.random.RandomState(seed)
+    u, v, w, p = initflow(case)
+    for a in (u, v, w):
+        a[1:-1, 1:-1, 1:-1] += 0.02 * (rng.rand(*ng) - 0.5)
+    if ulp_seed is not None:
+        r2 = np.random.RandomState(ulp_seed)
+        for a in (u, v, w):
+            a *= 1. + np.finfo(float).eps * (r2.randint(0, 2, size=a.shape) * 2 - 1)
+    visct, pp = o.zeros(), o.zeros()
+    o.bounduvw(u, v, w, True, False); o.boundp(p, 0); o.cmpt_sgs(u, v, w, visct); o.boundp(visct, 1)
+    dt = 0.5 * o.chkdt(visct, u, v, w)
+    for _ in range(nsteps):
+        o.step(dt, u, v, w, p, pp, visct)
+    o.close()
+    return u, v, w, p, dt
+
+
+def one_ulp_sensitivity(case, nsteps, seed, trials=2):
+    """How far the reference algorithm's own result (the oracle's) moves when every initial velocity value moves by one unit in the last place:
+    the largest relative change of u, v, w over `trials` random sign patterns. ~1e-15 for well-posed cases."""
+    base = oracle_steps(case, nsteps, seed)
+    worst = 0.
+    for t in range(trials):
+        pert = oracle_steps(case, nsteps, seed, ulp_seed=100 + t)
+        worst = max(worst, max(relerr(pert[i], base[i]) for i in range(3)))
+    return worst, base

@@ -38,6 +38,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
     o = Oracle(case, nthreads=8)
     u, v, w, p = initflow(case)
     for a in (u, v, w): a[1:-1, 1:-1, 1:-1] += 0.02 * (rng.rand(*ng) - 0.5)
+    init0 = tuple(a.copy(order="F") for a in (u, v, w, p))
     h.upload(u, v, w, p); h.startup()
     visct, pp = o.zeros(), o.zeros()
     o.bounduvw(u, v, w, True, False); o.boundp(p, 0); o.cmpt_sgs(u, v, w, visct); o.boundp(visct, 1)
@@ -47,9 +48,23 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
     gu, gv, gw, gp, gvis = h.download()
     errs = [relerr(a, b) for a, b in ((gu, u), (gv, v), (gw, w))] + [relerr(gvis, visct)]
     both_blew_up = not np.isfinite(u).all() and not np.isfinite(gu).all()      # unstable case: the reference blows up the same way
-    # triply periodic boxes with n3 not a power of two: the reference's own answer is defined to 1e-8 only (tests/test_oracle_solver.py)
+    # triply periodic boxes with n3 not a power of two: the yardstick is how far the reference algorithm's OWN result moves when the initial field moves
+    # by one unit in the last place (tests/test_oracle_solver.py: 1e-10..1e-7 there, 1e-15 for well-posed boxes)
     illposed = name.startswith("tgv") and (ng[2] & (ng[2] - 1)) != 0
-    ok = both_blew_up or (max(errs[:3]) < (1e-8 if illposed else 1e-9) and errs[3] < 1e-6)
+    bound = 1e-9
+    if illposed and max(errs[:3]) >= 1e-9:
+        sens = 0.
+        for t in range(2):
+            r2 = np.random.RandomState(100 + t)
+            o2 = Oracle(case, nthreads=8)
+            u2, v2, w2, p2 = (a.copy(order="F") for a in init0)
+            for a in (u2, v2, w2): a *= 1. + np.finfo(float).eps * (r2.randint(0, 2, size=a.shape) * 2 - 1)
+            vis2, pp2 = o2.zeros(), o2.zeros()
+            o2.bounduvw(u2, v2, w2, True, False); o2.boundp(p2, 0); o2.cmpt_sgs(u2, v2, w2, vis2); o2.boundp(vis2, 1)
+            for _ in range(2): o2.step(dt, u2, v2, w2, p2, pp2, vis2)
+            sens = max(sens, max(relerr(a, b) for a, b in ((u2, u), (v2, v), (w2, w))))
+        bound = max(bound, 4. * sens)
+    ok = both_blew_up or (max(errs[:3]) < bound and errs[3] < 1e-6)
     bad += not ok
     print("OK " if ok else "BAD", name, ng, " ".join("%.1e" % e for e in errs), "div %.1e / oracle %.1e" % (h.chkdiv()[1], o.chkdiv(u, v, w)[1]), flush=True)
     h.close()
