@@ -237,13 +237,14 @@ def test_triperiodic_default_pins_the_null_mode(ng):
     assert o.chkdiv(gu, gv, gw)[1] <= 2. * o.chkdiv(u, v, w)[1] + 1e-14
 
 
-@pytest.mark.parametrize("ng", [(74, 52, 26), (20, 58, 12), (76, 46, 19), (46, 74, 15)])
+@pytest.mark.parametrize("ng", [(74, 52, 26), (20, 58, 12), (76, 46, 19), (46, 74, 15), (16, 32, 48)])
 @pytest.mark.parametrize("keep", [0, 1], ids=["pinned", "reference_null_mode"])
 def test_triperiodic_within_the_reference_algorithms_own_sensitivity(ng, keep, monkeypatch):
     """Sizes the size fuzzer flagged at 1e-8..3e-8 (n3 not a power of two). The yardstick is the reference algorithm itself: how far ITS two-step
     result moves when the initial field moves by one unit in the last place (tests/util.py one_ulp_sensitivity; 2e-8 at 74x52x26, 1e-15 for
-    well-posed boxes, tests/test_oracle_solver.py). The device -- default member p(n3) = 0 and CALES_KEEP_NULL_MODE alike -- stays within a small
-    multiple of it, and its divergence after projection is not worse than the oracle's."""
+    well-posed boxes, tests/test_oracle_solver.py) plus the digits its round-off-defined pressure constant costs (tests/util.py triperiodic_bounds).
+    The device -- default member p(n3) = 0 and CALES_KEEP_NULL_MODE alike -- stays within that, and its divergence after projection is not worse
+    than the oracle's."""
     from tests.util import one_ulp_sensitivity
     if keep:
         monkeypatch.setenv("CALES_KEEP_NULL_MODE", "1")
@@ -259,8 +260,13 @@ def test_triperiodic_within_the_reference_algorithms_own_sensitivity(ng, keep, m
     for _ in range(2):
         h.step(dt)
     gu, gv, gw, gp, gvis = h.download()
-    err = max(relerr(a, b) for a, b in ((gu, u), (gv, v), (gw, w)))
-    assert sens > 1e-11 and err < 4. * sens + 1e-12, (err, sens)
+    # (16x32x48: the algorithm is insensitive to the last place of its input there, 1e-15, but its constant is 4e5 -- the second term of the bound:
+    #  the digits such a constant costs, relative to the 0.01 of the w component of this flow)
+    from tests.util import triperiodic_bounds
+    bounds = triperiodic_bounds(case, (u, v, w), p, dt, 2, sens)
+    for a, b, bd, nm in ((gu, u, bounds[0], "u"), (gv, v, bounds[1], "v"), (gw, w, bounds[2], "w")):
+        assert relerr(a, b) < bd, (nm, relerr(a, b), bd, sens)
+    assert max(bounds) < 1e-5
     o = Oracle(case, nthreads=4)
     assert h.chkdiv()[1] <= 2. * o.chkdiv(u, v, w)[1] + 1e-14
     h.close()

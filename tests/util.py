@@ -108,3 +108,16 @@ def one_ulp_sensitivity(case, nsteps, seed, trials=2):
         pert = oracle_steps(case, nsteps, seed, ulp_seed=100 + t)
         worst = max(worst, max(relerr(pert[i], base[i]) for i in range(3)))
     return worst, base
+
+
+def triperiodic_bounds(case, fields, p, dt, nsteps, sens):
+    """Per-field bounds (relative to each field's own maximum, as relerr measures) for time steps of a triply periodic box whose pressure the reference
+    algorithm returns as C + p' with a round-off-defined constant C (solver.f90:160-178 on a grid whose dzf is not exactly uniform): (1) four times the
+    algorithm's own response to one unit in the last place (`sens`, one_ulp_sensitivity); (2) the digits C costs: p' is carried with an absolute error of
+    eps |C| that depends on the summation order of the transforms (two CPU evaluations of the same algorithm differ by 2-200 eps |C| per solve,
+    tests/test_oracle_solver.py; 100 here), and every one of the 3 nsteps projections moves the velocity by dt grad p'. |C| is taken from the mean of the
+    accumulated pressure."""
+    eps = np.finfo(float).eps
+    C = abs(float(np.asarray(p)[1:-1, 1:-1, 1:-1].mean()))
+    dxi = max(float(case.ng[d]) / float(case.l[d]) for d in range(3))
+    return [1e-9 + 4. * sens + 100. * eps * C * dt * dxi * 3 * nsteps / max(float(np.abs(f).max()), 1e-300) for f in fields]
