@@ -114,6 +114,7 @@ void cales_destroy(cales_ctx *c) {
   field_free(c, c->scr1); field_free(c, c->scr2); hipFree(c->d_red); hipFree(c->d_force); if (c->d_mpart) hipFree(c->d_mpart); if (c->d_abct) hipFree(c->d_abct); if (c->d_cs) hipFree(c->d_cs); if (c->d_nullw) hipFree(c->d_nullw); if (c->d_stat) hipFree(c->d_stat); if (c->d_stat2) hipFree(c->d_stat2); hipHostFree(c->h_red);
   field_free(c, c->s0); field_free(c, c->uc); field_free(c, c->vc); field_free(c, c->wc); field_free(c, c->uf); field_free(c, c->vf); field_free(c, c->wf); field_free(c, c->alph2); if (!c->p1d_in_comm) hipFree(c->d_p1d);
   for (int m = 0; m < 6; ++m) { field_free(c, c->wk[m]); field_free(c, c->sij[m]); field_free(c, c->mij[m]); }
+  for (int m = 0; m < 3; ++m) if (c->ss2[m]) hipFree(c->ss2[m] - 2 * c->field_ofs);
   cales_comm_release_native(c);
   hipFree(c->d_del);
   if (c->own_stream) hipStreamDestroy(c->stream);
@@ -214,6 +215,9 @@ int cales_create(const cales_case *cs, void *stream, cales_ctx **out) {
     if (field_alloc(c, &c->uc) || field_alloc(c, &c->vc) || field_alloc(c, &c->wc) || field_alloc(c, &c->uf) ||
         field_alloc(c, &c->vf) || field_alloc(c, &c->wf) || field_alloc(c, &c->alph2) || dev_alloc(c, &c->d_p1d, 2 * (size_t)n3 + 2))
       return fail(13);
+    if (dsmag_pairs(c)) {      // |S|Sij as three fields of pairs between K_AC and the fused last pass: the twelve scalar scratch fields of the other forms are not needed
+      for (int m = 0; m < 3; ++m) { real *b = nullptr; if (dev_alloc(c, &b, 2 * c->ntot + 2 * LINE_REALS)) return fail(13); c->ss2[m] = b + 2 * c->field_ofs; }
+    } else
     for (int m = 0; m < 6; ++m) if (field_alloc(c, &c->sij[m]) || field_alloc(c, &c->mij[m])) return fail(13);
   }
   if (solver_setup(c)) return fail(14);

@@ -68,7 +68,7 @@ struct Spec {
 
 // Run-time switches: read from the environment ONCE, by cales_create; the launch path only looks at these fields.
 struct Flags {
-  bool unaligned = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_eager = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, gaussel_pair = false, unfused_rk = false, dsmag_unfused_filter = false, overlap = false, fft_staged = false, dsmag_store_uc = false, xghosts_in_step = false, unmerged_bc = false, smag_tile = false, plain_grid = false, band_grid = false;
+  bool unaligned = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_eager = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, gaussel_pair = false, unfused_rk = false, dsmag_unfused_filter = false, overlap = false, fft_staged = false, dsmag_store_uc = false, dsmag_unpaired = false, xghosts_in_step = false, unmerged_bc = false, smag_tile = false, plain_grid = false, band_grid = false;
   int kchunk = 0; long tile_min_blocks = 2048; int smag_ty = 10;
   void read_env() {
     unaligned = getenv("CALES_UNALIGNED") != nullptr;
@@ -90,6 +90,7 @@ struct Flags {
     band_grid = getenv("CALES_BAND_GRID") != nullptr;
     gaussel_march = getenv("CALES_GAUSSEL_MARCH") != nullptr;
     fft_generic = getenv("CALES_FFT_GENERIC") != nullptr;
+    dsmag_unpaired = getenv("CALES_DSMAG_UNPAIRED") != nullptr;      // dynamic model: |S|Sij as six fields instead of three fields of pairs
     xghosts_in_step = getenv("CALES_XGHOSTS_IN_STEP") != nullptr;      // keep the x ghost columns up to date after every operator of cales_step
     fft_staged = getenv("CALES_FFT_STAGED") != nullptr;      // the radix-8 kernels with staging copies through LDS (k_fft_y8) instead of the register-ended ones
     keep_null_mode = getenv("CALES_KEEP_NULL_MODE") != nullptr;
@@ -147,6 +148,7 @@ struct cales_ctx {
   real *d_force;                    // f(3) + dpdl(3) accumulators on device
   int red_blocks;
   // sgs scratch
+  real *ss2[3] = {nullptr, nullptr, nullptr};      // |S|Sij as three pair fields (2 ntot reals each; dsmag_pairs, k_sgs.hip) instead of sij / mij
   real *s0, *wk[6], *sij[6], *mij[6], *uc, *vc, *wc, *uf, *vf, *wf, *alph2, *d_p1d;
   real is_wall[6];
   bool sgs_first;
@@ -181,7 +183,7 @@ struct cales_ctx {
   bool defer_imp_rhs = false; real hf12 = 0.;   // z-implicit step: u -= hf12*dudtd and u += f are applied inside the Helmholtz sweep
   bool bc_no_halo = false;      // ghost-cell operators skip the slab exchange (the ghost rows are up to date)
   bool visct_bc_done = false;   // cmpt_sgs has already updated the ghost cells of the eddy-viscosity field (dsmag, lazy form: with the scratch fields' exchange)
-  bool defer_halo = false; std::vector<real *> deferred;      // y-halo exchanges collected for halo_flush_deferred (k_bound.hip)
+  bool defer_halo = false; std::vector<real *> deferred; std::vector<unsigned char> deferred_wide;      // (wide: the field is a pair field, rows twice as long)      // y-halo exchanges collected for halo_flush_deferred (k_bound.hip)
   // cell-centred fields whose ghost-cell update rides along with the next bounduvw that takes the one-launch path (cales_step: the pressure after the
   // fused correction + pressure update; p, pp and the eddy viscosity at the end of the step); bounduvw clears the count when it has taken them
   int bc_nride = 0; real *bc_ride[4] = {nullptr, nullptr, nullptr, nullptr}; int bc_ride_which[4] = {0, 0, 0, 0};
@@ -261,6 +263,8 @@ int op_force_from_partials(cales_ctx *c, int mask, const real *part, int nblk);
 int op_correc_updatep(cales_ctx *c, real dtrk, real alpha, int upd);
 int op_updatep(cales_ctx *c, real alpha);
 int op_cmpt_sgs(cales_ctx *c);
+bool dsmag_pairs(const cales_ctx *c);
+int op_boundp_wide(cales_ctx *c, int nf, real **p2, int which);      // ghost cells of pair fields (y, z; x periodic and wrapped by the consumers)
 int op_xwrap_zghost(cales_ctx *c, int nf, real **f);      // periodic copy of the x ghost columns on the planes k = 0 and n3+1
 bool sgs_wraps_x(const cales_ctx *c);      // the SGS pass of this case reads wrapped interior columns instead of x ghost columns
 int op_chkdt(cales_ctx *c, real *dtmax);

@@ -100,12 +100,13 @@ __global__ __launch_bounds__(256) void k_bc_merged(Geom g, MJobs J) {
     p[g.ix(i, 0, k)] = p[g.ix(i, n2, k)]; p[g.ix(i, n2 + 1, k)] = p[g.ix(i, 1, k)];
   }
 }
-static int launch_merged(cales_ctx *c, MJobs &J) {
+static int launch_merged(cales_ctx *c, MJobs &J, const Geom *gg = nullptr) {
   if (!J.nf) return 0;
-  const int *n = c->n;
+  const Geom &G = gg ? *gg : c->g;
+  const int n[3] = {G.n1, G.n2, G.n3};
   // one grid for the three regions: region 0 needs (n1+2) x (n2+2), region 1 (n2+2) x n3, region 2 n1 x n3 threads
   const int ex = std::max(n[0] + 2, n[1] + 2), ey = std::max(n[1] + 2, n[2]);
-  hipLaunchKernelGGL(k_bc_merged, dim3((ex + 63) / 64, (ey + 3) / 4, 3 * J.nf), dim3(64, 4, 1), 0, c->stream, c->g, J);
+  hipLaunchKernelGGL(k_bc_merged, dim3((ex + 63) / 64, (ey + 3) / 4, 3 * J.nf), dim3(64, 4, 1), 0, c->stream, G, J);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -119,7 +120,7 @@ static bool merged_ok(const cales_ctx *c, const char *cbx, const char *cby) {
 
 // y-slab neighbours (bound.f90:619-696 for idir = 2): pack the first/last interior rows of nf fields into the
 // staging buffer A, let the host exchange them, unpack into the ghost rows. Planes include the x/z ghosts.
-struct HaloFields { int nf; real *p[12]; };
+struct HaloFields { int nf; real *p[12]; unsigned char wide[12]; int off[12]; };      // wide: a pair field (rows twice as long); off: first staging plane of the field, in planes of s1 (n3+2) values
 // x ghost columns of the two z ghost planes, rows 0..n2+1: the corners the velocity update after the projection leaves alone (bounduvw with
 // is_correc does not touch the z ghost planes of w, and the periodic copies of the step's earlier calls were skipped: cales_step, step_xskip)
 __global__ __launch_bounds__(256) void k_xwrap_zghost(Geom g, HaloFields H) {
@@ -129,37 +130,46 @@ __global__ __launch_bounds__(256) void k_xwrap_zghost(Geom g, HaloFields H) {
   p[g.ix(0, j, k)] = p[g.ix(g.n1, j, k)]; p[g.ix(g.n1 + 1, j, k)] = p[g.ix(1, j, k)];
 }
 __global__ __launch_bounds__(256) void k_pack_y(Geom g, HaloFields H, real *__restrict__ lo, real *__restrict__ hi) {
-  const int i = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y * 4 + threadIdx.y, f = blockIdx.z;
-  if (i > g.n1 + 1 || k > g.n3 + 1) return;
-  const size_t q = (size_t)i + (size_t)g.s1 * ((size_t)k + (size_t)(g.n3 + 2) * f);
-  lo[q] = H.p[f][g.ix(i, 1, k)]; hi[q] = H.p[f][g.ix(i, g.n2, k)];
+  const int i = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y * 4 + threadIdx.y, f = blockIdx.z, w = H.wide[f];
+  if (i >= (g.n1 + 2) << w || k > g.n3 + 1) return;
+  const size_t s1 = (size_t)g.s1 << w, s12 = (size_t)g.s12 << w;
+  const size_t q = (size_t)i + s1 * k + (size_t)g.s1 * (g.n3 + 2) * H.off[f];
+  lo[q] = H.p[f][i + s1 * 1 + s12 * k]; hi[q] = H.p[f][i + s1 * g.n2 + s12 * k];
 }
 __global__ __launch_bounds__(256) void k_unpack_y(Geom g, HaloFields H, const real *__restrict__ lo, const real *__restrict__ hi, int has_lo, int has_hi) {
-  const int i = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y * 4 + threadIdx.y, f = blockIdx.z;
-  if (i > g.n1 + 1 || k > g.n3 + 1) return;
-  const size_t q = (size_t)i + (size_t)g.s1 * ((size_t)k + (size_t)(g.n3 + 2) * f);
-  if (has_lo) H.p[f][g.ix(i, 0, k)] = lo[q];
-  if (has_hi) H.p[f][g.ix(i, g.n2 + 1, k)] = hi[q];
+  const int i = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y * 4 + threadIdx.y, f = blockIdx.z, w = H.wide[f];
+  if (i >= (g.n1 + 2) << w || k > g.n3 + 1) return;
+  const size_t s1 = (size_t)g.s1 << w, s12 = (size_t)g.s12 << w;
+  const size_t q = (size_t)i + s1 * k + (size_t)g.s1 * (g.n3 + 2) * H.off[f];
+  if (has_lo) H.p[f][i + s12 * k] = lo[q];
+  if (has_hi) H.p[f][i + s1 * (g.n2 + 1) + s12 * k] = hi[q];
 }
-static int halo_y_on(cales_ctx *c, int nf, real **flds, hipStream_t st, bool overlapped) {
-  const int64_t plane = (int64_t)c->g.s1 * (c->n[2] + 2), cnt = plane * nf;
+// A field of PAIRS (two values per cell, k_sgs.hip dsmag_pairs) is, for every operation that copies whole rows or planes, a field of twice the width:
+// 2 (n1 + 2) values per row, pitches doubled. Its x ghost "columns" mean nothing in that view -- the callers skip direction x.
+static Geom wide_geom(const cales_ctx *c) { Geom g = c->g; g.n1 = 2 * c->g.n1 + 2; g.s1 = 2 * c->g.s1; g.s12 = 2 * c->g.s12; return g; }
+// (wide[q] != 0: field q is a pair field; nullptr: none is)
+static int halo_y_on(cales_ctx *c, int nf, real **flds, hipStream_t st, bool overlapped, const unsigned char *wide = nullptr) {
+  const Geom &G = c->g;
+  HaloFields H; H.nf = nf; int planes = 0, anyw = 0;
+  for (int q = 0; q < nf; ++q) { H.p[q] = flds[q]; H.wide[q] = wide ? wide[q] : 0; H.off[q] = planes; planes += 1 + H.wide[q]; anyw |= H.wide[q]; }
+  const int64_t cnt = (int64_t)G.s1 * (c->n[2] + 2) * planes;
   if (4 * cnt > c->comm.nbuf) { c->err = "halo staging buffer too small"; return 1; }
-  HaloFields H; H.nf = nf; for (int q = 0; q < nf; ++q) H.p[q] = flds[q];
-  dim3 b(64, 4, 1), gr((c->g.s1 + 63) / 64, (c->n[2] + 2 + 3) / 4, nf);
-  hipLaunchKernelGGL(k_pack_y, gr, b, 0, st, c->g, H, c->comm.A, c->comm.A + cnt);
+  dim3 b(64, 4, 1), gr(((G.s1 << anyw) + 63) / 64, (c->n[2] + 2 + 3) / 4, nf);
+  hipLaunchKernelGGL(k_pack_y, gr, b, 0, st, G, H, c->comm.A, c->comm.A + cnt);
   { ProfScope ps(c, "halo_exchange", st);
     const int rc = overlapped ? c->comm.halo_s(c->comm.user, 0, cnt, 0, cnt, cnt, (void *)st) : c->comm.halo(c->comm.user, 0, cnt, 0, cnt, cnt);
     if (rc) { c->err = "halo callback failed"; return 1; } }
   const int has_lo = (c->per_y || c->rank > 0) ? 1 : 0, has_hi = (c->per_y || c->rank < c->P - 1) ? 1 : 0;
-  hipLaunchKernelGGL(k_unpack_y, gr, b, 0, st, c->g, H, c->comm.B, c->comm.B + cnt, has_lo, has_hi);
+  hipLaunchKernelGGL(k_unpack_y, gr, b, 0, st, G, H, c->comm.B, c->comm.B + cnt, has_lo, has_hi);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
-static int halo_y_comm(cales_ctx *c, int nf, real **flds) {
+static int halo_y_comm(cales_ctx *c, int nf, real **flds, bool wide = false) {
   if (!c->comm.on) { c->err = "nranks > 1 but no communication hooks registered (cales_set_comm)"; return 1; }
   if (c->bc_no_halo) return 0;      // the ghost rows already hold the neighbours' rows (end-of-step refresh of the x ghost columns, cales_step)
-  if (c->defer_halo) { for (int q = 0; q < nf; ++q) c->deferred.push_back(flds[q]); return 0; }      // exchanged later, beside kernels (halo_flush_deferred)
-  return halo_y_on(c, nf, flds, c->stream, false);
+  if (c->defer_halo) { for (int q = 0; q < nf; ++q) { c->deferred.push_back(flds[q]); c->deferred_wide.push_back(wide ? 1 : 0); } return 0; }      // exchanged later (halo_flush_deferred)
+  unsigned char w[12]; for (int q = 0; q < nf && q < 12; ++q) w[q] = wide ? 1 : 0;
+  return halo_y_on(c, nf, flds, c->stream, false, w);
 }
 // The y-halo rows of the fields collected while c->defer_halo was set travel on the second stream, after everything queued on the
 // context's stream so far (their ghost-cell kernels included: what those wrote into the ghost rows is overwritten by the rows
@@ -169,10 +179,13 @@ static int halo_y_comm(cales_ctx *c, int nf, real **flds) {
 int halo_flush_deferred(cales_ctx *c, bool overlapped) {
   if (c->deferred.empty()) return 0;
   if (overlapped) { if (int e = stream_after(c, c->comm_stream, c->stream)) return e; }
-  for (size_t q0 = 0; q0 < c->deferred.size(); q0 += 12) {
-    const int nf = (int)std::min<size_t>(12, c->deferred.size() - q0);
-    if (int e = halo_y_on(c, nf, c->deferred.data() + q0, overlapped ? c->comm_stream : c->stream, overlapped)) { c->deferred.clear(); return e; }
+  for (size_t q0 = 0; q0 < c->deferred.size();) {      // as many fields per exchange as the staging buffers hold: twelve planes, a pair field takes two
+    int nf = 0, planes = 0;
+    while (q0 + nf < c->deferred.size() && nf < 12 && planes + 1 + c->deferred_wide[q0 + nf] <= 12) { planes += 1 + c->deferred_wide[q0 + nf]; ++nf; }
+    if (int e = halo_y_on(c, nf, c->deferred.data() + q0, overlapped ? c->comm_stream : c->stream, overlapped, c->deferred_wide.data() + q0)) { c->deferred.clear(); c->deferred_wide.clear(); return e; }
+    q0 += nf;
   }
+  c->deferred_wide.clear();
   c->deferred.clear();
   return 0;
 }
@@ -201,6 +214,25 @@ static void merged_pfield(cales_ctx *c, MField &F, real *p, int which) {
   F.bc0 = plane(bc, 3, 0, c->n); F.bc1 = plane(bc, 3, 1, c->n); F.dr0 = c->dzc[0]; F.dr1 = c->dzc[c->n[2]];
 }
 // ------------------------------------------------------------------------------------------ boundp (bound.f90:156-200)
+// pair fields (x and y periodic only: dsmag_pairs): the y rows (wrapped on one rank, exchanged between slabs) and the z ghost planes through the
+// one-launch kernel in the doubled-width view; direction x is the consumers' business (they wrap around)
+int op_boundp_wide(cales_ctx *c, int nf, real **p2, int which) {
+  ProfScope ps(c, "boundp");
+  const char *cbc = which == 0 ? c->C.cbcpre : c->C.cbcsgs;
+  if (!merged_ok(c, cbc, cbc + 2) || nf > 8 || !(bc_skipped(c) & 1)) { c->err = "pair fields need periodic x and y and a caller that skips direction x"; return 1; }
+  if (c->P > 1) { if (int e = halo_y_comm(c, nf, p2, true)) return e; }
+  const bool per_z = cbc[4] == 'P' && cbc[5] == 'P';
+  const Geom G = wide_geom(c);
+  MJobs J; J.nf = nf; J.do_x = 0; J.wrap_y = c->P == 1; J.do_z = per_z || !(bc_skipped(c) & 4);
+  if (!J.wrap_y && !J.do_z) return 0;
+  for (int q = 0; q < nf; ++q) {
+    merged_pfield(c, J.f[q], p2[q], which);
+    if (!per_z) { J.f[q].t0 = 0; J.f[q].t1 = 0; }      // (pointwise z conditions would need the BC planes in the doubled view: the callers skip z at walls)
+  }
+  if (!per_z) J.do_z = 0;
+  if (!J.wrap_y && !J.do_z) return 0;
+  return launch_merged(c, J, &G);
+}
 // nf <= 8 fields with the same BC set in one halo exchange and as few launches as the job table allows
 int op_boundp_multi(cales_ctx *c, int nf, real **p, int which) {
   ProfScope ps(c, "boundp");

@@ -499,7 +499,7 @@ __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijA
 #ifndef TYL
 #define TYL 8
 #endif
-struct LmfArgs { LijMijArgs L; const real *ss[6]; int by0; BandMap bm; int gx; };      // bm: block map of this launch (bm.gx = 0: plain 3-D grid); gx: x tiles of the whole field      // by0: first y tile of this launch (interior and edge tiles of a slab are launched apart)
+struct LmfArgs { LijMijArgs L; const real *ss[6]; const real2 *ss2[3]; int by0; BandMap bm; int gx; };      // ss2: |S|Sij as three fields of pairs (PAIR = 1), ss: six fields      // bm: block map of this launch (bm.gx = 0: plain 3-D grid); gx: x tiles of the whole field      // by0: first y tile of this launch (interior and edge tiles of a slab are launched apart)
 // Every global access of the plane loop is UNCONDITIONAL (out-of-range lanes, rows and planes are clamped onto valid cells whose values are
 // never used): a load inside a divergent branch makes the compiler wait with s_waitcnt vmcnt(0) at the next use of ANY loaded value -- it
 // cannot count the operations in flight across the branch -- and that drained, right behind the barrier of every plane, the six loads of
@@ -511,7 +511,9 @@ constexpr int LMF_KMAX = 256;      // longest k chunk (block sums of a chunk in 
 // UCF = 1: the cell-centred velocity u_c = (u(i) + u(i-1))/2, v_c = (v(j) + v(j-1))/2, w_c = (w(k) + w(k-1))/2 (sgs.f90:860-869, the same expressions
 // K_AC stored) is formed here from u, v, w: five loads per plane instead of three, and K_AC writes three fields less (3 of its 16 words; the pass is
 // bound by its writes) -- x periodic, z walls or periodic, y periodic / slab neighbours / walls; otherwise UCF = 0 reads the stored fields.
-template <typename OFF, int YW, int UCF>      // YW = 1: walls or wall-model faces in y (ducts); 0: the channel instantiation carries none of that logic
+// PAIR = 1: K_AC stored |S|Sij as three fields of PAIRS (S11,S22), (S33,S12), (S13,S23) per cell: nine 16-byte loads per plane instead of eighteen
+// 8-byte ones. The pass is bound by what its ten waves issue, not by bytes: 3.95 -> 3.45 ms at 512^3 (K_AC's paired stores cost 0.28 of the 0.5 back).
+template <typename OFF, int YW, int UCF, int PAIR = 0>      // YW = 1: walls or wall-model faces in y (ducts); 0: the channel instantiation carries none of that logic
 __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) {
   const LijMijArgs &A = B.L;
   __shared__ real sh[2][9][TYL + 2][64];
@@ -577,6 +579,14 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
   }
   // |S|Sij: y and x combination of one plane (three rows in, lanes beside by DPP)
   auto ssload = [&](int kk, real (*raw)[3]) {
+    if (PAIR) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const OFF o = 2 * (c0s + (OFF)kk * sk), s2 = 2 * sj;      // a pair field is twice as wide: byte offsets double
+        const real2 a = *(const real2 *)((const char *)B.ss2[q] + (o - s2)), b = *(const real2 *)((const char *)B.ss2[q] + o), c_ = *(const real2 *)((const char *)B.ss2[q] + (o + s2));
+        raw[2 * q][0] = a.x; raw[2 * q + 1][0] = a.y; raw[2 * q][1] = b.x; raw[2 * q + 1][1] = b.y; raw[2 * q][2] = c_.x; raw[2 * q + 1][2] = c_.y;
+      }
+    } else
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
       const OFF o = c0s + (OFF)kk * sk;
@@ -711,6 +721,7 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
 struct StrainTileArgs {
   const real *u[3];
   real *s0, *ssij[6], *uc[3], *uf[3];
+  real2 *ss2[3];      // PAIR = 1: |S|Sij as three fields of pairs (S11,S22), (S33,S12), (S13,S23) instead of ssij
   const real *dzci, *dzfi;
   real dxi, dyi;
   int kchunk, zlo, zhi;
@@ -742,7 +753,7 @@ __global__ __launch_bounds__(256) void k_wall_shear_y(Geom g, const real *__rest
     twy[(size_t)(g.n3 + 2 + k) * g.s1 + i] = sqrt(0.5 * visc * (sqrt(t1 * t1 + t2 * t2) * dyi));
   }
 }
-template <typename OFF, int SMAG, int TY, int YW>      // YW = 1: walls or wall-model faces in y (ducts); the channel instantiations carry none of that logic
+template <typename OFF, int SMAG, int TY, int YW, int PAIR = 0>      // YW = 1: walls or wall-model faces in y (ducts); the channel instantiations carry none of that logic
 __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTileArgs A) {
   // (one barrier per plane with four ring slots and double-buffered sums, as in k_lij_mij_tile, measured 13 % slower here)
   __shared__ real ring[3][3][TY + 2][66];      // rows: x-halo cell, 64 own cells, x-halo cell
@@ -872,8 +883,15 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
         stb(A.visct, idx, (t * t) * s0v);
       } else {
         stb(A.s0, idx, s0v);                                              // stands for visct = s0 (sgs.f90:184) until the final kernel
+        if (PAIR) {      // |S|Sij (sgs.f90:198-210), two components per 16-byte store
+          const OFF i2 = 2 * idx;
+          *(real2 *)((char *)A.ss2[0] + i2) = make_real2(s0v * s11, s0v * s22);
+          *(real2 *)((char *)A.ss2[1] + i2) = make_real2(s0v * s33, s0v * s12);
+          *(real2 *)((char *)A.ss2[2] + i2) = make_real2(s0v * s13, s0v * s23);
+        } else {
         stb(A.ssij[0], idx, s0v * s11); stb(A.ssij[1], idx, s0v * s22); stb(A.ssij[2], idx, s0v * s33);      // |S|Sij (sgs.f90:198-210)
         stb(A.ssij[3], idx, s0v * s12); stb(A.ssij[4], idx, s0v * s13); stb(A.ssij[5], idx, s0v * s23);
+        }
         if (A.uc[0]) { stb(A.uc[0], idx, 0.5 * (u_ccc + u_mcc)); stb(A.uc[1], idx, 0.5 * (v_ccc + v_cmc)); stb(A.uc[2], idx, 0.5 * (w_ccc + w_ccm)); }      // (null: the last pass forms them itself)
       }
     }
@@ -1024,8 +1042,18 @@ static bool dsmag_fast_ok(const cales_ctx *c) {
   for (int q = 2; q < 4; ++q) if ((c->is_wall[q] != 0. || c->C.lwm[q] != 0) && (c->fl.dsmag_unfused_filter || c->n[1] < 3)) return false;
   return c->n[2] >= 3 && !c->fl.dsmag_reference_sequence;
 }
+// |S|Sij as three fields of pairs between K_AC and the fused last pass: x and y periodic (the one-launch ghost-cell kernel takes a pair field as a
+// field of twice the width), the cell-centred velocity formed by the last pass, 32-bit byte offsets still enough for a field twice as long
+bool dsmag_pairs(const cales_ctx *c) {
+  if (c->C.sgstype != 2 || !dsmag_fast_ok(c) || c->fl.dsmag_unfused_filter || c->fl.dsmag_unpaired || c->fl.dsmag_xghosts || c->fl.wide_offsets || c->fl.unmerged_bc) return false;
+  for (int q = 0; q < 4; ++q) if (c->C.cbcpre[q] != 'P') return false;
+  const bool perz = c->C.cbcpre[4] == 'P' && c->C.cbcpre[5] == 'P';
+  if (!perz && !(c->is_wall[4] != 0. && c->is_wall[5] != 0.)) return false;      // z: periodic, or two walls (whose ghost planes the filters never read)
+  return (2 * c->ntot + 64) * sizeof(real) < (1ull << 32);
+}
 static int dsmag_fast(cales_ctx *c) {
   const int *n = c->n; real **f = c->f; real *visct = f[CALES_VISCT];
+  const bool pair = c->ss2[0] != nullptr;
   dim3 b(BX, BY, 1), gr = grid3(n[0], n[1], n[2], b);
   real **ssij = c->sij, **mij = c->mij;
   const int zlo = c->is_wall[4] != 0., zhi = c->is_wall[5] != 0.;
@@ -1061,12 +1089,14 @@ static int dsmag_fast(cales_ctx *c) {
     StrainTileArgs S;
     S.u[0] = f[CALES_U]; S.u[1] = f[CALES_V]; S.u[2] = f[CALES_W]; S.s0 = lazy ? visct : c->s0;
     for (int m = 0; m < 6; ++m) S.ssij[m] = ssij[m];
+    for (int m = 0; m < 3; ++m) S.ss2[m] = reinterpret_cast<real2 *>(c->ss2[m]);
     S.uc[0] = ucf ? nullptr : c->uc; S.uc[1] = ucf ? nullptr : c->vc; S.uc[2] = ucf ? nullptr : c->wc; S.uf[0] = c->uf; S.uf[1] = c->vf; S.uf[2] = c->wf;
     S.dzci = c->d_dzci; S.dzfi = c->d_dzfi; S.dxi = c->dli[0]; S.dyi = c->dli[1]; S.kchunk = kch; S.zlo = zlo; S.zhi = zhi; S.wmlo = wmlo; S.wmhi = wmhi; S.flo = flo; S.fhi = fhi;
     S.wylo = wylo; S.wyhi = wyhi; S.wmylo = wmylo; S.wmyhi = wmyhi; S.twy = nullptr; S.dl2 = c->dl[1];
     S.bm = BandMap{0, 0, 0, 0}; S.perx = c->step_xskip ? 1 : 0;
     if (!c->fl.plain_grid && (band_wanted(mg.x) || c->fl.band_grid)) { S.bm = band_map(mg.x, mg.y, mg.z); mg = dim3(band_blocks(S.bm), 1, 1); }
     if (wylo || wyhi || wmylo || wmyhi) { if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 0, TYS, 1>), mg, mb, 0, c->stream, c->g, S); else hipLaunchKernelGGL((k_strain_tile<size_t, 0, TYS, 1>), mg, mb, 0, c->stream, c->g, S); }
+    else if (pair) hipLaunchKernelGGL((k_strain_tile<unsigned, 0, TYS, 0, 1>), mg, mb, 0, c->stream, c->g, S);
     else if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 0, TYS, 0>), mg, mb, 0, c->stream, c->g, S); else hipLaunchKernelGGL((k_strain_tile<size_t, 0, TYS, 0>), mg, mb, 0, c->stream, c->g, S); }
   // sgs-type ghost cells: only the periodic exchange matters (products of ghosts = ghosts of products; the wall ghosts are
   // replaced by the extrapolation rule inside the filters)
@@ -1086,7 +1116,7 @@ static int dsmag_fast(cales_ctx *c) {
   // x/z ghost cells
   c->defer_halo = c->P > 1;
   c->bc_skip = perx | skipz;
-  int e_ = op_boundp_multi(c, 6, ssij, 1);
+  int e_ = pair ? op_boundp_wide(c, 3, c->ss2, 1) : op_boundp_multi(c, 6, ssij, 1);
   c->bc_skip = perx;
   if (!e_) e_ = op_bounduvw(c, c->bcuf, c->bcvf, c->bcwf, 0, 0, c->uf, c->vf, c->wf);
   c->bc_skip = perx | skipz;
@@ -1098,7 +1128,7 @@ static int dsmag_fast(cales_ctx *c) {
   if (!e_ && lazy && c->in_step && c->P > 1) { e_ = op_boundp(c, visct, 1); c->visct_bc_done = !e_; }      // |S| is final (K_AC wrote it): its rows travel along
   c->defer_halo = false;
   if (!e_ && c->P > 1) e_ = halo_flush_deferred(c, overlap);
-  if (e_) { c->deferred.clear(); return e_; }
+  if (e_) { c->deferred.clear(); c->deferred_wide.clear(); return e_; }
   LijMijArgs L;
   L.uc[0] = ucf ? f[CALES_U] : c->uc; L.uc[1] = ucf ? f[CALES_V] : c->vc; L.uc[2] = ucf ? f[CALES_W] : c->wc; L.uf[0] = c->uf; L.uf[1] = c->vf; L.uf[2] = c->wf;
   L.vcg = c->vc; L.perz = perz ? 1 : 0; L.xwrap = c->step_xskip ? 1 : 0;
@@ -1113,6 +1143,7 @@ static int dsmag_fast(cales_ctx *c) {
     while (kch > LMF_KMAX) { kch = (kch + 1) / 2; mg.z = (n[2] + kch - 1) / kch; }      // the kernel keeps a chunk's block sums in LDS
     L.kchunk = kch; L.nblk = mg.x * mg.y;
     LmfArgs B; B.L = L; for (int m = 0; m < 6; ++m) B.ss[m] = ssij[m];
+    for (int m = 0; m < 3; ++m) B.ss2[m] = reinterpret_cast<const real2 *>(c->ss2[m]);
     auto launch = [&](int by0, int nby) {
       if (nby <= 0) return;
       B.by0 = by0; B.gx = mg.x; dim3 gg(mg.x, nby, mg.z);
@@ -1120,7 +1151,8 @@ static int dsmag_fast(cales_ctx *c) {
       if (!c->fl.plain_grid && (band_wanted(mg.x) || c->fl.band_grid)) { B.bm = band_map(mg.x, nby, mg.z); gg = dim3(band_blocks(B.bm), 1, 1); }
       const bool yw = wylo || wyhi || wmylo || wmyhi;
 #define LMF_LAUNCH(YWV, UCV) do { if (small) hipLaunchKernelGGL((k_lmf_tile<unsigned, YWV, UCV>), gg, mb, 0, c->stream, c->g, B); else hipLaunchKernelGGL((k_lmf_tile<size_t, YWV, UCV>), gg, mb, 0, c->stream, c->g, B); } while (0)
-      if (yw) { if (ucf) LMF_LAUNCH(1, 1); else LMF_LAUNCH(1, 0); } else { if (ucf) LMF_LAUNCH(0, 1); else LMF_LAUNCH(0, 0); }
+      if (pair) { if (ucf) hipLaunchKernelGGL((k_lmf_tile<unsigned, 0, 1, 1>), gg, mb, 0, c->stream, c->g, B); else hipLaunchKernelGGL((k_lmf_tile<unsigned, 0, 0, 1>), gg, mb, 0, c->stream, c->g, B); }
+      else if (yw) { if (ucf) LMF_LAUNCH(1, 1); else LMF_LAUNCH(1, 0); } else { if (ucf) LMF_LAUNCH(0, 1); else LMF_LAUNCH(0, 0); }
 #undef LMF_LAUNCH
     };
     if (overlap) {

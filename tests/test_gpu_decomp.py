@@ -130,7 +130,7 @@ def test_slab_ranks_batched_scratch_field_exchange(name, ng, P, events, monkeypa
     if events:
         monkeypatch.setenv("CALES_LOOPBACK_EVENTS", "1")
     test_slab_ranks_match_single_rank(name, ng, P)
-    monkeypatch.setenv("CALES_DSMAG_STORE_UC", "1")
+    monkeypatch.setenv("CALES_DSMAG_STORE_UC", "CALES_DSMAG_UNPAIRED", "1")
     test_slab_ranks_match_single_rank(name, ng, P)
 
 

@@ -182,6 +182,8 @@ SWITCH_CASES = [
     ({"CALES_DSMAG_STORE_UC": "1"}, ["chan_dsmag", "chan_dsmag_wm", "tgv_dsmag_ppp", "duct_dsmag_wm", "duct_dsmag"]),
     # the y transform with staging copies through LDS instead of the register-ended one (golden sizes are not powers of two: see also test_gpu_vs_oracle)
     ({"CALES_FFT_STAGED": "1"}, ["chan_dsmag", "tgv_ppp"]),
+    # dynamic model: |S|Sij as six scalar fields between K_AC and the last pass instead of three fields of pairs (the default where x and y are periodic)
+    ({"CALES_DSMAG_UNPAIRED": "1"}, ["chan_dsmag", "chan_dsmag_wm", "tgv_dsmag_ppp", "chan_dsmag_p2"]),
     # tile heights of the LDS form of the static Smagorinsky pass
     ({"CALES_SMAG_TILE": "1", "CALES_SMAG_TY": "6"}, ["chan_smag", "chan_smag_wm", "duct_smag_wm"]),
     ({"CALES_SMAG_TILE": "1", "CALES_SMAG_TY": "14"}, ["chan_smag", "chan_smag_wm", "duct_smag_wm"]),
