@@ -905,31 +905,36 @@ __global__ __launch_bounds__(64 * gt_width(M, NV) / NV, (PER ? 2 : M <= 8 ? 4 : 
   real *tabl = shz + W * P;
   if (TL) { for (int q = t; q < 64 * M; q += NT) { tabl[q] = abc[q]; tabl[64 * M + q] = abc[128 * M + q]; } }
   {
-    const int x = t % W, kk = t / W;
+    // two neighbouring columns per thread, 16-byte accesses: eight lanes per 128-B line and half as many load / store instructions (the copy of this
+    // pattern alone: 0.57 -> 0.46 ms at 512^3, 4.85 -> 3.62 ms at 1024^3, tools/micro/ztile.hip); ndbl is even (ng(1), 2 cw n2l)
+    constexpr int W2 = W / 2, KP2 = NT / W2, NQ2 = 64 * M / KP2;
+    const int x = 2 * (t % W2), kk = t / W2;
     const bool ok = W * tile + x < ndbl;
-    real v[NQ];
+    real2 v[NQ2];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {      // (measured: faster than unconditional loads from clamped places, 0.59 against 0.87 ms at 512^3)
-      const int k = kk + KP * q;
-      v[q] = (ok && k < nz) ? p[base + x + (size_t)k * kst] : 0.;
+    for (int q = 0; q < NQ2; ++q) {      // (conditional loads: measured faster than unconditional loads from clamped places, 0.59 against 0.87 ms at 512^3)
+      const int k = kk + KP2 * q;
+      v[q] = (ok && k < nz) ? *reinterpret_cast<const real2 *>(p + base + x + (size_t)k * kst) : make_real2(0., 0.);
     }
     if (NV == 2 && T.dud) {      // (the z-only Helmholtz sweeps come as pairs of real columns that share the matrix: NV = 2 only)
       const real f = T.force ? T.force[0] : 0.;
       const size_t pq = (size_t)(W * tile + x) + (size_t)g.n1 * blockIdx.y;
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int k = kk + KP * q;
+      for (int q = 0; q < NQ2; ++q) {
+        const int k = kk + KP2 * q;
         if (ok && k < T.nq) {
-          real t = (k < nz ? v[q] : p[base + x + (size_t)k * kst]) - T.hf12 * T.dud[base + x + (size_t)k * kst];
-          if (T.force) t = t + f;
-          if (k == 0 && T.has_lo) t = t + T.rb[pq];
-          if (k == nz - 1 && T.has_hi) t = t + T.rb[pq + (size_t)g.n1 * g.n2];
-          if (k < nz) v[q] = t; else p[base + x + (size_t)k * kst] = t;
+          const size_t o = base + x + (size_t)k * kst;
+          const real2 own = k < nz ? v[q] : *reinterpret_cast<const real2 *>(p + o), dd = *reinterpret_cast<const real2 *>(T.dud + o);
+          real2 t = make_real2(own.x - T.hf12 * dd.x, own.y - T.hf12 * dd.y);
+          if (T.force) { t.x = t.x + f; t.y = t.y + f; }
+          if (k == 0 && T.has_lo) { t.x = t.x + T.rb[pq]; t.y = t.y + T.rb[pq + 1]; }
+          if (k == nz - 1 && T.has_hi) { t.x = t.x + T.rb[pq + (size_t)g.n1 * g.n2]; t.y = t.y + T.rb[pq + 1 + (size_t)g.n1 * g.n2]; }
+          if (k < nz) v[q] = t; else *reinterpret_cast<real2 *>(p + o) = t;
         }
       }
     }
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) { const int k = kk + KP * q; shz[x * P + k + k / M] = v[q]; }
+    for (int q = 0; q < NQ2; ++q) { const int k = kk + KP2 * q; shz[x * P + k + k / M] = v[q].x; shz[(x + 1) * P + k + k / M] = v[q].y; }
   }
   __syncthreads();
   const int x = (t >> 6) * NV, ch = t & 63, d = W * tile + x;
@@ -1066,14 +1071,19 @@ __global__ __launch_bounds__(64 * gt_width(M, NV) / NV, (PER ? 2 : M <= 8 ? 4 : 
   {
     // (addresses formed again from an offset the compiler cannot recognise: it would otherwise keep those of the load phase alive through the
     //  solve, in scratch memory where registers are short -- 19 of the 29 spilled registers of the 16-plane instantiation)
-    const int x = t % W, kk = t / W;
+    constexpr int W2 = W / 2, KP2 = NT / W2, NQ2 = 64 * M / KP2;
+    const int x = 2 * (t % W2), kk = t / W2;
     const bool ok = W * tile + x < ndbl;
     size_t o = base + x + (size_t)kk * kst;
     int kq = kk;      // (the LDS places likewise)
     asm volatile("" : "+v"(o), "+v"(kq));
-    const size_t step = (size_t)KP * kst;
+    const size_t step = (size_t)KP2 * kst;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) { const int k = kq + KP * q; if (ok && k < nz) p[o] = shz[x * P + k + k / M]; o += step; }
+    for (int q = 0; q < NQ2; ++q) {
+      const int k = kq + KP2 * q;
+      if (ok && k < nz) *reinterpret_cast<real2 *>(p + o) = make_real2(shz[x * P + k + k / M], shz[(x + 1) * P + k + k / M]);
+      o += step;
+    }
   }
 }
 template <int M, int NV, int PER = 0>
