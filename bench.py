@@ -7,17 +7,21 @@ dynamic Smagorinsky, from the reference's examples/les/_manuscript_turbulent_cha
 is_wallturb=T; deterministic), bulk-velocity forcing in x. A step = 3 RK substeps (src/main.f90:417-508)
 with the fields resident in HBM. dt is fixed to 0.5*dt_cfl(initial field).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--ng n1 n2 n3] [--sgs none|smag|dsmag]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--ng n1 n2 n3] [--sgs none|smag|dsmag] [--configs all|none|c1,c2,c4,c5] [--no-cpu]
+
+After the headline measurement (N = 1) the other four BASELINE.json configurations are timed for a few steps each on the same GPU and reported
+under "configs" (C1 64^3 Taylor-Green, C2 256x128x128 wall-modelled channel, C4 512x256x256 z-implicit duct, C5 1024^3 cavity); the headline
+fields are the 512^3 channel's alone.
 
 N > 1: one process per GPU (torch.distributed.run), y-slab decomposition of the SAME 512^3 problem
 (strong scaling), see cales_amd/decomp.py.
 """
 import os as _os
 _os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC between the ranks' processes (RCCL); must be set before the HIP runtime starts
-# threads of the CPU baseline pinned to cores (read by the OpenMP run-time when it is loaded, i.e. before torch pulls it in). The host's thread count
-# is taken first: once the run-time has bound the main thread to its place, sched_getaffinity shows that one core only
+# The CPU baseline runs in a CHILD process (cpu_baseline below) that alone gets OMP_PROC_BIND / OMP_PLACES: set process-wide they would make the
+# OpenMP run-time bind the launching thread of EVERY rank of a --gpus N run to the first core of the common affinity mask, and the HIP / RCCL helper
+# threads created from it would inherit that one-core mask.
 _HOST_THREADS = len(_os.sched_getaffinity(0)) if hasattr(_os, "sched_getaffinity") else (_os.cpu_count() or 1)
-_os.environ.setdefault("OMP_PROC_BIND", "spread"); _os.environ.setdefault("OMP_PLACES", "cores")
 import argparse
 import json
 import os
@@ -61,6 +65,107 @@ def channel_case(ng, sgs):
     return case
 
 
+# The other BASELINE.json configurations, timed after the headline measurement on the same GPU. `words` = compulsory words per cell
+# and launch of the kernels these cases run that differ from the table above; `w_ref` = words per cell and substep of the reference's loop nests.
+CONFIGS = {
+    "c1": {"file": "taylor_green_64.nml", "impdiff": 0, "warmup": 20, "steps": 200, "w_ref": 44, "baseline_config": 0,
+           "what": "triply periodic Taylor-Green vortex 64^3, explicit diffusion, no subgrid model",
+           "words": {"mom_rk_fused": 11}},     # no eddy viscosity read: u,v,w,p + 3 old r.h.s. in, u,v,w + 3 r.h.s. out = 13; 10, 13, 10 over the substeps
+    "c2": {"file": "channel_wall_model_256.nml", "impdiff": 0, "warmup": 10, "steps": 60, "w_ref": 51, "baseline_config": 1,
+           "what": "turbulent channel 256x128x128, static Smagorinsky + log-law wall model on both z walls, bulk forcing in x",
+           "words": {"cmpt_sgs_smag": 4}},     # u,v,w in, visct out
+    "c4": {"file": "duct_wall_model_512.nml", "impdiff": 2, "warmup": 3, "steps": 20, "w_ref": 72, "baseline_config": 3,
+           "what": "square duct 512x256x256, static Smagorinsky + wall model on four walls, z-implicit (Crank-Nicolson) diffusion, NN pressure in y and z",
+           "words": {"cmpt_sgs_smag": 4, "helmholtz_z": 3,      # per component: u, implicit r.h.s. in; u out
+                     "mom_rk_fused": 15}},    # + 3 implicit r.h.s. out: 14, 17, 14 over the substeps
+    "c5": {"file": "lid_driven_cavity_1024.nml", "impdiff": 0, "warmup": 1, "steps": 3, "w_ref": 44, "baseline_config": 4,
+           "what": "lid-driven cavity 1024^3, no subgrid model, all-Neumann pressure (DCT-II/III in x and y), fields of 8.6 GB",
+           "words": {"mom_rk_fused": 11}},
+}
+SOLVE = ["fft_x_fwd", "fft_y_fwd", "gaussel_z", "fft_y_bwd", "fft_x_bwd"]
+
+
+def load_case(fname, impdiff=0):
+    from cales_amd.nml import parse_text
+    case = parse_text(open(os.path.join(ROOT, "cales_amd", "cases", fname)).read())
+    case.impdiff = impdiff
+    return case
+
+
+def solve_figures(stats, nloc, RB):
+    """fillps + Poisson solve from the per-kernel timers: time of one solve and its compulsory words (10: five passes x read + write; 12 when fillps
+    is folded into the forward x pass: u,v,w in, spectrum out)."""
+    ms = sum(stats[k][1] / stats[k][0] for k in SOLVE if k in stats and stats[k][0])
+    words, note = 10, "x fwd, y fwd, z tridiagonal, y bwd, x bwd: 5 passes x (read + write)"
+    if stats.get("fillps_fft_x_fwd", (0, 0))[0]:
+        ms += stats["fillps_fft_x_fwd"][1] / stats["fillps_fft_x_fwd"][0]; words = 12
+        note = "fillps + solve: fillps folded into the x-forward pass (u,v,w in, spectrum out) + y fwd, z tridiagonal, y bwd, x bwd"
+    return ms, words, note
+
+
+def run_config(key, HotPath, initflow, SMALL, RB):
+    """A few steps of one of the other BASELINE.json configurations on the current device: ms/step without per-kernel events, then the same number
+    of steps with events for the dominant kernel's roofline fraction and the solve's."""
+    cfg = CONFIGS[key]
+    case = load_case(cfg["file"], cfg["impdiff"])
+    t_setup = time.perf_counter()
+    h = HotPath(case)
+    try:
+        if case.inivel == "zer":      # one zero field uploaded four times (1024^3: 8.6 GB of host memory instead of 34)
+            z = np.zeros(tuple(int(x) + 2 for x in case.ng), order="F", dtype=np.float32 if RB == 4.0 else np.float64)
+            h.upload(z, z, z, z); del z
+        else:
+            u, v, w, p = initflow(case); h.upload(u, v, w, p); del u, v, w, p
+        h.startup()
+        dt = 0.5 * h.chkdt()
+        icheck = int(case.icheck) if int(case.icheck) > 0 else 10
+        nblocks = [0]
+
+        def run(first, count):
+            for istep in range(first + 1, first + count + 1):
+                h.step(dt)
+                if istep % icheck == 0:
+                    dtmax = h.chkdt(); divtot, divmax = h.chkdiv(); nblocks[0] += 1
+                    if dt > dtmax * case.cfl or not np.isfinite(divtot) or divmax > SMALL:
+                        raise RuntimeError(f"{key} invalid at step {istep}: dtmax {dtmax}, divergence {divmax}")
+        W, K = cfg["warmup"], cfg["steps"]
+        run(0, W); h.sync()
+        t_setup = time.perf_counter() - t_setup
+        nblocks[0] = 0
+        t0 = time.perf_counter(); run(W, K); h.sync(); t = time.perf_counter() - t0
+        timed_blocks = nblocks[0]
+        h.profile_reset(); h.profile(True)
+        run(W + K, K); h.sync()
+        h.profile(False)
+        stats = h.profile_stats()
+        divtot, divmax = h.chkdiv()
+        if not np.isfinite(divtot) or divmax > SMALL:
+            raise RuntimeError(f"{key} invalid: divergence {divmax}")
+    finally:
+        h.close()
+    ncell = float(np.prod(case.ng))
+    words = dict(WORDS); words.update(cfg["words"])
+    leaf = {k: v for k, v in stats.items() if k in words and v[0] > 0}
+    dom = max(leaf, key=lambda k: leaf[k][1])
+    calls, ms = leaf[dom]
+    ach = words[dom] * RB * ncell / (ms / calls * 1e-3)
+    sms, sw, snote = solve_figures(stats, ncell, RB)
+    ms_step = 1e3 * t / K
+    return {"baseline_config": cfg["baseline_config"], "workload": cfg["what"], "grid": "x".join(str(int(x)) for x in case.ng), "case_file": "cales_amd/cases/" + cfg["file"],
+            "impdiff": cfg["impdiff"], "dt": dt, "steps": K, "warmup": W, "ms_per_step": ms_step, "time_steps_per_s": 1e3 / ms_step, "setup_s": t_setup,
+            "icheck_blocks_in_timed_region": timed_blocks,
+            "dominant_kernel": dom,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
+                         "words_per_cell": words[dom], "avg_launch_ms": ms / calls, "launches": calls},
+            "poisson_solve": {"ms": sms, "words_per_cell": sw, "frac_of_hbm_peak": sw * RB * ncell / (sms * 1e-3) / HBM_PEAK if sms else None, "passes": snote},
+            # the reference's loop nests would move 3 x 8 B x N x w_ref per step (SURVEY.md 8d): the step's time at 100 % of the peak, and the measured step against it
+            "ideal_ms_reference_traffic_at_peak": 1e3 * 3 * RB * ncell * cfg["w_ref"] / HBM_PEAK,
+            "step_vs_reference_traffic_frac_of_peak": 3 * RB * ncell * cfg["w_ref"] / (t / K) / HBM_PEAK,
+            "timer_scopes_per_step": sum(v[0] for v in stats.values()) / K,
+            "kernels_ms_per_step": {k: round(v[1] / K, 4) for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])[:12]},
+            "divmax": divmax}
+
+
 def _transpose_report(out, stats, case, world, a, solve, h):
     if world <= 1 or not stats.get("alltoall", (0, 0))[0]:
         return
@@ -88,10 +193,24 @@ def _transpose_report(out, stats, case, world, a, solve, h):
                                 "No N > 1 run on hardware exists yet (no multi-GPU box was available to the build)"}
 
 
-def cpu_baseline(case_full, seconds_budget=40.0, full_budget=150.0, sample_dims=(256, 256, 128)):
+def cpu_baseline(a):
+    """The CPU baseline in a child process of its own: only that process sees OMP_PROC_BIND / OMP_PLACES (threads pinned to cores), it never touches
+    the GPU, and the memory of the 512^3 oracle run (~35 GB) is returned to the host when it exits."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("OMP_PROC_BIND", "spread"); env.setdefault("OMP_PLACES", "cores")
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--ng"] + [str(x) for x in a.ng] + ["--sgs", a.sgs]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode or not lines:
+        return {"error": f"cpu baseline child failed (exit code {r.returncode})", "value": None, "unit": "time-steps/s", "cores": 0, "kind": "port", "sample": "none"}
+    return json.loads(lines[-1])
+
+
+def _cpu_baseline_impl(case_full, seconds_budget=40.0, full_budget=150.0, sample_dims=(256, 256, 128)):
     """Oracle (oracle/cales_oracle.c, OpenMP) timed on the host's cores, twice:
       1. a bounded sample, 256x256x128 (1/16 of the cells), on the team size that runs it fastest among {32, 64, 128, all host threads}
-         (threads pinned: OMP_PROC_BIND=spread, OMP_PLACES=cores, set at the top of this file; fields first-touched by the threads that use them);
+         (threads pinned: OMP_PROC_BIND=spread, OMP_PLACES=cores in this child process's environment; fields first-touched by the threads that use them);
       2. ONE real step of the full workload (512^3: ~35 GB of host memory, ~30 s) with that team, when the host has the memory and the first
          measurement says it fits `full_budget` seconds (a warm-up step comes first when there is time for two).
     `value` is the full-size measurement when it exists, otherwise the sample's rate scaled by cell count (labelled `scaled`)."""
@@ -182,14 +301,23 @@ def main():
     ap.add_argument("--ng", type=int, nargs=3, default=[512, 512, 512])
     ap.add_argument("--sgs", default="dsmag", choices=["none", "smag", "dsmag"])
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--configs", default="all", help="N = 1: the other BASELINE.json configurations timed after the headline measurement: all | none | c1,c2,c4,c5")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: several ranks on ONE GPU with host-staged messages (tests of the launch path on a one-GPU box; not a measurement)")
     ap.add_argument("--overlap", action="store_true",
                     help="N > 1: exchanges on the library's second stream beside kernels (CALES_OVERLAP=1; default: in order on one stream, the form "
                          "with the fewest assumptions, until a node with real peers has confirmed the overlapped one)")
     a = ap.parse_args()
+    if a.cpu_baseline_child:      # (cpu_baseline above; nothing here touches the GPU)
+        print(json.dumps(_cpu_baseline_impl(channel_case(a.ng, a.sgs))))
+        return
     if a.overlap:
         os.environ["CALES_OVERLAP"] = "1"
+    want = [] if a.configs == "none" else sorted(CONFIGS) if a.configs == "all" else [k.strip().lower() for k in a.configs.split(",") if k.strip()]
+    for k in want:
+        if k not in CONFIGS:
+            raise SystemExit(f"--configs: unknown configuration '{k}' (c1, c2, c4, c5)")
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: start the N ranks ourselves, as CHILD processes of a parent that never touches the GPU (nothing has
@@ -303,14 +431,10 @@ def main():
                     traffic = row["hbm_read_bytes"] + row["hbm_write_bytes"]; traffic_src = prof.get("source")
         except (OSError, ValueError, KeyError):
             pass
-        solve = ["fft_x_fwd", "fft_y_fwd", "gaussel_z", "fft_y_bwd", "fft_x_bwd"]
-        solve_ms = sum(stats[k][1] / stats[k][0] for k in solve if k in stats and stats[k][0])
-        solve_words, solve_note = 10, "x fwd, y fwd, z tridiagonal, y bwd, x bwd: 5 passes x (read + write)"
-        if stats.get("fillps_fft_x_fwd", (0, 0))[0]:
-            # cales_step folds fillps into the forward x pass (u,v,w in instead of pp): the pair fillps + solve is priced at its
-            # compulsory 4 + 4 x 2 words (the separate passes: 4 + 10)
-            solve_ms += stats["fillps_fft_x_fwd"][1] / stats["fillps_fft_x_fwd"][0]; solve_words = 12
-            solve_note = "fillps + solve: fillps folded into the x-forward pass (u,v,w in, spectrum out) + y fwd, z tridiagonal, y bwd, x bwd"
+        solve = SOLVE
+        # cales_step folds fillps into the forward x pass (u,v,w in instead of pp): the pair fillps + solve is priced at its
+        # compulsory 4 + 4 x 2 words (the separate passes: 4 + 10)
+        solve_ms, solve_words, solve_note = solve_figures(stats, nloc, RB)
         out = {
             "metric": "time-steps/sec", "value": a.steps / t, "unit": "time-steps/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_step, "ms_per_step_with_kernel_events": 1e3 * t_prof / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -348,10 +472,20 @@ def main():
             _transpose_report(out, stats, case, world, a, solve, h)
         except Exception as e:      # never lose the bench line over the extra report
             out["transpose"] = {"error": repr(e)}
+        h.close(); h = None      # (frees the 45 GB of the 512^3 context before the 1024^3 case)
+        if world == 1 and want:
+            from cales_amd.hotpath import HotPath as _HP
+            out["configs"] = {}
+            for k in want:
+                try:
+                    out["configs"][k] = run_config(k, _HP, initflow, SMALL, RB)
+                except Exception as e:      # never lose the headline line over a side measurement
+                    out["configs"][k] = {"error": repr(e)}
         if world == 1 and not a.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(case)
+            out["cpu_baseline"] = cpu_baseline(a)
         print(json.dumps(out))
-    h.close()
+    if h is not None:
+        h.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -5,6 +5,13 @@
 
 static thread_local std::string g_create_err;
 
+// ------------------------------------------------------------------------------------------ launch check (common.hpp, LAUNCH)
+void launch_failed(cales_ctx *c, const char *what, hipError_t e) {
+  if (c->launch_err.empty()) c->launch_err = std::string("kernel launch failed: ") + what + ": " + hipGetErrorString(e) + " (the context is unusable from here on)";
+}
+// every operator entry: refuse a failed context, run, and report a launch that failed on the way
+#define ENTRY(c, expr) do { LAUNCHCHK(c); const int e_ = (expr); if (e_) return e_; LAUNCHCHK(c); return 0; } while (0)
+
 // ------------------------------------------------------------------------------------------ profiling
 int stream_after(cales_ctx *c, hipStream_t later, hipStream_t earlier) {
   if (c->sync_ev.size() < 64) { hipEvent_t e; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->sync_ev.push_back(e); c->sync_next = c->sync_ev.size() - 1; }
@@ -157,8 +164,8 @@ int cales_create(const cales_case *cs, void *stream, cales_ctx **out) {
   // Row pitch: a multiple of one cache line (128 B = 16 doubles / 32 floats) with room for the n1/2+1 complex modes of a row stored from i = 1; with the
   // one-line-minus-one-element offset of dev_alloc, element i = 1 of every row is 128-B aligned, so kernels whose waves handle 64 consecutive
   // cells from i = 1 read and write whole cache lines (partial-line writes cost ~1.5x, tools/micro/wrtile.hip).
-  g.s1 = c->fl.unaligned ? g.n1 + 4 - (g.n1 & 1) : (g.n1 + 3 + LINE_REALS - 1) / LINE_REALS * LINE_REALS;
-  c->field_ofs = c->fl.unaligned ? 0 : LINE_REALS - 1;
+  g.s1 = (g.n1 + 3 + LINE_REALS - 1) / LINE_REALS * LINE_REALS;
+  c->field_ofs = LINE_REALS - 1;
   g.s12 = (long)g.s1 * (g.n2 + 2); g.jlo = c->lo[1] - 1; g.ng2 = cs->ng[1];
   c->ntot = (size_t)g.s12 * (g.n3 + 2);
   const int n3 = c->n[2];
@@ -222,6 +229,7 @@ int cales_create(const cales_case *cs, void *stream, cales_ctx **out) {
   }
   if (solver_setup(c)) return fail(14);
   if (hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "sync failed"; return fail(15); }
+  if (!c->launch_err.empty()) { c->err = c->launch_err; return fail(16); }      // a set-up kernel (twiddles, tables) or attribute call failed
   *out = c;
   return 0;
 }
@@ -231,21 +239,25 @@ int cales_local_size(const cales_ctx *c, int32_t n[3], int32_t lo[3]) { for (int
 
 // ------------------------------------------------------------------------------------------ copies
 int cales_set_field(cales_ctx *c, int field, const real *host) {
+  LAUNCHCHK(c);
   if (field < 0 || field >= CALES_NFIELDS || !c->f[field]) { c->err = "bad field id"; return 1; }
   if (field == CALES_VISCT) { c->visct_zero = false; c->visct_lazy = false; }
   const size_t nh = (size_t)(c->n[0] + 2) * (c->n[1] + 2) * (c->n[2] + 2);
   const dim3 b(64, 4, 1), gr((c->n[0] + 2 + 63) / 64, (c->n[1] + 2 + 3) / 4, c->n[2] + 2);
   HIPCHK(c, hipMemcpyAsync(c->scr1, host, nh * sizeof(real), hipMemcpyHostToDevice, c->stream));     // scr1: scratch between operators
-  hipLaunchKernelGGL(k_repack, gr, b, 0, c->stream, c->g, 1, c->f[field], c->scr1);
+  LAUNCH(c, k_repack, gr, b, 0, c->stream, c->g, 1, c->f[field], c->scr1);
+  LAUNCHCHK(c);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }
 int cales_get_field(cales_ctx *c, int field, real *host) {
+  LAUNCHCHK(c);
   if (field < 0 || field >= CALES_NFIELDS || !c->f[field]) { c->err = "bad field id"; return 1; }
   if (field == CALES_VISCT) if (int e = materialize_visct(c)) return e;
   const size_t nh = (size_t)(c->n[0] + 2) * (c->n[1] + 2) * (c->n[2] + 2);
   const dim3 b(64, 4, 1), gr((c->n[0] + 2 + 63) / 64, (c->n[1] + 2 + 3) / 4, c->n[2] + 2);
-  hipLaunchKernelGGL(k_repack, gr, b, 0, c->stream, c->g, 0, c->f[field], c->scr1);
+  LAUNCH(c, k_repack, gr, b, 0, c->stream, c->g, 0, c->f[field], c->scr1);
+  LAUNCHCHK(c);
   HIPCHK(c, hipMemcpyAsync(host, c->scr1, nh * sizeof(real), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
@@ -272,21 +284,23 @@ int cales_get_bcvel(cales_ctx *c, int ivel, real *x, real *y, real *z) {
 
 // ------------------------------------------------------------------------------------------ operators
 int cales_bounduvw(cales_ctx *c, int is_updt_wm, int is_correc) {
-  return op_bounduvw(c, c->bcu, c->bcv, c->bcw, is_updt_wm, is_correc, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W]);
+  ENTRY(c, op_bounduvw(c, c->bcu, c->bcv, c->bcw, is_updt_wm, is_correc, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W]));
 }
 int cales_boundp(cales_ctx *c, int field, int which) {
   if (field < 0 || field >= CALES_NFIELDS || !c->f[field]) { c->err = "bad field id"; return 1; }
-  return op_boundp(c, c->f[field], which);
+  ENTRY(c, op_boundp(c, c->f[field], which));
 }
 int cales_get_forcing(cales_ctx *c, real f[3]);
-int cales_mom(cales_ctx *c) { return op_mom(c); }
-int cales_rk(cales_ctx *c, int irk, real dt) { if (irk < 1 || irk > 3) { c->err = "irk must be 1..3"; return 1; } return op_rk(c, irk, dt); }
+int cales_mom(cales_ctx *c) { ENTRY(c, op_mom(c)); }
+int cales_rk(cales_ctx *c, int irk, real dt) { if (irk < 1 || irk > 3) { c->err = "irk must be 1..3"; return 1; } ENTRY(c, op_rk(c, irk, dt)); }
 int cales_rk_par(cales_ctx *c, const real rkpar[2], real dt, real f_out[3]) {
   if (!rkpar) { c->err = "cales_rk_par: rkpar is NULL"; return 1; }
+  LAUNCHCHK(c);
   if (int e = op_rk_par(c, rkpar[0], rkpar[1], dt)) return e;
+  LAUNCHCHK(c);
   return f_out ? cales_get_forcing(c, f_out) : 0;
 }
-int cales_bulk_forcing(cales_ctx *c) { return op_bulk_forcing(c); }
+int cales_bulk_forcing(cales_ctx *c) { ENTRY(c, op_bulk_forcing(c)); }
 int cales_get_forcing(cales_ctx *c, real f[3]) {
   HIPCHK(c, hipMemcpyAsync(c->h_red + 32, c->d_force, 3 * sizeof(real), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -295,40 +309,52 @@ int cales_get_forcing(cales_ctx *c, real f[3]) {
 }
 int cales_bulk_mean(cales_ctx *c, int field, int c_or_f, real *mean) {
   if (field < 0 || field >= CALES_NFIELDS || !c->f[field]) { c->err = "bad field id"; return 1; }
+  LAUNCHCHK(c);
   if (int e = op_bulk_mean_dev(c, c->f[field], c_or_f, nullptr)) return e;
+  LAUNCHCHK(c);
   HIPCHK(c, hipMemcpyAsync(c->h_red + 16, c->res + 16, sizeof(real), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   *mean = c->h_red[16];
   return 0;
 }
-int cales_fillps(cales_ctx *c, real dtrki) { return op_fillps(c, dtrki); }
-int cales_updt_rhs_b(cales_ctx *c) { return op_updt_rhs_b(c); }
-int cales_solver(cales_ctx *c) { return op_solver(c); }
-int cales_helmholtz(cales_ctx *c, int ivel, real alpha) { return op_helmholtz(c, ivel, alpha); }
-int cales_helmholtz_z(cales_ctx *c, int ivel, real alpha) { if (ivel < 1 || ivel > 3) { c->err = "ivel must be 1..3"; return 1; } return op_helmholtz_z(c, ivel, alpha); }
-int cales_correc(cales_ctx *c, real dtrk) { return op_correc(c, dtrk); }
-int cales_updatep(cales_ctx *c, real alpha) { return op_updatep(c, alpha); }
-int cales_cmpt_sgs(cales_ctx *c) { return op_cmpt_sgs(c); }
-int cales_chkdt(cales_ctx *c, real *dtmax) { return op_chkdt(c, dtmax); }
-int cales_chkdiv(cales_ctx *c, real *divtot, real *divmax) { return op_chkdiv(c, divtot, divmax); }
-int cales_out1d_single_point_chan(cales_ctx *c, real *buf) { if (!c || !buf) return 1; return op_stats_chan(c, buf); }
-int cales_out1d_chan_budgets(cales_ctx *c, real *budget, real *leakage) { if (!c) return 1; return op_stats_chan_budget(c, budget, leakage); }
-int cales_out1d(cales_ctx *c, int field, int idir, int use_dzc, real *buf) { if (!c || !buf) return 1; return op_out1d(c, field, idir, use_dzc, buf); }
-int cales_out1d_chan(cales_ctx *c, real *buf) { if (!c || !buf) return 1; return op_out1d_chan(c, buf); }
-int cales_out2d_duct(cales_ctx *c, real *buf) { if (!c || !buf) return 1; return op_out2d_duct(c, buf); }
+int cales_fillps(cales_ctx *c, real dtrki) { ENTRY(c, op_fillps(c, dtrki)); }
+int cales_updt_rhs_b(cales_ctx *c) { ENTRY(c, op_updt_rhs_b(c)); }
+int cales_solver(cales_ctx *c) { ENTRY(c, op_solver(c)); }
+int cales_helmholtz(cales_ctx *c, int ivel, real alpha) { ENTRY(c, op_helmholtz(c, ivel, alpha)); }
+int cales_helmholtz_z(cales_ctx *c, int ivel, real alpha) { if (ivel < 1 || ivel > 3) { c->err = "ivel must be 1..3"; return 1; } ENTRY(c, op_helmholtz_z(c, ivel, alpha)); }
+int cales_correc(cales_ctx *c, real dtrk) { ENTRY(c, op_correc(c, dtrk)); }
+int cales_updatep(cales_ctx *c, real alpha) { ENTRY(c, op_updatep(c, alpha)); }
+int cales_cmpt_sgs(cales_ctx *c) { ENTRY(c, op_cmpt_sgs(c)); }
+int cales_chkdt(cales_ctx *c, real *dtmax) { ENTRY(c, op_chkdt(c, dtmax)); }
+int cales_chkdiv(cales_ctx *c, real *divtot, real *divmax) { ENTRY(c, op_chkdiv(c, divtot, divmax)); }
+int cales_out1d_single_point_chan(cales_ctx *c, real *buf) { if (!c || !buf) return 1; ENTRY(c, op_stats_chan(c, buf)); }
+int cales_out1d_chan_budgets(cales_ctx *c, real *budget, real *leakage) { if (!c) return 1; ENTRY(c, op_stats_chan_budget(c, budget, leakage)); }
+int cales_out1d(cales_ctx *c, int field, int idir, int use_dzc, real *buf) { if (!c || !buf) return 1; ENTRY(c, op_out1d(c, field, idir, use_dzc, buf)); }
+int cales_out1d_chan(cales_ctx *c, real *buf) { if (!c || !buf) return 1; ENTRY(c, op_out1d_chan(c, buf)); }
+int cales_out2d_duct(cales_ctx *c, real *buf) { if (!c || !buf) return 1; ENTRY(c, op_out2d_duct(c, buf)); }
 
 // ------------------------------------------------------------------------------------------ time step (main.f90:412-508)
 __global__ void k_zero6(real *f) { if (threadIdx.x < 6) f[threadIdx.x] = 0.; }
 
+static int step_body(cales_ctx *c, real dt);
 int cales_step(cales_ctx *c, real dt) {
+  LAUNCHCHK(c);
+  const int e = step_body(c, dt);
+  LAUNCHCHK(c);
+  // an error in the middle of a step leaves the fields between two operators (x ghost columns stale with step_xskip, a half-applied substep): the
+  // context is marked failed so that operator-level calls cannot read that state as if it were a finished step
+  if (e) { c->launch_err = "an earlier cales_step failed (" + c->err + "): the fields are in an intermediate state, the context is unusable"; return e; }
+  return 0;
+}
+static int step_body(cales_ctx *c, real dt) {
   static const real rk[3][2] = {{32. / 60., 0.}, {25. / 60., -17. / 60.}, {45. / 60., -25. / 60.}};
-  hipLaunchKernelGGL(k_zero6, dim3(1), dim3(64), 0, c->stream, c->d_force);     // dpdl(:) = 0
+  LAUNCH(c, k_zero6, dim3(1), dim3(64), 0, c->stream, c->d_force);     // dpdl(:) = 0
   c->in_step = true;
-  struct Reset { cales_ctx *c; ~Reset() { c->in_step = false; c->step_xskip = false; c->defer_force = false; c->defer_imp_rhs = false; c->fuse_fillps_dti = 0.; c->fuse_mean_mask = 0; } } reset{c};      // also on the error returns
+  struct Reset { cales_ctx *c; ~Reset() { c->in_step = false; c->step_xskip = false; c->bc_nride = 0; c->defer_force = false; c->defer_imp_rhs = false; c->fuse_fillps_dti = 0.; c->fuse_mean_mask = 0; } } reset{c};      // also on the error returns
   // periodic x, explicit diffusion, no wall model, the fused passes everywhere: every kernel of the step wraps around instead of reading x ghost
   // columns, which are then left alone until the step returns (common.hpp, step_xskip)
   { bool ok = !c->fl.xghosts_in_step && CBP(c, 0, 1) == 'P' && CBP(c, 1, 1) == 'P' && c->C.impdiff == 0 && !c->fl.unfused_rk && !c->fl.unfused_correc &&
-              !c->fl.unfused_fillps && !c->fl.unaligned && solver_can_fuse_fillps(c) && c->xkind == 0 && sgs_wraps_x(c);
+              !c->fl.unfused_fillps && solver_can_fuse_fillps(c) && c->xkind == 0 && sgs_wraps_x(c);
     for (int q = 0; q < 6; ++q) ok = ok && c->C.lwm[q] == 0;
     for (int d = 0; d < 3; ++d) ok = ok && ((c->C.bcpre[2 * d] == 0. && c->C.bcpre[2 * d + 1] == 0.) || c->C.cbcpre[2 * d] == 'P');      // (fillps inside the x transform)
     c->step_xskip = ok; }
@@ -348,7 +374,7 @@ int cales_step(cales_ctx *c, real dt) {
       c->defer_force = ok && (c->C.is_forced[0] || c->C.is_forced[1] || c->C.is_forced[2]); }
     // homogeneous pressure BCs (no boundary r.h.s.) and a radix-8 x plan: fillps is done by the forward x transform, which then
     // also sums the bulk means of the forced components (their increment is only needed by the correction kernel)
-    bool fuse_fill = !c->fl.unfused_fillps && !c->fl.unaligned && solver_can_fuse_fillps(c);
+    bool fuse_fill = !c->fl.unfused_fillps && solver_can_fuse_fillps(c);
     for (int d = 0; d < 3; ++d) fuse_fill = fuse_fill && ((c->C.bcpre[2 * d] == 0. && c->C.bcpre[2 * d + 1] == 0.) || c->C.cbcpre[2 * d] == 'P');
     c->fuse_mean_mask = (fuse_fill && c->defer_force && !c->fl.unfused_mean)
                             ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;

@@ -68,10 +68,11 @@ struct Spec {
 
 // Run-time switches: read from the environment ONCE, by cales_create; the launch path only looks at these fields.
 struct Flags {
-  bool unaligned = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_eager = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, gaussel_pair = false, unfused_rk = false, dsmag_unfused_filter = false, overlap = false, fft_staged = false, dsmag_store_uc = false, dsmag_unpaired = false, xghosts_in_step = false, unmerged_bc = false, smag_tile = false, plain_grid = false, band_grid = false;
-  int kchunk = 0; long tile_min_blocks = 2048; int smag_ty = 10;
+  bool helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_eager = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, unfused_rk = false, dsmag_unfused_filter = false, overlap = false, fft_staged = false, dsmag_store_uc = false, dsmag_unpaired = false, xghosts_in_step = false, unmerged_bc = false, smag_tile = false, plain_grid = false, band_grid = false;
+  int kchunk = 0; long tile_min_blocks = 2048;
+  std::string test_bad_launch;      // CALES_TEST_BAD_LAUNCH: test hook of the launch check (LAUNCH below)
   void read_env() {
-    unaligned = getenv("CALES_UNALIGNED") != nullptr;
+    test_bad_launch = getenv("CALES_TEST_BAD_LAUNCH") ? getenv("CALES_TEST_BAD_LAUNCH") : "";
     helmholtz_z_per_column = getenv("CALES_HELMHOLTZ_Z_PER_COLUMN") != nullptr;
     unfused_imp_rhs = getenv("CALES_UNFUSED_IMP_RHS") != nullptr;
     unfused_correc = getenv("CALES_UNFUSED_CORREC") != nullptr;
@@ -94,7 +95,6 @@ struct Flags {
     xghosts_in_step = getenv("CALES_XGHOSTS_IN_STEP") != nullptr;      // keep the x ghost columns up to date after every operator of cales_step
     fft_staged = getenv("CALES_FFT_STAGED") != nullptr;      // the radix-8 kernels with staging copies through LDS (k_fft_y8) instead of the register-ended ones
     keep_null_mode = getenv("CALES_KEEP_NULL_MODE") != nullptr;
-    gaussel_pair = getenv("CALES_GAUSSEL_PAIR") != nullptr;
     unfused_rk = getenv("CALES_UNFUSED_RK") != nullptr;
     dsmag_unfused_filter = getenv("CALES_DSMAG_UNFUSED_FILTER") != nullptr;
     // exchanges beside the kernels on a second stream: opt-in (CALES_OVERLAP=1) until a run with real peers has confirmed it -- the emulated
@@ -103,7 +103,6 @@ struct Flags {
     unmerged_bc = getenv("CALES_UNMERGED_BC") != nullptr;
     kchunk = getenv("CALES_KCHUNK") ? atoi(getenv("CALES_KCHUNK")) : 0;
     tile_min_blocks = getenv("CALES_TILE_MIN_BLOCKS") ? atol(getenv("CALES_TILE_MIN_BLOCKS")) : 2048;
-    { const int t = getenv("CALES_SMAG_TY") ? atoi(getenv("CALES_SMAG_TY")) : 10; smag_ty = (t == 6 || t == 14) ? t : 10; }
   }
 };
 
@@ -119,6 +118,7 @@ struct cales_ctx {
   hipStream_t comm_stream = nullptr;      // exchanges that overlap kernels (created by cales_set_comm_overlap)
   std::vector<hipEvent_t> sync_ev; size_t sync_next = 0;      // ordering events between the two streams (no timing), reused round-robin
   std::string err;
+  std::string launch_err;      // first failed kernel launch / attribute call (LAUNCH below): the context is failed from then on
   // host copies of the grid
   std::vector<real> dzc, dzf, zc, zf, dzci, dzfi, gvr_c, gvr_f;
   char cbcvel[18];
@@ -210,6 +210,31 @@ struct cales_ctx {
       (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                              \
       return 1;                                                                                    \
     }                                                                                              \
+  } while (0)
+
+// ---- every kernel launch is checked (the reference ignores its istat everywhere, src/solver_gpu.f90:80).
+// LAUNCH = hipLaunchKernelGGL + hipGetLastError: an invalid configuration (block size, LDS size, too many registers for the block) is caught at the
+// launch site. The FIRST failure is recorded in c->launch_err with the kernel's name and stays there: the context is failed, LAUNCHCHK at the end
+// of every operator and cales_* entry returns non-zero with that message (cales_last_error), and every later call on the context refuses to run --
+// never a silently wrong field. Void helpers and lambdas record through the same path (HIPSOFT for other HIP calls whose status must not be lost).
+// Test hook: CALES_TEST_BAD_LAUNCH=<substring of a kernel name> gives the matching launches a block of 4096 threads (invalid on every device).
+void launch_failed(cales_ctx *c, const char *what, hipError_t e);
+#define LAUNCH(c, kernel, grid, block, lds, stream, ...)                                           \
+  do {                                                                                             \
+    dim3 blk_ = (block);                                                                           \
+    if (!(c)->fl.test_bad_launch.empty() && strstr(#kernel, (c)->fl.test_bad_launch.c_str())) blk_ = dim3(4096, 1, 1); \
+    hipLaunchKernelGGL(kernel, grid, blk_, lds, stream, __VA_ARGS__);                              \
+    const hipError_t le_ = hipGetLastError();                                                      \
+    if (le_ != hipSuccess) launch_failed(c, #kernel, le_);                                         \
+  } while (0)
+#define LAUNCHCHK(c)                                                                               \
+  do {                                                                                             \
+    if (!(c)->launch_err.empty()) { (c)->err = (c)->launch_err; return 1; }                        \
+  } while (0)
+#define HIPSOFT(c, call)                                                                           \
+  do {                                                                                             \
+    const hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) launch_failed(c, #call, e_);                                             \
   } while (0)
 
 // profiling bracket: PROF_BEGIN(ctx,"name"); launch...; PROF_END(ctx)

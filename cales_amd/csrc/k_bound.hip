@@ -48,8 +48,8 @@ static int launch_jobs(cales_ctx *c, BcJobs &J) {
   if (J.njobs == 0) return 0;
   const int na = J.idir == 1 ? c->n[1] : c->n[0], nb = J.idir == 3 ? c->n[1] : c->n[2];
   dim3 b(64, 4, 1), gr((na + 2 + 63) / 64, (nb + 2 + 3) / 4, J.njobs);
-  hipLaunchKernelGGL(k_set_bc, gr, b, 0, c->stream, c->g, J);
-  HIPCHK(c, hipGetLastError());
+  LAUNCH(c, k_set_bc, gr, b, 0, c->stream, c->g, J);
+  LAUNCHCHK(c);
   return 0;
 }
 static inline const real *plane(const DBound &b, int idir, int ibound, const int *n) {
@@ -106,8 +106,8 @@ static int launch_merged(cales_ctx *c, MJobs &J, const Geom *gg = nullptr) {
   const int n[3] = {G.n1, G.n2, G.n3};
   // one grid for the three regions: region 0 needs (n1+2) x (n2+2), region 1 (n2+2) x n3, region 2 n1 x n3 threads
   const int ex = std::max(n[0] + 2, n[1] + 2), ey = std::max(n[1] + 2, n[2]);
-  hipLaunchKernelGGL(k_bc_merged, dim3((ex + 63) / 64, (ey + 3) / 4, 3 * J.nf), dim3(64, 4, 1), 0, c->stream, G, J);
-  HIPCHK(c, hipGetLastError());
+  LAUNCH(c, k_bc_merged, dim3((ex + 63) / 64, (ey + 3) / 4, 3 * J.nf), dim3(64, 4, 1), 0, c->stream, G, J);
+  LAUNCHCHK(c);
   return 0;
 }
 // x periodic, y periodic on one rank or exchanged between slabs, z pointwise
@@ -155,13 +155,13 @@ static int halo_y_on(cales_ctx *c, int nf, real **flds, hipStream_t st, bool ove
   const int64_t cnt = (int64_t)G.s1 * (c->n[2] + 2) * planes;
   if (4 * cnt > c->comm.nbuf) { c->err = "halo staging buffer too small"; return 1; }
   dim3 b(64, 4, 1), gr(((G.s1 << anyw) + 63) / 64, (c->n[2] + 2 + 3) / 4, nf);
-  hipLaunchKernelGGL(k_pack_y, gr, b, 0, st, G, H, c->comm.A, c->comm.A + cnt);
+  LAUNCH(c, k_pack_y, gr, b, 0, st, G, H, c->comm.A, c->comm.A + cnt);
   { ProfScope ps(c, "halo_exchange", st);
     const int rc = overlapped ? c->comm.halo_s(c->comm.user, 0, cnt, 0, cnt, cnt, (void *)st) : c->comm.halo(c->comm.user, 0, cnt, 0, cnt, cnt);
     if (rc) { c->err = "halo callback failed"; return 1; } }
   const int has_lo = (c->per_y || c->rank > 0) ? 1 : 0, has_hi = (c->per_y || c->rank < c->P - 1) ? 1 : 0;
-  hipLaunchKernelGGL(k_unpack_y, gr, b, 0, st, G, H, c->comm.B, c->comm.B + cnt, has_lo, has_hi);
-  HIPCHK(c, hipGetLastError());
+  LAUNCH(c, k_unpack_y, gr, b, 0, st, G, H, c->comm.B, c->comm.B + cnt, has_lo, has_hi);
+  LAUNCHCHK(c);
   return 0;
 }
 static int halo_y_comm(cales_ctx *c, int nf, real **flds, bool wide = false) {
@@ -402,8 +402,8 @@ static int updt_wallmodelbc(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, co
     const int na = idir == 1 ? n[1] : n[0], nb = idir == 3 ? n[1] : n[2];
     gx = std::max(gx, (na + 2 + 63) / 64); gy = std::max(gy, (nb + 2 + 3) / 4);
   }
-  if (J.n) hipLaunchKernelGGL(k_wallmodel, dim3(gx, gy, 2 * J.n), dim3(64, 4, 1), 0, c->stream, c->g, J);
-  HIPCHK(c, hipGetLastError());
+  if (J.n) LAUNCH(c, k_wallmodel, dim3(gx, gy, 2 * J.n), dim3(64, 4, 1), 0, c->stream, c->g, J);
+  LAUNCHCHK(c);
   return 0;
 }
 
@@ -504,9 +504,9 @@ static int rhs_b_dir(cales_ctx *c, real *p, int idir, const char *cbc6, const ch
   for (int ib = 0; ib <= 1; ++ib) {
     if (!ISB(c, ib, idir)) continue;
     RhsJob J; J.p = p; J.rhs = rhs + (size_t)ib * na * nb; J.idir = idir; J.pos = ib ? n[idir - 1] - q : 1; J.na = na; J.nb = nb;
-    hipLaunchKernelGGL(k_updt_rhs_b, dim3((na + 63) / 64, (nb + 3) / 4), dim3(64, 4), 0, c->stream, c->g, J);
+    LAUNCH(c, k_updt_rhs_b, dim3((na + 63) / 64, (nb + 3) / 4), dim3(64, 4), 0, c->stream, c->g, J);
   }
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return 0;
 }
 static bool plane_all_zero(const cales_ctx *c, int idir) { (void)c; (void)idir; return false; }
@@ -562,11 +562,11 @@ int op_rhs_b_velxy(cales_ctx *c, int ivel, real alpha) {
     const int na = idir == 1 ? n[1] : n[0];
     for (int ib = 0; ib <= 1; ++ib) {
       if (!ISB(c, ib, idir) || cbc[ib] == 'P') continue;
-      hipLaunchKernelGGL(k_rhs_b_velxy, dim3((na + 63) / 64, (n[2] + 3) / 4), dim3(64, 4), 0, c->stream, c->g, c->f[CALES_U + ivel - 1],
+      LAUNCH(c, k_rhs_b_velxy, dim3((na + 63) / 64, (n[2] + 3) / 4), dim3(64, 4), 0, c->stream, c->g, c->f[CALES_U + ivel - 1],
                          plane(bc, idir, ib, n), idir, ib, cbc[ib], cf, c->dl[idir - 1], alpha, ib ? n[idir - 1] - q : 1);
     }
   }
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return 0;
 }
 // planes != nullptr: the two contributions go to planes[0 / n1*n2] instead of being added to the field; has[ib] tells which exist
@@ -583,16 +583,16 @@ int op_rhs_b_velz(cales_ctx *c, int ivel, real alpha, real *planes, int *has) {
     if (has) has[ib] = 1;
     const real dlc = cf == 'c' ? (ib ? c->dzc[n3] : c->dzc[0]) : (ib ? c->dzc[n3 - 1] : c->dzc[1]);
     const real dlf = ib ? c->dzf[n3] : c->dzf[1];
-    hipLaunchKernelGGL(k_rhs_b_velz, dim3((n[0] + 63) / 64, (n[1] + 3) / 4), dim3(64, 4), 0, c->stream, c->g, c->f[CALES_U + ivel - 1],
+    LAUNCH(c, k_rhs_b_velz, dim3((n[0] + 63) / 64, (n[1] + 3) / 4), dim3(64, 4), 0, c->stream, c->g, c->f[CALES_U + ivel - 1],
                        plane(bc, 3, ib, n), ib, cbc[ib], cf, dlc, dlf, alpha, ib ? n3 - q : 1, planes ? planes + (size_t)ib * n[0] * n[1] : nullptr);
   }
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return 0;
 }
 
 int op_xwrap_zghost(cales_ctx *c, int nf, real **f) {
   HaloFields H; H.nf = nf; for (int q = 0; q < nf; ++q) H.p[q] = f[q];
-  hipLaunchKernelGGL(k_xwrap_zghost, dim3((c->n[1] + 2 + 255) / 256, 2, nf), dim3(256), 0, c->stream, c->g, H);
-  HIPCHK(c, hipGetLastError());
+  LAUNCH(c, k_xwrap_zghost, dim3((c->n[1] + 2 + 255) / 256, 2, nf), dim3(256), 0, c->stream, c->g, H);
+  LAUNCHCHK(c);
   return 0;
 }

@@ -208,20 +208,20 @@ int op_momrk(cales_ctx *c, real f1, real f2, real f12) {
   const int nos = c->C.sgstype == 0 && c->visct_zero;     // visct known to be identically zero (never set by the host since the last zeroing)
 #define MOMRK_LAUNCH(IMP_)                                                                                             \
   do {                                                                                                                 \
-    if (small) { if (nos) hipLaunchKernelGGL((k_momrk<IMP_, unsigned, 1>), gr, b, 0, c->stream, c->g, A);              \
-                 else hipLaunchKernelGGL((k_momrk<IMP_, unsigned, 0>), gr, b, 0, c->stream, c->g, A); }                \
-    else { if (nos) hipLaunchKernelGGL((k_momrk<IMP_, size_t, 1>), gr, b, 0, c->stream, c->g, A);                      \
-           else hipLaunchKernelGGL((k_momrk<IMP_, size_t, 0>), gr, b, 0, c->stream, c->g, A); }                        \
+    if (small) { if (nos) LAUNCH(c, (k_momrk<IMP_, unsigned, 1>), gr, b, 0, c->stream, c->g, A);              \
+                 else LAUNCH(c, (k_momrk<IMP_, unsigned, 0>), gr, b, 0, c->stream, c->g, A); }                \
+    else { if (nos) LAUNCH(c, (k_momrk<IMP_, size_t, 1>), gr, b, 0, c->stream, c->g, A);                      \
+           else LAUNCH(c, (k_momrk<IMP_, size_t, 0>), gr, b, 0, c->stream, c->g, A); }                        \
   } while (0)
   if (c->C.impdiff == 2) MOMRK_LAUNCH(2); else if (c->C.impdiff == 1) MOMRK_LAUNCH(1); else MOMRK_LAUNCH(0);
 #undef MOMRK_LAUNCH
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   bool wm = false; for (int q = 0; q < 6; ++q) wm = wm || c->C.lwm[q] != 0;
   if (wm) {
     GhostCopy G; for (int q = 0; q < 3; ++q) { G.src[q] = c->f[CALES_U + q]; G.dst[q] = c->f2[q]; }
     const int na = std::max(n[0], n[1]), nb = std::max(n[1], n[2]);
-    hipLaunchKernelGGL(k_copy_ghosts, dim3((na + 2 + 63) / 64, (nb + 2 + 3) / 4, 18), dim3(64, 4, 1), 0, c->stream, c->g, G);
-    HIPCHK(c, hipGetLastError());
+    LAUNCH(c, k_copy_ghosts, dim3((na + 2 + 63) / 64, (nb + 2 + 3) / 4, 18), dim3(64, 4, 1), 0, c->stream, c->g, G);
+    LAUNCHCHK(c);
   }
   for (int q = 0; q < 3; ++q) std::swap(c->f[CALES_U + q], c->f2[q]);
   return 0;

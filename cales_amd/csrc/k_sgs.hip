@@ -56,9 +56,9 @@ static int extrapolate(cales_ctx *c, int nf, real **p, const int *iface, int mod
     }
     if (!J.njobs) continue;
     const int na = idir == 1 ? n[1] : n[0], nb = idir == 3 ? n[1] : n[2];
-    hipLaunchKernelGGL(k_extrapolate, dim3((na + 2 + 63) / 64, (nb + 2 + 3) / 4, J.njobs), dim3(64, 4), 0, c->stream, c->g, J);
+    LAUNCH(c, k_extrapolate, dim3((na + 2 + 63) / 64, (nb + 2 + 3) / 4, J.njobs), dim3(64, 4), 0, c->stream, c->g, J);
   }
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return 0;
 }
 
@@ -97,10 +97,10 @@ __global__ __launch_bounds__(BX *BY) void k_strain(Geom g, real dxi, real dyi, c
 static int strain_rate(cales_ctx *c, const real *u, const real *v, const real *w, real *s0, real **sij) {
   ProfScope ps(c, "strain_rate");
   dim3 b(BX, BY, 1), gr = grid3(c->n[0], c->n[1], c->n[2], b);
-  if (sij) hipLaunchKernelGGL(k_strain<1>, gr, b, 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, u, v, w, s0, sij[0], sij[1], sij[2], sij[3], sij[4], sij[5]);
-  else hipLaunchKernelGGL(k_strain<0>, gr, b, 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, u, v, w, s0, (real *)nullptr,
+  if (sij) LAUNCH(c, k_strain<1>, gr, b, 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, u, v, w, s0, sij[0], sij[1], sij[2], sij[3], sij[4], sij[5]);
+  else LAUNCH(c, k_strain<0>, gr, b, 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, u, v, w, s0, (real *)nullptr,
                           (real *)nullptr, (real *)nullptr, (real *)nullptr, (real *)nullptr, (real *)nullptr);
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return 0;
 }
 
@@ -262,8 +262,8 @@ int materialize_visct(cales_ctx *c) {
   if (!c->visct_lazy) return 0;
   c->visct_lazy = false;
   const int *n = c->n;
-  hipLaunchKernelGGL(k_scale_planes, dim3((n[0] + 2 + 63) / 64, (n[1] + 2 + 3) / 4, n[2] + 2), dim3(64, 4, 1), 0, c->stream, c->g, c->d_cs, c->f[CALES_VISCT]);
-  HIPCHK(c, hipGetLastError());
+  LAUNCH(c, k_scale_planes, dim3((n[0] + 2 + 63) / 64, (n[1] + 2 + 3) / 4, n[2] + 2), dim3(64, 4, 1), 0, c->stream, c->g, c->d_cs, c->f[CALES_VISCT]);
+  LAUNCHCHK(c);
   return 0;
 }
 __global__ __launch_bounds__(256) void k_alph2(Geom g, real w0, real w1, real w2, real w3, real w4, real w5, real *__restrict__ alph2) {
@@ -738,17 +738,18 @@ struct StrainTileArgs {
 // sqrt(tau_w) at the two y walls for every (i, k): the argument of the van Driest damping of the cells whose nearest wall is a y wall
 // (sgs.f90:117-143, cases 3 and 4 of the select), from the fields themselves (their ghost cells, not the extrapolated ones)
 __global__ __launch_bounds__(256) void k_wall_shear_y(Geom g, const real *__restrict__ u, const real *__restrict__ w, real visc, real dyi,
-                                                      int lo, int hi, real *__restrict__ twy) {
+                                                      int lo, int hi, real *__restrict__ twy, int perx) {
   const int i = blockIdx.x * 64 + threadIdx.x + 1, k = blockIdx.y * 4 + threadIdx.y + 1;
   if (i > g.n1 || k > g.n3) return;
   const int n2 = g.n2;
+  const int im1 = (perx && i == 1) ? g.n1 : i - 1;      // x periodic inside cales_step: the wrapped interior column, the ghost column 0 may be stale (step_xskip)
   if (lo) {
-    const real t1 = u[g.ix(i, 1, k)] - u[g.ix(i, 0, k)] + u[g.ix(i - 1, 1, k)] - u[g.ix(i - 1, 0, k)];
+    const real t1 = u[g.ix(i, 1, k)] - u[g.ix(i, 0, k)] + u[g.ix(im1, 1, k)] - u[g.ix(im1, 0, k)];
     const real t2 = w[g.ix(i, 1, k)] - w[g.ix(i, 0, k)] + w[g.ix(i, 1, k - 1)] - w[g.ix(i, 0, k - 1)];
     twy[(size_t)k * g.s1 + i] = sqrt(0.5 * visc * (sqrt(t1 * t1 + t2 * t2) * dyi));
   }
   if (hi) {
-    const real t1 = u[g.ix(i, n2, k)] - u[g.ix(i, n2 + 1, k)] + u[g.ix(i - 1, n2, k)] - u[g.ix(i - 1, n2 + 1, k)];
+    const real t1 = u[g.ix(i, n2, k)] - u[g.ix(i, n2 + 1, k)] + u[g.ix(im1, n2, k)] - u[g.ix(im1, n2 + 1, k)];
     const real t2 = w[g.ix(i, n2, k)] - w[g.ix(i, n2 + 1, k)] + w[g.ix(i, n2, k - 1)] - w[g.ix(i, n2 + 1, k - 1)];
     twy[(size_t)(g.n3 + 2 + k) * g.s1 + i] = sqrt(0.5 * visc * (sqrt(t1 * t1 + t2 * t2) * dyi));
   }
@@ -1096,9 +1097,9 @@ static int dsmag_fast(cales_ctx *c) {
     S.wylo = wylo; S.wyhi = wyhi; S.wmylo = wmylo; S.wmyhi = wmyhi; S.twy = nullptr; S.dl2 = c->dl[1];
     S.bm = BandMap{0, 0, 0, 0}; S.perx = c->step_xskip ? 1 : 0;
     if (!c->fl.plain_grid && (band_wanted(mg.x) || c->fl.band_grid)) { S.bm = band_map(mg.x, mg.y, mg.z); mg = dim3(band_blocks(S.bm), 1, 1); }
-    if (wylo || wyhi || wmylo || wmyhi) { if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 0, TYS, 1>), mg, mb, 0, c->stream, c->g, S); else hipLaunchKernelGGL((k_strain_tile<size_t, 0, TYS, 1>), mg, mb, 0, c->stream, c->g, S); }
-    else if (pair) hipLaunchKernelGGL((k_strain_tile<unsigned, 0, TYS, 0, 1>), mg, mb, 0, c->stream, c->g, S);
-    else if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 0, TYS, 0>), mg, mb, 0, c->stream, c->g, S); else hipLaunchKernelGGL((k_strain_tile<size_t, 0, TYS, 0>), mg, mb, 0, c->stream, c->g, S); }
+    if (wylo || wyhi || wmylo || wmyhi) { if (small) LAUNCH(c, (k_strain_tile<unsigned, 0, TYS, 1>), mg, mb, 0, c->stream, c->g, S); else LAUNCH(c, (k_strain_tile<size_t, 0, TYS, 1>), mg, mb, 0, c->stream, c->g, S); }
+    else if (pair) LAUNCH(c, (k_strain_tile<unsigned, 0, TYS, 0, 1>), mg, mb, 0, c->stream, c->g, S);
+    else if (small) LAUNCH(c, (k_strain_tile<unsigned, 0, TYS, 0>), mg, mb, 0, c->stream, c->g, S); else LAUNCH(c, (k_strain_tile<size_t, 0, TYS, 0>), mg, mb, 0, c->stream, c->g, S); }
   // sgs-type ghost cells: only the periodic exchange matters (products of ghosts = ghosts of products; the wall ghosts are
   // replaced by the extrapolation rule inside the filters)
   // These twelve scratch fields are read by the tile kernels only: with periodic x their ghost columns are not filled (the
@@ -1123,7 +1124,7 @@ static int dsmag_fast(cales_ctx *c) {
   c->bc_skip = perx | skipz;
   if (!e_ && !ucf) { real *cc[3] = {c->uc, c->vc, c->wc}; e_ = op_boundp_multi(c, 3, cc, 1); }
   if (!e_ && ucf && !(wylo && wyhi)) {      // v_c of the rows 1 and n2 only: their copies in the ghost rows (periodic wrap or the slab neighbours') are what the last pass reads for row 0
-    hipLaunchKernelGGL(k_vc_edge_rows, dim3((n[0] + 2 + 63) / 64, (n[2] + 2 + 3) / 4), dim3(64, 4), 0, c->stream, c->g, f[CALES_V], c->vc);
+    LAUNCH(c, k_vc_edge_rows, dim3((n[0] + 2 + 63) / 64, (n[2] + 2 + 3) / 4), dim3(64, 4), 0, c->stream, c->g, f[CALES_V], c->vc);
     real *cc[1] = {c->vc}; e_ = op_boundp_multi(c, 1, cc, 1); }
   c->bc_skip = 0;
   if (!e_ && lazy && c->in_step && c->P > 1) { e_ = op_boundp(c, visct, 1); c->visct_bc_done = !e_; }      // |S| is final (K_AC wrote it): its rows travel along
@@ -1151,8 +1152,8 @@ static int dsmag_fast(cales_ctx *c) {
       B.bm = BandMap{0, 0, 0, 0};
       if (!c->fl.plain_grid && (band_wanted(mg.x) || c->fl.band_grid)) { B.bm = band_map(mg.x, nby, mg.z); gg = dim3(band_blocks(B.bm), 1, 1); }
       const bool yw = wylo || wyhi || wmylo || wmyhi;
-#define LMF_LAUNCH(YWV, UCV) do { if (small) hipLaunchKernelGGL((k_lmf_tile<unsigned, YWV, UCV>), gg, mb, 0, c->stream, c->g, B); else hipLaunchKernelGGL((k_lmf_tile<size_t, YWV, UCV>), gg, mb, 0, c->stream, c->g, B); } while (0)
-      if (pair) { if (ucf) hipLaunchKernelGGL((k_lmf_tile<unsigned, 0, 1, 1>), gg, mb, 0, c->stream, c->g, B); else hipLaunchKernelGGL((k_lmf_tile<unsigned, 0, 0, 1>), gg, mb, 0, c->stream, c->g, B); }
+#define LMF_LAUNCH(YWV, UCV) do { if (small) LAUNCH(c, (k_lmf_tile<unsigned, YWV, UCV>), gg, mb, 0, c->stream, c->g, B); else LAUNCH(c, (k_lmf_tile<size_t, YWV, UCV>), gg, mb, 0, c->stream, c->g, B); } while (0)
+      if (pair) { if (ucf) LAUNCH(c, (k_lmf_tile<unsigned, 0, 1, 1>), gg, mb, 0, c->stream, c->g, B); else LAUNCH(c, (k_lmf_tile<unsigned, 0, 0, 1>), gg, mb, 0, c->stream, c->g, B); }
       else if (yw) { if (ucf) LMF_LAUNCH(1, 1); else LMF_LAUNCH(1, 0); } else { if (ucf) LMF_LAUNCH(0, 1); else LMF_LAUNCH(0, 0); }
 #undef LMF_LAUNCH
     };
@@ -1163,29 +1164,29 @@ static int dsmag_fast(cales_ctx *c) {
       if (int e = stream_after(c, c->stream, c->comm_stream)) return e;
       launch(0, 1); launch(hi0, (int)mg.y - hi0);
     } else launch(0, (int)mg.y);
-    hipLaunchKernelGGL(k_plane_fold, dim3(2 * n[2]), dim3(256), 0, c->stream, n[2], L.nblk, c->wk[0], c->d_p1d);
+    LAUNCH(c, k_plane_fold, dim3(2 * n[2]), dim3(256), 0, c->stream, n[2], L.nblk, c->wk[0], c->d_p1d);
   } else {
   // K_B: filter(|S| Sij)
   { ProfScope ps(c, "filter_s0sij");
     tiles(TYB, 64, mb, mg, kch);
     Filter6Args A; A.kchunk = kch; A.zlo = zlo; A.zhi = zhi; A.perx = perx;
     for (int m = 0; m < 6; ++m) { A.in[m] = ssij[m]; A.out[m] = mij[m]; }
-    if (small) hipLaunchKernelGGL(k_filter6_tile<unsigned>, mg, mb, 0, c->stream, c->g, A); else hipLaunchKernelGGL(k_filter6_tile<size_t>, mg, mb, 0, c->stream, c->g, A); }
+    if (small) LAUNCH(c, k_filter6_tile<unsigned>, mg, mb, 0, c->stream, c->g, A); else LAUNCH(c, k_filter6_tile<size_t>, mg, mb, 0, c->stream, c->g, A); }
   // K_DF: strain rate of the filtered velocity, Mij, Lij, contractions and plane partial sums in one pass
   { ProfScope ps(c, "lij_mij_contract");
     tiles(TYF, 62, mb, mg, kch);
     L.kchunk = kch; L.nblk = mg.x * mg.y;
-    if (small) hipLaunchKernelGGL(k_lij_mij_tile<unsigned>, mg, mb, 0, c->stream, c->g, L); else hipLaunchKernelGGL(k_lij_mij_tile<size_t>, mg, mb, 0, c->stream, c->g, L);
-    hipLaunchKernelGGL(k_plane_fold, dim3(2 * n[2]), dim3(256), 0, c->stream, n[2], L.nblk, c->wk[0], c->d_p1d); }
+    if (small) LAUNCH(c, k_lij_mij_tile<unsigned>, mg, mb, 0, c->stream, c->g, L); else LAUNCH(c, k_lij_mij_tile<size_t>, mg, mb, 0, c->stream, c->g, L);
+    LAUNCH(c, k_plane_fold, dim3(2 * n[2]), dim3(256), 0, c->stream, n[2], L.nblk, c->wk[0], c->d_p1d); }
   }
   if (c->P > 1) { if (int e = allreduce_res(c, (int)(c->d_p1d - c->res), 2 * n[2], 0)) return e; }   // sgs.f90:475
   const real gar = c->dl[0] * c->dl[1] / (c->C.l[0] * c->C.l[1]);
   if (lazy) {
     if (!c->d_cs) HIPCHK(c, hipMalloc(&c->d_cs, (n[2] + 2) * sizeof(real)));
-    hipLaunchKernelGGL(k_dsmag_coef, dim3(1), dim3(256), 0, c->stream, n[2], gar, c->d_p1d, c->d_cs, CBP(c, 0, 3) == 'P' && CBP(c, 1, 3) == 'P' ? 1 : 0);
+    LAUNCH(c, k_dsmag_coef, dim3(1), dim3(256), 0, c->stream, n[2], gar, c->d_p1d, c->d_cs, CBP(c, 0, 3) == 'P' && CBP(c, 1, 3) == 'P' ? 1 : 0);
     c->visct_lazy = true;
-  } else hipLaunchKernelGGL(k_dsmag_final, gr, b, 0, c->stream, c->g, gar, c->d_p1d, c->s0, visct);
-  HIPCHK(c, hipGetLastError());
+  } else LAUNCH(c, k_dsmag_final, gr, b, 0, c->stream, c->g, gar, c->d_p1d, c->s0, visct);
+  LAUNCHCHK(c);
   return 0;
 }
 
@@ -1219,8 +1220,8 @@ static int wall_shear_y_planes(cales_ctx *c, int wylo, int wyhi, const real **ou
   } else if (cnt > c->ntot) { c->err = "smag: wall-shear scratch too small"; return 1; }
   const int lo = wylo && ISB(c, 0, 2) ? 1 : 0, hi = wyhi && ISB(c, 1, 2) ? 1 : 0;
   if (lo || hi)
-    hipLaunchKernelGGL(k_wall_shear_y, dim3((n[0] + 63) / 64, (n[2] + 3) / 4), dim3(64, 4), 0, c->stream, c->g, c->f[CALES_U], c->f[CALES_W], c->visc, c->dli[1], lo, hi, twy);
-  HIPCHK(c, hipGetLastError());
+    LAUNCH(c, k_wall_shear_y, dim3((n[0] + 63) / 64, (n[2] + 3) / 4), dim3(64, 4), 0, c->stream, c->g, c->f[CALES_U], c->f[CALES_W], c->visc, c->dli[1], lo, hi, twy, c->step_xskip ? 1 : 0);
+  LAUNCHCHK(c);
   if (c->P > 1 && c->comm.allred(c->comm.user, 0, (int64_t)cnt, 0)) { c->err = "allreduce callback failed (wall-shear planes)"; return 1; }
   *out = twy;
   return 0;
@@ -1229,11 +1230,12 @@ static int smag_fast(cales_ctx *c) {
   const int *n = c->n; real **f = c->f;
   if (!c->d_del) {
     HIPCHK(c, hipMalloc(&c->d_del, (n[2] + 2) * sizeof(real)));
-    hipLaunchKernelGGL(k_smag_del, dim3((n[2] + 2 + 63) / 64), dim3(64), 0, c->stream, n[2] + 2, c->dl[0], c->dl[1], c->d_dzf, c->d_del);
+    LAUNCH(c, k_smag_del, dim3((n[2] + 2 + 63) / 64), dim3(64), 0, c->stream, n[2] + 2, c->dl[0], c->dl[1], c->d_dzf, c->d_del);
   }
-  // tile height of the Smagorinsky pass: the pass is bound by latency (one barrier pair per plane, two square roots and an exponential per
-  // cell), not by bandwidth, so several small blocks per CU beat one block of sixteen waves (measured: 10 rows beat 14 by 5-33 % from 256x128x128 to 512^3 and 6 rows lose; CALES_SMAG_TY = 6, 10, 14 for A/B runs)
-  const int TYM = c->fl.smag_ty;
+  // tile height of the LDS-tile form (CALES_SMAG_TILE): the pass is bound by latency (one barrier pair per plane, two square roots and an exponential
+  // per cell), not by bandwidth, so several small blocks per CU beat one block of sixteen waves (measured in round 2: 10 rows beat 14 by 5-33 % from
+  // 256x128x128 to 512^3 and 6 rows lose; the run-time choice CALES_SMAG_TY went with its A/B)
+  constexpr int TYM = 10;
   dim3 mb(64, TYM + 2, 1), mg((n[0] + 63) / 64, (n[1] + TYM - 1) / TYM, 1);
   int kch = n[2];
   while ((long)mg.x * mg.y * ((n[2] + kch - 1) / kch) < tile_min_blocks(c) && kch > 32) kch = (kch + 1) / 2;
@@ -1266,18 +1268,18 @@ static int smag_fast(cales_ctx *c) {
     if (int fk = tile_kchunk(c, (long)rgx * rgy, n[2])) kr = fk;
     S.kchunk = kr; S.bm = band_map(rgx, rgy, (n[2] + kr - 1) / kr);
     const dim3 rg(band_blocks(S.bm), 1, 1);
-    if (yw) { if (small) hipLaunchKernelGGL((k_smag_rows<unsigned, 1>), rg, rb, 0, c->stream, c->g, S); else hipLaunchKernelGGL((k_smag_rows<size_t, 1>), rg, rb, 0, c->stream, c->g, S); }
-    else if (small) hipLaunchKernelGGL((k_smag_rows<unsigned, 0>), rg, rb, 0, c->stream, c->g, S); else hipLaunchKernelGGL((k_smag_rows<size_t, 0>), rg, rb, 0, c->stream, c->g, S);
-    HIPCHK(c, hipGetLastError());
+    if (yw) { if (small) LAUNCH(c, (k_smag_rows<unsigned, 1>), rg, rb, 0, c->stream, c->g, S); else LAUNCH(c, (k_smag_rows<size_t, 1>), rg, rb, 0, c->stream, c->g, S); }
+    else if (small) LAUNCH(c, (k_smag_rows<unsigned, 0>), rg, rb, 0, c->stream, c->g, S); else LAUNCH(c, (k_smag_rows<size_t, 0>), rg, rb, 0, c->stream, c->g, S);
+    LAUNCHCHK(c);
     return 0;
   }
-#define SMAG_LAUNCH(TYV) do { if (yw) { if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 1, TYV, 1>), mg, mb, 0, c->stream, c->g, S); \
-                                         else hipLaunchKernelGGL((k_strain_tile<size_t, 1, TYV, 1>), mg, mb, 0, c->stream, c->g, S); } \
-                              else if (small) hipLaunchKernelGGL((k_strain_tile<unsigned, 1, TYV, 0>), mg, mb, 0, c->stream, c->g, S); \
-                              else hipLaunchKernelGGL((k_strain_tile<size_t, 1, TYV, 0>), mg, mb, 0, c->stream, c->g, S); } while (0)
-  if (TYM == 6) SMAG_LAUNCH(6); else if (TYM == 10) SMAG_LAUNCH(10); else SMAG_LAUNCH(14);
+#define SMAG_LAUNCH(TYV) do { if (yw) { if (small) LAUNCH(c, (k_strain_tile<unsigned, 1, TYV, 1>), mg, mb, 0, c->stream, c->g, S); \
+                                         else LAUNCH(c, (k_strain_tile<size_t, 1, TYV, 1>), mg, mb, 0, c->stream, c->g, S); } \
+                              else if (small) LAUNCH(c, (k_strain_tile<unsigned, 1, TYV, 0>), mg, mb, 0, c->stream, c->g, S); \
+                              else LAUNCH(c, (k_strain_tile<size_t, 1, TYV, 0>), mg, mb, 0, c->stream, c->g, S); } while (0)
+  SMAG_LAUNCH(10);
 #undef SMAG_LAUNCH
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return 0;
 }
 
@@ -1300,7 +1302,7 @@ int op_cmpt_sgs(cales_ctx *c) {
   if (c->sgs_first) {
     c->sgs_first = false;
     if (c->C.sgstype == 2)
-      hipLaunchKernelGGL(k_alph2, grid3(n[0] + 2, n[1] + 2, n[2] + 2, dim3(64, 4, 1)), dim3(64, 4, 1), 0, c->stream, c->g, c->is_wall[0], c->is_wall[1],
+      LAUNCH(c, k_alph2, grid3(n[0] + 2, n[1] + 2, n[2] + 2, dim3(64, 4, 1)), dim3(64, 4, 1), 0, c->stream, c->g, c->is_wall[0], c->is_wall[1],
                          c->is_wall[2], c->is_wall[3], c->is_wall[4], c->is_wall[5], c->alph2);
   }
   if (c->C.sgstype == 2 && dsmag_fast_ok(c)) return dsmag_fast(c);
@@ -1317,7 +1319,7 @@ int op_cmpt_sgs(cales_ctx *c) {
       if (int e = strain_rate(c, uvw[0], uvw[1], uvw[2], c->s0, nullptr)) return e;
       if (int e = extrapolate(c, 3, uvw, if123, 0, wk[0], 1)) return e;
     } else {            // degenerate grids: the copies of the reference
-      hipLaunchKernelGGL(k_copy3, lin_grid(nt), dim3(256), 0, c->stream, nt, f[CALES_U], f[CALES_V], f[CALES_W], wk[0], wk[1], wk[2]);
+      LAUNCH(c, k_copy3, lin_grid(nt), dim3(256), 0, c->stream, nt, f[CALES_U], f[CALES_V], f[CALES_W], wk[0], wk[1], wk[2]);
       if (int e = extrapolate(c, 3, wk, if123, 0)) return e;
       if (int e = strain_rate(c, wk[0], wk[1], wk[2], c->s0, nullptr)) return e;
     }
@@ -1326,56 +1328,56 @@ int op_cmpt_sgs(cales_ctx *c) {
     A.sumw = 0.; for (int q = 0; q < 6; ++q) A.sumw += c->is_wall[q];
     if (!c->d_del) {
       HIPCHK(c, hipMalloc(&c->d_del, (n[2] + 2) * sizeof(real)));
-      hipLaunchKernelGGL(k_smag_del, dim3((n[2] + 2 + 63) / 64), dim3(64), 0, c->stream, n[2] + 2, c->dl[0], c->dl[1], c->d_dzf, c->d_del);
+      LAUNCH(c, k_smag_del, dim3((n[2] + 2 + 63) / 64), dim3(64), 0, c->stream, n[2] + 2, c->dl[0], c->dl[1], c->d_dzf, c->d_del);
     }
     const real *twy = nullptr;      // several slabs: the shear of the y walls comes from the slabs that own them
     if (c->P > 1 && (c->is_wall[2] != 0. || c->is_wall[3] != 0.)) { if (int e = wall_shear_y_planes(c, c->is_wall[2] != 0., c->is_wall[3] != 0., &twy)) return e; }
-    hipLaunchKernelGGL(k_smag, gr, b, 0, c->stream, c->g, A, c->d_zc, c->d_dzci, c->d_del, f[CALES_U], f[CALES_V], f[CALES_W], c->s0, visct, twy);
-    HIPCHK(c, hipGetLastError());
+    LAUNCH(c, k_smag, gr, b, 0, c->stream, c->g, A, c->d_zc, c->d_dzci, c->d_del, f[CALES_U], f[CALES_V], f[CALES_W], c->s0, visct, twy);
+    LAUNCHCHK(c);
     return 0;
   }
   // ---- dynamic model (sgs.f90:153-380): wk(1:3) = u,v,w ; extrapolate at wall-model faces ; strain rate (sgs.f90:173-181)
-  hipLaunchKernelGGL(k_copy3, lin_grid(nt), dim3(256), 0, c->stream, nt, f[CALES_U], f[CALES_V], f[CALES_W], wk[0], wk[1], wk[2]);
+  LAUNCH(c, k_copy3, lin_grid(nt), dim3(256), 0, c->stream, nt, f[CALES_U], f[CALES_V], f[CALES_W], wk[0], wk[1], wk[2]);
   if (int e = extrapolate(c, 3, wk, if123, 0)) return e;
   real **sij = c->sij, **mij = c->mij, **lij = c->sij;
   if (int e = strain_rate(c, wk[0], wk[1], wk[2], c->s0, sij)) return e;
-  hipLaunchKernelGGL(k_copy1, lin_grid(nt), dim3(256), 0, c->stream, nt, c->s0, visct);
+  LAUNCH(c, k_copy1, lin_grid(nt), dim3(256), 0, c->stream, nt, c->s0, visct);
   if (int e = op_boundp(c, c->s0, 1)) return e;
   for (int m = 0; m < 6; ++m) if (int e = op_boundp(c, sij[m], 1)) return e;
   CP6 csij; P6 pwk, pmij; CP6 cmij;
   for (int m = 0; m < 6; ++m) { csij.p[m] = sij[m]; pwk.p[m] = wk[m]; pmij.p[m] = mij[m]; cmij.p[m] = mij[m]; }
-  hipLaunchKernelGGL(k_s0sij, lin_grid(nt), dim3(256), 0, c->stream, nt, c->s0, csij, pwk);
+  LAUNCH(c, k_s0sij, lin_grid(nt), dim3(256), 0, c->stream, nt, c->s0, csij, pwk);
   const int if0[6] = {0, 0, 0, 0, 0, 0};
   if (int e = extrapolate(c, 6, wk, if0, 1)) return e;
-  for (int m = 0; m < 6; ++m) hipLaunchKernelGGL(k_filter3d, gr, b, 0, c->stream, c->g, wk[m], mij[m]);
-  hipLaunchKernelGGL(k_copy3, lin_grid(nt), dim3(256), 0, c->stream, nt, f[CALES_U], f[CALES_V], f[CALES_W], wk[0], wk[1], wk[2]);
+  for (int m = 0; m < 6; ++m) LAUNCH(c, k_filter3d, gr, b, 0, c->stream, c->g, wk[m], mij[m]);
+  LAUNCH(c, k_copy3, lin_grid(nt), dim3(256), 0, c->stream, nt, f[CALES_U], f[CALES_V], f[CALES_W], wk[0], wk[1], wk[2]);
   if (int e = extrapolate(c, 3, wk, if123, 1)) return e;
-  hipLaunchKernelGGL(k_filter3d, gr, b, 0, c->stream, c->g, wk[0], c->uf);
-  hipLaunchKernelGGL(k_filter3d, gr, b, 0, c->stream, c->g, wk[1], c->vf);
-  hipLaunchKernelGGL(k_filter3d, gr, b, 0, c->stream, c->g, wk[2], c->wf);
+  LAUNCH(c, k_filter3d, gr, b, 0, c->stream, c->g, wk[0], c->uf);
+  LAUNCH(c, k_filter3d, gr, b, 0, c->stream, c->g, wk[1], c->vf);
+  LAUNCH(c, k_filter3d, gr, b, 0, c->stream, c->g, wk[2], c->wf);
   if (int e = op_bounduvw(c, c->bcuf, c->bcvf, c->bcwf, 0, 0, c->uf, c->vf, c->wf)) return e;
   real *ff[3] = {c->uf, c->vf, c->wf};
   if (int e = extrapolate(c, 3, ff, if123, 0)) return e;
   if (int e = strain_rate(c, c->uf, c->vf, c->wf, c->s0, sij)) return e;
-  hipLaunchKernelGGL(k_mij, gr, b, 0, c->stream, c->g, pmij, c->alph2, c->s0, csij);
-  hipLaunchKernelGGL(k_interp, gr, b, 0, c->stream, c->g, f[CALES_U], f[CALES_V], f[CALES_W], c->uc, c->vc, c->wc);
+  LAUNCH(c, k_mij, gr, b, 0, c->stream, c->g, pmij, c->alph2, c->s0, csij);
+  LAUNCH(c, k_interp, gr, b, 0, c->stream, c->g, f[CALES_U], f[CALES_V], f[CALES_W], c->uc, c->vc, c->wc);
   if (int e = op_boundp(c, c->uc, 1)) return e;
   if (int e = op_boundp(c, c->vc, 1)) return e;
   if (int e = op_boundp(c, c->wc, 1)) return e;
-  hipLaunchKernelGGL(k_uiuj, lin_grid(nt), dim3(256), 0, c->stream, nt, c->uc, c->vc, c->wc, pwk);
+  LAUNCH(c, k_uiuj, lin_grid(nt), dim3(256), 0, c->stream, nt, c->uc, c->vc, c->wc, pwk);
   if (int e = extrapolate(c, 6, wk, if0, 1)) return e;
-  for (int m = 0; m < 6; ++m) hipLaunchKernelGGL(k_filter3d, gr, b, 0, c->stream, c->g, wk[m], lij[m]);
+  for (int m = 0; m < 6; ++m) LAUNCH(c, k_filter3d, gr, b, 0, c->stream, c->g, wk[m], lij[m]);
   real *cc[3] = {c->uc, c->vc, c->wc};
   if (int e = extrapolate(c, 3, cc, if0, 1)) return e;
-  hipLaunchKernelGGL(k_filter3d, gr, b, 0, c->stream, c->g, c->uc, c->uf);
-  hipLaunchKernelGGL(k_filter3d, gr, b, 0, c->stream, c->g, c->vc, c->vf);
-  hipLaunchKernelGGL(k_filter3d, gr, b, 0, c->stream, c->g, c->wc, c->wf);
+  LAUNCH(c, k_filter3d, gr, b, 0, c->stream, c->g, c->uc, c->uf);
+  LAUNCH(c, k_filter3d, gr, b, 0, c->stream, c->g, c->vc, c->vf);
+  LAUNCH(c, k_filter3d, gr, b, 0, c->stream, c->g, c->wc, c->wf);
   CP6 clij; for (int m = 0; m < 6; ++m) clij.p[m] = lij[m];
-  hipLaunchKernelGGL(k_contract, gr, b, 0, c->stream, c->g, cmij, clij, c->uf, c->vf, c->wf, wk[0], wk[1]);
-  hipLaunchKernelGGL(k_plane_sum, dim3(n[2], 2), dim3(256), 0, c->stream, c->g, wk[0], wk[1], c->d_p1d);
+  LAUNCH(c, k_contract, gr, b, 0, c->stream, c->g, cmij, clij, c->uf, c->vf, c->wf, wk[0], wk[1]);
+  LAUNCH(c, k_plane_sum, dim3(n[2], 2), dim3(256), 0, c->stream, c->g, wk[0], wk[1], c->d_p1d);
   if (c->P > 1) { if (int e = allreduce_res(c, (int)(c->d_p1d - c->res), 2 * n[2], 0)) return e; }   // sgs.f90:475
   const real gar = c->dl[0] * c->dl[1] / (c->C.l[0] * c->C.l[1]);
-  hipLaunchKernelGGL(k_dsmag_final, gr, b, 0, c->stream, c->g, gar, c->d_p1d, visct, visct);
-  HIPCHK(c, hipGetLastError());
+  LAUNCH(c, k_dsmag_final, gr, b, 0, c->stream, c->g, gar, c->d_p1d, visct, visct);
+  LAUNCHCHK(c);
   return 0;
 }

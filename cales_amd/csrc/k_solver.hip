@@ -1091,15 +1091,16 @@ static void launch_gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, real l
                                 real *p, int fixnull, const TileMap &T) {
   constexpr int W = gt_width(M, NV), lds = W * (64 * (M + 1) + 4) * 8 + (GT_TL && M == 16 ? 2 * 64 * M * 8 : 0);
   static bool once = false;
-  if (!once) { hipFuncSetAttribute((const void *)k_gaussel_tile<M, NV, PER>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
-  if (!c->d_abct) { if (hipMalloc(&c->d_abct, 2 * 3 * 64 * 16 * sizeof(real)) != hipSuccess) { c->d_abct = nullptr; return; } }
+  if (!once) { HIPSOFT(c, hipFuncSetAttribute((const void *)k_gaussel_tile<M, NV, PER>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); once = true; }
+  // (a failed allocation fails the context: launch_failed is sticky, op_solver's LAUNCHCHK returns it -- the z solve is never skipped silently)
+  if (!c->d_abct) { const hipError_t e = hipMalloc(&c->d_abct, 2 * 3 * 64 * 16 * sizeof(real)); if (e != hipSuccess) { c->d_abct = nullptr; launch_failed(c, "hipMalloc(tridiagonal coefficient table)", e); return; } }
   // the pressure operands never change: their table is built once (Helmholtz operands are rescaled every substep -> second table)
   const bool pressure = da == c->d_a;
   real *tab = c->d_abct + (pressure ? 0 : 3 * 64 * 16);
   // (periodic z: the table holds the n-1 rows of the system proper; identity rows from row n on)
-  if (!pressure || !c->abct_ready) hipLaunchKernelGGL(k_abc_chunked, dim3((64 * M + 255) / 256), dim3(256), 0, c->stream, PER ? nz - 1 : nz, M, da, db, dc, tab);
+  if (!pressure || !c->abct_ready) LAUNCH(c, k_abc_chunked, dim3((64 * M + 255) / 256), dim3(256), 0, c->stream, PER ? nz - 1 : nz, M, da, db, dc, tab);
   if (pressure) c->abct_ready = true;
-  hipLaunchKernelGGL((k_gaussel_tile<M, NV, PER>), dim3((ndbl + W - 1) / W, nrow), dim3(64 * W / NV), lds, c->stream, c->g, nz, ndbl, lscale, tab,
+  LAUNCH(c, (k_gaussel_tile<M, NV, PER>), dim3((ndbl + W - 1) / W, nrow), dim3(64 * W / NV), lds, c->stream, c->g, nz, ndbl, lscale, tab,
                      c->d_lamx, c->d_lamy, p, fixnull, T, da, db, dc);
 }
 // one rank: ndbl doubles of each of the nrow rows; several ranks (T.blocked): nrow = peers, ndbl = 2 cw n2l doubles per plane of a peer block
@@ -1257,13 +1258,13 @@ int solver_setup(cales_ctx *c) {
                while (CB > 1 && ((size_t)CB * (n2g + n2g / 8 + 1) + n2g) * sizeof(cpx) > 150 * 1024) CB /= 2;
                sp.y8_threads = CB * T; sp.shy8 = ((size_t)CB * (n2g + n2g / 8 + 1) + n2g) * sizeof(cpx);
                sp.shy8r = ((size_t)CB * ((((n2g + n2g / 8) + 15) & ~15) + 4) + n2g) * sizeof(cpx);      // k_fft_y8r: line pitch = 4 (mod 16) slots
-               if (sp.shy8r > 64 * 1024) { hipFuncSetAttribute((const void *)k_fft_y8r<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8r);
-                                           hipFuncSetAttribute((const void *)k_fft_y8r<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8r); }
+               if (sp.shy8r > 64 * 1024) { HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y8r<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8r));
+                                           HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y8r<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8r)); }
                if (sp.shy8 > 64 * 1024) {      // n2 = 1024: 4 columns (64-B row segments) need 90 KB of LDS
-                 hipFuncSetAttribute((const void *)k_fft_y8<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8);
-                 hipFuncSetAttribute((const void *)k_fft_y8<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8);
-                 hipFuncSetAttribute((const void *)k_fft_y8<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8);
-                 hipFuncSetAttribute((const void *)k_fft_y8<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8); } }
+                 HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y8<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8));
+                 HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y8<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8));
+                 HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y8<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8));
+                 HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y8<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8)); } }
   if (c->ykind >= 3) {      // DCT-IV / DST-IV in y: N/2-point lines, two per complex column
     if (!make_plan(n2g / 2, sp.py4)) { c->err = "solver: ng(2)/2 must factor into primes <= 127"; return 1; }
     sp.CBy4 = 4; sp.shy4 = (size_t)2 * sp.CBy4 * 2 * (n2g / 2 + 1) * sizeof(cpx);
@@ -1466,10 +1467,10 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
       const long rb = (long)n[1] * kpc * ch, re = rb + rows_c;
       { ProfScope ps(c, fill ? "fillps_fft_x_fwd" : "fft_x_fwd");
         F.pofs = (int)(xblocks_c * ch);
-        if (fill && c->xkind) hipLaunchKernelGGL((k_fft_x8<0, 1, 1>), dim3(xblocks_c), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters_c, (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec, F, rb, re);
-        else if (fill) hipLaunchKernelGGL((k_fft_x8<0, 0, 1>), dim3(xblocks_c), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters_c, (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec, F, rb, re);
-        else if (c->xkind) hipLaunchKernelGGL((k_fft_x8<0, 1>), dim3(xblocks_c), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters_c, (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec, FillArgs{}, rb, re);
-        else hipLaunchKernelGGL((k_fft_x8<0, 0>), dim3(xblocks_c), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters_c, (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec, FillArgs{}, rb, re); }
+        if (fill && c->xkind) LAUNCH(c, (k_fft_x8<0, 1, 1>), dim3(xblocks_c), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters_c, (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec, F, rb, re);
+        else if (fill) LAUNCH(c, (k_fft_x8<0, 0, 1>), dim3(xblocks_c), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters_c, (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec, F, rb, re);
+        else if (c->xkind) LAUNCH(c, (k_fft_x8<0, 1>), dim3(xblocks_c), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters_c, (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec, FillArgs{}, rb, re);
+        else LAUNCH(c, (k_fft_x8<0, 0>), dim3(xblocks_c), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters_c, (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec, FillArgs{}, rb, re); }
       if (int e = exchange_chunk(0, ch)) return e;
     }
     if (fill && F.mean_mask) { pend_mean_mask = F.mean_mask; pend_mean_part = F.part; pend_mean_nblk = (int)(xblocks_c * NCH); }
@@ -1477,9 +1478,9 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
       HIPCHK(c, hipStreamWaitEvent(c->stream, ev_arrived[ch], 0));
       ProfScope ps(c, "fft_y_fwd");
       const dim3 gy((ncol + CB8 - 1) / CB8, (kpc + ykchunk_c - 1) / ykchunk_c);
-      if (c->ykind) hipLaunchKernelGGL((k_fft_y8<0, 1>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1));
-      else if (c->fl.fft_staged) hipLaunchKernelGGL((k_fft_y8<0, 0>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1));
-        else hipLaunchKernelGGL((k_fft_y8r<0>), gy, dim3(sp->y8_threads), sp->shy8r, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, S, mode_spec, kpc * ch, kpc * (ch + 1));
+      if (c->ykind) LAUNCH(c, (k_fft_y8<0, 1>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1));
+      else if (c->fl.fft_staged) LAUNCH(c, (k_fft_y8<0, 0>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1));
+        else LAUNCH(c, (k_fft_y8r<0>), gy, dim3(sp->y8_threads), sp->shy8r, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, S, mode_spec, kpc * ch, kpc * (ch + 1));
     }
   } else {
   if (poisson && c->fuse_fillps_dti != 0. && sp->x8) {
@@ -1491,31 +1492,31 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
       if (c->n_mpart < 3 * (size_t)xblocks) { if (c->d_mpart) hipFree(c->d_mpart); HIPCHK(c, hipMalloc(&c->d_mpart, 3 * (size_t)xblocks * sizeof(real))); c->n_mpart = 3 * (size_t)xblocks; }
       F.part = c->d_mpart;
     }
-    if (c->xkind) hipLaunchKernelGGL((k_fft_x8<0, 1, 1>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
+    if (c->xkind) LAUNCH(c, (k_fft_x8<0, 1, 1>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
                                      (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec, F);
-    else hipLaunchKernelGGL((k_fft_x8<0, 0, 1>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
+    else LAUNCH(c, (k_fft_x8<0, 0, 1>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
                             (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec, F);
     if (F.mean_mask) if (int e = op_force_from_partials(c, F.mean_mask, F.part, (int)xblocks)) return e;
   } else { ProfScope ps(c, "fft_x_fwd");
-    if (use8x && c->xkind) hipLaunchKernelGGL((k_fft_x8<0, 1>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
+    if (use8x && c->xkind) LAUNCH(c, (k_fft_x8<0, 1>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec);
-    else if (use8x) hipLaunchKernelGGL((k_fft_x8<0, 0>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
+    else if (use8x) LAUNCH(c, (k_fft_x8<0, 0>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec);
-    else if (c->xkind >= 5) hipLaunchKernelGGL(k_dst1<0>, dim3((unsigned)nrows), dim3(256), (size_t)2 * (VS->p1x.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1x, 0, (const cpx *)VS->tw1x, pp, 1., S, slab_spec, c->xkind, 0);
-    else if (c->xkind == 3) hipLaunchKernelGGL((k_fft_x4<0, 0>), dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
+    else if (c->xkind >= 5) LAUNCH(c, k_dst1<0>, dim3((unsigned)nrows), dim3(256), (size_t)2 * (VS->p1x.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1x, 0, (const cpx *)VS->tw1x, pp, 1., S, slab_spec, c->xkind, 0);
+    else if (c->xkind == 3) LAUNCH(c, (k_fft_x4<0, 0>), dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
                        (const cpx *)c->d_twx, (const cpx *)c->d_tw4x, pp, 1., S, slab_spec);
-    else if (c->xkind == 4) hipLaunchKernelGGL((k_fft_x4<0, 1>), dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
+    else if (c->xkind == 4) LAUNCH(c, (k_fft_x4<0, 1>), dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
                        (const cpx *)c->d_twx, (const cpx *)c->d_tw4x, pp, 1., S, slab_spec);
-    else hipLaunchKernelGGL(k_fft_x<0>, dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx, c->xkind,
+    else LAUNCH(c, k_fft_x<0>, dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx, c->xkind,
                        (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, 1., S, slab_spec); }
   if (dist) { ProfScope ps(c, "alltoall"); if (c->comm.a2a(c->comm.user, 0, a2a_count)) { c->err = "alltoall callback failed"; return 1; } }
   { ProfScope ps(c, "fft_y_fwd");
-    if (c->ykind >= 5) hipLaunchKernelGGL(k_dst1<1>, dim3(ncol, n[2]), dim3(256), (size_t)2 * (VS->p1y.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1y, ncol, (const cpx *)VS->tw1y, pp, 1., S, mode_spec, c->ykind, 0);
-    else if (c->ykind == 3) hipLaunchKernelGGL(k_fft_y4<0>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
-    else if (c->ykind == 4) hipLaunchKernelGGL(k_fft_y4<1>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
-    else if (use8y && c->ykind) hipLaunchKernelGGL((k_fft_y8<0, 1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
-    else if (use8y) { if (c->fl.fft_staged) hipLaunchKernelGGL((k_fft_y8<0, 0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); else hipLaunchKernelGGL((k_fft_y8r<0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8r, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, S, mode_spec); }
-    else hipLaunchKernelGGL(k_fft_y<0>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
+    if (c->ykind >= 5) LAUNCH(c, k_dst1<1>, dim3(ncol, n[2]), dim3(256), (size_t)2 * (VS->p1y.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1y, ncol, (const cpx *)VS->tw1y, pp, 1., S, mode_spec, c->ykind, 0);
+    else if (c->ykind == 3) LAUNCH(c, k_fft_y4<0>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
+    else if (c->ykind == 4) LAUNCH(c, k_fft_y4<1>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
+    else if (use8y && c->ykind) LAUNCH(c, (k_fft_y8<0, 1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
+    else if (use8y) { if (c->fl.fft_staged) LAUNCH(c, (k_fft_y8<0, 0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); else LAUNCH(c, (k_fft_y8r<0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8r, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, S, mode_spec); }
+    else LAUNCH(c, k_fft_y<0>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
   }
   // pressure equation without a Dirichlet condition in z: the zero-eigenvalue mode (if x and y have one) is singular
   const int fixnull = (poisson && CBP(c, 0, 3) != 'D' && CBP(c, 1, 3) != 'D' && !c->fl.keep_null_mode) ? 1 : 0;
@@ -1523,14 +1524,14 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
   const bool refnull = poisson && lscale == (real)1. && CBP(c, 0, 3) != 'D' && CBP(c, 1, 3) != 'D' && c->fl.keep_null_mode && mofs == 0;
   if (refnull) {
     if (!c->d_nullw) HIPCHK(c, hipMalloc(&c->d_nullw, (size_t)5 * (c->C.ng[2] + 2) * sizeof(real)));
-    hipLaunchKernelGGL(k_null_column, dim3(1), dim3(64), 0, c->stream, c->g, S, nz, periodic_z ? 1 : 0, da, db, dc, c->d_lamx, c->d_lamy, mode_spec, c->d_nullw, 0);
+    LAUNCH(c, k_null_column, dim3(1), dim3(64), 0, c->stream, c->g, S, nz, periodic_z ? 1 : 0, da, db, dc, c->d_lamx, c->d_lamy, mode_spec, c->d_nullw, 0);
   }
   { ProfScope ps(c, "gaussel_z");
     dim3 b(64, 4), gr((ncol + 63) / 64, (n2g + 3) / 4);
     if (c->xkind && !c->ykind)       // real x modes paired into complex columns + periodic y: Hermitian separation of rows ky and N-ky
-      hipLaunchKernelGGL(k_gaussel_herm, dim3((unsigned)(((long)4 * ncol * (n2g / 2 + 1) + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, lscale,
+      LAUNCH(c, k_gaussel_herm, dim3((unsigned)(((long)4 * ncol * (n2g / 2 + 1) + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, lscale,
                          da, db, dc, c->d_lamx, c->d_lamy, (real *)mode_spec, c->scr1, fixnull);
-    else if (!c->fl.gaussel_pair && (periodic_z || fixnull || !poisson || CBP(c, 0, 3) == 'D' || CBP(c, 1, 3) == 'D') &&
+    else if ((periodic_z || fixnull || !poisson || CBP(c, 0, 3) == 'D' || CBP(c, 1, 3) == 'D') &&
              [&]() {
                TileMap T{}; T.blocked = dist ? 1 : 0; T.cw = c->cw; T.n2l = n[1]; T.mofs = mofs; T.nmode = c->xkind ? c->C.ng[0] / 2 : mh;
                T.kstride = (size_t)2 * c->cw * n[1]; T.segstride = T.kstride * n[2];
@@ -1540,58 +1541,57 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
                                  : gaussel_tile<2, 1>(c, nz, ndbl, nseg, lscale, da, db, dc, (real *)mode_spec, fixnull, T);
                return c->xkind ? gaussel_tile<1>(c, nz, ndbl, nseg, lscale, da, db, dc, (real *)mode_spec, fixnull, T)
                                : gaussel_tile<2>(c, nz, ndbl, nseg, lscale, da, db, dc, (real *)mode_spec, fixnull, T); }()) {}
-    else if (c->xkind && !periodic_z && !c->fl.gaussel_pair)
-      hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, lscale, da, db, dc,
+    else if (c->xkind && !periodic_z)
+      LAUNCH(c, k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, lscale, da, db, dc,
                          c->d_lamx, c->d_lamy, (real *)mode_spec, c->scr1, fixnull, 1);
     else if (periodic_z && c->xkind)      // real x modes (one eigenvalue each) with the periodic-z closure: scalar columns of the in-place spectrum, one rank
-      hipLaunchKernelGGL((k_gaussel<real, 1>), dim3((2 * (c->C.ng[0] / 2) + 63) / 64, (n2g + 3) / 4), b, 0, c->stream, c->g, nz, 2 * (c->C.ng[0] / 2), n2g, 1, 0, 2 * (c->C.ng[0] / 2), S, lscale,
+      LAUNCH(c, (k_gaussel<real, 1>), dim3((2 * (c->C.ng[0] / 2) + 63) / 64, (n2g + 3) / 4), b, 0, c->stream, c->g, nz, 2 * (c->C.ng[0] / 2), n2g, 1, 0, 2 * (c->C.ng[0] / 2), S, lscale,
                          da, db, dc, c->d_lamx, c->d_lamy, pp, c->scr1, c->scr2, fixnull);
-    else if (c->xkind) hipLaunchKernelGGL(k_gaussel_split, gr, b, 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, lscale, da, db, dc, c->d_lamx, c->d_lamy,
+    else if (c->xkind) LAUNCH(c, k_gaussel_split, gr, b, 0, c->stream, c->g, nz, ncol, n2g, mofs, c->C.ng[0] / 2, S, lscale, da, db, dc, c->d_lamx, c->d_lamy,
                                      (real2 *)mode_spec, (real2 *)c->scr1, fixnull);
-    else if (periodic_z) hipLaunchKernelGGL((k_gaussel<real2, 1>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (real *)mode_spec, c->scr1, c->scr2, fixnull);
-    else if (c->fl.gaussel_pair) hipLaunchKernelGGL((k_gaussel<real2, 0>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (real *)mode_spec, c->scr1, c->scr2, fixnull);
-    else hipLaunchKernelGGL(k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (real *)mode_spec, c->scr1, fixnull, 0); }
-  if (refnull) hipLaunchKernelGGL(k_null_column, dim3(1), dim3(64), 0, c->stream, c->g, S, nz, periodic_z ? 1 : 0, da, db, dc, c->d_lamx, c->d_lamy, mode_spec, c->d_nullw, 1);
+    else if (periodic_z) LAUNCH(c, (k_gaussel<real2, 1>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (real *)mode_spec, c->scr1, c->scr2, fixnull);
+    else LAUNCH(c, k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (real *)mode_spec, c->scr1, fixnull, 0); }
+  if (refnull) LAUNCH(c, k_null_column, dim3(1), dim3(64), 0, c->stream, c->g, S, nz, periodic_z ? 1 : 0, da, db, dc, c->d_lamx, c->d_lamy, mode_spec, c->d_nullw, 1);
   if (pend_mean_mask) if (int e = op_force_from_partials(c, pend_mean_mask, pend_mean_part, pend_mean_nblk)) return e;
   if (pipe) {
     for (int ch = 0; ch < NCH; ++ch) {
       { ProfScope ps(c, "fft_y_bwd");
         const dim3 gy((ncol + CB8 - 1) / CB8, (kpc + ykchunk_c - 1) / ykchunk_c);
-        if (c->ykind) hipLaunchKernelGGL((k_fft_y8<1, 1>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1));
-        else if (c->fl.fft_staged) hipLaunchKernelGGL((k_fft_y8<1, 0>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1));
-        else hipLaunchKernelGGL((k_fft_y8r<1>), gy, dim3(sp->y8_threads), sp->shy8r, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, S, mode_spec, kpc * ch, kpc * (ch + 1)); }
+        if (c->ykind) LAUNCH(c, (k_fft_y8<1, 1>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1));
+        else if (c->fl.fft_staged) LAUNCH(c, (k_fft_y8<1, 0>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1));
+        else LAUNCH(c, (k_fft_y8r<1>), gy, dim3(sp->y8_threads), sp->shy8r, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, S, mode_spec, kpc * ch, kpc * (ch + 1)); }
       if (int e = exchange_chunk(1, ch)) return e;
     }
     for (int ch = 0; ch < NCH; ++ch) {
       HIPCHK(c, hipStreamWaitEvent(c->stream, ev_arrived[ch], 0));
       ProfScope ps(c, "fft_x_bwd");
       const long rb = (long)n[1] * kpc * ch, re = rb + rows_c;
-      if (c->xkind) hipLaunchKernelGGL((k_fft_x8<1, 1>), dim3(xblocks_c), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters_c, (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec, FillArgs{}, rb, re);
-      else hipLaunchKernelGGL((k_fft_x8<1, 0>), dim3(xblocks_c), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters_c, (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec, FillArgs{}, rb, re);
+      if (c->xkind) LAUNCH(c, (k_fft_x8<1, 1>), dim3(xblocks_c), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters_c, (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec, FillArgs{}, rb, re);
+      else LAUNCH(c, (k_fft_x8<1, 0>), dim3(xblocks_c), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters_c, (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec, FillArgs{}, rb, re);
     }
   } else {
   { ProfScope ps(c, "fft_y_bwd");
-    if (c->ykind >= 5) hipLaunchKernelGGL(k_dst1<1>, dim3(ncol, n[2]), dim3(256), (size_t)2 * (VS->p1y.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1y, ncol, (const cpx *)VS->tw1y, pp, 1., S, mode_spec, c->ykind, 1);
-    else if (c->ykind == 3) hipLaunchKernelGGL(k_fft_y4<0>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
-    else if (c->ykind == 4) hipLaunchKernelGGL(k_fft_y4<1>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
-    else if (use8y && c->ykind) hipLaunchKernelGGL((k_fft_y8<1, 1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
-    else if (use8y) { if (c->fl.fft_staged) hipLaunchKernelGGL((k_fft_y8<1, 0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); else hipLaunchKernelGGL((k_fft_y8r<1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8r, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, S, mode_spec); }
-    else hipLaunchKernelGGL(k_fft_y<1>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
+    if (c->ykind >= 5) LAUNCH(c, k_dst1<1>, dim3(ncol, n[2]), dim3(256), (size_t)2 * (VS->p1y.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1y, ncol, (const cpx *)VS->tw1y, pp, 1., S, mode_spec, c->ykind, 1);
+    else if (c->ykind == 3) LAUNCH(c, k_fft_y4<0>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
+    else if (c->ykind == 4) LAUNCH(c, k_fft_y4<1>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
+    else if (use8y && c->ykind) LAUNCH(c, (k_fft_y8<1, 1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
+    else if (use8y) { if (c->fl.fft_staged) LAUNCH(c, (k_fft_y8<1, 0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); else LAUNCH(c, (k_fft_y8r<1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8r, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, S, mode_spec); }
+    else LAUNCH(c, k_fft_y<1>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
   if (dist) { ProfScope ps(c, "alltoall"); if (c->comm.a2a(c->comm.user, 1, a2a_count)) { c->err = "alltoall callback failed"; return 1; } }
   { ProfScope ps(c, "fft_x_bwd");
-    if (use8x && c->xkind) hipLaunchKernelGGL((k_fft_x8<1, 1>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
+    if (use8x && c->xkind) LAUNCH(c, (k_fft_x8<1, 1>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec);
-    else if (use8x) hipLaunchKernelGGL((k_fft_x8<1, 0>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
+    else if (use8x) LAUNCH(c, (k_fft_x8<1, 0>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec);
-    else if (c->xkind >= 5) hipLaunchKernelGGL(k_dst1<2>, dim3((unsigned)nrows), dim3(256), (size_t)2 * (VS->p1x.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1x, 0, (const cpx *)VS->tw1x, pp, c->normfft, S, slab_spec, c->xkind, 1);
-    else if (c->xkind == 3) hipLaunchKernelGGL((k_fft_x4<1, 0>), dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
+    else if (c->xkind >= 5) LAUNCH(c, k_dst1<2>, dim3((unsigned)nrows), dim3(256), (size_t)2 * (VS->p1x.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1x, 0, (const cpx *)VS->tw1x, pp, c->normfft, S, slab_spec, c->xkind, 1);
+    else if (c->xkind == 3) LAUNCH(c, (k_fft_x4<1, 0>), dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
                        (const cpx *)c->d_twx, (const cpx *)c->d_tw4x, pp, c->normfft, S, slab_spec);
-    else if (c->xkind == 4) hipLaunchKernelGGL((k_fft_x4<1, 1>), dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
+    else if (c->xkind == 4) LAUNCH(c, (k_fft_x4<1, 1>), dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
                        (const cpx *)c->d_twx, (const cpx *)c->d_tw4x, pp, c->normfft, S, slab_spec);
-    else hipLaunchKernelGGL(k_fft_x<1>, dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx, c->xkind,
+    else LAUNCH(c, k_fft_x<1>, dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx, c->xkind,
                        (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec); }
   }
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return 0;
 }
 
@@ -1660,15 +1660,15 @@ int op_helmholtz_z(cales_ctx *c, int ivel, real alpha) {
   int has[2] = {0, 0};
   if (int e = op_rhs_b_velz(c, ivel, alpha, fused ? c->scr2 : nullptr, fused ? has : nullptr)) return e;
   real *abc = c->d_red + 64 + 16 * (n3 + 2);     // scaled coefficients live behind the reduction partials
-  hipLaunchKernelGGL(k_scale_abc, dim3((n3 + 63) / 64), dim3(64), 0, c->stream, n3, alpha, c->d_av[ivel - 1], c->d_bv[ivel - 1], c->d_cv[ivel - 1], abc, abc + n3, abc + 2 * n3);
+  LAUNCH(c, k_scale_abc, dim3((n3 + 63) / 64), dim3(64), 0, c->stream, n3, alpha, c->d_av[ivel - 1], c->d_bv[ivel - 1], c->d_cv[ivel - 1], abc, abc + n3, abc + 2 * n3);
   const char *bcz = &c->cbcvel[6 * (ivel - 1) + 4];
   const int q = (ivel == 3 && bcz[1] == 'D') ? 1 : 0;
   const bool periodic = bcz[0] == 'P' && bcz[1] == 'P';
   dim3 b(64, 4), gr((n[0] + 63) / 64, (n[1] + 3) / 4);
   real *fld = c->f[CALES_U + ivel - 1];
   Spec S; S.blocked = 0; S.cw = 0; S.n2l = n[1]; S.n3 = n3;
-  if (periodic) hipLaunchKernelGGL((k_gaussel<real, 1>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, 1., abc, abc + n3, abc + 2 * n3, (const real *)nullptr, (const real *)nullptr, fld, c->scr1, c->scr2, 0);
-  else if (c->fl.helmholtz_z_per_column) hipLaunchKernelGGL((k_gaussel<real, 0>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, 1., abc, abc + n3, abc + 2 * n3, (const real *)nullptr, (const real *)nullptr, fld, c->scr1, c->scr2, 0);
+  if (periodic) LAUNCH(c, (k_gaussel<real, 1>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, 1., abc, abc + n3, abc + 2 * n3, (const real *)nullptr, (const real *)nullptr, fld, c->scr1, c->scr2, 0);
+  else if (c->fl.helmholtz_z_per_column) LAUNCH(c, (k_gaussel<real, 0>), gr, b, 0, c->stream, c->g, n3 - q, n[0], n[1], 1, 0, n[0], S, 1., abc, abc + n3, abc + 2 * n3, (const real *)nullptr, (const real *)nullptr, fld, c->scr1, c->scr2, 0);
   else if (c->P >= 1 && n3 - q >= 2 && n3 - q <= 512 && n3 <= 64 * (n3 - q <= 128 ? 2 : n3 - q <= 256 ? 4 : 8) && !c->fl.gaussel_march && [&]() {
              // the in-LDS tile of the pressure solve on the real field: u, dudtd in, u out (3 words instead of 5)
              TileMap T{}; T.nolam = 1; T.nq = n3;
@@ -1677,12 +1677,12 @@ int op_helmholtz_z(cales_ctx *c, int ivel, real alpha) {
              return gaussel_tile<2>(c, n3 - q, n[0], n[1], 1., abc, abc + n3, abc + 2 * n3, fld + 1, 0, T); }()) {}
   else {
     real *zz = abc + 3 * n3, *dd = abc + 4 * n3;       // behind the scaled coefficients (cales_create reserves 6 (n3+2) doubles)
-    hipLaunchKernelGGL(k_thomas_coef, dim3(1), dim3(64), 0, c->stream, n3 - q, abc, abc + n3, abc + 2 * n3, zz, dd);
-    if (fused) hipLaunchKernelGGL(k_gaussel_cols_rhs, gr, b, 0, c->stream, c->g, n3 - q, n3, abc, zz, dd, fld, c->f[CALES_DUDTD + ivel - 1], c->hf12,
+    LAUNCH(c, k_thomas_coef, dim3(1), dim3(64), 0, c->stream, n3 - q, abc, abc + n3, abc + 2 * n3, zz, dd);
+    if (fused) LAUNCH(c, k_gaussel_cols_rhs, gr, b, 0, c->stream, c->g, n3 - q, n3, abc, zz, dd, fld, c->f[CALES_DUDTD + ivel - 1], c->hf12,
                                   c->C.is_forced[ivel - 1] ? c->d_force + (ivel - 1) : (const real *)nullptr, c->scr2, has[0], has[1]);
-    else hipLaunchKernelGGL(k_gaussel_cols, gr, b, 0, c->stream, c->g, n3 - q, abc, zz, dd, fld);
+    else LAUNCH(c, k_gaussel_cols, gr, b, 0, c->stream, c->g, n3 - q, abc, zz, dd, fld);
   }
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return 0;
 }
 
@@ -1736,7 +1736,7 @@ static int velset_build(cales_ctx *c, SolverPlans &sp, int iv, VelSet &V) {
     if (N < 2 || !make_plan(N, V.p1x) || (size_t)2 * (N + 1) * sizeof(cpx) > 150 * 1024) { c->err = "helmholtz: x line not supported by the face-centred transform kernel"; return 1; } if (mk(N, &V.tw1x)) return 1; }
   if (V.ykind >= 5) { const int N = next(V.ykind, n2g);
     if (N < 2 || !make_plan(N, V.p1y) || (size_t)2 * (N + 1) * sizeof(cpx) > 150 * 1024) { c->err = "helmholtz: y line not supported by the face-centred transform kernel"; return 1; } if (mk(N, &V.tw1y)) return 1; }
-  if (V.xkind >= 5 || V.ykind >= 5) hipFuncSetAttribute((const void *)k_dst1<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), hipFuncSetAttribute((const void *)k_dst1<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), hipFuncSetAttribute((const void *)k_dst1<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  if (V.xkind >= 5 || V.ykind >= 5) { HIPSOFT(c, hipFuncSetAttribute((const void *)k_dst1<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); HIPSOFT(c, hipFuncSetAttribute((const void *)k_dst1<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); HIPSOFT(c, hipFuncSetAttribute((const void *)k_dst1<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); }
   // the DCT-IV / DST-IV kernels (kinds 3, 4) read tables that solver_setup makes only when the pressure needs them
   const real pi = std::acos(-1.0);
   if ((V.xkind == 3 || V.xkind == 4) && !c->d_tw4x) {
@@ -1772,7 +1772,7 @@ int op_helmholtz(cales_ctx *c, int ivel, real alpha) {
   if (int e = op_rhs_b_velxy(c, ivel, alpha)) return e;      // main.f90:424-431: boundary terms of the x and y faces, then z
   if (int e = op_rhs_b_velz(c, ivel, alpha)) return e;
   real *abc = c->d_red + 64 + 16 * (n3 + 2);
-  hipLaunchKernelGGL(k_scale_abc, dim3((n3 + 63) / 64), dim3(64), 0, c->stream, n3, alpha, c->d_av[ivel - 1], c->d_bv[ivel - 1], c->d_cv[ivel - 1], abc, abc + n3, abc + 2 * n3);
+  LAUNCH(c, k_scale_abc, dim3((n3 + 63) / 64), dim3(64), 0, c->stream, n3, alpha, c->d_av[ivel - 1], c->d_bv[ivel - 1], c->d_cv[ivel - 1], abc, abc + n3, abc + 2 * n3);
   const char *bcz = &c->cbcvel[6 * (ivel - 1) + 4];
   const int q = (ivel == 3 && bcz[1] == 'D') ? 1 : 0;
   // the solve runs with the component's kinds, eigenvalues and normalisation in place of the pressure's

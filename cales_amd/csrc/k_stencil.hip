@@ -109,15 +109,15 @@ int op_mom(cales_ctx *c) {
   dim3 b(BX, BY, 1), gr = grid3(c->n[0], c->n[1], c->n[2], b);
   real **f = c->f;
   if (c->C.impdiff == 2)
-    hipLaunchKernelGGL(k_mom<2>, gr, b, 0, c->stream, c->g, f[CALES_U], f[CALES_V], f[CALES_W], f[CALES_VISCT], c->d_dzci, c->d_dzfi,
+    LAUNCH(c, k_mom<2>, gr, b, 0, c->stream, c->g, f[CALES_U], f[CALES_V], f[CALES_W], f[CALES_VISCT], c->d_dzci, c->d_dzfi,
                        c->dli[0], c->dli[1], c->visc, f[CALES_DUDT], f[CALES_DVDT], f[CALES_DWDT], f[CALES_DUDTD], f[CALES_DVDTD], f[CALES_DWDTD]);
   else if (c->C.impdiff == 1)
-    hipLaunchKernelGGL(k_mom<1>, gr, b, 0, c->stream, c->g, f[CALES_U], f[CALES_V], f[CALES_W], f[CALES_VISCT], c->d_dzci, c->d_dzfi,
+    LAUNCH(c, k_mom<1>, gr, b, 0, c->stream, c->g, f[CALES_U], f[CALES_V], f[CALES_W], f[CALES_VISCT], c->d_dzci, c->d_dzfi,
                        c->dli[0], c->dli[1], c->visc, f[CALES_DUDT], f[CALES_DVDT], f[CALES_DWDT], f[CALES_DUDTD], f[CALES_DVDTD], f[CALES_DWDTD]);
   else
-    hipLaunchKernelGGL(k_mom<0>, gr, b, 0, c->stream, c->g, f[CALES_U], f[CALES_V], f[CALES_W], f[CALES_VISCT], c->d_dzci, c->d_dzfi,
+    LAUNCH(c, k_mom<0>, gr, b, 0, c->stream, c->g, f[CALES_U], f[CALES_V], f[CALES_W], f[CALES_VISCT], c->d_dzci, c->d_dzfi,
                        c->dli[0], c->dli[1], c->visc, f[CALES_DUDT], f[CALES_DVDT], f[CALES_DWDT], (real *)nullptr, (real *)nullptr, (real *)nullptr);
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return 0;
 }
 
@@ -223,9 +223,9 @@ int op_bulk_mean_dev(cales_ctx *c, const real *p, int c_or_f, real *d_out) {
   ProfScope ps(c, "bulk_mean");
   const int nbx = 8;
   dim3 gr(nbx, c->n[2]);
-  hipLaunchKernelGGL(k_bulk_mean_partial, gr, dim3(256), 0, c->stream, c->g, p, c_or_f ? c->d_gvr_f : c->d_gvr_c, c->d_red + 64);
-  hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, nbx * c->n[2], 0, c->res, 16);
-  HIPCHK(c, hipGetLastError());
+  LAUNCH(c, k_bulk_mean_partial, gr, dim3(256), 0, c->stream, c->g, p, c_or_f ? c->d_gvr_f : c->d_gvr_c, c->d_red + 64);
+  LAUNCH(c, k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, nbx * c->n[2], 0, c->res, 16);
+  LAUNCHCHK(c);
   return allreduce_res(c, 16, 1, 0);
 }
 
@@ -233,14 +233,14 @@ static int forcing_component(cales_ctx *c, int comp) {   // cmpt_bulk_forcing, r
   const int nbx = 8;
   dim3 gr(nbx, c->n[2]);
   const real *p = c->f[CALES_U + comp];
-  hipLaunchKernelGGL(k_bulk_mean_partial, gr, dim3(256), 0, c->stream, c->g, p, comp == 2 ? c->d_gvr_c : c->d_gvr_f, c->d_red + 64);
-  if (c->P == 1) hipLaunchKernelGGL(k_fold_force, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, nbx * c->n[2], c->C.velf[comp], c->res, 8 + comp, c->d_force, comp);
+  LAUNCH(c, k_bulk_mean_partial, gr, dim3(256), 0, c->stream, c->g, p, comp == 2 ? c->d_gvr_c : c->d_gvr_f, c->d_red + 64);
+  if (c->P == 1) LAUNCH(c, k_fold_force, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, nbx * c->n[2], c->C.velf[comp], c->res, 8 + comp, c->d_force, comp);
   else {
-    hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, nbx * c->n[2], 0, c->res, 8 + comp);
+    LAUNCH(c, k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, nbx * c->n[2], 0, c->res, 8 + comp);
     if (int e = allreduce_res(c, 8 + comp, 1, 0)) return e;
-    hipLaunchKernelGGL(k_force_finish, dim3(1), dim3(64), 0, c->stream, c->res, 8 + comp, c->C.velf[comp], c->d_force, comp);
+    LAUNCH(c, k_force_finish, dim3(1), dim3(64), 0, c->stream, c->res, 8 + comp, c->C.velf[comp], c->d_force, comp);
   }
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return 0;
 }
 
@@ -248,12 +248,12 @@ static int forcing_component(cales_ctx *c, int comp) {   // cmpt_bulk_forcing, r
 int op_force_from_partials(cales_ctx *c, int mask, const real *part, int nblk) {
   for (int comp = 0; comp < 3; ++comp) {
     if (!(mask >> comp & 1)) continue;
-    if (c->P == 1) { hipLaunchKernelGGL(k_fold_force, dim3(1), dim3(256), 0, c->stream, part + (size_t)comp * nblk, nblk, c->C.velf[comp], c->res, 8 + comp, c->d_force, comp); continue; }
-    hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, part + (size_t)comp * nblk, nblk, 0, c->res, 8 + comp);
+    if (c->P == 1) { LAUNCH(c, k_fold_force, dim3(1), dim3(256), 0, c->stream, part + (size_t)comp * nblk, nblk, c->C.velf[comp], c->res, 8 + comp, c->d_force, comp); continue; }
+    LAUNCH(c, k_fold, dim3(1), dim3(256), 0, c->stream, part + (size_t)comp * nblk, nblk, 0, c->res, 8 + comp);
     if (int e = allreduce_res(c, 8 + comp, 1, 0)) return e;
-    hipLaunchKernelGGL(k_force_finish, dim3(1), dim3(64), 0, c->stream, c->res, 8 + comp, c->C.velf[comp], c->d_force, comp);
+    LAUNCH(c, k_force_finish, dim3(1), dim3(64), 0, c->stream, c->res, 8 + comp, c->C.velf[comp], c->d_force, comp);
   }
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return 0;
 }
 
@@ -275,24 +275,24 @@ int op_rk_par(cales_ctx *c, real rkpar1, real rkpar2, real dt) {
     if (int e = op_mom(c)) return e;
     ProfScope ps(c, "rk_update");
     if (c->C.impdiff)
-      hipLaunchKernelGGL(k_rk_update<1>, gr, b, 0, c->stream, c->g, f1, f2, f12, c->dli[0], c->dli[1], c->C.bforce[0], c->C.bforce[1], c->C.bforce[2],
+      LAUNCH(c, k_rk_update<1>, gr, b, 0, c->stream, c->g, f1, f2, f12, c->dli[0], c->dli[1], c->C.bforce[0], c->C.bforce[1], c->C.bforce[2],
                          c->d_dzci, f[CALES_P], f[CALES_U], f[CALES_V], f[CALES_W], f[CALES_DUDT], f[CALES_DVDT], f[CALES_DWDT],
                          f[CALES_DUDTO], f[CALES_DVDTO], f[CALES_DWDTO], f[CALES_DUDTD], f[CALES_DVDTD], f[CALES_DWDTD]);
     else
-      hipLaunchKernelGGL(k_rk_update<0>, gr, b, 0, c->stream, c->g, f1, f2, f12, c->dli[0], c->dli[1], c->C.bforce[0], c->C.bforce[1], c->C.bforce[2],
+      LAUNCH(c, k_rk_update<0>, gr, b, 0, c->stream, c->g, f1, f2, f12, c->dli[0], c->dli[1], c->C.bforce[0], c->C.bforce[1], c->C.bforce[2],
                          c->d_dzci, f[CALES_P], f[CALES_U], f[CALES_V], f[CALES_W], f[CALES_DUDT], f[CALES_DVDT], f[CALES_DWDT],
                          f[CALES_DUDTO], f[CALES_DVDTO], f[CALES_DWDTO], (real *)nullptr, (real *)nullptr, (real *)nullptr);
   }
   for (int q = 0; q < 3; ++q) std::swap(f[CALES_DUDT + q], f[CALES_DUDTO + q]);     // swap, rk.f90:98-100
   if (!(c->C.is_forced[0] && c->C.is_forced[1] && c->C.is_forced[2]) && !c->force_zeroed) {      // unforced components stay zero for good
-    hipLaunchKernelGGL(k_zero_force, dim3(1), dim3(64), 0, c->stream, c->d_force); c->force_zeroed = true; }
+    LAUNCH(c, k_zero_force, dim3(1), dim3(64), 0, c->stream, c->d_force); c->force_zeroed = true; }
   for (int q = 0; q < 3; ++q) if (c->C.is_forced[q] && !(c->fuse_mean_mask >> q & 1)) if (int e = forcing_component(c, q)) return e;
   c->hf12 = .5 * f12;
   if (c->C.impdiff && !c->defer_imp_rhs) {
     ProfScope ps(c, "rk_imp_rhs");
-    hipLaunchKernelGGL(k_rk_imp_rhs, gr, b, 0, c->stream, c->g, .5 * f12, f[CALES_U], f[CALES_V], f[CALES_W], f[CALES_DUDTD], f[CALES_DVDTD], f[CALES_DWDTD]);
+    LAUNCH(c, k_rk_imp_rhs, gr, b, 0, c->stream, c->g, .5 * f12, f[CALES_U], f[CALES_V], f[CALES_W], f[CALES_DUDTD], f[CALES_DVDTD], f[CALES_DWDTD]);
   }
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return 0;
 }
 
@@ -310,9 +310,9 @@ int op_bulk_forcing(cales_ctx *c) {
   if (!(c->C.is_forced[0] || c->C.is_forced[1] || c->C.is_forced[2]) || c->defer_imp_rhs || c->defer_force) return 0;
   ProfScope ps(c, "bulk_forcing");
   dim3 b(BX, BY, 1), gr = grid3(c->n[0], c->n[1], c->n[2], b);
-  hipLaunchKernelGGL(k_bulk_forcing, gr, b, 0, c->stream, c->g, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W], c->d_force,
+  LAUNCH(c, k_bulk_forcing, gr, b, 0, c->stream, c->g, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W], c->d_force,
                      c->C.is_forced[0], c->C.is_forced[1], c->C.is_forced[2]);
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return 0;
 }
 
@@ -328,9 +328,9 @@ __global__ __launch_bounds__(BX *BY) void k_fillps(Geom g, real dti, real dtidxi
 int op_fillps(cales_ctx *c, real dti) {
   ProfScope ps(c, "fillps");
   dim3 b(BX, BY, 1), gr = grid3(c->n[0], c->n[1], c->n[2], b);
-  hipLaunchKernelGGL(k_fillps, gr, b, 0, c->stream, c->g, dti, dti * c->dli[0], dti * c->dli[1], c->d_dzfi, c->f[CALES_U], c->f[CALES_V],
+  LAUNCH(c, k_fillps, gr, b, 0, c->stream, c->g, dti, dti * c->dli[0], dti * c->dli[1], c->d_dzfi, c->f[CALES_U], c->f[CALES_V],
                      c->f[CALES_W], c->f[CALES_PP]);
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return 0;
 }
 
@@ -399,24 +399,24 @@ int op_correc_updatep(cales_ctx *c, real dt, real alpha, int upd) {
   const int mode = !upd ? 0 : (c->C.impdiff == 2 ? 2 : 1);
   const int fmask = c->defer_force ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;
   const int perx = c->step_xskip ? 1 : 0;      // (operator-level calls read the ghost column of pp the caller provided)
-  if (mode == 0) hipLaunchKernelGGL(k_correc_cell<0>, gr, b, 0, c->stream, c->g, fi, fj, dt, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], f_[0], f_[1], f_[2], f_[3], c->d_force, fmask, perx);
-  else if (mode == 1) hipLaunchKernelGGL(k_correc_cell<1>, gr, b, 0, c->stream, c->g, fi, fj, dt, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], f_[0], f_[1], f_[2], f_[3], c->d_force, fmask, perx);
-  else hipLaunchKernelGGL(k_correc_cell<2>, gr, b, 0, c->stream, c->g, fi, fj, dt, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], f_[0], f_[1], f_[2], f_[3], c->d_force, fmask, perx);
+  if (mode == 0) LAUNCH(c, k_correc_cell<0>, gr, b, 0, c->stream, c->g, fi, fj, dt, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], f_[0], f_[1], f_[2], f_[3], c->d_force, fmask, perx);
+  else if (mode == 1) LAUNCH(c, k_correc_cell<1>, gr, b, 0, c->stream, c->g, fi, fj, dt, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], f_[0], f_[1], f_[2], f_[3], c->d_force, fmask, perx);
+  else LAUNCH(c, k_correc_cell<2>, gr, b, 0, c->stream, c->g, fi, fj, dt, alpha, c->d_dzci, c->d_dzfi, c->f[CALES_PP], f_[0], f_[1], f_[2], f_[3], c->d_force, fmask, perx);
   // periodic x: the ghost columns are overwritten by the periodic copy of the bounduvw that always follows (main.f90:500) -- inside
   // cales_step their correction is dead work
   if (!(c->in_step && c->cbcvel[0] == 'P' && c->cbcvel[1] == 'P'))
-    hipLaunchKernelGGL(k_correc_edge, dim3((n[1] + 2 + 63) / 64, (n[2] + 2 + 3) / 4, 2), dim3(64, 4, 1), 0, c->stream, c->g, fi, fj, dt, c->d_dzci, c->f[CALES_PP],
+    LAUNCH(c, k_correc_edge, dim3((n[1] + 2 + 63) / 64, (n[2] + 2 + 3) / 4, 2), dim3(64, 4, 1), 0, c->stream, c->g, fi, fj, dt, c->d_dzci, c->f[CALES_PP],
                        f_[0], f_[1], f_[2]);
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return 0;
 }
 int op_correc(cales_ctx *c, real dt) {
   if (!c->fl.unfused_correc) return op_correc_updatep(c, dt, 0., 0);
   ProfScope ps(c, "correc");
   dim3 b(BX, BY, 1), gr = grid3(c->n[0] + 2, c->n[1] + 2, c->n[2] + 2, b);
-  hipLaunchKernelGGL(k_correc, gr, b, 0, c->stream, c->g, dt * c->dli[0], dt * c->dli[1], dt, c->d_dzci, c->f[CALES_PP], c->f[CALES_U],
+  LAUNCH(c, k_correc, gr, b, 0, c->stream, c->g, dt * c->dli[0], dt * c->dli[1], dt, c->d_dzci, c->f[CALES_PP], c->f[CALES_U],
                      c->f[CALES_V], c->f[CALES_W]);
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return 0;
 }
 
@@ -436,10 +436,10 @@ __global__ __launch_bounds__(BX *BY) void k_updatep(Geom g, real alpha, real dxi
 int op_updatep(cales_ctx *c, real alpha) {
   ProfScope ps(c, "updatep");
   dim3 b(BX, BY, 1), gr = grid3(c->n[0], c->n[1], c->n[2], b);
-  if (c->C.impdiff == 2) hipLaunchKernelGGL(k_updatep<2>, gr, b, 0, c->stream, c->g, alpha, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, c->f[CALES_PP], c->f[CALES_P]);
-  else if (c->C.impdiff == 1) hipLaunchKernelGGL(k_updatep<1>, gr, b, 0, c->stream, c->g, alpha, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, c->f[CALES_PP], c->f[CALES_P]);
-  else hipLaunchKernelGGL(k_updatep<0>, gr, b, 0, c->stream, c->g, alpha, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, c->f[CALES_PP], c->f[CALES_P]);
-  HIPCHK(c, hipGetLastError());
+  if (c->C.impdiff == 2) LAUNCH(c, k_updatep<2>, gr, b, 0, c->stream, c->g, alpha, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, c->f[CALES_PP], c->f[CALES_P]);
+  else if (c->C.impdiff == 1) LAUNCH(c, k_updatep<1>, gr, b, 0, c->stream, c->g, alpha, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, c->f[CALES_PP], c->f[CALES_P]);
+  else LAUNCH(c, k_updatep<0>, gr, b, 0, c->stream, c->g, alpha, c->dli[0], c->dli[1], c->d_dzci, c->d_dzfi, c->f[CALES_PP], c->f[CALES_P]);
+  LAUNCHCHK(c);
   return 0;
 }
 
@@ -462,10 +462,10 @@ __global__ __launch_bounds__(256) void k_chkdiv_partial(Geom g, real dxi, real d
 }
 int op_chkdiv(cales_ctx *c, real *divtot, real *divmax) {
   const int nbx = 8, np = nbx * c->n[2];
-  hipLaunchKernelGGL(k_chkdiv_partial, dim3(nbx, c->n[2]), dim3(256), 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzfi, c->f[CALES_U],
+  LAUNCH(c, k_chkdiv_partial, dim3(nbx, c->n[2]), dim3(256), 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzfi, c->f[CALES_U],
                      c->f[CALES_V], c->f[CALES_W], c->d_red + 64, c->d_red + 64 + np);
-  hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, np, 0, c->res, 0);
-  hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64 + np, np, 1, c->res, 1);
+  LAUNCH(c, k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, np, 0, c->res, 0);
+  LAUNCH(c, k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64 + np, np, 1, c->res, 1);
   if (int e = allreduce_res(c, 0, 1, 0)) return e;
   if (int e = allreduce_res(c, 1, 1, 1)) return e;
   HIPCHK(c, hipMemcpyAsync(c->h_red, c->res, 2 * sizeof(real), hipMemcpyDeviceToHost, c->stream));
@@ -535,11 +535,11 @@ int op_stats_chan(cales_ctx *c, real *buf) {
   const size_t need = (size_t)NSTAT * n3 * (nbx + 1);
   if (!c->d_stat) HIPCHK(c, hipMalloc(&c->d_stat, need * sizeof(real)));
   real *part = c->d_stat, *out = c->d_stat + (size_t)NSTAT * n3 * nbx;
-  hipLaunchKernelGGL(k_stats_chan_partial, dim3(nbx, n3), dim3(256), 0, c->stream, c->g, c->dl[0], c->dl[1], c->d_dzc, c->d_dzf, c->f[CALES_U], c->f[CALES_V],
+  LAUNCH(c, k_stats_chan_partial, dim3(nbx, n3), dim3(256), 0, c->stream, c->g, c->dl[0], c->dl[1], c->d_dzc, c->d_dzf, c->f[CALES_U], c->f[CALES_V],
                      c->f[CALES_W], c->f[CALES_P], c->f[CALES_VISCT], part);
   const real ratio = c->dl[0] * c->dl[1] / (c->C.l[0] * c->C.l[1]);
-  hipLaunchKernelGGL(k_stats_fold, dim3((NSTAT * n3 + 255) / 256), dim3(256), 0, c->stream, n3, nbx, ratio, part, out);
-  HIPCHK(c, hipGetLastError());
+  LAUNCH(c, k_stats_fold, dim3((NSTAT * n3 + 255) / 256), dim3(256), 0, c->stream, n3, nbx, ratio, part, out);
+  LAUNCHCHK(c);
   HIPCHK(c, hipMemcpyAsync(buf, out, (size_t)NSTAT * n3 * sizeof(real), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
@@ -657,19 +657,19 @@ int op_stats_chan_budget(cales_ctx *c, real *budget, real *leak) {
   real *part = c->d_stat2, *out = c->d_stat2 + (size_t)NBUDGET * n3 * nbx;
   const real ratio = c->dl[0] * c->dl[1] / (c->C.l[0] * c->C.l[1]);
   if (budget) {
-    hipLaunchKernelGGL(k_stats_budget_partial, dim3(nbx, n3), dim3(256), 0, c->stream, c->g, c->dl[0], c->dl[1], c->d_dzc, c->d_dzf, c->f[CALES_U], c->f[CALES_V],
+    LAUNCH(c, k_stats_budget_partial, dim3(nbx, n3), dim3(256), 0, c->stream, c->g, c->dl[0], c->dl[1], c->d_dzc, c->d_dzf, c->f[CALES_U], c->f[CALES_V],
                        c->f[CALES_W], c->f[CALES_P], part);
-    hipLaunchKernelGGL(k_stats_fold_n, dim3((NBUDGET * n3 + 255) / 256), dim3(256), 0, c->stream, NBUDGET, n3, nbx, ratio, part, out);
+    LAUNCH(c, k_stats_fold_n, dim3((NBUDGET * n3 + 255) / 256), dim3(256), 0, c->stream, NBUDGET, n3, nbx, ratio, part, out);
     HIPCHK(c, hipMemcpyAsync(budget, out, (size_t)NBUDGET * n3 * sizeof(real), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   if (leak) {
-    hipLaunchKernelGGL(k_stats_leak_partial, dim3(nbx, n3), dim3(256), 0, c->stream, c->g, c->dl[0], c->dl[1], c->d_dzf, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W], part);
-    hipLaunchKernelGGL(k_stats_leak_fold, dim3((n3 + 63) / 64), dim3(64), 0, c->stream, n3, nbx, ratio, c->d_dzf, part, out);
+    LAUNCH(c, k_stats_leak_partial, dim3(nbx, n3), dim3(256), 0, c->stream, c->g, c->dl[0], c->dl[1], c->d_dzf, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W], part);
+    LAUNCH(c, k_stats_leak_fold, dim3((n3 + 63) / 64), dim3(64), 0, c->stream, n3, nbx, ratio, c->d_dzf, part, out);
     HIPCHK(c, hipMemcpyAsync(leak, out, (size_t)6 * n3 * sizeof(real), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
-  HIPCHK(c, hipGetLastError());
+  LAUNCHCHK(c);
   return 0;
 }
 
@@ -700,8 +700,8 @@ int op_out1d(cales_ctx *c, int field, int idir, int use_dzc, real *buf) {
   real *out = nullptr; HIPCHK(c, hipMalloc(&out, (size_t)ne * sizeof(real)));
   // grid_area_ratio of the reference: dl(1) dl(2) / (l(1) l(2)) along z, dl(1) / (l(1) l(3)) along y, dl(2) / (l(2) l(3)) along x
   const real ratio = idir == 3 ? c->dl[0] * c->dl[1] / (c->C.l[0] * c->C.l[1]) : idir == 2 ? c->dl[0] / (c->C.l[0] * c->C.l[2]) : c->dl[1] / (c->C.l[1] * c->C.l[2]);
-  hipLaunchKernelGGL(k_out1d, dim3(ne), dim3(256), 0, c->stream, c->g, idir, ratio, use_dzc ? c->d_dzc : c->d_dzf, c->f[field], out);
-  HIPCHK(c, hipGetLastError());
+  LAUNCH(c, k_out1d, dim3(ne), dim3(256), 0, c->stream, c->g, idir, ratio, use_dzc ? c->d_dzc : c->d_dzf, c->f[field], out);
+  LAUNCHCHK(c);
   HIPCHK(c, hipMemcpyAsync(buf, out, (size_t)ne * sizeof(real), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   hipFree(out);
@@ -726,8 +726,8 @@ __global__ __launch_bounds__(256) void k_out1d_chan(Geom g, real ratio, const re
 int op_out1d_chan(cales_ctx *c, real *buf) {
   const int n3 = c->n[2];
   real *out = nullptr; HIPCHK(c, hipMalloc(&out, (size_t)7 * n3 * sizeof(real)));
-  hipLaunchKernelGGL(k_out1d_chan, dim3(n3), dim3(256), 0, c->stream, c->g, c->dl[0] * c->dl[1] / (c->C.l[0] * c->C.l[1]), c->f[CALES_U], c->f[CALES_V], c->f[CALES_W], out);
-  HIPCHK(c, hipGetLastError());
+  LAUNCH(c, k_out1d_chan, dim3(n3), dim3(256), 0, c->stream, c->g, c->dl[0] * c->dl[1] / (c->C.l[0] * c->C.l[1]), c->f[CALES_U], c->f[CALES_V], c->f[CALES_W], out);
+  LAUNCHCHK(c);
   HIPCHK(c, hipMemcpyAsync(buf, out, (size_t)7 * n3 * sizeof(real), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   hipFree(out);
@@ -752,8 +752,8 @@ __global__ __launch_bounds__(256) void k_out2d_duct(Geom g, real ratio, const re
 int op_out2d_duct(cales_ctx *c, real *buf) {
   const int n2 = c->n[1], n3 = c->n[2];
   real *out = nullptr; HIPCHK(c, hipMalloc(&out, (size_t)9 * n2 * n3 * sizeof(real)));
-  hipLaunchKernelGGL(k_out2d_duct, dim3((n2 + 3) / 4, n3), dim3(256), 0, c->stream, c->g, c->dl[0] / c->C.l[0], c->f[CALES_U], c->f[CALES_V], c->f[CALES_W], out);
-  HIPCHK(c, hipGetLastError());
+  LAUNCH(c, k_out2d_duct, dim3((n2 + 3) / 4, n3), dim3(256), 0, c->stream, c->g, c->dl[0] / c->C.l[0], c->f[CALES_U], c->f[CALES_V], c->f[CALES_W], out);
+  LAUNCHCHK(c);
   HIPCHK(c, hipMemcpyAsync(buf, out, (size_t)9 * n2 * n3 * sizeof(real), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   hipFree(out);
@@ -796,16 +796,16 @@ int op_chkdt(cales_ctx *c, real *dtmax) {
   const int nbx = 8, np = nbx * c->n[2];
   real **f = c->f;
   if (c->C.impdiff == 2)
-    hipLaunchKernelGGL(k_chkdt_partial<2>, dim3(nbx, c->n[2]), dim3(256), 0, c->stream, c->g, 1. / c->dl[0], 1. / c->dl[1], c->visc, c->d_dzci,
+    LAUNCH(c, k_chkdt_partial<2>, dim3(nbx, c->n[2]), dim3(256), 0, c->stream, c->g, 1. / c->dl[0], 1. / c->dl[1], c->visc, c->d_dzci,
                        c->d_dzfi, f[CALES_VISCT], f[CALES_U], f[CALES_V], f[CALES_W], c->d_red + 64, c->d_red + 64 + np);
   else if (c->C.impdiff == 1)
-    hipLaunchKernelGGL(k_chkdt_partial<1>, dim3(nbx, c->n[2]), dim3(256), 0, c->stream, c->g, 1. / c->dl[0], 1. / c->dl[1], c->visc, c->d_dzci,
+    LAUNCH(c, k_chkdt_partial<1>, dim3(nbx, c->n[2]), dim3(256), 0, c->stream, c->g, 1. / c->dl[0], 1. / c->dl[1], c->visc, c->d_dzci,
                        c->d_dzfi, f[CALES_VISCT], f[CALES_U], f[CALES_V], f[CALES_W], c->d_red + 64, c->d_red + 64 + np);
   else
-    hipLaunchKernelGGL(k_chkdt_partial<0>, dim3(nbx, c->n[2]), dim3(256), 0, c->stream, c->g, 1. / c->dl[0], 1. / c->dl[1], c->visc, c->d_dzci,
+    LAUNCH(c, k_chkdt_partial<0>, dim3(nbx, c->n[2]), dim3(256), 0, c->stream, c->g, 1. / c->dl[0], 1. / c->dl[1], c->visc, c->d_dzci,
                        c->d_dzfi, f[CALES_VISCT], f[CALES_U], f[CALES_V], f[CALES_W], c->d_red + 64, c->d_red + 64 + np);
-  hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, np, 1, c->res, 0);
-  hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64 + np, np, 1, c->res, 1);
+  LAUNCH(c, k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, np, 1, c->res, 0);
+  LAUNCH(c, k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64 + np, np, 1, c->res, 1);
   if (int e = allreduce_res(c, 0, 2, 1)) return e;
   HIPCHK(c, hipMemcpyAsync(c->h_red, c->res, 2 * sizeof(real), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -25,7 +25,7 @@ P, r = dist.get_world_size(), dist.get_rank()
 # (the static-Smagorinsky duct runs on any number of slabs: the shear planes of the y walls travel to every rank, k_sgs.hip wall_shear_y_planes;
 #  the reference stops at two subdomains between two opposite walls, sanity.f90:98-111)
 for name, ng in (("chan_dsmag", (64, 16 * P, 24)), ("duct_smag_wm", (32, 16 * P, 16)), ("duct_smag_wm_imp1d", (32, 8 * P, 16)), ("tgv_dsmag_ppp", (32, 8 * P, 16)),
-                 ("cavity_nnn", (32, 8 * P, 12))):
+                 ("cavity_nnn", (32, 8 * P, 12)), ("duct_smag", (64, 8 * P, 16))):
     _, case = load_golden(name)
     case.ng[:] = ng
     if case.sgstype == "none" and case.cbcvel[0, 0, 0] != "P":

@@ -51,6 +51,8 @@ SLAB_CASES = [("chan_smag_wm", (32, 24, 16), 2), ("chan_smag_wm", (32, 24, 16), 
                                        ("duct_smag_wm", (16, 32, 24), 4), ("duct_smag_wm", (16, 64, 24), 8), ("duct_smag_wm_imp1d", (16, 32, 24), 4),
                                        ("duct_smag_wm_imp1d", (32, 64, 16), 8), ("duct_smag_wm", (16, 24, 24), 3), ("cavity_smag", (16, 24, 12), 4), ("cavity_smag", (16, 24, 12), 3),
                                        ("devchan_nd", (32, 24, 12), 3),
+                                       # static Smagorinsky duct without wall model, power-of-two rows: x ghost columns left alone inside the step, the shear planes wrap around
+                                       ("duct_smag", (64, 32, 16), 4), ("duct_smag", (64, 16, 16), 2),
                                        # dynamic model with walls in y/z and in x/y/z (kernel-per-loop sequence, slab halos of its scratch fields)
                                        ("duct_dsmag_wm", (16, 24, 20), 2), ("duct_dsmag", (16, 24, 12), 3), ("cavity_dsmag", (16, 24, 12), 2),
                                        ("couette_imp3d_ops", (32, 24, 16), 2), ("chan_dsmag", (128, 32, 136), 2),
@@ -150,7 +152,7 @@ def test_slab_ranks_with_switch_combinations(name, ng, P, seed, monkeypatch):
     """Several slabs with three to five run-time switches at once (fixed seeds; overlap on for every other one): same bar as the plain slab test."""
     rng = np.random.RandomState(2000 + seed)
     pool = ["CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_DSMAG_EAGER", "CALES_GAUSSEL_MARCH",
-            "CALES_GAUSSEL_PAIR", "CALES_DSMAG_XGHOSTS", "CALES_WIDE_OFFSETS", "CALES_DSMAG_UNFUSED_FILTER", "CALES_UNMERGED_BC", "CALES_FFT_STAGED", "CALES_DSMAG_STORE_UC",
+            "CALES_DSMAG_XGHOSTS", "CALES_WIDE_OFFSETS", "CALES_DSMAG_UNFUSED_FILTER", "CALES_UNMERGED_BC", "CALES_FFT_STAGED", "CALES_DSMAG_STORE_UC",
             "CALES_XGHOSTS_IN_STEP", "CALES_BAND_GRID", "CALES_SMAG_TILE", "CALES_FFT_GENERIC", "CALES_HELMHOLTZ_Z_PER_COLUMN", "CALES_UNFUSED_IMP_RHS"]
     for k in rng.choice(pool, size=rng.randint(3, 6), replace=False):
         monkeypatch.setenv(str(k), "1")

@@ -166,13 +166,11 @@ def test_unfused_paths(name, env, monkeypatch):
 
 
 SWITCH_CASES = [
-    # one lane per complex mode in the marching z sweep; per-column pivots / separate implicit r.h.s. passes in the z-implicit step
-    ({"CALES_GAUSSEL_PAIR": "1"}, ["chan_dsmag", "chan_smag_wm", "tgv_ppp", "cavity_nnn"]),
+    # per-column pivots / separate implicit r.h.s. passes in the z-implicit step
     ({"CALES_HELMHOLTZ_Z_PER_COLUMN": "1"}, ["duct_smag_wm_imp1d", "halfchan_imp1d"]),
     ({"CALES_UNFUSED_IMP_RHS": "1"}, ["duct_smag_wm_imp1d", "halfchan_imp1d"]),
-    # ghost columns of the dynamic model's scratch fields filled instead of wrapped; rows without the 128-byte alignment
+    # ghost columns of the dynamic model's scratch fields filled instead of wrapped
     ({"CALES_DSMAG_XGHOSTS": "1"}, ["chan_dsmag", "chan_dsmag_wm", "tgv_dsmag_ppp", "duct_dsmag_wm"]),
-    ({"CALES_UNALIGNED": "1"}, ["chan_dsmag", "chan_smag_wm", "tgv_ppp", "duct_smag_wm_imp1d", "cavity_nnn", "devchan_nd"]),
     # k chunks of the marching tile kernels: forced length (with its three-plane prologues inside the field) and the block-count threshold
     ({"CALES_KCHUNK": "3"}, ["chan_dsmag", "chan_dsmag_wm", "chan_smag_wm", "duct_dsmag_wm", "duct_smag_wm_imp1d"]),
     ({"CALES_KCHUNK": "5", "CALES_SMAG_TILE": "1"}, ["chan_smag_wm", "duct_smag_wm"]),
@@ -184,9 +182,8 @@ SWITCH_CASES = [
     ({"CALES_FFT_STAGED": "1"}, ["chan_dsmag", "tgv_ppp"]),
     # dynamic model: |S|Sij as six scalar fields between K_AC and the last pass instead of three fields of pairs (the default where x and y are periodic)
     ({"CALES_DSMAG_UNPAIRED": "1"}, ["chan_dsmag", "chan_dsmag_wm", "tgv_dsmag_ppp", "chan_dsmag_p2"]),
-    # tile heights of the LDS form of the static Smagorinsky pass
-    ({"CALES_SMAG_TILE": "1", "CALES_SMAG_TY": "6"}, ["chan_smag", "chan_smag_wm", "duct_smag_wm"]),
-    ({"CALES_SMAG_TILE": "1", "CALES_SMAG_TY": "14"}, ["chan_smag", "chan_smag_wm", "duct_smag_wm"]),
+    # the LDS-tile form of the static Smagorinsky pass
+    ({"CALES_SMAG_TILE": "1"}, ["chan_smag", "chan_smag_wm", "duct_smag_wm"]),
 ]
 
 
@@ -198,7 +195,7 @@ def test_remaining_switches(envs, name, monkeypatch):
     for k, v in envs.items():
         monkeypatch.setenv(k, v)
     test_fused_step_matches_operator_sequence(name)
-    if "CALES_SMAG_TY" in envs or "CALES_KCHUNK" in envs:
+    if "CALES_SMAG_TILE" in envs or "CALES_KCHUNK" in envs:
         test_startup_and_substeps(name)      # stage by stage at 1e-13 as well
 
 
@@ -296,7 +293,8 @@ def test_plane_statistics_against_reference(name):
     h.close()
 
 
-@pytest.mark.parametrize("name", ["tgv_ppp", "chan_smag_wm", "chan_dsmag", "duct_smag_wm", "duct_smag_wm_imp1d", "duct_dsmag", "cavity_nnn", "devchan_nd", "halfchan_imp1d"])
+@pytest.mark.parametrize("name", ["tgv_ppp", "chan_smag_wm", "chan_dsmag", "duct_smag_wm", "duct_smag_wm_imp1d", "duct_dsmag", "cavity_nnn", "devchan_nd", "halfchan_imp1d",
+                                  "chan_dsmag_p2", "chan_smag_p2", "duct_dsmag_p2", "tgv_ppp_p2"])
 def test_profiles_and_duct_statistics(name):
     """cales_out1d, cales_out1d_chan, cales_out2d_duct (src/output.f90:50-163, 317-507) on the end-of-step state of the golden cases: against what
     the reference's own routines print (8 significant digits, tests/golden/outstats.npz) and against the oracle to 1e-13 of each column's scale

@@ -96,7 +96,12 @@ def test_tridiagonal_paths_agree(name, ng, monkeypatch):
                                             # power-of-two rows with periodic x: cales_step leaves the x ghost columns alone until it returns and its kernels
                                             # wrap around (one full tile, two tiles, a row shorter than a tile; all ghost cells are compared at the end)
                                             ("chan_dsmag", (64, 20, 12), 3), ("chan_dsmag", (128, 12, 20), 2), ("chan_smag", (64, 18, 12), 3), ("chan_smag", (128, 10, 16), 2),
-                                            ("chan_smag", (16, 12, 10), 3), ("tgv_dsmag_ppp", (64, 16, 24), 3), ("duct_dsmag", (64, 18, 20), 2), ("tgv_ppp", (128, 8, 8), 3)])
+                                            ("chan_smag", (16, 12, 10), 3), ("tgv_dsmag_ppp", (64, 16, 24), 3), ("duct_dsmag", (64, 18, 20), 2), ("tgv_ppp", (128, 8, 8), 3),
+                                            # static Smagorinsky duct WITHOUT wall model, power-of-two rows: the step leaves the x ghost columns alone and the
+                                            # shear of the y walls (k_wall_shear_y) has to wrap around like every other reader; one and two x tiles
+                                            ("duct_smag", (64, 16, 20), 3), ("duct_smag", (128, 12, 16), 2), ("duct_smag", (24, 18, 12), 3),
+                                            # BASELINE configs[0] at its own size in FP64
+                                            ("tgv_ppp", (64, 64, 64), 3)])
 def test_time_steps(name, ng, nsteps):
     """u,v,w <= 1e-9, p (mean removed) <= 1e-8 after the steps; divmax same order of magnitude"""
     from cales_amd.hotpath import initflow
@@ -137,7 +142,7 @@ def test_time_steps_with_x_ghosts_kept(name, ng, nsteps, monkeypatch):
 
 
 _BOOL_SWITCHES = ["CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_KEEP_LAST_RHS",
-                  "CALES_DSMAG_EAGER", "CALES_GAUSSEL_MARCH", "CALES_GAUSSEL_PAIR", "CALES_DSMAG_XGHOSTS", "CALES_WIDE_OFFSETS", "CALES_UNALIGNED",
+                  "CALES_DSMAG_EAGER", "CALES_GAUSSEL_MARCH", "CALES_DSMAG_XGHOSTS", "CALES_WIDE_OFFSETS",
                   "CALES_DSMAG_UNFUSED_FILTER", "CALES_UNMERGED_BC", "CALES_FFT_STAGED", "CALES_DSMAG_STORE_UC", "CALES_DSMAG_UNPAIRED", "CALES_XGHOSTS_IN_STEP", "CALES_BAND_GRID",
                   "CALES_PLAIN_GRID", "CALES_SMAG_TILE", "CALES_FFT_GENERIC", "CALES_HELMHOLTZ_Z_PER_COLUMN", "CALES_UNFUSED_IMP_RHS",
                   "CALES_DSMAG_REFERENCE_SEQUENCE", "CALES_SMAG_REFERENCE_SEQUENCE"]
@@ -578,6 +583,7 @@ OPEN_SETS = [(("DN", "NN"), None, (16, 12, 10)),      # the developing channel: 
              (("DD", "DD"), ("DN", "DN"), (12, 16, 10))]
 
 
+@pytest.mark.imp3d_open
 @pytest.mark.parametrize("xset,yset,ng", OPEN_SETS)
 @pytest.mark.parametrize("ivel", [1, 2, 3])
 def test_helmholtz_3d_open_boundaries(xset, yset, ng, ivel):
@@ -603,6 +609,7 @@ def test_helmholtz_3d_open_boundaries(xset, yset, ng, ivel):
     h.close()
 
 
+@pytest.mark.imp3d_open
 @pytest.mark.parametrize("xset,yset,ng", [OPEN_SETS[0], OPEN_SETS[1], OPEN_SETS[4], OPEN_SETS[7]])
 def test_time_steps_imp3d_open(xset, yset, ng):
     """Three steps of an inflow / outflow box with 3-D implicit diffusion (impdiff = 1): momentum split, boundary terms of the inflow faces,

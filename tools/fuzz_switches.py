@@ -9,7 +9,7 @@ from cales_amd.hotpath import HotPath, initflow
 from oracle.oracle import Oracle
 
 POOL = ["CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_KEEP_LAST_RHS", "CALES_DSMAG_EAGER",
-        "CALES_GAUSSEL_MARCH", "CALES_GAUSSEL_PAIR", "CALES_DSMAG_XGHOSTS", "CALES_WIDE_OFFSETS", "CALES_UNALIGNED", "CALES_DSMAG_UNFUSED_FILTER", "CALES_UNMERGED_BC",
+        "CALES_GAUSSEL_MARCH", "CALES_DSMAG_XGHOSTS", "CALES_WIDE_OFFSETS", "CALES_DSMAG_UNFUSED_FILTER", "CALES_UNMERGED_BC",
         "CALES_FFT_STAGED", "CALES_DSMAG_STORE_UC", "CALES_DSMAG_UNPAIRED", "CALES_XGHOSTS_IN_STEP", "CALES_BAND_GRID", "CALES_PLAIN_GRID", "CALES_SMAG_TILE", "CALES_FFT_GENERIC",
         "CALES_HELMHOLTZ_Z_PER_COLUMN", "CALES_UNFUSED_IMP_RHS", "CALES_DSMAG_REFERENCE_SEQUENCE", "CALES_SMAG_REFERENCE_SEQUENCE"]
 NAMES = ["chan_dsmag", "chan_dsmag_wm", "chan_smag_wm", "tgv_dsmag_ppp", "cavity_nnn", "duct_smag_wm_imp1d", "chan_smag", "duct_dsmag_wm", "duct_dsmag", "cavity_dsmag",
@@ -19,7 +19,7 @@ bad = 0
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 26):
     name = NAMES[trial % len(NAMES)]
     ng = (int(2 ** rng.randint(3, 8)) if trial % 2 else int(2 * rng.randint(4, 40)), int(2 * rng.randint(4, 30)), int(rng.randint(10, 60)))
-    for k in POOL + ["CALES_KCHUNK", "CALES_SMAG_TY"]:
+    for k in POOL + ["CALES_KCHUNK"]:
         os.environ.pop(k, None)
     chosen = [str(k) for k in rng.choice(POOL, size=rng.randint(2, 7), replace=False)]
     for k in chosen:
