@@ -47,6 +47,7 @@ struct ostate {
   double is_wall[6];
   int sgs_first;
   int nthreads;
+  int team_sums;                    /* o_set_team_sums: sums over all cells by planes (timing runs); 0 = the reference's cell-by-cell order */
 };
 
 #define IX(i,j,k) ((size_t)(i) + s1*((size_t)(j) + s2*(size_t)(k)))
@@ -267,13 +268,13 @@ static void fft_rec(int n, const cpx *in, int istride, cpx *out, const cpx *tw, 
   cpx tstack[64]; cpx *t = r <= 64 ? tstack : (cpx *)malloc(sizeof(cpx)*r);      /* (no allocator call per recursion level for the usual radices) */
   for (int k = 0; k < m; k++) {
     for (int q = 0; q < r; q++) {
-      cpx x = out[(size_t)q*m + k], w = tw[(size_t)((long)q*k % n)*tstride];
+      cpx x = out[(size_t)q*m + k], w = tw[(size_t)((long)q*k)*tstride];      /* q k < r m = n: no wrap */
       t[q].re = x.re*w.re - x.im*w.im; t[q].im = x.re*w.im + x.im*w.re;
     }
     for (int p = 0; p < r; p++) {
       double sr = 0., si = 0.;
       for (int q = 0; q < r; q++) {
-        cpx w = tw[(size_t)(((long)p*q*m) % n)*tstride];
+        cpx w = tw[(size_t)((long)((p*q) % r)*m)*tstride];      /* (p q m) mod n = ((p q) mod r) m */
         sr += t[q].re*w.re - t[q].im*w.im; si += t[q].re*w.im + t[q].im*w.re;
       }
       out[(size_t)p*m + k].re = sr; out[(size_t)p*m + k].im = si;
@@ -303,38 +304,46 @@ static const cpx *twiddles(int n) {
   }
   return res;
 }
-static void cfft(int n, cpx *x) { /* forward, unnormalised */
-  cpx *y = (cpx *)malloc(sizeof(cpx)*n);
-  fft_rec(n, x, 1, y, twiddles(n), 1);
-  memcpy(x, y, sizeof(cpx)*n); free(y);
+/* scratch of the calling thread, grown on demand (three allocator calls per line -- 1.6e6 lines per solve at 512^3 -- were the other thing besides
+   the twiddle look-up that every thread of a large team queued for) */
+static void *scratch(int slot, size_t bytes) {
+  static __thread void *buf[4]; static __thread size_t cap[4];
+  if (cap[slot] < bytes) { free(buf[slot]); buf[slot] = malloc(bytes); cap[slot] = bytes; }
+  return buf[slot];
 }
-void o_r2r(int kind, int n, double *x, int st) {
-  double *y = (double *)malloc(sizeof(double)*(n > 0 ? n : 1)); cpx *z; const double pi = PI;
+static void cfft(int n, cpx *x) { /* forward, unnormalised */
+  cpx *y = (cpx *)scratch(0, sizeof(cpx)*n);
+  fft_rec(n, x, 1, y, twiddles(n), 1);
+  memcpy(x, y, sizeof(cpx)*n);
+}
+static void r2r_impl(int kind, int n, double *x, int st, int depth) {
+  /* (RODFT10/01 call REDFT10/01 on their own y: the nested call takes the second pair of scratch slots) */
+  double *y = (double *)scratch(1 + 2*depth, sizeof(double)*(n > 0 ? n : 1)); cpx *z; const double pi = PI;
   switch (kind) {
   case O_R2HC: /* Y_k = sum x_j e^{-2 pi i jk/n}; out r0..r_{n/2}, i_{(n+1)/2-1}..i_1 */
-    z = (cpx *)malloc(sizeof(cpx)*n);
+    z = (cpx *)scratch(2, sizeof(cpx)*n);
     for (int j = 0; j < n; j++) { z[j].re = x[(size_t)j*st]; z[j].im = 0.; }
     cfft(n, z);
     for (int k = 0; k <= n/2; k++) y[k] = z[k].re;
     for (int k = 1; k < (n+1)/2; k++) y[n-k] = z[k].im;
-    free(z); break;
+    break;
   case O_HC2R: /* inverse of the above, unnormalised: x_j = sum_k Y_k e^{+2 pi i jk/n} */
-    z = (cpx *)malloc(sizeof(cpx)*n);
+    z = (cpx *)scratch(2, sizeof(cpx)*n);
     for (int k = 0; k <= n/2; k++) { z[k].re = x[(size_t)k*st]; z[k].im = 0.; }
     for (int k = 1; k < (n+1)/2; k++) { z[k].im = x[(size_t)(n-k)*st]; z[n-k].re = z[k].re; z[n-k].im = -z[k].im; }
     for (int k = 0; k < n; k++) z[k].im = -z[k].im;       /* conj -> forward FFT -> conj */
     cfft(n, z);
     for (int j = 0; j < n; j++) y[j] = z[j].re;
-    free(z); break;
+    break;
   case O_REDFT10: /* DCT-II: Y_k = 2 sum x_j cos(pi (j+1/2) k / n), via Makhoul's length-n FFT */
-    z = (cpx *)malloc(sizeof(cpx)*n);
+    z = (cpx *)scratch(2, sizeof(cpx)*n);
     for (int j = 0; j < (n+1)/2; j++) { z[j].re = x[(size_t)(2*j)*st]; z[j].im = 0.; }
     for (int j = 0; j < n/2; j++) { z[n-1-j].re = x[(size_t)(2*j+1)*st]; z[n-1-j].im = 0.; }
     cfft(n, z);
     for (int k = 0; k < n; k++) { double a = -pi*k/(2.*n); y[k] = 2.*(z[k].re*cos(a) - z[k].im*sin(a)); }
-    free(z); break;
+    break;
   case O_REDFT01: /* DCT-III: Y_k = x_0 + 2 sum_{j>=1} x_j cos(pi j (k+1/2)/n) */
-    z = (cpx *)malloc(sizeof(cpx)*n);
+    z = (cpx *)scratch(2, sizeof(cpx)*n);
     for (int k = 0; k < n; k++) { /* V_k = (x_k - i x_{n-k}) e^{+i pi k/2n}, x_n := 0; then inverse FFT */
       double xr = x[(size_t)k*st], xi = k == 0 ? 0. : -x[(size_t)(n-k)*st], a = pi*k/(2.*n);
       z[k].re = xr*cos(a) - xi*sin(a); z[k].im = -(xr*sin(a) + xi*cos(a)); /* conj for inverse via forward */
@@ -342,15 +351,15 @@ void o_r2r(int kind, int n, double *x, int st) {
     cfft(n, z);
     for (int j = 0; j < (n+1)/2; j++) y[2*j] = z[j].re;
     for (int j = 0; j < n/2; j++) y[2*j+1] = z[n-1-j].re;
-    free(z); break;
+    break;
   case O_RODFT10: /* DST-II: Y_k = 2 sum x_j sin(pi (j+1/2)(k+1)/n) = DCT-II of (-1)^j x_j, reversed */
     for (int j = 0; j < n; j++) y[j] = (j & 1) ? -x[(size_t)j*st] : x[(size_t)j*st];
-    o_r2r(O_REDFT10, n, y, 1);
+    r2r_impl(O_REDFT10, n, y, 1, 1);
     for (int k = 0; k < n/2; k++) { double t = y[k]; y[k] = y[n-1-k]; y[n-1-k] = t; }
     break;
   case O_RODFT01: /* DST-III: Y_k = (-1)^k x_{n-1} + 2 sum_{j<n-1} x_j sin(pi (j+1)(k+1/2)/n) */
     for (int j = 0; j < n; j++) y[j] = x[(size_t)(n-1-j)*st];
-    o_r2r(O_REDFT01, n, y, 1);
+    r2r_impl(O_REDFT01, n, y, 1, 1);
     for (int k = 0; k < n; k++) if (k & 1) y[k] = -y[k];
     break;
   case O_REDFT11: for (int k = 0; k < n; k++) { double a = 0.;
@@ -364,8 +373,8 @@ void o_r2r(int kind, int n, double *x, int st) {
   default: for (int k = 0; k < n; k++) y[k] = x[(size_t)k*st];
   }
   for (int k = 0; k < n; k++) x[(size_t)k*st] = y[k];
-  free(y);
 }
+void o_r2r(int kind, int n, double *x, int st) { r2r_impl(kind, n, x, st, 0); }
 
 /* ------------------------------------------------------------------ create / destroy */
 ostate *o_create(const oparams *p) {
@@ -436,6 +445,7 @@ void o_destroy(ostate *s) {
 }
 /* first touch of a haloed field by the threads that will work on its planes (timing aid of bench.py's cpu_baseline: a field allocated by the
    caller and first written by one thread lives on that thread's NUMA node; the loops below are split over (k, j) like this one). No arithmetic. */
+void o_set_team_sums(ostate *s, int on) { s->team_sums = on != 0; }
 void o_first_touch(const ostate *s, double *a) {
   const int *n = s->n; const size_t s1 = s->s1, s2 = s->s2;
   #pragma omp parallel for collapse(2) schedule(static) num_threads(s->nthreads)
@@ -479,6 +489,7 @@ static void set_bc(ostate *s, char ctype, int ibound, int idir, int centered, co
   double sgn = (ctype == 'D' && centered) ? -1. : 1.;
   #define PA(m,a_,b_) (idir == 1 ? p[IX(m,a_,b_)] : idir == 2 ? p[IX(a_,m,b_)] : p[IX(a_,b_,m)])
   #define SETP(m,a_,b_,val) do { if (idir == 1) p[IX(m,a_,b_)] = (val); else if (idir == 2) p[IX(a_,m,b_)] = (val); else p[IX(a_,b_,m)] = (val); } while (0)
+  #pragma omp parallel for schedule(static) num_threads(s->nthreads)
   for (int b_ = 0; b_ <= nb+1; b_++) for (int a_ = 0; a_ <= na+1; a_++) {
     double bcv = bc ? bc[a_ + (size_t)(na+2)*b_ + ibound*pl] : 0.;
     switch (ctype) {
@@ -501,9 +512,13 @@ static void updthalo_self(ostate *s, int idir, double *p) {
   if (idir == 1) return;                       /* pencil axis */
   if (ISB(0,idir)) return;                     /* neighbours are MPI_PROC_NULL */
   const int *n = s->n; size_t s1 = s->s1, s2 = s->s2;
-  if (idir == 2) { for (int k = 0; k <= n[2]+1; k++) for (int i = 0; i <= n[0]+1; i++) {
+  if (idir == 2) {
+    #pragma omp parallel for schedule(static) num_threads(s->nthreads)
+    for (int k = 0; k <= n[2]+1; k++) for (int i = 0; i <= n[0]+1; i++) {
       p[IX(i,n[1]+1,k)] = p[IX(i,1,k)]; p[IX(i,0,k)] = p[IX(i,n[1],k)]; } }
-  else { for (int j = 0; j <= n[1]+1; j++) for (int i = 0; i <= n[0]+1; i++) {
+  else {
+    #pragma omp parallel for schedule(static) num_threads(s->nthreads)
+    for (int j = 0; j <= n[1]+1; j++) for (int i = 0; i <= n[0]+1; i++) {
       p[IX(i,j,n[2]+1)] = p[IX(i,j,1)]; p[IX(i,j,0)] = p[IX(i,j,n[2])]; } }
 }
 void o_boundp(ostate *s, int which, double *p) {   /* bound.f90:156-200 */
@@ -744,7 +759,20 @@ void o_mom(ostate *s, const double *u, const double *v, const double *w, const d
 double o_bulk_mean(ostate *s, int c_or_f, const double *p) {
   const int *n = s->n; size_t s1 = s->s1, s2 = s->s2; const double *g = c_or_f ? s->gvr_f : s->gvr_c;
   double mean = 0.;
-  for (int k = 1; k <= n[2]; k++) for (int j = 1; j <= n[1]; j++) for (int i = 1; i <= n[0]; i++) mean = mean + p[IX(i,j,k)]*g[k];
+  if (!s->team_sums) {      /* the reference's order on one rank (utils.f90:35-46): cell by cell -- what the golden vectors were made with */
+    for (int k = 1; k <= n[2]; k++) for (int j = 1; j <= n[1]; j++) for (int i = 1; i <= n[0]; i++) mean = mean + p[IX(i,j,k)]*g[k];
+    return mean;
+  }
+  /* o_set_team_sums (the timed CPU baseline): every plane is summed in the reference's (i, j) order by one thread and the planes are added in order --
+     one value for every team size, equal to the sequential sum to a few units in the last place (as the reference's own value is across rank counts:
+     local sums + MPI_ALLREDUCE) */
+  double *part = (double *)malloc(sizeof(double)*(size_t)(n[2]+2));
+  #pragma omp parallel for schedule(static) num_threads(s->nthreads)
+  for (int k = 1; k <= n[2]; k++) { double a = 0.;
+    for (int j = 1; j <= n[1]; j++) for (int i = 1; i <= n[0]; i++) a = a + p[IX(i,j,k)]*g[k];
+    part[k] = a; }
+  for (int k = 1; k <= n[2]; k++) mean = mean + part[k];
+  free(part);
   return mean;
 }
 void o_bulk_forcing(ostate *s, const double *f, double *u, double *v, double *w) {
@@ -957,6 +985,7 @@ double o_chkdt(ostate *s, const double *visct, const double *u, const double *v,
   const int *n = s->n; const size_t s1 = s->s1, s2 = s->s2; const double *dzci = s->dzci, *dzfi = s->dzfi;
   double dxi = 1./s->dl[0], dyi = 1./s->dl[1], dl2i = dxi*dxi + dyi*dyi, visc = s->visc;
   double dti = 0., dtid = 0.; const int imp = s->P.impdiff;
+  #pragma omp parallel for collapse(2) schedule(static) reduction(max:dti,dtid) num_threads(s->nthreads)
   for (int k = 1; k <= n[2]; k++) for (int j = 1; j <= n[1]; j++) for (int i = 1; i <= n[0]; i++) {
     double ux = fabs(u[IX(i,j,k)]);
     double vx = 0.25*fabs(v[IX(i,j,k)] + v[IX(i,j-1,k)] + v[IX(i+1,j,k)] + v[IX(i+1,j-1,k)]);
@@ -985,10 +1014,23 @@ double o_chkdt(ostate *s, const double *visct, const double *u, const double *v,
 void o_chkdiv(ostate *s, const double *u, const double *v, const double *w, double *divtot, double *divmax) { /* chkdiv.f90:16-52 */
   const int *n = s->n; const size_t s1 = s->s1, s2 = s->s2; double dxi = s->dli[0], dyi = s->dli[1];
   double dt_ = 0., dm = 0.;
-  for (int k = 1; k <= n[2]; k++) for (int j = 1; j <= n[1]; j++) for (int i = 1; i <= n[0]; i++) {
-    double div = (w[IX(i,j,k)] - w[IX(i,j,k-1)])*s->dzfi[k] + (v[IX(i,j,k)] - v[IX(i,j-1,k)])*dyi + (u[IX(i,j,k)] - u[IX(i-1,j,k)])*dxi;
-    dm = fmax(dm, fabs(div)); dt_ = dt_ + div;
+  if (!s->team_sums) {
+    for (int k = 1; k <= n[2]; k++) for (int j = 1; j <= n[1]; j++) for (int i = 1; i <= n[0]; i++) {
+      double div = (w[IX(i,j,k)] - w[IX(i,j,k-1)])*s->dzfi[k] + (v[IX(i,j,k)] - v[IX(i,j-1,k)])*dyi + (u[IX(i,j,k)] - u[IX(i-1,j,k)])*dxi;
+      dm = fmax(dm, fabs(div)); dt_ = dt_ + div;
+    }
+    *divtot = dt_; *divmax = dm; return;
   }
+  double *part = (double *)malloc(sizeof(double)*(size_t)(n[2]+2));
+  /* (the maximum is exact in any order; the total is summed plane by plane in the reference's (i, j) order, planes added in order: one value for every team size) */
+  #pragma omp parallel for schedule(static) reduction(max:dm) num_threads(s->nthreads)
+  for (int k = 1; k <= n[2]; k++) { double a = 0.;
+    for (int j = 1; j <= n[1]; j++) for (int i = 1; i <= n[0]; i++) {
+      double div = (w[IX(i,j,k)] - w[IX(i,j,k-1)])*s->dzfi[k] + (v[IX(i,j,k)] - v[IX(i,j-1,k)])*dyi + (u[IX(i,j,k)] - u[IX(i-1,j,k)])*dxi;
+      dm = fmax(dm, fabs(div)); a = a + div; }
+    part[k] = a; }
+  for (int k = 1; k <= n[2]; k++) dt_ = dt_ + part[k];
+  free(part);
   *divtot = dt_; *divmax = dm;
 }
 
@@ -1076,12 +1118,24 @@ static void extrapolate(ostate *s, double *p, int iface, int use_cbc) {   /* sgs
     for (int d = 1; d <= 3; d++) for (int ib = 0; ib <= 1; ib++) done[ib + 2*(d-1)] = ISB(ib,d) && CBV(ib,d,d) == 'D' && iface != d;
   } else { factor0 = (1./s->dzci[0])*s->dzci[1]; factor1 = (1./s->dzci[n[2]])*s->dzci[n[2]-1];
     for (int d = 1; d <= 3; d++) for (int ib = 0; ib <= 1; ib++) done[ib + 2*(d-1)] = ISB(ib,d) && LWM(ib,d) != 0 && iface != d; }
-  if (done[0]) for (int k = 0; k <= n[2]+1; k++) for (int j = 0; j <= n[1]+1; j++) p[IX(0,j,k)] = 2.*p[IX(1,j,k)] - p[IX(2,j,k)];
-  if (done[1]) for (int k = 0; k <= n[2]+1; k++) for (int j = 0; j <= n[1]+1; j++) p[IX(n[0]+1,j,k)] = 2.*p[IX(n[0],j,k)] - p[IX(n[0]-1,j,k)];
-  if (done[2]) for (int k = 0; k <= n[2]+1; k++) for (int i = 0; i <= n[0]+1; i++) p[IX(i,0,k)] = 2.*p[IX(i,1,k)] - p[IX(i,2,k)];
-  if (done[3]) for (int k = 0; k <= n[2]+1; k++) for (int i = 0; i <= n[0]+1; i++) p[IX(i,n[1]+1,k)] = 2.*p[IX(i,n[1],k)] - p[IX(i,n[1]-1,k)];
-  if (done[4]) for (int j = 0; j <= n[1]+1; j++) for (int i = 0; i <= n[0]+1; i++) p[IX(i,j,0)] = (1.+factor0)*p[IX(i,j,1)] - factor0*p[IX(i,j,2)];
-  if (done[5]) for (int j = 0; j <= n[1]+1; j++) for (int i = 0; i <= n[0]+1; i++) p[IX(i,j,n[2]+1)] = (1.+factor1)*p[IX(i,j,n[2])] - factor1*p[IX(i,j,n[2]-1)];
+  if (done[0]) {
+    #pragma omp parallel for schedule(static) num_threads(s->nthreads)
+    for (int k = 0; k <= n[2]+1; k++) for (int j = 0; j <= n[1]+1; j++) p[IX(0,j,k)] = 2.*p[IX(1,j,k)] - p[IX(2,j,k)]; }
+  if (done[1]) {
+    #pragma omp parallel for schedule(static) num_threads(s->nthreads)
+    for (int k = 0; k <= n[2]+1; k++) for (int j = 0; j <= n[1]+1; j++) p[IX(n[0]+1,j,k)] = 2.*p[IX(n[0],j,k)] - p[IX(n[0]-1,j,k)]; }
+  if (done[2]) {
+    #pragma omp parallel for schedule(static) num_threads(s->nthreads)
+    for (int k = 0; k <= n[2]+1; k++) for (int i = 0; i <= n[0]+1; i++) p[IX(i,0,k)] = 2.*p[IX(i,1,k)] - p[IX(i,2,k)]; }
+  if (done[3]) {
+    #pragma omp parallel for schedule(static) num_threads(s->nthreads)
+    for (int k = 0; k <= n[2]+1; k++) for (int i = 0; i <= n[0]+1; i++) p[IX(i,n[1]+1,k)] = 2.*p[IX(i,n[1],k)] - p[IX(i,n[1]-1,k)]; }
+  if (done[4]) {
+    #pragma omp parallel for schedule(static) num_threads(s->nthreads)
+    for (int j = 0; j <= n[1]+1; j++) for (int i = 0; i <= n[0]+1; i++) p[IX(i,j,0)] = (1.+factor0)*p[IX(i,j,1)] - factor0*p[IX(i,j,2)]; }
+  if (done[5]) {
+    #pragma omp parallel for schedule(static) num_threads(s->nthreads)
+    for (int j = 0; j <= n[1]+1; j++) for (int i = 0; i <= n[0]+1; i++) p[IX(i,j,n[2]+1)] = (1.+factor1)*p[IX(i,j,n[2])] - factor1*p[IX(i,j,n[2]-1)]; }
 }
 static void strain_rate(ostate *s, const double *u, const double *v, const double *w, double *s0, double **sij) { /* sgs.f90:1019-1110 */
   const int *n = s->n; const size_t s1 = s->s1, s2 = s->s2; const double dxi = s->dli[0], dyi = s->dli[1]; const double *dzci = s->dzci, *dzfi = s->dzfi;
@@ -1120,8 +1174,16 @@ static void filter3d(ostate *s, const double *p, double *pf) {   /* sgs.f90:616-
     #undef Q
   }
 }
+/* copy of a haloed field by the team, split over (k, j) like the loops that use it (a memcpy by one thread would also first-touch a fresh scratch
+   field on that thread's NUMA node) */
+static void pcopy(ostate *s, double *d, const double *a) {
+  const int *n = s->n; const size_t s1 = s->s1, s2 = s->s2;
+  #pragma omp parallel for collapse(2) schedule(static) num_threads(s->nthreads)
+  for (int k = 0; k <= n[2] + 1; k++) for (int j = 0; j <= n[1] + 1; j++) memcpy(&d[IX(0,j,k)], &a[IX(0,j,k)], sizeof(double)*s1);
+}
 static void ave1d_channel_z(ostate *s, double *p) {       /* sgs.f90:433-482, idir = 3 */
   const int *n = s->n; const size_t s1 = s->s1, s2 = s->s2; double gar = s->dl[0]*s->dl[1]/(s->P.l[0]*s->P.l[1]);
+  #pragma omp parallel for schedule(static) num_threads(s->nthreads)
   for (int k = 1; k <= n[2]; k++) { double a = 0.;
     for (int j = 1; j <= n[1]; j++) for (int i = 1; i <= n[0]; i++) a = a + p[IX(i,j,k)];
     a = a*gar;
@@ -1145,7 +1207,7 @@ void o_cmpt_sgs(ostate *s, const double *u, const double *v, const double *w, do
     }
   }
   double *s0 = s->s0, **wk = s->wk;
-  memcpy(wk[0], u, sizeof(double)*nt); memcpy(wk[1], v, sizeof(double)*nt); memcpy(wk[2], w, sizeof(double)*nt);
+  pcopy(s, wk[0], u); pcopy(s, wk[1], v); pcopy(s, wk[2], w);
   extrapolate(s, wk[0], 1, 0); extrapolate(s, wk[1], 2, 0); extrapolate(s, wk[2], 3, 0);
   if (s->P.sgstype == 1) {
     strain_rate(s, wk[0], wk[1], wk[2], s0, NULL);
@@ -1195,23 +1257,28 @@ void o_cmpt_sgs(ostate *s, const double *u, const double *v, const double *w, do
   /* dynamic Smagorinsky, sgs.f90:153-380 */
   double **sij = s->sij, **mij = s->mij, **lij = s->sij;
   strain_rate(s, wk[0], wk[1], wk[2], s0, sij);
-  memcpy(visct, s0, sizeof(double)*nt);
+  pcopy(s, visct, s0);
   o_boundp(s, 1, s0); for (int m = 0; m < 6; m++) o_boundp(s, 1, sij[m]);
-  for (int m = 0; m < 6; m++) for (size_t q = 0; q < nt; q++) wk[m][q] = s0[q]*sij[m][q];
+  for (int m = 0; m < 6; m++) {
+    #pragma omp parallel for schedule(static) num_threads(s->nthreads)
+    for (size_t q = 0; q < nt; q++) wk[m][q] = s0[q]*sij[m][q]; }
   for (int m = 0; m < 6; m++) extrapolate(s, wk[m], 0, 1);
   for (int m = 0; m < 6; m++) filter3d(s, wk[m], mij[m]);
-  memcpy(wk[0], u, sizeof(double)*nt); memcpy(wk[1], v, sizeof(double)*nt); memcpy(wk[2], w, sizeof(double)*nt);
+  pcopy(s, wk[0], u); pcopy(s, wk[1], v); pcopy(s, wk[2], w);
   extrapolate(s, wk[0], 1, 1); extrapolate(s, wk[1], 2, 1); extrapolate(s, wk[2], 3, 1);
   filter3d(s, wk[0], s->uf); filter3d(s, wk[1], s->vf); filter3d(s, wk[2], s->wf);
   bounduvw_bc(s, &s->bcuf, &s->bcvf, &s->bcwf, 0, 0, s->uf, s->vf, s->wf);
   extrapolate(s, s->uf, 1, 0); extrapolate(s, s->vf, 2, 0); extrapolate(s, s->wf, 3, 0);
   strain_rate(s, s->uf, s->vf, s->wf, s0, sij);
+  #pragma omp parallel for collapse(2) schedule(static) num_threads(s->nthreads)
   for (int k = 1; k <= n[2]; k++) for (int j = 1; j <= n[1]; j++) for (int i = 1; i <= n[0]; i++) { size_t c = IX(i,j,k);
     for (int m = 0; m < 6; m++) mij[m][c] = 2.*(mij[m][c] - s->alph2[c]*s0[c]*sij[m][c]); }
+  #pragma omp parallel for collapse(2) schedule(static) num_threads(s->nthreads)
   for (int k = 1; k <= n[2]; k++) for (int j = 1; j <= n[1]; j++) for (int i = 1; i <= n[0]; i++) {   /* interpolate, sgs.f90:850-870 */
     size_t c = IX(i,j,k);
     s->uc[c] = 0.5*(u[c] + u[IX(i-1,j,k)]); s->vc[c] = 0.5*(v[c] + v[IX(i,j-1,k)]); s->wc[c] = 0.5*(w[c] + w[IX(i,j,k-1)]); }
   o_boundp(s, 1, s->uc); o_boundp(s, 1, s->vc); o_boundp(s, 1, s->wc);
+  #pragma omp parallel for schedule(static) num_threads(s->nthreads)
   for (size_t q = 0; q < nt; q++) {
     wk[0][q] = s->uc[q]*s->uc[q]; wk[1][q] = s->vc[q]*s->vc[q]; wk[2][q] = s->wc[q]*s->wc[q];
     wk[3][q] = s->uc[q]*s->vc[q]; wk[4][q] = s->uc[q]*s->wc[q]; wk[5][q] = s->vc[q]*s->wc[q]; }
@@ -1219,6 +1286,7 @@ void o_cmpt_sgs(ostate *s, const double *u, const double *v, const double *w, do
   for (int m = 0; m < 6; m++) filter3d(s, wk[m], lij[m]);
   extrapolate(s, s->uc, 0, 1); extrapolate(s, s->vc, 0, 1); extrapolate(s, s->wc, 0, 1);
   filter3d(s, s->uc, s->uf); filter3d(s, s->vc, s->vf); filter3d(s, s->wc, s->wf);
+  #pragma omp parallel for collapse(2) schedule(static) num_threads(s->nthreads)
   for (int k = 1; k <= n[2]; k++) for (int j = 1; j <= n[1]; j++) for (int i = 1; i <= n[0]; i++) { size_t c = IX(i,j,k);
     double m_[6], l_[6]; for (int m = 0; m < 6; m++) { m_[m] = mij[m][c]; l_[m] = lij[m][c]; }
     double uf = s->uf[c], vf = s->vf[c], wf = s->wf[c];
@@ -1226,6 +1294,7 @@ void o_cmpt_sgs(ostate *s, const double *u, const double *v, const double *w, do
     wk[0][c] = m_[0]*l_[0] + m_[1]*l_[1] + m_[2]*l_[2] + (m_[3]*l_[3] + m_[4]*l_[4] + m_[5]*l_[5])*2.;
     wk[1][c] = m_[0]*m_[0] + m_[1]*m_[1] + m_[2]*m_[2] + (m_[3]*m_[3] + m_[4]*m_[4] + m_[5]*m_[5])*2.; }
   ave1d_channel_z(s, wk[0]); ave1d_channel_z(s, wk[1]);
+  #pragma omp parallel for collapse(2) schedule(static) num_threads(s->nthreads)
   for (int k = 1; k <= n[2]; k++) for (int j = 1; j <= n[1]; j++) for (int i = 1; i <= n[0]; i++) { size_t c = IX(i,j,k);
     visct[c] = visct[c]*wk[0][c]/wk[1][c]; visct[c] = fmax(visct[c], 0.); }
 }

@@ -45,6 +45,9 @@ typedef struct ostate ostate;
 
 ostate *o_create(const oparams *p);
 void    o_destroy(ostate *s);
+/* sums over all cells (bulk mean, total divergence): 0 (default) = cell by cell in the reference's order on one rank, what the golden vectors pin;
+   1 = plane by plane over the OpenMP team (bench.py's timed CPU baseline: a serial sum over 1.3e8 cells three times a step would idle 127 cores) */
+void    o_set_team_sums(ostate *s, int on);
 
 /* set-up products (src/initgrid.f90, src/bound.f90:726-867, src/initsolver.f90) */
 void o_first_touch(const ostate *s, double *a);

@@ -43,7 +43,7 @@ def _p(a: np.ndarray):
 
 
 class Oracle:
-    def __init__(self, case, nthreads: int = 1):
+    def __init__(self, case, nthreads: int = 1, team_sums: bool = False):
         self.lib = C.CDLL(build())
         L = self.lib
         L.o_create.restype = C.c_void_p
@@ -69,6 +69,8 @@ class Oracle:
         p.nthreads = int(nthreads)
         self.params = p
         self.h = C.c_void_p(L.o_create(C.byref(p)))
+        if team_sums:      # timing runs: sums over all cells by planes over the team instead of cell by cell on one thread (cales_oracle.h)
+            L.o_set_team_sums(self.h, 1)
         self.n = tuple(int(x) for x in case.ng)
         self.shape = tuple(x + 2 for x in self.n)
 

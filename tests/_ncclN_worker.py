@@ -28,6 +28,8 @@ for name, ng in (("chan_dsmag", (64, 16 * P, 24)), ("duct_smag_wm", (32, 16 * P,
                  ("cavity_nnn", (32, 8 * P, 12)), ("duct_smag", (64, 8 * P, 16))):
     _, case = load_golden(name)
     case.ng[:] = ng
+    if P >= 8 and name.startswith("duct_smag_wm"):
+        case.hwm = 0.2      # the sampling height must lie inside the slab that owns the wall (sanity.f90:224-231): l(2)/8 = 0.25 is its upper bound
     if case.sgstype == "none" and case.cbcvel[0, 0, 0] != "P":
         case.cbcsgs[:, 0] = "D"
     u, v, w, p = initflow(case)

@@ -217,7 +217,7 @@ def test_n_rank_nccl_process_group(layer, overlap):
     assert r.returncode == 0 and "NCCLN OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
-@pytest.mark.parametrize("P", [2, 3])
+@pytest.mark.parametrize("P", [2, 3, 8])      # 8: the rank count of the node the north star names (rank order, cw = ceil(33 / 8) = 5 padded mode columns, 8-way reductions)
 def test_n_processes_one_gpu_staged_gloo(P):
     """Real processes (torch.distributed.run, one per rank) sharing the ONE GPU of the test box: RCCL refuses that, so the exchanges go
     through gloo with host staging (decomp.StagedGlooComm). Everything else is the production path of `bench.py --gpus N`: rendezvous, rank
@@ -248,6 +248,24 @@ def test_bench_two_processes_one_gpu():
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 1.) < 1e-9
     assert d["config"]["decomposition"] == "y-slabs x2" and "transpose" in d and d["transpose"]["alltoall_calls_per_step"] == 6.0
     assert d["icheck"]["blocks_in_timed_region"] >= 1
+
+
+def test_bench_eight_processes_one_gpu_bare_form():
+    """`python bench.py --gpus 8` in the bare form at the REAL rank count of the target node, the eight ranks sharing the one GPU of the test box through
+    gloo: 257 -> 33 x-modes over 8 ranks in blocks of cw = 5 (the last rank holds three padded columns), 8-row slabs, max-over-ranks timing over eight
+    processes, the 8-way rendezvous -- everything but RCCL itself."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1", "--ng", "64", "64", "32",
+                        "--backend", "gloo", "--no-cpu"], capture_output=True, text=True, timeout=1500, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 4 and d["value"] > 0 and d["config"]["decomposition"] == "y-slabs x8"
+    assert d["transpose"]["alltoall_calls_per_step"] == 6.0 and d["divmax"] < 1e-11
+    assert "configs" not in d and "cpu_baseline" not in d      # side measurements belong to the N = 1 line only
 
 
 def test_bench_bare_form_spawns_its_ranks():

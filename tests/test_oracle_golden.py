@@ -285,3 +285,36 @@ def test_profiles_and_duct_statistics_against_reference(name):
     dl2 = float(case.l[1]) / n2
     printed_equal(np.tile((np.arange(n2) + 0.5) * dl2, n3), duct[:, 0], "y")
     printed_equal(np.repeat(o.grid()["zc"][1:-1], n2), duct[:, 1], "z")
+
+
+@pytest.mark.parametrize("name,ng", [("chan_dsmag", (48, 40, 36)), ("duct_smag_wm_imp1d", (32, 24, 40))])
+def test_team_sums_agree_with_the_reference_order(name, ng):
+    """Oracle(team_sums=True), the mode bench.py's CPU baseline times: the bulk mean and the total divergence are summed plane by plane over the OpenMP
+    team instead of cell by cell on one thread (a serial sum over 1.3e8 cells three times a step would idle the host). Same value for every team size,
+    and equal to the reference-order result to a few units in the last place -- after two steps the fields agree to 1e-12."""
+    from cales_amd.hotpath import initflow
+    g, case = load_golden(name)
+    case.ng[:] = ng
+    out = []
+    for team, nth in ((False, 4), (True, 1), (True, 3), (True, 8)):
+        o = Oracle(case, nthreads=nth, team_sums=team)
+        u, v, w, p = initflow(case)
+        rng = np.random.RandomState(3)
+        for a in (u, v, w):
+            a[1:-1, 1:-1, 1:-1] += 0.02 * (rng.rand(*ng) - 0.5)
+        visct, pp = o.zeros(), o.zeros()
+        o.bounduvw(u, v, w, True, False); o.boundp(p, 0); o.cmpt_sgs(u, v, w, visct); o.boundp(visct, 1)
+        dt = 0.5 * o.chkdt(visct, u, v, w)
+        mean = o.bulk_mean(u, "f")
+        for _ in range(2):
+            o.step(dt, u, v, w, p, pp, visct)
+        out.append((mean, u, v, w, visct, o.chkdiv(u, v, w)))
+        o.close()
+    ref = out[0]
+    assert all(abs(x[0] - ref[0]) <= 1e-14 * abs(ref[0]) for x in out[1:])
+    for x in out[1:]:
+        for q in range(1, 5):
+            assert relerr(x[q], ref[q]) < (1e-12 if q < 4 else 1e-9)
+    # one value for every team size: bit for bit
+    for x in out[2:]:
+        assert x[0] == out[1][0] and all(np.array_equal(x[q], out[1][q]) for q in range(1, 5)) and x[5] == out[1][5]
