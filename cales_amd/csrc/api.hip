@@ -350,7 +350,7 @@ static int step_body(cales_ctx *c, real dt) {
   static const real rk[3][2] = {{32. / 60., 0.}, {25. / 60., -17. / 60.}, {45. / 60., -25. / 60.}};
   LAUNCH(c, k_zero6, dim3(1), dim3(64), 0, c->stream, c->d_force);     // dpdl(:) = 0
   c->in_step = true;
-  struct Reset { cales_ctx *c; ~Reset() { c->in_step = false; c->step_xskip = false; c->bc_nride = 0; c->defer_force = false; c->defer_imp_rhs = false; c->fuse_fillps_dti = 0.; c->fuse_mean_mask = 0; } } reset{c};      // also on the error returns
+  struct Reset { cales_ctx *c; ~Reset() { c->in_step = false; c->step_xskip = false; c->bc_nride = 0; c->fold_dtrk = 0.; c->defer_force = false; c->defer_imp_rhs = false; c->fuse_fillps_dti = 0.; c->fuse_mean_mask = 0; } } reset{c};      // also on the error returns
   // periodic x, explicit diffusion, no wall model, the fused passes everywhere: every kernel of the step wraps around instead of reading x ghost
   // columns, which are then left alone until the step returns (common.hpp, step_xskip)
   { bool ok = !c->fl.xghosts_in_step && CBP(c, 0, 1) == 'P' && CBP(c, 1, 1) == 'P' && c->C.impdiff == 0 && !c->fl.unfused_rk && !c->fl.unfused_correc &&
@@ -358,6 +358,15 @@ static int step_body(cales_ctx *c, real dt) {
     for (int q = 0; q < 6; ++q) ok = ok && c->C.lwm[q] == 0;
     for (int d = 0; d < 3; ++d) ok = ok && ((c->C.bcpre[2 * d] == 0. && c->C.bcpre[2 * d + 1] == 0.) || c->C.cbcpre[2 * d] == 'P');      // (fillps inside the x transform)
     c->step_xskip = ok; }
+  // dynamic model, one rank, x and y periodic (|S|Sij as pair fields), z periodic or two no-slip walls, explicit diffusion, no wall model: the
+  // projection u = u* - dtrk grad(pp) (+ the deferred forcing) and p += pp are folded into the strain-rate pass of cmpt_sgs, which reads the velocity
+  // anyway -- the correction pass (9 words per cell) disappears (dsmag_fast, k_strain_tile<.., CORR = 1>)
+  bool fold_correc = c->step_xskip && c->P == 1 && c->C.sgstype == 2 && c->C.impdiff == 0 && dsmag_pairs(c) && !c->fl.unfolded_correc && !c->fl.unfused_correc;
+  { const bool perz = CBV(c, 0, 3, 3) == 'P' && CBV(c, 1, 3, 3) == 'P';
+    bool walls = true;
+    for (int iv = 1; iv <= 3; ++iv) for (int sd = 0; sd <= 1; ++sd) walls = walls && CBV(c, sd, 3, iv) == 'D';
+    walls = walls && CBP(c, 0, 3) == 'N' && CBP(c, 1, 3) == 'N';
+    fold_correc = fold_correc && (perz || walls); }
   for (int irk = 1; irk <= 3; ++irk) {
     const real dtrk = (rk[irk - 1][0] + rk[irk - 1][1]) * dt, dtrki = 1. / dtrk;
     real alpha = 0.;
@@ -394,6 +403,8 @@ static int step_body(cales_ctx *c, real dt) {
     else { if (int e = op_fillps(c, dtrki)) return e; if (int e = op_updt_rhs_b(c)) return e; }
     { const int e = op_solver(c); c->fuse_fillps_dti = 0.; if (e) return e; }
     if (int e = op_boundp(c, c->f[CALES_PP], 0)) return e;
+    if (fold_correc) c->fold_dtrk = dtrk;      // correc, bounduvw, updatep, boundp(p): inside the cmpt_sgs below (dsmag_fast)
+    else {
     { const int e = fuse_cu ? op_correc_updatep(c, dtrk, alpha, 1) : op_correc(c, dtrk); c->defer_force = false; if (e) return e; }
     // the pressure is final once the fused correction has run: its ghost cells ride along with those of the velocity (one launch, one slab exchange)
     if (fuse_cu && !c->fl.unmerged_bc) { c->bc_nride = 1; c->bc_ride[0] = c->f[CALES_P]; c->bc_ride_which[0] = 0; }
@@ -402,8 +413,9 @@ static int step_body(cales_ctx *c, real dt) {
       if (e) return e;
       if (!fuse_cu) { if (int e2 = op_updatep(c, alpha)) return e2; }
       if (!rode) { if (int e2 = op_boundp(c, c->f[CALES_P], 0)) return e2; } }
+    }
     c->visct_bc_done = false;
-    if (int e = op_cmpt_sgs(c)) return e;
+    { const int e = op_cmpt_sgs(c); c->fold_dtrk = 0.; c->defer_force = false; if (e) return e; }
     // no subgrid model and homogeneous sgs BC values: the eddy viscosity is zero, ghost cells included, since start-up (sgs.f90:62-68)
     bool visct_ghosts = !(c->C.sgstype == 0 && c->visct_zero && !c->sgs_first);
     for (int q = 0; q < 6; ++q) if (c->C.bcsgs[q] != 0.) visct_ghosts = true;

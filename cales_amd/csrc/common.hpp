@@ -68,11 +68,12 @@ struct Spec {
 
 // Run-time switches: read from the environment ONCE, by cales_create; the launch path only looks at these fields.
 struct Flags {
-  bool helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_eager = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, unfused_rk = false, dsmag_unfused_filter = false, overlap = false, fft_staged = false, dsmag_store_uc = false, dsmag_unpaired = false, xghosts_in_step = false, unmerged_bc = false, smag_tile = false, plain_grid = false, band_grid = false;
+  bool unfolded_correc = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_eager = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, unfused_rk = false, dsmag_unfused_filter = false, overlap = false, fft_staged = false, dsmag_store_uc = false, dsmag_unpaired = false, xghosts_in_step = false, unmerged_bc = false, smag_tile = false, plain_grid = false, band_grid = false;
   int kchunk = 0; long tile_min_blocks = 2048;
   std::string test_bad_launch;      // CALES_TEST_BAD_LAUNCH: test hook of the launch check (LAUNCH below)
   void read_env() {
     test_bad_launch = getenv("CALES_TEST_BAD_LAUNCH") ? getenv("CALES_TEST_BAD_LAUNCH") : "";
+    unfolded_correc = getenv("CALES_UNFOLDED_CORREC") != nullptr;      // dynamic model in cales_step: the projection as a pass of its own (k_correc_cell) instead of inside the strain-rate pass
     helmholtz_z_per_column = getenv("CALES_HELMHOLTZ_Z_PER_COLUMN") != nullptr;
     unfused_imp_rhs = getenv("CALES_UNFUSED_IMP_RHS") != nullptr;
     unfused_correc = getenv("CALES_UNFUSED_CORREC") != nullptr;
@@ -192,6 +193,9 @@ struct cales_ctx {
   // interior column instead (a ghost-column update touches two cache lines per row and field for two values: 1.2 of 45 ms per step at 512^3) -- and
   // are brought up to date once, when the step returns
   bool step_xskip = false;
+  // cales_step, dynamic model on one rank with x and y periodic: the velocity correction and the pressure update of the substep are done by the
+  // strain-rate pass of the cmpt_sgs that follows (k_strain_tile<.., CORR = 1>, k_sgs.hip) -- != 0: the dtrk of the pending projection
+  real fold_dtrk = 0.;
   int field_ofs = 0;       // doubles between a field's allocation and its element (0,0,0)
   real *d_nullw = nullptr; // work space of k_null_column (CALES_KEEP_NULL_MODE)
 };

@@ -734,6 +734,14 @@ struct StrainTileArgs {
   int wylo, wyhi, wmylo, wmyhi; const real *twy; real dl2;
   BandMap bm;      // block -> (x tile, y tile, k chunk) map of the 1-D launches (bm.gx = 0: plain 3-D grid)
   int perx;        // x periodic: halo columns beyond the ends of a row are the wrapped interior columns (the ghost columns may be stale inside cales_step)
+  // CORR = 1 (cales_step, x and y periodic, one rank, z walls or z periodic, explicit diffusion, no wall model): u[] is the PREDICTION u*, v*, w* and the
+  // projection (correc.f90:44-67 with the deferred bulk forcing) + pressure update (updatep.f90:30-47) happen here -- every velocity value the pass
+  // reads is corrected while it is loaded, u = (u* + f) - dtrk grad(pp) at the periodically wrapped interior cell, the z ghost planes by their
+  // boundary rule (bounduvw with is_correc, bound.f90:18-154), the corrected velocity of the tile's own cells goes to un[] (a second set of buffers:
+  // neighbouring tiles still read u*) and p += pp in place. The pass k_correc_cell<1> (9 words per cell) disappears: 13 + 9 -> 19 words.
+  const real *pp; real *p; real *un[3]; const real *force; int fmask; real cfi, cfj, cdt;
+  const real *bcz[2][2];      // Dirichlet planes of u and v at the two z walls (bounduvw's 2 bc - u(1)), [component][side]
+  int zper;                   // z periodic: ghost planes are the wrapped interior planes
 };
 // sqrt(tau_w) at the two y walls for every (i, k): the argument of the van Driest damping of the cells whose nearest wall is a y wall
 // (sgs.f90:117-143, cases 3 and 4 of the select), from the fields themselves (their ghost cells, not the extrapolated ones)
@@ -754,8 +762,9 @@ __global__ __launch_bounds__(256) void k_wall_shear_y(Geom g, const real *__rest
     twy[(size_t)(g.n3 + 2 + k) * g.s1 + i] = sqrt(0.5 * visc * (sqrt(t1 * t1 + t2 * t2) * dyi));
   }
 }
-template <typename OFF, int SMAG, int TY, int YW, int PAIR = 0>      // YW = 1: walls or wall-model faces in y (ducts); the channel instantiations carry none of that logic
+template <typename OFF, int SMAG, int TY, int YW, int PAIR = 0, int CORR = 0>      // YW = 1: walls or wall-model faces in y (ducts); the channel instantiations carry none of that logic
 __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTileArgs A) {
+  static_assert(!CORR || (!SMAG && !YW && PAIR), "the projection is folded into the paired dynamic-model pass only");
   // (one barrier per plane with four ring slots and double-buffered sums, as in k_lij_mij_tile, measured 13 % slower here)
   __shared__ real ring[3][3][TY + 2][66];      // rows: x-halo cell, 64 own cells, x-halo cell
   __shared__ real shs[SMAG ? 1 : 3][TY + 2][64];
@@ -779,8 +788,77 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
     if (YW && yex != 0 && q != 1) return yex > 0 ? 2. * ldb(A.u[q], o + sjb) - ldb(A.u[q], o + 2 * sjb) : 2. * ldb(A.u[q], o - sjb) - ldb(A.u[q], o - 2 * sjb);
     return ldb(A.u[q], o);
   };
+  // ---- CORR: corrected velocity on load (see StrainTileArgs). Rows and columns are the wrapped interior ones (jr, iq / ih), pp's neighbours
+  // i+1 (the lane beside, or the halo column), j+1 (row jp, loaded again: a cache hit), k+1 (the next plane's own value, rolled).
+  const int jr = !CORR ? j : j == 0 ? g.n2 : j == g.n2 + 1 ? 1 : j, jp = jr >= g.n2 ? 1 : jr + 1;
+  const OFF cl = (CORR && ldok) ? (OFF)g.ix(iq, jr, 0) * RSZ : c0, cly = (CORR && ldok) ? (OFF)g.ix(iq, jp, 0) * RSZ : 0;
+  const int ihp = ih >= g.n1 ? 1 : ih + 1;      // column right of the halo column (needed by the lane right of the tile only)
+  const OFF chl = (CORR && hok) ? (OFF)g.ix(ih, jr, 0) * RSZ : ch, chy = (CORR && hok) ? (OFF)g.ix(ih, jp, 0) * RSZ : 0, chx = (CORR && hok) ? (OFF)g.ix(ihp, jr, 0) * RSZ : 0;
+  auto kz = [&](int kk) { return !A.zper ? kk : kk == 0 ? g.n3 : kk == g.n3 + 1 ? 1 : kk; };
+  real f3[3] = {0., 0., 0.};
+  if (CORR) { f3[0] = (A.fmask & 1) ? ldc(A.force, 0) : 0.; f3[1] = (A.fmask & 2) ? ldc(A.force, 1) : 0.; f3[2] = (A.fmask & 4) ? ldc(A.force, 2) : 0.; }
+  // what is in flight for one column between two iterations: the raw prediction of a plane and the pp values its correction needs
+  struct Raw { real q[3], py, pz, px; };
+  auto rawload = [&](bool ok, OFF o, OFF oy, bool wantx, OFF ox, int kk, Raw &r) {      // plane kk (already mapped by kz; 0 <= kk <= n3+1)
+    const OFF a = o + (OFF)kk * sk;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) r.q[q] = ok ? ldb(A.u[q], a) : 0.;
+    r.py = ok ? ldb(A.pp, oy + (OFF)kk * sk) : 0.;
+    r.pz = ok ? ldb(A.pp, o + (OFF)min(kk + 1, g.n3 + 1) * sk) : 0.;
+    r.px = (ok && wantx) ? ldb(A.pp, ox + (OFF)kk * sk) : 0.;
+  };
+  // corrected values of an interior plane (kq = its index in 1..n3) from the raw ones: P0 = pp of the cell, px / r.py / r.pz its neighbours
+  auto fix = [&](const Raw &r, real P0, real px, int kq, real *o) {
+    o[0] = ((A.fmask & 1) ? r.q[0] + f3[0] : r.q[0]) - A.cfi * (px - P0);
+    o[1] = ((A.fmask & 2) ? r.q[1] + f3[1] : r.q[1]) - A.cfj * (r.py - P0);
+    o[2] = ((A.fmask & 4) ? r.q[2] + f3[2] : r.q[2]) - A.cdt * ldc(A.dzci, kq) * (r.pz - P0);
+  };
+  // plane kk (raw values r / e of the own and the halo column, pp of the two cells P0 / E0) -> corrected values cc / hh. A z ghost plane next to a
+  // wall comes from its boundary rule: u, v = 2 bc - (the plane beside it: below[] / hbelow[]), w(0) by the formula without forcing (correc.f90 loops
+  // over k = 0..n3 for w), w(n3+1) untouched (bounduvw with is_correc leaves the normal component's z faces alone, bound.f90:60-75)
+  const size_t q2 = (size_t)iq + (size_t)(g.n1 + 2) * jr, q2h = (size_t)ih + (size_t)(g.n1 + 2) * jr;
+  auto complete = [&](int kk, const Raw &r, const Raw &e, real P0, real E0, const real *beside, const real *hbeside, real *cc, real *hh) {
+    const bool wall = !A.zper && (kk == 0 || kk == g.n3 + 1);
+    const int kq = kz(kk);
+    real px = lane_next(P0);
+    if (tx == 63) px = E0;
+    const real ex = tx == 0 ? P0 : e.px;
+    if (!wall) { fix(r, P0, px, kq, cc); if (edge) fix(e, E0, ex, kq, hh); }
+    else {
+      const int sd = kk == 0 ? 0 : 1;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) { cc[q] = ldok ? 2. * A.bcz[q][sd][q2] - beside[q] : 0.; if (edge) hh[q] = hok ? 2. * A.bcz[q][sd][q2h] - hbeside[q] : 0.; }
+      cc[2] = kk == 0 ? r.q[2] - A.cdt * ldc(A.dzci, 0) * (r.pz - P0) : r.q[2];
+      if (edge) hh[2] = kk == 0 ? e.q[2] - A.cdt * ldc(A.dzci, 0) * (e.pz - E0) : e.q[2];
+    }
+  };
+  Raw rn = {}, rh = {}; real p0n = 0., p0h = 0., pl = 0.;      // in flight: plane k+1 of the own / the halo column, pp and p of its cells
+  if (CORR) {
+    real c1[3], h1[3] = {0., 0., 0.}, c0v[3], h0[3] = {0., 0., 0.};
+    { Raw r, e = {}; const int kq = kz(kbeg);      // plane kbeg: always interior
+      rawload(ldok, cl, cly, false, 0, kq, r); const real P0 = ldok ? ldb(A.pp, cl + (OFF)kq * sk) : 0.; real E0 = 0.;
+      if (edge) { rawload(hok, chl, chy, tx == 63, chx, kq, e); E0 = hok ? ldb(A.pp, chl + (OFF)kq * sk) : 0.; }
+      complete(kbeg, r, e, P0, E0, nullptr, nullptr, c1, h1);
+      if (outok) { const OFF a = c0 + (OFF)kbeg * sk; stb(A.p, a, ldb(A.p, a) + P0); }      // p += pp (updatep.f90:30-47, explicit diffusion)
+      p0n = r.pz; p0h = e.pz; }
+    { Raw r, e = {}; const int kq = kz(kbeg - 1);      // plane kbeg-1: interior, wrapped, or the ghost plane below the lower wall
+      rawload(ldok, cl, cly, false, 0, kq, r); const real P0 = ldok ? ldb(A.pp, cl + (OFF)kq * sk) : 0.; real E0 = 0.;
+      if (edge) { rawload(hok, chl, chy, tx == 63, chx, kq, e); E0 = hok ? ldb(A.pp, chl + (OFF)kq * sk) : 0.; }
+      complete(kbeg - 1, r, e, P0, E0, c1, h1, c0v, h0); }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      ring[(kbeg - 1) % 3][q][ty][tx + 1] = c0v[q]; ring[kbeg % 3][q][ty][tx + 1] = c1[q];
+      if (edge) { ring[(kbeg - 1) % 3][q][ty][hx] = h0[q]; ring[kbeg % 3][q][ty][hx] = h1[q]; }
+      if (outok) stb(A.un[q], c0 + (OFF)kbeg * sk, c1[q]);
+    }
+    // plane kbeg+1 (<= n3: n3 >= 3 and chunks of several planes) stays raw until the first iteration completes it
+    rawload(ldok, cl, cly, false, 0, kz(kbeg + 1), rn);
+    if (edge) rawload(hok, chl, chy, tx == 63, chx, kz(kbeg + 1), rh);
+    pl = (outok && kbeg + 1 <= kend) ? ldb(A.p, c0 + (OFF)(kbeg + 1) * sk) : 0.;
+  }
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
+    if (CORR) break;
     ring[(kbeg - 1) % 3][q][ty][tx + 1] = ldok ? ld(q, c0 + (OFF)(kbeg - 1) * sk) : 0.;
     ring[kbeg % 3][q][ty][tx + 1] = ldok ? ld(q, c0 + (OFF)kbeg * sk) : 0.;
     if (edge) {
@@ -815,6 +893,27 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
   int km = (kbeg - 1) % 3, kc = kbeg % 3, kp = (kbeg + 1) % 3;
   for (int k = kbeg; k <= kend; ++k) {
     const OFF idx = c0 + (OFF)k * sk;
+    if (CORR) {
+      // plane k+1, loaded during the last iteration, is completed here (one iteration of latency behind its loads), stored if it belongs to this
+      // chunk, and plane k+2 goes into flight
+      real cc[3], hh[3] = {0., 0., 0.}, bes[2] = {0., 0.}, hbes[2] = {0., 0.};
+      if (!A.zper && k == g.n3) { bes[0] = ring[kc][0][ty][tx + 1]; bes[1] = ring[kc][1][ty][tx + 1]; if (edge) { hbes[0] = ring[kc][0][ty][hx]; hbes[1] = ring[kc][1][ty][hx]; } }
+      complete(k + 1, rn, rh, p0n, p0h, bes, hbes, cc, hh);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { ring[kp][q][ty][tx + 1] = cc[q]; if (edge) ring[kp][q][ty][hx] = hh[q]; }
+      if (outok && k + 1 <= kend) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) stb(A.un[q], idx + sk, cc[q]);
+        stb(A.p, idx + sk, pl + p0n);
+      }
+      const real p0n_next = rn.pz, p0h_next = rh.pz;
+      if (k + 2 <= g.n3 + 1) {
+        rawload(ldok, cl, cly, false, 0, kz(k + 2), rn);
+        if (edge) rawload(hok, chl, chy, tx == 63, chx, kz(k + 2), rh);
+        pl = (outok && k + 2 <= kend) ? ldb(A.p, idx + 2 * sk) : 0.;
+      }
+      p0n = p0n_next; p0h = p0h_next;
+    } else {
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       const bool ex = A.wmhi && k == g.n3 && q < 2;
@@ -824,6 +923,7 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
     if (k + 2 <= g.n3 + 1) {
 #pragma unroll
       for (int q = 0; q < 3; ++q) { fn[q] = ldok ? ld(q, idx + 2 * sk) : 0.; fh[q] = hok ? ld(q, ch + (OFF)(k + 2) * sk) : 0.; }
+    }
     }
     __syncthreads();
     const bool lo = A.zlo && k == 1, hi = A.zhi && k == g.n3;
@@ -1038,6 +1138,15 @@ __global__ __launch_bounds__(256) void k_vc_edge_rows(Geom g, const real *__rest
   vc[g.ix(i, 1, k)] = 0.5 * (v[g.ix(i, 1, k)] + v[g.ix(i, 0, k)]);
   vc[g.ix(i, g.n2, k)] = 0.5 * (v[g.ix(i, g.n2, k)] + v[g.ix(i, g.n2 - 1, k)]);
 }
+// z faces of the normal velocity after a projection folded into k_strain_tile<.., CORR = 1> (which writes the planes 1..n3): plane 0 is corrected like
+// every other (correc.f90:60-66: k = 0..n3, ghost rows and columns included), plane n3+1 keeps the value the last bounduvw gave the prediction
+__global__ __launch_bounds__(256) void k_wface_fold(Geom g, const real *__restrict__ ws, real *__restrict__ wd, const real *__restrict__ pp, real cz0) {
+  const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+  if (i > g.n1 + 1 || j > g.n2 + 1) return;
+  const size_t a = g.ix(i, j, 0), b = g.ix(i, j, g.n3 + 1);
+  wd[a] = ws[a] - cz0 * (pp[a + g.s12] - pp[a]);
+  wd[b] = ws[b];
+}
 static bool dsmag_fast_ok(const cales_ctx *c) {
   for (int q = 0; q < 2; ++q) if (c->is_wall[q] != 0. || c->C.lwm[q] != 0) return false;      // walls or wall model in x: general path
   // walls / wall model in y (ducts): the fused last pass knows the wall rule along y, the two-pass form does not
@@ -1086,7 +1195,9 @@ static int dsmag_fast(cales_ctx *c) {
   const bool ucf = !c->fl.dsmag_unfused_filter && !c->fl.dsmag_store_uc && CBP(c, 0, 1) == 'P' && CBP(c, 1, 1) == 'P' && !c->fl.dsmag_xghosts && ((zlo && zhi) || perz);
   // K_AC: |S|, |S|Sij, cell-centred and test-filtered velocity in one pass over u,v,w (no wall-model faces ->
   // extrapolate(...,lwm) is a no-op; u,v are extrapolated through the z walls, w on the faces is not, sgs.f90:705-710)
-  { ProfScope ps(c, "strain_filter_uvw");
+  const bool fold = c->fold_dtrk != 0. && pair;      // (cales_step decides; pair: the instantiation that exists)
+  if (c->fold_dtrk != 0. && !fold) { c->err = "dsmag: projection folded into the strain-rate pass without pair fields"; return 1; }
+  { ProfScope ps(c, fold ? "correc_strain_filter_uvw" : "strain_filter_uvw");
     tiles(TYS, 64, mb, mg, kch);
     StrainTileArgs S;
     S.u[0] = f[CALES_U]; S.u[1] = f[CALES_V]; S.u[2] = f[CALES_W]; S.s0 = lazy ? visct : c->s0;
@@ -1097,9 +1208,30 @@ static int dsmag_fast(cales_ctx *c) {
     S.wylo = wylo; S.wyhi = wyhi; S.wmylo = wmylo; S.wmyhi = wmyhi; S.twy = nullptr; S.dl2 = c->dl[1];
     S.bm = BandMap{0, 0, 0, 0}; S.perx = c->step_xskip ? 1 : 0;
     if (!c->fl.plain_grid && (band_wanted(mg.x) || c->fl.band_grid)) { S.bm = band_map(mg.x, mg.y, mg.z); mg = dim3(band_blocks(S.bm), 1, 1); }
+    if (fold) {      // the projection of this substep is pending (cales_step): corrected velocity on load, u, v, w to the second buffers, p += pp
+      S.pp = f[CALES_PP]; S.p = f[CALES_P]; for (int q = 0; q < 3; ++q) S.un[q] = c->f2[q];
+      S.force = c->d_force; S.fmask = c->defer_force ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;
+      S.cdt = c->fold_dtrk; S.cfi = c->fold_dtrk * c->dli[0]; S.cfj = c->fold_dtrk * c->dli[1]; S.zper = perz ? 1 : 0;
+      const size_t pl = (size_t)(n[0] + 2) * (n[1] + 2);
+      S.bcz[0][0] = c->bcu.z; S.bcz[0][1] = c->bcu.z + pl; S.bcz[1][0] = c->bcv.z; S.bcz[1][1] = c->bcv.z + pl;
+      LAUNCH(c, (k_strain_tile<unsigned, 0, TYS, 0, 1, 1>), mg, mb, 0, c->stream, c->g, S);
+    } else
     if (wylo || wyhi || wmylo || wmyhi) { if (small) LAUNCH(c, (k_strain_tile<unsigned, 0, TYS, 1>), mg, mb, 0, c->stream, c->g, S); else LAUNCH(c, (k_strain_tile<size_t, 0, TYS, 1>), mg, mb, 0, c->stream, c->g, S); }
     else if (pair) LAUNCH(c, (k_strain_tile<unsigned, 0, TYS, 0, 1>), mg, mb, 0, c->stream, c->g, S);
     else if (small) LAUNCH(c, (k_strain_tile<unsigned, 0, TYS, 0>), mg, mb, 0, c->stream, c->g, S); else LAUNCH(c, (k_strain_tile<size_t, 0, TYS, 0>), mg, mb, 0, c->stream, c->g, S); }
+  if (fold) {
+    // the corrected velocity sits in the second buffers: swap (as the fused momentum pass does), give the normal component its two z faces -- the
+    // reference's correc covers w(:,:,0) (correc.f90:60-66) and leaves w(:,:,n3+1) as it was, and bounduvw with is_correc touches neither -- and
+    // fill the ghost cells of u, v, w and p (the pressure rides along) as main.f90:500-504 does after correc / updatep
+    for (int q = 0; q < 3; ++q) std::swap(c->f[CALES_U + q], c->f2[q]);
+    if (!perz)
+      LAUNCH(c, k_wface_fold, dim3((n[0] + 2 + 63) / 64, (n[1] + 2 + 3) / 4), dim3(64, 4), 0, c->stream, c->g, c->f2[2], c->f[CALES_W], f[CALES_PP], c->fold_dtrk * c->dzci[0]);
+    if (!c->fl.unmerged_bc) { c->bc_nride = 1; c->bc_ride[0] = f[CALES_P]; c->bc_ride_which[0] = 0; }
+    const int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 1, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W]);
+    const bool rode = !c->fl.unmerged_bc && c->bc_nride == 0; c->bc_nride = 0;
+    if (e) return e;
+    if (!rode) { if (int e2 = op_boundp(c, f[CALES_P], 0)) return e2; }
+  }
   // sgs-type ghost cells: only the periodic exchange matters (products of ghosts = ghosts of products; the wall ghosts are
   // replaced by the extrapolation rule inside the filters)
   // These twelve scratch fields are read by the tile kernels only: with periodic x their ghost columns are not filled (the

@@ -182,6 +182,9 @@ SWITCH_CASES = [
     ({"CALES_FFT_STAGED": "1"}, ["chan_dsmag", "tgv_ppp"]),
     # dynamic model: |S|Sij as six scalar fields between K_AC and the last pass instead of three fields of pairs (the default where x and y are periodic)
     ({"CALES_DSMAG_UNPAIRED": "1"}, ["chan_dsmag", "chan_dsmag_wm", "tgv_dsmag_ppp", "chan_dsmag_p2"]),
+    # dynamic model inside cales_step: the projection as a pass of its own (k_correc_cell) instead of inside the strain-rate pass (the default on one rank
+    # with x and y periodic; chan_dsmag_p2 / tgv_dsmag_ppp at power-of-two rows take the folded form by default, see test_step_at_power_of_two_rows)
+    ({"CALES_UNFOLDED_CORREC": "1"}, ["chan_dsmag", "chan_dsmag_p2", "tgv_dsmag_ppp"]),
     # the LDS-tile form of the static Smagorinsky pass
     ({"CALES_SMAG_TILE": "1"}, ["chan_smag", "chan_smag_wm", "duct_smag_wm"]),
 ]
