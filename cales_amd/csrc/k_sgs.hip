@@ -793,6 +793,10 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
   const int jr = !CORR ? j : j == 0 ? g.n2 : j == g.n2 + 1 ? 1 : j, jp = jr >= g.n2 ? 1 : jr + 1;
   const OFF cl = (CORR && ldok) ? (OFF)g.ix(iq, jr, 0) * RSZ : c0, cly = (CORR && ldok) ? (OFF)g.ix(iq, jp, 0) * RSZ : 0;
   const int ihp = ih >= g.n1 ? 1 : ih + 1;      // column right of the halo column (needed by the lane right of the tile only)
+  // a row that does not fill its tile: the lane at i = n1+1 stands for the wrapped column 1 (the halo of the last cell) and the lane beside it holds
+  // nothing -- its pp(i+1) is pp(2), loaded by itself
+  const bool ownx = CORR && ldok && i == g.n1 + 1 && tx < 63;
+  const OFF clx = ownx ? (OFF)g.ix(iq >= g.n1 ? 1 : iq + 1, jr, 0) * RSZ : 0;
   const OFF chl = (CORR && hok) ? (OFF)g.ix(ih, jr, 0) * RSZ : ch, chy = (CORR && hok) ? (OFF)g.ix(ih, jp, 0) * RSZ : 0, chx = (CORR && hok) ? (OFF)g.ix(ihp, jr, 0) * RSZ : 0;
   auto kz = [&](int kk) { return !A.zper ? kk : kk == 0 ? g.n3 : kk == g.n3 + 1 ? 1 : kk; };
   real f3[3] = {0., 0., 0.};
@@ -822,6 +826,7 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
     const int kq = kz(kk);
     real px = lane_next(P0);
     if (tx == 63) px = E0;
+    if (ownx) px = r.px;
     const real ex = tx == 0 ? P0 : e.px;
     if (!wall) { fix(r, P0, px, kq, cc); if (edge) fix(e, E0, ex, kq, hh); }
     else {
@@ -836,13 +841,13 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
   if (CORR) {
     real c1[3], h1[3] = {0., 0., 0.}, c0v[3], h0[3] = {0., 0., 0.};
     { Raw r, e = {}; const int kq = kz(kbeg);      // plane kbeg: always interior
-      rawload(ldok, cl, cly, false, 0, kq, r); const real P0 = ldok ? ldb(A.pp, cl + (OFF)kq * sk) : 0.; real E0 = 0.;
+      rawload(ldok, cl, cly, ownx, clx, kq, r); const real P0 = ldok ? ldb(A.pp, cl + (OFF)kq * sk) : 0.; real E0 = 0.;
       if (edge) { rawload(hok, chl, chy, tx == 63, chx, kq, e); E0 = hok ? ldb(A.pp, chl + (OFF)kq * sk) : 0.; }
       complete(kbeg, r, e, P0, E0, nullptr, nullptr, c1, h1);
       if (outok) { const OFF a = c0 + (OFF)kbeg * sk; stb(A.p, a, ldb(A.p, a) + P0); }      // p += pp (updatep.f90:30-47, explicit diffusion)
       p0n = r.pz; p0h = e.pz; }
     { Raw r, e = {}; const int kq = kz(kbeg - 1);      // plane kbeg-1: interior, wrapped, or the ghost plane below the lower wall
-      rawload(ldok, cl, cly, false, 0, kq, r); const real P0 = ldok ? ldb(A.pp, cl + (OFF)kq * sk) : 0.; real E0 = 0.;
+      rawload(ldok, cl, cly, ownx, clx, kq, r); const real P0 = ldok ? ldb(A.pp, cl + (OFF)kq * sk) : 0.; real E0 = 0.;
       if (edge) { rawload(hok, chl, chy, tx == 63, chx, kq, e); E0 = hok ? ldb(A.pp, chl + (OFF)kq * sk) : 0.; }
       complete(kbeg - 1, r, e, P0, E0, c1, h1, c0v, h0); }
 #pragma unroll
@@ -852,7 +857,7 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
       if (outok) stb(A.un[q], c0 + (OFF)kbeg * sk, c1[q]);
     }
     // plane kbeg+1 (<= n3: n3 >= 3 and chunks of several planes) stays raw until the first iteration completes it
-    rawload(ldok, cl, cly, false, 0, kz(kbeg + 1), rn);
+    rawload(ldok, cl, cly, ownx, clx, kz(kbeg + 1), rn);
     if (edge) rawload(hok, chl, chy, tx == 63, chx, kz(kbeg + 1), rh);
     pl = (outok && kbeg + 1 <= kend) ? ldb(A.p, c0 + (OFF)(kbeg + 1) * sk) : 0.;
   }
@@ -908,7 +913,7 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
       }
       const real p0n_next = rn.pz, p0h_next = rh.pz;
       if (k + 2 <= g.n3 + 1) {
-        rawload(ldok, cl, cly, false, 0, kz(k + 2), rn);
+        rawload(ldok, cl, cly, ownx, clx, kz(k + 2), rn);
         if (edge) rawload(hok, chl, chy, tx == 63, chx, kz(k + 2), rh);
         pl = (outok && k + 2 <= kend) ? ldb(A.p, idx + 2 * sk) : 0.;
       }

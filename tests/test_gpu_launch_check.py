@@ -57,10 +57,12 @@ def test_failed_launch_at_operator_level(monkeypatch):
     h.close()
 
 
-def test_failed_launch_during_create(monkeypatch):
-    """set-up kernels (twiddle and coefficient tables) are checked too: cales_create fails and says which kernel"""
-    from cales_amd.hotpath import CalesError, HotPath
-    monkeypatch.setenv("CALES_TEST_BAD_LAUNCH", "k_")      # every kernel
+def test_every_kernel_name_is_hooked(monkeypatch):
+    """the hook matches on the kernel's name: with every launch made invalid ("k_") the first entry that launches anything -- set-up kernels of
+    cales_create if there are any, otherwise the upload's repack kernel -- fails and says which kernel"""
+    from cales_amd.hotpath import CalesError, HotPath, initflow
+    monkeypatch.setenv("CALES_TEST_BAD_LAUNCH", "k_")
     g, case = load_golden("chan_smag"); case.ng[:] = (32, 16, 12)
-    with pytest.raises(CalesError, match="kernel launch failed"):
-        HotPath(case)
+    with pytest.raises(CalesError, match="kernel launch failed.*k_"):
+        h = HotPath(case)
+        h.upload(*initflow(case))
