@@ -15,7 +15,6 @@
 #define TYM 10      // measured at 512^3: 10 (12 waves, 120 KB of LDS, one block per CU) 2.89 ms, 6 (two blocks per CU) 2.92-3.00, 8: 3.17
 #endif
 
-static_assert(5 * (TYM + 2) <= 64, "the x-halo columns of a tile are fetched by the 64 lanes of one wave, 5 fields per row");
 
 struct MomRkArgs {
   const real *u, *v, *w, *s, *p, *duo, *dvo, *dwo;
@@ -31,8 +30,16 @@ struct MomRkArgs {
   int perx;      // x periodic: the x-halo columns of the tiles at the ends of a row are the wrapped interior columns (valid whether or not the ghost columns are up to date)
 };
 
-// NOS = 1: no subgrid model (visct is identically zero, sgs.f90:62-68): its loads, LDS traffic and terms are compiled out
-template <int IMP, typename OFF, int NOS>
+// NOS = 1: no subgrid model (visct is identically zero, sgs.f90:62-68): its loads, LDS traffic and terms are compiled out.
+// RD / WR: the old r.h.s. is read (weight f2 != 0) / the new one is stored -- compile-time, because EVERY global access of the plane loop is
+// unconditional straight-line code: lanes, rows and planes outside the field are clamped onto valid cells on the way in and sent to the row's x ghost
+// cell (which the ghost-cell update that always follows rewrites) on the way out. With loads and stores inside divergent branches the compiler
+// cannot count the operations in flight and waits with s_waitcnt vmcnt(0): the wave then stalls at the top of every plane until the six to nine
+// STORES of the plane before are acknowledged (on gfx9 stores count in vmcnt too), and the eddy viscosity scaled while loading (visct = |S| cs(k),
+// a multiplication right behind the load) made the prefetch of plane k+2 a blocking one -- tools/memseq.py shows the order of accesses and waits.
+// The two y-halo waves of a block (no outputs) run a loop of their own without stencil and stores; every wave fetches the two x-halo cells of ITS row
+// for the five fields with its first ten lanes.
+template <int IMP, typename OFF, int NOS, int RD, int WR>
 __global__ __launch_bounds__(64 * (TYM + 2), (TYM <= 6 ? 4 : 3)) void k_momrk(Geom g, MomRkArgs A) {
   __shared__ real sh[4][4][TYM + 2][66];
   __shared__ real shp[3][TYM + 2][66];
@@ -41,45 +48,48 @@ __global__ __launch_bounds__(64 * (TYM + 2), (TYM <= 6 ? 4 : 3)) void k_momrk(Ge
   if (A.bm.gx && !band_block(A.bm, bx_, by_, bz_)) return;
   const int i = bx_ * 64 + tx + 1, j = by_ * TYM + ty;
   const int kbeg = bz_ * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
-  const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1;
   const bool outok = ty >= 1 && ty <= TYM && i <= g.n1 && j <= g.n2;
-  // (a row that does not fill its last tile: the lane beside the last cell loads the column right of it -- the wrapped first column when the ghost
-  //  columns are not maintained)
-  const OFF c0 = ldok ? (OFF)g.ix((A.perx && i == g.n1 + 1) ? 1 : i, j, 0) * RSZ : 0;        // byte offsets (see ldb in common.hpp)
+  // own cell, clamped into the field (a row that does not fill its last tile: the lane beside the last cell loads the column right of it -- the
+  // wrapped first column when the ghost columns are not maintained; lanes further right load that column again, rows beyond n2+1 the last ghost row)
+  const int ic = (A.perx && i >= g.n1 + 1) ? 1 : min(i, g.n1 + 1), jc = min(j, g.n2 + 1);
+  const OFF c0 = (OFF)g.ix(ic, jc, 0) * RSZ;        // byte offsets (see ldb in common.hpp)
+  const OFF cst = outok ? c0 : (OFF)g.ix(0, jc, 0) * RSZ;      // where this thread's results go: its cell, or the x ghost cell of its row (dead until the next ghost-cell update)
   const OFF sk = (OFF)g.s12 * RSZ;
-  // x-halo columns (i = 64 bx and 64 bx + 65): the two y-halo waves, which have no outputs, fetch them for all rows of the
-  // tile -- wave 0 the left column, wave TYM+1 the right one; lane l -> row l/5, field l%5. One register instead of five.
-  const bool hwave = ty == 0 || ty == TYM + 1;
-  const int hr = tx / 5, hf_ = tx % 5, hxs = ty == 0 ? 0 : 65, hi0 = ty == 0 ? bx_ * 64 : bx_ * 64 + 65, hj = by_ * TYM + hr;
+  // x-halo cells (i = 64 bx and 64 bx + 65) of this wave's row: lanes 0..4 the five fields of the left one, lanes 5..9 of the right one
+  const int hf_ = tx % 5, hside = (tx / 5) & 1, hxs = hside ? 65 : 0, hi0 = bx_ * 64 + (hside ? 65 : 0);
   const int hi_ = !A.perx ? hi0 : hi0 == 0 ? g.n1 : hi0 == g.n1 + 1 ? 1 : hi0;
-  const bool hok = hwave && tx < 5 * (TYM + 2) && hi0 <= g.n1 + 1 && hj <= g.n2 + 1 && !(NOS && hf_ == 3);
-  const real *hp = nullptr;
-  if (hok) { const real *fp = hf_ == 0 ? A.u : hf_ == 1 ? A.v : hf_ == 2 ? A.w : hf_ == 3 ? A.s : A.p; hp = fp + g.ix(hi_, hj, 0); }
+  const bool hok = tx < 10 && hi0 <= g.n1 + 1 && j <= g.n2 + 1 && !(NOS && hf_ == 3);
+  const real *hp = A.u + g.ix(ic, jc, 0);      // (lanes without a halo cell load their own cell of u again: every lane loads, nothing branches)
+  if (hok) { const real *fp = hf_ == 0 ? A.u : hf_ == 1 ? A.v : hf_ == 2 ? A.w : hf_ == 3 ? A.s : A.p; hp = fp + g.ix(hi_, jc, 0); }
   const size_t sk64 = (size_t)g.s12;
-  auto ld5 = [&](int k, real *q, real &h) {
-    const real csk = (!NOS && A.cs && k <= g.n3 + 1) ? ldc(A.cs, k) : 1.;
-    if (ldok && k <= g.n3 + 1) { const OFF c = c0 + (OFF)k * sk; q[0] = ldb(A.u, c); q[1] = ldb(A.v, c); q[2] = ldb(A.w, c); q[3] = NOS ? 0. : ldb(A.s, c) * csk; q[4] = ldb(A.p, c); }
-    else { q[0] = q[1] = q[2] = q[3] = q[4] = 0.; }
-    h = (hok && k <= g.n3 + 1) ? hp[(size_t)k * sk64] : 0.;
-    if (hf_ == 3) h = h * csk;
+  auto ld5 = [&](int k, real *q, real &h) {      // raw values: nothing is computed from them until put()
+    const int kk = min(k, g.n3 + 1); const OFF c = c0 + (OFF)kk * sk;
+    q[0] = ldb(A.u, c); q[1] = ldb(A.v, c); q[2] = ldb(A.w, c); q[3] = NOS ? 0. : ldb(A.s, c); q[4] = ldb(A.p, c);
+    h = hp[(size_t)kk * sk64];
   };
-  // plane kk of the five fields -> ring slot kk&3 (u,v,w,visct) and kk%3 (p)
+  // plane kk of the five fields -> ring slot kk&3 (u,v,w,visct) and kk%3 (p); the eddy viscosity of the dynamic model's lazy form is |S| cs(k)
   auto put = [&](int kk, const real *q, real h) {
+    const real csk = (!NOS && A.cs) ? ldc(A.cs, min(kk, g.n3 + 1)) : 1.;
 #pragma unroll
-    for (int f = 0; f < (NOS ? 3 : 4); ++f) sh[f][kk & 3][ty][tx + 1] = q[f];
+    for (int f = 0; f < 3; ++f) sh[f][kk & 3][ty][tx + 1] = q[f];
+    if (!NOS) sh[3][kk & 3][ty][tx + 1] = q[3] * csk;
     shp[kk % 3][ty][tx + 1] = q[4];
-    if (hok) { if (hf_ < 4) sh[hf_][kk & 3][hr][hxs] = h; else shp[kk % 3][hr][hxs] = h; }
+    if (hok) { if (hf_ < 3) sh[hf_][kk & 3][ty][hxs] = h; else if (hf_ == 3) sh[3][kk & 3][ty][hxs] = h * csk; else shp[kk % 3][ty][hxs] = h; }
   };
   { real q[5], h;
     ld5(kbeg - 1, q, h); put(kbeg - 1, q, h); ld5(kbeg, q, h); put(kbeg, q, h); ld5(kbeg + 1, q, h); put(kbeg + 1, q, h); }
+  auto march = [&](auto halo_c) {
+    constexpr bool HALO = decltype(halo_c)::value;      // a y-halo wave: loads and LDS only
   for (int k = kbeg; k <= kend; ++k) {
     __syncthreads();
+    // the old r.h.s. of this plane first, then the prefetch of plane k+2: loads return in order, so waiting for the r.h.s. (needed at the end of this
+    // iteration) leaves the prefetch in flight -- the other way round the wait for the r.h.s. would also be a wait for the prefetch
+    real duo = 0., dvo = 0., dwo = 0.;
+    if (!HALO && RD) { const OFF c = c0 + (OFF)k * sk; duo = ldb(A.duo, c); dvo = ldb(A.dvo, c); dwo = ldb(A.dwo, c); }
     real pf[5], hf;
     ld5(k + 2, pf, hf);                                     // prefetch, in flight during the stencil
-    if (outok) {
-      const OFF c = c0 + (OFF)k * sk;
-      real duo = 0., dvo = 0., dwo = 0.;
-      if (A.rd_old) { duo = ldb(A.duo, c); dvo = ldb(A.dvo, c); dwo = ldb(A.dwo, c); }
+    if (!HALO) {
+      const OFF cs_ = cst + (OFF)k * sk;
       const int km = (k - 1) & 3, kc = k & 3, kp = (k + 1) & 3;
 #define LS(f, sl, di, dj) sh[f][sl][ty + (dj)][tx + 1 + (di)]
       const real u_ccm = LS(0, km, 0, 0), u_cmc = LS(0, kc, 0, -1), u_mcc = LS(0, kc, -1, 0),
@@ -160,12 +170,15 @@ __global__ __launch_bounds__(64 * (TYM + 2), (TYM <= 6 ? 4 : 3)) void k_momrk(Ge
       real un = u_ccc + A.f1 * du + A.f2 * duo + A.f12 * (A.bfx - dxi * (p_pcc - p_ccc));
       real vn = v_ccc + A.f1 * dv + A.f2 * dvo + A.f12 * (A.bfy - dyi * (p_cpc - p_ccc));
       real wn = w_ccc + A.f1 * dw + A.f2 * dwo + A.f12 * (A.bfz - dzci_k * (p_ccp - p_ccc));
-      if (IMP) { un = un + A.f12 * dud; vn = vn + A.f12 * dvd; wn = wn + A.f12 * dwd; stb(A.dud, c, dud); stb(A.dvd, c, dvd); stb(A.dwd, c, dwd); }
-      stb(A.un, c, un); stb(A.vn, c, vn); stb(A.wn, c, wn);
-      if (A.wr_new) { stb(A.du, c, du); stb(A.dv, c, dv); stb(A.dw, c, dw); }
+      if (IMP) { un = un + A.f12 * dud; vn = vn + A.f12 * dvd; wn = wn + A.f12 * dwd; stb(A.dud, cs_, dud); stb(A.dvd, cs_, dvd); stb(A.dwd, cs_, dwd); }
+      stb(A.un, cs_, un); stb(A.vn, cs_, vn); stb(A.wn, cs_, wn);
+      if (WR) { stb(A.du, cs_, du); stb(A.dv, cs_, dv); stb(A.dw, cs_, dw); }
     }
     put(k + 2, pf, hf);        // slots (k+2)&3 and (k+2)%3 were last read in iteration k-1, i.e. before this iteration's barrier
   }
+  };
+  // (the row of a wave is uniform: a scalar branch, each loop straight-line code)
+  if (__builtin_amdgcn_readfirstlane((int)(ty == 0 || ty == TYM + 1))) march(std::true_type{}); else march(std::false_type{});
 }
 
 // The reference updates u,v,w in place, so their ghost cells keep the values of the last bounduvw until the next one -- and the wall model
@@ -206,15 +219,22 @@ int op_momrk(cales_ctx *c, real f1, real f2, real f12) {
   if (!c->fl.plain_grid && (band_wanted(gr.x) || c->fl.band_grid)) { A.bm = band_map(gr.x, gr.y, gr.z); gr = dim3(band_blocks(A.bm), 1, 1); }
   const bool small = (c->ntot + 16) * sizeof(real) < (1ull << 32) && !c->fl.wide_offsets;      // 32-bit byte offsets
   const int nos = c->C.sgstype == 0 && c->visct_zero;     // visct known to be identically zero (never set by the host since the last zeroing)
+#define MOMRK_L2(IMP_, RD_, WR_)                                                                                      \
+  do {                                                                                                                 \
+    if (small) { if (nos) LAUNCH(c, (k_momrk<IMP_, unsigned, 1, RD_, WR_>), gr, b, 0, c->stream, c->g, A);              \
+                 else LAUNCH(c, (k_momrk<IMP_, unsigned, 0, RD_, WR_>), gr, b, 0, c->stream, c->g, A); }                \
+    else { if (nos) LAUNCH(c, (k_momrk<IMP_, size_t, 1, RD_, WR_>), gr, b, 0, c->stream, c->g, A);                      \
+           else LAUNCH(c, (k_momrk<IMP_, size_t, 0, RD_, WR_>), gr, b, 0, c->stream, c->g, A); }                        \
+  } while (0)
+  // (read the old r.h.s., store the new one): (0,1) first substep, (1,1) second, (1,0) third inside cales_step; (0,0) a first substep whose r.h.s. nobody keeps
 #define MOMRK_LAUNCH(IMP_)                                                                                             \
   do {                                                                                                                 \
-    if (small) { if (nos) LAUNCH(c, (k_momrk<IMP_, unsigned, 1>), gr, b, 0, c->stream, c->g, A);              \
-                 else LAUNCH(c, (k_momrk<IMP_, unsigned, 0>), gr, b, 0, c->stream, c->g, A); }                \
-    else { if (nos) LAUNCH(c, (k_momrk<IMP_, size_t, 1>), gr, b, 0, c->stream, c->g, A);                      \
-           else LAUNCH(c, (k_momrk<IMP_, size_t, 0>), gr, b, 0, c->stream, c->g, A); }                        \
+    if (A.rd_old && A.wr_new) MOMRK_L2(IMP_, 1, 1); else if (A.rd_old) MOMRK_L2(IMP_, 1, 0);                            \
+    else if (A.wr_new) MOMRK_L2(IMP_, 0, 1); else MOMRK_L2(IMP_, 0, 0);                                                 \
   } while (0)
   if (c->C.impdiff == 2) MOMRK_LAUNCH(2); else if (c->C.impdiff == 1) MOMRK_LAUNCH(1); else MOMRK_LAUNCH(0);
 #undef MOMRK_LAUNCH
+#undef MOMRK_L2
   LAUNCHCHK(c);
   bool wm = false; for (int q = 0; q < 6; ++q) wm = wm || c->C.lwm[q] != 0;
   if (wm) {

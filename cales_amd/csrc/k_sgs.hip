@@ -788,16 +788,22 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
     if (YW && yex != 0 && q != 1) return yex > 0 ? 2. * ldb(A.u[q], o + sjb) - ldb(A.u[q], o + 2 * sjb) : 2. * ldb(A.u[q], o - sjb) - ldb(A.u[q], o - 2 * sjb);
     return ldb(A.u[q], o);
   };
-  // ---- CORR: corrected velocity on load (see StrainTileArgs). Rows and columns are the wrapped interior ones (jr, iq / ih), pp's neighbours
-  // i+1 (the lane beside, or the halo column), j+1 (row jp, loaded again: a cache hit), k+1 (the next plane's own value, rolled).
+  // ---- CORR: corrected velocity on load (see StrainTileArgs). Rows and columns are the wrapped interior ones (jr, iq), pp's neighbours i+1 (the lane
+  // beside), j+1 (row jp, loaded again: a cache hit), k+1 (the next plane's own value, rolled). The tile's two x-halo COLUMNS are completed by the two
+  // y-halo waves, one tile row per lane (wave 0 the column left of the tile, wave TY+1 the one right of it): as a branch of the edge lanes the same
+  // work ran in every one of the sixteen waves (+39 % vector, +65 % scalar instructions per wave in the first version of this pass).
   const int jr = !CORR ? j : j == 0 ? g.n2 : j == g.n2 + 1 ? 1 : j, jp = jr >= g.n2 ? 1 : jr + 1;
   const OFF cl = (CORR && ldok) ? (OFF)g.ix(iq, jr, 0) * RSZ : c0, cly = (CORR && ldok) ? (OFF)g.ix(iq, jp, 0) * RSZ : 0;
-  const int ihp = ih >= g.n1 ? 1 : ih + 1;      // column right of the halo column (needed by the lane right of the tile only)
-  // a row that does not fill its tile: the lane at i = n1+1 stands for the wrapped column 1 (the halo of the last cell) and the lane beside it holds
-  // nothing -- its pp(i+1) is pp(2), loaded by itself
-  const bool ownx = CORR && ldok && i == g.n1 + 1 && tx < 63;
+  // pp(i+1) of the own cell comes from the lane beside it, except for the last lane of the tile (the halo column right of it) and, in a row that does
+  // not fill its tile, for the lane at i = n1+1 -- it stands for the wrapped column 1 and the lane beside it holds nothing: those two load it
+  const bool ownx = CORR && ldok && ((i == g.n1 + 1 && tx < 63) || (tx == 63 && i <= g.n1));
   const OFF clx = ownx ? (OFF)g.ix(iq >= g.n1 ? 1 : iq + 1, jr, 0) * RSZ : 0;
-  const OFF chl = (CORR && hok) ? (OFF)g.ix(ih, jr, 0) * RSZ : ch, chy = (CORR && hok) ? (OFF)g.ix(ih, jp, 0) * RSZ : 0, chx = (CORR && hok) ? (OFF)g.ix(ihp, jr, 0) * RSZ : 0;
+  const bool sjob = CORR && (ty == 0 || ty == TY + 1) && tx < TY + 2;      // side job: lane tx of a y-halo wave completes the halo column of tile row tx
+  const int sside = ty == 0 ? 0 : 1, hxs = sside ? 65 : 0, si0 = bx * 64 + (sside ? 65 : 0), sj0 = by * TY + tx;
+  const bool sok = sjob && si0 <= g.n1 + 1 && sj0 <= g.n2 + 1;
+  const int si = si0 == 0 ? g.n1 : si0 == g.n1 + 1 ? 1 : si0, sxr = si >= g.n1 ? 1 : si + 1;
+  const int sjr = sj0 == 0 ? g.n2 : sj0 == g.n2 + 1 ? 1 : sj0, sjp = sjr >= g.n2 ? 1 : sjr + 1;
+  const OFF so = sok ? (OFF)g.ix(si, sjr, 0) * RSZ : 0, soy = sok ? (OFF)g.ix(si, sjp, 0) * RSZ : 0, sox = sok ? (OFF)g.ix(sxr, sjr, 0) * RSZ : 0;
   auto kz = [&](int kk) { return !A.zper ? kk : kk == 0 ? g.n3 : kk == g.n3 + 1 ? 1 : kk; };
   real f3[3] = {0., 0., 0.};
   if (CORR) { f3[0] = (A.fmask & 1) ? ldc(A.force, 0) : 0.; f3[1] = (A.fmask & 2) ? ldc(A.force, 1) : 0.; f3[2] = (A.fmask & 4) ? ldc(A.force, 2) : 0.; }
@@ -807,58 +813,54 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
     const OFF a = o + (OFF)kk * sk;
 #pragma unroll
     for (int q = 0; q < 3; ++q) r.q[q] = ok ? ldb(A.u[q], a) : 0.;
+#ifndef KEXP_NOPY
     r.py = ok ? ldb(A.pp, oy + (OFF)kk * sk) : 0.;
+#else
+    r.py = 0.;
+#endif
     r.pz = ok ? ldb(A.pp, o + (OFF)min(kk + 1, g.n3 + 1) * sk) : 0.;
     r.px = (ok && wantx) ? ldb(A.pp, ox + (OFF)kk * sk) : 0.;
   };
-  // corrected values of an interior plane (kq = its index in 1..n3) from the raw ones: P0 = pp of the cell, px / r.py / r.pz its neighbours
-  auto fix = [&](const Raw &r, real P0, real px, int kq, real *o) {
-    o[0] = ((A.fmask & 1) ? r.q[0] + f3[0] : r.q[0]) - A.cfi * (px - P0);
-    o[1] = ((A.fmask & 2) ? r.q[1] + f3[1] : r.q[1]) - A.cfj * (r.py - P0);
-    o[2] = ((A.fmask & 4) ? r.q[2] + f3[2] : r.q[2]) - A.cdt * ldc(A.dzci, kq) * (r.pz - P0);
-  };
-  // plane kk (raw values r / e of the own and the halo column, pp of the two cells P0 / E0) -> corrected values cc / hh. A z ghost plane next to a
-  // wall comes from its boundary rule: u, v = 2 bc - (the plane beside it: below[] / hbelow[]), w(0) by the formula without forcing (correc.f90 loops
-  // over k = 0..n3 for w), w(n3+1) untouched (bounduvw with is_correc leaves the normal component's z faces alone, bound.f90:60-75)
-  const size_t q2 = (size_t)iq + (size_t)(g.n1 + 2) * jr, q2h = (size_t)ih + (size_t)(g.n1 + 2) * jr;
-  auto complete = [&](int kk, const Raw &r, const Raw &e, real P0, real E0, const real *beside, const real *hbeside, real *cc, real *hh) {
-    const bool wall = !A.zper && (kk == 0 || kk == g.n3 + 1);
-    const int kq = kz(kk);
-    real px = lane_next(P0);
-    if (tx == 63) px = E0;
-    if (ownx) px = r.px;
-    const real ex = tx == 0 ? P0 : e.px;
-    if (!wall) { fix(r, P0, px, kq, cc); if (edge) fix(e, E0, ex, kq, hh); }
-    else {
+  // plane kk of one column (raw values r, pp of the cell P0 and of the cell right of it px) -> corrected values o[3]. Interior planes:
+  // (u* + f) - dtrk grad(pp), the operations of k_correc_cell in their order. A z ghost plane next to a wall comes from its boundary rule: u, v = 2 bc -
+  // (the plane beside it, bes[]), w(0) by the formula without forcing (correc.f90 loops over k = 0..n3 for w), w(n3+1) untouched (bounduvw with
+  // is_correc leaves the normal component's z faces alone, bound.f90:60-75)
+  auto complete = [&](int kk, const Raw &r, real P0, real px, bool ok, size_t qbc, const real *bes, real *o) {
+    if (A.zper || (kk != 0 && kk != g.n3 + 1)) {
+      const int kq = kz(kk);
+      o[0] = ((A.fmask & 1) ? r.q[0] + f3[0] : r.q[0]) - A.cfi * (px - P0);
+      o[1] = ((A.fmask & 2) ? r.q[1] + f3[1] : r.q[1]) - A.cfj * (r.py - P0);
+      o[2] = ((A.fmask & 4) ? r.q[2] + f3[2] : r.q[2]) - A.cdt * ldc(A.dzci, kq) * (r.pz - P0);
+    } else {
       const int sd = kk == 0 ? 0 : 1;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) { cc[q] = ldok ? 2. * A.bcz[q][sd][q2] - beside[q] : 0.; if (edge) hh[q] = hok ? 2. * A.bcz[q][sd][q2h] - hbeside[q] : 0.; }
-      cc[2] = kk == 0 ? r.q[2] - A.cdt * ldc(A.dzci, 0) * (r.pz - P0) : r.q[2];
-      if (edge) hh[2] = kk == 0 ? e.q[2] - A.cdt * ldc(A.dzci, 0) * (e.pz - E0) : e.q[2];
+      o[0] = ok ? 2. * A.bcz[0][sd][qbc] - bes[0] : 0.; o[1] = ok ? 2. * A.bcz[1][sd][qbc] - bes[1] : 0.;
+      o[2] = kk == 0 ? r.q[2] - A.cdt * ldc(A.dzci, 0) * (r.pz - P0) : r.q[2];
     }
   };
-  Raw rn = {}, rh = {}; real p0n = 0., p0h = 0., pl = 0.;      // in flight: plane k+1 of the own / the halo column, pp and p of its cells
+  const size_t q2 = (size_t)iq + (size_t)(g.n1 + 2) * jr, q2s = (size_t)si + (size_t)(g.n1 + 2) * sjr;
+  auto ownpx = [&](real P0, const Raw &r) { const real nx = lane_next(P0); return ownx ? r.px : nx; };
+  Raw rn = {}, rh = {}; real p0n = 0., p0h = 0., pl = 0.;      // in flight: plane k+1 of the own column / of the side job's column, pp and p of its cells
   if (CORR) {
-    real c1[3], h1[3] = {0., 0., 0.}, c0v[3], h0[3] = {0., 0., 0.};
-    { Raw r, e = {}; const int kq = kz(kbeg);      // plane kbeg: always interior
-      rawload(ldok, cl, cly, ownx, clx, kq, r); const real P0 = ldok ? ldb(A.pp, cl + (OFF)kq * sk) : 0.; real E0 = 0.;
-      if (edge) { rawload(hok, chl, chy, tx == 63, chx, kq, e); E0 = hok ? ldb(A.pp, chl + (OFF)kq * sk) : 0.; }
-      complete(kbeg, r, e, P0, E0, nullptr, nullptr, c1, h1);
+    real c1[3], c0v[3], h1[3] = {0., 0., 0.}, h0[3] = {0., 0., 0.};
+    { Raw r; const int kq = kz(kbeg);      // plane kbeg: always interior
+      rawload(ldok, cl, cly, ownx, clx, kq, r); const real P0 = ldok ? ldb(A.pp, cl + (OFF)kq * sk) : 0.;
+      complete(kbeg, r, P0, ownpx(P0, r), ldok, q2, nullptr, c1);
       if (outok) { const OFF a = c0 + (OFF)kbeg * sk; stb(A.p, a, ldb(A.p, a) + P0); }      // p += pp (updatep.f90:30-47, explicit diffusion)
-      p0n = r.pz; p0h = e.pz; }
-    { Raw r, e = {}; const int kq = kz(kbeg - 1);      // plane kbeg-1: interior, wrapped, or the ghost plane below the lower wall
-      rawload(ldok, cl, cly, ownx, clx, kq, r); const real P0 = ldok ? ldb(A.pp, cl + (OFF)kq * sk) : 0.; real E0 = 0.;
-      if (edge) { rawload(hok, chl, chy, tx == 63, chx, kq, e); E0 = hok ? ldb(A.pp, chl + (OFF)kq * sk) : 0.; }
-      complete(kbeg - 1, r, e, P0, E0, c1, h1, c0v, h0); }
+      p0n = r.pz;
+      if (sjob) { Raw e; rawload(sok, so, soy, true, sox, kq, e); const real E0 = sok ? ldb(A.pp, so + (OFF)kq * sk) : 0.; complete(kbeg, e, E0, e.px, sok, q2s, nullptr, h1); p0h = e.pz; } }
+    { Raw r; const int kq = kz(kbeg - 1);      // plane kbeg-1: interior, wrapped, or the ghost plane below the lower wall
+      rawload(ldok, cl, cly, ownx, clx, kq, r); const real P0 = ldok ? ldb(A.pp, cl + (OFF)kq * sk) : 0.;
+      complete(kbeg - 1, r, P0, ownpx(P0, r), ldok, q2, c1, c0v);
+      if (sjob) { Raw e; rawload(sok, so, soy, true, sox, kq, e); const real E0 = sok ? ldb(A.pp, so + (OFF)kq * sk) : 0.; complete(kbeg - 1, e, E0, e.px, sok, q2s, h1, h0); } }
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       ring[(kbeg - 1) % 3][q][ty][tx + 1] = c0v[q]; ring[kbeg % 3][q][ty][tx + 1] = c1[q];
-      if (edge) { ring[(kbeg - 1) % 3][q][ty][hx] = h0[q]; ring[kbeg % 3][q][ty][hx] = h1[q]; }
+      if (sjob) { ring[(kbeg - 1) % 3][q][tx][hxs] = h0[q]; ring[kbeg % 3][q][tx][hxs] = h1[q]; }
       if (outok) stb(A.un[q], c0 + (OFF)kbeg * sk, c1[q]);
     }
-    // plane kbeg+1 (<= n3: n3 >= 3 and chunks of several planes) stays raw until the first iteration completes it
+    // plane kbeg+1 stays raw until the first iteration completes it
     rawload(ldok, cl, cly, ownx, clx, kz(kbeg + 1), rn);
-    if (edge) rawload(hok, chl, chy, tx == 63, chx, kz(kbeg + 1), rh);
+    if (sjob) rawload(sok, so, soy, true, sox, kz(kbeg + 1), rh);
     pl = (outok && kbeg + 1 <= kend) ? ldb(A.p, c0 + (OFF)(kbeg + 1) * sk) : 0.;
   }
 #pragma unroll
@@ -901,23 +903,37 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
     if (CORR) {
       // plane k+1, loaded during the last iteration, is completed here (one iteration of latency behind its loads), stored if it belongs to this
       // chunk, and plane k+2 goes into flight
-      real cc[3], hh[3] = {0., 0., 0.}, bes[2] = {0., 0.}, hbes[2] = {0., 0.};
-      if (!A.zper && k == g.n3) { bes[0] = ring[kc][0][ty][tx + 1]; bes[1] = ring[kc][1][ty][tx + 1]; if (edge) { hbes[0] = ring[kc][0][ty][hx]; hbes[1] = ring[kc][1][ty][hx]; } }
-      complete(k + 1, rn, rh, p0n, p0h, bes, hbes, cc, hh);
+      const bool top = !A.zper && k == g.n3;      // plane k+1 is the ghost plane above the upper wall: its rule needs plane n3 of the same column
+      real cc[3], bes[2] = {0., 0.};
+      if (top) { bes[0] = ring[kc][0][ty][tx + 1]; bes[1] = ring[kc][1][ty][tx + 1]; }
+      complete(k + 1, rn, p0n, ownpx(p0n, rn), ldok, q2, bes, cc);
 #pragma unroll
-      for (int q = 0; q < 3; ++q) { ring[kp][q][ty][tx + 1] = cc[q]; if (edge) ring[kp][q][ty][hx] = hh[q]; }
+      for (int q = 0; q < 3; ++q) ring[kp][q][ty][tx + 1] = cc[q];
       if (outok && k + 1 <= kend) {
+#ifndef KEXP_NOUN
 #pragma unroll
         for (int q = 0; q < 3; ++q) stb(A.un[q], idx + sk, cc[q]);
+#endif
+#ifndef KEXP_NOP
         stb(A.p, idx + sk, pl + p0n);
+#endif
       }
-      const real p0n_next = rn.pz, p0h_next = rh.pz;
-      if (k + 2 <= g.n3 + 1) {
-        rawload(ldok, cl, cly, ownx, clx, kz(k + 2), rn);
-        if (edge) rawload(hok, chl, chy, tx == 63, chx, kz(k + 2), rh);
+      p0n = rn.pz;
+      const bool more = k + 2 <= g.n3 + 1; const int k2 = kz(min(k + 2, g.n3 + 1));
+      if (more) { rawload(ldok, cl, cly, ownx, clx, k2, rn);
+#ifndef KEXP_NOP
         pl = (outok && k + 2 <= kend) ? ldb(A.p, idx + 2 * sk) : 0.;
+#endif
       }
-      p0n = p0n_next; p0h = p0h_next;
+      if (sjob) {
+        real hh[3], hbes[2] = {0., 0.};
+        if (top) { hbes[0] = ring[kc][0][tx][hxs]; hbes[1] = ring[kc][1][tx][hxs]; }
+        complete(k + 1, rh, p0h, rh.px, sok, q2s, hbes, hh);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) ring[kp][q][tx][hxs] = hh[q];
+        p0h = rh.pz;
+        if (more) rawload(sok, so, soy, true, sox, k2, rh);
+      }
     } else {
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
