@@ -361,7 +361,7 @@ static int step_body(cales_ctx *c, real dt) {
   // dynamic model, one rank, x and y periodic (|S|Sij as pair fields), z periodic or two no-slip walls, explicit diffusion, no wall model: the
   // projection u = u* - dtrk grad(pp) (+ the deferred forcing) and p += pp are folded into the strain-rate pass of cmpt_sgs, which reads the velocity
   // anyway -- the correction pass (9 words per cell) disappears (dsmag_fast, k_strain_tile<.., CORR = 1>)
-  bool fold_correc = c->step_xskip && c->P == 1 && c->C.sgstype == 2 && c->C.impdiff == 0 && dsmag_pairs(c) && !c->fl.unfolded_correc && !c->fl.unfused_correc;
+  bool fold_correc = c->step_xskip && c->P == 1 && c->C.sgstype == 2 && c->C.impdiff == 0 && dsmag_pairs(c) && !c->fl.unfolded_correc && !c->fl.unfused_correc && !c->fl.dsmag_store_uc && c->n[0] % 64 == 0;      // (whole 64-cell tiles in x)
   { const bool perz = CBV(c, 0, 3, 3) == 'P' && CBV(c, 1, 3, 3) == 'P';
     bool walls = true;
     for (int iv = 1; iv <= 3; ++iv) for (int sd = 0; sd <= 1; ++sd) walls = walls && CBV(c, sd, 3, iv) == 'D';

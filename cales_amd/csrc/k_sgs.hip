@@ -718,6 +718,9 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
 #ifndef TYS
 #define TYS 14      // measured at 512^3 (A/B on one box): 14 beats 6 and 10 for the dynamic-model pass (-7 %) and the Smagorinsky pass (-26 %)
 #endif
+#ifndef TYC
+#define TYC 10      // tile height of k_corr_strain_tile (K_AC with the projection folded in). Measured at 512^3 on one box: 10 rows (twelve waves, 144 VGPRs, 88 KB)
+#endif              // 3.37 ms per call, 14 rows (sixteen waves at the 128-register cap, 117 KB) 3.49; a 14-row build that spilled fourteen registers 4.5
 struct StrainTileArgs {
   const real *u[3];
   real *s0, *ssij[6], *uc[3], *uf[3];
@@ -762,9 +765,8 @@ __global__ __launch_bounds__(256) void k_wall_shear_y(Geom g, const real *__rest
     twy[(size_t)(g.n3 + 2 + k) * g.s1 + i] = sqrt(0.5 * visc * (sqrt(t1 * t1 + t2 * t2) * dyi));
   }
 }
-template <typename OFF, int SMAG, int TY, int YW, int PAIR = 0, int CORR = 0>      // YW = 1: walls or wall-model faces in y (ducts); the channel instantiations carry none of that logic
+template <typename OFF, int SMAG, int TY, int YW, int PAIR = 0>      // YW = 1: walls or wall-model faces in y (ducts); the channel instantiations carry none of that logic
 __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTileArgs A) {
-  static_assert(!CORR || (!SMAG && !YW && PAIR), "the projection is folded into the paired dynamic-model pass only");
   // (one barrier per plane with four ring slots and double-buffered sums, as in k_lij_mij_tile, measured 13 % slower here)
   __shared__ real ring[3][3][TY + 2][66];      // rows: x-halo cell, 64 own cells, x-halo cell
   __shared__ real shs[SMAG ? 1 : 3][TY + 2][64];
@@ -788,84 +790,8 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
     if (YW && yex != 0 && q != 1) return yex > 0 ? 2. * ldb(A.u[q], o + sjb) - ldb(A.u[q], o + 2 * sjb) : 2. * ldb(A.u[q], o - sjb) - ldb(A.u[q], o - 2 * sjb);
     return ldb(A.u[q], o);
   };
-  // ---- CORR: corrected velocity on load (see StrainTileArgs). Rows and columns are the wrapped interior ones (jr, iq), pp's neighbours i+1 (the lane
-  // beside), j+1 (row jp, loaded again: a cache hit), k+1 (the next plane's own value, rolled). The tile's two x-halo COLUMNS are completed by the two
-  // y-halo waves, one tile row per lane (wave 0 the column left of the tile, wave TY+1 the one right of it): as a branch of the edge lanes the same
-  // work ran in every one of the sixteen waves (+39 % vector, +65 % scalar instructions per wave in the first version of this pass).
-  const int jr = !CORR ? j : j == 0 ? g.n2 : j == g.n2 + 1 ? 1 : j, jp = jr >= g.n2 ? 1 : jr + 1;
-  const OFF cl = (CORR && ldok) ? (OFF)g.ix(iq, jr, 0) * RSZ : c0, cly = (CORR && ldok) ? (OFF)g.ix(iq, jp, 0) * RSZ : 0;
-  // pp(i+1) of the own cell comes from the lane beside it, except for the last lane of the tile (the halo column right of it) and, in a row that does
-  // not fill its tile, for the lane at i = n1+1 -- it stands for the wrapped column 1 and the lane beside it holds nothing: those two load it
-  const bool ownx = CORR && ldok && ((i == g.n1 + 1 && tx < 63) || (tx == 63 && i <= g.n1));
-  const OFF clx = ownx ? (OFF)g.ix(iq >= g.n1 ? 1 : iq + 1, jr, 0) * RSZ : 0;
-  const bool sjob = CORR && (ty == 0 || ty == TY + 1) && tx < TY + 2;      // side job: lane tx of a y-halo wave completes the halo column of tile row tx
-  const int sside = ty == 0 ? 0 : 1, hxs = sside ? 65 : 0, si0 = bx * 64 + (sside ? 65 : 0), sj0 = by * TY + tx;
-  const bool sok = sjob && si0 <= g.n1 + 1 && sj0 <= g.n2 + 1;
-  const int si = si0 == 0 ? g.n1 : si0 == g.n1 + 1 ? 1 : si0, sxr = si >= g.n1 ? 1 : si + 1;
-  const int sjr = sj0 == 0 ? g.n2 : sj0 == g.n2 + 1 ? 1 : sj0, sjp = sjr >= g.n2 ? 1 : sjr + 1;
-  const OFF so = sok ? (OFF)g.ix(si, sjr, 0) * RSZ : 0, soy = sok ? (OFF)g.ix(si, sjp, 0) * RSZ : 0, sox = sok ? (OFF)g.ix(sxr, sjr, 0) * RSZ : 0;
-  auto kz = [&](int kk) { return !A.zper ? kk : kk == 0 ? g.n3 : kk == g.n3 + 1 ? 1 : kk; };
-  real f3[3] = {0., 0., 0.};
-  if (CORR) { f3[0] = (A.fmask & 1) ? ldc(A.force, 0) : 0.; f3[1] = (A.fmask & 2) ? ldc(A.force, 1) : 0.; f3[2] = (A.fmask & 4) ? ldc(A.force, 2) : 0.; }
-  // what is in flight for one column between two iterations: the raw prediction of a plane and the pp values its correction needs
-  struct Raw { real q[3], py, pz, px; };
-  auto rawload = [&](bool ok, OFF o, OFF oy, bool wantx, OFF ox, int kk, Raw &r) {      // plane kk (already mapped by kz; 0 <= kk <= n3+1)
-    const OFF a = o + (OFF)kk * sk;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) r.q[q] = ok ? ldb(A.u[q], a) : 0.;
-#ifndef KEXP_NOPY
-    r.py = ok ? ldb(A.pp, oy + (OFF)kk * sk) : 0.;
-#else
-    r.py = 0.;
-#endif
-    r.pz = ok ? ldb(A.pp, o + (OFF)min(kk + 1, g.n3 + 1) * sk) : 0.;
-    r.px = (ok && wantx) ? ldb(A.pp, ox + (OFF)kk * sk) : 0.;
-  };
-  // plane kk of one column (raw values r, pp of the cell P0 and of the cell right of it px) -> corrected values o[3]. Interior planes:
-  // (u* + f) - dtrk grad(pp), the operations of k_correc_cell in their order. A z ghost plane next to a wall comes from its boundary rule: u, v = 2 bc -
-  // (the plane beside it, bes[]), w(0) by the formula without forcing (correc.f90 loops over k = 0..n3 for w), w(n3+1) untouched (bounduvw with
-  // is_correc leaves the normal component's z faces alone, bound.f90:60-75)
-  auto complete = [&](int kk, const Raw &r, real P0, real px, bool ok, size_t qbc, const real *bes, real *o) {
-    if (A.zper || (kk != 0 && kk != g.n3 + 1)) {
-      const int kq = kz(kk);
-      o[0] = ((A.fmask & 1) ? r.q[0] + f3[0] : r.q[0]) - A.cfi * (px - P0);
-      o[1] = ((A.fmask & 2) ? r.q[1] + f3[1] : r.q[1]) - A.cfj * (r.py - P0);
-      o[2] = ((A.fmask & 4) ? r.q[2] + f3[2] : r.q[2]) - A.cdt * ldc(A.dzci, kq) * (r.pz - P0);
-    } else {
-      const int sd = kk == 0 ? 0 : 1;
-      o[0] = ok ? 2. * A.bcz[0][sd][qbc] - bes[0] : 0.; o[1] = ok ? 2. * A.bcz[1][sd][qbc] - bes[1] : 0.;
-      o[2] = kk == 0 ? r.q[2] - A.cdt * ldc(A.dzci, 0) * (r.pz - P0) : r.q[2];
-    }
-  };
-  const size_t q2 = (size_t)iq + (size_t)(g.n1 + 2) * jr, q2s = (size_t)si + (size_t)(g.n1 + 2) * sjr;
-  auto ownpx = [&](real P0, const Raw &r) { const real nx = lane_next(P0); return ownx ? r.px : nx; };
-  Raw rn = {}, rh = {}; real p0n = 0., p0h = 0., pl = 0.;      // in flight: plane k+1 of the own column / of the side job's column, pp and p of its cells
-  if (CORR) {
-    real c1[3], c0v[3], h1[3] = {0., 0., 0.}, h0[3] = {0., 0., 0.};
-    { Raw r; const int kq = kz(kbeg);      // plane kbeg: always interior
-      rawload(ldok, cl, cly, ownx, clx, kq, r); const real P0 = ldok ? ldb(A.pp, cl + (OFF)kq * sk) : 0.;
-      complete(kbeg, r, P0, ownpx(P0, r), ldok, q2, nullptr, c1);
-      if (outok) { const OFF a = c0 + (OFF)kbeg * sk; stb(A.p, a, ldb(A.p, a) + P0); }      // p += pp (updatep.f90:30-47, explicit diffusion)
-      p0n = r.pz;
-      if (sjob) { Raw e; rawload(sok, so, soy, true, sox, kq, e); const real E0 = sok ? ldb(A.pp, so + (OFF)kq * sk) : 0.; complete(kbeg, e, E0, e.px, sok, q2s, nullptr, h1); p0h = e.pz; } }
-    { Raw r; const int kq = kz(kbeg - 1);      // plane kbeg-1: interior, wrapped, or the ghost plane below the lower wall
-      rawload(ldok, cl, cly, ownx, clx, kq, r); const real P0 = ldok ? ldb(A.pp, cl + (OFF)kq * sk) : 0.;
-      complete(kbeg - 1, r, P0, ownpx(P0, r), ldok, q2, c1, c0v);
-      if (sjob) { Raw e; rawload(sok, so, soy, true, sox, kq, e); const real E0 = sok ? ldb(A.pp, so + (OFF)kq * sk) : 0.; complete(kbeg - 1, e, E0, e.px, sok, q2s, h1, h0); } }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      ring[(kbeg - 1) % 3][q][ty][tx + 1] = c0v[q]; ring[kbeg % 3][q][ty][tx + 1] = c1[q];
-      if (sjob) { ring[(kbeg - 1) % 3][q][tx][hxs] = h0[q]; ring[kbeg % 3][q][tx][hxs] = h1[q]; }
-      if (outok) stb(A.un[q], c0 + (OFF)kbeg * sk, c1[q]);
-    }
-    // plane kbeg+1 stays raw until the first iteration completes it
-    rawload(ldok, cl, cly, ownx, clx, kz(kbeg + 1), rn);
-    if (sjob) rawload(sok, so, soy, true, sox, kz(kbeg + 1), rh);
-    pl = (outok && kbeg + 1 <= kend) ? ldb(A.p, c0 + (OFF)(kbeg + 1) * sk) : 0.;
-  }
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
-    if (CORR) break;
     ring[(kbeg - 1) % 3][q][ty][tx + 1] = ldok ? ld(q, c0 + (OFF)(kbeg - 1) * sk) : 0.;
     ring[kbeg % 3][q][ty][tx + 1] = ldok ? ld(q, c0 + (OFF)kbeg * sk) : 0.;
     if (edge) {
@@ -900,41 +826,6 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
   int km = (kbeg - 1) % 3, kc = kbeg % 3, kp = (kbeg + 1) % 3;
   for (int k = kbeg; k <= kend; ++k) {
     const OFF idx = c0 + (OFF)k * sk;
-    if (CORR) {
-      // plane k+1, loaded during the last iteration, is completed here (one iteration of latency behind its loads), stored if it belongs to this
-      // chunk, and plane k+2 goes into flight
-      const bool top = !A.zper && k == g.n3;      // plane k+1 is the ghost plane above the upper wall: its rule needs plane n3 of the same column
-      real cc[3], bes[2] = {0., 0.};
-      if (top) { bes[0] = ring[kc][0][ty][tx + 1]; bes[1] = ring[kc][1][ty][tx + 1]; }
-      complete(k + 1, rn, p0n, ownpx(p0n, rn), ldok, q2, bes, cc);
-#pragma unroll
-      for (int q = 0; q < 3; ++q) ring[kp][q][ty][tx + 1] = cc[q];
-      if (outok && k + 1 <= kend) {
-#ifndef KEXP_NOUN
-#pragma unroll
-        for (int q = 0; q < 3; ++q) stb(A.un[q], idx + sk, cc[q]);
-#endif
-#ifndef KEXP_NOP
-        stb(A.p, idx + sk, pl + p0n);
-#endif
-      }
-      p0n = rn.pz;
-      const bool more = k + 2 <= g.n3 + 1; const int k2 = kz(min(k + 2, g.n3 + 1));
-      if (more) { rawload(ldok, cl, cly, ownx, clx, k2, rn);
-#ifndef KEXP_NOP
-        pl = (outok && k + 2 <= kend) ? ldb(A.p, idx + 2 * sk) : 0.;
-#endif
-      }
-      if (sjob) {
-        real hh[3], hbes[2] = {0., 0.};
-        if (top) { hbes[0] = ring[kc][0][tx][hxs]; hbes[1] = ring[kc][1][tx][hxs]; }
-        complete(k + 1, rh, p0h, rh.px, sok, q2s, hbes, hh);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) ring[kp][q][tx][hxs] = hh[q];
-        p0h = rh.pz;
-        if (more) rawload(sok, so, soy, true, sox, k2, rh);
-      }
-    } else {
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       const bool ex = A.wmhi && k == g.n3 && q < 2;
@@ -944,7 +835,6 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
     if (k + 2 <= g.n3 + 1) {
 #pragma unroll
       for (int q = 0; q < 3; ++q) { fn[q] = ldok ? ld(q, idx + 2 * sk) : 0.; fh[q] = hok ? ld(q, ch + (OFF)(k + 2) * sk) : 0.; }
-    }
     }
     __syncthreads();
     const bool lo = A.zlo && k == 1, hi = A.zhi && k == g.n3;
@@ -1031,6 +921,230 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
       }
     }
     const int t = km; km = kc; kc = kp; kp = t;
+  }
+}
+// ---- K_AC with the projection folded in (StrainTileArgs, "CORR"; cales_step on one rank, x and y periodic, z walls or periodic): every velocity value
+// the pass reads is corrected while it is loaded, u = (u* + f) - dtrk grad(pp) at the periodically wrapped interior cell (the operations of
+// k_correc_cell in their order), the z ghost planes by their boundary rule; the corrected velocity of the tile's own cells goes to un[] (a second set of
+// buffers: neighbouring tiles still read u*) and p += pp in place. Same tile, ring and strain-rate / filter arithmetic as k_strain_tile<.., PAIR = 1>.
+// Memory accesses are laid out for the hardware's in-order counters (see k_momrk): every global access of the plane loop is unconditional straight-line
+// code -- loads from clamped / wrapped cells, stores of lanes without an output to the x ghost cell of their row (dead inside cales_step: every reader
+// wraps around, the step's last ghost-cell update rewrites it) -- so the waits are counted (the loads of plane k+2 stay in flight behind the eleven
+// stores of plane k) instead of s_waitcnt vmcnt(0) at every use. A plane is completed ONE iteration after its loads were issued. The two y-halo
+// waves have no outputs: they run a loop of their own and complete the tile's two x-halo COLUMNS, one tile row per lane (wave 0 the column left of the
+// tile, wave TY+1 the one right of it), which as a branch of the edge lanes ran in every one of the sixteen waves.
+template <typename OFF, int TY>
+__global__ __launch_bounds__(64 * (TY + 2)) void k_corr_strain_tile(Geom g, StrainTileArgs A) {
+  __shared__ real ring[3][3][TY + 2][66];      // rows: x-halo cell, 64 own cells, x-halo cell
+  __shared__ real shs[3][TY + 2][64];
+  // pp of the tile's cells, planes k+1 / k+2 (by parity), column 64 = the x-halo cell right of the row: the correction of a cell needs pp(i+1) (the lane
+  // beside: DPP; last lane: column 64), pp(j+1) (the row above: here) and pp(k+1) (its own next value) -- two global loads per cell and plane less
+  __shared__ real sP[2][TY + 2][65];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (A.bm.gx && !band_block(A.bm, bx, by, bz)) return;
+  const int n1 = g.n1, n2 = g.n2, n3 = g.n3;      // (n1 a multiple of 64: every tile is full in x, dsmag_fast)
+  const int i = bx * 64 + tx + 1, j = by * TY + ty;
+  const int kbeg = bz * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, n3);
+  const bool edge = tx == 0 || tx == 63;
+  const int hx = tx == 0 ? 0 : 65;
+  const bool outok = ty >= 1 && ty <= TY && j <= n2;
+  // the cell this thread loads: wrapped in y
+  // (rows beyond n2+1 keep wrapping: row n2+2 holds pp of row 2, which the correction of row n2+1 -- the wrapped row 1, the halo of the last row -- reads from sP)
+  const int jq = j == 0 ? n2 : j > n2 ? min(j - n2, n2) : j, jp = jq >= n2 ? 1 : jq + 1;
+  const OFF sk = (OFF)g.s12 * RSZ;
+  const OFF cl = (OFF)g.ix(i, jq, 0) * RSZ, cly = (OFF)g.ix(i, jp, 0) * RSZ;
+  const OFF cdump = (OFF)g.ix(0, min(j, n2 + 1), 0) * RSZ;      // the x ghost cell of the row: where lanes / planes without an output of their own store
+  const OFF cst = outok ? cl : cdump;
+  // side job of the y-halo waves: lane tx < TY+2 completes the x-halo cell of tile row tx (other lanes repeat their own cell: no branches around loads)
+  const bool hwave = ty == 0 || ty == TY + 1;
+  const int sside = ty == 0 ? 0 : 1, hxs = sside ? 65 : 0, si0 = bx * 64 + (sside ? 65 : 0), sj0 = by * TY + tx;
+  const bool sok = hwave && tx < TY + 2 && sj0 <= n2 + 1;
+  const int si = !sok ? i : si0 == 0 ? n1 : si0 == n1 + 1 ? 1 : si0, sjr = !sok ? jq : sj0 == 0 ? n2 : sj0 == n2 + 1 ? 1 : sj0;
+  const int sxr = si >= n1 ? 1 : si + 1, sjp = sjr >= n2 ? 1 : sjr + 1;
+  const OFF so = (OFF)g.ix(si, sjr, 0) * RSZ, soy = (OFF)g.ix(si, sjp, 0) * RSZ, sox = (OFF)g.ix(sxr, sjr, 0) * RSZ;
+  const int srow = sok ? tx : 0;
+  auto kz = [&](int kk) { return !A.zper ? kk : kk == 0 ? n3 : kk == n3 + 1 ? 1 : kk; };      // plane that holds the values of plane kk
+  const real f0 = (A.fmask & 1) ? ldc(A.force, 0) : 0., f1 = (A.fmask & 2) ? ldc(A.force, 1) : 0., f2 = (A.fmask & 4) ? ldc(A.force, 2) : 0.;
+  // what is in flight for one column between two iterations: the prediction of a plane and pp of the cell above it (k+1); the side job's column also
+  // loads its pp(i+1) and pp(j+1), the own cells find theirs in sP (the top halo row, whose row above is another block's, loads its pp(j+1))
+  struct Raw { real q[3], pz; };
+  struct RawS { real q[3], pz, px, py; };
+  auto rawload = [&](OFF o, int kk, Raw &r) {      // kk: a plane index in 0..n3+1 (mapped by kz)
+    const OFF a = o + (OFF)kk * sk;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) r.q[q] = ldb(A.u[q], a);
+    r.pz = ldb(A.pp, o + (OFF)min(kk + 1, n3 + 1) * sk);
+  };
+  auto rawloads = [&](int kk, RawS &r) {
+    const OFF a = so + (OFF)kk * sk;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) r.q[q] = ldb(A.u[q], a);
+    r.pz = ldb(A.pp, so + (OFF)min(kk + 1, n3 + 1) * sk); r.px = ldb(A.pp, sox + (OFF)kk * sk); r.py = ldb(A.pp, soy + (OFF)kk * sk);
+  };
+  // interior plane kq: (u* + f) - dtrk grad(pp), k_correc_cell's operations in their order
+  auto fix = [&](const real *q, real P0, real px, real py, real pz, int kq, real *o) {
+    o[0] = ((A.fmask & 1) ? q[0] + f0 : q[0]) - A.cfi * (px - P0);
+    o[1] = ((A.fmask & 2) ? q[1] + f1 : q[1]) - A.cfj * (py - P0);
+    o[2] = ((A.fmask & 4) ? q[2] + f2 : q[2]) - A.cdt * ldc(A.dzci, kq) * (pz - P0);
+  };
+  // ghost plane next to a wall (sd = 0: plane 0, 1: plane n3+1): u, v = 2 bc - (the plane beside it, bes[]) as bounduvw sets them, w(0) by the formula
+  // without forcing (correc.f90 covers k = 0..n3 for w), w(n3+1) untouched (bounduvw with is_correc leaves the normal component's z faces alone)
+  auto wallfix = [&](const real *q, real P0, real pz, int sd, size_t qbc, const real *bes, real *o) {
+    o[0] = 2. * A.bcz[0][sd][qbc] - bes[0]; o[1] = 2. * A.bcz[1][sd][qbc] - bes[1];
+    o[2] = sd == 0 ? q[2] - A.cdt * ldc(A.dzci, 0) * (pz - P0) : q[2];
+  };
+  const size_t q2 = (size_t)i + (size_t)(n1 + 2) * jq, q2s = (size_t)si + (size_t)(n1 + 2) * sjr;
+  Raw rn; RawS rh = {}; real p0n, p0h = 0., pyt = 0.;      // in flight at the top of iteration k: plane k+1 of the own / the side job's column, pp of its cell, p of the own cell; pyt: pp(j+1) of the top halo row
+  { // ---- planes kbeg-1 and kbeg complete, plane kbeg+1 in flight (pp's neighbours by direct loads here: sP serves the loop)
+    real c1[3], c0v[3], h1[3] = {0., 0., 0.}, h0[3] = {0., 0., 0.};
+    const bool low = !A.zper && kbeg == 1;      // plane kbeg-1 is the ghost plane below the lower wall
+    const OFF clx = (OFF)g.ix(i >= n1 ? 1 : i + 1, jq, 0) * RSZ;
+    { const int kq = kz(kbeg); Raw r; rawload(cl, kq, r); const real P0 = ldb(A.pp, cl + (OFF)kq * sk);
+      fix(r.q, P0, ldb(A.pp, clx + (OFF)kq * sk), ldb(A.pp, cly + (OFF)kq * sk), r.pz, kq, c1); p0n = r.pz;
+      const OFF a = cst + (OFF)kbeg * sk; stb(A.p, a, ldb(A.p, a) + P0);      // p += pp (updatep.f90:30-47, explicit diffusion); lanes without output: their ghost cell
+      if (hwave) { RawS e; rawloads(kq, e); const real E0 = ldb(A.pp, so + (OFF)kq * sk); fix(e.q, E0, e.px, e.py, e.pz, kq, h1); p0h = e.pz; } }
+    { const int kq = kz(kbeg - 1); Raw r; rawload(cl, kq, r); const real P0 = ldb(A.pp, cl + (OFF)kq * sk);
+      if (low) wallfix(r.q, P0, r.pz, 0, q2, c1, c0v); else fix(r.q, P0, ldb(A.pp, clx + (OFF)kq * sk), ldb(A.pp, cly + (OFF)kq * sk), r.pz, kq, c0v);
+      if (hwave) { RawS e; rawloads(kq, e); const real E0 = ldb(A.pp, so + (OFF)kq * sk);
+                   if (low) wallfix(e.q, E0, e.pz, 0, q2s, h1, h0); else fix(e.q, E0, e.px, e.py, e.pz, kq, h0); } }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      ring[(kbeg - 1) % 3][q][ty][tx + 1] = c0v[q]; ring[kbeg % 3][q][ty][tx + 1] = c1[q];
+      if (sok) { ring[(kbeg - 1) % 3][q][srow][hxs] = h0[q]; ring[kbeg % 3][q][srow][hxs] = h1[q]; }
+      stb(A.un[q], cst + (OFF)kbeg * sk, c1[q]);
+    }
+    sP[(kbeg + 1) & 1][ty][tx] = p0n;      // pp of plane kbeg+1
+    if (sok && sside) sP[(kbeg + 1) & 1][srow][64] = p0h;
+    rawload(cl, kz(kbeg + 1), rn);
+    if (hwave) { rawloads(kz(kbeg + 1), rh); pyt = ldb(A.pp, cly + (OFF)kz(kbeg + 1) * sk); }
+    __syncthreads();
+  }
+  int km = (kbeg - 1) % 3, kc = kbeg % 3, kp = (kbeg + 1) % 3;
+  real keep[3] = {0., 0., 0.};
+  // one plane. HALO: a y-halo wave (side job, no outputs); TOP: plane k+1 is the ghost plane above the upper wall (k = n3, walls)
+  auto plane = [&](const int k, auto halo_c, auto top_c) {
+    constexpr bool HALO = decltype(halo_c)::value, TOP = decltype(top_c)::value;
+    const OFF idx = cst + (OFF)k * sk;
+    { // plane k+1, loaded during the last iteration, is completed, stored if it belongs to this chunk, and plane k+2 goes into flight
+      const int par = (k + 1) & 1, k2 = kz(min(k + 2, n3 + 1));
+      real cc[3];
+      if (TOP) { const real bes[2] = {ring[kc][0][ty][tx + 1], ring[kc][1][ty][tx + 1]}; wallfix(rn.q, p0n, rn.pz, 1, q2, bes, cc); }
+      else {
+        real px = lane_next(p0n);
+        if (tx == 63) px = sP[par][ty][64];
+        const real py = (HALO && ty == TY + 1) ? pyt : sP[par][ty + (ty == TY + 1 ? 0 : 1)][tx];
+        fix(rn.q, p0n, px, py, rn.pz, kz(k + 1), cc);
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) ring[kp][q][ty][tx + 1] = cc[q];
+      sP[par ^ 1][ty][tx] = rn.pz;      // pp of plane k+2
+      if (!HALO) {
+        // (plane k+1 of the NEXT chunk, or the ghost plane n3+1, goes to the row's x ghost cell like the results of lanes without output)
+        const OFF dst = (outok && k + 1 <= kend ? cst : cdump) + (OFF)(k + 1) * sk;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) stb(A.un[q], dst, cc[q]);
+      }
+      p0n = rn.pz;
+      rawload(cl, k2, rn);
+      // (the data registers of the last plane's three filtered-velocity stores stay allocated up to here: reused earlier, the compiler has to wait
+      //  for those stores -- the youngest operations in flight, i.e. for everything -- before the first instruction that overwrites them)
+      if (!HALO) asm volatile("" :: "v"(keep[0]), "v"(keep[1]), "v"(keep[2]));
+      if (HALO) {
+        real hh[3];
+        if (TOP) { const real hbes[2] = {ring[kc][0][srow][hxs], ring[kc][1][srow][hxs]}; wallfix(rh.q, p0h, rh.pz, 1, q2s, hbes, hh); }
+        else fix(rh.q, p0h, sside ? rh.px : sP[par][srow][0], rh.py, rh.pz, kz(k + 1), hh);
+        if (sok) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) ring[kp][q][srow][hxs] = hh[q];
+          if (sside) sP[par ^ 1][srow][64] = rh.pz;
+        }
+        p0h = rh.pz;
+        rawloads(k2, rh);
+        pyt = ldb(A.pp, cly + (OFF)k2 * sk);
+      }
+    }
+    __syncthreads();
+    // p += pp of plane k+1 (updatep.f90:30-47, explicit diffusion): loaded here, stored behind the second barrier -- load, wait and store inside one
+    // iteration, nothing of it carried around the loop; pp(k+1) of the cell is still in sP
+    const OFF dstp = (outok && k + 1 <= kend ? cst : cdump) + (OFF)(k + 1) * sk;
+    real pl = 0.;
+    if (!HALO) pl = ldb(A.p, dstp);
+    const bool lo = A.zlo && k == 1, hi = A.zhi && k == n3;
+    real r[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      auto zcomb = [&](int x) {
+        const real qm = ring[km][q][ty][x], qc = ring[kc][q][ty][x], qp = ring[kp][q][ty][x];
+        const real vm = (lo && q < 2) ? 2. * qc - qp : qm;      // u,v extrapolated through the walls, w (on the faces) not
+        const real vp = (hi && q < 2) ? 2. * qc - qm : qp;
+        return vm + 2. * qc + vp;
+      };
+      const real G = zcomb(tx + 1);
+      real pv = lane_prev(G), nx = lane_next(G);
+      if (edge) { const real Gh = zcomb(hx); if (tx == 0) pv = Gh; else nx = Gh; }
+      r[q] = pv + 2. * G + nx;
+      shs[q][ty][tx] = r[q];
+    }
+    if (!HALO) {
+#define RU(dk, dj, di) ring[dk][0][ty + (dj)][tx + 1 + (di)]
+#define RV(dk, dj, di) ring[dk][1][ty + (dj)][tx + 1 + (di)]
+#define RW(dk, dj, di) ring[dk][2][ty + (dj)][tx + 1 + (di)]
+      // the thirty ring values are read group by group (the scheduling barriers keep the compiler from hoisting all LDS reads to the top, which costs
+      // the fourteen registers this pass does not have at sixteen waves per block); expressions and their order as in k_strain_tile
+      const real dxi = A.dxi, dyi = A.dyi, zc = ldc(A.dzci, k), zm = ldc(A.dzci, k - 1);
+      const real u_ccc = RU(kc, 0, 0), u_mcc = RU(kc, 0, -1), v_ccc = RV(kc, 0, 0), v_cmc = RV(kc, -1, 0), w_ccc = RW(kc, 0, 0), w_ccm = RW(km, 0, 0);
+      const real s11 = (u_ccc - u_mcc) * dxi, s22 = (v_ccc - v_cmc) * dyi, s33 = (w_ccc - w_ccm) * ldc(A.dzfi, k);
+      real s12, s13, s23;
+      { const real u_mmc = RU(kc, -1, -1), u_cmc = RU(kc, -1, 0), u_mpc = RU(kc, 1, -1), u_cpc = RU(kc, 1, 0);
+        const real v_mmc = RV(kc, -1, -1), v_pmc = RV(kc, -1, 1), v_mcc = RV(kc, 0, -1), v_pcc = RV(kc, 0, 1);
+        s12 = .125 * ((u_cpc - u_ccc) * dyi + (v_pcc - v_ccc) * dxi + (u_ccc - u_cmc) * dyi + (v_pmc - v_cmc) * dxi +
+                      (u_mpc - u_mcc) * dyi + (v_ccc - v_mcc) * dxi + (u_mcc - u_mmc) * dyi + (v_cmc - v_mmc) * dxi); }
+      __builtin_amdgcn_sched_barrier(0);
+      { const real u_mcm = RU(km, 0, -1), u_ccm = RU(km, 0, 0), u_mcp = RU(kp, 0, -1), u_ccp = RU(kp, 0, 0);
+        const real w_mcm = RW(km, 0, -1), w_pcm = RW(km, 0, 1), w_mcc = RW(kc, 0, -1), w_pcc = RW(kc, 0, 1);
+        s13 = .125 * ((u_ccp - u_ccc) * zc + (w_pcc - w_ccc) * dxi + (u_ccc - u_ccm) * zm + (w_pcm - w_ccm) * dxi +
+                      (u_mcp - u_mcc) * zc + (w_ccc - w_mcc) * dxi + (u_mcc - u_mcm) * zm + (w_ccm - w_mcm) * dxi); }
+      __builtin_amdgcn_sched_barrier(0);
+      { const real v_cmm = RV(km, -1, 0), v_ccm = RV(km, 0, 0), v_cmp = RV(kp, -1, 0), v_ccp = RV(kp, 0, 0);
+        const real w_cmm = RW(km, -1, 0), w_cpm = RW(km, 1, 0), w_cmc = RW(kc, -1, 0), w_cpc = RW(kc, 1, 0);
+        s23 = .125 * ((v_ccp - v_ccc) * zc + (w_cpc - w_ccc) * dyi + (v_ccc - v_ccm) * zm + (w_cpm - w_ccm) * dyi +
+                      (v_cmp - v_cmc) * zc + (w_ccc - w_cmc) * dyi + (v_cmc - v_cmm) * zm + (w_ccm - w_cmm) * dyi); }
+#undef RU
+#undef RV
+#undef RW
+      const real s0v = sqrt(2. * (s11 * s11 + s22 * s22 + s33 * s33 + 2. * (s12 * s12 + s13 * s13 + s23 * s23)));
+      stb(A.s0, idx, s0v);                                              // stands for visct = s0 (sgs.f90:184) until the final kernel
+      const OFF i2 = 2 * idx;      // |S|Sij (sgs.f90:198-210), two components per 16-byte store
+      typedef real v2 __attribute__((ext_vector_type(2)));
+      __builtin_nontemporal_store(v2{s0v * s11, s0v * s22}, (v2 *)((char *)A.ss2[0] + i2));
+      __builtin_nontemporal_store(v2{s0v * s33, s0v * s12}, (v2 *)((char *)A.ss2[1] + i2));
+      __builtin_nontemporal_store(v2{s0v * s13, s0v * s23}, (v2 *)((char *)A.ss2[2] + i2));
+      // (the cell-centred velocity is not stored: the last pass forms it from u, v, w itself -- the only form this pass serves, dsmag_fast)
+    }
+    __syncthreads();
+    if (!HALO) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { keep[q] = (shs[q][ty - 1][tx] + 2. * r[q] + shs[q][ty + 1][tx]) / 64.; stb(A.uf[q], idx, keep[q]); }
+      stb(A.p, dstp, pl + sP[(k + 1) & 1][ty][tx]);
+    }
+    const int t = km; km = kc; kc = kp; kp = t;
+  };
+  const std::true_type T_; const std::false_type F_;
+  const bool topw = !A.zper && kend == n3;      // the chunk's last plane sits under the upper wall
+  const int klast = topw ? kend - 1 : kend;
+  // (a wave's row is uniform: scalar branches, each loop straight-line code)
+  // The first plane is peeled off: the loop is then entered with the same operations in flight as its back edge carries (the loads of a plane with
+  // that plane's stores behind them), and the compiler's counted waits hold; entered from the prologue, whose last operation is a load, the merge of
+  // the two states at the loop header makes every wait a wait for everything.
+  if (__builtin_amdgcn_readfirstlane((int)hwave)) {
+    if (kbeg <= klast) plane(kbeg, T_, F_);
+    for (int k = kbeg + 1; k <= klast; ++k) plane(k, T_, F_);
+    if (topw) plane(kend, T_, T_);
+  } else {
+    if (kbeg <= klast) plane(kbeg, F_, F_);
+    for (int k = kbeg + 1; k <= klast; ++k) plane(k, F_, F_);
+    if (topw) plane(kend, F_, T_);
   }
 }
 // Static Smagorinsky, row-marching form (default): one wave per row of 62 cells marching in k with everything in registers -- x neighbours by
@@ -1159,7 +1273,7 @@ __global__ __launch_bounds__(256) void k_vc_edge_rows(Geom g, const real *__rest
   vc[g.ix(i, 1, k)] = 0.5 * (v[g.ix(i, 1, k)] + v[g.ix(i, 0, k)]);
   vc[g.ix(i, g.n2, k)] = 0.5 * (v[g.ix(i, g.n2, k)] + v[g.ix(i, g.n2 - 1, k)]);
 }
-// z faces of the normal velocity after a projection folded into k_strain_tile<.., CORR = 1> (which writes the planes 1..n3): plane 0 is corrected like
+// z faces of the normal velocity after a projection folded into k_corr_strain_tile (which writes the planes 1..n3): plane 0 is corrected like
 // every other (correc.f90:60-66: k = 0..n3, ghost rows and columns included), plane n3+1 keeps the value the last bounduvw gave the prediction
 __global__ __launch_bounds__(256) void k_wface_fold(Geom g, const real *__restrict__ ws, real *__restrict__ wd, const real *__restrict__ pp, real cz0) {
   const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
@@ -1216,10 +1330,10 @@ static int dsmag_fast(cales_ctx *c) {
   const bool ucf = !c->fl.dsmag_unfused_filter && !c->fl.dsmag_store_uc && CBP(c, 0, 1) == 'P' && CBP(c, 1, 1) == 'P' && !c->fl.dsmag_xghosts && ((zlo && zhi) || perz);
   // K_AC: |S|, |S|Sij, cell-centred and test-filtered velocity in one pass over u,v,w (no wall-model faces ->
   // extrapolate(...,lwm) is a no-op; u,v are extrapolated through the z walls, w on the faces is not, sgs.f90:705-710)
-  const bool fold = c->fold_dtrk != 0. && pair;      // (cales_step decides; pair: the instantiation that exists)
+  const bool fold = c->fold_dtrk != 0. && pair && ucf;      // (cales_step decides; pair fields and the cell-centred velocity formed by the last pass: the instantiation that exists)
   if (c->fold_dtrk != 0. && !fold) { c->err = "dsmag: projection folded into the strain-rate pass without pair fields"; return 1; }
   { ProfScope ps(c, fold ? "correc_strain_filter_uvw" : "strain_filter_uvw");
-    tiles(TYS, 64, mb, mg, kch);
+    tiles(fold ? TYC : TYS, 64, mb, mg, kch);
     StrainTileArgs S;
     S.u[0] = f[CALES_U]; S.u[1] = f[CALES_V]; S.u[2] = f[CALES_W]; S.s0 = lazy ? visct : c->s0;
     for (int m = 0; m < 6; ++m) S.ssij[m] = ssij[m];
@@ -1235,7 +1349,7 @@ static int dsmag_fast(cales_ctx *c) {
       S.cdt = c->fold_dtrk; S.cfi = c->fold_dtrk * c->dli[0]; S.cfj = c->fold_dtrk * c->dli[1]; S.zper = perz ? 1 : 0;
       const size_t pl = (size_t)(n[0] + 2) * (n[1] + 2);
       S.bcz[0][0] = c->bcu.z; S.bcz[0][1] = c->bcu.z + pl; S.bcz[1][0] = c->bcv.z; S.bcz[1][1] = c->bcv.z + pl;
-      LAUNCH(c, (k_strain_tile<unsigned, 0, TYS, 0, 1, 1>), mg, mb, 0, c->stream, c->g, S);
+      LAUNCH(c, (k_corr_strain_tile<unsigned, TYC>), mg, mb, 0, c->stream, c->g, S);
     } else
     if (wylo || wyhi || wmylo || wmyhi) { if (small) LAUNCH(c, (k_strain_tile<unsigned, 0, TYS, 1>), mg, mb, 0, c->stream, c->g, S); else LAUNCH(c, (k_strain_tile<size_t, 0, TYS, 1>), mg, mb, 0, c->stream, c->g, S); }
     else if (pair) LAUNCH(c, (k_strain_tile<unsigned, 0, TYS, 0, 1>), mg, mb, 0, c->stream, c->g, S);

@@ -343,3 +343,33 @@ def test_profiles_on_slabs_add_up():
     tol = lambda a, b: np.abs(a - b).max() <= 1e-13 * np.abs(b).max()
     assert tol(sum(r["z"] for r in res), ref["z"]) and tol(sum(r["x"] for r in res), ref["x"]) and tol(sum(r["chan"] for r in res), ref["chan"])
     assert tol(np.concatenate([r["y"] for r in res]), ref["y"]) and tol(np.concatenate([r["duct"] for r in res], axis=1), ref["duct"])
+
+
+@pytest.mark.parametrize("name,ng,nsteps,kchunk", [("chan_dsmag", (64, 20, 12), 3, None), ("chan_dsmag", (128, 30, 23), 2, "5"), ("tgv_dsmag_ppp", (64, 16, 24), 2, None),
+                                                   ("chan_dsmag", (64, 8, 40), 2, "7"), ("chan_dsmag", (192, 12, 16), 2, None)])
+def test_folded_projection_equals_the_separate_pass(name, ng, nsteps, kchunk, monkeypatch):
+    """cales_step on one rank, dynamic model, x and y periodic with whole 64-cell tiles in x: the velocity correction and the pressure update are done by
+    the strain-rate pass of cmpt_sgs (k_corr_strain_tile: corrected velocity on load, the z ghost planes by their boundary rule, p += pp) instead of
+    k_correc_cell. Same operations on the same values -- the two forms agree to round-off of the strain-rate block's association (1e-13 on every field,
+    ghost cells included; 1e-9 on the eddy viscosity, whose plane coefficients are quotients of sums); partial y tiles, k chunks that end inside the
+    field, z walls and z periodic."""
+    from cales_amd.hotpath import HotPath, initflow
+    if kchunk:
+        monkeypatch.setenv("CALES_KCHUNK", kchunk)
+    out = {}
+    for mode in ("fold", "separate"):
+        if mode == "separate":
+            monkeypatch.setenv("CALES_UNFOLDED_CORREC", "1")
+        g, case = load_golden(name); case.ng[:] = ng
+        h = HotPath(case); u, v, w, p = initflow(case)
+        rng = np.random.RandomState(1)
+        for a in (u, v, w):
+            a[1:-1, 1:-1, 1:-1] += 0.02 * (rng.rand(*ng) - 0.5)
+        h.upload(u, v, w, p); h.startup(); dt = 0.5 * h.chkdt()
+        for _ in range(nsteps):
+            h.step(dt)
+        out[mode] = h.download() + [h.get("pp")]
+        st = h.profile_stats() if False else None
+        h.close()
+    for nm, a, b in zip(("u", "v", "w", "p", "visct", "pp"), out["fold"], out["separate"]):
+        assert relerr(a, b) < (1e-9 if nm == "visct" else 1e-12), nm
