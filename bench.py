@@ -215,6 +215,20 @@ def cpu_baseline(a):
     return json.loads(lines[-1])
 
 
+def cpu_quota_cores():
+    """CPU time the container may use, in cores (cgroup v2 cpu.max, v1 cfs quota), or None when unlimited / unknown."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def _cpu_baseline_impl(case_full, seconds_budget=40.0, full_budget=150.0, sample_dims=(256, 256, 128)):
     """Oracle (oracle/cales_oracle.c, OpenMP) timed on the host's cores, twice:
       1. a bounded sample, 256x256x128 (1/16 of the cells), on the team size that runs it fastest among {32, 64, 128, all host threads}
@@ -238,7 +252,13 @@ def _cpu_baseline_impl(case_full, seconds_budget=40.0, full_budget=150.0, sample
     tried = {}
     t_begin = time.perf_counter()
     best = None
-    for cores in sorted({min(avail, c) for c in (32, 64, 128, avail)}):
+    # what the container may use is not what the host shows: the GPU boxes of this pool run with a CPU quota (cgroup cpu.max = 1600000 100000, i.e.
+    # 16 cores' worth of time, on a host that lists 256 hardware threads) -- a team larger than the quota is throttled and runs SLOWER (0.49 / 0.80 /
+    # 1.15 / 2.50 s per 256x256x128 step with 16 / 32 / 64 / 128 threads, tools/oracle_prof.py), which is the whole of the "port does not scale
+    # beyond 32 threads" of rounds 2 and 3. The teams tried are the quota and its neighbours; without a quota 32, 64, 128 and all hardware threads.
+    quota = cpu_quota_cores()
+    sizes = (32, 64, 128, avail) if quota is None else (max(1, int(quota) // 2), int(quota + 0.5), 2 * int(quota + 0.5))
+    for cores in sorted({max(1, min(avail, c)) for c in sizes}):
         # a trial = one warm-up step (twiddles, scratch first touch) + one timed step; stop trying larger teams when the budget is half used
         if tried and time.perf_counter() - t_begin > 0.5 * seconds_budget:
             break
@@ -284,7 +304,8 @@ def _cpu_baseline_impl(case_full, seconds_budget=40.0, full_budget=150.0, sample
         pass
     dims = "x".join(str(int(x)) for x in case.ng)
     scaled_value = (1.0 / t) * ncell_s / ncell_f
-    sample = (f"{k} steps of the same case at {dims} ({t:.3f} s/step, OpenMP over {cores} of {avail} host threads pinned to cores, fastest of {sorted(tried)}; "
+    sample = (f"{k} steps of the same case at {dims} ({t:.3f} s/step, OpenMP over {cores} of {avail} host threads"
+              + (f" -- the container's CPU quota is {quota:g} cores, larger teams are throttled" if quota else "") + f", fastest of {sorted(tried)}; "
               f"scaled by cell count that is {scaled_value:.4f} steps/s at full size)")
     if full:
         sample = (f"ONE real step of the workload itself ({full['grid']}: {full['s_per_step']:.1f} s on {cores} threads"
@@ -295,7 +316,7 @@ def _cpu_baseline_impl(case_full, seconds_budget=40.0, full_budget=150.0, sample
             "full_size": full,
             "measured": {"grid": dims, "s_per_step": t, "steps": k, "time_steps_per_s": 1.0 / t, "scaled_to_full_size": scaled_value,
                          "s_per_step_by_threads": {str(c): round(v, 4) for c, v in sorted(tried.items())}},
-            "scaled": full is None and ncell_s != ncell_f, "cpu_model": model, "host_threads_available": avail,
+            "scaled": full is None and ncell_s != ncell_f, "cpu_model": model, "host_threads_available": avail, "cpu_quota_cores": quota,
             "omp": {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES")},
             "sample": sample + ". The oracle is a C port of the path (OpenMP over planes), not the reference's 2decomp/FFTW build (FFTW is not in the image); "
                                "the reference itself parallelises with one MPI rank per core"}
