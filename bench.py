@@ -332,6 +332,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--configs", default="all", help="N = 1: the other BASELINE.json configurations timed after the headline measurement: all | none | c1,c2,c4,c5")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--skip-headline", action="store_true",
+                    help="profiling aid (tools/profile_configs.sh): only the configurations named by --configs, printed as {\"configs\": ...}; NOT a bench line")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: several ranks on ONE GPU with host-staged messages (tests of the launch path on a one-GPU box; not a measurement)")
     ap.add_argument("--overlap", action="store_true",
@@ -363,6 +365,11 @@ def main():
         sys.stdout.write(r.stdout if not lines else lines[-1] + "\n"); sys.stdout.flush()
         raise SystemExit(r.returncode if r.returncode or lines else 1)
 
+    if a.skip_headline:
+        from cales_amd import capi
+        from cales_amd.hotpath import SMALL, HotPath, initflow
+        print(json.dumps({"configs": {k: run_config(k, HotPath, initflow, SMALL, 4.0 if capi.SINGLE else 8.0) for k in want}}))
+        return
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
