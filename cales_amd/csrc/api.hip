@@ -61,6 +61,16 @@ static int field_alloc(cales_ctx *c, real **p) {
   return 0;
 }
 static void field_free(cales_ctx *c, real *p) { if (p) hipFree(p - c->field_ofs); }
+// two fields in ONE allocation, the second right behind the first: a kernel that addresses the first with 32-bit byte offsets reaches the second with the
+// constant c->pp_companion_bytes added (the correction pressure and its companion scratch field, k_corr_strain_tile on several slabs)
+static int field_alloc_pair(cales_ctx *c, real **p, real **q) {
+  real *base = nullptr;
+  const size_t one = c->ntot + LINE_REALS;
+  if (dev_alloc(c, &base, 2 * one)) return 1;
+  *p = base + c->field_ofs; *q = base + one + c->field_ofs;
+  c->pp_companion_bytes = one * sizeof(real);
+  return 0;
+}
 // host layout (0:n1+1,0:n2+1,0:n3+1), x contiguous  <->  device layout with row pitch s1
 __global__ __launch_bounds__(256) void k_repack(Geom g, int to_device, real *__restrict__ dev, real *__restrict__ packed) {
   const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
@@ -118,7 +128,7 @@ void cales_destroy(cales_ctx *c) {
   DBound *bs[11] = {&c->bcu, &c->bcv, &c->bcw, &c->bcp, &c->bcs, &c->bcuf, &c->bcvf, &c->bcwf, &c->bcu_mag, &c->bcv_mag, &c->bcw_mag};
   for (auto *b : bs) free_bound(*b);
   for (int d = 0; d < 3; ++d) hipFree(c->rhsbp[d]);
-  field_free(c, c->scr1); field_free(c, c->scr2); hipFree(c->d_red); hipFree(c->d_force); if (c->d_mpart) hipFree(c->d_mpart); if (c->d_abct) hipFree(c->d_abct); if (c->d_cs) hipFree(c->d_cs); if (c->d_nullw) hipFree(c->d_nullw); if (c->d_stat) hipFree(c->d_stat); if (c->d_stat2) hipFree(c->d_stat2); hipHostFree(c->h_red);
+  field_free(c, c->scr1); hipFree(c->d_red); hipFree(c->d_force); if (c->d_mpart) hipFree(c->d_mpart); if (c->d_abct) hipFree(c->d_abct); if (c->d_cs) hipFree(c->d_cs); if (c->d_nullw) hipFree(c->d_nullw); if (c->d_stat) hipFree(c->d_stat); if (c->d_stat2) hipFree(c->d_stat2); hipHostFree(c->h_red);
   field_free(c, c->s0); field_free(c, c->uc); field_free(c, c->vc); field_free(c, c->wc); field_free(c, c->uf); field_free(c, c->vf); field_free(c, c->wf); field_free(c, c->alph2); if (!c->p1d_in_comm) hipFree(c->d_p1d);
   for (int m = 0; m < 6; ++m) { field_free(c, c->wk[m]); field_free(c, c->sij[m]); field_free(c, c->mij[m]); }
   for (int m = 0; m < 3; ++m) if (c->ss2[m]) hipFree(c->ss2[m] - 2 * c->field_ofs);
@@ -202,8 +212,8 @@ int cales_create(const cales_case *cs, void *stream, cales_ctx **out) {
     if (upload_vec(c, &c->rhsbp[0], rx) || upload_vec(c, &c->rhsbp[1], ry) || upload_vec(c, &c->rhsbp[2], rz)) return fail(7); }
   // fields (haloed); r.h.s. buffers use the same layout so every kernel shares one index
   const int nfields = cs->impdiff ? CALES_NFIELDS : CALES_DUDTD;
-  for (int q = 0; q < nfields; ++q) if (field_alloc(c, &c->f[q])) return fail(8);
-  if (field_alloc(c, &c->scr1) || field_alloc(c, &c->scr2)) return fail(9);
+  for (int q = 0; q < nfields; ++q) if (q != CALES_PP && field_alloc(c, &c->f[q])) return fail(8);
+  if (field_alloc(c, &c->scr1) || field_alloc_pair(c, &c->f[CALES_PP], &c->scr2)) return fail(9);      // (scr2 lives in pp's allocation: freed with it)
   for (int q = 0; q < 3; ++q) if (field_alloc(c, &c->f2[q])) return fail(9);
   c->red_blocks = 8;
   if (dev_alloc(c, &c->d_red, 64 + 16 * (size_t)(n3 + 2) + 6 * (size_t)(n3 + 2)) || dev_alloc(c, &c->d_force, 8)) return fail(10);
@@ -335,6 +345,11 @@ int cales_out2d_duct(cales_ctx *c, real *buf) { if (!c || !buf) return 1; ENTRY(
 
 // ------------------------------------------------------------------------------------------ time step (main.f90:412-508)
 __global__ void k_zero6(real *f) { if (threadIdx.x < 6) f[threadIdx.x] = 0.; }
+__global__ __launch_bounds__(256) void k_row2_to_companion(Geom g, const real *__restrict__ pp, real *__restrict__ comp) {
+  const int i = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y * 4 + threadIdx.y;
+  if (i > g.n1 + 1 || k > g.n3 + 1) return;
+  comp[g.ix(i, 1, k)] = pp[g.ix(i, 2, k)];
+}
 
 static int step_body(cales_ctx *c, real dt);
 int cales_step(cales_ctx *c, real dt) {
@@ -361,12 +376,14 @@ static int step_body(cales_ctx *c, real dt) {
   // dynamic model, one rank, x and y periodic (|S|Sij as pair fields), z periodic or two no-slip walls, explicit diffusion, no wall model: the
   // projection u = u* - dtrk grad(pp) (+ the deferred forcing) and p += pp are folded into the strain-rate pass of cmpt_sgs, which reads the velocity
   // anyway -- the correction pass (9 words per cell) disappears (dsmag_fast, k_strain_tile<.., CORR = 1>)
-  bool fold_correc = c->step_xskip && c->P == 1 && c->C.sgstype == 2 && c->C.impdiff == 0 && dsmag_pairs(c) && !c->fl.unfolded_correc && !c->fl.unfused_correc && !c->fl.dsmag_store_uc && c->n[0] % 64 == 0;      // (whole 64-cell tiles in x)
+  bool fold_correc = c->step_xskip && c->C.sgstype == 2 && c->C.impdiff == 0 && dsmag_pairs(c) && !c->fl.unfolded_correc && !c->fl.unfused_correc && !c->fl.dsmag_store_uc && c->n[0] % 64 == 0;      // (whole 64-cell tiles in x)
   { const bool perz = CBV(c, 0, 3, 3) == 'P' && CBV(c, 1, 3, 3) == 'P';
     bool walls = true;
     for (int iv = 1; iv <= 3; ++iv) for (int sd = 0; sd <= 1; ++sd) walls = walls && CBV(c, sd, 3, iv) == 'D';
     walls = walls && CBP(c, 0, 3) == 'N' && CBP(c, 1, 3) == 'N';
-    fold_correc = fold_correc && (perz || walls); }
+    fold_correc = fold_correc && (perz || walls);
+    // several slabs: the pass reaches the companion field of pp with 32-bit offsets (two fields under 4 GB), exchanges through the slab hooks
+    if (c->P > 1) fold_correc = fold_correc && c->comm.on && 2 * (c->ntot + 2 * LINE_REALS) * sizeof(real) < (1ull << 32); }
   for (int irk = 1; irk <= 3; ++irk) {
     const real dtrk = (rk[irk - 1][0] + rk[irk - 1][1]) * dt, dtrki = 1. / dtrk;
     real alpha = 0.;
@@ -402,6 +419,13 @@ static int step_body(cales_ctx *c, real dt) {
     if (fuse_fill) c->fuse_fillps_dti = dtrki;
     else { if (int e = op_fillps(c, dtrki)) return e; if (int e = op_updt_rhs_b(c)) return e; }
     { const int e = op_solver(c); c->fuse_fillps_dti = 0.; if (e) return e; }
+    if (fold_correc && c->P > 1) {
+      // the folded projection corrects v in the ghost row n2+1 too and needs pp one row further out: row 2 of every slab goes to row 1 of pp's companion
+      // field and both fields take the ghost-cell update -- ONE exchange; the upper neighbour's row 2 arrives in the companion's ghost row n2+1
+      LAUNCH(c, k_row2_to_companion, dim3((c->n[0] + 2 + 63) / 64, (c->n[2] + 2 + 3) / 4), dim3(64, 4), 0, c->stream, c->g, c->f[CALES_PP], c->scr2);
+      real *two[2] = {c->f[CALES_PP], c->scr2};
+      if (int e = op_boundp_multi(c, 2, two, 0)) return e;
+    } else
     if (int e = op_boundp(c, c->f[CALES_PP], 0)) return e;
     if (fold_correc) c->fold_dtrk = dtrk;      // correc, bounduvw, updatep, boundp(p): inside the cmpt_sgs below (dsmag_fast)
     else {

@@ -196,6 +196,7 @@ struct cales_ctx {
   // cales_step, dynamic model on one rank with x and y periodic: the velocity correction and the pressure update of the substep are done by the
   // strain-rate pass of the cmpt_sgs that follows (k_strain_tile<.., CORR = 1>, k_sgs.hip) -- != 0: the dtrk of the pending projection
   real fold_dtrk = 0.;
+  size_t pp_companion_bytes = 0;      // scr2 sits this many bytes behind CALES_PP in one allocation (api.hip field_alloc_pair)
   int field_ofs = 0;       // doubles between a field's allocation and its element (0,0,0)
   real *d_nullw = nullptr; // work space of k_null_column (CALES_KEEP_NULL_MODE)
 };

@@ -745,6 +745,10 @@ struct StrainTileArgs {
   const real *pp; real *p; real *un[3]; const real *force; int fmask; real cfi, cfj, cdt;
   const real *bcz[2][2];      // Dirichlet planes of u and v at the two z walls (bounduvw's 2 bc - u(1)), [component][side]
   int zper;                   // z periodic: ghost planes are the wrapped interior planes
+  // several slabs (pery = 0): the ghost rows 0 and n2+1 of u*, v*, w* and pp hold the neighbours' rows (exchanged), and the one value further out that the
+  // correction of v in row n2+1 needs -- pp of the upper neighbour's row 2 -- sits in ghost row n2+1 of the COMPANION field, allocated right behind pp
+  // (ppd = its distance in bytes; cales_step copies row 2 there and exchanges both fields in one message). One slab: rows wrap around.
+  int pery; size_t ppd;
 };
 // sqrt(tau_w) at the two y walls for every (i, k): the argument of the van Driest damping of the cells whose nearest wall is a y wall
 // (sgs.f90:117-143, cases 3 and 4 of the select), from the fields themselves (their ghost cells, not the extrapolated ones)
@@ -949,20 +953,25 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_corr_strain_tile(Geom g, Stra
   const bool edge = tx == 0 || tx == 63;
   const int hx = tx == 0 ? 0 : 65;
   const bool outok = ty >= 1 && ty <= TY && j <= n2;
-  // the cell this thread loads: wrapped in y
-  // (rows beyond n2+1 keep wrapping: row n2+2 holds pp of row 2, which the correction of row n2+1 -- the wrapped row 1, the halo of the last row -- reads from sP)
-  const int jq = j == 0 ? n2 : j > n2 ? min(j - n2, n2) : j, jp = jq >= n2 ? 1 : jq + 1;
+  // the rows this thread loads. One slab: wrapped in y (rows beyond n2+1 keep wrapping: row n2+2 holds pp of row 2, which the correction of row n2+1 --
+  // the wrapped row 1, the halo of the last row -- reads from sP). Several slabs: the ghost rows as they are, pp of "row n2+2" from the companion field
+  auto urow = [&](int r) { return A.pery ? (r == 0 ? n2 : r > n2 ? min(r - n2, n2) : r) : min(r, n2 + 1); };
+  auto poff = [&](int col, int r) -> OFF {      // byte offset (from pp) of pp(col, r, 0)
+    if (A.pery || r <= n2 + 1) return (OFF)g.ix(col, urow(r), 0) * RSZ;
+    return (OFF)(A.ppd + g.ix(col, n2 + 1, 0) * RSZ);      // (rows beyond n2+2: never used)
+  };
+  const int jq = urow(j);
   const OFF sk = (OFF)g.s12 * RSZ;
-  const OFF cl = (OFF)g.ix(i, jq, 0) * RSZ, cly = (OFF)g.ix(i, jp, 0) * RSZ;
+  const OFF cl = (OFF)g.ix(i, jq, 0) * RSZ, clp = poff(i, j), cly = poff(i, j + 1);
   const OFF cdump = (OFF)g.ix(0, min(j, n2 + 1), 0) * RSZ;      // the x ghost cell of the row: where lanes / planes without an output of their own store
   const OFF cst = outok ? cl : cdump;
   // side job of the y-halo waves: lane tx < TY+2 completes the x-halo cell of tile row tx (other lanes repeat their own cell: no branches around loads)
   const bool hwave = ty == 0 || ty == TY + 1;
   const int sside = ty == 0 ? 0 : 1, hxs = sside ? 65 : 0, si0 = bx * 64 + (sside ? 65 : 0), sj0 = by * TY + tx;
   const bool sok = hwave && tx < TY + 2 && sj0 <= n2 + 1;
-  const int si = !sok ? i : si0 == 0 ? n1 : si0 == n1 + 1 ? 1 : si0, sjr = !sok ? jq : sj0 == 0 ? n2 : sj0 == n2 + 1 ? 1 : sj0;
-  const int sxr = si >= n1 ? 1 : si + 1, sjp = sjr >= n2 ? 1 : sjr + 1;
-  const OFF so = (OFF)g.ix(si, sjr, 0) * RSZ, soy = (OFF)g.ix(si, sjp, 0) * RSZ, sox = (OFF)g.ix(sxr, sjr, 0) * RSZ;
+  const int si = !sok ? i : si0 == 0 ? n1 : si0 == n1 + 1 ? 1 : si0, sjr = !sok ? jq : urow(sj0), sjx = !sok ? j : sj0;
+  const int sxr = si >= n1 ? 1 : si + 1;
+  const OFF so = (OFF)g.ix(si, sjr, 0) * RSZ, sop = poff(si, sjx), soy = poff(si, sjx + 1), sox = poff(sxr, sjx);
   const int srow = sok ? tx : 0;
   auto kz = [&](int kk) { return !A.zper ? kk : kk == 0 ? n3 : kk == n3 + 1 ? 1 : kk; };      // plane that holds the values of plane kk
   const real f0 = (A.fmask & 1) ? ldc(A.force, 0) : 0., f1 = (A.fmask & 2) ? ldc(A.force, 1) : 0., f2 = (A.fmask & 4) ? ldc(A.force, 2) : 0.;
@@ -970,17 +979,17 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_corr_strain_tile(Geom g, Stra
   // loads its pp(i+1) and pp(j+1), the own cells find theirs in sP (the top halo row, whose row above is another block's, loads its pp(j+1))
   struct Raw { real q[3], pz; };
   struct RawS { real q[3], pz, px, py; };
-  auto rawload = [&](OFF o, int kk, Raw &r) {      // kk: a plane index in 0..n3+1 (mapped by kz)
-    const OFF a = o + (OFF)kk * sk;
+  auto rawload = [&](int kk, Raw &r) {      // kk: a plane index in 0..n3+1 (mapped by kz)
+    const OFF a = cl + (OFF)kk * sk;
 #pragma unroll
     for (int q = 0; q < 3; ++q) r.q[q] = ldb(A.u[q], a);
-    r.pz = ldb(A.pp, o + (OFF)min(kk + 1, n3 + 1) * sk);
+    r.pz = ldb(A.pp, clp + (OFF)min(kk + 1, n3 + 1) * sk);
   };
   auto rawloads = [&](int kk, RawS &r) {
     const OFF a = so + (OFF)kk * sk;
 #pragma unroll
     for (int q = 0; q < 3; ++q) r.q[q] = ldb(A.u[q], a);
-    r.pz = ldb(A.pp, so + (OFF)min(kk + 1, n3 + 1) * sk); r.px = ldb(A.pp, sox + (OFF)kk * sk); r.py = ldb(A.pp, soy + (OFF)kk * sk);
+    r.pz = ldb(A.pp, sop + (OFF)min(kk + 1, n3 + 1) * sk); r.px = ldb(A.pp, sox + (OFF)kk * sk); r.py = ldb(A.pp, soy + (OFF)kk * sk);
   };
   // interior plane kq: (u* + f) - dtrk grad(pp), k_correc_cell's operations in their order
   auto fix = [&](const real *q, real P0, real px, real py, real pz, int kq, real *o) {
@@ -999,14 +1008,14 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_corr_strain_tile(Geom g, Stra
   { // ---- planes kbeg-1 and kbeg complete, plane kbeg+1 in flight (pp's neighbours by direct loads here: sP serves the loop)
     real c1[3], c0v[3], h1[3] = {0., 0., 0.}, h0[3] = {0., 0., 0.};
     const bool low = !A.zper && kbeg == 1;      // plane kbeg-1 is the ghost plane below the lower wall
-    const OFF clx = (OFF)g.ix(i >= n1 ? 1 : i + 1, jq, 0) * RSZ;
-    { const int kq = kz(kbeg); Raw r; rawload(cl, kq, r); const real P0 = ldb(A.pp, cl + (OFF)kq * sk);
+    const OFF clx = poff(i >= n1 ? 1 : i + 1, j);
+    { const int kq = kz(kbeg); Raw r; rawload(kq, r); const real P0 = ldb(A.pp, clp + (OFF)kq * sk);
       fix(r.q, P0, ldb(A.pp, clx + (OFF)kq * sk), ldb(A.pp, cly + (OFF)kq * sk), r.pz, kq, c1); p0n = r.pz;
       const OFF a = cst + (OFF)kbeg * sk; stb(A.p, a, ldb(A.p, a) + P0);      // p += pp (updatep.f90:30-47, explicit diffusion); lanes without output: their ghost cell
-      if (hwave) { RawS e; rawloads(kq, e); const real E0 = ldb(A.pp, so + (OFF)kq * sk); fix(e.q, E0, e.px, e.py, e.pz, kq, h1); p0h = e.pz; } }
-    { const int kq = kz(kbeg - 1); Raw r; rawload(cl, kq, r); const real P0 = ldb(A.pp, cl + (OFF)kq * sk);
+      if (hwave) { RawS e; rawloads(kq, e); const real E0 = ldb(A.pp, sop + (OFF)kq * sk); fix(e.q, E0, e.px, e.py, e.pz, kq, h1); p0h = e.pz; } }
+    { const int kq = kz(kbeg - 1); Raw r; rawload(kq, r); const real P0 = ldb(A.pp, clp + (OFF)kq * sk);
       if (low) wallfix(r.q, P0, r.pz, 0, q2, c1, c0v); else fix(r.q, P0, ldb(A.pp, clx + (OFF)kq * sk), ldb(A.pp, cly + (OFF)kq * sk), r.pz, kq, c0v);
-      if (hwave) { RawS e; rawloads(kq, e); const real E0 = ldb(A.pp, so + (OFF)kq * sk);
+      if (hwave) { RawS e; rawloads(kq, e); const real E0 = ldb(A.pp, sop + (OFF)kq * sk);
                    if (low) wallfix(e.q, E0, e.pz, 0, q2s, h1, h0); else fix(e.q, E0, e.px, e.py, e.pz, kq, h0); } }
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -1016,7 +1025,7 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_corr_strain_tile(Geom g, Stra
     }
     sP[(kbeg + 1) & 1][ty][tx] = p0n;      // pp of plane kbeg+1
     if (sok && sside) sP[(kbeg + 1) & 1][srow][64] = p0h;
-    rawload(cl, kz(kbeg + 1), rn);
+    rawload(kz(kbeg + 1), rn);
     if (hwave) { rawloads(kz(kbeg + 1), rh); pyt = ldb(A.pp, cly + (OFF)kz(kbeg + 1) * sk); }
     __syncthreads();
   }
@@ -1046,7 +1055,7 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_corr_strain_tile(Geom g, Stra
         for (int q = 0; q < 3; ++q) stb(A.un[q], dst, cc[q]);
       }
       p0n = rn.pz;
-      rawload(cl, k2, rn);
+      rawload(k2, rn);
       // (the data registers of the last plane's three filtered-velocity stores stay allocated up to here: reused earlier, the compiler has to wait
       //  for those stores -- the youngest operations in flight, i.e. for everything -- before the first instruction that overwrites them)
       if (!HALO) asm volatile("" :: "v"(keep[0]), "v"(keep[1]), "v"(keep[2]));
@@ -1347,6 +1356,7 @@ static int dsmag_fast(cales_ctx *c) {
       S.pp = f[CALES_PP]; S.p = f[CALES_P]; for (int q = 0; q < 3; ++q) S.un[q] = c->f2[q];
       S.force = c->d_force; S.fmask = c->defer_force ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;
       S.cdt = c->fold_dtrk; S.cfi = c->fold_dtrk * c->dli[0]; S.cfj = c->fold_dtrk * c->dli[1]; S.zper = perz ? 1 : 0;
+      S.pery = c->P == 1 ? 1 : 0; S.ppd = c->pp_companion_bytes;
       const size_t pl = (size_t)(n[0] + 2) * (n[1] + 2);
       S.bcz[0][0] = c->bcu.z; S.bcz[0][1] = c->bcu.z + pl; S.bcz[1][0] = c->bcv.z; S.bcz[1][1] = c->bcv.z + pl;
       LAUNCH(c, (k_corr_strain_tile<unsigned, TYC>), mg, mb, 0, c->stream, c->g, S);

@@ -60,6 +60,9 @@ SLAB_CASES = [("chan_smag_wm", (32, 24, 16), 2), ("chan_smag_wm", (32, 24, 16), 
                                        # bulk means fused into the forward pass or not (wall model), Neumann-Neumann kinds, periodic z, a duct with the dynamic model
                                        ("chan_dsmag_wm", (64, 32, 32), 4), ("cavity_nnn", (64, 32, 32), 2), ("tgv_ppp", (32, 32, 16), 2), ("duct_dsmag_wm", (32, 32, 32), 2),
                                        ("chan_smag", (128, 64, 64), 8),
+                                       # dynamic model with whole 64-cell tiles in x: the projection folded into the strain-rate pass on every slab (ghost rows from the
+                                       # neighbours, pp of the upper neighbour's row 2 through the companion field); slabs shorter and longer than a tile, z periodic
+                                       ("chan_dsmag", (64, 32, 24), 4), ("chan_dsmag", (64, 64, 16), 8), ("tgv_dsmag_ppp", (64, 24, 16), 3), ("chan_dsmag", (128, 44, 20), 2),
                                        # 3-D implicit diffusion with no-slip walls in x and y (wall-normal DST-I in the slab and in the mode-block layout)
                                        ("cavity_imp3d", (32, 24, 12), 2), ("cavity_imp3d", (20, 36, 10), 4),
                                        # ... and with open boundaries: inflow / outflow along x (RODFT01/10 in the slab) and along y (in the mode-block layout)
