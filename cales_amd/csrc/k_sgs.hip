@@ -769,11 +769,11 @@ __global__ __launch_bounds__(256) void k_wall_shear_y(Geom g, const real *__rest
     twy[(size_t)(g.n3 + 2 + k) * g.s1 + i] = sqrt(0.5 * visc * (sqrt(t1 * t1 + t2 * t2) * dyi));
   }
 }
-template <typename OFF, int SMAG, int TY, int YW, int PAIR = 0>      // YW = 1: walls or wall-model faces in y (ducts); the channel instantiations carry none of that logic
+template <typename OFF, int TY, int YW, int PAIR = 0>      // YW = 1: walls or wall-model faces in y (ducts); the channel instantiations carry none of that logic
 __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTileArgs A) {
   // (one barrier per plane with four ring slots and double-buffered sums, as in k_lij_mij_tile, measured 13 % slower here)
   __shared__ real ring[3][3][TY + 2][66];      // rows: x-halo cell, 64 own cells, x-halo cell
-  __shared__ real shs[SMAG ? 1 : 3][TY + 2][64];
+  __shared__ real shs[3][TY + 2][64];
   const int tx = threadIdx.x, ty = threadIdx.y;
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   if (A.bm.gx && !band_block(A.bm, bx, by, bz)) return;
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
   const int iq = (A.perx && i == g.n1 + 1) ? 1 : i;      // (the column right of the last cell of the row, loaded by the last tile's lane beside it)
   const OFF c0 = ldok ? (OFF)g.ix(iq, j, 0) * RSZ : 0, ch = hok ? (OFF)g.ix(ih, j, 0) * RSZ : 0, sk = (OFF)g.s12 * RSZ;   // byte offsets
   real fn[3], fh[3];
-  // ghost rows at wall-model y faces (SMAG pass of ducts): u and w are replaced by 2 Q(1) - Q(2) along y; v, normal to the face, is not
+  // ghost rows at wall-model y faces: u and w are replaced by 2 Q(1) - Q(2) along y; v, normal to the face, is not
   const int yex = !YW ? 0 : (A.wmylo && j == 0) ? 1 : (A.wmyhi && j == g.n2 + 1) ? -1 : 0;
   const OFF sjb = (OFF)g.s1 * RSZ;
   auto ld = [&](int q, OFF o) -> real {
@@ -809,24 +809,6 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
       if (edge) ring[0][q][ty][hx] = (1. + A.flo) * ring[1][q][ty][hx] - A.flo * fh[q];
     }
   }
-  // van Driest: wall units from the shear at the nearer z wall of this column (sgs.f90:117-143), read from the fields
-  // themselves (their ghost cells, not the extrapolated ones)
-  real tw_lo = 0., tw_hi = 0.;
-  if (SMAG && outok) {
-    const real *u = A.u[0], *v = A.u[1];
-    const int im1 = (A.perx && i == 1) ? g.n1 : i - 1;
-    if (A.zlo) {
-      const real t1 = u[g.ix(i, j, 1)] - u[g.ix(i, j, 0)] + u[g.ix(im1, j, 1)] - u[g.ix(im1, j, 0)];
-      const real t2 = v[g.ix(i, j, 1)] - v[g.ix(i, j, 0)] + v[g.ix(i, j - 1, 1)] - v[g.ix(i, j - 1, 0)];
-      tw_lo = sqrt(0.5 * A.visc * (sqrt(t1 * t1 + t2 * t2) * A.dzci[0]));      // sqrt(tauw), constant along the column
-    }
-    if (A.zhi) {
-      const int n3 = g.n3;
-      const real t1 = u[g.ix(i, j, n3)] - u[g.ix(i, j, n3 + 1)] + u[g.ix(im1, j, n3)] - u[g.ix(im1, j, n3 + 1)];
-      const real t2 = v[g.ix(i, j, n3)] - v[g.ix(i, j, n3 + 1)] + v[g.ix(i, j - 1, n3)] - v[g.ix(i, j - 1, n3 + 1)];
-      tw_hi = sqrt(0.5 * A.visc * (sqrt(t1 * t1 + t2 * t2) * A.dzci[n3]));
-    }
-  }
   int km = (kbeg - 1) % 3, kc = kbeg % 3, kp = (kbeg + 1) % 3;
   for (int k = kbeg; k <= kend; ++k) {
     const OFF idx = c0 + (OFF)k * sk;
@@ -843,7 +825,6 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
     __syncthreads();
     const bool lo = A.zlo && k == 1, hi = A.zhi && k == g.n3;
     real r[3];
-    if (!SMAG) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       auto zcomb = [&](int x) {
@@ -857,7 +838,6 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
       if (edge) { const real Gh = zcomb(hx); if (tx == 0) pv = Gh; else nx = Gh; }
       r[q] = pv + 2. * G + nx;
       shs[q][ty][tx] = r[q];
-    }
     }
     if (outok) {
 #define RU(dk, dj, di) ring[dk][0][ty + (dj)][tx + 1 + (di)]
@@ -881,23 +861,7 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
       const real s23 = .125 * ((v_ccp - v_ccc) * zc + (w_cpc - w_ccc) * dyi + (v_ccc - v_ccm) * zm + (w_cpm - w_ccm) * dyi +
                                  (v_cmp - v_cmc) * zc + (w_ccc - w_cmc) * dyi + (v_cmc - v_cmm) * zm + (w_ccm - w_cmm) * dyi);
       const real s0v = sqrt(2. * (s11 * s11 + s22 * s22 + s33 * s33 + 2. * (s12 * s12 + s13 * s13 + s23 * s23)));
-      if (SMAG) {
-        real fd = 1.;
-        if (A.zlo || A.zhi || (YW && (A.wylo || A.wyhi))) {     // nearest wall in the order y-, y+, z-, z+: the first one wins a tie (minloc, sgs.f90:116)
-          const int jg = j + g.jlo;                  // distances to the y walls use global rows
-          real dmin = YW && A.wylo ? A.dl2 * (jg - 0.5) : CALES_BIG, tw = 0.; int loc = 2;
-          { const real d = YW && A.wyhi ? A.dl2 * (g.ng2 - jg + 0.5) : CALES_BIG; if (d < dmin) { dmin = d; loc = 3; } }
-          { const real d = A.zlo ? ldc(A.zc, k) : CALES_BIG; if (d < dmin) { dmin = d; loc = 4; } }
-          { const real d = A.zhi ? A.l3 - ldc(A.zc, k) : CALES_BIG; if (d < dmin) { dmin = d; loc = 5; } }
-          if (loc == 2) tw = A.twy[(size_t)k * g.s1 + i];
-          else if (loc == 3) tw = A.twy[(size_t)(g.n3 + 2 + k) * g.s1 + i];
-          else tw = loc == 4 ? tw_lo : tw_hi;
-          const real dw_plus = dmin * tw * (1. / A.visc);
-          fd = 1. - exp(-dw_plus / 25.);
-        }
-        const real t = 0.11 * ldc(A.del, k) * fd;      // c_smag, src/param.f90:33
-        stb(A.visct, idx, (t * t) * s0v);
-      } else {
+      {
         stb(A.s0, idx, s0v);                                              // stands for visct = s0 (sgs.f90:184) until the final kernel
         if (PAIR) {      // |S|Sij (sgs.f90:198-210), two components per 16-byte store
           const OFF i2 = 2 * idx;
@@ -913,7 +877,7 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
       }
     }
     __syncthreads();
-    if (!SMAG && outok) {
+    if (outok) {
       // next to a no-slip y wall the ghost row of u and w is the extrapolation 2 Q(1) - Q(2) (extrapolate(...,cbc), sgs.f90:705-710): its
       // y combination is 4 Q(1); v, normal to the wall, keeps its ghost row
       const bool ylo = YW && A.wylo && j == 1, yhi = YW && A.wyhi && j == g.n2;
@@ -1160,7 +1124,7 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_corr_strain_tile(Geom g, Stra
 // DPP lane moves, the rows j-1 and j+1 loaded again by this wave (they are their own waves' rows: cache hits), z neighbours rolled from plane
 // to plane. No LDS and no barriers: the tile form above is bound by its barrier pair per plane with two square roots and an exponential per
 // cell in between (0.26 of the HBM peak); here waves never wait for each other and the VGPR count alone sets the occupancy.
-// Same arithmetic, in the same order, as k_strain_tile<SMAG = 1> (sgs.f90:98-152, 598-680).
+// (sgs.f90:98-152, 598-680)
 constexpr int SROWS = 4;      // rows (waves) per block
 template <typename OFF, int YW>
 // (four waves per SIMD -- 128 VGPRs -- for channels; the duct logic needs a few registers more and would spill under that cap)
@@ -1361,9 +1325,9 @@ static int dsmag_fast(cales_ctx *c) {
       S.bcz[0][0] = c->bcu.z; S.bcz[0][1] = c->bcu.z + pl; S.bcz[1][0] = c->bcv.z; S.bcz[1][1] = c->bcv.z + pl;
       LAUNCH(c, (k_corr_strain_tile<unsigned, TYC>), mg, mb, 0, c->stream, c->g, S);
     } else
-    if (wylo || wyhi || wmylo || wmyhi) { if (small) LAUNCH(c, (k_strain_tile<unsigned, 0, TYS, 1>), mg, mb, 0, c->stream, c->g, S); else LAUNCH(c, (k_strain_tile<size_t, 0, TYS, 1>), mg, mb, 0, c->stream, c->g, S); }
-    else if (pair) LAUNCH(c, (k_strain_tile<unsigned, 0, TYS, 0, 1>), mg, mb, 0, c->stream, c->g, S);
-    else if (small) LAUNCH(c, (k_strain_tile<unsigned, 0, TYS, 0>), mg, mb, 0, c->stream, c->g, S); else LAUNCH(c, (k_strain_tile<size_t, 0, TYS, 0>), mg, mb, 0, c->stream, c->g, S); }
+    if (wylo || wyhi || wmylo || wmyhi) { if (small) LAUNCH(c, (k_strain_tile<unsigned, TYS, 1>), mg, mb, 0, c->stream, c->g, S); else LAUNCH(c, (k_strain_tile<size_t, TYS, 1>), mg, mb, 0, c->stream, c->g, S); }
+    else if (pair) LAUNCH(c, (k_strain_tile<unsigned, TYS, 0, 1>), mg, mb, 0, c->stream, c->g, S);
+    else if (small) LAUNCH(c, (k_strain_tile<unsigned, TYS, 0>), mg, mb, 0, c->stream, c->g, S); else LAUNCH(c, (k_strain_tile<size_t, TYS, 0>), mg, mb, 0, c->stream, c->g, S); }
   if (fold) {
     // the corrected velocity sits in the second buffers: swap (as the fused momentum pass does), give the normal component its two z faces -- the
     // reference's correc covers w(:,:,0) (correc.f90:60-66) and leaves w(:,:,n3+1) as it was, and bounduvw with is_correc touches neither -- and
@@ -1509,20 +1473,9 @@ static int smag_fast(cales_ctx *c) {
     HIPCHK(c, hipMalloc(&c->d_del, (n[2] + 2) * sizeof(real)));
     LAUNCH(c, k_smag_del, dim3((n[2] + 2 + 63) / 64), dim3(64), 0, c->stream, n[2] + 2, c->dl[0], c->dl[1], c->d_dzf, c->d_del);
   }
-  // tile height of the LDS-tile form (CALES_SMAG_TILE): the pass is bound by latency (one barrier pair per plane, two square roots and an exponential
-  // per cell), not by bandwidth, so several small blocks per CU beat one block of sixteen waves (measured in round 2: 10 rows beat 14 by 5-33 % from
-  // 256x128x128 to 512^3 and 6 rows lose; the run-time choice CALES_SMAG_TY went with its A/B)
-  constexpr int TYM = 10;
-  dim3 mb(64, TYM + 2, 1), mg((n[0] + 63) / 64, (n[1] + TYM - 1) / TYM, 1);
-  int kch = n[2];
-  while ((long)mg.x * mg.y * ((n[2] + kch - 1) / kch) < tile_min_blocks(c) && kch > 32) kch = (kch + 1) / 2;
-  // small grids: fewer blocks than one per CU leave most of the chip idle; shorter chunks (their three-plane prologue weighs more) beat that
-  while ((long)mg.x * mg.y * ((n[2] + kch - 1) / kch) < 256 && kch > 8) kch = (kch + 1) / 2;
-  if (int fk = tile_kchunk(c, (long)mg.x * mg.y, n[2])) kch = fk;
-  mg.z = (n[2] + kch - 1) / kch;
   StrainTileArgs S = {};
   S.u[0] = f[CALES_U]; S.u[1] = f[CALES_V]; S.u[2] = f[CALES_W]; S.visct = f[CALES_VISCT];
-  S.dzci = c->d_dzci; S.dzfi = c->d_dzfi; S.dxi = c->dli[0]; S.dyi = c->dli[1]; S.kchunk = kch;
+  S.dzci = c->d_dzci; S.dzfi = c->d_dzfi; S.dxi = c->dli[0]; S.dyi = c->dli[1];
   S.zlo = c->is_wall[4] != 0.; S.zhi = c->is_wall[5] != 0.;
   S.wmlo = ISB(c, 0, 3) && LWM(c, 0, 3) != 0; S.wmhi = ISB(c, 1, 3) && LWM(c, 1, 3) != 0;
   S.flo = (1. / c->dzci[0]) * c->dzci[1]; S.fhi = (1. / c->dzci[n[2]]) * c->dzci[n[2] - 1];
@@ -1534,8 +1487,9 @@ static int smag_fast(cales_ctx *c) {
   if (S.wylo || S.wyhi) { if (int e = wall_shear_y_planes(c, S.wylo, S.wyhi, &S.twy)) return e; }
   const bool small = (c->ntot + 16) * sizeof(real) < (1ull << 32) && !c->fl.wide_offsets;
   const bool yw = S.wylo || S.wyhi || S.wmylo || S.wmyhi;
-  if (!c->fl.smag_tile) {
-    // row-marching form: one wave per row of 62 cells; chunks of k so that every CU holds several blocks' worth of independent waves
+  {
+    // row-marching form: one wave per row of 62 cells; chunks of k so that every CU holds several blocks' worth of independent waves (the LDS-tile
+    // form of this pass -- two barriers per plane, 2.4 against 2.9 TB/s -- lost its A/B in round 2 and went in round 4)
     const dim3 rb(64, SROWS, 1);
     const int rgx = (n[0] + 61) / 62, rgy = (n[1] + SROWS - 1) / SROWS;
     int kr = n[2];
@@ -1550,14 +1504,6 @@ static int smag_fast(cales_ctx *c) {
     LAUNCHCHK(c);
     return 0;
   }
-#define SMAG_LAUNCH(TYV) do { if (yw) { if (small) LAUNCH(c, (k_strain_tile<unsigned, 1, TYV, 1>), mg, mb, 0, c->stream, c->g, S); \
-                                         else LAUNCH(c, (k_strain_tile<size_t, 1, TYV, 1>), mg, mb, 0, c->stream, c->g, S); } \
-                              else if (small) LAUNCH(c, (k_strain_tile<unsigned, 1, TYV, 0>), mg, mb, 0, c->stream, c->g, S); \
-                              else LAUNCH(c, (k_strain_tile<size_t, 1, TYV, 0>), mg, mb, 0, c->stream, c->g, S); } while (0)
-  SMAG_LAUNCH(10);
-#undef SMAG_LAUNCH
-  LAUNCHCHK(c);
-  return 0;
 }
 
 // every kernel the SGS pass of this case launches reads wrapped interior columns where x is periodic (cales_step may leave the x ghost columns stale)

@@ -581,7 +581,7 @@ __global__ __launch_bounds__(512) void k_fft_y8r(Geom g, int N, int ncols, int k
   cpx *tw = reinterpret_cast<cpx *>(smem), *line = tw + N + (size_t)c * ld;
   for (int q = threadIdx.x; q < N; q += blockDim.x) tw[q] = twg[q];
   const bool colok = m0 + c < ncols;
-  const int mc = colok ? m0 + c : ncols - 1;      // (columns beyond the last one repeat it: every load unconditional, nothing stored)
+  const int mc = colok ? m0 + c : ncols - 1;      // (columns beyond the last one repeat it: every load and store unconditional)
   cpx nxt[8], v[8];
   auto fetch = [&](int k) {
 #pragma unroll
@@ -594,10 +594,10 @@ __global__ __launch_bounds__(512) void k_fft_y8r(Geom g, int N, int ncols, int k
     for (int e = 0; e < 8; ++e) v[e] = nxt[e];
     fetch(min(k + 1, kend));                                                   // in flight during the transform (the last plane again: unused)
     fft_line8_dif<INV>(N, line, t, tw, v);
-    if (colok) {
+    // (unconditional: lanes of columns beyond the last one hold a copy of the last column and store ITS values to ITS places once more -- a branch
+    //  around the stores makes the wait for the next plane's loads a wait for these stores as well, s_waitcnt vmcnt(0) instead of vmcnt(8))
 #pragma unroll
-      for (int e = 0; e < 8; ++e) pc[S.at_mode(g, mc, t + e * T + 1, k)] = make_real2(v[e].x, v[e].y);
-    }
+    for (int e = 0; e < 8; ++e) pc[S.at_mode(g, mc, t + e * T + 1, k)] = make_real2(v[e].x, v[e].y);
     __syncthreads();                                                           // the last stage's reads are done before the next plane writes
   }
 }
@@ -1261,9 +1261,7 @@ int solver_setup(cales_ctx *c) {
                if (sp.shy8r > 64 * 1024) { HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y8r<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8r));
                                            HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y8r<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8r)); }
                if (sp.shy8 > 64 * 1024) {      // n2 = 1024: 4 columns (64-B row segments) need 90 KB of LDS
-                 HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y8<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8));
                  HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y8<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8));
-                 HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y8<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8));
                  HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y8<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8)); } }
   if (c->ykind >= 3) {      // DCT-IV / DST-IV in y: N/2-point lines, two per complex column
     if (!make_plan(n2g / 2, sp.py4)) { c->err = "solver: ng(2)/2 must factor into primes <= 127"; return 1; }
@@ -1479,8 +1477,7 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
       ProfScope ps(c, "fft_y_fwd");
       const dim3 gy((ncol + CB8 - 1) / CB8, (kpc + ykchunk_c - 1) / ykchunk_c);
       if (c->ykind) LAUNCH(c, (k_fft_y8<0, 1>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1));
-      else if (c->fl.fft_staged) LAUNCH(c, (k_fft_y8<0, 0>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1));
-        else LAUNCH(c, (k_fft_y8r<0>), gy, dim3(sp->y8_threads), sp->shy8r, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, S, mode_spec, kpc * ch, kpc * (ch + 1));
+      else LAUNCH(c, (k_fft_y8r<0>), gy, dim3(sp->y8_threads), sp->shy8r, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, S, mode_spec, kpc * ch, kpc * (ch + 1));
     }
   } else {
   if (poisson && c->fuse_fillps_dti != 0. && sp->x8) {
@@ -1515,7 +1512,7 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
     else if (c->ykind == 3) LAUNCH(c, k_fft_y4<0>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
     else if (c->ykind == 4) LAUNCH(c, k_fft_y4<1>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
     else if (use8y && c->ykind) LAUNCH(c, (k_fft_y8<0, 1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
-    else if (use8y) { if (c->fl.fft_staged) LAUNCH(c, (k_fft_y8<0, 0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); else LAUNCH(c, (k_fft_y8r<0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8r, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, S, mode_spec); }
+    else if (use8y) LAUNCH(c, (k_fft_y8r<0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8r, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, S, mode_spec);
     else LAUNCH(c, k_fft_y<0>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
   }
   // pressure equation without a Dirichlet condition in z: the zero-eigenvalue mode (if x and y have one) is singular
@@ -1558,7 +1555,6 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
       { ProfScope ps(c, "fft_y_bwd");
         const dim3 gy((ncol + CB8 - 1) / CB8, (kpc + ykchunk_c - 1) / ykchunk_c);
         if (c->ykind) LAUNCH(c, (k_fft_y8<1, 1>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1));
-        else if (c->fl.fft_staged) LAUNCH(c, (k_fft_y8<1, 0>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1));
         else LAUNCH(c, (k_fft_y8r<1>), gy, dim3(sp->y8_threads), sp->shy8r, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, S, mode_spec, kpc * ch, kpc * (ch + 1)); }
       if (int e = exchange_chunk(1, ch)) return e;
     }
@@ -1575,7 +1571,7 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
     else if (c->ykind == 3) LAUNCH(c, k_fft_y4<0>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
     else if (c->ykind == 4) LAUNCH(c, k_fft_y4<1>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
     else if (use8y && c->ykind) LAUNCH(c, (k_fft_y8<1, 1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
-    else if (use8y) { if (c->fl.fft_staged) LAUNCH(c, (k_fft_y8<1, 0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); else LAUNCH(c, (k_fft_y8r<1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8r, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, S, mode_spec); }
+    else if (use8y) LAUNCH(c, (k_fft_y8r<1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8r, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, S, mode_spec);
     else LAUNCH(c, k_fft_y<1>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
   if (dist) { ProfScope ps(c, "alltoall"); if (c->comm.a2a(c->comm.user, 1, a2a_count)) { c->err = "alltoall callback failed"; return 1; } }
   { ProfScope ps(c, "fft_x_bwd");

@@ -47,7 +47,7 @@ SLAB_CASES = [("chan_smag_wm", (32, 24, 16), 2), ("chan_smag_wm", (32, 24, 16), 
                                        ("halfchan_imp1d", (16, 16, 12), 2), ("chan_smag", (64, 16, 8), 8),
                                        ("duct_smag_wm", (16, 24, 24), 2), ("duct_smag_wm_imp1d", (16, 24, 24), 2), ("cavity_nnn", (16, 24, 12), 4),
                                        # static Smagorinsky between y walls on more than two slabs (BASELINE configs[3] on 4 and 8 GPUs): van Driest with global rows and
-                                       # the shear planes of both y walls summed over the slabs; row-marching kernel, tile kernel (CALES_SMAG_TILE in the test below), k_smag
+                                       # the shear planes of both y walls summed over the slabs; row-marching kernel, k_smag
                                        ("duct_smag_wm", (16, 32, 24), 4), ("duct_smag_wm", (16, 64, 24), 8), ("duct_smag_wm_imp1d", (16, 32, 24), 4),
                                        ("duct_smag_wm_imp1d", (32, 64, 16), 8), ("duct_smag_wm", (16, 24, 24), 3), ("cavity_smag", (16, 24, 12), 4), ("cavity_smag", (16, 24, 12), 3),
                                        ("devchan_nd", (32, 24, 12), 3),
@@ -135,16 +135,13 @@ def test_slab_ranks_batched_scratch_field_exchange(name, ng, P, events, monkeypa
     if events:
         monkeypatch.setenv("CALES_LOOPBACK_EVENTS", "1")
     test_slab_ranks_match_single_rank(name, ng, P)
-    monkeypatch.setenv("CALES_DSMAG_STORE_UC", "CALES_DSMAG_UNPAIRED", "1")
+    monkeypatch.setenv("CALES_DSMAG_STORE_UC", "1")
     test_slab_ranks_match_single_rank(name, ng, P)
 
 
 @pytest.mark.parametrize("name,ng,P", [("duct_smag_wm", (16, 32, 24), 4), ("duct_smag_wm_imp1d", (64, 32, 16), 8)])
-def test_slab_ranks_smag_tile_and_reference_sequence(name, ng, P, monkeypatch):
-    """The two other forms of the static-Smagorinsky pass on more than two slabs between y walls: the LDS tile kernel and the kernel-per-loop sequence."""
-    monkeypatch.setenv("CALES_SMAG_TILE", "1")
-    test_slab_ranks_match_single_rank(name, ng, P)
-    monkeypatch.delenv("CALES_SMAG_TILE")
+def test_slab_ranks_smag_reference_sequence(name, ng, P, monkeypatch):
+    """The other form of the static-Smagorinsky pass on more than two slabs between y walls: the kernel-per-loop sequence."""
     monkeypatch.setenv("CALES_SMAG_REFERENCE_SEQUENCE", "1")
     test_slab_ranks_match_single_rank(name, ng, P)
 
@@ -155,8 +152,8 @@ def test_slab_ranks_with_switch_combinations(name, ng, P, seed, monkeypatch):
     """Several slabs with three to five run-time switches at once (fixed seeds; overlap on for every other one): same bar as the plain slab test."""
     rng = np.random.RandomState(2000 + seed)
     pool = ["CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFOLDED_CORREC", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_DSMAG_EAGER", "CALES_GAUSSEL_MARCH",
-            "CALES_DSMAG_XGHOSTS", "CALES_WIDE_OFFSETS", "CALES_DSMAG_UNFUSED_FILTER", "CALES_UNMERGED_BC", "CALES_FFT_STAGED", "CALES_DSMAG_STORE_UC",
-            "CALES_XGHOSTS_IN_STEP", "CALES_BAND_GRID", "CALES_SMAG_TILE", "CALES_FFT_GENERIC", "CALES_HELMHOLTZ_Z_PER_COLUMN", "CALES_UNFUSED_IMP_RHS"]
+            "CALES_DSMAG_XGHOSTS", "CALES_WIDE_OFFSETS", "CALES_DSMAG_UNFUSED_FILTER", "CALES_UNMERGED_BC", "CALES_DSMAG_STORE_UC",
+            "CALES_XGHOSTS_IN_STEP", "CALES_BAND_GRID", "CALES_FFT_GENERIC", "CALES_HELMHOLTZ_Z_PER_COLUMN", "CALES_UNFUSED_IMP_RHS"]
     for k in rng.choice(pool, size=rng.randint(3, 6), replace=False):
         monkeypatch.setenv(str(k), "1")
     if seed % 2:

@@ -173,20 +173,16 @@ SWITCH_CASES = [
     ({"CALES_DSMAG_XGHOSTS": "1"}, ["chan_dsmag", "chan_dsmag_wm", "tgv_dsmag_ppp", "duct_dsmag_wm"]),
     # k chunks of the marching tile kernels: forced length (with its three-plane prologues inside the field) and the block-count threshold
     ({"CALES_KCHUNK": "3"}, ["chan_dsmag", "chan_dsmag_wm", "chan_smag_wm", "duct_dsmag_wm", "duct_smag_wm_imp1d"]),
-    ({"CALES_KCHUNK": "5", "CALES_SMAG_TILE": "1"}, ["chan_smag_wm", "duct_smag_wm"]),
+    ({"CALES_KCHUNK": "5"}, ["chan_smag_wm", "duct_smag_wm"]),
     ({"CALES_TILE_MIN_BLOCKS": "1000000"}, ["chan_dsmag", "duct_smag_wm_imp1d"]),
     ({"CALES_TILE_MIN_BLOCKS": "1"}, ["chan_dsmag", "duct_smag_wm_imp1d"]),
     # dynamic model: K_AC stores the cell-centred velocity instead of the last pass forming it from u, v, w (ducts: the YW instantiations)
     ({"CALES_DSMAG_STORE_UC": "1"}, ["chan_dsmag", "chan_dsmag_wm", "tgv_dsmag_ppp", "duct_dsmag_wm", "duct_dsmag"]),
-    # the y transform with staging copies through LDS instead of the register-ended one (golden sizes are not powers of two: see also test_gpu_vs_oracle)
-    ({"CALES_FFT_STAGED": "1"}, ["chan_dsmag", "tgv_ppp"]),
     # dynamic model: |S|Sij as six scalar fields between K_AC and the last pass instead of three fields of pairs (the default where x and y are periodic)
     ({"CALES_DSMAG_UNPAIRED": "1"}, ["chan_dsmag", "chan_dsmag_wm", "tgv_dsmag_ppp", "chan_dsmag_p2"]),
     # dynamic model inside cales_step: the projection as a pass of its own (k_correc_cell) instead of inside the strain-rate pass (the default on one rank
     # with x and y periodic; chan_dsmag_p2 / tgv_dsmag_ppp at power-of-two rows take the folded form by default, see test_step_at_power_of_two_rows)
     ({"CALES_UNFOLDED_CORREC": "1"}, ["chan_dsmag", "chan_dsmag_p2", "tgv_dsmag_ppp"]),
-    # the LDS-tile form of the static Smagorinsky pass
-    ({"CALES_SMAG_TILE": "1"}, ["chan_smag", "chan_smag_wm", "duct_smag_wm"]),
 ]
 
 
@@ -198,7 +194,7 @@ def test_remaining_switches(envs, name, monkeypatch):
     for k, v in envs.items():
         monkeypatch.setenv(k, v)
     test_fused_step_matches_operator_sequence(name)
-    if "CALES_SMAG_TILE" in envs or "CALES_KCHUNK" in envs:
+    if "CALES_KCHUNK" in envs:
         test_startup_and_substeps(name)      # stage by stage at 1e-13 as well
 
 
@@ -216,13 +212,6 @@ def test_smag_reference_sequence(name, monkeypatch):
     """Static Smagorinsky through the kernel-per-loop sequence (the path ducts and cavities take)."""
     monkeypatch.setenv("CALES_SMAG_REFERENCE_SEQUENCE", "1")
     test_startup_and_substeps(name, general_sgs=True)
-
-
-@pytest.mark.parametrize("name", ["chan_smag", "chan_smag_wm", "duct_smag_wm", "duct_smag_wm_imp1d"])
-def test_smag_tile_form(name, monkeypatch):
-    """Static Smagorinsky through the LDS tile kernel (CALES_SMAG_TILE) instead of the default row-marching kernel: same planes at 1e-13."""
-    monkeypatch.setenv("CALES_SMAG_TILE", "1")
-    test_startup_and_substeps(name)
 
 
 @pytest.mark.parametrize("name", ["chan_dsmag", "chan_dsmag_wm", "tgv_dsmag_ppp", "duct_dsmag_wm", "duct_dsmag"])

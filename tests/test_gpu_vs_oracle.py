@@ -57,14 +57,6 @@ def test_poisson_solve_generic_transforms(name, ng, monkeypatch):
     test_poisson_solve(name, ng)
 
 
-@pytest.mark.parametrize("name,ng", [("chan_smag", (64, 128, 8)), ("tgv_ppp", (32, 32, 16)), ("chan_smag", (512, 64, 6)), ("chan_smag", (16, 256, 4)), ("halfchan_imp1d", (16, 1024, 4))])
-def test_poisson_solve_staged_y_transform(name, ng, monkeypatch):
-    """CALES_FFT_STAGED: the periodic y transform of power-of-two lines through k_fft_y8 (staging copies in LDS) instead of the register-ended
-    k_fft_y8r (the default, which test_poisson_solve covers at 64, 128, 256, 512 and 1024 points: radix 8-8, 2-8-8, 4-8-8, 8-8-8, 2-8-8-8)."""
-    monkeypatch.setenv("CALES_FFT_STAGED", "1")
-    test_poisson_solve(name, ng)
-
-
 @pytest.mark.parametrize("name,ng", [("chan_smag", (32, 16, 24)), ("cavity_nnn", (24, 20, 70)), ("halfchan_imp1d", (16, 16, 200)), ("cavity_nnn", (24, 20, 700))])
 def test_tridiagonal_paths_agree(name, ng, monkeypatch):
     """the in-LDS substructured sweep (default on one rank) against the marching Thomas sweep (CALES_GAUSSEL_MARCH)"""
@@ -143,8 +135,8 @@ def test_time_steps_with_x_ghosts_kept(name, ng, nsteps, monkeypatch):
 
 _BOOL_SWITCHES = ["CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFOLDED_CORREC", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_KEEP_LAST_RHS",
                   "CALES_DSMAG_EAGER", "CALES_GAUSSEL_MARCH", "CALES_DSMAG_XGHOSTS", "CALES_WIDE_OFFSETS",
-                  "CALES_DSMAG_UNFUSED_FILTER", "CALES_UNMERGED_BC", "CALES_FFT_STAGED", "CALES_DSMAG_STORE_UC", "CALES_DSMAG_UNPAIRED", "CALES_XGHOSTS_IN_STEP", "CALES_BAND_GRID",
-                  "CALES_PLAIN_GRID", "CALES_SMAG_TILE", "CALES_FFT_GENERIC", "CALES_HELMHOLTZ_Z_PER_COLUMN", "CALES_UNFUSED_IMP_RHS",
+                  "CALES_DSMAG_UNFUSED_FILTER", "CALES_UNMERGED_BC", "CALES_DSMAG_STORE_UC", "CALES_DSMAG_UNPAIRED", "CALES_XGHOSTS_IN_STEP", "CALES_BAND_GRID",
+                  "CALES_PLAIN_GRID", "CALES_FFT_GENERIC", "CALES_HELMHOLTZ_Z_PER_COLUMN", "CALES_UNFUSED_IMP_RHS",
                   "CALES_DSMAG_REFERENCE_SEQUENCE", "CALES_SMAG_REFERENCE_SEQUENCE"]
 
 
