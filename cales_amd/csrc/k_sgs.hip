@@ -516,7 +516,15 @@ constexpr int LMF_KMAX = 256;      // longest k chunk (block sums of a chunk in 
 template <typename OFF, int YW, int UCF, int PAIR = 0>      // YW = 1: walls or wall-model faces in y (ducts); 0: the channel instantiation carries none of that logic
 __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) {
   const LijMijArgs &A = B.L;
-  __shared__ real sh[2][9][TYL + 2][64];
+  // FUC (no walls in y): the test-filtered CELL-CENTRED velocity is not filtered here -- the filter is linear and shift-invariant, so F(u_c) =
+  // F((u(i) + u(i-1))/2) = (u_f(i) + u_f(i-1))/2, and the filtered face velocity u_f (K_AC's output) is in this pass's LDS ring anyway for the strain rate
+  // of the filtered field; likewise v_f along y and w_f along z. Three of the nine quantities leave the z/x/y filter (a third of its LDS traffic, 12 %
+  // of the pass's vector instructions). The identity holds wherever the two filters treat the walls alike: everywhere for the tangential components
+  // (K_AC extrapolates u, v through a z wall exactly as the wall rule Q(0) = 2Q(1) - Q(2) does), not for w in the two planes next to a z wall, where the
+  // reference extrapolates the cell-centred w_c (sgs.f90:751-766) and the face values are what they are: those planes keep the filter of w_c (slot 0).
+  constexpr bool FUC = !YW;
+  constexpr int NSH = FUC ? 7 : 9, Q0 = FUC ? 3 : 0;      // filtered through LDS: the six products (+ w_c at wall planes, slot 0), or all nine
+  __shared__ real sh[2][NSH][TYL + 2][64];
   __shared__ real ring[4][3][TYL + 2][64];
   // plane sums: every working wave adds its lanes in fours (two DPP steps) and leaves sixteen partial sums per quantity; the first halo wave, idle
   // behind the barrier, adds the 128 partials of the previous plane (the full six-step wave sum ran in all ten waves before: 24 vector instructions
@@ -629,11 +637,12 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
     uiuj(sc, qc);
     if (!LO && !HI) { uiuj(sm, qm); uiuj(sp, qp); }
 #pragma unroll
-    for (int q = 0; q < 9; ++q) {
+    for (int q = Q0; q < 9; ++q) {
       const real G = (LO || HI) ? 4. * qc[q] : qm[q] + 2. * qc[q] + qp[q];
       r[q] = lane_prev(G) + 2. * G + lane_next(G);
-      sh[buf][q][ty][tx] = r[q];
+      sh[buf][q - Q0 + (FUC ? 1 : 0)][ty][tx] = r[q];
     }
+    if (FUC && (LO || HI)) { const real G = 4. * qc[2]; r[2] = lane_prev(G) + 2. * G + lane_next(G); sh[buf][0][ty][tx] = r[2]; }      // w_c next to a z wall
     __syncthreads();
     if (k > kbeg && ty == 0) fold(k - 1, buf ^ 1);
     // plane k+1 of |S|Sij: its 18 loads were issued at the end of the previous plane and are folded into six values here, before
@@ -643,9 +652,14 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
     if (outok) {
       real F[9];
 #pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        const real dn = sh[buf][q][ty - 1][tx], up = sh[buf][q][ty + 1][tx];
+      for (int q = Q0; q < 9; ++q) {
+        const real dn = sh[buf][q - Q0 + (FUC ? 1 : 0)][ty - 1][tx], up = sh[buf][q - Q0 + (FUC ? 1 : 0)][ty + 1][tx];
         F[q] = ((ylo ? 2. * r[q] - up : dn) + 2. * r[q] + (yhi ? 2. * r[q] - dn : up)) / 64.;
+      }
+      if (FUC) {
+        F[0] = .5 * (ring[kc][0][ty][tx] + ring[kc][0][ty][tx - 1]); F[1] = .5 * (ring[kc][1][ty][tx] + ring[kc][1][ty - 1][tx]);
+        if (LO || HI) F[2] = (sh[buf][0][ty - 1][tx] + 2. * r[2] + sh[buf][0][ty + 1][tx]) / 64.;
+        else F[2] = .5 * (ring[kc][2][ty][tx] + ring[km][2][ty][tx]);
       }
       const real l0 = F[3] - F[0] * F[0], l1 = F[4] - F[1] * F[1], l2 = F[5] - F[2] * F[2], l3 = F[6] - F[0] * F[1],
                    l4 = F[7] - F[0] * F[2], l5 = F[8] - F[1] * F[2];
