@@ -499,6 +499,10 @@ __global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijA
 #ifndef TYL
 #define TYL 8
 #endif
+#ifndef TYLF
+#define TYLF 8      // tile height of the instantiations without y walls (their LDS leaves room for twelve rows: six filtered quantities instead of nine)
+#endif
+#define LMF_TY(YW) ((YW) ? TYL : TYLF)
 struct LmfArgs { LijMijArgs L; const real *ss[6]; const real2 *ss2[3]; int by0; BandMap bm; int gx; };      // ss2: |S|Sij as three fields of pairs (PAIR = 1), ss: six fields      // bm: block map of this launch (bm.gx = 0: plain 3-D grid); gx: x tiles of the whole field      // by0: first y tile of this launch (interior and edge tiles of a slab are launched apart)
 // Every global access of the plane loop is UNCONDITIONAL (out-of-range lanes, rows and planes are clamped onto valid cells whose values are
 // never used): a load inside a divergent branch makes the compiler wait with s_waitcnt vmcnt(0) at the next use of ANY loaded value -- it
@@ -514,8 +518,9 @@ constexpr int LMF_KMAX = 256;      // longest k chunk (block sums of a chunk in 
 // PAIR = 1: K_AC stored |S|Sij as three fields of PAIRS (S11,S22), (S33,S12), (S13,S23) per cell: nine 16-byte loads per plane instead of eighteen
 // 8-byte ones. The pass is bound by what its ten waves issue, not by bytes: 3.95 -> 3.45 ms at 512^3 (K_AC's paired stores cost 0.28 of the 0.5 back).
 template <typename OFF, int YW, int UCF, int PAIR = 0>      // YW = 1: walls or wall-model faces in y (ducts); 0: the channel instantiation carries none of that logic
-__global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) {
+__global__ __launch_bounds__(64 * (LMF_TY(YW) + 2)) void k_lmf_tile(Geom g, LmfArgs B) {
   const LijMijArgs &A = B.L;
+  constexpr int TL = LMF_TY(YW);      // tile height
   // FUC (no walls in y): the test-filtered CELL-CENTRED velocity is not filtered here -- the filter is linear and shift-invariant, so F(u_c) =
   // F((u(i) + u(i-1))/2) = (u_f(i) + u_f(i-1))/2, and the filtered face velocity u_f (K_AC's output) is in this pass's LDS ring anyway for the strain rate
   // of the filtered field; likewise v_f along y and w_f along z. Three of the nine quantities leave the z/x/y filter (a third of its LDS traffic, 12 %
@@ -523,27 +528,28 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
   // (K_AC extrapolates u, v through a z wall exactly as the wall rule Q(0) = 2Q(1) - Q(2) does), not for w in the two planes next to a z wall, where the
   // reference extrapolates the cell-centred w_c (sgs.f90:751-766) and the face values are what they are: those planes keep the filter of w_c (slot 0).
   constexpr bool FUC = !YW;
-  constexpr int NSH = FUC ? 7 : 9, Q0 = FUC ? 3 : 0;      // filtered through LDS: the six products (+ w_c at wall planes, slot 0), or all nine
-  __shared__ real sh[2][NSH][TYL + 2][64];
-  __shared__ real ring[4][3][TYL + 2][64];
+  constexpr int NSH = FUC ? 6 : 9, Q0 = FUC ? 3 : 0;      // filtered through LDS: the six products, or all nine
+  __shared__ real sh[2][NSH][TL + 2][64];
+  __shared__ real shw[FUC ? TL + 2 : 1][64];      // FUC: w_c in the plane next to a z wall (one buffer: the two wall planes are never consecutive, n3 >= 3)
+  __shared__ real ring[4][3][TL + 2][64];
   // plane sums: every working wave adds its lanes in fours (two DPP steps) and leaves sixteen partial sums per quantity; the first halo wave, idle
   // behind the barrier, adds the 128 partials of the previous plane (the full six-step wave sum ran in all ten waves before: 24 vector instructions
   // per plane and wave less in a pass that is bound by them)
-  __shared__ real psum[2][2][TYL][16];
+  __shared__ real psum[2][2][TL][16];
   __shared__ real bsum[2][LMF_KMAX];
   const int tx = threadIdx.x, ty = threadIdx.y;
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   if (B.bm.gx && !band_block(B.bm, bx, by, bz)) return;
   by += B.by0;
-  const int i = bx * 62 + tx, j = by * TYL + ty;
+  const int i = bx * 62 + tx, j = by * TL + ty;
   const int kbeg = bz * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
-  const bool outok = tx >= 1 && tx <= 62 && ty >= 1 && ty <= TYL && i <= g.n1 && j <= g.n2;
+  const bool outok = tx >= 1 && tx <= 62 && ty >= 1 && ty <= TL && i <= g.n1 && j <= g.n2;
   const int iw = A.perx ? (i == 0 ? g.n1 : (i == g.n1 + 1 ? 1 : i)) : i;
   const int ic = min(iw, g.n1 + 1), jc = min(j, g.n2 + 1);      // clamped: lanes / rows beyond the field read its last ghost column / row
   const OFF c0 = (OFF)g.ix(ic, jc, 0) * RSZ, sk = (OFF)g.s12 * RSZ, sj = (OFF)g.s1 * RSZ;      // byte offsets
   // rows whose |S|Sij this thread combines: its own and the two beside it; the two halo waves (and rows beyond n2) take a row of the tile
   // interior instead (cache hits, results unused)
-  const int jo = max(by * TYL + 1, min(min(j, by * TYL + TYL), g.n2));
+  const int jo = max(by * TL + 1, min(min(j, by * TL + TL), g.n2));
   const OFF c0s = (OFF)g.ix(ic, jo, 0) * RSZ;
   real sm[3], sc[3], sp[3], sn[3], fn[3];
   // ghost rows of u_f and w_f at wall-model y faces: 2 Q(1) - Q(2) along y (extrapolate(...,lwm) after bounduvw, sgs.f90:683-748); v_f keeps its own.
@@ -616,8 +622,11 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
   const int blk = by * B.gx + bx;
   auto fold = [&](int k, int b) {      // block sums of plane k by ONE whole wave, fixed order
     const real *p0 = &psum[b][0][0][0], *p1 = &psum[b][1][0][0];
-    static_assert(TYL * 16 == 128, "two partials per lane");
-    const real a = wave_sum_lane63(p0[tx] + p0[tx + 64]), bs = wave_sum_lane63(p1[tx] + p1[tx + 64]);
+    static_assert(TL * 16 >= 128 && TL * 16 <= 192, "two or three partials per lane");
+    constexpr int NP3 = TL * 16 - 128;      // partials beyond the first 128
+    const int t3 = min(tx, NP3 > 0 ? NP3 - 1 : 0) + 128; const real w3 = (NP3 > 0 && tx < NP3) ? 1. : 0.;
+    const real a = wave_sum_lane63(NP3 > 0 ? p0[tx] + p0[tx + 64] + w3 * p0[t3] : p0[tx] + p0[tx + 64]),
+               bs = wave_sum_lane63(NP3 > 0 ? p1[tx] + p1[tx + 64] + w3 * p1[t3] : p1[tx] + p1[tx + 64]);
     if (tx == 63) { bsum[0][k - kbeg] = a; bsum[1][k - kbeg] = bs; }
   };
   // grid coefficients of the plane, one plane ahead through the scalar cache (uniform: scalar registers)
@@ -640,9 +649,9 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
     for (int q = Q0; q < 9; ++q) {
       const real G = (LO || HI) ? 4. * qc[q] : qm[q] + 2. * qc[q] + qp[q];
       r[q] = lane_prev(G) + 2. * G + lane_next(G);
-      sh[buf][q - Q0 + (FUC ? 1 : 0)][ty][tx] = r[q];
+      sh[buf][q - Q0][ty][tx] = r[q];
     }
-    if (FUC && (LO || HI)) { const real G = 4. * qc[2]; r[2] = lane_prev(G) + 2. * G + lane_next(G); sh[buf][0][ty][tx] = r[2]; }      // w_c next to a z wall
+    if (FUC && (LO || HI)) { const real G = 4. * qc[2]; r[2] = lane_prev(G) + 2. * G + lane_next(G); shw[ty][tx] = r[2]; }      // w_c next to a z wall
     __syncthreads();
     if (k > kbeg && ty == 0) fold(k - 1, buf ^ 1);
     // plane k+1 of |S|Sij: its 18 loads were issued at the end of the previous plane and are folded into six values here, before
@@ -653,12 +662,12 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
       real F[9];
 #pragma unroll
       for (int q = Q0; q < 9; ++q) {
-        const real dn = sh[buf][q - Q0 + (FUC ? 1 : 0)][ty - 1][tx], up = sh[buf][q - Q0 + (FUC ? 1 : 0)][ty + 1][tx];
+        const real dn = sh[buf][q - Q0][ty - 1][tx], up = sh[buf][q - Q0][ty + 1][tx];
         F[q] = ((ylo ? 2. * r[q] - up : dn) + 2. * r[q] + (yhi ? 2. * r[q] - dn : up)) / 64.;
       }
       if (FUC) {
         F[0] = .5 * (ring[kc][0][ty][tx] + ring[kc][0][ty][tx - 1]); F[1] = .5 * (ring[kc][1][ty][tx] + ring[kc][1][ty - 1][tx]);
-        if (LO || HI) F[2] = (sh[buf][0][ty - 1][tx] + 2. * r[2] + sh[buf][0][ty + 1][tx]) / 64.;
+        if (LO || HI) F[2] = (shw[ty - 1][tx] + 2. * r[2] + shw[ty + 1][tx]) / 64.;
         else F[2] = .5 * (ring[kc][2][ty][tx] + ring[km][2][ty][tx]);
       }
       const real l0 = F[3] - F[0] * F[0], l1 = F[4] - F[1] * F[1], l2 = F[5] - F[2] * F[2], l3 = F[6] - F[0] * F[1],
@@ -702,7 +711,7 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
     }
     ssload(min(k + 2, g.n3 + 1), rw);
     lm += dpp_f64<0x111>(lm); lm += dpp_f64<0x112>(lm); mm += dpp_f64<0x111>(mm); mm += dpp_f64<0x112>(mm);      // row_shr 1, 2: lanes 3, 7, 11, ... hold four lanes' sum
-    if ((tx & 3) == 3 && ty >= 1 && ty <= TYL) { psum[buf][0][ty - 1][tx >> 2] = lm; psum[buf][1][ty - 1][tx >> 2] = mm; }
+    if ((tx & 3) == 3 && ty >= 1 && ty <= TL) { psum[buf][0][ty - 1][tx >> 2] = lm; psum[buf][1][ty - 1][tx >> 2] = mm; }
 #pragma unroll
     for (int q = 0; q < 3; ++q) { sm[q] = sc[q]; sc[q] = sp[q]; sp[q] = sn[q]; }
 #pragma unroll
@@ -721,7 +730,7 @@ __global__ __launch_bounds__(64 * (TYL + 2)) void k_lmf_tile(Geom g, LmfArgs B) 
   if (ty == 0 && kend >= kbeg) fold(kend, kend & 1);
   __syncthreads();
   // the chunk's block sums leave in one go
-  for (int q = ty * 64 + tx; q < 2 * (kend - kbeg + 1); q += 64 * (TYL + 2)) {
+  for (int q = ty * 64 + tx; q < 2 * (kend - kbeg + 1); q += 64 * (TL + 2)) {
     const int w = q & 1, kk = q >> 1;
     A.part[(size_t)(w * g.n3 + kbeg + kk - 1) * A.nblk + blk] = bsum[w][kk];
   }
@@ -1140,14 +1149,14 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_corr_strain_tile(Geom g, Stra
 // cell in between (0.26 of the HBM peak); here waves never wait for each other and the VGPR count alone sets the occupancy.
 // (sgs.f90:98-152, 598-680)
 constexpr int SROWS = 4;      // rows (waves) per block
-template <typename OFF, int YW>
-// (four waves per SIMD -- 128 VGPRs -- for channels; the duct logic needs a few registers more and would spill under that cap)
-__global__ __launch_bounds__(64 * SROWS, (YW ? 3 : 4)) void k_smag_rows(Geom g, StrainTileArgs A) {
+// EX = 1: the block holds a row next to a wall-model y face (block-uniform: the other blocks of a duct run the loads of the channel form).
+// Every global access of the plane loop is straight-line code ("In-order counters"): the extrapolated ghost row is c1 Q(o1) - c2 Q(o2)
+// with per-thread offsets and weights instead of a branch around two loads, the shear of the nearer y wall is loaded for every plane whether the
+// nearest wall turns out to be that one or a z wall -- the branches of the first version made each of the plane's loads a round trip of its own
+// (0.50 ms per call for the 512 x 256 x 256 duct against 0.37 ms now).
+template <typename OFF, int YW, int EX>
+__device__ __forceinline__ void smag_rows_body(const Geom &g, const StrainTileArgs &A, const int bx, const int by, const int bz) {
   const int tx = threadIdx.x;
-  // band map (common.hpp): the rows two waves both load (j-1, j+1, the shared columns of neighbouring x tiles) meet in one L2 instead of
-  // being fetched from memory by two (measured 1.8 x the compulsory reads with the plain 3-D grid, 1.27 x with the bands)
-  int bx, by, bz;
-  if (!band_block(A.bm, bx, by, bz)) return;
   const int i = bx * 62 + tx, j = by * SROWS + threadIdx.y + 1;
   if (j > g.n2) return;
   const int kbeg = bz * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
@@ -1156,13 +1165,15 @@ __global__ __launch_bounds__(64 * SROWS, (YW ? 3 : 4)) void k_smag_rows(Geom g, 
   const int iw = !A.perx ? i : i == 0 ? g.n1 : i == g.n1 + 1 ? 1 : i;      // periodic x: wrapped columns instead of the ghost columns
   const OFF c0 = ldok ? (OFF)g.ix(iw, j, 0) * RSZ : (OFF)g.ix(1, j, 0) * RSZ;
   // ghost rows at wall-model y faces: u and w are replaced by 2 Q(1) - Q(2) along y; v, normal to the face, is not (extrapolate(...,lwm), sgs.f90:683-748)
-  const bool exlo = YW && A.wmylo && j == 1, exhi = YW && A.wmyhi && j == g.n2;
+  const bool exlo = EX && A.wmylo && j == 1, exhi = EX && A.wmyhi && j == g.n2;
   // (lanes beyond the row read cell 0 of the field and planes beyond n3+1 are clamped: every load is unconditional, nothing branches around it)
+  const OFF a1 = exlo ? c0 : c0 - sj, a2 = exlo ? c0 + sj : c0 - sj, b1 = exhi ? c0 : c0 + sj, b2 = exhi ? c0 - sj : c0 + sj;      // rows j-1 (a) and j+1 (b)
+  const real ac1 = exlo ? 2. : 1., ac2 = exlo ? 1. : 0., bc1 = exhi ? 2. : 1., bc2 = exhi ? 1. : 0.;
   auto ldu = [&](int q, int dj, int k) -> real {      // q = 0 (u) or 2 (w), dj = -1, 0, +1
-    const OFF o = c0 + (OFF)k * sk;
-    if (YW && dj < 0 && exlo) return 2. * ldb(A.u[q], o) - ldb(A.u[q], o + sj);
-    if (YW && dj > 0 && exhi) return 2. * ldb(A.u[q], o) - ldb(A.u[q], o - sj);
-    return ldb(A.u[q], dj < 0 ? o - sj : dj > 0 ? o + sj : o);
+    const OFF o = (OFF)k * sk;
+    if (EX && dj < 0) return ac1 * ldb(A.u[q], a1 + o) - ac2 * ldb(A.u[q], a2 + o);
+    if (EX && dj > 0) return bc1 * ldb(A.u[q], b1 + o) - bc2 * ldb(A.u[q], b2 + o);
+    return ldb(A.u[q], dj < 0 ? c0 + o - sj : dj > 0 ? c0 + o + sj : c0 + o);
   };
   auto ldv = [&](int dj, int k) -> real { return ldb(A.u[1], c0 + (OFF)k * sk - (dj < 0 ? sj : 0)); };
   // planes k-1, k, k+1 of u(j), v(j-1), v(j); plane k of u(j-1), u(j+1); planes k-1, k of w(j-1), w(j), w(j+1)
@@ -1191,9 +1202,17 @@ __global__ __launch_bounds__(64 * SROWS, (YW ? 3 : 4)) void k_smag_rows(Geom g, 
     }
   }
   const real dxi = A.dxi, dyi = A.dyi;
+  // van Driest with y walls: the nearer y wall of this row (the first one wins a tie) is known before the loop; its shear plane is read for every k
+  const int jg = j + g.jlo;
+  real dminy = YW && A.wylo ? A.dl2 * (jg - 0.5) : CALES_BIG; int locy = 2;
+  { const real d = YW && A.wyhi ? A.dl2 * (g.ng2 - jg + 0.5) : CALES_BIG; if (d < dminy) { dminy = d; locy = 3; } }
+  const real *twp = (YW && A.twy) ? A.twy + (size_t)(locy == 3 ? g.n3 + 2 : 0) * g.s1 + (ldok ? i : 1) : A.del;
+  const int tws = (YW && A.twy) ? g.s1 : 0;
+  real twyc = YW ? twp[(size_t)kbeg * tws] : 0.;
   for (int k = kbeg; k <= kend; ++k) {
     // next iteration's planes, in flight during this one's arithmetic
     const int k2 = min(k + 2, g.n3 + 1), k1 = k + 1;
+    const real twyn = YW ? twp[(size_t)k1 * tws] : 0.;
     const real u0n = ldu(0, 0, k2), vAn = ldv(-1, k2), vCn = ldv(0, k2);
     const real uAn = ldu(0, -1, k1), uBn = ldu(0, 1, k1);
     const real wAn = ldu(2, -1, k1), wCn = ldu(2, 0, k1), wBn = ldu(2, 1, k1);
@@ -1218,14 +1237,10 @@ __global__ __launch_bounds__(64 * SROWS, (YW ? 3 : 4)) void k_smag_rows(Geom g, 
     if (outok) {
       real fd = 1.;
       if (A.zlo || A.zhi || (YW && (A.wylo || A.wyhi))) {     // nearest wall in the order y-, y+, z-, z+: the first one wins a tie (minloc, sgs.f90:116)
-        const int jg = j + g.jlo;
-        real dmin = YW && A.wylo ? A.dl2 * (jg - 0.5) : CALES_BIG, tw = 0.; int loc = 2;
-        { const real d = YW && A.wyhi ? A.dl2 * (g.ng2 - jg + 0.5) : CALES_BIG; if (d < dmin) { dmin = d; loc = 3; } }
+        real dmin = dminy; int loc = locy;
         { const real d = A.zlo ? ldc(A.zc, k) : CALES_BIG; if (d < dmin) { dmin = d; loc = 4; } }
         { const real d = A.zhi ? A.l3 - ldc(A.zc, k) : CALES_BIG; if (d < dmin) { dmin = d; loc = 5; } }
-        if (YW && loc == 2) tw = A.twy[(size_t)k * g.s1 + i];
-        else if (YW && loc == 3) tw = A.twy[(size_t)(g.n3 + 2 + k) * g.s1 + i];
-        else tw = loc == 4 ? tw_lo : tw_hi;
+        const real tw = loc < 4 ? twyc : loc == 4 ? tw_lo : tw_hi;
         const real dw_plus = dmin * tw * (1. / A.visc);
         fd = 1. - exp(-dw_plus / 25.);
       }
@@ -1234,7 +1249,18 @@ __global__ __launch_bounds__(64 * SROWS, (YW ? 3 : 4)) void k_smag_rows(Geom g, 
     }
     u0m = u0c; u0c = u0p; u0p = u0n; vAm = vAc; vAc = vAp; vAp = vAn; vCm = vCc; vCc = vCp; vCp = vCn;
     uA = uAn; uB = uBn; wAm = wAc; wCm = wCc; wBm = wBc; wAc = wAn; wCc = wCn; wBc = wBn;
+    twyc = twyn;
   }
+}
+template <typename OFF, int YW>
+// (four waves per SIMD -- 128 VGPRs -- for channels; the duct logic needs a few registers more and would spill under that cap)
+__global__ __launch_bounds__(64 * SROWS, (YW ? 3 : 4)) void k_smag_rows(Geom g, StrainTileArgs A) {
+  // band map (common.hpp): the rows two waves both load (j-1, j+1, the shared columns of neighbouring x tiles) meet in one L2 instead of
+  // being fetched from memory by two (measured 1.8 x the compulsory reads with the plain 3-D grid, 1.27 x with the bands)
+  int bx, by, bz;
+  if (!band_block(A.bm, bx, by, bz)) return;
+  if (YW && ((A.wmylo && by == 0) || (A.wmyhi && (by + 1) * SROWS >= g.n2))) smag_rows_body<OFF, YW, 1>(g, A, bx, by, bz);
+  else smag_rows_body<OFF, YW, 0>(g, A, bx, by, bz);
 }
 // p1d[which*n3 + k-1] = sum over the blocks' partials, fixed order (ave1d_channel, sgs.f90:462-472)
 __global__ __launch_bounds__(256) void k_plane_fold(int n3, int nblk, const real *__restrict__ part, real *__restrict__ p1d) {
@@ -1366,7 +1392,8 @@ static int dsmag_fast(cales_ctx *c) {
   const bool overlap = c->P > 1 && c->comm.halo_s && c->comm_stream && !c->fl.dsmag_unfused_filter;
   // (every check that can fail comes BEFORE the deferred exchange is queued: an error return behind halo_flush_deferred would leave the
   //  exchange in flight on the second stream with nobody joining it)
-  { dim3 tb, tg; int tk; tiles(c->fl.dsmag_unfused_filter ? TYF : TYL, 62, tb, tg, tk);
+  const int lmf_ty = (wylo || wyhi || wmylo || wmyhi) ? TYL : TYLF;      // tile height of the fused last pass (k_lmf_tile<.., YW>)
+  { dim3 tb, tg; int tk; tiles(c->fl.dsmag_unfused_filter ? TYF : lmf_ty, 62, tb, tg, tk);
     if ((size_t)2 * n[2] * tg.x * tg.y > c->ntot) { c->err = "dsmag: partial-sum scratch too small"; return 1; } }
   // several ranks: ONE exchange for the y-halo rows of all these fields (six |S|Sij, three filtered velocities, v_c, and |S| itself in the lazy form
   // inside cales_step) instead of one per ghost-cell call; their ghost-cell kernels run first, the rows that then arrive carry the neighbour's
@@ -1396,7 +1423,7 @@ static int dsmag_fast(cales_ctx *c) {
   if (!c->fl.dsmag_unfused_filter) {
     // K_B + K_DF in one pass: filter(|S|Sij) on the fly, strain rate of the filtered velocity, Mij, Lij, contractions, plane partial sums
     ProfScope ps(c, "lij_mij_filter_contract");
-    tiles(TYL, 62, mb, mg, kch);
+    tiles(lmf_ty, 62, mb, mg, kch);
     while (kch > LMF_KMAX) { kch = (kch + 1) / 2; mg.z = (n[2] + kch - 1) / kch; }      // the kernel keeps a chunk's block sums in LDS
     L.kchunk = kch; L.nblk = mg.x * mg.y;
     LmfArgs B; B.L = L; for (int m = 0; m < 6; ++m) B.ss[m] = ssij[m];
@@ -1414,7 +1441,7 @@ static int dsmag_fast(cales_ctx *c) {
     };
     if (overlap) {
       // tiles that read the ghost rows j = 0 or j = n2+1 wait for the rows in flight; the others run beside the exchange
-      int hi0 = (int)mg.y; while (hi0 > 1 && (hi0 - 1) * TYL + TYL + 1 >= n[1] + 1) --hi0;      // first tile (> 0) that reaches row n2+1
+      int hi0 = (int)mg.y; while (hi0 > 1 && (hi0 - 1) * lmf_ty + lmf_ty + 1 >= n[1] + 1) --hi0;      // first tile (> 0) that reaches row n2+1
       launch(1, hi0 - 1);
       if (int e = stream_after(c, c->stream, c->comm_stream)) return e;
       launch(0, 1); launch(hi0, (int)mg.y - hi0);
