@@ -365,7 +365,7 @@ static int step_body(cales_ctx *c, real dt) {
   static const real rk[3][2] = {{32. / 60., 0.}, {25. / 60., -17. / 60.}, {45. / 60., -25. / 60.}};
   LAUNCH(c, k_zero6, dim3(1), dim3(64), 0, c->stream, c->d_force);     // dpdl(:) = 0
   c->in_step = true;
-  struct Reset { cales_ctx *c; ~Reset() { c->in_step = false; c->step_xskip = false; c->bc_nride = 0; c->fold_dtrk = 0.; c->defer_force = false; c->defer_imp_rhs = false; c->fuse_fillps_dti = 0.; c->fuse_mean_mask = 0; } } reset{c};      // also on the error returns
+  struct Reset { cales_ctx *c; ~Reset() { c->in_step = false; c->step_xskip = false; c->bc_nride = 0; c->fold_dtrk = 0.; c->fold_mom_dtrk = 0.; c->bc_view_dtrk = 0.; c->defer_force = false; c->defer_imp_rhs = false; c->fuse_fillps_dti = 0.; c->fuse_mean_mask = 0; } } reset{c};      // also on the error returns
   // periodic x, explicit diffusion, no wall model, the fused passes everywhere: every kernel of the step wraps around instead of reading x ghost
   // columns, which are then left alone until the step returns (common.hpp, step_xskip)
   { bool ok = !c->fl.xghosts_in_step && CBP(c, 0, 1) == 'P' && CBP(c, 1, 1) == 'P' && c->C.impdiff == 0 && !c->fl.unfused_rk && !c->fl.unfused_correc &&
@@ -384,6 +384,19 @@ static int step_body(cales_ctx *c, real dt) {
     fold_correc = fold_correc && (perz || walls);
     // several slabs: the pass reaches the companion field of pp with 32-bit offsets (two fields under 4 GB), exchanges through the slab hooks
     if (c->P > 1) fold_correc = fold_correc && c->comm.on && 2 * (c->ntot + 2 * LINE_REALS) * sizeof(real) < (1ull << 32); }
+  // no subgrid model, explicit diffusion, no wall model, every direction periodic or between no-slip walls with homogeneous Neumann
+  // pressure (Taylor-Green, channels, cavities without a model): the projection and pressure update of substeps 1 and 2 are applied by the momentum
+  // pass of the NEXT substep while it loads its planes (k_momrk<.., CORR = 1>) -- between the two the fields hold the prediction, whose ghost cells
+  // receive the projected values through the corrected view of the ghost-cell kernels. The correction pass (9 words per cell) runs once per step
+  // instead of three times; substep 3 keeps it so that the step returns the projected fields.
+  bool fold_mom = !c->fl.unfolded_mom && !fold_correc && c->C.sgstype == 0 && c->visct_zero && !c->sgs_first && c->C.impdiff == 0 && (c->P == 1 || c->comm.on) && c->n[2] >= 3 &&
+                  !c->fl.unfused_rk && !c->fl.unfused_correc;
+  for (int q = 0; q < 6; ++q) fold_mom = fold_mom && c->C.lwm[q] == 0;
+  for (int d = 1; d <= 3 && fold_mom; ++d) {
+    bool per = CBP(c, 0, d) == 'P' && CBP(c, 1, d) == 'P', walls = CBP(c, 0, d) == 'N' && CBP(c, 1, d) == 'N' && c->C.bcpre[2 * (d - 1)] == 0. && c->C.bcpre[2 * (d - 1) + 1] == 0.;
+    for (int iv = 1; iv <= 3; ++iv) for (int sd = 0; sd <= 1; ++sd) { per = per && CBV(c, sd, d, iv) == 'P'; walls = walls && CBV(c, sd, d, iv) == 'D'; }
+    fold_mom = per || walls;
+  }
   for (int irk = 1; irk <= 3; ++irk) {
     const real dtrk = (rk[irk - 1][0] + rk[irk - 1][1]) * dt, dtrki = 1. / dtrk;
     real alpha = 0.;
@@ -405,6 +418,7 @@ static int step_body(cales_ctx *c, real dt) {
     c->fuse_mean_mask = (fuse_fill && c->defer_force && !c->fl.unfused_mean)
                             ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;
     c->skip_rhs_store = irk == 3 && !c->fl.keep_last_rhs;
+    const bool p_ghosts_due = c->fold_mom_dtrk != 0.;      // the momentum pass below stores p + pp of the interior cells: its ghost cells ride along with those of the prediction
     { const int e = op_rk(c, irk, dt); c->skip_rhs_store = false; if (e) return e; }
     if (int e = op_bulk_forcing(c)) { c->defer_imp_rhs = false; return e; }
     if (c->C.impdiff == 2) {
@@ -415,7 +429,11 @@ static int step_body(cales_ctx *c, real dt) {
       alpha = -.5 * c->visc * dtrk;
       for (int iv = 1; iv <= 3; ++iv) if (int e = op_helmholtz(c, iv, alpha)) return e;
     }
-    if (int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 0, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W])) return e;
+    if (p_ghosts_due && !c->fl.unmerged_bc) { c->bc_nride = 1; c->bc_ride[0] = c->f[CALES_P]; c->bc_ride_which[0] = 0; }
+    { const int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 0, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W]);
+      const bool rode = p_ghosts_due && !c->fl.unmerged_bc && c->bc_nride == 0; c->bc_nride = 0;
+      if (e) return e;
+      if (p_ghosts_due && !rode) { if (int e2 = op_boundp(c, c->f[CALES_P], 0)) return e2; } }
     if (fuse_fill) c->fuse_fillps_dti = dtrki;
     else { if (int e = op_fillps(c, dtrki)) return e; if (int e = op_updt_rhs_b(c)) return e; }
     { const int e = op_solver(c); c->fuse_fillps_dti = 0.; if (e) return e; }
@@ -428,7 +446,16 @@ static int step_body(cales_ctx *c, real dt) {
     } else
     if (int e = op_boundp(c, c->f[CALES_PP], 0)) return e;
     if (fold_correc) c->fold_dtrk = dtrk;      // correc, bounduvw, updatep, boundp(p): inside the cmpt_sgs below (dsmag_fast)
-    else {
+    else if (fold_mom && irk < 3) {
+      // the ghost cells of the projected velocity now (through the corrected view), its interior cells and p + pp in the next substep's momentum pass
+      c->fold_mom_fmask = c->defer_force ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;
+      c->defer_force = false;
+      c->bc_view_dtrk = dtrk;
+      const int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 1, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W]);
+      c->bc_view_dtrk = 0.;
+      if (e) return e;
+      c->fold_mom_dtrk = dtrk;
+    } else {
     { const int e = fuse_cu ? op_correc_updatep(c, dtrk, alpha, 1) : op_correc(c, dtrk); c->defer_force = false; if (e) return e; }
     // the pressure is final once the fused correction has run: its ghost cells ride along with those of the velocity (one launch, one slab exchange)
     if (fuse_cu && !c->fl.unmerged_bc) { c->bc_nride = 1; c->bc_ride[0] = c->f[CALES_P]; c->bc_ride_which[0] = 0; }

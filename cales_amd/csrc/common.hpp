@@ -68,11 +68,12 @@ struct Spec {
 
 // Run-time switches: read from the environment ONCE, by cales_create; the launch path only looks at these fields.
 struct Flags {
-  bool unfolded_correc = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_eager = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, unfused_rk = false, dsmag_unfused_filter = false, overlap = false, dsmag_store_uc = false, dsmag_unpaired = false, xghosts_in_step = false, unmerged_bc = false, plain_grid = false, band_grid = false;
+  bool unfolded_correc = false, unfolded_mom = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_eager = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, unfused_rk = false, dsmag_unfused_filter = false, overlap = false, dsmag_store_uc = false, dsmag_unpaired = false, xghosts_in_step = false, unmerged_bc = false, plain_grid = false, band_grid = false;
   int kchunk = 0; long tile_min_blocks = 2048;
   std::string test_bad_launch;      // CALES_TEST_BAD_LAUNCH: test hook of the launch check (LAUNCH below)
   void read_env() {
     test_bad_launch = getenv("CALES_TEST_BAD_LAUNCH") ? getenv("CALES_TEST_BAD_LAUNCH") : "";
+    unfolded_mom = getenv("CALES_UNFOLDED_MOM") != nullptr;      // no subgrid model in cales_step: the projection as a pass of its own (k_correc_cell) in every substep instead of inside the next momentum pass
     unfolded_correc = getenv("CALES_UNFOLDED_CORREC") != nullptr;      // dynamic model in cales_step: the projection as a pass of its own (k_correc_cell) instead of inside the strain-rate pass
     helmholtz_z_per_column = getenv("CALES_HELMHOLTZ_Z_PER_COLUMN") != nullptr;
     unfused_imp_rhs = getenv("CALES_UNFUSED_IMP_RHS") != nullptr;
@@ -194,6 +195,12 @@ struct cales_ctx {
   // cales_step, dynamic model on one rank with x and y periodic: the velocity correction and the pressure update of the substep are done by the
   // strain-rate pass of the cmpt_sgs that follows (k_strain_tile<.., CORR = 1>, k_sgs.hip) -- != 0: the dtrk of the pending projection
   real fold_dtrk = 0.;
+  // cales_step without subgrid model (explicit diffusion, one rank, every direction periodic or between no-slip walls with Neumann pressure): the
+  // projection of substeps 1 and 2 is applied by the momentum pass of the NEXT substep while it loads its planes (k_momrk<.., CORR = 1>); the ghost
+  // cells of the prediction receive their final values through a corrected view in the ghost-cell kernels (bc_view_dtrk). != 0: the dtrk of the
+  // pending projection, with the mask of the components whose bulk-forcing increment it adds
+  real fold_mom_dtrk = 0.; int fold_mom_fmask = 0;
+  real bc_view_dtrk = 0.;      // op_bounduvw: sources are read as (u* + f) - dtrk grad(pp) wherever they are interior cells
   size_t pp_companion_bytes = 0;      // scr2 sits this many bytes behind CALES_PP in one allocation (api.hip field_alloc_pair)
   int field_ofs = 0;       // doubles between a field's allocation and its element (0,0,0)
   real *d_nullw = nullptr; // work space of k_null_column (CALES_KEEP_NULL_MODE)
@@ -334,6 +341,15 @@ __device__ inline real dpp_f64(real v) {       // lanes without a source receive
   lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xf, true);
   hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xf, true);
   return __hiloint2double(hi, lo);
+#endif
+}
+// the value of one lane (a compile-time lane number) in all lanes: v_readlane_b32 through a scalar register
+template <int LANE>
+__device__ inline real lane_bcast(real v) {
+#ifdef CALES_SINGLE
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), LANE));
+#else
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), LANE), __builtin_amdgcn_readlane(__double2loint(v), LANE));
 #endif
 }
 __device__ inline real lane_prev(real v) { return dpp_f64<0x138>(v); }   // wave_shr:1, lane i <- lane i-1 (lane 0 <- 0)

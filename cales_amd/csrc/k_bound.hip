@@ -7,6 +7,25 @@
 // reference is kept because corner ghosts depend on it.
 #include "common.hpp"
 
+// Corrected view (cales_step, projection folded into the next momentum pass): a source cell that is an INTERIOR cell (1..n in all three directions) is
+// read as the projected velocity (u* + f) - dtrk grad(pp) of component comp = 1..3 (the expressions of k_correc_cell), every other cell as stored --
+// ghost cells written by an earlier direction of the same update are final already. comp = 0: plain reads.
+struct CorrView { const real *pp, *dzci, *force; real cfi, cfj, dt; int fmask, perx; };      // force: the bulk-forcing increments of the substep (device), fmask: the forced components
+__device__ inline real view_rd(const Geom &g, const CorrView &V, int comp, const real *p, int i, int j, int k) {
+  const size_t c = g.ix(i, j, k);
+  const real v = p[c];
+  if (!comp || i < 1 || i > g.n1 || j < 1 || j > g.n2 || k < 1 || k > g.n3) return v;
+  const real pc = V.pp[c];
+  const real pb = comp == 1 ? V.pp[(V.perx && i == g.n1) ? g.ix(1, j, k) : c + 1] : comp == 2 ? V.pp[c + g.s1] : V.pp[c + g.s12];
+  const real cf = comp == 1 ? V.cfi : comp == 2 ? V.cfj : V.dt * V.dzci[k];
+  return ((V.fmask >> (comp - 1) & 1) ? v + V.force[comp - 1] : v) - cf * (pb - pc);
+}
+static CorrView corr_view(const cales_ctx *c) {
+  CorrView V{};
+  V.pp = c->f[CALES_PP]; V.dzci = c->d_dzci; V.force = c->d_force; V.cfi = c->bc_view_dtrk * c->dli[0]; V.cfj = c->bc_view_dtrk * c->dli[1]; V.dt = c->bc_view_dtrk;
+  V.fmask = c->fold_mom_fmask; V.perx = c->step_xskip ? 1 : 0;
+  return V;
+}
 struct BcJob {
   real *p;          // field
   const real *bc;   // plane of side `ibound` (already offset), (0:na+1,0:nb+1)
@@ -14,8 +33,9 @@ struct BcJob {
   char ctype;         // 'P','D','N'
   char centered;
   char ibound;
+  char vcomp = 0;     // != 0: sources through the corrected view of this velocity component
 };
-struct BcJobs { int njobs, idir; BcJob job[6]; };
+struct BcJobs { int njobs, idir; BcJob job[6]; CorrView V; };
 
 __global__ __launch_bounds__(256) void k_set_bc(Geom g, BcJobs J) {
   const BcJob jb = J.job[blockIdx.z];
@@ -27,18 +47,23 @@ __global__ __launch_bounds__(256) void k_set_bc(Geom g, BcJobs J) {
   const size_t base = idir == 1 ? g.ix(0, a, b) : idir == 2 ? g.ix(a, 0, b) : g.ix(a, b, 0);
   real *p = jb.p + base;
 #define P(m) p[(long)(m)*st]
+  // sources (cells 1, n-1, n of the line): through the corrected view when the job asks for it
+  auto R = [&](int m) -> real {
+    if (!jb.vcomp) return P(m);
+    return idir == 1 ? view_rd(g, J.V, jb.vcomp, jb.p, m, a, b) : idir == 2 ? view_rd(g, J.V, jb.vcomp, jb.p, a, m, b) : view_rd(g, J.V, jb.vcomp, jb.p, a, b, m);
+  };
   const real bcv = jb.bc ? jb.bc[a + (size_t)(na + 2) * b] : 0.;
   const real sgn = (jb.ctype == 'D' && jb.centered) ? -1. : 1.;
   switch (jb.ctype) {
   case 'P':   // bound.f90:220-248 (one job handles both ends)
-    { const real lo = P(n), hi = P(1); P(0) = lo; P(n + 1) = hi; } break;
+    { const real lo = R(n), hi = R(1); P(0) = lo; P(n + 1) = hi; } break;
   case 'D':   // bound.f90:249-319
-    if (jb.centered) { if (jb.ibound == 0) P(0) = 2. * bcv + sgn * P(1); else P(n + 1) = 2. * bcv + sgn * P(n); }
-    else { if (jb.ibound == 0) P(0) = bcv; else { P(n + 1) = P(n - 1); P(n) = bcv; } }
+    if (jb.centered) { if (jb.ibound == 0) P(0) = 2. * bcv + sgn * R(1); else P(n + 1) = 2. * bcv + sgn * R(n); }
+    else { if (jb.ibound == 0) P(0) = bcv; else { P(n + 1) = R(n - 1); P(n) = bcv; } }
     break;
   case 'N':   // bound.f90:320-396
-    if (jb.centered) { if (jb.ibound == 0) P(0) = -jb.dr * bcv + sgn * P(1); else P(n + 1) = jb.dr * bcv + sgn * P(n); }
-    else { if (jb.ibound == 0) P(0) = -jb.dr * bcv + P(1); else { P(n + 1) = P(n); P(n) = jb.dr * bcv + P(n - 1); } }
+    if (jb.centered) { if (jb.ibound == 0) P(0) = -jb.dr * bcv + sgn * R(1); else P(n + 1) = jb.dr * bcv + sgn * R(n); }
+    else { if (jb.ibound == 0) P(0) = -jb.dr * bcv + R(1); else { P(n + 1) = R(n); P(n) = jb.dr * bcv + R(n - 1); } }
     break;
   }
 #undef P
@@ -59,7 +84,7 @@ static inline const real *plane(const DBound &b, int idir, int ibound, const int
 }
 static inline void add_job(BcJobs &J, real *p, char ctype, int ibound, int centered, const real *bc, real dr) {
   BcJob &j = J.job[J.njobs++];
-  j.p = p; j.bc = bc; j.dr = dr; j.ctype = ctype; j.centered = (char)centered; j.ibound = (char)ibound;
+  j.p = p; j.bc = bc; j.dr = dr; j.ctype = ctype; j.centered = (char)centered; j.ibound = (char)ibound; j.vcomp = 0;
 }
 
 // ---- all three directions in ONE launch, for the common BC sets: x periodic, y periodic (or exchanged between slabs), any
@@ -68,8 +93,8 @@ static inline void add_job(BcJobs &J, real *p, char ctype, int ibound, int cente
 // operation applied to the periodically wrapped interior cell -- so each thread computes its ghost cell from interior cells only
 // and no ordering between the directions is left. Saves two of the three launches of every bounduvw / boundp (19 -> 7 per substep
 // for a channel), which is what small grids are bound by.
-struct MField { real *p; const real *bc0, *bc1; real dr0, dr1; char t0, t1, centered; };      // z sides: 'P','D','N' or 0 (leave z alone)
-struct MJobs { int nf, do_x, wrap_y, do_z; MField f[8]; };
+struct MField { real *p; const real *bc0, *bc1; real dr0, dr1; char t0, t1, centered, vcomp = 0; };      // vcomp != 0: sources through the corrected view (CorrView) of this velocity component      // z sides: 'P','D','N' or 0 (leave z alone)
+struct MJobs { int nf, do_x, wrap_y, do_z; MField f[8]; CorrView V; };
 __global__ __launch_bounds__(256) void k_bc_merged(Geom g, MJobs J) {
   const int region = blockIdx.z % 3; const MField F = J.f[blockIdx.z / 3];
   const int n1 = g.n1, n2 = g.n2, n3 = g.n3;
@@ -78,26 +103,27 @@ __global__ __launch_bounds__(256) void k_bc_merged(Geom g, MJobs J) {
   auto wy = [&](int j) { return !J.wrap_y ? j : j == 0 ? n2 : j == n2 + 1 ? 1 : j; };
   const bool top_face = J.do_z && F.t1 == 'D' && !F.centered;      // plane n3 itself is boundary data (face-centred normal component)
   real *p = F.p;
+  auto S = [&](int i, int j, int k) -> real { return F.vcomp ? view_rd(g, J.V, F.vcomp, F.p, i, j, k) : F.p[g.ix(i, j, k)]; };      // sources
   if (region == 0) {               // z ghost planes of the column (a, b), ghost columns included
     if (!J.do_z || a > n1 + 1 || b > n2 + 1) return;
     const int ia = wx(a), jb = wy(b);
     const size_t q2 = (size_t)a + (size_t)(n1 + 2) * b;
-    if (F.t0 == 'P') { p[g.ix(a, b, 0)] = p[g.ix(ia, jb, n3)]; p[g.ix(a, b, n3 + 1)] = p[g.ix(ia, jb, 1)]; return; }
-    if (F.t0 == 'D') p[g.ix(a, b, 0)] = F.centered ? 2. * F.bc0[q2] - p[g.ix(ia, jb, 1)] : F.bc0[q2];
-    else if (F.t0 == 'N') p[g.ix(a, b, 0)] = -F.dr0 * F.bc0[q2] + p[g.ix(ia, jb, 1)];
+    if (F.t0 == 'P') { p[g.ix(a, b, 0)] = S(ia, jb, n3); p[g.ix(a, b, n3 + 1)] = S(ia, jb, 1); return; }
+    if (F.t0 == 'D') p[g.ix(a, b, 0)] = F.centered ? 2. * F.bc0[q2] - S(ia, jb, 1) : F.bc0[q2];
+    else if (F.t0 == 'N') p[g.ix(a, b, 0)] = -F.dr0 * F.bc0[q2] + S(ia, jb, 1);
     if (F.t1 == 'D') {
-      if (F.centered) p[g.ix(a, b, n3 + 1)] = 2. * F.bc1[q2] - p[g.ix(ia, jb, n3)];
-      else { p[g.ix(a, b, n3 + 1)] = p[g.ix(ia, jb, n3 - 1)]; p[g.ix(a, b, n3)] = F.bc1[q2]; }
-    } else if (F.t1 == 'N') p[g.ix(a, b, n3 + 1)] = F.dr1 * F.bc1[q2] + p[g.ix(ia, jb, n3)];
+      if (F.centered) p[g.ix(a, b, n3 + 1)] = 2. * F.bc1[q2] - S(ia, jb, n3);
+      else { p[g.ix(a, b, n3 + 1)] = S(ia, jb, n3 - 1); p[g.ix(a, b, n3)] = F.bc1[q2]; }
+    } else if (F.t1 == 'N') p[g.ix(a, b, n3 + 1)] = F.dr1 * F.bc1[q2] + S(ia, jb, n3);
   } else if (region == 1) {        // x ghost columns of the rows (b, k), k = 1..n3 (ghost rows included)
     const int bb = a, k = b + 1;   // lanes along y (rows 4 KB apart share DRAM pages; along z they would be a plane apart), blocks along z
     if (!J.do_x || k > n3 || bb > n2 + 1 || (top_face && k == n3)) return;
     const int jb = wy(bb);
-    p[g.ix(0, bb, k)] = p[g.ix(n1, jb, k)]; p[g.ix(n1 + 1, bb, k)] = p[g.ix(1, jb, k)];
+    p[g.ix(0, bb, k)] = S(n1, jb, k); p[g.ix(n1 + 1, bb, k)] = S(1, jb, k);
   } else {                         // y ghost rows, i = 1..n1, k = 1..n3
     const int i = a + 1, k = b + 1;
     if (!J.wrap_y || i > n1 || k > n3 || (top_face && k == n3)) return;
-    p[g.ix(i, 0, k)] = p[g.ix(i, n2, k)]; p[g.ix(i, n2 + 1, k)] = p[g.ix(i, 1, k)];
+    p[g.ix(i, 0, k)] = S(i, n2, k); p[g.ix(i, n2 + 1, k)] = S(i, 1, k);
   }
 }
 static int launch_merged(cales_ctx *c, MJobs &J, const Geom *gg = nullptr) {
@@ -120,7 +146,7 @@ static bool merged_ok(const cales_ctx *c, const char *cbx, const char *cby) {
 
 // y-slab neighbours (bound.f90:619-696 for idir = 2): pack the first/last interior rows of nf fields into the
 // staging buffer A, let the host exchange them, unpack into the ghost rows. Planes include the x/z ghosts.
-struct HaloFields { int nf; real *p[12]; unsigned char wide[12]; int off[12]; };      // wide: a pair field (rows twice as long); off: first staging plane of the field, in planes of s1 (n3+2) values
+struct HaloFields { int nf; real *p[12]; unsigned char wide[12]; int off[12]; unsigned char vcomp[12]; CorrView V; };      // vcomp != 0: the rows that leave are read through the corrected view      // wide: a pair field (rows twice as long); off: first staging plane of the field, in planes of s1 (n3+2) values
 // x ghost columns of the two z ghost planes, rows 0..n2+1: the corners the velocity update after the projection leaves alone (bounduvw with
 // is_correc does not touch the z ghost planes of w, and the periodic copies of the step's earlier calls were skipped: cales_step, step_xskip)
 __global__ __launch_bounds__(256) void k_xwrap_zghost(Geom g, HaloFields H) {
@@ -134,6 +160,7 @@ __global__ __launch_bounds__(256) void k_pack_y(Geom g, HaloFields H, real *__re
   if (i >= (g.n1 + 2) << w || k > g.n3 + 1) return;
   const size_t s1 = (size_t)g.s1 << w, s12 = (size_t)g.s12 << w;
   const size_t q = (size_t)i + s1 * k + (size_t)g.s1 * (g.n3 + 2) * H.off[f];
+  if (H.vcomp[f]) { lo[q] = view_rd(g, H.V, H.vcomp[f], H.p[f], i, 1, k); hi[q] = view_rd(g, H.V, H.vcomp[f], H.p[f], i, g.n2, k); return; }      // (never a pair field)
   lo[q] = H.p[f][i + s1 * 1 + s12 * k]; hi[q] = H.p[f][i + s1 * g.n2 + s12 * k];
 }
 __global__ __launch_bounds__(256) void k_unpack_y(Geom g, HaloFields H, const real *__restrict__ lo, const real *__restrict__ hi, int has_lo, int has_hi) {
@@ -151,7 +178,11 @@ static Geom wide_geom(const cales_ctx *c) { Geom g = c->g; g.n1 = 2 * c->g.n1 + 
 static int halo_y_on(cales_ctx *c, int nf, real **flds, hipStream_t st, bool overlapped, const unsigned char *wide = nullptr) {
   const Geom &G = c->g;
   HaloFields H; H.nf = nf; int planes = 0, anyw = 0;
-  for (int q = 0; q < nf; ++q) { H.p[q] = flds[q]; H.wide[q] = wide ? wide[q] : 0; H.off[q] = planes; planes += 1 + H.wide[q]; anyw |= H.wide[q]; }
+  for (int q = 0; q < nf; ++q) { H.p[q] = flds[q]; H.wide[q] = wide ? wide[q] : 0; H.off[q] = planes; planes += 1 + H.wide[q]; anyw |= H.wide[q]; H.vcomp[q] = 0; }
+  if (c->bc_view_dtrk != 0.) {      // op_bounduvw through the corrected view: the velocity rows that leave are those of the projected velocity
+    H.V = corr_view(c);
+    for (int q = 0; q < nf; ++q) for (int iv = 0; iv < 3; ++iv) if (flds[q] == c->f[CALES_U + iv]) H.vcomp[q] = (unsigned char)(iv + 1);
+  }
   const int64_t cnt = (int64_t)G.s1 * (c->n[2] + 2) * planes;
   if (4 * cnt > c->comm.nbuf) { c->err = "halo staging buffer too small"; return 1; }
   dim3 b(64, 4, 1), gr(((G.s1 << anyw) + 63) / 64, (c->n[2] + 2 + 3) / 4, nf);
@@ -196,9 +227,12 @@ static int halo_self(cales_ctx *c, int nf, real **flds) {
     const bool periodic = idir == 2 ? c->per_y : !ISB(c, 0, 3);
     if (!periodic) continue;             // not periodic: neighbours are MPI_PROC_NULL
     BcJobs J; J.njobs = 0; J.idir = idir;
+    const bool view = c->bc_view_dtrk != 0.;      // op_bounduvw through the corrected view: the periodic copies are those of the projected velocity
+    if (view) J.V = corr_view(c);
     for (int q = 0; q < nf; ++q) {
       if (J.njobs == 6) { if (int e = launch_jobs(c, J)) return e; J.njobs = 0; }
       add_job(J, flds[q], 'P', 0, 1, nullptr, 0.);
+      if (view) for (int iv = 0; iv < 3; ++iv) if (flds[q] == c->f[CALES_U + iv]) J.job[J.njobs - 1].vcomp = (char)(iv + 1);
     }
     if (int e = launch_jobs(c, J)) return e;
   }
@@ -413,6 +447,9 @@ int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm
   const int *n = c->n;
   real *fl[3] = {u, v, w};
   DBound *bnd[3] = {&bu, &bv, &bw};
+  // corrected view (cales_step, fold_mom): the fields hold the prediction, the ghost cells receive the values of the projected velocity
+  const bool view = c->bc_view_dtrk != 0.;
+  const CorrView V = view ? corr_view(c) : CorrView{};
   bool merged = merged_ok(c, c->C.cbcpre, c->C.cbcpre + 2);       // velocity and pressure are periodic together (sanity.f90:163-175)
   for (int ivel = 1; ivel <= 3 && merged; ++ivel) {
     for (int d = 1; d <= 2; ++d) merged = merged && CBV(c, 0, d, ivel) == 'P' && CBV(c, 1, d, ivel) == 'P';
@@ -433,8 +470,9 @@ int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm
     MJobs J; J.nf = 3 + nr; J.do_x = !(bc_skipped(c) & 1); J.wrap_y = c->P == 1; J.do_z = per_z || !(bc_skipped(c) & 4);
     for (int q = 0; q < nr; ++q) merged_pfield(c, J.f[3 + q], c->bc_ride[q], c->bc_ride_which[q]);
     if (nr) c->bc_nride = 0;      // taken
+    J.V = V;
     for (int ivel = 1; ivel <= 3; ++ivel) {
-      MField &F = J.f[ivel - 1]; F.p = fl[ivel - 1];
+      MField &F = J.f[ivel - 1]; F.p = fl[ivel - 1]; F.vcomp = view ? (char)ivel : 0;
       const bool normal = ivel == 3;
       F.centered = normal ? 0 : 1;
       F.bc0 = plane(*bnd[ivel - 1], 3, 0, n); F.bc1 = plane(*bnd[ivel - 1], 3, 1, n);
@@ -455,10 +493,13 @@ int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm
     const bool impose_norm = (!is_correc) || periodic;
     const real drn0 = idir < 3 ? c->dl[idir - 1] : c->dzf[0], drn1 = idir < 3 ? c->dl[idir - 1] : c->dzf[n[2]];
     const real drt0 = idir < 3 ? c->dl[idir - 1] : c->dzc[0], drt1 = idir < 3 ? c->dl[idir - 1] : c->dzc[n[2]];
+    J.V = V;
     for (int ivel = 1; ivel <= 3; ++ivel) {
       real *p = fl[ivel - 1];
       const bool normal = ivel == idir;
       const char c0 = CBV(c, 0, idir, ivel), c1 = CBV(c, 1, idir, ivel);
+      const int first = J.njobs;
+      struct SetView { BcJobs &J; int first, comp; ~SetView() { for (int q = first; q < J.njobs; ++q) J.job[q].vcomp = (char)comp; } } setview{J, first, view ? ivel : 0};
       if (normal) {
         if (!impose_norm) continue;
         if (c0 == 'P') add_job(J, p, 'P', 0, 0, nullptr, 0.);

@@ -28,6 +28,12 @@ struct MomRkArgs {
   // third substep is never used (the next step starts with f2 = 0) -> not written
   int rd_old, wr_new;
   int perx;      // x periodic: the x-halo columns of the tiles at the ends of a row are the wrapped interior columns (valid whether or not the ghost columns are up to date)
+  // CORR = 1 (cales_step without subgrid model, substeps 2 and 3): u, v, w are the PREDICTION u*, v*, w* of the substep before and the projection
+  // (correc.f90:44-67 with the deferred bulk forcing) + pressure update (updatep.f90:30-47) happen while the planes are loaded: every INTERIOR cell
+  // (1..n in all three directions) is corrected on its way into the LDS ring, u = (u* + f) - cfi (pp(i+1) - pp(i)) etc., the ghost cells hold the
+  // final values already (op_bounduvw through the corrected view, k_bound.hip), and p + pp -- valid in the ghost cells too, both fields' conditions
+  // being linear and homogeneous -- goes to the ring and, for the tile's own cells, to pn. The pass k_correc_cell<1> (9 words per cell) disappears.
+  const real *pp; real *pn; real cfi, cfj, cdt; const real *force; int fmask;
 };
 
 // NOS = 1: no subgrid model (visct is identically zero, sgs.f90:62-68): its loads, LDS traffic and terms are compiled out.
@@ -39,7 +45,7 @@ struct MomRkArgs {
 // a multiplication right behind the load) made the prefetch of plane k+2 a blocking one -- tools/memseq.py shows the order of accesses and waits.
 // The two y-halo waves of a block (no outputs) run a loop of their own without stencil and stores; every wave fetches the two x-halo cells of ITS row
 // for the five fields with its first ten lanes.
-template <int IMP, typename OFF, int NOS, int RD, int WR>
+template <int IMP, typename OFF, int NOS, int RD, int WR, int CORR = 0>
 __global__ __launch_bounds__(64 * (TYM + 2), (TYM <= 6 ? 4 : 3)) void k_momrk(Geom g, MomRkArgs A) {
   __shared__ real sh[4][4][TYM + 2][66];
   __shared__ real shp[3][TYM + 2][66];
@@ -51,7 +57,7 @@ __global__ __launch_bounds__(64 * (TYM + 2), (TYM <= 6 ? 4 : 3)) void k_momrk(Ge
   const bool outok = ty >= 1 && ty <= TYM && i <= g.n1 && j <= g.n2;
   // own cell, clamped into the field (a row that does not fill its last tile: the lane beside the last cell loads the column right of it -- the
   // wrapped first column when the ghost columns are not maintained; lanes further right load that column again, rows beyond n2+1 the last ghost row)
-  const int ic = (A.perx && i >= g.n1 + 1) ? 1 : min(i, g.n1 + 1), jc = min(j, g.n2 + 1);
+  const int ic = A.perx ? (i > g.n1 ? (i - 1) % g.n1 + 1 : i) : min(i, g.n1 + 1), jc = min(j, g.n2 + 1);      // (wrapped columns one after the other: the lane right of the last cell finds ITS right neighbour in the next lane, which the folded projection needs)
   const OFF c0 = (OFF)g.ix(ic, jc, 0) * RSZ;        // byte offsets (see ldb in common.hpp)
   const OFF cst = outok ? c0 : (OFF)g.ix(0, jc, 0) * RSZ;      // where this thread's results go: its cell, or the x ghost cell of its row (dead until the next ghost-cell update)
   const OFF sk = (OFF)g.s12 * RSZ;
@@ -62,32 +68,84 @@ __global__ __launch_bounds__(64 * (TYM + 2), (TYM <= 6 ? 4 : 3)) void k_momrk(Ge
   const real *hp = A.u + g.ix(ic, jc, 0);      // (lanes without a halo cell load their own cell of u again: every lane loads, nothing branches)
   if (hok) { const real *fp = hf_ == 0 ? A.u : hf_ == 1 ? A.v : hf_ == 2 ? A.w : hf_ == 3 ? A.s : A.p; hp = fp + g.ix(hi_, jc, 0); }
   const size_t sk64 = (size_t)g.s12;
+  // CORR: pp of the own cell one plane ahead (q[5]; the plane's own value is rolled in ppc), pp of the cell above in y (q[6]); the halo lanes the two
+  // pp values their field's correction needs (q[7], q[8]): the halo cell's own and the one beside it in the field's direction
+  const bool rowin = j >= 1 && j <= g.n2;
+  const OFF cup = CORR ? (OFF)g.ix(ic, min(jc + 1, g.n2 + 1), 0) * RSZ : 0;
+  const real *hpa = A.pp, *hpb = A.pp; size_t hbk = 0; bool hin = false, hfm = false; real hcf = 0., hfo = 0.;
+  real fo[3] = {0., 0., 0.};
+  if (CORR) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) fo[q] = (A.fmask >> q & 1) ? ldc(A.force, q) : 0.;
+    hpa = hpb = A.pp + g.ix(ic, jc, 0);
+    if (hok) {
+      const int hb_ = (A.perx && hi_ == g.n1) ? 1 : min(hi_ + 1, g.n1 + 1);
+      hpa = A.pp + g.ix(hi_, jc, 0);
+      hpb = hf_ == 0 ? A.pp + g.ix(hb_, jc, 0) : hf_ == 1 ? A.pp + g.ix(hi_, min(jc + 1, g.n2 + 1), 0) : hpa;
+      hbk = hf_ == 2 ? 1 : 0;      // w: the plane above
+      hin = rowin && (A.perx || (hi0 >= 1 && hi0 <= g.n1));
+      hcf = hf_ == 0 ? A.cfi : hf_ == 1 ? A.cfj : 0.; hfo = hf_ < 3 ? fo[hf_] : 0.; hfm = hf_ < 3 && (A.fmask >> hf_ & 1);
+    }
+  }
+  real ppc = 0.;      // CORR: pp of the own cell in the plane that put() takes next
   auto ld5 = [&](int k, real *q, real &h) {      // raw values: nothing is computed from them until put()
     const int kk = min(k, g.n3 + 1); const OFF c = c0 + (OFF)kk * sk;
     q[0] = ldb(A.u, c); q[1] = ldb(A.v, c); q[2] = ldb(A.w, c); q[3] = NOS ? 0. : ldb(A.s, c); q[4] = ldb(A.p, c);
     h = hp[(size_t)kk * sk64];
+    if (CORR) {
+      const int kn = min(k + 1, g.n3 + 1);
+      q[5] = ldb(A.pp, c0 + (OFF)kn * sk); q[6] = ldb(A.pp, cup + (OFF)kk * sk);
+      q[7] = hpa[(size_t)kk * sk64]; q[8] = hpb[(size_t)min(kk + (int)hbk, g.n3 + 1) * sk64];
+    }
   };
   // plane kk of the five fields -> ring slot kk&3 (u,v,w,visct) and kk%3 (p); the eddy viscosity of the dynamic model's lazy form is |S| cs(k)
   auto put = [&](int kk, const real *q, real h) {
     const real csk = (!NOS && A.cs) ? ldc(A.cs, min(kk, g.n3 + 1)) : 1.;
+    if (CORR) {
+      const bool pin = kk >= 1 && kk <= g.n3, m = pin && rowin && (i <= g.n1 || (A.perx && i == g.n1 + 1));      // (the wrapped first column right of a short row's last cell is an interior cell)
+      const real czk = A.cdt * ldc(A.dzci, min(kk, g.n3));
+      real ppx = lane_next(ppc);
+      const real pph = lane_bcast<5>(q[7]);      // pp at the tile's right halo column (lane 5: field u, right side)
+      if (tx == 63) ppx = pph;
+      // the expressions of k_correc_cell: (u + f) - fi (pp(i+1) - pp(i)); forcing in the inner cells only (all of these are)
+      const real uc_ = ((A.fmask & 1) ? q[0] + fo[0] : q[0]) - A.cfi * (ppx - ppc);
+      const real vc_ = ((A.fmask & 2) ? q[1] + fo[1] : q[1]) - A.cfj * (q[6] - ppc);
+      const real wc_ = ((A.fmask & 4) ? q[2] + fo[2] : q[2]) - czk * (q[5] - ppc);
+      sh[0][kk & 3][ty][tx + 1] = m ? uc_ : q[0]; sh[1][kk & 3][ty][tx + 1] = m ? vc_ : q[1]; sh[2][kk & 3][ty][tx + 1] = m ? wc_ : q[2];
+      shp[kk % 3][ty][tx + 1] = q[4] + ppc;
+      // halo lanes: everything but the one LDS write is computed by all lanes (a branch around arithmetic on loaded values would hold the waits for them)
+      const real hcfk = hf_ == 2 ? czk : hcf;
+      const real hc_ = (hfm ? h + hfo : h) - hcfk * (q[8] - q[7]);
+      const real hv = hf_ == 4 ? h + q[7] : ((hin && pin) ? hc_ : h);
+      // (lanes without a halo cell write to their own place in the ring of the eddy viscosity, which this instantiation -- no subgrid model -- never reads)
+      real *hd = !hok ? &sh[3][kk & 3][ty][tx + 1] : hf_ == 4 ? &shp[kk % 3][ty][hxs] : &sh[hf_ < 3 ? hf_ : 0][kk & 3][ty][hxs];
+      *hd = hv;
+      ppc = q[5];
+      return;
+    }
 #pragma unroll
     for (int f = 0; f < 3; ++f) sh[f][kk & 3][ty][tx + 1] = q[f];
     if (!NOS) sh[3][kk & 3][ty][tx + 1] = q[3] * csk;
     shp[kk % 3][ty][tx + 1] = q[4];
     if (hok) { if (hf_ < 3) sh[hf_][kk & 3][ty][hxs] = h; else if (hf_ == 3) sh[3][kk & 3][ty][hxs] = h * csk; else shp[kk % 3][ty][hxs] = h; }
   };
-  { real q[5], h;
+  { real q[CORR ? 9 : 5], h;
+    if (CORR) ppc = ldb(A.pp, c0 + (OFF)(kbeg - 1) * sk);
     ld5(kbeg - 1, q, h); put(kbeg - 1, q, h); ld5(kbeg, q, h); put(kbeg, q, h); ld5(kbeg + 1, q, h); put(kbeg + 1, q, h); }
   auto march = [&](auto halo_c) {
     constexpr bool HALO = decltype(halo_c)::value;      // a y-halo wave: loads and LDS only
+  // CORR: the values stored by the plane before stay in their registers until this plane's loads are issued -- a register that is the data of a store in
+  // flight may only be overwritten after a wait for that store (s_waitcnt vmcnt(0) right behind the barrier otherwise)
+  real keep[7] = {0., 0., 0., 0., 0., 0., 0.};
   for (int k = kbeg; k <= kend; ++k) {
     __syncthreads();
     // the old r.h.s. of this plane first, then the prefetch of plane k+2: loads return in order, so waiting for the r.h.s. (needed at the end of this
     // iteration) leaves the prefetch in flight -- the other way round the wait for the r.h.s. would also be a wait for the prefetch
     real duo = 0., dvo = 0., dwo = 0.;
     if (!HALO && RD) { const OFF c = c0 + (OFF)k * sk; duo = ldb(A.duo, c); dvo = ldb(A.dvo, c); dwo = ldb(A.dwo, c); }
-    real pf[5], hf;
+    real pf[CORR ? 9 : 5], hf;
     ld5(k + 2, pf, hf);                                     // prefetch, in flight during the stencil
+    if (CORR && !HALO) asm volatile("" :: "v"(keep[0]), "v"(keep[1]), "v"(keep[2]), "v"(keep[3]), "v"(keep[4]), "v"(keep[5]), "v"(keep[6]));
     if (!HALO) {
       const OFF cs_ = cst + (OFF)k * sk;
       const int km = (k - 1) & 3, kc = k & 3, kp = (k + 1) & 3;
@@ -172,6 +230,8 @@ __global__ __launch_bounds__(64 * (TYM + 2), (TYM <= 6 ? 4 : 3)) void k_momrk(Ge
       real wn = w_ccc + A.f1 * dw + A.f2 * dwo + A.f12 * (A.bfz - dzci_k * (p_ccp - p_ccc));
       if (IMP) { un = un + A.f12 * dud; vn = vn + A.f12 * dvd; wn = wn + A.f12 * dwd; stb(A.dud, cs_, dud); stb(A.dvd, cs_, dvd); stb(A.dwd, cs_, dwd); }
       stb(A.un, cs_, un); stb(A.vn, cs_, vn); stb(A.wn, cs_, wn);
+      if (CORR) { stb(A.pn, cs_, p_ccc);      // p + pp of the own cell (updatep.f90:30-47, explicit form)
+                  keep[0] = un; keep[1] = vn; keep[2] = wn; keep[3] = p_ccc; if (WR) { keep[4] = du; keep[5] = dv; keep[6] = dw; } }
       if (WR) { stb(A.du, cs_, du); stb(A.dv, cs_, dv); stb(A.dw, cs_, dw); }
     }
     put(k + 2, pf, hf);        // slots (k+2)&3 and (k+2)%3 were last read in iteration k-1, i.e. before this iteration's barrier
@@ -208,6 +268,10 @@ int op_momrk(cales_ctx *c, real f1, real f2, real f12) {
   A.rd_old = f2 != 0.; A.wr_new = !c->skip_rhs_store;
   A.perx = c->step_xskip ? 1 : 0;      // (operator-level calls read the ghost columns the caller provided, as the reference does)
   A.f1 = f1; A.f2 = f2; A.f12 = f12; A.bfx = c->C.bforce[0]; A.bfy = c->C.bforce[1]; A.bfz = c->C.bforce[2];
+  // the projection of the substep before is still pending (cales_step, fold_mom): this pass applies it while loading
+  const bool corr = c->fold_mom_dtrk != 0.;
+  A.pp = f[CALES_PP]; A.pn = c->scr1; A.cfi = c->fold_mom_dtrk * c->dli[0]; A.cfj = c->fold_mom_dtrk * c->dli[1]; A.cdt = c->fold_mom_dtrk;
+  A.force = c->d_force; A.fmask = c->fold_mom_fmask;
   dim3 b(64, TYM + 2, 1), gr((n[0] + 63) / 64, (n[1] + TYM - 1) / TYM, 1);
   int kchunk = n[2];
   while ((long)gr.x * gr.y * ((n[2] + kchunk - 1) / kchunk) < tile_min_blocks(c) && kchunk > 32) kchunk = (kchunk + 1) / 2;
@@ -232,6 +296,11 @@ int op_momrk(cales_ctx *c, real f1, real f2, real f12) {
     if (A.rd_old && A.wr_new) MOMRK_L2(IMP_, 1, 1); else if (A.rd_old) MOMRK_L2(IMP_, 1, 0);                            \
     else if (A.wr_new) MOMRK_L2(IMP_, 0, 1); else MOMRK_L2(IMP_, 0, 0);                                                 \
   } while (0)
+  if (corr) {
+    if (!(nos && c->C.impdiff == 0 && A.rd_old)) { c->err = "momrk: a pending projection needs the explicit, no-subgrid-model form"; return 1; }
+    if (small) { if (A.wr_new) LAUNCH(c, (k_momrk<0, unsigned, 1, 1, 1, 1>), gr, b, 0, c->stream, c->g, A); else LAUNCH(c, (k_momrk<0, unsigned, 1, 1, 0, 1>), gr, b, 0, c->stream, c->g, A); }
+    else { if (A.wr_new) LAUNCH(c, (k_momrk<0, size_t, 1, 1, 1, 1>), gr, b, 0, c->stream, c->g, A); else LAUNCH(c, (k_momrk<0, size_t, 1, 1, 0, 1>), gr, b, 0, c->stream, c->g, A); }
+  } else
   if (c->C.impdiff == 2) MOMRK_LAUNCH(2); else if (c->C.impdiff == 1) MOMRK_LAUNCH(1); else MOMRK_LAUNCH(0);
 #undef MOMRK_LAUNCH
 #undef MOMRK_L2
@@ -244,5 +313,6 @@ int op_momrk(cales_ctx *c, real f1, real f2, real f12) {
     LAUNCHCHK(c);
   }
   for (int q = 0; q < 3; ++q) std::swap(c->f[CALES_U + q], c->f2[q]);
+  if (corr) { std::swap(c->f[CALES_P], c->scr1); c->fold_mom_dtrk = 0.; }      // the updated pressure (interior cells; the caller renews its ghost cells)
   return 0;
 }

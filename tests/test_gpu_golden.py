@@ -362,3 +362,49 @@ def test_folded_projection_equals_the_separate_pass(name, ng, nsteps, kchunk, mo
         h.close()
     for nm, a, b in zip(("u", "v", "w", "p", "visct", "pp"), out["fold"], out["separate"]):
         assert relerr(a, b) < (1e-9 if nm == "visct" else 1e-12), nm
+
+
+def _nosgs_case(name, ng):
+    g, case = load_golden({"chan_nosgs": "chan_smag"}.get(name, name)); case.ng[:] = ng
+    if name == "chan_nosgs":      # DNS channel: bulk forcing in x, z walls, no subgrid model
+        case.sgstype = "none"
+    return case
+
+
+@pytest.mark.parametrize("name,ng,nsteps,kchunk", [("tgv_ppp", (64, 16, 24), 3, None), ("tgv_ppp", (32, 24, 16), 2, "5"), ("tgv_ppp", (24, 10, 9), 2, None),
+                                                   ("cavity_nnn", (32, 24, 20), 3, None), ("cavity_nnn", (70, 14, 9), 2, "4"), ("cavity_nnn", (128, 8, 12), 2, None),
+                                                   ("chan_nosgs", (64, 16, 16), 3, None), ("chan_nosgs", (128, 12, 10), 2, "3"), ("chan_nosgs", (48, 20, 12), 2, None),
+                                                   # the ghost cells direction by direction (k_set_bc) instead of the one-launch kernel
+                                                   ("tgv_ppp", (64, 16, 24), 2, "unmerged"), ("chan_nosgs", (64, 16, 16), 2, "unmerged")])
+def test_projection_folded_into_the_momentum_pass_equals_the_separate_pass(name, ng, nsteps, kchunk, monkeypatch):
+    """cales_step without subgrid model (explicit diffusion, one rank, every direction periodic or between no-slip walls): the projection and pressure update of
+    substeps 1 and 2 are applied by the momentum pass of the next substep while it loads its planes (k_momrk<.., CORR = 1>), the ghost cells of the projected
+    velocity come from the ghost-cell kernels' corrected view. Same operations on the same values as k_correc_cell + bounduvw + boundp: all fields agree to
+    round-off, ghost cells included -- triply periodic, all walls (x ghost columns maintained), a forced channel (x ghost columns left alone inside the step),
+    partial tiles in x and y, k chunks that end inside the field."""
+    from cales_amd.hotpath import HotPath, initflow
+    if kchunk == "unmerged":
+        monkeypatch.setenv("CALES_UNMERGED_BC", "1")
+    elif kchunk:
+        monkeypatch.setenv("CALES_KCHUNK", kchunk)
+    out = {}
+    for mode in ("fold", "separate"):
+        if mode == "separate":
+            monkeypatch.setenv("CALES_UNFOLDED_MOM", "1")
+        case = _nosgs_case(name, ng)
+        h = HotPath(case); u, v, w, p = initflow(case)
+        rng = np.random.RandomState(2)
+        for a in (u, v, w):
+            a[1:-1, 1:-1, 1:-1] += 0.02 * (rng.rand(*ng) - 0.5)
+        h.upload(u, v, w, p); h.startup(); dt = 0.5 * h.chkdt()
+        h.profile(True)
+        for _ in range(nsteps):
+            h.step(dt)
+        h.profile(False); st = h.profile_stats()
+        out[mode] = h.download() + [h.get("pp"), h.chkdiv()[1], h.dpdl()]
+        ncorr = st.get("correc_updatep", (0, 0.))[0]
+        assert ncorr == (nsteps if mode == "fold" else 3 * nsteps), (mode, ncorr)      # the fold is what ran: one correction pass per step instead of three
+        h.close()
+    for nm, a, b in zip(("u", "v", "w", "p", "visct", "pp"), out["fold"], out["separate"]):
+        assert relerr(a, b) < 1e-12, nm
+    assert out["fold"][6] < 2. * out["separate"][6] + 1e-12 and np.abs(np.asarray(out["fold"][7]) - np.asarray(out["separate"][7])).max() < 1e-12 * max(1., np.abs(np.asarray(out["separate"][7])).max())
