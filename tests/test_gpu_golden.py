@@ -183,6 +183,9 @@ SWITCH_CASES = [
     # dynamic model inside cales_step: the projection as a pass of its own (k_correc_cell) instead of inside the strain-rate pass (the default on one rank
     # with x and y periodic; chan_dsmag_p2 / tgv_dsmag_ppp at power-of-two rows take the folded form by default, see test_step_at_power_of_two_rows)
     ({"CALES_UNFOLDED_CORREC": "1"}, ["chan_dsmag", "chan_dsmag_p2", "tgv_dsmag_ppp"]),
+    # no subgrid model inside cales_step: the projection of every substep as a pass of its own instead of inside the next momentum pass (the default for
+    # explicit diffusion with every direction periodic or between no-slip walls)
+    ({"CALES_UNFOLDED_MOM": "1"}, ["tgv_ppp", "tgv_ppp_p2", "cavity_nnn"]),
 ]
 
 
