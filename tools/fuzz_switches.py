@@ -12,7 +12,7 @@ POOL = ["CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFOLDED_CORREC", "CA
         "CALES_GAUSSEL_MARCH", "CALES_DSMAG_XGHOSTS", "CALES_WIDE_OFFSETS", "CALES_DSMAG_UNFUSED_FILTER", "CALES_UNMERGED_BC",
         "CALES_DSMAG_STORE_UC", "CALES_DSMAG_UNPAIRED", "CALES_XGHOSTS_IN_STEP", "CALES_BAND_GRID", "CALES_PLAIN_GRID", "CALES_FFT_GENERIC",
         "CALES_HELMHOLTZ_Z_PER_COLUMN", "CALES_UNFUSED_IMP_RHS", "CALES_DSMAG_REFERENCE_SEQUENCE", "CALES_SMAG_REFERENCE_SEQUENCE"]
-NAMES = ["chan_dsmag", "chan_dsmag_wm", "chan_smag_wm", "tgv_dsmag_ppp", "cavity_nnn", "duct_smag_wm_imp1d", "chan_smag", "duct_dsmag_wm", "duct_dsmag", "cavity_dsmag",
+NAMES = ["tgv_ppp", "chan_dsmag", "chan_dsmag_wm", "chan_smag_wm", "tgv_dsmag_ppp", "cavity_nnn", "duct_smag_wm_imp1d", "chan_smag", "duct_dsmag_wm", "duct_dsmag", "cavity_dsmag",
          "duct_smag_wm", "devchan_nd", "halfchan_imp1d"]
 rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 bad = 0
