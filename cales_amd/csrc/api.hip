@@ -10,7 +10,10 @@ void launch_failed(cales_ctx *c, const char *what, hipError_t e) {
   if (c->launch_err.empty()) c->launch_err = std::string("kernel launch failed: ") + what + ": " + hipGetErrorString(e) + " (the context is unusable from here on)";
 }
 // every operator entry: refuse a failed context, run, and report a launch that failed on the way
-#define ENTRY(c, expr) do { LAUNCHCHK(c); const int e_ = (expr); if (e_) return e_; LAUNCHCHK(c); return 0; } while (0)
+static int finish_pending(cales_ctx *c);
+// ... and first of all completes a projection that cales_step left to its successor (common.hpp, pend_xskip)
+#define ENTER(c) do { LAUNCHCHK(c); if (const int pe_ = finish_pending(c)) return pe_; } while (0)
+#define ENTRY(c, expr) do { ENTER(c); const int e_ = (expr); if (e_) return e_; LAUNCHCHK(c); return 0; } while (0)
 
 // ------------------------------------------------------------------------------------------ profiling
 int stream_after(cales_ctx *c, hipStream_t later, hipStream_t earlier) {
@@ -244,12 +247,12 @@ int cales_create(const cales_case *cs, void *stream, cales_ctx **out) {
   return 0;
 }
 
-int cales_sync(cales_ctx *c) { HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
+int cales_sync(cales_ctx *c) { ENTER(c); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }      // (what has been asked for is done when this returns: a pending projection too)
 int cales_local_size(const cales_ctx *c, int32_t n[3], int32_t lo[3]) { for (int d = 0; d < 3; ++d) { n[d] = c->n[d]; lo[d] = c->lo[d]; } return 0; }
 
 // ------------------------------------------------------------------------------------------ copies
 int cales_set_field(cales_ctx *c, int field, const real *host) {
-  LAUNCHCHK(c);
+  ENTER(c);
   if (field < 0 || field >= CALES_NFIELDS || !c->f[field]) { c->err = "bad field id"; return 1; }
   if (field == CALES_VISCT) { c->visct_zero = false; c->visct_lazy = false; }
   const size_t nh = (size_t)(c->n[0] + 2) * (c->n[1] + 2) * (c->n[2] + 2);
@@ -261,7 +264,7 @@ int cales_set_field(cales_ctx *c, int field, const real *host) {
   return 0;
 }
 int cales_get_field(cales_ctx *c, int field, real *host) {
-  LAUNCHCHK(c);
+  ENTER(c);
   if (field < 0 || field >= CALES_NFIELDS || !c->f[field]) { c->err = "bad field id"; return 1; }
   if (field == CALES_VISCT) if (int e = materialize_visct(c)) return e;
   const size_t nh = (size_t)(c->n[0] + 2) * (c->n[1] + 2) * (c->n[2] + 2);
@@ -305,7 +308,7 @@ int cales_mom(cales_ctx *c) { ENTRY(c, op_mom(c)); }
 int cales_rk(cales_ctx *c, int irk, real dt) { if (irk < 1 || irk > 3) { c->err = "irk must be 1..3"; return 1; } ENTRY(c, op_rk(c, irk, dt)); }
 int cales_rk_par(cales_ctx *c, const real rkpar[2], real dt, real f_out[3]) {
   if (!rkpar) { c->err = "cales_rk_par: rkpar is NULL"; return 1; }
-  LAUNCHCHK(c);
+  ENTER(c);
   if (int e = op_rk_par(c, rkpar[0], rkpar[1], dt)) return e;
   LAUNCHCHK(c);
   return f_out ? cales_get_forcing(c, f_out) : 0;
@@ -319,7 +322,7 @@ int cales_get_forcing(cales_ctx *c, real f[3]) {
 }
 int cales_bulk_mean(cales_ctx *c, int field, int c_or_f, real *mean) {
   if (field < 0 || field >= CALES_NFIELDS || !c->f[field]) { c->err = "bad field id"; return 1; }
-  LAUNCHCHK(c);
+  ENTER(c);
   if (int e = op_bulk_mean_dev(c, c->f[field], c_or_f, nullptr)) return e;
   LAUNCHCHK(c);
   HIPCHK(c, hipMemcpyAsync(c->h_red + 16, c->res + 16, sizeof(real), hipMemcpyDeviceToHost, c->stream));
@@ -344,13 +347,72 @@ int cales_out1d_chan(cales_ctx *c, real *buf) { if (!c || !buf) return 1; ENTRY(
 int cales_out2d_duct(cales_ctx *c, real *buf) { if (!c || !buf) return 1; ENTRY(c, op_out2d_duct(c, buf)); }
 
 // ------------------------------------------------------------------------------------------ time step (main.f90:412-508)
-__global__ void k_zero6(real *f) { if (threadIdx.x < 6) f[threadIdx.x] = 0.; }
+__global__ void k_zero6(real *f, int first) { if ((int)threadIdx.x >= first && threadIdx.x < 6) f[threadIdx.x] = 0.; }      // first = 3: dpdl only (the increments f(0:2) of a pending projection are still needed)
 __global__ __launch_bounds__(256) void k_row2_to_companion(Geom g, const real *__restrict__ pp, real *__restrict__ comp) {
   const int i = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y * 4 + threadIdx.y;
   if (i > g.n1 + 1 || k > g.n3 + 1) return;
   comp[g.ix(i, 1, k)] = pp[g.ix(i, 2, k)];
 }
 
+// the projection of a substep may be left to the next momentum pass (step_body): static conditions of the case and the switches
+static bool fold_mom_ok(const cales_ctx *c) {
+  bool ok = !c->fl.unfolded_mom && c->C.sgstype == 0 && c->visct_zero && !c->sgs_first && c->C.impdiff == 0 && (c->P == 1 || c->comm.on) && c->n[2] >= 3 &&
+            !c->fl.unfused_rk && !c->fl.unfused_correc;
+  for (int q = 0; q < 6; ++q) ok = ok && c->C.lwm[q] == 0;
+  for (int d = 1; d <= 3 && ok; ++d) {
+    bool per = CBP(c, 0, d) == 'P' && CBP(c, 1, d) == 'P', walls = CBP(c, 0, d) == 'N' && CBP(c, 1, d) == 'N' && c->C.bcpre[2 * (d - 1)] == 0. && c->C.bcpre[2 * (d - 1) + 1] == 0.;
+    for (int iv = 1; iv <= 3; ++iv) for (int sd = 0; sd <= 1; ++sd) { per = per && CBV(c, sd, d, iv) == 'P'; walls = walls && CBV(c, sd, d, iv) == 'D'; }
+    ok = per || walls;
+  }
+  return ok;
+}
+// correction + pressure update of a substep as passes of their own, and the ghost cells of what they produced (main.f90:498-504)
+static int project_now(cales_ctx *c, real dtrk, real alpha) {
+  const bool fuse_cu = !c->fl.unfused_correc && c->C.impdiff != 1;     // updatep only needs pp: one pass with correc
+  { const int e = fuse_cu ? op_correc_updatep(c, dtrk, alpha, 1) : op_correc(c, dtrk); c->defer_force = false; if (e) return e; }
+  // the pressure is final once the fused correction has run: its ghost cells ride along with those of the velocity (one launch, one slab exchange)
+  if (fuse_cu && !c->fl.unmerged_bc) { c->bc_nride = 1; c->bc_ride[0] = c->f[CALES_P]; c->bc_ride_which[0] = 0; }
+  const int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 1, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W]);
+  const bool rode = fuse_cu && !c->fl.unmerged_bc && c->bc_nride == 0; c->bc_nride = 0;
+  if (e) return e;
+  if (!fuse_cu) { if (int e2 = op_updatep(c, alpha)) return e2; }
+  if (!rode) { if (int e2 = op_boundp(c, c->f[CALES_P], 0)) return e2; }
+  return 0;
+}
+// the ghost cells of everything a caller may look at, all directions (the corners of the x ghost columns with the z ghost planes included), when the
+// step left the x ghost columns alone (step_xskip)
+static int end_of_step_refresh(cales_ctx *c) {
+  if (!c->step_xskip) return 0;
+  c->step_xskip = false;
+  c->bc_nride = 3; c->bc_ride[0] = c->f[CALES_P]; c->bc_ride[1] = c->f[CALES_PP]; c->bc_ride[2] = c->f[CALES_VISCT];
+  c->bc_ride_which[0] = 0; c->bc_ride_which[1] = 0; c->bc_ride_which[2] = 1;
+  if (c->fl.unmerged_bc) c->bc_nride = 0;
+  c->bc_no_halo = true;      // (only the x ghost columns are stale: the rows the neighbours sent are complete but for their two ends, which the local copies fill)
+  struct NoHalo { cales_ctx *c; ~NoHalo() { c->bc_no_halo = false; } } nohalo{c};
+  const int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 0, 1, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W]);
+  const bool rode = !c->fl.unmerged_bc && c->bc_nride == 0; c->bc_nride = 0;
+  if (e) return e;
+  if (!(CBV(c, 0, 3, 3) == 'P' && CBV(c, 1, 3, 3) == 'P')) { if (int e2 = op_xwrap_zghost(c, 3, c->f + CALES_U)) return e2; }      // (periodic z: the z copies of the launch above cover the corners)
+  if (!rode) {
+    real *pq[2] = {c->f[CALES_P], c->f[CALES_PP]};
+    if (int e2 = op_boundp_multi(c, 2, pq, 0)) return e2;
+    if (int e2 = op_boundp(c, c->f[CALES_VISCT], 1)) return e2;
+  }
+  return 0;
+}
+// A projection that cales_step left to its successor (fold_mom, third substep) is completed here -- correction pass, ghost cells, and the refresh of
+// the x ghost columns -- before anything else looks at the fields. Collective over the ranks like every entry of the C-ABI.
+static int finish_pending(cales_ctx *c) {
+  if (c->fold_mom_dtrk == 0. || c->in_step) return 0;
+  const real dtrk = c->fold_mom_dtrk;
+  c->fold_mom_dtrk = 0.;
+  c->in_step = true; c->step_xskip = c->pend_xskip; c->defer_force = c->fold_mom_fmask != 0;
+  struct Restore { cales_ctx *c; ~Restore() { c->in_step = false; c->step_xskip = false; c->defer_force = false; c->bc_nride = 0; } } restore{c};
+  if (int e = project_now(c, dtrk, 0.)) { c->launch_err = "completing a pending projection failed (" + c->err + "): the context is unusable"; return e; }
+  if (int e = end_of_step_refresh(c)) { c->launch_err = "completing a pending projection failed (" + c->err + "): the context is unusable"; return e; }
+  LAUNCHCHK(c);
+  return 0;
+}
 static int step_body(cales_ctx *c, real dt);
 int cales_step(cales_ctx *c, real dt) {
   LAUNCHCHK(c);
@@ -363,9 +425,11 @@ int cales_step(cales_ctx *c, real dt) {
 }
 static int step_body(cales_ctx *c, real dt) {
   static const real rk[3][2] = {{32. / 60., 0.}, {25. / 60., -17. / 60.}, {45. / 60., -25. / 60.}};
-  LAUNCH(c, k_zero6, dim3(1), dim3(64), 0, c->stream, c->d_force);     // dpdl(:) = 0
+  if (c->fold_mom_dtrk != 0. && !fold_mom_ok(c)) { if (int e = finish_pending(c)) return e; }      // (the conditions changed between two steps: a field was set by hand)
+  const bool pending_in = c->fold_mom_dtrk != 0.;      // the step before left its last projection to this step's first momentum pass
+  LAUNCH(c, k_zero6, dim3(1), dim3(64), 0, c->stream, c->d_force, pending_in ? 3 : 0);     // dpdl(:) = 0
   c->in_step = true;
-  struct Reset { cales_ctx *c; ~Reset() { c->in_step = false; c->step_xskip = false; c->bc_nride = 0; c->fold_dtrk = 0.; c->fold_mom_dtrk = 0.; c->bc_view_dtrk = 0.; c->defer_force = false; c->defer_imp_rhs = false; c->fuse_fillps_dti = 0.; c->fuse_mean_mask = 0; } } reset{c};      // also on the error returns
+  struct Reset { cales_ctx *c; bool keep = false; ~Reset() { c->in_step = false; c->step_xskip = false; c->bc_nride = 0; c->fold_dtrk = 0.; if (!keep) c->fold_mom_dtrk = 0.; c->bc_view_dtrk = 0.; c->defer_force = false; c->defer_imp_rhs = false; c->fuse_fillps_dti = 0.; c->fuse_mean_mask = 0; } } reset{c};      // also on the error returns
   // periodic x, explicit diffusion, no wall model, the fused passes everywhere: every kernel of the step wraps around instead of reading x ghost
   // columns, which are then left alone until the step returns (common.hpp, step_xskip)
   { bool ok = !c->fl.xghosts_in_step && CBP(c, 0, 1) == 'P' && CBP(c, 1, 1) == 'P' && c->C.impdiff == 0 && !c->fl.unfused_rk && !c->fl.unfused_correc &&
@@ -389,14 +453,7 @@ static int step_body(cales_ctx *c, real dt) {
   // pass of the NEXT substep while it loads its planes (k_momrk<.., CORR = 1>) -- between the two the fields hold the prediction, whose ghost cells
   // receive the projected values through the corrected view of the ghost-cell kernels. The correction pass (9 words per cell) runs once per step
   // instead of three times; substep 3 keeps it so that the step returns the projected fields.
-  bool fold_mom = !c->fl.unfolded_mom && !fold_correc && c->C.sgstype == 0 && c->visct_zero && !c->sgs_first && c->C.impdiff == 0 && (c->P == 1 || c->comm.on) && c->n[2] >= 3 &&
-                  !c->fl.unfused_rk && !c->fl.unfused_correc;
-  for (int q = 0; q < 6; ++q) fold_mom = fold_mom && c->C.lwm[q] == 0;
-  for (int d = 1; d <= 3 && fold_mom; ++d) {
-    bool per = CBP(c, 0, d) == 'P' && CBP(c, 1, d) == 'P', walls = CBP(c, 0, d) == 'N' && CBP(c, 1, d) == 'N' && c->C.bcpre[2 * (d - 1)] == 0. && c->C.bcpre[2 * (d - 1) + 1] == 0.;
-    for (int iv = 1; iv <= 3; ++iv) for (int sd = 0; sd <= 1; ++sd) { per = per && CBV(c, sd, d, iv) == 'P'; walls = walls && CBV(c, sd, d, iv) == 'D'; }
-    fold_mom = per || walls;
-  }
+  const bool fold_mom = !fold_correc && fold_mom_ok(c);
   for (int irk = 1; irk <= 3; ++irk) {
     const real dtrk = (rk[irk - 1][0] + rk[irk - 1][1]) * dt, dtrki = 1. / dtrk;
     real alpha = 0.;
@@ -446,8 +503,9 @@ static int step_body(cales_ctx *c, real dt) {
     } else
     if (int e = op_boundp(c, c->f[CALES_PP], 0)) return e;
     if (fold_correc) c->fold_dtrk = dtrk;      // correc, bounduvw, updatep, boundp(p): inside the cmpt_sgs below (dsmag_fast)
-    else if (fold_mom && irk < 3) {
-      // the ghost cells of the projected velocity now (through the corrected view), its interior cells and p + pp in the next substep's momentum pass
+    else if (fold_mom && (irk < 3 || !c->fl.eager_projection)) {
+      // the ghost cells of the projected velocity now (through the corrected view), its interior cells and p + pp in the next momentum pass -- the next
+      // substep's, or after the third substep the next step's (finish_pending for every other entry of the C-ABI)
       c->fold_mom_fmask = c->defer_force ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;
       c->defer_force = false;
       c->bc_view_dtrk = dtrk;
@@ -455,16 +513,7 @@ static int step_body(cales_ctx *c, real dt) {
       c->bc_view_dtrk = 0.;
       if (e) return e;
       c->fold_mom_dtrk = dtrk;
-    } else {
-    { const int e = fuse_cu ? op_correc_updatep(c, dtrk, alpha, 1) : op_correc(c, dtrk); c->defer_force = false; if (e) return e; }
-    // the pressure is final once the fused correction has run: its ghost cells ride along with those of the velocity (one launch, one slab exchange)
-    if (fuse_cu && !c->fl.unmerged_bc) { c->bc_nride = 1; c->bc_ride[0] = c->f[CALES_P]; c->bc_ride_which[0] = 0; }
-    { const int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 1, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W]);
-      const bool rode = fuse_cu && !c->fl.unmerged_bc && c->bc_nride == 0; c->bc_nride = 0;
-      if (e) return e;
-      if (!fuse_cu) { if (int e2 = op_updatep(c, alpha)) return e2; }
-      if (!rode) { if (int e2 = op_boundp(c, c->f[CALES_P], 0)) return e2; } }
-    }
+    } else if (int e = project_now(c, dtrk, alpha)) return e;
     c->visct_bc_done = false;
     { const int e = op_cmpt_sgs(c); c->fold_dtrk = 0.; c->defer_force = false; if (e) return e; }
     // no subgrid model and homogeneous sgs BC values: the eddy viscosity is zero, ghost cells included, since start-up (sgs.f90:62-68)
@@ -473,23 +522,8 @@ static int step_body(cales_ctx *c, real dt) {
     if (visct_ghosts && !c->visct_bc_done) { if (int e = op_boundp(c, c->f[CALES_VISCT], 1)) return e; }
     c->visct_bc_done = false;
   }
-  if (c->step_xskip) {      // the ghost cells of everything a caller may look at, all directions (the corners of the x ghost columns with the z ghost planes included)
-    c->step_xskip = false;
-    c->bc_nride = 3; c->bc_ride[0] = c->f[CALES_P]; c->bc_ride[1] = c->f[CALES_PP]; c->bc_ride[2] = c->f[CALES_VISCT];
-    c->bc_ride_which[0] = 0; c->bc_ride_which[1] = 0; c->bc_ride_which[2] = 1;
-    if (c->fl.unmerged_bc) c->bc_nride = 0;
-    c->bc_no_halo = true;      // (only the x ghost columns are stale: the rows the neighbours sent are complete but for their two ends, which the local copies fill)
-    struct NoHalo { cales_ctx *c; ~NoHalo() { c->bc_no_halo = false; } } nohalo{c};
-    { const int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 0, 1, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W]);
-      const bool rode = !c->fl.unmerged_bc && c->bc_nride == 0; c->bc_nride = 0;
-      if (e) return e;
-      if (!(CBV(c, 0, 3, 3) == 'P' && CBV(c, 1, 3, 3) == 'P')) { if (int e2 = op_xwrap_zghost(c, 3, c->f + CALES_U)) return e2; }      // (periodic z: the z copies of the launch above cover the corners)
-      if (!rode) {
-        real *pq[2] = {c->f[CALES_P], c->f[CALES_PP]};
-        if (int e2 = op_boundp_multi(c, 2, pq, 0)) return e2;
-        if (int e2 = op_boundp(c, c->f[CALES_VISCT], 1)) return e2;
-      } }
-  }
+  if (c->fold_mom_dtrk != 0.) { c->pend_xskip = c->step_xskip; reset.keep = true; }      // the last projection is the next step's (or finish_pending's), the refresh with it
+  else if (int e = end_of_step_refresh(c)) return e;
   c->h_red[40] = dt;
   return 0;
 }

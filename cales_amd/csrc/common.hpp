@@ -68,12 +68,13 @@ struct Spec {
 
 // Run-time switches: read from the environment ONCE, by cales_create; the launch path only looks at these fields.
 struct Flags {
-  bool unfolded_correc = false, unfolded_mom = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_eager = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, unfused_rk = false, dsmag_unfused_filter = false, overlap = false, dsmag_store_uc = false, dsmag_unpaired = false, xghosts_in_step = false, unmerged_bc = false, plain_grid = false, band_grid = false;
+  bool unfolded_correc = false, unfolded_mom = false, eager_projection = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_eager = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, unfused_rk = false, dsmag_unfused_filter = false, overlap = false, dsmag_store_uc = false, dsmag_unpaired = false, xghosts_in_step = false, unmerged_bc = false, plain_grid = false, band_grid = false;
   int kchunk = 0; long tile_min_blocks = 2048;
   std::string test_bad_launch;      // CALES_TEST_BAD_LAUNCH: test hook of the launch check (LAUNCH below)
   void read_env() {
     test_bad_launch = getenv("CALES_TEST_BAD_LAUNCH") ? getenv("CALES_TEST_BAD_LAUNCH") : "";
     unfolded_mom = getenv("CALES_UNFOLDED_MOM") != nullptr;      // no subgrid model in cales_step: the projection as a pass of its own (k_correc_cell) in every substep instead of inside the next momentum pass
+    eager_projection = getenv("CALES_EAGER_PROJECTION") != nullptr;      // ... folded, but the third substep's projection done before cales_step returns instead of by the next step's first momentum pass (or the first call that looks at the fields)
     unfolded_correc = getenv("CALES_UNFOLDED_CORREC") != nullptr;      // dynamic model in cales_step: the projection as a pass of its own (k_correc_cell) instead of inside the strain-rate pass
     helmholtz_z_per_column = getenv("CALES_HELMHOLTZ_Z_PER_COLUMN") != nullptr;
     unfused_imp_rhs = getenv("CALES_UNFUSED_IMP_RHS") != nullptr;
@@ -200,6 +201,10 @@ struct cales_ctx {
   // cells of the prediction receive their final values through a corrected view in the ghost-cell kernels (bc_view_dtrk). != 0: the dtrk of the
   // pending projection, with the mask of the components whose bulk-forcing increment it adds
   real fold_mom_dtrk = 0.; int fold_mom_fmask = 0;
+  // The third substep's projection stays pending ACROSS the return of cales_step (fold_mom_dtrk != 0 outside a step): the next step's first momentum
+  // pass applies it, or -- finish_pending in api.hip -- the first other entry of the C-ABI that reads or writes a field (every one of them calls it,
+  // cales_sync included: a caller never sees the prediction). pend_xskip: the x ghost columns were left alone by that step.
+  bool pend_xskip = false;
   real bc_view_dtrk = 0.;      // op_bounduvw: sources are read as (u* + f) - dtrk grad(pp) wherever they are interior cells
   size_t pp_companion_bytes = 0;      // scr2 sits this many bytes behind CALES_PP in one allocation (api.hip field_alloc_pair)
   int field_ofs = 0;       // doubles between a field's allocation and its element (0,0,0)

@@ -297,9 +297,10 @@ int op_momrk(cales_ctx *c, real f1, real f2, real f12) {
     else if (A.wr_new) MOMRK_L2(IMP_, 0, 1); else MOMRK_L2(IMP_, 0, 0);                                                 \
   } while (0)
   if (corr) {
-    if (!(nos && c->C.impdiff == 0 && A.rd_old)) { c->err = "momrk: a pending projection needs the explicit, no-subgrid-model form"; return 1; }
-    if (small) { if (A.wr_new) LAUNCH(c, (k_momrk<0, unsigned, 1, 1, 1, 1>), gr, b, 0, c->stream, c->g, A); else LAUNCH(c, (k_momrk<0, unsigned, 1, 1, 0, 1>), gr, b, 0, c->stream, c->g, A); }
-    else { if (A.wr_new) LAUNCH(c, (k_momrk<0, size_t, 1, 1, 1, 1>), gr, b, 0, c->stream, c->g, A); else LAUNCH(c, (k_momrk<0, size_t, 1, 1, 0, 1>), gr, b, 0, c->stream, c->g, A); }
+    if (!(nos && c->C.impdiff == 0)) { c->err = "momrk: a pending projection needs the explicit, no-subgrid-model form"; return 1; }
+#define MOMRK_CORR(RD_, WR_) do { if (small) LAUNCH(c, (k_momrk<0, unsigned, 1, RD_, WR_, 1>), gr, b, 0, c->stream, c->g, A); else LAUNCH(c, (k_momrk<0, size_t, 1, RD_, WR_, 1>), gr, b, 0, c->stream, c->g, A); } while (0)
+    if (A.rd_old && A.wr_new) MOMRK_CORR(1, 1); else if (A.rd_old) MOMRK_CORR(1, 0); else if (A.wr_new) MOMRK_CORR(0, 1); else MOMRK_CORR(0, 0);
+#undef MOMRK_CORR
   } else
   if (c->C.impdiff == 2) MOMRK_LAUNCH(2); else if (c->C.impdiff == 1) MOMRK_LAUNCH(1); else MOMRK_LAUNCH(0);
 #undef MOMRK_LAUNCH
