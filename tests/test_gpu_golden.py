@@ -390,6 +390,11 @@ def test_projection_folded_into_the_momentum_pass_equals_the_separate_pass(name,
         monkeypatch.setenv("CALES_UNMERGED_BC", "1")
     elif kchunk:
         monkeypatch.setenv("CALES_KCHUNK", kchunk)
+    # the third substep's projection: completed inside the step (the default below 4M cells per rank) or left to the next step's first momentum pass and,
+    # after the last step, to the download (CALES_LAZY_PROJECTION: the default of large grids)
+    lazy = (ng[0] + ng[1] + nsteps) % 2 == 0
+    if lazy:
+        monkeypatch.setenv("CALES_LAZY_PROJECTION", "1")
     out = {}
     for mode in ("fold", "separate"):
         if mode == "separate":
@@ -407,7 +412,7 @@ def test_projection_folded_into_the_momentum_pass_equals_the_separate_pass(name,
         h.profile(False); st = h.profile_stats()
         ncorr = st.get("correc_updatep", (0, 0.))[0]
         # the fold is what ran: no correction pass inside the steps (the last projection is completed by the download above), three per step otherwise
-        assert ncorr == (1 if mode == "fold" else 3 * nsteps), (mode, ncorr)
+        assert ncorr == ((1 if lazy else nsteps) if mode == "fold" else 3 * nsteps), (mode, lazy, ncorr)
         h.close()
     for nm, a, b in zip(("u", "v", "w", "p", "visct", "pp"), out["fold"], out["separate"]):
         assert relerr(a, b) < 1e-12, nm

@@ -133,7 +133,7 @@ def test_time_steps_with_x_ghosts_kept(name, ng, nsteps, monkeypatch):
     test_time_steps(name, ng, nsteps)
 
 
-_BOOL_SWITCHES = ["CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFOLDED_CORREC", "CALES_UNFOLDED_MOM", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_KEEP_LAST_RHS",
+_BOOL_SWITCHES = ["CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFOLDED_CORREC", "CALES_UNFOLDED_MOM", "CALES_LAZY_PROJECTION", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_KEEP_LAST_RHS",
                   "CALES_DSMAG_EAGER", "CALES_GAUSSEL_MARCH", "CALES_DSMAG_XGHOSTS", "CALES_WIDE_OFFSETS",
                   "CALES_DSMAG_UNFUSED_FILTER", "CALES_UNMERGED_BC", "CALES_DSMAG_STORE_UC", "CALES_DSMAG_UNPAIRED", "CALES_XGHOSTS_IN_STEP", "CALES_BAND_GRID",
                   "CALES_PLAIN_GRID", "CALES_FFT_GENERIC", "CALES_HELMHOLTZ_Z_PER_COLUMN", "CALES_UNFUSED_IMP_RHS",
