@@ -129,7 +129,10 @@ int cales_out1d_chan(cales_ctx *ctx, cales_real *buf);
 #define CALES_NSTATS_DUCT 9
 int cales_out2d_duct(cales_ctx *ctx, cales_real *buf);
 
-/* one time step = 3 RK substeps in the order of src/main.f90:417-508; no host synchronisation */
+/* one time step = 3 RK substeps in the order of src/main.f90:417-508; no host synchronisation.
+ * Without subgrid model (explicit diffusion, periodic / no-slip directions) the LAST projection of the step may still be pending when this returns --
+ * the next cales_step applies it in its first momentum pass; every other entry that reads or writes a field, cales_sync included, completes it first,
+ * so what a caller can observe is always the projected state of src/main.f90:498-504 (CALES_EAGER_PROJECTION). */
 int cales_step(cales_ctx *ctx, cales_real dt);
 int cales_get_dpdl(cales_ctx *ctx, cales_real dpdl[3]);                         /* main.f90:492,508 (sync) */
 
