@@ -503,7 +503,7 @@ static int step_body(cales_ctx *c, real dt) {
     } else
     if (int e = op_boundp(c, c->f[CALES_PP], 0)) return e;
     if (fold_correc) c->fold_dtrk = dtrk;      // correc, bounduvw, updatep, boundp(p): inside the cmpt_sgs below (dsmag_fast)
-    else if (fold_mom && (irk < 3 || (!c->fl.eager_projection && (c->fl.lazy_projection || (size_t)c->n[0] * c->n[1] * c->n[2] >= ((size_t)1 << 22))))) {
+    else if (fold_mom && (irk < 3 || (!c->fl.eager_projection && (c->fl.lazy_projection || (c->P == 1 && (size_t)c->n[0] * c->n[1] * c->n[2] >= ((size_t)1 << 22)))))) {
       // the ghost cells of the projected velocity now (through the corrected view), its interior cells and p + pp in the next momentum pass -- the next
       // substep's, or after the third substep the next step's (finish_pending for every other entry of the C-ABI)
       c->fold_mom_fmask = c->defer_force ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;

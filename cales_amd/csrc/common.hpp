@@ -74,7 +74,7 @@ struct Flags {
   void read_env() {
     test_bad_launch = getenv("CALES_TEST_BAD_LAUNCH") ? getenv("CALES_TEST_BAD_LAUNCH") : "";
     unfolded_mom = getenv("CALES_UNFOLDED_MOM") != nullptr;      // no subgrid model in cales_step: the projection as a pass of its own (k_correc_cell) in every substep instead of inside the next momentum pass
-    lazy_projection = getenv("CALES_LAZY_PROJECTION") != nullptr;      // ... the third substep's projection left to the next step on grids of any size (default: 4M cells per rank and more -- measured: 1024^3 166.0 -> 161.5 ms/step, 64^3 0.235 -> 0.242)
+    lazy_projection = getenv("CALES_LAZY_PROJECTION") != nullptr;      // ... the third substep's projection left to the next step on grids of any size (default: one rank with 4M cells or more -- measured: 1024^3 166.0 -> 161.5 ms/step, 64^3 0.235 -> 0.242)
     eager_projection = getenv("CALES_EAGER_PROJECTION") != nullptr;      // ... folded, but the third substep's projection done before cales_step returns instead of by the next step's first momentum pass (or the first call that looks at the fields)
     unfolded_correc = getenv("CALES_UNFOLDED_CORREC") != nullptr;      // dynamic model in cales_step: the projection as a pass of its own (k_correc_cell) instead of inside the strain-rate pass
     helmholtz_z_per_column = getenv("CALES_HELMHOLTZ_Z_PER_COLUMN") != nullptr;
