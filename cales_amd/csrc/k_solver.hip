@@ -894,7 +894,7 @@ __global__ __launch_bounds__(64 * gt_width(M, NV) / NV, (PER ? 2 : M <= 8 ? 4 : 
                                                             const real *__restrict__ ra = nullptr, const real *__restrict__ rb_ = nullptr, const real *__restrict__ rc = nullptr) {
   extern __shared__ real shz[];
   const int nsys = PER ? nz - 1 : nz;      // rows of the tridiagonal system proper
-  constexpr int W = gt_width(M, NV), CP = M + 1, P = 64 * CP + 4, NT = 64 * W / NV, KP = NT / W, NQ = 64 * M / KP;
+  constexpr int W = gt_width(M, NV), CP = M + 1, P = 64 * CP + 4, NT = 64 * W / NV;
   const int t = threadIdx.x;
   const int tile = blockIdx.x;
   const size_t base = (T.blocked ? T.segstride * blockIdx.y : g.ix(0, blockIdx.y + 1, 1)) + (size_t)W * tile;      // doubles from p

@@ -417,3 +417,21 @@ def test_projection_folded_into_the_momentum_pass_equals_the_separate_pass(name,
     for nm, a, b in zip(("u", "v", "w", "p", "visct", "pp"), out["fold"], out["separate"]):
         assert relerr(a, b) < 1e-12, nm
     assert out["fold"][6] < 2. * out["separate"][6] + 1e-12 and np.abs(np.asarray(out["fold"][7]) - np.asarray(out["separate"][7])).max() < 1e-12 * max(1., np.abs(np.asarray(out["separate"][7])).max())
+
+
+def test_pending_projection_is_completed_by_every_entry_that_looks(monkeypatch):
+    """CALES_LAZY_PROJECTION (the default of large one-rank grids): cales_step returns with the third substep's projection pending. cales_sync completes it
+    (one correction pass, once), a second sync does nothing more, the next step consumes a pending projection in its first momentum pass without any
+    correction pass, and chkdiv -- which reads the velocity -- sees a divergence-free field right after a step."""
+    from cales_amd.hotpath import HotPath, initflow
+    monkeypatch.setenv("CALES_LAZY_PROJECTION", "1")
+    case = _nosgs_case("cavity_nnn", (32, 16, 12))
+    h = HotPath(case); h.upload(*initflow(case)); h.startup(); dt = 0.5 * h.chkdt()
+    ncorr = lambda: h.profile_stats().get("correc_updatep", (0, 0.))[0]
+    h.profile(True)
+    h.step(dt); assert ncorr() == 0
+    h.sync(); assert ncorr() == 1
+    h.sync(); assert ncorr() == 1
+    h.step(dt); h.step(dt); h.step(dt); assert ncorr() == 1      # three steps, each consuming its predecessor's projection
+    assert h.chkdiv()[1] < 1e-12 and ncorr() == 2
+    h.profile(False); h.close()
