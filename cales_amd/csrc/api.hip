@@ -361,7 +361,9 @@ static bool fold_mom_ok(const cales_ctx *c) {
   for (int q = 0; q < 6; ++q) ok = ok && c->C.lwm[q] == 0;
   for (int d = 1; d <= 3 && ok; ++d) {
     bool per = CBP(c, 0, d) == 'P' && CBP(c, 1, d) == 'P', walls = CBP(c, 0, d) == 'N' && CBP(c, 1, d) == 'N' && c->C.bcpre[2 * (d - 1)] == 0. && c->C.bcpre[2 * (d - 1) + 1] == 0.;
-    for (int iv = 1; iv <= 3; ++iv) for (int sd = 0; sd <= 1; ++sd) { per = per && CBV(c, sd, d, iv) == 'P'; walls = walls && CBV(c, sd, d, iv) == 'D'; }
+    // (walls: the normal component is prescribed -- with the homogeneous Neumann pressure its face values do not change in the projection --, the tangential
+    //  ones no-slip or free-slip: either rule is an affine map of the mirrored interior cell, which the corrected view reads projected)
+    for (int iv = 1; iv <= 3; ++iv) for (int sd = 0; sd <= 1; ++sd) { per = per && CBV(c, sd, d, iv) == 'P'; walls = walls && (CBV(c, sd, d, iv) == 'D' || (iv != d && CBV(c, sd, d, iv) == 'N')); }
     ok = per || walls;
   }
   return ok;

@@ -35,7 +35,7 @@ def run(case, ng, nsteps, unfolded):
 
 
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
-    name = ("tgv_ppp", "cavity_nnn", "chan_nosgs")[trial % 3]
+    name = ("tgv_ppp", "cavity_nnn", "chan_nosgs", "halfchan_nosgs")[trial % 4]
     P = int(rng.choice([1, 1, 1, 2, 3, 4]))
     n2l = int(rng.randint(2, 22)); n2l += (n2l * P) % 2      # (ng(2) even, sanity.f90)
     n1 = int(rng.choice([16, 32, 64, 128, 192])) if rng.rand() < 0.6 else 2 * int(rng.randint(4, 80))
