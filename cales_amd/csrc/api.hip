@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void k_row2_to_companion(Geom g, const real *_
 
 // the projection of a substep may be left to the next momentum pass (step_body): static conditions of the case and the switches
 static bool fold_mom_ok(const cales_ctx *c) {
-  bool ok = !c->fl.unfolded_mom && c->C.sgstype == 0 && c->visct_zero && !c->sgs_first && c->C.impdiff == 0 && (c->P == 1 || c->comm.on) && c->n[2] >= 3 &&
+  bool ok = !c->fl.unfolded_mom && c->C.sgstype == 0 && c->visct_zero && !c->sgs_first && (c->C.impdiff == 0 || c->C.impdiff == 2) && (c->P == 1 || c->comm.on) && c->n[2] >= 3 &&
             !c->fl.unfused_rk && !c->fl.unfused_correc;
   for (int q = 0; q < 6; ++q) ok = ok && c->C.lwm[q] == 0;
   for (int d = 1; d <= 3 && ok; ++d) {
@@ -410,6 +410,12 @@ static int finish_pending(cales_ctx *c) {
   c->fold_mom_dtrk = 0.;
   c->in_step = true; c->step_xskip = c->pend_xskip; c->defer_force = c->fold_mom_fmask != 0;
   struct Restore { cales_ctx *c; ~Restore() { c->in_step = false; c->step_xskip = false; c->defer_force = false; c->bc_nride = 0; } } restore{c};
+  if (c->fold_mom_pdone) {      // (z-implicit diffusion: the pressure is up to date, ghost cells included)
+    c->fold_mom_pdone = false;
+    int e = op_correc(c, dtrk);
+    if (!e) e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 1, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W]);
+    if (e) { c->launch_err = "completing a pending projection failed (" + c->err + "): the context is unusable"; return e; }
+  } else
   if (int e = project_now(c, dtrk, 0.)) { c->launch_err = "completing a pending projection failed (" + c->err + "): the context is unusable"; return e; }
   if (int e = end_of_step_refresh(c)) { c->launch_err = "completing a pending projection failed (" + c->err + "): the context is unusable"; return e; }
   LAUNCHCHK(c);
@@ -431,7 +437,7 @@ static int step_body(cales_ctx *c, real dt) {
   const bool pending_in = c->fold_mom_dtrk != 0.;      // the step before left its last projection to this step's first momentum pass
   LAUNCH(c, k_zero6, dim3(1), dim3(64), 0, c->stream, c->d_force, pending_in ? 3 : 0);     // dpdl(:) = 0
   c->in_step = true;
-  struct Reset { cales_ctx *c; bool keep = false; ~Reset() { c->in_step = false; c->step_xskip = false; c->bc_nride = 0; c->fold_dtrk = 0.; if (!keep) c->fold_mom_dtrk = 0.; c->bc_view_dtrk = 0.; c->defer_force = false; c->defer_imp_rhs = false; c->fuse_fillps_dti = 0.; c->fuse_mean_mask = 0; } } reset{c};      // also on the error returns
+  struct Reset { cales_ctx *c; bool keep = false; ~Reset() { c->in_step = false; c->step_xskip = false; c->bc_nride = 0; c->fold_dtrk = 0.; if (!keep) { c->fold_mom_dtrk = 0.; c->fold_mom_pdone = false; } c->bc_view_dtrk = 0.; c->defer_force = false; c->defer_imp_rhs = false; c->fuse_fillps_dti = 0.; c->fuse_mean_mask = 0; } } reset{c};      // also on the error returns
   // periodic x, explicit diffusion, no wall model, the fused passes everywhere: every kernel of the step wraps around instead of reading x ghost
   // columns, which are then left alone until the step returns (common.hpp, step_xskip)
   { bool ok = !c->fl.xghosts_in_step && CBP(c, 0, 1) == 'P' && CBP(c, 1, 1) == 'P' && c->C.impdiff == 0 && !c->fl.unfused_rk && !c->fl.unfused_correc &&
@@ -477,7 +483,7 @@ static int step_body(cales_ctx *c, real dt) {
     c->fuse_mean_mask = (fuse_fill && c->defer_force && !c->fl.unfused_mean)
                             ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;
     c->skip_rhs_store = irk == 3 && !c->fl.keep_last_rhs;
-    const bool p_ghosts_due = c->fold_mom_dtrk != 0.;      // the momentum pass below stores p + pp of the interior cells: its ghost cells ride along with those of the prediction
+    const bool p_ghosts_due = c->fold_mom_dtrk != 0. && !c->fold_mom_pdone;      // the momentum pass below stores p + pp of the interior cells: its ghost cells ride along with those of the prediction
     { const int e = op_rk(c, irk, dt); c->skip_rhs_store = false; if (e) return e; }
     if (int e = op_bulk_forcing(c)) { c->defer_imp_rhs = false; return e; }
     if (c->C.impdiff == 2) {
@@ -510,6 +516,11 @@ static int step_body(cales_ctx *c, real dt) {
       // substep's, or after the third substep the next step's (finish_pending for every other entry of the C-ABI)
       c->fold_mom_fmask = c->defer_force ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;
       c->defer_force = false;
+      if (c->C.impdiff == 2) {      // z-implicit diffusion: the pressure update keeps its own pass (updatep.f90:40-46) -- the z Laplacian of pp has no values in ghost cells
+        if (int e = op_updatep(c, alpha)) return e;
+        if (int e = op_boundp(c, c->f[CALES_P], 0)) return e;
+        c->fold_mom_pdone = true;
+      }
       c->bc_view_dtrk = dtrk;
       const int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 1, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W]);
       c->bc_view_dtrk = 0.;

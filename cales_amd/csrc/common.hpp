@@ -202,6 +202,7 @@ struct cales_ctx {
   // cells of the prediction receive their final values through a corrected view in the ghost-cell kernels (bc_view_dtrk). != 0: the dtrk of the
   // pending projection, with the mask of the components whose bulk-forcing increment it adds
   real fold_mom_dtrk = 0.; int fold_mom_fmask = 0;
+  bool fold_mom_pdone = false;      // z-implicit diffusion: the pressure update ran as a pass of its own (its z Laplacian of pp cannot be formed in ghost cells), only the velocity is pending
   // The third substep's projection stays pending ACROSS the return of cales_step (fold_mom_dtrk != 0 outside a step): the next step's first momentum
   // pass applies it, or -- finish_pending in api.hip -- the first other entry of the C-ABI that reads or writes a field (every one of them calls it,
   // cales_sync included: a caller never sees the prediction). pend_xskip: the x ghost columns were left alone by that step.

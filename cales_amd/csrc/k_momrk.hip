@@ -112,11 +112,11 @@ __global__ __launch_bounds__(64 * (TYM + 2), (TYM <= 6 ? 4 : 3)) void k_momrk(Ge
       const real vc_ = ((A.fmask & 2) ? q[1] + fo[1] : q[1]) - A.cfj * (q[6] - ppc);
       const real wc_ = ((A.fmask & 4) ? q[2] + fo[2] : q[2]) - czk * (q[5] - ppc);
       sh[0][kk & 3][ty][tx + 1] = m ? uc_ : q[0]; sh[1][kk & 3][ty][tx + 1] = m ? vc_ : q[1]; sh[2][kk & 3][ty][tx + 1] = m ? wc_ : q[2];
-      shp[kk % 3][ty][tx + 1] = q[4] + ppc;
+      shp[kk % 3][ty][tx + 1] = CORR == 1 ? q[4] + ppc : q[4];      // (CORR = 2: the pressure was updated by a pass of its own, z-implicit diffusion)
       // halo lanes: everything but the one LDS write is computed by all lanes (a branch around arithmetic on loaded values would hold the waits for them)
       const real hcfk = hf_ == 2 ? czk : hcf;
       const real hc_ = (hfm ? h + hfo : h) - hcfk * (q[8] - q[7]);
-      const real hv = hf_ == 4 ? h + q[7] : ((hin && pin) ? hc_ : h);
+      const real hv = hf_ == 4 ? (CORR == 1 ? h + q[7] : h) : ((hin && pin) ? hc_ : h);
       // (lanes without a halo cell write to their own place in the ring of the eddy viscosity, which this instantiation -- no subgrid model -- never reads)
       real *hd = !hok ? &sh[3][kk & 3][ty][tx + 1] : hf_ == 4 ? &shp[kk % 3][ty][hxs] : &sh[hf_ < 3 ? hf_ : 0][kk & 3][ty][hxs];
       *hd = hv;
@@ -230,8 +230,8 @@ __global__ __launch_bounds__(64 * (TYM + 2), (TYM <= 6 ? 4 : 3)) void k_momrk(Ge
       real wn = w_ccc + A.f1 * dw + A.f2 * dwo + A.f12 * (A.bfz - dzci_k * (p_ccp - p_ccc));
       if (IMP) { un = un + A.f12 * dud; vn = vn + A.f12 * dvd; wn = wn + A.f12 * dwd; stb(A.dud, cs_, dud); stb(A.dvd, cs_, dvd); stb(A.dwd, cs_, dwd); }
       stb(A.un, cs_, un); stb(A.vn, cs_, vn); stb(A.wn, cs_, wn);
-      if (CORR) { stb(A.pn, cs_, p_ccc);      // p + pp of the own cell (updatep.f90:30-47, explicit form)
-                  keep[0] = un; keep[1] = vn; keep[2] = wn; keep[3] = p_ccc; if (WR) { keep[4] = du; keep[5] = dv; keep[6] = dw; } }
+      if (CORR) { if (CORR == 1) stb(A.pn, cs_, p_ccc);      // p + pp of the own cell (updatep.f90:30-47, explicit form)
+                  keep[0] = un; keep[1] = vn; keep[2] = wn; keep[3] = CORR == 1 ? p_ccc : 0.; if (WR) { keep[4] = du; keep[5] = dv; keep[6] = dw; } }
       if (WR) { stb(A.du, cs_, du); stb(A.dv, cs_, dv); stb(A.dw, cs_, dw); }
     }
     put(k + 2, pf, hf);        // slots (k+2)&3 and (k+2)%3 were last read in iteration k-1, i.e. before this iteration's barrier
@@ -296,10 +296,13 @@ int op_momrk(cales_ctx *c, real f1, real f2, real f12) {
     if (A.rd_old && A.wr_new) MOMRK_L2(IMP_, 1, 1); else if (A.rd_old) MOMRK_L2(IMP_, 1, 0);                            \
     else if (A.wr_new) MOMRK_L2(IMP_, 0, 1); else MOMRK_L2(IMP_, 0, 0);                                                 \
   } while (0)
+  const bool pdone = corr && c->fold_mom_pdone;      // the pressure was updated by a pass of its own (z-implicit diffusion): velocity only (CORR = 2)
   if (corr) {
-    if (!(nos && c->C.impdiff == 0)) { c->err = "momrk: a pending projection needs the explicit, no-subgrid-model form"; return 1; }
-#define MOMRK_CORR(RD_, WR_) do { if (small) LAUNCH(c, (k_momrk<0, unsigned, 1, RD_, WR_, 1>), gr, b, 0, c->stream, c->g, A); else LAUNCH(c, (k_momrk<0, size_t, 1, RD_, WR_, 1>), gr, b, 0, c->stream, c->g, A); } while (0)
-    if (A.rd_old && A.wr_new) MOMRK_CORR(1, 1); else if (A.rd_old) MOMRK_CORR(1, 0); else if (A.wr_new) MOMRK_CORR(0, 1); else MOMRK_CORR(0, 0);
+    if (!(nos && ((c->C.impdiff == 0 && !pdone) || (c->C.impdiff == 2 && pdone)))) { c->err = "momrk: a pending projection needs the no-subgrid-model form, explicit or z-implicit"; return 1; }
+#define MOMRK_CORR(IMP_, CORR_, RD_, WR_) do { if (small) LAUNCH(c, (k_momrk<IMP_, unsigned, 1, RD_, WR_, CORR_>), gr, b, 0, c->stream, c->g, A); else LAUNCH(c, (k_momrk<IMP_, size_t, 1, RD_, WR_, CORR_>), gr, b, 0, c->stream, c->g, A); } while (0)
+#define MOMRK_CORR4(IMP_, CORR_) do { if (A.rd_old && A.wr_new) MOMRK_CORR(IMP_, CORR_, 1, 1); else if (A.rd_old) MOMRK_CORR(IMP_, CORR_, 1, 0); else if (A.wr_new) MOMRK_CORR(IMP_, CORR_, 0, 1); else MOMRK_CORR(IMP_, CORR_, 0, 0); } while (0)
+    if (pdone) MOMRK_CORR4(2, 2); else MOMRK_CORR4(0, 1);
+#undef MOMRK_CORR4
 #undef MOMRK_CORR
   } else
   if (c->C.impdiff == 2) MOMRK_LAUNCH(2); else if (c->C.impdiff == 1) MOMRK_LAUNCH(1); else MOMRK_LAUNCH(0);
@@ -314,6 +317,6 @@ int op_momrk(cales_ctx *c, real f1, real f2, real f12) {
     LAUNCHCHK(c);
   }
   for (int q = 0; q < 3; ++q) std::swap(c->f[CALES_U + q], c->f2[q]);
-  if (corr) { std::swap(c->f[CALES_P], c->scr1); c->fold_mom_dtrk = 0.; }      // the updated pressure (interior cells; the caller renews its ghost cells)
+  if (corr) { if (!pdone) std::swap(c->f[CALES_P], c->scr1); c->fold_mom_dtrk = 0.; c->fold_mom_pdone = false; }      // the updated pressure (interior cells; the caller renews its ghost cells)
   return 0;
 }

@@ -368,17 +368,21 @@ def test_folded_projection_equals_the_separate_pass(name, ng, nsteps, kchunk, mo
 
 
 def _nosgs_case(name, ng):
-    g, case = load_golden({"chan_nosgs": "chan_smag", "halfchan_nosgs": "halfchan_imp1d"}.get(name, name)); case.ng[:] = ng
-    if name == "chan_nosgs":      # DNS channel: bulk forcing in x, z walls, no subgrid model
+    g, case = load_golden({"chan_nosgs": "chan_smag", "chan_nosgs_imp1d": "chan_smag", "halfchan_nosgs": "halfchan_imp1d"}.get(name, name)); case.ng[:] = ng
+    if name in ("chan_nosgs", "chan_nosgs_imp1d"):      # DNS channel: bulk forcing in x, z walls, no subgrid model
         case.sgstype = "none"
     if name == "halfchan_nosgs":      # open channel: no-slip bottom, free-slip top (Neumann u, v; w = 0), bulk forcing, explicit diffusion
         case.impdiff = 0
+    if name == "chan_nosgs_imp1d":      # DNS channel with z-implicit diffusion: the velocity correction folds, the pressure update keeps its pass
+        case.impdiff = 2
     return case
 
 
 @pytest.mark.parametrize("name,ng,nsteps,kchunk", [("tgv_ppp", (64, 16, 24), 3, None), ("tgv_ppp", (32, 24, 16), 2, "5"), ("tgv_ppp", (24, 10, 9), 2, None),
                                                    ("cavity_nnn", (32, 24, 20), 3, None), ("cavity_nnn", (70, 14, 9), 2, "4"), ("cavity_nnn", (128, 8, 12), 2, None),
                                                    ("chan_nosgs", (64, 16, 16), 3, None), ("chan_nosgs", (128, 12, 10), 2, "3"), ("chan_nosgs", (48, 20, 12), 2, None),
+                                                   ("chan_nosgs_imp1d", (64, 16, 16), 3, None), ("chan_nosgs_imp1d", (48, 12, 10), 2, "3"), ("halfchan_imp1d", (64, 12, 16), 2, None),
+                                                   ("halfchan_imp1d", (24, 10, 12), 3, "unmerged"),
                                                    ("halfchan_nosgs", (64, 12, 16), 3, None), ("halfchan_nosgs", (40, 16, 13), 2, "4"), ("halfchan_nosgs", (32, 8, 10), 2, "unmerged"),
                                                    # the ghost cells direction by direction (k_set_bc) instead of the one-launch kernel
                                                    ("tgv_ppp", (64, 16, 24), 2, "unmerged"), ("chan_nosgs", (64, 16, 16), 2, "unmerged")])
@@ -413,7 +417,7 @@ def test_projection_folded_into_the_momentum_pass_equals_the_separate_pass(name,
             h.step(dt)
         out[mode] = h.download() + [h.get("pp"), h.chkdiv()[1], h.dpdl()]
         h.profile(False); st = h.profile_stats()
-        ncorr = st.get("correc_updatep", (0, 0.))[0]
+        ncorr = st.get("correc_updatep", (0, 0.))[0] + st.get("correc", (0, 0.))[0]      # (z-implicit diffusion, folded: the completion corrects the velocity only)
         # the fold is what ran: no correction pass inside the steps (the last projection is completed by the download above), three per step otherwise
         assert ncorr == ((1 if lazy else nsteps) if mode == "fold" else 3 * nsteps), (mode, lazy, ncorr)
         h.close()

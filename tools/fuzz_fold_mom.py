@@ -30,12 +30,12 @@ def run(case, ng, nsteps, unfolded):
     h.profile(True)
     for _ in range(nsteps): h.step(dt)
     out = h.download() + [h.get("pp")]
-    h.profile(False); ncorr = h.profile_stats().get("correc_updatep", (0, 0.))[0]; h.close()
+    h.profile(False); ncorr = (h.profile_stats().get("correc_updatep", (0, 0.))[0] + h.profile_stats().get("correc", (0, 0.))[0]); h.close()
     return out, dt, ncorr
 
 
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
-    name = ("tgv_ppp", "cavity_nnn", "chan_nosgs", "halfchan_nosgs")[trial % 4]
+    name = ("tgv_ppp", "cavity_nnn", "chan_nosgs", "halfchan_nosgs", "chan_nosgs_imp1d", "halfchan_imp1d")[trial % 6]
     P = int(rng.choice([1, 1, 1, 2, 3, 4]))
     n2l = int(rng.randint(2, 22)); n2l += (n2l * P) % 2      # (ng(2) even, sanity.f90)
     n1 = int(rng.choice([16, 32, 64, 128, 192])) if rng.rand() < 0.6 else 2 * int(rng.randint(4, 80))
@@ -62,7 +62,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
                 for _ in range(nsteps): h.step(dt)
                 out = h.download()
                 h.profile(False)
-                return out + [h.lo, h.n, h.profile_stats().get("correc_updatep", (0, 0.))[0]]
+                return out + [h.lo, h.n, (h.profile_stats().get("correc_updatep", (0, 0.))[0] + h.profile_stats().get("correc", (0, 0.))[0])]
             res = run_loopback(case, P, body)
             folded = all(r_[7] == (1 if 'CALES_LAZY_PROJECTION' in chosen else nsteps) for r_ in res)
             errs = []
