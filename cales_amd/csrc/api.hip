@@ -448,14 +448,15 @@ static int step_body(cales_ctx *c, real dt) {
   // dynamic model, one rank, x and y periodic (|S|Sij as pair fields), z periodic or two no-slip walls, explicit diffusion, no wall model: the
   // projection u = u* - dtrk grad(pp) (+ the deferred forcing) and p += pp are folded into the strain-rate pass of cmpt_sgs, which reads the velocity
   // anyway -- the correction pass (9 words per cell) disappears (dsmag_fast, k_strain_tile<.., CORR = 1>)
-  bool fold_correc = c->step_xskip && c->C.sgstype == 2 && c->C.impdiff == 0 && dsmag_pairs(c) && !c->fl.unfolded_correc && !c->fl.unfused_correc && !c->fl.dsmag_store_uc && c->n[0] % 64 == 0;      // (whole 64-cell tiles in x)
+  bool fold_correc = c->step_xskip && c->C.sgstype == 2 && c->C.impdiff == 0 && dsmag_pairs(c) && !c->fl.unfolded_correc && !c->fl.unfused_correc && c->n[0] % 64 == 0;      // (whole 64-cell tiles in x)
   { const bool perz = CBV(c, 0, 3, 3) == 'P' && CBV(c, 1, 3, 3) == 'P';
     bool walls = true;
     for (int iv = 1; iv <= 3; ++iv) for (int sd = 0; sd <= 1; ++sd) walls = walls && CBV(c, sd, 3, iv) == 'D';
     walls = walls && CBP(c, 0, 3) == 'N' && CBP(c, 1, 3) == 'N';
     fold_correc = fold_correc && (perz || walls);
     // several slabs: the pass reaches the companion field of pp with 32-bit offsets (two fields under 4 GB), exchanges through the slab hooks
-    if (c->P > 1) fold_correc = fold_correc && c->comm.on && 2 * (c->ntot + 2 * LINE_REALS) * sizeof(real) < (1ull << 32); }
+    // (at least two rows per slab: row 2 goes to the companion field BEFORE the exchange, and with one row per slab "row 2" is the stale ghost row n2+1)
+    if (c->P > 1) fold_correc = fold_correc && c->comm.on && c->n[1] >= 2 && 2 * (c->ntot + 2 * LINE_REALS) * sizeof(real) < (1ull << 32); }
   // no subgrid model, explicit diffusion, no wall model, every direction periodic or between no-slip walls with homogeneous Neumann
   // pressure (Taylor-Green, channels, cavities without a model): the projection and pressure update of substeps 1 and 2 are applied by the momentum
   // pass of the NEXT substep while it loads its planes (k_momrk<.., CORR = 1>) -- between the two the fields hold the prediction, whose ghost cells
@@ -511,7 +512,9 @@ static int step_body(cales_ctx *c, real dt) {
     } else
     if (int e = op_boundp(c, c->f[CALES_PP], 0)) return e;
     if (fold_correc) c->fold_dtrk = dtrk;      // correc, bounduvw, updatep, boundp(p): inside the cmpt_sgs below (dsmag_fast)
-    else if (fold_mom && (irk < 3 || (!c->fl.eager_projection && (c->fl.lazy_projection || (c->P == 1 && (size_t)c->n[0] * c->n[1] * c->n[2] >= ((size_t)1 << 22)))))) {
+    else if (fold_mom && (irk < 3 || (!c->fl.eager_projection && c->P == 1 && (c->fl.lazy_projection || (size_t)c->n[0] * c->n[1] * c->n[2] >= ((size_t)1 << 22))))) {
+      // (several slabs: the THIRD substep's projection is never left pending -- completing it moves slab rows, which would turn every rank-local entry of
+      //  the C-ABI, cales_get_field on rank 0 for one, into a collective that blocks until the other ranks call something; CALES_LAZY_PROJECTION is ignored there)
       // the ghost cells of the projected velocity now (through the corrected view), its interior cells and p + pp in the next momentum pass -- the next
       // substep's, or after the third substep the next step's (finish_pending for every other entry of the C-ABI)
       c->fold_mom_fmask = c->defer_force ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;

@@ -68,7 +68,7 @@ struct Spec {
 
 // Run-time switches: read from the environment ONCE, by cales_create; the launch path only looks at these fields.
 struct Flags {
-  bool unfolded_correc = false, unfolded_mom = false, eager_projection = false, lazy_projection = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_eager = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, unfused_rk = false, dsmag_unfused_filter = false, overlap = false, dsmag_store_uc = false, dsmag_unpaired = false, xghosts_in_step = false, unmerged_bc = false, plain_grid = false, band_grid = false;
+  bool unfolded_correc = false, unfolded_mom = false, eager_projection = false, lazy_projection = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, unfused_rk = false, dsmag_unfused_filter = false, overlap = false, xghosts_in_step = false, unmerged_bc = false;
   int kchunk = 0; long tile_min_blocks = 2048;
   std::string test_bad_launch;      // CALES_TEST_BAD_LAUNCH: test hook of the launch check (LAUNCH below)
   void read_env() {
@@ -86,15 +86,10 @@ struct Flags {
     keep_last_rhs = getenv("CALES_KEEP_LAST_RHS") != nullptr;
     wide_offsets = getenv("CALES_WIDE_OFFSETS") != nullptr;
     dsmag_reference_sequence = getenv("CALES_DSMAG_REFERENCE_SEQUENCE") != nullptr;
-    dsmag_eager = getenv("CALES_DSMAG_EAGER") != nullptr;
     dsmag_xghosts = getenv("CALES_DSMAG_XGHOSTS") != nullptr;
-    dsmag_store_uc = getenv("CALES_DSMAG_STORE_UC") != nullptr;      // K_AC stores the cell-centred velocity (three fields) instead of the last pass forming it
     smag_reference_sequence = getenv("CALES_SMAG_REFERENCE_SEQUENCE") != nullptr;
-    plain_grid = getenv("CALES_PLAIN_GRID") != nullptr;
-    band_grid = getenv("CALES_BAND_GRID") != nullptr;
     gaussel_march = getenv("CALES_GAUSSEL_MARCH") != nullptr;
     fft_generic = getenv("CALES_FFT_GENERIC") != nullptr;
-    dsmag_unpaired = getenv("CALES_DSMAG_UNPAIRED") != nullptr;      // dynamic model: |S|Sij as six fields instead of three fields of pairs
     xghosts_in_step = getenv("CALES_XGHOSTS_IN_STEP") != nullptr;      // keep the x ghost columns up to date after every operator of cales_step
     keep_null_mode = getenv("CALES_KEEP_NULL_MODE") != nullptr;
     unfused_rk = getenv("CALES_UNFUSED_RK") != nullptr;

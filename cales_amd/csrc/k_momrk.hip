@@ -280,7 +280,7 @@ int op_momrk(cales_ctx *c, real f1, real f2, real f12) {
   if (int fk = tile_kchunk(c, (long)gr.x * gr.y, n[2])) kchunk = fk;
   gr.z = (n[2] + kchunk - 1) / kchunk; A.kchunk = kchunk;
   A.bm = BandMap{0, 0, 0, 0};
-  if (!c->fl.plain_grid && (band_wanted(gr.x) || c->fl.band_grid)) { A.bm = band_map(gr.x, gr.y, gr.z); gr = dim3(band_blocks(A.bm), 1, 1); }
+  if (band_wanted(gr.x)) { A.bm = band_map(gr.x, gr.y, gr.z); gr = dim3(band_blocks(A.bm), 1, 1); }
   const bool small = (c->ntot + 16) * sizeof(real) < (1ull << 32) && !c->fl.wide_offsets;      // 32-bit byte offsets
   const int nos = c->C.sgstype == 0 && c->visct_zero;     // visct known to be identically zero (never set by the host since the last zeroing)
 #define MOMRK_L2(IMP_, RD_, WR_)                                                                                      \
@@ -299,6 +299,10 @@ int op_momrk(cales_ctx *c, real f1, real f2, real f12) {
   const bool pdone = corr && c->fold_mom_pdone;      // the pressure was updated by a pass of its own (z-implicit diffusion): velocity only (CORR = 2)
   if (corr) {
     if (!(nos && ((c->C.impdiff == 0 && !pdone) || (c->C.impdiff == 2 && pdone)))) { c->err = "momrk: a pending projection needs the no-subgrid-model form, explicit or z-implicit"; return 1; }
+    // periodic rows read without ghost columns: lane 63 of the last tile takes pp(i+1) from its right-halo lane, which has a cell of its own only while the
+    // wrapped column n1+1 is not lane 63 itself -- rows shorter than a tile or whole tiles. step_xskip implies the radix-8 x plan (a power of two,
+    // solver_can_fuse_fillps), so nothing reaches this today; the kernel's assumption is enforced here rather than left to that coincidence
+    if (A.perx && n[0] % 64 == 63) { c->err = "momrk: the folded projection with wrapped x columns needs n1 % 64 != 63"; return 1; }
 #define MOMRK_CORR(IMP_, CORR_, RD_, WR_) do { if (small) LAUNCH(c, (k_momrk<IMP_, unsigned, 1, RD_, WR_, CORR_>), gr, b, 0, c->stream, c->g, A); else LAUNCH(c, (k_momrk<IMP_, size_t, 1, RD_, WR_, CORR_>), gr, b, 0, c->stream, c->g, A); } while (0)
 #define MOMRK_CORR4(IMP_, CORR_) do { if (A.rd_old && A.wr_new) MOMRK_CORR(IMP_, CORR_, 1, 1); else if (A.rd_old) MOMRK_CORR(IMP_, CORR_, 1, 0); else if (A.wr_new) MOMRK_CORR(IMP_, CORR_, 0, 1); else MOMRK_CORR(IMP_, CORR_, 0, 0); } while (0)
     if (pdone) MOMRK_CORR4(2, 2); else MOMRK_CORR4(0, 1);

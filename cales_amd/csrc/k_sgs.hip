@@ -1304,7 +1304,7 @@ static bool dsmag_fast_ok(const cales_ctx *c) {
 // |S|Sij as three fields of pairs between K_AC and the fused last pass: x and y periodic (the one-launch ghost-cell kernel takes a pair field as a
 // field of twice the width), the cell-centred velocity formed by the last pass, 32-bit byte offsets still enough for a field twice as long
 bool dsmag_pairs(const cales_ctx *c) {
-  if (c->C.sgstype != 2 || !dsmag_fast_ok(c) || c->fl.dsmag_unfused_filter || c->fl.dsmag_unpaired || c->fl.dsmag_xghosts || c->fl.wide_offsets || c->fl.unmerged_bc) return false;
+  if (c->C.sgstype != 2 || !dsmag_fast_ok(c) || c->fl.dsmag_unfused_filter || c->fl.dsmag_xghosts || c->fl.wide_offsets || c->fl.unmerged_bc) return false;
   for (int q = 0; q < 4; ++q) if (c->C.cbcpre[q] != 'P') return false;
   const bool perz = c->C.cbcpre[4] == 'P' && c->C.cbcpre[5] == 'P';
   if (!perz && !(c->is_wall[4] != 0. && c->is_wall[5] != 0.)) return false;      // z: periodic, or two walls (whose ghost planes the filters never read)
@@ -1336,11 +1336,11 @@ static int dsmag_fast(cales_ctx *c) {
   dim3 mb, mg; int kch;
   const bool small = (c->ntot + 16) * sizeof(real) < (1ull << 32) && !c->fl.wide_offsets;      // 32-bit byte offsets (ldb/stb)
   // lazy form (homogeneous sgs BCs): |S| goes straight into the eddy-viscosity field and the last pass only makes the n3 plane coefficients
-  bool lazy = !c->fl.dsmag_eager;
+  bool lazy = true;
   for (int q = 0; q < 6; ++q) lazy = lazy && c->C.bcsgs[q] == 0.;
   // the cell-centred velocity is not stored where the last pass can form it itself (k_lmf_tile<.., UCF = 1>): x periodic, z walls or periodic
   const bool perz = CBP(c, 0, 3) == 'P' && CBP(c, 1, 3) == 'P';
-  const bool ucf = !c->fl.dsmag_unfused_filter && !c->fl.dsmag_store_uc && CBP(c, 0, 1) == 'P' && CBP(c, 1, 1) == 'P' && !c->fl.dsmag_xghosts && ((zlo && zhi) || perz);
+  const bool ucf = !c->fl.dsmag_unfused_filter && CBP(c, 0, 1) == 'P' && CBP(c, 1, 1) == 'P' && !c->fl.dsmag_xghosts && ((zlo && zhi) || perz);
   // K_AC: |S|, |S|Sij, cell-centred and test-filtered velocity in one pass over u,v,w (no wall-model faces ->
   // extrapolate(...,lwm) is a no-op; u,v are extrapolated through the z walls, w on the faces is not, sgs.f90:705-710)
   const bool fold = c->fold_dtrk != 0. && pair && ucf;      // (cales_step decides; pair fields and the cell-centred velocity formed by the last pass: the instantiation that exists)
@@ -1355,7 +1355,7 @@ static int dsmag_fast(cales_ctx *c) {
     S.dzci = c->d_dzci; S.dzfi = c->d_dzfi; S.dxi = c->dli[0]; S.dyi = c->dli[1]; S.kchunk = kch; S.zlo = zlo; S.zhi = zhi; S.wmlo = wmlo; S.wmhi = wmhi; S.flo = flo; S.fhi = fhi;
     S.wylo = wylo; S.wyhi = wyhi; S.wmylo = wmylo; S.wmyhi = wmyhi; S.twy = nullptr; S.dl2 = c->dl[1];
     S.bm = BandMap{0, 0, 0, 0}; S.perx = c->step_xskip ? 1 : 0;
-    if (!c->fl.plain_grid && (band_wanted(mg.x) || c->fl.band_grid)) { S.bm = band_map(mg.x, mg.y, mg.z); mg = dim3(band_blocks(S.bm), 1, 1); }
+    if (band_wanted(mg.x)) { S.bm = band_map(mg.x, mg.y, mg.z); mg = dim3(band_blocks(S.bm), 1, 1); }
     if (fold) {      // the projection of this substep is pending (cales_step): corrected velocity on load, u, v, w to the second buffers, p += pp
       S.pp = f[CALES_PP]; S.p = f[CALES_P]; for (int q = 0; q < 3; ++q) S.un[q] = c->f2[q];
       S.force = c->d_force; S.fmask = c->defer_force ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;
@@ -1432,7 +1432,7 @@ static int dsmag_fast(cales_ctx *c) {
       if (nby <= 0) return;
       B.by0 = by0; B.gx = mg.x; dim3 gg(mg.x, nby, mg.z);
       B.bm = BandMap{0, 0, 0, 0};
-      if (!c->fl.plain_grid && (band_wanted(mg.x) || c->fl.band_grid)) { B.bm = band_map(mg.x, nby, mg.z); gg = dim3(band_blocks(B.bm), 1, 1); }
+      if (band_wanted(mg.x)) { B.bm = band_map(mg.x, nby, mg.z); gg = dim3(band_blocks(B.bm), 1, 1); }
       const bool yw = wylo || wyhi || wmylo || wmyhi;
 #define LMF_LAUNCH(YWV, UCV) do { if (small) LAUNCH(c, (k_lmf_tile<unsigned, YWV, UCV>), gg, mb, 0, c->stream, c->g, B); else LAUNCH(c, (k_lmf_tile<size_t, YWV, UCV>), gg, mb, 0, c->stream, c->g, B); } while (0)
       if (pair) { if (ucf) LAUNCH(c, (k_lmf_tile<unsigned, 0, 1, 1>), gg, mb, 0, c->stream, c->g, B); else LAUNCH(c, (k_lmf_tile<unsigned, 0, 0, 1>), gg, mb, 0, c->stream, c->g, B); }

@@ -132,7 +132,10 @@ int cales_out2d_duct(cales_ctx *ctx, cales_real *buf);
 /* one time step = 3 RK substeps in the order of src/main.f90:417-508; no host synchronisation.
  * Without subgrid model (explicit diffusion, periodic / no-slip directions) the LAST projection of the step may still be pending when this returns --
  * the next cales_step applies it in its first momentum pass; every other entry that reads or writes a field, cales_sync included, completes it first,
- * so what a caller can observe is always the projected state of src/main.f90:498-504 (CALES_EAGER_PROJECTION). */
+ * so what a caller can observe is always the projected state of src/main.f90:498-504 (CALES_EAGER_PROJECTION). ONE RANK ONLY: on several
+ * slabs completing a projection moves slab rows, so cales_step always completes it itself and no entry is a hidden collective. Three entries do not
+ * complete a pending projection because they read no field: cales_get_forcing, cales_get_dpdl (scalars accumulated by the step) and cales_get_bcvel
+ * (boundary planes the projection does not touch). */
 int cales_step(cales_ctx *ctx, cales_real dt);
 int cales_get_dpdl(cales_ctx *ctx, cales_real dpdl[3]);                         /* main.f90:492,508 (sync) */
 

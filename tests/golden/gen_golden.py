@@ -87,6 +87,13 @@ END_ONLY = {
     "tgv_ppp_p2": ("dns/triperiodic/input.nml",
                    {r"ng\(1:3\) = .*": "ng(1:3) = 32, 16, 16", r"l\(1:3\) = .*": "l(1:3) = 6.283185307179586, 6.283185307179586, 6.283185307179586",
                     r"visci = .*": "visci = 1600.", r"inivel = .*": "inivel = 'tgv'"}, 0),
+    # rows of 64 cells = one whole tile in x: the only row lengths at which the dynamic model's strain-rate pass takes the projection on load
+    # (k_corr_strain_tile, api.hip `fold_correc`: n1 % 64 == 0) -- the dominant kernel of the 512^3 bench
+    "chan_dsmag_x64": ("les/_manuscript_turbulent_channel/input.nml",
+                       {r"ng\(1:3\) = .*": "ng(1:3) = 64, 16, 12", r"gr = 5\.": "gr = 2.", r"sgstype = 'smag'": "sgstype = 'dsmag'"}, 0),
+    "tgv_dsmag_ppp_x64": ("dns/triperiodic/input.nml",
+                          {r"ng\(1:3\) = .*": "ng(1:3) = 64, 16, 16", r"l\(1:3\) = .*": "l(1:3) = 6.283185307179586, 6.283185307179586, 6.283185307179586",
+                           r"visci = .*": "visci = 1600.", r"inivel = .*": "inivel = 'tgv'", r"sgstype = 'none'": "sgstype = 'dsmag'"}, 0),
 }
 END_KEYS = ("input_nml", "impdiff", "dt", "dt_cfl", "dpdl", "r3_div", "s0raw_u", "s0raw_v", "s0raw_w", "s0raw_p", "r3_s7_u", "r3_s7_v", "r3_s7_w", "r3_s8_p", "r3_s9_visct")
 CASES.update(END_ONLY)

@@ -100,6 +100,53 @@ def test_slab_ranks_match_single_rank(name, ng, P):
     assert relerr(pg[1:-1, :, 1:-1] - pg[1:-1, :, 1:-1].mean(), pref[1:-1, :, 1:-1] - pref[1:-1, :, 1:-1].mean()) < 1e-9
 
 
+@pytest.mark.parametrize("lazy", [False, True], ids=["eager", "lazy-ignored"])
+@pytest.mark.parametrize("name,ng,P", [("chan_nosgs", (64, 24, 16), 2), ("chan_nosgs", (32, 24, 12), 3), ("cavity_nnn", (32, 16, 12), 2), ("cavity_nnn", (16, 24, 12), 3)])
+def test_slab_ranks_projection_folded_into_the_momentum_pass(name, ng, P, lazy, monkeypatch):
+    """No subgrid model on several slabs: the projection of substeps 1 and 2 is applied by the next momentum pass on every slab (k_momrk<.., CORR = 1>:
+    the p + pp store, the P / scr1 swap, the pressure's ghost rows riding with the prediction's bounduvw). Compared with the ONE-rank run with the separate
+    correction pass: velocity, p (mean removed) AND pp, x and z ghost cells included. The third substep's projection is never left pending on several
+    slabs -- completing it would make every later entry a collective --, so CALES_LAZY_PROJECTION changes nothing there: one correction pass per step and
+    rank either way, and a download that only rank 0 makes returns."""
+    from cales_amd.decomp import run_loopback
+    from cales_amd.hotpath import HotPath, initflow
+    from tests.test_gpu_golden import _nosgs_case
+    case = _nosgs_case(name, ng)
+    nsteps = 2
+
+    def perturbed():
+        u, v, w, p = initflow(case); r2 = np.random.RandomState(1)
+        for a in (u, v, w): a[1:-1, 1:-1, 1:-1] += 0.02 * (r2.rand(*ng) - 0.5)
+        return u, v, w, p
+    monkeypatch.setenv("CALES_UNFOLDED_MOM", "1")
+    h = HotPath(case); h.upload(*perturbed()); h.startup(); dt = 0.5 * h.chkdt()
+    for _ in range(nsteps): h.step(dt)
+    ref = h.download() + [h.get("pp")]; h.close()
+    monkeypatch.delenv("CALES_UNFOLDED_MOM")
+    if lazy:
+        monkeypatch.setenv("CALES_LAZY_PROJECTION", "1")
+
+    def body(h, r):
+        h.upload_global(*perturbed()); h.startup()
+        h.profile(True)
+        for _ in range(nsteps): h.step(dt)
+        h.profile(False); st = h.profile_stats()
+        ncorr = st.get("correc_updatep", (0, 0.))[0] + st.get("correc", (0, 0.))[0]
+        local = h.get("u") if r == 0 else None      # rank-local: the other ranks are not inside the library while this runs
+        return h.download() + [h.get("pp"), h.lo, h.n, ncorr, local]
+    res = run_loopback(case, P, body)
+    for r, R in enumerate(res):
+        sl = slice(R[6][1], R[6][1] + R[7][1])
+        assert R[8] == nsteps, (r, R[8])
+        for q, nm in ((0, "u"), (1, "v"), (2, "w")):
+            assert relerr(R[q][:, 1:-1, :], ref[q][:, sl, :]) < 1e-10, (r, nm)
+    assert relerr(res[0][9][:, 1:-1, :], ref[0][:, 1:res[0][7][1] + 1, :]) < 1e-10
+    for q, a, nm in ((3, 3, "p"), (5, 5, "pp")):
+        d = np.concatenate([R[q][:, 1:-1, :] - ref[a][:, R[6][1]:R[6][1] + R[7][1], :] for R in res], axis=1)
+        d = d - d[1:-1, :, 1:-1].mean()
+        assert np.abs(d).max() < 1e-9 * np.abs(ref[a] - ref[a][1:-1, 1:-1, 1:-1].mean()).max(), nm
+
+
 @pytest.mark.parametrize("name,ng,P", SLAB_CASES)
 def test_slab_ranks_overlapped_event_ordered(name, ng, P, monkeypatch):
     """CALES_OVERLAP=1: the exchanges of the Poisson solve (k-chunks) and the y halos of the dynamic model's scratch fields run on the library's
@@ -131,11 +178,12 @@ def test_slab_ranks_in_order_exchanges(name, ng, P, monkeypatch):
 @pytest.mark.parametrize("name,ng,P", [("chan_dsmag", (64, 32, 24), 4), ("duct_dsmag_wm", (32, 32, 32), 2), ("tgv_dsmag_ppp", (32, 24, 16), 3)])
 def test_slab_ranks_batched_scratch_field_exchange(name, ng, P, events, monkeypatch):
     """The dynamic model's ghost-cell calls queue their rows and one exchange follows (in order): eleven fields when the last pass forms the cell-centred
-    velocity itself, thirteen = two exchanges (twelve + one) when K_AC stores it (CALES_DSMAG_STORE_UC); plain and event-ordered emulation."""
+    velocity itself, thirteen = two exchanges (twelve + one) when K_AC stores it (here through CALES_DSMAG_XGHOSTS, which also turns the pair fields off); plain and
+    event-ordered emulation."""
     if events:
         monkeypatch.setenv("CALES_LOOPBACK_EVENTS", "1")
     test_slab_ranks_match_single_rank(name, ng, P)
-    monkeypatch.setenv("CALES_DSMAG_STORE_UC", "1")
+    monkeypatch.setenv("CALES_DSMAG_XGHOSTS", "1")
     test_slab_ranks_match_single_rank(name, ng, P)
 
 
@@ -151,9 +199,9 @@ def test_slab_ranks_smag_reference_sequence(name, ng, P, monkeypatch):
 def test_slab_ranks_with_switch_combinations(name, ng, P, seed, monkeypatch):
     """Several slabs with three to five run-time switches at once (fixed seeds; overlap on for every other one): same bar as the plain slab test."""
     rng = np.random.RandomState(2000 + seed)
-    pool = ["CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFOLDED_CORREC", "CALES_UNFOLDED_MOM", "CALES_LAZY_PROJECTION", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_DSMAG_EAGER", "CALES_GAUSSEL_MARCH",
-            "CALES_DSMAG_XGHOSTS", "CALES_WIDE_OFFSETS", "CALES_DSMAG_UNFUSED_FILTER", "CALES_UNMERGED_BC", "CALES_DSMAG_STORE_UC",
-            "CALES_XGHOSTS_IN_STEP", "CALES_BAND_GRID", "CALES_FFT_GENERIC", "CALES_HELMHOLTZ_Z_PER_COLUMN", "CALES_UNFUSED_IMP_RHS"]
+    pool = ["CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFOLDED_CORREC", "CALES_UNFOLDED_MOM", "CALES_LAZY_PROJECTION", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_GAUSSEL_MARCH",
+            "CALES_DSMAG_XGHOSTS", "CALES_WIDE_OFFSETS", "CALES_DSMAG_UNFUSED_FILTER", "CALES_UNMERGED_BC",
+            "CALES_XGHOSTS_IN_STEP", "CALES_FFT_GENERIC", "CALES_HELMHOLTZ_Z_PER_COLUMN", "CALES_UNFUSED_IMP_RHS"]
     for k in rng.choice(pool, size=rng.randint(3, 6), replace=False):
         monkeypatch.setenv(str(k), "1")
     if seed % 2:

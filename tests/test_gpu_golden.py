@@ -2,6 +2,8 @@
 compiled operators. Same stage-by-stage replay as tests/test_oracle_golden.py: every operator is fed
 the golden input of its stage. FP64 tolerance 1e-13 relative (L-inf, scaled by the field maximum);
 the kernels keep the reference's expression order but are compiled with FMA contraction."""
+import os
+
 import numpy as np
 import pytest
 
@@ -137,13 +139,41 @@ def test_fused_step_matches_operator_sequence(name):
 
 
 @pytest.mark.parametrize("keep_x", [False, True], ids=["wrap", "xghosts"])
-@pytest.mark.parametrize("name", ["chan_dsmag_p2", "chan_smag_p2", "duct_dsmag_p2", "tgv_ppp_p2"])
+@pytest.mark.parametrize("name", ["chan_dsmag_p2", "chan_smag_p2", "duct_dsmag_p2", "tgv_ppp_p2", "chan_dsmag_x64", "tgv_dsmag_ppp_x64"])
 def test_fused_step_at_power_of_two_rows(name, keep_x, monkeypatch):
     """Reference-made end-of-step states at power-of-two row lengths: radix-8 transforms, fillps inside the forward x pass, the x ghost columns left
     alone until the step returns (and, with CALES_XGHOSTS_IN_STEP, updated by every ghost-cell operator as at the operator level)."""
     if keep_x:
         monkeypatch.setenv("CALES_XGHOSTS_IN_STEP", "1")
     test_fused_step_matches_operator_sequence(name)
+
+
+@pytest.mark.parametrize("folded", [True, False], ids=["folded", "separate"])
+@pytest.mark.parametrize("name", ["chan_dsmag_x64", "tgv_dsmag_ppp_x64"])
+def test_folded_strain_pass_against_reference_made_state(name, folded, monkeypatch):
+    """Reference-made end-of-step states (src/sgs.f90:153-380 + src/correc.f90:44-67 + src/updatep.f90:30-47 through the compiled modules,
+    gen_golden.py END_ONLY) at rows of 64 cells, the only row lengths at which the dynamic model's strain-rate pass takes the projection on load
+    (k_corr_strain_tile, the dominant kernel of the 512^3 bench: api.hip `fold_correc` asks for whole 64-cell tiles in x). The profile counters
+    say which kernels ran: the folded pass in every substep and no correction pass of its own -- or, with CALES_UNFOLDED_CORREC, the opposite."""
+    if not folded:
+        monkeypatch.setenv("CALES_UNFOLDED_CORREC", "1")
+    g, case = load_golden(name)
+    h = _hot(case)
+    h.upload(*(F(g["s0raw_" + k]) for k in "uvwp")); h.startup()
+    h.profile(True)
+    h.step(float(g["dt"]))
+    u, v, w, p, visct = h.download()
+    h.profile(False); st = h.profile_stats()
+    nfold, ncorr = st.get("correc_strain_filter_uvw", (0, 0.))[0], st.get("correc_updatep", (0, 0.))[0]
+    assert (nfold, ncorr) == ((3, 0) if folded else (0, 3)), st
+    for a, k in zip((u, v, w), "uvw"):
+        assert relerr(a, g["r3_s7_" + k]) < 1e-10, k
+    pg = g["r3_s8_p"]
+    assert relerr(p - p[1:-1, 1:-1, 1:-1].mean(), pg - pg[1:-1, 1:-1, 1:-1].mean()) < 1e-9
+    assert relerr(visct, g["r3_s9_visct"]) < 1e-8
+    assert np.abs(h.dpdl() - g["dpdl"]).max() < 1e-9 * max(1., np.abs(g["dpdl"]).max())
+    assert h.chkdiv()[1] < 1e-12
+    h.close()
 
 
 @pytest.mark.parametrize("name", ["chan_dsmag", "duct_smag_wm_imp1d"])
@@ -154,8 +184,8 @@ def test_wide_offset_kernels(name, monkeypatch):
     test_fused_step_matches_operator_sequence(name)
 
 
-@pytest.mark.parametrize("env", ["CALES_DSMAG_REFERENCE_SEQUENCE", "CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_GAUSSEL_MARCH", "CALES_DSMAG_EAGER", "CALES_KEEP_LAST_RHS",
-                                 "CALES_DSMAG_UNFUSED_FILTER", "CALES_UNMERGED_BC", "CALES_BAND_GRID", "CALES_PLAIN_GRID"])
+@pytest.mark.parametrize("env", ["CALES_DSMAG_REFERENCE_SEQUENCE", "CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_GAUSSEL_MARCH", "CALES_KEEP_LAST_RHS",
+                                 "CALES_DSMAG_UNFUSED_FILTER", "CALES_UNMERGED_BC"])
 @pytest.mark.parametrize("name", ["chan_dsmag", "chan_dsmag_wm", "tgv_dsmag_ppp", "duct_smag_wm_imp1d", "duct_dsmag_wm"])
 def test_unfused_paths(name, env, monkeypatch):
     """The kernel-per-loop forms behind the operator-level entries (general dsmag sequence, mom + rk_update, correc +
@@ -176,13 +206,10 @@ SWITCH_CASES = [
     ({"CALES_KCHUNK": "5"}, ["chan_smag_wm", "duct_smag_wm"]),
     ({"CALES_TILE_MIN_BLOCKS": "1000000"}, ["chan_dsmag", "duct_smag_wm_imp1d"]),
     ({"CALES_TILE_MIN_BLOCKS": "1"}, ["chan_dsmag", "duct_smag_wm_imp1d"]),
-    # dynamic model: K_AC stores the cell-centred velocity instead of the last pass forming it from u, v, w (ducts: the YW instantiations)
-    ({"CALES_DSMAG_STORE_UC": "1"}, ["chan_dsmag", "chan_dsmag_wm", "tgv_dsmag_ppp", "duct_dsmag_wm", "duct_dsmag"]),
-    # dynamic model: |S|Sij as six scalar fields between K_AC and the last pass instead of three fields of pairs (the default where x and y are periodic)
-    ({"CALES_DSMAG_UNPAIRED": "1"}, ["chan_dsmag", "chan_dsmag_wm", "tgv_dsmag_ppp", "chan_dsmag_p2"]),
-    # dynamic model inside cales_step: the projection as a pass of its own (k_correc_cell) instead of inside the strain-rate pass (the default on one rank
-    # with x and y periodic; chan_dsmag_p2 / tgv_dsmag_ppp at power-of-two rows take the folded form by default, see test_step_at_power_of_two_rows)
-    ({"CALES_UNFOLDED_CORREC": "1"}, ["chan_dsmag", "chan_dsmag_p2", "tgv_dsmag_ppp"]),
+    # dynamic model inside cales_step: the projection as a pass of its own (k_correc_cell) instead of inside the strain-rate pass. The folded form needs
+    # rows that are whole 64-cell tiles (api.hip `fold_correc`), so of the golden cases only chan_dsmag_x64 / tgv_dsmag_ppp_x64 take it by default
+    # (test_folded_strain_pass_against_reference_made_state asserts which kernels ran); on the shorter rows here the switch only has to be harmless
+    ({"CALES_UNFOLDED_CORREC": "1"}, ["chan_dsmag", "chan_dsmag_p2", "tgv_dsmag_ppp", "chan_dsmag_x64"]),
     # no subgrid model inside cales_step: the projection of every substep as a pass of its own instead of inside the next momentum pass (the default for
     # explicit diffusion with every direction periodic or between no-slip walls)
     ({"CALES_UNFOLDED_MOM": "1"}, ["tgv_ppp", "tgv_ppp_p2", "cavity_nnn"]),
@@ -441,4 +468,104 @@ def test_pending_projection_is_completed_by_every_entry_that_looks(monkeypatch):
     h.sync(); assert ncorr() == 1
     h.step(dt); h.step(dt); h.step(dt); assert ncorr() == 1      # three steps, each consuming its predecessor's projection
     assert h.chkdiv()[1] < 1e-12 and ncorr() == 2
+    h.profile(False); h.close()
+
+
+# ---- every entry of include/cales.h that takes a context, against a projection left pending by cales_step (api.hip ENTER / finish_pending) ----
+# entries that read or write no field (or are the consumer itself): they do not have to complete a pending projection
+_NO_FIELD_ENTRIES = {"cales_destroy", "cales_last_error", "cales_local_size", "cales_get_forcing", "cales_get_dpdl", "cales_get_bcvel", "cales_step",
+                     "cales_profile_enable", "cales_profile_reset", "cales_profile_count", "cales_profile_get", "cales_device_info",
+                     "cales_comm_buffer_doubles", "cales_set_comm", "cales_set_comm_overlap", "cales_comm_init_rccl"}
+
+
+def _entry_calls(h, dt):
+    """name -> a call of that entry with valid arguments on the context `h` (an explicit or z-implicit case without subgrid model)"""
+    import ctypes as C
+    from cales_amd import capi
+    L, H = h.L, h.h
+    z = lambda: h.zeros()
+    r1 = capi.c_real(0.)
+    n = h.n
+    st = np.zeros((27, n[2]), order="F"); bud = np.zeros((38, n[2]), order="F"); lk = np.zeros((6, n[2]), order="F")
+    o1 = np.zeros(n[2]); oc = np.zeros((7, n[2]), order="F"); od = np.zeros((9, n[1], n[2]), order="F")
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    rk = np.array([32. / 60., 0.]); f3 = np.zeros(3)
+    fld = [z() for _ in range(5)]
+    return {
+        "cales_sync": lambda: L.cales_sync(H),
+        "cales_upload_state": lambda: L.cales_upload_state(H, *[P(a) for a in fld[:4]]),
+        "cales_download_state": lambda: L.cales_download_state(H, *[P(a) for a in fld]),
+        "cales_set_field": lambda: L.cales_set_field(H, capi.FIELDS["p"], P(fld[0])),
+        "cales_get_field": lambda: L.cales_get_field(H, capi.FIELDS["u"], P(fld[0])),
+        "cales_bounduvw": lambda: L.cales_bounduvw(H, 1, 0),
+        "cales_boundp": lambda: L.cales_boundp(H, capi.FIELDS["p"], 0),
+        "cales_mom": lambda: L.cales_mom(H),
+        "cales_rk": lambda: L.cales_rk(H, 1, dt),
+        "cales_rk_par": lambda: L.cales_rk_par(H, P(rk), dt, P(f3)),
+        "cales_bulk_forcing": lambda: L.cales_bulk_forcing(H),
+        "cales_bulk_mean": lambda: L.cales_bulk_mean(H, capi.FIELDS["u"], 1, C.byref(r1)),
+        "cales_fillps": lambda: L.cales_fillps(H, 1. / dt),
+        "cales_updt_rhs_b": lambda: L.cales_updt_rhs_b(H),
+        "cales_solver": lambda: L.cales_solver(H),
+        "cales_helmholtz_z": lambda: L.cales_helmholtz_z(H, 1, -1e-4),
+        "cales_helmholtz": lambda: L.cales_helmholtz(H, 1, -1e-4),      # (refused without 3-D implicit diffusion -- AFTER the pending projection was completed)
+        "cales_correc": lambda: L.cales_correc(H, dt),
+        "cales_updatep": lambda: L.cales_updatep(H, 0.),
+        "cales_cmpt_sgs": lambda: L.cales_cmpt_sgs(H),
+        "cales_chkdt": lambda: L.cales_chkdt(H, C.byref(r1)),
+        "cales_chkdiv": lambda: L.cales_chkdiv(H, C.byref(r1), C.byref(capi.c_real(0.))),
+        "cales_out1d_single_point_chan": lambda: L.cales_out1d_single_point_chan(H, P(st)),
+        "cales_out1d_chan_budgets": lambda: L.cales_out1d_chan_budgets(H, P(bud), P(lk)),
+        "cales_out1d": lambda: L.cales_out1d(H, capi.FIELDS["u"], 3, 0, P(o1)),
+        "cales_out1d_chan": lambda: L.cales_out1d_chan(H, P(oc)),
+        "cales_out2d_duct": lambda: L.cales_out2d_duct(H, P(od)),
+    }
+
+
+def _header_ctx_entries():
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "cales.h")).read()
+    return sorted(set(re.findall(r"\b(cales_[a-z_0-9]+)\s*\(\s*(?:const\s+)?cales_ctx\s*\*", hdr)))
+
+
+@pytest.mark.parametrize("name", ["cavity_nnn", "chan_nosgs_imp1d"])
+def test_every_entry_sees_the_projected_state(name, monkeypatch):
+    """The pending-projection contract, mechanically (the state protected is src/main.f90:498-504): after a cales_step that leaves its
+    last projection to its successor, EVERY entry of include/cales.h that takes a context and reads or writes a field completes the projection before it
+    does anything else -- enumerated from the header, so an entry added later fails here until it is classified. Detected by the profile counters (one
+    correction pass appears), and by value: the velocity the entry leaves behind is divergence-free where the entry does not change it."""
+    from cales_amd.hotpath import HotPath, initflow
+    monkeypatch.setenv("CALES_LAZY_PROJECTION", "1")
+    case = _nosgs_case(name, (32, 16, 12))
+    entries = _header_ctx_entries()
+    assert "cales_sync" in entries and "cales_get_field" in entries and len(entries) > 40, entries
+    probe = HotPath(case); table = _entry_calls(probe, 1e-3); probe.close()
+    unclassified = [e for e in entries if e not in table and e not in _NO_FIELD_ENTRIES]
+    assert not unclassified, f"entries of include/cales.h without a rule for a pending projection: {unclassified}"
+    u0 = initflow(case)
+    for e in entries:
+        if e in _NO_FIELD_ENTRIES:
+            continue
+        h = HotPath(case); h.upload(*u0); h.startup(); dt = 0.5 * h.chkdt()
+        ncorr = lambda: sum(h.profile_stats().get(k, (0, 0.))[0] for k in ("correc_updatep", "correc"))
+        h.profile(True)
+        h.step(dt)
+        assert ncorr() == 0, (e, "the step was expected to leave its last projection pending")
+        rc = _entry_calls(h, dt)[e]()
+        assert ncorr() >= 1, (e, "did not complete the pending projection")
+        # (the two Helmholtz entries refuse a case without the matching implicit diffusion -- after the pending projection was completed)
+        assert rc == 0 or e == "cales_helmholtz" or (e == "cales_helmholtz_z" and case.impdiff != 2), (e, h.L.cales_last_error(h.h))
+        if e in ("cales_sync", "cales_get_field", "cales_download_state", "cales_chkdt", "cales_bulk_mean", "cales_boundp", "cales_out1d", "cales_out1d_chan", "cales_helmholtz"):
+            n1 = ncorr()
+            assert h.chkdiv()[1] < 1e-12, e      # what the entry saw was the projected velocity
+            assert ncorr() == n1, e              # ... and nothing was pending any more
+        h.profile(False); h.close()
+    # the entries that deliberately do not complete it leave it pending (and the next step still consumes it)
+    h = HotPath(case); h.upload(*u0); h.startup(); dt = 0.5 * h.chkdt()
+    ncorr = lambda: sum(h.profile_stats().get(k, (0, 0.))[0] for k in ("correc_updatep", "correc"))
+    h.profile(True); h.step(dt)
+    h.dpdl(); f = np.zeros(3); h._chk(h.L.cales_get_forcing(h.h, f.ctypes.data_as(__import__("ctypes").c_void_p))); h.bcvel_planes(1)
+    assert ncorr() == 0
+    h.step(dt); assert ncorr() == 0
+    assert h.chkdiv()[1] < 1e-12 and ncorr() == 1
     h.profile(False); h.close()

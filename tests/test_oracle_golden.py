@@ -214,7 +214,7 @@ def test_solver_operands_and_z_sweep(name):
                 assert np.array_equal(g[f"r{irk}_s1b_{k}"], g[f"r{irk}_s1b_{k}_orc"]), (irk, k)
 
 
-END_CASES = ["chan_dsmag_p2", "chan_smag_p2", "duct_dsmag_p2", "tgv_ppp_p2"]
+END_CASES = ["chan_dsmag_p2", "chan_smag_p2", "duct_dsmag_p2", "tgv_ppp_p2", "chan_dsmag_x64", "tgv_dsmag_ppp_x64"]
 
 
 @pytest.mark.parametrize("name", END_CASES)
