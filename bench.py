@@ -471,6 +471,19 @@ def main():
                     traffic = row["hbm_read_bytes"] + row["hbm_write_bytes"]; traffic_src = prof.get("source")
         except (OSError, ValueError, KeyError):
             pass
+        # ... and the kernel FURTHEST below the HBM roof among those that weigh at least 3 % of the step (the dominant kernel by time is also the best
+        # streaming pass of the step: its fraction alone hides where the headroom is)
+        tot_ms = sum(v[1] for v in leaf.values())
+        heavy = {k: v for k, v in leaf.items() if v[1] >= 0.03 * tot_ms}
+        frac_of = lambda k: WORDS[k] * RB * nloc / (leaf[k][1] / leaf[k][0] * 1e-3) / HBM_PEAK
+        worst = min(heavy, key=frac_of)
+        wtraffic = None
+        try:
+            for row in prof.get("kernels", []):
+                if row["kernel"].startswith(kmap.get(worst, "\0")) and "hbm_read_bytes" in row and prof.get("ncell") == ncell and world == 1:
+                    wtraffic = row["hbm_read_bytes"] + row["hbm_write_bytes"]
+        except (NameError, KeyError):
+            pass
         solve = SOLVE
         # cales_step folds fillps into the forward x pass (u,v,w in instead of pp): the pair fillps + solve is priced at its
         # compulsory 4 + 4 x 2 words (the separate passes: 4 + 10)
@@ -490,6 +503,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": ach / HBM_PEAK, "frac_of_guide_copy_rate": ach / HBM_COPY, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": WORDS[dom] * RB * nloc, "avg_launch_ms": ms / calls, "launches": calls},
+            "roofline_worst": {"bound": "hbm", "kernel": worst, "achieved": frac_of(worst) * HBM_PEAK / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                               "frac": frac_of(worst), "traffic": wtraffic, "algorithmic_bytes_per_launch": WORDS[worst] * RB * nloc,
+                               "avg_launch_ms": leaf[worst][1] / leaf[worst][0], "launches": leaf[worst][0], "share_of_kernel_time": leaf[worst][1] / tot_ms,
+                               "what": "the kernel furthest below the HBM roof among those with >= 3 % of the step's kernel time"},
             "poisson_solve": {"ms": solve_ms, "words_per_cell": solve_words, "passes": solve_note,
                               "algorithmic_GBps": solve_words * RB * nloc / (solve_ms * 1e-3) / 1e9 if solve_ms else None,
                               "frac_of_hbm_peak": solve_words * RB * nloc / (solve_ms * 1e-3) / HBM_PEAK if solve_ms else None,
