@@ -94,6 +94,14 @@ END_ONLY = {
     "tgv_dsmag_ppp_x64": ("dns/triperiodic/input.nml",
                           {r"ng\(1:3\) = .*": "ng(1:3) = 64, 16, 16", r"l\(1:3\) = .*": "l(1:3) = 6.283185307179586, 6.283185307179586, 6.283185307179586",
                            r"visci = .*": "visci = 1600.", r"inivel = .*": "inivel = 'tgv'", r"sgstype = 'none'": "sgstype = 'dsmag'"}, 0),
+    # static Smagorinsky at rows of 64 cells: the projection folded into the Smagorinsky pass (k_corr_smag_tile, k_smagfold.hip: whole 64-cell tiles in x)
+    # with a wall model on the z walls, on the four walls of a duct, and with z-implicit diffusion (the pressure update with the z Laplacian of pp)
+    "chan_smag_wm_x64": ("les/_manuscript_turbulent_channel_wall_model/input.nml",
+                         {r"ng\(1:3\) = .*": "ng(1:3) = 64, 16, 10", r"visci = .*": "visci = 5640."}, 0),
+    "duct_smag_wm_x64": ("les/_manuscript_turbulent_duct_wall_model/input.nml",
+                         {r"ng\(1:3\) = .*": "ng(1:3) = 64, 10, 10", r"hwm = 0\.1": "hwm = 0.25"}, 0),
+    "duct_smag_wm_imp1d_x64": ("les/_manuscript_turbulent_duct_wall_model/input.nml",
+                               {r"ng\(1:3\) = .*": "ng(1:3) = 64, 10, 12", r"hwm = 0\.1": "hwm = 0.25"}, 2),
 }
 END_KEYS = ("input_nml", "impdiff", "dt", "dt_cfl", "dpdl", "r3_div", "s0raw_u", "s0raw_v", "s0raw_w", "s0raw_p", "r3_s7_u", "r3_s7_v", "r3_s7_w", "r3_s8_p", "r3_s9_visct")
 CASES.update(END_ONLY)

@@ -214,7 +214,7 @@ def test_solver_operands_and_z_sweep(name):
                 assert np.array_equal(g[f"r{irk}_s1b_{k}"], g[f"r{irk}_s1b_{k}_orc"]), (irk, k)
 
 
-END_CASES = ["chan_dsmag_p2", "chan_smag_p2", "duct_dsmag_p2", "tgv_ppp_p2", "chan_dsmag_x64", "tgv_dsmag_ppp_x64"]
+END_CASES = ["chan_dsmag_p2", "chan_smag_p2", "duct_dsmag_p2", "tgv_ppp_p2", "chan_dsmag_x64", "tgv_dsmag_ppp_x64", "chan_smag_wm_x64", "duct_smag_wm_x64", "duct_smag_wm_imp1d_x64"]
 
 
 @pytest.mark.parametrize("name", END_CASES)
@@ -229,7 +229,10 @@ def test_step_at_power_of_two_rows(name):
     dpdl = o.step(float(g["dt"]), u, v, w, p, pp, visct)
     for a, k in zip((u, v, w), "uvw"):
         assert relerr(a, g["r3_s7_" + k]) < 1e-12, k
-    assert relerr(p, g["r3_s8_p"]) < 1e-11
+    # (the pressure's constant is the zero mode of the singular solve through the +eps pivot, solver.f90:165: defined by round-off, it moves with the
+    #  summation order of the run that made the vector -- compared after removing the mean where it does)
+    pg = g["r3_s8_p"]
+    assert relerr(p, pg) < 1e-11 or relerr(p - p[1:-1, 1:-1, 1:-1].mean(), pg - pg[1:-1, 1:-1, 1:-1].mean()) < 1e-11
     assert relerr(visct, g["r3_s9_visct"]) < 1e-10
     assert np.abs(dpdl - g["dpdl"]).max() < 1e-10 * max(1., np.abs(g["dpdl"]).max())
 
