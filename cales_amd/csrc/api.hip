@@ -463,10 +463,6 @@ static int step_body(cales_ctx *c, real dt) {
   // receive the projected values through the corrected view of the ghost-cell kernels. The correction pass (9 words per cell) runs once per step
   // instead of three times; substep 3 keeps it so that the step returns the projected fields.
   const bool fold_mom = !fold_correc && fold_mom_ok(c);
-  // static Smagorinsky (one rank, x periodic in whole 64-cell tiles, explicit or z-implicit diffusion, homogeneous pressure conditions; walls and wall
-  // models in y and z allowed): the projection and the pressure update are applied by the Smagorinsky pass while it loads its planes (k_corr_smag_tile);
-  // the ghost cells of the prediction -- wall model included -- receive their final values first, through the corrected view
-  const bool fold_smag = !fold_correc && !fold_mom && smag_fold_ok(c) && !c->sgs_first;
   for (int irk = 1; irk <= 3; ++irk) {
     const real dtrk = (rk[irk - 1][0] + rk[irk - 1][1]) * dt, dtrki = 1. / dtrk;
     real alpha = 0.;
@@ -516,15 +512,7 @@ static int step_body(cales_ctx *c, real dt) {
     } else
     if (int e = op_boundp(c, c->f[CALES_PP], 0)) return e;
     if (fold_correc) c->fold_dtrk = dtrk;      // correc, bounduvw, updatep, boundp(p): inside the cmpt_sgs below (dsmag_fast)
-    else if (fold_smag) {
-      c->fold_mom_fmask = c->defer_force ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;
-      c->defer_force = false;
-      c->bc_view_dtrk = dtrk;
-      const int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 1, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W]);
-      c->bc_view_dtrk = 0.;
-      if (e) { c->fold_mom_fmask = 0; return e; }
-      c->fold_dtrk = dtrk; c->fold_alpha = alpha;      // correc, updatep, boundp(p): inside the cmpt_sgs below (op_smag_fold)
-    } else if (fold_mom && (irk < 3 || (!c->fl.eager_projection && c->P == 1 && (c->fl.lazy_projection || (size_t)c->n[0] * c->n[1] * c->n[2] >= ((size_t)1 << 22))))) {
+    else if (fold_mom && (irk < 3 || (!c->fl.eager_projection && c->P == 1 && (c->fl.lazy_projection || (size_t)c->n[0] * c->n[1] * c->n[2] >= ((size_t)1 << 22))))) {
       // (several slabs: the THIRD substep's projection is never left pending -- completing it moves slab rows, which would turn every rank-local entry of
       //  the C-ABI, cales_get_field on rank 0 for one, into a collective that blocks until the other ranks call something; CALES_LAZY_PROJECTION is ignored there)
       // the ghost cells of the projected velocity now (through the corrected view), its interior cells and p + pp in the next momentum pass -- the next
@@ -543,7 +531,7 @@ static int step_body(cales_ctx *c, real dt) {
       c->fold_mom_dtrk = dtrk;
     } else if (int e = project_now(c, dtrk, alpha)) return e;
     c->visct_bc_done = false;
-    { const int e = op_cmpt_sgs(c); c->fold_dtrk = 0.; c->defer_force = false; if (fold_smag) c->fold_mom_fmask = 0; if (e) return e; }
+    { const int e = op_cmpt_sgs(c); c->fold_dtrk = 0.; c->defer_force = false; if (e) return e; }
     // no subgrid model and homogeneous sgs BC values: the eddy viscosity is zero, ghost cells included, since start-up (sgs.f90:62-68)
     bool visct_ghosts = !(c->C.sgstype == 0 && c->visct_zero && !c->sgs_first);
     for (int q = 0; q < 6; ++q) if (c->C.bcsgs[q] != 0.) visct_ghosts = true;

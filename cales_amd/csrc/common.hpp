@@ -192,8 +192,6 @@ struct cales_ctx {
   // cales_step, dynamic model on one rank with x and y periodic: the velocity correction and the pressure update of the substep are done by the
   // strain-rate pass of the cmpt_sgs that follows (k_strain_tile<.., CORR = 1>, k_sgs.hip) -- != 0: the dtrk of the pending projection
   real fold_dtrk = 0.;
-  // ... or, static Smagorinsky (smag_fold_ok, k_smagfold.hip): by the Smagorinsky pass, with the pressure update of z-implicit diffusion (alpha)
-  real fold_alpha = 0.;
   // cales_step without subgrid model (explicit diffusion, one rank, every direction periodic or between no-slip walls with Neumann pressure): the
   // projection of substeps 1 and 2 is applied by the momentum pass of the NEXT substep while it loads its planes (k_momrk<.., CORR = 1>); the ghost
   // cells of the prediction receive their final values through a corrected view in the ghost-cell kernels (bc_view_dtrk). != 0: the dtrk of the
@@ -283,9 +281,6 @@ int op_rk(cales_ctx *c, int irk, real dt);
 int op_rk_par(cales_ctx *c, real rkpar1, real rkpar2, real dt);
 int op_momrk(cales_ctx *c, real f1, real f2, real f12);
 int op_bulk_forcing(cales_ctx *c);
-int op_copy_ghosts(cales_ctx *c, real *const *src, real *const *dst);      // ghost layers of three fields, all six faces (k_momrk.hip)
-int op_smag_fold(cales_ctx *c);      // static Smagorinsky with the pending projection folded in (k_smagfold.hip)
-bool smag_fold_ok(const cales_ctx *c);
 int op_bulk_mean_dev(cales_ctx *c, const real *p, int c_or_f, real *d_out);   // result to device scalar
 int op_fillps(cales_ctx *c, real dtrki);
 int op_updt_rhs_b(cales_ctx *c);
@@ -335,21 +330,6 @@ void solver_teardown(cales_ctx *c);
 __device__ inline real ldc(const real *p, int k) { return ((const __attribute__((address_space(4))) real *)p)[k]; }
 template <typename OFF> __device__ inline real ldb(const real *b, OFF o) { return *(const real *)((const char *)b + o); }
 template <typename OFF> __device__ inline void stb(real *b, OFF o, real v) { *(real *)((char *)b + o) = v; }
-
-// Corrected view (cales_step, projection folded into a later pass): a source cell that is an INTERIOR cell (1..n in all three directions) is
-// read as the projected velocity (u* + f) - dtrk grad(pp) of component comp = 1..3 (the expressions of k_correc_cell), every other cell as stored --
-// ghost cells written by an earlier direction of the same update are final already. comp = 0: plain reads.
-struct CorrView { const real *pp, *dzci, *force; real cfi, cfj, dt; int fmask, perx; };      // force: the bulk-forcing increments of the substep (device), fmask: the forced components
-__device__ inline real view_rd(const Geom &g, const CorrView &V, int comp, const real *p, int i, int j, int k) {
-  const size_t c = g.ix(i, j, k);
-  const real v = p[c];
-  if (!comp || i < 1 || i > g.n1 || j < 1 || j > g.n2 || k < 1 || k > g.n3) return v;
-  const real pc = V.pp[c];
-  const real pb = comp == 1 ? V.pp[(V.perx && i == g.n1) ? g.ix(1, j, k) : c + 1] : comp == 2 ? V.pp[c + g.s1] : V.pp[c + g.s12];
-  const real cf = comp == 1 ? V.cfi : comp == 2 ? V.cfj : V.dt * V.dzci[k];
-  return ((V.fmask >> (comp - 1) & 1) ? v + V.force[comp - 1] : v) - cf * (pb - pc);
-}
-CorrView corr_view(const cales_ctx *c);      // k_bound.hip: the view of the pending projection (c->bc_view_dtrk)
 
 // ---- cross-lane moves on the vector ALU (DPP) instead of ds_bpermute: no LDS-pipe traffic, short latency ----
 template <int CTRL, int ROWMASK = 0xf>

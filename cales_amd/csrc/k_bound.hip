@@ -7,9 +7,20 @@
 // reference is kept because corner ghosts depend on it.
 #include "common.hpp"
 
-// (CorrView / view_rd / corr_view: common.hpp -- the ghost-cell kernels, the wall model and the wall-shear planes of the folded Smagorinsky pass read
-//  through the same corrected view)
-CorrView corr_view(const cales_ctx *c) {
+// Corrected view (cales_step, projection folded into the next momentum pass): a source cell that is an INTERIOR cell (1..n in all three directions) is
+// read as the projected velocity (u* + f) - dtrk grad(pp) of component comp = 1..3 (the expressions of k_correc_cell), every other cell as stored --
+// ghost cells written by an earlier direction of the same update are final already. comp = 0: plain reads.
+struct CorrView { const real *pp, *dzci, *force; real cfi, cfj, dt; int fmask, perx; };      // force: the bulk-forcing increments of the substep (device), fmask: the forced components
+__device__ inline real view_rd(const Geom &g, const CorrView &V, int comp, const real *p, int i, int j, int k) {
+  const size_t c = g.ix(i, j, k);
+  const real v = p[c];
+  if (!comp || i < 1 || i > g.n1 || j < 1 || j > g.n2 || k < 1 || k > g.n3) return v;
+  const real pc = V.pp[c];
+  const real pb = comp == 1 ? V.pp[(V.perx && i == g.n1) ? g.ix(1, j, k) : c + 1] : comp == 2 ? V.pp[c + g.s1] : V.pp[c + g.s12];
+  const real cf = comp == 1 ? V.cfi : comp == 2 ? V.cfj : V.dt * V.dzci[k];
+  return ((V.fmask >> (comp - 1) & 1) ? v + V.force[comp - 1] : v) - cf * (pb - pc);
+}
+static CorrView corr_view(const cales_ctx *c) {
   CorrView V{};
   V.pp = c->f[CALES_PP]; V.dzci = c->d_dzci; V.force = c->d_force; V.cfi = c->bc_view_dtrk * c->dli[0]; V.cfj = c->bc_view_dtrk * c->dli[1]; V.dt = c->bc_view_dtrk;
   V.fmask = c->fold_mom_fmask; V.perx = c->step_xskip ? 1 : 0;
@@ -325,9 +336,7 @@ struct WmArgs {
 // largest face and the blocks beyond a smaller one return.
 // component 0: first tangential component loop, 1: second (wmodel.f90:138-153/154-170, 189-204/205-221, 240-255/256-271)
 struct WmJobs { WmArgs a[6]; int n; };
-// view != 0: the velocity is read through the corrected view V (the fields hold the prediction of a projection folded into a later pass). V is an argument
-// of its own: inside WmJobs, whose entries are indexed by blockIdx, it sent the whole struct to scratch memory (944 B per lane, 44 -> 540 us per launch)
-__global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmJobs J, CorrView V, int view) {
+__global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmJobs J) {
   const WmArgs &A = J.a[blockIdx.z >> 1];
   const int na = A.idir == 1 ? g.n2 : g.n1, nb = A.idir == 3 ? g.n2 : g.n3;
   const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y, comp = blockIdx.z & 1;
@@ -336,15 +345,14 @@ __global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmJobs J, CorrView V,
   const real visci = 1. / A.visc;
   real t1, t2;
 #define M(pl, a_, b_) pl[(a_) + ld * (b_)]
-#define RDV(comp, f, ii, jj, kk) (view ? view_rd(g, V, comp, f, ii, jj, kk) : f[g.ix(ii, jj, kk)])
   if (A.idir == 1) {          // wall normal x; a = j, b = k; tangential: v (first), w (second)
     const int i1 = A.i1, i2 = A.i2;
     if (comp == 0) {
       if (a > na || b < 1 || b > nb) return;           // j = 0..n2, k = 1..n3
       const int j = a, k = b;
-      const real v1 = RDV(2, A.v, i1, j, k), v2 = RDV(2, A.v, i2, j, k);
-      const real w1 = 0.25 * (RDV(3, A.w, i1, j, k) + RDV(3, A.w, i1, j + 1, k) + RDV(3, A.w, i1, j, k - 1) + RDV(3, A.w, i1, j + 1, k - 1));
-      const real w2 = 0.25 * (RDV(3, A.w, i2, j, k) + RDV(3, A.w, i2, j + 1, k) + RDV(3, A.w, i2, j, k - 1) + RDV(3, A.w, i2, j + 1, k - 1));
+      const real v1 = A.v[g.ix(i1, j, k)], v2 = A.v[g.ix(i2, j, k)];
+      const real w1 = 0.25 * (A.w[g.ix(i1, j, k)] + A.w[g.ix(i1, j + 1, k)] + A.w[g.ix(i1, j, k - 1)] + A.w[g.ix(i1, j + 1, k - 1)]);
+      const real w2 = 0.25 * (A.w[g.ix(i2, j, k)] + A.w[g.ix(i2, j + 1, k)] + A.w[g.ix(i2, j, k - 1)] + A.w[g.ix(i2, j + 1, k - 1)]);
       const real v_mag = M(A.mag_a, j, k), w_mag = 0.25 * (M(A.mag_b, j, k) + M(A.mag_b, j + 1, k) + M(A.mag_b, j, k - 1) + M(A.mag_b, j + 1, k - 1));
       wallmodel(A.mtype, vel_relative(v1, v2, A.coef, v_mag), vel_relative(w1, w2, A.coef, w_mag), A.h, A.l1d, A.visc, t1, t2);
       M(A.bc_a, j, k) = A.sgn * visci * t1;
@@ -352,9 +360,9 @@ __global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmJobs J, CorrView V,
       if (a < 1 || a > na || b > nb) return;           // j = 1..n2, k = 0..n3
       const int j = a, k = b;
       const real wei = (A.zf[k] - A.zc[k]) / A.dzc[k];
-      const real v1 = 0.5 * ((1. - wei) * (RDV(2, A.v, i1, j - 1, k) + RDV(2, A.v, i1, j, k)) + wei * (RDV(2, A.v, i1, j - 1, k + 1) + RDV(2, A.v, i1, j, k + 1)));
-      const real v2 = 0.5 * ((1. - wei) * (RDV(2, A.v, i2, j - 1, k) + RDV(2, A.v, i2, j, k)) + wei * (RDV(2, A.v, i2, j - 1, k + 1) + RDV(2, A.v, i2, j, k + 1)));
-      const real w1 = RDV(3, A.w, i1, j, k), w2 = RDV(3, A.w, i2, j, k);
+      const real v1 = 0.5 * ((1. - wei) * (A.v[g.ix(i1, j - 1, k)] + A.v[g.ix(i1, j, k)]) + wei * (A.v[g.ix(i1, j - 1, k + 1)] + A.v[g.ix(i1, j, k + 1)]));
+      const real v2 = 0.5 * ((1. - wei) * (A.v[g.ix(i2, j - 1, k)] + A.v[g.ix(i2, j, k)]) + wei * (A.v[g.ix(i2, j - 1, k + 1)] + A.v[g.ix(i2, j, k + 1)]));
+      const real w1 = A.w[g.ix(i1, j, k)], w2 = A.w[g.ix(i2, j, k)];
       const real v_mag = 0.5 * ((1. - wei) * (M(A.mag_a, j - 1, k) + M(A.mag_a, j, k)) + wei * (M(A.mag_a, j - 1, k + 1) + M(A.mag_a, j, k + 1)));
       const real w_mag = M(A.mag_b, j, k);
       wallmodel(A.mtype, vel_relative(v1, v2, A.coef, v_mag), vel_relative(w1, w2, A.coef, w_mag), A.h, A.l1d, A.visc, t1, t2);
@@ -365,9 +373,9 @@ __global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmJobs J, CorrView V,
     if (comp == 0) {
       if (a > na || b < 1 || b > nb) return;           // i = 0..n1, k = 1..n3
       const int i = a, k = b;
-      const real u1 = RDV(1, A.u, i, j1, k), u2 = RDV(1, A.u, i, j2, k);
-      const real w1 = 0.25 * (RDV(3, A.w, i, j1, k) + RDV(3, A.w, i + 1, j1, k) + RDV(3, A.w, i, j1, k - 1) + RDV(3, A.w, i + 1, j1, k - 1));
-      const real w2 = 0.25 * (RDV(3, A.w, i, j2, k) + RDV(3, A.w, i + 1, j2, k) + RDV(3, A.w, i, j2, k - 1) + RDV(3, A.w, i + 1, j2, k - 1));
+      const real u1 = A.u[g.ix(i, j1, k)], u2 = A.u[g.ix(i, j2, k)];
+      const real w1 = 0.25 * (A.w[g.ix(i, j1, k)] + A.w[g.ix(i + 1, j1, k)] + A.w[g.ix(i, j1, k - 1)] + A.w[g.ix(i + 1, j1, k - 1)]);
+      const real w2 = 0.25 * (A.w[g.ix(i, j2, k)] + A.w[g.ix(i + 1, j2, k)] + A.w[g.ix(i, j2, k - 1)] + A.w[g.ix(i + 1, j2, k - 1)]);
       const real u_mag = M(A.mag_a, i, k), w_mag = 0.25 * (M(A.mag_b, i, k) + M(A.mag_b, i + 1, k) + M(A.mag_b, i, k - 1) + M(A.mag_b, i + 1, k - 1));
       wallmodel(A.mtype, vel_relative(u1, u2, A.coef, u_mag), vel_relative(w1, w2, A.coef, w_mag), A.h, A.l1d, A.visc, t1, t2);
       M(A.bc_a, i, k) = A.sgn * visci * t1;
@@ -375,9 +383,9 @@ __global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmJobs J, CorrView V,
       if (a < 1 || a > na || b > nb) return;           // i = 1..n1, k = 0..n3
       const int i = a, k = b;
       const real wei = (A.zf[k] - A.zc[k]) / A.dzc[k];
-      const real u1 = 0.5 * ((1. - wei) * (RDV(1, A.u, i - 1, j1, k) + RDV(1, A.u, i, j1, k)) + wei * (RDV(1, A.u, i - 1, j1, k + 1) + RDV(1, A.u, i, j1, k + 1)));
-      const real u2 = 0.5 * ((1. - wei) * (RDV(1, A.u, i - 1, j2, k) + RDV(1, A.u, i, j2, k)) + wei * (RDV(1, A.u, i - 1, j2, k + 1) + RDV(1, A.u, i, j2, k + 1)));
-      const real w1 = RDV(3, A.w, i, j1, k), w2 = RDV(3, A.w, i, j2, k);
+      const real u1 = 0.5 * ((1. - wei) * (A.u[g.ix(i - 1, j1, k)] + A.u[g.ix(i, j1, k)]) + wei * (A.u[g.ix(i - 1, j1, k + 1)] + A.u[g.ix(i, j1, k + 1)]));
+      const real u2 = 0.5 * ((1. - wei) * (A.u[g.ix(i - 1, j2, k)] + A.u[g.ix(i, j2, k)]) + wei * (A.u[g.ix(i - 1, j2, k + 1)] + A.u[g.ix(i, j2, k + 1)]));
+      const real w1 = A.w[g.ix(i, j1, k)], w2 = A.w[g.ix(i, j2, k)];
       const real u_mag = 0.5 * ((1. - wei) * (M(A.mag_a, i - 1, k) + M(A.mag_a, i, k)) + wei * (M(A.mag_a, i - 1, k + 1) + M(A.mag_a, i, k + 1)));
       const real w_mag = M(A.mag_b, i, k);
       wallmodel(A.mtype, vel_relative(u1, u2, A.coef, u_mag), vel_relative(w1, w2, A.coef, w_mag), A.h, A.l1d, A.visc, t1, t2);
@@ -388,32 +396,30 @@ __global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmJobs J, CorrView V,
     if (comp == 0) {
       if (a > na || b < 1 || b > nb) return;           // i = 0..n1, j = 1..n2
       const int i = a, j = b;
-      const real u1 = RDV(1, A.u, i, j, k1), u2 = RDV(1, A.u, i, j, k2);
-      const real v1 = 0.25 * (RDV(2, A.v, i, j, k1) + RDV(2, A.v, i + 1, j, k1) + RDV(2, A.v, i, j - 1, k1) + RDV(2, A.v, i + 1, j - 1, k1));
-      const real v2 = 0.25 * (RDV(2, A.v, i, j, k2) + RDV(2, A.v, i + 1, j, k2) + RDV(2, A.v, i, j - 1, k2) + RDV(2, A.v, i + 1, j - 1, k2));
+      const real u1 = A.u[g.ix(i, j, k1)], u2 = A.u[g.ix(i, j, k2)];
+      const real v1 = 0.25 * (A.v[g.ix(i, j, k1)] + A.v[g.ix(i + 1, j, k1)] + A.v[g.ix(i, j - 1, k1)] + A.v[g.ix(i + 1, j - 1, k1)]);
+      const real v2 = 0.25 * (A.v[g.ix(i, j, k2)] + A.v[g.ix(i + 1, j, k2)] + A.v[g.ix(i, j - 1, k2)] + A.v[g.ix(i + 1, j - 1, k2)]);
       const real u_mag = M(A.mag_a, i, j), v_mag = 0.25 * (M(A.mag_b, i, j) + M(A.mag_b, i + 1, j) + M(A.mag_b, i, j - 1) + M(A.mag_b, i + 1, j - 1));
       wallmodel(A.mtype, vel_relative(u1, u2, A.coef, u_mag), vel_relative(v1, v2, A.coef, v_mag), A.h, A.l1d, A.visc, t1, t2);
       M(A.bc_a, i, j) = A.sgn * visci * t1;
     } else {
       if (a < 1 || a > na || b > nb) return;           // i = 1..n1, j = 0..n2
       const int i = a, j = b;
-      const real u1 = 0.25 * (RDV(1, A.u, i - 1, j, k1) + RDV(1, A.u, i, j, k1) + RDV(1, A.u, i - 1, j + 1, k1) + RDV(1, A.u, i, j + 1, k1));
-      const real u2 = 0.25 * (RDV(1, A.u, i - 1, j, k2) + RDV(1, A.u, i, j, k2) + RDV(1, A.u, i - 1, j + 1, k2) + RDV(1, A.u, i, j + 1, k2));
-      const real v1 = RDV(2, A.v, i, j, k1), v2 = RDV(2, A.v, i, j, k2);
+      const real u1 = 0.25 * (A.u[g.ix(i - 1, j, k1)] + A.u[g.ix(i, j, k1)] + A.u[g.ix(i - 1, j + 1, k1)] + A.u[g.ix(i, j + 1, k1)]);
+      const real u2 = 0.25 * (A.u[g.ix(i - 1, j, k2)] + A.u[g.ix(i, j, k2)] + A.u[g.ix(i - 1, j + 1, k2)] + A.u[g.ix(i, j + 1, k2)]);
+      const real v1 = A.v[g.ix(i, j, k1)], v2 = A.v[g.ix(i, j, k2)];
       const real u_mag = 0.25 * (M(A.mag_a, i - 1, j) + M(A.mag_a, i, j) + M(A.mag_a, i - 1, j + 1) + M(A.mag_a, i, j + 1));
       const real v_mag = M(A.mag_b, i, j);
       wallmodel(A.mtype, vel_relative(u1, u2, A.coef, u_mag), vel_relative(v1, v2, A.coef, v_mag), A.h, A.l1d, A.visc, t1, t2);
       M(A.bc_b, i, j) = A.sgn * visci * t2;
     }
   }
-#undef RDV
 #undef M
 }
 
 static int updt_wallmodelbc(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, const real *u, const real *v, const real *w) {
   const int *n = c->n; const real h = c->C.hwm; const real *dl = c->dl;
   WmJobs J; J.n = 0; int gx = 0, gy = 0;
-  const int view = c->bc_view_dtrk != 0. ? 1 : 0; const CorrView V = view ? corr_view(c) : CorrView{};
   for (int idir = 1; idir <= 3; ++idir) for (int ib = 0; ib <= 1; ++ib) {
     if (!(ISB(c, ib, idir) && LWM(c, ib, idir) != 0)) continue;
     WmArgs &A = J.a[J.n++]; A.idir = idir; A.ibound = ib; A.mtype = LWM(c, ib, idir); A.h = h; A.visc = c->visc; A.l1d = c->C.l[idir - 1];
@@ -430,7 +436,7 @@ static int updt_wallmodelbc(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, co
     const int na = idir == 1 ? n[1] : n[0], nb = idir == 3 ? n[1] : n[2];
     gx = std::max(gx, (na + 2 + 63) / 64); gy = std::max(gy, (nb + 2 + 3) / 4);
   }
-  if (J.n) LAUNCH(c, k_wallmodel, dim3(gx, gy, 2 * J.n), dim3(64, 4, 1), 0, c->stream, c->g, J, V, view);
+  if (J.n) LAUNCH(c, k_wallmodel, dim3(gx, gy, 2 * J.n), dim3(64, 4, 1), 0, c->stream, c->g, J);
   LAUNCHCHK(c);
   return 0;
 }
@@ -516,12 +522,9 @@ int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm
     const real drt0 = idir < 3 ? c->dl[idir - 1] : c->dzc[0], drt1 = idir < 3 ? c->dl[idir - 1] : c->dzc[n[2]];
     for (int ib = 0; ib <= 1; ++ib) {
       if (!(ISB(c, ib, idir) && LWM(c, ib, idir) != 0)) continue;
-      for (int ivel = 1; ivel <= 3; ++ivel) if (ivel != idir) {
+      for (int ivel = 1; ivel <= 3; ++ivel) if (ivel != idir)
         add_job(J, fl[ivel - 1], CBV(c, ib, idir, ivel), ib, 1, plane(*bnd[ivel - 1], idir, ib, n), ib ? drt1 : drt0);
-        J.job[J.njobs - 1].vcomp = view ? (char)ivel : 0;
-      }
     }
-    J.V = V;
     if (int e = launch_jobs(c, J)) return e;
   }
   return 0;

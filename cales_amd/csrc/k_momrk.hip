@@ -254,15 +254,6 @@ __global__ __launch_bounds__(256) void k_copy_ghosts(Geom g, GhostCopy G) {     
   const size_t c = idir == 1 ? g.ix(m, a, b) : idir == 2 ? g.ix(a, m, b) : g.ix(a, b, m);
   G.dst[f][c] = G.src[f][c];
 }
-// all ghost layers (six faces) of three fields from one set of buffers to another
-int op_copy_ghosts(cales_ctx *c, real *const *src, real *const *dst) {
-  const int *n = c->n;
-  GhostCopy G; for (int q = 0; q < 3; ++q) { G.src[q] = src[q]; G.dst[q] = dst[q]; }
-  const int na = std::max(n[0], n[1]), nb = std::max(n[1], n[2]);
-  LAUNCH(c, k_copy_ghosts, dim3((na + 2 + 63) / 64, (nb + 2 + 3) / 4, 18), dim3(64, 4, 1), 0, c->stream, c->g, G);
-  LAUNCHCHK(c);
-  return 0;
-}
 // mom_xyz_ad + update of rk (rk.f90:74-94); leaves the new velocities in c->f[CALES_U..W] (pointers swapped with c->f2)
 int op_momrk(cales_ctx *c, real f1, real f2, real f12) {
   ProfScope ps(c, "mom_rk_fused");
@@ -324,7 +315,10 @@ int op_momrk(cales_ctx *c, real f1, real f2, real f12) {
   LAUNCHCHK(c);
   bool wm = false; for (int q = 0; q < 6; ++q) wm = wm || c->C.lwm[q] != 0;
   if (wm) {
-    if (int e = op_copy_ghosts(c, c->f + CALES_U, c->f2)) return e;
+    GhostCopy G; for (int q = 0; q < 3; ++q) { G.src[q] = c->f[CALES_U + q]; G.dst[q] = c->f2[q]; }
+    const int na = std::max(n[0], n[1]), nb = std::max(n[1], n[2]);
+    LAUNCH(c, k_copy_ghosts, dim3((na + 2 + 63) / 64, (nb + 2 + 3) / 4, 18), dim3(64, 4, 1), 0, c->stream, c->g, G);
+    LAUNCHCHK(c);
   }
   for (int q = 0; q < 3; ++q) std::swap(c->f[CALES_U + q], c->f2[q]);
   if (corr) { if (!pdone) std::swap(c->f[CALES_P], c->scr1); c->fold_mom_dtrk = 0.; c->fold_mom_pdone = false; }      // the updated pressure (interior cells; the caller renews its ghost cells)

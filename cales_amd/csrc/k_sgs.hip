@@ -1525,7 +1525,6 @@ static int smag_fast(cales_ctx *c) {
   S.wylo = c->is_wall[2] != 0.; S.wyhi = c->is_wall[3] != 0.; S.dl2 = c->dl[1];
   S.wmylo = ISB(c, 0, 2) && LWM(c, 0, 2) != 0; S.wmyhi = ISB(c, 1, 2) && LWM(c, 1, 2) != 0;
   S.twy = nullptr;
-  if (c->fold_dtrk != 0.) return op_smag_fold(c);      // cales_step: the projection of the substep is pending and this pass applies it (k_smagfold.hip)
   if (S.wylo || S.wyhi) { if (int e = wall_shear_y_planes(c, S.wylo, S.wyhi, &S.twy)) return e; }
   const bool small = (c->ntot + 16) * sizeof(real) < (1ull << 32) && !c->fl.wide_offsets;
   const bool yw = S.wylo || S.wyhi || S.wmylo || S.wmyhi;
