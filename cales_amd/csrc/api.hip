@@ -241,6 +241,7 @@ int cales_create(const cales_case *cs, void *stream, cales_ctx **out) {
     for (int m = 0; m < 6; ++m) if (field_alloc(c, &c->sij[m]) || field_alloc(c, &c->mij[m])) return fail(13);
   }
   if (solver_setup(c)) return fail(14);
+  { hipDeviceProp_t pr; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) c->ncu = pr.multiProcessorCount; }
   if (hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "sync failed"; return fail(15); }
   if (!c->launch_err.empty()) { c->err = c->launch_err; return fail(16); }      // a set-up kernel (twiddles, tables) or attribute call failed
   *out = c;
@@ -555,7 +556,7 @@ int cales_get_dpdl(cales_ctx *c, real dpdl[3]) {
 #define CALES_RES_TAIL 4096
 int cales_comm_buffer_doubles(const cales_ctx *c, int64_t *n) {
   const int64_t a2a = 2 * (int64_t)c->P * c->n[2] * c->n[1] * c->cw;                 // [peer][k][jl][mm] complex
-  const int64_t halo = 4 * 12 * (int64_t)c->g.s1 * (c->n[2] + 2);                    // lo|hi x up to 12 fields (send in A, recv in B)
+  const int64_t halo = 4 * 16 * (int64_t)c->g.s1 * (c->n[2] + 2);                    // lo|hi x up to 16 field planes (send in A, recv in B)
   const int64_t tail = CALES_RES_TAIL + 2 * (int64_t)(c->n[2] + 2);
   *n = std::max(a2a, halo) + tail;
   return 0;

@@ -174,6 +174,7 @@ struct cales_ctx {
   real *d_stat = nullptr;      // partial sums and result of the plane statistics
   bool abct_ready = false, force_zeroed = false;
   real *d_abct = nullptr;      // tridiagonal coefficients in the chunked order of k_gaussel_tile
+  int ncu = 0;      // compute units of the device (balanced_kchunk)
   int fuse_mean_mask = 0; real *d_mpart = nullptr; size_t n_mpart = 0;      // bulk means of the forced components are summed by that pass too
   real fuse_fillps_dti = 0.;   // != 0: the forward x transform of the next pressure solve forms pp = div(u*)/dtrk itself (cales_step)
   bool defer_force = false;      // explicit step, forced directions periodic, no wall model: u += f is applied by the correction kernel
@@ -399,5 +400,25 @@ static inline int tile_kchunk(const cales_ctx *c, long nxy_blocks, int n3) {
   return 0;
 }
 static inline long tile_min_blocks(const cales_ctx *c) { return c->fl.tile_min_blocks; }
+// Few rounds of blocks (a y slab of a decomposed grid, a mid-size grid): the marching tile kernels hold ONE block per CU, a launch then runs in
+// ceil(blocks / CUs) rounds of (chunk length + prologue) planes each, and half-empty last rounds show -- one rank of eight of the 512^3 channel:
+// strain-rate pass 1.48 -> 1.32 ms/step with 9 chunks of 57 planes (504 blocks, 1.97 rounds) instead of 16 of 32 (896 blocks, 3.5 rounds), the
+// dynamic model's last pass 1.39 -> 1.27 with 7 chunks instead of 16; the measured order of eight chunk lengths follows rounds x (planes + 3).
+// With many rounds (the 512^3 grid on one GPU: 6.5) the passes are bound by bandwidth, idle CUs of the last round leave theirs to the others and
+// the rule does not hold (measured: 13 full rounds 3 % SLOWER than 6.5) -- so: only below six rounds, chunk lengths from 16 planes.
+static inline int balanced_kchunk(const cales_ctx *c, long nxy_blocks, int n3, int kch0, int kmax = 1 << 30) {
+  const long ncu = c->ncu > 0 ? c->ncu : 256;
+  const int nch0 = (n3 + kch0 - 1) / kch0;
+  if (nxy_blocks * nch0 >= 6 * ncu || c->fl.kchunk > 0 || c->fl.tile_min_blocks != 2048) return kch0;      // (switches that force chunking: the tests' business)
+  long best = -1; int bk = kch0;
+  for (int nch = 1; nch <= 4 * nch0 + 4; ++nch) {
+    const int kch = (n3 + nch - 1) / nch;
+    if (kch < 16 && kch < kch0) break;
+    if (kch > kmax) continue;
+    const long nb = nxy_blocks * ((n3 + kch - 1) / kch), cost = ((nb + ncu - 1) / ncu) * (kch + 3);
+    if (best < 0 || cost < best) { best = cost; bk = kch; }
+  }
+  return bk;
+}
 static inline int bc_skipped(const cales_ctx *c) { return c->bc_skip | (c->step_xskip ? 1 : 0); }
 static inline dim3 grid3(int nx, int ny, int nz, dim3 b) { return dim3((nx + b.x - 1) / b.x, (ny + b.y - 1) / b.y, (nz + b.z - 1) / b.z); }

@@ -146,7 +146,7 @@ static bool merged_ok(const cales_ctx *c, const char *cbx, const char *cby) {
 
 // y-slab neighbours (bound.f90:619-696 for idir = 2): pack the first/last interior rows of nf fields into the
 // staging buffer A, let the host exchange them, unpack into the ghost rows. Planes include the x/z ghosts.
-struct HaloFields { int nf; real *p[12]; unsigned char wide[12]; int off[12]; unsigned char vcomp[12]; CorrView V; };      // vcomp != 0: the rows that leave are read through the corrected view      // wide: a pair field (rows twice as long); off: first staging plane of the field, in planes of s1 (n3+2) values
+struct HaloFields { int nf; real *p[16]; unsigned char wide[16]; int off[16]; unsigned char vcomp[16]; CorrView V; };      // vcomp != 0: the rows that leave are read through the corrected view      // wide: a pair field (rows twice as long); off: first staging plane of the field, in planes of s1 (n3+2) values
 // x ghost columns of the two z ghost planes, rows 0..n2+1: the corners the velocity update after the projection leaves alone (bounduvw with
 // is_correc does not touch the z ghost planes of w, and the periodic copies of the step's earlier calls were skipped: cales_step, step_xskip)
 __global__ __launch_bounds__(256) void k_xwrap_zghost(Geom g, HaloFields H) {
@@ -199,7 +199,7 @@ static int halo_y_comm(cales_ctx *c, int nf, real **flds, bool wide = false) {
   if (!c->comm.on) { c->err = "nranks > 1 but no communication hooks registered (cales_set_comm)"; return 1; }
   if (c->bc_no_halo) return 0;      // the ghost rows already hold the neighbours' rows (end-of-step refresh of the x ghost columns, cales_step)
   if (c->defer_halo) { for (int q = 0; q < nf; ++q) { c->deferred.push_back(flds[q]); c->deferred_wide.push_back(wide ? 1 : 0); } return 0; }      // exchanged later (halo_flush_deferred)
-  unsigned char w[12]; for (int q = 0; q < nf && q < 12; ++q) w[q] = wide ? 1 : 0;
+  unsigned char w[16]; for (int q = 0; q < nf && q < 16; ++q) w[q] = wide ? 1 : 0;
   return halo_y_on(c, nf, flds, c->stream, false, w);
 }
 // The y-halo rows of the fields collected while c->defer_halo was set travel on the second stream, after everything queued on the
@@ -210,9 +210,9 @@ static int halo_y_comm(cales_ctx *c, int nf, real **flds, bool wide = false) {
 int halo_flush_deferred(cales_ctx *c, bool overlapped) {
   if (c->deferred.empty()) return 0;
   if (overlapped) { if (int e = stream_after(c, c->comm_stream, c->stream)) return e; }
-  for (size_t q0 = 0; q0 < c->deferred.size();) {      // as many fields per exchange as the staging buffers hold: twelve planes, a pair field takes two
+  for (size_t q0 = 0; q0 < c->deferred.size();) {      // as many fields per exchange as the staging buffers hold: sixteen planes, a pair field takes two
     int nf = 0, planes = 0;
-    while (q0 + nf < c->deferred.size() && nf < 12 && planes + 1 + c->deferred_wide[q0 + nf] <= 12) { planes += 1 + c->deferred_wide[q0 + nf]; ++nf; }
+    while (q0 + nf < c->deferred.size() && nf < 16 && planes + 1 + c->deferred_wide[q0 + nf] <= 16) { planes += 1 + c->deferred_wide[q0 + nf]; ++nf; }
     if (int e = halo_y_on(c, nf, c->deferred.data() + q0, overlapped ? c->comm_stream : c->stream, overlapped, c->deferred_wide.data() + q0)) { c->deferred.clear(); c->deferred_wide.clear(); return e; }
     q0 += nf;
   }

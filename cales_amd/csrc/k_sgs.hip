@@ -1324,12 +1324,13 @@ static int dsmag_fast(cales_ctx *c) {
   const int wylo = ISB(c, 0, 2) && c->is_wall[2] != 0., wyhi = ISB(c, 1, 2) && c->is_wall[3] != 0.;
   const int wmylo = ISB(c, 0, 2) && LWM(c, 0, 2) != 0, wmyhi = ISB(c, 1, 2) && LWM(c, 1, 2) != 0;
   // tiles of 62 x TY columns marching in k; k is also split into chunks so that several rounds of blocks balance the chip
-  auto tiles = [&](int ty, int wx, dim3 &mb, dim3 &mg, int &kchunk) {
+  auto tiles = [&](int ty, int wx, dim3 &mb, dim3 &mg, int &kchunk, int kmax = 1 << 30) {
     mb = dim3(64, ty + 2, 1); mg = dim3((n[0] + wx - 1) / wx, (n[1] + ty - 1) / ty, 1);
     kchunk = n[2];
     while ((long)mg.x * mg.y * ((n[2] + kchunk - 1) / kchunk) < tile_min_blocks(c) && kchunk > 32) kchunk = (kchunk + 1) / 2;
     // small grids: fewer blocks than one per CU leave most of the chip idle; shorter chunks (their three-plane prologue weighs more) beat that
     while ((long)mg.x * mg.y * ((n[2] + kchunk - 1) / kchunk) < 256 && kchunk > 8) kchunk = (kchunk + 1) / 2;
+    kchunk = balanced_kchunk(c, (long)mg.x * mg.y, n[2], kchunk, kmax);
     if (int fk = tile_kchunk(c, (long)mg.x * mg.y, n[2])) kchunk = fk;
     mg.z = (n[2] + kchunk - 1) / kchunk;
   };
@@ -1376,10 +1377,14 @@ static int dsmag_fast(cales_ctx *c) {
     if (!perz)
       LAUNCH(c, k_wface_fold, dim3((n[0] + 2 + 63) / 64, (n[1] + 2 + 3) / 4), dim3(64, 4), 0, c->stream, c->g, c->f2[2], c->f[CALES_W], f[CALES_PP], c->fold_dtrk * c->dzci[0]);
     if (!c->fl.unmerged_bc) { c->bc_nride = 1; c->bc_ride[0] = f[CALES_P]; c->bc_ride_which[0] = 0; }
+    // several slabs: the rows of u, v, w and p travel in the SAME exchange as the scratch fields' below (fifteen planes; their next readers, the last pass
+    // and the next momentum pass, come behind it) -- three exchanges per substep instead of four
+    c->defer_halo = c->P > 1 && !c->fl.unmerged_bc;
     const int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 1, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W]);
+    c->defer_halo = false;
     const bool rode = !c->fl.unmerged_bc && c->bc_nride == 0; c->bc_nride = 0;
-    if (e) return e;
-    if (!rode) { if (int e2 = op_boundp(c, f[CALES_P], 0)) return e2; }
+    if (e) { c->deferred.clear(); c->deferred_wide.clear(); return e; }
+    if (!rode) { if (int e2 = op_boundp(c, f[CALES_P], 0)) { c->deferred.clear(); c->deferred_wide.clear(); return e2; } }
   }
   // sgs-type ghost cells: only the periodic exchange matters (products of ghosts = ghosts of products; the wall ghosts are
   // replaced by the extrapolation rule inside the filters)
@@ -1423,7 +1428,7 @@ static int dsmag_fast(cales_ctx *c) {
   if (!c->fl.dsmag_unfused_filter) {
     // K_B + K_DF in one pass: filter(|S|Sij) on the fly, strain rate of the filtered velocity, Mij, Lij, contractions, plane partial sums
     ProfScope ps(c, "lij_mij_filter_contract");
-    tiles(lmf_ty, 62, mb, mg, kch);
+    tiles(lmf_ty, 62, mb, mg, kch, LMF_KMAX);
     while (kch > LMF_KMAX) { kch = (kch + 1) / 2; mg.z = (n[2] + kch - 1) / kch; }      // the kernel keeps a chunk's block sums in LDS
     L.kchunk = kch; L.nblk = mg.x * mg.y;
     LmfArgs B; B.L = L; for (int m = 0; m < 6; ++m) B.ss[m] = ssij[m];
