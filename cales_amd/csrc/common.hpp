@@ -68,7 +68,7 @@ struct Spec {
 
 // Run-time switches: read from the environment ONCE, by cales_create; the launch path only looks at these fields.
 struct Flags {
-  bool unfolded_correc = false, unfolded_mom = false, eager_projection = false, lazy_projection = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, unfused_rk = false, dsmag_unfused_filter = false, overlap = false, xghosts_in_step = false, unmerged_bc = false;
+  bool unfolded_correc = false, unfolded_mom = false, eager_projection = false, lazy_projection = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, unfused_rk = false, overlap = false, xghosts_in_step = false, unmerged_bc = false;
   int kchunk = 0; long tile_min_blocks = 2048;
   std::string test_bad_launch;      // CALES_TEST_BAD_LAUNCH: test hook of the launch check (LAUNCH below)
   void read_env() {
@@ -93,7 +93,6 @@ struct Flags {
     xghosts_in_step = getenv("CALES_XGHOSTS_IN_STEP") != nullptr;      // keep the x ghost columns up to date after every operator of cales_step
     keep_null_mode = getenv("CALES_KEEP_NULL_MODE") != nullptr;
     unfused_rk = getenv("CALES_UNFUSED_RK") != nullptr;
-    dsmag_unfused_filter = getenv("CALES_DSMAG_UNFUSED_FILTER") != nullptr;
     // exchanges beside the kernels on a second stream: opt-in (CALES_OVERLAP=1) until a run with real peers has confirmed it -- the emulated
     // ranks of the tests cannot show a gain, and the in-order exchanges are the form with the fewest assumptions (CALES_NO_OVERLAP wins)
     overlap = getenv("CALES_OVERLAP") != nullptr && atoi(getenv("CALES_OVERLAP")) != 0 && getenv("CALES_NO_OVERLAP") == nullptr;

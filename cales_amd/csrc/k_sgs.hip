@@ -278,9 +278,9 @@ __global__ __launch_bounds__(256) void k_alph2(Geom g, real w0, real w1, real w2
 // ================================================================================================
 // Fast path of the dynamic model for cases whose only walls are in z (channels) and without wall model.
 // Same arithmetic as the reference sequence (sgs.f90:153-380) re-associated for the hardware, three passes:
-//  K_AC  u,v,w -> |S|, |S|Sij, cell-centred velocity, test-filtered velocity        (k_strain_tile)
-//  K_B   |S|Sij -> filter(|S|Sij)                                                  (k_filter6_tile)
-//  K_DF  filtered velocity, cell-centred velocity, filter(|S|Sij) -> plane sums of Mij Lij and Mij Mij (k_lij_mij_tile)
+//  K_AC  u,v,w -> |S|, |S|Sij, cell-centred velocity, test-filtered velocity        (k_strain_tile / k_corr_strain_tile)
+//  K_B + K_DF  filter(|S|Sij) on the fly, filtered velocity, cell-centred velocity -> plane sums of Mij Lij and Mij Mij (k_lmf_tile; the
+//        two-pass form k_filter6_tile + k_lij_mij_tile of rounds 1-2 went in round 5)
 //  then <LM>/<MM> per plane and visct = max(|S| <LM>/<MM>, 0).
 //  * the 27-point top-hat (sgs.f90:632-679) is separable, (1,2,1)^3/64, combined z first, then x, then y;
 //  * the wall extrapolation of filtered fields (extrapolate(...,cbc), sgs.f90:705-710,751-766, factor 1) is the rule
@@ -293,76 +293,10 @@ __global__ __launch_bounds__(256) void k_alph2(Geom g, real w0, real w1, real w2
 // kernels that write fields (K_AC, K_B) use tiles of 64 x TY outputs starting at i = 1 + 64 bx so that rows are read and
 // written as whole 128-B lines; the read-only K_DF uses 62 x TY outputs with the x halo inside the wave. With the wall rule
 // Q(0) = 2Q(1)-Q(2) ghost planes of extrapolated quantities are never read.
-#ifndef TYB
-#define TYB 8       // measured at 512^3: 8 (divides the usual n2, 10 waves per block) beats 14 and 6
-#endif
-struct Filter6Args { const real *in[6]; real *out[6]; int kchunk, zlo, zhi, perx; };   // perx: x ghost columns are not stored, wrap around
-// K_B: top-hat filter of six fields (the products |S|Sij). Tile = 64 x TYB outputs from i = 1 + 64 bx (whole 128-B lines in and
-// out); x combination first, on the plane just loaded (lanes 0 and 63 also load the x-halo cell beside them), then three
-// x-combined planes of the own cell roll in registers for the z combination, y neighbours through LDS.
-template <typename OFF>
-__global__ __launch_bounds__(64 * (TYB + 2)) void k_filter6_tile(Geom g, Filter6Args A) {
-  __shared__ real sh[2][6][TYB + 2][64];
-  const int tx = threadIdx.x, ty = threadIdx.y;
-  const int i = blockIdx.x * 64 + tx + 1, j = blockIdx.y * TYB + ty;        // ty = 0 / TYB+1 are halo rows
-  const int kbeg = blockIdx.z * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
-  const bool edge = tx == 0 || tx == 63;
-  const int ih = tx == 0 ? i - 1 : i + 1;
-  const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1, hok = edge && ih <= g.n1 + 1 && j <= g.n2 + 1;
-  const bool outok = ty >= 1 && ty <= TYB && i <= g.n1 && j <= g.n2;
-  const int iw = (A.perx && i == g.n1 + 1) ? 1 : i, ihw = A.perx ? (ih == 0 ? g.n1 : (ih == g.n1 + 1 ? 1 : ih)) : ih;     // periodic x without ghost columns
-  const OFF c0 = ldok ? (OFF)g.ix(iw, j, 0) * RSZ : 0, ch = hok ? (OFF)g.ix(ihw, j, 0) * RSZ : 0, sk = (OFF)g.s12 * RSZ;   // byte offsets
-  auto load = [&](int kk, real *r, real *h) {
-#pragma unroll
-    for (int q = 0; q < 6; ++q) { r[q] = ldok ? ldb(A.in[q], c0 + (OFF)kk * sk) : 0.; h[q] = hok ? ldb(A.in[q], ch + (OFF)kk * sk) : 0.; }
-  };
-  auto xcomb = [&](const real *r, const real *h, real *X) {
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      real pv = lane_prev(r[q]), nx = lane_next(r[q]);
-      if (tx == 0) pv = h[q];
-      if (tx == 63) nx = h[q];
-      X[q] = pv + 2. * r[q] + nx;
-    }
-  };
-  real xm[6], xc[6], xp[6], rn[6], hn[6];
-  load(kbeg - 1, rn, hn); xcomb(rn, hn, xm);
-  load(kbeg, rn, hn); xcomb(rn, hn, xc);
-  load(kbeg + 1, rn, hn);
-  int buf = 0;
-  for (int k = kbeg; k <= kend; ++k) {
-    const OFF idx = c0 + (OFF)k * sk;
-    xcomb(rn, hn, xp);
-    if (k + 2 <= g.n3 + 1) load(k + 2, rn, hn);                 // prefetch
-    const bool lo = A.zlo && k == 1, hi = A.zhi && k == g.n3;
-    real G[6];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      const real vm = lo ? 2. * xc[q] - xp[q] : xm[q];          // wall rule Q(0) = 2Q(1) - Q(2)
-      const real vp = hi ? 2. * xc[q] - xm[q] : xp[q];
-      G[q] = vm + 2. * xc[q] + vp;
-      sh[buf][q][ty][tx] = G[q];
-    }
-    __syncthreads();
-    if (outok) {
-#pragma unroll
-      for (int q = 0; q < 6; ++q) stb(A.out[q], idx, (sh[buf][q][ty - 1][tx] + 2. * G[q] + sh[buf][q][ty + 1][tx]) / 64.);
-    }
-#pragma unroll
-    for (int q = 0; q < 6; ++q) { xm[q] = xc[q]; xc[q] = xp[q]; }
-    buf ^= 1;
-  }
-}
 __device__ inline void uiuj(const real *s, real *q) {
   q[0] = s[0]; q[1] = s[1]; q[2] = s[2]; q[3] = s[0] * s[0]; q[4] = s[1] * s[1]; q[5] = s[2] * s[2];
   q[6] = s[0] * s[1]; q[7] = s[0] * s[2]; q[8] = s[1] * s[2];
 }
-// K_D + K_F in one pass: Lij from the on-the-fly filters of uc,vc,wc and their products (z-first separable top-hat), the strain
-// rate of the test-filtered velocity from an LDS ring of three raw planes of uf,vf,wf, Mij = 2 (filter(|S|Sij) - alph2 |Sf| Sfij)
-// (sgs.f90:261-272), the contractions (sgs.f90:344-355) and the per-plane partial sums. Mij is never stored.
-#ifndef TYF
-#define TYF 8       // measured: 8 and 10 beat 14 (spills at 1024 threads), 6, 9, 11, 12
-#endif
 struct LijMijArgs {
   const real *uc[3], *uf[3], *mf[6];
   real *part;
@@ -377,116 +311,6 @@ struct LijMijArgs {
   // vcg = the field whose ghost row 0 holds v_c of the row below the slab (periodic copy or the neighbour's), the one value v(-1) would be needed for
   const real *vcg; int perz, xwrap;      // xwrap: inside cales_step with stale x ghost columns, u(0) is read as u(n1)
 };
-template <typename OFF>
-__global__ __launch_bounds__(64 * (TYF + 2)) void k_lij_mij_tile(Geom g, LijMijArgs A) {
-  // one barrier per plane: the filter sums and the partial sums are double-buffered and the ring of raw planes has a fourth
-  // slot, so a wave that is already in the next plane never overwrites what a slower wave still reads (153 KB of LDS)
-  __shared__ real sh[2][9][TYF + 2][64];
-  __shared__ real ring[4][3][TYF + 2][64];
-  __shared__ real shr[2][2][TYF + 2];
-  const int tx = threadIdx.x, ty = threadIdx.y;
-  const int i = blockIdx.x * 62 + tx, j = blockIdx.y * TYF + ty;
-  const int kbeg = blockIdx.z * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, g.n3);
-  const bool ldok = i <= g.n1 + 1 && j <= g.n2 + 1;
-  const bool outok = tx >= 1 && tx <= 62 && ty >= 1 && ty <= TYF && i <= g.n1 && j <= g.n2;
-  const int iw = A.perx ? (i == 0 ? g.n1 : (i == g.n1 + 1 ? 1 : i)) : i;
-  const OFF c0 = ldok ? (OFF)g.ix(iw, j, 0) * RSZ : 0, sk = (OFF)g.s12 * RSZ;      // byte offsets
-  real sm[3], sc[3], sp[3], sn[3], fn[3];
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    sm[q] = ldok ? ldb(A.uc[q], c0 + (OFF)(kbeg - 1) * sk) : 0.;
-    sc[q] = ldok ? ldb(A.uc[q], c0 + (OFF)kbeg * sk) : 0.;
-    sp[q] = ldok ? ldb(A.uc[q], c0 + (OFF)(kbeg + 1) * sk) : 0.;
-    ring[(kbeg - 1) & 3][q][ty][tx] = ldok ? ldb(A.uf[q], c0 + (OFF)(kbeg - 1) * sk) : 0.;
-    ring[kbeg & 3][q][ty][tx] = ldok ? ldb(A.uf[q], c0 + (OFF)kbeg * sk) : 0.;
-    fn[q] = ldok ? ldb(A.uf[q], c0 + (OFF)(kbeg + 1) * sk) : 0.;
-    if (A.wmlo && kbeg == 1 && q < 2) ring[0][q][ty][tx] = (1. + A.flo) * ring[1][q][ty][tx] - A.flo * fn[q];
-  }
-  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-  auto fold = [&](int k, int b) {      // block sums of plane k, fixed order
-    real a = 0., bsum = 0.;
-    for (int q = 1; q <= TYF; ++q) { a += shr[b][0][q]; bsum += shr[b][1][q]; }
-    A.part[(size_t)(k - 1) * A.nblk + blk] = a; A.part[(size_t)(g.n3 + k - 1) * A.nblk + blk] = bsum;
-  };
-  // one plane; LO / HI = the plane next to a z wall (compile-time: the interior planes carry no wall logic at all). At a wall the
-  // ghost plane of every filtered quantity is the extrapolation Q(0) = 2Q(1) - Q(2), so its z combination Q(0) + 2Q(1) + Q(2) is 4 Q(1)
-  auto plane = [&](const int k, auto lo_c, auto hi_c) {
-    constexpr bool LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
-    const int km = (k - 1) & 3, kc = k & 3, kp = (k + 1) & 3, buf = k & 1;
-    const OFF idx = c0 + (OFF)k * sk;
-#pragma unroll
-    for (int q = 0; q < 3; ++q)
-      ring[kp][q][ty][tx] = (HI && A.wmhi && q < 2) ? (1. + A.fhi) * ring[kc][q][ty][tx] - A.fhi * ring[km][q][ty][tx] : fn[q];
-    if (k + 2 <= g.n3 + 1) {
-#pragma unroll
-      for (int q = 0; q < 3; ++q) { sn[q] = ldok ? ldb(A.uc[q], idx + 2 * sk) : 0.; fn[q] = ldok ? ldb(A.uf[q], idx + 2 * sk) : 0.; }
-    }
-    real mf[6];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) mf[q] = outok ? ldb(A.mf[q], idx) : 0.;
-    real qm[9], qc[9], qp[9], r[9];
-    uiuj(sc, qc);
-    if (!LO && !HI) { uiuj(sm, qm); uiuj(sp, qp); }
-#pragma unroll
-    for (int q = 0; q < 9; ++q) {
-      const real G = (LO || HI) ? 4. * qc[q] : qm[q] + 2. * qc[q] + qp[q];
-      r[q] = lane_prev(G) + 2. * G + lane_next(G);
-      sh[buf][q][ty][tx] = r[q];
-    }
-    __syncthreads();
-    if (k > kbeg && tx == 0 && ty == 0) fold(k - 1, buf ^ 1);
-    real lm = 0., mm = 0.;
-    if (outok) {
-      real F[9];
-#pragma unroll
-      for (int q = 0; q < 9; ++q) F[q] = (sh[buf][q][ty - 1][tx] + 2. * r[q] + sh[buf][q][ty + 1][tx]) / 64.;
-      const real l0 = F[3] - F[0] * F[0], l1 = F[4] - F[1] * F[1], l2 = F[5] - F[2] * F[2], l3 = F[6] - F[0] * F[1],
-                   l4 = F[7] - F[0] * F[2], l5 = F[8] - F[1] * F[2];
-#define RU(dk, dj, di) ring[dk][0][ty + (dj)][tx + (di)]
-#define RV(dk, dj, di) ring[dk][1][ty + (dj)][tx + (di)]
-#define RW(dk, dj, di) ring[dk][2][ty + (dj)][tx + (di)]
-      const real u_mcm = RU(km, 0, -1), u_ccm = RU(km, 0, 0), u_mmc = RU(kc, -1, -1), u_cmc = RU(kc, -1, 0), u_mcc = RU(kc, 0, -1),
-                   u_ccc = RU(kc, 0, 0), u_mpc = RU(kc, 1, -1), u_cpc = RU(kc, 1, 0), u_mcp = RU(kp, 0, -1), u_ccp = RU(kp, 0, 0);
-      const real v_cmm = RV(km, -1, 0), v_ccm = RV(km, 0, 0), v_mmc = RV(kc, -1, -1), v_cmc = RV(kc, -1, 0), v_pmc = RV(kc, -1, 1),
-                   v_mcc = RV(kc, 0, -1), v_ccc = RV(kc, 0, 0), v_pcc = RV(kc, 0, 1), v_cmp = RV(kp, -1, 0), v_ccp = RV(kp, 0, 0);
-      const real w_cmm = RW(km, -1, 0), w_mcm = RW(km, 0, -1), w_ccm = RW(km, 0, 0), w_pcm = RW(km, 0, 1), w_cpm = RW(km, 1, 0),
-                   w_cmc = RW(kc, -1, 0), w_mcc = RW(kc, 0, -1), w_ccc = RW(kc, 0, 0), w_pcc = RW(kc, 0, 1), w_cpc = RW(kc, 1, 0);
-#undef RU
-#undef RV
-#undef RW
-      const real dxi = A.dxi, dyi = A.dyi, zc = A.dzci[k], zm = A.dzci[k - 1];
-      real sij[6];
-      sij[0] = (u_ccc - u_mcc) * dxi; sij[1] = (v_ccc - v_cmc) * dyi; sij[2] = (w_ccc - w_ccm) * A.dzfi[k];
-      sij[3] = .125 * ((u_cpc - u_ccc) * dyi + (v_pcc - v_ccc) * dxi + (u_ccc - u_cmc) * dyi + (v_pmc - v_cmc) * dxi +
-                       (u_mpc - u_mcc) * dyi + (v_ccc - v_mcc) * dxi + (u_mcc - u_mmc) * dyi + (v_cmc - v_mmc) * dxi);
-      sij[4] = .125 * ((u_ccp - u_ccc) * zc + (w_pcc - w_ccc) * dxi + (u_ccc - u_ccm) * zm + (w_pcm - w_ccm) * dxi +
-                       (u_mcp - u_mcc) * zc + (w_ccc - w_mcc) * dxi + (u_mcc - u_mcm) * zm + (w_ccm - w_mcm) * dxi);
-      sij[5] = .125 * ((v_ccp - v_ccc) * zc + (w_cpc - w_ccc) * dyi + (v_ccc - v_ccm) * zm + (w_cpm - w_ccm) * dyi +
-                       (v_cmp - v_cmc) * zc + (w_ccc - w_cmc) * dyi + (v_cmc - v_cmm) * zm + (w_ccm - w_cmm) * dyi);
-      const real s0 = sqrt(2. * (sij[0] * sij[0] + sij[1] * sij[1] + sij[2] * sij[2] + 2. * (sij[3] * sij[3] + sij[4] * sij[4] + sij[5] * sij[5])));
-      const real a2s0 = (LO || HI ? 2.52 : 4.00) * s0;      // alph2 (sgs.f90:783-816)
-      const real m0 = 2. * (mf[0] - a2s0 * sij[0]), m1 = 2. * (mf[1] - a2s0 * sij[1]), m2 = 2. * (mf[2] - a2s0 * sij[2]),
-                   m3 = 2. * (mf[3] - a2s0 * sij[3]), m4 = 2. * (mf[4] - a2s0 * sij[4]), m5 = 2. * (mf[5] - a2s0 * sij[5]);
-      lm = m0 * l0 + m1 * l1 + m2 * l2 + (m3 * l3 + m4 * l4 + m5 * l5) * 2.;       // sgs.f90:344-349
-      mm = m0 * m0 + m1 * m1 + m2 * m2 + (m3 * m3 + m4 * m4 + m5 * m5) * 2.;       // sgs.f90:350-355
-    }
-    lm = wave_sum_lane63(lm); mm = wave_sum_lane63(mm);
-    if (tx == 63) { shr[buf][0][ty] = lm; shr[buf][1][ty] = mm; }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) { sm[q] = sc[q]; sc[q] = sp[q]; sp[q] = sn[q]; }
-  };
-  {
-    const std::true_type T; const std::false_type F_;
-    int k = kbeg;
-    const int klast = (A.zhi && kend == g.n3) ? kend - 1 : kend;       // n3 >= 3: the two wall planes are distinct
-    if (A.zlo && k == 1 && k <= kend) { plane(k, T, F_); ++k; }
-    for (; k <= klast; ++k) plane(k, F_, F_);
-    if (k <= kend) plane(k, F_, T);
-  }
-  __syncthreads();
-  if (tx == 0 && ty == 0 && kend >= kbeg) fold(kend, kend & 1);
-}
-
 // K_B + K_D + K_F in one pass (the default): as k_lij_mij_tile, but the test filter of the six products |S|Sij is formed on the fly
 // instead of being read back from a pass of its own -- 12 words per cell less (k_filter6_tile's 6 in + 6 out), 12 in and nothing
 // but partial sums out. The kernel is bound by its vector instructions (profiles/r02a_sq.md: k_lij_mij_tile VALU busy 0.61, LDS 0.31),
@@ -1298,13 +1122,13 @@ __global__ __launch_bounds__(256) void k_wface_fold(Geom g, const real *__restri
 static bool dsmag_fast_ok(const cales_ctx *c) {
   for (int q = 0; q < 2; ++q) if (c->is_wall[q] != 0. || c->C.lwm[q] != 0) return false;      // walls or wall model in x: general path
   // walls / wall model in y (ducts): the fused last pass knows the wall rule along y, the two-pass form does not
-  for (int q = 2; q < 4; ++q) if ((c->is_wall[q] != 0. || c->C.lwm[q] != 0) && (c->fl.dsmag_unfused_filter || c->n[1] < 3)) return false;
+  for (int q = 2; q < 4; ++q) if ((c->is_wall[q] != 0. || c->C.lwm[q] != 0) && c->n[1] < 3) return false;
   return c->n[2] >= 3 && !c->fl.dsmag_reference_sequence;
 }
 // |S|Sij as three fields of pairs between K_AC and the fused last pass: x and y periodic (the one-launch ghost-cell kernel takes a pair field as a
 // field of twice the width), the cell-centred velocity formed by the last pass, 32-bit byte offsets still enough for a field twice as long
 bool dsmag_pairs(const cales_ctx *c) {
-  if (c->C.sgstype != 2 || !dsmag_fast_ok(c) || c->fl.dsmag_unfused_filter || c->fl.dsmag_xghosts || c->fl.wide_offsets || c->fl.unmerged_bc) return false;
+  if (c->C.sgstype != 2 || !dsmag_fast_ok(c) || c->fl.dsmag_xghosts || c->fl.wide_offsets || c->fl.unmerged_bc) return false;
   for (int q = 0; q < 4; ++q) if (c->C.cbcpre[q] != 'P') return false;
   const bool perz = c->C.cbcpre[4] == 'P' && c->C.cbcpre[5] == 'P';
   if (!perz && !(c->is_wall[4] != 0. && c->is_wall[5] != 0.)) return false;      // z: periodic, or two walls (whose ghost planes the filters never read)
@@ -1341,7 +1165,7 @@ static int dsmag_fast(cales_ctx *c) {
   for (int q = 0; q < 6; ++q) lazy = lazy && c->C.bcsgs[q] == 0.;
   // the cell-centred velocity is not stored where the last pass can form it itself (k_lmf_tile<.., UCF = 1>): x periodic, z walls or periodic
   const bool perz = CBP(c, 0, 3) == 'P' && CBP(c, 1, 3) == 'P';
-  const bool ucf = !c->fl.dsmag_unfused_filter && CBP(c, 0, 1) == 'P' && CBP(c, 1, 1) == 'P' && !c->fl.dsmag_xghosts && ((zlo && zhi) || perz);
+  const bool ucf = CBP(c, 0, 1) == 'P' && CBP(c, 1, 1) == 'P' && !c->fl.dsmag_xghosts && ((zlo && zhi) || perz);
   // K_AC: |S|, |S|Sij, cell-centred and test-filtered velocity in one pass over u,v,w (no wall-model faces ->
   // extrapolate(...,lwm) is a no-op; u,v are extrapolated through the z walls, w on the faces is not, sgs.f90:705-710)
   const bool fold = c->fold_dtrk != 0. && pair && ucf;      // (cales_step decides; pair fields and the cell-centred velocity formed by the last pass: the instantiation that exists)
@@ -1394,11 +1218,11 @@ static int dsmag_fast(cales_ctx *c) {
   const int perx = (CBP(c, 0, 1) == 'P' && CBP(c, 1, 1) == 'P' && !c->fl.dsmag_xghosts) ? 1 : 0;
   const int skipz = (zlo && zhi) ? 4 : 0;
   // several ranks with the second stream: the y-halo rows of the twelve scratch fields travel while the interior tiles of the last pass run
-  const bool overlap = c->P > 1 && c->comm.halo_s && c->comm_stream && !c->fl.dsmag_unfused_filter;
+  const bool overlap = c->P > 1 && c->comm.halo_s && c->comm_stream;
   // (every check that can fail comes BEFORE the deferred exchange is queued: an error return behind halo_flush_deferred would leave the
   //  exchange in flight on the second stream with nobody joining it)
   const int lmf_ty = (wylo || wyhi || wmylo || wmyhi) ? TYL : TYLF;      // tile height of the fused last pass (k_lmf_tile<.., YW>)
-  { dim3 tb, tg; int tk; tiles(c->fl.dsmag_unfused_filter ? TYF : lmf_ty, 62, tb, tg, tk);
+  { dim3 tb, tg; int tk; tiles(lmf_ty, 62, tb, tg, tk);
     if ((size_t)2 * n[2] * tg.x * tg.y > c->ntot) { c->err = "dsmag: partial-sum scratch too small"; return 1; } }
   // several ranks: ONE exchange for the y-halo rows of all these fields (six |S|Sij, three filtered velocities, v_c, and |S| itself in the lazy form
   // inside cales_step) instead of one per ghost-cell call; their ghost-cell kernels run first, the rows that then arrive carry the neighbour's
@@ -1425,7 +1249,7 @@ static int dsmag_fast(cales_ctx *c) {
   L.part = c->wk[0]; L.dzci = c->d_dzci; L.dzfi = c->d_dzfi; L.dxi = c->dli[0]; L.dyi = c->dli[1];
   L.zlo = zlo; L.zhi = zhi; L.wmlo = wmlo; L.wmhi = wmhi; L.flo = flo; L.fhi = fhi; L.perx = perx;
   L.wylo = wylo; L.wyhi = wyhi; L.wmylo = wmylo; L.wmyhi = wmyhi;
-  if (!c->fl.dsmag_unfused_filter) {
+  {
     // K_B + K_DF in one pass: filter(|S|Sij) on the fly, strain rate of the filtered velocity, Mij, Lij, contractions, plane partial sums
     ProfScope ps(c, "lij_mij_filter_contract");
     tiles(lmf_ty, 62, mb, mg, kch, LMF_KMAX);
@@ -1452,19 +1276,6 @@ static int dsmag_fast(cales_ctx *c) {
       launch(0, 1); launch(hi0, (int)mg.y - hi0);
     } else launch(0, (int)mg.y);
     LAUNCH(c, k_plane_fold, dim3(2 * n[2]), dim3(256), 0, c->stream, n[2], L.nblk, c->wk[0], c->d_p1d);
-  } else {
-  // K_B: filter(|S| Sij)
-  { ProfScope ps(c, "filter_s0sij");
-    tiles(TYB, 64, mb, mg, kch);
-    Filter6Args A; A.kchunk = kch; A.zlo = zlo; A.zhi = zhi; A.perx = perx;
-    for (int m = 0; m < 6; ++m) { A.in[m] = ssij[m]; A.out[m] = mij[m]; }
-    if (small) LAUNCH(c, k_filter6_tile<unsigned>, mg, mb, 0, c->stream, c->g, A); else LAUNCH(c, k_filter6_tile<size_t>, mg, mb, 0, c->stream, c->g, A); }
-  // K_DF: strain rate of the filtered velocity, Mij, Lij, contractions and plane partial sums in one pass
-  { ProfScope ps(c, "lij_mij_contract");
-    tiles(TYF, 62, mb, mg, kch);
-    L.kchunk = kch; L.nblk = mg.x * mg.y;
-    if (small) LAUNCH(c, k_lij_mij_tile<unsigned>, mg, mb, 0, c->stream, c->g, L); else LAUNCH(c, k_lij_mij_tile<size_t>, mg, mb, 0, c->stream, c->g, L);
-    LAUNCH(c, k_plane_fold, dim3(2 * n[2]), dim3(256), 0, c->stream, n[2], L.nblk, c->wk[0], c->d_p1d); }
   }
   if (c->P > 1) { if (int e = allreduce_res(c, (int)(c->d_p1d - c->res), 2 * n[2], 0)) return e; }   // sgs.f90:475
   const real gar = c->dl[0] * c->dl[1] / (c->C.l[0] * c->C.l[1]);

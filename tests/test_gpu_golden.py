@@ -186,7 +186,7 @@ def test_wide_offset_kernels(name, monkeypatch):
 
 
 @pytest.mark.parametrize("env", ["CALES_DSMAG_REFERENCE_SEQUENCE", "CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_GAUSSEL_MARCH", "CALES_KEEP_LAST_RHS",
-                                 "CALES_DSMAG_UNFUSED_FILTER", "CALES_UNMERGED_BC"])
+                                 "CALES_UNMERGED_BC"])
 @pytest.mark.parametrize("name", ["chan_dsmag", "chan_dsmag_wm", "tgv_dsmag_ppp", "duct_smag_wm_imp1d", "duct_dsmag_wm"])
 def test_unfused_paths(name, env, monkeypatch):
     """The kernel-per-loop forms behind the operator-level entries (general dsmag sequence, mom + rk_update, correc +
