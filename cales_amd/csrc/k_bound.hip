@@ -136,6 +136,112 @@ static int launch_merged(cales_ctx *c, MJobs &J, const Geom *gg = nullptr) {
   LAUNCHCHK(c);
   return 0;
 }
+// ---- ANY set of pointwise conditions (periodic, Dirichlet, Neumann on cell-centred data, Dirichlet on face-centred data) in all three directions in ONE
+// launch: ducts, cavities, half channels -- the cases k_bc_merged (periodic x and y) leaves to one k_set_bc launch per direction. The reference applies
+// x, then y, then z over WHOLE planes (bound.f90:158-199, set_bc: ghost rows and planes of the other directions included), so a later direction also
+// rewrites the edge and corner cells of an earlier one from the values that one left. Every rule is "target = c bc + s source" with ONE source cell
+// (set_bc, bound.f90:202-399), so that sequence has a closed form: the value of a cell the z rule sets is the z rule applied to the value the x and y
+// rules leave in its source cell, and so on down to a cell no rule sets -- Z(Y(X(stored))) with each rule's boundary value taken where the reference
+// takes it (the plane entry of the cell being set, ghost positions included). A thread computes its cell from stored cells no thread writes: no
+// ordering between the directions is left. Not served: Neumann on face-centred data (outflow: set_bc copies the OLD boundary value into the ghost
+// cell while it rewrites the boundary value itself) -- such sets keep the launch per direction.
+struct ADir { char t0, t1, cen; real dr0, dr1; const real *bc0, *bc1; };      // t = 0: this end is left alone; 'P': both ends; cen = 0: face-centred along this direction
+struct AField { real *p; ADir d[3]; char vcomp; };      // vcomp != 0: stored cells through the corrected view of this velocity component
+struct AJobs { int nf; AField f[6]; CorrView V; };
+__device__ inline bool a_set(const ADir &R, int idx, int n) {
+  if (idx == 0) return R.t0 != 0;
+  if (idx == n + 1) return R.t1 != 0;
+  return idx == n && !R.cen && R.t1 == 'D';
+}
+// the rule of direction R for the cell at index idx (in 0, n, n+1): value = c * bc(side) + s * value(src)
+__device__ inline void a_rule(const ADir &R, int idx, int n, real &c, real &s, int &src, int &side) {
+  if (idx == 0) {
+    side = 0; src = 1;
+    if (R.t0 == 'P') { c = 0.; s = 1.; src = n; }
+    else if (R.t0 == 'D') { if (R.cen) { c = 2.; s = -1.; } else { c = 1.; s = 0.; } }
+    else { c = -R.dr0; s = 1.; }                                              // 'N', cell-centred: bound.f90:320-348
+  } else {
+    side = 1; src = n;
+    if (R.t1 == 'P') { c = 0.; s = 1.; src = 1; }
+    else if (R.t1 == 'D') { if (R.cen) { c = 2.; s = -1.; } else if (idx == n) { c = 1.; s = 0.; } else { c = 0.; s = 1.; src = n - 1; } }
+    else { c = R.dr1; s = 1.; }
+  }
+}
+__global__ __launch_bounds__(256) void k_bc_all(Geom g, AJobs J) {
+  const int region = blockIdx.z % 3; const AField F = J.f[blockIdx.z / 3];
+  const int n1 = g.n1, n2 = g.n2, n3 = g.n3;
+  const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y;
+  real *p = F.p;
+  auto S = [&](int i, int j, int k) -> real { return F.vcomp ? view_rd(g, J.V, F.vcomp, F.p, i, j, k) : F.p[g.ix(i, j, k)]; };      // stored cells
+  auto VX = [&](int i, int j, int k) -> real {      // what the x rules leave at (i, j, k)
+    const ADir &R = F.d[0];
+    if (!a_set(R, i, n1)) return S(i, j, k);
+    real c, s_; int src, side; a_rule(R, i, n1, c, s_, src, side);
+    const real *bc = side ? R.bc1 : R.bc0;
+    real v = (c != 0. && bc) ? c * bc[j + (size_t)(n2 + 2) * k] : 0.;
+    if (s_ != 0.) v += s_ * S(src, j, k);
+    return v;
+  };
+  auto VY = [&](int i, int j, int k) -> real {      // ... the x and y rules
+    const ADir &R = F.d[1];
+    if (!a_set(R, j, n2)) return VX(i, j, k);
+    real c, s_; int src, side; a_rule(R, j, n2, c, s_, src, side);
+    const real *bc = side ? R.bc1 : R.bc0;
+    real v = (c != 0. && bc) ? c * bc[i + (size_t)(n1 + 2) * k] : 0.;
+    if (s_ != 0.) v += s_ * VX(i, src, k);
+    return v;
+  };
+  auto VZ = [&](int i, int j, int k) -> real {      // ... all three
+    const ADir &R = F.d[2];
+    if (!a_set(R, k, n3)) return VY(i, j, k);
+    real c, s_; int src, side; a_rule(R, k, n3, c, s_, src, side);
+    const real *bc = side ? R.bc1 : R.bc0;
+    real v = (c != 0. && bc) ? c * bc[i + (size_t)(n1 + 2) * j] : 0.;
+    if (s_ != 0.) v += s_ * VY(i, j, src);
+    return v;
+  };
+  // the (up to three) indices a direction sets: 0, n+1 and, for face-centred Dirichlet data, n
+  if (region == 0) {               // planes the z rules set, every (i, j) of the plane
+    if (a > n1 + 1 || b > n2 + 2 - 1) return;
+    const int ks[3] = {0, n3 + 1, n3};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) if (a_set(F.d[2], ks[q], n3)) p[g.ix(a, b, ks[q])] = VZ(a, b, ks[q]);
+  } else if (region == 1) {        // rows the y rules set, in the planes the z rules leave alone
+    if (a > n1 + 1 || b > n3 + 1 || a_set(F.d[2], b, n3)) return;
+    const int js[3] = {0, n2 + 1, n2};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) if (a_set(F.d[1], js[q], n2)) p[g.ix(a, js[q], b)] = VY(a, js[q], b);
+  } else {                         // columns the x rules set, in the rows and planes the others leave alone
+    if (a > n2 + 1 || b > n3 + 1 || a_set(F.d[1], a, n2) || a_set(F.d[2], b, n3)) return;
+    const int is_[3] = {0, n1 + 1, n1};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) if (a_set(F.d[0], is_[q], n1)) p[g.ix(is_[q], a, b)] = VX(is_[q], a, b);
+  }
+}
+static int launch_all(cales_ctx *c, AJobs &J) {
+  if (!J.nf) return 0;
+  const int *n = c->n;
+  const int ex = std::max(n[0] + 2, n[1] + 2), ey = std::max(n[1] + 2, n[2] + 2);
+  LAUNCH(c, k_bc_all, dim3((ex + 63) / 64, (ey + 3) / 4, 3 * J.nf), dim3(64, 4, 1), 0, c->stream, c->g, J);
+  LAUNCHCHK(c);
+  return 0;
+}
+// one direction of one field: the types of its two ends as the reference's loops over idir / ibound would apply them on this rank
+static void a_dir(cales_ctx *c, ADir &D, int idir, char c0, char c1, int centered, const real *bc0, const real *bc1, real dr0, real dr1) {
+  D.t0 = D.t1 = 0; D.cen = (char)centered; D.dr0 = dr0; D.dr1 = dr1; D.bc0 = bc0; D.bc1 = bc1;
+  if (bc_skipped(c) >> (idir - 1) & 1) return;
+  if (c0 == 'P' && c1 == 'P') {
+    if (idir == 2 && c->P > 1) return;                // rows exchanged between the slabs (halo_y_comm, before the launch)
+    if (idir == 3 && ISB(c, 0, 3)) { }               // (z is never decomposed: periodic z is a local copy)
+    D.t0 = D.t1 = 'P'; return;
+  }
+  if (ISB(c, 0, idir)) D.t0 = c0;
+  if (ISB(c, 1, idir)) D.t1 = c1;
+}
+static bool a_served(const AJobs &J) {      // no Neumann condition on face-centred data
+  for (int q = 0; q < J.nf; ++q) for (int d = 0; d < 3; ++d) { const ADir &D = J.f[q].d[d]; if (!D.cen && (D.t0 == 'N' || D.t1 == 'N')) return false; }
+  return true;
+}
 // x periodic, y periodic on one rank or exchanged between slabs, z pointwise
 static bool merged_ok(const cales_ctx *c, const char *cbx, const char *cby) {
   if (c->fl.unmerged_bc) return false;
@@ -247,6 +353,15 @@ static void merged_pfield(cales_ctx *c, MField &F, real *p, int which) {
   F.t0 = per_z ? 'P' : cbc[4]; F.t1 = per_z ? 'P' : cbc[5];
   F.bc0 = plane(bc, 3, 0, c->n); F.bc1 = plane(bc, 3, 1, c->n); F.dr0 = c->dzc[0]; F.dr1 = c->dzc[c->n[2]];
 }
+// a cell-centred field with the pressure (which = 0) or the sgs (1) BC set as one entry of the all-directions kernel
+static void all_pfield(cales_ctx *c, AField &F, real *p, int which) {
+  const char *cbc = which == 0 ? c->C.cbcpre : c->C.cbcsgs; const DBound &bc = which == 0 ? c->bcp : c->bcs;
+  F.p = p; F.vcomp = 0;
+  for (int idir = 1; idir <= 3; ++idir) {
+    const real dr0 = idir < 3 ? c->dl[idir - 1] : c->dzc[0], dr1 = idir < 3 ? c->dl[idir - 1] : c->dzc[c->n[2]];
+    a_dir(c, F.d[idir - 1], idir, cbc[2 * (idir - 1)], cbc[2 * (idir - 1) + 1], 1, plane(bc, idir, 0, c->n), plane(bc, idir, 1, c->n), dr0, dr1);
+  }
+}
 // ------------------------------------------------------------------------------------------ boundp (bound.f90:156-200)
 // pair fields (x and y periodic only: dsmag_pairs): the y rows (wrapped on one rank, exchanged between slabs) and the z ghost planes through the
 // one-launch kernel in the doubled-width view; direction x is the consumers' business (they wrap around)
@@ -277,6 +392,15 @@ int op_boundp_multi(cales_ctx *c, int nf, real **p, int which) {
     MJobs J; J.nf = nf; J.do_x = !(bc_skipped(c) & 1); J.wrap_y = c->P == 1; J.do_z = per_z || !(bc_skipped(c) & 4);
     for (int q = 0; q < nf; ++q) merged_pfield(c, J.f[q], p[q], which);
     return launch_merged(c, J);
+  }
+  if (!c->fl.unmerged_bc) {      // every other set of a cell-centred field: all directions in one launch (k_bc_all), six fields at a time
+    if (c->P > 1) { if (int e = halo_y_comm(c, nf, p)) return e; }
+    for (int q0 = 0; q0 < nf; q0 += 6) {
+      AJobs J; J.nf = std::min(6, nf - q0); J.V = CorrView{};
+      for (int q = 0; q < J.nf; ++q) all_pfield(c, J.f[q], p[q0 + q], which);
+      if (int e = launch_all(c, J)) return e;
+    }
+    return 0;
   }
   if (int e = halo_self(c, nf, p)) return e;
   for (int idir = 1; idir <= 3; ++idir) {
@@ -455,6 +579,29 @@ int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm
     for (int d = 1; d <= 2; ++d) merged = merged && CBV(c, 0, d, ivel) == 'P' && CBV(c, 1, d, ivel) == 'P';
     if (ivel == 3 && (CBV(c, 0, 3, 3) == 'N' || CBV(c, 1, 3, 3) == 'N')) merged = false;      // face-centred Neumann reads the plane it rewrites
   }
+  // the all-directions kernel for the sets the periodic one does not serve: types of every (component, direction, end) as the loops below would apply them
+  AJobs JA; JA.nf = 0; JA.V = V; bool allv = false; int nra = 0; real *alla[6] = {fl[0], fl[1], fl[2], nullptr, nullptr, nullptr};
+  if (!merged && !c->fl.unmerged_bc) {
+    JA.nf = 3;
+    for (int ivel = 1; ivel <= 3; ++ivel) {
+      AField &F = JA.f[ivel - 1]; F.p = fl[ivel - 1]; F.vcomp = view ? (char)ivel : 0;
+      for (int idir = 1; idir <= 3; ++idir) {
+        const bool periodic = CBV(c, 0, idir, idir) == 'P' && CBV(c, 1, idir, idir) == 'P', normal = ivel == idir;
+        const real dr0 = idir < 3 ? c->dl[idir - 1] : (normal ? c->dzf[0] : c->dzc[0]), dr1 = idir < 3 ? c->dl[idir - 1] : (normal ? c->dzf[n[2]] : c->dzc[n[2]]);
+        char c0 = CBV(c, 0, idir, ivel), c1 = CBV(c, 1, idir, ivel);
+        if (normal && is_correc && !periodic) c0 = c1 = 0;      // the corrected normal velocity keeps its wall value (bound.f90:60-75)
+        a_dir(c, F.d[idir - 1], idir, c0, c1, normal ? 0 : 1, plane(*bnd[ivel - 1], idir, 0, n), plane(*bnd[ivel - 1], idir, 1, n), dr0, dr1);
+        if (!c0 && !c1) F.d[idir - 1].t0 = F.d[idir - 1].t1 = 0;
+        if (!normal) { if (LWM(c, 0, idir) != 0) F.d[idir - 1].t0 = 0; if (LWM(c, 1, idir) != 0) F.d[idir - 1].t1 = 0; }      // set below from the wall-model stress
+      }
+    }
+    allv = a_served(JA);
+    if (allv && c->bc_nride > 0 && c->bc_nride <= 3 && !(bc_skipped(c) & 4)) {      // riders (cales_step): cell-centred fields join this launch -- and this slab exchange
+      nra = c->bc_nride;
+      for (int q = 0; q < nra; ++q) { all_pfield(c, JA.f[3 + q], c->bc_ride[q], c->bc_ride_which[q]); alla[3 + q] = c->bc_ride[q]; }
+      JA.nf = 3 + nra;
+    }
+  }
   if (merged) {
     // riders (cales_step): cell-centred fields whose BC sets take the one-launch kernel too join this launch -- and this slab exchange
     int nr = 0;
@@ -483,6 +630,11 @@ int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm
       if (!normal) { if (LWM(c, 0, 3) != 0) F.t0 = 0; if (LWM(c, 1, 3) != 0) F.t1 = 0; }      // set below from the wall-model stress
     }
     if (int e = launch_merged(c, J)) return e;
+  } else if (allv) {
+    // every other pointwise set: the three directions of the three components (and of the riders) in ONE launch (k_bc_all)
+    if (c->P > 1) { if (int e = halo_y_comm(c, 3 + nra, alla)) return e; }
+    if (nra) c->bc_nride = 0;      // taken
+    if (int e = launch_all(c, JA)) return e;
   } else {
   if (int e = halo_self(c, 3, fl)) return e;
   for (int idir = 1; idir <= 3; ++idir) {
@@ -517,7 +669,22 @@ int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm
   }
   }
   if (is_updt_wm) if (int e = updt_wallmodelbc(c, bu, bv, bw, u, v, w)) return e;
-  for (int idir = 1; idir <= 3; ++idir) {   // tangential Neumann BCs carrying the wall-model stress (bound.f90:125-148)
+  if (!c->fl.unmerged_bc) {      // tangential Neumann BCs carrying the wall-model stress (bound.f90:125-148): every wall-model face in one launch
+    AJobs JW; JW.nf = 3; JW.V = V; bool any = false;
+    for (int ivel = 1; ivel <= 3; ++ivel) {
+      AField &F = JW.f[ivel - 1]; F.p = fl[ivel - 1]; F.vcomp = view ? (char)ivel : 0;
+      for (int idir = 1; idir <= 3; ++idir) {
+        ADir &D = F.d[idir - 1]; D.t0 = D.t1 = 0; D.cen = 1; D.dr0 = idir < 3 ? c->dl[idir - 1] : c->dzc[0]; D.dr1 = idir < 3 ? c->dl[idir - 1] : c->dzc[n[2]];
+        D.bc0 = plane(*bnd[ivel - 1], idir, 0, n); D.bc1 = plane(*bnd[ivel - 1], idir, 1, n);
+        if (ivel == idir) continue;
+        if (ISB(c, 0, idir) && LWM(c, 0, idir) != 0) { D.t0 = CBV(c, 0, idir, ivel); any = true; }
+        if (ISB(c, 1, idir) && LWM(c, 1, idir) != 0) { D.t1 = CBV(c, 1, idir, ivel); any = true; }
+      }
+    }
+    if (!any) return 0;
+    if (a_served(JW)) return launch_all(c, JW);
+  }
+  for (int idir = 1; idir <= 3; ++idir) {   // ... or one launch per direction
     BcJobs J; J.njobs = 0; J.idir = idir;
     const real drt0 = idir < 3 ? c->dl[idir - 1] : c->dzc[0], drt1 = idir < 3 ? c->dl[idir - 1] : c->dzc[n[2]];
     for (int ib = 0; ib <= 1; ++ib) {

@@ -83,6 +83,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     except Exception as e:
         print(trial, name, ng, "P", P, chosen, "exception:", repr(e)[:200]); bad += 1; continue
     tol = [1e-10 if P > 1 else 1e-12] * len(errs)
+    if P > 1 and len(tol) > 5: tol[5] = 1e-9      # pp on slabs: div(u*) / dtrk amplifies the last digits the slab-wise bulk-mean sums move (2e-10 seen on the half channel)
     if len(tol) > 5 and name == "tgv_ppp": tol[5] = 1e-10      # pp: with periodic z its round-off-defined constant moves the last digits (the velocity and p do not see it)
     ok = all(e < t for e, t in zip(errs, tol))
     print(trial, name, ng, "P", P, "kchunk", os.environ.get("CALES_KCHUNK"), chosen, "steps", nsteps, "folded" if folded else "NOT-FOLDED", "OK" if ok else "BAD", " ".join(f"{e:.1e}" for e in errs), flush=True)
