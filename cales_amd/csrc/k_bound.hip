@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256) void k_bc_merged(Geom g, MJobs J) {
   auto wx = [&](int i) { return !J.do_x ? i : i == 0 ? n1 : i == n1 + 1 ? 1 : i; };
   auto wy = [&](int j) { return !J.wrap_y ? j : j == 0 ? n2 : j == n2 + 1 ? 1 : j; };
   const bool top_face = J.do_z && F.t1 == 'D' && !F.centered;      // plane n3 itself is boundary data (face-centred normal component)
+  const bool zset0 = J.do_z && F.t0 != 0, zset1 = J.do_z && F.t1 != 0;      // the z condition sets the ghost plane below / above
   real *p = F.p;
   auto S = [&](int i, int j, int k) -> real { return F.vcomp ? view_rd(g, J.V, F.vcomp, F.p, i, j, k) : F.p[g.ix(i, j, k)]; };      // sources
   if (region == 0) {               // z ghost planes of the column (a, b), ghost columns included
@@ -115,14 +116,15 @@ __global__ __launch_bounds__(256) void k_bc_merged(Geom g, MJobs J) {
       if (F.centered) p[g.ix(a, b, n3 + 1)] = 2. * F.bc1[q2] - S(ia, jb, n3);
       else { p[g.ix(a, b, n3 + 1)] = S(ia, jb, n3 - 1); p[g.ix(a, b, n3)] = F.bc1[q2]; }
     } else if (F.t1 == 'N') p[g.ix(a, b, n3 + 1)] = F.dr1 * F.bc1[q2] + S(ia, jb, n3);
-  } else if (region == 1) {        // x ghost columns of the rows (b, k), k = 1..n3 (ghost rows included)
-    const int bb = a, k = b + 1;   // lanes along y (rows 4 KB apart share DRAM pages; along z they would be a plane apart), blocks along z
-    if (!J.do_x || k > n3 || bb > n2 + 1 || (top_face && k == n3)) return;
+  } else if (region == 1) {        // x ghost columns of the rows (b, k) (ghost rows included), in every plane the z condition does not set -- the ghost planes too
+    // where z is left alone (the corrected normal velocity, skipped directions): the reference's x and y copies run over whole planes (bound.f90:158-199)
+    const int bb = a, k = b;       // lanes along y (rows 4 KB apart share DRAM pages; along z they would be a plane apart), blocks along z
+    if (!J.do_x || k > n3 + 1 || bb > n2 + 1 || (top_face && k == n3) || (k == 0 && zset0) || (k == n3 + 1 && zset1)) return;
     const int jb = wy(bb);
     p[g.ix(0, bb, k)] = S(n1, jb, k); p[g.ix(n1 + 1, bb, k)] = S(1, jb, k);
-  } else {                         // y ghost rows, i = 1..n1, k = 1..n3
-    const int i = a + 1, k = b + 1;
-    if (!J.wrap_y || i > n1 || k > n3 || (top_face && k == n3)) return;
+  } else {                         // y ghost rows, i = 1..n1, the same planes
+    const int i = a + 1, k = b;
+    if (!J.wrap_y || i > n1 || k > n3 + 1 || (top_face && k == n3) || (k == 0 && zset0) || (k == n3 + 1 && zset1)) return;
     p[g.ix(i, 0, k)] = S(i, n2, k); p[g.ix(i, n2 + 1, k)] = S(i, 1, k);
   }
 }
@@ -131,7 +133,7 @@ static int launch_merged(cales_ctx *c, MJobs &J, const Geom *gg = nullptr) {
   const Geom &G = gg ? *gg : c->g;
   const int n[3] = {G.n1, G.n2, G.n3};
   // one grid for the three regions: region 0 needs (n1+2) x (n2+2), region 1 (n2+2) x n3, region 2 n1 x n3 threads
-  const int ex = std::max(n[0] + 2, n[1] + 2), ey = std::max(n[1] + 2, n[2]);
+  const int ex = std::max(n[0] + 2, n[1] + 2), ey = std::max(n[1] + 2, n[2] + 2);
   LAUNCH(c, k_bc_merged, dim3((ex + 63) / 64, (ey + 3) / 4, 3 * J.nf), dim3(64, 4, 1), 0, c->stream, G, J);
   LAUNCHCHK(c);
   return 0;
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256) void k_bc_all(Geom g, AJobs J) {
   };
   // the (up to three) indices a direction sets: 0, n+1 and, for face-centred Dirichlet data, n
   if (region == 0) {               // planes the z rules set, every (i, j) of the plane
-    if (a > n1 + 1 || b > n2 + 2 - 1) return;
+    if (a > n1 + 1 || b > n2 + 1) return;
     const int ks[3] = {0, n3 + 1, n3};
 #pragma unroll
     for (int q = 0; q < 3; ++q) if (a_set(F.d[2], ks[q], n3)) p[g.ix(a, b, ks[q])] = VZ(a, b, ks[q]);
@@ -229,7 +231,7 @@ static int launch_all(cales_ctx *c, AJobs &J) {
 // one direction of one field: the types of its two ends as the reference's loops over idir / ibound would apply them on this rank
 static void a_dir(cales_ctx *c, ADir &D, int idir, char c0, char c1, int centered, const real *bc0, const real *bc1, real dr0, real dr1) {
   D.t0 = D.t1 = 0; D.cen = (char)centered; D.dr0 = dr0; D.dr1 = dr1; D.bc0 = bc0; D.bc1 = bc1;
-  if (bc_skipped(c) >> (idir - 1) & 1) return;
+  if ((bc_skipped(c) >> (idir - 1) & 1) && !(idir == 3 && c0 == 'P' && c1 == 'P')) return;      // (a periodic z is copied even where z is "skipped": the skip is for wall planes nobody reads)
   if (c0 == 'P' && c1 == 'P') {
     if (idir == 2 && c->P > 1) return;                // rows exchanged between the slabs (halo_y_comm, before the launch)
     if (idir == 3 && ISB(c, 0, 3)) { }               // (z is never decomposed: periodic z is a local copy)

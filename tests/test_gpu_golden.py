@@ -570,3 +570,28 @@ def test_every_entry_sees_the_projected_state(name, monkeypatch):
     h.step(dt); assert ncorr() == 0
     assert h.chkdiv()[1] < 1e-12 and ncorr() == 1
     h.profile(False); h.close()
+
+
+@pytest.mark.parametrize("is_correc", [False, True], ids=["impose", "is_correc"])
+@pytest.mark.parametrize("name,ng", [("duct_smag_wm", (16, 12, 10)), ("duct_dsmag", (24, 10, 12)), ("cavity_nnn", (12, 10, 14)), ("halfchan_imp1d", (16, 12, 10)),
+                                     ("devchan_nd", (14, 8, 10)), ("chan_smag_wm", (16, 8, 12)), ("cavity_dsmag", (10, 12, 8))])
+def test_all_directions_ghost_cell_kernel_equals_the_sequence(name, ng, is_correc, monkeypatch):
+    """k_bc_all (every direction of a bounduvw / boundp in one launch: the closed form Z(Y(X(stored))) of bound.f90:158-199) against the reference's
+    order, one launch per direction (CALES_UNMERGED_BC), on RANDOM fields -- ghost cells included, so that every corner and edge cell and every cell a
+    direction leaves alone is told apart -- for ducts (with and without wall model), cavities, a half channel (free-slip top), inflow / outflow (Neumann on
+    face-centred data: not served, both runs take the sequence) and a wall-modelled channel (the periodic kernel + the wall-model faces)."""
+    g, case = load_golden(name); case.ng[:] = ng
+    rng = np.random.RandomState(11)
+    shape = tuple(x + 2 for x in ng)
+    f0 = [F(rng.rand(*shape) - 0.5) for _ in range(5)]
+    out = {}
+    for mode in ("all", "sequence"):
+        if mode == "sequence":
+            monkeypatch.setenv("CALES_UNMERGED_BC", "1")
+        h = _hot(case)
+        h.upload(*f0[:4]); h.set("visct", f0[4]); h.set("pp", f0[3])
+        h.bounduvw(True, is_correc); h.boundp("p", 0); h.boundp("visct", 1); h.boundp("pp", 0)
+        out[mode] = [h.get(k) for k in ("u", "v", "w", "p", "visct", "pp")]
+        h.close()
+    for nm, a, b in zip(("u", "v", "w", "p", "visct", "pp"), out["all"], out["sequence"]):
+        assert np.abs(a - b).max() <= 4e-16 * max(1., np.abs(b).max()), (nm, np.abs(a - b).max())
