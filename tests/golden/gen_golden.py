@@ -102,6 +102,22 @@ END_ONLY = {
                          {r"ng\(1:3\) = .*": "ng(1:3) = 64, 10, 10", r"hwm = 0\.1": "hwm = 0.25"}, 0),
     "duct_smag_wm_imp1d_x64": ("les/_manuscript_turbulent_duct_wall_model/input.nml",
                                {r"ng\(1:3\) = .*": "ng(1:3) = 64, 10, 12", r"hwm = 0\.1": "hwm = 0.25"}, 2),
+    # more fast paths at 64-cell rows, each reached only there: the projection folded into the NEXT momentum pass (k_momrk<.., CORR>) for a DNS channel with bulk
+    # forcing (x ghost columns left alone), a cavity (Neumann transforms in the radix-8 kernels, every ghost cell through k_bc_all, the velocity's corrected
+    # view) and a half channel with z-implicit diffusion (velocity only folded, CORR = 2); the dynamic model's tile passes with walls in y (k_strain_tile<YW>,
+    # k_lmf_tile<YW>); the triply periodic box with the periodic-z tridiagonal tile
+    "chan_nosgs_x64": ("les/_manuscript_turbulent_channel/input.nml",
+                       {r"ng\(1:3\) = .*": "ng(1:3) = 64, 16, 12", r"gr = 5\.": "gr = 2.", r"sgstype = 'smag'": "sgstype = 'none'"}, 0),
+    "cavity_nnn_x64": ("dns/lid_driven_cavity/input.nml",
+                       {r"ng\(1:3\) = .*": "ng(1:3) = 64, 16, 12", r"gr = 0\.": "gr = 1.5"}, 0),
+    "halfchan_imp1d_x64": ("dns/half_channel/input.nml",
+                           {r"ng\(1:3\) = .*": "ng(1:3) = 64, 16, 12", r"gr = 0\.": "gr = 2.", r"inivel = .*": "inivel = 'hcp'"}, 2),
+    "duct_dsmag_x64": ("les/_manuscript_turbulent_duct_wall_model/input.nml",
+                       {r"ng\(1:3\) = .*": "ng(1:3) = 64, 12, 12", r"sgstype = 'smag'": "sgstype = 'dsmag'",
+                        r"lwm\(0:1,1:3\) = .*": "lwm(0:1,1:3) = 0,0, 0,0, 0,0", r"gr = 0\.": "gr = 1.5"}, 0),
+    "tgv_ppp_x64": ("dns/triperiodic/input.nml",
+                    {r"ng\(1:3\) = .*": "ng(1:3) = 64, 16, 16", r"l\(1:3\) = .*": "l(1:3) = 6.283185307179586, 6.283185307179586, 6.283185307179586",
+                     r"visci = .*": "visci = 1600.", r"inivel = .*": "inivel = 'tgv'"}, 0),
 }
 END_KEYS = ("input_nml", "impdiff", "dt", "dt_cfl", "dpdl", "r3_div", "s0raw_u", "s0raw_v", "s0raw_w", "s0raw_p", "r3_s7_u", "r3_s7_v", "r3_s7_w", "r3_s8_p", "r3_s9_visct")
 CASES.update(END_ONLY)

@@ -140,7 +140,8 @@ def test_fused_step_matches_operator_sequence(name):
 
 @pytest.mark.parametrize("keep_x", [False, True], ids=["wrap", "xghosts"])
 @pytest.mark.parametrize("name", ["chan_dsmag_p2", "chan_smag_p2", "duct_dsmag_p2", "tgv_ppp_p2", "chan_dsmag_x64", "tgv_dsmag_ppp_x64",
-                                  "chan_smag_wm_x64", "duct_smag_wm_x64", "duct_smag_wm_imp1d_x64"])
+                                  "chan_smag_wm_x64", "duct_smag_wm_x64", "duct_smag_wm_imp1d_x64",
+                                  "chan_nosgs_x64", "cavity_nnn_x64", "halfchan_imp1d_x64", "duct_dsmag_x64", "tgv_ppp_x64"])
 def test_fused_step_at_power_of_two_rows(name, keep_x, monkeypatch):
     """Reference-made end-of-step states at power-of-two row lengths: radix-8 transforms, fillps inside the forward x pass, the x ghost columns left
     alone until the step returns (and, with CALES_XGHOSTS_IN_STEP, updated by every ghost-cell operator as at the operator level)."""
@@ -172,6 +173,33 @@ def test_folded_strain_pass_against_reference_made_state(name, folded, monkeypat
     pg = g["r3_s8_p"]
     assert relerr(p - p[1:-1, 1:-1, 1:-1].mean(), pg - pg[1:-1, 1:-1, 1:-1].mean()) < 1e-9
     assert relerr(visct, g["r3_s9_visct"]) < 1e-8
+    assert np.abs(h.dpdl() - g["dpdl"]).max() < 1e-9 * max(1., np.abs(g["dpdl"]).max())
+    assert h.chkdiv()[1] < 1e-12
+    h.close()
+
+
+@pytest.mark.parametrize("folded", [True, False], ids=["folded", "separate"])
+@pytest.mark.parametrize("name", ["chan_nosgs_x64", "cavity_nnn_x64", "halfchan_imp1d_x64", "tgv_ppp_x64"])
+def test_folded_momentum_pass_against_reference_made_state(name, folded, monkeypatch):
+    """No subgrid model: the projection of substeps 1 and 2 is applied by the next momentum pass (k_momrk<.., CORR>), the ghost cells through the corrected
+    view. Held to end-of-step states made by the reference's compiled modules at 64-cell rows (gen_golden.py END_ONLY): a forced DNS channel, a cavity,
+    a half channel with z-implicit diffusion (velocity only folded), the triply periodic box. The counters say what ran: ONE correction pass per step
+    (the third substep's) with the fold, three without (CALES_UNFOLDED_MOM)."""
+    if not folded:
+        monkeypatch.setenv("CALES_UNFOLDED_MOM", "1")
+    g, case = load_golden(name)
+    h = _hot(case)
+    h.upload(*(F(g["s0raw_" + k]) for k in "uvwp")); h.startup()
+    h.profile(True)
+    h.step(float(g["dt"]))
+    u, v, w, p, visct = h.download()
+    h.profile(False); st = h.profile_stats()
+    ncorr = st.get("correc_updatep", (0, 0.))[0] + st.get("correc", (0, 0.))[0]
+    assert ncorr == (1 if folded else 3), st
+    for a, k in zip((u, v, w), "uvw"):
+        assert relerr(a, g["r3_s7_" + k]) < 1e-10, k
+    pg = g["r3_s8_p"]
+    assert relerr(p - p[1:-1, 1:-1, 1:-1].mean(), pg - pg[1:-1, 1:-1, 1:-1].mean()) < 1e-9
     assert np.abs(h.dpdl() - g["dpdl"]).max() < 1e-9 * max(1., np.abs(g["dpdl"]).max())
     assert h.chkdiv()[1] < 1e-12
     h.close()
