@@ -68,6 +68,13 @@ def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     tag = args[0]
     ncell = float(args[1]) if len(args) > 1 else None
+    if ncell is None:      # the grid of the profiled bench run, from its own JSON line ("... channel 512x512x512, ...")
+        try:
+            line = open(f"{GO}/{tag}_bench_under_rocprof.json").read().strip().splitlines()[-1]
+            m = re.search(r"(\d+)x(\d+)x(\d+)", json.loads(line)["config"]["workload"])
+            ncell = float(int(m.group(1)) * int(m.group(2)) * int(m.group(3)))
+        except Exception:
+            ncell = None
     rows = []
     for f in glob.glob(f"{GO}/{tag}_stats/**/*kernel_stats.csv", recursive=True):
         shutil.copy(f, f"profiles/{tag}_kernel_stats.csv")
