@@ -686,6 +686,43 @@ def _laplacian_identity(h, case, grid, rng, planes, tol=1e-9):
         assert np.abs(lap - rhs[1:-1, j, 1:-1]).max() < tol * np.abs(lap).max(), j
 
 
+@pytest.mark.parametrize("key,nsteps", [("c2", 10), ("c4", 3), ("c3", 2)])
+def test_baseline_configs_by_value_at_full_size(key, nsteps):
+    """BASELINE.json configs[1], [3] and [2] at their FULL sizes, BY VALUE: the case files bench.py times (256 x 128 x 128 wall-modelled channel with the static
+    model, 512 x 256 x 256 wall-modelled duct with z-implicit diffusion, 512^3 channel with the dynamic model -- the headline run itself), a perturbed initial
+    field, whole time steps on the device against the oracle (OpenMP team of 16: 512^3 takes it ~10 s per step and ~45 GB of host memory): u, v, w <= 1e-9,
+    p (mean removed) <= 1e-8, eddy viscosity <= 1e-7 of each field's maximum, ghost cells included. configs[4] (1024^3: 8.6 GB per field)
+    stays with the size-independent properties of test_c5_cavity_full_size."""
+    import bench
+    from cales_amd.hotpath import HotPath
+    case = bench.channel_case((512, 512, 512), "dsmag") if key == "c3" else bench.load_case(bench.CONFIGS[key]["file"], bench.CONFIGS[key]["impdiff"])
+    ng = tuple(int(x) for x in case.ng)
+    o = Oracle(case, nthreads=16, team_sums=True)
+    u, v, w, p = o.initflow(case.inivel, case.is_wallturb)
+    rng = np.random.RandomState(5)
+    for a in (u, v, w):
+        for k in range(ng[2]):      # plane by plane: no second copy of a 1 GB field
+            a[1:-1, 1:-1, k + 1] += 0.02 * (rng.rand(ng[0], ng[1]) - 0.5)
+    h = HotPath(case)
+    h.upload(u, v, w, p); h.startup()
+    visct, pp = o.zeros(), o.zeros()
+    o.bounduvw(u, v, w, True, False); o.boundp(p, 0); o.cmpt_sgs(u, v, w, visct); o.boundp(visct, 1)
+    dt = 0.5 * o.chkdt(visct, u, v, w)
+    assert abs(h.chkdt() / (2 * dt) - 1) < 1e-12
+    for _ in range(nsteps):
+        h.step(dt); o.step(dt, u, v, w, p, pp, visct)
+    errs = {nm: relerr(h.get(nm), b) for nm, b in (("u", u), ("v", v), ("w", w))}
+    gp = h.get("p")[1:-1, 1:-1, 1:-1]; pi = p[1:-1, 1:-1, 1:-1]
+    errs["p"] = relerr(gp - gp.mean(), pi - pi.mean())
+    del gp, pi
+    errs["visct"] = relerr(h.get("visct"), visct)
+    dg, do = h.chkdiv(), o.chkdiv(u, v, w)
+    print(key, ng, nsteps, "steps:", " ".join(f"{k} {e:.1e}" for k, e in errs.items()), f"divmax {dg[1]:.1e} (oracle {do[1]:.1e})")
+    assert max(errs["u"], errs["v"], errs["w"]) < 1e-9 and errs["p"] < 1e-8 and errs["visct"] < 1e-7, errs
+    assert dg[1] < 20. * do[1] + 1e-14 and dg[1] < 1e-11
+    h.close(); o.close()
+
+
 def test_c4_duct_full_size():
     """BASELINE.json configs[3] at FULL size on one GPU: square duct 512x256x256, wall model on the four walls, z-implicit
     (Crank-Nicolson) viscous terms -> Helmholtz sweeps + DCT Poisson solve. Size-independent properties after three steps (the
