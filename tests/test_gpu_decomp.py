@@ -71,11 +71,24 @@ SLAB_CASES = [("chan_smag_wm", (32, 24, 16), 2), ("chan_smag_wm", (32, 24, 16), 
 
 @pytest.mark.parametrize("name,ng,P", SLAB_CASES)
 def test_slab_ranks_match_single_rank(name, ng, P):
-    from cales_amd.decomp import run_loopback
     case = _case(name, ng)
     if P == 8 and name.startswith("duct_smag"):
         case.hwm = 0.2      # the sampling height must lie inside the slab that owns the wall (sanity.f90:224-231): l(2)/8 = 0.25 is its upper bound here
-    nsteps = 2
+    _slabs_against_single_rank(case, P, 2)
+
+
+@pytest.mark.parametrize("key,P", [("c3", 8), ("c3", 2), ("c2", 4), ("c4", 8)])
+def test_slab_ranks_match_single_rank_at_baseline_sizes(key, P):
+    """The decomposition the north star asks for, at BASELINE.json's own sizes and by value: the 512^3 channel with the dynamic model on 8 and 2 slabs, the
+    256 x 128 x 128 wall-modelled channel on 4, the 512 x 256 x 256 wall-modelled duct (z-implicit) on 8 -- emulated ranks on one GPU (every rank a context of
+    its own, exchanges through device copies) against the one-rank run of the same case file bench.py times; two steps, every field of every slab."""
+    import bench
+    case = bench.channel_case((512, 512, 512), "dsmag") if key == "c3" else bench.load_case(bench.CONFIGS[key]["file"], bench.CONFIGS[key]["impdiff"])
+    _slabs_against_single_rank(case, P, 2)
+
+
+def _slabs_against_single_rank(case, P, nsteps):
+    from cales_amd.decomp import run_loopback
     u, v, w, p, visct, dt, div, dpdl = _single(case, nsteps)
 
     def body(h, r):
@@ -156,6 +169,14 @@ def test_slab_ranks_overlapped_event_ordered(name, ng, P, monkeypatch):
     monkeypatch.setenv("CALES_OVERLAP", "1")
     monkeypatch.setenv("CALES_LOOPBACK_EVENTS", "1")
     test_slab_ranks_match_single_rank(name, ng, P)
+
+
+@pytest.mark.parametrize("key,P", [("c3", 8), ("c4", 4)])
+def test_slab_ranks_overlapped_event_ordered_at_baseline_sizes(key, P, monkeypatch):
+    """The second-stream path at production sizes (several k-chunks per exchange, whole tiles beside the halo rows in flight), event-ordered emulation."""
+    monkeypatch.setenv("CALES_OVERLAP", "1")
+    monkeypatch.setenv("CALES_LOOPBACK_EVENTS", "1")
+    test_slab_ranks_match_single_rank_at_baseline_sizes(key, P)
 
 
 @pytest.mark.parametrize("name,ng,P", [("chan_dsmag", (128, 32, 136), 2), ("chan_dsmag_wm", (72, 32, 40), 4), ("cavity_nnn", (64, 32, 32), 2), ("duct_dsmag_wm", (32, 32, 32), 2)])
