@@ -399,6 +399,9 @@ static inline int tile_kchunk(const cales_ctx *c, long nxy_blocks, int n3) {
   return 0;
 }
 static inline long tile_min_blocks(const cales_ctx *c) { return c->fl.tile_min_blocks; }
+// shortest chunk of a grid with fewer blocks than CUs: every block runs at once, a launch lasts (chunk + 3-plane prologue) planes -- 64^3 Taylor-Green:
+// momentum pass 77 -> 54 us per step with chunks of 4 planes instead of 8 (192 blocks of 7 planes against 48 of 11), the step 0.223 -> 0.200 ms
+constexpr int SMALL_KCH = 4;
 // Few rounds of blocks (a y slab of a decomposed grid, a mid-size grid): the marching tile kernels hold ONE block per CU, a launch then runs in
 // ceil(blocks / CUs) rounds of (chunk length + prologue) planes each, and half-empty last rounds show -- one rank of eight of the 512^3 channel:
 // strain-rate pass 1.48 -> 1.32 ms/step with 9 chunks of 57 planes (504 blocks, 1.97 rounds) instead of 16 of 32 (896 blocks, 3.5 rounds), the

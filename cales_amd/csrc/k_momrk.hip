@@ -276,7 +276,7 @@ int op_momrk(cales_ctx *c, real f1, real f2, real f12) {
   int kchunk = n[2];
   while ((long)gr.x * gr.y * ((n[2] + kchunk - 1) / kchunk) < tile_min_blocks(c) && kchunk > 32) kchunk = (kchunk + 1) / 2;
   // small grids: fewer blocks than one per CU leave most of the chip idle; shorter chunks (their three-plane prologue weighs more) beat that
-  while ((long)gr.x * gr.y * ((n[2] + kchunk - 1) / kchunk) < 256 && kchunk > 8) kchunk = (kchunk + 1) / 2;
+  while ((long)gr.x * gr.y * ((n[2] + kchunk - 1) / kchunk) < 256 && kchunk > SMALL_KCH) kchunk = (kchunk + 1) / 2;
   kchunk = balanced_kchunk(c, (long)gr.x * gr.y, n[2], kchunk);
   if (int fk = tile_kchunk(c, (long)gr.x * gr.y, n[2])) kchunk = fk;
   gr.z = (n[2] + kchunk - 1) / kchunk; A.kchunk = kchunk;

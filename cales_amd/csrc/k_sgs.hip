@@ -1153,7 +1153,7 @@ static int dsmag_fast(cales_ctx *c) {
     kchunk = n[2];
     while ((long)mg.x * mg.y * ((n[2] + kchunk - 1) / kchunk) < tile_min_blocks(c) && kchunk > 32) kchunk = (kchunk + 1) / 2;
     // small grids: fewer blocks than one per CU leave most of the chip idle; shorter chunks (their three-plane prologue weighs more) beat that
-    while ((long)mg.x * mg.y * ((n[2] + kchunk - 1) / kchunk) < 256 && kchunk > 8) kchunk = (kchunk + 1) / 2;
+    while ((long)mg.x * mg.y * ((n[2] + kchunk - 1) / kchunk) < 256 && kchunk > SMALL_KCH) kchunk = (kchunk + 1) / 2;
     kchunk = balanced_kchunk(c, (long)mg.x * mg.y, n[2], kchunk, kmax);
     if (int fk = tile_kchunk(c, (long)mg.x * mg.y, n[2])) kchunk = fk;
     mg.z = (n[2] + kchunk - 1) / kchunk;
