@@ -450,19 +450,18 @@ __global__ __launch_bounds__(256) void k_chkdiv_partial(Geom g, real dxi, real d
   __shared__ real sh[4];
   const int k = blockIdx.y + 1;
   real acc = 0., mx = 0.;
-  const long nplane = (long)g.n1 * g.n2;
-  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nplane; q += (long)gridDim.x * 256) {
-    const int i = (int)(q % g.n1) + 1, j = (int)(q / g.n1) + 1;
+  for (int j = blockIdx.x * 4 + threadIdx.y + 1; j <= g.n2; j += gridDim.x * 4)
+  for (int i = threadIdx.x + 1; i <= g.n1; i += 64) {
     const size_t c = g.ix(i, j, k);
     const real div = (w[c] - w[c - g.s12]) * dzfi[k] + (v[c] - v[c - g.s1]) * dyi + (u[c] - u[c - 1]) * dxi;
     mx = fmax(mx, fabs(div)); acc += div;
   }
   const real rs = block_reduce<0>(acc, sh), rm = block_reduce<1>(mx, sh);
-  if (threadIdx.x == 0) { const size_t o = (size_t)blockIdx.y * gridDim.x + blockIdx.x; psum[o] = rs; pmax[o] = rm; }
+  if (threadIdx.x == 0 && threadIdx.y == 0) { const size_t o = (size_t)blockIdx.y * gridDim.x + blockIdx.x; psum[o] = rs; pmax[o] = rm; }
 }
 int op_chkdiv(cales_ctx *c, real *divtot, real *divmax) {
   const int nbx = 8, np = nbx * c->n[2];
-  LAUNCH(c, k_chkdiv_partial, dim3(nbx, c->n[2]), dim3(256), 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzfi, c->f[CALES_U],
+  LAUNCH(c, k_chkdiv_partial, dim3(nbx, c->n[2]), dim3(64, 4), 0, c->stream, c->g, c->dli[0], c->dli[1], c->d_dzfi, c->f[CALES_U],
                      c->f[CALES_V], c->f[CALES_W], c->d_red + 64, c->d_red + 64 + np);
   LAUNCH(c, k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, np, 0, c->res, 0);
   LAUNCH(c, k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64 + np, np, 1, c->res, 1);
@@ -770,9 +769,10 @@ __global__ __launch_bounds__(256) void k_chkdt_partial(Geom g, real dxi, real dy
   const int k = blockIdx.y + 1;
   const real dl2i = dxi * dxi + dyi * dyi, zf2 = dzfi[k] * dzfi[k], zc2 = dzci[k] * dzci[k];
   real dti = 0., dtid = 0.;
-  const long nplane = (long)g.n1 * g.n2, sj = g.s1, sk = g.s12;
-  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nplane; q += (long)gridDim.x * 256) {
-    const int i = (int)(q % g.n1) + 1, j = (int)(q / g.n1) + 1;
+  const long sj = g.s1, sk = g.s12;
+  // (block = 64 x 4: lanes along x, four rows at a time -- no division per cell)
+  for (int j = blockIdx.x * 4 + threadIdx.y + 1; j <= g.n2; j += gridDim.x * 4)
+  for (int i = threadIdx.x + 1; i <= g.n1; i += 64) {
     const size_t c = g.ix(i, j, k);
     const real ux = fabs(u[c]), vx = 0.25 * fabs(v[c] + v[c - sj] + v[c + 1] + v[c + 1 - sj]),
                  wx = 0.25 * fabs(w[c] + w[c - sk] + w[c + 1] + w[c + 1 - sk]);
@@ -789,20 +789,20 @@ __global__ __launch_bounds__(256) void k_chkdt_partial(Geom g, real dxi, real dy
     dtid = fmax(fmax(fmax(dtid, dtidx), dtidy), dtidz);
   }
   const real ra = block_reduce<1>(dti, sh), rd = block_reduce<1>(dtid, sh);
-  if (threadIdx.x == 0) { const size_t o = (size_t)blockIdx.y * gridDim.x + blockIdx.x; pa[o] = ra; pd[o] = rd; }
+  if (threadIdx.x == 0 && threadIdx.y == 0) { const size_t o = (size_t)blockIdx.y * gridDim.x + blockIdx.x; pa[o] = ra; pd[o] = rd; }
 }
 int op_chkdt(cales_ctx *c, real *dtmax) {
   if (int e = materialize_visct(c)) return e;
   const int nbx = 8, np = nbx * c->n[2];
   real **f = c->f;
   if (c->C.impdiff == 2)
-    LAUNCH(c, k_chkdt_partial<2>, dim3(nbx, c->n[2]), dim3(256), 0, c->stream, c->g, 1. / c->dl[0], 1. / c->dl[1], c->visc, c->d_dzci,
+    LAUNCH(c, k_chkdt_partial<2>, dim3(nbx, c->n[2]), dim3(64, 4), 0, c->stream, c->g, 1. / c->dl[0], 1. / c->dl[1], c->visc, c->d_dzci,
                        c->d_dzfi, f[CALES_VISCT], f[CALES_U], f[CALES_V], f[CALES_W], c->d_red + 64, c->d_red + 64 + np);
   else if (c->C.impdiff == 1)
-    LAUNCH(c, k_chkdt_partial<1>, dim3(nbx, c->n[2]), dim3(256), 0, c->stream, c->g, 1. / c->dl[0], 1. / c->dl[1], c->visc, c->d_dzci,
+    LAUNCH(c, k_chkdt_partial<1>, dim3(nbx, c->n[2]), dim3(64, 4), 0, c->stream, c->g, 1. / c->dl[0], 1. / c->dl[1], c->visc, c->d_dzci,
                        c->d_dzfi, f[CALES_VISCT], f[CALES_U], f[CALES_V], f[CALES_W], c->d_red + 64, c->d_red + 64 + np);
   else
-    LAUNCH(c, k_chkdt_partial<0>, dim3(nbx, c->n[2]), dim3(256), 0, c->stream, c->g, 1. / c->dl[0], 1. / c->dl[1], c->visc, c->d_dzci,
+    LAUNCH(c, k_chkdt_partial<0>, dim3(nbx, c->n[2]), dim3(64, 4), 0, c->stream, c->g, 1. / c->dl[0], 1. / c->dl[1], c->visc, c->d_dzci,
                        c->d_dzfi, f[CALES_VISCT], f[CALES_U], f[CALES_V], f[CALES_W], c->d_red + 64, c->d_red + 64 + np);
   LAUNCH(c, k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64, np, 1, c->res, 0);
   LAUNCH(c, k_fold, dim3(1), dim3(256), 0, c->stream, c->d_red + 64 + np, np, 1, c->res, 1);
