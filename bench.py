@@ -50,8 +50,6 @@ WORDS = {"mom_xyz_ad": 7, "rk_update": 13, "fillps": 4, "correc": 7, "updatep": 
                                     # and the r.h.s. of substep 3 (never read): 11, 14, 11 -> 12 on average over a step
          "strain_filter_uvw": 13,   # u,v,w in; |S|, 6 |S|Sij, 3 test-filtered velocities out (+ 3 cell-centred ones when the last pass does not form them itself)
          "correc_strain_filter_uvw": 19,   # the same pass with the projection and the pressure update folded in (cales_step, one rank): u*,v*,w*,pp,p in; u,v,w,p + |S|, 6 |S|Sij, 3 filtered velocities out
-         "filter_s0sij": 12,        # 6 in, 6 out
-         "lij_mij_contract": 12,    # 3 + 3 + 6 in; plane partial sums out
          "lij_mij_filter_contract": 12,   # the same pass with the test filter of |S|Sij formed on the fly: 3 (u,v,w, or the stored cell-centred velocity) + 3 + 6 (raw |S|Sij) in; partial sums out
          "strain_rate": 10, "filter3d": 2}
 # momentum pass without subgrid model (no eddy viscosity read): u,v,w,p + 3 old r.h.s. in, u,v,w + 3 r.h.s. out = 13; 10, 13, 10 over the substeps.

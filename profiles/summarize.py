@@ -111,8 +111,8 @@ def main():
             r["sq"] = sq[k]
     rows.sort(key=lambda r: -r["total_ms"])
     json.dump(rows, open(f"profiles/{tag}_kernels.json", "w"), indent=1)
-    b2k = {"mom_rk_fused": "k_momrk", "strain_filter_uvw": "k_strain_tile", "correc_strain_filter_uvw": "k_corr_strain_tile", "filter_s0sij": "k_filter6_tile",
-           "lij_mij_contract": "k_lij_mij_tile", "lij_mij_filter_contract": "k_lmf_tile", "correc": "k_correc", "fillps": "k_fillps", "updatep": "k_updatep",
+    b2k = {"mom_rk_fused": "k_momrk", "strain_filter_uvw": "k_strain_tile", "correc_strain_filter_uvw": "k_corr_strain_tile",
+           "lij_mij_filter_contract": "k_lmf_tile", "correc": "k_correc", "fillps": "k_fillps", "updatep": "k_updatep",
            "gaussel_z": "k_gaussel", "fft_x_fwd": "k_fft_x8<0, 0, 0", "fillps_fft_x_fwd": "k_fft_x8<0, 0, 1", "correc_updatep": "k_correc_cell", "fft_x_bwd": "k_fft_x8<1", "fft_y_fwd": "k_fft_y8r<0",
            "fft_y_bwd": "k_fft_y8r<1"}
     if ncell:
