@@ -30,6 +30,7 @@ int main() {
   };
   for (int kch : {1, 4}) {
     char nm[64];
+    snprintf(nm, sizeof nm, "4 columns (64 B), kchunk %d", kch);  run(nm, [&] { hipLaunchKernelGGL(segcopy<4>, dim3((ncols + 3) / 4, (nplanes + kch - 1) / kch), dim3(512), 0, 0, p, ncols, pitch, nrows, nplanes, kch); });
     snprintf(nm, sizeof nm, "8 columns (128 B), kchunk %d", kch);  run(nm, [&] { hipLaunchKernelGGL(segcopy<8>, dim3((ncols + 7) / 8, (nplanes + kch - 1) / kch), dim3(512), 0, 0, p, ncols, pitch, nrows, nplanes, kch); });
     snprintf(nm, sizeof nm, "16 columns (256 B), kchunk %d", kch); run(nm, [&] { hipLaunchKernelGGL(segcopy<16>, dim3((ncols + 15) / 16, (nplanes + kch - 1) / kch), dim3(512), 0, 0, p, ncols, pitch, nrows, nplanes, kch); });
     snprintf(nm, sizeof nm, "32 columns (512 B), kchunk %d", kch); run(nm, [&] { hipLaunchKernelGGL(segcopy<32>, dim3((ncols + 31) / 32, (nplanes + kch - 1) / kch), dim3(512), 0, 0, p, ncols, pitch, nrows, nplanes, kch); });
