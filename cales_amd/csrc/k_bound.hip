@@ -234,8 +234,7 @@ static void a_dir(cales_ctx *c, ADir &D, int idir, char c0, char c1, int centere
   if ((bc_skipped(c) >> (idir - 1) & 1) && !(idir == 3 && c0 == 'P' && c1 == 'P')) return;      // (a periodic z is copied even where z is "skipped": the skip is for wall planes nobody reads)
   if (c0 == 'P' && c1 == 'P') {
     if (idir == 2 && c->P > 1) return;                // rows exchanged between the slabs (halo_y_comm, before the launch)
-    if (idir == 3 && ISB(c, 0, 3)) { }               // (z is never decomposed: periodic z is a local copy)
-    D.t0 = D.t1 = 'P'; return;
+    D.t0 = D.t1 = 'P'; return;                        // (x and z are never decomposed: a local copy)
   }
   if (ISB(c, 0, idir)) D.t0 = c0;
   if (ISB(c, 1, idir)) D.t1 = c1;
