@@ -471,18 +471,19 @@ static int step_body(cales_ctx *c, real dt) {
     const char *bz = &c->cbcvel[4];
     c->defer_imp_rhs = c->C.impdiff == 2 && !c->fl.helmholtz_z_per_column && !c->fl.unfused_imp_rhs &&
                        !(bz[0] == 'P' && bz[1] == 'P') && !(bz[6] == 'P' && bz[7] == 'P') && !(bz[12] == 'P' && bz[13] == 'P');
-    // explicit step without wall model, forced directions periodic: the velocity between the forcing and the correction is only
-    // differenced along the forced direction (fillps) -- the increment is added by the correction kernel, one pass less
+    // explicit step, forced directions periodic: the velocity between the forcing and the correction is only differenced along the forced direction
+    // (fillps) -- the increment is added by the correction kernel, one pass less. With a wall model the one other reader of that velocity, k_wallmodel,
+    // adds the increment to the interior cells it samples, and the bulk means are summed before it runs (not by the forward x transform, below)
     const bool fuse_cu = !c->fl.unfused_correc && c->C.impdiff != 1;     // updatep only needs pp: one pass with correc
+    bool any_wm = false; for (int q = 0; q < 6; ++q) any_wm = any_wm || c->C.lwm[q] != 0;
     { bool ok = c->C.impdiff == 0 && fuse_cu && !c->fl.unfused_forcing;
-      for (int q = 0; q < 6; ++q) ok = ok && c->C.lwm[q] == 0;
       for (int d = 0; d < 3; ++d) if (c->C.is_forced[d]) ok = ok && c->cbcvel[6 * d + 2 * d] == 'P' && c->cbcvel[6 * d + 2 * d + 1] == 'P';
       c->defer_force = ok && (c->C.is_forced[0] || c->C.is_forced[1] || c->C.is_forced[2]); }
     // homogeneous pressure BCs (no boundary r.h.s.) and a radix-8 x plan: fillps is done by the forward x transform, which then
     // also sums the bulk means of the forced components (their increment is only needed by the correction kernel)
     bool fuse_fill = !c->fl.unfused_fillps && solver_can_fuse_fillps(c);
     for (int d = 0; d < 3; ++d) fuse_fill = fuse_fill && ((c->C.bcpre[2 * d] == 0. && c->C.bcpre[2 * d + 1] == 0.) || c->C.cbcpre[2 * d] == 'P');
-    c->fuse_mean_mask = (fuse_fill && c->defer_force && !c->fl.unfused_mean)
+    c->fuse_mean_mask = (fuse_fill && c->defer_force && !c->fl.unfused_mean && !any_wm)
                             ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;
     c->skip_rhs_store = irk == 3 && !c->fl.keep_last_rhs;
     const bool p_ghosts_due = c->fold_mom_dtrk != 0. && !c->fold_mom_pdone;      // the momentum pass below stores p + pp of the interior cells: its ghost cells ride along with those of the prediction

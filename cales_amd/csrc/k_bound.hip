@@ -461,7 +461,10 @@ struct WmArgs {
 // largest face and the blocks beyond a smaller one return.
 // component 0: first tangential component loop, 1: second (wmodel.f90:138-153/154-170, 189-204/205-221, 240-255/256-271)
 struct WmJobs { WmArgs a[6]; int n; };
-__global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmJobs J) {
+// fmask != 0 (cales_step with the bulk forcing left to the correction pass, defer_force): the fields hold u* without this substep's increment f = force[comp];
+// the reference samples the velocity AFTER bulk_forcing has added f to the interior cells (mom.f90:311-335; main.f90:417-440), the ghost cells still being
+// those of the last bounduvw -- so f is added to every sample of a forced component that is an interior cell, and to no ghost cell
+__global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmJobs J, const real *__restrict__ force, int fmask) {
   const WmArgs &A = J.a[blockIdx.z >> 1];
   const int na = A.idir == 1 ? g.n2 : g.n1, nb = A.idir == 3 ? g.n2 : g.n3;
   const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y, comp = blockIdx.z & 1;
@@ -469,15 +472,20 @@ __global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmJobs J) {
   const size_t ld = na + 2;
   const real visci = 1. / A.visc;
   real t1, t2;
+  const real f0 = (fmask & 1) ? force[0] : 0., f1 = (fmask & 2) ? force[1] : 0., f2 = (fmask & 4) ? force[2] : 0.;
+  auto inner = [&](int i, int j, int k) { return i >= 1 && i <= g.n1 && j >= 1 && j <= g.n2 && k >= 1 && k <= g.n3; };
+  auto U = [&](int i, int j, int k) -> real { const real x = A.u[g.ix(i, j, k)]; return (fmask & 1) && inner(i, j, k) ? x + f0 : x; };
+  auto V = [&](int i, int j, int k) -> real { const real x = A.v[g.ix(i, j, k)]; return (fmask & 2) && inner(i, j, k) ? x + f1 : x; };
+  auto W = [&](int i, int j, int k) -> real { const real x = A.w[g.ix(i, j, k)]; return (fmask & 4) && inner(i, j, k) ? x + f2 : x; };
 #define M(pl, a_, b_) pl[(a_) + ld * (b_)]
   if (A.idir == 1) {          // wall normal x; a = j, b = k; tangential: v (first), w (second)
     const int i1 = A.i1, i2 = A.i2;
     if (comp == 0) {
       if (a > na || b < 1 || b > nb) return;           // j = 0..n2, k = 1..n3
       const int j = a, k = b;
-      const real v1 = A.v[g.ix(i1, j, k)], v2 = A.v[g.ix(i2, j, k)];
-      const real w1 = 0.25 * (A.w[g.ix(i1, j, k)] + A.w[g.ix(i1, j + 1, k)] + A.w[g.ix(i1, j, k - 1)] + A.w[g.ix(i1, j + 1, k - 1)]);
-      const real w2 = 0.25 * (A.w[g.ix(i2, j, k)] + A.w[g.ix(i2, j + 1, k)] + A.w[g.ix(i2, j, k - 1)] + A.w[g.ix(i2, j + 1, k - 1)]);
+      const real v1 = V(i1, j, k), v2 = V(i2, j, k);
+      const real w1 = 0.25 * (W(i1, j, k) + W(i1, j + 1, k) + W(i1, j, k - 1) + W(i1, j + 1, k - 1));
+      const real w2 = 0.25 * (W(i2, j, k) + W(i2, j + 1, k) + W(i2, j, k - 1) + W(i2, j + 1, k - 1));
       const real v_mag = M(A.mag_a, j, k), w_mag = 0.25 * (M(A.mag_b, j, k) + M(A.mag_b, j + 1, k) + M(A.mag_b, j, k - 1) + M(A.mag_b, j + 1, k - 1));
       wallmodel(A.mtype, vel_relative(v1, v2, A.coef, v_mag), vel_relative(w1, w2, A.coef, w_mag), A.h, A.l1d, A.visc, t1, t2);
       M(A.bc_a, j, k) = A.sgn * visci * t1;
@@ -485,9 +493,9 @@ __global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmJobs J) {
       if (a < 1 || a > na || b > nb) return;           // j = 1..n2, k = 0..n3
       const int j = a, k = b;
       const real wei = (A.zf[k] - A.zc[k]) / A.dzc[k];
-      const real v1 = 0.5 * ((1. - wei) * (A.v[g.ix(i1, j - 1, k)] + A.v[g.ix(i1, j, k)]) + wei * (A.v[g.ix(i1, j - 1, k + 1)] + A.v[g.ix(i1, j, k + 1)]));
-      const real v2 = 0.5 * ((1. - wei) * (A.v[g.ix(i2, j - 1, k)] + A.v[g.ix(i2, j, k)]) + wei * (A.v[g.ix(i2, j - 1, k + 1)] + A.v[g.ix(i2, j, k + 1)]));
-      const real w1 = A.w[g.ix(i1, j, k)], w2 = A.w[g.ix(i2, j, k)];
+      const real v1 = 0.5 * ((1. - wei) * (V(i1, j - 1, k) + V(i1, j, k)) + wei * (V(i1, j - 1, k + 1) + V(i1, j, k + 1)));
+      const real v2 = 0.5 * ((1. - wei) * (V(i2, j - 1, k) + V(i2, j, k)) + wei * (V(i2, j - 1, k + 1) + V(i2, j, k + 1)));
+      const real w1 = W(i1, j, k), w2 = W(i2, j, k);
       const real v_mag = 0.5 * ((1. - wei) * (M(A.mag_a, j - 1, k) + M(A.mag_a, j, k)) + wei * (M(A.mag_a, j - 1, k + 1) + M(A.mag_a, j, k + 1)));
       const real w_mag = M(A.mag_b, j, k);
       wallmodel(A.mtype, vel_relative(v1, v2, A.coef, v_mag), vel_relative(w1, w2, A.coef, w_mag), A.h, A.l1d, A.visc, t1, t2);
@@ -498,9 +506,9 @@ __global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmJobs J) {
     if (comp == 0) {
       if (a > na || b < 1 || b > nb) return;           // i = 0..n1, k = 1..n3
       const int i = a, k = b;
-      const real u1 = A.u[g.ix(i, j1, k)], u2 = A.u[g.ix(i, j2, k)];
-      const real w1 = 0.25 * (A.w[g.ix(i, j1, k)] + A.w[g.ix(i + 1, j1, k)] + A.w[g.ix(i, j1, k - 1)] + A.w[g.ix(i + 1, j1, k - 1)]);
-      const real w2 = 0.25 * (A.w[g.ix(i, j2, k)] + A.w[g.ix(i + 1, j2, k)] + A.w[g.ix(i, j2, k - 1)] + A.w[g.ix(i + 1, j2, k - 1)]);
+      const real u1 = U(i, j1, k), u2 = U(i, j2, k);
+      const real w1 = 0.25 * (W(i, j1, k) + W(i + 1, j1, k) + W(i, j1, k - 1) + W(i + 1, j1, k - 1));
+      const real w2 = 0.25 * (W(i, j2, k) + W(i + 1, j2, k) + W(i, j2, k - 1) + W(i + 1, j2, k - 1));
       const real u_mag = M(A.mag_a, i, k), w_mag = 0.25 * (M(A.mag_b, i, k) + M(A.mag_b, i + 1, k) + M(A.mag_b, i, k - 1) + M(A.mag_b, i + 1, k - 1));
       wallmodel(A.mtype, vel_relative(u1, u2, A.coef, u_mag), vel_relative(w1, w2, A.coef, w_mag), A.h, A.l1d, A.visc, t1, t2);
       M(A.bc_a, i, k) = A.sgn * visci * t1;
@@ -508,9 +516,9 @@ __global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmJobs J) {
       if (a < 1 || a > na || b > nb) return;           // i = 1..n1, k = 0..n3
       const int i = a, k = b;
       const real wei = (A.zf[k] - A.zc[k]) / A.dzc[k];
-      const real u1 = 0.5 * ((1. - wei) * (A.u[g.ix(i - 1, j1, k)] + A.u[g.ix(i, j1, k)]) + wei * (A.u[g.ix(i - 1, j1, k + 1)] + A.u[g.ix(i, j1, k + 1)]));
-      const real u2 = 0.5 * ((1. - wei) * (A.u[g.ix(i - 1, j2, k)] + A.u[g.ix(i, j2, k)]) + wei * (A.u[g.ix(i - 1, j2, k + 1)] + A.u[g.ix(i, j2, k + 1)]));
-      const real w1 = A.w[g.ix(i, j1, k)], w2 = A.w[g.ix(i, j2, k)];
+      const real u1 = 0.5 * ((1. - wei) * (U(i - 1, j1, k) + U(i, j1, k)) + wei * (U(i - 1, j1, k + 1) + U(i, j1, k + 1)));
+      const real u2 = 0.5 * ((1. - wei) * (U(i - 1, j2, k) + U(i, j2, k)) + wei * (U(i - 1, j2, k + 1) + U(i, j2, k + 1)));
+      const real w1 = W(i, j1, k), w2 = W(i, j2, k);
       const real u_mag = 0.5 * ((1. - wei) * (M(A.mag_a, i - 1, k) + M(A.mag_a, i, k)) + wei * (M(A.mag_a, i - 1, k + 1) + M(A.mag_a, i, k + 1)));
       const real w_mag = M(A.mag_b, i, k);
       wallmodel(A.mtype, vel_relative(u1, u2, A.coef, u_mag), vel_relative(w1, w2, A.coef, w_mag), A.h, A.l1d, A.visc, t1, t2);
@@ -521,18 +529,18 @@ __global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmJobs J) {
     if (comp == 0) {
       if (a > na || b < 1 || b > nb) return;           // i = 0..n1, j = 1..n2
       const int i = a, j = b;
-      const real u1 = A.u[g.ix(i, j, k1)], u2 = A.u[g.ix(i, j, k2)];
-      const real v1 = 0.25 * (A.v[g.ix(i, j, k1)] + A.v[g.ix(i + 1, j, k1)] + A.v[g.ix(i, j - 1, k1)] + A.v[g.ix(i + 1, j - 1, k1)]);
-      const real v2 = 0.25 * (A.v[g.ix(i, j, k2)] + A.v[g.ix(i + 1, j, k2)] + A.v[g.ix(i, j - 1, k2)] + A.v[g.ix(i + 1, j - 1, k2)]);
+      const real u1 = U(i, j, k1), u2 = U(i, j, k2);
+      const real v1 = 0.25 * (V(i, j, k1) + V(i + 1, j, k1) + V(i, j - 1, k1) + V(i + 1, j - 1, k1));
+      const real v2 = 0.25 * (V(i, j, k2) + V(i + 1, j, k2) + V(i, j - 1, k2) + V(i + 1, j - 1, k2));
       const real u_mag = M(A.mag_a, i, j), v_mag = 0.25 * (M(A.mag_b, i, j) + M(A.mag_b, i + 1, j) + M(A.mag_b, i, j - 1) + M(A.mag_b, i + 1, j - 1));
       wallmodel(A.mtype, vel_relative(u1, u2, A.coef, u_mag), vel_relative(v1, v2, A.coef, v_mag), A.h, A.l1d, A.visc, t1, t2);
       M(A.bc_a, i, j) = A.sgn * visci * t1;
     } else {
       if (a < 1 || a > na || b > nb) return;           // i = 1..n1, j = 0..n2
       const int i = a, j = b;
-      const real u1 = 0.25 * (A.u[g.ix(i - 1, j, k1)] + A.u[g.ix(i, j, k1)] + A.u[g.ix(i - 1, j + 1, k1)] + A.u[g.ix(i, j + 1, k1)]);
-      const real u2 = 0.25 * (A.u[g.ix(i - 1, j, k2)] + A.u[g.ix(i, j, k2)] + A.u[g.ix(i - 1, j + 1, k2)] + A.u[g.ix(i, j + 1, k2)]);
-      const real v1 = A.v[g.ix(i, j, k1)], v2 = A.v[g.ix(i, j, k2)];
+      const real u1 = 0.25 * (U(i - 1, j, k1) + U(i, j, k1) + U(i - 1, j + 1, k1) + U(i, j + 1, k1));
+      const real u2 = 0.25 * (U(i - 1, j, k2) + U(i, j, k2) + U(i - 1, j + 1, k2) + U(i, j + 1, k2));
+      const real v1 = V(i, j, k1), v2 = V(i, j, k2);
       const real u_mag = 0.25 * (M(A.mag_a, i - 1, j) + M(A.mag_a, i, j) + M(A.mag_a, i - 1, j + 1) + M(A.mag_a, i, j + 1));
       const real v_mag = M(A.mag_b, i, j);
       wallmodel(A.mtype, vel_relative(u1, u2, A.coef, u_mag), vel_relative(v1, v2, A.coef, v_mag), A.h, A.l1d, A.visc, t1, t2);
@@ -561,7 +569,8 @@ static int updt_wallmodelbc(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, co
     const int na = idir == 1 ? n[1] : n[0], nb = idir == 3 ? n[1] : n[2];
     gx = std::max(gx, (na + 2 + 63) / 64); gy = std::max(gy, (nb + 2 + 3) / 4);
   }
-  if (J.n) LAUNCH(c, k_wallmodel, dim3(gx, gy, 2 * J.n), dim3(64, 4, 1), 0, c->stream, c->g, J);
+  const int fmask = c->defer_force ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;
+  if (J.n) LAUNCH(c, k_wallmodel, dim3(gx, gy, 2 * J.n), dim3(64, 4, 1), 0, c->stream, c->g, J, (const real *)c->d_force, fmask);
   LAUNCHCHK(c);
   return 0;
 }
