@@ -461,10 +461,14 @@ struct WmArgs {
 // largest face and the blocks beyond a smaller one return.
 // component 0: first tangential component loop, 1: second (wmodel.f90:138-153/154-170, 189-204/205-221, 240-255/256-271)
 struct WmJobs { WmArgs a[6]; int n; };
-// fmask != 0 (cales_step with the bulk forcing left to the correction pass, defer_force): the fields hold u* without this substep's increment f = force[comp];
-// the reference samples the velocity AFTER bulk_forcing has added f to the interior cells (mom.f90:311-335; main.f90:417-440), the ghost cells still being
-// those of the last bounduvw -- so f is added to every sample of a forced component that is an interior cell, and to no ghost cell
-__global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmJobs J, const real *__restrict__ force, int fmask) {
+// fmask != 0 (cales_step with the bulk forcing left to the correction pass, defer_force): the fields hold u* without this substep's increment f = force[comp].
+// The reference samples the velocity AFTER bulk_forcing has added f to the interior cells (mom.f90:311-335; main.f90:417-440) and AFTER the ghost-cell rules of
+// this bounduvw have run on that field (bound.f90:18-124, the wall-model update follows them), so a sample carries f times the factor its ghost rule gives the
+// increment: 1 in an interior cell, in a periodic (or slab-neighbour) copy and in a Neumann ghost cell, -1 in the ghost cell of a no-slip wall (2 bc - u), 0 in
+// the ghost cell of a wall-model face (still the value of the last bounduvw) -- the product over the three directions in an edge or corner cell. WmForce::g
+// holds those factors per forced component, direction and side.
+struct WmForce { const real *force; int fmask; real g[3][3][2]; };
+__global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmJobs J, WmForce FF) {
   const WmArgs &A = J.a[blockIdx.z >> 1];
   const int na = A.idir == 1 ? g.n2 : g.n1, nb = A.idir == 3 ? g.n2 : g.n3;
   const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y, comp = blockIdx.z & 1;
@@ -472,11 +476,18 @@ __global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmJobs J, const real 
   const size_t ld = na + 2;
   const real visci = 1. / A.visc;
   real t1, t2;
-  const real f0 = (fmask & 1) ? force[0] : 0., f1 = (fmask & 2) ? force[1] : 0., f2 = (fmask & 4) ? force[2] : 0.;
-  auto inner = [&](int i, int j, int k) { return i >= 1 && i <= g.n1 && j >= 1 && j <= g.n2 && k >= 1 && k <= g.n3; };
-  auto U = [&](int i, int j, int k) -> real { const real x = A.u[g.ix(i, j, k)]; return (fmask & 1) && inner(i, j, k) ? x + f0 : x; };
-  auto V = [&](int i, int j, int k) -> real { const real x = A.v[g.ix(i, j, k)]; return (fmask & 2) && inner(i, j, k) ? x + f1 : x; };
-  auto W = [&](int i, int j, int k) -> real { const real x = A.w[g.ix(i, j, k)]; return (fmask & 4) && inner(i, j, k) ? x + f2 : x; };
+  const int fmask = FF.fmask;
+  const real f0 = (fmask & 1) ? FF.force[0] : 0., f1 = (fmask & 2) ? FF.force[1] : 0., f2 = (fmask & 4) ? FF.force[2] : 0.;
+  auto fac = [&](int q, int i, int j, int k) -> real {      // what the ghost rules make of a constant added to the interior of component q
+    real x = 1.;
+    if (i < 1) x *= FF.g[q][0][0]; else if (i > g.n1) x *= FF.g[q][0][1];
+    if (j < 1) x *= FF.g[q][1][0]; else if (j > g.n2) x *= FF.g[q][1][1];
+    if (k < 1) x *= FF.g[q][2][0]; else if (k > g.n3) x *= FF.g[q][2][1];
+    return x;
+  };
+  auto U = [&](int i, int j, int k) -> real { const real x = A.u[g.ix(i, j, k)]; return (fmask & 1) ? x + fac(0, i, j, k) * f0 : x; };
+  auto V = [&](int i, int j, int k) -> real { const real x = A.v[g.ix(i, j, k)]; return (fmask & 2) ? x + fac(1, i, j, k) * f1 : x; };
+  auto W = [&](int i, int j, int k) -> real { const real x = A.w[g.ix(i, j, k)]; return (fmask & 4) ? x + fac(2, i, j, k) * f2 : x; };
 #define M(pl, a_, b_) pl[(a_) + ld * (b_)]
   if (A.idir == 1) {          // wall normal x; a = j, b = k; tangential: v (first), w (second)
     const int i1 = A.i1, i2 = A.i2;
@@ -569,8 +580,18 @@ static int updt_wallmodelbc(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, co
     const int na = idir == 1 ? n[1] : n[0], nb = idir == 3 ? n[1] : n[2];
     gx = std::max(gx, (na + 2 + 63) / 64); gy = std::max(gy, (nb + 2 + 3) / 4);
   }
-  const int fmask = c->defer_force ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;
-  if (J.n) LAUNCH(c, k_wallmodel, dim3(gx, gy, 2 * J.n), dim3(64, 4, 1), 0, c->stream, c->g, J, (const real *)c->d_force, fmask);
+  WmForce FF; FF.force = c->d_force;
+  FF.fmask = c->defer_force ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;
+  for (int q = 0; q < 3; ++q) for (int d = 1; d <= 3; ++d) for (int sd = 0; sd <= 1; ++sd) {
+    const char t = CBV(c, sd, d, q + 1);
+    real x;
+    if (t == 'P' || !ISB(c, sd, d)) x = 1.;                                  // wrapped interior cell / the slab neighbour's interior cell
+    else if (q + 1 != d && LWM(c, sd, d) != 0) x = 0.;                       // wall-model face: the tangential ghost cell is set AFTER this kernel
+    else if (t == 'N') x = 1.;
+    else x = q + 1 == d ? 0. : -1.;                                          // 'D': face value of the normal component / 2 bc - u of a tangential one
+    FF.g[q][d - 1][sd] = x;
+  }
+  if (J.n) LAUNCH(c, k_wallmodel, dim3(gx, gy, 2 * J.n), dim3(64, 4, 1), 0, c->stream, c->g, J, FF);
   LAUNCHCHK(c);
   return 0;
 }

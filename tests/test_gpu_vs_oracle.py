@@ -155,6 +155,48 @@ def test_time_steps_with_switch_combinations(name, ng, seed, monkeypatch):
     test_time_steps(name, ng, 2)
 
 
+@pytest.mark.parametrize("P", [1, 2])
+@pytest.mark.parametrize("name,ng,hwm", [("chan_smag_wm", (32, 16, 12), None), ("chan_smag_wm", (64, 16, 12), None), ("chan_dsmag_wm", (32, 16, 16), None),
+                                         ("duct_smag_wm", (16, 24, 24), None), ("duct_smag_wm", (16, 8, 24), "first_cell"), ("duct_dsmag_wm", (16, 24, 20), None)])
+def test_deferred_forcing_with_wall_model_equals_the_separate_pass(name, ng, hwm, P, monkeypatch):
+    """cales_step leaves the bulk-forcing increment to the correction pass (one whole-field pass less); with a wall model k_wallmodel is the one reader of the
+    velocity in between and adds the increment to its samples with the factor the ghost-cell rule of each sample gives it (interior, periodic copy, Neumann: 1;
+    no-slip ghost: -1; wall-model ghost: 0). Against the separate pass (CALES_UNFUSED_FORCING, mom.f90:311-335 as its own kernel) to round-off, with an initial
+    field at HALF the target bulk velocity so that the first increment is of order one -- a wrong factor anywhere shows at 1e-3, not at the 1e-10 of a developed
+    flow. One rank and two slabs (the ghost rows are then the neighbour's interior cells)."""
+    from cales_amd.hotpath import HotPath, initflow
+    g, case = load_golden(name)
+    case.ng[:] = ng
+    # ("first_cell": with eight cells across the duct's 2 x 2 section the default sampling height lies inside the first cell -- index_wm = 1 / n, the
+    #  interpolation reaches the ghost cells of the last bounduvw)
+    u0 = [0.5 * a for a in initflow(case)[:3]] + [initflow(case)[3]]
+    rng = np.random.RandomState(3)
+    for a in u0[:3]:
+        a[1:-1, 1:-1, 1:-1] += 0.02 * (rng.rand(*ng) - 0.5)
+
+    def run():
+        if P == 1:
+            h = HotPath(case); h.upload(*u0); h.startup(); dt = 0.25 * h.chkdt()
+            for _ in range(3):
+                h.step(dt)
+            out = h.download(); h.close()
+            return out
+        from cales_amd.decomp import run_loopback
+
+        def body(h, r):
+            h.upload_global(*u0); h.startup(); dt = 0.25 * h.chkdt()
+            for _ in range(3):
+                h.step(dt)
+            return h.download()
+        res = run_loopback(case, P, body)
+        return [np.concatenate([res[r][q][:, 1:-1, :] for r in range(P)], axis=1) for q in range(5)]
+    a = run()
+    monkeypatch.setenv("CALES_UNFUSED_FORCING", "1")
+    b = run()
+    for x, y, nm in zip(a, b, "uvwps"):
+        assert relerr(x, y) < (1e-12 if nm in "uvw" else 1e-10), nm
+
+
 @pytest.mark.parametrize("name,ng", [("chan_dsmag", (32, 16, 16)), ("chan_dsmag", (64, 20, 12)), ("duct_dsmag", (16, 12, 12))])
 def test_time_steps_dsmag_with_inhomogeneous_sgs_bc_values(name, ng, monkeypatch):
     """Non-zero boundary VALUES of the eddy viscosity (bcsgs, src/param.f90:66; boundp(visct) with cbcsgs = 'D': ghost = 2 bc - visct(1)): the dynamic
