@@ -471,12 +471,24 @@ static int step_body(cales_ctx *c, real dt) {
     const char *bz = &c->cbcvel[4];
     c->defer_imp_rhs = c->C.impdiff == 2 && !c->fl.helmholtz_z_per_column && !c->fl.unfused_imp_rhs &&
                        !(bz[0] == 'P' && bz[1] == 'P') && !(bz[6] == 'P' && bz[7] == 'P') && !(bz[12] == 'P' && bz[13] == 'P');
+    // Wall models: the bounduvw between bulk_forcing and fillps (main.f90:492-494) updates the wall-model planes and sets the tangential ghost cells of the
+    // wall-model faces from them -- and nothing reads either before the bounduvw after correc (main.f90:500-501) has rewritten both: fillps differences the
+    // normal components, the solver and boundp see pp, correc only adds to the cells. The one exception is a sampling height inside the first cell
+    // (index_wm = 1 / n): that second wall-model update then interpolates with the ghost cell the first one left. Everywhere else the first update is
+    // skipped here (two launches per substep), with results identical to the last bit.
+    bool any_wm = false, wm_dead = true;
+    for (int d = 1; d <= 3; ++d) for (int sd = 0; sd <= 1; ++sd) if (ISB(c, sd, d) && LWM(c, sd, d) != 0) {
+      any_wm = true;
+      const int idx = IWM(c, sd, d), i1 = sd == 0 ? idx - 1 : idx + 1;
+      if (i1 < 1 || i1 > c->n[d - 1]) wm_dead = false;
+    }
+    for (int q = 0; q < 6; ++q) if (c->C.lwm[q] != 0) any_wm = true;      // (a face owned by another slab counts: the bulk means are then summed by their own pass on every rank)
+    wm_dead = wm_dead && any_wm && !c->fl.unmerged_bc;      // (decided per rank: neither the skipped launches nor the deferred addition communicate; CALES_UNMERGED_BC keeps the reference's full sequence: the A/B of the tests)
     // explicit step, forced directions periodic: the velocity between the forcing and the correction is only differenced along the forced direction
-    // (fillps) -- the increment is added by the correction kernel, one pass less. With a wall model the one other reader of that velocity, k_wallmodel,
-    // adds the increment to the interior cells it samples, and the bulk means are summed before it runs (not by the forward x transform, below)
+    // (fillps) -- the increment is added by the correction kernel, one pass less. With a wall model only where its first update is skipped (above):
+    // k_wallmodel would otherwise sample the velocity without the increment
     const bool fuse_cu = !c->fl.unfused_correc && c->C.impdiff != 1;     // updatep only needs pp: one pass with correc
-    bool any_wm = false; for (int q = 0; q < 6; ++q) any_wm = any_wm || c->C.lwm[q] != 0;
-    { bool ok = c->C.impdiff == 0 && fuse_cu && !c->fl.unfused_forcing;
+    { bool ok = c->C.impdiff == 0 && fuse_cu && !c->fl.unfused_forcing && (!any_wm || wm_dead);
       for (int d = 0; d < 3; ++d) if (c->C.is_forced[d]) ok = ok && c->cbcvel[6 * d + 2 * d] == 'P' && c->cbcvel[6 * d + 2 * d + 1] == 'P';
       c->defer_force = ok && (c->C.is_forced[0] || c->C.is_forced[1] || c->C.is_forced[2]); }
     // homogeneous pressure BCs (no boundary r.h.s.) and a radix-8 x plan: fillps is done by the forward x transform, which then
@@ -498,7 +510,9 @@ static int step_body(cales_ctx *c, real dt) {
       for (int iv = 1; iv <= 3; ++iv) if (int e = op_helmholtz(c, iv, alpha)) return e;
     }
     if (p_ghosts_due && !c->fl.unmerged_bc) { c->bc_nride = 1; c->bc_ride[0] = c->f[CALES_P]; c->bc_ride_which[0] = 0; }
-    { const int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 0, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W]);
+    { c->bc_skip_wm = wm_dead;
+      const int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 0, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W]);
+      c->bc_skip_wm = false;
       const bool rode = p_ghosts_due && !c->fl.unmerged_bc && c->bc_nride == 0; c->bc_nride = 0;
       if (e) return e;
       if (p_ghosts_due && !rode) { if (int e2 = op_boundp(c, c->f[CALES_P], 0)) return e2; } }

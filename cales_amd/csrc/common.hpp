@@ -185,6 +185,7 @@ struct cales_ctx {
   // fused correction + pressure update; p, pp and the eddy viscosity at the end of the step); bounduvw clears the count when it has taken them
   int bc_nride = 0; real *bc_ride[4] = {nullptr, nullptr, nullptr, nullptr}; int bc_ride_which[4] = {0, 0, 0, 0};
   int bc_skip = 0;         // bit d-1: boundp/bounduvw leave direction d alone (set around calls whose consumers do not need it)
+  bool bc_skip_wm = false; // op_bounduvw leaves the wall-model update and the tangential ghost cells of wall-model faces alone (cales_step, see step_body)
   // cales_step with periodic x: the x ghost columns are not maintained between the operators of a step -- every kernel of the step reads the wrapped
   // interior column instead (a ghost-column update touches two cache lines per row and field for two values: 1.2 of 45 ms per step at 512^3) -- and
   // are brought up to date once, when the step returns

@@ -461,14 +461,7 @@ struct WmArgs {
 // largest face and the blocks beyond a smaller one return.
 // component 0: first tangential component loop, 1: second (wmodel.f90:138-153/154-170, 189-204/205-221, 240-255/256-271)
 struct WmJobs { WmArgs a[6]; int n; };
-// fmask != 0 (cales_step with the bulk forcing left to the correction pass, defer_force): the fields hold u* without this substep's increment f = force[comp].
-// The reference samples the velocity AFTER bulk_forcing has added f to the interior cells (mom.f90:311-335; main.f90:417-440) and AFTER the ghost-cell rules of
-// this bounduvw have run on that field (bound.f90:18-124, the wall-model update follows them), so a sample carries f times the factor its ghost rule gives the
-// increment: 1 in an interior cell, in a periodic (or slab-neighbour) copy and in a Neumann ghost cell, -1 in the ghost cell of a no-slip wall (2 bc - u), 0 in
-// the ghost cell of a wall-model face (still the value of the last bounduvw) -- the product over the three directions in an edge or corner cell. WmForce::g
-// holds those factors per forced component, direction and side.
-struct WmForce { const real *force; int fmask; real g[3][3][2]; };
-__global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmJobs J, WmForce FF) {
+__global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmJobs J) {
   const WmArgs &A = J.a[blockIdx.z >> 1];
   const int na = A.idir == 1 ? g.n2 : g.n1, nb = A.idir == 3 ? g.n2 : g.n3;
   const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y, comp = blockIdx.z & 1;
@@ -476,27 +469,15 @@ __global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmJobs J, WmForce FF)
   const size_t ld = na + 2;
   const real visci = 1. / A.visc;
   real t1, t2;
-  const int fmask = FF.fmask;
-  const real f0 = (fmask & 1) ? FF.force[0] : 0., f1 = (fmask & 2) ? FF.force[1] : 0., f2 = (fmask & 4) ? FF.force[2] : 0.;
-  auto fac = [&](int q, int i, int j, int k) -> real {      // what the ghost rules make of a constant added to the interior of component q
-    real x = 1.;
-    if (i < 1) x *= FF.g[q][0][0]; else if (i > g.n1) x *= FF.g[q][0][1];
-    if (j < 1) x *= FF.g[q][1][0]; else if (j > g.n2) x *= FF.g[q][1][1];
-    if (k < 1) x *= FF.g[q][2][0]; else if (k > g.n3) x *= FF.g[q][2][1];
-    return x;
-  };
-  auto U = [&](int i, int j, int k) -> real { const real x = A.u[g.ix(i, j, k)]; return (fmask & 1) ? x + fac(0, i, j, k) * f0 : x; };
-  auto V = [&](int i, int j, int k) -> real { const real x = A.v[g.ix(i, j, k)]; return (fmask & 2) ? x + fac(1, i, j, k) * f1 : x; };
-  auto W = [&](int i, int j, int k) -> real { const real x = A.w[g.ix(i, j, k)]; return (fmask & 4) ? x + fac(2, i, j, k) * f2 : x; };
 #define M(pl, a_, b_) pl[(a_) + ld * (b_)]
   if (A.idir == 1) {          // wall normal x; a = j, b = k; tangential: v (first), w (second)
     const int i1 = A.i1, i2 = A.i2;
     if (comp == 0) {
       if (a > na || b < 1 || b > nb) return;           // j = 0..n2, k = 1..n3
       const int j = a, k = b;
-      const real v1 = V(i1, j, k), v2 = V(i2, j, k);
-      const real w1 = 0.25 * (W(i1, j, k) + W(i1, j + 1, k) + W(i1, j, k - 1) + W(i1, j + 1, k - 1));
-      const real w2 = 0.25 * (W(i2, j, k) + W(i2, j + 1, k) + W(i2, j, k - 1) + W(i2, j + 1, k - 1));
+      const real v1 = A.v[g.ix(i1, j, k)], v2 = A.v[g.ix(i2, j, k)];
+      const real w1 = 0.25 * (A.w[g.ix(i1, j, k)] + A.w[g.ix(i1, j + 1, k)] + A.w[g.ix(i1, j, k - 1)] + A.w[g.ix(i1, j + 1, k - 1)]);
+      const real w2 = 0.25 * (A.w[g.ix(i2, j, k)] + A.w[g.ix(i2, j + 1, k)] + A.w[g.ix(i2, j, k - 1)] + A.w[g.ix(i2, j + 1, k - 1)]);
       const real v_mag = M(A.mag_a, j, k), w_mag = 0.25 * (M(A.mag_b, j, k) + M(A.mag_b, j + 1, k) + M(A.mag_b, j, k - 1) + M(A.mag_b, j + 1, k - 1));
       wallmodel(A.mtype, vel_relative(v1, v2, A.coef, v_mag), vel_relative(w1, w2, A.coef, w_mag), A.h, A.l1d, A.visc, t1, t2);
       M(A.bc_a, j, k) = A.sgn * visci * t1;
@@ -504,9 +485,9 @@ __global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmJobs J, WmForce FF)
       if (a < 1 || a > na || b > nb) return;           // j = 1..n2, k = 0..n3
       const int j = a, k = b;
       const real wei = (A.zf[k] - A.zc[k]) / A.dzc[k];
-      const real v1 = 0.5 * ((1. - wei) * (V(i1, j - 1, k) + V(i1, j, k)) + wei * (V(i1, j - 1, k + 1) + V(i1, j, k + 1)));
-      const real v2 = 0.5 * ((1. - wei) * (V(i2, j - 1, k) + V(i2, j, k)) + wei * (V(i2, j - 1, k + 1) + V(i2, j, k + 1)));
-      const real w1 = W(i1, j, k), w2 = W(i2, j, k);
+      const real v1 = 0.5 * ((1. - wei) * (A.v[g.ix(i1, j - 1, k)] + A.v[g.ix(i1, j, k)]) + wei * (A.v[g.ix(i1, j - 1, k + 1)] + A.v[g.ix(i1, j, k + 1)]));
+      const real v2 = 0.5 * ((1. - wei) * (A.v[g.ix(i2, j - 1, k)] + A.v[g.ix(i2, j, k)]) + wei * (A.v[g.ix(i2, j - 1, k + 1)] + A.v[g.ix(i2, j, k + 1)]));
+      const real w1 = A.w[g.ix(i1, j, k)], w2 = A.w[g.ix(i2, j, k)];
       const real v_mag = 0.5 * ((1. - wei) * (M(A.mag_a, j - 1, k) + M(A.mag_a, j, k)) + wei * (M(A.mag_a, j - 1, k + 1) + M(A.mag_a, j, k + 1)));
       const real w_mag = M(A.mag_b, j, k);
       wallmodel(A.mtype, vel_relative(v1, v2, A.coef, v_mag), vel_relative(w1, w2, A.coef, w_mag), A.h, A.l1d, A.visc, t1, t2);
@@ -517,9 +498,9 @@ __global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmJobs J, WmForce FF)
     if (comp == 0) {
       if (a > na || b < 1 || b > nb) return;           // i = 0..n1, k = 1..n3
       const int i = a, k = b;
-      const real u1 = U(i, j1, k), u2 = U(i, j2, k);
-      const real w1 = 0.25 * (W(i, j1, k) + W(i + 1, j1, k) + W(i, j1, k - 1) + W(i + 1, j1, k - 1));
-      const real w2 = 0.25 * (W(i, j2, k) + W(i + 1, j2, k) + W(i, j2, k - 1) + W(i + 1, j2, k - 1));
+      const real u1 = A.u[g.ix(i, j1, k)], u2 = A.u[g.ix(i, j2, k)];
+      const real w1 = 0.25 * (A.w[g.ix(i, j1, k)] + A.w[g.ix(i + 1, j1, k)] + A.w[g.ix(i, j1, k - 1)] + A.w[g.ix(i + 1, j1, k - 1)]);
+      const real w2 = 0.25 * (A.w[g.ix(i, j2, k)] + A.w[g.ix(i + 1, j2, k)] + A.w[g.ix(i, j2, k - 1)] + A.w[g.ix(i + 1, j2, k - 1)]);
       const real u_mag = M(A.mag_a, i, k), w_mag = 0.25 * (M(A.mag_b, i, k) + M(A.mag_b, i + 1, k) + M(A.mag_b, i, k - 1) + M(A.mag_b, i + 1, k - 1));
       wallmodel(A.mtype, vel_relative(u1, u2, A.coef, u_mag), vel_relative(w1, w2, A.coef, w_mag), A.h, A.l1d, A.visc, t1, t2);
       M(A.bc_a, i, k) = A.sgn * visci * t1;
@@ -527,9 +508,9 @@ __global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmJobs J, WmForce FF)
       if (a < 1 || a > na || b > nb) return;           // i = 1..n1, k = 0..n3
       const int i = a, k = b;
       const real wei = (A.zf[k] - A.zc[k]) / A.dzc[k];
-      const real u1 = 0.5 * ((1. - wei) * (U(i - 1, j1, k) + U(i, j1, k)) + wei * (U(i - 1, j1, k + 1) + U(i, j1, k + 1)));
-      const real u2 = 0.5 * ((1. - wei) * (U(i - 1, j2, k) + U(i, j2, k)) + wei * (U(i - 1, j2, k + 1) + U(i, j2, k + 1)));
-      const real w1 = W(i, j1, k), w2 = W(i, j2, k);
+      const real u1 = 0.5 * ((1. - wei) * (A.u[g.ix(i - 1, j1, k)] + A.u[g.ix(i, j1, k)]) + wei * (A.u[g.ix(i - 1, j1, k + 1)] + A.u[g.ix(i, j1, k + 1)]));
+      const real u2 = 0.5 * ((1. - wei) * (A.u[g.ix(i - 1, j2, k)] + A.u[g.ix(i, j2, k)]) + wei * (A.u[g.ix(i - 1, j2, k + 1)] + A.u[g.ix(i, j2, k + 1)]));
+      const real w1 = A.w[g.ix(i, j1, k)], w2 = A.w[g.ix(i, j2, k)];
       const real u_mag = 0.5 * ((1. - wei) * (M(A.mag_a, i - 1, k) + M(A.mag_a, i, k)) + wei * (M(A.mag_a, i - 1, k + 1) + M(A.mag_a, i, k + 1)));
       const real w_mag = M(A.mag_b, i, k);
       wallmodel(A.mtype, vel_relative(u1, u2, A.coef, u_mag), vel_relative(w1, w2, A.coef, w_mag), A.h, A.l1d, A.visc, t1, t2);
@@ -540,18 +521,18 @@ __global__ __launch_bounds__(256) void k_wallmodel(Geom g, WmJobs J, WmForce FF)
     if (comp == 0) {
       if (a > na || b < 1 || b > nb) return;           // i = 0..n1, j = 1..n2
       const int i = a, j = b;
-      const real u1 = U(i, j, k1), u2 = U(i, j, k2);
-      const real v1 = 0.25 * (V(i, j, k1) + V(i + 1, j, k1) + V(i, j - 1, k1) + V(i + 1, j - 1, k1));
-      const real v2 = 0.25 * (V(i, j, k2) + V(i + 1, j, k2) + V(i, j - 1, k2) + V(i + 1, j - 1, k2));
+      const real u1 = A.u[g.ix(i, j, k1)], u2 = A.u[g.ix(i, j, k2)];
+      const real v1 = 0.25 * (A.v[g.ix(i, j, k1)] + A.v[g.ix(i + 1, j, k1)] + A.v[g.ix(i, j - 1, k1)] + A.v[g.ix(i + 1, j - 1, k1)]);
+      const real v2 = 0.25 * (A.v[g.ix(i, j, k2)] + A.v[g.ix(i + 1, j, k2)] + A.v[g.ix(i, j - 1, k2)] + A.v[g.ix(i + 1, j - 1, k2)]);
       const real u_mag = M(A.mag_a, i, j), v_mag = 0.25 * (M(A.mag_b, i, j) + M(A.mag_b, i + 1, j) + M(A.mag_b, i, j - 1) + M(A.mag_b, i + 1, j - 1));
       wallmodel(A.mtype, vel_relative(u1, u2, A.coef, u_mag), vel_relative(v1, v2, A.coef, v_mag), A.h, A.l1d, A.visc, t1, t2);
       M(A.bc_a, i, j) = A.sgn * visci * t1;
     } else {
       if (a < 1 || a > na || b > nb) return;           // i = 1..n1, j = 0..n2
       const int i = a, j = b;
-      const real u1 = 0.25 * (U(i - 1, j, k1) + U(i, j, k1) + U(i - 1, j + 1, k1) + U(i, j + 1, k1));
-      const real u2 = 0.25 * (U(i - 1, j, k2) + U(i, j, k2) + U(i - 1, j + 1, k2) + U(i, j + 1, k2));
-      const real v1 = V(i, j, k1), v2 = V(i, j, k2);
+      const real u1 = 0.25 * (A.u[g.ix(i - 1, j, k1)] + A.u[g.ix(i, j, k1)] + A.u[g.ix(i - 1, j + 1, k1)] + A.u[g.ix(i, j + 1, k1)]);
+      const real u2 = 0.25 * (A.u[g.ix(i - 1, j, k2)] + A.u[g.ix(i, j, k2)] + A.u[g.ix(i - 1, j + 1, k2)] + A.u[g.ix(i, j + 1, k2)]);
+      const real v1 = A.v[g.ix(i, j, k1)], v2 = A.v[g.ix(i, j, k2)];
       const real u_mag = 0.25 * (M(A.mag_a, i - 1, j) + M(A.mag_a, i, j) + M(A.mag_a, i - 1, j + 1) + M(A.mag_a, i, j + 1));
       const real v_mag = M(A.mag_b, i, j);
       wallmodel(A.mtype, vel_relative(u1, u2, A.coef, u_mag), vel_relative(v1, v2, A.coef, v_mag), A.h, A.l1d, A.visc, t1, t2);
@@ -580,18 +561,7 @@ static int updt_wallmodelbc(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, co
     const int na = idir == 1 ? n[1] : n[0], nb = idir == 3 ? n[1] : n[2];
     gx = std::max(gx, (na + 2 + 63) / 64); gy = std::max(gy, (nb + 2 + 3) / 4);
   }
-  WmForce FF; FF.force = c->d_force;
-  FF.fmask = c->defer_force ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;
-  for (int q = 0; q < 3; ++q) for (int d = 1; d <= 3; ++d) for (int sd = 0; sd <= 1; ++sd) {
-    const char t = CBV(c, sd, d, q + 1);
-    real x;
-    if (t == 'P' || !ISB(c, sd, d)) x = 1.;                                  // wrapped interior cell / the slab neighbour's interior cell
-    else if (q + 1 != d && LWM(c, sd, d) != 0) x = 0.;                       // wall-model face: the tangential ghost cell is set AFTER this kernel
-    else if (t == 'N') x = 1.;
-    else x = q + 1 == d ? 0. : -1.;                                          // 'D': face value of the normal component / 2 bc - u of a tangential one
-    FF.g[q][d - 1][sd] = x;
-  }
-  if (J.n) LAUNCH(c, k_wallmodel, dim3(gx, gy, 2 * J.n), dim3(64, 4, 1), 0, c->stream, c->g, J, FF);
+  if (J.n) LAUNCH(c, k_wallmodel, dim3(gx, gy, 2 * J.n), dim3(64, 4, 1), 0, c->stream, c->g, J);
   LAUNCHCHK(c);
   return 0;
 }
@@ -699,6 +669,9 @@ int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm
     if (int e = launch_jobs(c, J)) return e;
   }
   }
+  // cales_step, first bounduvw of a substep (bc_skip_wm): the wall-model planes and the tangential ghost cells they set are rewritten by the bounduvw that
+  // follows the correction before anything reads them (fillps, the solver and correc do not) -- see step_body
+  if (c->bc_skip_wm) return 0;
   if (is_updt_wm) if (int e = updt_wallmodelbc(c, bu, bv, bw, u, v, w)) return e;
   if (!c->fl.unmerged_bc) {      // tangential Neumann BCs carrying the wall-model stress (bound.f90:125-148): every wall-model face in one launch
     AJobs JW; JW.nf = 3; JW.V = V; bool any = false;

@@ -159,11 +159,13 @@ def test_time_steps_with_switch_combinations(name, ng, seed, monkeypatch):
 @pytest.mark.parametrize("name,ng,hwm", [("chan_smag_wm", (32, 16, 12), None), ("chan_smag_wm", (64, 16, 12), None), ("chan_dsmag_wm", (32, 16, 16), None),
                                          ("duct_smag_wm", (16, 24, 24), None), ("duct_smag_wm", (16, 8, 24), "first_cell"), ("duct_dsmag_wm", (16, 24, 20), None)])
 def test_deferred_forcing_with_wall_model_equals_the_separate_pass(name, ng, hwm, P, monkeypatch):
-    """cales_step leaves the bulk-forcing increment to the correction pass (one whole-field pass less); with a wall model k_wallmodel is the one reader of the
-    velocity in between and adds the increment to its samples with the factor the ghost-cell rule of each sample gives it (interior, periodic copy, Neumann: 1;
-    no-slip ghost: -1; wall-model ghost: 0). Against the separate pass (CALES_UNFUSED_FORCING, mom.f90:311-335 as its own kernel) to round-off, with an initial
-    field at HALF the target bulk velocity so that the first increment is of order one -- a wrong factor anywhere shows at 1e-3, not at the 1e-10 of a developed
-    flow. One rank and two slabs (the ghost rows are then the neighbour's interior cells)."""
+    """Two things cales_step does with a wall model, against the reference's full sequence: (1) the bounduvw between bulk_forcing and fillps leaves the wall-model
+    update and the tangential ghost cells of the wall-model faces alone -- the bounduvw after correc rewrites both before anything has read them (main.f90:492-501;
+    not when the sampling height lies inside the first cell, "first_cell": the second update then interpolates with the ghost cell the first one set, and nothing
+    is skipped); (2) with that update gone nothing samples the velocity between bulk_forcing and correc, so the forcing increment is added by the correction pass
+    (one whole-field pass less). Against CALES_UNFUSED_FORCING (mom.f90:311-335 as its own kernel, the skip still on) and against CALES_UNMERGED_BC (every ghost-cell
+    launch and both wall-model updates of the reference, no deferral) to round-off, from an initial field at HALF the target bulk velocity so that the first
+    increment is of order one. One rank and two slabs."""
     from cales_amd.hotpath import HotPath, initflow
     g, case = load_golden(name)
     case.ng[:] = ng
@@ -193,8 +195,11 @@ def test_deferred_forcing_with_wall_model_equals_the_separate_pass(name, ng, hwm
     a = run()
     monkeypatch.setenv("CALES_UNFUSED_FORCING", "1")
     b = run()
-    for x, y, nm in zip(a, b, "uvwps"):
-        assert relerr(x, y) < (1e-12 if nm in "uvw" else 1e-10), nm
+    monkeypatch.delenv("CALES_UNFUSED_FORCING"); monkeypatch.setenv("CALES_UNMERGED_BC", "1")
+    c_ = run()
+    for other, what in ((b, "separate forcing pass"), (c_, "full reference sequence")):
+        for x, y, nm in zip(a, other, "uvwps"):
+            assert relerr(x, y) < (1e-12 if nm in "uvw" else 1e-10), (what, nm)
 
 
 @pytest.mark.parametrize("name,ng", [("chan_dsmag", (32, 16, 16)), ("chan_dsmag", (64, 20, 12)), ("duct_dsmag", (16, 12, 12))])
