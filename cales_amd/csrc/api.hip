@@ -480,7 +480,7 @@ static int step_body(cales_ctx *c, real dt) {
     for (int d = 1; d <= 3; ++d) for (int sd = 0; sd <= 1; ++sd) if (ISB(c, sd, d) && LWM(c, sd, d) != 0) {
       any_wm = true;
       const int idx = IWM(c, sd, d), i1 = sd == 0 ? idx - 1 : idx + 1;
-      if (i1 < 1 || i1 > c->n[d - 1]) wm_dead = false;
+      if (i1 < 1 || i1 > c->n[d - 1] || d == 1) wm_dead = false;      // (wall-model faces in x: no reference-made vector holds this shortcut to account there)
     }
     for (int q = 0; q < 6; ++q) if (c->C.lwm[q] != 0) any_wm = true;      // (a face owned by another slab counts: the bulk means are then summed by their own pass on every rank)
     wm_dead = wm_dead && any_wm && !c->fl.unmerged_bc;      // (decided per rank: neither the skipped launches nor the deferred addition communicate; CALES_UNMERGED_BC keeps the reference's full sequence: the A/B of the tests)
