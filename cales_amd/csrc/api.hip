@@ -495,7 +495,7 @@ static int step_body(cales_ctx *c, real dt) {
     // also sums the bulk means of the forced components (their increment is only needed by the correction kernel)
     bool fuse_fill = !c->fl.unfused_fillps && solver_can_fuse_fillps(c);
     for (int d = 0; d < 3; ++d) fuse_fill = fuse_fill && ((c->C.bcpre[2 * d] == 0. && c->C.bcpre[2 * d + 1] == 0.) || c->C.cbcpre[2 * d] == 'P');
-    c->fuse_mean_mask = (fuse_fill && c->defer_force && !c->fl.unfused_mean && !any_wm)
+    c->fuse_mean_mask = (fuse_fill && c->defer_force && !c->fl.unfused_mean)
                             ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;
     c->skip_rhs_store = irk == 3 && !c->fl.keep_last_rhs;
     const bool p_ghosts_due = c->fold_mom_dtrk != 0. && !c->fold_mom_pdone;      // the momentum pass below stores p + pp of the interior cells: its ghost cells ride along with those of the prediction
