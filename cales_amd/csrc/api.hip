@@ -406,7 +406,18 @@ static int end_of_step_refresh(cales_ctx *c) {
 // A projection that cales_step left to its successor (fold_mom, third substep) is completed here -- correction pass, ghost cells, and the refresh of
 // the x ghost columns -- before anything else looks at the fields. Collective over the ranks like every entry of the C-ABI.
 static int finish_pending(cales_ctx *c) {
-  if (c->fold_mom_dtrk == 0. || c->in_step) return 0;
+  if (c->in_step) return 0;
+  if (c->fold_mom_dtrk == 0.) {
+    if (!c->pend_xrefresh) return 0;
+    // only the refresh of the x ghost columns is due (cales_step with step_xskip, common.hpp)
+    c->pend_xrefresh = false;
+    c->in_step = true; c->step_xskip = true;
+    struct Restore { cales_ctx *c; ~Restore() { c->in_step = false; c->step_xskip = false; c->bc_nride = 0; } } restore{c};
+    if (int e = end_of_step_refresh(c)) { c->launch_err = "refreshing the x ghost columns failed (" + c->err + "): the context is unusable"; return e; }
+    LAUNCHCHK(c);
+    return 0;
+  }
+  c->pend_xrefresh = false;      // (the completion below ends with the refresh)
   const real dtrk = c->fold_mom_dtrk;
   c->fold_mom_dtrk = 0.;
   c->in_step = true; c->step_xskip = c->pend_xskip; c->defer_force = c->fold_mom_fmask != 0;
@@ -445,6 +456,10 @@ static int step_body(cales_ctx *c, real dt) {
               !c->fl.unfused_fillps && solver_can_fuse_fillps(c) && c->xkind == 0 && sgs_wraps_x(c);
     for (int q = 0; q < 6; ++q) ok = ok && c->C.lwm[q] == 0;
     for (int d = 0; d < 3; ++d) ok = ok && ((c->C.bcpre[2 * d] == 0. && c->C.bcpre[2 * d + 1] == 0.) || c->C.cbcpre[2 * d] == 'P');      // (fillps inside the x transform)
+    if (c->pend_xrefresh && !ok) {      // the step before left the x ghost columns stale and this one reads them
+      c->pend_xrefresh = false; c->step_xskip = true;
+      if (int e = end_of_step_refresh(c)) return e;
+    }
     c->step_xskip = ok; }
   // dynamic model, one rank, x and y periodic (|S|Sij as pair fields), z periodic or two no-slip walls, explicit diffusion, no wall model: the
   // projection u = u* - dtrk grad(pp) (+ the deferred forcing) and p += pp are folded into the strain-rate pass of cmpt_sgs, which reads the velocity
@@ -555,6 +570,7 @@ static int step_body(cales_ctx *c, real dt) {
     c->visct_bc_done = false;
   }
   if (c->fold_mom_dtrk != 0.) { c->pend_xskip = c->step_xskip; reset.keep = true; }      // the last projection is the next step's (or finish_pending's), the refresh with it
+  else if (c->step_xskip && !c->fl.eager_projection) c->pend_xrefresh = true;      // the x ghost columns wait for the first caller that is not the next step (finish_pending)
   else if (int e = end_of_step_refresh(c)) return e;
   c->h_red[40] = dt;
   return 0;

@@ -135,7 +135,9 @@ int cales_out2d_duct(cales_ctx *ctx, cales_real *buf);
  * so what a caller can observe is always the projected state of src/main.f90:498-504 (CALES_EAGER_PROJECTION). ONE RANK ONLY: on several
  * slabs completing a projection moves slab rows, so cales_step always completes it itself and no entry is a hidden collective. Three entries do not
  * complete a pending projection because they read no field: cales_get_forcing, cales_get_dpdl (scalars accumulated by the step) and cales_get_bcvel
- * (boundary planes the projection does not touch). */
+ * (boundary planes the projection does not touch).
+ * With periodic x (explicit diffusion, no wall model) the kernels of a step wrap around and the x GHOST COLUMNS are likewise brought up to date by the first
+ * entry other than the next cales_step (local copies, any number of slabs; the same mechanism, the same three exceptions). */
 int cales_step(cales_ctx *ctx, cales_real dt);
 int cales_get_dpdl(cales_ctx *ctx, cales_real dpdl[3]);                         /* main.f90:492,508 (sync) */
 

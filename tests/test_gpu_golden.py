@@ -557,6 +557,44 @@ def _header_ctx_entries():
     return sorted(set(re.findall(r"\b(cales_[a-z_0-9]+)\s*\(\s*(?:const\s+)?cales_ctx\s*\*", hdr)))
 
 
+@pytest.mark.parametrize("first", ["chkdt", "chkdiv", "get_field", "stats", "cmpt_sgs"])
+@pytest.mark.parametrize("name,ng", [("chan_dsmag", (64, 16, 12)), ("chan_smag", (64, 18, 12)), ("tgv_dsmag_ppp", (64, 16, 16))])
+def test_x_ghost_columns_are_refreshed_for_the_first_reader(name, ng, first, monkeypatch):
+    """cales_step with periodic x leaves the x ghost columns alone (its kernels wrap around) and, since round 5, returns with them STALE: the next cales_step
+    does not read them, every other entry of include/cales.h brings them up to date before it does anything else (finish_pending, pend_xrefresh). Whatever
+    entry comes first after the steps -- a reduction that reads u(n1+1), a download, the plane statistics, an operator -- must see what the eager form
+    (CALES_EAGER_PROJECTION, refresh inside the step) sees: same scalars, same fields, ghost cells included, to the last bit."""
+    from cales_amd.hotpath import HotPath, initflow
+    g, case = load_golden(name); case.ng[:] = ng
+    u0 = initflow(case)
+    rng = np.random.RandomState(2)
+    for a in u0[:3]:
+        a[1:-1, 1:-1, 1:-1] += 0.02 * (rng.rand(*ng) - 0.5)
+
+    def run():
+        h = HotPath(case); h.upload(*u0); h.startup(); dt = 0.4 * h.chkdt()
+        for _ in range(3):
+            h.step(dt)
+        out = {}
+        if first == "chkdt": out["chkdt"] = h.chkdt()
+        elif first == "chkdiv": out["chkdiv"] = h.chkdiv()
+        elif first == "get_field": out["w"] = h.get("w")
+        elif first == "stats": out["stats"] = h.stats_chan()
+        else: h.cmpt_sgs()
+        out["fields"] = h.download(); out["dt2"] = h.chkdt(); out["div"] = h.chkdiv()
+        h.close()
+        return out
+    lazy = run()
+    monkeypatch.setenv("CALES_EAGER_PROJECTION", "1")
+    eager = run()
+    for k in lazy:
+        if k == "fields":
+            for a, b, nm in zip(lazy[k], eager[k], "uvwps"):
+                assert np.array_equal(a, b), nm
+        else:
+            assert np.array_equal(np.asarray(lazy[k]), np.asarray(eager[k])), k
+
+
 @pytest.mark.parametrize("name", ["cavity_nnn", "chan_nosgs_imp1d"])
 def test_every_entry_sees_the_projected_state(name, monkeypatch):
     """The pending-projection contract, mechanically (the state protected is src/main.f90:498-504): after a cales_step that leaves its
