@@ -5,6 +5,7 @@ TAG=${1:-r05}; CFGS=${2:-"c1 c2 c4 c5"}
 export TMPDIR=/tmp
 O=$PWD/gpurun_out
 for c in $CFGS; do
+  rm -rf $O/${TAG}_${c}_stats $O/${TAG}_${c}_fetch $O/${TAG}_${c}_write      # (a tag used before: its old files would be summed with the new ones)
   rocprofv3 --output-format csv --kernel-trace --stats -d $O/${TAG}_${c}_stats -- python3 bench.py --skip-headline --configs $c --no-cpu > $O/${TAG}_${c}.json 2> $O/${TAG}_${c}.log
   if [ $c != c1 ]; then
     rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $O/${TAG}_${c}_fetch -- python3 bench.py --skip-headline --configs $c --no-cpu > /dev/null 2> $O/${TAG}_${c}_fetch.log

@@ -10,6 +10,7 @@ ARGS=${@:-"--steps 3 --warmup 1 --no-cpu"}
 export TMPDIR=/tmp
 O=$PWD/gpurun_out
 mkdir -p $O
+rm -rf $O/${TAG}_stats $O/${TAG}_fetch $O/${TAG}_write $O/${TAG}_sq1 $O/${TAG}_sq2 $O/${TAG}_calib_fetch $O/${TAG}_calib_write      # (a tag used before: its old files would be summed with the new ones)
 if [ ! -x tools/micro/calib ]; then (cd tools/micro && hipcc --offload-arch=gfx950 -O3 -o calib calib.hip); fi
 ./tools/micro/calib > $O/${TAG}_calib.jsonl 2>&1
 if [ ! -x tools/micro/segcopy ]; then (cd tools/micro && hipcc --offload-arch=gfx950 -O3 -o segcopy segcopy.hip); fi
