@@ -491,12 +491,8 @@ static int step_body(cales_ctx *c, real dt) {
     // normal components, the solver and boundp see pp, correc only adds to the cells. The one exception is a sampling height inside the first cell
     // (index_wm = 1 / n): that second wall-model update then interpolates with the ghost cell the first one left. Everywhere else the first update is
     // skipped here (two launches per substep), with results identical to the last bit.
-    bool any_wm = false, wm_dead = true;
-    for (int d = 1; d <= 3; ++d) for (int sd = 0; sd <= 1; ++sd) if (ISB(c, sd, d) && LWM(c, sd, d) != 0) {
-      any_wm = true;
-      const int idx = IWM(c, sd, d), i1 = sd == 0 ? idx - 1 : idx + 1;
-      if (i1 < 1 || i1 > c->n[d - 1] || d == 1) wm_dead = false;      // (wall-model faces in x: no reference-made vector holds this shortcut to account there)
-    }
+    bool any_wm = false, wm_dead = !wm_samples_ghost(c);
+    for (int sd = 0; sd <= 1; ++sd) if (ISB(c, sd, 1) && LWM(c, sd, 1) != 0) wm_dead = false;      // (wall-model faces in x: no reference-made vector holds this shortcut to account there)
     for (int q = 0; q < 6; ++q) if (c->C.lwm[q] != 0) any_wm = true;      // (a face owned by another slab counts: the bulk means are then summed by their own pass on every rank)
     wm_dead = wm_dead && any_wm && !c->fl.unmerged_bc;      // (decided per rank: neither the skipped launches nor the deferred addition communicate; CALES_UNMERGED_BC keeps the reference's full sequence: the A/B of the tests)
     // explicit step, forced directions periodic: the velocity between the forcing and the correction is only differenced along the forced direction

@@ -426,5 +426,13 @@ static inline int balanced_kchunk(const cales_ctx *c, long nxy_blocks, int n3, i
   }
   return bk;
 }
+// a wall-model face of this rank whose sampling height lies inside the first cell: its interpolation reaches the ghost cell (index_wm = 1 / n, wmodel.f90:120-131)
+static inline bool wm_samples_ghost(const cales_ctx *c) {
+  for (int d = 1; d <= 3; ++d) for (int sd = 0; sd <= 1; ++sd) if (ISB(c, sd, d) && LWM(c, sd, d) != 0) {
+    const int idx = IWM(c, sd, d), i1 = sd == 0 ? idx - 1 : idx + 1;
+    if (i1 < 1 || i1 > c->n[d - 1]) return true;
+  }
+  return false;
+}
 static inline int bc_skipped(const cales_ctx *c) { return c->bc_skip | (c->step_xskip ? 1 : 0); }
 static inline dim3 grid3(int nx, int ny, int nz, dim3 b) { return dim3((nx + b.x - 1) / b.x, (ny + b.y - 1) / b.y, (nz + b.z - 1) / b.z); }

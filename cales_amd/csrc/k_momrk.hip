@@ -315,7 +315,8 @@ int op_momrk(cales_ctx *c, real f1, real f2, real f12) {
 #undef MOMRK_L2
   LAUNCHCHK(c);
   bool wm = false; for (int q = 0; q < 6; ++q) wm = wm || c->C.lwm[q] != 0;
-  if (wm) {
+  // (inside cales_step the only reader of those ghost layers before the next bounduvw rewrites them is a wall model that samples the ghost cell itself)
+  if (wm && (!c->in_step || wm_samples_ghost(c) || c->fl.unmerged_bc)) {
     GhostCopy G; for (int q = 0; q < 3; ++q) { G.src[q] = c->f[CALES_U + q]; G.dst[q] = c->f2[q]; }
     const int na = std::max(n[0], n[1]), nb = std::max(n[1], n[2]);
     LAUNCH(c, k_copy_ghosts, dim3((na + 2 + 63) / 64, (nb + 2 + 3) / 4, 18), dim3(64, 4, 1), 0, c->stream, c->g, G);
