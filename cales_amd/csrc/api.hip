@@ -492,9 +492,9 @@ static int step_body(cales_ctx *c, real dt) {
     // (index_wm = 1 / n): that second wall-model update then interpolates with the ghost cell the first one left. Everywhere else the first update is
     // skipped here (two launches per substep), with results identical to the last bit.
     bool any_wm = false, wm_dead = !wm_samples_ghost(c);
-    for (int sd = 0; sd <= 1; ++sd) if (ISB(c, sd, 1) && LWM(c, sd, 1) != 0) wm_dead = false;      // (wall-model faces in x: no reference-made vector holds this shortcut to account there)
+    for (int sd = 0; sd <= 1; ++sd) if (LWM(c, sd, 1) != 0) wm_dead = false;      // (wall-model faces in x: no reference-made vector holds this shortcut to account there)
     for (int q = 0; q < 6; ++q) if (c->C.lwm[q] != 0) any_wm = true;      // (a face owned by another slab counts: the bulk means are then summed by their own pass on every rank)
-    wm_dead = wm_dead && any_wm && !c->fl.unmerged_bc;      // (decided per rank: neither the skipped launches nor the deferred addition communicate; CALES_UNMERGED_BC keeps the reference's full sequence: the A/B of the tests)
+    wm_dead = wm_dead && any_wm && !c->fl.unmerged_bc;      // (from the case alone, the same on every rank: the deferred forcing moves the all-reduce of the bulk means; CALES_UNMERGED_BC keeps the reference's full sequence: the A/B of the tests)
     // explicit step, forced directions periodic: the velocity between the forcing and the correction is only differenced along the forced direction
     // (fillps) -- the increment is added by the correction kernel, one pass less. With a wall model only where its first update is skipped (above):
     // k_wallmodel would otherwise sample the velocity without the increment

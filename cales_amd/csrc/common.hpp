@@ -426,11 +426,14 @@ static inline int balanced_kchunk(const cales_ctx *c, long nxy_blocks, int n3, i
   }
   return bk;
 }
-// a wall-model face of this rank whose sampling height lies inside the first cell: its interpolation reaches the ghost cell (index_wm = 1 / n, wmodel.f90:120-131)
+// some wall-model face of the CASE (on whichever rank) has its sampling height inside the first cell: its interpolation reaches the ghost cell (index_wm = 1 / n,
+// wmodel.f90:120-131; the conditions of host_setup.cpp's index search, from global quantities only -- every rank must answer alike: what hangs on the answer
+// moves an all-reduce from one place of the substep to another)
 static inline bool wm_samples_ghost(const cales_ctx *c) {
-  for (int d = 1; d <= 3; ++d) for (int sd = 0; sd <= 1; ++sd) if (ISB(c, sd, d) && LWM(c, sd, d) != 0) {
-    const int idx = IWM(c, sd, d), i1 = sd == 0 ? idx - 1 : idx + 1;
-    if (i1 < 1 || i1 > c->n[d - 1]) return true;
+  const real h = c->C.hwm;
+  for (int d = 1; d <= 3; ++d) for (int sd = 0; sd <= 1; ++sd) if (c->C.lwm[sd + 2 * (d - 1)] != 0) {
+    const real first = d < 3 ? 0.5 * c->dl[d - 1] : (sd == 0 ? c->zc[1] : c->C.l[2] - c->zc[c->n[2]]);      // distance of the first cell centre from the wall
+    if (!(first < h)) return true;
   }
   return false;
 }
