@@ -493,7 +493,7 @@ static int step_body(cales_ctx *c, real dt) {
     // skipped here (two launches per substep), with results identical to the last bit.
     bool any_wm = false, wm_dead = !wm_samples_ghost(c);
     for (int sd = 0; sd <= 1; ++sd) if (LWM(c, sd, 1) != 0) wm_dead = false;      // (wall-model faces in x: no reference-made vector holds this shortcut to account there)
-    for (int q = 0; q < 6; ++q) if (c->C.lwm[q] != 0) any_wm = true;      // (a face owned by another slab counts: the bulk means are then summed by their own pass on every rank)
+    for (int q = 0; q < 6; ++q) if (c->C.lwm[q] != 0) any_wm = true;      // (of the case: a face owned by another slab counts)
     wm_dead = wm_dead && any_wm && !c->fl.unmerged_bc;      // (from the case alone, the same on every rank: the deferred forcing moves the all-reduce of the bulk means; CALES_UNMERGED_BC keeps the reference's full sequence: the A/B of the tests)
     // explicit step, forced directions periodic: the velocity between the forcing and the correction is only differenced along the forced direction
     // (fillps) -- the increment is added by the correction kernel, one pass less. With a wall model only where its first update is skipped (above):
