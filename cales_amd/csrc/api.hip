@@ -131,7 +131,7 @@ void cales_destroy(cales_ctx *c) {
   DBound *bs[11] = {&c->bcu, &c->bcv, &c->bcw, &c->bcp, &c->bcs, &c->bcuf, &c->bcvf, &c->bcwf, &c->bcu_mag, &c->bcv_mag, &c->bcw_mag};
   for (auto *b : bs) free_bound(*b);
   for (int d = 0; d < 3; ++d) hipFree(c->rhsbp[d]);
-  field_free(c, c->scr1); hipFree(c->d_red); hipFree(c->d_force); if (c->d_mpart) hipFree(c->d_mpart); if (c->d_abct) hipFree(c->d_abct); if (c->d_cs) hipFree(c->d_cs); if (c->d_nullw) hipFree(c->d_nullw); if (c->d_stat) hipFree(c->d_stat); if (c->d_stat2) hipFree(c->d_stat2); hipHostFree(c->h_red);
+  field_free(c, c->scr1); hipFree(c->d_red); hipFree(c->d_force); if (c->d_mpart) hipFree(c->d_mpart); if (c->d_abct) hipFree(c->d_abct); if (c->d_hztab) hipFree(c->d_hztab); if (c->d_cs) hipFree(c->d_cs); if (c->d_nullw) hipFree(c->d_nullw); if (c->d_stat) hipFree(c->d_stat); if (c->d_stat2) hipFree(c->d_stat2); hipHostFree(c->h_red);
   field_free(c, c->s0); field_free(c, c->uc); field_free(c, c->vc); field_free(c, c->wc); field_free(c, c->uf); field_free(c, c->vf); field_free(c, c->wf); field_free(c, c->alph2); if (!c->p1d_in_comm) hipFree(c->d_p1d);
   for (int m = 0; m < 6; ++m) { field_free(c, c->wk[m]); field_free(c, c->sij[m]); field_free(c, c->mij[m]); }
   for (int m = 0; m < 3; ++m) if (c->ss2[m]) hipFree(c->ss2[m] - 2 * c->field_ofs);

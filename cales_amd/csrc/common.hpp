@@ -36,7 +36,20 @@ struct Geom {              // passed by value to kernels
   __host__ __device__ inline size_t ix(int i, int j, int k) const { return (size_t)i + (size_t)s1 * (size_t)j + (size_t)s12 * (size_t)k; }
 };
 
-struct DBound { real *x, *y, *z; };   // device BC planes (0:na+1,0:nb+1,0:1), reference src/typedef.f90:10-14
+struct DBound { real *x, *y, *z; };
+// Boundary term of an inhomogeneous z condition in the r.h.s. of a velocity Helmholtz solve (cmpt_rhs_b / bc_rhs, bound.f90:447-560, times alpha, main.f90:432):
+// one side of one component; `at` evaluates it for column (i, j) with the operations of the reference in their order. Used by k_rhs_b_velz (the term as a
+// pass of its own / as a plane) and by the in-LDS Helmholtz sweep, which adds it while it loads plane 1 / n.
+struct RhsBz {
+  const real *bc; char ctype, cf; real dlc, dlf, sgn, alpha;
+  __host__ __device__ inline real at(int i, int j, int n1) const {
+    const real bcv = bc[i + (size_t)(n1 + 2) * j];
+    real r = 0.;
+    if (cf == 'c') { if (ctype == 'D') r = -2. * bcv / dlc / dlf; else if (ctype == 'N') r = sgn * bcv / dlf; }
+    else           { if (ctype == 'D') r = -bcv / dlc / dlf;      else if (ctype == 'N') r = sgn * bcv / dlc; }
+    return r * alpha;
+  }
+};   // device BC planes (0:na+1,0:nb+1,0:1), reference src/typedef.f90:10-14
 
 // Communication hooks (include/cales.h): y-slab neighbours, slab<->mode-block all-to-all, all-reduce.
 struct Comm {
@@ -173,6 +186,9 @@ struct cales_ctx {
   real *d_stat = nullptr;      // partial sums and result of the plane statistics
   bool abct_ready = false, force_zeroed = false;
   real *d_abct = nullptr;      // tridiagonal coefficients in the chunked order of k_gaussel_tile
+  // z-only Helmholtz sweeps: the chunked tables of (ivel, alpha) pairs already seen -- three alphas per step, the same every step while dt stays (four slots per
+  // component, round robin); a hit saves the scaling and the table kernel of that sweep
+  struct HzTab { real alpha = 0.; int nz = 0; bool ok = false; } hz_tab[3][4]; int hz_next[3] = {0, 0, 0}; real *d_hztab = nullptr;
   int ncu = 0;      // compute units of the device (balanced_kchunk)
   int fuse_mean_mask = 0; real *d_mpart = nullptr; size_t n_mpart = 0;      // bulk means of the forced components are summed by that pass too
   real fuse_fillps_dti = 0.;   // != 0: the forward x transform of the next pressure solve forms pp = div(u*)/dtrk itself (cales_step)

@@ -742,13 +742,10 @@ __global__ __launch_bounds__(256) void k_rhs_b_velz(Geom g, real *p, const real 
                                                     real dlf, real alpha, int pos, real *plane_out) {
   const int i = blockIdx.x * 64 + threadIdx.x + 1, j = blockIdx.y * 4 + threadIdx.y + 1;
   if (i > g.n1 || j > g.n2) return;
-  const real bcv = bcplane[i + (size_t)(g.n1 + 2) * j];
-  const real sgn = ib == 0 ? 1. : -1.;
-  real r = 0.;
-  if (c_or_f == 'c') { if (ctype == 'D') r = -2. * bcv / dlc / dlf; else if (ctype == 'N') r = sgn * bcv / dlf; }
-  else               { if (ctype == 'D') r = -bcv / dlc / dlf;      else if (ctype == 'N') r = sgn * bcv / dlc; }
-  if (plane_out) plane_out[(size_t)(i - 1) + (size_t)g.n1 * (j - 1)] = r * alpha;      // added by the fused Helmholtz sweep, in the reference's order
-  else p[g.ix(i, j, pos)] += r * alpha;
+  const RhsBz R{bcplane, ctype, c_or_f, dlc, dlf, ib == 0 ? (real)1. : (real)-1., alpha};
+  const real r = R.at(i, j, g.n1);
+  if (plane_out) plane_out[(size_t)(i - 1) + (size_t)g.n1 * (j - 1)] = r;      // added by the column form of the fused Helmholtz sweep, in the reference's order
+  else p[g.ix(i, j, pos)] += r;
 }
 // The same term on the x (idir = 1) and y (idir = 2) faces for the 3-D implicit step (main.f90:424-431: rhsbx, rhsby times alpha, added by
 // updt_rhs_b to the first and the last unknown plane of the direction, bound.f90:578-603): inflow profiles, moving side walls.
@@ -782,6 +779,22 @@ int op_rhs_b_velxy(cales_ctx *c, int ivel, real alpha) {
   return 0;
 }
 // planes != nullptr: the two contributions go to planes[0 / n1*n2] instead of being added to the field; has[ib] tells which exist
+// the two sides as arguments of the in-LDS sweep (no launch): has[ib] as below
+void rhs_b_velz_args(cales_ctx *c, int ivel, real alpha, RhsBz *R, int *has) {
+  const int *n = c->n; const int n3 = n[2];
+  const char cf = ivel == 3 ? 'f' : 'c';
+  const DBound &bc = ivel == 1 ? c->bcu : ivel == 2 ? c->bcv : c->bcw;
+  const char *cbc = &c->cbcvel[6 * (ivel - 1) + 4];
+  has[0] = has[1] = 0;
+  for (int ib = 0; ib <= 1; ++ib) {
+    R[ib] = RhsBz{nullptr, 0, cf, 1., 1., 1., 0.};
+    if (!ISB(c, ib, 3) || cbc[ib] == 'P') continue;
+    has[ib] = 1;
+    const real dlc = cf == 'c' ? (ib ? c->dzc[n3] : c->dzc[0]) : (ib ? c->dzc[n3 - 1] : c->dzc[1]);
+    const real dlf = ib ? c->dzf[n3] : c->dzf[1];
+    R[ib] = RhsBz{plane(bc, 3, ib, n), cbc[ib], cf, dlc, dlf, ib == 0 ? (real)1. : (real)-1., alpha};
+  }
+}
 int op_rhs_b_velz(cales_ctx *c, int ivel, real alpha, real *planes, int *has) {
   const int *n = c->n; const int n3 = n[2];
   const char cf = ivel == 3 ? 'f' : 'c';

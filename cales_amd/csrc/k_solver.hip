@@ -880,7 +880,7 @@ __global__ void k_abc_chunked(int nz, int M, const real *__restrict__ a, const r
 struct TileMap { int blocked, cw, n2l, mofs, nmode; size_t kstride, segstride;
                  // z-only Helmholtz sweeps of real fields (no eigenvalue shift): nolam; cales_step forms the r.h.s. of rk.f90:108-118 and
                  // main.f90:422-433 while loading, (u - hf12*dudtd) + f + rhs_b, and plane nz+1 (wall face of w) receives the first two terms
-                 int nolam, nq, has_lo, has_hi; const real *dud, *force, *rb; real hf12; };
+                 int nolam, nq, has_lo, has_hi; const real *dud, *force; RhsBz blo, bhi; real hf12; };
 // PER = 1: periodic z (solver.f90:109-150, gaussel_periodic): the tile solves the (n-1)-row system for the right-hand side AND for the closure
 // vector p2 = (-a(1), 0, ..., 0, -c(n-1)) -- one more right-hand side of the same matrix, kept in registers -- and the last row follows from
 // p(n) = (p(n) - c(n) p1(1) - a(n) p1(n-1)) / (b(n) + lambda + c(n) p2(1) + a(n) p2(n-1) + eps), p(1:n-1) = p1 + p2 p(n); ra, rb_, rc: the raw a, b, c.
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(64 * gt_width(M, NV) / NV, (PER ? 2 : M <= 8 ? 4 : 
     }
     if (NV == 2 && T.dud) {      // (the z-only Helmholtz sweeps come as pairs of real columns that share the matrix: NV = 2 only)
       const real f = T.force ? T.force[0] : 0.;
-      const size_t pq = (size_t)(W * tile + x) + (size_t)g.n1 * blockIdx.y;
+      const int bi = W * tile + x + 1, bj = (int)blockIdx.y + 1;      // column (i, j) of the pair's first member
 #pragma unroll
       for (int q = 0; q < NQ2; ++q) {
         const int k = kk + KP2 * q;
@@ -935,8 +935,8 @@ __global__ __launch_bounds__(64 * gt_width(M, NV) / NV, (PER ? 2 : M <= 8 ? 4 : 
           const real2 own = k < nz ? v[q] : *reinterpret_cast<const real2 *>(p + o), dd = *reinterpret_cast<const real2 *>(T.dud + o);
           real2 t = make_real2(own.x - T.hf12 * dd.x, own.y - T.hf12 * dd.y);
           if (T.force) { t.x = t.x + f; t.y = t.y + f; }
-          if (k == 0 && T.has_lo) { t.x = t.x + T.rb[pq]; t.y = t.y + T.rb[pq + 1]; }
-          if (k == nz - 1 && T.has_hi) { t.x = t.x + T.rb[pq + (size_t)g.n1 * g.n2]; t.y = t.y + T.rb[pq + 1 + (size_t)g.n1 * g.n2]; }
+          if (k == 0 && T.has_lo) { t.x = t.x + T.blo.at(bi, bj, g.n1); t.y = t.y + T.blo.at(bi + 1, bj, g.n1); }
+          if (k == nz - 1 && T.has_hi) { t.x = t.x + T.bhi.at(bi, bj, g.n1); t.y = t.y + T.bhi.at(bi + 1, bj, g.n1); }
           if (k < nz) v[q] = t; else *reinterpret_cast<real2 *>(p + o) = t;
         }
       }
@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(64 * gt_width(M, NV) / NV, (PER ? 2 : M <= 8 ? 4 : 
 }
 template <int M, int NV, int PER = 0>
 static void launch_gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, real lscale, const real *da, const real *db, const real *dc,
-                                real *p, int fixnull, const TileMap &T) {
+                                real *p, int fixnull, const TileMap &T, real *tab_of_caller = nullptr, bool tab_ready = false) {
   constexpr int W = gt_width(M, NV), lds = W * (64 * (M + 1) + 4) * 8 + (GT_TL && M == 16 ? 2 * 64 * M * 8 : 0);
   static bool once = false;
   if (!once) { HIPSOFT(c, hipFuncSetAttribute((const void *)k_gaussel_tile<M, NV, PER>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); once = true; }
@@ -1104,22 +1104,22 @@ static void launch_gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, real l
   if (!c->d_abct) { const hipError_t e = hipMalloc(&c->d_abct, 2 * 3 * 64 * 16 * sizeof(real)); if (e != hipSuccess) { c->d_abct = nullptr; launch_failed(c, "hipMalloc(tridiagonal coefficient table)", e); return; } }
   // the pressure operands never change: their table is built once (Helmholtz operands are rescaled every substep -> second table)
   const bool pressure = da == c->d_a;
-  real *tab = c->d_abct + (pressure ? 0 : 3 * 64 * 16);
+  real *tab = tab_of_caller ? tab_of_caller : c->d_abct + (pressure ? 0 : 3 * 64 * 16);
   // (periodic z: the table holds the n-1 rows of the system proper; identity rows from row n on)
-  if (!pressure || !c->abct_ready) LAUNCH(c, k_abc_chunked, dim3((64 * M + 255) / 256), dim3(256), 0, c->stream, PER ? nz - 1 : nz, M, da, db, dc, tab);
-  if (pressure) c->abct_ready = true;
+  if (tab_of_caller ? !tab_ready : (!pressure || !c->abct_ready)) LAUNCH(c, k_abc_chunked, dim3((64 * M + 255) / 256), dim3(256), 0, c->stream, PER ? nz - 1 : nz, M, da, db, dc, tab);
+  if (pressure && !tab_of_caller) c->abct_ready = true;
   LAUNCH(c, (k_gaussel_tile<M, NV, PER>), dim3((ndbl + W - 1) / W, nrow), dim3(64 * W / NV), lds, c->stream, c->g, nz, ndbl, lscale, tab,
                      c->d_lamx, c->d_lamy, p, fixnull, T, da, db, dc);
 }
 // one rank: ndbl doubles of each of the nrow rows; several ranks (T.blocked): nrow = peers, ndbl = 2 cw n2l doubles per plane of a peer block
 template <int NV, int PER = 0>
 static bool gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, real lscale, const real *da, const real *db, const real *dc,
-                         real *p, int fixnull, const TileMap &T) {
+                         real *p, int fixnull, const TileMap &T, real *tab = nullptr, bool tab_ready = false) {
   if (nz < (PER ? 4 : 2) || nz > 1024 || c->fl.gaussel_march) return false;
-  if (nz <= 128) launch_gaussel_tile<2, NV, PER>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T);
-  else if (nz <= 256) launch_gaussel_tile<4, NV, PER>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T);
-  else if (nz <= 512) launch_gaussel_tile<8, NV, PER>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T);
-  else launch_gaussel_tile<16, NV, PER>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T);
+  if (nz <= 128) launch_gaussel_tile<2, NV, PER>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T, tab, tab_ready);
+  else if (nz <= 256) launch_gaussel_tile<4, NV, PER>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T, tab, tab_ready);
+  else if (nz <= 512) launch_gaussel_tile<8, NV, PER>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T, tab, tab_ready);
+  else launch_gaussel_tile<16, NV, PER>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T, tab, tab_ready);
   return true;
 }
 
@@ -1655,6 +1655,7 @@ __global__ void k_scale_abc(int n, real alpha, const real *a, const real *b, con
   if (k < n) { aa[k] = a[k] * alpha; bb[k] = b[k] * alpha + 1.; cc[k] = c[k] * alpha; }
 }
 int op_rhs_b_velz(cales_ctx *c, int ivel, real alpha, real *planes = nullptr, int *has = nullptr);
+void rhs_b_velz_args(cales_ctx *c, int ivel, real alpha, RhsBz *R, int *has);
 int op_rhs_b_velxy(cales_ctx *c, int ivel, real alpha);
 int op_helmholtz_z(cales_ctx *c, int ivel, real alpha) {
   if (c->C.impdiff != 2) { c->err = "helmholtz_z needs impdiff = 2"; return 1; }
@@ -1662,9 +1663,28 @@ int op_helmholtz_z(cales_ctx *c, int ivel, real alpha) {
   const int *n = c->n; const int n3 = n[2];
   const bool fused = c->defer_imp_rhs;
   int has[2] = {0, 0};
-  if (int e = op_rhs_b_velz(c, ivel, alpha, fused ? c->scr2 : nullptr, fused ? has : nullptr)) return e;
+  const char *bcz0 = &c->cbcvel[6 * (ivel - 1) + 4];
+  const int q0 = (ivel == 3 && bcz0[1] == 'D') ? 1 : 0;
+  // the in-LDS sweep evaluates the boundary term itself (RhsBz): no pass, no plane
+  const bool tile_path = !(bcz0[0] == 'P' && bcz0[1] == 'P') && !c->fl.helmholtz_z_per_column && n3 - q0 >= 2 && n3 - q0 <= 512 &&
+                         n3 <= 64 * (n3 - q0 <= 128 ? 2 : n3 - q0 <= 256 ? 4 : 8) && !c->fl.gaussel_march;
+  RhsBz RB[2] = {};
+  if (fused && tile_path) rhs_b_velz_args(c, ivel, alpha, RB, has);
+  else if (int e = op_rhs_b_velz(c, ivel, alpha, fused ? c->scr2 : nullptr, fused ? has : nullptr)) return e;
   real *abc = c->d_red + 64 + 16 * (n3 + 2);     // scaled coefficients live behind the reduction partials
-  LAUNCH(c, k_scale_abc, dim3((n3 + 63) / 64), dim3(64), 0, c->stream, n3, alpha, c->d_av[ivel - 1], c->d_bv[ivel - 1], c->d_cv[ivel - 1], abc, abc + n3, abc + 2 * n3);
+  // the table of this (component, alpha) from an earlier sweep (in-LDS form only: the others read the scaled coefficients themselves)
+  real *hz = nullptr; bool hz_ready = false;
+  if (tile_path) {
+    if (!c->d_hztab) { const hipError_t e = hipMalloc(&c->d_hztab, (size_t)12 * 3 * 64 * 16 * sizeof(real)); if (e != hipSuccess) c->d_hztab = nullptr; }
+    if (c->d_hztab) {
+      int sl = -1;
+      for (int q4 = 0; q4 < 4; ++q4) { const auto &h4 = c->hz_tab[ivel - 1][q4]; if (h4.ok && h4.alpha == alpha && h4.nz == n3 - q0) sl = q4; }
+      hz_ready = sl >= 0;
+      if (sl < 0) { sl = c->hz_next[ivel - 1]; c->hz_next[ivel - 1] = (sl + 1) % 4; c->hz_tab[ivel - 1][sl].alpha = alpha; c->hz_tab[ivel - 1][sl].nz = n3 - q0; c->hz_tab[ivel - 1][sl].ok = true; }
+      hz = c->d_hztab + (size_t)(4 * (ivel - 1) + sl) * 3 * 64 * 16;
+    }
+  }
+  if (!hz_ready) LAUNCH(c, k_scale_abc, dim3((n3 + 63) / 64), dim3(64), 0, c->stream, n3, alpha, c->d_av[ivel - 1], c->d_bv[ivel - 1], c->d_cv[ivel - 1], abc, abc + n3, abc + 2 * n3);
   const char *bcz = &c->cbcvel[6 * (ivel - 1) + 4];
   const int q = (ivel == 3 && bcz[1] == 'D') ? 1 : 0;
   const bool periodic = bcz[0] == 'P' && bcz[1] == 'P';
@@ -1677,8 +1697,8 @@ int op_helmholtz_z(cales_ctx *c, int ivel, real alpha) {
              // the in-LDS tile of the pressure solve on the real field: u, dudtd in, u out (3 words instead of 5)
              TileMap T{}; T.nolam = 1; T.nq = n3;
              if (fused) { T.dud = c->f[CALES_DUDTD + ivel - 1] + 1; T.hf12 = c->hf12; T.force = c->C.is_forced[ivel - 1] ? c->d_force + (ivel - 1) : nullptr;
-                          T.rb = c->scr2; T.has_lo = has[0]; T.has_hi = has[1]; }
-             return gaussel_tile<2>(c, n3 - q, n[0], n[1], 1., abc, abc + n3, abc + 2 * n3, fld + 1, 0, T); }()) {}
+                          T.blo = RB[0]; T.bhi = RB[1]; T.has_lo = has[0]; T.has_hi = has[1]; }
+             return gaussel_tile<2>(c, n3 - q, n[0], n[1], 1., abc, abc + n3, abc + 2 * n3, fld + 1, 0, T, hz, hz_ready); }()) {}
   else {
     real *zz = abc + 3 * n3, *dd = abc + 4 * n3;       // behind the scaled coefficients (cales_create reserves 6 (n3+2) doubles)
     LAUNCH(c, k_thomas_coef, dim3(1), dim3(64), 0, c->stream, n3 - q, abc, abc + n3, abc + 2 * n3, zz, dd);

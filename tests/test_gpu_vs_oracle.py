@@ -125,6 +125,31 @@ def test_time_steps(name, ng, nsteps):
     h.close()
 
 
+@pytest.mark.parametrize("name,ng", [("halfchan_imp1d", (16, 16, 16)), ("duct_smag_wm_imp1d", (16, 12, 12)), ("duct_smag_wm_imp1d", (64, 16, 20))])
+def test_z_implicit_steps_with_a_changing_time_step(name, ng):
+    """The z-only Helmholtz sweeps keep the coefficient tables of the (component, alpha) pairs they have seen (four per component; three alphas per step while
+    dt stays): seven steps with five different time steps -- hits, misses and evictions -- against the oracle, which scales a, b, c anew for every sweep
+    (main.f90:432-437)."""
+    from cales_amd.hotpath import initflow
+    g, case = load_golden(name); case.ng[:] = ng
+    o = Oracle(case, nthreads=8); h = _hot(case)
+    u, v, w, p = initflow(case)
+    rng = np.random.RandomState(4)
+    for a in (u, v, w):
+        a[1:-1, 1:-1, 1:-1] += 0.02 * (rng.rand(*ng) - 0.5)
+    h.upload(u, v, w, p); h.startup()
+    visct, pp = o.zeros(), o.zeros()
+    o.bounduvw(u, v, w, True, False); o.boundp(p, 0); o.cmpt_sgs(u, v, w, visct); o.boundp(visct, 1)
+    dt = 0.5 * o.chkdt(visct, u, v, w)
+    for fac in (1., 0.7, 1., 0.5, 0.9, 0.7, 0.6):
+        h.step(fac * dt); o.step(fac * dt, u, v, w, p, pp, visct)
+    gu, gv, gw, gp, gvis = h.download()
+    for a, b, nm in ((gu, u, "u"), (gv, v, "v"), (gw, w, "w")):
+        assert relerr(a, b) < 1e-9, nm
+    assert relerr(gvis, visct) < 1e-7
+    h.close()
+
+
 @pytest.mark.parametrize("name,ng,nsteps", [("chan_dsmag", (32, 16, 16), 3), ("chan_smag", (64, 18, 12), 2), ("tgv_ppp", (32, 24, 16), 3)])
 def test_time_steps_with_x_ghosts_kept(name, ng, nsteps, monkeypatch):
     """CALES_XGHOSTS_IN_STEP: every ghost-cell operator of cales_step fills the x ghost columns and the kernels read them (the form the operator-level
