@@ -151,6 +151,7 @@ def run_config(key, HotPath, initflow, SMALL, RB):
         divtot, divmax = h.chkdiv()
         if not np.isfinite(divtot) or divmax > SMALL:
             raise RuntimeError(f"{key} invalid: divergence {divmax}")
+        plan = h.describe_plan()
     finally:
         h.close()
     ncell = float(np.prod(case.ng))
@@ -162,7 +163,7 @@ def run_config(key, HotPath, initflow, SMALL, RB):
     sms, sw, snote = solve_figures(stats, ncell, RB)
     ms_step = 1e3 * t / K
     return {"baseline_config": cfg["baseline_config"], "workload": cfg["what"], "grid": "x".join(str(int(x)) for x in case.ng), "case_file": "cales_amd/cases/" + cfg["file"],
-            "impdiff": cfg["impdiff"], "dt": dt, "dt_lowered_times": len(dts) - 1, "steps": K, "warmup": W, "ms_per_step": ms_step, "time_steps_per_s": 1e3 / ms_step, "setup_s": t_setup,
+            "impdiff": cfg["impdiff"], "path": plan, "dt": dt, "dt_lowered_times": len(dts) - 1, "steps": K, "warmup": W, "ms_per_step": ms_step, "time_steps_per_s": 1e3 / ms_step, "setup_s": t_setup,
             "icheck_blocks_in_timed_region": timed_blocks,
             "dominant_kernel": dom,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
@@ -341,6 +342,11 @@ def main():
     ap.add_argument("--overlap", action="store_true",
                     help="N > 1: exchanges on the library's second stream beside kernels (CALES_OVERLAP=1; default: in order on one stream, the form "
                          "with the fewest assumptions, until a node with real peers has confirmed the overlapped one)")
+    ap.add_argument("--one-order", action="store_true",
+                    help="N > 1: time only one exchange order (in order, or with --overlap the second-stream one) instead of both in one invocation")
+    ap.add_argument("--timeout", type=int, default=int(os.environ.get("CALES_BENCH_TIMEOUT_S", "1200")),
+                    help="N > 1: seconds after which a rank that is still running (rendezvous that never completes, an exchange whose peer never "
+                         "arrives) prints what it was doing and exits with status 124, which makes the launcher end the other ranks and exit non-zero")
     a = ap.parse_args()
     if a.cpu_baseline_child:      # (cpu_baseline above; nothing here touches the GPU)
         print(json.dumps(_cpu_baseline_impl(channel_case(a.ng, a.sgs))))
@@ -362,10 +368,25 @@ def main():
             so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
-        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        sys.stdout.write(r.stdout if not lines else lines[-1] + "\n"); sys.stdout.flush()
-        raise SystemExit(r.returncode if r.returncode or lines else 1)
+        # hang guard: the ranks arm their own watchdog (rank_watchdog below: a rank that cannot rendezvous or sits in an exchange whose peer never
+        # arrives exits non-zero after --timeout seconds, torch.distributed.run then ends the others); this parent is the second line -- its children
+        # live in a process group of their own and are KILLED (never re-executed: they have touched the GPU) when they outlive the limit + 60 s
+        import signal
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            stdout, _ = proc.communicate(timeout=a.timeout + 60)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            stdout, _ = proc.communicate()
+            sys.stderr.write(f"bench.py --gpus {a.gpus}: the ranks did not finish within {a.timeout + 60} s and were killed\n")
+            sys.stdout.write(stdout or ""); sys.stdout.flush()
+            raise SystemExit(124)
+        lines = [l for l in (stdout or "").splitlines() if l.startswith("{")]
+        sys.stdout.write((stdout or "") if not lines else lines[-1] + "\n"); sys.stdout.flush()
+        raise SystemExit(proc.returncode if proc.returncode or lines else 1)
 
     if a.skip_headline:
         from cales_amd import capi
@@ -374,6 +395,21 @@ def main():
         return
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # ---- hang guard of a rank (N > 1): a daemon thread that ends THIS process with status 124 when the run has not finished after --timeout seconds --
+    # os._exit works while the main thread sits in hipStreamSynchronize or in a collective (ctypes and torch release the GIL there); the launcher
+    # (torch.distributed.run, or the parent above) then ends the other ranks and exits non-zero. `stage` says where the rank was.
+    stage = ["start"]
+    if world > 1:
+        import threading
+
+        def rank_watchdog():
+            time.sleep(a.timeout)
+            sys.stderr.write(f"bench.py rank {rank}/{world}: still in stage '{stage[0]}' after {a.timeout} s -- giving up (exit 124)\n"); sys.stderr.flush()
+            os._exit(124)
+        threading.Thread(target=rank_watchdog, daemon=True).start()
+        if os.environ.get("CALES_BENCH_TEST_HANG_RANK") == str(rank):      # test hook of the hang guard (tests/test_gpu_decomp.py): this rank never reaches the rendezvous
+            stage[0] = "test hook: hanging before the rendezvous"
+            time.sleep(10 ** 6)
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -382,10 +418,13 @@ def main():
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
+        import datetime
+        stage[0] = "rendezvous (init_process_group)"
+        pg_timeout = datetime.timedelta(seconds=max(60, a.timeout // 2))
         if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=pg_timeout)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_timeout)
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
 
@@ -394,62 +433,94 @@ def main():
     capi_single = capi.SINGLE                      # CALES_PRECISION=single: the -D_SINGLE_PRECISION build (not the headline number: BASELINE.json quotes FP64)
     RB = 4.0 if capi_single else 8.0               # bytes per real
     case = channel_case(a.ng, a.sgs)
-    if world == 1:
-        from cales_amd.hotpath import HotPath
-        h = HotPath(case)
-        u, v, w, p = initflow(case)
-        h.upload(u, v, w, p)
-        del u, v, w, p
-    else:
-        from cales_amd.decomp import SlabHotPath
-        h = SlabHotPath(case, dist, torch)
-        h.upload_initial()
-    h.startup()
-    dt = 0.5 * h.chkdt()
-
-    def barrier():
-        h.sync()                      # the context's own HIP stream
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     icheck = int(case.icheck) if int(case.icheck) > 0 else 10
-    checks = []
 
-    def run_steps(first, count):
-        """`count` time steps of the reference's loop (main.f90:405-544): every `icheck` steps chkdt and chkdiv with their abort
-        rules -- two reductions that wait for the device, as the reference's do (dt itself stays fixed)."""
-        for istep in range(first + 1, first + count + 1):
-            h.step(dt)
-            if istep % icheck == 0:
-                dtmax = h.chkdt(); divtot, divmax = h.chkdiv()
-                checks.append((istep, dtmax, divtot, divmax))
-                if dt > dtmax * case.cfl or not np.isfinite(divtot) or divmax > SMALL:       # main.f90:530,538 (fixed dt = 0.5 dt_cfl); small of param.f90:24
-                    raise SystemExit(f"bench invalid at step {istep}: dtmax {dtmax}, divergence {divmax}")
+    def measure(label):
+        """One context, W warm-up steps, K timed steps, K more with per-kernel events; the exchange order is whatever CALES_OVERLAP says when the context
+        is created (Flags::read_env). Returns the open context (rank 0 reads its plan and exchange kind) and the measurements."""
+        stage[0] = f"{label}: set-up"
+        if world == 1:
+            from cales_amd.hotpath import HotPath
+            h = HotPath(case)
+            u, v, w, p = initflow(case)
+            h.upload(u, v, w, p)
+            del u, v, w, p
+        else:
+            from cales_amd.decomp import SlabHotPath
+            h = SlabHotPath(case, dist, torch)
+            h.upload_initial()
+        h.startup()
+        dt = 0.5 * h.chkdt()
+        # same-box calibration (read / write / copy streams over this context's own fields, cales_calibrate) BEFORE the warm-up steps, so that the
+        # timed region starts from the steady state of consecutive steps
+        calib = h.calibrate(3)
 
-    run_steps(0, a.warmup)
-    barrier()
-    # timed region: exactly K steps (icheck blocks included), no per-kernel events (two hipEventRecords around each of the ~200
-    # launches of a step cost 1-3 % of the step at 512^3)
-    t0 = time.perf_counter()
-    run_steps(a.warmup, a.steps)
-    barrier()
-    t = time.perf_counter() - t0
-    # the same K steps again with HIP events on the context's stream around every kernel: durations for the roofline object
-    h.profile_reset(); h.profile(True)
-    t0 = time.perf_counter()
-    run_steps(a.warmup + a.steps, a.steps)
-    barrier()
-    t_prof = time.perf_counter() - t0
-    h.profile(False)
-    if world > 1:
-        tt = torch.tensor([t, t_prof], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t, t_prof = float(tt[0].item()), float(tt[1].item())
-    stats = h.profile_stats()
-    divtot, divmax = h.chkdiv()
-    if not np.isfinite(divtot) or divmax > SMALL:       # the reference's abort rule, main.f90:538
-        raise SystemExit(f"bench invalid: divergence {divmax}")
+        def barrier():
+            h.sync()                      # the context's own HIP stream
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        checks = []
+
+        def run_steps(first, count):
+            """`count` time steps of the reference's loop (main.f90:405-544): every `icheck` steps chkdt and chkdiv with their abort
+            rules -- two reductions that wait for the device, as the reference's do (dt itself stays fixed)."""
+            for istep in range(first + 1, first + count + 1):
+                h.step(dt)
+                if istep % icheck == 0:
+                    dtmax = h.chkdt(); divtot, divmax = h.chkdiv()
+                    checks.append((istep, dtmax, divtot, divmax))
+                    if dt > dtmax * case.cfl or not np.isfinite(divtot) or divmax > SMALL:       # main.f90:530,538 (fixed dt = 0.5 dt_cfl); small of param.f90:24
+                        raise SystemExit(f"bench invalid at step {istep}: dtmax {dtmax}, divergence {divmax}")
+
+        stage[0] = f"{label}: warm-up steps"
+        run_steps(0, a.warmup)
+        barrier()
+        # timed region: exactly K steps (icheck blocks included), no per-kernel events (two hipEventRecords around each of the ~200
+        # launches of a step cost 1-3 % of the step at 512^3)
+        stage[0] = f"{label}: timed steps"
+        t0 = time.perf_counter()
+        run_steps(a.warmup, a.steps)
+        barrier()
+        t = time.perf_counter() - t0
+        # the same K steps again with HIP events on the context's stream around every kernel: durations for the roofline object
+        stage[0] = f"{label}: steps with kernel events"
+        h.profile_reset(); h.profile(True)
+        t0 = time.perf_counter()
+        run_steps(a.warmup + a.steps, a.steps)
+        barrier()
+        t_prof = time.perf_counter() - t0
+        h.profile(False)
+        if world > 1:
+            tt = torch.tensor([t, t_prof], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t, t_prof = float(tt[0].item()), float(tt[1].item())
+        stats = h.profile_stats()
+        divtot, divmax = h.chkdiv()
+        if not np.isfinite(divtot) or divmax > SMALL:       # the reference's abort rule, main.f90:538
+            raise SystemExit(f"bench invalid: divergence {divmax}")
+        stage[0] = f"{label}: done"
+        return h, {"t": t, "t_prof": t_prof, "stats": stats, "checks": checks, "divmax": divmax, "dt": dt, "calibration": calib}
+
+    overlap_env = os.environ.get("CALES_OVERLAP", "0") not in ("", "0") and "CALES_NO_OVERLAP" not in os.environ
+    h, m = measure("second-stream exchanges" if overlap_env and world > 1 else "in-order exchanges" if world > 1 else "single GPU")
+    t, t_prof, stats, checks, divmax, dt = m["t"], m["t_prof"], m["stats"], m["checks"], m["divmax"], m["dt"]
+    # N > 1: BOTH exchange orders in one invocation (VERDICT r05 item 1a) -- `value` is the in-order run above, the second-stream order (k-chunked
+    # transposition beside the x / y transforms, scratch-field halos beside the interior tiles of the dynamic model's last pass) is timed on a fresh
+    # context and reported under "overlap"
+    both = world > 1 and not a.one_order and not overlap_env and a.backend == "nccl"
+    m2 = None
+    plan1 = h.describe_plan()
+    native1 = getattr(h, "native", False)
+    if both:
+        h.close(); h = None
+        os.environ["CALES_OVERLAP"] = "1"
+        try:
+            h, m2 = measure("second-stream exchanges")
+            m2["plan"] = h.describe_plan()
+        finally:
+            os.environ["CALES_OVERLAP"] = "0"
 
     if rank == 0:
         ncell = float(np.prod(case.ng)); nloc = ncell / world
@@ -475,6 +546,11 @@ def main():
         heavy = {k: v for k, v in leaf.items() if v[1] >= 0.03 * tot_ms}
         frac_of = lambda k: WORDS[k] * RB * nloc / (leaf[k][1] / leaf[k][0] * 1e-3) / HBM_PEAK
         worst = min(heavy, key=frac_of)
+        # every heavy kernel within 0.02 of that minimum is listed with it (the z sweep at 0.477 hid the dynamic model's last pass at
+        # 0.494 and 26 % of the step)
+        near = sorted((k for k in heavy if k != worst and frac_of(k) <= frac_of(worst) + 0.02), key=frac_of)
+        calib = m["calibration"]
+        copy_rate = calib["copy_GBps"] * 1e9      # the read + write copy of field-shaped rows THIS box sustains (cales_calibrate, before the warm-up steps)
         wtraffic = None
         try:
             for row in prof.get("kernels", []):
@@ -493,22 +569,33 @@ def main():
             "config": {"workload": f"turbulent channel {case.ng[0]}x{case.ng[1]}x{case.ng[2]}, sgstype={case.sgstype}, "
                                    "PP/PP/NN pressure BCs, bulk forcing in x (BASELINE.json configs[2]); 3 RK substeps/step",
                        "decomposition": f"y-slabs x{world}" if world > 1 else "single GPU", "dt": dt,
-                       "exchange_order": (("second stream beside kernels (CALES_OVERLAP=1)" if os.environ.get("CALES_OVERLAP", "0") not in ("", "0") and "CALES_NO_OVERLAP" not in os.environ
+                       # the path cales_step took (struct StepPlan, cales_describe_plan): WHICH fused / folded form of every operator was timed
+                       "path": plan1,
+                       "exchange_order": (("second stream beside kernels (CALES_OVERLAP=1)" if overlap_env
                                            else "in order on the context's stream (default)") if world > 1 else None),
-                       "exchanges": ("RCCL from the library" if getattr(h, "native", False) else
+                       "exchanges": ("RCCL from the library" if native1 else
                                      "gloo with host staging, ranks sharing one GPU: a test of the launch path, NOT a measurement" if a.backend == "gloo" else
                                      "torch.distributed callbacks") if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK, "frac_of_guide_copy_rate": ach / HBM_COPY, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": ach / HBM_PEAK, "frac_of_guide_copy_rate": ach / HBM_COPY, "frac_of_measured_copy_rate": ach / copy_rate,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": WORDS[dom] * RB * nloc, "avg_launch_ms": ms / calls, "launches": calls},
             "roofline_worst": {"bound": "hbm", "kernel": worst, "achieved": frac_of(worst) * HBM_PEAK / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                               "frac": frac_of(worst), "traffic": wtraffic, "algorithmic_bytes_per_launch": WORDS[worst] * RB * nloc,
+                               "frac": frac_of(worst), "frac_of_measured_copy_rate": frac_of(worst) * HBM_PEAK / copy_rate,
+                               "traffic": wtraffic, "algorithmic_bytes_per_launch": WORDS[worst] * RB * nloc,
                                "avg_launch_ms": leaf[worst][1] / leaf[worst][0], "launches": leaf[worst][0], "share_of_kernel_time": leaf[worst][1] / tot_ms,
-                               "what": "the kernel furthest below the HBM roof among those with >= 3 % of the step's kernel time"},
+                               "also_within_0.02": [{"kernel": k, "frac": frac_of(k), "frac_of_measured_copy_rate": frac_of(k) * HBM_PEAK / copy_rate,
+                                                     "avg_launch_ms": leaf[k][1] / leaf[k][0], "launches": leaf[k][0], "share_of_kernel_time": leaf[k][1] / tot_ms,
+                                                     "algorithmic_bytes_per_launch": WORDS[k] * RB * nloc} for k in near],
+                               "what": "the kernel furthest below the HBM roof among those with >= 3 % of the step's kernel time, and every other such kernel within 0.02 of it"},
+            # same-box calibration (cales_calibrate): streams over the rows of this context's own fields in the library's layout, 8 B per lane, before the warm-up steps
+            "calibration": dict(calib, what="read-only / write-only / copy (bytes read + written) over field-shaped rows of the timed context, GB/s on THIS box; "
+                                            "frac_of_measured_copy_rate = algorithmic bytes per second / copy_GBps"),
             "poisson_solve": {"ms": solve_ms, "words_per_cell": solve_words, "passes": solve_note,
                               "algorithmic_GBps": solve_words * RB * nloc / (solve_ms * 1e-3) / 1e9 if solve_ms else None,
                               "frac_of_hbm_peak": solve_words * RB * nloc / (solve_ms * 1e-3) / HBM_PEAK if solve_ms else None,
-                              "frac_of_guide_copy_rate": solve_words * RB * nloc / (solve_ms * 1e-3) / HBM_COPY if solve_ms else None},
+                              "frac_of_guide_copy_rate": solve_words * RB * nloc / (solve_ms * 1e-3) / HBM_COPY if solve_ms else None,
+                              "frac_of_measured_copy_rate": solve_words * RB * nloc / (solve_ms * 1e-3) / copy_rate if solve_ms else None},
             # north_star: ">= 50 % of the HBM roofline on the Poisson + RK sweep": one (fillps +) solve + one fused
             # momentum/RK pass (its compulsory words, averaged over the three substeps) over the time of exactly those kernels
             "poisson_plus_rk": (lambda ms, w: {"ms": ms, "words_per_cell": w, "algorithmic_GBps": w * RB * nloc / (ms * 1e-3) / 1e9,
@@ -527,6 +614,19 @@ def main():
             _transpose_report(out, stats, case, world, a, solve, h)
         except Exception as e:      # never lose the bench line over the extra report
             out["transpose"] = {"error": repr(e)}
+        if m2 is not None:      # the second exchange order of the same invocation
+            o2 = {"ms_per_step": 1e3 * m2["t"] / a.steps, "value": a.steps / m2["t"], "ms_per_step_with_kernel_events": 1e3 * m2["t_prof"] / a.steps,
+                  "exchange_order": "second stream beside kernels (CALES_OVERLAP=1)", "path": m2["plan"], "divmax": m2["divmax"],
+                  "speedup_over_in_order": m["t"] / m2["t"],
+                  "kernels_ms_per_step": {k: round(v[1] / a.steps, 4) for k, v in sorted(m2["stats"].items(), key=lambda kv: -kv[1][1])}}
+            try:
+                _transpose_report(o2, m2["stats"], case, world, a, solve, h)
+            except Exception as e:
+                o2["transpose"] = {"error": repr(e)}
+            out["overlap"] = o2
+        elif world > 1:
+            out["overlap"] = {"skipped": "--one-order" if a.one_order else "the timed run IS the second-stream order (--overlap / CALES_OVERLAP=1)" if overlap_env
+                              else "gloo with host staging has no second-stream exchanges"}
         h.close(); h = None      # (frees the 45 GB of the 512^3 context before the 1024^3 case)
         if world == 1 and want:
             from cales_amd.hotpath import HotPath as _HP

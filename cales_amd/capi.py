@@ -34,7 +34,7 @@ SYMBOLS = ["cales_real_size", "cales_initgrid", "cales_initflow", "cales_check_c
            "cales_chkdiv", "cales_out1d_single_point_chan", "cales_out1d_chan_budgets", "cales_out1d", "cales_out1d_chan", "cales_out2d_duct", "cales_step", "cales_get_dpdl", "cales_profile_enable", "cales_profile_reset",
            "cales_profile_count", "cales_profile_get", "cales_device_info", "cales_comm_buffer_doubles", "cales_set_comm",
            "cales_initflow_slab", "cales_comm_unique_id", "cales_comm_init_rccl", "cales_comm_selftest",
-           "cales_device_count", "cales_set_device", "cales_set_comm_overlap", "cales_rk_par"]
+           "cales_device_count", "cales_set_device", "cales_set_comm_overlap", "cales_rk_par", "cales_describe_plan", "cales_calibrate"]
 
 
 class CalesCase(C.Structure):
@@ -125,6 +125,7 @@ def lib() -> C.CDLL:
             "cales_device_count": [C.POINTER(C.c_int)], "cales_set_device": [C.c_int],
             "cales_set_comm_overlap": [C.c_void_p, C.c_void_p, C.c_void_p],
             "cales_rk_par": [C.c_void_p, dp, c_real, dp],
+            "cales_describe_plan": [C.c_void_p, C.c_char_p, C.c_int], "cales_calibrate": [C.c_void_p, C.c_int, dp, dp],
         }.items():
             fn = getattr(L, name)
             fn.argtypes = args

@@ -81,6 +81,22 @@ __global__ __launch_bounds__(256) void k_repack(Geom g, int to_device, real *__r
   const size_t h = (size_t)i + (size_t)(g.n1 + 2) * ((size_t)j + (size_t)(g.n2 + 2) * k);
   if (to_device) dev[g.ix(i, j, k)] = packed[h]; else packed[h] = dev[g.ix(i, j, k)];
 }
+// Same-box calibration (bench.py "calibration"): three streams over the rows of the context's own fields in the library's layout
+// (padded rows, element 1 of every row on a 128-B boundary, 8 B per lane -- what the FP64 passes do), timed with HIP events on the context's stream.
+// MODE 0: read-only, 1: write-only, 2: copy. Rows are dealt to the blocks round-robin (the order of tools/micro/calib.hip's calib_copy8_rows).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_calib_rows(Geom g, long nrows, const real *__restrict__ a, real *__restrict__ b, real *__restrict__ sink) {
+  real acc = 0.;
+  for (long r = blockIdx.x; r < nrows; r += gridDim.x) {
+    const size_t o = (size_t)r * g.s1 + 1;
+    for (int i = threadIdx.x; i < g.n1; i += 256) {
+      if (MODE == 0) acc += a[o + i];
+      else if (MODE == 1) b[o + i] = (real)1.5;
+      else b[o + i] = a[o + i];
+    }
+  }
+  if (MODE == 0 && acc == (real)1.2345e30) sink[blockIdx.x] = acc;      // never true: no write traffic
+}
 static int upload_vec(cales_ctx *c, real **p, const std::vector<real> &v) {
   if (dev_alloc(c, p, v.size(), false)) return 1;
   HIPCHK(c, hipMemcpy(*p, v.data(), v.size() * sizeof(real), hipMemcpyHostToDevice));
@@ -433,6 +449,97 @@ static int finish_pending(cales_ctx *c) {
   LAUNCHCHK(c);
   return 0;
 }
+// ---- the plan of a step (StepPlan, common.hpp): every decision about WHICH form of an operator a substep takes is made here, from the case, the
+// switches and the state recorded in the plan's in_* fields -- step_body below only reads the result.
+static void make_plan(cales_ctx *c) {
+  StepPlan pl;
+  pl.valid = true;
+  pl.in_visct_zero = c->visct_zero; pl.in_sgs_first = c->sgs_first; pl.in_comm_on = c->comm.on; pl.in_overlap = c->comm_stream != nullptr;
+  const Flags &fl = c->fl;
+  for (int q = 0; q < 6; ++q) if (c->C.lwm[q] != 0) pl.any_wm = true;      // (of the case: a face owned by another slab counts)
+  // fillps inside the forward x transform: homogeneous pressure BCs (no boundary r.h.s.) and a radix-8 x plan; the transform then also sums the bulk
+  // means of the forced components (their increment is only needed by the correction kernel)
+  pl.fuse_fill = !fl.unfused_fillps && solver_can_fuse_fillps(c);
+  for (int d = 0; d < 3; ++d) pl.fuse_fill = pl.fuse_fill && ((c->C.bcpre[2 * d] == 0. && c->C.bcpre[2 * d + 1] == 0.) || c->C.cbcpre[2 * d] == 'P');
+  // periodic x, explicit diffusion, no wall model, the fused passes everywhere: every kernel of the step wraps around instead of reading x ghost
+  // columns, which are then left alone until the step returns (common.hpp, step_xskip)
+  pl.xskip = !fl.xghosts_in_step && CBP(c, 0, 1) == 'P' && CBP(c, 1, 1) == 'P' && c->C.impdiff == 0 && !fl.unfused_rk && !fl.unfused_correc &&
+             pl.fuse_fill && c->xkind == 0 && sgs_wraps_x(c) && !pl.any_wm;
+  // dynamic model, x and y periodic (|S|Sij as pair fields), z periodic or two no-slip walls, explicit diffusion, no wall model: the projection
+  // u = u* - dtrk grad(pp) (+ the deferred forcing) and p += pp are folded into the strain-rate pass of cmpt_sgs, which reads the velocity anyway --
+  // the correction pass (9 words per cell) disappears (dsmag_fast, k_corr_strain_tile)
+  pl.fold_correc = pl.xskip && c->C.sgstype == 2 && c->C.impdiff == 0 && dsmag_pairs(c) && !fl.unfolded_correc && !fl.unfused_correc && c->n[0] % 64 == 0;      // (whole 64-cell tiles in x)
+  { const bool perz = CBV(c, 0, 3, 3) == 'P' && CBV(c, 1, 3, 3) == 'P';
+    bool walls = true;
+    for (int iv = 1; iv <= 3; ++iv) for (int sd = 0; sd <= 1; ++sd) walls = walls && CBV(c, sd, 3, iv) == 'D';
+    walls = walls && CBP(c, 0, 3) == 'N' && CBP(c, 1, 3) == 'N';
+    pl.fold_correc = pl.fold_correc && (perz || walls);
+    // several slabs: the pass reaches the companion field of pp with 32-bit offsets (two fields under 4 GB), exchanges through the slab hooks
+    // (at least two rows per slab: row 2 goes to the companion field BEFORE the exchange, and with one row per slab "row 2" is the stale ghost row n2+1)
+    if (c->P > 1) pl.fold_correc = pl.fold_correc && c->comm.on && c->n[1] >= 2 && 2 * (c->ntot + 2 * LINE_REALS) * sizeof(real) < (1ull << 32); }
+  // no subgrid model, explicit or z-implicit diffusion, no wall model, every direction periodic or between walls with homogeneous Neumann pressure
+  // (Taylor-Green, channels, cavities without a model): the projection and pressure update of substeps 1 and 2 are applied by the momentum pass of the
+  // NEXT substep while it loads its planes (k_momrk<.., CORR = 1>) -- between the two the fields hold the prediction, whose ghost cells receive the
+  // projected values through the corrected view of the ghost-cell kernels. The correction pass (9 words per cell) runs once per step instead of three times.
+  pl.fold_mom = !pl.fold_correc && fold_mom_ok(c);
+  // ... and the THIRD substep's projection may be left to the next step's first momentum pass (finish_pending for every other entry of the C-ABI). One rank
+  // only: on several slabs completing it moves slab rows, which would turn every rank-local entry of the C-ABI into a hidden collective
+  pl.lazy_last = pl.fold_mom && !fl.eager_projection && c->P == 1 && (fl.lazy_projection || (size_t)c->n[0] * c->n[1] * c->n[2] >= ((size_t)1 << 22));
+  // z-implicit diffusion: the Helmholtz sweeps form their r.h.s. themselves (k_gaussel_cols_rhs); needs the shared-pivot form
+  { const char *bz = &c->cbcvel[4];
+    pl.defer_imp_rhs = c->C.impdiff == 2 && !fl.helmholtz_z_per_column && !fl.unfused_imp_rhs &&
+                       !(bz[0] == 'P' && bz[1] == 'P') && !(bz[6] == 'P' && bz[7] == 'P') && !(bz[12] == 'P' && bz[13] == 'P'); }
+  // Wall models: the bounduvw between bulk_forcing and fillps (main.f90:492-494) updates the wall-model planes and sets the tangential ghost cells of the
+  // wall-model faces from them -- and nothing reads either before the bounduvw after correc (main.f90:500-501) has rewritten both: fillps differences the
+  // normal components, the solver and boundp see pp, correc only adds to the cells. The one exception is a sampling height inside the first cell
+  // (index_wm = 1 / n): that second wall-model update then interpolates with the ghost cell the first one left. Everywhere else the first update is
+  // skipped (two launches per substep), with results identical to the last bit.
+  { bool dead = !wm_samples_ghost(c);
+    for (int sd = 0; sd <= 1; ++sd) if (LWM(c, sd, 1) != 0) dead = false;      // (wall-model faces in x: no reference-made vector holds this shortcut to account there)
+    // (from the case alone, the same on every rank: the deferred forcing moves the all-reduce of the bulk means; CALES_UNMERGED_BC keeps the reference's
+    //  full sequence: the A/B of the tests)
+    pl.skip_first_wm = dead && pl.any_wm && !fl.unmerged_bc; }
+  // explicit step, forced directions periodic: the velocity between the forcing and the correction is only differenced along the forced direction
+  // (fillps) -- the increment is added by the correction kernel, one pass less. With a wall model only where its first update is skipped (above):
+  // k_wallmodel would otherwise sample the velocity without the increment
+  pl.fuse_cu = !fl.unfused_correc && c->C.impdiff != 1;     // updatep only needs pp: one pass with correc
+  { bool ok = c->C.impdiff == 0 && pl.fuse_cu && !fl.unfused_forcing && (!pl.any_wm || pl.skip_first_wm);
+    for (int d = 0; d < 3; ++d) if (c->C.is_forced[d]) ok = ok && c->cbcvel[6 * d + 2 * d] == 'P' && c->cbcvel[6 * d + 2 * d + 1] == 'P';
+    pl.force_mask = (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0);
+    pl.defer_force = ok && pl.force_mask != 0; }
+  pl.mean_mask = (pl.fuse_fill && pl.defer_force && !fl.unfused_mean) ? pl.force_mask : 0;
+  pl.keep_last_rhs = fl.keep_last_rhs;
+  // no subgrid model and homogeneous sgs BC values: the eddy viscosity is zero, ghost cells included, since start-up (sgs.f90:62-68; the first
+  // cmpt_sgs of a context zeroes the whole field)
+  pl.visct_ghosts = !(c->C.sgstype == 0 && (c->visct_zero || c->sgs_first));
+  for (int q = 0; q < 6; ++q) if (c->C.bcsgs[q] != 0.) pl.visct_ghosts = true;
+  c->plan = pl;
+}
+static const StepPlan &current_plan(cales_ctx *c) {
+  const StepPlan &pl = c->plan;
+  if (!pl.valid || pl.in_visct_zero != c->visct_zero || pl.in_sgs_first != c->sgs_first || pl.in_comm_on != c->comm.on || pl.in_overlap != (c->comm_stream != nullptr)) make_plan(c);
+  return c->plan;
+}
+int cales_describe_plan(cales_ctx *c, char *buf, int buflen) {
+  if (!c || !buf || buflen < 1) return 1;
+  const StepPlan &pl = current_plan(c);      // (reads no field: a pending projection stays pending)
+  std::string s;
+  s += std::string("projection=") + (pl.fold_correc ? "in_strain_rate_pass" : pl.fold_mom ? (pl.lazy_last ? "in_next_momentum_pass(all_substeps)" : "in_next_momentum_pass(substeps_1_2)") : (pl.fuse_cu ? "own_pass(correc+updatep)" : "own_passes"));
+  s += std::string(";x_ghost_columns=") + (pl.xskip ? "wrapped" : "maintained");
+  s += std::string(";fillps=") + (pl.fuse_fill ? "in_x_transform" : "own_pass");
+  s += std::string(";bulk_forcing=") + (pl.force_mask == 0 ? "none" : pl.defer_imp_rhs ? "in_helmholtz_sweep" : pl.defer_force ? (pl.mean_mask ? "in_correction(means_in_x_transform)" : "in_correction(means_own_pass)") : "own_pass");
+  if (c->C.impdiff == 2) s += std::string(";implicit_rhs=") + (pl.defer_imp_rhs ? "in_helmholtz_sweep" : "own_pass");
+  if (pl.any_wm) s += std::string(";first_wall_model_update=") + (pl.skip_first_wm ? "skipped" : "kept");
+  s += std::string(";ghost_cells=") + (c->fl.unmerged_bc ? "by_direction" : "one_launch");
+  s += std::string(";visct_ghost_cells=") + (pl.visct_ghosts ? "updated" : "zero_field");
+  s += std::string(";momentum=") + (c->fl.unfused_rk ? "mom+rk_update" : "fused_mom_rk");
+  s += std::string(";sgs=") + sgs_path_name(c);
+  s += std::string(";solver=") + solver_path_name(c);
+  s += ";ranks=" + std::to_string(c->P) + ";exchanges=" + (c->P == 1 ? "none" : !c->comm.on ? "unset" : (c->comm_stream && (c->comm.halo_s || c->comm.a2a_part)) ? "second_stream" : "in_order");
+  std::snprintf(buf, buflen, "%s", s.c_str());
+  return (int)s.size() < buflen ? 0 : 2;      // 2: truncated
+}
+
 static int step_body(cales_ctx *c, real dt);
 int cales_step(cales_ctx *c, real dt) {
   LAUNCHCHK(c);
@@ -443,94 +550,50 @@ int cales_step(cales_ctx *c, real dt) {
   if (e) { c->launch_err = "an earlier cales_step failed (" + c->err + "): the fields are in an intermediate state, the context is unusable"; return e; }
   return 0;
 }
+// One time step, src/main.f90:417-508. WHICH form every operator takes is the plan's (make_plan); what is left here is the sequence and the
+// hand-over of the plan's decisions to the operators through the context's per-call fields (reset on every return by `reset`).
 static int step_body(cales_ctx *c, real dt) {
   static const real rk[3][2] = {{32. / 60., 0.}, {25. / 60., -17. / 60.}, {45. / 60., -25. / 60.}};
-  if (c->fold_mom_dtrk != 0. && !fold_mom_ok(c)) { if (int e = finish_pending(c)) return e; }      // (the conditions changed between two steps: a field was set by hand)
+  const StepPlan pl = current_plan(c);      // (a copy: the plan of THIS step, whatever the step does to the state it was made from)
+  if (c->fold_mom_dtrk != 0. && !pl.fold_mom) { if (int e = finish_pending(c)) return e; }      // (the conditions changed between two steps: a field was set by hand)
   const bool pending_in = c->fold_mom_dtrk != 0.;      // the step before left its last projection to this step's first momentum pass
   LAUNCH(c, k_zero6, dim3(1), dim3(64), 0, c->stream, c->d_force, pending_in ? 3 : 0);     // dpdl(:) = 0
   c->in_step = true;
-  struct Reset { cales_ctx *c; bool keep = false; ~Reset() { c->in_step = false; c->step_xskip = false; c->bc_nride = 0; c->fold_dtrk = 0.; if (!keep) { c->fold_mom_dtrk = 0.; c->fold_mom_pdone = false; } c->bc_view_dtrk = 0.; c->defer_force = false; c->defer_imp_rhs = false; c->fuse_fillps_dti = 0.; c->fuse_mean_mask = 0; } } reset{c};      // also on the error returns
-  // periodic x, explicit diffusion, no wall model, the fused passes everywhere: every kernel of the step wraps around instead of reading x ghost
-  // columns, which are then left alone until the step returns (common.hpp, step_xskip)
-  { bool ok = !c->fl.xghosts_in_step && CBP(c, 0, 1) == 'P' && CBP(c, 1, 1) == 'P' && c->C.impdiff == 0 && !c->fl.unfused_rk && !c->fl.unfused_correc &&
-              !c->fl.unfused_fillps && solver_can_fuse_fillps(c) && c->xkind == 0 && sgs_wraps_x(c);
-    for (int q = 0; q < 6; ++q) ok = ok && c->C.lwm[q] == 0;
-    for (int d = 0; d < 3; ++d) ok = ok && ((c->C.bcpre[2 * d] == 0. && c->C.bcpre[2 * d + 1] == 0.) || c->C.cbcpre[2 * d] == 'P');      // (fillps inside the x transform)
-    if (c->pend_xrefresh && !ok) {      // the step before left the x ghost columns stale and this one reads them
-      c->pend_xrefresh = false; c->step_xskip = true;
-      if (int e = end_of_step_refresh(c)) return e;
-    }
-    c->step_xskip = ok; }
-  // dynamic model, one rank, x and y periodic (|S|Sij as pair fields), z periodic or two no-slip walls, explicit diffusion, no wall model: the
-  // projection u = u* - dtrk grad(pp) (+ the deferred forcing) and p += pp are folded into the strain-rate pass of cmpt_sgs, which reads the velocity
-  // anyway -- the correction pass (9 words per cell) disappears (dsmag_fast, k_strain_tile<.., CORR = 1>)
-  bool fold_correc = c->step_xskip && c->C.sgstype == 2 && c->C.impdiff == 0 && dsmag_pairs(c) && !c->fl.unfolded_correc && !c->fl.unfused_correc && c->n[0] % 64 == 0;      // (whole 64-cell tiles in x)
-  { const bool perz = CBV(c, 0, 3, 3) == 'P' && CBV(c, 1, 3, 3) == 'P';
-    bool walls = true;
-    for (int iv = 1; iv <= 3; ++iv) for (int sd = 0; sd <= 1; ++sd) walls = walls && CBV(c, sd, 3, iv) == 'D';
-    walls = walls && CBP(c, 0, 3) == 'N' && CBP(c, 1, 3) == 'N';
-    fold_correc = fold_correc && (perz || walls);
-    // several slabs: the pass reaches the companion field of pp with 32-bit offsets (two fields under 4 GB), exchanges through the slab hooks
-    // (at least two rows per slab: row 2 goes to the companion field BEFORE the exchange, and with one row per slab "row 2" is the stale ghost row n2+1)
-    if (c->P > 1) fold_correc = fold_correc && c->comm.on && c->n[1] >= 2 && 2 * (c->ntot + 2 * LINE_REALS) * sizeof(real) < (1ull << 32); }
-  // no subgrid model, explicit diffusion, no wall model, every direction periodic or between no-slip walls with homogeneous Neumann
-  // pressure (Taylor-Green, channels, cavities without a model): the projection and pressure update of substeps 1 and 2 are applied by the momentum
-  // pass of the NEXT substep while it loads its planes (k_momrk<.., CORR = 1>) -- between the two the fields hold the prediction, whose ghost cells
-  // receive the projected values through the corrected view of the ghost-cell kernels. The correction pass (9 words per cell) runs once per step
-  // instead of three times; substep 3 keeps it so that the step returns the projected fields.
-  const bool fold_mom = !fold_correc && fold_mom_ok(c);
+  struct Reset { cales_ctx *c; bool keep = false; ~Reset() { c->in_step = false; c->step_xskip = false; c->bc_nride = 0; c->fold_dtrk = 0.; if (!keep) { c->fold_mom_dtrk = 0.; c->fold_mom_pdone = false; } c->bc_view_dtrk = 0.; c->defer_force = false; c->defer_imp_rhs = false; c->fuse_fillps_dti = 0.; c->fuse_mean_mask = 0; c->bc_skip_wm = false; c->skip_rhs_store = false; } } reset{c};      // also on the error returns
+  if (c->pend_xrefresh && !pl.xskip) {      // the step before left the x ghost columns stale and this one reads them
+    c->pend_xrefresh = false; c->step_xskip = true;
+    if (int e = end_of_step_refresh(c)) return e;
+  }
+  c->step_xskip = pl.xskip;
   for (int irk = 1; irk <= 3; ++irk) {
     const real dtrk = (rk[irk - 1][0] + rk[irk - 1][1]) * dt, dtrki = 1. / dtrk;
     real alpha = 0.;
-    // z-implicit diffusion: the Helmholtz sweeps form their r.h.s. themselves (k_gaussel_cols_rhs); needs the shared-pivot form
-    const char *bz = &c->cbcvel[4];
-    c->defer_imp_rhs = c->C.impdiff == 2 && !c->fl.helmholtz_z_per_column && !c->fl.unfused_imp_rhs &&
-                       !(bz[0] == 'P' && bz[1] == 'P') && !(bz[6] == 'P' && bz[7] == 'P') && !(bz[12] == 'P' && bz[13] == 'P');
-    // Wall models: the bounduvw between bulk_forcing and fillps (main.f90:492-494) updates the wall-model planes and sets the tangential ghost cells of the
-    // wall-model faces from them -- and nothing reads either before the bounduvw after correc (main.f90:500-501) has rewritten both: fillps differences the
-    // normal components, the solver and boundp see pp, correc only adds to the cells. The one exception is a sampling height inside the first cell
-    // (index_wm = 1 / n): that second wall-model update then interpolates with the ghost cell the first one left. Everywhere else the first update is
-    // skipped here (two launches per substep), with results identical to the last bit.
-    bool any_wm = false, wm_dead = !wm_samples_ghost(c);
-    for (int sd = 0; sd <= 1; ++sd) if (LWM(c, sd, 1) != 0) wm_dead = false;      // (wall-model faces in x: no reference-made vector holds this shortcut to account there)
-    for (int q = 0; q < 6; ++q) if (c->C.lwm[q] != 0) any_wm = true;      // (of the case: a face owned by another slab counts)
-    wm_dead = wm_dead && any_wm && !c->fl.unmerged_bc;      // (from the case alone, the same on every rank: the deferred forcing moves the all-reduce of the bulk means; CALES_UNMERGED_BC keeps the reference's full sequence: the A/B of the tests)
-    // explicit step, forced directions periodic: the velocity between the forcing and the correction is only differenced along the forced direction
-    // (fillps) -- the increment is added by the correction kernel, one pass less. With a wall model only where its first update is skipped (above):
-    // k_wallmodel would otherwise sample the velocity without the increment
-    const bool fuse_cu = !c->fl.unfused_correc && c->C.impdiff != 1;     // updatep only needs pp: one pass with correc
-    { bool ok = c->C.impdiff == 0 && fuse_cu && !c->fl.unfused_forcing && (!any_wm || wm_dead);
-      for (int d = 0; d < 3; ++d) if (c->C.is_forced[d]) ok = ok && c->cbcvel[6 * d + 2 * d] == 'P' && c->cbcvel[6 * d + 2 * d + 1] == 'P';
-      c->defer_force = ok && (c->C.is_forced[0] || c->C.is_forced[1] || c->C.is_forced[2]); }
-    // homogeneous pressure BCs (no boundary r.h.s.) and a radix-8 x plan: fillps is done by the forward x transform, which then
-    // also sums the bulk means of the forced components (their increment is only needed by the correction kernel)
-    bool fuse_fill = !c->fl.unfused_fillps && solver_can_fuse_fillps(c);
-    for (int d = 0; d < 3; ++d) fuse_fill = fuse_fill && ((c->C.bcpre[2 * d] == 0. && c->C.bcpre[2 * d + 1] == 0.) || c->C.cbcpre[2 * d] == 'P');
-    c->fuse_mean_mask = (fuse_fill && c->defer_force && !c->fl.unfused_mean)
-                            ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;
-    c->skip_rhs_store = irk == 3 && !c->fl.keep_last_rhs;
+    c->defer_imp_rhs = pl.defer_imp_rhs;
+    c->defer_force = pl.defer_force;
+    c->fuse_mean_mask = pl.mean_mask;
+    c->skip_rhs_store = irk == 3 && !pl.keep_last_rhs;
     const bool p_ghosts_due = c->fold_mom_dtrk != 0. && !c->fold_mom_pdone;      // the momentum pass below stores p + pp of the interior cells: its ghost cells ride along with those of the prediction
     { const int e = op_rk(c, irk, dt); c->skip_rhs_store = false; if (e) return e; }
-    if (int e = op_bulk_forcing(c)) { c->defer_imp_rhs = false; return e; }
+    if (int e = op_bulk_forcing(c)) return e;
     if (c->C.impdiff == 2) {
       alpha = -.5 * c->visc * dtrk;
-      for (int iv = 1; iv <= 3; ++iv) if (int e = op_helmholtz_z(c, iv, alpha)) { c->defer_imp_rhs = false; return e; }
-      c->defer_imp_rhs = false;
+      for (int iv = 1; iv <= 3; ++iv) if (int e = op_helmholtz_z(c, iv, alpha)) return e;
     } else if (c->C.impdiff == 1) {
       alpha = -.5 * c->visc * dtrk;
       for (int iv = 1; iv <= 3; ++iv) if (int e = op_helmholtz(c, iv, alpha)) return e;
     }
+    c->defer_imp_rhs = false;
     if (p_ghosts_due && !c->fl.unmerged_bc) { c->bc_nride = 1; c->bc_ride[0] = c->f[CALES_P]; c->bc_ride_which[0] = 0; }
-    { c->bc_skip_wm = wm_dead;
+    { c->bc_skip_wm = pl.skip_first_wm;
       const int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 0, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W]);
       c->bc_skip_wm = false;
       const bool rode = p_ghosts_due && !c->fl.unmerged_bc && c->bc_nride == 0; c->bc_nride = 0;
       if (e) return e;
       if (p_ghosts_due && !rode) { if (int e2 = op_boundp(c, c->f[CALES_P], 0)) return e2; } }
-    if (fuse_fill) c->fuse_fillps_dti = dtrki;
+    if (pl.fuse_fill) c->fuse_fillps_dti = dtrki;
     else { if (int e = op_fillps(c, dtrki)) return e; if (int e = op_updt_rhs_b(c)) return e; }
     { const int e = op_solver(c); c->fuse_fillps_dti = 0.; if (e) return e; }
-    if (fold_correc && c->P > 1) {
+    if (pl.fold_correc && c->P > 1) {
       // the folded projection corrects v in the ghost row n2+1 too and needs pp one row further out: row 2 of every slab goes to row 1 of pp's companion
       // field and both fields take the ghost-cell update -- ONE exchange; the upper neighbour's row 2 arrives in the companion's ghost row n2+1
       LAUNCH(c, k_row2_to_companion, dim3((c->n[0] + 2 + 63) / 64, (c->n[2] + 2 + 3) / 4), dim3(64, 4), 0, c->stream, c->g, c->f[CALES_PP], c->scr2);
@@ -538,13 +601,11 @@ static int step_body(cales_ctx *c, real dt) {
       if (int e = op_boundp_multi(c, 2, two, 0)) return e;
     } else
     if (int e = op_boundp(c, c->f[CALES_PP], 0)) return e;
-    if (fold_correc) c->fold_dtrk = dtrk;      // correc, bounduvw, updatep, boundp(p): inside the cmpt_sgs below (dsmag_fast)
-    else if (fold_mom && (irk < 3 || (!c->fl.eager_projection && c->P == 1 && (c->fl.lazy_projection || (size_t)c->n[0] * c->n[1] * c->n[2] >= ((size_t)1 << 22))))) {
-      // (several slabs: the THIRD substep's projection is never left pending -- completing it moves slab rows, which would turn every rank-local entry of
-      //  the C-ABI, cales_get_field on rank 0 for one, into a collective that blocks until the other ranks call something; CALES_LAZY_PROJECTION is ignored there)
+    if (pl.fold_correc) c->fold_dtrk = dtrk;      // correc, bounduvw, updatep, boundp(p): inside the cmpt_sgs below (dsmag_fast)
+    else if (pl.fold_mom && (irk < 3 || pl.lazy_last)) {
       // the ghost cells of the projected velocity now (through the corrected view), its interior cells and p + pp in the next momentum pass -- the next
       // substep's, or after the third substep the next step's (finish_pending for every other entry of the C-ABI)
-      c->fold_mom_fmask = c->defer_force ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0;
+      c->fold_mom_fmask = c->defer_force ? pl.force_mask : 0;
       c->defer_force = false;
       if (c->C.impdiff == 2) {      // z-implicit diffusion: the pressure update keeps its own pass (updatep.f90:40-46) -- the z Laplacian of pp has no values in ghost cells
         if (int e = op_updatep(c, alpha)) return e;
@@ -559,10 +620,7 @@ static int step_body(cales_ctx *c, real dt) {
     } else if (int e = project_now(c, dtrk, alpha)) return e;
     c->visct_bc_done = false;
     { const int e = op_cmpt_sgs(c); c->fold_dtrk = 0.; c->defer_force = false; if (e) return e; }
-    // no subgrid model and homogeneous sgs BC values: the eddy viscosity is zero, ghost cells included, since start-up (sgs.f90:62-68)
-    bool visct_ghosts = !(c->C.sgstype == 0 && c->visct_zero && !c->sgs_first);
-    for (int q = 0; q < 6; ++q) if (c->C.bcsgs[q] != 0.) visct_ghosts = true;
-    if (visct_ghosts && !c->visct_bc_done) { if (int e = op_boundp(c, c->f[CALES_VISCT], 1)) return e; }
+    if (pl.visct_ghosts && !c->visct_bc_done) { if (int e = op_boundp(c, c->f[CALES_VISCT], 1)) return e; }
     c->visct_bc_done = false;
   }
   if (c->fold_mom_dtrk != 0.) { c->pend_xskip = c->step_xskip; reset.keep = true; }      // the last projection is the next step's (or finish_pending's), the refresh with it
@@ -630,6 +688,36 @@ int cales_profile_get(cales_ctx *c, int idx, char *name, int namelen, int64_t *c
   if (name && namelen > 0) std::snprintf(name, namelen, "%s", c->stats[idx].name.c_str());
   if (calls) *calls = c->stats[idx].calls;
   if (total_ms) *total_ms = c->stats[idx].ms;
+  return 0;
+}
+int cales_calibrate(cales_ctx *c, int reps, real gbps[3], int64_t *bytes_per_stream) {
+  if (!c || !gbps || reps < 1) return 1;
+  ENTER(c);      // (completes a pending projection: the scratch field written below is then dead)
+  const long nrows = (long)(c->n[1] + 2) * (c->n[2] + 2);
+  const double bytes = (double)nrows * c->n[0] * sizeof(real);
+  if (bytes_per_stream) *bytes_per_stream = (int64_t)bytes;
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+  const dim3 gr(256 * 16), bl(256);
+  const real *a = c->f[CALES_U]; real *b = c->scr1;      // scr1: scratch between operators
+  auto run = [&](int mode) {
+    if (mode == 0) LAUNCH(c, k_calib_rows<0>, gr, bl, 0, c->stream, c->g, nrows, a, b, c->d_red);
+    else if (mode == 1) LAUNCH(c, k_calib_rows<1>, gr, bl, 0, c->stream, c->g, nrows, a, b, c->d_red);
+    else LAUNCH(c, k_calib_rows<2>, gr, bl, 0, c->stream, c->g, nrows, a, b, c->d_red);
+  };
+  int rc = 0;
+  for (int mode = 0; mode < 3 && !rc; ++mode) {
+    run(mode);
+    if (hipEventRecord(e0, c->stream) != hipSuccess) { rc = 1; break; }
+    for (int r = 0; r < reps; ++r) run(mode);
+    if (hipEventRecord(e1, c->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) { rc = 1; break; }
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess || !(ms > 0.f)) { rc = 1; break; }
+    gbps[mode] = (real)((mode == 2 ? 2. : 1.) * bytes * reps / (ms * 1e-3) / 1e9);
+  }
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  if (rc) { c->err = "cales_calibrate: event timing failed"; return rc; }
+  LAUNCHCHK(c);
   return 0;
 }
 int cales_device_info(cales_ctx *c, char *name, int namelen, int64_t *hbm_bytes) {

@@ -115,11 +115,33 @@ struct Flags {
   }
 };
 
+// The path ONE cales_step takes through the fused / folded forms of its operators (reference sequence src/main.f90:417-508): decided once by
+// make_plan (api.hip) from the case, the switches (Flags) and the few pieces of state listed under `in_*`, re-made only when one of those changes, and
+// READ -- never re-derived -- by step_body. cales_describe_plan (include/cales.h) prints it: bench.py puts the string into its line (config.path), the
+// golden tests assert it next to the profile counters.
+struct StepPlan {
+  bool valid = false;
+  bool in_visct_zero = false, in_sgs_first = false, in_comm_on = false, in_overlap = false;      // the state the plan was made from
+  bool xskip = false;            // periodic x: the step's kernels wrap around, the x ghost columns are left alone until somebody else reads them
+  bool fold_correc = false;      // dynamic model: projection + pressure update inside the strain-rate pass of the substep's cmpt_sgs (k_corr_strain_tile)
+  bool fold_mom = false;         // no subgrid model: projection of substeps 1, 2 (and 3: lazy_last) inside the NEXT momentum pass (k_momrk<CORR>)
+  bool lazy_last = false;        // ... the third substep's projection stays pending across the return of cales_step (one rank only)
+  bool defer_imp_rhs = false;    // z-implicit: the Helmholtz sweeps form their r.h.s. (implicit part of rk, forcing, boundary terms) while loading
+  bool any_wm = false, skip_first_wm = false;   // wall model: the update between bulk_forcing and fillps is dead work (main.f90:492-501) and skipped
+  bool fuse_cu = false;          // correc + updatep in one pass
+  bool defer_force = false;      // bulk-forcing increment added by the correction pass (means summed by the forward x transform: mean_mask)
+  bool fuse_fill = false;        // fillps inside the forward x transform of the pressure solve
+  bool visct_ghosts = false;     // the eddy viscosity's ghost cells are updated after cmpt_sgs (not needed while the field is identically zero)
+  bool keep_last_rhs = false;
+  int mean_mask = 0, force_mask = 0;
+};
+
 struct KernelStat { std::string name; int64_t calls = 0; real ms = 0.; };
 
 struct cales_ctx {
   cales_case C;
   Flags fl;
+  StepPlan plan;      // see StepPlan above
   Geom g;
   int n[3], lo[3];
   real dl[3], dli[3], visc;
@@ -316,6 +338,8 @@ int op_out1d(cales_ctx *c, int field, int idir, int use_dzc, real *buf);
 int op_out1d_chan(cales_ctx *c, real *buf);
 int op_out2d_duct(cales_ctx *c, real *buf);
 bool solver_can_fuse_fillps(cales_ctx *c);
+std::string solver_path_name(cales_ctx *c);      // which transform / tridiagonal kernels the pressure solve of this context takes (cales_describe_plan)
+const char *sgs_path_name(const cales_ctx *c);      // likewise for cmpt_sgs
 int op_force_from_partials(cales_ctx *c, int mask, const real *part, int nblk);
 int op_correc_updatep(cales_ctx *c, real dtrk, real alpha, int upd);
 int op_updatep(cales_ctx *c, real alpha);

@@ -1369,6 +1369,13 @@ bool sgs_wraps_x(const cales_ctx *c) {
   if (c->C.sgstype == 1) return smag_fast_ok(c);
   return dsmag_fast_ok(c) && !c->fl.dsmag_xghosts;
 }
+// the form of cmpt_sgs this context takes (cales_describe_plan): the same predicates op_cmpt_sgs / dsmag_fast / smag_fast branch on
+const char *sgs_path_name(const cales_ctx *c) {
+  if (c->C.sgstype == 0) return "none";
+  if (c->C.sgstype == 1) return smag_fast_ok(c) ? "smag_rows" : "smag_reference_sequence";
+  if (!dsmag_fast_ok(c)) return "dsmag_reference_sequence";
+  return dsmag_pairs(c) ? "dsmag_tiles(pair_fields)" : "dsmag_tiles";
+}
 int op_cmpt_sgs(cales_ctx *c) {
   const int *n = c->n; const size_t nt = c->ntot;
   real **f = c->f; real *visct = f[CALES_VISCT];

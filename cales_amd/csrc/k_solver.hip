@@ -1599,6 +1599,23 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
   return 0;
 }
 
+// the kernels the pressure solve of this context takes (cales_describe_plan): the selections of solve_field above, by name
+std::string solver_path_name(cales_ctx *c) {
+  SolverPlans *sp = find_plans(c);
+  if (!sp) return "unset";
+  static const char *kinds[] = {"PP", "NN", "DD", "ND", "DN"};
+  const bool use8x = sp->x8 && c->xkind <= 1, use8y = sp->y8 && c->ykind <= 1;
+  const bool perz = CBP(c, 0, 3) == 'P' && CBP(c, 1, 3) == 'P';
+  const int nz = c->n[2];
+  const bool hasd = CBP(c, 0, 3) == 'D' || CBP(c, 1, 3) == 'D';
+  const bool tile = !(c->xkind && !c->ykind) && (perz || hasd || !c->fl.keep_null_mode) && !(nz < (perz ? 4 : 2) || nz > 1024 || c->fl.gaussel_march);
+  std::string s = std::string("x:") + kinds[c->xkind] + (use8x ? "/radix8" : c->xkind >= 3 ? "/dct4" : "/mixed_radix");
+  s += std::string(",y:") + kinds[c->ykind] + (use8y ? (c->ykind ? "/radix8" : "/radix8_register_ends") : c->ykind >= 3 ? "/dct4" : "/mixed_radix");
+  s += std::string(",z:") + (c->xkind && !c->ykind ? "thomas_hermitian" : tile ? (perz ? "lds_tile_periodic" : "lds_tile") : "thomas_march");
+  if (c->fl.keep_null_mode) s += ",null_mode:reference_order";
+  return s;
+}
+
 int op_solver(cales_ctx *c) {
   return solve_field(c, c->f[CALES_PP], c->d_a, c->d_b, c->d_c, c->n[2], 1., CBP(c, 0, 3) == 'P' && CBP(c, 1, 3) == 'P', true);
 }

@@ -105,6 +105,14 @@ module cales_c
     integer(c_int) function cales_rk_par(ctx,rkpar,dt,f) bind(C,name='cales_rk_par')      ! rk(rkpar,...,dt,...,f), src/rk.f90:17
       import; type(c_ptr), value :: ctx; real(c_rp), intent(in) :: rkpar(2); real(c_rp), value :: dt; real(c_rp) :: f(3)
     end function
+    ! the path the next cales_step takes, as text "key=value;..." (struct StepPlan; the sequence it protects: src/main.f90:417-508)
+    integer(c_int) function cales_describe_plan(ctx,buf,buflen) bind(C,name='cales_describe_plan')
+      import; type(c_ptr), value :: ctx; character(kind=c_char) :: buf(*); integer(c_int), value :: buflen
+    end function
+    ! same-box calibration: read / write / copy streams over the context's own fields, GB/s (bench line)
+    integer(c_int) function cales_calibrate(ctx,reps,gbps,nbytes) bind(C,name='cales_calibrate')
+      import; type(c_ptr), value :: ctx; integer(c_int), value :: reps; real(c_rp) :: gbps(3); integer(c_int64_t) :: nbytes
+    end function
     integer(c_int) function cales_fillps(ctx,dtrki) bind(C,name='cales_fillps')
       import; type(c_ptr), value :: ctx; real(c_rp), value :: dtrki
     end function

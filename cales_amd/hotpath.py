@@ -241,6 +241,20 @@ class HotPath:
         """src/main.f90:370-375: ghost cells and eddy viscosity of the initial state."""
         self.bounduvw(True, False); self.boundp("p", 0); self.cmpt_sgs(); self.boundp("visct", 1)
 
+    def describe_plan(self) -> Dict[str, str]:
+        """The path the next cales_step takes (struct StepPlan): {'projection': 'in_strain_rate_pass', 'fillps': 'in_x_transform', ...}."""
+        buf = C.create_string_buffer(2048)
+        rc = self.L.cales_describe_plan(self.h, buf, 2048)
+        if rc not in (0, 2):
+            self._chk(rc)
+        return dict(kv.split("=", 1) for kv in buf.value.decode().split(";") if "=" in kv)
+
+    def calibrate(self, reps: int = 3) -> Dict[str, float]:
+        """Read-only / write-only / copy streams over this context's own fields (cales_calibrate): GB/s on THIS box."""
+        g = np.zeros(3, dtype=REAL); nb = C.c_int64(0)
+        self._chk(self.L.cales_calibrate(self.h, int(reps), _p(g), C.byref(nb)))
+        return {"read_GBps": float(g[0]), "write_GBps": float(g[1]), "copy_GBps": float(g[2]), "bytes_per_stream": int(nb.value), "launches": int(reps)}
+
     # -- measurement
     def profile(self, on: bool):
         self._chk(self.L.cales_profile_enable(self.h, int(on)))

@@ -140,6 +140,11 @@ int cales_out2d_duct(cales_ctx *ctx, cales_real *buf);
  * entry other than the next cales_step (local copies, any number of slabs; the same mechanism, the same three exceptions). */
 int cales_step(cales_ctx *ctx, cales_real dt);
 int cales_get_dpdl(cales_ctx *ctx, cales_real dpdl[3]);                         /* main.f90:492,508 (sync) */
+/* The path the NEXT cales_step takes through the fused / folded forms of its operators, as text "key=value;key=value;..." (projection, x ghost columns,
+ * fillps, bulk forcing, wall model, ghost cells, sgs, solver kernels, ranks, exchanges): decided once from the case, the CALES_* switches and the
+ * context's state (struct StepPlan, cales_amd/csrc/common.hpp), re-made only when one of those changes, and only READ by the step -- the sequence it
+ * protects is src/main.f90:417-508. Reads no field (a pending projection stays pending). Returns 0, or 2 when buf was too short (text truncated). */
+int cales_describe_plan(cales_ctx *ctx, char *buf, int buflen);
 
 /* ---- multi-GPU: y-slab decomposition --------------------------------------
  * The reference exchanges halos with MPI_SENDRECV / cudecompUpdateHalos (src/bound.f90:619-723) and transposes
@@ -190,6 +195,10 @@ int cales_profile_count(cales_ctx *ctx);
 int cales_profile_get(cales_ctx *ctx, int idx, char *name, int namelen, int64_t *calls, cales_real *total_ms);
 /* algorithmic words (8 B) per cell per call of the named kernel group, for the roofline line */
 int cales_device_info(cales_ctx *ctx, char *name, int namelen, int64_t *hbm_bytes);
+/* Same-box calibration for the roofline fractions: read-only, write-only and copy streams over the rows of the context's own fields in
+ * the library's layout (8 B per lane), `reps` launches each after one warm-up, timed with HIP events on the context's stream; gbps[0..2] = read, write,
+ * copy in GB/s (copy counts bytes read + written), *bytes_per_stream = bytes one launch reads (or writes). Overwrites a scratch field only. (sync) */
+int cales_calibrate(cales_ctx *ctx, int reps, cales_real gbps[3], int64_t *bytes_per_stream);
 
 #ifdef __cplusplus
 }

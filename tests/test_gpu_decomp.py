@@ -354,3 +354,45 @@ def test_bench_bare_form_spawns_its_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--ng", "64", "63", "32",
                         "--backend", "gloo", "--no-cpu"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode != 0
+
+
+def test_bench_hung_rank_fails_the_launch_within_the_timeout():
+    """a rank that cannot rendezvous (here: rank 1 never calls init_process_group, bench.py's test hook) must make the launcher exit
+    NON-ZERO within a stated time instead of waiting forever -- every rank arms a watchdog (--timeout seconds, exit status 124), torch.distributed.run
+    ends the others, and the bare form's parent kills the whole process group if even that fails. Both launch forms."""
+    import os, subprocess, sys, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CALES_BENCH_TEST_HANG_RANK"] = "1"
+    args = ["--gpus", "2", "--steps", "2", "--warmup", "0", "--ng", "64", "64", "32", "--backend", "gloo", "--no-cpu", "--timeout", "45"]
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode != 0 and time.time() - t0 < 240, (r.returncode, time.time() - t0, r.stderr[-2000:])
+    assert "giving up (exit 124)" in r.stderr or "were killed" in r.stderr, r.stderr[-3000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]      # no bench line from a run that did not finish
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29621",
+                        os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode != 0 and time.time() - t0 < 240, (r.returncode, time.time() - t0, r.stderr[-2000:])
+
+
+def test_bench_reports_both_exchange_orders():
+    """`bench.py --gpus N` times BOTH exchange orders in one invocation (in order = `value`, second stream under "overlap"), with the plan string of each.
+    Real peers (RCCL) only: skipped on the one-GPU box, where the gloo form reports why the second order was not timed."""
+    import json, os, subprocess, sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "CALES_OVERLAP")}
+    n = torch.cuda.device_count()
+    backend = ["--backend", "gloo"] if n < 2 else []
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--ng", "64", "64", "32", "--no-cpu"] + backend,
+                       capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["exchange_order"].startswith("in order") and d["config"]["path"]["ranks"] == "2" and d["config"]["path"]["exchanges"] == "in_order"
+    assert d["calibration"]["copy_GBps"] > 0 and d["roofline"]["frac_of_measured_copy_rate"] > 0
+    if n < 2:
+        assert "skipped" in d["overlap"]
+    else:
+        o = d["overlap"]
+        assert o["ms_per_step"] > 0 and o["path"]["exchanges"] == "second_stream" and o["transpose"]["chunks_per_exchange"] > 1.5 and o["divmax"] < 1e-11

@@ -168,6 +168,11 @@ def test_folded_strain_pass_against_reference_made_state(name, folded, monkeypat
     h.profile(False); st = h.profile_stats()
     nfold, ncorr = st.get("correc_strain_filter_uvw", (0, 0.))[0], st.get("correc_updatep", (0, 0.))[0]
     assert (nfold, ncorr) == ((3, 0) if folded else (0, 3)), st
+    # ... and the plan the step read (cales_describe_plan, struct StepPlan) names the same path
+    pl = h.describe_plan()
+    assert pl["projection"] == ("in_strain_rate_pass" if folded else "own_pass(correc+updatep)"), pl
+    assert pl["x_ghost_columns"] == "wrapped" and pl["fillps"] == "in_x_transform" and pl["sgs"] == "dsmag_tiles(pair_fields)", pl
+    assert pl["bulk_forcing"] == ("in_correction(means_in_x_transform)" if name.startswith("chan") else "none"), pl
     for a, k in zip((u, v, w), "uvw"):
         assert relerr(a, g["r3_s7_" + k]) < 1e-10, k
     pg = g["r3_s8_p"]
@@ -196,6 +201,11 @@ def test_folded_momentum_pass_against_reference_made_state(name, folded, monkeyp
     h.profile(False); st = h.profile_stats()
     ncorr = st.get("correc_updatep", (0, 0.))[0] + st.get("correc", (0, 0.))[0]
     assert ncorr == (1 if folded else 3), st
+    pl = h.describe_plan()      # the plan the step read (struct StepPlan) names the same path
+    assert pl["projection"] == ("in_next_momentum_pass(substeps_1_2)" if folded else "own_pass(correc+updatep)"), pl
+    assert pl["sgs"] == "none" and pl["visct_ghost_cells"] == "zero_field", pl
+    if name == "halfchan_imp1d_x64":
+        assert pl["implicit_rhs"] == "in_helmholtz_sweep", pl
     for a, k in zip((u, v, w), "uvw"):
         assert relerr(a, g["r3_s7_" + k]) < 1e-10, k
     pg = g["r3_s8_p"]
@@ -502,7 +512,7 @@ def test_pending_projection_is_completed_by_every_entry_that_looks(monkeypatch):
 
 # ---- every entry of include/cales.h that takes a context, against a projection left pending by cales_step (api.hip ENTER / finish_pending) ----
 # entries that read or write no field (or are the consumer itself): they do not have to complete a pending projection
-_NO_FIELD_ENTRIES = {"cales_destroy", "cales_last_error", "cales_local_size", "cales_get_forcing", "cales_get_dpdl", "cales_get_bcvel", "cales_step",
+_NO_FIELD_ENTRIES = {"cales_destroy", "cales_last_error", "cales_local_size", "cales_get_forcing", "cales_get_dpdl", "cales_get_bcvel", "cales_step", "cales_describe_plan",
                      "cales_profile_enable", "cales_profile_reset", "cales_profile_count", "cales_profile_get", "cales_device_info",
                      "cales_comm_buffer_doubles", "cales_set_comm", "cales_set_comm_overlap", "cales_comm_init_rccl"}
 
@@ -548,6 +558,7 @@ def _entry_calls(h, dt):
         "cales_out1d": lambda: L.cales_out1d(H, capi.FIELDS["u"], 3, 0, P(o1)),
         "cales_out1d_chan": lambda: L.cales_out1d_chan(H, P(oc)),
         "cales_out2d_duct": lambda: L.cales_out2d_duct(H, P(od)),
+        "cales_calibrate": lambda: L.cales_calibrate(H, 1, P(f3), None),
     }
 
 
@@ -661,3 +672,43 @@ def test_all_directions_ghost_cell_kernel_equals_the_sequence(name, ng, is_corre
         h.close()
     for nm, a, b in zip(("u", "v", "w", "p", "visct", "pp"), out["all"], out["sequence"]):
         assert np.abs(a - b).max() <= 4e-16 * max(1., np.abs(b).max()), (nm, np.abs(a - b).max())
+
+
+@pytest.mark.parametrize("name,env,expect", [
+    ("chan_dsmag_x64", {}, {"projection": "in_strain_rate_pass", "x_ghost_columns": "wrapped", "fillps": "in_x_transform", "ghost_cells": "one_launch",
+                            "sgs": "dsmag_tiles(pair_fields)", "solver": "x:PP/radix8,y:PP/radix8_register_ends,z:lds_tile", "exchanges": "none"}),
+    ("chan_dsmag_x64", {"CALES_UNMERGED_BC": "1"}, {"projection": "own_pass(correc+updatep)", "ghost_cells": "by_direction", "sgs": "dsmag_tiles"}),
+    ("chan_dsmag", {}, {"projection": "own_pass(correc+updatep)", "x_ghost_columns": "maintained", "fillps": "own_pass", "solver": "x:PP/mixed_radix,y:PP/mixed_radix,z:lds_tile"}),
+    ("chan_dsmag", {"CALES_DSMAG_REFERENCE_SEQUENCE": "1", "CALES_GAUSSEL_MARCH": "1"}, {"sgs": "dsmag_reference_sequence", "solver": "x:PP/mixed_radix,y:PP/mixed_radix,z:thomas_march"}),
+    ("chan_smag_wm_x64", {}, {"projection": "own_pass(correc+updatep)", "sgs": "smag_rows", "x_ghost_columns": "maintained"}),
+    ("chan_smag_wm_x64", {"CALES_UNFUSED_FORCING": "1"}, {"bulk_forcing": "own_pass"}),
+    ("duct_smag_wm_imp1d_x64", {}, {"implicit_rhs": "in_helmholtz_sweep", "bulk_forcing": "in_helmholtz_sweep", "solver": "x:PP/radix8,y:NN/mixed_radix,z:lds_tile"}),
+    ("cavity_nnn_x64", {}, {"projection": "in_next_momentum_pass(substeps_1_2)", "solver": "x:NN/radix8,y:NN/radix8,z:lds_tile", "sgs": "none", "visct_ghost_cells": "zero_field"}),
+    ("cavity_nnn_x64", {"CALES_LAZY_PROJECTION": "1"}, {"projection": "in_next_momentum_pass(all_substeps)"}),
+    ("cavity_dsmag", {}, {"sgs": "dsmag_reference_sequence", "projection": "own_pass(correc+updatep)"}),
+    ("tgv_ppp_x64", {"CALES_UNFOLDED_MOM": "1", "CALES_KEEP_NULL_MODE": "1"}, {"projection": "own_pass(correc+updatep)", "solver": "x:PP/radix8,y:PP/radix8_register_ends,z:lds_tile_periodic,null_mode:reference_order"}),
+])
+def test_step_plan_is_a_value(name, env, expect, monkeypatch):
+    """The path of a step is a VALUE (struct StepPlan, api.hip make_plan): computed from the case, the switches and the context's state, read by step_body,
+    printed by cales_describe_plan. Held here against the cases whose goldens pin each path (the sequence protected: src/main.f90:417-508), before and
+    after a step (the plan describes the NEXT step and must not change by taking one), and across a change of the state it was made from."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    g, case = load_golden(name)
+    h = _hot(case)
+    h.upload(*(F(g["s0raw_" + k]) for k in "uvwp")); h.startup()
+    pl = h.describe_plan()
+    for k, v in expect.items():
+        assert pl.get(k) == v, (k, pl)
+    assert pl["ranks"] == "1"
+    if "first_wall_model_update" in pl and case.impdiff == 0 and not env:      # the deferred forcing needs the first wall-model update to be dead work
+        assert pl["bulk_forcing"] == ("in_correction(means_in_x_transform)" if pl["first_wall_model_update"] == "skipped" else "own_pass"), pl
+    h.step(float(g["dt"]))
+    assert h.describe_plan() == pl
+    if pl["sgs"] == "none" and pl["projection"].startswith("in_next_momentum_pass"):
+        # an eddy viscosity set by hand: the momentum pass reads it again, the fold that assumes a zero field is off, and the plan says so
+        h.set("visct", h.zeros() + 1e-5)
+        pl2 = h.describe_plan()
+        assert pl2["projection"] == "own_pass(correc+updatep)" and pl2["visct_ghost_cells"] == "updated", pl2
+        h.step(float(g["dt"])); assert h.chkdiv()[1] < 1e-11
+    h.close()
