@@ -91,6 +91,10 @@ END_ONLY = {
     # (k_corr_strain_tile, api.hip `fold_correc`: n1 % 64 == 0) -- the dominant kernel of the 512^3 bench
     "chan_dsmag_x64": ("les/_manuscript_turbulent_channel/input.nml",
                        {r"ng\(1:3\) = .*": "ng(1:3) = 64, 16, 12", r"gr = 5\.": "gr = 2.", r"sgstype = 'smag'": "sgstype = 'dsmag'"}, 0),
+    # ... and a row of TWO 64-cell tiles (and two 10-row tiles in y): the x seam of k_corr_strain_tile -- lane 63's pp(i+1) from the halo column, the halo
+    # waves' side job -- held to the reference itself and not only to the oracle
+    "chan_dsmag_x128": ("les/_manuscript_turbulent_channel/input.nml",
+                        {r"ng\(1:3\) = .*": "ng(1:3) = 128, 12, 10", r"gr = 5\.": "gr = 2.", r"sgstype = 'smag'": "sgstype = 'dsmag'"}, 0),
     "tgv_dsmag_ppp_x64": ("dns/triperiodic/input.nml",
                           {r"ng\(1:3\) = .*": "ng(1:3) = 64, 16, 16", r"l\(1:3\) = .*": "l(1:3) = 6.283185307179586, 6.283185307179586, 6.283185307179586",
                            r"visci = .*": "visci = 1600.", r"inivel = .*": "inivel = 'tgv'", r"sgstype = 'none'": "sgstype = 'dsmag'"}, 0),

@@ -139,7 +139,7 @@ def test_fused_step_matches_operator_sequence(name):
 
 
 @pytest.mark.parametrize("keep_x", [False, True], ids=["wrap", "xghosts"])
-@pytest.mark.parametrize("name", ["chan_dsmag_p2", "chan_smag_p2", "duct_dsmag_p2", "tgv_ppp_p2", "chan_dsmag_x64", "tgv_dsmag_ppp_x64",
+@pytest.mark.parametrize("name", ["chan_dsmag_p2", "chan_smag_p2", "duct_dsmag_p2", "tgv_ppp_p2", "chan_dsmag_x64", "chan_dsmag_x128", "tgv_dsmag_ppp_x64",
                                   "chan_smag_wm_x64", "duct_smag_wm_x64", "duct_smag_wm_imp1d_x64",
                                   "chan_nosgs_x64", "cavity_nnn_x64", "halfchan_imp1d_x64", "duct_dsmag_x64", "tgv_ppp_x64"])
 def test_fused_step_at_power_of_two_rows(name, keep_x, monkeypatch):
@@ -151,7 +151,7 @@ def test_fused_step_at_power_of_two_rows(name, keep_x, monkeypatch):
 
 
 @pytest.mark.parametrize("folded", [True, False], ids=["folded", "separate"])
-@pytest.mark.parametrize("name", ["chan_dsmag_x64", "tgv_dsmag_ppp_x64"])
+@pytest.mark.parametrize("name", ["chan_dsmag_x64", "chan_dsmag_x128", "tgv_dsmag_ppp_x64"])
 def test_folded_strain_pass_against_reference_made_state(name, folded, monkeypatch):
     """Reference-made end-of-step states (src/sgs.f90:153-380 + src/correc.f90:44-67 + src/updatep.f90:30-47 through the compiled modules,
     gen_golden.py END_ONLY) at rows of 64 cells, the only row lengths at which the dynamic model's strain-rate pass takes the projection on load

@@ -214,7 +214,7 @@ def test_solver_operands_and_z_sweep(name):
                 assert np.array_equal(g[f"r{irk}_s1b_{k}"], g[f"r{irk}_s1b_{k}_orc"]), (irk, k)
 
 
-END_CASES = ["chan_dsmag_p2", "chan_smag_p2", "duct_dsmag_p2", "tgv_ppp_p2", "chan_dsmag_x64", "tgv_dsmag_ppp_x64", "chan_smag_wm_x64", "duct_smag_wm_x64", "duct_smag_wm_imp1d_x64",
+END_CASES = ["chan_dsmag_p2", "chan_smag_p2", "duct_dsmag_p2", "tgv_ppp_p2", "chan_dsmag_x64", "chan_dsmag_x128", "tgv_dsmag_ppp_x64", "chan_smag_wm_x64", "duct_smag_wm_x64", "duct_smag_wm_imp1d_x64",
              "chan_nosgs_x64", "cavity_nnn_x64", "halfchan_imp1d_x64", "duct_dsmag_x64", "tgv_ppp_x64"]
 
 
