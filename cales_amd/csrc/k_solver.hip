@@ -526,11 +526,15 @@ __global__ __launch_bounds__(512) void k_fft_y8(Geom g, int N, int ncols, int kc
   for (int q = threadIdx.x; q < N; q += blockDim.x) tw[q] = twg[q];
   const int NE = 8;                                                          // CB*N / blockDim.x
   cpx nxt[NE];
+  // (every global access unconditional -- columns beyond the last one repeat it: their lanes transform a copy of the last column and store ITS values to
+  //  ITS places once more. A branch around a load or a store makes every wait of the plane loop an s_waitcnt vmcnt(0): the wait for the prefetched
+  //  plane then also waits for the write acknowledgements of the plane just stored; tools/memseq.py shows counted waits where it showed `w0`.
+  //  512 x 256 x 256 duct: y passes 0.390 / 0.417 -> 0.362 / 0.395 ms per step)
   auto fetch = [&](int k) {
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
       const int q = threadIdx.x + e * blockDim.x, col = q % CB, j = q / CB;
-      if (m0 + col < ncols) { const real2 v = pc[S.at_mode(g, m0 + col, j + 1, k)]; nxt[e] = cpx{v.x, v.y}; }
+      const real2 v = pc[S.at_mode(g, min(m0 + col, ncols - 1), j + 1, k)]; nxt[e] = cpx{v.x, v.y};
     }
   };
   // kind 1 (Neumann-Neumann, DCT-II/III on the real and the imaginary part alike): Makhoul order in, weights out (forward);
@@ -544,7 +548,7 @@ __global__ __launch_bounds__(512) void k_fft_y8(Geom g, int N, int ncols, int kc
       base[(size_t)col * ld + lpad((kind && !INV) ? makhoul(j) : j)] = nxt[e];
     }
     __syncthreads();
-    if (k < kend) fetch(k + 1);                                               // in flight during the transform
+    fetch(min(k + 1, kend));                                                  // in flight during the transform (the last plane again: unused)
     if (kind && INV) {            // Z_k = conj(w_k) (C_k - i C_{N-k}), C_N := 0
       cpx tmp[NE];
 #pragma unroll
@@ -562,13 +566,13 @@ __global__ __launch_bounds__(512) void k_fft_y8(Geom g, int N, int ncols, int kc
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
       const int q = threadIdx.x + e * blockDim.x, c2 = q % CB, j = q / CB;
-      if (m0 + c2 < ncols) {
+      {
         const cpx *Zc = base + (size_t)c2 * ld;
         cpx v;
         if (!kind) v = Zc[lpad(j)];
         else if (!INV) { const cpx w = twd[j]; v = cadd(cmul(w, Zc[lpad(j)]), cmul(cconj(w), Zc[lpad((N - j) % N)])); }   // C_j = w_j V_j + conj(w_j) V_{N-j}
         else v = Zc[lpad(makhoul(j))];
-        pc[S.at_mode(g, m0 + c2, j + 1, k)] = make_real2(v.x, v.y);
+        pc[S.at_mode(g, min(m0 + c2, ncols - 1), j + 1, k)] = make_real2(v.x, v.y);
       }
     }
     __syncthreads();
@@ -607,6 +611,154 @@ __global__ __launch_bounds__(512) void k_fft_y8r(Geom g, int N, int ncols, int k
 #pragma unroll
     for (int e = 0; e < 8; ++e) pc[S.at_mode(g, mc, t + e * T + 1, k)] = make_real2(v[e].x, v[e].y);
     __syncthreads();                                                           // the last stage's reads are done before the next plane writes
+  }
+}
+
+// ------------------------------------------------------------------------------------------ 1024-point lines in y: 16 elements per thread
+// radix-16 butterfly in registers, natural order in and out, as 4 x 4: y[n1][k2] = DFT4 over n2 of v[n1 + 4 n2], times W16^(n1 k2),
+// X[k2 + 4 k1] = DFT4 over n1
+template <int INV>
+__device__ inline void fft16_regs(cpx *v) {
+  const real c1 = 0.92387953251128675613, s1 = 0.38268343236508977173, h = 0.70710678118654752440;      // cos(pi/8), sin(pi/8), sqrt(1/2)
+  auto dft4 = [](cpx &a0, cpx &a1, cpx &a2, cpx &a3) {
+    const cpx b0 = cadd(a0, a2), b1 = csub(a0, a2), b2 = cadd(a1, a3), b3 = mul_mi<INV>(csub(a1, a3));
+    a0 = cadd(b0, b2); a1 = cadd(b1, b3); a2 = csub(b0, b2); a3 = csub(b1, b3);
+  };
+  // W16^m = exp(-+ 2 pi i m / 16) (forward -, inverse +), as (re, im of the FORWARD value)
+  auto w16 = [](cpx a, real wr, real wi) { if (INV) wi = -wi; return cpx{a.x * wr - a.y * wi, a.x * wi + a.y * wr}; };
+#pragma unroll
+  for (int n1 = 0; n1 < 4; ++n1) dft4(v[n1], v[n1 + 4], v[n1 + 8], v[n1 + 12]);      // v[n1 + 4 k2] = y[n1][k2]
+  v[1 + 4] = w16(v[1 + 4], c1, -s1); v[1 + 8] = w16(v[1 + 8], h, -h);   v[1 + 12] = w16(v[1 + 12], s1, -c1);      // m = 1, 2, 3
+  v[2 + 4] = w16(v[2 + 4], h, -h);   v[2 + 8] = mul_mi<INV>(v[2 + 8]);   v[2 + 12] = w16(v[2 + 12], -h, -h);       // m = 2, 4, 6
+  v[3 + 4] = w16(v[3 + 4], s1, -c1); v[3 + 8] = w16(v[3 + 8], -h, -h);  v[3 + 12] = w16(v[3 + 12], -c1, s1);      // m = 3, 6, 9
+  // DFT4 over n1 for every k2: results X[k2 + 4 k1] -- in place that is a 4 x 4 transposition of the register names
+  cpx x[16];
+#pragma unroll
+  for (int k2 = 0; k2 < 4; ++k2) {
+    cpx a0 = v[0 + 4 * k2], a1 = v[1 + 4 * k2], a2 = v[2 + 4 * k2], a3 = v[3 + 4 * k2];
+    dft4(a0, a1, a2, a3);
+    x[k2] = a0; x[k2 + 4] = a1; x[k2 + 8] = a2; x[k2 + 12] = a3;
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) v[q] = x[q];
+}
+// y pass for N = 1024 (reference src/fft.f90:323-493 for the Neumann kinds): EIGHT adjacent complex columns per block -- whole 128-B
+// segments of every row, where the eight-elements-per-thread kernels above hold four columns (64-B segments: tools/micro/segcopy copies that pattern at
+// 3.4-3.9 TB/s against 4.7) -- with 512 threads, thread (c, t) = (threadIdx.x % 8, threadIdx.x / 8) owning SIXTEEN elements i = t + 64 e of column
+// m0 + c. Register-ended decimation in frequency like fft_line8_dif: radix 16 from registers (twiddles w^(t r)), radix 8 with Ns' = 8 (two butterflies per
+// thread, twiddles w^(16 k r)), radix 8 with Ns' = 1 back into registers as X[t + 64 e] -- two LDS round trips for the transform, 128 KB of lines + the
+// twiddle table in the 160 KB of a CU. KIND = 1 (Neumann-Neumann, DCT-II / DCT-III of the real and the imaginary part alike, Makhoul's re-ordering):
+// forward the rows are LOADED in Makhoul order (v[i] = x[dct_src(i)]: any row order is coalesced, the lanes of a segment are columns) and the weights
+// C_k = w_k V_k + conj(w_k) V_{N-k} need one more LDS exchange for the partner; inverse Z_k = conj(w_k) (C_k - i C_{N-k}) takes the exchange first and
+// the results are STORED in Makhoul order. w_k = twd[t] twd[64 e]: one register and sixteen block-uniform values instead of sixteen loads per plane.
+// All global accesses unconditional (columns beyond the last one repeat it), the next plane prefetched into registers.
+template <int INV, int KIND>
+__global__ __launch_bounds__(512, 2) void k_fft_y16(Geom g, int ncols, int kchunk, const cpx *__restrict__ twg, const cpx *__restrict__ twd, Spec S,
+                                                    real2 *__restrict__ pc, int k0 = 0, int k1 = -1) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int N = 1024, T = 64, ld = N + 1;      // (odd pitch: the eight lanes of a write group are the eight columns -- eight different 16-B slots)
+  const int c = threadIdx.x & 7, t = threadIdx.x >> 3;
+  const int m0 = blockIdx.x * 8, kbeg = k0 + blockIdx.y * kchunk + 1, kend = min(kbeg + kchunk - 1, k1 < 0 ? g.n3 : k1);
+  cpx *tw = reinterpret_cast<cpx *>(smem), *line = tw + N + (size_t)c * ld;
+  unsigned *ro = reinterpret_cast<unsigned *>(tw + N + 8 * (size_t)ld);      // element offset of row q + 1 from row 1 (the same for every column and plane)
+  const size_t r0 = S.at_mode(g, 0, 1, 1);
+  for (int q = threadIdx.x; q < N; q += 512) { tw[q] = twg[q]; ro[q] = (unsigned)(S.at_mode(g, 0, q + 1, 1) - r0); }
+  const int mc = min(m0 + c, ncols - 1);
+  // planes are pstride elements apart; a0: the column's row 1 in plane 1
+  const size_t a0 = S.at_mode(g, mc, 1, 1), pstride = S.blocked ? (size_t)S.cw * S.n2l : (size_t)(g.s12 >> 1);
+  // rows this thread loads / stores for element i = t + 64 e: natural (i), or Makhoul's dct_src(i) = 2 i (e < 8), 2 (N - 1 - i) + 1 (e >= 8)
+  // (`tv` = t behind an opaque move made anew in every plane: the row offsets are loop invariants, and hoisted out of the plane loop their thirty-two
+  //  registers are spilled to scratch memory -- whose reloads count in vmcnt like the prefetch they then wait for)
+  int tv = t;
+  auto mrow = [&](int e) { return e < 8 ? 2 * (tv + T * e) : 2 * (N - 1 - (tv + T * e)) + 1; };
+  cpx wt = {1., 0.};
+  if (KIND) wt = twd[t];
+  const __attribute__((address_space(4))) real *twu = (const __attribute__((address_space(4))) real *)twd;      // twd[64 e]: block-uniform, scalar loads
+  cpx nxt[16], v[16];
+  auto fetch = [&](int k) {
+    const real2 *pl = pc + a0 + (size_t)(k - 1) * pstride;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { const real2 q = pl[ro[(KIND && !INV) ? mrow(e) : tv + T * e]]; nxt[e] = cpx{q.x, q.y}; }
+  };
+  __syncthreads();      // (the tables)
+  fetch(kbeg);
+  for (int k = kbeg; k <= kend; ++k) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = nxt[e];
+    asm volatile("" : "+v"(tv));
+    fetch(min(k + 1, kend));                                                   // in flight during the transform (the last plane again: unused)
+    if (KIND && INV) {      // Z_k = conj(w_k) (C_k - i C_{N-k}), C_N := 0, k = t + 64 e
+#pragma unroll
+      for (int e = 0; e < 16; ++e) line[t + T * e] = v[e];
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int kk = t + T * e;
+        const cpx cm = kk == 0 ? cpx{0., 0.} : line[N - kk];
+        const cpx w = e == 0 ? wt : cmul(wt, cpx{twu[2 * T * e], twu[2 * T * e + 1]});
+        v[e] = cmul(cconj(w), cpx{v[e].x + cm.y, v[e].y - cm.x});
+        if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (four partners at a time, see the twiddles below)
+      }
+      __syncthreads();
+    }
+    // radix 16 from registers: in[t + 64 r] -> butterfly -> twiddle w^(t r) -> out[t + 64 r]
+    fft16_regs<INV>(v);
+    line[t] = v[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) {      // (four at a time: all fifteen twiddles fetched at once cost the registers the prefetched plane needs)
+      line[t + T * r] = tw_mul<INV>(v[r], tw[t * r]);
+      if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    // radix 8, Ns' = 8: butterflies j = t and t + 64: in[(j - k) 8 + k + 8 r], k = j mod 8 -> twiddle w^(16 k r) -> out[j + 128 r]
+    const int kq = t & 7;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int j = t + T * b, base = (j - kq) * 8 + kq;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[8 * b + r] = line[base + 8 * r];
+      fft8_regs<INV>(v + 8 * b);
+#pragma unroll
+      for (int r = 1; r < 8; ++r) v[8 * b + r] = tw_mul<INV>(v[8 * b + r], tw[16 * kq * r]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) line[t + T * b + 128 * r] = v[8 * b + r];
+    __syncthreads();
+    // radix 8, Ns' = 1: in[8 j + r] -> X[j + 128 r] = X[t + 64 (2 r + b)], in registers
+    cpx xo[16];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int j = t + T * b;
+      cpx u[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) u[r] = line[8 * j + r];
+      fft8_regs<INV>(u);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) xo[2 * r + b] = u[r];
+    }
+    real2 *pl = pc + a0 + (size_t)(k - 1) * pstride;
+    if (KIND && !INV) {      // C_k = w_k V_k + conj(w_k) V_{N-k}, k = t + 64 e: the partner through LDS
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 16; ++e) line[t + T * e] = xo[e];
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int kk = t + T * e;
+        const cpx pm = line[(N - kk) & (N - 1)];
+        const cpx w = e == 0 ? wt : cmul(wt, cpx{twu[2 * T * e], twu[2 * T * e + 1]});
+        const cpx o = cadd(cmul(w, xo[e]), cmul(cconj(w), pm));
+        pl[ro[tv + T * e]] = make_real2(o.x, o.y);
+        if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) pl[ro[(KIND && INV) ? mrow(e) : tv + T * e]] = make_real2(xo[e].x, xo[e].y);
+    }
+    __syncthreads();                                                           // this plane's last LDS reads are done before the next plane writes
   }
 }
 
@@ -1226,7 +1378,7 @@ __global__ __launch_bounds__(256) void k_gaussel(Geom g, int nz, int ncol, int n
 }
 
 // ------------------------------------------------------------------------------------------ host side
-struct SolverPlans { FftPlan py4; int CBy4; size_t shy4; FftPlan px, py; int Rx, CBy; size_t shx, shy; bool x8, y8; int x8_threads, y8_threads; size_t shx8, shy8, shy8r; };
+struct SolverPlans { FftPlan py4; int CBy4; size_t shy4; FftPlan px, py; int Rx, CBy; size_t shx, shy; bool x8, y8, y16 = false; int x8_threads, y8_threads; size_t shx8, shy8, shy8r, shy16 = 0; };
 struct VelSet { bool ready = false; int xkind = 0, ykind = 0; real *lamx = nullptr, *lamy = nullptr; real normfft = 1.; FftPlan p1x, p1y; real *tw1x = nullptr, *tw1y = nullptr; };
 struct PlanSlot { cales_ctx *ctx; SolverPlans sp; VelSet vs[3]; };
 // one entry per context; a list (stable addresses) behind a mutex: contexts are created and destroyed from several host threads in the
@@ -1271,6 +1423,14 @@ int solver_setup(cales_ctx *c) {
                if (sp.shy8 > 64 * 1024) {      // n2 = 1024: 4 columns (64-B row segments) need 90 KB of LDS
                  HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y8<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8));
                  HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y8<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8)); } }
+  sp.y16 = sp.y8 && n2g == 1024 && c->ykind <= 1;      // 1024-point lines: eight columns per block, sixteen elements per thread (k_fft_y16)
+  if (sp.y16) {
+    sp.shy16 = ((size_t)n2g + 8 * ((size_t)n2g + 1)) * sizeof(cpx) + (size_t)n2g * sizeof(unsigned);
+    HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y16<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy16));
+    HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y16<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy16));
+    HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y16<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy16));
+    HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y16<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy16));
+  }
   if (c->ykind >= 3) {      // DCT-IV / DST-IV in y: N/2-point lines, two per complex column
     if (!make_plan(n2g / 2, sp.py4)) { c->err = "solver: ng(2)/2 must factor into primes <= 127"; return 1; }
     sp.CBy4 = 4; sp.shy4 = (size_t)2 * sp.CBy4 * 2 * (n2g / 2 + 1) * sizeof(cpx);
@@ -1285,6 +1445,7 @@ int solver_setup(cales_ctx *c) {
   }
   if (c->ykind == 2) sp.y8 = false;      // the sign changes of the Dirichlet-Dirichlet transform live in the generic y kernel only
   if (c->fl.fft_generic) sp.x8 = sp.y8 = false;
+  if (!sp.y8) sp.y16 = false;
   // eigenvalues (initsolver.f90:66-98); x: modes 0..n1/2 (half-complex symmetry), y: modes 0..n2-1
   std::vector<real> lx(n1 + 2, 0.), ly(n2g);
   hs_eigenvalues(n1, bx.c_str(), 'c', lx.data()); hs_eigenvalues(n2g, by.c_str(), 'c', ly.data());
@@ -1424,7 +1585,16 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
   const int ncol = dist ? c->cw : mh, mofs = dist ? c->rank * c->cw : 0;
   const int64_t a2a_count = (int64_t)n[2] * n[1] * c->cw * 2;
   const int nh = c->C.ng[0] / 2;
-  const int Rx8 = use8x ? sp->x8_threads / (nh / 8) : 1, CB8 = use8y ? sp->y8_threads / (n2g / 8) : 1;
+  const bool use16y = use8y && sp->y16;
+  const int Rx8 = use8x ? sp->x8_threads / (nh / 8) : 1, CB8 = use16y ? 8 : use8y ? sp->y8_threads / (n2g / 8) : 1;
+  // real x modes (Neumann in x) fill the complex columns 0 .. n1/2 - 1: the slot of "mode n1/2" is never written by the x pass nor read back by it
+  const int ncol_y = (!dist && c->xkind == 1 && use8y) ? nh : ncol;
+  auto launch_y16 = [&](int inv, dim3 gy, int kc, int ka, int kb) {
+    if (inv) { if (c->ykind) LAUNCH(c, (k_fft_y16<1, 1>), gy, dim3(512), sp->shy16, c->stream, c->g, ncol_y, kc, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, ka, kb);
+               else LAUNCH(c, (k_fft_y16<1, 0>), gy, dim3(512), sp->shy16, c->stream, c->g, ncol_y, kc, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, ka, kb); }
+    else { if (c->ykind) LAUNCH(c, (k_fft_y16<0, 1>), gy, dim3(512), sp->shy16, c->stream, c->g, ncol_y, kc, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, ka, kb);
+           else LAUNCH(c, (k_fft_y16<0, 0>), gy, dim3(512), sp->shy16, c->stream, c->g, ncol_y, kc, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, ka, kb); }
+  };
   // persistent blocks: several row groups / planes per block so that the register prefetch overlaps the transforms
   const long xgroups = (nrows + Rx8 - 1) / Rx8;
   int xiters = 1; while (xiters < 8 && xgroups / (xiters * 2) >= 2048) xiters *= 2;
@@ -1483,8 +1653,9 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
     for (int ch = 0; ch < NCH; ++ch) {
       HIPCHK(c, hipStreamWaitEvent(c->stream, ev_arrived[ch], 0));
       ProfScope ps(c, "fft_y_fwd");
-      const dim3 gy((ncol + CB8 - 1) / CB8, (kpc + ykchunk_c - 1) / ykchunk_c);
-      if (c->ykind) LAUNCH(c, (k_fft_y8<0, 1>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1));
+      const dim3 gy((ncol_y + CB8 - 1) / CB8, (kpc + ykchunk_c - 1) / ykchunk_c);
+      if (use16y) launch_y16(0, gy, ykchunk_c, kpc * ch, kpc * (ch + 1));
+      else if (c->ykind) LAUNCH(c, (k_fft_y8<0, 1>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol_y, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1));
       else LAUNCH(c, (k_fft_y8r<0>), gy, dim3(sp->y8_threads), sp->shy8r, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, S, mode_spec, kpc * ch, kpc * (ch + 1));
     }
   } else {
@@ -1519,7 +1690,8 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
     if (c->ykind >= 5) LAUNCH(c, k_dst1<1>, dim3(ncol, n[2]), dim3(256), (size_t)2 * (VS->p1y.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1y, ncol, (const cpx *)VS->tw1y, pp, 1., S, mode_spec, c->ykind, 0);
     else if (c->ykind == 3) LAUNCH(c, k_fft_y4<0>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
     else if (c->ykind == 4) LAUNCH(c, k_fft_y4<1>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
-    else if (use8y && c->ykind) LAUNCH(c, (k_fft_y8<0, 1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
+    else if (use16y) launch_y16(0, dim3((ncol_y + 7) / 8, ychunks), ykchunk, 0, -1);
+    else if (use8y && c->ykind) LAUNCH(c, (k_fft_y8<0, 1>), dim3((ncol_y + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol_y, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
     else if (use8y) LAUNCH(c, (k_fft_y8r<0>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8r, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, S, mode_spec);
     else LAUNCH(c, k_fft_y<0>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
   }
@@ -1561,8 +1733,9 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
   if (pipe) {
     for (int ch = 0; ch < NCH; ++ch) {
       { ProfScope ps(c, "fft_y_bwd");
-        const dim3 gy((ncol + CB8 - 1) / CB8, (kpc + ykchunk_c - 1) / ykchunk_c);
-        if (c->ykind) LAUNCH(c, (k_fft_y8<1, 1>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1));
+        const dim3 gy((ncol_y + CB8 - 1) / CB8, (kpc + ykchunk_c - 1) / ykchunk_c);
+        if (use16y) launch_y16(1, gy, ykchunk_c, kpc * ch, kpc * (ch + 1));
+        else if (c->ykind) LAUNCH(c, (k_fft_y8<1, 1>), gy, dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol_y, ykchunk_c, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, kpc * ch, kpc * (ch + 1));
         else LAUNCH(c, (k_fft_y8r<1>), gy, dim3(sp->y8_threads), sp->shy8r, c->stream, c->g, n2g, ncol, ykchunk_c, (const cpx *)c->d_twy, S, mode_spec, kpc * ch, kpc * (ch + 1)); }
       if (int e = exchange_chunk(1, ch)) return e;
     }
@@ -1578,7 +1751,8 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
     if (c->ykind >= 5) LAUNCH(c, k_dst1<1>, dim3(ncol, n[2]), dim3(256), (size_t)2 * (VS->p1y.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1y, ncol, (const cpx *)VS->tw1y, pp, 1., S, mode_spec, c->ykind, 1);
     else if (c->ykind == 3) LAUNCH(c, k_fft_y4<0>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
     else if (c->ykind == 4) LAUNCH(c, k_fft_y4<1>, dim3((ncol + sp->CBy4 - 1) / sp->CBy4, n[2]), dim3(256), sp->shy4, c->stream, c->g, sp->py4, sp->CBy4, ncol, (const cpx *)c->d_twy4, (const cpx *)c->d_tw4y, S, mode_spec);
-    else if (use8y && c->ykind) LAUNCH(c, (k_fft_y8<1, 1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
+    else if (use16y) launch_y16(1, dim3((ncol_y + 7) / 8, ychunks), ykchunk, 0, -1);
+    else if (use8y && c->ykind) LAUNCH(c, (k_fft_y8<1, 1>), dim3((ncol_y + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8, c->stream, c->g, n2g, ncol_y, ykchunk, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec);
     else if (use8y) LAUNCH(c, (k_fft_y8r<1>), dim3((ncol + CB8 - 1) / CB8, ychunks), dim3(sp->y8_threads), sp->shy8r, c->stream, c->g, n2g, ncol, ykchunk, (const cpx *)c->d_twy, S, mode_spec);
     else LAUNCH(c, k_fft_y<1>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
   if (dist) { ProfScope ps(c, "alltoall"); if (c->comm.a2a(c->comm.user, 1, a2a_count)) { c->err = "alltoall callback failed"; return 1; } }
