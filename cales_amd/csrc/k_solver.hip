@@ -642,38 +642,51 @@ __device__ inline void fft16_regs(cpx *v) {
 #pragma unroll
   for (int q = 0; q < 16; ++q) v[q] = x[q];
 }
-// y pass for N = 1024 (reference src/fft.f90:323-493 for the Neumann kinds): EIGHT adjacent complex columns per block -- whole 128-B
-// segments of every row, where the eight-elements-per-thread kernels above hold four columns (64-B segments: tools/micro/segcopy copies that pattern at
-// 3.4-3.9 TB/s against 4.7) -- with 512 threads, thread (c, t) = (threadIdx.x % 8, threadIdx.x / 8) owning SIXTEEN elements i = t + 64 e of column
-// m0 + c. Register-ended decimation in frequency like fft_line8_dif: radix 16 from registers (twiddles w^(t r)), radix 8 with Ns' = 8 (two butterflies per
-// thread, twiddles w^(16 k r)), radix 8 with Ns' = 1 back into registers as X[t + 64 e] -- two LDS round trips for the transform, 128 KB of lines + the
-// twiddle table in the 160 KB of a CU. KIND = 1 (Neumann-Neumann, DCT-II / DCT-III of the real and the imaginary part alike, Makhoul's re-ordering):
-// forward the rows are LOADED in Makhoul order (v[i] = x[dct_src(i)]: any row order is coalesced, the lanes of a segment are columns) and the weights
-// C_k = w_k V_k + conj(w_k) V_{N-k} need one more LDS exchange for the partner; inverse Z_k = conj(w_k) (C_k - i C_{N-k}) takes the exchange first and
-// the results are STORED in Makhoul order. w_k = twd[t] twd[64 e]: one register and sixteen block-uniform values instead of sixteen loads per plane.
-// All global accesses unconditional (columns beyond the last one repeat it), the next plane prefetched into registers.
-template <int INV, int KIND>
-__global__ __launch_bounds__(512, 2) void k_fft_y16(Geom g, int ncols, int kchunk, const cpx *__restrict__ twg, const cpx *__restrict__ twd, Spec S,
-                                                    real2 *__restrict__ pc, int k0 = 0, int k1 = -1) {
+// small radices in registers, natural order in and out (the last stage of k_fft_y16)
+template <int R, int INV>
+__device__ inline void fftR_regs(cpx *u) {
+  if (R == 8) fft8_regs<INV>(u);
+  else if (R == 4) {
+    const cpx b0 = cadd(u[0], u[2]), b1 = csub(u[0], u[2]), b2 = cadd(u[1], u[3]), b3 = mul_mi<INV>(csub(u[1], u[3]));
+    u[0] = cadd(b0, b2); u[1] = cadd(b1, b3); u[2] = csub(b0, b2); u[3] = csub(b1, b3);
+  } else { const cpx a = u[0], b = u[1]; u[0] = cadd(a, b); u[1] = csub(a, b); }
+}
+// y pass for N = 256, 512, 1024 with SIXTEEN elements per thread (reference src/fft.f90:323-493 for the Neumann kinds): EIGHT adjacent
+// complex columns per block -- whole 128-B segments of every row at any of these lengths (the eight-elements-per-thread kernels above hold four columns
+// of a 1024-point line, 64-B segments: tools/micro/segcopy copies that pattern at 3.4-3.9 TB/s against 4.7) -- with 8 T threads, T = N/16, thread
+// (c, t) = (threadIdx.x % 8, threadIdx.x / 8) owning the elements i = t + T e, e = 0..15, of column m0 + c. Register-ended decimation in frequency like
+// fft_line8_dif: radix 16 from registers (twiddles w^(t r)), radix 8 with Ns' = N/128 (two butterflies per thread, twiddles w^(16 k r)), a last stage of
+// radix Ns' = 8, 4, 2 (two, four, eight butterflies per thread) back into registers as X[t + T e] -- two LDS round trips for the transform; eight lines
+// + the twiddle table + the row offsets: 150 / 76 / 38 KB of the 160 KB of a CU, i.e. one block of 512 / two of 256 / four of 128 threads per CU at the
+// two waves per SIMD its ~210 registers allow. KIND = 1 (Neumann-Neumann, DCT-II / DCT-III of the real and the imaginary part alike, Makhoul's
+// re-ordering): forward the rows are LOADED in Makhoul order (v[i] = x[dct_src(i)]: any row order is coalesced, the lanes of a segment are columns) and
+// the weights C_k = w_k V_k + conj(w_k) V_{N-k} need one more LDS exchange for the partner; inverse Z_k = conj(w_k) (C_k - i C_{N-k}) takes the exchange
+// first and the results are STORED in Makhoul order. w_k = twd[t] twd[T e]: one register and sixteen block-uniform values instead of sixteen loads per
+// plane. All global accesses unconditional (columns beyond the last one repeat it), the next plane prefetched into registers.
+// 1024^3 cavity: y passes 15.2 / 16.4 -> 10.3 / 10.3 ms per step (0.40 -> 0.63 of the HBM peak).
+template <int N, int INV, int KIND>
+__global__ __launch_bounds__(N / 2, 2) void k_fft_y16(Geom g, int ncols, int kchunk, const cpx *__restrict__ twg, const cpx *__restrict__ twd, Spec S,
+                                                      real2 *__restrict__ pc, int k0 = 0, int k1 = -1) {
   extern __shared__ __align__(16) unsigned char smem[];
-  constexpr int N = 1024, T = 64, ld = N + 1;      // (odd pitch: the eight lanes of a write group are the eight columns -- eight different 16-B slots)
+  constexpr int T = N / 16, ld = N + 1;      // (odd pitch: the eight lanes of a write group are the eight columns -- eight different 16-B slots)
+  constexpr int NSA = N / 128, RB = NSA, NBB = 16 / RB;      // stage A: radix 8, Ns' = NSA; stage B: radix RB = NSA, Ns' = 1, NBB butterflies per thread
   const int c = threadIdx.x & 7, t = threadIdx.x >> 3;
   const int m0 = blockIdx.x * 8, kbeg = k0 + blockIdx.y * kchunk + 1, kend = min(kbeg + kchunk - 1, k1 < 0 ? g.n3 : k1);
   cpx *tw = reinterpret_cast<cpx *>(smem), *line = tw + N + (size_t)c * ld;
   unsigned *ro = reinterpret_cast<unsigned *>(tw + N + 8 * (size_t)ld);      // element offset of row q + 1 from row 1 (the same for every column and plane)
   const size_t r0 = S.at_mode(g, 0, 1, 1);
-  for (int q = threadIdx.x; q < N; q += 512) { tw[q] = twg[q]; ro[q] = (unsigned)(S.at_mode(g, 0, q + 1, 1) - r0); }
+  for (int q = threadIdx.x; q < N; q += 8 * T) { tw[q] = twg[q]; ro[q] = (unsigned)(S.at_mode(g, 0, q + 1, 1) - r0); }
   const int mc = min(m0 + c, ncols - 1);
   // planes are pstride elements apart; a0: the column's row 1 in plane 1
   const size_t a0 = S.at_mode(g, mc, 1, 1), pstride = S.blocked ? (size_t)S.cw * S.n2l : (size_t)(g.s12 >> 1);
-  // rows this thread loads / stores for element i = t + 64 e: natural (i), or Makhoul's dct_src(i) = 2 i (e < 8), 2 (N - 1 - i) + 1 (e >= 8)
+  // rows this thread loads / stores for element i = t + T e: natural (i), or Makhoul's dct_src(i) = 2 i (e < 8), 2 (N - 1 - i) + 1 (e >= 8)
   // (`tv` = t behind an opaque move made anew in every plane: the row offsets are loop invariants, and hoisted out of the plane loop their thirty-two
   //  registers are spilled to scratch memory -- whose reloads count in vmcnt like the prefetch they then wait for)
   int tv = t;
   auto mrow = [&](int e) { return e < 8 ? 2 * (tv + T * e) : 2 * (N - 1 - (tv + T * e)) + 1; };
   cpx wt = {1., 0.};
   if (KIND) wt = twd[t];
-  const __attribute__((address_space(4))) real *twu = (const __attribute__((address_space(4))) real *)twd;      // twd[64 e]: block-uniform, scalar loads
+  const __attribute__((address_space(4))) real *twu = (const __attribute__((address_space(4))) real *)twd;      // twd[T e]: block-uniform, scalar loads
   cpx nxt[16], v[16];
   auto fetch = [&](int k) {
     const real2 *pl = pc + a0 + (size_t)(k - 1) * pstride;
@@ -687,7 +700,7 @@ __global__ __launch_bounds__(512, 2) void k_fft_y16(Geom g, int ncols, int kchun
     for (int e = 0; e < 16; ++e) v[e] = nxt[e];
     asm volatile("" : "+v"(tv));
     fetch(min(k + 1, kend));                                                   // in flight during the transform (the last plane again: unused)
-    if (KIND && INV) {      // Z_k = conj(w_k) (C_k - i C_{N-k}), C_N := 0, k = t + 64 e
+    if (KIND && INV) {      // Z_k = conj(w_k) (C_k - i C_{N-k}), C_N := 0, k = t + T e
 #pragma unroll
       for (int e = 0; e < 16; ++e) line[t + T * e] = v[e];
       __syncthreads();
@@ -701,7 +714,7 @@ __global__ __launch_bounds__(512, 2) void k_fft_y16(Geom g, int ncols, int kchun
       }
       __syncthreads();
     }
-    // radix 16 from registers: in[t + 64 r] -> butterfly -> twiddle w^(t r) -> out[t + 64 r]
+    // radix 16 from registers: in[t + T r] -> butterfly -> twiddle w^(t r) -> out[t + T r]
     fft16_regs<INV>(v);
     line[t] = v[0];
 #pragma unroll
@@ -710,13 +723,13 @@ __global__ __launch_bounds__(512, 2) void k_fft_y16(Geom g, int ncols, int kchun
       if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
-    // radix 8, Ns' = 8: butterflies j = t and t + 64: in[(j - k) 8 + k + 8 r], k = j mod 8 -> twiddle w^(16 k r) -> out[j + 128 r]
-    const int kq = t & 7;
+    // stage A, radix 8, Ns' = NSA: butterflies j = t and t + T: in[(j - k) 8 + k + NSA r], k = j mod NSA -> twiddle w^(16 k r) -> out[j + (N/8) r]
+    const int kq = t & (NSA - 1);      // (T is a multiple of NSA: k is the same for both butterflies)
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const int j = t + T * b, base = (j - kq) * 8 + kq;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[8 * b + r] = line[base + 8 * r];
+      for (int r = 0; r < 8; ++r) v[8 * b + r] = line[base + NSA * r];
       fft8_regs<INV>(v + 8 * b);
 #pragma unroll
       for (int r = 1; r < 8; ++r) v[8 * b + r] = tw_mul<INV>(v[8 * b + r], tw[16 * kq * r]);
@@ -725,22 +738,22 @@ __global__ __launch_bounds__(512, 2) void k_fft_y16(Geom g, int ncols, int kchun
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 8; ++r) line[t + T * b + 128 * r] = v[8 * b + r];
+      for (int r = 0; r < 8; ++r) line[t + T * b + (N / 8) * r] = v[8 * b + r];
     __syncthreads();
-    // radix 8, Ns' = 1: in[8 j + r] -> X[j + 128 r] = X[t + 64 (2 r + b)], in registers
+    // stage B, radix RB, Ns' = 1: butterflies j = t + T b: in[RB j + r] -> X[j + (N/RB) r] = X[t + T (b + NBB r)], in registers
     cpx xo[16];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < NBB; ++b) {
       const int j = t + T * b;
-      cpx u[8];
+      cpx u[RB];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) u[r] = line[8 * j + r];
-      fft8_regs<INV>(u);
+      for (int r = 0; r < RB; ++r) u[r] = line[RB * j + r];
+      fftR_regs<RB, INV>(u);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) xo[2 * r + b] = u[r];
+      for (int r = 0; r < RB; ++r) xo[b + NBB * r] = u[r];
     }
     real2 *pl = pc + a0 + (size_t)(k - 1) * pstride;
-    if (KIND && !INV) {      // C_k = w_k V_k + conj(w_k) V_{N-k}, k = t + 64 e: the partner through LDS
+    if (KIND && !INV) {      // C_k = w_k V_k + conj(w_k) V_{N-k}, k = t + T e: the partner through LDS
       __syncthreads();
 #pragma unroll
       for (int e = 0; e < 16; ++e) line[t + T * e] = xo[e];
@@ -1423,13 +1436,20 @@ int solver_setup(cales_ctx *c) {
                if (sp.shy8 > 64 * 1024) {      // n2 = 1024: 4 columns (64-B row segments) need 90 KB of LDS
                  HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y8<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8));
                  HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y8<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy8)); } }
-  sp.y16 = sp.y8 && n2g == 1024 && c->ykind <= 1;      // 1024-point lines: eight columns per block, sixteen elements per thread (k_fft_y16)
+  // eight columns per block, sixteen elements per thread (k_fft_y16): 1024-point lines of either kind, 256- and 512-point Neumann lines (where the
+  // alternative is the staged k_fft_y8: 512 x 256 x 256 duct 0.39 / 0.42 -> 0.30 / 0.31 ms per step). Periodic 512-point lines stay with k_fft_y8r:
+  // measured 1.49 / 1.55 against 1.45 / 1.52 ms per step at 512^3 -- both sit at the copy rate of that access pattern (128-B segments at a pitch of 4224 B)
+  sp.y16 = sp.y8 && c->ykind <= 1 && (n2g == 1024 || (c->ykind == 1 && (n2g == 512 || n2g == 256)));
   if (sp.y16) {
     sp.shy16 = ((size_t)n2g + 8 * ((size_t)n2g + 1)) * sizeof(cpx) + (size_t)n2g * sizeof(unsigned);
-    HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y16<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy16));
-    HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y16<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy16));
-    HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y16<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy16));
-    HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y16<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy16));
+    if (sp.shy16 > 64 * 1024) {
+#define Y16_ATTR(NN) do { HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y16<NN, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy16)); \
+                          HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y16<NN, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy16)); \
+                          HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y16<NN, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy16)); \
+                          HIPSOFT(c, hipFuncSetAttribute((const void *)k_fft_y16<NN, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.shy16)); } while (0)
+      if (n2g == 1024) Y16_ATTR(1024); else Y16_ATTR(512);
+#undef Y16_ATTR
+    }
   }
   if (c->ykind >= 3) {      // DCT-IV / DST-IV in y: N/2-point lines, two per complex column
     if (!make_plan(n2g / 2, sp.py4)) { c->err = "solver: ng(2)/2 must factor into primes <= 127"; return 1; }
@@ -1590,16 +1610,31 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
   // real x modes (Neumann in x) fill the complex columns 0 .. n1/2 - 1: the slot of "mode n1/2" is never written by the x pass nor read back by it
   const int ncol_y = (!dist && c->xkind == 1 && use8y) ? nh : ncol;
   auto launch_y16 = [&](int inv, dim3 gy, int kc, int ka, int kb) {
-    if (inv) { if (c->ykind) LAUNCH(c, (k_fft_y16<1, 1>), gy, dim3(512), sp->shy16, c->stream, c->g, ncol_y, kc, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, ka, kb);
-               else LAUNCH(c, (k_fft_y16<1, 0>), gy, dim3(512), sp->shy16, c->stream, c->g, ncol_y, kc, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, ka, kb); }
-    else { if (c->ykind) LAUNCH(c, (k_fft_y16<0, 1>), gy, dim3(512), sp->shy16, c->stream, c->g, ncol_y, kc, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, ka, kb);
-           else LAUNCH(c, (k_fft_y16<0, 0>), gy, dim3(512), sp->shy16, c->stream, c->g, ncol_y, kc, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, ka, kb); }
+#define Y16_GO(NN, IV, KD) LAUNCH(c, (k_fft_y16<NN, IV, KD>), gy, dim3(NN / 2), sp->shy16, c->stream, c->g, ncol_y, kc, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec, ka, kb)
+#define Y16_N(NN) do { if (inv) { if (c->ykind) Y16_GO(NN, 1, 1); else Y16_GO(NN, 1, 0); } else { if (c->ykind) Y16_GO(NN, 0, 1); else Y16_GO(NN, 0, 0); } } while (0)
+    if (n2g == 1024) Y16_N(1024); else if (n2g == 512) Y16_N(512); else Y16_N(256);
+#undef Y16_N
+#undef Y16_GO
   };
   // persistent blocks: several row groups / planes per block so that the register prefetch overlaps the transforms
   const long xgroups = (nrows + Rx8 - 1) / Rx8;
   int xiters = 1; while (xiters < 8 && xgroups / (xiters * 2) >= 2048) xiters *= 2;
   const unsigned xblocks = (unsigned)((xgroups + xiters - 1) / xiters);
   int ykchunk = 1; { const long cg = (ncol + CB8 - 1) / CB8; while (ykchunk < 8 && cg * (n[2] / (ykchunk * 2)) >= 2048 && n[2] % (ykchunk * 2) == 0) ykchunk *= 2; }
+  // k_fft_y16 holds 1 / 2 / 4 blocks per CU (1024 / 512 / 256 points): a launch runs in ceil(blocks / slots) rounds of (planes per block + ~1.5 planes of
+  // set-up: tables, the first plane's latency) each -- the chunk length that minimises that product (512^3: 7 planes, 5 rounds of 8.5 against 5 of 9.5
+  // with 8; 512 x 256 x 256: 3 planes; 1024^3: 32)
+  auto y16_chunk = [&](int planes) {
+    const long slots = (long)(c->ncu > 0 ? c->ncu : 256) * (n2g >= 1024 ? 1 : n2g >= 512 ? 2 : 4), tiles = (ncol_y + 7) / 8;
+    double best = 1e300; int bk = 1;
+    for (int kc = 1; kc <= 32 && kc <= planes; ++kc) {
+      const long nb = tiles * ((planes + kc - 1) / kc);
+      const double cost = (double)((nb + slots - 1) / slots) * (kc + 1.5);
+      if (cost < best) { best = cost; bk = kc; }
+    }
+    return bk;
+  };
+  if (use16y) ykchunk = y16_chunk(n[2]);
   const int ychunks = (n[2] + ykchunk - 1) / ykchunk;
   // ---- pipelined exchange (cales_set_comm_overlap): the spectrum travels in k-chunks on the second stream while the x transforms of
   // the next chunk and the y transforms of the previous one run on the context's stream (the reference's cuDecomp pipelined
@@ -1613,6 +1648,7 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
   int xiters_c = 1; while (xiters_c < 8 && xgroups_c / (xiters_c * 2) >= 2048 / NCH) xiters_c *= 2;
   const unsigned xblocks_c = (unsigned)((xgroups_c + xiters_c - 1) / xiters_c);
   int ykchunk_c = 1; { const long cg = (ncol + CB8 - 1) / CB8; while (ykchunk_c < 8 && cg * (kpc / (ykchunk_c * 2)) >= 2048 / NCH && kpc % (ykchunk_c * 2) == 0) ykchunk_c *= 2; }
+  if (use16y) ykchunk_c = y16_chunk(kpc);
   hipEvent_t ev_arrived[4];
   // the bulk means summed by the fused fillps pass: several ranks all-reduce them on the context's stream, and RCCL orders the operations of
   // one communicator across streams -- issued between the chunk exchanges it would hold the y transforms back, so it follows the z sweep
