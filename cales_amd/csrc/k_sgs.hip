@@ -1119,6 +1119,27 @@ __global__ __launch_bounds__(256) void k_wface_fold(Geom g, const real *__restri
   wd[a] = ws[a] - cz0 * (pp[a + g.s12] - pp[a]);
   wd[b] = ws[b];
 }
+// Several slabs, projection folded into the strain-rate pass: the corrected velocity and p + pp of the two GHOST rows (the neighbours' rows n2 and 1) are
+// formed HERE, from the prediction's ghost rows and pp's -- the operands the neighbour's own pass has for those rows, the operations of `fix` in
+// k_corr_strain_tile (correc.f90:44-67, updatep.f90:30-47) in their order -- instead of travelling: four field planes per substep less in the slab
+// exchange (63 -> 51 planes per step). pp of "row n2+2" for v in the upper ghost row: the companion field (api.hip). Interior
+// cells i = 1..n1, k = 1..n3 of the two rows; their x and z ghost cells follow from the ghost-cell kernel, whose loops cover the ghost rows, and
+// plane 0 of w from k_wface_fold.
+__global__ __launch_bounds__(256) void k_fold_ghost_rows(Geom g, const real *__restrict__ us, const real *__restrict__ vs, const real *__restrict__ ws,
+                                                         real *__restrict__ ud, real *__restrict__ vd, real *__restrict__ wd, const real *__restrict__ pp,
+                                                         const real *__restrict__ ppc, real *__restrict__ p, const real *__restrict__ force, int fmask,
+                                                         real cfi, real cfj, real cdt, const real *__restrict__ dzci, int perx) {
+  const int i = blockIdx.x * 64 + threadIdx.x + 1, k = blockIdx.y * 4 + threadIdx.y + 1, side = blockIdx.z;
+  if (i > g.n1 || k > g.n3) return;
+  const int j = side ? g.n2 + 1 : 0, ip = (perx && i == g.n1) ? 1 : i + 1;
+  const size_t a = g.ix(i, j, k);
+  const real P0 = pp[a], px = pp[g.ix(ip, j, k)], py = side ? ppc[a] : pp[a + g.s1], pz = pp[a + g.s12];
+  const real f0 = (fmask & 1) ? force[0] : 0., f1 = (fmask & 2) ? force[1] : 0., f2 = (fmask & 4) ? force[2] : 0.;
+  ud[a] = ((fmask & 1) ? us[a] + f0 : us[a]) - cfi * (px - P0);
+  vd[a] = ((fmask & 2) ? vs[a] + f1 : vs[a]) - cfj * (py - P0);
+  wd[a] = ((fmask & 4) ? ws[a] + f2 : ws[a]) - cdt * dzci[k] * (pz - P0);
+  p[a] = p[a] + P0;
+}
 static bool dsmag_fast_ok(const cales_ctx *c) {
   for (int q = 0; q < 2; ++q) if (c->is_wall[q] != 0. || c->C.lwm[q] != 0) return false;      // walls or wall model in x: general path
   // walls / wall model in y (ducts): the fused last pass knows the wall rule along y, the two-pass form does not
@@ -1201,14 +1222,21 @@ static int dsmag_fast(cales_ctx *c) {
     if (!perz)
       LAUNCH(c, k_wface_fold, dim3((n[0] + 2 + 63) / 64, (n[1] + 2 + 3) / 4), dim3(64, 4), 0, c->stream, c->g, c->f2[2], c->f[CALES_W], f[CALES_PP], c->fold_dtrk * c->dzci[0]);
     if (!c->fl.unmerged_bc) { c->bc_nride = 1; c->bc_ride[0] = f[CALES_P]; c->bc_ride_which[0] = 0; }
-    // several slabs: the rows of u, v, w and p travel in the SAME exchange as the scratch fields' below (fifteen planes; their next readers, the last pass
-    // and the next momentum pass, come behind it) -- three exchanges per substep instead of four
-    c->defer_halo = c->P > 1 && !c->fl.unmerged_bc;
+    // several slabs: the ghost rows of u, v, w and p do not travel at all -- k_fold_ghost_rows forms them from the prediction's ghost rows and pp's,
+    // the ghost-cell kernel below gives them their x and z ghost cells (round 5: in the same exchange as the scratch fields', fifteen planes; now eleven)
+    const bool local_rows = c->P > 1 && !c->fl.unmerged_bc;
+    if (local_rows)
+      LAUNCH(c, k_fold_ghost_rows, dim3((n[0] + 63) / 64, (n[2] + 3) / 4, 2), dim3(64, 4), 0, c->stream, c->g, c->f2[0], c->f2[1], c->f2[2], c->f[CALES_U], c->f[CALES_V],
+             c->f[CALES_W], f[CALES_PP], c->scr2, f[CALES_P], c->d_force, c->defer_force ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0,
+             c->fold_dtrk * c->dli[0], c->fold_dtrk * c->dli[1], c->fold_dtrk, c->d_dzci, c->step_xskip ? 1 : 0);
+    const bool no_halo_before = c->bc_no_halo;
+    c->bc_no_halo = no_halo_before || local_rows;
     const int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 1, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W]);
-    c->defer_halo = false;
     const bool rode = !c->fl.unmerged_bc && c->bc_nride == 0; c->bc_nride = 0;
-    if (e) { c->deferred.clear(); c->deferred_wide.clear(); return e; }
-    if (!rode) { if (int e2 = op_boundp(c, f[CALES_P], 0)) { c->deferred.clear(); c->deferred_wide.clear(); return e2; } }
+    int e2 = 0;
+    if (!e && !rode) e2 = op_boundp(c, f[CALES_P], 0);
+    c->bc_no_halo = no_halo_before;
+    if (e || e2) { c->deferred.clear(); c->deferred_wide.clear(); return e ? e : e2; }
   }
   // sgs-type ghost cells: only the periodic exchange matters (products of ghosts = ghosts of products; the wall ghosts are
   // replaced by the extrapolation rule inside the filters)
