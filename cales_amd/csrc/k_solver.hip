@@ -1259,6 +1259,211 @@ __global__ __launch_bounds__(64 * gt_width(M, NV) / NV, (PER ? 2 : M <= 8 ? 4 : 
     }
   }
 }
+// The same tile PERSISTENT over `tpb` neighbouring tiles of a segment, for nz = 1024 planes in chunks of sixteen (the 1024^3 cavity): the
+// classic form holds one block of 1024 threads and 140 KB of LDS per CU, so the load of a tile, its solve and its store run one after the other (5.6 ms
+// at 1024^3, 0.38 of the HBM peak). Here a block has 512 threads -- at two waves per SIMD the 256 registers a thread may use hold the NEXT tile (sixteen
+// 16-byte loads issued before the solve, in flight while it runs) --, every wave solves TWO columns one after the other (NV = 1: real x modes, one
+// eigenvalue each), and the stores of a tile drain while the next one is filled and solved: every global access is unconditional (full tiles of full
+// chunks only: ndbl a multiple of 16, nz = 1024; everything else keeps the classic form), so the waits are counted. Same arithmetic: the solve below is
+// the text of k_gaussel_tile<16, NV, 0>.
+template <int NV>
+__global__ __launch_bounds__(512, 2) void k_gaussel_tile_p(Geom g, int nz, int ndbl, real lscale, const real *__restrict__ abc,
+                                                           const real *__restrict__ lamx, const real *__restrict__ lamy,
+                                                           real *__restrict__ p, int fixnull, TileMap T, int tpb,
+                                                           const real *__restrict__ ra = nullptr, const real *__restrict__ rb_ = nullptr, const real *__restrict__ rc = nullptr) {
+  extern __shared__ real shz[];
+  constexpr int M = 16, PER = 0, CPW = NV == 1 ? 2 : 1;
+  const int nsys = nz;
+  constexpr int W = gt_width(M, NV), CP = M + 1, P = 64 * CP + 4, NT = 512;
+  static_assert(64 * W / (NV * CPW) == NT, "512 threads: sixteen columns, CPW column sets per wave");
+  const int t = threadIdx.x;
+  const size_t seg = T.blocked ? T.segstride * blockIdx.y : g.ix(0, blockIdx.y + 1, 1);      // doubles from p
+  const size_t kst = T.blocked ? T.kstride : (size_t)g.s12;
+  constexpr bool TL = GT_TL && M == 16;
+  real *tabl = shz + W * P;
+  if (TL) { for (int q = t; q < 64 * M; q += NT) { tabl[q] = abc[q]; tabl[64 * M + q] = abc[128 * M + q]; } }
+  const int tile0 = blockIdx.x * tpb, tend = min(tile0 + tpb, ndbl / W);
+  constexpr int W2 = W / 2, KP2 = NT / W2, NQ2 = 64 * M / KP2;
+  const int xl = 2 * (t % W2), kk = t / W2;
+  real2 vn[NQ2];
+  auto fetch = [&](int tile) {
+    const real *src = p + seg + (size_t)W * tile + xl + (size_t)kk * kst;
+#pragma unroll
+    for (int q = 0; q < NQ2; ++q) vn[q] = *reinterpret_cast<const real2 *>(src + (size_t)(KP2 * q) * kst);
+  };
+  // the diagonal of this lane's chunk (the same for every column and tile; the sub- and the superdiagonal sit in LDS): sixteen values loaded ONCE -- a
+  // global load inside the solve would be waited for behind the prefetched tile (memory operations return in order)
+  real B0r[M];
+#pragma unroll
+  for (int r = 0; r < M; ++r) B0r[r] = abc[64 * M + r * 64 + (t & 63)];
+  if (tile0 < tend) fetch(tile0);
+  // (one tile; the first is peeled off the loop below, which is then entered with the operations in flight that its back edge carries -- a tile's loads
+  //  with the previous tile's stores behind them -- and the compiler's counted waits hold: merged with the prologue's state every wait would be for everything)
+  auto one_tile = [&](const int tile) {
+#pragma unroll
+    for (int q = 0; q < NQ2; ++q) { const int k = kk + KP2 * q; shz[xl * P + k + k / M] = vn[q].x; shz[(xl + 1) * P + k + k / M] = vn[q].y; }
+    // the eigenvalues of this wave's columns BEFORE the next tile's loads go out: a global load inside the solve would be waited for behind them (memory
+    // operations return in order). Padding modes of the last rank of a blocked layout read the table's first entry: their columns are skipped below.
+    // (Loading them with the tile they belong to, one iteration ahead, measured 3 % slower: 13.9 against 13.5 ms per step at 1024^3.)
+    real lamv[CPW]; bool cok[CPW];
+#pragma unroll
+    for (int cc = 0; cc < CPW; ++cc) {
+      const int x = ((t >> 6) * CPW + cc) * NV, d = W * tile + x;
+      int mode = NV == 1 ? d : d >> 1, j = blockIdx.y + 1;
+      cok[cc] = d < ndbl;
+      if (T.blocked) {
+        const int f = d >> 1, mm = f % T.cw, jl = f / T.cw;
+        j = blockIdx.y * T.n2l + jl + 1;
+        mode = NV == 1 ? 2 * (mm + T.mofs) + (d & 1) : mm + T.mofs;
+        cok[cc] = cok[cc] && mm + T.mofs < T.nmode;
+      }
+      lamv[cc] = (lamx[cok[cc] ? mode : 0] + lamy[j - 1]) * lscale;      // (never the z-only sweeps without eigenvalues, T.nolam: the host keeps those on the classic form)
+    }
+    __syncthreads();
+    fetch(min(tile + 1, tend - 1));      // in flight during the solve (the last tile again: unused)
+#pragma unroll
+    for (int cc = 0; cc < CPW; ++cc) {
+      const int x = ((t >> 6) * CPW + cc) * NV, ch = t & 63;
+      const bool colok = cok[cc];
+      if (colok) {
+        const real lam = lamv[cc];
+        const bool nullc = fixnull && lam == 0.;      // singular mode: the member with p(nz) = 0, see k_gaussel_ri
+        real *col = shz + x * P + ch * CP;
+        const int k0 = ch * M;
+        real cp[M - 1], V[M - 1];      // the swept right-hand sides go back to their LDS slots (registers: no spills at 4 waves/SIMD)
+        real cprev = 0., vprev = 0., rprev[NV] = {};
+        // periodic z: the last plane's right-hand side (its row is an identity row of the tile), the closure vector's two entries
+        real pnr[NV] = {}, E[PER ? M - 1 : 1] = {}, eprev = 0.;
+        const real e_first = PER ? -ra[0] : 0., e_last = PER ? -rc[nsys - 1] : 0.;
+        if (PER) {
+    #pragma unroll
+          for (int q = 0; q < NV; ++q) pnr[q] = shz[(x + q) * P + (nz - 1) + (nz - 1) / M];
+        }
+    #pragma unroll
+        for (int r = 0; r < M - 1; ++r) {
+          const int k = k0 + r;
+          const bool pin = !PER && nullc && k == nz - 1, live = k < nsys && !pin;
+          // (every load unconditional, the selection afterwards: a load inside a divergent branch is waited for on the spot -- sixteen serial
+          //  round trips to the table per chunk)
+          const real A0 = TL ? tabl[r * 64 + ch] : abc[r * 64 + ch], C0 = TL ? tabl[64 * M + r * 64 + ch] : abc[128 * M + r * 64 + ch], B0 = B0r[r];
+          const real A = pin ? 0. : A0, C = pin ? 0. : C0, B = pin ? 1. : B0 + (k < nsys ? lam : 0.);
+          const real z = rcp_nr(B - A * cprev + CALES_EPS);
+          cp[r] = C * z; V[r] = (r == 0 ? A : -A * vprev) * z;
+    #pragma unroll
+          for (int q = 0; q < NV; ++q) { const real D0 = col[q * P + r], D = live ? D0 : 0.; rprev[q] = (D - A * rprev[q]) * z; col[q * P + r] = rprev[q]; }
+          if (PER) { const real D2 = (k == 0 ? e_first : 0.) + (k == nsys - 1 ? e_last : 0.); eprev = (D2 - A * eprev) * z; E[r] = eprev; }
+          cprev = cp[r]; vprev = V[r];
+        }
+        // first interior row of the chunk as a function of the separators beside it
+        real Vb = V[M - 2], Wb = cp[M - 2], Rb[NV], Eb = eprev;
+    #pragma unroll
+        for (int q = 0; q < NV; ++q) Rb[q] = rprev[q];
+    #pragma unroll
+        for (int r = M - 3; r >= 0; --r) {
+          Vb = V[r] - cp[r] * Vb; Wb = -cp[r] * Wb;
+    #pragma unroll
+          for (int q = 0; q < NV; ++q) Rb[q] = col[q * P + r] - cp[r] * Rb[q];
+          if (PER) Eb = E[r] - cp[r] * Eb;
+        }
+        const bool last = ch == 63;
+        // (cross-lane reads are issued by all lanes and masked afterwards: a lane switched off by a branch would be read as zero)
+        real Vn = __shfl_down(Vb, 1, 64), Wn = __shfl_down(Wb, 1, 64);
+        if (last) { Vn = 0.; Wn = 0.; }
+        // separator row
+        real al, be, ga, de[NV], de2 = 0.;
+        {
+          const int k = k0 + M - 1, r = M - 1;
+          const bool pin = !PER && nullc && k == nz - 1, live = k < nsys && !pin;
+          const real A0 = TL ? tabl[r * 64 + ch] : abc[r * 64 + ch], C0 = TL ? tabl[64 * M + r * 64 + ch] : abc[128 * M + r * 64 + ch], B0 = B0r[r];
+          const real A = pin ? 0. : A0, C = pin ? 0. : C0, B = pin ? 1. : B0 + (k < nsys ? lam : 0.);
+          al = -A * V[M - 2]; be = B - A * cp[M - 2] - C * Vn; ga = -C * Wn;
+          if (PER) {
+            real En = __shfl_down(Eb, 1, 64);
+            if (last) En = 0.;
+            const real D2 = (k == 0 ? e_first : 0.) + (k == nsys - 1 ? e_last : 0.);
+            de2 = D2 - A * eprev - C * En;
+          }
+    #pragma unroll
+          for (int q = 0; q < NV; ++q) {
+            real Rn = __shfl_down(Rb[q], 1, 64);
+            if (last) Rn = 0.;
+            const real D0 = col[q * P + M - 1], D = live ? D0 : 0.;
+            de[q] = D - A * rprev[q] - C * Rn;
+          }
+        }
+        // parallel cyclic reduction over the 64 separators
+    #pragma unroll
+        for (int h = 1; h < 64; h <<= 1) {
+          const bool lo = ch >= h, hi = ch + h < 64;
+          const real rb = rcp_nr(be);
+          const real rbm = __shfl_up(rb, h, 64), rbp = __shfl_down(rb, h, 64);
+          const real k1 = lo ? al * rbm : 0., k2 = hi ? ga * rbp : 0.;
+          const real alm = __shfl_up(al, h, 64), gam = __shfl_up(ga, h, 64), alp = __shfl_down(al, h, 64), gap = __shfl_down(ga, h, 64);
+          be = be - gam * k1 - alp * k2;
+    #pragma unroll
+          for (int q = 0; q < NV; ++q) de[q] = de[q] - __shfl_up(de[q], h, 64) * k1 - __shfl_down(de[q], h, 64) * k2;
+          if (PER) de2 = de2 - __shfl_up(de2, h, 64) * k1 - __shfl_down(de2, h, 64) * k2;
+          al = -alm * k1; ga = -gap * k2;
+        }
+        const real rb = rcp_nr(be);
+        // periodic z: row n-1 of the system sits in chunk cL at place rL; rows 1 and n-1 of p1 and p2 are fetched from their lanes
+        const int cL = PER ? (nsys - 1) / M : 0, rL = PER ? (nsys - 1) % M : 0;
+        real Es = 0., e1 = 0., eL = 0.;
+        if (PER) {
+          Es = de2 * rb;
+          real sp2 = __shfl_up(Es, 1, 64);
+          if (ch == 0) sp2 = 0.;
+          real xv2 = eprev - V[M - 2] * sp2 - cp[M - 2] * Es;
+          E[M - 2] = xv2;
+    #pragma unroll
+          for (int r = M - 3; r >= 0; --r) { xv2 = E[r] - V[r] * sp2 - cp[r] * xv2; E[r] = xv2; }
+          real mine = Es;
+    #pragma unroll
+          for (int r = 0; r < M - 1; ++r) if (r == rL) mine = E[r];
+          e1 = __shfl(E[0], 0, 64); eL = __shfl(mine, cL, 64);
+        }
+    #pragma unroll
+        for (int q = 0; q < NV; ++q) {
+          const real s = de[q] * rb;
+          real sp = __shfl_up(s, 1, 64);
+          if (ch == 0) sp = 0.;
+          real xv = rprev[q] - V[M - 2] * sp - cp[M - 2] * s;
+          real mine = (rL == M - 2) ? xv : s;
+          col[q * P + M - 2] = xv;
+    #pragma unroll
+          for (int r = M - 3; r >= 0; --r) { xv = col[q * P + r] - V[r] * sp - cp[r] * xv; col[q * P + r] = xv; if (PER && r == rL) mine = xv; }
+          col[q * P + M - 1] = s;
+          if (PER) {
+            const real p11 = __shfl(xv, 0, 64), p1n = __shfl(mine, cL, 64);      // xv: row 1 of the chunk (lane 0: row 1 of the system)
+            const real an = ra[nz - 1], bn = rb_[nz - 1], cn = rc[nz - 1];
+            const real den = (bn + lam) + cn * e1 + an * eL + CALES_EPS;
+            const real pn = nullc ? 0. : ((pnr[q] - cn * p11) - an * p1n) * (1. / den);      // null mode of the triply periodic problem: p(n) = 0
+    #pragma unroll
+            for (int r = 0; r < M - 1; ++r) if (k0 + r < nsys) col[q * P + r] = col[q * P + r] + E[r] * pn;
+            if (k0 + M - 1 < nsys) col[q * P + M - 1] = s + Es * pn;
+            if (ch == nsys / M) col[q * P + nsys % M] = pn;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    {
+      size_t o = seg + (size_t)W * tile + xl + (size_t)kk * kst;
+      int kq = kk;      // (formed again behind an opaque move, as in the classic form: the places of the load phase would otherwise stay alive through the solve)
+      asm volatile("" : "+v"(o), "+v"(kq));
+      const size_t step = (size_t)KP2 * kst;
+#pragma unroll
+      for (int q = 0; q < NQ2; ++q) {
+        const int k = kq + KP2 * q;
+        *reinterpret_cast<real2 *>(p + o) = make_real2(shz[xl * P + k + k / M], shz[(xl + 1) * P + k + k / M]);
+        o += step;
+      }
+    }
+    __syncthreads();      // the tile has left the LDS before the next one is written
+  };
+  if (tile0 < tend) one_tile(tile0);
+  for (int tile = tile0 + 1; tile < tend; ++tile) one_tile(tile);
+}
 template <int M, int NV, int PER = 0>
 static void launch_gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, real lscale, const real *da, const real *db, const real *dc,
                                 real *p, int fixnull, const TileMap &T, real *tab_of_caller = nullptr, bool tab_ready = false) {
@@ -1276,6 +1481,21 @@ static void launch_gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, real l
   LAUNCH(c, (k_gaussel_tile<M, NV, PER>), dim3((ndbl + W - 1) / W, nrow), dim3(64 * W / NV), lds, c->stream, c->g, nz, ndbl, lscale, tab,
                      c->d_lamx, c->d_lamy, p, fixnull, T, da, db, dc);
 }
+// the persistent form (k_gaussel_tile_p): pressure operands only (their table is built once), tiles per block so that ~2048 blocks or more remain
+template <int NV>
+static void launch_gaussel_tile_p(cales_ctx *c, int nz, int ndbl, int nrow, real lscale, const real *da, const real *db, const real *dc, real *p, int fixnull, const TileMap &T) {
+  constexpr int M = 16, W = gt_width(M, NV), lds = W * (64 * (M + 1) + 4) * 8 + (GT_TL ? 2 * 64 * M * 8 : 0);
+  static bool once = false;
+  if (!once) { HIPSOFT(c, hipFuncSetAttribute((const void *)k_gaussel_tile_p<NV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); once = true; }
+  if (!c->d_abct) { const hipError_t e = hipMalloc(&c->d_abct, 2 * 3 * 64 * 16 * sizeof(real)); if (e != hipSuccess) { c->d_abct = nullptr; launch_failed(c, "hipMalloc(tridiagonal coefficient table)", e); return; } }
+  const bool pressure = da == c->d_a;
+  real *tab = c->d_abct + (pressure ? 0 : 3 * 64 * 16);
+  if (!pressure || !c->abct_ready) LAUNCH(c, k_abc_chunked, dim3((64 * M + 255) / 256), dim3(256), 0, c->stream, nz, M, da, db, dc, tab);
+  if (pressure) c->abct_ready = true;
+  const int ntile = ndbl / W;
+  int tpb = 1; while (tpb * 2 <= ntile && tpb < 32 && (long)nrow * ((ntile + 2 * tpb - 1) / (2 * tpb)) >= 2048) tpb *= 2;
+  LAUNCH(c, (k_gaussel_tile_p<NV>), dim3((ntile + tpb - 1) / tpb, nrow), dim3(512), lds, c->stream, c->g, nz, ndbl, lscale, tab, c->d_lamx, c->d_lamy, p, fixnull, T, tpb, da, db, dc);
+}
 // one rank: ndbl doubles of each of the nrow rows; several ranks (T.blocked): nrow = peers, ndbl = 2 cw n2l doubles per plane of a peer block
 template <int NV, int PER = 0>
 static bool gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, real lscale, const real *da, const real *db, const real *dc,
@@ -1284,6 +1504,7 @@ static bool gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, real lscale, 
   if (nz <= 128) launch_gaussel_tile<2, NV, PER>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T, tab, tab_ready);
   else if (nz <= 256) launch_gaussel_tile<4, NV, PER>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T, tab, tab_ready);
   else if (nz <= 512) launch_gaussel_tile<8, NV, PER>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T, tab, tab_ready);
+  else if (!PER && NV == 1 && nz == 1024 && ndbl % 16 == 0 && !T.dud && !T.nolam && !tab) launch_gaussel_tile_p<1>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T);
   else launch_gaussel_tile<16, NV, PER>(c, nz, ndbl, nrow, lscale, da, db, dc, p, fixnull, T, tab, tab_ready);
   return true;
 }

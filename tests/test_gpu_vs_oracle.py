@@ -29,8 +29,9 @@ def _hot(case):
                                      # deep z: the in-LDS tridiagonal tile with 2, 4, 8, 16 planes per lane, partial last chunks
                                      ("chan_smag", (16, 8, 100)), ("chan_smag", (16, 8, 130)), ("cavity_nnn", (40, 8, 300)),
                                      ("chan_smag", (16, 4, 512)), ("duct_smag_wm", (16, 8, 514)), ("chan_smag", (8, 4, 1024)),
-                                     # 513..1024 planes of real x modes (16 planes per lane, one matrix per column): full, partial and nearly empty last chunks; odd column counts
-                                     ("cavity_nnn", (16, 8, 1024)), ("cavity_nnn", (40, 4, 700)), ("cavity_nnn", (24, 6, 520)), ("devchan_nd", (16, 8, 600)), ("cavity_nnn", (18, 4, 1000)),
+                                     # 513..1024 planes of real x modes (16 planes per lane, one matrix per column): full, partial and nearly empty last chunks; odd column counts;
+                                     # 1024 planes in whole 16-column tiles take the persistent form (k_gaussel_tile_p): one tile per block, and two (64 x 1024 x 1024)
+                                     ("cavity_nnn", (16, 8, 1024)), ("cavity_nnn", (64, 4, 1024)), ("cavity_nnn", (64, 1024, 1024)), ("cavity_nnn", (40, 4, 700)), ("cavity_nnn", (24, 6, 520)), ("devchan_nd", (16, 8, 600)), ("cavity_nnn", (18, 4, 1000)),
                                      # periodic y lines of 16 ... 512 points: every first radix of the register-ended transform (8-2, 8-4, 8-8, 2-8-8, 4-8-8, 8-8-8)
                                      ("chan_smag", (16, 16, 6)), ("chan_smag", (16, 32, 6)), ("tgv_ppp", (16, 64, 8)), ("chan_smag", (16, 256, 4)), ("tgv_ppp", (32, 512, 4))])
 def test_poisson_solve(name, ng):
