@@ -1265,7 +1265,9 @@ __global__ __launch_bounds__(64 * gt_width(M, NV) / NV, (PER ? 2 : M <= 8 ? 4 : 
 // 16-byte loads issued before the solve, in flight while it runs) --, every wave solves TWO columns one after the other (NV = 1: real x modes, one
 // eigenvalue each), and the stores of a tile drain while the next one is filled and solved: every global access is unconditional (full tiles of full
 // chunks only: ndbl a multiple of 16, nz = 1024; everything else keeps the classic form), so the waits are counted. Same arithmetic: the solve below is
-// the text of k_gaussel_tile<16, NV, 0>.
+// the text of k_gaussel_tile<16, NV, 0>. (The same form for 512 planes of complex modes -- eight planes per lane, 256 threads, two blocks per CU, all three
+// diagonals in registers, the two columns left over by the whole tiles in a classic launch -- was built and measured at 512^3: 1.65 against 1.68 ms per
+// step. Two classic blocks per CU already overlap each other's phases as well; not kept.)
 template <int NV>
 __global__ __launch_bounds__(512, 2) void k_gaussel_tile_p(Geom g, int nz, int ndbl, real lscale, const real *__restrict__ abc,
                                                            const real *__restrict__ lamx, const real *__restrict__ lamy,

@@ -26,9 +26,10 @@ def _hot(case):
                                      ("chan_smag", (28, 22, 10)), ("cavity_nnn", (52, 14, 8)), ("duct_smag_wm", (44, 26, 12)),
                                      # other prime factors (17, 19, 23, 37): run-time radix stage
                                      ("chan_smag", (34, 38, 10)), ("cavity_nnn", (46, 74, 8)), ("duct_smag_wm", (38, 34, 12)),
-                                     # deep z: the in-LDS tridiagonal tile with 2, 4, 8, 16 planes per lane, partial last chunks
+                                     # deep z: the in-LDS tridiagonal tile with 2, 4, 8, 16 planes per lane, partial last chunks; 512 planes of 129 / 513 complex modes: the persistent
+                                     # form on the whole tiles, the classic one on the two columns left over
                                      ("chan_smag", (16, 8, 100)), ("chan_smag", (16, 8, 130)), ("cavity_nnn", (40, 8, 300)),
-                                     ("chan_smag", (16, 4, 512)), ("duct_smag_wm", (16, 8, 514)), ("chan_smag", (8, 4, 1024)),
+                                     ("chan_smag", (16, 4, 512)), ("chan_smag", (256, 8, 512)), ("chan_smag", (1024, 4, 512)), ("duct_smag_wm", (16, 8, 514)), ("chan_smag", (8, 4, 1024)),
                                      # 513..1024 planes of real x modes (16 planes per lane, one matrix per column): full, partial and nearly empty last chunks; odd column counts;
                                      # 1024 planes in whole 16-column tiles take the persistent form (k_gaussel_tile_p): one tile per block, and two (64 x 1024 x 1024)
                                      ("cavity_nnn", (16, 8, 1024)), ("cavity_nnn", (64, 4, 1024)), ("cavity_nnn", (64, 1024, 1024)), ("cavity_nnn", (40, 4, 700)), ("cavity_nnn", (24, 6, 520)), ("devchan_nd", (16, 8, 600)), ("cavity_nnn", (18, 4, 1000)),
