@@ -66,7 +66,12 @@ SLAB_CASES = [("chan_smag_wm", (32, 24, 16), 2), ("chan_smag_wm", (32, 24, 16), 
                                        # 3-D implicit diffusion with no-slip walls in x and y (wall-normal DST-I in the slab and in the mode-block layout)
                                        ("cavity_imp3d", (32, 24, 12), 2), ("cavity_imp3d", (20, 36, 10), 4),
                                        # ... and with open boundaries: inflow / outflow along x (RODFT01/10 in the slab) and along y (in the mode-block layout)
-                                       ("devchan_imp3d", (32, 24, 12), 3), ("openy_imp3d", (16, 24, 12), 2), ("openy_imp3d", (20, 36, 10), 4)]
+                                       ("devchan_imp3d", (32, 24, 12), 3), ("openy_imp3d", (16, 24, 12), 2), ("openy_imp3d", (20, 36, 10), 4),
+                                       # 256-, 512- and 1024-point y lines in the mode-block layout: eight columns per block, sixteen elements per thread (k_fft_y16:
+                                       # Neumann 256 / 512 / 1024, periodic 1024), ranks whose mode columns are not a multiple of eight; 1024 planes of real x modes on
+                                       # slabs: the persistent z tile (k_gaussel_tile_p) on the blocks of a peer segment
+                                       ("cavity_nnn", (32, 1024, 12), 4), ("cavity_nnn", (48, 512, 10), 2), ("cavity_nnn", (64, 256, 12), 8), ("chan_smag", (32, 1024, 8), 2),
+                                       ("cavity_nnn", (32, 16, 1024), 2)]
 
 
 @pytest.mark.parametrize("name,ng,P", SLAB_CASES)
