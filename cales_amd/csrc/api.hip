@@ -64,14 +64,15 @@ static int field_alloc(cales_ctx *c, real **p) {
   return 0;
 }
 static void field_free(cales_ctx *c, real *p) { if (p) hipFree(p - c->field_ofs); }
-// two fields in ONE allocation, the second right behind the first: a kernel that addresses the first with 32-bit byte offsets reaches the second with the
-// constant c->pp_companion_bytes added (the correction pressure and its companion scratch field, k_corr_strain_tile on several slabs)
-static int field_alloc_pair(cales_ctx *c, real **p, real **q) {
+// k fields in ONE allocation, each right behind the one before: a kernel that addresses the first with 32-bit byte offsets reaches the others with
+// multiples of the constant c->pp_companion_bytes added (the correction pressure and its companions, the velocity and its companion: the second /
+// third ghost rows of k_corr_strain_tile on several slabs). p[0] is what field_free takes.
+static int field_alloc_multi(cales_ctx *c, int k, real **p) {
   real *base = nullptr;
   const size_t one = c->ntot + LINE_REALS;
-  if (dev_alloc(c, &base, 2 * one)) return 1;
-  *p = base + c->field_ofs; *q = base + one + c->field_ofs;
-  c->pp_companion_bytes = one * sizeof(real);
+  if (dev_alloc(c, &base, (size_t)k * one)) return 1;
+  for (int q = 0; q < k; ++q) p[q] = base + (size_t)q * one + c->field_ofs;
+  c->pp_companion_bytes = one * sizeof(real); c->comp_one = one;
   return 0;
 }
 // host layout (0:n1+1,0:n2+1,0:n3+1), x contiguous  <->  device layout with row pitch s1
@@ -231,9 +232,19 @@ int cales_create(const cales_case *cs, void *stream, cales_ctx **out) {
     if (upload_vec(c, &c->rhsbp[0], rx) || upload_vec(c, &c->rhsbp[1], ry) || upload_vec(c, &c->rhsbp[2], rz)) return fail(7); }
   // fields (haloed); r.h.s. buffers use the same layout so every kernel shares one index
   const int nfields = cs->impdiff ? CALES_NFIELDS : CALES_DUDTD;
-  for (int q = 0; q < nfields; ++q) if (q != CALES_PP && field_alloc(c, &c->f[q])) return fail(8);
-  if (field_alloc(c, &c->scr1) || field_alloc_pair(c, &c->f[CALES_PP], &c->scr2)) return fail(9);      // (scr2 lives in pp's allocation: freed with it)
-  for (int q = 0; q < 3; ++q) if (field_alloc(c, &c->f2[q])) return fail(9);
+  // several slabs with the dynamic model: companions behind u, v, w (both buffer sets) and two behind pp (common.hpp, vel_comp)
+  c->vel_comp = P > 1 && cs->sgstype == 2;
+  for (int q = 0; q < nfields; ++q) {
+    if (q == CALES_PP) continue;
+    if (c->vel_comp && q <= CALES_W) { real *two[2]; if (field_alloc_multi(c, 2, two)) return fail(8); c->f[q] = two[0]; }
+    else if (field_alloc(c, &c->f[q])) return fail(8);
+  }
+  { real *three[3]; if (field_alloc(c, &c->scr1) || field_alloc_multi(c, c->vel_comp ? 3 : 2, three)) return fail(9);      // (scr2, scr3 live in pp's allocation: freed with it)
+    c->f[CALES_PP] = three[0]; c->scr2 = three[1]; c->scr3 = c->vel_comp ? three[2] : nullptr; }
+  for (int q = 0; q < 3; ++q) {
+    if (c->vel_comp) { real *two[2]; if (field_alloc_multi(c, 2, two)) return fail(9); c->f2[q] = two[0]; }
+    else if (field_alloc(c, &c->f2[q])) return fail(9);
+  }
   c->red_blocks = 8;
   if (dev_alloc(c, &c->d_red, 64 + 16 * (size_t)(n3 + 2) + 6 * (size_t)(n3 + 2)) || dev_alloc(c, &c->d_force, 8)) return fail(10);
   c->res = c->d_red;
@@ -476,7 +487,9 @@ static void make_plan(cales_ctx *c) {
     pl.fold_correc = pl.fold_correc && (perz || walls);
     // several slabs: the pass reaches the companion field of pp with 32-bit offsets (two fields under 4 GB), exchanges through the slab hooks
     // (at least two rows per slab: row 2 goes to the companion field BEFORE the exchange, and with one row per slab "row 2" is the stale ghost row n2+1)
-    if (c->P > 1) pl.fold_correc = pl.fold_correc && c->comm.on && c->n[1] >= 2 && 2 * (c->ntot + 2 * LINE_REALS) * sizeof(real) < (1ull << 32); }
+    if (c->P > 1) pl.fold_correc = pl.fold_correc && c->comm.on && c->n[1] >= 2 && 2 * (c->ntot + 2 * LINE_REALS) * sizeof(real) < (1ull << 32);
+    // ... with a second ghost row of the prediction and a third of pp (companion fields) the pass forms the ghost rows of all its outputs itself
+    pl.fold_rows2 = pl.fold_correc && c->P > 1 && c->vel_comp && c->n[1] >= 4 && 3 * (c->ntot + 2 * LINE_REALS) * sizeof(real) < (1ull << 32) && !fl.unmerged_bc; }
   // no subgrid model, explicit or z-implicit diffusion, no wall model, every direction periodic or between walls with homogeneous Neumann pressure
   // (Taylor-Green, channels, cavities without a model): the projection and pressure update of substeps 1 and 2 are applied by the momentum pass of the
   // NEXT substep while it loads its planes (k_momrk<.., CORR = 1>) -- between the two the fields hold the prediction, whose ghost cells receive the
@@ -524,7 +537,7 @@ int cales_describe_plan(cales_ctx *c, char *buf, int buflen) {
   if (!c || !buf || buflen < 1) return 1;
   const StepPlan &pl = current_plan(c);      // (reads no field: a pending projection stays pending)
   std::string s;
-  s += std::string("projection=") + (pl.fold_correc ? "in_strain_rate_pass" : pl.fold_mom ? (pl.lazy_last ? "in_next_momentum_pass(all_substeps)" : "in_next_momentum_pass(substeps_1_2)") : (pl.fuse_cu ? "own_pass(correc+updatep)" : "own_passes"));
+  s += std::string("projection=") + (pl.fold_rows2 ? "in_strain_rate_pass(ghost_rows_local)" : pl.fold_correc ? "in_strain_rate_pass" : pl.fold_mom ? (pl.lazy_last ? "in_next_momentum_pass(all_substeps)" : "in_next_momentum_pass(substeps_1_2)") : (pl.fuse_cu ? "own_pass(correc+updatep)" : "own_passes"));
   s += std::string(";x_ghost_columns=") + (pl.xskip ? "wrapped" : "maintained");
   s += std::string(";fillps=") + (pl.fuse_fill ? "in_x_transform" : "own_pass");
   s += std::string(";bulk_forcing=") + (pl.force_mask == 0 ? "none" : pl.defer_imp_rhs ? "in_helmholtz_sweep" : pl.defer_force ? (pl.mean_mask ? "in_correction(means_in_x_transform)" : "in_correction(means_own_pass)") : "own_pass");
@@ -559,7 +572,7 @@ static int step_body(cales_ctx *c, real dt) {
   const bool pending_in = c->fold_mom_dtrk != 0.;      // the step before left its last projection to this step's first momentum pass
   LAUNCH(c, k_zero6, dim3(1), dim3(64), 0, c->stream, c->d_force, pending_in ? 3 : 0);     // dpdl(:) = 0
   c->in_step = true;
-  struct Reset { cales_ctx *c; bool keep = false; ~Reset() { c->in_step = false; c->step_xskip = false; c->bc_nride = 0; c->fold_dtrk = 0.; if (!keep) { c->fold_mom_dtrk = 0.; c->fold_mom_pdone = false; } c->bc_view_dtrk = 0.; c->defer_force = false; c->defer_imp_rhs = false; c->fuse_fillps_dti = 0.; c->fuse_mean_mask = 0; c->bc_skip_wm = false; c->skip_rhs_store = false; } } reset{c};      // also on the error returns
+  struct Reset { cales_ctx *c; bool keep = false; ~Reset() { c->in_step = false; c->step_xskip = false; c->bc_nride = 0; c->fold_dtrk = 0.; c->fold_rows2 = false; if (!keep) { c->fold_mom_dtrk = 0.; c->fold_mom_pdone = false; } c->bc_view_dtrk = 0.; c->defer_force = false; c->defer_imp_rhs = false; c->fuse_fillps_dti = 0.; c->fuse_mean_mask = 0; c->bc_skip_wm = false; c->skip_rhs_store = false; c->defer_halo = false; c->bc_no_halo = false; } } reset{c};      // also on the error returns
   if (c->pend_xrefresh && !pl.xskip) {      // the step before left the x ghost columns stale and this one reads them
     c->pend_xrefresh = false; c->step_xskip = true;
     if (int e = end_of_step_refresh(c)) return e;
@@ -585,7 +598,14 @@ static int step_body(cales_ctx *c, real dt) {
     c->defer_imp_rhs = false;
     if (p_ghosts_due && !c->fl.unmerged_bc) { c->bc_nride = 1; c->bc_ride[0] = c->f[CALES_P]; c->bc_ride_which[0] = 0; }
     { c->bc_skip_wm = pl.skip_first_wm;
-      const int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 0, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W]);
+      // (two ghost rows of the prediction, fold_rows2: the rows 2 / n2-1 travel to the neighbours' companion fields in the same message as the rows 1 / n2)
+      c->defer_halo = pl.fold_rows2;
+      int e = op_bounduvw(c, c->bcu, c->bcv, c->bcw, 1, 0, c->f[CALES_U], c->f[CALES_V], c->f[CALES_W]);
+      if (pl.fold_rows2) {
+        if (!e) e = halo_y_rows(c, 3, c->f + CALES_U, 2);
+        c->defer_halo = false;
+        if (!e) e = halo_flush_deferred(c, false); else { c->deferred.clear(); c->deferred_wide.clear(); }
+      }
       c->bc_skip_wm = false;
       const bool rode = p_ghosts_due && !c->fl.unmerged_bc && c->bc_nride == 0; c->bc_nride = 0;
       if (e) return e;
@@ -593,6 +613,18 @@ static int step_body(cales_ctx *c, real dt) {
     if (pl.fuse_fill) c->fuse_fillps_dti = dtrki;
     else { if (int e = op_fillps(c, dtrki)) return e; if (int e = op_updt_rhs_b(c)) return e; }
     { const int e = op_solver(c); c->fuse_fillps_dti = 0.; if (e) return e; }
+    if (pl.fold_rows2) {
+      // three ghost rows of pp above (n2+1, and n2+2, n2+3 in the ghost rows n2+1 of its two companions), two below (0, and -1 in the first companion's row 0):
+      // ONE exchange, behind the ghost-cell kernel (the rows that travel carry their x and z ghost cells)
+      c->defer_halo = true;
+      real *one[1] = {c->f[CALES_PP]};
+      int e = op_boundp(c, c->f[CALES_PP], 0);
+      if (!e) e = halo_y_rows(c, 1, one, 2);
+      if (!e) e = halo_y_rows(c, 1, one, 3);
+      c->defer_halo = false;
+      if (!e) e = halo_flush_deferred(c, false); else { c->deferred.clear(); c->deferred_wide.clear(); }      // (whole rows travel: the x and z ghost cells the kernel above gave them included)
+      if (e) return e;
+    } else
     if (pl.fold_correc && c->P > 1) {
       // the folded projection corrects v in the ghost row n2+1 too and needs pp one row further out: row 2 of every slab goes to row 1 of pp's companion
       // field and both fields take the ghost-cell update -- ONE exchange; the upper neighbour's row 2 arrives in the companion's ghost row n2+1
@@ -601,7 +633,7 @@ static int step_body(cales_ctx *c, real dt) {
       if (int e = op_boundp_multi(c, 2, two, 0)) return e;
     } else
     if (int e = op_boundp(c, c->f[CALES_PP], 0)) return e;
-    if (pl.fold_correc) c->fold_dtrk = dtrk;      // correc, bounduvw, updatep, boundp(p): inside the cmpt_sgs below (dsmag_fast)
+    if (pl.fold_correc) { c->fold_dtrk = dtrk; c->fold_rows2 = pl.fold_rows2; }      // correc, bounduvw, updatep, boundp(p): inside the cmpt_sgs below (dsmag_fast)
     else if (pl.fold_mom && (irk < 3 || pl.lazy_last)) {
       // the ghost cells of the projected velocity now (through the corrected view), its interior cells and p + pp in the next momentum pass -- the next
       // substep's, or after the third substep the next step's (finish_pending for every other entry of the C-ABI)
@@ -619,7 +651,7 @@ static int step_body(cales_ctx *c, real dt) {
       c->fold_mom_dtrk = dtrk;
     } else if (int e = project_now(c, dtrk, alpha)) return e;
     c->visct_bc_done = false;
-    { const int e = op_cmpt_sgs(c); c->fold_dtrk = 0.; c->defer_force = false; if (e) return e; }
+    { const int e = op_cmpt_sgs(c); c->fold_dtrk = 0.; c->fold_rows2 = false; c->defer_force = false; if (e) return e; }
     if (pl.visct_ghosts && !c->visct_bc_done) { if (int e = op_boundp(c, c->f[CALES_VISCT], 1)) return e; }
     c->visct_bc_done = false;
   }

@@ -124,6 +124,8 @@ struct StepPlan {
   bool in_visct_zero = false, in_sgs_first = false, in_comm_on = false, in_overlap = false;      // the state the plan was made from
   bool xskip = false;            // periodic x: the step's kernels wrap around, the x ghost columns are left alone until somebody else reads them
   bool fold_correc = false;      // dynamic model: projection + pressure update inside the strain-rate pass of the substep's cmpt_sgs (k_corr_strain_tile)
+  bool fold_rows2 = false;       // ... on several slabs with TWO ghost rows of the prediction (three of pp): the pass also forms the ghost rows of everything it writes,
+                                 // so no row of u, v, w, p, |S|, |S|Sij, the filtered velocity or v_c travels after it (27 field planes per step instead of 48)
   bool fold_mom = false;         // no subgrid model: projection of substeps 1, 2 (and 3: lazy_last) inside the NEXT momentum pass (k_momrk<CORR>)
   bool lazy_last = false;        // ... the third substep's projection stays pending across the return of cales_step (one rank only)
   bool defer_imp_rhs = false;    // z-implicit: the Helmholtz sweeps form their r.h.s. (implicit part of rk, forcing, boundary terms) while loading
@@ -230,7 +232,7 @@ struct cales_ctx {
   bool step_xskip = false;
   // cales_step, dynamic model on one rank with x and y periodic: the velocity correction and the pressure update of the substep are done by the
   // strain-rate pass of the cmpt_sgs that follows (k_strain_tile<.., CORR = 1>, k_sgs.hip) -- != 0: the dtrk of the pending projection
-  real fold_dtrk = 0.;
+  real fold_dtrk = 0.; bool fold_rows2 = false;      // (fold_rows2: with two ghost rows of the prediction, StepPlan)
   // cales_step without subgrid model (explicit diffusion, one rank, every direction periodic or between no-slip walls with Neumann pressure): the
   // projection of substeps 1 and 2 is applied by the momentum pass of the NEXT substep while it loads its planes (k_momrk<.., CORR = 1>); the ghost
   // cells of the prediction receive their final values through a corrected view in the ghost-cell kernels (bc_view_dtrk). != 0: the dtrk of the
@@ -245,7 +247,11 @@ struct cales_ctx {
   // brings them up to date first (finish_pending; local copies, no exchange: safe on several slabs) -- the refresh is 0.2 ms of strided accesses at 512^3
   bool pend_xrefresh = false;
   real bc_view_dtrk = 0.;      // op_bounduvw: sources are read as (u* + f) - dtrk grad(pp) wherever they are interior cells
-  size_t pp_companion_bytes = 0;      // scr2 sits this many bytes behind CALES_PP in one allocation (api.hip field_alloc_pair)
+  size_t pp_companion_bytes = 0;      // scr2 sits this many bytes behind CALES_PP in one allocation (api.hip field_alloc_multi)
+  // several slabs with the dynamic model: u, v, w (both buffer sets) and pp carry COMPANION fields right behind them in their allocations (the same
+  // distance for all: comp_one reals) -- the second ghost rows of the folded strain-rate pass (rows -1 and n2+2 in the companion's ghost rows 0 and
+  // n2+1; pp a second companion for row n2+3), exchanged from the rows 2 / n2-1 (3) of the neighbours (k_bound.hip, halo kinds 2 and 3)
+  bool vel_comp = false; size_t comp_one = 0; real *scr3 = nullptr;
   int field_ofs = 0;       // doubles between a field's allocation and its element (0,0,0)
   real *d_nullw = nullptr; // work space of k_null_column (CALES_KEEP_NULL_MODE)
 };
@@ -318,6 +324,7 @@ int op_bounduvw(cales_ctx *c, DBound &bu, DBound &bv, DBound &bw, int is_updt_wm
 int op_boundp(cales_ctx *c, real *p, int which);
 int op_boundp_multi(cales_ctx *c, int nf, real **p, int which);
 int halo_flush_deferred(cales_ctx *c, bool overlapped = true);
+int halo_y_rows(cales_ctx *c, int nf, real **flds, int kind);      // kind 2 / 3: rows 2, n2-1 (3, n2-2) of the neighbours into the ghost rows of the fields' first (second) companions
 int op_mom(cales_ctx *c);
 int op_rk(cales_ctx *c, int irk, real dt);
 int op_rk_par(cales_ctx *c, real rkpar1, real rkpar2, real dt);

@@ -253,7 +253,7 @@ static bool merged_ok(const cales_ctx *c, const char *cbx, const char *cby) {
 
 // y-slab neighbours (bound.f90:619-696 for idir = 2): pack the first/last interior rows of nf fields into the
 // staging buffer A, let the host exchange them, unpack into the ghost rows. Planes include the x/z ghosts.
-struct HaloFields { int nf; real *p[16]; unsigned char wide[16]; int off[16]; unsigned char vcomp[16]; CorrView V; };      // vcomp != 0: the rows that leave are read through the corrected view      // wide: a pair field (rows twice as long); off: first staging plane of the field, in planes of s1 (n3+2) values
+struct HaloFields { int nf; real *p[16]; unsigned char wide[16]; int off[16]; unsigned char vcomp[16]; unsigned char rofs[16]; real *dst[16]; CorrView V; };      // rofs / dst: rows 1 + rofs and n2 - rofs leave, into the ghost rows of dst (a companion field; rofs = 0: the field itself)      // vcomp != 0: the rows that leave are read through the corrected view      // wide: a pair field (rows twice as long); off: first staging plane of the field, in planes of s1 (n3+2) values
 // x ghost columns of the two z ghost planes, rows 0..n2+1: the corners the velocity update after the projection leaves alone (bounduvw with
 // is_correc does not touch the z ghost planes of w, and the periodic copies of the step's earlier calls were skipped: cales_step, step_xskip)
 __global__ __launch_bounds__(256) void k_xwrap_zghost(Geom g, HaloFields H) {
@@ -268,15 +268,15 @@ __global__ __launch_bounds__(256) void k_pack_y(Geom g, HaloFields H, real *__re
   const size_t s1 = (size_t)g.s1 << w, s12 = (size_t)g.s12 << w;
   const size_t q = (size_t)i + s1 * k + (size_t)g.s1 * (g.n3 + 2) * H.off[f];
   if (H.vcomp[f]) { lo[q] = view_rd(g, H.V, H.vcomp[f], H.p[f], i, 1, k); hi[q] = view_rd(g, H.V, H.vcomp[f], H.p[f], i, g.n2, k); return; }      // (never a pair field)
-  lo[q] = H.p[f][i + s1 * 1 + s12 * k]; hi[q] = H.p[f][i + s1 * g.n2 + s12 * k];
+  lo[q] = H.p[f][i + s1 * (1 + H.rofs[f]) + s12 * k]; hi[q] = H.p[f][i + s1 * (g.n2 - H.rofs[f]) + s12 * k];
 }
 __global__ __launch_bounds__(256) void k_unpack_y(Geom g, HaloFields H, const real *__restrict__ lo, const real *__restrict__ hi, int has_lo, int has_hi) {
   const int i = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y * 4 + threadIdx.y, f = blockIdx.z, w = H.wide[f];
   if (i >= (g.n1 + 2) << w || k > g.n3 + 1) return;
   const size_t s1 = (size_t)g.s1 << w, s12 = (size_t)g.s12 << w;
   const size_t q = (size_t)i + s1 * k + (size_t)g.s1 * (g.n3 + 2) * H.off[f];
-  if (has_lo) H.p[f][i + s12 * k] = lo[q];
-  if (has_hi) H.p[f][i + s1 * (g.n2 + 1) + s12 * k] = hi[q];
+  if (has_lo) H.dst[f][i + s12 * k] = lo[q];
+  if (has_hi) H.dst[f][i + s1 * (g.n2 + 1) + s12 * k] = hi[q];
 }
 // A field of PAIRS (two values per cell, k_sgs.hip dsmag_pairs) is, for every operation that copies whole rows or planes, a field of twice the width:
 // 2 (n1 + 2) values per row, pitches doubled. Its x ghost "columns" mean nothing in that view -- the callers skip direction x.
@@ -285,10 +285,15 @@ static Geom wide_geom(const cales_ctx *c) { Geom g = c->g; g.n1 = 2 * c->g.n1 + 
 static int halo_y_on(cales_ctx *c, int nf, real **flds, hipStream_t st, bool overlapped, const unsigned char *wide = nullptr) {
   const Geom &G = c->g;
   HaloFields H; H.nf = nf; int planes = 0, anyw = 0;
-  for (int q = 0; q < nf; ++q) { H.p[q] = flds[q]; H.wide[q] = wide ? wide[q] : 0; H.off[q] = planes; planes += 1 + H.wide[q]; anyw |= H.wide[q]; H.vcomp[q] = 0; }
+  // (wide[q]: 0 a field, 1 a pair field, 2 / 3 the second / third rows of a field into its first / second companion)
+  for (int q = 0; q < nf; ++q) {
+    const int kind = wide ? wide[q] : 0;
+    H.p[q] = flds[q]; H.wide[q] = kind == 1; H.off[q] = planes; planes += 1 + H.wide[q]; anyw |= H.wide[q]; H.vcomp[q] = 0;
+    H.rofs[q] = kind >= 2 ? (unsigned char)(kind - 1) : 0; H.dst[q] = kind >= 2 ? flds[q] + (size_t)(kind - 1) * c->comp_one : flds[q];
+  }
   if (c->bc_view_dtrk != 0.) {      // op_bounduvw through the corrected view: the velocity rows that leave are those of the projected velocity
     H.V = corr_view(c);
-    for (int q = 0; q < nf; ++q) for (int iv = 0; iv < 3; ++iv) if (flds[q] == c->f[CALES_U + iv]) H.vcomp[q] = (unsigned char)(iv + 1);
+    for (int q = 0; q < nf; ++q) for (int iv = 0; iv < 3; ++iv) if (flds[q] == c->f[CALES_U + iv] && !H.rofs[q]) H.vcomp[q] = (unsigned char)(iv + 1);
   }
   const int64_t cnt = (int64_t)G.s1 * (c->n[2] + 2) * planes;
   if (4 * cnt > c->comm.nbuf) { c->err = "halo staging buffer too small"; return 1; }
@@ -301,6 +306,13 @@ static int halo_y_on(cales_ctx *c, int nf, real **flds, hipStream_t st, bool ove
   LAUNCH(c, k_unpack_y, gr, b, 0, st, G, H, c->comm.B, c->comm.B + cnt, has_lo, has_hi);
   LAUNCHCHK(c);
   return 0;
+}
+int halo_y_rows(cales_ctx *c, int nf, real **flds, int kind) {
+  if (!c->comm.on) { c->err = "nranks > 1 but no communication hooks registered (cales_set_comm)"; return 1; }
+  if (!c->comp_one || kind < 2 || kind > 3) { c->err = "halo_y_rows: no companion fields"; return 1; }
+  if (c->defer_halo) { for (int q = 0; q < nf; ++q) { c->deferred.push_back(flds[q]); c->deferred_wide.push_back((unsigned char)kind); } return 0; }
+  unsigned char w[16]; for (int q = 0; q < nf && q < 16; ++q) w[q] = (unsigned char)kind;
+  return halo_y_on(c, nf, flds, c->stream, false, w);
 }
 static int halo_y_comm(cales_ctx *c, int nf, real **flds, bool wide = false) {
   if (!c->comm.on) { c->err = "nranks > 1 but no communication hooks registered (cales_set_comm)"; return 1; }
@@ -319,7 +331,7 @@ int halo_flush_deferred(cales_ctx *c, bool overlapped) {
   if (overlapped) { if (int e = stream_after(c, c->comm_stream, c->stream)) return e; }
   for (size_t q0 = 0; q0 < c->deferred.size();) {      // as many fields per exchange as the staging buffers hold: sixteen planes, a pair field takes two
     int nf = 0, planes = 0;
-    while (q0 + nf < c->deferred.size() && nf < 16 && planes + 1 + c->deferred_wide[q0 + nf] <= 16) { planes += 1 + c->deferred_wide[q0 + nf]; ++nf; }
+    while (q0 + nf < c->deferred.size() && nf < 16 && planes + 1 + (c->deferred_wide[q0 + nf] == 1) <= 16) { planes += 1 + (c->deferred_wide[q0 + nf] == 1); ++nf; }
     if (int e = halo_y_on(c, nf, c->deferred.data() + q0, overlapped ? c->comm_stream : c->stream, overlapped, c->deferred_wide.data() + q0)) { c->deferred.clear(); c->deferred_wide.clear(); return e; }
     q0 += nf;
   }

@@ -590,6 +590,7 @@ struct StrainTileArgs {
   // boundary rule (bounduvw with is_correc, bound.f90:18-154), the corrected velocity of the tile's own cells goes to un[] (a second set of buffers:
   // neighbouring tiles still read u*) and p += pp in place. The pass k_correc_cell<1> (9 words per cell) disappears: 13 + 9 -> 19 words.
   const real *pp; real *p; real *un[3]; const real *force; int fmask; real cfi, cfj, cdt;
+  real *vcg = nullptr;      // EXT = 1: the field whose ghost rows 0 and n2+1 receive v_c (LijMijArgs::vcg)
   const real *bcz[2][2];      // Dirichlet planes of u and v at the two z walls (bounduvw's 2 bc - u(1)), [component][side]
   int zper;                   // z periodic: ghost planes are the wrapped interior planes
   // several slabs (pery = 0): the ghost rows 0 and n2+1 of u*, v*, w* and pp hold the neighbours' rows (exchanged), and the one value further out that the
@@ -748,7 +749,11 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_strain_tile(Geom g, StrainTil
 // stores of plane k) instead of s_waitcnt vmcnt(0) at every use. A plane is completed ONE iteration after its loads were issued. The two y-halo
 // waves have no outputs: they run a loop of their own and complete the tile's two x-halo COLUMNS, one tile row per lane (wave 0 the column left of the
 // tile, wave TY+1 the one right of it), which as a branch of the edge lanes ran in every one of the sixteen waves.
-template <typename OFF, int TY>
+// EXT = 1 (several slabs, StepPlan::fold_rows2): the tile rows start one row lower and the pass ALSO forms the two ghost rows j = 0 and n2+1 of everything
+// it writes -- corrected u, v, w, p + pp, |S|, |S|Sij, the filtered velocity, and v_c of those two rows for the last pass (A.vcg) -- from a SECOND ghost
+// row of the prediction (rows -1 / n2+2: the ghost rows 0 / n2+1 of the companion field that sits A.ppd bytes behind every velocity field) and a third of
+// pp (row n2+3: its second companion): nothing this pass produces travels between the slabs afterwards.
+template <typename OFF, int TY, int EXT = 0>
 __global__ __launch_bounds__(64 * (TY + 2)) void k_corr_strain_tile(Geom g, StrainTileArgs A) {
   __shared__ real ring[3][3][TY + 2][66];      // rows: x-halo cell, 64 own cells, x-halo cell
   __shared__ real shs[3][TY + 2][64];
@@ -759,30 +764,37 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_corr_strain_tile(Geom g, Stra
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   if (A.bm.gx && !band_block(A.bm, bx, by, bz)) return;
   const int n1 = g.n1, n2 = g.n2, n3 = g.n3;      // (n1 a multiple of 64: every tile is full in x, dsmag_fast)
-  const int i = bx * 64 + tx + 1, j = by * TY + ty;
+  const int i = bx * 64 + tx + 1, j = by * TY + ty - EXT;
   const int kbeg = bz * A.kchunk + 1, kend = min(kbeg + A.kchunk - 1, n3);
   const bool edge = tx == 0 || tx == 63;
   const int hx = tx == 0 ? 0 : 65;
-  const bool outok = ty >= 1 && ty <= TY && j <= n2;
+  const bool outok = ty >= 1 && ty <= TY && j >= 1 - EXT && j <= n2 + EXT;
   // the rows this thread loads. One slab: wrapped in y (rows beyond n2+1 keep wrapping: row n2+2 holds pp of row 2, which the correction of row n2+1 --
   // the wrapped row 1, the halo of the last row -- reads from sP). Several slabs: the ghost rows as they are, pp of "row n2+2" from the companion field
-  auto urow = [&](int r) { return A.pery ? (r == 0 ? n2 : r > n2 ? min(r - n2, n2) : r) : min(r, n2 + 1); };
-  auto poff = [&](int col, int r) -> OFF {      // byte offset (from pp) of pp(col, r, 0)
-    if (A.pery || r <= n2 + 1) return (OFF)g.ix(col, urow(r), 0) * RSZ;
-    return (OFF)(A.ppd + g.ix(col, n2 + 1, 0) * RSZ);      // (rows beyond n2+2: never used)
+  auto urow = [&](int r) { return A.pery ? (r == 0 ? n2 : r > n2 ? min(r - n2, n2) : r) : min(max(r, 0), n2 + 1); };
+  // byte offset (from its field's base) of cell (col, row r, plane 0) of a field with `nc` companions behind it: several slabs -- the rows 0 .. n2+1 as they
+  // are, row -1 in the first companion's ghost row 0, row n2+1+q (q = 1 .. nc) in companion q's ghost row n2+1 (rows further out: the last of them; the
+  // values only reach tile rows that have no output). nc = 0: clamped to the ghost rows.
+  auto foff = [&](int col, int r, int nc) -> OFF {
+    if (A.pery) return (OFF)g.ix(col, urow(r), 0) * RSZ;
+    if (EXT && r < 0) return (OFF)(A.ppd + g.ix(col, 0, 0) * RSZ);
+    if (r <= n2 + 1 || nc == 0) return (OFF)g.ix(col, min(r, n2 + 1), 0) * RSZ;
+    return (OFF)((size_t)min(r - (n2 + 1), nc) * A.ppd + g.ix(col, n2 + 1, 0) * RSZ);
   };
+  constexpr int NCV = EXT, NCP = 1 + EXT;      // companions of the velocity fields / of pp
   const int jq = urow(j);
   const OFF sk = (OFF)g.s12 * RSZ;
-  const OFF cl = (OFF)g.ix(i, jq, 0) * RSZ, clp = poff(i, j), cly = poff(i, j + 1);
-  const OFF cdump = (OFF)g.ix(0, min(j, n2 + 1), 0) * RSZ;      // the x ghost cell of the row: where lanes / planes without an output of their own store
+  const OFF cl = foff(i, j, NCV), clp = foff(i, j, NCP), cly = foff(i, j + 1, NCP);
+  const OFF cdump = (OFF)g.ix(0, min(max(j, 0), n2 + 1), 0) * RSZ;      // the x ghost cell of the row: where lanes / planes without an output of their own store
   const OFF cst = outok ? cl : cdump;
+  const OFF cvc = (EXT && outok && (j == 0 || j == n2 + 1)) ? cl : cdump;
   // side job of the y-halo waves: lane tx < TY+2 completes the x-halo cell of tile row tx (other lanes repeat their own cell: no branches around loads)
   const bool hwave = ty == 0 || ty == TY + 1;
-  const int sside = ty == 0 ? 0 : 1, hxs = sside ? 65 : 0, si0 = bx * 64 + (sside ? 65 : 0), sj0 = by * TY + tx;
-  const bool sok = hwave && tx < TY + 2 && sj0 <= n2 + 1;
+  const int sside = ty == 0 ? 0 : 1, hxs = sside ? 65 : 0, si0 = bx * 64 + (sside ? 65 : 0), sj0 = by * TY + tx - EXT;
+  const bool sok = hwave && tx < TY + 2 && sj0 <= n2 + 1 + EXT;
   const int si = !sok ? i : si0 == 0 ? n1 : si0 == n1 + 1 ? 1 : si0, sjr = !sok ? jq : urow(sj0), sjx = !sok ? j : sj0;
   const int sxr = si >= n1 ? 1 : si + 1;
-  const OFF so = (OFF)g.ix(si, sjr, 0) * RSZ, sop = poff(si, sjx), soy = poff(si, sjx + 1), sox = poff(sxr, sjx);
+  const OFF so = foff(si, sjx, NCV), sop = foff(si, sjx, NCP), soy = foff(si, sjx + 1, NCP), sox = foff(sxr, sjx, NCP);
   const int srow = sok ? tx : 0;
   auto kz = [&](int kk) { return !A.zper ? kk : kk == 0 ? n3 : kk == n3 + 1 ? 1 : kk; };      // plane that holds the values of plane kk
   const real f0 = (A.fmask & 1) ? ldc(A.force, 0) : 0., f1 = (A.fmask & 2) ? ldc(A.force, 1) : 0., f2 = (A.fmask & 4) ? ldc(A.force, 2) : 0.;
@@ -819,7 +831,7 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_corr_strain_tile(Geom g, Stra
   { // ---- planes kbeg-1 and kbeg complete, plane kbeg+1 in flight (pp's neighbours by direct loads here: sP serves the loop)
     real c1[3], c0v[3], h1[3] = {0., 0., 0.}, h0[3] = {0., 0., 0.};
     const bool low = !A.zper && kbeg == 1;      // plane kbeg-1 is the ghost plane below the lower wall
-    const OFF clx = poff(i >= n1 ? 1 : i + 1, j);
+    const OFF clx = foff(i >= n1 ? 1 : i + 1, j, NCP);
     { const int kq = kz(kbeg); Raw r; rawload(kq, r); const real P0 = ldb(A.pp, clp + (OFF)kq * sk);
       fix(r.q, P0, ldb(A.pp, clx + (OFF)kq * sk), ldb(A.pp, cly + (OFF)kq * sk), r.pz, kq, c1); p0n = r.pz;
       const OFF a = cst + (OFF)kbeg * sk; stb(A.p, a, ldb(A.p, a) + P0);      // p += pp (updatep.f90:30-47, explicit diffusion); lanes without output: their ghost cell
@@ -941,6 +953,9 @@ __global__ __launch_bounds__(64 * (TY + 2)) void k_corr_strain_tile(Geom g, Stra
       __builtin_nontemporal_store(v2{s0v * s33, s0v * s12}, (v2 *)((char *)A.ss2[1] + i2));
       __builtin_nontemporal_store(v2{s0v * s13, s0v * s23}, (v2 *)((char *)A.ss2[2] + i2));
       // (the cell-centred velocity is not stored: the last pass forms it from u, v, w itself -- the only form this pass serves, dsmag_fast)
+      // EXT: v_c of the two ghost rows, which the last pass reads from A.vcg (row 0: its lower neighbour v(-1) is in this tile's ring, nowhere else);
+      // every other row stores to its dump cell -- no branch around the store
+      if (EXT) stb(A.vcg, cvc + (OFF)k * sk, 0.5 * (v_ccc + v_cmc));
     }
     __syncthreads();
     if (!HALO) {
@@ -1169,8 +1184,8 @@ static int dsmag_fast(cales_ctx *c) {
   const int wylo = ISB(c, 0, 2) && c->is_wall[2] != 0., wyhi = ISB(c, 1, 2) && c->is_wall[3] != 0.;
   const int wmylo = ISB(c, 0, 2) && LWM(c, 0, 2) != 0, wmyhi = ISB(c, 1, 2) && LWM(c, 1, 2) != 0;
   // tiles of 62 x TY columns marching in k; k is also split into chunks so that several rounds of blocks balance the chip
-  auto tiles = [&](int ty, int wx, dim3 &mb, dim3 &mg, int &kchunk, int kmax = 1 << 30) {
-    mb = dim3(64, ty + 2, 1); mg = dim3((n[0] + wx - 1) / wx, (n[1] + ty - 1) / ty, 1);
+  auto tiles = [&](int ty, int wx, dim3 &mb, dim3 &mg, int &kchunk, int kmax = 1 << 30, int rows_more = 0) {
+    mb = dim3(64, ty + 2, 1); mg = dim3((n[0] + wx - 1) / wx, (n[1] + rows_more + ty - 1) / ty, 1);
     kchunk = n[2];
     while ((long)mg.x * mg.y * ((n[2] + kchunk - 1) / kchunk) < tile_min_blocks(c) && kchunk > 32) kchunk = (kchunk + 1) / 2;
     // small grids: fewer blocks than one per CU leave most of the chip idle; shorter chunks (their three-plane prologue weighs more) beat that
@@ -1190,9 +1205,10 @@ static int dsmag_fast(cales_ctx *c) {
   // K_AC: |S|, |S|Sij, cell-centred and test-filtered velocity in one pass over u,v,w (no wall-model faces ->
   // extrapolate(...,lwm) is a no-op; u,v are extrapolated through the z walls, w on the faces is not, sgs.f90:705-710)
   const bool fold = c->fold_dtrk != 0. && pair && ucf;      // (cales_step decides; pair fields and the cell-centred velocity formed by the last pass: the instantiation that exists)
+  const bool ext = fold && c->fold_rows2 && c->P > 1;      // ... which also forms the ghost rows of its outputs from two ghost rows of the prediction (StepPlan::fold_rows2)
   if (c->fold_dtrk != 0. && !fold) { c->err = "dsmag: projection folded into the strain-rate pass without pair fields"; return 1; }
   { ProfScope ps(c, fold ? "correc_strain_filter_uvw" : "strain_filter_uvw");
-    tiles(fold ? TYC : TYS, 64, mb, mg, kch);
+    tiles(fold ? TYC : TYS, 64, mb, mg, kch, 1 << 30, ext ? 2 : 0);
     StrainTileArgs S;
     S.u[0] = f[CALES_U]; S.u[1] = f[CALES_V]; S.u[2] = f[CALES_W]; S.s0 = lazy ? visct : c->s0;
     for (int m = 0; m < 6; ++m) S.ssij[m] = ssij[m];
@@ -1209,7 +1225,9 @@ static int dsmag_fast(cales_ctx *c) {
       S.pery = c->P == 1 ? 1 : 0; S.ppd = c->pp_companion_bytes;
       const size_t pl = (size_t)(n[0] + 2) * (n[1] + 2);
       S.bcz[0][0] = c->bcu.z; S.bcz[0][1] = c->bcu.z + pl; S.bcz[1][0] = c->bcv.z; S.bcz[1][1] = c->bcv.z + pl;
-      LAUNCH(c, (k_corr_strain_tile<unsigned, TYC>), mg, mb, 0, c->stream, c->g, S);
+      S.vcg = c->vc;
+      if (ext) LAUNCH(c, (k_corr_strain_tile<unsigned, TYC, 1>), mg, mb, 0, c->stream, c->g, S);
+      else LAUNCH(c, (k_corr_strain_tile<unsigned, TYC>), mg, mb, 0, c->stream, c->g, S);
     } else
     if (wylo || wyhi || wmylo || wmyhi) { if (small) LAUNCH(c, (k_strain_tile<unsigned, TYS, 1>), mg, mb, 0, c->stream, c->g, S); else LAUNCH(c, (k_strain_tile<size_t, TYS, 1>), mg, mb, 0, c->stream, c->g, S); }
     else if (pair) LAUNCH(c, (k_strain_tile<unsigned, TYS, 0, 1>), mg, mb, 0, c->stream, c->g, S);
@@ -1225,7 +1243,7 @@ static int dsmag_fast(cales_ctx *c) {
     // several slabs: the ghost rows of u, v, w and p do not travel at all -- k_fold_ghost_rows forms them from the prediction's ghost rows and pp's,
     // the ghost-cell kernel below gives them their x and z ghost cells (round 5: in the same exchange as the scratch fields', fifteen planes; now eleven)
     const bool local_rows = c->P > 1 && !c->fl.unmerged_bc;
-    if (local_rows)
+    if (local_rows && !ext)      // (ext: the strain-rate pass has formed them itself)
       LAUNCH(c, k_fold_ghost_rows, dim3((n[0] + 63) / 64, (n[2] + 3) / 4, 2), dim3(64, 4), 0, c->stream, c->g, c->f2[0], c->f2[1], c->f2[2], c->f[CALES_U], c->f[CALES_V],
              c->f[CALES_W], f[CALES_PP], c->scr2, f[CALES_P], c->d_force, c->defer_force ? (c->C.is_forced[0] ? 1 : 0) | (c->C.is_forced[1] ? 2 : 0) | (c->C.is_forced[2] ? 4 : 0) : 0,
              c->fold_dtrk * c->dli[0], c->fold_dtrk * c->dli[1], c->fold_dtrk, c->d_dzci, c->step_xskip ? 1 : 0);
@@ -1246,7 +1264,7 @@ static int dsmag_fast(cales_ctx *c) {
   const int perx = (CBP(c, 0, 1) == 'P' && CBP(c, 1, 1) == 'P' && !c->fl.dsmag_xghosts) ? 1 : 0;
   const int skipz = (zlo && zhi) ? 4 : 0;
   // several ranks with the second stream: the y-halo rows of the twelve scratch fields travel while the interior tiles of the last pass run
-  const bool overlap = c->P > 1 && c->comm.halo_s && c->comm_stream;
+  const bool overlap = c->P > 1 && c->comm.halo_s && c->comm_stream && !ext;      // (ext: no row of these fields travels)
   // (every check that can fail comes BEFORE the deferred exchange is queued: an error return behind halo_flush_deferred would leave the
   //  exchange in flight on the second stream with nobody joining it)
   const int lmf_ty = (wylo || wyhi || wmylo || wmyhi) ? TYL : TYLF;      // tile height of the fused last pass (k_lmf_tile<.., YW>)
@@ -1255,19 +1273,23 @@ static int dsmag_fast(cales_ctx *c) {
   // several ranks: ONE exchange for the y-halo rows of all these fields (six |S|Sij, three filtered velocities, v_c, and |S| itself in the lazy form
   // inside cales_step) instead of one per ghost-cell call; their ghost-cell kernels run first, the rows that then arrive carry the neighbour's
   // x/z ghost cells
-  c->defer_halo = c->P > 1;
+  c->defer_halo = c->P > 1 && !ext;
+  const bool no_halo_before = c->bc_no_halo;
+  if (ext) c->bc_no_halo = true;      // the ghost rows of every field below were formed by the strain-rate pass: their x and z ghost cells only
   c->bc_skip = perx | skipz;
   int e_ = pair ? op_boundp_wide(c, 3, c->ss2, 1) : op_boundp_multi(c, 6, ssij, 1);
   c->bc_skip = perx;
   if (!e_) e_ = op_bounduvw(c, c->bcuf, c->bcvf, c->bcwf, 0, 0, c->uf, c->vf, c->wf);
   c->bc_skip = perx | skipz;
   if (!e_ && !ucf) { real *cc[3] = {c->uc, c->vc, c->wc}; e_ = op_boundp_multi(c, 3, cc, 1); }
-  if (!e_ && ucf && !(wylo && wyhi)) {      // v_c of the rows 1 and n2 only: their copies in the ghost rows (periodic wrap or the slab neighbours') are what the last pass reads for row 0
+  if (!e_ && ucf && ext) { real *cc[1] = {c->vc}; e_ = op_boundp_multi(c, 1, cc, 1); }      // (v_c of the two ghost rows came from the strain-rate pass)
+  else if (!e_ && ucf && !(wylo && wyhi)) {      // v_c of the rows 1 and n2 only: their copies in the ghost rows (periodic wrap or the slab neighbours') are what the last pass reads for row 0
     LAUNCH(c, k_vc_edge_rows, dim3((n[0] + 2 + 63) / 64, (n[2] + 2 + 3) / 4), dim3(64, 4), 0, c->stream, c->g, f[CALES_V], c->vc);
     real *cc[1] = {c->vc}; e_ = op_boundp_multi(c, 1, cc, 1); }
   c->bc_skip = 0;
   if (!e_ && lazy && c->in_step && c->P > 1) { e_ = op_boundp(c, visct, 1); c->visct_bc_done = !e_; }      // |S| is final (K_AC wrote it): its rows travel along
   c->defer_halo = false;
+  c->bc_no_halo = no_halo_before;
   if (!e_ && c->P > 1) e_ = halo_flush_deferred(c, overlap);
   if (e_) { c->deferred.clear(); c->deferred_wide.clear(); return e_; }
   LijMijArgs L;
