@@ -425,3 +425,45 @@ def test_bench_second_order_cannot_cost_the_first():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["value"] > 0 and d["n_gpus"] == 2 and "error" in d["overlap"], d.get("overlap")
+
+
+@pytest.mark.parametrize("name,ng,P,rows2", [("chan_dsmag", (64, 32, 24), 4, True), ("chan_dsmag", (64, 64, 16), 8, True), ("tgv_dsmag_ppp", (64, 24, 16), 3, True),
+                                             ("chan_dsmag", (64, 24, 16), 8, False)])      # (three rows per slab: the second ghost row would be the slab's own ghost row -- the one-row form)
+def test_slab_halo_volume_of_the_dynamic_model(name, ng, P, rows2):
+    """Several slabs, dynamic model with the projection folded into the strain-rate pass (reference halos src/bound.f90:619-723, the dynamic
+    model's ghost-cell calls src/sgs.f90:191-197,256,280-282): with two ghost rows of the prediction and three of pp the pass forms the ghost rows of all its
+    outputs, so a substep exchanges 6 + 3 = 9 field planes in 2 messages (round 5: 20 in 3) -- counted here from the callbacks of the emulated ranks, with the plan
+    string saying which form ran, and the fields against the one-rank run as everywhere."""
+    from cales_amd.decomp import run_loopback
+    case = _case(name, ng)
+    u, v, w, p, visct, dt, div, dpdl = _single(case, 2)
+    calls = {}
+
+    def body(h, r):
+        h.upload_initial(); h.startup()
+        pl = h.describe_plan()
+        halo = h.comm.halo
+        cnt = [0, 0]
+
+        def counted(a, b, c_, d, n_):
+            cnt[0] += 1; cnt[1] += n_
+            return halo(a, b, c_, d, n_)
+        h.comm.halo = counted
+        h.step(dt); h.step(dt)
+        h.comm.halo = halo
+        calls[r] = (cnt[0], cnt[1], pl)
+        return h.download() + [h.lo, h.n]
+
+    res = run_loopback(case, P, body)
+    n1, n3 = ng[0], ng[2]
+    s1 = (n1 + 3 + 15) // 16 * 16
+    plane = s1 * (n3 + 2)
+    for r in range(P):
+        ncall, nreal, pl = calls[r]
+        assert pl["projection"] == ("in_strain_rate_pass(ghost_rows_local)" if rows2 else "in_strain_rate_pass"), pl
+        per_substep = nreal / plane / 6.      # two steps of three substeps; the count of one direction's staging block
+        assert ncall == (12 if rows2 else 18) and abs(per_substep - (9 if rows2 else 16)) < 1e-9, (ncall, per_substep)
+        ur, vr, wr, pr, visr, lo, n = res[r]
+        sl = slice(lo[1], lo[1] + n[1])
+        for a, b, nm in ((ur, u, "u"), (vr, v, "v"), (wr, w, "w"), (visr, visct, "visct")):
+            assert relerr(a[:, 1:-1, :], b[:, sl, :]) < 1e-10, (r, nm)
