@@ -1842,7 +1842,13 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
   // persistent blocks: several row groups / planes per block so that the register prefetch overlaps the transforms
   const long xgroups = (nrows + Rx8 - 1) / Rx8;
   int xiters = 1; while (xiters < 8 && xgroups / (xiters * 2) >= 2048) xiters *= 2;
+  // measured (round 6, one box, row groups per block 1 / 2 / 4 / 8): forward pass with fillps 512 x 256 x 256 0.672 / 0.690 / 0.723 / 0.748 ms per step but
+  // 512^3 3.15 / 2.90 / 2.84 / 2.77 and 1024^3 25.3 / 23.2 / 22.9 / 21.2 -- persistent blocks pay from ~16 000 row groups; inverse periodic pass 512^3
+  // 1.36 / 1.41 / 1.44 / 1.50 (one group per block), inverse Neumann pass 1024^3 12.6 / 12.0 / 11.4 / 10.8 (eight)
+  if (xgroups <= 8192) xiters = 1;
   const unsigned xblocks = (unsigned)((xgroups + xiters - 1) / xiters);
+  const int xiters_b = (c->xkind == 0 && nh <= 256) ? 1 : xiters;
+  const unsigned xblocks_b = (unsigned)((xgroups + xiters_b - 1) / xiters_b);
   int ykchunk = 1; { const long cg = (ncol + CB8 - 1) / CB8; while (ykchunk < 8 && cg * (n[2] / (ykchunk * 2)) >= 2048 && n[2] % (ykchunk * 2) == 0) ykchunk *= 2; }
   // k_fft_y16 holds 1 / 2 / 4 blocks per CU (1024 / 512 / 256 points): a launch runs in ceil(blocks / slots) rounds of (planes per block + ~1.5 planes of
   // set-up: tables, the first plane's latency) each -- the chunk length that minimises that product (512^3: 7 planes, 5 rounds of 8.5 against 5 of 9.5
@@ -2016,9 +2022,9 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
     else LAUNCH(c, k_fft_y<1>, dim3((ncol + sp->CBy - 1) / sp->CBy, n[2]), dim3(256), sp->shy, c->stream, c->g, sp->py, sp->CBy, ncol, c->ykind, (const cpx *)c->d_twy, (const cpx *)c->scr_twyd, S, mode_spec); }
   if (dist) { ProfScope ps(c, "alltoall"); if (c->comm.a2a(c->comm.user, 1, a2a_count)) { c->err = "alltoall callback failed"; return 1; } }
   { ProfScope ps(c, "fft_x_bwd");
-    if (use8x && c->xkind) LAUNCH(c, (k_fft_x8<1, 1>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
+    if (use8x && c->xkind) LAUNCH(c, (k_fft_x8<1, 1>), dim3(xblocks_b), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters_b,
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec);
-    else if (use8x) LAUNCH(c, (k_fft_x8<1, 0>), dim3(xblocks), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters,
+    else if (use8x) LAUNCH(c, (k_fft_x8<1, 0>), dim3(xblocks_b), dim3(sp->x8_threads), sp->shx8, c->stream, c->g, nh, xiters_b,
                                    (const cpx *)c->d_twx, (const cpx *)c->d_twx_post, (const cpx *)c->d_twy_post, pp, c->normfft, S, slab_spec);
     else if (c->xkind >= 5) LAUNCH(c, k_dst1<2>, dim3((unsigned)nrows), dim3(256), (size_t)2 * (VS->p1x.N + 1) * sizeof(cpx), c->stream, c->g, VS->p1x, 0, (const cpx *)VS->tw1x, pp, c->normfft, S, slab_spec, c->xkind, 1);
     else if (c->xkind == 3) LAUNCH(c, (k_fft_x4<1, 0>), dim3((unsigned)((nrows + sp->Rx - 1) / sp->Rx)), dim3(256), sp->shx, c->stream, c->g, sp->px, sp->Rx,
