@@ -1849,7 +1849,9 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
   const unsigned xblocks = (unsigned)((xgroups + xiters - 1) / xiters);
   const int xiters_b = (c->xkind == 0 && nh <= 256) ? 1 : xiters;
   const unsigned xblocks_b = (unsigned)((xgroups + xiters_b - 1) / xiters_b);
-  int ykchunk = 1; { const long cg = (ncol + CB8 - 1) / CB8; while (ykchunk < 8 && cg * (n[2] / (ykchunk * 2)) >= 2048 && n[2] % (ykchunk * 2) == 0) ykchunk *= 2; }
+  // planes per block of the eight-elements-per-thread y kernels: measured at 512^3 (round 6, in the step, planes per block 1 / 2 / 8): y passes 2.77 / 2.69 / 2.94 ms
+  // per step -- many short blocks beat long persistent ones; from 8192 blocks on
+  int ykchunk = 1; { const long cg = (ncol + CB8 - 1) / CB8; while (ykchunk < 8 && cg * (n[2] / (ykchunk * 2)) >= 8192 && n[2] % (ykchunk * 2) == 0) ykchunk *= 2; }
   // k_fft_y16 holds 1 / 2 / 4 blocks per CU (1024 / 512 / 256 points): a launch runs in ceil(blocks / slots) rounds of (planes per block + ~1.5 planes of
   // set-up: tables, the first plane's latency) each -- the chunk length that minimises that product (512^3: 7 planes, 5 rounds of 8.5 against 5 of 9.5
   // with 8; 512 x 256 x 256: 3 planes; 1024^3: 32)
