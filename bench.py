@@ -185,6 +185,10 @@ def _transpose_report(out, stats, case, world, a, solve, h):
     # second stream (cales_set_comm_overlap) -- in k-chunks that travel beside the x/y transforms. Durations from HIP events on the
     # stream the exchange is queued on, rank 0 (with the library's own RCCL calls these bracket the ncclSend/ncclRecv group itself).
     cw = -(-(int(case.ng[0]) // 2 + 1) // world)
+    try:      # (the library pads the columns per rank to whole 128-B lines where that costs 6 % or less: its own figure)
+        cw = int(h.describe_plan().get("mode_columns_per_rank", cw))
+    except Exception:
+        pass
     from cales_amd import capi
     blk = int(case.ng[2]) * (int(case.ng[1]) // world) * cw * (8.0 if capi.SINGLE else 16.0)      # complex modes
     calls, ms = stats["alltoall"]
