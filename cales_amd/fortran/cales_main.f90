@@ -59,7 +59,7 @@ program cales
   character(len=100) :: filename
   character(len=7) :: fldnum
   character(len=4) :: chkptnum
-  character(kind=c_char) :: cmsg(512)
+  character(kind=c_char) :: cmsg(512), cplan(1024)
   character(kind=c_char) :: token(128)
 #ifdef CALES_MPI
   integer :: comm_node,locrank,ndev
@@ -207,6 +207,12 @@ program cales
   call chk(cales_upload_state(ctx,u,v,w,p))
   call chk(cales_bounduvw(ctx,1,0)); call chk(cales_boundp(ctx,CALES_P,0))          ! main.f90:370-375
   call chk(cales_cmpt_sgs(ctx));     call chk(cales_boundp(ctx,CALES_VISCT,1))
+  ! which fused / folded form of every operator the steps below take (cales_describe_plan; not part of the reference's log)
+  if(cales_describe_plan(ctx,cplan,1024_c_int) == 0 .and. myid == 0) then
+    k = 1
+    do while(k < 1024 .and. cplan(k) /= c_null_char); k = k + 1; end do
+    print*, '*** Path of a time step: ', cplan(1:k-1)
+  end if
   !
   ! post-process and write initial condition (main.f90:377-395)
   !
