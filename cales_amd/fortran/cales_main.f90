@@ -211,7 +211,7 @@ program cales
   if(cales_describe_plan(ctx,cplan,1024_c_int) == 0 .and. myid == 0) then
     k = 1
     do while(k < 1024 .and. cplan(k) /= c_null_char); k = k + 1; end do
-    print*, '*** Path of a time step: ', cplan(1:k-1)
+    write(*,'(a,*(a1))') ' *** Path of a time step: ', cplan(1:k-1)
   end if
   !
   ! post-process and write initial condition (main.f90:377-395)
