@@ -548,7 +548,7 @@ int cales_describe_plan(cales_ctx *c, char *buf, int buflen) {
   s += std::string(";momentum=") + (c->fl.unfused_rk ? "mom+rk_update" : "fused_mom_rk");
   s += std::string(";sgs=") + sgs_path_name(c);
   s += std::string(";solver=") + solver_path_name(c);
-  if (c->P > 1) s += ";mode_columns_per_rank=" + std::to_string(c->cw);      // (padded to whole 128-B lines where that costs 6 % or less: solver_setup)
+  if (c->P > 1) s += ";mode_columns_per_rank=" + std::to_string(c->nyq_ok ? c->cw_nyq : c->cw);      // of the pressure solve (padded to whole 128-B lines where that costs 6 % or less: solver_setup)
   s += ";ranks=" + std::to_string(c->P) + ";exchanges=" + (c->P == 1 ? "none" : !c->comm.on ? "unset" : (c->comm_stream && (c->comm.halo_s || c->comm.a2a_part)) ? "second_stream" : "in_order");
   std::snprintf(buf, buflen, "%s", s.c_str());
   return (int)s.size() < buflen ? 0 : 2;      // 2: truncated

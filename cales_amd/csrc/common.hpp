@@ -65,6 +65,7 @@ struct Comm {
 //               on the slab side peer = m/cw, on the mode-block side peer = (j-1)/n2l.
 struct Spec {
   int blocked, cw, n2l, n3;
+  int nyq = 0;      // periodic x: the two REAL modes 0 and n1/2 of a row share complex slot 0 (re, im) and the row has n1/2 complex slots -- whole 128-B lines (k_solver.hip, "Nyquist packing")
   // slab side: global mode m, LOCAL row jl (1-based), plane k (1-based)
   __host__ __device__ inline size_t at_slab(const Geom &g, int m, int jl, int k) const {
     if (!blocked) return (g.ix(0, jl, k) >> 1) + (size_t)m;
@@ -81,7 +82,7 @@ struct Spec {
 
 // Run-time switches: read from the environment ONCE, by cales_create; the launch path only looks at these fields.
 struct Flags {
-  bool unfolded_correc = false, unfolded_mom = false, eager_projection = false, lazy_projection = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, unfused_rk = false, overlap = false, xghosts_in_step = false, unmerged_bc = false;
+  bool unfolded_correc = false, unfolded_mom = false, eager_projection = false, lazy_projection = false, helmholtz_z_per_column = false, unfused_imp_rhs = false, unfused_correc = false, unfused_forcing = false, unfused_fillps = false, unfused_mean = false, keep_last_rhs = false, wide_offsets = false, dsmag_reference_sequence = false, dsmag_xghosts = false, smag_reference_sequence = false, gaussel_march = false, fft_generic = false, keep_null_mode = false, unfused_rk = false, overlap = false, xghosts_in_step = false, unmerged_bc = false, no_nyquist_packing = false;
   int kchunk = 0; long tile_min_blocks = 2048;
   std::string test_bad_launch;      // CALES_TEST_BAD_LAUNCH: test hook of the launch check (LAUNCH below)
   void read_env() {
@@ -102,6 +103,7 @@ struct Flags {
     dsmag_xghosts = getenv("CALES_DSMAG_XGHOSTS") != nullptr;
     smag_reference_sequence = getenv("CALES_SMAG_REFERENCE_SEQUENCE") != nullptr;
     gaussel_march = getenv("CALES_GAUSSEL_MARCH") != nullptr;
+    no_nyquist_packing = getenv("CALES_NO_NYQUIST_PACKING") != nullptr;      // periodic x and y: the real modes 0 and n1/2 in columns of their own (n1/2 + 1 mode columns) instead of sharing column 0
     fft_generic = getenv("CALES_FFT_GENERIC") != nullptr;
     xghosts_in_step = getenv("CALES_XGHOSTS_IN_STEP") != nullptr;      // keep the x ghost columns up to date after every operator of cales_step
     keep_null_mode = getenv("CALES_KEEP_NULL_MODE") != nullptr;
@@ -172,6 +174,7 @@ struct cales_ctx {
   real *d_av[3], *d_bv[3], *d_cv[3];
   real normfft;
   int xkind, ykind;            // 0: periodic (r2c / c2c), 1: Neumann-Neumann cell-centred (DCT-II/III)
+  bool nyq_ok = false; int cw_nyq = 0;      // the pressure solve packs the modes 0 and n1/2 into one column (solver_setup: periodic x and y, walls in z, radix-8 transforms, the z tile); mode columns per rank then
   real *d_twx, *d_twy;       // twiddle tables
   real *d_twx_post, *d_twy_post;    // d_twy_post: DCT weights of the x direction
   real *scr_twyd = nullptr;           // DCT weights of the y direction

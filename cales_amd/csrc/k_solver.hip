@@ -310,7 +310,10 @@ __global__ __launch_bounds__(256, (KIND == 1 && FILL == 1) ? 2 : 1) void k_fft_x
     } else if (!kind) {
 #pragma unroll
       for (int e = 0; e < NE; ++e) { const real2 v = spec[S.at_slab(g, t + e * T, j, k)]; nxt[e] = cpx{v.x, v.y}; }
-      if (t == 0) { const real2 v = spec[S.at_slab(g, nh, j, k)]; nxt[NE] = cpx{v.x, v.y}; }
+      if (t == 0) {
+        if (S.nyq) { nxt[NE] = cpx{nxt[0].y, 0.}; nxt[0].y = 0.; }      // slot 0 = (mode 0, mode nh), both real
+        else { const real2 v = spec[S.at_slab(g, nh, j, k)]; nxt[NE] = cpx{v.x, v.y}; }
+      }
     } else {            // DCT-III: the n real coefficients of the row as nh coalesced pairs; combined in LDS below
 #pragma unroll
       for (int e = 0; e < NE; ++e) { const real2 v = spec[S.at_slab(g, t + e * T, j, k)]; nxt[e] = cpx{v.x, v.y}; }
@@ -363,8 +366,12 @@ __global__ __launch_bounds__(256, (KIND == 1 && FILL == 1) ? 2 : 1) void k_fft_x
           const cpx wO = cmul(twp[kk], O);
           const cpx xk = cadd(E, wO), xm = cconj(csub(E, wO));
           if (!kind) {
+            // (S.nyq: the modes 0 and nh of a real row are real -- they share slot 0, and no slot nh exists)
+            if (S.nyq && kk == 0) spec[S.at_slab(g, 0, j, k)] = make_real2(xk.x, xm.x);
+            else {
             spec[S.at_slab(g, kk, j, k)] = make_real2(xk.x, xk.y);
             spec[S.at_slab(g, nh - kk, j, k)] = make_real2(xm.x, xm.y);
+            }
           } else {      // DCT-II coefficients Y_k = 2 Re(w_k V_k), Y_{n-k} = -2 Im(w_k V_k) at the real slots of the row
             real *sd = reinterpret_cast<real *>(spec);
             const int n = 2 * nh, k2 = nh - kk;
@@ -1042,7 +1049,8 @@ __global__ void k_abc_chunked(int nz, int M, const real *__restrict__ a, const r
 }
 // Segments of columns (blockIdx.y): one rank -- row j of the in-place spectrum (ndbl doubles, plane stride s12); several ranks --
 // the block of peer blockIdx.y in the layout [peer][k][jl][m], whose (jl, m) planes are contiguous runs of 2 cw n2l doubles.
-struct TileMap { int blocked, cw, n2l, mofs, nmode; size_t kstride, segstride;
+struct TileMap { int blocked, cw, n2l, mofs, nmode; size_t kstride, segstride; int nyq = 0;      // nyq: mode 0's column holds the modes 0 and n1/2 (Spec::nyq): left to k_gaussel_nyq
+                
                  // z-only Helmholtz sweeps of real fields (no eigenvalue shift): nolam; cales_step forms the r.h.s. of rk.f90:108-118 and
                  // main.f90:422-433 while loading, (u - hf12*dudtd) + f + rhs_b, and plane nz+1 (wall face of w) receives the first two terms
                  int nolam, nq, has_lo, has_hi; const real *dud, *force; RhsBz blo, bhi; real hf12; };
@@ -1120,6 +1128,7 @@ __global__ __launch_bounds__(64 * gt_width(M, NV) / NV, (PER ? 2 : M <= 8 ? 4 : 
     mode = NV == 1 ? 2 * (mm + T.mofs) + (d & 1) : mm + T.mofs;
     colok = colok && mm + T.mofs < T.nmode;      // padding modes of the last rank: skipped (their slots are never read)
   }
+  if (T.nyq && mode == 0) colok = false;      // (the packed column of the modes 0 and n1/2: k_gaussel_nyq)
   if (colok) {
     const real lam = T.nolam ? 0. : (lamx[mode] + lamy[j - 1]) * lscale;
     const bool nullc = fixnull && lam == 0.;      // singular mode: the member with p(nz) = 0, see k_gaussel_ri
@@ -1258,6 +1267,167 @@ __global__ __launch_bounds__(64 * gt_width(M, NV) / NV, (PER ? 2 : M <= 8 ? 4 : 
       o += step;
     }
   }
+}
+// Nyquist packing (Spec::nyq): with periodic x the modes 0 and nh = n1/2 of a real row are REAL, so the x pass stores them as ONE complex value in slot 0 and
+// a row of the spectrum is nh complex values -- whole 128-B lines for the y transforms, the z tile and the mode blocks of several ranks (257 columns were
+// 32 tiles of eight and a 33rd for one column; 33 columns per rank on eight ranks were rows of 528 bytes that no line is aligned to). The y transform of
+// that column is Z = A + i B with A, B the Hermitian spectra of the two real sequences; they have DIFFERENT x eigenvalues, so the z solve separates them by
+// the rows ky and N - ky -- A = (Z(ky) + conj Z(N-ky)) / 2, B = (Z(ky) - conj Z(N-ky)) / (2 i) --, solves Re A, Im A with lambda_x(0) and Re B, Im B with
+// lambda_x(nh) (four real columns of a tile: the solve is the text of k_gaussel_tile<M, 1, 0>), and puts Z'(ky) = A' + i B', Z'(N-ky) = conj A' + i conj B'
+// back. One block per pair of rows, ky = 0 .. N/2 (ky = 0 and N/2 pair with themselves: A, B real there). 1 / (nh + 1) of the solve's work; the rank that
+// holds mode 0 runs it. Reference: the same equations as src/solver.f90:82-179 for the modes 0 and n1/2 (FFTW's half-complex r0 and r_{n/2}).
+template <int M>
+__global__ __launch_bounds__(256) void k_gaussel_nyq(Geom g, int nz, int N, int nh, real lscale, const real *__restrict__ abc, const real *__restrict__ lamx,
+                                                     const real *__restrict__ lamy, real2 *__restrict__ p, int fixnull, Spec S,
+                                                     const real *__restrict__ ra = nullptr, const real *__restrict__ rb_ = nullptr, const real *__restrict__ rc = nullptr) {
+  extern __shared__ real shz[];
+  constexpr int NV = 1, PER = 0, CP = M + 1, P = 64 * CP + 4, NT = 256;
+  constexpr bool TL = false;
+  const real *tabl = nullptr;
+  const int nsys = nz;
+  const int t = threadIdx.x, ky = blockIdx.x, kp = (N - ky) % N;
+  for (int k = t; k < 64 * M; k += NT) {
+    real2 z1 = make_real2(0., 0.), z2 = z1;
+    if (k < nz) { z1 = p[S.at_mode(g, 0, ky + 1, k + 1)]; z2 = p[S.at_mode(g, 0, kp + 1, k + 1)]; }
+    const int o = k + k / M;
+    shz[0 * P + o] = 0.5 * (z1.x + z2.x); shz[1 * P + o] = 0.5 * (z1.y - z2.y);      // A = (Z(ky) + conj Z(N-ky)) / 2
+    shz[2 * P + o] = 0.5 * (z1.y + z2.y); shz[3 * P + o] = -0.5 * (z1.x - z2.x);     // B = (Z(ky) - conj Z(N-ky)) / (2 i)
+  }
+  __syncthreads();
+  const int x = t >> 6, ch = t & 63;
+  const bool colok = true;
+  if (colok) {
+    const real lam = (lamx[x < 2 ? 0 : nh] + lamy[ky]) * lscale;
+    const bool nullc = fixnull && lam == 0.;      // singular mode: the member with p(nz) = 0, see k_gaussel_ri
+    real *col = shz + x * P + ch * CP;
+    const int k0 = ch * M;
+    real cp[M - 1], V[M - 1];      // the swept right-hand sides go back to their LDS slots (registers: no spills at 4 waves/SIMD)
+    real cprev = 0., vprev = 0., rprev[NV] = {};
+    // periodic z: the last plane's right-hand side (its row is an identity row of the tile), the closure vector's two entries
+    real pnr[NV] = {}, E[PER ? M - 1 : 1] = {}, eprev = 0.;
+    const real e_first = PER ? -ra[0] : 0., e_last = PER ? -rc[nsys - 1] : 0.;
+    if (PER) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) pnr[q] = shz[(x + q) * P + (nz - 1) + (nz - 1) / M];
+    }
+#pragma unroll
+    for (int r = 0; r < M - 1; ++r) {
+      const int k = k0 + r;
+      const bool pin = !PER && nullc && k == nz - 1, live = k < nsys && !pin;
+      // (every load unconditional, the selection afterwards: a load inside a divergent branch is waited for on the spot -- sixteen serial
+      //  round trips to the table per chunk)
+      const real A0 = TL ? tabl[r * 64 + ch] : abc[r * 64 + ch], C0 = TL ? tabl[64 * M + r * 64 + ch] : abc[128 * M + r * 64 + ch], B0 = abc[64 * M + r * 64 + ch];
+      const real A = pin ? 0. : A0, C = pin ? 0. : C0, B = pin ? 1. : B0 + (k < nsys ? lam : 0.);
+      const real z = rcp_nr(B - A * cprev + CALES_EPS);
+      cp[r] = C * z; V[r] = (r == 0 ? A : -A * vprev) * z;
+#pragma unroll
+      for (int q = 0; q < NV; ++q) { const real D0 = col[q * P + r], D = live ? D0 : 0.; rprev[q] = (D - A * rprev[q]) * z; col[q * P + r] = rprev[q]; }
+      if (PER) { const real D2 = (k == 0 ? e_first : 0.) + (k == nsys - 1 ? e_last : 0.); eprev = (D2 - A * eprev) * z; E[r] = eprev; }
+      cprev = cp[r]; vprev = V[r];
+    }
+    // first interior row of the chunk as a function of the separators beside it
+    real Vb = V[M - 2], Wb = cp[M - 2], Rb[NV], Eb = eprev;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) Rb[q] = rprev[q];
+#pragma unroll
+    for (int r = M - 3; r >= 0; --r) {
+      Vb = V[r] - cp[r] * Vb; Wb = -cp[r] * Wb;
+#pragma unroll
+      for (int q = 0; q < NV; ++q) Rb[q] = col[q * P + r] - cp[r] * Rb[q];
+      if (PER) Eb = E[r] - cp[r] * Eb;
+    }
+    const bool last = ch == 63;
+    // (cross-lane reads are issued by all lanes and masked afterwards: a lane switched off by a branch would be read as zero)
+    real Vn = __shfl_down(Vb, 1, 64), Wn = __shfl_down(Wb, 1, 64);
+    if (last) { Vn = 0.; Wn = 0.; }
+    // separator row
+    real al, be, ga, de[NV], de2 = 0.;
+    {
+      const int k = k0 + M - 1, r = M - 1;
+      const bool pin = !PER && nullc && k == nz - 1, live = k < nsys && !pin;
+      const real A0 = TL ? tabl[r * 64 + ch] : abc[r * 64 + ch], C0 = TL ? tabl[64 * M + r * 64 + ch] : abc[128 * M + r * 64 + ch], B0 = abc[64 * M + r * 64 + ch];
+      const real A = pin ? 0. : A0, C = pin ? 0. : C0, B = pin ? 1. : B0 + (k < nsys ? lam : 0.);
+      al = -A * V[M - 2]; be = B - A * cp[M - 2] - C * Vn; ga = -C * Wn;
+      if (PER) {
+        real En = __shfl_down(Eb, 1, 64);
+        if (last) En = 0.;
+        const real D2 = (k == 0 ? e_first : 0.) + (k == nsys - 1 ? e_last : 0.);
+        de2 = D2 - A * eprev - C * En;
+      }
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        real Rn = __shfl_down(Rb[q], 1, 64);
+        if (last) Rn = 0.;
+        const real D0 = col[q * P + M - 1], D = live ? D0 : 0.;
+        de[q] = D - A * rprev[q] - C * Rn;
+      }
+    }
+    // parallel cyclic reduction over the 64 separators
+#pragma unroll
+    for (int h = 1; h < 64; h <<= 1) {
+      const bool lo = ch >= h, hi = ch + h < 64;
+      const real rb = rcp_nr(be);
+      const real rbm = __shfl_up(rb, h, 64), rbp = __shfl_down(rb, h, 64);
+      const real k1 = lo ? al * rbm : 0., k2 = hi ? ga * rbp : 0.;
+      const real alm = __shfl_up(al, h, 64), gam = __shfl_up(ga, h, 64), alp = __shfl_down(al, h, 64), gap = __shfl_down(ga, h, 64);
+      be = be - gam * k1 - alp * k2;
+#pragma unroll
+      for (int q = 0; q < NV; ++q) de[q] = de[q] - __shfl_up(de[q], h, 64) * k1 - __shfl_down(de[q], h, 64) * k2;
+      if (PER) de2 = de2 - __shfl_up(de2, h, 64) * k1 - __shfl_down(de2, h, 64) * k2;
+      al = -alm * k1; ga = -gap * k2;
+    }
+    const real rb = rcp_nr(be);
+    // periodic z: row n-1 of the system sits in chunk cL at place rL; rows 1 and n-1 of p1 and p2 are fetched from their lanes
+    const int cL = PER ? (nsys - 1) / M : 0, rL = PER ? (nsys - 1) % M : 0;
+    real Es = 0., e1 = 0., eL = 0.;
+    if (PER) {
+      Es = de2 * rb;
+      real sp2 = __shfl_up(Es, 1, 64);
+      if (ch == 0) sp2 = 0.;
+      real xv2 = eprev - V[M - 2] * sp2 - cp[M - 2] * Es;
+      E[M - 2] = xv2;
+#pragma unroll
+      for (int r = M - 3; r >= 0; --r) { xv2 = E[r] - V[r] * sp2 - cp[r] * xv2; E[r] = xv2; }
+      real mine = Es;
+#pragma unroll
+      for (int r = 0; r < M - 1; ++r) if (r == rL) mine = E[r];
+      e1 = __shfl(E[0], 0, 64); eL = __shfl(mine, cL, 64);
+    }
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const real s = de[q] * rb;
+      real sp = __shfl_up(s, 1, 64);
+      if (ch == 0) sp = 0.;
+      real xv = rprev[q] - V[M - 2] * sp - cp[M - 2] * s;
+      real mine = (rL == M - 2) ? xv : s;
+      col[q * P + M - 2] = xv;
+#pragma unroll
+      for (int r = M - 3; r >= 0; --r) { xv = col[q * P + r] - V[r] * sp - cp[r] * xv; col[q * P + r] = xv; if (PER && r == rL) mine = xv; }
+      col[q * P + M - 1] = s;
+      if (PER) {
+        const real p11 = __shfl(xv, 0, 64), p1n = __shfl(mine, cL, 64);      // xv: row 1 of the chunk (lane 0: row 1 of the system)
+        const real an = ra[nz - 1], bn = rb_[nz - 1], cn = rc[nz - 1];
+        const real den = (bn + lam) + cn * e1 + an * eL + CALES_EPS;
+        const real pn = nullc ? 0. : ((pnr[q] - cn * p11) - an * p1n) * (1. / den);      // null mode of the triply periodic problem: p(n) = 0
+#pragma unroll
+        for (int r = 0; r < M - 1; ++r) if (k0 + r < nsys) col[q * P + r] = col[q * P + r] + E[r] * pn;
+        if (k0 + M - 1 < nsys) col[q * P + M - 1] = s + Es * pn;
+        if (ch == nsys / M) col[q * P + nsys % M] = pn;
+      }
+    }
+  }
+  __syncthreads();
+  for (int k = t; k < nz; k += NT) {
+    const int o = k + k / M;
+    const real ar = shz[0 * P + o], ai = shz[1 * P + o], br = shz[2 * P + o], bi = shz[3 * P + o];
+    p[S.at_mode(g, 0, ky + 1, k + 1)] = make_real2(ar - bi, ai + br);      // A' + i B'
+    p[S.at_mode(g, 0, kp + 1, k + 1)] = make_real2(ar + bi, br - ai);      // conj A' + i conj B'
+  }
+}
+template <int M>
+static void launch_gaussel_nyq(cales_ctx *c, int nz, int N, int nh, real lscale, const real *da, const real *db, const real *dc, real2 *p, int fixnull, const Spec &S, const real *tab) {
+  constexpr int lds = 4 * (64 * (M + 1) + 4) * 8;
+  LAUNCH(c, (k_gaussel_nyq<M>), dim3(N / 2 + 1), dim3(256), lds, c->stream, c->g, nz, N, nh, lscale, tab, c->d_lamx, c->d_lamy, p, fixnull, S, da, db, dc);
 }
 // The same tile PERSISTENT over `tpb` neighbouring tiles of a segment, for nz = 1024 planes in chunks of sixteen (the 1024^3 cavity): the
 // classic form holds one block of 1024 threads and 140 KB of LDS per CU, so the load of a tile, its solve and its store run one after the other (5.6 ms
@@ -1703,6 +1873,11 @@ int solver_setup(cales_ctx *c) {
   // on the links -- not padded there.
   if (c->P > 1) { const int cw8 = (c->cw + 7) / 8 * 8; if (100 * (cw8 - c->cw) <= 6 * c->cw && (size_t)cw8 * n2g * n3 <= c->ntot) c->cw = cw8; }
   if (c->P > 1 && (size_t)c->cw * n2g * n3 > c->ntot) { c->err = "solver: scratch too small for the mode-block layout"; return 1; }
+  // Nyquist packing of the pressure solve (k_gaussel_nyq): periodic x AND y (the Hermitian pairing of rows needs the complex y transform), radix-8 passes,
+  // the z solve in the LDS tile; n1/2 mode columns instead of n1/2 + 1
+  { const bool pz = CBP(c, 0, 3) == 'P' && CBP(c, 1, 3) == 'P', hasd = CBP(c, 0, 3) == 'D' || CBP(c, 1, 3) == 'D';
+    c->nyq_ok = c->xkind == 0 && c->ykind == 0 && sp.x8 && sp.y8 && !pz && (hasd || !c->fl.keep_null_mode) && n3 >= 2 && n3 <= 1024 && !c->fl.gaussel_march && !c->fl.no_nyquist_packing;
+    c->cw_nyq = (n1 / 2 + c->P - 1) / c->P; }
   HIPCHK(c, hipMalloc(&c->d_lamx, (n1 + 2) * sizeof(real))); HIPCHK(c, hipMalloc(&c->d_lamy, n2g * sizeof(real)));
   HIPCHK(c, hipMemcpy(c->d_lamx, lx.data(), (n1 + 2) * sizeof(real), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_lamy, ly.data(), n2g * sizeof(real), hipMemcpyHostToDevice));
@@ -1827,11 +2002,13 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
   const bool use8x = sp->x8 && c->xkind <= 1, use8y = sp->y8 && c->ykind <= 1;
   const VelSet *VS = static_cast<const VelSet *>(c->cur_velset);      // transform set of the velocity component being solved (nullptr: the pressure's)
   if (dist && !c->comm.on) { c->err = "solver: nranks > 1 but no communication hooks registered (cales_set_comm)"; return 1; }
-  Spec S; S.blocked = dist ? 1 : 0; S.cw = c->cw; S.n2l = n[1]; S.n3 = n[2];
+  const bool nyq = poisson && !VS && c->nyq_ok && c->xkind == 0 && c->ykind == 0;
+  const int cw = nyq ? c->cw_nyq : c->cw, nmodes = nyq ? n[0] / 2 : mh;      // complex mode columns: per rank, in all
+  Spec S; S.blocked = dist ? 1 : 0; S.cw = cw; S.n2l = n[1]; S.n3 = n[2]; S.nyq = nyq ? 1 : 0;
   real2 *slab_spec = dist ? reinterpret_cast<real2 *>(c->comm.A) : reinterpret_cast<real2 *>(pp + 1);   // in place: modes of row (j,k) from i = 1
   real2 *mode_spec = dist ? reinterpret_cast<real2 *>(c->comm.B) : reinterpret_cast<real2 *>(pp + 1);
-  const int ncol = dist ? c->cw : mh, mofs = dist ? c->rank * c->cw : 0;
-  const int64_t a2a_count = (int64_t)n[2] * n[1] * c->cw * 2;
+  const int ncol = dist ? cw : nmodes, mofs = dist ? c->rank * cw : 0;
+  const int64_t a2a_count = (int64_t)n[2] * n[1] * cw * 2;
   const int nh = c->C.ng[0] / 2;
   const bool use16y = use8y && sp->y16;
   const int Rx8 = use8x ? sp->x8_threads / (nh / 8) : 1, CB8 = use16y ? 8 : use8y ? sp->y8_threads / (n2g / 8) : 1;
@@ -1879,7 +2056,7 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
   if (dist && c->comm.a2a_part && c->comm_stream && use8x && use8y) { if (n[2] % 4 == 0 && n[2] >= 32) NCH = 4; else if (n[2] % 2 == 0 && n[2] >= 8) NCH = 2; }
   const bool pipe = NCH > 1;
   const int kpc = n[2] / NCH;                                   // planes per chunk
-  const int64_t a2a_stride = a2a_count, a2a_chunk = (int64_t)kpc * n[1] * c->cw * 2;
+  const int64_t a2a_stride = a2a_count, a2a_chunk = (int64_t)kpc * n[1] * cw * 2;
   const long rows_c = (long)n[1] * kpc, xgroups_c = (rows_c + Rx8 - 1) / Rx8;
   int xiters_c = 1; while (xiters_c < 8 && xgroups_c / (xiters_c * 2) >= 2048 / NCH) xiters_c *= 2;
   const unsigned xblocks_c = (unsigned)((xgroups_c + xiters_c - 1) / xiters_c);
@@ -1982,9 +2159,9 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
                          da, db, dc, c->d_lamx, c->d_lamy, (real *)mode_spec, c->scr1, fixnull);
     else if ((periodic_z || fixnull || !poisson || CBP(c, 0, 3) == 'D' || CBP(c, 1, 3) == 'D') &&
              [&]() {
-               TileMap T{}; T.blocked = dist ? 1 : 0; T.cw = c->cw; T.n2l = n[1]; T.mofs = mofs; T.nmode = c->xkind ? c->C.ng[0] / 2 : mh;
-               T.kstride = (size_t)2 * c->cw * n[1]; T.segstride = T.kstride * n[2];
-               const int ndbl = dist ? 2 * c->cw * n[1] : (c->xkind ? 2 * (c->C.ng[0] / 2) : 2 * mh), nseg = dist ? c->P : n2g;
+               TileMap T{}; T.blocked = dist ? 1 : 0; T.cw = cw; T.n2l = n[1]; T.mofs = mofs; T.nmode = c->xkind ? c->C.ng[0] / 2 : nmodes; T.nyq = nyq ? 1 : 0;
+               T.kstride = (size_t)2 * cw * n[1]; T.segstride = T.kstride * n[2];
+               const int ndbl = dist ? 2 * cw * n[1] : (c->xkind ? 2 * (c->C.ng[0] / 2) : 2 * nmodes), nseg = dist ? c->P : n2g;
                if (periodic_z)      // the cyclic closure inside the tile (gaussel_periodic, solver.f90:109-150)
                  return c->xkind ? gaussel_tile<1, 1>(c, nz, ndbl, nseg, lscale, da, db, dc, (real *)mode_spec, fixnull, T)
                                  : gaussel_tile<2, 1>(c, nz, ndbl, nseg, lscale, da, db, dc, (real *)mode_spec, fixnull, T);
@@ -2000,6 +2177,13 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
                                      (real2 *)mode_spec, (real2 *)c->scr1, fixnull);
     else if (periodic_z) LAUNCH(c, (k_gaussel<real2, 1>), gr, b, 0, c->stream, c->g, nz, ncol, n2g, 0, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (real *)mode_spec, c->scr1, c->scr2, fixnull);
     else LAUNCH(c, k_gaussel_ri, dim3((unsigned)(((long)2 * ncol * n2g + 255) / 256)), dim3(256), 0, c->stream, c->g, nz, ncol, n2g, mofs, mh, S, lscale, da, db, dc, c->d_lamx, c->d_lamy, (real *)mode_spec, c->scr1, fixnull, 0); }
+  if (nyq && mofs == 0) {      // the packed column of the modes 0 and n1/2 (the tile left it out); same coefficient table as the tile of this nz
+    ProfScope ps(c, "gaussel_z");
+    if (nz <= 128) launch_gaussel_nyq<2>(c, nz, n2g, nh, lscale, da, db, dc, mode_spec, fixnull, S, c->d_abct);
+    else if (nz <= 256) launch_gaussel_nyq<4>(c, nz, n2g, nh, lscale, da, db, dc, mode_spec, fixnull, S, c->d_abct);
+    else if (nz <= 512) launch_gaussel_nyq<8>(c, nz, n2g, nh, lscale, da, db, dc, mode_spec, fixnull, S, c->d_abct);
+    else launch_gaussel_nyq<16>(c, nz, n2g, nh, lscale, da, db, dc, mode_spec, fixnull, S, c->d_abct);
+  }
   if (refnull) LAUNCH(c, k_null_column, dim3(1), dim3(64), 0, c->stream, c->g, S, nz, periodic_z ? 1 : 0, da, db, dc, c->d_lamx, c->d_lamy, mode_spec, c->d_nullw, 1);
   if (pend_mean_mask) if (int e = op_force_from_partials(c, pend_mean_mask, pend_mean_part, pend_mean_nblk)) return e;
   if (pipe) {
@@ -2058,6 +2242,7 @@ std::string solver_path_name(cales_ctx *c) {
   std::string s = std::string("x:") + kinds[c->xkind] + (use8x ? "/radix8" : c->xkind >= 3 ? "/dct4" : "/mixed_radix");
   s += std::string(",y:") + kinds[c->ykind] + (use8y ? (c->ykind ? "/radix8" : "/radix8_register_ends") : c->ykind >= 3 ? "/dct4" : "/mixed_radix");
   s += std::string(",z:") + (c->xkind && !c->ykind ? "thomas_hermitian" : tile ? (perz ? "lds_tile_periodic" : "lds_tile") : "thomas_march");
+  if (c->nyq_ok) s += ",modes_0_and_n1/2:one_column";
   if (c->fl.keep_null_mode) s += ",null_mode:reference_order";
   return s;
 }

@@ -225,7 +225,7 @@ def test_slab_ranks_smag_reference_sequence(name, ng, P, monkeypatch):
 def test_slab_ranks_with_switch_combinations(name, ng, P, seed, monkeypatch):
     """Several slabs with three to five run-time switches at once (fixed seeds; overlap on for every other one): same bar as the plain slab test."""
     rng = np.random.RandomState(2000 + seed)
-    pool = ["CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFOLDED_CORREC", "CALES_UNFOLDED_MOM", "CALES_LAZY_PROJECTION", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_GAUSSEL_MARCH",
+    pool = ["CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFOLDED_CORREC", "CALES_UNFOLDED_MOM", "CALES_LAZY_PROJECTION", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_GAUSSEL_MARCH", "CALES_NO_NYQUIST_PACKING",
             "CALES_DSMAG_XGHOSTS", "CALES_WIDE_OFFSETS", "CALES_UNMERGED_BC",
             "CALES_XGHOSTS_IN_STEP", "CALES_FFT_GENERIC", "CALES_HELMHOLTZ_Z_PER_COLUMN", "CALES_UNFUSED_IMP_RHS"]
     for k in rng.choice(pool, size=rng.randint(3, 6), replace=False):
@@ -291,7 +291,7 @@ def test_n_rank_nccl_process_group(layer, overlap):
     assert r.returncode == 0 and "NCCLN OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
-@pytest.mark.parametrize("P", [2, 3, 8])      # 8: the rank count of the node the north star names (rank order, cw = ceil(33 / 8) = 5 padded mode columns, 8-way reductions)
+@pytest.mark.parametrize("P", [2, 3, 8])      # 8: the rank count of the node the north star names (rank order, 32 packed mode columns in blocks of 4 -- 3: blocks of 11, one padding column on the last rank --, 8-way reductions)
 def test_n_processes_one_gpu_staged_gloo(P):
     """Real processes (torch.distributed.run, one per rank) sharing the ONE GPU of the test box: RCCL refuses that, so the exchanges go
     through gloo with host staging (decomp.StagedGlooComm). Everything else is the production path of `bench.py --gpus N`: rendezvous, rank
@@ -326,7 +326,7 @@ def test_bench_two_processes_one_gpu():
 
 def test_bench_eight_processes_one_gpu_bare_form():
     """`python bench.py --gpus 8` in the bare form at the REAL rank count of the target node, the eight ranks sharing the one GPU of the test box through
-    gloo: 257 -> 33 x-modes over 8 ranks in blocks of cw = 5 (the last rank holds three padded columns), 8-row slabs, max-over-ranks timing over eight
+    gloo: the 32 mode columns of 64-point rows (modes 0 and 32 share column 0) over 8 ranks in blocks of 4, 8-row slabs, max-over-ranks timing over eight
     processes, the 8-way rendezvous -- everything but RCCL itself."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

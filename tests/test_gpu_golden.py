@@ -223,7 +223,7 @@ def test_wide_offset_kernels(name, monkeypatch):
     test_fused_step_matches_operator_sequence(name)
 
 
-@pytest.mark.parametrize("env", ["CALES_DSMAG_REFERENCE_SEQUENCE", "CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_GAUSSEL_MARCH", "CALES_KEEP_LAST_RHS",
+@pytest.mark.parametrize("env", ["CALES_DSMAG_REFERENCE_SEQUENCE", "CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_GAUSSEL_MARCH", "CALES_NO_NYQUIST_PACKING", "CALES_KEEP_LAST_RHS",
                                  "CALES_UNMERGED_BC"])
 @pytest.mark.parametrize("name", ["chan_dsmag", "chan_dsmag_wm", "tgv_dsmag_ppp", "duct_smag_wm_imp1d", "duct_dsmag_wm"])
 def test_unfused_paths(name, env, monkeypatch):
@@ -676,7 +676,8 @@ def test_all_directions_ghost_cell_kernel_equals_the_sequence(name, ng, is_corre
 
 @pytest.mark.parametrize("name,env,expect", [
     ("chan_dsmag_x64", {}, {"projection": "in_strain_rate_pass", "x_ghost_columns": "wrapped", "fillps": "in_x_transform", "ghost_cells": "one_launch",
-                            "sgs": "dsmag_tiles(pair_fields)", "solver": "x:PP/radix8,y:PP/radix8_register_ends,z:lds_tile", "exchanges": "none"}),
+                            "sgs": "dsmag_tiles(pair_fields)", "solver": "x:PP/radix8,y:PP/radix8_register_ends,z:lds_tile,modes_0_and_n1/2:one_column", "exchanges": "none"}),
+    ("chan_dsmag_x64", {"CALES_NO_NYQUIST_PACKING": "1"}, {"solver": "x:PP/radix8,y:PP/radix8_register_ends,z:lds_tile"}),
     ("chan_dsmag_x64", {"CALES_UNMERGED_BC": "1"}, {"projection": "own_pass(correc+updatep)", "ghost_cells": "by_direction", "sgs": "dsmag_tiles"}),
     ("chan_dsmag", {}, {"projection": "own_pass(correc+updatep)", "x_ghost_columns": "maintained", "fillps": "own_pass", "solver": "x:PP/mixed_radix,y:PP/mixed_radix,z:lds_tile"}),
     ("chan_dsmag", {"CALES_DSMAG_REFERENCE_SEQUENCE": "1", "CALES_GAUSSEL_MARCH": "1"}, {"sgs": "dsmag_reference_sequence", "solver": "x:PP/mixed_radix,y:PP/mixed_radix,z:thomas_march"}),

@@ -75,6 +75,28 @@ def test_tridiagonal_paths_agree(name, ng, monkeypatch):
     assert np.abs(out[0] - out[1]).max() < 1e-11 * np.abs(out[1]).max()
 
 
+@pytest.mark.parametrize("name,ng", [("chan_smag", (64, 16, 6)), ("chan_smag", (64, 32, 100)), ("chan_dsmag", (128, 64, 130)), ("chan_smag", (64, 16, 300)), ("chan_smag", (64, 16, 512)),
+                                     ("chan_smag", (128, 16, 700)), ("chan_smag", (64, 16, 1024)), ("chan_smag", (512, 1024, 4)), ("halfchan_imp1d", (64, 64, 40))])
+def test_nyquist_packing_agrees(name, ng, monkeypatch):
+    """periodic x and y: the real x modes 0 and n1/2 sharing column 0 of the spectrum (default; k_gaussel_nyq separates them in the z solve by the Hermitian
+    pairing of the y rows) against columns of their own (CALES_NO_NYQUIST_PACKING) -- every chunking of the z tile, y lines of every first radix"""
+    g, case = load_golden(name)
+    case.ng[:] = ng
+    rng = np.random.RandomState(11)
+    rhs = np.zeros(tuple(x + 2 for x in ng), order="F"); rhs[1:-1, 1:-1, 1:-1] = rng.rand(*ng) - 0.5
+    # (content in the two packed modes in particular: a constant and the alternating row, modulated in y and z)
+    rhs[1:-1, 1:-1, 1:-1] += (1. + 0.5 * np.cos(np.pi * np.arange(ng[0])))[:, None, None] * rng.rand(1, ng[1], ng[2])
+    out = []
+    for packed in (True, False):
+        if not packed:
+            monkeypatch.setenv("CALES_NO_NYQUIST_PACKING", "1")
+        h = _hot(case)
+        assert ("one_column" in h.describe_plan()["solver"]) == packed
+        h.set("pp", rhs); h.solver()
+        a = h.get("pp")[1:-1, 1:-1, 1:-1]; out.append(a - a.mean()); h.close()
+    assert np.abs(out[0] - out[1]).max() < 1e-12 * np.abs(out[1]).max()
+
+
 @pytest.mark.parametrize("name,ng,nsteps", [("tgv_ppp", (32, 24, 16), 5), ("chan_smag_wm", (32, 16, 16), 5), ("chan_dsmag", (32, 16, 16), 5),
                                             ("halfchan_imp1d", (16, 16, 16), 3), ("chan_smag", (24, 20, 12), 10),
                                             # tile kernels: partial tiles in x and y, several x tiles, k chunks, wall-modelled z faces
@@ -161,7 +183,7 @@ def test_time_steps_with_x_ghosts_kept(name, ng, nsteps, monkeypatch):
 
 
 _BOOL_SWITCHES = ["CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFOLDED_CORREC", "CALES_UNFOLDED_MOM", "CALES_LAZY_PROJECTION", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_KEEP_LAST_RHS",
-                  "CALES_GAUSSEL_MARCH", "CALES_DSMAG_XGHOSTS", "CALES_WIDE_OFFSETS",
+                  "CALES_GAUSSEL_MARCH", "CALES_NO_NYQUIST_PACKING", "CALES_DSMAG_XGHOSTS", "CALES_WIDE_OFFSETS",
                   "CALES_UNMERGED_BC", "CALES_XGHOSTS_IN_STEP",
                   "CALES_FFT_GENERIC", "CALES_HELMHOLTZ_Z_PER_COLUMN", "CALES_UNFUSED_IMP_RHS",
                   "CALES_DSMAG_REFERENCE_SEQUENCE", "CALES_SMAG_REFERENCE_SEQUENCE"]

@@ -9,7 +9,7 @@ from cales_amd.hotpath import HotPath, initflow
 from oracle.oracle import Oracle
 
 POOL = ["CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFOLDED_CORREC", "CALES_UNFOLDED_MOM", "CALES_LAZY_PROJECTION", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_KEEP_LAST_RHS", 
-        "CALES_GAUSSEL_MARCH", "CALES_DSMAG_XGHOSTS", "CALES_WIDE_OFFSETS", "CALES_UNMERGED_BC",
+        "CALES_GAUSSEL_MARCH", "CALES_NO_NYQUIST_PACKING", "CALES_DSMAG_XGHOSTS", "CALES_WIDE_OFFSETS", "CALES_UNMERGED_BC",
         "CALES_XGHOSTS_IN_STEP", "CALES_FFT_GENERIC",
         "CALES_HELMHOLTZ_Z_PER_COLUMN", "CALES_UNFUSED_IMP_RHS", "CALES_DSMAG_REFERENCE_SEQUENCE", "CALES_SMAG_REFERENCE_SEQUENCE"]
 NAMES = ["tgv_ppp", "chan_dsmag", "chan_dsmag_wm", "chan_smag_wm", "tgv_dsmag_ppp", "cavity_nnn", "duct_smag_wm_imp1d", "chan_smag", "duct_dsmag_wm", "duct_dsmag", "cavity_dsmag",
