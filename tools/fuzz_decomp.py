@@ -16,8 +16,11 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 20):
     P = int(rng.choice([2, 3, 4]))
     ng = (int(2 * rng.randint(4, 40)), int(2 * P * rng.randint(2, 8)), int(2 * rng.randint(5, 40)))
     if trial % 3 == 2: ng = (int(2 ** rng.randint(4, 8)),) + ng[1:]      # power-of-two rows (see fuzz_sizes.py)
+    if os.environ.get("FUZZ_POW2"):      # power-of-two rows AND y lines: radix-8 passes both ways; periodic x and y then pack the modes 0 and n1/2 (k_gaussel_nyq)
+        P = int(rng.choice([2, 4, 8]))
+        ng = (int(2 ** rng.randint(6, 9)), int(max(2 * P, 2 ** rng.randint(4, 8))), int(rng.choice([2 * rng.randint(5, 40), 2 * rng.randint(65, 300)])))
     if os.environ.get("FUZZ_SWITCHES"):      # three to five run-time switches at once (the single-rank run takes the same ones)
-        pool = ["CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFOLDED_CORREC", "CALES_UNFOLDED_MOM", "CALES_LAZY_PROJECTION", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_GAUSSEL_MARCH",
+        pool = ["CALES_UNFUSED_RK", "CALES_UNFUSED_CORREC", "CALES_UNFOLDED_CORREC", "CALES_UNFOLDED_MOM", "CALES_LAZY_PROJECTION", "CALES_UNFUSED_FORCING", "CALES_UNFUSED_FILLPS", "CALES_UNFUSED_MEAN", "CALES_GAUSSEL_MARCH", "CALES_NO_NYQUIST_PACKING",
                 "CALES_DSMAG_XGHOSTS", "CALES_WIDE_OFFSETS", "CALES_UNMERGED_BC", 
                 "CALES_XGHOSTS_IN_STEP", "CALES_FFT_GENERIC", "CALES_HELMHOLTZ_Z_PER_COLUMN", "CALES_UNFUSED_IMP_RHS", "CALES_OVERLAP",
                 "CALES_LOOPBACK_EVENTS", "CALES_DSMAG_REFERENCE_SEQUENCE", "CALES_SMAG_REFERENCE_SEQUENCE"]

@@ -20,6 +20,8 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
     name = names[trial % len(names)]
     ng = tuple(int(2 * rng.randint(2, 40)) for _ in range(2)) + (int(rng.randint(9, 80)),)      # ng(3) may be odd
     if trial % 3 == 2: ng = (int(2 ** rng.randint(4, 8)),) + ng[1:]      # power-of-two rows: the radix-8 x pass, fillps inside it, cales_step without x ghost updates
+    if os.environ.get("FUZZ_POW2"):      # power-of-two rows AND y lines (radix-8 passes both ways, the packed modes 0 and n1/2 with periodic x and y), every chunking of the z tile
+        ng = (int(2 ** rng.randint(6, 9)), int(2 ** rng.randint(4, 8)), int(rng.choice([rng.randint(9, 80), rng.randint(129, 600)])))
     if np.any(case_lwm(name)): ng = ng[:2] + (max(ng[2], 12),)
     if name.startswith("open:"):
         from tests.test_gpu_vs_oracle import OPEN_SETS, _open_case
