@@ -6,7 +6,7 @@
 #   4. two SQ passes (8 slots each): issue/wait/LDS cycles and instruction counts
 # Everything lands in gpurun_out/TAG_*; profiles/summarize.py condenses it into profiles/TAG_*.
 TAG=${1:-r02}; shift
-ARGS=${@:-"--steps 3 --warmup 1 --no-cpu"}
+ARGS=${@:-"--steps 3 --warmup 1 --no-cpu --configs none"}      # (the side configurations have tools/profile_configs.sh; with them in the trace the output exceeds what a gpurun call merges back)
 export TMPDIR=/tmp
 O=$PWD/gpurun_out
 mkdir -p $O
