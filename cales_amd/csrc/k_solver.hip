@@ -1068,6 +1068,14 @@ constexpr int gt_width(int, int) { return 16; }      // columns per tile: one 12
 #ifndef GT_TL
 #define GT_TL 1
 #endif
+// pitch of a tile column in LDS = 64 (M + 1) + GT_PAD doubles. The load / store phases touch eight columns x (two planes per 16-lane group of a ds_write_b64,
+// four per 32-lane group of a ds_read_b64; banks: doubles mod 16 / mod 32, MI355X_MICROARCH.md "LDS"): with a pitch = 4 (mod 16) the eight columns fell on two
+// bank offsets for the stores (4-way) and four for the loads (2-way); 9 (mod 16) puts two columns 2 (mod 16) / 18 (mod 32) doubles apart -- conflict-free stores,
+// one 2-way pair among the loads. Measured (round 6, z sweep per step): 512^3 1.667 -> 1.634 ms, 1024^3 13.36 -> 12.70, 256 x 128 x 128 0.130 -> 0.124
+// (pads 1 and 5 within noise of 9). The solve phase walks one column per wave with a lane pitch of M + 1 doubles (odd): conflict-free at any column pitch.
+#ifndef GT_PAD
+#define GT_PAD 9
+#endif
 template <int M, int NV, int PER>
 __global__ __launch_bounds__(64 * gt_width(M, NV) / NV, (PER ? 2 : M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_gaussel_tile(Geom g, int nz, int ndbl, real lscale, const real *__restrict__ abc,
                                                             const real *__restrict__ lamx, const real *__restrict__ lamy,
@@ -1075,7 +1083,7 @@ __global__ __launch_bounds__(64 * gt_width(M, NV) / NV, (PER ? 2 : M <= 8 ? 4 : 
                                                             const real *__restrict__ ra = nullptr, const real *__restrict__ rb_ = nullptr, const real *__restrict__ rc = nullptr) {
   extern __shared__ real shz[];
   const int nsys = PER ? nz - 1 : nz;      // rows of the tridiagonal system proper
-  constexpr int W = gt_width(M, NV), CP = M + 1, P = 64 * CP + 4, NT = 64 * W / NV;
+  constexpr int W = gt_width(M, NV), CP = M + 1, P = 64 * CP + GT_PAD, NT = 64 * W / NV;
   const int t = threadIdx.x;
   const int tile = blockIdx.x;
   const size_t base = (T.blocked ? T.segstride * blockIdx.y : g.ix(0, blockIdx.y + 1, 1)) + (size_t)W * tile;      // doubles from p
@@ -1281,7 +1289,7 @@ __global__ __launch_bounds__(256) void k_gaussel_nyq(Geom g, int nz, int N, int 
                                                      const real *__restrict__ lamy, real2 *__restrict__ p, int fixnull, Spec S,
                                                      const real *__restrict__ ra = nullptr, const real *__restrict__ rb_ = nullptr, const real *__restrict__ rc = nullptr) {
   extern __shared__ real shz[];
-  constexpr int NV = 1, PER = 0, CP = M + 1, P = 64 * CP + 4, NT = 256;
+  constexpr int NV = 1, PER = 0, CP = M + 1, P = 64 * CP + GT_PAD, NT = 256;
   constexpr bool TL = false;
   const real *tabl = nullptr;
   const int nsys = nz;
@@ -1426,7 +1434,7 @@ __global__ __launch_bounds__(256) void k_gaussel_nyq(Geom g, int nz, int N, int 
 }
 template <int M>
 static void launch_gaussel_nyq(cales_ctx *c, int nz, int N, int nh, real lscale, const real *da, const real *db, const real *dc, real2 *p, int fixnull, const Spec &S, const real *tab) {
-  constexpr int lds = 4 * (64 * (M + 1) + 4) * 8;
+  constexpr int lds = 4 * (64 * (M + 1) + GT_PAD) * 8;
   LAUNCH(c, (k_gaussel_nyq<M>), dim3(N / 2 + 1), dim3(256), lds, c->stream, c->g, nz, N, nh, lscale, tab, c->d_lamx, c->d_lamy, p, fixnull, S, da, db, dc);
 }
 // The same tile PERSISTENT over `tpb` neighbouring tiles of a segment, for nz = 1024 planes in chunks of sixteen (the 1024^3 cavity): the
@@ -1446,7 +1454,7 @@ __global__ __launch_bounds__(512, 2) void k_gaussel_tile_p(Geom g, int nz, int n
   extern __shared__ real shz[];
   constexpr int M = 16, PER = 0, CPW = NV == 1 ? 2 : 1;
   const int nsys = nz;
-  constexpr int W = gt_width(M, NV), CP = M + 1, P = 64 * CP + 4, NT = 512;
+  constexpr int W = gt_width(M, NV), CP = M + 1, P = 64 * CP + GT_PAD, NT = 512;
   static_assert(64 * W / (NV * CPW) == NT, "512 threads: sixteen columns, CPW column sets per wave");
   const int t = threadIdx.x;
   const size_t seg = T.blocked ? T.segstride * blockIdx.y : g.ix(0, blockIdx.y + 1, 1);      // doubles from p
@@ -1639,7 +1647,7 @@ __global__ __launch_bounds__(512, 2) void k_gaussel_tile_p(Geom g, int nz, int n
 template <int M, int NV, int PER = 0>
 static void launch_gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, real lscale, const real *da, const real *db, const real *dc,
                                 real *p, int fixnull, const TileMap &T, real *tab_of_caller = nullptr, bool tab_ready = false) {
-  constexpr int W = gt_width(M, NV), lds = W * (64 * (M + 1) + 4) * 8 + (GT_TL && M == 16 ? 2 * 64 * M * 8 : 0);
+  constexpr int W = gt_width(M, NV), lds = W * (64 * (M + 1) + GT_PAD) * 8 + (GT_TL && M == 16 ? 2 * 64 * M * 8 : 0);
   static bool once = false;
   if (!once) { HIPSOFT(c, hipFuncSetAttribute((const void *)k_gaussel_tile<M, NV, PER>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); once = true; }
   // (a failed allocation fails the context: launch_failed is sticky, op_solver's LAUNCHCHK returns it -- the z solve is never skipped silently)
@@ -1656,7 +1664,7 @@ static void launch_gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, real l
 // the persistent form (k_gaussel_tile_p): pressure operands only (their table is built once), tiles per block so that ~2048 blocks or more remain
 template <int NV>
 static void launch_gaussel_tile_p(cales_ctx *c, int nz, int ndbl, int nrow, real lscale, const real *da, const real *db, const real *dc, real *p, int fixnull, const TileMap &T) {
-  constexpr int M = 16, W = gt_width(M, NV), lds = W * (64 * (M + 1) + 4) * 8 + (GT_TL ? 2 * 64 * M * 8 : 0);
+  constexpr int M = 16, W = gt_width(M, NV), lds = W * (64 * (M + 1) + GT_PAD) * 8 + (GT_TL ? 2 * 64 * M * 8 : 0);
   static bool once = false;
   if (!once) { HIPSOFT(c, hipFuncSetAttribute((const void *)k_gaussel_tile_p<NV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); once = true; }
   if (!c->d_abct) { const hipError_t e = hipMalloc(&c->d_abct, 2 * 3 * 64 * 16 * sizeof(real)); if (e != hipSuccess) { c->d_abct = nullptr; launch_failed(c, "hipMalloc(tridiagonal coefficient table)", e); return; } }
