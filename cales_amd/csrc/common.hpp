@@ -461,11 +461,13 @@ constexpr int SMALL_KCH = 4;
 // strain-rate pass 1.48 -> 1.32 ms/step with 9 chunks of 57 planes (504 blocks, 1.97 rounds) instead of 16 of 32 (896 blocks, 3.5 rounds), the
 // dynamic model's last pass 1.39 -> 1.27 with 7 chunks instead of 16; the measured order of eight chunk lengths follows rounds x (planes + 3).
 // With many rounds (the 512^3 grid on one GPU: 6.5) the passes are bound by bandwidth, idle CUs of the last round leave theirs to the others and
-// the rule does not hold (measured: 13 full rounds 3 % SLOWER than 6.5) -- so: only below six rounds, chunk lengths from 16 planes.
+// the rule does not hold (measured: 13 full rounds 3 % SLOWER than 6.5) -- so: only below seven rounds, chunk lengths from 16 planes. (6.5 rounds, end of
+// round 6: one rank of four -- 16 chunks of 32 planes against 12 of 43 -- strain-rate pass 2.94 -> 2.74, last pass 2.60 -> 2.56, momentum 2.03 -> 1.91 ms/step,
+// every chunk length tried in the order of the product; the 512 x 256 x 256 duct momentum 2.52 -> 2.44; one rank of two -- 8 chunks of 64 against 6 of 86 -- equal.)
 static inline int balanced_kchunk(const cales_ctx *c, long nxy_blocks, int n3, int kch0, int kmax = 1 << 30) {
   const long ncu = c->ncu > 0 ? c->ncu : 256;
   const int nch0 = (n3 + kch0 - 1) / kch0;
-  if (nxy_blocks * nch0 >= 6 * ncu || c->fl.kchunk > 0 || c->fl.tile_min_blocks != 2048) return kch0;      // (switches that force chunking: the tests' business)
+  if (nxy_blocks * nch0 >= 7 * ncu || c->fl.kchunk > 0 || c->fl.tile_min_blocks != 2048) return kch0;      // (switches that force chunking: the tests' business)
   long best = -1; int bk = kch0;
   for (int nch = 1; nch <= 4 * nch0 + 4; ++nch) {
     const int kch = (n3 + nch - 1) / nch;
