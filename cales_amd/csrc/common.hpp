@@ -65,7 +65,7 @@ struct Comm {
 //               on the slab side peer = m/cw, on the mode-block side peer = (j-1)/n2l.
 struct Spec {
   int blocked, cw, n2l, n3;
-  int nyq = 0;      // periodic x: the two REAL modes 0 and n1/2 of a row share complex slot 0 (re, im) and the row has n1/2 complex slots -- whole 128-B lines (k_solver.hip, "Nyquist packing")
+  int nyq = 0;      // periodic x (periodic or Neumann y): the two REAL modes 0 and n1/2 of a row share complex slot 0 (re, im) and the row has n1/2 complex slots -- whole 128-B lines (k_solver.hip, "Nyquist packing")
   // slab side: global mode m, LOCAL row jl (1-based), plane k (1-based)
   __host__ __device__ inline size_t at_slab(const Geom &g, int m, int jl, int k) const {
     if (!blocked) return (g.ix(0, jl, k) >> 1) + (size_t)m;
@@ -103,7 +103,7 @@ struct Flags {
     dsmag_xghosts = getenv("CALES_DSMAG_XGHOSTS") != nullptr;
     smag_reference_sequence = getenv("CALES_SMAG_REFERENCE_SEQUENCE") != nullptr;
     gaussel_march = getenv("CALES_GAUSSEL_MARCH") != nullptr;
-    no_nyquist_packing = getenv("CALES_NO_NYQUIST_PACKING") != nullptr;      // periodic x and y: the real modes 0 and n1/2 in columns of their own (n1/2 + 1 mode columns) instead of sharing column 0
+    no_nyquist_packing = getenv("CALES_NO_NYQUIST_PACKING") != nullptr;      // periodic x, periodic or Neumann y: the real modes 0 and n1/2 in columns of their own (n1/2 + 1 mode columns) instead of sharing column 0
     fft_generic = getenv("CALES_FFT_GENERIC") != nullptr;
     xghosts_in_step = getenv("CALES_XGHOSTS_IN_STEP") != nullptr;      // keep the x ghost columns up to date after every operator of cales_step
     keep_null_mode = getenv("CALES_KEEP_NULL_MODE") != nullptr;

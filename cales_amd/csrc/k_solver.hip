@@ -1284,7 +1284,8 @@ __global__ __launch_bounds__(64 * gt_width(M, NV) / NV, (PER ? 2 : M <= 8 ? 4 : 
 // lambda_x(nh) (four real columns of a tile: the solve is the text of k_gaussel_tile<M, 1, 0>), and puts Z'(ky) = A' + i B', Z'(N-ky) = conj A' + i conj B'
 // back. One block per pair of rows, ky = 0 .. N/2 (ky = 0 and N/2 pair with themselves: A, B real there). 1 / (nh + 1) of the solve's work; the rank that
 // holds mode 0 runs it. Reference: the same equations as src/solver.f90:82-179 for the modes 0 and n1/2 (FFTW's half-complex r0 and r_{n/2}).
-template <int M>
+// Neumann y (HERM = 0; ducts): the y transform is real, so Re Z is the transform of mode 0 and Im Z that of mode n1/2, row by row -- no pairing, only the two eigenvalues.
+template <int M, int HERM>
 __global__ __launch_bounds__(256) void k_gaussel_nyq(Geom g, int nz, int N, int nh, real lscale, const real *__restrict__ abc, const real *__restrict__ lamx,
                                                      const real *__restrict__ lamy, real2 *__restrict__ p, int fixnull, Spec S,
                                                      const real *__restrict__ ra = nullptr, const real *__restrict__ rb_ = nullptr, const real *__restrict__ rc = nullptr) {
@@ -1293,19 +1294,23 @@ __global__ __launch_bounds__(256) void k_gaussel_nyq(Geom g, int nz, int N, int 
   constexpr bool TL = false;
   const real *tabl = nullptr;
   const int nsys = nz;
-  const int t = threadIdx.x, ky = blockIdx.x, kp = (N - ky) % N;
+  // HERM = 0 (Neumann y: a real transform, the real and the imaginary part of a column transform independently): Re = mode 0, Im = mode n1/2 of the same
+  // row, no pairing -- the block takes the rows 2 b and 2 b + 1, columns (Re, Im) of the one and of the other
+  const int t = threadIdx.x, ky = HERM ? blockIdx.x : 2 * blockIdx.x, kp = HERM ? (N - ky) % N : ky + 1;
   for (int k = t; k < 64 * M; k += NT) {
     real2 z1 = make_real2(0., 0.), z2 = z1;
     if (k < nz) { z1 = p[S.at_mode(g, 0, ky + 1, k + 1)]; z2 = p[S.at_mode(g, 0, kp + 1, k + 1)]; }
     const int o = k + k / M;
-    shz[0 * P + o] = 0.5 * (z1.x + z2.x); shz[1 * P + o] = 0.5 * (z1.y - z2.y);      // A = (Z(ky) + conj Z(N-ky)) / 2
-    shz[2 * P + o] = 0.5 * (z1.y + z2.y); shz[3 * P + o] = -0.5 * (z1.x - z2.x);     // B = (Z(ky) - conj Z(N-ky)) / (2 i)
+    if (HERM) {
+      shz[0 * P + o] = 0.5 * (z1.x + z2.x); shz[1 * P + o] = 0.5 * (z1.y - z2.y);      // A = (Z(ky) + conj Z(N-ky)) / 2
+      shz[2 * P + o] = 0.5 * (z1.y + z2.y); shz[3 * P + o] = -0.5 * (z1.x - z2.x);     // B = (Z(ky) - conj Z(N-ky)) / (2 i)
+    } else { shz[0 * P + o] = z1.x; shz[1 * P + o] = z1.y; shz[2 * P + o] = z2.x; shz[3 * P + o] = z2.y; }
   }
   __syncthreads();
   const int x = t >> 6, ch = t & 63;
   const bool colok = true;
   if (colok) {
-    const real lam = (lamx[x < 2 ? 0 : nh] + lamy[ky]) * lscale;
+    const real lam = HERM ? (lamx[x < 2 ? 0 : nh] + lamy[ky]) * lscale : (lamx[(x & 1) ? nh : 0] + lamy[x < 2 ? ky : kp]) * lscale;
     const bool nullc = fixnull && lam == 0.;      // singular mode: the member with p(nz) = 0, see k_gaussel_ri
     real *col = shz + x * P + ch * CP;
     const int k0 = ch * M;
@@ -1428,14 +1433,17 @@ __global__ __launch_bounds__(256) void k_gaussel_nyq(Geom g, int nz, int N, int 
   for (int k = t; k < nz; k += NT) {
     const int o = k + k / M;
     const real ar = shz[0 * P + o], ai = shz[1 * P + o], br = shz[2 * P + o], bi = shz[3 * P + o];
-    p[S.at_mode(g, 0, ky + 1, k + 1)] = make_real2(ar - bi, ai + br);      // A' + i B'
-    p[S.at_mode(g, 0, kp + 1, k + 1)] = make_real2(ar + bi, br - ai);      // conj A' + i conj B'
+    if (HERM) {
+      p[S.at_mode(g, 0, ky + 1, k + 1)] = make_real2(ar - bi, ai + br);      // A' + i B'
+      p[S.at_mode(g, 0, kp + 1, k + 1)] = make_real2(ar + bi, br - ai);      // conj A' + i conj B'
+    } else { p[S.at_mode(g, 0, ky + 1, k + 1)] = make_real2(ar, ai); p[S.at_mode(g, 0, kp + 1, k + 1)] = make_real2(br, bi); }
   }
 }
 template <int M>
 static void launch_gaussel_nyq(cales_ctx *c, int nz, int N, int nh, real lscale, const real *da, const real *db, const real *dc, real2 *p, int fixnull, const Spec &S, const real *tab) {
   constexpr int lds = 4 * (64 * (M + 1) + GT_PAD) * 8;
-  LAUNCH(c, (k_gaussel_nyq<M>), dim3(N / 2 + 1), dim3(256), lds, c->stream, c->g, nz, N, nh, lscale, tab, c->d_lamx, c->d_lamy, p, fixnull, S, da, db, dc);
+  if (c->ykind == 0) LAUNCH(c, (k_gaussel_nyq<M, 1>), dim3(N / 2 + 1), dim3(256), lds, c->stream, c->g, nz, N, nh, lscale, tab, c->d_lamx, c->d_lamy, p, fixnull, S, da, db, dc);
+  else LAUNCH(c, (k_gaussel_nyq<M, 0>), dim3(N / 2), dim3(256), lds, c->stream, c->g, nz, N, nh, lscale, tab, c->d_lamx, c->d_lamy, p, fixnull, S, da, db, dc);
 }
 // The same tile PERSISTENT over `tpb` neighbouring tiles of a segment, for nz = 1024 planes in chunks of sixteen (the 1024^3 cavity): the
 // classic form holds one block of 1024 threads and 140 KB of LDS per CU, so the load of a tile, its solve and its store run one after the other (5.6 ms
@@ -1881,10 +1889,10 @@ int solver_setup(cales_ctx *c) {
   // on the links -- not padded there.
   if (c->P > 1) { const int cw8 = (c->cw + 7) / 8 * 8; if (100 * (cw8 - c->cw) <= 6 * c->cw && (size_t)cw8 * n2g * n3 <= c->ntot) c->cw = cw8; }
   if (c->P > 1 && (size_t)c->cw * n2g * n3 > c->ntot) { c->err = "solver: scratch too small for the mode-block layout"; return 1; }
-  // Nyquist packing of the pressure solve (k_gaussel_nyq): periodic x AND y (the Hermitian pairing of rows needs the complex y transform), radix-8 passes,
-  // the z solve in the LDS tile; n1/2 mode columns instead of n1/2 + 1
+  // Nyquist packing of the pressure solve (k_gaussel_nyq): periodic x, periodic or Neumann y (the pair is separated by the Hermitian pairing of rows / by real and
+  // imaginary part), radix-8 passes, the z solve in the LDS tile; n1/2 mode columns instead of n1/2 + 1
   { const bool pz = CBP(c, 0, 3) == 'P' && CBP(c, 1, 3) == 'P', hasd = CBP(c, 0, 3) == 'D' || CBP(c, 1, 3) == 'D';
-    c->nyq_ok = c->xkind == 0 && c->ykind == 0 && sp.x8 && sp.y8 && !pz && (hasd || !c->fl.keep_null_mode) && n3 >= 2 && n3 <= 1024 && !c->fl.gaussel_march && !c->fl.no_nyquist_packing;
+    c->nyq_ok = c->xkind == 0 && c->ykind <= 1 && sp.x8 && sp.y8 && !pz && (hasd || !c->fl.keep_null_mode) && n3 >= 2 && n3 <= 1024 && !c->fl.gaussel_march && !c->fl.no_nyquist_packing;
     c->cw_nyq = (n1 / 2 + c->P - 1) / c->P; }
   HIPCHK(c, hipMalloc(&c->d_lamx, (n1 + 2) * sizeof(real))); HIPCHK(c, hipMalloc(&c->d_lamy, n2g * sizeof(real)));
   HIPCHK(c, hipMemcpy(c->d_lamx, lx.data(), (n1 + 2) * sizeof(real), hipMemcpyHostToDevice));
@@ -2010,7 +2018,7 @@ static int solve_field(cales_ctx *c, real *pp, const real *da, const real *db, c
   const bool use8x = sp->x8 && c->xkind <= 1, use8y = sp->y8 && c->ykind <= 1;
   const VelSet *VS = static_cast<const VelSet *>(c->cur_velset);      // transform set of the velocity component being solved (nullptr: the pressure's)
   if (dist && !c->comm.on) { c->err = "solver: nranks > 1 but no communication hooks registered (cales_set_comm)"; return 1; }
-  const bool nyq = poisson && !VS && c->nyq_ok && c->xkind == 0 && c->ykind == 0;
+  const bool nyq = poisson && !VS && c->nyq_ok && c->xkind == 0 && c->ykind <= 1;
   const int cw = nyq ? c->cw_nyq : c->cw, nmodes = nyq ? n[0] / 2 : mh;      // complex mode columns: per rank, in all
   Spec S; S.blocked = dist ? 1 : 0; S.cw = cw; S.n2l = n[1]; S.n3 = n[2]; S.nyq = nyq ? 1 : 0;
   real2 *slab_spec = dist ? reinterpret_cast<real2 *>(c->comm.A) : reinterpret_cast<real2 *>(pp + 1);   // in place: modes of row (j,k) from i = 1

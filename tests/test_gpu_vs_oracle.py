@@ -76,10 +76,12 @@ def test_tridiagonal_paths_agree(name, ng, monkeypatch):
 
 
 @pytest.mark.parametrize("name,ng", [("chan_smag", (64, 16, 6)), ("chan_smag", (64, 32, 100)), ("chan_dsmag", (128, 64, 130)), ("chan_smag", (64, 16, 300)), ("chan_smag", (64, 16, 512)),
-                                     ("chan_smag", (128, 16, 700)), ("chan_smag", (64, 16, 1024)), ("chan_smag", (512, 1024, 4)), ("halfchan_imp1d", (64, 64, 40))])
+                                     ("chan_smag", (128, 16, 700)), ("chan_smag", (64, 16, 1024)), ("chan_smag", (512, 1024, 4)), ("halfchan_imp1d", (64, 64, 40)),
+                                     # Neumann y (ducts): no pairing of rows, Re = mode 0 and Im = mode n1/2; the staged y kernel (32, 128 points) and k_fft_y16 (256)
+                                     ("duct_smag_wm", (64, 32, 40)), ("duct_dsmag", (128, 128, 130)), ("duct_smag_wm", (128, 256, 24)), ("duct_dsmag_wm", (64, 16, 300))])
 def test_nyquist_packing_agrees(name, ng, monkeypatch):
-    """periodic x and y: the real x modes 0 and n1/2 sharing column 0 of the spectrum (default; k_gaussel_nyq separates them in the z solve by the Hermitian
-    pairing of the y rows) against columns of their own (CALES_NO_NYQUIST_PACKING) -- every chunking of the z tile, y lines of every first radix"""
+    """periodic x, periodic or Neumann y: the real x modes 0 and n1/2 sharing column 0 of the spectrum (default; k_gaussel_nyq separates them in the z solve by the
+    Hermitian pairing of the y rows / by real and imaginary part) against columns of their own (CALES_NO_NYQUIST_PACKING) -- every chunking of the z tile, y lines of every first radix"""
     g, case = load_golden(name)
     case.ng[:] = ng
     rng = np.random.RandomState(11)

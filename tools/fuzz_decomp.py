@@ -45,6 +45,8 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 20):
     try:
         res = run_loopback(case, P, body)
     except Exception as e:
+        if "sanity.f90" in str(e):      # a case the reference itself refuses on this grid / rank count
+            print("SKIP", name, ng, P, str(e)[:100]); continue
         print("BAD", name, ng, P, "loopback failed:", str(e)[:100]); bad += 1; continue
     worst = 0.
     for r, (ur, vr, wr, pr, visr, lo, n) in enumerate(res):
