@@ -1076,7 +1076,7 @@ constexpr int gt_width(int, int) { return 16; }      // columns per tile: one 12
 #ifndef GT_PAD
 #define GT_PAD 9
 #endif
-template <int M, int NV, int PER>
+template <int M, int NV, int PER, int DUD = 0>      // DUD = 1: the z-only Helmholtz sweeps (TileMap::dud), which form their right-hand side while loading -- an instantiation of their own, the pressure solve carries none of it
 __global__ __launch_bounds__(64 * gt_width(M, NV) / NV, (PER ? 2 : M <= 8 ? 4 : NV == 1 ? 4 : 2)) void k_gaussel_tile(Geom g, int nz, int ndbl, real lscale, const real *__restrict__ abc,
                                                             const real *__restrict__ lamx, const real *__restrict__ lamy,
                                                             real *__restrict__ p, int fixnull, TileMap T,
@@ -1105,21 +1105,39 @@ __global__ __launch_bounds__(64 * gt_width(M, NV) / NV, (PER ? 2 : M <= 8 ? 4 : 
       const int k = kk + KP2 * q;
       v[q] = (ok && k < nz) ? *reinterpret_cast<const real2 *>(p + base + x + (size_t)k * kst) : make_real2(0., 0.);
     }
-    if (NV == 2 && T.dud) {      // (the z-only Helmholtz sweeps come as pairs of real columns that share the matrix: NV = 2 only)
+    if (NV == 2 && DUD) {      // (the z-only Helmholtz sweeps come as pairs of real columns that share the matrix: NV = 2 only)
       const real f = T.force ? T.force[0] : 0.;
-      const int bi = W * tile + x + 1, bj = (int)blockIdx.y + 1;      // column (i, j) of the pair's first member
+      const int bi = ok ? W * tile + x + 1 : 1, bj = (int)blockIdx.y + 1;      // column (i, j) of the pair's first member
+      // every load of this part unconditional, from a place that exists (plane 1 of the pair) where the lane has none, the selection afterwards: inside the
+      // divergent branches they used to sit in, each was waited for on the spot -- 4 + 2 + 2 serial round trips per block (tools/memseq.py: L w0 L w0 ...)
+      const size_t osafe = base + (ok ? x : 0);
+      real2 dd[NQ2], ex[NQ2];
 #pragma unroll
       for (int q = 0; q < NQ2; ++q) {
         const int k = kk + KP2 * q;
-        if (ok && k < T.nq) {
-          const size_t o = base + x + (size_t)k * kst;
-          const real2 own = k < nz ? v[q] : *reinterpret_cast<const real2 *>(p + o), dd = *reinterpret_cast<const real2 *>(T.dud + o);
-          real2 t = make_real2(own.x - T.hf12 * dd.x, own.y - T.hf12 * dd.y);
-          if (T.force) { t.x = t.x + f; t.y = t.y + f; }
-          if (k == 0 && T.has_lo) { t.x = t.x + T.blo.at(bi, bj, g.n1); t.y = t.y + T.blo.at(bi + 1, bj, g.n1); }
-          if (k == nz - 1 && T.has_hi) { t.x = t.x + T.bhi.at(bi, bj, g.n1); t.y = t.y + T.bhi.at(bi + 1, bj, g.n1); }
-          if (k < nz) v[q] = t; else *reinterpret_cast<real2 *>(p + o) = t;
+        dd[q] = *reinterpret_cast<const real2 *>(T.dud + ((ok && k < T.nq) ? base + x + (size_t)k * kst : osafe));
+      }
+      if (T.nq > nz) {      // (the wall face of w: its plane lies outside the system and only receives the explicit terms)
+#pragma unroll
+        for (int q = 0; q < NQ2; ++q) {
+          const int k = kk + KP2 * q;
+          ex[q] = *reinterpret_cast<const real2 *>(p + ((ok && k >= nz && k < T.nq) ? base + x + (size_t)k * kst : osafe));
         }
+      }
+      real2 lo = make_real2(0., 0.), hi = lo;
+      if (T.has_lo) lo = make_real2(T.blo.at(bi, bj, g.n1), T.blo.at(bi + 1, bj, g.n1));
+      if (T.has_hi) hi = make_real2(T.bhi.at(bi, bj, g.n1), T.bhi.at(bi + 1, bj, g.n1));
+#pragma unroll
+      for (int q = 0; q < NQ2; ++q) {
+        const int k = kk + KP2 * q;
+        const bool in = ok && k < T.nq;
+        const real2 own = k < nz ? v[q] : ex[q];
+        real2 t = make_real2(own.x - T.hf12 * dd[q].x, own.y - T.hf12 * dd[q].y);
+        if (T.force) { t.x = t.x + f; t.y = t.y + f; }
+        if (k == 0) { t.x = t.x + lo.x; t.y = t.y + lo.y; }
+        if (k == nz - 1) { t.x = t.x + hi.x; t.y = t.y + hi.y; }
+        if (in && k < nz) v[q] = t;
+        if (in && k >= nz) *reinterpret_cast<real2 *>(p + base + x + (size_t)k * kst) = t;
       }
     }
 #pragma unroll
@@ -1657,7 +1675,11 @@ static void launch_gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, real l
                                 real *p, int fixnull, const TileMap &T, real *tab_of_caller = nullptr, bool tab_ready = false) {
   constexpr int W = gt_width(M, NV), lds = W * (64 * (M + 1) + GT_PAD) * 8 + (GT_TL && M == 16 ? 2 * 64 * M * 8 : 0);
   static bool once = false;
-  if (!once) { HIPSOFT(c, hipFuncSetAttribute((const void *)k_gaussel_tile<M, NV, PER>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); once = true; }
+  if (!once) {
+    HIPSOFT(c, hipFuncSetAttribute((const void *)k_gaussel_tile<M, NV, PER>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if constexpr (NV == 2 && PER == 0) HIPSOFT(c, hipFuncSetAttribute((const void *)k_gaussel_tile<M, NV, PER, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    once = true;
+  }
   // (a failed allocation fails the context: launch_failed is sticky, op_solver's LAUNCHCHK returns it -- the z solve is never skipped silently)
   if (!c->d_abct) { const hipError_t e = hipMalloc(&c->d_abct, 2 * 3 * 64 * 16 * sizeof(real)); if (e != hipSuccess) { c->d_abct = nullptr; launch_failed(c, "hipMalloc(tridiagonal coefficient table)", e); return; } }
   // the pressure operands never change: their table is built once (Helmholtz operands are rescaled every substep -> second table)
@@ -1666,6 +1688,10 @@ static void launch_gaussel_tile(cales_ctx *c, int nz, int ndbl, int nrow, real l
   // (periodic z: the table holds the n-1 rows of the system proper; identity rows from row n on)
   if (tab_of_caller ? !tab_ready : (!pressure || !c->abct_ready)) LAUNCH(c, k_abc_chunked, dim3((64 * M + 255) / 256), dim3(256), 0, c->stream, PER ? nz - 1 : nz, M, da, db, dc, tab);
   if (pressure && !tab_of_caller) c->abct_ready = true;
+  if constexpr (NV == 2 && PER == 0) {
+    if (T.dud) { LAUNCH(c, (k_gaussel_tile<M, NV, PER, 1>), dim3((ndbl + W - 1) / W, nrow), dim3(64 * W / NV), lds, c->stream, c->g, nz, ndbl, lscale, tab, c->d_lamx, c->d_lamy, p, fixnull, T, da, db, dc); return; }
+  }
+  if (T.dud) { launch_failed(c, "k_gaussel_tile: the Helmholtz form exists for pairs of real columns and non-periodic z only", hipErrorInvalidValue); return; }
   LAUNCH(c, (k_gaussel_tile<M, NV, PER>), dim3((ndbl + W - 1) / W, nrow), dim3(64 * W / NV), lds, c->stream, c->g, nz, ndbl, lscale, tab,
                      c->d_lamx, c->d_lamy, p, fixnull, T, da, db, dc);
 }
